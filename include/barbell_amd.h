@@ -1,0 +1,151 @@
+/*
+ * barbell_amd.h — C-ABI of the MI355X-native Barbell annotate hot path.
+ *
+ * This is the drop-in boundary for ONE path of rickbeeloo/barbell: the per-read match loop
+ * `Demuxer::demux` (reference src/annotate/searcher.rs:430-490) together with its constructor
+ * (`Demuxer::new` :202-217, `add_query_group` :220-226) and the one-time query preparation
+ * (`BarcodeGroup::new`, src/annotate/barcodes.rs:105-197).  The reference has no FFI of its own;
+ * the narrowest seam is `DemuxProcessor::process_record` -> `Demuxer::demux`
+ * (src/annotate/annotator.rs:123-135).  A per-read call is the wrong granularity for a GPU, so the
+ * boundary is per BATCH and maps 1:1 onto paraseq's hooks: `process_record` appends the read to a
+ * staging buffer, `on_batch_complete` (annotator.rs:137-139) makes one `bb_annotate_batch` call and
+ * turns the returned rows into `BarbellMatch` values for the existing `write_annotation_batch`
+ * (annotator.rs:13-26).  INTEGRATION.md shows that Rust-side stub.
+ *
+ * Conventions: plain C, caller owns every buffer, nothing throws across the boundary, every
+ * reference `panic!` on this path becomes a negative error code.  Strings never cross: the caller
+ * maps `read_idx` back to its read id and `barcode_idx` back to its label.  All entry points need
+ * a gfx950 GPU; there is no CPU fallback in this library (the CPU restatement lives in oracle/ and
+ * is test infrastructure only).
+ */
+#ifndef BARBELL_AMD_H
+#define BARBELL_AMD_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- error codes (negative; 0 = ok) ------------------------------------------------------- */
+#define BB_OK               0
+#define BB_E_INVALID       -1  /* null pointer / bad argument                                        */
+#define BB_E_ONE_QUERY     -2  /* group with a single query sequence (barcodes.rs:113-117 panic)     */
+#define BB_E_UNEQUAL_LEN   -3  /* sequences of a group differ in length (barcodes.rs:325-328)        */
+#define BB_E_NO_BARCODE    -4  /* prefix+suffix cover the whole sequence (barcodes.rs:124-128)       */
+#define BB_E_NO_FLANK      -5  /* neither shared prefix nor suffix (barcodes.rs:131-133)             */
+#define BB_E_NOT_IUPAC     -6  /* non-IUPAC character in a query (barcodes.rs:45-47)                 */
+#define BB_E_CAPACITY      -7  /* caller's row buffer too small; *n_rows holds the required count    */
+#define BB_E_NO_DEVICE     -8  /* no gfx950 device / HIP runtime failure at create                   */
+#define BB_E_HIP           -9  /* HIP runtime error during a batch (see bb_last_error)               */
+#define BB_E_UNSUPPORTED  -10  /* geometry outside what the kernels were built for (see bb_limits)   */
+#define BB_E_NOMEM        -11
+
+/* ---- match_type / strand encodings (searcher.rs:31-75, barcodes.rs:8-33) ------------------ */
+#define BB_FTAG   0
+#define BB_RTAG   1
+#define BB_FFLANK 2
+#define BB_RFLANK 3
+#define BB_FWD    0
+#define BB_RC     1
+
+/* One query group = one `BarcodeGroup` (barcodes.rs:57-72): N equally long sequences
+ * <shared prefix><barcode><shared suffix>.  `flank_k` is `--flank-max-errors`
+ * (bin/main.rs:90-91); a negative value selects the automatic cutoff
+ * `get_edit_cut_off(prefix_len + suffix_len)` (edit_model.rs:2-11, annotator.rs:219-226).      */
+typedef struct {
+    const uint8_t* const* seqs;      /* n_seqs pointers, ASCII IUPAC                              */
+    const uint32_t*       seq_lens;  /* n_seqs lengths; must all be equal (barcodes.rs:325-328)   */
+    uint32_t              n_seqs;
+    uint8_t               type;      /* BB_FTAG or BB_RTAG                                        */
+    int32_t               flank_k;   /* <0 = auto                                                 */
+} bb_group_desc;
+
+/* `Demuxer::new(alpha, verbose, min_score_frac, min_score_diff_frac)` (searcher.rs:202) with the
+ * CLI defaults of bin/main.rs:98-111: alpha 0.4, min_score 0.2, min_score_diff 0.1.            */
+typedef struct {
+    float   alpha;
+    double  min_score;
+    double  min_score_diff;
+    int32_t device;                  /* HIP device ordinal                                        */
+} bb_params;
+
+/* One `BarbellMatch` (searcher.rs:31-64) without its strings.  48 bytes, POD.                  */
+typedef struct {
+    uint32_t read_idx;               /* index of the read inside the batch                        */
+    uint32_t read_len;
+    int32_t  rel_dist_to_end;        /* searcher.rs:183-199                                       */
+    uint32_t read_start_bar, read_end_bar;
+    uint32_t read_start_flank, read_end_flank;
+    uint32_t bar_start, bar_end;
+    int16_t  flank_cost, barcode_cost;
+    int16_t  barcode_idx;            /* index into the group's sequences; -1 = label "flank"      */
+    uint8_t  group_idx;
+    uint8_t  match_type;             /* BB_FTAG / BB_RTAG / BB_FFLANK / BB_RFLANK                 */
+    uint8_t  strand;                 /* BB_FWD / BB_RC                                            */
+    uint8_t  _pad[3];
+} bb_row;
+
+/* Geometry of a prepared group, for callers that want to display it like
+ * `BarcodeGroup::display` (barcodes.rs:199-248) or test it like barcodes.rs:488-546.           */
+typedef struct {
+    uint32_t flank_len, prefix_len, suffix_len, mask_len;
+    uint32_t bar_lo, bar_hi;         /* bar_region, inclusive end (barcodes.rs:192)               */
+    uint32_t pad_lo, pad_hi;         /* pad_region, pad_hi unclamped (barcodes.rs:160-163)        */
+    uint32_t pattern_len;            /* length of the padded barcode patterns                     */
+    int32_t  flank_k;                /* resolved flank cutoff                                     */
+    int32_t  bar_k1, bar_k2;         /* barcode cutoffs of the two passes (searcher.rs:458-460)   */
+    double   perfect_score;          /* searcher.rs:229-239                                       */
+} bb_group_info;
+
+typedef struct bb_ctx bb_ctx;        /* opaque; one per host thread / GPU stream; NOT thread-safe */
+
+/* Replaces Demuxer::new + add_query_group + BarcodeGroup::new.  Returns BB_OK or an error code. */
+int bb_create(const bb_group_desc* groups, uint32_t n_groups, const bb_params* params, bb_ctx** out);
+void bb_destroy(bb_ctx* ctx);
+
+int bb_n_groups(const bb_ctx* ctx);
+int bb_group_get_info(const bb_ctx* ctx, uint32_t group, bb_group_info* info);
+/* copies the N-masked flank (flank_len bytes) / one padded pattern (pattern_len bytes) */
+int bb_group_get_flank(const bb_ctx* ctx, uint32_t group, uint8_t* out);
+int bb_group_get_pattern(const bb_ctx* ctx, uint32_t group, uint32_t idx, int rc, uint8_t* out);
+
+/* Replaces the per-read loop `for record in batch { demuxer.demux(id, seq) }`
+ * (annotator.rs:123-135).  `bases` = concatenated read sequences exactly as they appear in the
+ * FASTQ (no normalisation, annotator.rs:126-127), `offsets` = n_reads+1 byte offsets.
+ * Rows come back ordered by (read_idx, read_start_flank) — within a read that is the order
+ * `collapse_overlapping_matches` returns (interval.rs:12,27) — so the TSV is deterministic.
+ * Host-pointer variant: copies the batch to the GPU and the rows back.                         */
+int bb_annotate_batch(bb_ctx* ctx, const uint8_t* bases, const uint64_t* offsets, uint32_t n_reads,
+                      bb_row* rows, uint64_t rows_cap, uint64_t* n_rows);
+
+/* Device-pointer variant: `d_bases`, `d_offsets` and `d_rows` are HIP device pointers on the
+ * context's device.  The call enqueues on the context's stream and returns after the row count is
+ * known (one small D2H of 8 bytes); rows stay in HBM.                                          */
+int bb_annotate_batch_dev(bb_ctx* ctx, const uint8_t* d_bases, const uint64_t* d_offsets,
+                          uint32_t n_reads, bb_row* d_rows, uint64_t rows_cap, uint64_t* n_rows);
+
+/* Histogram of emitted rows per (group, barcode): for each group n_seqs tag counters followed by
+ * one flank-only counter; groups concatenated.  Accumulates over batches until bb_counts_reset.
+ * `bb_counts_dev` returns the device pointer (uint64, bb_counts_len entries) so a multi-GPU
+ * driver can all-reduce it with RCCL without a host round trip.                                */
+uint32_t  bb_counts_len(const bb_ctx* ctx);
+int       bb_counts(bb_ctx* ctx, uint64_t* out);
+uint64_t* bb_counts_dev(bb_ctx* ctx);
+int       bb_counts_reset(bb_ctx* ctx);
+
+/* Timing of the last batch: per-kernel device time in ms measured with HIP events on the
+ * context's stream (k = 0..bb_n_kernels()-1), and its name.                                    */
+int         bb_n_kernels(void);
+const char* bb_kernel_name(int k);
+float       bb_last_kernel_ms(const bb_ctx* ctx, int k);
+void        bb_set_timing(bb_ctx* ctx, int enable);
+
+const char* bb_strerror(int code);
+const char* bb_last_error(const bb_ctx* ctx);   /* detail of the last BB_E_HIP / BB_E_UNSUPPORTED */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BARBELL_AMD_H */

@@ -1,0 +1,668 @@
+/*
+ * bb_oracle.c — CPU restatement of Barbell's annotate hot path (Demuxer::demux and everything
+ * under it).  TEST INFRASTRUCTURE: the checker for the HIP path, never the thing shipped.
+ *
+ * PINNING STATUS: "parity unpinned" beyond the reference's own known-answer tests.
+ *   The first-party logic (searcher.rs, cigar_parse.rs, interval.rs, barcodes.rs, edit_model.rs)
+ *   is restated line by line below with file:line citations.  The arithmetic underneath it lives
+ *   in third-party crates that are NOT in /root/reference and cannot be fetched or built here
+ *   (no cargo/rustc, no network):
+ *       sassy 0.2.1          (Cargo.lock:1060-1079)  Searcher::search / search_encoded_patterns
+ *       cigar-lodhi-rs 0.1.0 (Cargo.lock:242-248)    Lodhi::new(3, 0.5).compute(&Cigar)
+ *       pa-types 1.2.0       (Cargo.lock:764-772)    Cigar / CigarOp / Pos
+ *   Their published behaviour is restated in the functions tagged [H1]..[H9] (hazard numbers of
+ *   SURVEY.md §8c).  These are pinned ONLY by the five sassy known-answer tests of
+ *   src/annotate/cigar_parse.rs:104-176 (tests/test_oracle_kat.py) plus what Barbell's own code
+ *   lets one deduce.  Every tie-break that those do not pin is a documented
+ *   assumption; the HIP path must be bit-identical to THIS file.
+ *
+ * Published algorithm being restated (sassy): semi-global unit-cost edit distance of a pattern
+ * against every end position of a text (pattern global, text local: D[0][i] = 0, D[j][0] = j),
+ * IUPAC matching (two characters match iff their base sets intersect), reverse complement handled
+ * by searching complement(pattern) in reversed(text), optional overhang: pattern characters that
+ * fall outside the text cost alpha each (rounded down), matches reported at local minima of the
+ * end-position cost that are <= k, each with a traceback (CIGAR).
+ */
+#include "bb_oracle.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define PADDING 10 /* src/lib.rs:10 */
+
+static int g_full_trace = 0;
+void bbo_set_full_trace(int on) { g_full_trace = on; }
+
+/* ------------------------------------------------------------------------------------------ */
+/* [H6] IUPAC profile.  4-bit base sets A=1 C=2 G=4 T=8; case-insensitive; X = empty set;      */
+/* anything that is not an IUPAC letter is invalid (0xFF) for queries (barcodes.rs:45-47) and  */
+/* matches nothing when it appears in a read.                                                  */
+/* ------------------------------------------------------------------------------------------ */
+uint8_t bbo_iupac_code(uint8_t c) {
+    switch (c) {
+        case 'A': case 'a': return 1;
+        case 'C': case 'c': return 2;
+        case 'G': case 'g': return 4;
+        case 'T': case 't': case 'U': case 'u': return 8;
+        case 'R': case 'r': return 1 | 4;
+        case 'Y': case 'y': return 2 | 8;
+        case 'S': case 's': return 4 | 2;
+        case 'W': case 'w': return 1 | 8;
+        case 'K': case 'k': return 4 | 8;
+        case 'M': case 'm': return 1 | 2;
+        case 'B': case 'b': return 2 | 4 | 8;
+        case 'D': case 'd': return 1 | 4 | 8;
+        case 'H': case 'h': return 1 | 2 | 8;
+        case 'V': case 'v': return 1 | 2 | 4;
+        case 'N': case 'n': return 15;
+        case 'X': case 'x': return 0;
+        default: return 0xFF;
+    }
+}
+static inline uint8_t text_code(uint8_t c) {
+    uint8_t k = bbo_iupac_code(c);
+    return k == 0xFF ? 0 : k;
+}
+/* complement of a base set: A<->T, C<->G */
+static inline uint8_t comp_code(uint8_t k) {
+    return (uint8_t)(((k & 1) << 3) | ((k & 8) >> 3) | ((k & 2) << 1) | ((k & 4) >> 1));
+}
+/* barcodes.rs:394-441 RC table: complement that keeps case and IUPAC codes */
+static uint8_t rc_char(uint8_t c) {
+    static const char from[] = "ACTGactgRYSWKMBDHVNXryswkmbdhvnx";
+    static const char to[]   = "TGACtgacYRSWMKVHDBNXyrswmkvhdbnx";
+    for (int i = 0; from[i]; ++i)
+        if ((uint8_t)from[i] == c) return (uint8_t)to[i];
+    return c;
+}
+
+/* [H4] overhang cost of `len` pattern characters outside the text: floor(alpha * len) in f32 */
+static inline int overhang_cost(float alpha, int len) { return (int)floorf((float)len * alpha); }
+
+/* ------------------------------------------------------------------------------------------ */
+/* DP primitives                                                                               */
+/* ------------------------------------------------------------------------------------------ */
+/* advance one text column in place: col[j] = D[j][i-1] -> D[j][i]; col[0] stays 0 */
+static void dp_column(const uint8_t* pcode, int m, uint8_t tcode, int32_t* col) {
+    int32_t diag = col[0];
+    for (int j = 1; j <= m; ++j) {
+        int32_t left = col[j];
+        int32_t best = diag + ((pcode[j - 1] & tcode) ? 0 : 1);
+        if (left + 1 < best) best = left + 1;
+        if (col[j - 1] + 1 < best) best = col[j - 1] + 1;
+        diag = left;
+        col[j] = best;
+    }
+}
+
+typedef struct { int32_t e, cost; } end_hit;
+typedef struct { end_hit* v; int n, cap; } end_list;
+static void end_push(end_list* l, int e, int cost) {
+    if (l->n == l->cap) { l->cap = l->cap ? 2 * l->cap : 8; l->v = (end_hit*)realloc(l->v, sizeof(end_hit) * (size_t)l->cap); }
+    l->v[l->n].e = e; l->v[l->n].cost = cost; l->n++;
+}
+
+/*
+ * [H1] local-minimum rule.  C[0..imax] is the cost of the best match ENDING at position i
+ * (i characters of the text consumed).  A position is reported when the cost sequence stops
+ * decreasing there: state `decreasing` becomes true on a strict decrease, false on a strict
+ * increase, is unchanged on a plateau; on a strict increase the PREVIOUS position is reported if
+ * `decreasing` and its cost <= k (so a plateau is reported at its right end); at the end of the
+ * sequence the last position is reported under the same condition.  `decreasing` starts true.
+ * This streaming form is what the scan kernels implement.
+ */
+typedef struct { int decreasing; int32_t prev; int started; } lm_state;
+static inline void lm_step(lm_state* s, int idx, int32_t cur, int k, end_list* out) {
+    if (!s->started) { s->started = 1; s->decreasing = 1; s->prev = cur; return; }
+    if (cur > s->prev) {
+        if (s->decreasing && s->prev <= k) end_push(out, idx - 1, s->prev);
+        s->decreasing = 0;
+    } else if (cur < s->prev) {
+        s->decreasing = 1;
+    }
+    s->prev = cur;
+}
+static inline void lm_finish(lm_state* s, int last_idx, int k, end_list* out) {
+    if (s->started && s->decreasing && s->prev <= k) end_push(out, last_idx, s->prev);
+}
+
+/*
+ * One strand of Searcher::search.  pcode: pattern base sets (m), tcode: text base sets in scan
+ * direction (n).  alpha < 0: no overhang (D[j][0] = j, ends 0..n).  alpha >= 0 [H4]:
+ *   left : D[j][0] = floor(alpha*j)           (pattern prefix of length j before the text)
+ *   right: C[n+o] = D[m-o][n] + floor(alpha*o), o = 1..m (pattern suffix of length o after it)
+ */
+static void scan_strand(const uint8_t* pcode, int m, const uint8_t* tcode, int n, int k, float alpha,
+                        end_list* out) {
+    int32_t* col = (int32_t*)malloc(sizeof(int32_t) * (size_t)(m + 1));
+    for (int j = 0; j <= m; ++j) col[j] = alpha >= 0.f ? overhang_cost(alpha, j) : j;
+    lm_state st = {0, 0, 0};
+    lm_step(&st, 0, col[m], k, out);
+    for (int i = 1; i <= n; ++i) {
+        dp_column(pcode, m, tcode[i - 1], col);
+        lm_step(&st, i, col[m], k, out);
+    }
+    int last = n;
+    if (alpha >= 0.f) {
+        for (int o = 1; o <= m; ++o) lm_step(&st, n + o, col[m - o] + overhang_cost(alpha, o), k, out);
+        last = n + m;
+    }
+    lm_finish(&st, last, k, out);
+    free(col);
+}
+
+/*
+ * [H3] traceback (sassy get_trace restated).  Walk from the end cell back to row 0, preferring, at
+ * cell (j,i) with cost g:  (1) diagonal Match if D[j-1][i-1]==g and the characters match,
+ * (2) Ins  (text char only)   if D[j][i-1]   == g-1,
+ * (3) Sub  (diagonal)         if D[j-1][i-1] == g-1,
+ * (4) Del  (pattern char only) if D[j-1][i]  == g-1.
+ * KAT cigar_parse.rs:163-176 pins (3) before (4).  At text column 0 with pattern left: with
+ * overhang the walk stops (pattern_start = j, those characters are outside the text); without,
+ * the rest of the pattern is consumed as Del at column 0 (KAT cigar_parse.rs:137-148).
+ * The DP matrix is recomputed on the last m+k text columns only; that window provably contains
+ * every cell the walk can visit (tests/test_oracle_props.py checks it against the full matrix).
+ * `e` is the scan end index (0..n, or n+o for a right overhang of o characters).
+ */
+static void trace_match(const uint8_t* pcode, int m, const uint8_t* tcode, int n, int k, float alpha,
+                        int e, int cost, bbo_match* out) {
+    int o = e > n ? e - n : 0;
+    int j0 = m - o, i0 = e > n ? n : e;
+    int g = cost - (o ? overhang_cost(alpha, o) : 0);
+    int s0 = i0 - (m + k);
+    if (s0 < 0 || g_full_trace) s0 = 0;
+    int w = i0 - s0;
+    size_t stride = (size_t)(w + 1);
+    int32_t* D = (int32_t*)malloc(sizeof(int32_t) * (size_t)(m + 1) * stride);
+    int32_t* col = (int32_t*)malloc(sizeof(int32_t) * (size_t)(m + 1));
+    for (int j = 0; j <= m; ++j) {
+        col[j] = (s0 == 0 && alpha >= 0.f) ? overhang_cost(alpha, j) : j;
+        D[(size_t)j * stride] = col[j];
+    }
+    for (int c = 1; c <= w; ++c) {
+        dp_column(pcode, m, tcode[s0 + c - 1], col);
+        for (int j = 0; j <= m; ++j) D[(size_t)j * stride + (size_t)c] = col[j];
+    }
+#define DD(j, i) D[(size_t)(j) * stride + (size_t)(i)]
+    if (DD(j0, w) != g) { fprintf(stderr, "bb_oracle: trace cost mismatch %d vs %d\n", DD(j0, w), g); abort(); }
+    uint8_t* rev = (uint8_t*)malloc((size_t)(m + w + 2));
+    int nops = 0, j = j0, i = w;
+    while (j > 0) {
+        if (i == 0 && s0 == 0 && alpha >= 0.f) break; /* left overhang: rest of pattern is outside */
+        if (i > 0 && DD(j - 1, i - 1) == g && (pcode[j - 1] & tcode[s0 + i - 1])) { rev[nops++] = BBO_MATCH; --j; --i; continue; }
+        if (i > 0 && DD(j, i - 1) == g - 1) { rev[nops++] = BBO_INS; --i; --g; continue; }
+        if (i > 0 && DD(j - 1, i - 1) == g - 1) { rev[nops++] = BBO_SUB; --j; --i; --g; continue; }
+        if (DD(j - 1, i) == g - 1) { rev[nops++] = BBO_DEL; --j; --g; continue; }
+        fprintf(stderr, "bb_oracle: trace failed at (%d,%d)\n", j, i); abort();
+    }
+#undef DD
+    out->pattern_start = j; out->pattern_end = j0;
+    out->text_start = s0 + i; out->text_end = i0;
+    out->cost = cost; out->n_ops = nops;
+    out->ops = (uint8_t*)malloc((size_t)(nops ? nops : 1));
+    for (int t = 0; t < nops; ++t) out->ops[t] = rev[nops - 1 - t];
+    free(rev); free(col); free(D);
+}
+
+/*
+ * sassy Searcher::<Iupac>::search(pattern, text, k) restated.
+ * [H2] order of the result: forward-strand matches by ascending end position, then
+ * reverse-complement matches in the order the rc scan finds them (ascending end position in the
+ * REVERSED text).  KAT cigar_parse.rs:163-176 pins that the forward match comes first.
+ * [H5] rc: complement(pattern) (same index order) is searched in reversed(text); text_start/end are
+ * mirrored back to forward coordinates, ops stay in pattern order.
+ */
+int bbo_search(const uint8_t* pat, int m, const uint8_t* text, int n, int k, float alpha, int rc, bbo_match** out) {
+    uint8_t* pc = (uint8_t*)malloc((size_t)(m ? m : 1));
+    uint8_t* tc = (uint8_t*)malloc((size_t)(n ? n : 1));
+    for (int j = 0; j < m; ++j) pc[j] = text_code(pat[j]);
+    for (int i = 0; i < n; ++i) tc[i] = text_code(text[i]);
+    end_list ends = {0, 0, 0};
+    scan_strand(pc, m, tc, n, k, alpha, &ends);
+    int nf = ends.n, total = nf;
+    bbo_match* ms = (bbo_match*)calloc((size_t)(nf ? nf : 1), sizeof(bbo_match));
+    for (int t = 0; t < nf; ++t) {
+        trace_match(pc, m, tc, n, k, alpha, ends.v[t].e, ends.v[t].cost, &ms[t]);
+        ms[t].strand = BB_FWD; ms[t].pattern_idx = 0; ms[t].rc_text_len = n;
+    }
+    if (rc) {
+        uint8_t* pcc = (uint8_t*)malloc((size_t)(m ? m : 1));
+        uint8_t* trv = (uint8_t*)malloc((size_t)(n ? n : 1));
+        for (int j = 0; j < m; ++j) pcc[j] = comp_code(pc[j]);
+        for (int i = 0; i < n; ++i) trv[i] = tc[n - 1 - i];
+        end_list re = {0, 0, 0};
+        scan_strand(pcc, m, trv, n, k, alpha, &re);
+        total = nf + re.n;
+        ms = (bbo_match*)realloc(ms, sizeof(bbo_match) * (size_t)(total ? total : 1));
+        for (int t = 0; t < re.n; ++t) {
+            bbo_match* mm = &ms[nf + t];
+            memset(mm, 0, sizeof(*mm));
+            trace_match(pcc, m, trv, n, k, alpha, re.v[t].e, re.v[t].cost, mm);
+            int ts = mm->text_start, te = mm->text_end;
+            mm->text_start = n - te; mm->text_end = n - ts;
+            mm->strand = BB_RC; mm->pattern_idx = 0; mm->rc_text_len = n;
+        }
+        free(re.v); free(pcc); free(trv);
+    }
+    free(ends.v); free(pc); free(tc);
+    *out = ms;
+    return total;
+}
+void bbo_free_matches(bbo_match* ms, int n) {
+    if (!ms) return;
+    for (int i = 0; i < n; ++i) free(ms[i].ops);
+    free(ms);
+}
+
+/*
+ * Match::to_path restated: exactly one Pos per unit op, path[t] = the cell at which op t is
+ * applied (before advancing) — SURVEY Appendix A; KATs cigar_parse.rs:137-176 distinguish this
+ * from "after advancing".  [H5] For Rc matches the walk runs in reversed-text coordinates
+ * (i' ascending from n - text_end) and each text index is mirrored to max(0, n-1-i'), so pattern
+ * indices stay comparable with the forward flank and text indices run downwards
+ * (cigar_parse.rs:79-81 takes min/max).
+ */
+int bbo_to_path(const bbo_match* m, bbo_pos* path) {
+    int j = m->pattern_start;
+    int i = m->strand == BB_RC ? m->rc_text_len - m->text_end : m->text_start;
+    for (int t = 0; t < m->n_ops; ++t) {
+        path[t].i = j;
+        if (m->strand == BB_RC) { int f = m->rc_text_len - 1 - i; path[t].j = f < 0 ? 0 : f; }
+        else path[t].j = i;
+        switch (m->ops[t]) {
+            case BBO_MATCH: case BBO_SUB: ++j; ++i; break;
+            case BBO_INS: ++i; break;
+            default: ++j; break;
+        }
+    }
+    return m->n_ops;
+}
+
+/* cigar_parse.rs:6-68 map_pat_to_text_with_cost + compute_subpath_cost. returns 0 when None */
+int bbo_map_pat_to_text_with_cost(const bbo_match* m, int p_start, int p_end,
+                                  int* pat_lo, int* pat_hi, int* txt_lo, int* txt_hi, int* cost) {
+    bbo_pos* path = (bbo_pos*)malloc(sizeof(bbo_pos) * (size_t)(m->n_ops ? m->n_ops : 1));
+    int n = bbo_to_path(m, path);
+    int si = -1, ei = -1;
+    for (int t = 0; t < n; ++t)
+        if (path[t].i >= p_start && path[t].i < p_end) { if (si < 0) si = t; ei = t; }
+    if (si < 0) { free(path); return 0; }
+    int c = 0;
+    for (int t = si; t <= ei; ++t) c += m->ops[t] != BBO_MATCH; /* cigar_parse.rs:47-68 */
+    *pat_lo = path[si].i; *pat_hi = path[ei].i + 1;
+    *txt_lo = path[si].j; *txt_hi = path[ei].j + 1;
+    *cost = c;
+    free(path);
+    return 1;
+}
+
+/* cigar_parse.rs:71-82: first and last path cell with pattern idx in [start,end] (inclusive);
+ * `next()` then `next_back()` on one filtered iterator => None unless there are >= 2 such cells */
+int bbo_get_matching_region(const bbo_match* m, int start, int end, int* lo, int* hi) {
+    bbo_pos* path = (bbo_pos*)malloc(sizeof(bbo_pos) * (size_t)(m->n_ops ? m->n_ops : 1));
+    int n = bbo_to_path(m, path);
+    int first = -1, last = -1, cnt = 0;
+    for (int t = 0; t < n; ++t)
+        if (path[t].i >= start && path[t].i <= end) { if (first < 0) first = t; last = t; ++cnt; }
+    if (cnt < 2) { free(path); return 0; }
+    int a = path[first].j, b = path[last].j;
+    *lo = a < b ? a : b; *hi = a < b ? b : a;
+    free(path);
+    return 1;
+}
+
+/*
+ * [H8] Lodhi::new(3, 0.5).compute(&cigar) restated.  The CIGAR is read as a string of alignment
+ * columns (one per unit op), x_c = 1 for Match columns.  Score = gap-weighted count of length-3
+ * subsequences of matched columns (Lodhi et al. 2002 string subsequence kernel, p = 3):
+ *        sum over c1<c2<c3, all matched, of lambda^(c3 - c1 + 1),   lambda = 0.5
+ * evaluated left to right in f64 by the standard recurrences
+ *        score += lambda*A2 ; A2 = lambda*(A2 + A1) ; A1 = lambda*(A1 + 1)     (match column)
+ *                             A2 = lambda*A2        ; A1 = lambda*A1           (other column)
+ * The HIP kernel runs the identical sequence of f64 operations (no FMA contraction).
+ */
+double bbo_lodhi(const uint8_t* ops, int n_ops) {
+    const double lambda = 0.5;
+    double a1 = 0.0, a2 = 0.0, score = 0.0;
+    for (int c = 0; c < n_ops; ++c) {
+        if (ops[c] == BBO_MATCH) {
+            score = score + lambda * a2;
+            a2 = lambda * (a2 + a1);
+            a1 = lambda * (a1 + 1.0);
+        } else {
+            a2 = lambda * a2;
+            a1 = lambda * a1;
+        }
+    }
+    return score;
+}
+
+/* edit_model.rs:2-11 */
+int bbo_edit_cut_off(int l) {
+    double a = (double)l;
+    double value = 0.5100 * a - 1.7312 * sqrt(a);
+    double c = ceil(value);
+    return c > 0.0 ? (int)c : 0;
+}
+
+/* searcher.rs:183-199 */
+int bbo_rel_dist_to_end(long pos, long read_len) {
+    if (pos < 0) return 1;
+    if (pos <= read_len / 2) return pos == 0 ? 1 : (int)pos;
+    if (pos == read_len) return -1;
+    return (int)-(read_len - pos);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* interval.rs:4-79 collapse_overlapping_matches                                               */
+/* ------------------------------------------------------------------------------------------ */
+static int is_overlap(const bb_row* a, const bb_row* b, float threshold) { /* interval.rs:30-42 */
+    uint32_t start = a->read_start_flank > b->read_start_flank ? a->read_start_flank : b->read_start_flank;
+    uint32_t end = a->read_end_flank < b->read_end_flank ? a->read_end_flank : b->read_end_flank;
+    if (end <= start) return 0;
+    uint32_t overlap = end - start;
+    uint32_t la = a->read_end_flank - a->read_start_flank, lb = b->read_end_flank - b->read_start_flank;
+    uint32_t min_len = la < lb ? la : lb;
+    return ((float)overlap / (float)min_len) >= threshold;
+}
+/* interval.rs:48-76 comparator: <0 if a sorts before b */
+static int best_cmp(const bb_row* a, const bb_row* b) {
+    int pa = (a->match_type == BB_FTAG || a->match_type == BB_RTAG) ? 1 : 2;
+    int pb = (b->match_type == BB_FTAG || b->match_type == BB_RTAG) ? 1 : 2;
+    if (pa != pb) return pa < pb ? -1 : 1;
+    if (pa == 1) {
+        if (a->barcode_cost != b->barcode_cost) return a->barcode_cost < b->barcode_cost ? -1 : 1;
+        if (a->flank_cost != b->flank_cost) return a->flank_cost < b->flank_cost ? -1 : 1;
+        return 0;
+    }
+    uint32_t la = a->read_end_flank - a->read_start_flank, lb = b->read_end_flank - b->read_start_flank;
+    if (la != lb) return la > lb ? -1 : 1; /* longer first */
+    return 0;
+}
+int bbo_collapse(bb_row* rows, int n, float filter_overlap) {
+    if (n == 0) return 0;
+    /* stable sort by read_start_flank (interval.rs:12) */
+    for (int i = 1; i < n; ++i) {
+        bb_row x = rows[i];
+        int j = i - 1;
+        while (j >= 0 && rows[j].read_start_flank > x.read_start_flank) { rows[j + 1] = rows[j]; --j; }
+        rows[j + 1] = x;
+    }
+    int out = 0, gs = 0; /* current group = rows[gs..i) */
+    for (int i = 1; i <= n; ++i) {
+        int joins = 0;
+        if (i < n)
+            for (int g = gs; g < i; ++g)
+                if (is_overlap(&rows[g], &rows[i], filter_overlap)) { joins = 1; break; }
+        if (!joins) {
+            /* select_best_match: stable sort by best_cmp, take [0] = first minimal element */
+            int best = gs;
+            for (int g = gs + 1; g < i; ++g)
+                if (best_cmp(&rows[g], &rows[best]) < 0) best = g;
+            bb_row b = rows[best];
+            rows[out++] = b; /* out <= gs, safe */
+            gs = i;
+        }
+    }
+    return out;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* query preparation: BarcodeGroup::new (barcodes.rs:105-197)                                  */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct {
+    uint32_t n_seqs, seq_len;
+    uint8_t* flank; uint32_t flank_len, prefix_len, suffix_len, mask_len;
+    uint32_t bar_lo, bar_hi, pad_lo, pad_hi, m_bar;
+    uint8_t *pat_fwd, *pat_rc; /* n_seqs x m_bar ASCII */
+    uint8_t type; int32_t flank_k, k1, k2; double perfect;
+} ogroup;
+
+struct bbo_ctx { uint32_t n_groups; ogroup* g; bb_params p; };
+
+static int prep_group(const bb_group_desc* d, ogroup* g) {
+    memset(g, 0, sizeof(*g));
+    if (!d->seqs || !d->seq_lens || d->n_seqs == 0) return BB_E_INVALID;
+    if (d->n_seqs == 1) return BB_E_ONE_QUERY;                     /* barcodes.rs:113-117 */
+    uint32_t L = d->seq_lens[0], n = d->n_seqs;
+    for (uint32_t s = 1; s < n; ++s)
+        if (d->seq_lens[s] != L) return BB_E_UNEQUAL_LEN;          /* barcodes.rs:325-328 */
+    if (L == 0) return BB_E_NO_BARCODE;
+    for (uint32_t s = 0; s < n; ++s) {
+        if (!d->seqs[s]) return BB_E_INVALID;
+        for (uint32_t i = 0; i < L; ++i)
+            if (bbo_iupac_code(d->seqs[s][i]) == 0xFF) return BB_E_NOT_IUPAC; /* barcodes.rs:45-47 */
+    }
+    /* longest common prefix / suffix, barcodes.rs:337-385 */
+    uint32_t pre = L, suf = L;
+    for (uint32_t s = 1; s < n; ++s) {
+        uint32_t c = 0;
+        while (c < L && d->seqs[0][c] == d->seqs[s][c]) ++c;
+        if (c < pre) pre = c;
+        c = 0;
+        while (c < L && d->seqs[0][L - 1 - c] == d->seqs[s][L - 1 - c]) ++c;
+        if (c < suf) suf = c;
+    }
+    if (pre + suf >= L) return BB_E_NO_BARCODE;                    /* barcodes.rs:124-128 */
+    if (pre == 0 && suf == 0) return BB_E_NO_FLANK;                /* barcodes.rs:131-133 */
+    uint32_t mask = L - pre - suf;
+    g->n_seqs = n; g->seq_len = L; g->prefix_len = pre; g->suffix_len = suf; g->mask_len = mask;
+    g->flank_len = L;
+    g->flank = (uint8_t*)malloc(L);
+    memcpy(g->flank, d->seqs[0], pre);
+    memset(g->flank + pre, 'N', mask);                             /* barcodes.rs:145-154 */
+    memcpy(g->flank + pre + mask, d->seqs[0] + L - suf, suf);
+    g->bar_lo = pre; g->bar_hi = pre + mask - 1;                   /* barcodes.rs:192 */
+    g->pad_lo = pre >= PADDING ? pre - PADDING : 0;                /* barcodes.rs:160-163 */
+    g->pad_hi = pre + mask + PADDING;
+    uint32_t end = g->pad_hi < L ? g->pad_hi : L;                  /* barcodes.rs:167 */
+    g->m_bar = end - g->pad_lo;
+    g->pat_fwd = (uint8_t*)malloc((size_t)n * g->m_bar);
+    g->pat_rc = (uint8_t*)malloc((size_t)n * g->m_bar);
+    for (uint32_t s = 0; s < n; ++s) {
+        memcpy(g->pat_fwd + (size_t)s * g->m_bar, d->seqs[s] + g->pad_lo, g->m_bar);
+        for (uint32_t i = 0; i < g->m_bar; ++i)                    /* barcodes.rs:85-88,394-396 */
+            g->pat_rc[(size_t)s * g->m_bar + i] = rc_char(d->seqs[s][g->pad_lo + g->m_bar - 1 - i]);
+    }
+    g->type = d->type;
+    g->flank_k = d->flank_k >= 0 ? d->flank_k : bbo_edit_cut_off((int)(pre + suf)); /* annotator.rs:219-226 */
+    g->k1 = (int32_t)((float)g->m_bar * 0.4f);                     /* searcher.rs:458-460 */
+    g->k2 = (int32_t)g->m_bar;                                     /* searcher.rs:276 */
+    /* searcher.rs:229-239: all-Match CIGAR of length pad_hi - pad_lo (pad_hi NOT clamped) */
+    uint32_t lbar = g->pad_hi - g->pad_lo;
+    uint8_t* perfect = (uint8_t*)calloc(lbar, 1);
+    g->perfect = bbo_lodhi(perfect, (int)lbar);
+    free(perfect);
+    return BB_OK;
+}
+static void free_group(ogroup* g) { free(g->flank); free(g->pat_fwd); free(g->pat_rc); }
+
+int bbo_create(const bb_group_desc* groups, uint32_t n_groups, const bb_params* params, bbo_ctx** out) {
+    if (!groups || !params || !out || n_groups == 0) return BB_E_INVALID;
+    bbo_ctx* c = (bbo_ctx*)calloc(1, sizeof(*c));
+    c->g = (ogroup*)calloc(n_groups, sizeof(ogroup));
+    c->n_groups = n_groups; c->p = *params;
+    for (uint32_t i = 0; i < n_groups; ++i) {
+        int rcode = prep_group(&groups[i], &c->g[i]);
+        if (rcode != BB_OK) { for (uint32_t k = 0; k <= i; ++k) free_group(&c->g[k]); free(c->g); free(c); return rcode; }
+    }
+    *out = c;
+    return BB_OK;
+}
+void bbo_destroy(bbo_ctx* c) {
+    if (!c) return;
+    for (uint32_t i = 0; i < c->n_groups; ++i) free_group(&c->g[i]);
+    free(c->g); free(c);
+}
+int bbo_group_get_info(const bbo_ctx* c, uint32_t gi, bb_group_info* o) {
+    if (!c || gi >= c->n_groups || !o) return BB_E_INVALID;
+    const ogroup* g = &c->g[gi];
+    o->flank_len = g->flank_len; o->prefix_len = g->prefix_len; o->suffix_len = g->suffix_len; o->mask_len = g->mask_len;
+    o->bar_lo = g->bar_lo; o->bar_hi = g->bar_hi; o->pad_lo = g->pad_lo; o->pad_hi = g->pad_hi;
+    o->pattern_len = g->m_bar; o->flank_k = g->flank_k; o->bar_k1 = g->k1; o->bar_k2 = g->k2; o->perfect_score = g->perfect;
+    return BB_OK;
+}
+int bbo_group_get_flank(const bbo_ctx* c, uint32_t gi, uint8_t* out) {
+    if (!c || gi >= c->n_groups || !out) return BB_E_INVALID;
+    memcpy(out, c->g[gi].flank, c->g[gi].flank_len);
+    return BB_OK;
+}
+int bbo_group_get_pattern(const bbo_ctx* c, uint32_t gi, uint32_t idx, int rc, uint8_t* out) {
+    if (!c || gi >= c->n_groups || !out || idx >= c->g[gi].n_seqs) return BB_E_INVALID;
+    const ogroup* g = &c->g[gi];
+    memcpy(out, (rc ? g->pat_rc : g->pat_fwd) + (size_t)idx * g->m_bar, g->m_bar);
+    return BB_OK;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* [H7] sassy v2 search_encoded_patterns restated for ONE pattern: forward strand only, no      */
+/* overhang (regular_searcher = new_rc(), patterns were encoded per strand: barcodes.rs:76,     */
+/* searcher.rs:333), every local minimum <= k reported in ascending end position; Barbell keeps */
+/* the first strictly-lowest-cost one per pattern (searcher.rs:294-300).                        */
+/* returns 1 and fills `best` if the pattern has a match <= k                                   */
+/* ------------------------------------------------------------------------------------------ */
+static int best_match_for_pattern(const uint8_t* pcode, int m, const uint8_t* wcode, int wn, int k, bbo_match* best) {
+    end_list ends = {0, 0, 0};
+    scan_strand(pcode, m, wcode, wn, k, -1.f, &ends);
+    int bi = -1;
+    for (int t = 0; t < ends.n; ++t)
+        if (bi < 0 || ends.v[t].cost < ends.v[bi].cost) bi = t; /* searcher.rs:294-300 */
+    if (bi >= 0) {
+        trace_match(pcode, m, wcode, wn, k, -1.f, ends.v[bi].e, ends.v[bi].cost, best);
+        best->strand = BB_FWD; best->rc_text_len = wn;
+    }
+    free(ends.v);
+    return bi >= 0;
+}
+
+typedef struct { bb_row* v; int n, cap; } row_list;
+static void row_push(row_list* l, const bb_row* r) {
+    if (l->n == l->cap) { l->cap = l->cap ? 2 * l->cap : 8; l->v = (bb_row*)realloc(l->v, sizeof(bb_row) * (size_t)l->cap); }
+    l->v[l->n++] = *r;
+}
+
+/* searcher.rs:241-265 */
+static void push_flank_only(row_list* rows, uint32_t read_idx, uint32_t read_len, uint32_t gi, const ogroup* g, const bbo_match* fm) {
+    bb_row r; memset(&r, 0, sizeof(r));
+    r.read_idx = read_idx; r.read_len = read_len;
+    r.rel_dist_to_end = bbo_rel_dist_to_end(fm->text_start, read_len);
+    r.read_start_bar = (uint32_t)fm->text_start; r.read_end_bar = (uint32_t)fm->text_end;
+    r.read_start_flank = (uint32_t)fm->text_start; r.read_end_flank = (uint32_t)fm->text_end;
+    r.bar_start = 0; r.bar_end = 0;
+    r.match_type = g->type == BB_FTAG ? BB_FFLANK : BB_RFLANK;
+    r.flank_cost = (int16_t)fm->cost; r.barcode_cost = (int16_t)g->m_bar; /* barcodes[0].seq.len() */
+    r.barcode_idx = -1; r.group_idx = (uint8_t)gi; r.strand = (uint8_t)fm->strand;
+    row_push(rows, &r);
+}
+
+/* Demuxer::demux (searcher.rs:430-490) for one read; rows appended to `rows` (already collapsed) */
+static void demux_read(const bbo_ctx* c, uint32_t read_idx, const uint8_t* read, uint32_t n, row_list* rows) {
+    int first_row = rows->n;
+    uint8_t* rcode = (uint8_t*)malloc(n ? n : 1);
+    for (uint32_t i = 0; i < n; ++i) rcode[i] = text_code(read[i]);
+    for (uint32_t gi = 0; gi < c->n_groups; ++gi) {                                   /* :433 */
+        const ogroup* g = &c->g[gi];
+        bbo_match* fms = NULL;
+        int nfm = bbo_search(g->flank, (int)g->flank_len, read, (int)n, g->flank_k, c->p.alpha, 1, &fms); /* :438 */
+        for (int f = 0; f < nfm; ++f) {                                               /* :440 */
+            const bbo_match* fm = &fms[f];
+            int lo, hi;
+            if (!bbo_get_matching_region(fm, (int)g->bar_lo, (int)g->bar_hi, &lo, &hi)) continue; /* :445-449 */
+            uint32_t ws = lo >= PADDING ? (uint32_t)(lo - PADDING) : 0;                /* :453 */
+            uint32_t we = (uint32_t)(hi + PADDING) < n ? (uint32_t)(hi + PADDING) : n; /* :454 */
+            if (we < ws) we = ws; /* the reference would panic on the slice; cannot happen for lo <= n */
+            const uint8_t* wcode = rcode + ws; int wn = (int)(we - ws);
+            const uint8_t* pats = fm->strand == BB_FWD ? g->pat_fwd : g->pat_rc;       /* barcodes.rs:97-102 */
+            int m = (int)g->m_bar;
+            bbo_match* best = (bbo_match*)calloc(g->n_seqs, sizeof(bbo_match));
+            uint8_t* has = (uint8_t*)calloc(g->n_seqs, 1);
+            uint8_t* pcode = (uint8_t*)malloc((size_t)m);
+            int k = g->k1, matched = 0;
+            for (int pass = 0; pass < 2; ++pass) {                                    /* :282-328 */
+                matched = 0;
+                for (uint32_t p = 0; p < g->n_seqs; ++p) {
+                    for (int j = 0; j < m; ++j) pcode[j] = text_code(pats[(size_t)p * m + j]);
+                    if (has[p]) { free(best[p].ops); best[p].ops = NULL; has[p] = 0; }
+                    has[p] = (uint8_t)best_match_for_pattern(pcode, m, wcode, wn, k, &best[p]);
+                    matched += has[p];
+                }
+                if (matched <= 1 && g->k1 < g->k2 && pass == 0) k = g->k2; else break; /* :303-306 */
+            }
+            if (matched == 0) {                                                       /* :353-362 */
+                push_flank_only(rows, read_idx, n, gi, g, fm);
+            } else {
+                /* :364-377 score every candidate, stable sort descending by s_norm: top = first
+                 * maximum in ascending idx order, second = best of the rest */
+                int top = -1, second = -1; double top_s = 0, second_s = 0;
+                double* sc = (double*)malloc(sizeof(double) * g->n_seqs);
+                for (uint32_t p = 0; p < g->n_seqs; ++p) {
+                    if (!has[p]) continue;
+                    double s = bbo_lodhi(best[p].ops, best[p].n_ops);
+                    sc[p] = g->perfect > 0.0 ? s / g->perfect : 0.0;                   /* :368-372 */
+                    if (top < 0 || sc[p] > top_s) { top = (int)p; top_s = sc[p]; }
+                }
+                for (uint32_t p = 0; p < g->n_seqs; ++p) {
+                    if (!has[p] || (int)p == top) continue;
+                    if (second < 0 || sc[p] > second_s) { second = (int)p; second_s = sc[p]; }
+                }
+                int rel_lo = (int)(g->bar_lo - g->pad_lo), rel_hi = (int)(g->bar_hi - g->pad_lo); /* :379-382 */
+                int pl, ph, tl, th, bc;
+                if (!bbo_map_pat_to_text_with_cost(&best[top], rel_lo, rel_hi, &pl, &ph, &tl, &th, &bc)) {
+                    fprintf(stderr, "bb_oracle: No barcode match region found; unusual\n"); abort(); /* :388 */
+                }
+                int valid = top_s >= c->p.min_score;                                   /* :391-396 */
+                if (second >= 0) valid = valid && (top_s - second_s) >= c->p.min_score_diff;
+                if (valid) {                                                           /* :398-416 */
+                    bb_row r; memset(&r, 0, sizeof(r));
+                    r.read_idx = read_idx; r.read_len = n;
+                    r.rel_dist_to_end = bbo_rel_dist_to_end(fm->text_start, n);
+                    r.read_start_bar = ws + (uint32_t)tl; r.read_end_bar = ws + (uint32_t)th;
+                    r.read_start_flank = (uint32_t)fm->text_start; r.read_end_flank = (uint32_t)fm->text_end;
+                    r.bar_start = ws + (uint32_t)pl; r.bar_end = ws + (uint32_t)ph;
+                    r.match_type = g->type;
+                    r.flank_cost = (int16_t)fm->cost; r.barcode_cost = (int16_t)bc;
+                    r.barcode_idx = (int16_t)top; r.group_idx = (uint8_t)gi; r.strand = (uint8_t)fm->strand;
+                    row_push(rows, &r);
+                } else {
+                    push_flank_only(rows, read_idx, n, gi, g, fm);                     /* :417-425 */
+                }
+                free(sc);
+            }
+            for (uint32_t p = 0; p < g->n_seqs; ++p) if (has[p]) free(best[p].ops);
+            free(best); free(has); free(pcode);
+        }
+        bbo_free_matches(fms, nfm);
+    }
+    free(rcode);
+    rows->n = first_row + bbo_collapse(rows->v + first_row, rows->n - first_row, 0.8f); /* :489 */
+}
+
+int bbo_annotate_batch(bbo_ctx* c, const uint8_t* bases, const uint64_t* offsets, uint32_t n_reads,
+                       bb_row* rows, uint64_t rows_cap, uint64_t* n_rows, int n_threads) {
+    if (!c || (!bases && n_reads) || !offsets || !n_rows) return BB_E_INVALID;
+    row_list* per = (row_list*)calloc(n_reads ? n_reads : 1, sizeof(row_list));
+#ifdef _OPENMP
+    if (n_threads < 1) n_threads = 1;
+#pragma omp parallel for schedule(dynamic, 16) num_threads(n_threads)
+#endif
+    for (long i = 0; i < (long)n_reads; ++i)
+        demux_read(c, (uint32_t)i, bases + offsets[i], (uint32_t)(offsets[i + 1] - offsets[i]), &per[i]);
+    (void)n_threads;
+    uint64_t total = 0;
+    for (uint32_t i = 0; i < n_reads; ++i) total += (uint64_t)per[i].n;
+    *n_rows = total;
+    int rcode = BB_OK;
+    if (total > rows_cap || (!rows && total)) rcode = BB_E_CAPACITY;
+    else {
+        uint64_t o = 0;
+        for (uint32_t i = 0; i < n_reads; ++i) { if (per[i].n) memcpy(rows + o, per[i].v, sizeof(bb_row) * (size_t)per[i].n); o += (uint64_t)per[i].n; }
+    }
+    for (uint32_t i = 0; i < n_reads; ++i) free(per[i].v);
+    free(per);
+    return rcode;
+}

@@ -1,0 +1,81 @@
+/*
+ * bb_oracle.h — CPU restatement (plain C) of Barbell's annotate hot path.  TEST INFRASTRUCTURE.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may link or call this; the
+ * product library (barbell_amd/csrc) never does.  See oracle/README.md for the pinning status:
+ * the arithmetic of this path lives in un-vendored crates (sassy 0.2.1, cigar-lodhi-rs 0.1.0,
+ * pa-types 1.2.0) whose sources are absent from /root/reference, so everything beyond the
+ * reference's own known-answer tests is "parity unpinned" and isolated in the policy functions
+ * marked H1..H9 in bb_oracle.c.
+ */
+#ifndef BB_ORACLE_H
+#define BB_ORACLE_H
+
+#include "../include/barbell_amd.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* unit CIGAR ops, pa-types naming (Pos(i,j): i = pattern, j = text) */
+#define BBO_MATCH 0  /* +(1,1) cost 0 */
+#define BBO_SUB   1  /* +(1,1) cost 1 */
+#define BBO_INS   2  /* +(0,1) text char not in pattern */
+#define BBO_DEL   3  /* +(1,0) pattern char not in text */
+
+/* restatement of sassy::Match (fields Barbell reads: SURVEY Appendix A) */
+typedef struct {
+    int32_t text_start, text_end;        /* forward text coordinates, end exclusive          */
+    int32_t pattern_start, pattern_end;  /* part of the pattern inside the text (overhang)   */
+    int32_t cost;
+    int32_t strand;                      /* BB_FWD / BB_RC                                   */
+    int32_t pattern_idx;
+    int32_t n_ops;
+    uint8_t* ops;                        /* unit ops in pattern order (malloc'd)             */
+    int32_t rc_text_len;                 /* text length, needed by to_path for Rc matches    */
+} bbo_match;
+
+typedef struct { int32_t i, j; } bbo_pos;   /* Pos(pattern idx, text idx) */
+
+/* sassy Searcher::<Iupac>::search restated: alpha < 0 -> no overhang; rc != 0 -> also search the
+ * reverse complement.  Returns the number of matches, *out is malloc'd (free with bbo_free_matches). */
+int  bbo_search(const uint8_t* pat, int m, const uint8_t* text, int n, int k, float alpha, int rc,
+                bbo_match** out);
+void bbo_free_matches(bbo_match* ms, int n);
+/* Match::to_path: one Pos per unit op, path[t] = cell at which op t is applied. returns n_ops */
+int  bbo_to_path(const bbo_match* m, bbo_pos* path /* n_ops entries */);
+
+/* cigar_parse.rs:6-45 / :71-82 */
+int  bbo_map_pat_to_text_with_cost(const bbo_match* m, int p_start, int p_end,
+                                   int* pat_lo, int* pat_hi, int* txt_lo, int* txt_hi, int* cost);
+int  bbo_get_matching_region(const bbo_match* m, int start, int end, int* lo, int* hi);
+
+/* cigar-lodhi-rs Lodhi::new(3, 0.5).compute restated (H8) on a unit-op string */
+double bbo_lodhi(const uint8_t* ops, int n_ops);
+/* edit_model.rs:2-11 */
+int    bbo_edit_cut_off(int l);
+/* searcher.rs:183-199 */
+int    bbo_rel_dist_to_end(long pos, long read_len);
+/* interval.rs:4-79; collapses `rows` (n) in place, returns the new count */
+int    bbo_collapse(bb_row* rows, int n, float filter_overlap);
+/* IUPAC profile: 4-bit code, 0xFF = invalid */
+uint8_t bbo_iupac_code(uint8_t c);
+
+/* whole-path API with the same shape as the product's C-ABI */
+typedef struct bbo_ctx bbo_ctx;
+int  bbo_create(const bb_group_desc* groups, uint32_t n_groups, const bb_params* params, bbo_ctx** out);
+void bbo_destroy(bbo_ctx* ctx);
+int  bbo_group_get_info(const bbo_ctx* ctx, uint32_t group, bb_group_info* info);
+int  bbo_group_get_flank(const bbo_ctx* ctx, uint32_t group, uint8_t* out);
+int  bbo_group_get_pattern(const bbo_ctx* ctx, uint32_t group, uint32_t idx, int rc, uint8_t* out);
+/* Demuxer::demux over a batch; n_threads > 1 uses OpenMP over reads (one scratch per thread,
+ * like the reference's one Demuxer per paraseq worker, annotator.rs:88-101). */
+int  bbo_annotate_batch(bbo_ctx* ctx, const uint8_t* bases, const uint64_t* offsets, uint32_t n_reads,
+                        bb_row* rows, uint64_t rows_cap, uint64_t* n_rows, int n_threads);
+/* test hook: 1 = trace flank matches on the full DP matrix instead of the (m+k)-column window */
+void bbo_set_full_trace(int on);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

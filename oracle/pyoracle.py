@@ -1,0 +1,193 @@
+"""ctypes binding of oracle/libbb_oracle.so — TEST INFRASTRUCTURE.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; the
+product package `barbell_amd` never does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from barbell_amd import _abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libbb_oracle.so")
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "bb_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _SO
+
+
+class Match(C.Structure):
+    _fields_ = [
+        ("text_start", C.c_int32), ("text_end", C.c_int32),
+        ("pattern_start", C.c_int32), ("pattern_end", C.c_int32),
+        ("cost", C.c_int32), ("strand", C.c_int32), ("pattern_idx", C.c_int32),
+        ("n_ops", C.c_int32), ("ops", C.POINTER(C.c_uint8)), ("rc_text_len", C.c_int32),
+    ]
+
+
+class Pos(C.Structure):
+    _fields_ = [("i", C.c_int32), ("j", C.c_int32)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        L = C.CDLL(_SO)
+        L.bbo_search.restype = C.c_int
+        L.bbo_search.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_float, C.c_int,
+                                 C.POINTER(C.POINTER(Match))]
+        L.bbo_free_matches.argtypes = [C.POINTER(Match), C.c_int]
+        L.bbo_to_path.argtypes = [C.POINTER(Match), C.POINTER(Pos)]
+        L.bbo_map_pat_to_text_with_cost.argtypes = [C.POINTER(Match), C.c_int, C.c_int] + [C.POINTER(C.c_int)] * 5
+        L.bbo_get_matching_region.argtypes = [C.POINTER(Match), C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.bbo_lodhi.restype = C.c_double
+        L.bbo_lodhi.argtypes = [C.c_char_p, C.c_int]
+        L.bbo_edit_cut_off.argtypes = [C.c_int]
+        L.bbo_rel_dist_to_end.argtypes = [C.c_long, C.c_long]
+        L.bbo_collapse.argtypes = [C.c_void_p, C.c_int, C.c_float]
+        L.bbo_iupac_code.restype = C.c_uint8
+        L.bbo_iupac_code.argtypes = [C.c_uint8]
+        L.bbo_create.argtypes = [C.POINTER(_abi.GroupDesc), C.c_uint32, C.POINTER(_abi.Params), C.POINTER(C.c_void_p)]
+        L.bbo_destroy.argtypes = [C.c_void_p]
+        L.bbo_group_get_info.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(_abi.GroupInfo)]
+        L.bbo_group_get_flank.argtypes = [C.c_void_p, C.c_uint32, C.c_char_p]
+        L.bbo_group_get_pattern.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_char_p]
+        L.bbo_annotate_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64,
+                                         C.POINTER(C.c_uint64), C.c_int]
+        L.bbo_set_full_trace.argtypes = [C.c_int]
+        _lib = L
+    return _lib
+
+
+OPS = "=XID"  # Match, Sub, Ins, Del
+
+
+class PyMatch:
+    """Python copy of one bbo_match plus its path."""
+
+    def __init__(self, m):
+        L = lib()
+        for f in ("text_start", "text_end", "pattern_start", "pattern_end", "cost", "strand", "n_ops"):
+            setattr(self, f, getattr(m, f))
+        self.ops = bytes(m.ops[i] for i in range(m.n_ops))
+        path = (Pos * max(1, m.n_ops))()
+        L.bbo_to_path(C.byref(m), path)
+        self.path = [(path[i].i, path[i].j) for i in range(m.n_ops)]
+        self.cigar = "".join(OPS[o] for o in self.ops)
+
+
+def search(pattern, text, k, alpha=None, rc=True):
+    """sassy Searcher::search restated.  Returns (list[PyMatch], raw handle tuple to free)."""
+    L = lib()
+    out = C.POINTER(Match)()
+    n = L.bbo_search(pattern, len(pattern), text, len(text), k, -1.0 if alpha is None else float(alpha), int(rc), C.byref(out))
+    res = [PyMatch(out[i]) for i in range(n)]
+    return res, (out, n)
+
+
+def map_pat_to_text_with_cost(handle, idx, p_start, p_end):
+    L = lib()
+    out, n = handle
+    v = [C.c_int() for _ in range(5)]
+    ok = L.bbo_map_pat_to_text_with_cost(C.byref(out[idx]), p_start, p_end, *[C.byref(x) for x in v])
+    if not ok:
+        return None
+    pl, ph, tl, th, cost = [x.value for x in v]
+    return (pl, ph), (tl, th), cost
+
+
+def get_matching_region(handle, idx, start, end):
+    L = lib()
+    out, n = handle
+    lo, hi = C.c_int(), C.c_int()
+    ok = L.bbo_get_matching_region(C.byref(out[idx]), start, end, C.byref(lo), C.byref(hi))
+    return (lo.value, hi.value) if ok else None
+
+
+def free_matches(handle):
+    out, n = handle
+    lib().bbo_free_matches(out, n)
+
+
+def lodhi(ops):
+    return lib().bbo_lodhi(bytes(ops), len(ops))
+
+
+def collapse(rows, overlap=0.8):
+    rows = np.ascontiguousarray(rows, dtype=_abi.ROW_DTYPE).copy()
+    n = lib().bbo_collapse(rows.ctypes.data, len(rows), overlap)
+    return rows[:n]
+
+
+class Oracle:
+    """Same shape as barbell_amd.Demuxer, CPU restatement underneath."""
+
+    def __init__(self, groups, alpha=0.4, min_score=0.2, min_score_diff=0.1):
+        L = lib()
+        arr, keep = _abi.make_group_descs(groups)
+        p = _abi.Params(alpha, min_score, min_score_diff, -1)
+        h = C.c_void_p()
+        rc = L.bbo_create(arr, len(groups), C.byref(p), C.byref(h))
+        self.rc = rc
+        self.h = h if rc == 0 else None
+        self.n_groups = len(groups)
+        if rc != 0:
+            raise ValueError(f"bbo_create failed: {rc}")
+
+    def info(self, g):
+        i = _abi.GroupInfo()
+        assert lib().bbo_group_get_info(self.h, g, C.byref(i)) == 0
+        return i
+
+    def flank(self, g):
+        i = self.info(g)
+        buf = C.create_string_buffer(i.flank_len)
+        lib().bbo_group_get_flank(self.h, g, buf)
+        return buf.raw
+
+    def pattern(self, g, idx, rc=False):
+        i = self.info(g)
+        buf = C.create_string_buffer(i.pattern_len)
+        assert lib().bbo_group_get_pattern(self.h, g, idx, int(rc), buf) == 0
+        return buf.raw
+
+    def annotate(self, bases, offsets, n_threads=1):
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = len(offsets) - 1
+        cap = max(64, 4 * n)
+        while True:
+            rows = np.zeros(cap, dtype=_abi.ROW_DTYPE)
+            nr = C.c_uint64()
+            rc = lib().bbo_annotate_batch(self.h, bases.ctypes.data, offsets.ctypes.data, n, rows.ctypes.data, cap,
+                                          C.byref(nr), n_threads)
+            if rc == _abi.BB_E_CAPACITY:
+                cap = int(nr.value)
+                continue
+            assert rc == 0, rc
+            return rows[: nr.value]
+
+    def annotate_reads(self, reads, n_threads=1):
+        return self.annotate(*_abi.pack_reads(reads), n_threads=n_threads)
+
+    def close(self):
+        if self.h:
+            lib().bbo_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
