@@ -1,0 +1,64 @@
+"""Loader of the in-tree HIP library barbell_amd/libbarbell_amd.so (built by __graft_entry__.build()
+or barbell_amd/csrc/build.sh).  There is no fallback: if the library is missing, importing the
+compute entry points fails loudly."""
+import ctypes as C
+import os
+
+from . import _abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libbarbell_amd.so")
+
+# every symbol include/barbell_amd.h and include/barbell_amd_synth.h declare
+EXPORTS = [
+    "bb_create", "bb_destroy", "bb_n_groups", "bb_group_get_info", "bb_group_get_flank", "bb_group_get_pattern",
+    "bb_annotate_batch", "bb_annotate_batch_dev", "bb_counts_len", "bb_counts", "bb_counts_dev", "bb_counts_reset",
+    "bb_n_kernels", "bb_kernel_name", "bb_last_kernel_ms", "bb_set_timing", "bb_strerror", "bb_last_error",
+    "bb_synth_offsets", "bb_synth_reads_host", "bb_synth_reads_dev",
+]
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise ImportError(
+            f"{SO_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). barbell_amd has no CPU fallback."
+        )
+    L = C.CDLL(SO_PATH)
+    vp, u32, u64, i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int
+    L.bb_create.argtypes = [C.POINTER(_abi.GroupDesc), u32, C.POINTER(_abi.Params), C.POINTER(vp)]
+    L.bb_destroy.argtypes = [vp]
+    L.bb_destroy.restype = None
+    L.bb_n_groups.argtypes = [vp]
+    L.bb_group_get_info.argtypes = [vp, u32, C.POINTER(_abi.GroupInfo)]
+    L.bb_group_get_flank.argtypes = [vp, u32, C.c_char_p]
+    L.bb_group_get_pattern.argtypes = [vp, u32, u32, i32, C.c_char_p]
+    L.bb_annotate_batch.argtypes = [vp, vp, vp, u32, vp, u64, C.POINTER(u64)]
+    L.bb_annotate_batch_dev.argtypes = [vp, vp, vp, u32, vp, u64, C.POINTER(u64)]
+    L.bb_counts_len.argtypes = [vp]
+    L.bb_counts_len.restype = u32
+    L.bb_counts.argtypes = [vp, vp]
+    L.bb_counts_dev.argtypes = [vp]
+    L.bb_counts_dev.restype = vp
+    L.bb_counts_reset.argtypes = [vp]
+    L.bb_n_kernels.restype = i32
+    L.bb_kernel_name.argtypes = [i32]
+    L.bb_kernel_name.restype = C.c_char_p
+    L.bb_last_kernel_ms.argtypes = [vp, i32]
+    L.bb_last_kernel_ms.restype = C.c_float
+    L.bb_set_timing.argtypes = [vp, i32]
+    L.bb_set_timing.restype = None
+    L.bb_strerror.argtypes = [i32]
+    L.bb_strerror.restype = C.c_char_p
+    L.bb_last_error.argtypes = [vp]
+    L.bb_last_error.restype = C.c_char_p
+    L.bb_synth_offsets.argtypes = [u64, u32, u32, u64, u32, vp]
+    L.bb_synth_reads_host.argtypes = [C.POINTER(_abi.GroupDesc), u32, u64, u32, u32, u64, u32, vp, vp]
+    L.bb_synth_reads_dev.argtypes = [vp, u64, u32, u32, u64, u32, vp, vp]
+    _lib = L
+    return L

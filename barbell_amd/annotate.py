@@ -1,0 +1,250 @@
+"""Host-side mirror of the reference's annotate interface for the hot path.
+
+`Demuxer` has the reference's constructor and `add_query_group` (src/annotate/searcher.rs:202-226);
+instead of `demux(read_id, read) -> Vec<BarbellMatch>` per read (searcher.rs:430) it offers
+`demux_batch(reads)`: one C-ABI call per batch, rows identical to what the per-read loop of
+`DemuxProcessor::process_record` (src/annotate/annotator.rs:123-135) would have produced, in input
+order.  `annotate()` mirrors `annotate_with_groups`/`annotate` (annotator.rs:207-285): FASTQ in,
+annotation.tsv out, with the byte-exact schema of `BarbellMatch`'s serde layout (searcher.rs:31-64).
+All computation happens in the HIP library; there is no CPU path here.
+"""
+import ctypes as C
+import gzip
+
+import numpy as np
+
+from . import _abi, kits
+from ._lib import lib
+
+TSV_HEADER = ("read_id\tread_len\trel_dist_to_end\tread_start_bar\tread_end_bar\tread_start_flank\t"
+              "read_end_flank\tbar_start\tbar_end\tmatch_type\tflank_cost\tbarcode_cost\tlabel\tstrand\tcuts")
+
+
+class BarbellError(RuntimeError):
+    def __init__(self, code, detail=""):
+        self.code = code
+        msg = lib().bb_strerror(code).decode()
+        super().__init__(f"barbell_amd error {code}: {msg}" + (f" ({detail})" if detail else ""))
+
+
+class Demuxer:
+    """Demuxer::new(alpha, verbose, min_score_frac, min_score_diff_frac) (searcher.rs:202)."""
+
+    def __init__(self, alpha=0.4, verbose=False, min_score_frac=0.2, min_score_diff_frac=0.1, device=0):
+        self.alpha, self.verbose = float(alpha), bool(verbose)
+        self.min_score_frac, self.min_score_diff_frac = float(min_score_frac), float(min_score_diff_frac)
+        self.device = int(device)
+        self.queries = []
+        self._h = None
+
+    def add_query_group(self, group):  # searcher.rs:220-226
+        if self._h is not None:
+            raise RuntimeError("add_query_group after the first demux call")
+        self.queries.append(group)
+        return self
+
+    # -- context -------------------------------------------------------------------------------
+    def _ctx(self):
+        if self._h is None:
+            L = lib()
+            arr, keep = _abi.make_group_descs([g.as_tuple() for g in self.queries])
+            p = _abi.Params(self.alpha, self.min_score_frac, self.min_score_diff_frac, self.device)
+            h = C.c_void_p()
+            rc = L.bb_create(arr, len(self.queries), C.byref(p), C.byref(h))
+            if rc != 0:
+                raise BarbellError(rc)
+            self._h = h
+        return self._h
+
+    def close(self):
+        if self._h is not None:
+            lib().bb_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise BarbellError(rc, lib().bb_last_error(self._h).decode() if self._h else "")
+
+    # -- geometry ------------------------------------------------------------------------------
+    def group_info(self, g):
+        i = _abi.GroupInfo()
+        self._check(lib().bb_group_get_info(self._ctx(), g, C.byref(i)))
+        return i
+
+    def flank(self, g):
+        buf = C.create_string_buffer(self.group_info(g).flank_len)
+        self._check(lib().bb_group_get_flank(self._ctx(), g, buf))
+        return buf.raw
+
+    def pattern(self, g, idx, rc=False):
+        buf = C.create_string_buffer(self.group_info(g).pattern_len)
+        self._check(lib().bb_group_get_pattern(self._ctx(), g, idx, int(rc), buf))
+        return buf.raw
+
+    # -- the hot path --------------------------------------------------------------------------
+    def demux_packed(self, bases, offsets):
+        """bases uint8[total], offsets uint64[n+1] (host arrays) -> rows (ROW_DTYPE)."""
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = len(offsets) - 1
+        cap = max(64, 4 * n)
+        while True:
+            rows = np.zeros(cap, dtype=_abi.ROW_DTYPE)
+            nr = C.c_uint64()
+            rc = lib().bb_annotate_batch(self._ctx(), bases.ctypes.data, offsets.ctypes.data, n, rows.ctypes.data, cap, C.byref(nr))
+            if rc == _abi.BB_E_CAPACITY:
+                cap = int(nr.value)
+                continue
+            self._check(rc)
+            return rows[: nr.value]
+
+    def demux_batch(self, reads):
+        return self.demux_packed(*_abi.pack_reads(reads))
+
+    def demux_dev(self, d_bases, d_offsets, n_reads, d_rows, rows_cap):
+        """Device-pointer variant (ints = HIP device pointers). Returns the number of rows."""
+        nr = C.c_uint64()
+        rc = lib().bb_annotate_batch_dev(self._ctx(), d_bases, d_offsets, n_reads, d_rows, rows_cap, C.byref(nr))
+        if rc == _abi.BB_E_CAPACITY:
+            raise BarbellError(rc, f"need {nr.value} rows")
+        self._check(rc)
+        return int(nr.value)
+
+    # -- histogram / timing --------------------------------------------------------------------
+    def counts(self):
+        n = lib().bb_counts_len(self._ctx())
+        out = np.zeros(n, dtype=np.uint64)
+        self._check(lib().bb_counts(self._ctx(), out.ctypes.data))
+        return out
+
+    def counts_dev_ptr(self):
+        return lib().bb_counts_dev(self._ctx()), lib().bb_counts_len(self._ctx())
+
+    def counts_reset(self):
+        self._check(lib().bb_counts_reset(self._ctx()))
+
+    def set_timing(self, on=True):
+        lib().bb_set_timing(self._ctx(), int(on))
+
+    def kernel_ms(self):
+        L = lib()
+        return {L.bb_kernel_name(k).decode(): L.bb_last_kernel_ms(self._ctx(), k) for k in range(L.bb_n_kernels())}
+
+    # -- synthetic reads -----------------------------------------------------------------------
+    def synth_dev(self, seed, len_min, len_max, first_read, n, d_offsets, d_bases):
+        self._check(lib().bb_synth_reads_dev(self._ctx(), seed, len_min, len_max, first_read, n, d_offsets, d_bases))
+
+
+def synth_offsets(seed, len_min, len_max, first_read, n):
+    off = np.zeros(n + 1, dtype=np.uint64)
+    rc = lib().bb_synth_offsets(seed, len_min, len_max, first_read, n, off.ctypes.data)
+    if rc != 0:
+        raise BarbellError(rc)
+    return off
+
+
+def synth_reads_host(groups, seed, len_min, len_max, first_read, n):
+    """groups: list[kits.QueryGroup].  Returns (bases, offsets) generated on the host (no GPU)."""
+    off = synth_offsets(seed, len_min, len_max, first_read, n)
+    bases = np.zeros(int(off[-1]), dtype=np.uint8)
+    arr, keep = _abi.make_group_descs([g.as_tuple() for g in groups])
+    rc = lib().bb_synth_reads_host(arr, len(groups), seed, len_min, len_max, first_read, n, off.ctypes.data, bases.ctypes.data)
+    if rc != 0:
+        raise BarbellError(rc)
+    return bases, off
+
+
+# ---- TSV (searcher.rs:31-142, annotator.rs:13-26,246-251) ------------------------------------------
+def format_rows(rows, read_ids, groups):
+    """rows -> list of TSV lines (no header), csv-crate style: tab-delimited, no quoting needed for
+    these field types unless a read id contains a tab/quote/newline."""
+    out = []
+    for r in rows:
+        g = groups[int(r["group_idx"])]
+        label = "flank" if r["barcode_idx"] < 0 else g.labels[int(r["barcode_idx"])]
+        rid = read_ids[int(r["read_idx"])]
+        if any(ch in rid for ch in '\t"\n\r'):
+            rid = '"' + rid.replace('"', '""') + '"'
+        out.append("\t".join((
+            rid, str(int(r["read_len"])), str(int(r["rel_dist_to_end"])),
+            str(int(r["read_start_bar"])), str(int(r["read_end_bar"])),
+            str(int(r["read_start_flank"])), str(int(r["read_end_flank"])),
+            str(int(r["bar_start"])), str(int(r["bar_end"])),
+            _abi.MATCH_TYPE_STR[int(r["match_type"])], str(int(r["flank_cost"])), str(int(r["barcode_cost"])),
+            label, _abi.STRAND_STR[int(r["strand"])], "",
+        )))
+    return out
+
+
+def split_fastq_header(header):  # src/io/io.rs:6-17
+    parts = header.split(None, 1)
+    if not parts:
+        return "", ""
+    return parts[0], (parts[1].lstrip() if len(parts) > 1 else "")
+
+
+def read_fastq(path):
+    """Yields (read_id, seq bytes).  Plain or gzip FASTQ, 4-line records."""
+    op = gzip.open if str(path).endswith(".gz") else open
+    with op(path, "rb") as f:
+        while True:
+            h = f.readline()
+            if not h:
+                return
+            s = f.readline().rstrip(b"\r\n")
+            f.readline()
+            f.readline()
+            yield split_fastq_header(h[1:].decode().rstrip("\r\n"))[0], s
+
+
+def annotate(read_files, out_file, query_groups, alpha=0.4, min_score=0.2, min_score_diff=0.1, max_flank_errors=None,
+             batch_reads=65536, device=0):
+    """annotate_with_groups + annotate (annotator.rs:207-285): sets the flank threshold of each group
+    (explicit --flank-max-errors or the automatic cutoff), streams the FASTQ in batches through the
+    GPU and writes annotation.tsv.  Returns (total_reads, reads_with_rows)."""
+    for g in query_groups:
+        if max_flank_errors is not None:
+            g.set_flank_threshold(max_flank_errors)
+    dm = Demuxer(alpha, False, min_score, min_score_diff, device)
+    for g in query_groups:
+        dm.add_query_group(g)
+    total = found = 0
+    wrote_header = False
+    with open(out_file, "w") as out:
+        ids, seqs = [], []
+
+        def flush():
+            nonlocal total, found, wrote_header
+            if not ids:
+                return
+            rows = dm.demux_batch(seqs)
+            total += len(ids)
+            found += len(np.unique(rows["read_idx"]))
+            lines = format_rows(rows, ids, query_groups)
+            if lines and not wrote_header:  # csv writer emits the header with the first record only
+                out.write(TSV_HEADER + "\n")
+                wrote_header = True
+            if lines:
+                out.write("\n".join(lines) + "\n")
+            ids.clear()
+            seqs.clear()
+
+        for path in read_files:
+            for rid, s in read_fastq(path):
+                ids.append(rid)
+                seqs.append(s)
+                if len(ids) >= batch_reads:
+                    flush()
+        flush()
+    dm.close()
+    return total, found
+
+
+def annotate_with_kit(read_files, out_file, kit, use_extended=False, **kw):  # annotator.rs:196-204
+    return annotate(read_files, out_file, kits.groups_from_kit(kit, use_extended), **kw)

@@ -1,0 +1,597 @@
+// barbell_amd.hip — C-ABI implementation (include/barbell_amd.h): query preparation on the host
+// (BarcodeGroup::new, barcodes.rs:105-197), device tables, and the per-batch kernel pipeline.
+// No CPU fallback: every entry point that computes needs the GPU and fails loudly without it.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/barbell_amd.h"
+#include "../../include/barbell_amd_synth.h"
+#include "bb_common.h"
+#include "bb_kernels.h"
+#include "bb_synth.h"
+
+namespace {
+
+enum { K_SCAN = 0, K_PREFIX, K_TRACE, K_LISTS, K_BARCODE, K_COLLAPSE, K_EMIT, K_COUNT };
+const char* const kKernelNames[K_COUNT] = {"k_flank_scan", "k_scan_*", "k_flank_trace", "k_hit_lists",
+                                           "k_barcode",    "k_collapse", "k_emit"};
+
+struct HostGroup {
+    std::vector<std::string> seqs;
+    std::string flank;
+    std::vector<std::string> pat[2];
+    bb_group_info info;
+    uint8_t type;
+};
+
+// barcodes.rs:394-441
+uint8_t rc_char(uint8_t c) {
+    static const char from[] = "ACTGactgRYSWKMBDHVNXryswkmbdhvnx";
+    static const char to[] = "TGACtgacYRSWMKVHDBNXyrswmkvhdbnx";
+    for (int i = 0; from[i]; ++i)
+        if ((uint8_t)from[i] == c) return (uint8_t)to[i];
+    return c;
+}
+int overhang_cost(float alpha, int len) { return (int)floorf((float)len * alpha); }
+// edit_model.rs:2-11
+int edit_cut_off(int l) {
+    double a = (double)l;
+    double v = ceil(0.5100 * a - 1.7312 * sqrt(a));
+    return v > 0.0 ? (int)v : 0;
+}
+// score of an all-Match CIGAR of length n under the Lodhi(3, 0.5) recurrences (same op order as k_barcode)
+double lodhi_all_match(int n) {
+    double a1 = 0.0, a2 = 0.0, sc = 0.0;
+    for (int c = 0; c < n; ++c) { sc = sc + 0.5 * a2; a2 = 0.5 * (a2 + a1); a1 = 0.5 * (a1 + 1.0); }
+    return sc;
+}
+
+int prep_group(const bb_group_desc& d, float alpha, HostGroup& g) {
+    if (!d.seqs || !d.seq_lens || d.n_seqs == 0) return BB_E_INVALID;
+    if (d.n_seqs == 1) return BB_E_ONE_QUERY;
+    const uint32_t L = d.seq_lens[0], n = d.n_seqs;
+    for (uint32_t s = 1; s < n; ++s)
+        if (d.seq_lens[s] != L) return BB_E_UNEQUAL_LEN;
+    if (L == 0) return BB_E_NO_BARCODE;
+    for (uint32_t s = 0; s < n; ++s) {
+        if (!d.seqs[s]) return BB_E_INVALID;
+        for (uint32_t i = 0; i < L; ++i)
+            if (bb_iupac(d.seqs[s][i]) == 0xFF) return BB_E_NOT_IUPAC;
+    }
+    uint32_t pre = L, suf = L;  // barcodes.rs:337-385
+    for (uint32_t s = 1; s < n; ++s) {
+        uint32_t c = 0;
+        while (c < L && d.seqs[0][c] == d.seqs[s][c]) ++c;
+        pre = c < pre ? c : pre;
+        c = 0;
+        while (c < L && d.seqs[0][L - 1 - c] == d.seqs[s][L - 1 - c]) ++c;
+        suf = c < suf ? c : suf;
+    }
+    if (pre + suf >= L) return BB_E_NO_BARCODE;
+    if (pre == 0 && suf == 0) return BB_E_NO_FLANK;
+    const uint32_t mask = L - pre - suf;
+    g.seqs.resize(n);
+    for (uint32_t s = 0; s < n; ++s) g.seqs[s].assign((const char*)d.seqs[s], L);
+    g.flank = g.seqs[0].substr(0, pre) + std::string(mask, 'N') + g.seqs[0].substr(L - suf);
+    bb_group_info& I = g.info;
+    I.flank_len = L; I.prefix_len = pre; I.suffix_len = suf; I.mask_len = mask;
+    I.bar_lo = pre; I.bar_hi = pre + mask - 1;
+    I.pad_lo = pre >= BB_PADDING ? pre - BB_PADDING : 0;
+    I.pad_hi = pre + mask + BB_PADDING;
+    const uint32_t end = I.pad_hi < L ? I.pad_hi : L;
+    I.pattern_len = end - I.pad_lo;
+    g.pat[0].resize(n); g.pat[1].resize(n);
+    for (uint32_t s = 0; s < n; ++s) {
+        g.pat[0][s] = g.seqs[s].substr(I.pad_lo, I.pattern_len);
+        std::string r(I.pattern_len, 'N');
+        for (uint32_t i = 0; i < I.pattern_len; ++i) r[i] = (char)rc_char((uint8_t)g.pat[0][s][I.pattern_len - 1 - i]);
+        g.pat[1][s] = r;
+    }
+    g.type = d.type;
+    I.flank_k = d.flank_k >= 0 ? d.flank_k : edit_cut_off((int)(pre + suf));
+    I.bar_k1 = (int32_t)((float)I.pattern_len * 0.4f);
+    I.bar_k2 = (int32_t)I.pattern_len;
+    I.perfect_score = lodhi_all_match((int)(I.pad_hi - I.pad_lo));
+    (void)alpha;
+    return BB_OK;
+}
+
+struct Blob {
+    std::vector<uint8_t> b;
+    uint32_t alloc(size_t bytes) {
+        size_t o = (b.size() + 15) & ~(size_t)15;
+        b.resize(o + bytes, 0);
+        return (uint32_t)o;
+    }
+};
+
+}  // namespace
+
+struct bb_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bb_params params{};
+    std::vector<HostGroup> groups;
+    std::vector<bb_group_dev> gdev;
+    bb_group_dev* d_groups = nullptr;
+    uint8_t* d_tables = nullptr;
+    uint32_t counts_len = 0;
+    unsigned long long* d_counts = nullptr;
+    // work buffers
+    uint64_t cap_m = 0;  // entries of cnt/base (n*G*2+1)
+    uint32_t cap_reads = 0, cap_hits = 0;
+    uint32_t *d_cnt = nullptr, *d_base = nullptr, *d_sums = nullptr, *d_nrows = nullptr, *d_rowoff = nullptr;
+    uint32_t *d_hitcount = nullptr, *d_lists = nullptr, *d_listcnt = nullptr;
+    bb_hit_raw* d_raw = nullptr;
+    bb_hit* d_hits = nullptr;
+    bb_rowtmp* d_rows = nullptr;
+    // staging for the host-pointer variant
+    uint8_t* d_in_bases = nullptr; uint64_t cap_in_bases = 0;
+    uint64_t* d_in_offsets = nullptr; uint64_t cap_in_offsets = 0;
+    bb_row* d_out_rows = nullptr; uint64_t cap_out_rows = 0;
+    // synth
+    uint8_t* d_synth_table = nullptr;
+    bb_synth_params synth{};
+    // timing
+    bool timing = false;
+    hipEvent_t ev[K_COUNT + 1]{};
+    float ms[K_COUNT]{};
+    std::string last_error;
+};
+
+namespace {
+
+#define HIPCHK(ctx, call)                                                                        \
+    do {                                                                                         \
+        hipError_t e_ = (call);                                                                  \
+        if (e_ != hipSuccess) {                                                                  \
+            (ctx)->last_error = std::string(#call) + ": " + hipGetErrorString(e_);               \
+            return BB_E_HIP;                                                                     \
+        }                                                                                        \
+    } while (0)
+
+template <typename T>
+int grow(bb_ctx* c, T*& p, uint64_t& cap, uint64_t need) {
+    if (need <= cap && p) return BB_OK;
+    if (p) HIPCHK(c, hipFree(p));
+    p = nullptr;
+    uint64_t ncap = need + need / 4 + 64;
+    HIPCHK(c, hipMalloc((void**)&p, ncap * sizeof(T)));
+    cap = ncap;
+    return BB_OK;
+}
+
+void build_synth_tables(const std::vector<std::vector<std::string>>& seqs, bb_synth_params& P, std::vector<uint8_t>& table) {
+    P.n_groups = (uint32_t)seqs.size();
+    table.clear();
+    for (size_t g = 0; g < seqs.size() && g < BB_MAX_GROUPS; ++g) {
+        P.g[g].n_seqs = (uint32_t)seqs[g].size();
+        P.g[g].seq_len = (uint32_t)seqs[g][0].size();
+        P.g[g].off = (uint32_t)table.size();
+        for (auto& s : seqs[g]) table.insert(table.end(), s.begin(), s.end());
+    }
+}
+
+int upload_tables(bb_ctx* c) {
+    Blob blob;
+    c->gdev.resize(c->groups.size());
+    uint32_t count_off = 0;
+    const float alpha = c->params.alpha;
+    for (size_t gi = 0; gi < c->groups.size(); ++gi) {
+        const HostGroup& g = c->groups[gi];
+        bb_group_dev& D = c->gdev[gi];
+        memset(&D, 0, sizeof(D));
+        const int m = (int)g.info.flank_len, W = (m + 31) / 32, S = bb_peq_stride_words(W);
+        const int mb = (int)g.info.pattern_len, WB = (mb + 31) / 32, N = (int)g.seqs.size();
+        D.m = m; D.W = W; D.flank_k = g.info.flank_k;
+        D.bar_lo = (int)g.info.bar_lo; D.bar_hi = (int)g.info.bar_hi;
+        D.m_bar = mb; D.WB = WB; D.n_seqs = N; D.k1 = g.info.bar_k1; D.k2 = g.info.bar_k2;
+        D.rel_lo = (int)(g.info.bar_lo - g.info.pad_lo); D.rel_hi = (int)(g.info.bar_hi - g.info.pad_lo);
+        D.type = g.type; D.score0 = overhang_cost(alpha, m); D.count_off = (int)count_off; D.perfect = g.info.perfect_score;
+        count_off += (uint32_t)N + 1;
+        for (int s = 0; s < 2; ++s) {
+            D.off_peq_flank[s] = blob.alloc((size_t)256 * S * 4);
+            uint32_t* t = reinterpret_cast<uint32_t*>(blob.b.data() + D.off_peq_flank[s]);
+            for (int ch = 0; ch < 256; ++ch) {
+                const uint8_t tc = bb_text_code((uint8_t)ch);
+                for (int j = 0; j < m; ++j) {
+                    uint8_t pc = bb_text_code((uint8_t)g.flank[j]);
+                    if (s) pc = bb_comp_code(pc);  // rc strand: complement(pattern) vs reversed text
+                    if (pc & tc) t[ch * S + (j >> 5)] |= 1u << (j & 31);
+                }
+            }
+        }
+        D.off_pv0 = blob.alloc((size_t)BB_MAX_W * 4);
+        {
+            uint32_t* t = reinterpret_cast<uint32_t*>(blob.b.data() + D.off_pv0);
+            for (int j = 1; j <= m; ++j)
+                if (overhang_cost(alpha, j) - overhang_cost(alpha, j - 1) == 1) t[(j - 1) >> 5] |= 1u << ((j - 1) & 31);
+        }
+        D.off_ovh = blob.alloc((size_t)(m + 1) * 4);
+        {
+            int32_t* t = reinterpret_cast<int32_t*>(blob.b.data() + D.off_ovh);
+            for (int o = 0; o <= m; ++o) t[o] = overhang_cost(alpha, o);
+        }
+        const uint32_t peq_bar = blob.alloc((size_t)2 * 16 * N * WB * 4);
+        for (int s = 0; s < 2; ++s) {
+            D.off_peq_bar[s] = peq_bar + (uint32_t)((size_t)s * 16 * N * WB * 4);
+            uint32_t* t = reinterpret_cast<uint32_t*>(blob.b.data() + D.off_peq_bar[s]);
+            for (int code = 0; code < 16; ++code)
+                for (int p = 0; p < N; ++p)
+                    for (int j = 0; j < mb; ++j)
+                        if (bb_text_code((uint8_t)g.pat[s][p][j]) & code) t[((size_t)code * N + p) * WB + (j >> 5)] |= 1u << (j & 31);
+        }
+    }
+    c->counts_len = count_off;
+    HIPCHK(c, hipMalloc((void**)&c->d_tables, blob.b.size()));
+    HIPCHK(c, hipMemcpy(c->d_tables, blob.b.data(), blob.b.size(), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMalloc((void**)&c->d_groups, sizeof(bb_group_dev) * c->gdev.size()));
+    HIPCHK(c, hipMemcpy(c->d_groups, c->gdev.data(), sizeof(bb_group_dev) * c->gdev.size(), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMalloc((void**)&c->d_counts, sizeof(unsigned long long) * c->counts_len));
+    HIPCHK(c, hipMemset(c->d_counts, 0, sizeof(unsigned long long) * c->counts_len));
+    HIPCHK(c, hipMalloc((void**)&c->d_hitcount, 16));
+    HIPCHK(c, hipMalloc((void**)&c->d_listcnt, sizeof(uint32_t) * BB_MAX_GROUPS));
+    // synth tables
+    std::vector<std::vector<std::string>> seqs;
+    for (auto& g : c->groups) seqs.push_back(g.seqs);
+    std::vector<uint8_t> table;
+    build_synth_tables(seqs, c->synth, table);
+    HIPCHK(c, hipMalloc((void**)&c->d_synth_table, table.size()));
+    HIPCHK(c, hipMemcpy(c->d_synth_table, table.data(), table.size(), hipMemcpyHostToDevice));
+    return BB_OK;
+}
+
+int ensure_reads(bb_ctx* c, uint32_t n) {
+    const uint64_t M = (uint64_t)n * c->groups.size() * 2 + 1;
+    if (M > c->cap_m) {
+        uint64_t cap = 0;
+        int r;
+        if ((r = grow(c, c->d_cnt, cap, M))) return r;
+        cap = 0;
+        if ((r = grow(c, c->d_base, cap, M))) return r;
+        c->cap_m = cap;
+        uint64_t nb = (cap + 2047) / 2048 + 64, cs = 0;
+        if ((r = grow(c, c->d_sums, cs, nb))) return r;
+    }
+    if (n > c->cap_reads) {
+        uint64_t cap = 0;
+        int r;
+        if ((r = grow(c, c->d_nrows, cap, (uint64_t)n + 1))) return r;
+        cap = 0;
+        if ((r = grow(c, c->d_rowoff, cap, (uint64_t)n + 1))) return r;
+        c->cap_reads = (uint32_t)(cap - 1);
+    }
+    return BB_OK;
+}
+int ensure_hits(bb_ctx* c, uint64_t need) {
+    if (need <= c->cap_hits) return BB_OK;
+    uint64_t cap = 0;
+    int r;
+    if ((r = grow(c, c->d_raw, cap, need))) return r;
+    cap = 0;
+    if ((r = grow(c, c->d_hits, cap, need))) return r;
+    cap = 0;
+    if ((r = grow(c, c->d_rows, cap, need))) return r;
+    uint64_t lc = 0;
+    if ((r = grow(c, c->d_lists, lc, cap * c->groups.size()))) return r;
+    c->cap_hits = (uint32_t)cap;
+    return BB_OK;
+}
+
+int scan_u32(bb_ctx* c, const uint32_t* in, uint32_t* out, uint64_t n) {
+    const uint32_t nb = (uint32_t)((n + 2047) / 2048);
+    hipLaunchKernelGGL(k_scan_block, dim3(nb), dim3(256), 0, c->stream, in, out, n, c->d_sums);
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(64), 0, c->stream, c->d_sums, nb);
+    hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(256), 0, c->stream, out, n, (const uint32_t*)c->d_sums);
+    HIPCHK(c, hipGetLastError());
+    return BB_OK;
+}
+
+template <int W>
+void launch_scan(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n, uint32_t g) {
+    hipLaunchKernelGGL(k_flank_scan<W>, dim3((n + 255) / 256), dim3(256), 0, c->stream, d_bases, d_offsets, n,
+                       (const uint8_t*)c->d_tables, (const bb_group_dev*)c->d_groups, g, (uint32_t)c->groups.size(), c->d_cnt,
+                       c->d_raw, c->cap_hits, c->d_hitcount);
+}
+template <int W>
+void launch_trace(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n_hits, uint32_t g) {
+    hipLaunchKernelGGL(k_flank_trace<W>, dim3((n_hits + 63) / 64), dim3(64), 0, c->stream, d_bases, d_offsets,
+                       (const uint8_t*)c->d_tables, (const bb_group_dev*)c->d_groups, (uint32_t)c->groups.size(),
+                       (const bb_hit_raw*)c->d_raw, n_hits, (const uint32_t*)c->d_base, c->d_hits, g);
+}
+template <int WB>
+void launch_barcode(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n_hits, uint32_t g) {
+    const bb_group_dev& D = c->gdev[g];
+    const uint32_t N = (uint32_t)D.n_seqs;
+    const uint32_t hpb = N >= 256 ? 1 : 256 / N;
+    const uint32_t threads = ((hpb * N + 63) / 64) * 64;
+    const size_t peq_bytes = (size_t)2 * 16 * N * WB * 4;
+    const bool lds = peq_bytes <= 48 * 1024;
+    const size_t smem = (lds ? peq_bytes : 0) + (size_t)hpb * N * 8 + (size_t)hpb * 16 + (size_t)hpb * BB_MAX_WIN;
+    const uint32_t blocks = (n_hits + hpb - 1) / hpb;
+    const uint32_t* list = c->d_lists + (size_t)g * c->cap_hits;
+    if (lds)
+        hipLaunchKernelGGL((k_barcode<WB, true>), dim3(blocks), dim3(threads), smem, c->stream, d_bases, d_offsets,
+                           (const uint8_t*)c->d_tables, (const bb_group_dev*)c->d_groups, g, (const bb_hit*)c->d_hits, list,
+                           (const uint32_t*)c->d_listcnt, hpb, c->params.min_score, c->params.min_score_diff, c->d_rows);
+    else
+        hipLaunchKernelGGL((k_barcode<WB, false>), dim3(blocks), dim3(threads), smem, c->stream, d_bases, d_offsets,
+                           (const uint8_t*)c->d_tables, (const bb_group_dev*)c->d_groups, g, (const bb_hit*)c->d_hits, list,
+                           (const uint32_t*)c->d_listcnt, hpb, c->params.min_score, c->params.min_score_diff, c->d_rows);
+}
+
+void mark(bb_ctx* c, int i) {
+    if (c->timing) (void)hipEventRecord(c->ev[i], c->stream);
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* bb_strerror(int code) {
+    switch (code) {
+        case BB_OK: return "ok";
+        case BB_E_INVALID: return "invalid argument";
+        case BB_E_ONE_QUERY: return "a query group needs at least two sequences";
+        case BB_E_UNEQUAL_LEN: return "all sequences per group must be equally long";
+        case BB_E_NO_BARCODE: return "no barcode region found between shared prefix and suffix";
+        case BB_E_NO_FLANK: return "no shared prefix or suffix found";
+        case BB_E_NOT_IUPAC: return "sequence contains a character not supported by IUPAC";
+        case BB_E_CAPACITY: return "row buffer too small";
+        case BB_E_NO_DEVICE: return "no usable HIP device";
+        case BB_E_HIP: return "HIP runtime error";
+        case BB_E_UNSUPPORTED: return "query geometry outside the compiled kernel limits";
+        case BB_E_NOMEM: return "out of memory";
+        default: return "unknown error";
+    }
+}
+
+int bb_create(const bb_group_desc* groups, uint32_t n_groups, const bb_params* params, bb_ctx** out) {
+    if (!groups || !params || !out || n_groups == 0 || n_groups > BB_MAX_GROUPS) return BB_E_INVALID;
+    if (!(params->alpha >= 0.0f)) return BB_E_INVALID;
+    bb_ctx* c = new bb_ctx();
+    c->params = *params;
+    c->groups.resize(n_groups);
+    for (uint32_t i = 0; i < n_groups; ++i) {
+        int r = prep_group(groups[i], params->alpha, c->groups[i]);
+        if (r != BB_OK) { delete c; return r; }
+        const bb_group_info& I = c->groups[i].info;
+        if (I.flank_len > 32 * BB_MAX_W || I.pattern_len > 32 * BB_MAX_WB || I.flank_k > 63 ||
+            I.mask_len + (uint32_t)I.flank_k + 2 * BB_PADDING > BB_MAX_WIN || groups[i].n_seqs > 1024 ||
+            groups[i].n_seqs > 32767) {
+            delete c;
+            return BB_E_UNSUPPORTED;
+        }
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || params->device < 0 || params->device >= ndev) { delete c; return BB_E_NO_DEVICE; }
+    c->device = params->device;
+    if (hipSetDevice(c->device) != hipSuccess) { delete c; return BB_E_NO_DEVICE; }
+    if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return BB_E_NO_DEVICE; }
+    for (int i = 0; i <= K_COUNT; ++i)
+        if (hipEventCreate(&c->ev[i]) != hipSuccess) { delete c; return BB_E_NO_DEVICE; }
+    int r = upload_tables(c);
+    if (r != BB_OK) { fprintf(stderr, "barbell_amd: %s\n", c->last_error.c_str()); bb_destroy(c); return r; }
+    *out = c;
+    return BB_OK;
+}
+
+void bb_destroy(bb_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    void* ptrs[] = {c->d_groups, c->d_tables, c->d_counts, c->d_cnt, c->d_base, c->d_sums, c->d_nrows, c->d_rowoff, c->d_hitcount,
+                    c->d_lists, c->d_listcnt, c->d_raw, c->d_hits, c->d_rows, c->d_in_bases, c->d_in_offsets, c->d_out_rows,
+                    c->d_synth_table};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    for (int i = 0; i <= K_COUNT; ++i)
+        if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int bb_n_groups(const bb_ctx* c) { return c ? (int)c->groups.size() : BB_E_INVALID; }
+int bb_group_get_info(const bb_ctx* c, uint32_t g, bb_group_info* info) {
+    if (!c || g >= c->groups.size() || !info) return BB_E_INVALID;
+    *info = c->groups[g].info;
+    return BB_OK;
+}
+int bb_group_get_flank(const bb_ctx* c, uint32_t g, uint8_t* out) {
+    if (!c || g >= c->groups.size() || !out) return BB_E_INVALID;
+    memcpy(out, c->groups[g].flank.data(), c->groups[g].flank.size());
+    return BB_OK;
+}
+int bb_group_get_pattern(const bb_ctx* c, uint32_t g, uint32_t idx, int rc, uint8_t* out) {
+    if (!c || g >= c->groups.size() || !out || idx >= c->groups[g].seqs.size()) return BB_E_INVALID;
+    const std::string& s = c->groups[g].pat[rc ? 1 : 0][idx];
+    memcpy(out, s.data(), s.size());
+    return BB_OK;
+}
+
+int bb_annotate_batch_dev(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n, bb_row* d_rows,
+                          uint64_t rows_cap, uint64_t* n_rows) {
+    if (!c || !d_offsets || !n_rows || (!d_bases && n)) return BB_E_INVALID;
+    *n_rows = 0;
+    if (n == 0) return BB_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    const uint32_t G = (uint32_t)c->groups.size();
+    int r;
+    if ((r = ensure_reads(c, n))) return r;
+    if ((r = ensure_hits(c, (uint64_t)n * 3 + 1024))) return r;
+    const uint64_t M = (uint64_t)n * G * 2 + 1;
+    uint32_t n_hits = 0;
+    for (int attempt = 0;; ++attempt) {
+        mark(c, K_SCAN);
+        HIPCHK(c, hipMemsetAsync(c->d_hitcount, 0, 16, c->stream));
+        HIPCHK(c, hipMemsetAsync(c->d_cnt + (M - 1), 0, 4, c->stream));
+        for (uint32_t g = 0; g < G; ++g) {
+            switch (c->gdev[g].W) {
+                case 1: launch_scan<1>(c, d_bases, d_offsets, n, g); break;
+                case 2: launch_scan<2>(c, d_bases, d_offsets, n, g); break;
+                case 3: launch_scan<3>(c, d_bases, d_offsets, n, g); break;
+                default: launch_scan<4>(c, d_bases, d_offsets, n, g); break;
+            }
+        }
+        HIPCHK(c, hipGetLastError());
+        mark(c, K_PREFIX);
+        HIPCHK(c, hipMemcpyAsync(&n_hits, c->d_hitcount, 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (n_hits <= c->cap_hits) break;
+        if (attempt > 2) { c->last_error = "flank hit buffer overflow"; return BB_E_HIP; }
+        if ((r = ensure_hits(c, (uint64_t)n_hits + 1024))) return r;
+    }
+    if ((r = scan_u32(c, c->d_cnt, c->d_base, M))) return r;
+    mark(c, K_TRACE);
+    if (n_hits) {
+        for (uint32_t g = 0; g < G; ++g) {
+            switch (c->gdev[g].W) {
+                case 1: launch_trace<1>(c, d_bases, d_offsets, n_hits, g); break;
+                case 2: launch_trace<2>(c, d_bases, d_offsets, n_hits, g); break;
+                case 3: launch_trace<3>(c, d_bases, d_offsets, n_hits, g); break;
+                default: launch_trace<4>(c, d_bases, d_offsets, n_hits, g); break;
+            }
+        }
+        HIPCHK(c, hipGetLastError());
+    }
+    mark(c, K_LISTS);
+    if (n_hits) {
+        HIPCHK(c, hipMemsetAsync(c->d_listcnt, 0, sizeof(uint32_t) * BB_MAX_GROUPS, c->stream));
+        hipLaunchKernelGGL(k_hit_lists, dim3((n_hits + 255) / 256), dim3(256), 0, c->stream, (const bb_hit*)c->d_hits, n_hits,
+                           c->d_rows, c->d_lists, c->cap_hits, c->d_listcnt);
+    }
+    mark(c, K_BARCODE);
+    if (n_hits) {
+        for (uint32_t g = 0; g < G; ++g) {
+            if (c->gdev[g].WB == 1) launch_barcode<1>(c, d_bases, d_offsets, n_hits, g);
+            else launch_barcode<2>(c, d_bases, d_offsets, n_hits, g);
+        }
+        HIPCHK(c, hipGetLastError());
+    }
+    mark(c, K_COLLAPSE);
+    hipLaunchKernelGGL(k_collapse, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->d_rows, (const uint32_t*)c->d_base, n, G,
+                       c->d_nrows);
+    HIPCHK(c, hipMemsetAsync(c->d_nrows + n, 0, 4, c->stream));
+    if ((r = scan_u32(c, c->d_nrows, c->d_rowoff, (uint64_t)n + 1))) return r;
+    uint32_t total = 0;
+    HIPCHK(c, hipMemcpyAsync(&total, c->d_rowoff + n, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    *n_rows = total;
+    mark(c, K_EMIT);
+    if (total > rows_cap || (total && !d_rows)) return BB_E_CAPACITY;
+    if (total)
+        hipLaunchKernelGGL(k_emit, dim3((n + 255) / 256), dim3(256), 0, c->stream, (const bb_rowtmp*)c->d_rows,
+                           (const uint32_t*)c->d_base, (const uint32_t*)c->d_rowoff, n, G, (const bb_group_dev*)c->d_groups, d_rows,
+                           c->d_counts);
+    mark(c, K_COUNT);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->timing)
+        for (int i = 0; i < K_COUNT; ++i) (void)hipEventElapsedTime(&c->ms[i], c->ev[i], c->ev[i + 1]);
+    return BB_OK;
+}
+
+int bb_annotate_batch(bb_ctx* c, const uint8_t* bases, const uint64_t* offsets, uint32_t n, bb_row* rows, uint64_t rows_cap,
+                      uint64_t* n_rows) {
+    if (!c || !offsets || !n_rows || (!bases && n)) return BB_E_INVALID;
+    *n_rows = 0;
+    if (n == 0) return BB_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    const uint64_t nb = offsets[n];
+    int r;
+    if ((r = grow(c, c->d_in_bases, c->cap_in_bases, nb + 16))) return r;
+    if ((r = grow(c, c->d_in_offsets, c->cap_in_offsets, (uint64_t)n + 1))) return r;
+    uint64_t want = rows_cap < (uint64_t)n * 4 + 64 ? rows_cap : (uint64_t)n * 4 + 64;
+    if ((r = grow(c, c->d_out_rows, c->cap_out_rows, want ? want : 1))) return r;
+    HIPCHK(c, hipMemcpyAsync(c->d_in_bases, bases, nb, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_in_offsets, offsets, ((uint64_t)n + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    uint64_t dev_cap = c->cap_out_rows < rows_cap ? c->cap_out_rows : rows_cap;
+    r = bb_annotate_batch_dev(c, c->d_in_bases, c->d_in_offsets, n, c->d_out_rows, dev_cap, n_rows);
+    if (r == BB_E_CAPACITY && *n_rows <= rows_cap) {  // staging buffer was the limit, not the caller's
+        if ((r = grow(c, c->d_out_rows, c->cap_out_rows, *n_rows))) return r;
+        r = bb_annotate_batch_dev(c, c->d_in_bases, c->d_in_offsets, n, c->d_out_rows, c->cap_out_rows, n_rows);
+    }
+    if (r != BB_OK) return r;
+    if (*n_rows) HIPCHK(c, hipMemcpy(rows, c->d_out_rows, *n_rows * sizeof(bb_row), hipMemcpyDeviceToHost));
+    return BB_OK;
+}
+
+uint32_t bb_counts_len(const bb_ctx* c) { return c ? c->counts_len : 0; }
+int bb_counts(bb_ctx* c, uint64_t* out) {
+    if (!c || !out) return BB_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpy(out, c->d_counts, sizeof(uint64_t) * c->counts_len, hipMemcpyDeviceToHost));
+    return BB_OK;
+}
+uint64_t* bb_counts_dev(bb_ctx* c) { return c ? reinterpret_cast<uint64_t*>(c->d_counts) : nullptr; }
+int bb_counts_reset(bb_ctx* c) {
+    if (!c) return BB_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemset(c->d_counts, 0, sizeof(uint64_t) * c->counts_len));
+    return BB_OK;
+}
+
+int bb_n_kernels(void) { return K_COUNT; }
+const char* bb_kernel_name(int k) { return k >= 0 && k < K_COUNT ? kKernelNames[k] : ""; }
+float bb_last_kernel_ms(const bb_ctx* c, int k) { return c && k >= 0 && k < K_COUNT ? c->ms[k] : 0.f; }
+void bb_set_timing(bb_ctx* c, int enable) { if (c) c->timing = enable != 0; }
+const char* bb_last_error(const bb_ctx* c) { return c ? c->last_error.c_str() : ""; }
+
+// ---- synthetic reads (include/barbell_amd_synth.h) ---------------------------------------------
+static int synth_params_from_descs(const bb_group_desc* groups, uint32_t n_groups, uint64_t seed, uint32_t len_min, uint32_t len_max,
+                                   bb_synth_params& P, std::vector<uint8_t>& table) {
+    if (!groups || n_groups == 0 || n_groups > BB_MAX_GROUPS || len_min > len_max || len_min == 0) return BB_E_INVALID;
+    std::vector<std::vector<std::string>> seqs(n_groups);
+    for (uint32_t g = 0; g < n_groups; ++g) {
+        if (groups[g].n_seqs < 2) return BB_E_ONE_QUERY;
+        for (uint32_t s = 0; s < groups[g].n_seqs; ++s) {
+            if (groups[g].seq_lens[s] != groups[g].seq_lens[0]) return BB_E_UNEQUAL_LEN;
+            seqs[g].emplace_back((const char*)groups[g].seqs[s], groups[g].seq_lens[s]);
+        }
+    }
+    build_synth_tables(seqs, P, table);
+    P.seed = seed; P.len_min = len_min; P.len_max = len_max;
+    return BB_OK;
+}
+
+int bb_synth_offsets(uint64_t seed, uint32_t len_min, uint32_t len_max, uint64_t first_read, uint32_t n, uint64_t* offsets) {
+    if (!offsets || len_min > len_max || len_min == 0) return BB_E_INVALID;
+    bb_synth_params P{};
+    P.seed = seed; P.len_min = len_min; P.len_max = len_max;
+    uint64_t o = 0;
+    for (uint32_t i = 0; i < n; ++i) { offsets[i] = o; o += bb_synth_len(P, first_read + i); }
+    offsets[n] = o;
+    return BB_OK;
+}
+
+int bb_synth_reads_host(const bb_group_desc* groups, uint32_t n_groups, uint64_t seed, uint32_t len_min, uint32_t len_max,
+                        uint64_t first_read, uint32_t n, const uint64_t* offsets, uint8_t* bases) {
+    if (!offsets || !bases) return BB_E_INVALID;
+    bb_synth_params P{};
+    std::vector<uint8_t> table;
+    int r = synth_params_from_descs(groups, n_groups, seed, len_min, len_max, P, table);
+    if (r != BB_OK) return r;
+    for (uint32_t i = 0; i < n; ++i)
+        bb_synth_fill(P, table.data(), first_read + i, bases + offsets[i], (uint32_t)(offsets[i + 1] - offsets[i]));
+    return BB_OK;
+}
+
+int bb_synth_reads_dev(bb_ctx* c, uint64_t seed, uint32_t len_min, uint32_t len_max, uint64_t first_read, uint32_t n,
+                       const uint64_t* d_offsets, uint8_t* d_bases) {
+    if (!c || !d_offsets || !d_bases || len_min > len_max || len_min == 0) return BB_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    bb_synth_params P = c->synth;
+    P.seed = seed; P.len_min = len_min; P.len_max = len_max;
+    hipLaunchKernelGGL(k_synth, dim3((n + 255) / 256), dim3(256), 0, c->stream, P, (const uint8_t*)c->d_synth_table, first_read, n,
+                       d_offsets, d_bases);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return BB_OK;
+}
+
+}  // extern "C"

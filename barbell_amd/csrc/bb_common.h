@@ -1,0 +1,93 @@
+// bb_common.h — shared host/device definitions of the MI355X annotate hot path.
+// Everything here is first-party; nothing is shared with oracle/.
+#pragma once
+#include <stdint.h>
+
+#include "../../include/barbell_amd.h"
+
+#if defined(__HIPCC__)
+#define BB_HD __host__ __device__ __forceinline__
+#else
+#define BB_HD inline
+#endif
+
+#define BB_PADDING 10      // src/lib.rs:10
+#define BB_MAX_W 4         // flank pattern words (m <= 128)
+#define BB_MAX_WB 2        // padded barcode pattern words (m_bar <= 64)
+#define BB_MAX_WIN 128     // barcode window columns
+#define BB_MAX_GROUPS 8
+#define BB_MAX_OPS (64 + BB_MAX_WIN)  // unit ops of one barcode alignment
+
+// IUPAC base sets A=1 C=2 G=4 T=8 (case-insensitive, U=T, X = empty, non-letters invalid = 0xFF)
+BB_HD uint8_t bb_iupac(uint8_t c) {
+    switch (c & 0xDF) {  // fold case for letters
+        case 'A': return 1;
+        case 'C': return 2;
+        case 'G': return 4;
+        case 'T': case 'U': return 8;
+        case 'R': return 5;
+        case 'Y': return 10;
+        case 'S': return 6;
+        case 'W': return 9;
+        case 'K': return 12;
+        case 'M': return 3;
+        case 'B': return 14;
+        case 'D': return 13;
+        case 'H': return 11;
+        case 'V': return 7;
+        case 'N': return 15;
+        case 'X': return 0;
+        default: return 0xFF;
+    }
+}
+BB_HD bool bb_is_letter(uint8_t c) { uint8_t u = c & 0xDF; return u >= 'A' && u <= 'Z'; }
+// code of a read character: invalid characters match nothing
+BB_HD uint8_t bb_text_code(uint8_t c) {
+    if (!bb_is_letter(c)) return 0;
+    uint8_t k = bb_iupac(c);
+    return k == 0xFF ? 0 : k;
+}
+BB_HD uint8_t bb_comp_code(uint8_t k) { return (uint8_t)(((k & 1) << 3) | ((k & 8) >> 3) | ((k & 2) << 1) | ((k & 4) >> 1)); }
+
+// Per-group constants the kernels need (one per query group, in HBM, copied to LDS/SGPRs).
+struct bb_group_dev {
+    int32_t m;          // flank length (scan pattern)
+    int32_t W;          // ceil(m/32)
+    int32_t flank_k;
+    int32_t bar_lo, bar_hi;   // inclusive
+    int32_t m_bar, WB, n_seqs;
+    int32_t k1, k2;
+    int32_t rel_lo, rel_hi;   // bar_lo - pad_lo, bar_hi - pad_lo (searcher.rs:381-382)
+    int32_t type;             // BB_FTAG / BB_RTAG
+    int32_t score0;           // D[m][0] of the flank scan (floor(alpha*m))
+    int32_t count_off;        // offset of this group's counters in the histogram
+    int32_t _pad;
+    double perfect;
+    // byte offsets into the table blob
+    uint32_t off_peq_flank[2];   // [strand] 256 entries x PEQ_STRIDE(W) words, indexed by read byte
+    uint32_t off_pv0;            // W words: vertical +1 deltas of column 0 (left overhang)
+    uint32_t off_ovh;            // (m+1) int32: floor(alpha*o)
+    uint32_t off_pcode[2];       // [strand] m bytes: flank base sets (fwd, complemented)
+    uint32_t off_peq_bar[2];     // [strand] [16 codes][n_seqs] x WB words
+};
+
+BB_HD int bb_peq_stride_words(int W) { return W <= 2 ? 2 : 4; }
+
+// unordered flank hit, written by the scan kernel
+struct bb_hit_raw {
+    uint32_t read_idx;
+    uint32_t e;        // scan end index 0..n+m (in scan direction of the strand)
+    int16_t cost;
+    uint8_t group, strand;
+    uint32_t ordinal;  // order of discovery within (read, group, strand)
+};
+// ordered flank match after traceback + window computation
+struct bb_hit {
+    uint32_t read_idx;
+    uint32_t text_start, text_end;  // forward coordinates
+    uint32_t ws, we;                // barcode window [ws, we)
+    int16_t cost;
+    uint8_t group, strand;
+    uint8_t valid;                  // 0: get_matching_region returned None -> no row
+    uint8_t _pad[3];
+};

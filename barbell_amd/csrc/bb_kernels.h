@@ -1,0 +1,630 @@
+// bb_kernels.h — hand-written HIP kernels (gfx950 / CDNA4, wave64) of the annotate hot path.
+//
+// Pipeline per batch, all integer bit-twiddling, no MFMA:
+//   k_flank_scan   one lane per read: bit-parallel Myers/Hyyro semi-global scan of the N-masked
+//                  flank over the whole read, forward and reverse-complement strand in the same
+//                  lane (searcher.rs:438); Peq tables in LDS; local-minimum ends <= k emitted.
+//   scan           exclusive scan of per-(read,group,strand) hit counts -> deterministic slots.
+//   k_flank_trace  one lane per flank hit: (m+k)-column DP with move bits, traceback,
+//                  get_matching_region + window padding (cigar_parse.rs:71-82, searcher.rs:453-456).
+//   k_barcode      one lane per (flank hit, barcode): Myers forward pass over the <=128-column
+//                  window with move bits, first strictly-lowest local minimum, pass-1/pass-2
+//                  decision (searcher.rs:267-337), traceback, Lodhi score, sub-path mapping, per-hit
+//                  argmax + thresholds (searcher.rs:339-426) -> one row per hit.
+//   k_collapse     one lane per read: collapse_overlapping_matches (interval.rs:4-79).
+//   scan + k_emit  compaction of surviving rows in read order + per-barcode histogram.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "bb_common.h"
+#include "bb_synth.h"
+
+// ------------------------------------------------------------------------------------------------
+// Myers / Hyyro column step on a W-word (32-bit) vertical bit-vector.  Row r (1-based) <-> bit r-1.
+// pv/mv: vertical +1/-1 deltas of the previous column, updated in place to the new column.
+// d0: diagonal-zero vector, ph/mh: horizontal deltas (before the shift), all for the new column.
+// Top boundary row is all zero (text is free: D[0][i] = 0), so the horizontal carry-in is 0.
+// ------------------------------------------------------------------------------------------------
+template <int W>
+__device__ __forceinline__ void myers_step(uint32_t (&pv)[W], uint32_t (&mv)[W], const uint32_t (&eq)[W],
+                                           uint32_t (&d0)[W], uint32_t (&ph)[W], uint32_t (&mh)[W]) {
+    uint32_t carry = 0;
+#pragma unroll
+    for (int w = 0; w < W; ++w) {
+        uint32_t x = eq[w] & pv[w];
+        uint64_t s = (uint64_t)x + (uint64_t)pv[w] + (uint64_t)carry;
+        carry = (uint32_t)(s >> 32);
+        d0[w] = (((uint32_t)s) ^ pv[w]) | eq[w] | mv[w];
+    }
+#pragma unroll
+    for (int w = 0; w < W; ++w) {
+        ph[w] = mv[w] | ~(d0[w] | pv[w]);
+        mh[w] = pv[w] & d0[w];
+    }
+    uint32_t phs[W], mhs[W];
+#pragma unroll
+    for (int w = W - 1; w >= 0; --w) {
+        phs[w] = (ph[w] << 1) | (w ? (ph[w - 1] >> 31) : 0u);
+        mhs[w] = (mh[w] << 1) | (w ? (mh[w - 1] >> 31) : 0u);
+    }
+#pragma unroll
+    for (int w = 0; w < W; ++w) {
+        pv[w] = mhs[w] | ~(d0[w] | phs[w]);
+        mv[w] = phs[w] & d0[w];
+    }
+}
+
+// Move bits of the traceback preference (oracle [H3]): at cell (row, column) with cost g
+//   Match if diagonal-zero and characters match      (d0 & eq)
+//   Ins   else if D[j][i-1] == g-1                    (ph)
+//   Sub   else if D[j-1][i-1] == g-1                  (~d0)
+//   Del   otherwise
+// encoded as 2 bits per cell: 0 Match, 1 Sub, 2 Ins, 3 Del  ->  lo = Sub|Del, hi = Ins|Del.
+template <int W>
+__device__ __forceinline__ void move_bits(const uint32_t (&eq)[W], const uint32_t (&d0)[W], const uint32_t (&ph)[W],
+                                          uint32_t (&lo)[W], uint32_t (&hi)[W]) {
+#pragma unroll
+    for (int w = 0; w < W; ++w) {
+        uint32_t isM = d0[w] & eq[w];
+        uint32_t l = ~(isM | ph[w]);
+        lo[w] = l;
+        hi[w] = (ph[w] & ~isM) | (l & d0[w]);
+    }
+}
+
+template <int W>
+__device__ __forceinline__ uint32_t get_bit(const uint32_t (&v)[W], int bit) {
+    uint32_t word = v[0];
+#pragma unroll
+    for (int w = 1; w < W; ++w) word = (bit >> 5) == w ? v[w] : word;
+    return (word >> (bit & 31)) & 1u;
+}
+
+template <int W, int S>
+__device__ __forceinline__ void load_eq(const uint32_t* tab, uint32_t c, uint32_t (&eq)[W]) {
+    if constexpr (S == 2) {
+        uint2 v = *reinterpret_cast<const uint2*>(tab + c * 2);
+        eq[0] = v.x;
+        if constexpr (W > 1) eq[1] = v.y;
+    } else {
+        uint4 v = *reinterpret_cast<const uint4*>(tab + c * 4);
+        eq[0] = v.x;
+        if constexpr (W > 1) eq[1] = v.y;
+        if constexpr (W > 2) eq[2] = v.z;
+        if constexpr (W > 3) eq[3] = v.w;
+    }
+}
+
+// streaming local-minimum rule (oracle [H1]); evaluated lazily: only steps that touch the
+// <= k zone matter, and entering the zone from above is a strict decrease, so `dec` is always
+// fresh when it is read.
+struct lm_lane {
+    int32_t prev;
+    uint32_t dec;
+    uint32_t nrep;
+};
+
+__device__ __forceinline__ void emit_hit(bb_hit_raw* hits, uint32_t cap, uint32_t* count, uint32_t read, uint32_t e,
+                                         int32_t cost, uint32_t g, uint32_t strand, uint32_t ordinal) {
+    uint32_t slot = atomicAdd(count, 1u);
+    if (slot < cap) {
+        bb_hit_raw h;
+        h.read_idx = read; h.e = e; h.cost = (int16_t)cost; h.group = (uint8_t)g; h.strand = (uint8_t)strand; h.ordinal = ordinal;
+        hits[slot] = h;
+    }
+}
+
+#define BB_LM_STEP(ST, CUR, IDX, STRAND)                                                        \
+    do {                                                                                        \
+        int32_t cur_ = (CUR);                                                                   \
+        if (min(cur_, ST.prev) <= kk) {                                                         \
+            if (cur_ > ST.prev) {                                                               \
+                if (ST.dec && ST.prev <= kk)                                                    \
+                    emit_hit(hits, hit_cap, hit_count, read, (IDX)-1, ST.prev, g, STRAND, ST.nrep++); \
+                ST.dec = 0;                                                                     \
+            } else if (cur_ < ST.prev) {                                                        \
+                ST.dec = 1;                                                                     \
+            }                                                                                   \
+        }                                                                                       \
+        ST.prev = cur_;                                                                         \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// k_flank_scan: grid = ceil(n_reads/256) blocks of 256 lanes, one read per lane, one launch per group.
+// ------------------------------------------------------------------------------------------------
+template <int W>
+__global__ __launch_bounds__(256) void k_flank_scan(const uint8_t* __restrict__ bases, const uint64_t* __restrict__ offsets,
+                                                    uint32_t n_reads, const uint8_t* __restrict__ tables,
+                                                    const bb_group_dev* __restrict__ groups, uint32_t g, uint32_t n_groups,
+                                                    uint32_t* __restrict__ cnt, bb_hit_raw* __restrict__ hits,
+                                                    uint32_t hit_cap, uint32_t* __restrict__ hit_count) {
+    constexpr int S = (W <= 2 ? 2 : 4);
+    __shared__ __attribute__((aligned(16))) uint32_t s_peq[2][256 * S];
+    const bb_group_dev G = groups[g];
+    {
+        const uint32_t* src0 = reinterpret_cast<const uint32_t*>(tables + G.off_peq_flank[0]);
+        const uint32_t* src1 = reinterpret_cast<const uint32_t*>(tables + G.off_peq_flank[1]);
+        for (int i = threadIdx.x; i < 256 * S; i += 256) { s_peq[0][i] = src0[i]; s_peq[1][i] = src1[i]; }
+    }
+    __syncthreads();
+    const uint32_t read = blockIdx.x * 256u + threadIdx.x;
+    if (read >= n_reads) return;
+    const uint64_t off = offsets[read];
+    const uint32_t n = (uint32_t)(offsets[read + 1] - off);
+    const uint8_t* rb = bases + off;
+    const int32_t kk = G.flank_k;
+    const int m = G.m;
+    const int TW = (m - 1) >> 5, TB = (m - 1) & 31;
+    const uint32_t* pv0 = reinterpret_cast<const uint32_t*>(tables + G.off_pv0);
+    const int32_t* ovh = reinterpret_cast<const int32_t*>(tables + G.off_ovh);
+
+    uint32_t fpv[W], fmv[W], rpv[W], rmv[W];
+#pragma unroll
+    for (int w = 0; w < W; ++w) { fpv[w] = rpv[w] = pv0[w]; fmv[w] = rmv[w] = 0; }
+    int32_t fs = G.score0, rs = G.score0;
+    lm_lane fl = {G.score0, 1u, 0u}, rl = {G.score0, 1u, 0u};
+
+    auto step2 = [&](uint32_t cf, uint32_t cr, uint32_t idx) {
+        uint32_t eq[W], d0[W], ph[W], mh[W];
+        load_eq<W, S>(s_peq[0], cf, eq);
+        myers_step<W>(fpv, fmv, eq, d0, ph, mh);
+        fs += (int32_t)((ph[TW] >> TB) & 1u) - (int32_t)((mh[TW] >> TB) & 1u);
+        BB_LM_STEP(fl, fs, idx, 0u);
+        load_eq<W, S>(s_peq[1], cr, eq);
+        myers_step<W>(rpv, rmv, eq, d0, ph, mh);
+        rs += (int32_t)((ph[TW] >> TB) & 1u) - (int32_t)((mh[TW] >> TB) & 1u);
+        BB_LM_STEP(rl, rs, idx, 1u);
+    };
+
+    const uint32_t nblk = n >> 4;
+    for (uint32_t b = 0; b < nblk; ++b) {
+        uint32_t f[4], r[4];
+        __builtin_memcpy(f, rb + 16u * b, 16);
+        __builtin_memcpy(r, rb + (n - 16u * (b + 1)), 16);
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            uint32_t cf = (f[s >> 2] >> (8 * (s & 3))) & 0xFFu;
+            uint32_t cr = (r[(15 - s) >> 2] >> (8 * ((15 - s) & 3))) & 0xFFu;
+            step2(cf, cr, 16u * b + (uint32_t)s + 1u);
+        }
+    }
+    for (uint32_t t = 16u * nblk; t < n; ++t) step2(rb[t], rb[n - 1 - t], t + 1u);
+
+    // right overhang (oracle [H4]): C[n+o] = D[m-o][n] + floor(alpha*o), o = 1..m
+    {
+        int32_t fd = fs, rd = rs;
+        for (int o = 1; o <= m; ++o) {
+            fd -= (int32_t)((fpv[TW] >> TB) & 1u) - (int32_t)((fmv[TW] >> TB) & 1u);
+            rd -= (int32_t)((rpv[TW] >> TB) & 1u) - (int32_t)((rmv[TW] >> TB) & 1u);
+#pragma unroll
+            for (int w = W - 1; w >= 0; --w) {
+                fpv[w] = (fpv[w] << 1) | (w ? (fpv[w - 1] >> 31) : 0u);
+                fmv[w] = (fmv[w] << 1) | (w ? (fmv[w - 1] >> 31) : 0u);
+                rpv[w] = (rpv[w] << 1) | (w ? (rpv[w - 1] >> 31) : 0u);
+                rmv[w] = (rmv[w] << 1) | (w ? (rmv[w - 1] >> 31) : 0u);
+            }
+            int32_t oc = ovh[o];
+            BB_LM_STEP(fl, fd + oc, n + (uint32_t)o, 0u);
+            BB_LM_STEP(rl, rd + oc, n + (uint32_t)o, 1u);
+        }
+        if (fl.dec && fl.prev <= kk) emit_hit(hits, hit_cap, hit_count, read, n + (uint32_t)m, fl.prev, g, 0u, fl.nrep++);
+        if (rl.dec && rl.prev <= kk) emit_hit(hits, hit_cap, hit_count, read, n + (uint32_t)m, rl.prev, g, 1u, rl.nrep++);
+    }
+    cnt[((uint64_t)read * n_groups + g) * 2 + 0] = fl.nrep;
+    cnt[((uint64_t)read * n_groups + g) * 2 + 1] = rl.nrep;
+}
+
+// ------------------------------------------------------------------------------------------------
+// exclusive scan of uint32 (3 small kernels): 2048 elements per block
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_scan_block(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint64_t n,
+                                                    uint32_t* __restrict__ sums) {
+    __shared__ uint32_t s_w[4];
+    const uint64_t base = (uint64_t)blockIdx.x * 2048u + (uint64_t)threadIdx.x * 8u;
+    uint32_t v[8], t = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { v[i] = base + i < n ? in[base + i] : 0u; }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { uint32_t x = v[i]; v[i] = t; t += x; }
+    // wave inclusive scan of t
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t inc = t;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { uint32_t y = __shfl_up(inc, d, 64); if (lane >= d) inc += y; }
+    if (lane == 63) s_w[wv] = inc;
+    __syncthreads();
+    uint32_t wbase = 0;
+    for (int i = 0; i < wv; ++i) wbase += s_w[i];
+    const uint32_t excl = wbase + inc - t;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) if (base + i < n) out[base + i] = v[i] + excl;
+    if (threadIdx.x == 255) sums[blockIdx.x] = wbase + inc;
+}
+__global__ __launch_bounds__(64) void k_scan_sums(uint32_t* __restrict__ sums, uint32_t nb) {
+    // single wave, sequential chunks of 64 with carry
+    uint32_t carry = 0;
+    const int lane = threadIdx.x;
+    for (uint32_t b = 0; b < nb; b += 64) {
+        uint32_t x = b + lane < nb ? sums[b + lane] : 0u;
+        uint32_t inc = x;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { uint32_t y = __shfl_up(inc, d, 64); if (lane >= d) inc += y; }
+        if (b + lane < nb) sums[b + lane] = carry + inc - x;
+        carry += __shfl(inc, 63, 64);
+    }
+}
+__global__ __launch_bounds__(256) void k_scan_add(uint32_t* __restrict__ out, uint64_t n, const uint32_t* __restrict__ sums) {
+    const uint64_t base = (uint64_t)blockIdx.x * 2048u + (uint64_t)threadIdx.x * 8u;
+    const uint32_t a = sums[blockIdx.x];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) if (base + i < n) out[base + i] += a;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_flank_trace: one lane per raw flank hit.  Recomputes the DP on the last m+k columns before the
+// hit's end with move bits kept per column (private memory), walks back, and produces the ordered
+// bb_hit (flank coordinates + barcode window).
+// ------------------------------------------------------------------------------------------------
+template <int W>
+__global__ __launch_bounds__(64) void k_flank_trace(const uint8_t* __restrict__ bases, const uint64_t* __restrict__ offsets,
+                                                    const uint8_t* __restrict__ tables, const bb_group_dev* __restrict__ groups,
+                                                    uint32_t n_groups, const bb_hit_raw* __restrict__ raw, uint32_t n_hits,
+                                                    const uint32_t* __restrict__ slot_base, bb_hit* __restrict__ hits, uint32_t g_sel) {
+    constexpr int S = (W <= 2 ? 2 : 4);
+    constexpr int MAXC = 32 * W + 64;
+    const uint32_t t = blockIdx.x * 64u + threadIdx.x;
+    if (t >= n_hits) return;
+    const bb_hit_raw h = raw[t];
+    if (groups[h.group].W != W || (g_sel != 0xFFFFFFFFu && h.group != g_sel)) return;
+    const bb_group_dev G = groups[h.group];
+    const uint64_t off = offsets[h.read_idx];
+    const int32_t n = (int32_t)(offsets[h.read_idx + 1] - off);
+    const uint8_t* rb = bases + off;
+    const int m = G.m, k = G.flank_k;
+    const uint32_t* peq = reinterpret_cast<const uint32_t*>(tables + G.off_peq_flank[h.strand]);
+    const uint32_t* pv0 = reinterpret_cast<const uint32_t*>(tables + G.off_pv0);
+    const int32_t* ovh = reinterpret_cast<const int32_t*>(tables + G.off_ovh);
+
+    const int32_t e = (int32_t)h.e;
+    const int32_t o = e > n ? e - n : 0;
+    const int32_t j0 = m - o, i0 = e > n ? n : e;
+    int32_t s0 = i0 - (m + k);
+    if (s0 < 0) s0 = 0;
+    const int32_t w = i0 - s0;  // <= m + k < MAXC
+
+    uint32_t lo[MAXC][W], hi[MAXC][W];
+    uint32_t pv[W], mv[W];
+#pragma unroll
+    for (int x = 0; x < W; ++x) {
+        if (s0 == 0) pv[x] = pv0[x];
+        else { int bits = m - 32 * x; pv[x] = bits >= 32 ? 0xFFFFFFFFu : (bits > 0 ? ((1u << bits) - 1u) : 0u); }
+        mv[x] = 0;
+    }
+    for (int32_t c = 1; c <= w; ++c) {
+        const int32_t p = s0 + c - 1;  // scan position
+        const uint32_t ch = rb[h.strand ? (n - 1 - p) : p];
+        uint32_t eq[W], d0[W], ph[W], mh[W], l[W], hh[W];
+        load_eq<W, S>(peq, ch, eq);
+        myers_step<W>(pv, mv, eq, d0, ph, mh);
+        move_bits<W>(eq, d0, ph, l, hh);
+#pragma unroll
+        for (int x = 0; x < W; ++x) { lo[c][x] = l[x]; hi[c][x] = hh[x]; }
+    }
+    (void)ovh;
+    // traceback from (j0, w)
+    int32_t j = j0, i = w, cnt = 0, first_txt = 0, last_txt = 0;
+    while (j > 0) {
+        uint32_t op;
+        if (i == 0) {
+            if (s0 == 0) break;  // left overhang: remaining pattern is outside the read
+            op = 3u;
+        } else {
+            const int bit = j - 1;
+            uint32_t lw = lo[i][0], hw = hi[i][0];
+#pragma unroll
+            for (int x = 1; x < W; ++x) { lw = (bit >> 5) == x ? lo[i][x] : lw; hw = (bit >> 5) == x ? hi[i][x] : hw; }
+            op = ((lw >> (bit & 31)) & 1u) | (((hw >> (bit & 31)) & 1u) << 1);
+        }
+        if (op != 2u) --j;
+        if (op != 3u) --i;
+        if (j >= G.bar_lo && j <= G.bar_hi) {  // path cell Pos(j, s0+i) of this op
+            const int32_t sp = s0 + i;
+            int32_t f = h.strand ? (n - 1 - sp) : sp;
+            if (f < 0) f = 0;
+            if (cnt == 0) last_txt = f;
+            first_txt = f;
+            ++cnt;
+        }
+    }
+    const int32_t ts = s0 + i, te = i0;
+    bb_hit out;
+    out.read_idx = h.read_idx;
+    out.text_start = (uint32_t)(h.strand ? n - te : ts);
+    out.text_end = (uint32_t)(h.strand ? n - ts : te);
+    out.cost = h.cost; out.group = h.group; out.strand = h.strand;
+    out.valid = cnt >= 2;
+    int32_t rlo = first_txt < last_txt ? first_txt : last_txt, rhi = first_txt < last_txt ? last_txt : first_txt;
+    int32_t ws = rlo >= BB_PADDING ? rlo - BB_PADDING : 0;
+    int32_t we = rhi + BB_PADDING < n ? rhi + BB_PADDING : n;
+    if (we < ws) we = ws;
+    out.ws = (uint32_t)ws; out.we = (uint32_t)we;
+    out._pad[0] = out._pad[1] = out._pad[2] = 0;
+    const uint32_t slot = slot_base[((uint64_t)h.read_idx * n_groups + h.group) * 2 + h.strand] + h.ordinal;
+    hits[slot] = out;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_barcode: block = HPB hits x LPH lanes (LPH = n_seqs).  One lane per (hit, barcode pattern).
+// ------------------------------------------------------------------------------------------------
+struct bb_rowtmp {  // one per hit
+    bb_row row;
+    uint32_t valid;
+};
+
+__device__ __forceinline__ int32_t rel_dist_to_end(int64_t pos, int64_t read_len) {  // searcher.rs:183-199
+    if (pos < 0) return 1;
+    if (pos <= read_len / 2) return pos == 0 ? 1 : (int32_t)pos;
+    if (pos == read_len) return -1;
+    return (int32_t)-(read_len - pos);
+}
+
+template <int WB, bool PEQ_LDS>
+__global__ __launch_bounds__(1024) void k_barcode(const uint8_t* __restrict__ bases, const uint64_t* __restrict__ offsets,
+                                                  const uint8_t* __restrict__ tables, const bb_group_dev* __restrict__ groups,
+                                                  uint32_t g, const bb_hit* __restrict__ hits, const uint32_t* __restrict__ hit_list,
+                                                  const uint32_t* __restrict__ list_cnt, uint32_t hpb, double min_score, double min_score_diff,
+                                                  bb_rowtmp* __restrict__ rows) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const bb_group_dev G = groups[g];
+    const uint32_t n_list = list_cnt[g];
+    if (blockIdx.x * hpb >= n_list) return;
+    const int N = G.n_seqs, m = G.m_bar;
+    // LDS carve: [peq: 2*16*N*WB words][win: hpb*BB_MAX_WIN bytes][score: hpb*N doubles][cnt/top: hpb*4 ints]
+    uint32_t* s_peq = reinterpret_cast<uint32_t*>(smem);
+    size_t o = PEQ_LDS ? (size_t)2 * 16 * N * WB * 4 : 0;
+    double* s_score = reinterpret_cast<double*>(smem + o);
+    o += (size_t)hpb * N * 8;
+    int32_t* s_int = reinterpret_cast<int32_t*>(smem + o);  // [hpb][4]: cnt1, top, ncand, unused
+    o += (size_t)hpb * 16;
+    uint8_t* s_win = smem + o;
+
+    const uint32_t* gpeq0 = reinterpret_cast<const uint32_t*>(tables + G.off_peq_bar[0]);
+    if (PEQ_LDS) {
+        const int words = 2 * 16 * N * WB;  // strand-1 table follows strand-0 contiguously
+        for (int i = threadIdx.x; i < words; i += blockDim.x) s_peq[i] = gpeq0[i];
+    }
+    const int hl = threadIdx.x / N;       // local hit
+    const int p = threadIdx.x - hl * N;   // pattern index
+    const uint32_t li = blockIdx.x * hpb + hl;
+    const bool active = hl < (int)hpb && li < n_list;
+    bb_hit H;
+    uint32_t hit_idx = 0;
+    int32_t wn = 0;
+    if (active) {
+        hit_idx = hit_list[li];
+        H = hits[hit_idx];
+        wn = (int32_t)(H.we - H.ws);
+        const uint8_t* rb = bases + offsets[H.read_idx];
+        for (int c = p; c < wn; c += N) s_win[hl * BB_MAX_WIN + c] = bb_text_code(rb[H.ws + c]);
+        if (p == 0) { s_int[hl * 4 + 0] = 0; s_int[hl * 4 + 1] = -1; s_int[hl * 4 + 2] = 0; }
+    }
+    __syncthreads();
+
+    // ---- forward pass with move bits ----
+    uint32_t lo[BB_MAX_WIN + 1][WB], hi[BB_MAX_WIN + 1][WB];
+    int32_t best_cost = 0x7FFFFFFF, best_pos = -1;
+    if (active) {
+        const uint32_t* peq = PEQ_LDS ? s_peq + (size_t)H.strand * 16 * N * WB
+                                      : gpeq0 + (size_t)H.strand * 16 * N * WB;
+        uint32_t pv[WB], mv[WB];
+#pragma unroll
+        for (int x = 0; x < WB; ++x) { int bits = m - 32 * x; pv[x] = bits >= 32 ? 0xFFFFFFFFu : (bits > 0 ? ((1u << bits) - 1u) : 0u); mv[x] = 0; }
+        const int TW = (m - 1) >> 5, TB = (m - 1) & 31;
+        int32_t score = m, prev = m;
+        uint32_t dec = 1;
+        for (int32_t c = 1; c <= wn; ++c) {
+            const uint32_t code = s_win[hl * BB_MAX_WIN + c - 1];
+            uint32_t eq[WB], d0[WB], ph[WB], mh[WB], l[WB], hh[WB];
+            const uint32_t* e = peq + ((size_t)code * N + p) * WB;
+#pragma unroll
+            for (int x = 0; x < WB; ++x) eq[x] = e[x];
+            myers_step<WB>(pv, mv, eq, d0, ph, mh);
+            move_bits<WB>(eq, d0, ph, l, hh);
+#pragma unroll
+            for (int x = 0; x < WB; ++x) { lo[c][x] = l[x]; hi[c][x] = hh[x]; }
+            score += (int32_t)((ph[TW] >> TB) & 1u) - (int32_t)((mh[TW] >> TB) & 1u);
+            // local minima (every position is <= k2 = m): first strictly-lowest (searcher.rs:294-300)
+            if (score > prev) {
+                if (dec && prev < best_cost) { best_cost = prev; best_pos = c - 1; }
+                dec = 0;
+            } else if (score < prev) dec = 1;
+            prev = score;
+        }
+        if (dec && prev < best_cost) { best_cost = prev; best_pos = wn; }
+        if (best_pos >= 0 && best_cost <= G.k1) atomicAdd(&s_int[hl * 4 + 0], 1);
+        if (best_pos >= 0 && best_cost <= G.k2) atomicAdd(&s_int[hl * 4 + 2], 1);
+    }
+    __syncthreads();
+
+    // ---- pass decision (searcher.rs:303-328), traceback, Lodhi, sub-path ----
+    double s_norm = -1.0;
+    int32_t pat_lo = 0, pat_hi = 0, txt_lo = 0, txt_hi = 0, bcost = 0;
+    bool cand = false;
+    if (active) {
+        const int cnt1 = s_int[hl * 4 + 0];
+        const bool pass2 = cnt1 <= 1 && G.k1 < G.k2;
+        cand = best_pos >= 0 && (pass2 ? best_cost <= G.k2 : best_cost <= G.k1);
+        if (cand) {
+            uint8_t ops[BB_MAX_OPS];  // reversed
+            int nops = 0;
+            int32_t j = m, i = best_pos;
+            while (j > 0) {
+                uint32_t op;
+                if (i == 0) op = 3u;
+                else {
+                    const int bit = j - 1;
+                    uint32_t lw = lo[i][0], hw = hi[i][0];
+#pragma unroll
+                    for (int x = 1; x < WB; ++x) { lw = (bit >> 5) == x ? lo[i][x] : lw; hw = (bit >> 5) == x ? hi[i][x] : hw; }
+                    op = ((lw >> (bit & 31)) & 1u) | (((hw >> (bit & 31)) & 1u) << 1);
+                }
+                ops[nops++] = (uint8_t)op;
+                if (op != 2u) --j;
+                if (op != 3u) --i;
+            }
+            // forward walk: Lodhi (oracle [H8]) + map_pat_to_text_with_cost (cigar_parse.rs:6-68)
+            double a1 = 0.0, a2 = 0.0, sc = 0.0;
+            int32_t pj = 0, ti = i;
+            bool any = false;
+            for (int t = nops - 1; t >= 0; --t) {
+                const uint32_t op = ops[t];
+                if (op == 0u) { sc = sc + 0.5 * a2; a2 = 0.5 * (a2 + a1); a1 = 0.5 * (a1 + 1.0); }
+                else { a2 = 0.5 * a2; a1 = 0.5 * a1; }
+                if (pj >= G.rel_lo && pj < G.rel_hi) {
+                    if (!any) { any = true; pat_lo = pj; txt_lo = ti; }
+                    pat_hi = pj + 1; txt_hi = ti + 1; bcost += op != 0u;
+                }
+                if (op != 2u) ++pj;
+                if (op != 3u) ++ti;
+            }
+            s_norm = G.perfect > 0.0 ? sc / G.perfect : 0.0;
+        }
+        s_score[hl * N + p] = s_norm;
+    }
+    __syncthreads();
+    if (active && p == 0) {
+        // stable sort descending by s_norm (searcher.rs:377): top = first maximum, second = best of the rest
+        int top = -1, second = -1;
+        double ts = 0.0, ss = 0.0;
+        for (int q = 0; q < N; ++q) { double v = s_score[hl * N + q]; if (v >= 0.0 && (top < 0 || v > ts)) { top = q; ts = v; } }
+        for (int q = 0; q < N; ++q) { double v = s_score[hl * N + q]; if (v >= 0.0 && q != top && (second < 0 || v > ss)) { second = q; ss = v; } }
+        bool valid = top >= 0 && ts >= min_score;                         // searcher.rs:391-396
+        if (valid && second >= 0) valid = (ts - ss) >= min_score_diff;
+        s_int[hl * 4 + 1] = valid ? top : -1;
+    }
+    __syncthreads();
+    if (active) {
+        const int top = s_int[hl * 4 + 1];
+        const uint32_t read_len = (uint32_t)(offsets[H.read_idx + 1] - offsets[H.read_idx]);
+        if ((top >= 0 && p == top) || (top < 0 && p == 0)) {
+            bb_rowtmp R;
+            bb_row& r = R.row;
+            r.read_idx = H.read_idx; r.read_len = read_len;
+            r.rel_dist_to_end = rel_dist_to_end((int64_t)H.text_start, (int64_t)read_len);
+            r.read_start_flank = H.text_start; r.read_end_flank = H.text_end;
+            r.flank_cost = H.cost; r.group_idx = H.group; r.strand = H.strand;
+            r._pad[0] = r._pad[1] = r._pad[2] = 0;
+            if (top >= 0) {                                                // searcher.rs:398-416
+                r.read_start_bar = H.ws + (uint32_t)txt_lo; r.read_end_bar = H.ws + (uint32_t)txt_hi;
+                r.bar_start = H.ws + (uint32_t)pat_lo; r.bar_end = H.ws + (uint32_t)pat_hi;
+                r.match_type = (uint8_t)G.type; r.barcode_cost = (int16_t)bcost; r.barcode_idx = (int16_t)top;
+            } else {                                                       // searcher.rs:241-265
+                r.read_start_bar = H.text_start; r.read_end_bar = H.text_end;
+                r.bar_start = 0; r.bar_end = 0;
+                r.match_type = (uint8_t)(G.type == BB_FTAG ? BB_FFLANK : BB_RFLANK);
+                r.barcode_cost = (int16_t)G.m_bar; r.barcode_idx = -1;
+            }
+            R.valid = 1;
+            rows[hit_idx] = R;
+        }
+    }
+}
+
+// hits whose get_matching_region was None produce no row (searcher.rs:445-449); also builds the
+// per-group hit lists for k_barcode.
+__global__ __launch_bounds__(256) void k_hit_lists(const bb_hit* __restrict__ hits, uint32_t n_hits, bb_rowtmp* __restrict__ rows,
+                                                   uint32_t* __restrict__ lists, uint32_t list_stride, uint32_t* __restrict__ list_cnt) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= n_hits) return;
+    const bb_hit h = hits[t];
+    if (!h.valid) { rows[t].valid = 0; return; }
+    const uint32_t s = atomicAdd(&list_cnt[h.group], 1u);
+    lists[(size_t)h.group * list_stride + s] = t;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_collapse: one lane per read; rows of the read are rows[b0..b1) in reference order
+// (group, forward hits, rc hits).  collapse_overlapping_matches(.., 0.8) in place (interval.rs:4-79).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool rows_overlap(const bb_row& a, const bb_row& b, float thr) {  // interval.rs:30-42
+    const uint32_t start = max(a.read_start_flank, b.read_start_flank);
+    const uint32_t end = min(a.read_end_flank, b.read_end_flank);
+    if (end <= start) return false;
+    const uint32_t overlap = end - start;
+    const uint32_t min_len = min(a.read_end_flank - a.read_start_flank, b.read_end_flank - b.read_start_flank);
+    return ((float)overlap / (float)min_len) >= thr;
+}
+__device__ __forceinline__ int rows_cmp(const bb_row& a, const bb_row& b) {  // interval.rs:48-76
+    const int pa = (a.match_type == BB_FTAG || a.match_type == BB_RTAG) ? 1 : 2;
+    const int pb = (b.match_type == BB_FTAG || b.match_type == BB_RTAG) ? 1 : 2;
+    if (pa != pb) return pa < pb ? -1 : 1;
+    if (pa == 1) {
+        if (a.barcode_cost != b.barcode_cost) return a.barcode_cost < b.barcode_cost ? -1 : 1;
+        if (a.flank_cost != b.flank_cost) return a.flank_cost < b.flank_cost ? -1 : 1;
+        return 0;
+    }
+    const uint32_t la = a.read_end_flank - a.read_start_flank, lb = b.read_end_flank - b.read_start_flank;
+    if (la != lb) return la > lb ? -1 : 1;
+    return 0;
+}
+__global__ __launch_bounds__(256) void k_collapse(bb_rowtmp* __restrict__ rows, const uint32_t* __restrict__ slot_base,
+                                                  uint32_t n_reads, uint32_t n_groups, uint32_t* __restrict__ nrows) {
+    const uint32_t read = blockIdx.x * 256u + threadIdx.x;
+    if (read >= n_reads) return;
+    const uint32_t b0 = slot_base[(uint64_t)read * n_groups * 2], b1 = slot_base[(uint64_t)(read + 1) * n_groups * 2];
+    if (b0 == b1) { nrows[read] = 0; return; }
+    bb_rowtmp* R = rows + b0;
+    int n = 0;
+    for (uint32_t i = 0; i < b1 - b0; ++i)  // drop hits without a row, keep order
+        if (R[i].valid) { if ((int)i != n) R[n].row = R[i].row; ++n; }
+    for (int i = 1; i < n; ++i) {  // stable insertion sort by read_start_flank (interval.rs:12)
+        const bb_row x = R[i].row;
+        int j = i - 1;
+        while (j >= 0 && R[j].row.read_start_flank > x.read_start_flank) { R[j + 1].row = R[j].row; --j; }
+        R[j + 1].row = x;
+    }
+    int out = 0, gs = 0;
+    for (int i = 1; i <= n; ++i) {
+        bool joins = false;
+        if (i < n) {
+            const bb_row cur = R[i].row;
+            for (int q = gs; q < i && !joins; ++q) joins = rows_overlap(R[q].row, cur, 0.8f);
+        }
+        if (!joins) {
+            int best = gs;
+            for (int q = gs + 1; q < i; ++q)
+                if (rows_cmp(R[q].row, R[best].row) < 0) best = q;
+            const bb_row b = R[best].row;
+            R[out++].row = b;
+            gs = i;
+        }
+    }
+    nrows[read] = (uint32_t)out;
+}
+
+__global__ __launch_bounds__(256) void k_emit(const bb_rowtmp* __restrict__ rows, const uint32_t* __restrict__ slot_base,
+                                              const uint32_t* __restrict__ row_off, uint32_t n_reads, uint32_t n_groups,
+                                              const bb_group_dev* __restrict__ groups, bb_row* __restrict__ out,
+                                              unsigned long long* __restrict__ counts) {
+    const uint32_t read = blockIdx.x * 256u + threadIdx.x;
+    if (read >= n_reads) return;
+    const uint32_t b0 = slot_base[(uint64_t)read * n_groups * 2];
+    const uint32_t r0 = row_off[read], r1 = row_off[read + 1];
+    for (uint32_t i = 0; i < r1 - r0; ++i) {
+        const bb_row r = rows[b0 + i].row;
+        out[r0 + i] = r;
+        const bb_group_dev& G = groups[r.group_idx];
+        atomicAdd(&counts[G.count_off + (r.barcode_idx >= 0 ? r.barcode_idx : G.n_seqs)], 1ull);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// synthetic reads on the device: one lane per read
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_synth(bb_synth_params P, const uint8_t* __restrict__ table, uint64_t first_read,
+                                               uint32_t n, const uint64_t* __restrict__ offsets, uint8_t* __restrict__ bases) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t o = offsets[i];
+    bb_synth_fill(P, table, first_read + i, bases + o, (uint32_t)(offsets[i + 1] - o));
+}

@@ -1,0 +1,168 @@
+"""Parity tests proper: the HIP path (through the C-ABI) against the CPU oracle, bit-exact rows."""
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+from barbell_amd import _abi
+from tests.common import config_groups
+
+pytestmark = pytest.mark.gpu
+NT = os.cpu_count() or 1
+
+
+def run_both(groups, bases, offsets, **kw):
+    from barbell_amd import annotate as A
+    from oracle import pyoracle as po
+
+    dm = A.Demuxer(**kw)
+    for g in groups:
+        dm.add_query_group(g)
+    got = dm.demux_packed(bases, offsets)
+    okw = {}
+    if "alpha" in kw:
+        okw["alpha"] = kw["alpha"]
+    if "min_score_frac" in kw:
+        okw["min_score"] = kw["min_score_frac"]
+    if "min_score_diff_frac" in kw:
+        okw["min_score_diff"] = kw["min_score_diff_frac"]
+    want = po.Oracle([g.as_tuple() for g in groups], **okw).annotate(bases, offsets, n_threads=NT)
+    return dm, got, want
+
+
+def assert_same(got, want):
+    if got.tobytes() != want.tobytes():
+        n = min(len(got), len(want))
+        bad = [i for i in range(n) if got[i].tobytes() != want[i].tobytes()]
+        msg = f"{len(got)} vs {len(want)} rows; first diffs:\n"
+        for i in bad[:5]:
+            msg += f"  got  {got[i]}\n  want {want[i]}\n"
+        raise AssertionError(msg)
+
+
+@pytest.mark.parametrize("cfg,n,lmin,lmax", [
+    ("nbd96", 1500, 4000, 4000),   # configs[1] shape
+    ("nbd96", 1500, 1, 700),       # ragged, incl. reads shorter than the flank and than 16 nt
+    ("rbk24", 600, 600, 3999),     # configs[0]
+    ("dual", 600, 4000, 4000),     # configs[3]
+    ("rbk96x", 300, 600, 4000),    # configs[4] (RBK, 2 groups)
+    ("nbd96x", 300, 4000, 4000),   # configs[4] literal (no-op extended)
+])
+def test_synthetic_parity(cfg, n, lmin, lmax):
+    from barbell_amd import annotate as A
+
+    groups = config_groups(cfg)
+    bases, offsets = A.synth_reads_host(groups, 0xBA7BE11 ^ (zlib.crc32(cfg.encode()) % 1000), lmin, lmax, 0, n)
+    dm, got, want = run_both(groups, bases, offsets)
+    assert len(want) > 0
+    assert_same(got, want)
+    # histogram = rows per (group, barcode|flank)
+    cnt = dm.counts()
+    off = 0
+    for gi, g in enumerate(groups):
+        rg = got[got["group_idx"] == gi]
+        for b in range(len(g.seqs)):
+            assert cnt[off + b] == np.sum(rg["barcode_idx"] == b)
+        assert cnt[off + len(g.seqs)] == np.sum(rg["barcode_idx"] < 0)
+        off += len(g.seqs) + 1
+
+
+def test_empty_and_tiny_reads():
+    groups = config_groups("nbd96")
+    reads = [b"", b"A", b"ACGT", b"", bytes(groups[0].seqs[5]), bytes(groups[0].seqs[5])[:20], b"N" * 50, b""]
+    bases, offsets = _abi.pack_reads(reads)
+    _, got, want = run_both(groups, bases, offsets)
+    assert_same(got, want)
+    assert any(r["read_idx"] == 4 and r["barcode_idx"] == 5 for r in got)
+
+
+def test_iupac_lowercase_and_junk_in_reads():
+    groups = config_groups("nbd96")
+    rng = np.random.default_rng(5)
+    from barbell_amd import annotate as A
+
+    bases, offsets = A.synth_reads_host(groups, 99, 200, 600, 0, 400)
+    b = bases.copy()
+    idx = rng.choice(len(b), len(b) // 20, replace=False)
+    repl = np.frombuffer(b"NnacgtRYKM-*0123xX", dtype=np.uint8)
+    b[idx] = repl[rng.integers(0, len(repl), len(idx))]
+    _, got, want = run_both(groups, b, offsets)
+    assert_same(got, want)
+
+
+def test_thresholds_and_alpha_variants():
+    from barbell_amd import annotate as A
+
+    groups = config_groups("nbd96")
+    bases, offsets = A.synth_reads_host(groups, 1234, 500, 1500, 0, 500)
+    for kw in (dict(alpha=0.0), dict(alpha=1.0), dict(min_score_frac=0.6, min_score_diff_frac=0.3),
+               dict(min_score_frac=0.0, min_score_diff_frac=0.0)):
+        _, got, want = run_both(groups, bases, offsets, **kw)
+        assert_same(got, want)
+
+
+def test_many_hits_per_read_and_collapse():
+    # concatemer-like reads: the construct repeated back to back and overlapping, both strands
+    groups = config_groups("nbd96")
+    s = [bytes(x) for x in groups[0].seqs]
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    rc = lambda x: x.translate(comp)[::-1]
+    reads = [
+        s[0] + s[1] + s[2] + b"ACGTACGTAC" * 10 + rc(s[3]) + rc(s[4]),
+        (s[7] + b"TTTT") * 12,
+        s[9][:30] + s[10],            # overlapping flank hits -> collapse
+        s[11] + s[11][14:],            # shared prefix region
+        rc(s[12]) + s[12],
+    ]
+    bases, offsets = _abi.pack_reads(reads)
+    _, got, want = run_both(groups, bases, offsets)
+    assert len(want) >= 8
+    assert_same(got, want)
+
+
+def test_device_pointer_api_and_device_synth():
+    import torch
+
+    from barbell_amd import annotate as A
+
+    groups = config_groups("nbd96")
+    n = 3000
+    hb, ho = A.synth_reads_host(groups, 42, 1000, 1000, 100, n)
+    dm = A.Demuxer()
+    for g in groups:
+        dm.add_query_group(g)
+    d_off = torch.from_numpy(ho.astype(np.int64)).cuda()
+    d_bases = torch.empty(int(ho[-1]), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    dm.synth_dev(42, 1000, 1000, 100, n, d_off.data_ptr(), d_bases.data_ptr())
+    assert d_bases.cpu().numpy().tobytes() == hb.tobytes()          # device generator == host generator
+    d_rows = torch.empty(4 * n * 48, dtype=torch.uint8, device="cuda")
+    nr = dm.demux_dev(d_bases.data_ptr(), d_off.data_ptr(), n, d_rows.data_ptr(), 4 * n)
+    got = np.frombuffer(d_rows.cpu().numpy().tobytes()[: nr * 48], dtype=_abi.ROW_DTYPE)
+    want = dm.demux_packed(hb, ho)
+    assert_same(got, want)
+    # rows ordered by (read_idx, read_start_flank)
+    key = got["read_idx"].astype(np.int64) * (1 << 32) + got["read_start_flank"]
+    assert (np.diff(key) >= 0).all()
+    # too-small row buffer is an error code, not a crash
+    with pytest.raises(A.BarbellError) as e:
+        dm.demux_dev(d_bases.data_ptr(), d_off.data_ptr(), n, d_rows.data_ptr(), 3)
+    assert e.value.code == _abi.BB_E_CAPACITY
+
+
+def test_geometry_matches_oracle_on_device_ctx():
+    from barbell_amd import annotate as A
+    from oracle import pyoracle as po
+
+    for cfg in ("nbd96", "rbk24", "dual"):
+        groups = config_groups(cfg)
+        dm = A.Demuxer()
+        for g in groups:
+            dm.add_query_group(g)
+        o = po.Oracle([g.as_tuple() for g in groups])
+        for gi in range(len(groups)):
+            a, b = dm.group_info(gi), o.info(gi)
+            assert bytes(a) == bytes(b)
+            assert dm.flank(gi) == o.flank(gi)
+            assert dm.pattern(gi, 3, True) == o.pattern(gi, 3, True)
