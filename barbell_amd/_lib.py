@@ -29,6 +29,15 @@ def lib():
             f"{SO_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). barbell_amd has no CPU fallback."
         )
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so.7 / libhsa-runtime64;
+    # if ours were loaded first from /opt/rocm, torch would later fail with "No HIP GPUs are
+    # available".  Importing torch first makes our DT_NEEDED libamdhip64.so.7 resolve to the copy
+    # torch already mapped (same SONAME).  Set BARBELL_AMD_NO_TORCH=1 for a torch-free process.
+    if not os.environ.get("BARBELL_AMD_NO_TORCH"):
+        try:
+            import torch  # noqa: F401
+        except Exception:  # pragma: no cover
+            pass
     L = C.CDLL(SO_PATH)
     vp, u32, u64, i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int
     L.bb_create.argtypes = [C.POINTER(_abi.GroupDesc), u32, C.POINTER(_abi.Params), C.POINTER(vp)]

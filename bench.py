@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""bench.py — throughput of the annotate hot path on MI355X.
+
+Workload (BASELINE.json configs[1]): SQK-NBD114-96 (96 barcodes, 46-nt N-masked flank,
+--flank-max-errors 3) on synthetic 4 kb reads.  Per GPU, `--reads` reads (default 10 M = the named
+config) are generated on the device and stay resident in HBM; one "step" is one pass of the whole
+hot path (flank scan -> trace -> barcode search/score -> collapse -> rows) over one batch of
+`--batch` of those reads, step s taking batch s mod (reads/batch).  With N>1 every rank owns its own
+shard of the read stream (weak scaling, no data-path collective); the only collective is one RCCL
+all-reduce of the per-barcode histogram at the end of the timed region.
+
+Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel against the HBM roofline with
+the ALGORITHMIC bytes of SURVEY.md §8(d) (read length + 8 B offset + 48 B per row out); the path is
+integer-VALU bound, so that fraction is small by construction — the `compute` object carries the
+DP-cell rate that actually bounds it.  `cpu_baseline` is the CPU oracle (a scalar port, OpenMP over
+reads) timed on this box's host cores on a bounded sample of the same reads, and the sample's rows
+are compared with the GPU's (bit-exact) while we are at it.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+METRIC = "reads/s demultiplexed (SQK-NBD114-96, k≤5) at 1/2/4/8 MI355X; HBM GB/s vs roofline"
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+SEED = 0xBA7BE11 ^ 2    # seed = 0xBA7BE11 ^ config_id
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--reads", type=int, default=10_000_000, help="reads resident per GPU")
+    ap.add_argument("--batch", type=int, default=2_000_000, help="reads per step per GPU")
+    ap.add_argument("--read-len", type=int, default=4000)
+    ap.add_argument("--config", default="nbd96", choices=["nbd96", "dual", "rbk24", "rbk96x"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    from barbell_amd import annotate as A
+    from tests.common import config_groups
+
+    groups = config_groups(args.config)
+    dm = A.Demuxer(device=local_rank)
+    for g in groups:
+        dm.add_query_group(g)
+
+    batch = min(args.batch, args.reads)
+    n_batches = max(1, args.reads // batch)
+    n_res = n_batches * batch
+    L = args.read_len
+    first_read = rank * n_res  # contiguous shard of the read stream per rank
+
+    # ---- synthetic reads generated straight into HBM (fixed length -> offsets are i*L) ----
+    d_off = torch.arange(0, n_res + 1, dtype=torch.int64, device=dev) * L
+    d_bases = torch.empty(n_res * L, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    dm.synth_dev(SEED, L, L, first_read, n_res, d_off.data_ptr(), d_bases.data_ptr())
+    rows_cap = 4 * batch
+    d_rows = torch.empty(rows_cap * 48, dtype=torch.uint8, device=dev)
+    # per-batch offsets must start at the batch's own base pointer
+    d_off_b = d_off[: batch + 1].contiguous()
+    torch.cuda.synchronize()
+
+    def step(s):
+        b = s % n_batches
+        return dm.demux_dev(d_bases.data_ptr() + b * batch * L, d_off_b.data_ptr(), batch, d_rows.data_ptr(), rows_cap)
+
+    for s in range(args.warmup):
+        step(s)
+    dm.counts_reset()
+    dm.set_timing(True)
+    kms = {}
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    rows_total = 0
+    for s in range(args.steps):
+        rows_total += step(s)
+        for k, v in dm.kernel_ms().items():
+            kms[k] = kms.get(k, 0.0) + v
+    hist = torch.from_numpy(dm.counts().astype(np.int64)).to(dev)
+    if world > 1:
+        dist.all_reduce(hist)  # RCCL over xGMI: the only collective of the path
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t1 = time.perf_counter()
+    el = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el.item())
+    reads_done = args.steps * batch * world
+    value = reads_done / elapsed
+
+    if rank == 0:
+        # dominant kernel and its roofline
+        kavg = {k: v / args.steps for k, v in kms.items()}
+        dom = max(kavg, key=kavg.get)
+        rows_per_launch = rows_total / args.steps
+        alg_bytes = batch * (L + 8) + 48.0 * rows_per_launch  # SURVEY §8(d), per launch (= per batch)
+        achieved = alg_bytes / (kavg[dom] * 1e-3) / 1e9
+        gi = dm.group_info(0)
+        cells_flank = 2.0 * sum(dm.group_info(g).flank_len for g in range(len(groups))) * L * batch
+        out = {
+            "metric": METRIC, "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u32", "data": "synthetic",
+            "config": {"workload": f"{args.config}: SQK-NBD114-96 kit preset, {n_res} synthetic {L}-nt reads resident per GPU, "
+                                   f"flank-max-errors {gi.flank_k}, one step = one {batch}-read batch per GPU (BASELINE.json configs[1])"
+                       if args.config == "nbd96" else f"{args.config}: {n_res} synthetic {L}-nt reads per GPU, batch {batch}",
+                       "reads_per_gpu": n_res, "batch_reads": batch, "read_len": L, "sharding": f"reads x{world}",
+                       "rows_per_step": rows_per_launch},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": kavg[dom]},
+            "kernel_ms_per_step": kavg,
+            "compute": {"flank_gcups": cells_flank / (kavg.get("k_flank_scan", 0.0) * 1e-3 + 1e-12) / 1e9,
+                        "note": "integer VALU bound (bit-parallel Myers); no MFMA"},
+            "histogram_total": int(hist.sum().item()),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, groups, dm, d_bases, L)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(args, groups, dm, d_bases, L):
+    """Times the CPU oracle (kind "port") on a bounded sample of the SAME reads and checks that its
+    rows equal the GPU's on that sample."""
+    from oracle import pyoracle as po
+
+    po.build()
+    cores = os.cpu_count() or 1
+    orc = po.Oracle([g.as_tuple() for g in groups])
+    probe = min(max(64, 8 * cores), 4096)
+
+    def sample(n):
+        bases = d_bases[: n * L].cpu().numpy()
+        offsets = (np.arange(n + 1, dtype=np.uint64) * np.uint64(L))
+        return bases, offsets
+
+    b, o = sample(probe)
+    t = time.perf_counter()
+    orc.annotate(b, o, n_threads=cores)
+    rate = probe / (time.perf_counter() - t)
+    n = int(min(max(probe, rate * args.cpu_seconds), 2_000_000))
+    b, o = sample(n)
+    t = time.perf_counter()
+    want = orc.annotate(b, o, n_threads=cores)
+    dt = time.perf_counter() - t
+    got = dm.demux_packed(b, o)
+    return {"value": n / dt, "unit": "reads/s", "cores": cores, "kind": "port",
+            "sample": f"first {n} reads of the same synthetic stream, CPU oracle (scalar DP restatement, OpenMP over reads, "
+                      f"{cores} threads), {dt:.1f} s wall",
+            "parity_on_sample": bool(got.tobytes() == want.tobytes()), "rows_on_sample": int(len(want))}
+
+
+if __name__ == "__main__":
+    main()
