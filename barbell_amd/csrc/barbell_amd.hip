@@ -140,6 +140,8 @@ struct bb_ctx {
     bb_synth_params synth{};
     // timing
     bool timing = false;
+    uint32_t reg_threads = 512;  // BARBELL_AMD_REG_THREADS: block size of k_barcode_reg (tuning knob)
+    bool force_generic = false;  // BARBELL_AMD_GENERIC=1: use the generic (any-geometry) kernels, for tests
     hipEvent_t ev[K_COUNT + 1]{};
     float ms[K_COUNT]{};
     std::string last_error;
@@ -305,25 +307,47 @@ void launch_trace(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets, 
                        (const uint8_t*)c->d_tables, (const bb_group_dev*)c->d_groups, (uint32_t)c->groups.size(),
                        (const bb_hit_raw*)c->d_raw, n_hits, (const uint32_t*)c->d_base, c->d_hits, g);
 }
+template <int WB, int CW>
+void launch_barcode_reg(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n_hits, uint32_t g, const uint32_t* list) {
+    const bb_group_dev& D = c->gdev[g];
+    const uint32_t N = (uint32_t)D.n_seqs;
+    const uint32_t hpb = c->reg_threads / N;
+    const uint32_t threads = ((hpb * N + 63) / 64) * 64;
+    const size_t smem = (size_t)2 * 16 * N * WB * 4 + (size_t)hpb * 24 + (size_t)hpb * CW + 16;
+    const uint32_t blocks = (n_hits + hpb - 1) / hpb;
+    hipLaunchKernelGGL((k_barcode_reg<WB, CW>), dim3(blocks), dim3(threads), smem, c->stream, d_bases, d_offsets,
+                       (const uint8_t*)c->d_tables, (const bb_group_dev*)c->d_groups, g, (const bb_hit*)c->d_hits, list,
+                       (const uint32_t*)c->d_listcnt, n_hits, hpb, c->params.min_score, c->params.min_score_diff, c->d_rows);
+}
+
 template <int WB>
 void launch_barcode(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n_hits, uint32_t g) {
     const bb_group_dev& D = c->gdev[g];
+    const bb_group_info& I = c->groups[g].info;
     const uint32_t N = (uint32_t)D.n_seqs;
+    const uint32_t* list = c->groups.size() > 1 ? c->d_lists + (size_t)g * c->cap_hits : nullptr;
+    // widest barcode window the flank traceback can produce: (mask_len - 1 + flank_k) + 2*PADDING
+    const uint32_t win_max = I.mask_len + (uint32_t)I.flank_k + 2 * BB_PADDING - 1;
+    const size_t peq_bytes = (size_t)2 * 16 * N * WB * 4;
+    const bool reg_ok = !c->force_generic && D.m_bar <= 48 && N <= c->reg_threads && peq_bytes <= 48 * 1024 && win_max <= 64;
+    if (reg_ok) {
+        if (win_max <= 48) launch_barcode_reg<WB, 48>(c, d_bases, d_offsets, n_hits, g, list);
+        else launch_barcode_reg<WB, 64>(c, d_bases, d_offsets, n_hits, g, list);
+        return;
+    }
     const uint32_t hpb = N >= 256 ? 1 : 256 / N;
     const uint32_t threads = ((hpb * N + 63) / 64) * 64;
-    const size_t peq_bytes = (size_t)2 * 16 * N * WB * 4;
     const bool lds = peq_bytes <= 48 * 1024;
     const size_t smem = (lds ? peq_bytes : 0) + (size_t)hpb * N * 8 + (size_t)hpb * 16 + (size_t)hpb * BB_MAX_WIN;
     const uint32_t blocks = (n_hits + hpb - 1) / hpb;
-    const uint32_t* list = c->d_lists + (size_t)g * c->cap_hits;
     if (lds)
         hipLaunchKernelGGL((k_barcode<WB, true>), dim3(blocks), dim3(threads), smem, c->stream, d_bases, d_offsets,
                            (const uint8_t*)c->d_tables, (const bb_group_dev*)c->d_groups, g, (const bb_hit*)c->d_hits, list,
-                           (const uint32_t*)c->d_listcnt, hpb, c->params.min_score, c->params.min_score_diff, c->d_rows);
+                           (const uint32_t*)c->d_listcnt, n_hits, hpb, c->params.min_score, c->params.min_score_diff, c->d_rows);
     else
         hipLaunchKernelGGL((k_barcode<WB, false>), dim3(blocks), dim3(threads), smem, c->stream, d_bases, d_offsets,
                            (const uint8_t*)c->d_tables, (const bb_group_dev*)c->d_groups, g, (const bb_hit*)c->d_hits, list,
-                           (const uint32_t*)c->d_listcnt, hpb, c->params.min_score, c->params.min_score_diff, c->d_rows);
+                           (const uint32_t*)c->d_listcnt, n_hits, hpb, c->params.min_score, c->params.min_score_diff, c->d_rows);
 }
 
 void mark(bb_ctx* c, int i) {
@@ -357,6 +381,8 @@ int bb_create(const bb_group_desc* groups, uint32_t n_groups, const bb_params* p
     if (!(params->alpha >= 0.0f)) return BB_E_INVALID;
     bb_ctx* c = new bb_ctx();
     c->params = *params;
+    c->force_generic = getenv("BARBELL_AMD_GENERIC") && atoi(getenv("BARBELL_AMD_GENERIC")) != 0;
+    if (getenv("BARBELL_AMD_REG_THREADS")) { int t = atoi(getenv("BARBELL_AMD_REG_THREADS")); if (t >= 64 && t <= 512) c->reg_threads = (uint32_t)t; }
     c->groups.resize(n_groups);
     for (uint32_t i = 0; i < n_groups; ++i) {
         int r = prep_group(groups[i], params->alpha, c->groups[i]);
@@ -460,10 +486,10 @@ int bb_annotate_batch_dev(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_o
         HIPCHK(c, hipGetLastError());
     }
     mark(c, K_LISTS);
-    if (n_hits) {
+    if (n_hits && G > 1) {
         HIPCHK(c, hipMemsetAsync(c->d_listcnt, 0, sizeof(uint32_t) * BB_MAX_GROUPS, c->stream));
         hipLaunchKernelGGL(k_hit_lists, dim3((n_hits + 255) / 256), dim3(256), 0, c->stream, (const bb_hit*)c->d_hits, n_hits,
-                           c->d_rows, c->d_lists, c->cap_hits, c->d_listcnt);
+                           c->d_rows, c->d_lists, c->cap_hits, c->d_listcnt, G);
     }
     mark(c, K_BARCODE);
     if (n_hits) {

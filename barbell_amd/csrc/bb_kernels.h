@@ -372,11 +372,11 @@ template <int WB, bool PEQ_LDS>
 __global__ __launch_bounds__(1024) void k_barcode(const uint8_t* __restrict__ bases, const uint64_t* __restrict__ offsets,
                                                   const uint8_t* __restrict__ tables, const bb_group_dev* __restrict__ groups,
                                                   uint32_t g, const bb_hit* __restrict__ hits, const uint32_t* __restrict__ hit_list,
-                                                  const uint32_t* __restrict__ list_cnt, uint32_t hpb, double min_score, double min_score_diff,
-                                                  bb_rowtmp* __restrict__ rows) {
+                                                  const uint32_t* __restrict__ list_cnt, uint32_t n_hits_all, uint32_t hpb,
+                                                  double min_score, double min_score_diff, bb_rowtmp* __restrict__ rows) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const bb_group_dev G = groups[g];
-    const uint32_t n_list = list_cnt[g];
+    const uint32_t n_list = hit_list ? list_cnt[g] : n_hits_all;
     if (blockIdx.x * hpb >= n_list) return;
     const int N = G.n_seqs, m = G.m_bar;
     // LDS carve: [peq: 2*16*N*WB words][win: hpb*BB_MAX_WIN bytes][score: hpb*N doubles][cnt/top: hpb*4 ints]
@@ -396,13 +396,16 @@ __global__ __launch_bounds__(1024) void k_barcode(const uint8_t* __restrict__ ba
     const int hl = threadIdx.x / N;       // local hit
     const int p = threadIdx.x - hl * N;   // pattern index
     const uint32_t li = blockIdx.x * hpb + hl;
-    const bool active = hl < (int)hpb && li < n_list;
+    bool active = hl < (int)hpb && li < n_list;
     bb_hit H;
     uint32_t hit_idx = 0;
     int32_t wn = 0;
     if (active) {
-        hit_idx = hit_list[li];
+        hit_idx = hit_list ? hit_list[li] : li;
         H = hits[hit_idx];
+        if (!H.valid) { active = false; if (p == 0) rows[hit_idx].valid = 0; }
+    }
+    if (active) {
         wn = (int32_t)(H.we - H.ws);
         const uint8_t* rb = bases + offsets[H.read_idx];
         for (int c = p; c < wn; c += N) s_win[hl * BB_MAX_WIN + c] = bb_text_code(rb[H.ws + c]);
@@ -530,16 +533,288 @@ __global__ __launch_bounds__(1024) void k_barcode(const uint8_t* __restrict__ ba
     }
 }
 
-// hits whose get_matching_region was None produce no row (searcher.rs:445-449); also builds the
-// per-group hit lists for k_barcode.
+// ------------------------------------------------------------------------------------------------
+// k_barcode_reg: register-resident, branch-free variant of k_barcode for m_bar <= 48 and windows of
+// at most CW columns (CW = 48 or 64; all ONT kit presets).  Same arithmetic as k_barcode, but
+//   * the two move bit-vectors of every column live in VGPRs (3 registers per column), written and
+//     read with compile-time indices in fully unrolled column loops — no private memory;
+//   * forward pass, traceback and replay are predicated arithmetic, not divergent branches; the
+//     only branches are wave-uniform (skip 8-column chunks beyond the widest window in the wave);
+//   * the traceback records the alignment per COLUMN: the text-consuming op of each column in two
+//     bit planes, plus one bit per PATTERN ROW that was deleted (a run of Del moves inside a column
+//     is found with one count-leading-ones instead of a loop);
+//   * the Lodhi recurrence runs on power-of-two-scaled variables (b1 = 2^t a1, b2 = 2^t a2,
+//     S = 2^t score): every multiply of the oracle's recurrence is by 0.5 (exact), so the scaling
+//     commutes with the roundings of the adds and the result is bit-identical at 4 f64 adds per
+//     match column; a run of nd Del columns is one exact ldexp;
+//   * the per-hit argmax / runner-up uses 64-bit LDS atomics on the (monotone) score bit pattern.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int clz64(unsigned long long x) { return x ? __clzll((long long)x) : 64; }
+__device__ __forceinline__ int ctz64(unsigned long long x) { return x ? __ffsll((long long)x) - 1 : 64; }
+
+template <int WB, int CW>
+__global__ __launch_bounds__(512) void k_barcode_reg(const uint8_t* __restrict__ bases, const uint64_t* __restrict__ offsets,
+                                                     const uint8_t* __restrict__ tables, const bb_group_dev* __restrict__ groups,
+                                                     uint32_t g, const bb_hit* __restrict__ hits, const uint32_t* __restrict__ hit_list,
+                                                     const uint32_t* __restrict__ list_cnt, uint32_t n_hits_all, uint32_t hpb,
+                                                     double min_score, double min_score_diff, bb_rowtmp* __restrict__ rows) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const bb_group_dev G = groups[g];
+    const uint32_t n_list = hit_list ? list_cnt[g] : n_hits_all;
+    if (blockIdx.x * hpb >= n_list) return;
+    const int N = G.n_seqs, m = G.m_bar;
+    // LDS carve: [win: hpb*CW bytes][max u64[hpb]][second u64[hpb]][cnt1 i32[hpb]][top i32[hpb]][peq 2*16*N*WB words]
+    uint8_t* s_win = smem;
+    size_t o = (size_t)hpb * CW;
+    unsigned long long* s_max = reinterpret_cast<unsigned long long*>(smem + o);
+    o += (size_t)hpb * 8;
+    unsigned long long* s_sec = reinterpret_cast<unsigned long long*>(smem + o);
+    o += (size_t)hpb * 8;
+    int32_t* s_cnt1 = reinterpret_cast<int32_t*>(smem + o);
+    o += (size_t)hpb * 4;
+    int32_t* s_top = reinterpret_cast<int32_t*>(smem + o);
+    o += (size_t)hpb * 4;
+    o = (o + 15) & ~(size_t)15;
+    uint32_t* s_peq = reinterpret_cast<uint32_t*>(smem + o);
+    {
+        const uint32_t* gp = reinterpret_cast<const uint32_t*>(tables + G.off_peq_bar[0]);
+        const int words = 2 * 16 * N * WB;
+        for (int i = threadIdx.x; i < words; i += blockDim.x) s_peq[i] = gp[i];
+    }
+    const int hl = threadIdx.x / N;
+    const int p = threadIdx.x - hl * N;
+    const uint32_t li = blockIdx.x * hpb + hl;
+    bool active = hl < (int)hpb && li < n_list;
+    bb_hit H;
+    uint32_t hit_idx = 0;
+    int32_t wn = 0;
+    if (active) {
+        hit_idx = hit_list ? hit_list[li] : li;
+        H = hits[hit_idx];
+        if (!H.valid) { active = false; if (p == 0) rows[hit_idx].valid = 0; }
+    }
+    if (hl < (int)hpb) {
+        if (active) wn = (int32_t)(H.we - H.ws);
+        const uint8_t* rb = active ? bases + offsets[H.read_idx] + H.ws : bases;
+        for (int c = p; c < CW; c += N) s_win[hl * CW + c] = c < wn ? bb_text_code(rb[c]) : (uint8_t)0;
+        if (p == 0) { s_max[hl] = 0ull; s_sec[hl] = 0ull; s_cnt1[hl] = 0; s_top[hl] = 0x7FFFFFFF; }
+    }
+    __syncthreads();
+    const int hls = hl < (int)hpb ? hl : 0;  // lanes past the last hit of the block compute on hit 0's window, results unused
+
+    int wmax = wn;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) wmax = max(wmax, __shfl_xor(wmax, d, 64));
+    wmax = __builtin_amdgcn_readfirstlane(wmax);
+
+    // ---- forward pass: Myers + move bits; columns unrolled; all state in registers ----
+    uint32_t L0[CW], H0[CW], X[CW];
+    int32_t best_cost = wn == 0 ? m : 0x7FFFFFFF, best_pos = wn == 0 ? 0 : -1;
+    {
+        uint32_t wc[CW / 4];
+        const uint4* wsrc = reinterpret_cast<const uint4*>(s_win + hls * CW);
+#pragma unroll
+        for (int q = 0; q < CW / 16; ++q) { uint4 v = wsrc[q]; wc[4 * q] = v.x; wc[4 * q + 1] = v.y; wc[4 * q + 2] = v.z; wc[4 * q + 3] = v.w; }
+        const uint32_t* pb = s_peq + (size_t)(active ? H.strand : 0) * 16 * N * WB + (size_t)p * WB;
+        uint32_t pv[WB], mv[WB];
+#pragma unroll
+        for (int x = 0; x < WB; ++x) { int bits = m - 32 * x; pv[x] = bits >= 32 ? 0xFFFFFFFFu : (bits > 0 ? ((1u << bits) - 1u) : 0u); mv[x] = 0; }
+        const int TB = (m - 1) & 31;
+        int32_t score = m, prev = m;
+        bool dec = true;
+#pragma unroll
+        for (int c0 = 0; c0 < CW; c0 += 8) {
+            if (c0 < wmax) {  // wave-uniform
+#pragma unroll
+                for (int c = c0; c < c0 + 8; ++c) {
+                    const uint32_t code = (wc[c >> 2] >> (8 * (c & 3))) & 0xFu;
+                    uint32_t eq[WB], d0[WB], ph[WB], mh[WB], l[WB], hh[WB];
+                    const uint32_t* e = pb + (size_t)code * N * WB;
+                    if constexpr (WB == 2) { uint2 v = *reinterpret_cast<const uint2*>(e); eq[0] = v.x; eq[1] = v.y; }
+                    else eq[0] = e[0];
+                    myers_step<WB>(pv, mv, eq, d0, ph, mh);
+                    move_bits<WB>(eq, d0, ph, l, hh);
+                    L0[c] = l[0]; H0[c] = hh[0];
+                    if constexpr (WB == 2) X[c] = (l[1] & 0xFFFFu) | (hh[1] << 16);
+                    else X[c] = 0;
+                    score += (int32_t)((ph[WB - 1] >> TB) & 1u) - (int32_t)((mh[WB - 1] >> TB) & 1u);
+                    // local minima, first strictly-lowest (oracle [H1], searcher.rs:294-300); positions >= wn are masked
+                    const bool gt = score > prev, lt = score < prev;
+                    const bool upd1 = (c < wn) & gt & dec & (prev < best_cost);
+                    best_cost = upd1 ? prev : best_cost;
+                    best_pos = upd1 ? c : best_pos;
+                    dec = lt | (dec & !gt);
+                    const bool upd2 = (c + 1 == wn) & dec & (score < best_cost);  // end of the window
+                    best_cost = upd2 ? score : best_cost;
+                    best_pos = upd2 ? c + 1 : best_pos;
+                    prev = score;
+                }
+            }
+        }
+        if (active && best_pos >= 0 && best_cost <= G.k1) atomicAdd(&s_cnt1[hl], 1);
+    }
+    __syncthreads();
+
+    // ---- pass decision (searcher.rs:303-328) ----
+    bool cand = false;
+    if (active) {
+        const bool pass2 = s_cnt1[hl] <= 1 && G.k1 < G.k2;
+        cand = best_pos >= 0 && (pass2 ? best_cost <= G.k2 : best_cost <= G.k1);
+    }
+    // ---- traceback, one predicated step per column ----
+    unsigned long long delrow = 0ull, plo = 0ull, phi = 0ull;
+    int32_t j = m, i = cand ? best_pos : -1, tstart = 0;
+#pragma unroll
+    for (int c0 = CW; c0 >= 8; c0 -= 8) {
+        if (c0 - 7 <= wmax) {  // wave-uniform
+#pragma unroll
+            for (int c = c0; c > c0 - 8; --c) {
+                const bool act = i == c;
+                const unsigned long long lo64 = (unsigned long long)L0[c - 1] | ((unsigned long long)(X[c - 1] & 0xFFFFu) << 32);
+                const unsigned long long hi64 = (unsigned long long)H0[c - 1] | ((unsigned long long)(X[c - 1] >> 16) << 32);
+                const unsigned long long d64 = lo64 & hi64;
+                const int jj = act ? j : 1;
+                // run of Del moves from row jj downwards
+                const int nd = clz64(~(d64 << (64 - jj)));
+                const unsigned long long dm = (nd >= 64 ? ~0ull : ((1ull << nd) - 1ull)) << (jj - nd);
+                const int j2 = jj - nd;
+                const bool has = act & (j2 > 0);
+                const int b2i = has ? j2 - 1 : 0;
+                const unsigned long long lo = (lo64 >> b2i) & 1ull, hi = (hi64 >> b2i) & 1ull;
+                delrow |= act ? dm : 0ull;
+                plo |= has ? (lo << (c - 1)) : 0ull;
+                phi |= has ? (hi << (c - 1)) : 0ull;
+                const int j3 = j2 - ((has & !(hi == 1ull && lo == 0ull)) ? 1 : 0);  // Ins consumes no pattern row
+                const bool fin_here = act & (j2 == 0);           // path starts at column c (only Dels in it)
+                const bool fin_prev = has & (j3 == 0);           // path starts at column c-1
+                tstart = fin_here ? c : (fin_prev ? c - 1 : tstart);
+                j = act ? j3 : j;
+                i = act ? ((fin_here | fin_prev) ? -1 : c - 1) : i;
+            }
+        }
+    }
+    if (i == 0 && j > 0) {  // reached column 0 with pattern rows left: leading Dels (tstart stays 0)
+        delrow |= (1ull << j) - 1ull;
+    }
+    // ---- forward replay: Lodhi (scaled) + sub-path (cigar_parse.rs:6-68) ----
+    double s_norm = -1.0;
+    int32_t pat_lo = 0, pat_hi = 0, txt_lo = 0, txt_hi = 0, bcost = 0;
+    {
+        double S = 0.0, b1 = 0.0, b2 = 0.0;
+        int32_t t = 0, pj = 0;
+        bool any = false;
+        const int32_t rlo = G.rel_lo, rhi = G.rel_hi;
+        auto dels = [&](bool on, int32_t ti) {  // run of Del ops starting at pattern row pj, text index ti
+            const int nd = on ? ctz64(~(delrow >> pj)) : 0;
+            S = ldexp(S, nd);
+            t += nd;
+            const int32_t a = max(pj, rlo), b = min(pj + nd, rhi);
+            const bool inr = a < b;
+            pat_lo = (inr & !any) ? a : pat_lo;
+            txt_lo = (inr & !any) ? ti : txt_lo;
+            pat_hi = inr ? b : pat_hi;
+            txt_hi = inr ? ti + 1 : txt_hi;
+            bcost += inr ? b - a : 0;
+            any |= inr;
+            pj += nd;
+        };
+        dels(cand, tstart);
+#pragma unroll
+        for (int c0 = 1; c0 <= CW; c0 += 8) {
+            if (c0 <= wmax) {  // wave-uniform
+#pragma unroll
+                for (int c = c0; c < c0 + 8; ++c) {
+                    const bool on = cand & (c > tstart) & (c <= best_pos);
+                    const uint32_t lo = (uint32_t)(plo >> (c - 1)) & 1u, hi = (uint32_t)(phi >> (c - 1)) & 1u;
+                    const bool isM = on & (lo == 0u) & (hi == 0u);
+                    if (on) S = S + S;
+                    if (isM) {
+                        const double pw = __longlong_as_double((long long)(1023 + t) << 52);  // 2^t
+                        S = S + b2; b2 = b2 + b1; b1 = b1 + pw;
+                    }
+                    const bool inr = on & (pj >= rlo) & (pj < rhi);
+                    pat_lo = (inr & !any) ? pj : pat_lo;
+                    txt_lo = (inr & !any) ? c - 1 : txt_lo;
+                    pat_hi = inr ? pj + 1 : pat_hi;
+                    txt_hi = inr ? c : txt_hi;
+                    bcost += (inr & !isM) ? 1 : 0;
+                    any |= inr;
+                    pj += (on & !(hi == 1u && lo == 0u)) ? 1 : 0;
+                    t += on ? 1 : 0;
+                    dels(on, c);
+                }
+            }
+        }
+        if (cand) {
+            const double sc = S * __longlong_as_double((long long)(1023 - t) << 52);  // S * 2^-t (exact)
+            s_norm = G.perfect > 0.0 ? sc / G.perfect : 0.0;
+        }
+    }
+    // ---- per-hit argmax (first maximum) and runner-up: searcher.rs:377,390-396 ----
+    const unsigned long long key = cand ? (unsigned long long)__double_as_longlong(s_norm) + 1ull : 0ull;
+    if (cand) atomicMax(&s_max[hl], key);
+    __syncthreads();
+    if (cand && key == s_max[hl]) atomicMin(&s_top[hl], p);
+    __syncthreads();
+    if (active) {
+        const int top = s_top[hl];
+        if (cand && p != top) atomicMax(&s_sec[hl], key);
+    }
+    __syncthreads();
+    if (active) {
+        const int top = s_top[hl];
+        const bool have = top != 0x7FFFFFFF;
+        if ((have && p == top) || (!have && p == 0)) {
+            bool valid = have && s_norm >= min_score;
+            const unsigned long long sk = s_sec[hl];
+            if (valid && sk != 0ull) valid = (s_norm - __longlong_as_double((long long)(sk - 1ull))) >= min_score_diff;
+            const uint32_t read_len = (uint32_t)(offsets[H.read_idx + 1] - offsets[H.read_idx]);
+            bb_rowtmp R;
+            bb_row& r = R.row;
+            r.read_idx = H.read_idx; r.read_len = read_len;
+            r.rel_dist_to_end = rel_dist_to_end((int64_t)H.text_start, (int64_t)read_len);
+            r.read_start_flank = H.text_start; r.read_end_flank = H.text_end;
+            r.flank_cost = H.cost; r.group_idx = H.group; r.strand = H.strand;
+            r._pad[0] = r._pad[1] = r._pad[2] = 0;
+            if (valid) {
+                r.read_start_bar = H.ws + (uint32_t)txt_lo; r.read_end_bar = H.ws + (uint32_t)txt_hi;
+                r.bar_start = H.ws + (uint32_t)pat_lo; r.bar_end = H.ws + (uint32_t)pat_hi;
+                r.match_type = (uint8_t)G.type; r.barcode_cost = (int16_t)bcost; r.barcode_idx = (int16_t)top;
+            } else {
+                r.read_start_bar = H.text_start; r.read_end_bar = H.text_end;
+                r.bar_start = 0; r.bar_end = 0;
+                r.match_type = (uint8_t)(G.type == BB_FTAG ? BB_FFLANK : BB_RFLANK);
+                r.barcode_cost = (int16_t)G.m_bar; r.barcode_idx = -1;
+            }
+            R.valid = 1;
+            rows[hit_idx] = R;
+        }
+    }
+}
+
+// Per-group hit lists for k_barcode (only needed with more than one query group).  Hits whose
+// get_matching_region was None (searcher.rs:445-449) are skipped here and marked row-less.
+// One atomic per (wave, group): ballot + prefix popcount.
 __global__ __launch_bounds__(256) void k_hit_lists(const bb_hit* __restrict__ hits, uint32_t n_hits, bb_rowtmp* __restrict__ rows,
-                                                   uint32_t* __restrict__ lists, uint32_t list_stride, uint32_t* __restrict__ list_cnt) {
+                                                   uint32_t* __restrict__ lists, uint32_t list_stride, uint32_t* __restrict__ list_cnt,
+                                                   uint32_t n_groups) {
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
-    if (t >= n_hits) return;
-    const bb_hit h = hits[t];
-    if (!h.valid) { rows[t].valid = 0; return; }
-    const uint32_t s = atomicAdd(&list_cnt[h.group], 1u);
-    lists[(size_t)h.group * list_stride + s] = t;
+    const bool in = t < n_hits;
+    bb_hit h;
+    if (in) h = hits[t];
+    const bool valid = in && h.valid;
+    if (in && !valid) rows[t].valid = 0;
+    const unsigned lane = threadIdx.x & 63u;
+    for (uint32_t g = 0; g < n_groups; ++g) {
+        const bool mine = valid && h.group == g;
+        const unsigned long long mask = __ballot(mine);
+        if (mask == 0ull) continue;
+        uint32_t base = 0;
+        const int leader = __ffsll((long long)mask) - 1;
+        if ((int)lane == leader) base = atomicAdd(&list_cnt[g], (uint32_t)__popcll(mask));
+        base = __shfl(base, leader, 64);
+        if (mine) lists[(size_t)g * list_stride + base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = t;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

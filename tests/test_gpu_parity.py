@@ -68,6 +68,19 @@ def test_synthetic_parity(cfg, n, lmin, lmax):
         off += len(g.seqs) + 1
 
 
+def test_generic_kernels_match_too(monkeypatch):
+    """BARBELL_AMD_GENERIC=1 forces the any-geometry kernels (private-memory move bits) that configs
+    outside the register-resident limits would use; they must give the same rows."""
+    from barbell_amd import annotate as A
+
+    monkeypatch.setenv("BARBELL_AMD_GENERIC", "1")
+    for cfg in ("nbd96", "dual"):
+        groups = config_groups(cfg)
+        bases, offsets = A.synth_reads_host(groups, 31337, 400, 2500, 0, 500)
+        _, got, want = run_both(groups, bases, offsets)
+        assert_same(got, want)
+
+
 def test_empty_and_tiny_reads():
     groups = config_groups("nbd96")
     reads = [b"", b"A", b"ACGT", b"", bytes(groups[0].seqs[5]), bytes(groups[0].seqs[5])[:20], b"N" * 50, b""]
