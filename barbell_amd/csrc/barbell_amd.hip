@@ -140,6 +140,8 @@ struct bb_ctx {
     bb_synth_params synth{};
     // timing
     bool timing = false;
+    int n_cus = 256;
+    uint32_t reg_blocks_mult = 1;  // BARBELL_AMD_REG_BLOCKS: persistent blocks per resident slot (tuning knob)
     uint32_t reg_threads = 512;  // BARBELL_AMD_REG_THREADS: block size of k_barcode_reg (tuning knob)
     bool force_generic = false;  // BARBELL_AMD_GENERIC=1: use the generic (any-geometry) kernels, for tests
     hipEvent_t ev[K_COUNT + 1]{};
@@ -313,9 +315,13 @@ void launch_barcode_reg(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_off
     const uint32_t N = (uint32_t)D.n_seqs;
     const uint32_t hpb = c->reg_threads / N;
     const uint32_t threads = ((hpb * N + 63) / 64) * 64;
-    const size_t smem = (size_t)2 * 16 * N * WB * 4 + (size_t)hpb * 24 + (size_t)hpb * CW + 16;
-    const uint32_t blocks = (n_hits + hpb - 1) / hpb;
-    hipLaunchKernelGGL((k_barcode_reg<WB, CW>), dim3(blocks), dim3(threads), smem, c->stream, d_bases, d_offsets,
+    const size_t smem = (size_t)2 * 16 * N * WB * 4 + (size_t)hpb * 24 + (size_t)hpb * sizeof(bb_hit) + 16;
+    const uint32_t n_iter = (n_hits + hpb - 1) / hpb;
+    // persistent blocks: the Peq table is loaded once per block and the next hit records are prefetched
+    const uint32_t resident = (uint32_t)c->n_cus * (threads > 256 ? 1u : 2u) * c->reg_blocks_mult;
+    const uint32_t blocks = n_iter < resident ? n_iter : resident;
+    (void)d_bases; (void)d_offsets;
+    hipLaunchKernelGGL((k_barcode_reg<WB, CW>), dim3(blocks), dim3(threads), smem, c->stream,
                        (const uint8_t*)c->d_tables, (const bb_group_dev*)c->d_groups, g, (const bb_hit*)c->d_hits, list,
                        (const uint32_t*)c->d_listcnt, n_hits, hpb, c->params.min_score, c->params.min_score_diff, c->d_rows);
 }
@@ -399,6 +405,8 @@ int bb_create(const bb_group_desc* groups, uint32_t n_groups, const bb_params* p
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || params->device < 0 || params->device >= ndev) { delete c; return BB_E_NO_DEVICE; }
     c->device = params->device;
     if (hipSetDevice(c->device) != hipSuccess) { delete c; return BB_E_NO_DEVICE; }
+    { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0) c->n_cus = prop.multiProcessorCount; }
+    if (getenv("BARBELL_AMD_REG_BLOCKS")) { int t = atoi(getenv("BARBELL_AMD_REG_BLOCKS")); if (t >= 1 && t <= 16) c->reg_blocks_mult = (uint32_t)t; }
     if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return BB_E_NO_DEVICE; }
     for (int i = 0; i <= K_COUNT; ++i)
         if (hipEventCreate(&c->ev[i]) != hipSuccess) { delete c; return BB_E_NO_DEVICE; }

@@ -81,8 +81,9 @@ struct bb_hit_raw {
     uint8_t group, strand;
     uint32_t ordinal;  // order of discovery within (read, group, strand)
 };
-// ordered flank match after traceback + window computation
-struct bb_hit {
+// ordered flank match after traceback + window computation: 32-byte header + the window's base-set
+// codes (zero padded), so k_barcode_reg fetches everything it needs about a hit with six 16-byte loads
+struct __attribute__((aligned(16))) bb_hit {
     uint32_t read_idx;
     uint32_t text_start, text_end;  // forward coordinates
     uint32_t ws, we;                // barcode window [ws, we)
@@ -90,4 +91,7 @@ struct bb_hit {
     uint8_t group, strand;
     uint8_t valid;                  // 0: get_matching_region returned None -> no row
     uint8_t _pad[3];
+    uint32_t read_len;
+    uint8_t win[64];                // filled when we - ws <= 64
 };
+static_assert(sizeof(bb_hit) == 96, "bb_hit: 32-byte header + 64 window codes");

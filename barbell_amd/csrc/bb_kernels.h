@@ -349,8 +349,25 @@ __global__ __launch_bounds__(64) void k_flank_trace(const uint8_t* __restrict__ 
     if (we < ws) we = ws;
     out.ws = (uint32_t)ws; out.we = (uint32_t)we;
     out._pad[0] = out._pad[1] = out._pad[2] = 0;
+    out.read_len = (uint32_t)n;
     const uint32_t slot = slot_base[((uint64_t)h.read_idx * n_groups + h.group) * 2 + h.strand] + h.ordinal;
-    hits[slot] = out;
+    uint4* dst = reinterpret_cast<uint4*>(hits + slot);
+    const uint4* src = reinterpret_cast<const uint4*>(&out);
+    dst[0] = src[0]; dst[1] = src[1];
+    const int32_t wn = we - ws;
+    if (wn <= 64) {  // window codes for k_barcode_reg
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            uint32_t w4[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int b = 0; b < 16; ++b) {
+                const int c = 16 * q + b;
+                const uint32_t code = c < wn ? (uint32_t)bb_text_code(rb[ws + c]) : 0u;
+                w4[b >> 2] |= code << (8 * (b & 3));
+            }
+            dst[2 + q] = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -553,19 +570,19 @@ __device__ __forceinline__ int clz64(unsigned long long x) { return x ? __clzll(
 __device__ __forceinline__ int ctz64(unsigned long long x) { return x ? __ffsll((long long)x) - 1 : 64; }
 
 template <int WB, int CW>
-__global__ __launch_bounds__(512) void k_barcode_reg(const uint8_t* __restrict__ bases, const uint64_t* __restrict__ offsets,
-                                                     const uint8_t* __restrict__ tables, const bb_group_dev* __restrict__ groups,
+__global__ __launch_bounds__(512) void k_barcode_reg(const uint8_t* __restrict__ tables, const bb_group_dev* __restrict__ groups,
                                                      uint32_t g, const bb_hit* __restrict__ hits, const uint32_t* __restrict__ hit_list,
                                                      const uint32_t* __restrict__ list_cnt, uint32_t n_hits_all, uint32_t hpb,
                                                      double min_score, double min_score_diff, bb_rowtmp* __restrict__ rows) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const bb_group_dev G = groups[g];
     const uint32_t n_list = hit_list ? list_cnt[g] : n_hits_all;
-    if (blockIdx.x * hpb >= n_list) return;
+    const uint32_t n_iter = (n_list + hpb - 1) / hpb;
+    if (blockIdx.x >= n_iter) return;
     const int N = G.n_seqs, m = G.m_bar;
-    // LDS carve: [win: hpb*CW bytes][max u64[hpb]][second u64[hpb]][cnt1 i32[hpb]][top i32[hpb]][peq 2*16*N*WB words]
-    uint8_t* s_win = smem;
-    size_t o = (size_t)hpb * CW;
+    // LDS carve: [hit records: hpb x 96 B][max u64[hpb]][second u64[hpb]][cnt1 i32[hpb]][top i32[hpb]][peq 2*16*N*WB words]
+    uint4* s_hit = reinterpret_cast<uint4*>(smem);
+    size_t o = (size_t)hpb * sizeof(bb_hit);
     unsigned long long* s_max = reinterpret_cast<unsigned long long*>(smem + o);
     o += (size_t)hpb * 8;
     unsigned long long* s_sec = reinterpret_cast<unsigned long long*>(smem + o);
@@ -576,31 +593,47 @@ __global__ __launch_bounds__(512) void k_barcode_reg(const uint8_t* __restrict__
     o += (size_t)hpb * 4;
     o = (o + 15) & ~(size_t)15;
     uint32_t* s_peq = reinterpret_cast<uint32_t*>(smem + o);
-    {
+    {   // barcode Peq of both strands: loaded once per (persistent) block
         const uint32_t* gp = reinterpret_cast<const uint32_t*>(tables + G.off_peq_bar[0]);
         const int words = 2 * 16 * N * WB;
         for (int i = threadIdx.x; i < words; i += blockDim.x) s_peq[i] = gp[i];
     }
     const int hl = threadIdx.x / N;
     const int p = threadIdx.x - hl * N;
-    const uint32_t li = blockIdx.x * hpb + hl;
-    bool active = hl < (int)hpb && li < n_list;
-    bb_hit H;
-    uint32_t hit_idx = 0;
-    int32_t wn = 0;
-    if (active) {
-        hit_idx = hit_list ? hit_list[li] : li;
-        H = hits[hit_idx];
-        if (!H.valid) { active = false; if (p == 0) rows[hit_idx].valid = 0; }
-    }
-    if (hl < (int)hpb) {
-        if (active) wn = (int32_t)(H.we - H.ws);
-        const uint8_t* rb = active ? bases + offsets[H.read_idx] + H.ws : bases;
-        for (int c = p; c < CW; c += N) s_win[hl * CW + c] = c < wn ? bb_text_code(rb[c]) : (uint8_t)0;
-        if (p == 0) { s_max[hl] = 0ull; s_sec[hl] = 0ull; s_cnt1[hl] = 0; s_top[hl] = 0x7FFFFFFF; }
-    }
+    const bool in_blk = hl < (int)hpb;
+    const int hls = in_blk ? hl : 0;  // lanes past the last hit of the block shadow hit 0, results unused
+    constexpr int PIECES = (int)(sizeof(bb_hit) / 16);
+    // prefetch of the next iteration's hit records: lanes p < 6 of every local hit hold one 16-byte piece
+    uint4 pre = make_uint4(0u, 0u, 0u, 0u);
+    uint32_t pre_idx = 0;
+    auto prefetch = [&](uint32_t it) {
+        const uint32_t li = it * hpb + (uint32_t)hl;
+        if (in_blk && p < PIECES && it < n_iter && li < n_list) {
+            pre_idx = hit_list ? hit_list[li] : li;
+            pre = reinterpret_cast<const uint4*>(hits + pre_idx)[p];
+        }
+    };
+    prefetch(blockIdx.x);
+  for (uint32_t it = blockIdx.x; it < n_iter; it += gridDim.x) {
+    const uint32_t li = it * hpb + (uint32_t)hl;
+    const bool exists = in_blk && li < n_list;
+    if (exists && p < PIECES) s_hit[hl * PIECES + p] = pre;
+    if (in_blk && p == PIECES) { s_max[hl] = 0ull; s_sec[hl] = 0ull; s_cnt1[hl] = 0; s_top[hl] = 0x7FFFFFFF; }
     __syncthreads();
-    const int hls = hl < (int)hpb ? hl : 0;  // lanes past the last hit of the block compute on hit 0's window, results unused
+    const uint32_t hit_idx = hit_list ? (exists ? hit_list[li] : 0u) : li;
+    prefetch(it + gridDim.x);  // in flight during this iteration's compute
+    const bb_hit* Hs = reinterpret_cast<const bb_hit*>(s_hit + hls * PIECES);
+    bb_hit H;  // header only
+    {
+        const uint4 h0 = s_hit[hls * PIECES], h1 = s_hit[hls * PIECES + 1];
+        H.read_idx = h0.x; H.text_start = h0.y; H.text_end = h0.z; H.ws = h0.w;
+        H.we = h1.x; H.cost = (int16_t)(h1.y & 0xFFFFu); H.group = (uint8_t)((h1.y >> 16) & 0xFFu); H.strand = (uint8_t)(h1.y >> 24);
+        H.valid = (uint8_t)(h1.z & 0xFFu); H.read_len = h1.w;
+    }
+    (void)Hs;
+    bool active = exists && H.valid != 0;
+    if (exists && !H.valid && p == 0) rows[hit_idx].valid = 0;
+    const int32_t wn = active ? (int32_t)(H.we - H.ws) : 0;
 
     int wmax = wn;
 #pragma unroll
@@ -612,9 +645,8 @@ __global__ __launch_bounds__(512) void k_barcode_reg(const uint8_t* __restrict__
     int32_t best_cost = wn == 0 ? m : 0x7FFFFFFF, best_pos = wn == 0 ? 0 : -1;
     {
         uint32_t wc[CW / 4];
-        const uint4* wsrc = reinterpret_cast<const uint4*>(s_win + hls * CW);
 #pragma unroll
-        for (int q = 0; q < CW / 16; ++q) { uint4 v = wsrc[q]; wc[4 * q] = v.x; wc[4 * q + 1] = v.y; wc[4 * q + 2] = v.z; wc[4 * q + 3] = v.w; }
+        for (int q = 0; q < CW / 16; ++q) { uint4 v = s_hit[hls * PIECES + 2 + q]; wc[4 * q] = v.x; wc[4 * q + 1] = v.y; wc[4 * q + 2] = v.z; wc[4 * q + 3] = v.w; }
         const uint32_t* pb = s_peq + (size_t)(active ? H.strand : 0) * 16 * N * WB + (size_t)p * WB;
         uint32_t pv[WB], mv[WB];
 #pragma unroll
@@ -653,17 +685,18 @@ __global__ __launch_bounds__(512) void k_barcode_reg(const uint8_t* __restrict__
         }
         if (active && best_pos >= 0 && best_cost <= G.k1) atomicAdd(&s_cnt1[hl], 1);
     }
-    __syncthreads();
-
-    // ---- pass decision (searcher.rs:303-328) ----
-    bool cand = false;
-    if (active) {
-        const bool pass2 = s_cnt1[hl] <= 1 && G.k1 < G.k2;
-        cand = best_pos >= 0 && (pass2 ? best_cost <= G.k2 : best_cost <= G.k1);
-    }
-    // ---- traceback, one predicated step per column ----
+    // Every lane with a local minimum traces and scores (a wave executes those instructions for all
+    // its lanes anyway); which of them are candidates — pass 1 (<= k1) or the deeper pass 2
+    // (searcher.rs:303-328) — is decided after the block-wide count below.
+    bool cand = active && best_pos >= 0 && best_cost <= G.k2;
+    // ---- traceback, one predicated step per column.  The sub-path of map_pat_to_text_with_cost
+    // (cigar_parse.rs:6-68) falls out of it: every pattern row has exactly one consuming op, so the
+    // pattern span of rows [rel_lo, rel_hi) is constant, its text span is where rows rel_lo and
+    // rel_hi-1 are consumed, and its cost counts the non-match entries whose pattern index is in range.
+    const int32_t rlo = G.rel_lo, rhi = G.rel_hi;
     unsigned long long delrow = 0ull, plo = 0ull, phi = 0ull;
     int32_t j = m, i = cand ? best_pos : -1, tstart = 0;
+    int32_t txt_lo = 0, txt_hi = 0, bcost = 0;
 #pragma unroll
     for (int c0 = CW; c0 >= 8; c0 -= 8) {
         if (c0 - 7 <= wmax) {  // wave-uniform
@@ -674,17 +707,23 @@ __global__ __launch_bounds__(512) void k_barcode_reg(const uint8_t* __restrict__
                 const unsigned long long hi64 = (unsigned long long)H0[c - 1] | ((unsigned long long)(X[c - 1] >> 16) << 32);
                 const unsigned long long d64 = lo64 & hi64;
                 const int jj = act ? j : 1;
-                // run of Del moves from row jj downwards
+                // run of Del moves from row jj downwards: rows (j2, jj] are deleted at text position c
                 const int nd = clz64(~(d64 << (64 - jj)));
                 const unsigned long long dm = (nd >= 64 ? ~0ull : ((1ull << nd) - 1ull)) << (jj - nd);
                 const int j2 = jj - nd;
                 const bool has = act & (j2 > 0);
                 const int b2i = has ? j2 - 1 : 0;
-                const unsigned long long lo = (lo64 >> b2i) & 1ull, hi = (hi64 >> b2i) & 1ull;
+                const uint32_t lo = (uint32_t)(lo64 >> b2i) & 1u, hi = (uint32_t)(hi64 >> b2i) & 1u;
+                const bool isI = (hi == 1u) & (lo == 0u);
                 delrow |= act ? dm : 0ull;
-                plo |= has ? (lo << (c - 1)) : 0ull;
-                phi |= has ? (hi << (c - 1)) : 0ull;
-                const int j3 = j2 - ((has & !(hi == 1ull && lo == 0ull)) ? 1 : 0);  // Ins consumes no pattern row
+                plo |= has ? ((unsigned long long)lo << (c - 1)) : 0ull;
+                phi |= has ? ((unsigned long long)hi << (c - 1)) : 0ull;
+                const int j3 = j2 - ((has & !isI) ? 1 : 0);  // rows consumed before this column's text op = its pattern index
+                // sub-path: 1-based row rhi is the last in range, 1-based row rlo the last before the range
+                txt_hi = (act & (j2 < rhi) & (rhi <= jj)) ? c + 1 : txt_hi;            // row rhi deleted here: entry text idx c
+                txt_hi = (has & !isI & (j2 == rhi)) ? c : txt_hi;                      // row rhi matched/substituted: entry text idx c-1
+                txt_lo = (act & (j3 < rlo) & (rlo <= jj)) ? c : txt_lo;                // position after row rlo is consumed
+                bcost += (has & (lo | hi) & (j3 >= rlo) & (j3 < rhi)) ? 1 : 0;         // Sub / Ins entries in range
                 const bool fin_here = act & (j2 == 0);           // path starts at column c (only Dels in it)
                 const bool fin_prev = has & (j3 == 0);           // path starts at column c-1
                 tstart = fin_here ? c : (fin_prev ? c - 1 : tstart);
@@ -693,32 +732,27 @@ __global__ __launch_bounds__(512) void k_barcode_reg(const uint8_t* __restrict__
             }
         }
     }
-    if (i == 0 && j > 0) {  // reached column 0 with pattern rows left: leading Dels (tstart stays 0)
+    if (i == 0 && j > 0) {  // reached column 0 with pattern rows left: leading Dels at text position 0
         delrow |= (1ull << j) - 1ull;
+        txt_hi = rhi <= j ? 1 : txt_hi;
+        txt_lo = rlo <= j ? 0 : txt_lo;
     }
-    // ---- forward replay: Lodhi (scaled) + sub-path (cigar_parse.rs:6-68) ----
+    if (rlo == 0) txt_lo = tstart;
+    {   // deleted rows in range are non-match entries too
+        const unsigned long long rm = (rhi >= 64 ? ~0ull : ((1ull << rhi) - 1ull)) & ~((1ull << rlo) - 1ull);
+        bcost += __popcll(delrow & rm);
+    }
+    const int32_t pat_lo = rlo, pat_hi = rhi;
+    // ---- forward replay: Lodhi only.  Scaled recurrence (see header): b1 = 2^t a1, b2 = 2^t a2 change
+    // only at match columns; score += 2^-(t+1) * b2 (exact scaling, same rounding as the oracle's add).
     double s_norm = -1.0;
-    int32_t pat_lo = 0, pat_hi = 0, txt_lo = 0, txt_hi = 0, bcost = 0;
     {
-        double S = 0.0, b1 = 0.0, b2 = 0.0;
-        int32_t t = 0, pj = 0;
-        bool any = false;
-        const int32_t rlo = G.rel_lo, rhi = G.rel_hi;
-        auto dels = [&](bool on, int32_t ti) {  // run of Del ops starting at pattern row pj, text index ti
-            const int nd = on ? ctz64(~(delrow >> pj)) : 0;
-            S = ldexp(S, nd);
-            t += nd;
-            const int32_t a = max(pj, rlo), b = min(pj + nd, rhi);
-            const bool inr = a < b;
-            pat_lo = (inr & !any) ? a : pat_lo;
-            txt_lo = (inr & !any) ? ti : txt_lo;
-            pat_hi = inr ? b : pat_hi;
-            txt_hi = inr ? ti + 1 : txt_hi;
-            bcost += inr ? b - a : 0;
-            any |= inr;
-            pj += nd;
-        };
-        dels(cand, tstart);
+        double sc = 0.0, b1 = 0.0, b2 = 0.0;
+        int32_t pj = 0, t = 0;
+        {   // leading Dels
+            const int nd = cand ? ctz64(~delrow) : 0;
+            pj = nd; t = nd;
+        }
 #pragma unroll
         for (int c0 = 1; c0 <= CW; c0 += 8) {
             if (c0 <= wmax) {  // wave-uniform
@@ -726,31 +760,28 @@ __global__ __launch_bounds__(512) void k_barcode_reg(const uint8_t* __restrict__
                 for (int c = c0; c < c0 + 8; ++c) {
                     const bool on = cand & (c > tstart) & (c <= best_pos);
                     const uint32_t lo = (uint32_t)(plo >> (c - 1)) & 1u, hi = (uint32_t)(phi >> (c - 1)) & 1u;
-                    const bool isM = on & (lo == 0u) & (hi == 0u);
-                    if (on) S = S + S;
-                    if (isM) {
+                    if (on & ((lo | hi) == 0u)) {  // Match column
+                        const double w = __longlong_as_double((long long)(1022 - t) << 52);  // 2^-(t+1)
                         const double pw = __longlong_as_double((long long)(1023 + t) << 52);  // 2^t
-                        S = S + b2; b2 = b2 + b1; b1 = b1 + pw;
+                        sc = sc + w * b2; b2 = b2 + b1; b1 = b1 + pw;
                     }
-                    const bool inr = on & (pj >= rlo) & (pj < rhi);
-                    pat_lo = (inr & !any) ? pj : pat_lo;
-                    txt_lo = (inr & !any) ? c - 1 : txt_lo;
-                    pat_hi = inr ? pj + 1 : pat_hi;
-                    txt_hi = inr ? c : txt_hi;
-                    bcost += (inr & !isM) ? 1 : 0;
-                    any |= inr;
-                    pj += (on & !(hi == 1u && lo == 0u)) ? 1 : 0;
-                    t += on ? 1 : 0;
-                    dels(on, c);
+                    const int adv = (on & !((hi == 1u) & (lo == 0u))) ? 1 : 0;
+                    pj += adv;
+                    const int nd = on ? ctz64(~(delrow >> pj)) : 0;   // Dels that follow this column's op
+                    pj += nd;
+                    t += (on ? 1 : 0) + nd;
                 }
             }
         }
-        if (cand) {
-            const double sc = S * __longlong_as_double((long long)(1023 - t) << 52);  // S * 2^-t (exact)
-            s_norm = G.perfect > 0.0 ? sc / G.perfect : 0.0;
-        }
+        if (cand) s_norm = G.perfect > 0.0 ? sc / G.perfect : 0.0;
     }
-    // ---- per-hit argmax (first maximum) and runner-up: searcher.rs:377,390-396 ----
+    // ---- pass decision (searcher.rs:303-328), then per-hit argmax (first maximum) and runner-up:
+    // searcher.rs:377,390-396 ----
+    __syncthreads();
+    if (active) {
+        const bool pass2 = s_cnt1[hl] <= 1 && G.k1 < G.k2;
+        cand = cand && (pass2 || best_cost <= G.k1);
+    }
     const unsigned long long key = cand ? (unsigned long long)__double_as_longlong(s_norm) + 1ull : 0ull;
     if (cand) atomicMax(&s_max[hl], key);
     __syncthreads();
@@ -768,7 +799,7 @@ __global__ __launch_bounds__(512) void k_barcode_reg(const uint8_t* __restrict__
             bool valid = have && s_norm >= min_score;
             const unsigned long long sk = s_sec[hl];
             if (valid && sk != 0ull) valid = (s_norm - __longlong_as_double((long long)(sk - 1ull))) >= min_score_diff;
-            const uint32_t read_len = (uint32_t)(offsets[H.read_idx + 1] - offsets[H.read_idx]);
+            const uint32_t read_len = H.read_len;
             bb_rowtmp R;
             bb_row& r = R.row;
             r.read_idx = H.read_idx; r.read_len = read_len;
@@ -790,6 +821,8 @@ __global__ __launch_bounds__(512) void k_barcode_reg(const uint8_t* __restrict__
             rows[hit_idx] = R;
         }
     }
+    __syncthreads();  // LDS hit records / reduction cells are rewritten by the next iteration
+  }
 }
 
 // Per-group hit lists for k_barcode (only needed with more than one query group).  Hits whose
