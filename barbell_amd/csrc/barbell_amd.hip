@@ -143,6 +143,7 @@ struct bb_ctx {
     int n_cus = 256;
     uint32_t reg_blocks_mult = 1;  // BARBELL_AMD_REG_BLOCKS: persistent blocks per resident slot (tuning knob)
     uint32_t reg_threads = 512;  // BARBELL_AMD_REG_THREADS: block size of k_barcode_reg (tuning knob)
+    bool scan_v1 = false;        // BARBELL_AMD_SCAN_V1=1: the first-generation scan kernel (per-lane 16-byte loads)
     bool force_generic = false;  // BARBELL_AMD_GENERIC=1: use the generic (any-geometry) kernels, for tests
     hipEvent_t ev[K_COUNT + 1]{};
     float ms[K_COUNT]{};
@@ -299,6 +300,12 @@ int scan_u32(bb_ctx* c, const uint32_t* in, uint32_t* out, uint64_t n) {
 
 template <int W>
 void launch_scan(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n, uint32_t g) {
+    if (!c->scan_v1) {
+        hipLaunchKernelGGL(k_flank_scan2<W>, dim3((n + 255) / 256, 2), dim3(256), 0, c->stream, d_bases, d_offsets, n,
+                           (const uint8_t*)c->d_tables, (const bb_group_dev*)c->d_groups, g, (uint32_t)c->groups.size(), c->d_cnt,
+                           c->d_raw, c->cap_hits, c->d_hitcount);
+        return;
+    }
     hipLaunchKernelGGL(k_flank_scan<W>, dim3((n + 255) / 256), dim3(256), 0, c->stream, d_bases, d_offsets, n,
                        (const uint8_t*)c->d_tables, (const bb_group_dev*)c->d_groups, g, (uint32_t)c->groups.size(), c->d_cnt,
                        c->d_raw, c->cap_hits, c->d_hitcount);
@@ -388,6 +395,7 @@ int bb_create(const bb_group_desc* groups, uint32_t n_groups, const bb_params* p
     bb_ctx* c = new bb_ctx();
     c->params = *params;
     c->force_generic = getenv("BARBELL_AMD_GENERIC") && atoi(getenv("BARBELL_AMD_GENERIC")) != 0;
+    c->scan_v1 = getenv("BARBELL_AMD_SCAN_V1") && atoi(getenv("BARBELL_AMD_SCAN_V1")) != 0;
     if (getenv("BARBELL_AMD_REG_THREADS")) { int t = atoi(getenv("BARBELL_AMD_REG_THREADS")); if (t >= 64 && t <= 512) c->reg_threads = (uint32_t)t; }
     c->groups.resize(n_groups);
     for (uint32_t i = 0; i < n_groups; ++i) {

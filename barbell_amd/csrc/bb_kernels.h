@@ -215,6 +215,133 @@ __global__ __launch_bounds__(256) void k_flank_scan(const uint8_t* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_flank_scan2: the production scan.  One lane = one (read, strand); grid.y = strand, so a block
+// needs one strand's Peq table.  Reads are streamed from HBM in whole, 128-byte-aligned lines:
+// each lane's next line is copied global->LDS with eight 16-byte LDS-DMA loads
+// (global_load_lds_dwordx4: per-lane source address, wave-linear LDS destination, no VGPR staging),
+// then consumed 16 bytes at a time with conflict-free ds_read_b128.  Every line of the batch is
+// therefore requested from HBM exactly once per strand (k_flank_scan's per-lane 16-byte loads
+// re-fetched each line ~7x: profiles/r01_v1_pmc.txt).  The partial first/last line of a read is
+// walked with byte loads.  The reverse-complement strand walks lines and bytes downwards.
+// ------------------------------------------------------------------------------------------------
+template <int W, int STRAND>
+__device__ __forceinline__ void flank_scan_lane(const uint8_t* __restrict__ bases, const uint64_t* __restrict__ offsets,
+                                                uint32_t n_reads, const uint8_t* __restrict__ tables, const bb_group_dev& G,
+                                                uint32_t g, uint32_t n_groups, uint32_t* __restrict__ cnt,
+                                                bb_hit_raw* __restrict__ hits, uint32_t hit_cap, uint32_t* __restrict__ hit_count,
+                                                const uint32_t* s_peq, uint4* s_line /* this wave's [8][64] */) {
+    constexpr int S = (W <= 2 ? 2 : 4);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t read = blockIdx.x * 256u + threadIdx.x;
+    const bool live = read < n_reads;
+    const uint64_t off = live ? offsets[read] : 0ull;
+    const uint32_t n = live ? (uint32_t)(offsets[read + 1] - off) : 0u;
+    const uint8_t* rb = bases + off;
+    const int32_t kk = G.flank_k;
+    const int m = G.m;
+    const int TB = (m - 1) & 31;
+    const uint32_t* pv0 = reinterpret_cast<const uint32_t*>(tables + G.off_pv0);
+    const int32_t* ovh = reinterpret_cast<const int32_t*>(tables + G.off_ovh);
+
+    uint32_t pv[W], mv[W];
+#pragma unroll
+    for (int w = 0; w < W; ++w) { pv[w] = pv0[w]; mv[w] = 0; }
+    int32_t sc = G.score0;
+    lm_lane st = {G.score0, 1u, 0u};
+    uint32_t idx = 0;  // scan position (characters consumed)
+
+    auto step = [&](uint32_t ch) {
+        uint32_t eq[W], d0[W], ph[W], mh[W];
+        load_eq<W, S>(s_peq, ch, eq);
+        myers_step<W>(pv, mv, eq, d0, ph, mh);
+        sc += (int32_t)((ph[W - 1] >> TB) & 1u) - (int32_t)((mh[W - 1] >> TB) & 1u);
+        ++idx;
+        BB_LM_STEP(st, sc, idx, (uint32_t)STRAND);
+    };
+
+    // geometry of the walk in forward byte coordinates [0, n)
+    const uint64_t a0 = (uint64_t)(uintptr_t)rb;
+    uint32_t head, nlines;
+    if (STRAND == 0) head = (uint32_t)((128u - (uint32_t)(a0 & 127u)) & 127u);
+    else head = (uint32_t)((a0 + n) & 127u);
+    if (head > n) head = n;
+    nlines = (n - head) >> 7;
+    const uint32_t tail = n - head - (nlines << 7);
+
+    // partial first line
+    for (uint32_t t = 0; t < head; ++t) step(STRAND == 0 ? rb[t] : rb[n - 1 - t]);
+    // whole lines through LDS
+    uint32_t lmax = nlines;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) lmax = max(lmax, (uint32_t)__shfl_xor((int)lmax, d, 64));
+    lmax = __builtin_amdgcn_readfirstlane(lmax);
+    for (uint32_t l = 0; l < lmax; ++l) {
+        const bool on = l < nlines;
+        if (on) {
+            const uint8_t* src = STRAND == 0 ? rb + head + (l << 7) : rb + (n - head - ((l + 1) << 7));
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 16 * q),
+                                                 (__attribute__((address_space(3))) void*)(s_line + 64 * q), 16, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (on) {
+            for (int q = 0; q < 8; ++q) {
+                const uint4 v = s_line[64 * (STRAND == 0 ? q : 7 - q) + lane];
+#pragma unroll
+                for (int b = 0; b < 16; ++b) {
+                    const int bb = STRAND == 0 ? b : 15 - b;
+                    const uint32_t word = (bb >> 2) == 0 ? v.x : (bb >> 2) == 1 ? v.y : (bb >> 2) == 2 ? v.z : v.w;
+                    step((word >> (8 * (bb & 3))) & 0xFFu);
+                }
+            }
+        }
+    }
+    // partial last line
+    for (uint32_t t = 0; t < tail; ++t) step(STRAND == 0 ? rb[head + (nlines << 7) + t] : rb[tail - 1 - t]);
+
+    // right overhang (oracle [H4]): C[n+o] = D[m-o][n] + floor(alpha*o), o = 1..m
+    if (live) {
+        int32_t d = sc;
+        for (int o = 1; o <= m; ++o) {
+            d -= (int32_t)((pv[W - 1] >> TB) & 1u) - (int32_t)((mv[W - 1] >> TB) & 1u);
+#pragma unroll
+            for (int w = W - 1; w >= 0; --w) {
+                pv[w] = (pv[w] << 1) | (w ? (pv[w - 1] >> 31) : 0u);
+                mv[w] = (mv[w] << 1) | (w ? (mv[w - 1] >> 31) : 0u);
+            }
+            ++idx;
+            BB_LM_STEP(st, d + ovh[o], idx, (uint32_t)STRAND);
+        }
+        if (st.dec && st.prev <= kk) emit_hit(hits, hit_cap, hit_count, read, n + (uint32_t)m, st.prev, g, (uint32_t)STRAND, st.nrep++);
+        cnt[((uint64_t)read * n_groups + g) * 2 + STRAND] = st.nrep;
+    }
+}
+
+template <int W>
+__global__ __launch_bounds__(256) void k_flank_scan2(const uint8_t* __restrict__ bases, const uint64_t* __restrict__ offsets,
+                                                     uint32_t n_reads, const uint8_t* __restrict__ tables,
+                                                     const bb_group_dev* __restrict__ groups, uint32_t g, uint32_t n_groups,
+                                                     uint32_t* __restrict__ cnt, bb_hit_raw* __restrict__ hits,
+                                                     uint32_t hit_cap, uint32_t* __restrict__ hit_count) {
+    constexpr int S = (W <= 2 ? 2 : 4);
+    __shared__ __attribute__((aligned(16))) uint32_t s_peq[256 * S];
+    __shared__ __attribute__((aligned(16))) uint4 s_lines[4][8 * 64];
+    const bb_group_dev G = groups[g];
+    const uint32_t strand = blockIdx.y;
+    {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(tables + G.off_peq_flank[strand]);
+        for (int i = threadIdx.x; i < 256 * S; i += 256) s_peq[i] = src[i];
+    }
+    __syncthreads();
+    uint4* line = s_lines[threadIdx.x >> 6];
+    if (strand == 0)
+        flank_scan_lane<W, 0>(bases, offsets, n_reads, tables, G, g, n_groups, cnt, hits, hit_cap, hit_count, s_peq, line);
+    else
+        flank_scan_lane<W, 1>(bases, offsets, n_reads, tables, G, g, n_groups, cnt, hits, hit_cap, hit_count, s_peq, line);
+}
+
+// ------------------------------------------------------------------------------------------------
 // exclusive scan of uint32 (3 small kernels): 2048 elements per block
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_scan_block(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint64_t n,
