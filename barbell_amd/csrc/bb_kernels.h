@@ -224,6 +224,37 @@ __global__ __launch_bounds__(256) void k_flank_scan(const uint8_t* __restrict__ 
 // re-fetched each line ~7x: profiles/r01_v1_pmc.txt).  The partial first/last line of a read is
 // walked with byte loads.  The reverse-complement strand walks lines and bytes downwards.
 // ------------------------------------------------------------------------------------------------
+// Hits found by a lane are kept in registers (up to 4) and written once at the end of the read:
+// a returning global atomic inside the column loop would park the whole wave for a memory round
+// trip every time any lane reports (the dominant stall of the first version: profiles/r01_v2_pmc.txt).
+struct hit_buf {
+    uint32_t e0, e1, e2, e3;
+    uint32_t costs;  // 4 x 8 bit
+};
+#define BB_LM_STEP_BUF(ST, CUR, IDX)                                                            \
+    do {                                                                                        \
+        int32_t cur_ = (CUR);                                                                   \
+        if (min(cur_, ST.prev) <= kk) {                                                         \
+            if (cur_ > ST.prev) {                                                               \
+                if (ST.dec && ST.prev <= kk) {                                                  \
+                    const uint32_t e_ = (IDX)-1u, k_ = ST.nrep;                                 \
+                    if (k_ < 4u) {                                                              \
+                        hb.e0 = k_ == 0u ? e_ : hb.e0; hb.e1 = k_ == 1u ? e_ : hb.e1;           \
+                        hb.e2 = k_ == 2u ? e_ : hb.e2; hb.e3 = k_ == 3u ? e_ : hb.e3;           \
+                        hb.costs |= ((uint32_t)ST.prev & 0xFFu) << (8u * k_);                   \
+                    } else {                                                                    \
+                        emit_hit(hits, hit_cap, hit_count, read, e_, ST.prev, g, (uint32_t)STRAND, k_); \
+                    }                                                                           \
+                    ST.nrep = k_ + 1u;                                                          \
+                }                                                                               \
+                ST.dec = 0;                                                                     \
+            } else if (cur_ < ST.prev) {                                                        \
+                ST.dec = 1;                                                                     \
+            }                                                                                   \
+        }                                                                                       \
+        ST.prev = cur_;                                                                         \
+    } while (0)
+
 template <int W, int STRAND>
 __device__ __forceinline__ void flank_scan_lane(const uint8_t* __restrict__ bases, const uint64_t* __restrict__ offsets,
                                                 uint32_t n_reads, const uint8_t* __restrict__ tables, const bb_group_dev& G,
@@ -248,6 +279,7 @@ __device__ __forceinline__ void flank_scan_lane(const uint8_t* __restrict__ base
     for (int w = 0; w < W; ++w) { pv[w] = pv0[w]; mv[w] = 0; }
     int32_t sc = G.score0;
     lm_lane st = {G.score0, 1u, 0u};
+    hit_buf hb = {0u, 0u, 0u, 0u, 0u};
     uint32_t idx = 0;  // scan position (characters consumed)
 
     auto step = [&](uint32_t ch) {
@@ -256,7 +288,7 @@ __device__ __forceinline__ void flank_scan_lane(const uint8_t* __restrict__ base
         myers_step<W>(pv, mv, eq, d0, ph, mh);
         sc += (int32_t)((ph[W - 1] >> TB) & 1u) - (int32_t)((mh[W - 1] >> TB) & 1u);
         ++idx;
-        BB_LM_STEP(st, sc, idx, (uint32_t)STRAND);
+        BB_LM_STEP_BUF(st, sc, idx);
     };
 
     // geometry of the walk in forward byte coordinates [0, n)
@@ -311,10 +343,44 @@ __device__ __forceinline__ void flank_scan_lane(const uint8_t* __restrict__ base
                 mv[w] = (mv[w] << 1) | (w ? (mv[w - 1] >> 31) : 0u);
             }
             ++idx;
-            BB_LM_STEP(st, d + ovh[o], idx, (uint32_t)STRAND);
+            BB_LM_STEP_BUF(st, d + ovh[o], idx);
         }
-        if (st.dec && st.prev <= kk) emit_hit(hits, hit_cap, hit_count, read, n + (uint32_t)m, st.prev, g, (uint32_t)STRAND, st.nrep++);
+        if (st.dec && st.prev <= kk) {
+            const uint32_t e_ = n + (uint32_t)m, k_ = st.nrep;
+            if (k_ < 4u) {
+                hb.e0 = k_ == 0u ? e_ : hb.e0; hb.e1 = k_ == 1u ? e_ : hb.e1;
+                hb.e2 = k_ == 2u ? e_ : hb.e2; hb.e3 = k_ == 3u ? e_ : hb.e3;
+                hb.costs |= ((uint32_t)st.prev & 0xFFu) << (8u * k_);
+            } else {
+                emit_hit(hits, hit_cap, hit_count, read, e_, st.prev, g, (uint32_t)STRAND, k_);
+            }
+            st.nrep = k_ + 1u;
+        }
         cnt[((uint64_t)read * n_groups + g) * 2 + STRAND] = st.nrep;
+    }
+    // flush the buffered hits: one atomic per wave
+    {
+        const uint32_t mine = live ? min(st.nrep, 4u) : 0u;
+        uint32_t incl = mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t y = (uint32_t)__shfl_up((int)incl, d, 64); if ((int)lane >= d) incl += y; }
+        const uint32_t total = (uint32_t)__shfl((int)incl, 63, 64);
+        uint32_t base = 0;
+        if (total) {
+            if (lane == 0) base = atomicAdd(hit_count, total);
+            base = (uint32_t)__shfl((int)base, 0, 64);
+            uint32_t slot = base + incl - mine;
+            const uint32_t es[4] = {hb.e0, hb.e1, hb.e2, hb.e3};
+#pragma unroll
+            for (uint32_t k = 0; k < 4; ++k) {
+                if (k < mine && slot + k < hit_cap) {
+                    bb_hit_raw h;
+                    h.read_idx = read; h.e = es[k]; h.cost = (int16_t)((hb.costs >> (8u * k)) & 0xFFu);
+                    h.group = (uint8_t)g; h.strand = (uint8_t)STRAND; h.ordinal = k;
+                    hits[slot + k] = h;
+                }
+            }
+        }
     }
 }
 
