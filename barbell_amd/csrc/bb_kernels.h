@@ -762,6 +762,54 @@ __global__ __launch_bounds__(1024) void k_barcode(const uint8_t* __restrict__ ba
 __device__ __forceinline__ int clz64(unsigned long long x) { return x ? __clzll((long long)x) : 64; }
 __device__ __forceinline__ int ctz64(unsigned long long x) { return x ? __ffsll((long long)x) - 1 : 64; }
 
+// position (bit index) of the k-th (0-based) set bit of x; k < popcount(x)
+__device__ __forceinline__ int select64(unsigned long long x, int k) {
+    uint32_t w = (uint32_t)x;
+    int base = 0;
+    int pc = __popc(w);
+    if (k >= pc) { k -= pc; w = (uint32_t)(x >> 32); base = 32; }
+#pragma unroll
+    for (int s = 16; s >= 1; s >>= 1) {
+        const uint32_t lowm = (1u << s) - 1u;
+        pc = __popc(w & lowm);
+        const bool up = k >= pc;
+        k -= up ? pc : 0;
+        w = up ? (w >> s) : w;
+        base += up ? s : 0;
+    }
+    return base;
+}
+__device__ __forceinline__ unsigned long long low64(int n) { return n >= 64 ? ~0ull : ((1ull << n) - 1ull); }
+
+// map_pat_to_text_with_cost (cigar_parse.rs:6-68) in closed form from the traceback's masks, for
+// pattern rows [rlo, rhi): plo/phi = text op of each column (bit c-1), diagrow = rows consumed by a
+// Match/Sub, columns (tstart, best_pos] carry text ops.  Uses that an optimal alignment never has an
+// Ins next to a Del.  Every pattern row has exactly one consuming op, so the pattern span is constant.
+__device__ __forceinline__ void subpath_closed_form(unsigned long long plo, unsigned long long phi, unsigned long long diagrow,
+                                                    int tstart, int best_pos, int m, int rlo, int rhi,
+                                                    int32_t& txt_lo, int32_t& txt_hi, int32_t& bcost) {
+    const unsigned long long CM = low64(best_pos) & ~low64(tstart);        // columns with a text op (bit c-1)
+    const unsigned long long DG = CM & ~(phi & ~plo);                       // ... that consume a pattern row (not Ins)
+    const unsigned long long NR = diagrow;                                  // rows consumed by those columns, same order
+    const unsigned long long delrow = low64(m) & ~diagrow;
+    // text position after the last non-deleted row below row r has been consumed
+    auto pos_below = [&](int r) { const int k = __popcll(NR & low64(r)); return k == 0 ? tstart : select64(DG, k - 1) + 1; };
+    txt_lo = pos_below(rlo);                                                // = tstart when rlo == 0
+    {
+        const int r = rhi - 1;
+        if ((NR >> r) & 1ull) txt_hi = select64(DG, __popcll(NR & low64(r))) + 1;   // entry text idx = column - 1
+        else txt_hi = pos_below(r) + 1;                                             // deleted: entry text idx = current position
+    }
+    const int ka = __popcll(NR & low64(rlo)), kb = __popcll(NR & low64(rhi));
+    int32_t cost = __popcll(delrow & low64(rhi) & ~low64(rlo));
+    if (kb > ka) {
+        const int selA = ka == 0 ? tstart - 1 : select64(DG, ka - 1);
+        const int selB = select64(DG, kb - 1);
+        cost += __popcll((plo | phi) & low64(selB + 1) & ~low64(selA + 1));         // Sub / Ins entries in range
+    }
+    bcost = cost;
+}
+
 template <int WB, int CW>
 __global__ __launch_bounds__(512) void k_barcode_reg(const uint8_t* __restrict__ tables, const bb_group_dev* __restrict__ groups,
                                                      uint32_t g, const bb_hit* __restrict__ hits, const uint32_t* __restrict__ hit_list,
@@ -833,20 +881,22 @@ __global__ __launch_bounds__(512) void k_barcode_reg(const uint8_t* __restrict__
     for (int d = 32; d >= 1; d >>= 1) wmax = max(wmax, __shfl_xor(wmax, d, 64));
     wmax = __builtin_amdgcn_readfirstlane(wmax);
 
-    // ---- forward pass: Myers + move bits; columns unrolled; all state in registers ----
+    // ---- forward pass: Myers + move bits; columns unrolled; all state in registers.  The bottom-row
+    // score is not tracked per column: its +1/-1 deltas are collected in two 64-bit column masks and the
+    // local-minimum rule (oracle [H1]) is resolved bit-parallel after the loop. ----
     uint32_t L0[CW], H0[CW], X[CW];
-    int32_t best_cost = wn == 0 ? m : 0x7FFFFFFF, best_pos = wn == 0 ? 0 : -1;
+    int32_t best_cost = 0x7FFFFFFF, best_pos = -1;
     {
         uint32_t wc[CW / 4];
 #pragma unroll
         for (int q = 0; q < CW / 16; ++q) { uint4 v = s_hit[hls * PIECES + 2 + q]; wc[4 * q] = v.x; wc[4 * q + 1] = v.y; wc[4 * q + 2] = v.z; wc[4 * q + 3] = v.w; }
-        const uint32_t* pb = s_peq + (size_t)(active ? H.strand : 0) * 16 * N * WB + (size_t)p * WB;
+        const uint32_t NW = (uint32_t)(N * WB);
+        const uint32_t pb = (uint32_t)((active ? H.strand : 0) * 16) * NW + (uint32_t)p * WB;  // word index into s_peq
         uint32_t pv[WB], mv[WB];
 #pragma unroll
         for (int x = 0; x < WB; ++x) { int bits = m - 32 * x; pv[x] = bits >= 32 ? 0xFFFFFFFFu : (bits > 0 ? ((1u << bits) - 1u) : 0u); mv[x] = 0; }
         const int TB = (m - 1) & 31;
-        int32_t score = m, prev = m;
-        bool dec = true;
+        uint32_t up[2] = {0u, 0u}, dn[2] = {0u, 0u};  // bit c: score rises / falls going from position c to c+1
 #pragma unroll
         for (int c0 = 0; c0 < CW; c0 += 8) {
             if (c0 < wmax) {  // wave-uniform
@@ -854,27 +904,35 @@ __global__ __launch_bounds__(512) void k_barcode_reg(const uint8_t* __restrict__
                 for (int c = c0; c < c0 + 8; ++c) {
                     const uint32_t code = (wc[c >> 2] >> (8 * (c & 3))) & 0xFu;
                     uint32_t eq[WB], d0[WB], ph[WB], mh[WB], l[WB], hh[WB];
-                    const uint32_t* e = pb + (size_t)code * N * WB;
-                    if constexpr (WB == 2) { uint2 v = *reinterpret_cast<const uint2*>(e); eq[0] = v.x; eq[1] = v.y; }
-                    else eq[0] = e[0];
+                    const uint32_t ei = __umul24(code, NW) + pb;
+                    if constexpr (WB == 2) { uint2 v = *reinterpret_cast<const uint2*>(s_peq + ei); eq[0] = v.x; eq[1] = v.y; }
+                    else eq[0] = s_peq[ei];
                     myers_step<WB>(pv, mv, eq, d0, ph, mh);
                     move_bits<WB>(eq, d0, ph, l, hh);
                     L0[c] = l[0]; H0[c] = hh[0];
                     if constexpr (WB == 2) X[c] = (l[1] & 0xFFFFu) | (hh[1] << 16);
                     else X[c] = 0;
-                    score += (int32_t)((ph[WB - 1] >> TB) & 1u) - (int32_t)((mh[WB - 1] >> TB) & 1u);
-                    // local minima, first strictly-lowest (oracle [H1], searcher.rs:294-300); positions >= wn are masked
-                    const bool gt = score > prev, lt = score < prev;
-                    const bool upd1 = (c < wn) & gt & dec & (prev < best_cost);
-                    best_cost = upd1 ? prev : best_cost;
-                    best_pos = upd1 ? c : best_pos;
-                    dec = lt | (dec & !gt);
-                    const bool upd2 = (c + 1 == wn) & dec & (score < best_cost);  // end of the window
-                    best_cost = upd2 ? score : best_cost;
-                    best_pos = upd2 ? c + 1 : best_pos;
-                    prev = score;
+                    up[c >> 5] |= ((ph[WB - 1] >> TB) & 1u) << (c & 31);
+                    dn[c >> 5] |= ((mh[WB - 1] >> TB) & 1u) << (c & 31);
                 }
             }
+        }
+        // positions 0..wn; deltas of columns >= wn are garbage and masked off
+        const unsigned long long wmask = wn >= 64 ? ~0ull : ((1ull << wn) - 1ull);
+        const unsigned long long P = (((unsigned long long)up[1] << 32) | up[0]) & wmask;
+        const unsigned long long M = (((unsigned long long)dn[1] << 32) | dn[0]) & wmask;
+        // dec(q) = "last strict change before position q was a decrease" (initially true):
+        // dec(q+1) = M[q] | (~(P|M)[q] & dec(q))  ==  carry chain of (M | ~P) + M + 1
+        const unsigned long long A = M | ~P;
+        const unsigned long long D = (A + M + 1ull) ^ A ^ M;      // bit q = dec(q)
+        unsigned long long R = (P & D) | (D & (1ull << wn));    // reported positions (plateau right ends, or the window end)
+        if (!active) R = 0ull;
+        while (R) {  // first strictly-lowest reported position (searcher.rs:294-300); 1-4 iterations
+            const int q = ctz64(R);
+            R &= R - 1ull;
+            const unsigned long long lowq = (1ull << q) - 1ull;
+            const int32_t cq = m + __popcll(P & lowq) - __popcll(M & lowq);
+            if (cq < best_cost) { best_cost = cq; best_pos = q; }
         }
         if (active && best_pos >= 0 && best_cost <= G.k1) atomicAdd(&s_cnt1[hl], 1);
     }
@@ -882,14 +940,11 @@ __global__ __launch_bounds__(512) void k_barcode_reg(const uint8_t* __restrict__
     // its lanes anyway); which of them are candidates — pass 1 (<= k1) or the deeper pass 2
     // (searcher.rs:303-328) — is decided after the block-wide count below.
     bool cand = active && best_pos >= 0 && best_cost <= G.k2;
-    // ---- traceback, one predicated step per column.  The sub-path of map_pat_to_text_with_cost
-    // (cigar_parse.rs:6-68) falls out of it: every pattern row has exactly one consuming op, so the
-    // pattern span of rows [rel_lo, rel_hi) is constant, its text span is where rows rel_lo and
-    // rel_hi-1 are consumed, and its cost counts the non-match entries whose pattern index is in range.
+    // ---- traceback, one predicated step per column: text op of each column into two bit planes,
+    // rows consumed by a Match/Sub into a row mask (a run of Del moves is one count-leading-ones) ----
     const int32_t rlo = G.rel_lo, rhi = G.rel_hi;
-    unsigned long long delrow = 0ull, plo = 0ull, phi = 0ull;
+    unsigned long long diagrow = 0ull, plo = 0ull, phi = 0ull;
     int32_t j = m, i = cand ? best_pos : -1, tstart = 0;
-    int32_t txt_lo = 0, txt_hi = 0, bcost = 0;
 #pragma unroll
     for (int c0 = CW; c0 >= 8; c0 -= 8) {
         if (c0 - 7 <= wmax) {  // wave-uniform
@@ -898,44 +953,27 @@ __global__ __launch_bounds__(512) void k_barcode_reg(const uint8_t* __restrict__
                 const bool act = i == c;
                 const unsigned long long lo64 = (unsigned long long)L0[c - 1] | ((unsigned long long)(X[c - 1] & 0xFFFFu) << 32);
                 const unsigned long long hi64 = (unsigned long long)H0[c - 1] | ((unsigned long long)(X[c - 1] >> 16) << 32);
-                const unsigned long long d64 = lo64 & hi64;
                 const int jj = act ? j : 1;
-                // run of Del moves from row jj downwards: rows (j2, jj] are deleted at text position c
-                const int nd = clz64(~(d64 << (64 - jj)));
-                const unsigned long long dm = (nd >= 64 ? ~0ull : ((1ull << nd) - 1ull)) << (jj - nd);
+                const int nd = clz64(~((lo64 & hi64) << (64 - jj)));   // Del moves from row jj downwards (<= jj)
                 const int j2 = jj - nd;
                 const bool has = act & (j2 > 0);
-                const int b2i = has ? j2 - 1 : 0;
-                const uint32_t lo = (uint32_t)(lo64 >> b2i) & 1u, hi = (uint32_t)(hi64 >> b2i) & 1u;
-                const bool isI = (hi == 1u) & (lo == 0u);
-                delrow |= act ? dm : 0ull;
-                plo |= has ? ((unsigned long long)lo << (c - 1)) : 0ull;
-                phi |= has ? ((unsigned long long)hi << (c - 1)) : 0ull;
-                const int j3 = j2 - ((has & !isI) ? 1 : 0);  // rows consumed before this column's text op = its pattern index
-                // sub-path: 1-based row rhi is the last in range, 1-based row rlo the last before the range
-                txt_hi = (act & (j2 < rhi) & (rhi <= jj)) ? c + 1 : txt_hi;            // row rhi deleted here: entry text idx c
-                txt_hi = (has & !isI & (j2 == rhi)) ? c : txt_hi;                      // row rhi matched/substituted: entry text idx c-1
-                txt_lo = (act & (j3 < rlo) & (rlo <= jj)) ? c : txt_lo;                // position after row rlo is consumed
-                bcost += (has & (lo | hi) & (j3 >= rlo) & (j3 < rhi)) ? 1 : 0;         // Sub / Ins entries in range
-                const bool fin_here = act & (j2 == 0);           // path starts at column c (only Dels in it)
-                const bool fin_prev = has & (j3 == 0);           // path starts at column c-1
-                tstart = fin_here ? c : (fin_prev ? c - 1 : tstart);
+                const int sh = has ? j2 - 1 : 0;
+                const uint32_t lo = has ? (uint32_t)(lo64 >> sh) & 1u : 0u;
+                const uint32_t hi = has ? (uint32_t)(hi64 >> sh) & 1u : 0u;
+                plo |= (unsigned long long)lo << (c - 1);
+                phi |= (unsigned long long)hi << (c - 1);
+                const bool consume = has & (hi == 0u);                 // Match / Sub consume pattern row j2
+                diagrow |= consume ? (1ull << sh) : 0ull;
+                const int j3 = j2 - (consume ? 1 : 0);
+                const bool done = act & (j3 == 0);
+                tstart = done ? (has ? c - 1 : c) : tstart;
                 j = act ? j3 : j;
-                i = act ? ((fin_here | fin_prev) ? -1 : c - 1) : i;
+                i = act ? (done ? -1 : c - 1) : i;
             }
         }
     }
-    if (i == 0 && j > 0) {  // reached column 0 with pattern rows left: leading Dels at text position 0
-        delrow |= (1ull << j) - 1ull;
-        txt_hi = rhi <= j ? 1 : txt_hi;
-        txt_lo = rlo <= j ? 0 : txt_lo;
-    }
-    if (rlo == 0) txt_lo = tstart;
-    {   // deleted rows in range are non-match entries too
-        const unsigned long long rm = (rhi >= 64 ? ~0ull : ((1ull << rhi) - 1ull)) & ~((1ull << rlo) - 1ull);
-        bcost += __popcll(delrow & rm);
-    }
-    const int32_t pat_lo = rlo, pat_hi = rhi;
+    // (rows left when column 0 is reached are deleted at text position 0: they are simply absent from diagrow)
+    const unsigned long long delrow = cand ? (low64(m) & ~diagrow) : 0ull;
     // ---- forward replay: Lodhi only.  Scaled recurrence (see header): b1 = 2^t a1, b2 = 2^t a2 change
     // only at match columns; score += 2^-(t+1) * b2 (exact scaling, same rounding as the oracle's add).
     double s_norm = -1.0;
@@ -1001,8 +1039,10 @@ __global__ __launch_bounds__(512) void k_barcode_reg(const uint8_t* __restrict__
             r.flank_cost = H.cost; r.group_idx = H.group; r.strand = H.strand;
             r._pad[0] = r._pad[1] = r._pad[2] = 0;
             if (valid) {
+                int32_t txt_lo, txt_hi, bcost;
+                subpath_closed_form(plo, phi, diagrow, tstart, best_pos, m, rlo, rhi, txt_lo, txt_hi, bcost);
                 r.read_start_bar = H.ws + (uint32_t)txt_lo; r.read_end_bar = H.ws + (uint32_t)txt_hi;
-                r.bar_start = H.ws + (uint32_t)pat_lo; r.bar_end = H.ws + (uint32_t)pat_hi;
+                r.bar_start = H.ws + (uint32_t)rlo; r.bar_end = H.ws + (uint32_t)rhi;
                 r.match_type = (uint8_t)G.type; r.barcode_cost = (int16_t)bcost; r.barcode_idx = (int16_t)top;
             } else {
                 r.read_start_bar = H.text_start; r.read_end_bar = H.text_end;
