@@ -223,6 +223,8 @@ int upload_tables(bb_ctx* c) {
             int32_t* t = reinterpret_cast<int32_t*>(blob.b.data() + D.off_ovh);
             for (int o = 0; o <= m; ++o) t[o] = overhang_cost(alpha, o);
         }
+        D.off_lut = blob.alloc(256);
+        for (int ch = 0; ch < 256; ++ch) blob.b[D.off_lut + ch] = bb_text_code((uint8_t)ch);
         const uint32_t peq_bar = blob.alloc((size_t)2 * 16 * N * WB * 4);
         for (int s = 0; s < 2; ++s) {
             D.off_peq_bar[s] = peq_bar + (uint32_t)((size_t)s * 16 * N * WB * 4);
@@ -527,9 +529,9 @@ int bb_annotate_batch_dev(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_o
     mark(c, K_EMIT);
     if (total > rows_cap || (total && !d_rows)) return BB_E_CAPACITY;
     if (total)
-        hipLaunchKernelGGL(k_emit, dim3((n + 255) / 256), dim3(256), 0, c->stream, (const bb_rowtmp*)c->d_rows,
+        hipLaunchKernelGGL(k_emit, dim3((n + 255) / 256), dim3(256), (size_t)c->counts_len * 4, c->stream, (const bb_rowtmp*)c->d_rows,
                            (const uint32_t*)c->d_base, (const uint32_t*)c->d_rowoff, n, G, (const bb_group_dev*)c->d_groups, d_rows,
-                           c->d_counts);
+                           c->d_counts, c->counts_len);
     mark(c, K_COUNT);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stream));

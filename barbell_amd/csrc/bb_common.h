@@ -69,6 +69,7 @@ struct bb_group_dev {
     uint32_t off_ovh;            // (m+1) int32: floor(alpha*o)
     uint32_t off_pcode[2];       // [strand] m bytes: flank base sets (fwd, complemented)
     uint32_t off_peq_bar[2];     // [strand] [16 codes][n_seqs] x WB words
+    uint32_t off_lut;            // 256 bytes: read byte -> 4-bit base set (bb_text_code)
 };
 
 BB_HD int bb_peq_stride_words(int W) { return W <= 2 ? 2 : 4; }

@@ -548,6 +548,7 @@ __global__ __launch_bounds__(64) void k_flank_trace(const uint8_t* __restrict__ 
     const uint4* src = reinterpret_cast<const uint4*>(&out);
     dst[0] = src[0]; dst[1] = src[1];
     const int32_t wn = we - ws;
+    const uint8_t* lut = tables + G.off_lut;
     if (wn <= 64) {  // window codes for k_barcode_reg
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -555,7 +556,7 @@ __global__ __launch_bounds__(64) void k_flank_trace(const uint8_t* __restrict__ 
 #pragma unroll
             for (int b = 0; b < 16; ++b) {
                 const int c = 16 * q + b;
-                const uint32_t code = c < wn ? (uint32_t)bb_text_code(rb[ws + c]) : 0u;
+                const uint32_t code = c < wn ? (uint32_t)lut[rb[ws + c]] : 0u;
                 w4[b >> 2] |= code << (8 * (b & 3));
             }
             dst[2 + q] = make_uint4(w4[0], w4[1], w4[2], w4[3]);
@@ -566,10 +567,10 @@ __global__ __launch_bounds__(64) void k_flank_trace(const uint8_t* __restrict__ 
 // ------------------------------------------------------------------------------------------------
 // k_barcode: block = HPB hits x LPH lanes (LPH = n_seqs).  One lane per (hit, barcode pattern).
 // ------------------------------------------------------------------------------------------------
-struct bb_rowtmp {  // one per hit
+struct __attribute__((aligned(16))) bb_rowtmp {  // one per flank hit: the provisional row; row._pad[0] = 1 when the hit has a row
     bb_row row;
-    uint32_t valid;
 };
+static_assert(sizeof(bb_rowtmp) == 48, "bb_rowtmp is three 16-byte pieces");
 
 __device__ __forceinline__ int32_t rel_dist_to_end(int64_t pos, int64_t read_len) {  // searcher.rs:183-199
     if (pos < 0) return 1;
@@ -613,7 +614,7 @@ __global__ __launch_bounds__(1024) void k_barcode(const uint8_t* __restrict__ ba
     if (active) {
         hit_idx = hit_list ? hit_list[li] : li;
         H = hits[hit_idx];
-        if (!H.valid) { active = false; if (p == 0) rows[hit_idx].valid = 0; }
+        if (!H.valid) { active = false; if (p == 0) rows[hit_idx].row._pad[0] = 0; }
     }
     if (active) {
         wn = (int32_t)(H.we - H.ws);
@@ -726,7 +727,7 @@ __global__ __launch_bounds__(1024) void k_barcode(const uint8_t* __restrict__ ba
             r.rel_dist_to_end = rel_dist_to_end((int64_t)H.text_start, (int64_t)read_len);
             r.read_start_flank = H.text_start; r.read_end_flank = H.text_end;
             r.flank_cost = H.cost; r.group_idx = H.group; r.strand = H.strand;
-            r._pad[0] = r._pad[1] = r._pad[2] = 0;
+            r._pad[0] = 1; r._pad[1] = r._pad[2] = 0;
             if (top >= 0) {                                                // searcher.rs:398-416
                 r.read_start_bar = H.ws + (uint32_t)txt_lo; r.read_end_bar = H.ws + (uint32_t)txt_hi;
                 r.bar_start = H.ws + (uint32_t)pat_lo; r.bar_end = H.ws + (uint32_t)pat_hi;
@@ -737,7 +738,6 @@ __global__ __launch_bounds__(1024) void k_barcode(const uint8_t* __restrict__ ba
                 r.match_type = (uint8_t)(G.type == BB_FTAG ? BB_FFLANK : BB_RFLANK);
                 r.barcode_cost = (int16_t)G.m_bar; r.barcode_idx = -1;
             }
-            R.valid = 1;
             rows[hit_idx] = R;
         }
     }
@@ -873,7 +873,7 @@ __global__ __launch_bounds__(512) void k_barcode_reg(const uint8_t* __restrict__
     }
     (void)Hs;
     bool active = exists && H.valid != 0;
-    if (exists && !H.valid && p == 0) rows[hit_idx].valid = 0;
+    if (exists && !H.valid && p == 0) rows[hit_idx].row._pad[0] = 0;
     const int32_t wn = active ? (int32_t)(H.we - H.ws) : 0;
 
     int wmax = wn;
@@ -1037,7 +1037,7 @@ __global__ __launch_bounds__(512) void k_barcode_reg(const uint8_t* __restrict__
             r.rel_dist_to_end = rel_dist_to_end((int64_t)H.text_start, (int64_t)read_len);
             r.read_start_flank = H.text_start; r.read_end_flank = H.text_end;
             r.flank_cost = H.cost; r.group_idx = H.group; r.strand = H.strand;
-            r._pad[0] = r._pad[1] = r._pad[2] = 0;
+            r._pad[0] = 1; r._pad[1] = r._pad[2] = 0;
             if (valid) {
                 int32_t txt_lo, txt_hi, bcost;
                 subpath_closed_form(plo, phi, diagrow, tstart, best_pos, m, rlo, rhi, txt_lo, txt_hi, bcost);
@@ -1050,7 +1050,6 @@ __global__ __launch_bounds__(512) void k_barcode_reg(const uint8_t* __restrict__
                 r.match_type = (uint8_t)(G.type == BB_FTAG ? BB_FFLANK : BB_RFLANK);
                 r.barcode_cost = (int16_t)G.m_bar; r.barcode_idx = -1;
             }
-            R.valid = 1;
             rows[hit_idx] = R;
         }
     }
@@ -1069,7 +1068,7 @@ __global__ __launch_bounds__(256) void k_hit_lists(const bb_hit* __restrict__ hi
     bb_hit h;
     if (in) h = hits[t];
     const bool valid = in && h.valid;
-    if (in && !valid) rows[t].valid = 0;
+    if (in && !valid) rows[t].row._pad[0] = 0;
     const unsigned lane = threadIdx.x & 63u;
     for (uint32_t g = 0; g < n_groups; ++g) {
         const bool mine = valid && h.group == g;
@@ -1117,7 +1116,7 @@ __global__ __launch_bounds__(256) void k_collapse(bb_rowtmp* __restrict__ rows, 
     bb_rowtmp* R = rows + b0;
     int n = 0;
     for (uint32_t i = 0; i < b1 - b0; ++i)  // drop hits without a row, keep order
-        if (R[i].valid) { if ((int)i != n) R[n].row = R[i].row; ++n; }
+        if (R[i].row._pad[0]) { if ((int)i != n) R[n].row = R[i].row; ++n; }
     for (int i = 1; i < n; ++i) {  // stable insertion sort by read_start_flank (interval.rs:12)
         const bb_row x = R[i].row;
         int j = i - 1;
@@ -1146,16 +1145,30 @@ __global__ __launch_bounds__(256) void k_collapse(bb_rowtmp* __restrict__ rows, 
 __global__ __launch_bounds__(256) void k_emit(const bb_rowtmp* __restrict__ rows, const uint32_t* __restrict__ slot_base,
                                               const uint32_t* __restrict__ row_off, uint32_t n_reads, uint32_t n_groups,
                                               const bb_group_dev* __restrict__ groups, bb_row* __restrict__ out,
-                                              unsigned long long* __restrict__ counts) {
+                                              unsigned long long* __restrict__ counts, uint32_t counts_len) {
+    extern __shared__ uint32_t s_hist[];  // per-block histogram, flushed with one global atomic per non-empty bin
+    for (uint32_t i = threadIdx.x; i < counts_len; i += 256u) s_hist[i] = 0u;
+    __syncthreads();
     const uint32_t read = blockIdx.x * 256u + threadIdx.x;
-    if (read >= n_reads) return;
-    const uint32_t b0 = slot_base[(uint64_t)read * n_groups * 2];
-    const uint32_t r0 = row_off[read], r1 = row_off[read + 1];
-    for (uint32_t i = 0; i < r1 - r0; ++i) {
-        const bb_row r = rows[b0 + i].row;
-        out[r0 + i] = r;
-        const bb_group_dev& G = groups[r.group_idx];
-        atomicAdd(&counts[G.count_off + (r.barcode_idx >= 0 ? r.barcode_idx : G.n_seqs)], 1ull);
+    if (read < n_reads) {
+        const uint32_t b0 = slot_base[(uint64_t)read * n_groups * 2];
+        const uint32_t r0 = row_off[read], r1 = row_off[read + 1];
+        for (uint32_t i = 0; i < r1 - r0; ++i) {
+            const uint4* src = reinterpret_cast<const uint4*>(rows + b0 + i);
+            uint4 a = src[0], b = src[1], c = src[2];
+            const uint32_t group_idx = (c.z >> 16) & 0xFFu;           // bb_row bytes 42..43: barcode_idx(40..41), group_idx(42), match_type(43)
+            const int32_t barcode_idx = (int32_t)(int16_t)(c.z & 0xFFFFu);
+            c.w &= 0xFFFF00FFu;                                       // clear the pipeline's row flag (_pad[0], byte 45)
+            uint4* dst = reinterpret_cast<uint4*>(out + r0 + i);
+            dst[0] = a; dst[1] = b; dst[2] = c;
+            const bb_group_dev& G = groups[group_idx];
+            atomicAdd(&s_hist[G.count_off + (barcode_idx >= 0 ? barcode_idx : G.n_seqs)], 1u);
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < counts_len; i += 256u) {
+        const uint32_t v = s_hist[i];
+        if (v) atomicAdd(&counts[i], (unsigned long long)v);
     }
 }
 
