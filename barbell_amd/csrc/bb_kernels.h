@@ -290,6 +290,25 @@ __device__ __forceinline__ void flank_scan_lane(const uint8_t* __restrict__ base
         ++idx;
         BB_LM_STEP_BUF(st, sc, idx);
     };
+    // Fast path: the bottom-row score moves by at most 1 per column, so while it is more than 4 above
+    // k no position of the next 4 columns can be reported and neither the score nor the local-minimum
+    // state needs tracking; the exact score is re-derived from the vertical deltas afterwards:
+    // D[m][i] = popcount(Pv) - popcount(Mv) (top row is 0).
+    const uint32_t topmask = TB == 31 ? 0xFFFFFFFFu : ((2u << TB) - 1u);
+    auto score_now = [&]() {
+        int32_t v = 0;
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+            const uint32_t msk = w == W - 1 ? topmask : 0xFFFFFFFFu;
+            v += __popc(pv[w] & msk) - __popc(mv[w] & msk);
+        }
+        return v;
+    };
+    auto step_fast = [&](uint32_t ch) {
+        uint32_t eq[W], d0[W], ph[W], mh[W];
+        load_eq<W, S>(s_peq, ch, eq);
+        myers_step<W>(pv, mv, eq, d0, ph, mh);
+    };
 
     // geometry of the walk in forward byte coordinates [0, n)
     const uint64_t a0 = (uint64_t)(uintptr_t)rb;
@@ -321,10 +340,26 @@ __device__ __forceinline__ void flank_scan_lane(const uint8_t* __restrict__ base
             for (int q = 0; q < 8; ++q) {
                 const uint4 v = s_line[64 * (STRAND == 0 ? q : 7 - q) + lane];
 #pragma unroll
-                for (int b = 0; b < 16; ++b) {
-                    const int bb = STRAND == 0 ? b : 15 - b;
-                    const uint32_t word = (bb >> 2) == 0 ? v.x : (bb >> 2) == 1 ? v.y : (bb >> 2) == 2 ? v.z : v.w;
-                    step((word >> (8 * (bb & 3))) & 0xFFu);
+                for (int b0 = 0; b0 < 16; b0 += 4) {
+                    // sc is exact here (either stepped or re-derived); wave-uniform choice of path
+                    if (__any(sc <= kk + 4)) {
+#pragma unroll
+                        for (int b = b0; b < b0 + 4; ++b) {
+                            const int bb = STRAND == 0 ? b : 15 - b;
+                            const uint32_t word = (bb >> 2) == 0 ? v.x : (bb >> 2) == 1 ? v.y : (bb >> 2) == 2 ? v.z : v.w;
+                            step((word >> (8 * (bb & 3))) & 0xFFu);
+                        }
+                    } else {
+#pragma unroll
+                        for (int b = b0; b < b0 + 4; ++b) {
+                            const int bb = STRAND == 0 ? b : 15 - b;
+                            const uint32_t word = (bb >> 2) == 0 ? v.x : (bb >> 2) == 1 ? v.y : (bb >> 2) == 2 ? v.z : v.w;
+                            step_fast((word >> (8 * (bb & 3))) & 0xFFu);
+                        }
+                        idx += 4;
+                        sc = score_now();
+                        st.prev = sc;  // > k: the lazily evaluated `dec` needs no update (see lm_lane)
+                    }
                 }
             }
         }
@@ -948,27 +983,54 @@ __global__ __launch_bounds__(512) void k_barcode_reg(const uint8_t* __restrict__
 #pragma unroll
     for (int c0 = CW; c0 >= 8; c0 -= 8) {
         if (c0 - 7 <= wmax) {  // wave-uniform
+            // Once every walking lane of the wave is at or below pattern row 32 (rows only decrease), the
+            // high parts of the bit-vectors are dead and the step runs on 32-bit words.
+            if (WB == 1 || __all(i < 0 || j <= 32)) {
 #pragma unroll
-            for (int c = c0; c > c0 - 8; --c) {
-                const bool act = i == c;
-                const unsigned long long lo64 = (unsigned long long)L0[c - 1] | ((unsigned long long)(X[c - 1] & 0xFFFFu) << 32);
-                const unsigned long long hi64 = (unsigned long long)H0[c - 1] | ((unsigned long long)(X[c - 1] >> 16) << 32);
-                const int jj = act ? j : 1;
-                const int nd = clz64(~((lo64 & hi64) << (64 - jj)));   // Del moves from row jj downwards (<= jj)
-                const int j2 = jj - nd;
-                const bool has = act & (j2 > 0);
-                const int sh = has ? j2 - 1 : 0;
-                const uint32_t lo = has ? (uint32_t)(lo64 >> sh) & 1u : 0u;
-                const uint32_t hi = has ? (uint32_t)(hi64 >> sh) & 1u : 0u;
-                plo |= (unsigned long long)lo << (c - 1);
-                phi |= (unsigned long long)hi << (c - 1);
-                const bool consume = has & (hi == 0u);                 // Match / Sub consume pattern row j2
-                diagrow |= consume ? (1ull << sh) : 0ull;
-                const int j3 = j2 - (consume ? 1 : 0);
-                const bool done = act & (j3 == 0);
-                tstart = done ? (has ? c - 1 : c) : tstart;
-                j = act ? j3 : j;
-                i = act ? (done ? -1 : c - 1) : i;
+                for (int c = c0; c > c0 - 8; --c) {
+                    const bool act = i == c;
+                    const uint32_t l32 = L0[c - 1], h32 = H0[c - 1];
+                    const int jj = act ? j : 1;
+                    const uint32_t z = ~((l32 & h32) << (32 - jj));
+                    const int nd = z ? __clz((int)z) : 32;                 // Del moves from row jj downwards (<= jj)
+                    const int j2 = jj - nd;
+                    const bool has = act & (j2 > 0);
+                    const int sh = has ? j2 - 1 : 0;
+                    const uint32_t lo = has ? (l32 >> sh) & 1u : 0u;
+                    const uint32_t hi = has ? (h32 >> sh) & 1u : 0u;
+                    plo |= (unsigned long long)lo << (c - 1);
+                    phi |= (unsigned long long)hi << (c - 1);
+                    const bool consume = has & (hi == 0u);
+                    diagrow |= (unsigned long long)((consume ? 1u : 0u) << sh);
+                    const int j3 = j2 - (consume ? 1 : 0);
+                    const bool done = act & (j3 == 0);
+                    tstart = done ? (has ? c - 1 : c) : tstart;
+                    j = act ? j3 : j;
+                    i = act ? (done ? -1 : c - 1) : i;
+                }
+            } else {
+#pragma unroll
+                for (int c = c0; c > c0 - 8; --c) {
+                    const bool act = i == c;
+                    const unsigned long long lo64 = (unsigned long long)L0[c - 1] | ((unsigned long long)(X[c - 1] & 0xFFFFu) << 32);
+                    const unsigned long long hi64 = (unsigned long long)H0[c - 1] | ((unsigned long long)(X[c - 1] >> 16) << 32);
+                    const int jj = act ? j : 1;
+                    const int nd = clz64(~((lo64 & hi64) << (64 - jj)));   // Del moves from row jj downwards (<= jj)
+                    const int j2 = jj - nd;
+                    const bool has = act & (j2 > 0);
+                    const int sh = has ? j2 - 1 : 0;
+                    const uint32_t lo = has ? (uint32_t)(lo64 >> sh) & 1u : 0u;
+                    const uint32_t hi = has ? (uint32_t)(hi64 >> sh) & 1u : 0u;
+                    plo |= (unsigned long long)lo << (c - 1);
+                    phi |= (unsigned long long)hi << (c - 1);
+                    const bool consume = has & (hi == 0u);                 // Match / Sub consume pattern row j2
+                    diagrow |= consume ? (1ull << sh) : 0ull;
+                    const int j3 = j2 - (consume ? 1 : 0);
+                    const bool done = act & (j3 == 0);
+                    tstart = done ? (has ? c - 1 : c) : tstart;
+                    j = act ? j3 : j;
+                    i = act ? (done ? -1 : c - 1) : i;
+                }
             }
         }
     }
