@@ -493,7 +493,12 @@ __global__ __launch_bounds__(256) void k_scan_add(uint32_t* __restrict__ out, ui
 // hit's end with move bits kept per column (private memory), walks back, and produces the ordered
 // bb_hit (flank coordinates + barcode window).
 // ------------------------------------------------------------------------------------------------
-template <int W>
+// MOVES_IN_LDS: the two move bit-vectors of every column are kept in LDS ([column][word][lane], so the
+// 64 lanes of the block hit 64 different banks) instead of private memory — private arrays of this
+// size live in HBM-backed scratch and made this small kernel the largest HBM consumer of the pipeline
+// (profiles/r01_v3_pmc.txt: 10.9 GB fetched per 2 M reads).  The host picks the LDS variant whenever
+// (m + k + 1) * W * 512 bytes fit in 64 KB.
+template <int W, bool MOVES_IN_LDS>
 __global__ __launch_bounds__(64) void k_flank_trace(const uint8_t* __restrict__ bases, const uint64_t* __restrict__ offsets,
                                                     const uint8_t* __restrict__ tables, const bb_group_dev* __restrict__ groups,
                                                     uint32_t n_groups, const bb_hit_raw* __restrict__ raw, uint32_t n_hits,
@@ -520,7 +525,14 @@ __global__ __launch_bounds__(64) void k_flank_trace(const uint8_t* __restrict__ 
     if (s0 < 0) s0 = 0;
     const int32_t w = i0 - s0;  // <= m + k < MAXC
 
-    uint32_t lo[MAXC][W], hi[MAXC][W];
+    extern __shared__ uint32_t s_moves[];  // [column][lo|hi][word][64 lanes] when MOVES_IN_LDS
+    uint32_t plo_[MOVES_IN_LDS ? 1 : MAXC][W], phi_[MOVES_IN_LDS ? 1 : MAXC][W];
+    auto put = [&](int c, int x, uint32_t l, uint32_t hh) {
+        if constexpr (MOVES_IN_LDS) { s_moves[((c * 2 + 0) * W + x) * 64 + threadIdx.x] = l; s_moves[((c * 2 + 1) * W + x) * 64 + threadIdx.x] = hh; }
+        else { plo_[c][x] = l; phi_[c][x] = hh; }
+    };
+    auto get_lo = [&](int c, int x) -> uint32_t { if constexpr (MOVES_IN_LDS) return s_moves[((c * 2 + 0) * W + x) * 64 + threadIdx.x]; else return plo_[c][x]; };
+    auto get_hi = [&](int c, int x) -> uint32_t { if constexpr (MOVES_IN_LDS) return s_moves[((c * 2 + 1) * W + x) * 64 + threadIdx.x]; else return phi_[c][x]; };
     uint32_t pv[W], mv[W];
 #pragma unroll
     for (int x = 0; x < W; ++x) {
@@ -536,7 +548,7 @@ __global__ __launch_bounds__(64) void k_flank_trace(const uint8_t* __restrict__ 
         myers_step<W>(pv, mv, eq, d0, ph, mh);
         move_bits<W>(eq, d0, ph, l, hh);
 #pragma unroll
-        for (int x = 0; x < W; ++x) { lo[c][x] = l[x]; hi[c][x] = hh[x]; }
+        for (int x = 0; x < W; ++x) put(c, x, l[x], hh[x]);
     }
     (void)ovh;
     // traceback from (j0, w)
@@ -548,9 +560,7 @@ __global__ __launch_bounds__(64) void k_flank_trace(const uint8_t* __restrict__ 
             op = 3u;
         } else {
             const int bit = j - 1;
-            uint32_t lw = lo[i][0], hw = hi[i][0];
-#pragma unroll
-            for (int x = 1; x < W; ++x) { lw = (bit >> 5) == x ? lo[i][x] : lw; hw = (bit >> 5) == x ? hi[i][x] : hw; }
+            const uint32_t lw = get_lo(i, bit >> 5), hw = get_hi(i, bit >> 5);
             op = ((lw >> (bit & 31)) & 1u) | (((hw >> (bit & 31)) & 1u) << 1);
         }
         if (op != 2u) --j;
