@@ -257,7 +257,8 @@ struct hit_buf {
 
 template <int W, int STRAND>
 __device__ __forceinline__ void flank_scan_lane(const uint8_t* __restrict__ bases, const uint64_t* __restrict__ offsets,
-                                                uint32_t n_reads, const uint8_t* __restrict__ tables, const bb_group_dev& G,
+                                                uint32_t n_reads, const uint8_t* __restrict__ tables, int32_t kk, int m, int32_t score0,
+                                                uint32_t off_pv0, uint32_t off_ovh,
                                                 uint32_t g, uint32_t n_groups, uint32_t* __restrict__ cnt,
                                                 bb_hit_raw* __restrict__ hits, uint32_t hit_cap, uint32_t* __restrict__ hit_count,
                                                 const uint32_t* s_peq, uint4* s_line /* this wave's [8][64] */) {
@@ -268,17 +269,15 @@ __device__ __forceinline__ void flank_scan_lane(const uint8_t* __restrict__ base
     const uint64_t off = live ? offsets[read] : 0ull;
     const uint32_t n = live ? (uint32_t)(offsets[read + 1] - off) : 0u;
     const uint8_t* rb = bases + off;
-    const int32_t kk = G.flank_k;
-    const int m = G.m;
     const int TB = (m - 1) & 31;
-    const uint32_t* pv0 = reinterpret_cast<const uint32_t*>(tables + G.off_pv0);
-    const int32_t* ovh = reinterpret_cast<const int32_t*>(tables + G.off_ovh);
+    const uint32_t* pv0 = reinterpret_cast<const uint32_t*>(tables + off_pv0);
+    const int32_t* ovh = reinterpret_cast<const int32_t*>(tables + off_ovh);
 
     uint32_t pv[W], mv[W];
 #pragma unroll
     for (int w = 0; w < W; ++w) { pv[w] = pv0[w]; mv[w] = 0; }
-    int32_t sc = G.score0;
-    lm_lane st = {G.score0, 1u, 0u};
+    int32_t sc = score0;
+    lm_lane st = {score0, 1u, 0u};
     hit_buf hb = {0u, 0u, 0u, 0u, 0u};
     uint32_t idx = 0;  // scan position (characters consumed)
 
@@ -428,18 +427,21 @@ __global__ __launch_bounds__(256) void k_flank_scan2(const uint8_t* __restrict__
     constexpr int S = (W <= 2 ? 2 : 4);
     __shared__ __attribute__((aligned(16))) uint32_t s_peq[256 * S];
     __shared__ __attribute__((aligned(16))) uint4 s_lines[4][8 * 64];
-    const bb_group_dev G = groups[g];
+    const bb_group_dev* G = groups + g;
     const uint32_t strand = blockIdx.y;
     {
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(tables + G.off_peq_flank[strand]);
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(tables + G->off_peq_flank[strand]);
         for (int i = threadIdx.x; i < 256 * S; i += 256) s_peq[i] = src[i];
     }
     __syncthreads();
     uint4* line = s_lines[threadIdx.x >> 6];
+    const int32_t kk = G->flank_k, score0 = G->score0;
+    const int m = G->m;
+    const uint32_t o_pv0 = G->off_pv0, o_ovh = G->off_ovh;
     if (strand == 0)
-        flank_scan_lane<W, 0>(bases, offsets, n_reads, tables, G, g, n_groups, cnt, hits, hit_cap, hit_count, s_peq, line);
+        flank_scan_lane<W, 0>(bases, offsets, n_reads, tables, kk, m, score0, o_pv0, o_ovh, g, n_groups, cnt, hits, hit_cap, hit_count, s_peq, line);
     else
-        flank_scan_lane<W, 1>(bases, offsets, n_reads, tables, G, g, n_groups, cnt, hits, hit_cap, hit_count, s_peq, line);
+        flank_scan_lane<W, 1>(bases, offsets, n_reads, tables, kk, m, score0, o_pv0, o_ovh, g, n_groups, cnt, hits, hit_cap, hit_count, s_peq, line);
 }
 
 // ------------------------------------------------------------------------------------------------

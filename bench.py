@@ -124,6 +124,7 @@ def main():
         achieved = alg_bytes / (kavg[dom] * 1e-3) / 1e9
         gi = dm.group_info(0)
         cells_flank = 2.0 * sum(dm.group_info(g).flank_len for g in range(len(groups))) * L * batch
+        traffic, traffic_all, traffic_src = load_traffic(args, batch, L, dom)
         out = {
             "metric": METRIC, "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -134,11 +135,14 @@ def main():
                        "reads_per_gpu": n_res, "batch_reads": batch, "read_len": L, "sharding": f"reads x{world}",
                        "rows_per_step": rows_per_launch},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": kavg[dom]},
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": kavg[dom],
+                         "traffic_all_kernels_per_step": traffic_all, "traffic_source": traffic_src},
             "kernel_ms_per_step": kavg,
             "compute": {"flank_gcups": cells_flank / (kavg.get("k_flank_scan", 0.0) * 1e-3 + 1e-12) / 1e9,
-                        "note": "integer VALU bound (bit-parallel Myers); no MFMA"},
+                        "int_valu_peak_lane_ops_per_s": 256 * 4 * 16 * 2.4e9,
+                        "note": "integer VALU issue bound (bit-parallel Myers; one wave64 VALU op per 4 cycles per SIMD); "
+                                "no MFMA. PMC instruction counts: profiles/"},
             "histogram_total": int(hist.sum().item()),
         }
         if world == 1 and not args.no_cpu_baseline:
@@ -147,6 +151,21 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def load_traffic(args, batch, L, dom):
+    """HBM bytes per launch from the committed PMC passes (tools/collect_traffic.py), if they were
+    collected on this workload shape; otherwise null.  They cannot be measured live."""
+    path = os.path.join(ROOT, "profiles", f"traffic_{args.config}.json")
+    try:
+        t = json.load(open(path))
+    except Exception:
+        return None, None, None
+    if t.get("batch_reads") != batch or t.get("read_len") != L:
+        return None, None, None
+    ks = t["kernels"]
+    dom_bytes = sum(v["hbm_bytes"] for k, v in ks.items() if k.startswith(dom))
+    return dom_bytes or None, sum(v["hbm_bytes"] * v.get("launches_per_step", 1) for v in ks.values()), os.path.relpath(path, ROOT)
 
 
 def cpu_baseline(args, groups, dm, d_bases, L):
