@@ -24,7 +24,7 @@ for f in glob.glob(os.path.join(pmc_dir, "**", "*counter_collection.csv"), recur
         calls[k][r["Counter_Name"]] += 1
 res = {"command": cmd, "batch_reads": batch, "read_len": read_len, "note": "bytes per launch; hbm_bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950 FETCH_SIZE half-count correction)", "kernels": {}}
 for k in acc:
-    if not k.startswith("k_"):
+    if not k.startswith("k_") or k.startswith("k_synth"):  # k_synth is bench setup, not the path
         continue
     f = acc[k]["FETCH_SIZE"] / max(1, calls[k]["FETCH_SIZE"])
     w = acc[k]["WRITE_SIZE"] / max(1, calls[k]["WRITE_SIZE"])
