@@ -1,0 +1,80 @@
+// barbell-amd — command-line driver of the MI355X annotate path.  Mirrors the flags and defaults of
+// the reference's `barbell annotate` (bin/main.rs:64-112); only this subcommand exists (filter / trim /
+// inspect / kit are out of scope).
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "bb_host.hpp"
+
+using namespace barbell;
+
+static void usage() {
+    fputs(
+        "Usage: barbell-amd annotate -i <FASTQ>... [-o output.tsv] (--kit <KIT> | -q <FASTA>... [-b Ftag|Rtag ...])\n"
+        "                            [--flank-max-errors INT] [--min-score F=0.2] [--min-score-diff F=0.1]\n"
+        "                            [--alpha F=0.4] [--use-extended] [-t THREADS=10] [--verbose]\n"
+        "                            [--batch-reads N=65536] [--device D=0]\n"
+        "       barbell-amd kits          list the supported kit names\n",
+        stderr);
+}
+
+int main(int argc, char** argv) {
+    if (argc < 2) { usage(); return 2; }
+    const std::string cmd = argv[1];
+    if (cmd == "kits") {
+        for (const auto& k : supported_kits()) puts(k.c_str());
+        return 0;
+    }
+    if (cmd == "-h" || cmd == "--help") { usage(); return 0; }
+    if (cmd != "annotate") { usage(); return 2; }
+    std::vector<std::string> input, queries, btypes;
+    std::string output = "output.tsv", kit;
+    AnnotateConfig cfg;
+    std::vector<std::string>* multi = nullptr;
+    for (int i = 2; i < argc; ++i) {
+        const std::string a = argv[i];
+        auto need = [&](const char* what) -> const char* { if (i + 1 >= argc) { fprintf(stderr, "error: %s needs a value\n", what); exit(2); } return argv[++i]; };
+        if (a == "-i" || a == "--input") { multi = &input; }
+        else if (a == "-q" || a == "--queries") { multi = &queries; }
+        else if (a == "-b" || a == "--barcode-types") { multi = &btypes; }
+        else if (a == "-o" || a == "--output") { output = need("--output"); multi = nullptr; }
+        else if (a == "-t" || a == "--threads") { cfg.n_threads = (unsigned)atoi(need("--threads")); multi = nullptr; }
+        else if (a == "--kit") { kit = need("--kit"); multi = nullptr; }
+        else if (a == "--flank-max-errors") { cfg.max_flank_errors = (size_t)atol(need("--flank-max-errors")); multi = nullptr; }
+        else if (a == "--min-score") { cfg.min_score = atof(need("--min-score")); multi = nullptr; }
+        else if (a == "--min-score-diff") { cfg.min_score_diff = atof(need("--min-score-diff")); multi = nullptr; }
+        else if (a == "--alpha") { cfg.alpha = (float)atof(need("--alpha")); multi = nullptr; }
+        else if (a == "--batch-reads") { cfg.batch_reads = (size_t)atol(need("--batch-reads")); multi = nullptr; }
+        else if (a == "--device") { cfg.device = atoi(need("--device")); multi = nullptr; }
+        else if (a == "--use-extended") { cfg.use_extended = true; multi = nullptr; }
+        else if (a == "--verbose") { cfg.verbose = true; multi = nullptr; }
+        else if (a == "-h" || a == "--help") { usage(); return 0; }
+        else if (!a.empty() && a[0] != '-' && multi) { multi->push_back(a); }
+        else { fprintf(stderr, "error: unexpected argument '%s'\n", a.c_str()); usage(); return 2; }
+    }
+    if (input.empty()) { fputs("error: No FASTQ input files provided\n", stderr); return 2; }
+    if (kit.empty() == queries.empty()) { fputs("error: give either --kit or --queries (they conflict, bin/main.rs:85-87)\n", stderr); return 2; }
+    try {
+        AnnotateStats st;
+        if (!kit.empty()) {
+            st = annotate_with_kit(input, output, kit, cfg);
+        } else {
+            if (btypes.empty()) btypes.push_back("Ftag");  // bin/main.rs:81-82 default
+            std::vector<BarcodeType> types;
+            for (const auto& b : btypes) {
+                if (b == "Ftag") types.push_back(BarcodeType::Ftag);
+                else if (b == "Rtag") types.push_back(BarcodeType::Rtag);
+                else { fprintf(stderr, "error: unknown barcode type '%s' (Ftag or Rtag)\n", b.c_str()); return 2; }
+            }
+            st = annotate_with_files(input, queries, types, output, cfg);
+        }
+        fprintf(stderr, "Done: %zu records, %zu with annotations, %zu rows -> %s\n", st.total, st.found, st.rows, output.c_str());
+    } catch (const BarbellError& e) {
+        fprintf(stderr, "error: %s\n", e.what());  // the reference prints the anyhow error and exits non-zero (bin/main.rs:301-304)
+        return 1;
+    }
+    return 0;
+}

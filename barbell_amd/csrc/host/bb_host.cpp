@@ -1,0 +1,323 @@
+// bb_host.cpp — see bb_host.hpp.  Host plumbing only: kit/FASTA loading, FASTQ batching, C-ABI
+// calls, annotation.tsv.  No alignment arithmetic lives here.
+#include "bb_host.hpp"
+
+#include <zlib.h>
+
+#include <algorithm>
+#include <cctype>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+
+#include "kits_data.inc"
+
+namespace barbell {
+
+const char* as_str(BarcodeType t) {
+    switch (t) {
+        case BarcodeType::Ftag: return "Ftag";
+        case BarcodeType::Rtag: return "Rtag";
+        case BarcodeType::Fflank: return "Fflank";
+        default: return "Rflank";
+    }
+}
+
+const char* const TSV_HEADER =
+    "read_id\tread_len\trel_dist_to_end\tread_start_bar\tread_end_bar\tread_start_flank\tread_end_flank\t"
+    "bar_start\tbar_end\tmatch_type\tflank_cost\tbarcode_cost\tlabel\tstrand\tcuts";
+
+// ---- kit presets (kits.rs) ----------------------------------------------------------------------
+namespace {
+struct Label { std::string prefix; size_t number; bool a_flag; };
+Label parse_label_simple(const std::string& label) {  // kits.rs:710-739
+    Label l{"", 0, false};
+    size_t i = 0;
+    while (i < label.size() && std::isalpha((unsigned char)label[i])) l.prefix.push_back((char)std::toupper((unsigned char)label[i++]));
+    std::string num;
+    while (i < label.size() && std::isdigit((unsigned char)label[i])) num.push_back(label[i++]);
+    if (num.empty()) throw BarbellError(BB_E_INVALID, "Invalid numeric part in label: " + label);
+    l.number = std::stoul(num);
+    l.a_flag = i < label.size() && std::toupper((unsigned char)label[i]) == 'A';
+    return l;
+}
+std::string two(size_t n) { char b[16]; snprintf(b, sizeof b, "%02zu", n); return b; }
+}  // namespace
+
+std::vector<std::string> get_barcodes(const std::string& from_label, const std::string& to_label, bool use_12a_flag) {
+    const Label f = parse_label_simple(from_label), t = parse_label_simple(to_label);
+    if (f.prefix != t.prefix) throw BarbellError(BB_E_INVALID, "Mismatched label prefixes: " + f.prefix + " vs " + t.prefix);
+    const size_t start = std::min(f.number, t.number), end = std::max(f.number, t.number);
+    std::vector<std::string> out;
+    for (size_t i = start; i <= end; ++i) out.push_back((f.prefix == "AB" ? "AB" : "BC") + two(i));
+    if (f.prefix == "AB") return out;
+    const bool use_12a = use_12a_flag || ((f.a_flag || t.a_flag) && start <= 12 && 12 <= end);
+    for (auto& s : out) {
+        if (use_12a && s == "BC12") s = "BC12A";
+        if (f.prefix == "NB" && s.rfind("BC", 0) == 0) s = "NB" + s.substr(2);
+        if (f.prefix == "RBK" && s.rfind("BC", 0) == 0 && s.size() >= 4) {
+            const int n = std::atoi(s.substr(2, 2).c_str());
+            if (n == 26 || n == 39 || n == 40 || n == 48 || n == 54 || n == 60) s = "RBK" + s.substr(2);
+        }
+    }
+    return out;
+}
+
+const char* lookup_barcode_seq(const std::string& label) {  // kits.rs:1074-1103
+    const Label l = parse_label_simple(label);
+    const size_t idx = l.number ? l.number - 1 : 0;
+    auto get = [&](const char* const* tab, int n) -> const char* { return idx < (size_t)n ? tab[idx] : nullptr; };
+    if (l.prefix == "BC" || l.prefix == "NB") {
+        if (l.a_flag && l.number == 12) return BC12A_SEQ;
+        return l.prefix == "BC" ? get(BC_SEQS, BC_SEQS_N) : get(NB_SEQS, NB_SEQS_N);
+    }
+    if (l.prefix == "AB") return get(AB_SEQS, AB_SEQS_N);
+    if (l.prefix == "BP") return get(BP_SEQS, BP_SEQS_N);
+    if (l.prefix == "RBK") {
+        for (const auto& s : RBK_SPECIAL)
+            if ((size_t)s.number == l.number) return s.seq;
+        return get(BC_SEQS, BC_SEQS_N);
+    }
+    return nullptr;
+}
+
+std::vector<std::string> supported_kits() {
+    std::vector<std::string> v;
+    for (const auto& k : KITS) v.push_back(k.kit);
+    return v;
+}
+
+std::vector<BarcodeGroup> BarcodeGroup::new_from_kit(const std::string& kit_in, bool also_use_extended) {
+    std::string kit = kit_in;
+    const TemplateSpecData* specs = nullptr;
+    int n = 0;
+    for (int attempt = 0; attempt < 2 && !specs; ++attempt) {
+        for (const auto& k : KITS)
+            if (kit == k.kit) { specs = k.specs; n = k.n; }
+        if (!specs) std::replace(kit.begin(), kit.end(), '.', '-');  // kits.rs:694-702
+    }
+    if (!specs) throw BarbellError(BB_E_INVALID, "Unknown or unsupported kit: " + kit_in + ", please raise an issue");
+    std::vector<BarcodeGroup> groups;
+    for (int i = 0; i < n; ++i) {
+        const TemplateSpecData& t = specs[i];
+        if (t.extended && !also_use_extended) continue;  // barcodes.rs:258-262
+        BarcodeGroup g;
+        g.labels = get_barcodes(t.from, t.to, t.use_12a);
+        for (const auto& lab : g.labels) {
+            const char* bar = lookup_barcode_seq(lab);
+            if (!bar) throw BarbellError(BB_E_INVALID, "Barcode not found - odd - raise issue");
+            g.seqs.push_back(std::string(t.front) + bar + t.rear);
+        }
+        g.barcode_type = t.right ? BarcodeType::Rtag : BarcodeType::Ftag;
+        groups.push_back(std::move(g));
+    }
+    return groups;
+}
+
+BarcodeGroup BarcodeGroup::new_from_fasta(const std::string& fasta_file, BarcodeType bar_type) {
+    std::ifstream f(fasta_file);
+    if (!f) throw BarbellError(BB_E_INVALID, "Query file not found: " + fasta_file);
+    BarcodeGroup g;
+    g.barcode_type = bar_type;
+    std::string line, cur;
+    auto flush = [&]() { if (!cur.empty()) { g.seqs.push_back(cur); cur.clear(); } };
+    while (std::getline(f, line)) {
+        while (!line.empty() && (line.back() == '\r' || line.back() == '\n')) line.pop_back();
+        if (line.empty()) continue;
+        if (line[0] == '>') {
+            flush();
+            g.labels.push_back(line.substr(1, line.find_first_of(" \t", 1) == std::string::npos ? std::string::npos : line.find_first_of(" \t", 1) - 1));
+        } else {
+            for (char& c : line) c = (char)std::toupper((unsigned char)c);  // needletail normalize(true)
+            cur += line;
+        }
+    }
+    flush();
+    return g;
+}
+
+// ---- BarbellMatch -------------------------------------------------------------------------------
+std::string BarbellMatch::to_tsv() const {
+    std::string id = read_id;
+    if (id.find_first_of("\t\"\n\r") != std::string::npos) {  // csv-crate quoting
+        std::string q = "\"";
+        for (char c : id) { if (c == '"') q += '"'; q += c; }
+        id = q + "\"";
+    }
+    char buf[512];
+    snprintf(buf, sizeof buf, "\t%zu\t%ld\t%zu\t%zu\t%zu\t%zu\t%zu\t%zu\t%s\t%d\t%d\t", read_len, rel_dist_to_end, read_start_bar,
+             read_end_bar, read_start_flank, read_end_flank, bar_start, bar_end, as_str(match_type), flank_cost, barcode_cost);
+    return id + buf + label + "\t" + (strand_rc ? "Rc" : "Fwd") + "\t";
+}
+
+// ---- Demuxer ------------------------------------------------------------------------------------
+Demuxer::Demuxer(float alpha, bool verbose, double min_score_frac, double min_score_diff_frac, int device)
+    : alpha_(alpha), verbose_(verbose), min_score_(min_score_frac), min_score_diff_(min_score_diff_frac), device_(device) {}
+Demuxer::~Demuxer() { if (ctx_) bb_destroy(ctx_); }
+
+Demuxer& Demuxer::add_query_group(BarcodeGroup g) {
+    if (ctx_) throw BarbellError(BB_E_INVALID, "add_query_group after the first demux call");
+    queries_.push_back(std::move(g));
+    return *this;
+}
+
+void Demuxer::ensure_ctx() {
+    if (ctx_) return;
+    std::vector<bb_group_desc> descs(queries_.size());
+    std::vector<std::vector<const uint8_t*>> ptrs(queries_.size());
+    std::vector<std::vector<uint32_t>> lens(queries_.size());
+    for (size_t i = 0; i < queries_.size(); ++i) {
+        for (const auto& s : queries_[i].seqs) { ptrs[i].push_back((const uint8_t*)s.data()); lens[i].push_back((uint32_t)s.size()); }
+        descs[i].seqs = ptrs[i].data();
+        descs[i].seq_lens = lens[i].data();
+        descs[i].n_seqs = (uint32_t)queries_[i].seqs.size();
+        descs[i].type = queries_[i].barcode_type == BarcodeType::Rtag ? BB_RTAG : BB_FTAG;
+        descs[i].flank_k = queries_[i].k_cutoff ? (int32_t)*queries_[i].k_cutoff : -1;
+    }
+    bb_params p{alpha_, min_score_, min_score_diff_, device_};
+    const int rc = bb_create(descs.data(), (uint32_t)descs.size(), &p, &ctx_);
+    if (rc != BB_OK) { ctx_ = nullptr; throw BarbellError(rc, std::string("bb_create: ") + bb_strerror(rc)); }
+}
+
+bb_group_info Demuxer::group_info(size_t g) {
+    ensure_ctx();
+    bb_group_info i;
+    const int rc = bb_group_get_info(ctx_, (uint32_t)g, &i);
+    if (rc != BB_OK) throw BarbellError(rc, bb_strerror(rc));
+    return i;
+}
+
+std::vector<BarbellMatch> Demuxer::demux_batch(const std::vector<std::string>& read_ids, const std::vector<uint8_t>& bases,
+                                               const std::vector<uint64_t>& offsets) {
+    ensure_ctx();
+    const uint32_t n = (uint32_t)read_ids.size();
+    if (rows_.size() < (size_t)4 * n + 64) rows_.resize((size_t)4 * n + 64);
+    uint64_t n_rows = 0;
+    int rc = bb_annotate_batch(ctx_, bases.data(), offsets.data(), n, rows_.data(), rows_.size(), &n_rows);
+    if (rc == BB_E_CAPACITY) {
+        rows_.resize(n_rows);
+        rc = bb_annotate_batch(ctx_, bases.data(), offsets.data(), n, rows_.data(), rows_.size(), &n_rows);
+    }
+    if (rc != BB_OK) throw BarbellError(rc, std::string("bb_annotate_batch: ") + bb_strerror(rc) + " " + bb_last_error(ctx_));
+    std::vector<BarbellMatch> out;
+    out.reserve(n_rows);
+    for (uint64_t i = 0; i < n_rows; ++i) {
+        const bb_row& r = rows_[i];
+        const BarcodeGroup& g = queries_[r.group_idx];
+        BarbellMatch m;
+        m.read_id = read_ids[r.read_idx];
+        m.read_len = r.read_len; m.rel_dist_to_end = r.rel_dist_to_end;
+        m.read_start_bar = r.read_start_bar; m.read_end_bar = r.read_end_bar;
+        m.read_start_flank = r.read_start_flank; m.read_end_flank = r.read_end_flank;
+        m.bar_start = r.bar_start; m.bar_end = r.bar_end;
+        m.match_type = (BarcodeType)r.match_type;
+        m.flank_cost = r.flank_cost; m.barcode_cost = r.barcode_cost;
+        m.label = r.barcode_idx < 0 ? "flank" : g.labels[(size_t)r.barcode_idx];
+        m.strand_rc = r.strand == BB_RC;
+        out.push_back(std::move(m));
+    }
+    return out;
+}
+
+// ---- annotate (annotator.rs) ----------------------------------------------------------------------
+namespace {
+// the automatic flank cutoff (edit_model.rs:2-11) is applied inside bb_create when k_cutoff is unset
+struct FastqReader {  // plain or gzip (gzopen reads both), 4-line records; src/io/io.rs:29-33
+    gzFile f;
+    std::vector<char> buf;
+    explicit FastqReader(const std::string& path) : f(gzopen(path.c_str(), "rb")), buf(1 << 20) {
+        if (!f) throw BarbellError(BB_E_INVALID, "Failed to open FASTQ input: " + path);
+        gzbuffer(f, 1 << 20);
+    }
+    ~FastqReader() { if (f) gzclose(f); }
+    bool line(std::string& out) {
+        out.clear();
+        for (;;) {
+            if (!gzgets(f, buf.data(), (int)buf.size())) return !out.empty();
+            const size_t len = strlen(buf.data());
+            out.append(buf.data(), len);
+            if (len && buf[len - 1] == '\n') break;
+            if (len + 1 < buf.size()) break;  // EOF without newline
+        }
+        while (!out.empty() && (out.back() == '\n' || out.back() == '\r')) out.pop_back();
+        return true;
+    }
+    bool next(std::string& id, std::string& seq) {
+        std::string h, plus, qual;
+        do { if (!line(h)) return false; } while (h.empty());
+        if (h[0] != '@') throw BarbellError(BB_E_INVALID, "Input FASTQ parsing failed: record does not start with '@'");
+        if (!line(seq) || !line(plus) || !line(qual)) throw BarbellError(BB_E_INVALID, "Input FASTQ parsing failed: truncated record");
+        const size_t ws = h.find_first_of(" \t");  // split_fastq_header, io.rs:6-17
+        id = h.substr(1, ws == std::string::npos ? std::string::npos : ws - 1);
+        return true;
+    }
+};
+}  // namespace
+
+AnnotateStats annotate(const std::vector<std::string>& read_files, const std::string& out_file,
+                       std::vector<BarcodeGroup> query_groups, const AnnotateConfig& config) {
+    if (read_files.empty()) throw BarbellError(BB_E_INVALID, "No FASTQ input files provided");  // io.rs:20-26
+    FILE* out = fopen(out_file.c_str(), "w");
+    if (!out) throw BarbellError(BB_E_INVALID, "Failed to create annotation output file '" + out_file + "'");
+    Demuxer dm(config.alpha, config.verbose, config.min_score, config.min_score_diff, config.device);
+    for (auto& g : query_groups) dm.add_query_group(std::move(g));
+    AnnotateStats st;
+    std::vector<std::string> ids;
+    std::vector<uint8_t> bases;
+    std::vector<uint64_t> offsets{0};
+    bool header = false;
+    auto flush = [&]() {
+        if (ids.empty()) return;
+        const auto rows = dm.demux_batch(ids, bases, offsets);
+        st.total += ids.size();
+        const std::string* last = nullptr;
+        for (const auto& r : rows) {
+            if (!header) { fputs(TSV_HEADER, out); fputc('\n', out); header = true; }  // csv writer: header with the first record
+            fputs(r.to_tsv().c_str(), out);
+            fputc('\n', out);
+            if (!last || *last != r.read_id) ++st.found;
+            last = &r.read_id;
+        }
+        st.rows += rows.size();
+        ids.clear(); bases.clear(); offsets.assign(1, 0);
+    };
+    try {
+        for (const auto& path : read_files) {
+            FastqReader rd(path);
+            std::string id, seq;
+            while (rd.next(id, seq)) {
+                ids.push_back(id);
+                bases.insert(bases.end(), seq.begin(), seq.end());
+                offsets.push_back(bases.size());
+                if (ids.size() >= config.batch_reads) flush();
+            }
+        }
+        flush();
+    } catch (...) { fclose(out); throw; }
+    fclose(out);
+    return st;
+}
+
+AnnotateStats annotate_with_groups(const std::vector<std::string>& read_files, const std::string& out_file,
+                                   std::vector<BarcodeGroup> query_groups, const AnnotateConfig& config) {
+    for (auto& g : query_groups)
+        if (config.max_flank_errors) g.set_flank_threshold(*config.max_flank_errors);  // else: automatic cutoff inside bb_create
+    return annotate(read_files, out_file, std::move(query_groups), config);
+}
+AnnotateStats annotate_with_kit(const std::vector<std::string>& read_files, const std::string& out_file, const std::string& kit,
+                                const AnnotateConfig& config) {
+    return annotate_with_groups(read_files, out_file, BarcodeGroup::new_from_kit(kit, config.use_extended), config);
+}
+AnnotateStats annotate_with_files(const std::vector<std::string>& read_files, const std::vector<std::string>& query_files,
+                                  const std::vector<BarcodeType>& query_types, const std::string& out_file,
+                                  const AnnotateConfig& config) {
+    if (query_files.size() != query_types.size())
+        throw BarbellError(BB_E_INVALID, "Expected the same number of query files and barcode types, got " +
+                                             std::to_string(query_files.size()) + " query file(s) and " +
+                                             std::to_string(query_types.size()) + " barcode type(s)");
+    std::vector<BarcodeGroup> groups;
+    for (size_t i = 0; i < query_files.size(); ++i) groups.push_back(BarcodeGroup::new_from_fasta(query_files[i], query_types[i]));
+    return annotate_with_groups(read_files, out_file, std::move(groups), config);
+}
+
+}  // namespace barbell
