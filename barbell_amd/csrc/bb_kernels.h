@@ -891,22 +891,29 @@ __global__ __launch_bounds__(512) void k_barcode_reg(const uint8_t* __restrict__
     const bool in_blk = hl < (int)hpb;
     const int hls = in_blk ? hl : 0;  // lanes past the last hit of the block shadow hit 0, results unused
     constexpr int PIECES = (int)(sizeof(bb_hit) / 16);
-    // prefetch of the next iteration's hit records: lanes p < 6 of every local hit hold one 16-byte piece
-    uint4 pre = make_uint4(0u, 0u, 0u, 0u);
-    uint32_t pre_idx = 0;
+    // prefetch of the next iteration's hit records: the lanes of a hit share its six 16-byte pieces
+    // (piece p, p+N, p+2N: one piece per lane when N >= 6, up to three for the smallest groups)
+    uint4 pre[3] = {make_uint4(0u, 0u, 0u, 0u), make_uint4(0u, 0u, 0u, 0u), make_uint4(0u, 0u, 0u, 0u)};
     auto prefetch = [&](uint32_t it) {
         const uint32_t li = it * hpb + (uint32_t)hl;
         if (in_blk && p < PIECES && it < n_iter && li < n_list) {
-            pre_idx = hit_list ? hit_list[li] : li;
-            pre = reinterpret_cast<const uint4*>(hits + pre_idx)[p];
+            const uint32_t idx = hit_list ? hit_list[li] : li;
+            const uint4* src = reinterpret_cast<const uint4*>(hits + idx);
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+                if (p + q * N < PIECES) pre[q] = src[p + q * N];
         }
     };
     prefetch(blockIdx.x);
   for (uint32_t it = blockIdx.x; it < n_iter; it += gridDim.x) {
     const uint32_t li = it * hpb + (uint32_t)hl;
     const bool exists = in_blk && li < n_list;
-    if (exists && p < PIECES) s_hit[hl * PIECES + p] = pre;
-    if (in_blk && p == PIECES) { s_max[hl] = 0ull; s_sec[hl] = 0ull; s_cnt1[hl] = 0; s_top[hl] = 0x7FFFFFFF; }
+    if (exists && p < PIECES) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+            if (p + q * N < PIECES) s_hit[hl * PIECES + p + q * N] = pre[q];
+    }
+    if (in_blk && p == 0) { s_max[hl] = 0ull; s_sec[hl] = 0ull; s_cnt1[hl] = 0; s_top[hl] = 0x7FFFFFFF; }
     __syncthreads();
     const uint32_t hit_idx = hit_list ? (exists ? hit_list[li] : 0u) : li;
     prefetch(it + gridDim.x);  // in flight during this iteration's compute
@@ -997,7 +1004,7 @@ __global__ __launch_bounds__(512) void k_barcode_reg(const uint8_t* __restrict__
         if (c0 - 7 <= wmax) {  // wave-uniform
             // Once every walking lane of the wave is at or below pattern row 32 (rows only decrease), the
             // high parts of the bit-vectors are dead and the step runs on 32-bit words.
-            if (WB == 1 || __all(i < 0 || j <= 32)) {
+            if (WB == 1 || __all(i < 0 || i <= c0 - 8 || j <= 32)) {  // lanes that start below this chunk do not count
 #pragma unroll
                 for (int c = c0; c > c0 - 8; --c) {
                     const bool act = i == c;

@@ -197,6 +197,54 @@ def test_large_batch_properties_without_oracle():
     assert len(tags) > 0.7 * n and set(np.unique(tags["strand"]).tolist()) == {0, 1}
 
 
+def test_iupac_queries_and_custom_geometry():
+    """Custom query sets: IUPAC codes inside barcodes and flanks, a one-sided flank (no suffix), short
+    barcodes with a single-word pattern (WB = 1), few and many barcodes per group."""
+    from barbell_amd import annotate as A
+    from barbell_amd.kits import QueryGroup
+
+    rng = np.random.default_rng(11)
+
+    def rnd(n, alphabet=b"ACGT"):
+        return bytes(rng.choice(list(alphabet), n).tolist())
+
+    sets = []
+    # (a) IUPAC in the shared flank and in some barcodes, 40 barcodes of 16 nt
+    pre, suf = b"ACGTTRGCAYGT", b"GGNTCAGWC"
+    sets.append([QueryGroup([pre + rnd(16, b"ACGTACGTACGTRYN") + suf for _ in range(40)], [f"q{i}" for i in range(40)], _abi.BB_FTAG, 2)])
+    # (b) prefix only (no shared suffix), 12-nt barcodes -> pattern <= 32 rows (WB = 1), 7 barcodes, auto cutoff
+    pre = rnd(20)
+    seqs = [pre + rnd(12) for _ in range(7)]
+    seqs[0] = seqs[0][:-1] + b"A"; seqs[1] = seqs[1][:-1] + b"C"  # make sure the common suffix is empty
+    sets.append([QueryGroup(seqs, [f"p{i}" for i in range(7)], _abi.BB_RTAG, None)])
+    # (c) 200 barcodes in one group + a second small group
+    pre, suf = rnd(18), rnd(15)
+    sets.append([QueryGroup([pre + rnd(24) + suf for _ in range(200)], [f"b{i}" for i in range(200)], _abi.BB_FTAG, 4),
+                 QueryGroup([rnd(9) + b"T" + rnd(10) + rnd(1, b"A") + b"GGGGCCCCAAAA" for _ in range(3)][:3], ["x", "y", "z"], _abi.BB_RTAG, 1)])
+    for groups in sets:
+        # the small second group of (c) needs a shared prefix/suffix: rebuild it deterministically
+        if len(groups) == 2:
+            p2, s2 = rnd(10), rnd(12)
+            groups[1] = QueryGroup([p2 + rnd(10) + s2 for _ in range(3)], ["x", "y", "z"], _abi.BB_RTAG, 1)
+        plain = [QueryGroup([bytes(q).translate(bytes.maketrans(b"RYNWSKMBDHV", b"ACGATGACAAC")) for q in g.seqs], g.labels, g.match_type, g.flank_k)
+                 for g in groups]
+        bases, offsets = A.synth_reads_host(plain, 5, 150, 900, 0, 500)  # reads built from concrete instances of the queries
+        _, got, want = run_both(groups, bases, offsets)
+        assert len(want) > 50
+        assert_same(got, want)
+
+
+def test_long_reads():
+    """100 kb reads: many 128-byte lines per lane, offsets beyond 2^24, hits deep inside the read."""
+    from barbell_amd import annotate as A
+
+    groups = config_groups("nbd96")
+    bases, offsets = A.synth_reads_host(groups, 8, 60_000, 110_000, 0, 48)
+    _, got, want = run_both(groups, bases, offsets)
+    assert len(want) > 30
+    assert_same(got, want)
+
+
 def test_device_pointer_api_and_device_synth():
     import torch
 
