@@ -234,6 +234,51 @@ def test_iupac_queries_and_custom_geometry():
         assert_same(got, want)
 
 
+@pytest.mark.parametrize("seed", list(range(40)))
+def test_fuzz_geometry(seed):
+    """Random query geometry (barcode length, one- or two-sided flanks, group count and size, k, alpha,
+    thresholds) within the library's documented limits, reads with planted noisy constructs."""
+    from barbell_amd import annotate as A
+    from barbell_amd.kits import QueryGroup
+
+    rng = np.random.default_rng(1000 + seed)
+
+    def rnd(n):
+        return bytes(rng.choice(list(b"ACGT"), int(n)).tolist())
+
+    groups = []
+    for gi in range(int(rng.integers(1, 4))):
+        blen = int(rng.integers(4, 31))
+        pre = rnd(rng.integers(0, 41))
+        suf = rnd(rng.integers(0 if len(pre) else 3, 41))
+        n = int(rng.integers(2, 130))
+        seqs = []
+        while len(seqs) < n:
+            b = rnd(blen)
+            if b not in [q[len(pre):len(pre) + blen] for q in seqs]:
+                seqs.append(pre + b + suf)
+        # keep the shared prefix/suffix exactly pre/suf: first barcode characters must differ somewhere
+        k = int(rng.integers(0, 9)) if rng.random() < 0.7 else None
+        groups.append(QueryGroup(seqs, [f"g{gi}_{i}" for i in range(n)], int(rng.integers(0, 2)), k))
+    try:
+        probe = A.Demuxer()
+        for g in groups:
+            probe.add_query_group(g)
+        probe.group_info(0)
+    except A.BarbellError as e:
+        assert e.code in (_abi.BB_E_UNSUPPORTED, _abi.BB_E_NO_BARCODE, _abi.BB_E_NO_FLANK)
+        from oracle import pyoracle as po
+        if e.code != _abi.BB_E_UNSUPPORTED:  # the oracle rejects the same query sets
+            with pytest.raises(ValueError):
+                po.Oracle([g.as_tuple() for g in groups])
+        return
+    bases, offsets = A.synth_reads_host(groups, 50 + seed, 80, 1500, 0, 300)
+    kw = dict(alpha=float(rng.choice([0.0, 0.4, 0.7])), min_score_frac=float(rng.choice([0.1, 0.2, 0.5])),
+              min_score_diff_frac=float(rng.choice([0.0, 0.1, 0.2])))
+    _, got, want = run_both(groups, bases, offsets, **kw)
+    assert_same(got, want)
+
+
 def test_long_reads():
     """100 kb reads: many 128-byte lines per lane, offsets beyond 2^24, hits deep inside the read."""
     from barbell_amd import annotate as A
