@@ -963,8 +963,9 @@ __global__ __launch_bounds__(512) void k_barcode_reg(const uint8_t* __restrict__
                     else eq[0] = s_peq[ei];
                     myers_step<WB>(pv, mv, eq, d0, ph, mh);
                     move_bits<WB>(eq, d0, ph, l, hh);
-                    L0[c] = l[0]; H0[c] = hh[0];
-                    if constexpr (WB == 2) X[c] = (l[1] & 0xFFFFu) | (hh[1] << 16);
+                    // stored bit-reversed (row r <-> bit 64-r of {L0|H0 : X-part}) for the one-hot traceback below
+                    L0[c] = __brev(l[0]); H0[c] = __brev(hh[0]);
+                    if constexpr (WB == 2) X[c] = (__brev(l[1]) >> 16) | (__brev(hh[1]) & 0xFFFF0000u);
                     else X[c] = 0;
                     up[c >> 5] |= ((ph[WB - 1] >> TB) & 1u) << (c & 31);
                     dn[c >> 5] |= ((mh[WB - 1] >> TB) & 1u) << (c & 31);
@@ -994,66 +995,64 @@ __global__ __launch_bounds__(512) void k_barcode_reg(const uint8_t* __restrict__
     // its lanes anyway); which of them are candidates — pass 1 (<= k1) or the deeper pass 2
     // (searcher.rs:303-328) — is decided after the block-wide count below.
     bool cand = active && best_pos >= 0 && best_cost <= G.k2;
-    // ---- traceback, one predicated step per column: text op of each column into two bit planes,
-    // rows consumed by a Match/Sub into a row mask (a run of Del moves is one count-leading-ones) ----
+    // ---- traceback, one predicated step per column, on a ONE-HOT row cursor over bit-reversed move
+    // vectors (row r <-> bit 64-r).  With rows running towards higher bits, skipping a run of Del moves
+    // is one addition: the carry ripples through the run's ones and stops at the first non-Del row,
+    // nb = (Dr + b) & ~Dr.  A Match/Sub moves the cursor one row (b << 1), an Ins keeps it; the cursor
+    // falls off the top (b = 0) when row 1 has been consumed.  Outputs: the text op of each column in
+    // two bit planes, the rows consumed by a Match/Sub, the number of columns with a text op.
+    // Once every cursor of the wave is in the high word (rows <= 32) the step runs on 32-bit words.
     const int32_t rlo = G.rel_lo, rhi = G.rel_hi;
-    unsigned long long diagrow = 0ull, plo = 0ull, phi = 0ull;
-    int32_t j = m, i = cand ? best_pos : -1, tstart = 0;
+    unsigned long long plo = 0ull, phi = 0ull;
+    uint32_t b_lo = 0u, b_hi = 0u, dg_lo = 0u, dg_hi = 0u;   // cursor and consumed rows, bit-reversed
+    int32_t ntext = 0;
+    const uint32_t start_lo = m > 32 ? (1u << (64 - m)) : 0u, start_hi = m > 32 ? 0u : (1u << (32 - m));
 #pragma unroll
     for (int c0 = CW; c0 >= 8; c0 -= 8) {
         if (c0 - 7 <= wmax) {  // wave-uniform
-            // Once every walking lane of the wave is at or below pattern row 32 (rows only decrease), the
-            // high parts of the bit-vectors are dead and the step runs on 32-bit words.
-            if (WB == 1 || __all(i < 0 || i <= c0 - 8 || j <= 32)) {  // lanes that start below this chunk do not count
+            if (WB == 1 || __all(b_lo == 0u && (!cand || best_pos > c0))) {
 #pragma unroll
                 for (int c = c0; c > c0 - 8; --c) {
-                    const bool act = i == c;
-                    const uint32_t l32 = L0[c - 1], h32 = H0[c - 1];
-                    const int jj = act ? j : 1;
-                    const uint32_t z = ~((l32 & h32) << (32 - jj));
-                    const int nd = z ? __clz((int)z) : 32;                 // Del moves from row jj downwards (<= jj)
-                    const int j2 = jj - nd;
-                    const bool has = act & (j2 > 0);
-                    const int sh = has ? j2 - 1 : 0;
-                    const uint32_t lo = has ? (l32 >> sh) & 1u : 0u;
-                    const uint32_t hi = has ? (h32 >> sh) & 1u : 0u;
-                    plo |= (unsigned long long)lo << (c - 1);
-                    phi |= (unsigned long long)hi << (c - 1);
-                    const bool consume = has & (hi == 0u);
-                    diagrow |= (unsigned long long)((consume ? 1u : 0u) << sh);
-                    const int j3 = j2 - (consume ? 1 : 0);
-                    const bool done = act & (j3 == 0);
-                    tstart = done ? (has ? c - 1 : c) : tstart;
-                    j = act ? j3 : j;
-                    i = act ? (done ? -1 : c - 1) : i;
+                    if constexpr (WB == 1) b_hi = (cand & (best_pos == c)) ? start_hi : b_hi;
+                    const uint32_t Lr = L0[c - 1], Hr = H0[c - 1];
+                    const uint32_t Dr = Lr & Hr;
+                    const uint32_t nb = (Dr + b_hi) & ~Dr;
+                    const bool has = nb != 0u, lo = (Lr & nb) != 0u, hi = (Hr & nb) != 0u;
+                    plo |= lo ? (1ull << (c - 1)) : 0ull;
+                    phi |= hi ? (1ull << (c - 1)) : 0ull;
+                    const bool consume = has & !hi;
+                    dg_hi |= consume ? nb : 0u;
+                    b_hi = consume ? (nb << 1) : nb;
+                    ntext += has ? 1 : 0;
                 }
             } else {
 #pragma unroll
                 for (int c = c0; c > c0 - 8; --c) {
-                    const bool act = i == c;
-                    const unsigned long long lo64 = (unsigned long long)L0[c - 1] | ((unsigned long long)(X[c - 1] & 0xFFFFu) << 32);
-                    const unsigned long long hi64 = (unsigned long long)H0[c - 1] | ((unsigned long long)(X[c - 1] >> 16) << 32);
-                    const int jj = act ? j : 1;
-                    const int nd = clz64(~((lo64 & hi64) << (64 - jj)));   // Del moves from row jj downwards (<= jj)
-                    const int j2 = jj - nd;
-                    const bool has = act & (j2 > 0);
-                    const int sh = has ? j2 - 1 : 0;
-                    const uint32_t lo = has ? (uint32_t)(lo64 >> sh) & 1u : 0u;
-                    const uint32_t hi = has ? (uint32_t)(hi64 >> sh) & 1u : 0u;
-                    plo |= (unsigned long long)lo << (c - 1);
-                    phi |= (unsigned long long)hi << (c - 1);
-                    const bool consume = has & (hi == 0u);                 // Match / Sub consume pattern row j2
-                    diagrow |= consume ? (1ull << sh) : 0ull;
-                    const int j3 = j2 - (consume ? 1 : 0);
-                    const bool done = act & (j3 == 0);
-                    tstart = done ? (has ? c - 1 : c) : tstart;
-                    j = act ? j3 : j;
-                    i = act ? (done ? -1 : c - 1) : i;
+                    const bool st = cand & (best_pos == c);
+                    b_lo = st ? start_lo : b_lo;
+                    b_hi = st ? start_hi : b_hi;
+                    const uint32_t Lr_hi = L0[c - 1], Hr_hi = H0[c - 1], Lr_lo = X[c - 1] << 16, Hr_lo = X[c - 1] & 0xFFFF0000u;
+                    const unsigned long long Dr = ((unsigned long long)(Lr_hi & Hr_hi) << 32) | (Lr_lo & Hr_lo);
+                    const unsigned long long bb = ((unsigned long long)b_hi << 32) | b_lo;
+                    const unsigned long long nb = (Dr + bb) & ~Dr;
+                    const uint32_t nb_lo = (uint32_t)nb, nb_hi = (uint32_t)(nb >> 32);
+                    const bool has = nb != 0ull;
+                    const bool lo = ((Lr_lo & nb_lo) | (Lr_hi & nb_hi)) != 0u, hi = ((Hr_lo & nb_lo) | (Hr_hi & nb_hi)) != 0u;
+                    plo |= lo ? (1ull << (c - 1)) : 0ull;
+                    phi |= hi ? (1ull << (c - 1)) : 0ull;
+                    const bool consume = has & !hi;
+                    dg_lo |= consume ? nb_lo : 0u;
+                    dg_hi |= consume ? nb_hi : 0u;
+                    const unsigned long long nx = consume ? (nb << 1) : nb;
+                    b_lo = (uint32_t)nx; b_hi = (uint32_t)(nx >> 32);
+                    ntext += has ? 1 : 0;
                 }
             }
         }
     }
-    // (rows left when column 0 is reached are deleted at text position 0: they are simply absent from diagrow)
+    const int32_t tstart = cand ? best_pos - ntext : 0;   // columns (tstart, best_pos] carry the text ops
+    // consumed rows back in natural order (row r <-> bit r-1); rows never consumed were deleted
+    const unsigned long long diagrow = ((unsigned long long)__brev(dg_lo) << 32) | __brev(dg_hi);
     const unsigned long long delrow = cand ? (low64(m) & ~diagrow) : 0ull;
     // ---- forward replay: Lodhi only.  Scaled recurrence (see header): b1 = 2^t a1, b2 = 2^t a2 change
     // only at match columns; score += 2^-(t+1) * b2 (exact scaling, same rounding as the oracle's add).
