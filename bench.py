@@ -45,6 +45,10 @@ def main():
     ap.add_argument("--config", default="nbd96", choices=["nbd96", "dual", "rbk24", "rbk96x"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend for N>1 (nccl = RCCL over xGMI; gloo only for single-GPU dry runs)")
+    ap.add_argument("--device-mod", type=int, default=0,
+                    help="dry-run aid: map LOCAL_RANK onto LOCAL_RANK %% device-mod GPUs (0 = one GPU per rank)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -53,16 +57,21 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_idx = local_rank % args.device_mod if args.device_mod > 0 else local_rank
+    torch.cuda.set_device(dev_idx)
+    dev = torch.device("cuda", dev_idx)
+    cdev = dev if args.backend == "nccl" else torch.device("cpu")  # where collective tensors live
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     from barbell_amd import annotate as A
     from tests.common import config_groups
 
     groups = config_groups(args.config)
-    dm = A.Demuxer(device=local_rank)
+    dm = A.Demuxer(device=dev_idx)
     for g in groups:
         dm.add_query_group(g)
 
@@ -101,14 +110,14 @@ def main():
         rows_total += step(s)
         for k, v in dm.kernel_ms().items():
             kms[k] = kms.get(k, 0.0) + v
-    hist = torch.from_numpy(dm.counts().astype(np.int64)).to(dev)
+    hist = torch.from_numpy(dm.counts().astype(np.int64)).to(cdev)
     if world > 1:
         dist.all_reduce(hist)  # RCCL over xGMI: the only collective of the path
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     t1 = time.perf_counter()
-    el = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
+    el = torch.tensor([t1 - t0], dtype=torch.float64, device=cdev)
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
