@@ -7,7 +7,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
+#include <condition_variable>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/barbell_amd.h"
@@ -547,12 +551,9 @@ int bb_annotate_batch_dev(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_o
     return BB_OK;
 }
 
-int bb_annotate_batch(bb_ctx* c, const uint8_t* bases, const uint64_t* offsets, uint32_t n, bb_row* rows, uint64_t rows_cap,
-                      uint64_t* n_rows) {
-    if (!c || !offsets || !n_rows || (!bases && n)) return BB_E_INVALID;
-    *n_rows = 0;
-    if (n == 0) return BB_OK;
-    HIPCHK(c, hipSetDevice(c->device));
+// One chunk of a host batch, synchronous: H2D, pipeline, rows D2H.
+static int annotate_host_chunk(bb_ctx* c, const uint8_t* bases, const uint64_t* offsets, uint32_t n, bb_row* rows, uint64_t rows_cap,
+                               uint64_t* n_rows) {
     const uint64_t nb = offsets[n];
     int r;
     if ((r = grow(c, c->d_in_bases, c->cap_in_bases, nb + 16))) return r;
@@ -570,6 +571,118 @@ int bb_annotate_batch(bb_ctx* c, const uint8_t* bases, const uint64_t* offsets, 
     if (r != BB_OK) return r;
     if (*n_rows) HIPCHK(c, hipMemcpy(rows, c->d_out_rows, *n_rows * sizeof(bb_row), hipMemcpyDeviceToHost));
     return BB_OK;
+}
+
+// Host-pointer boundary.  Large batches are cut into ~256 MB chunks and the upload of chunk i+1 (a
+// helper thread with its own stream and a second pair of input buffers) overlaps the kernels and the
+// row download of chunk i; the hot path itself is unchanged (bb_annotate_batch_dev per chunk).
+int bb_annotate_batch(bb_ctx* c, const uint8_t* bases, const uint64_t* offsets, uint32_t n, bb_row* rows, uint64_t rows_cap,
+                      uint64_t* n_rows) {
+    if (!c || !offsets || !n_rows || (!bases && n)) return BB_E_INVALID;
+    *n_rows = 0;
+    if (n == 0) return BB_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    const uint64_t total_bytes = offsets[n] - offsets[0];
+    const uint64_t chunk_bytes = 256ull << 20;
+    if (total_bytes <= 2 * chunk_bytes || n < 8192) {
+        if (offsets[0] == 0) return annotate_host_chunk(c, bases, offsets, n, rows, rows_cap, n_rows);
+        std::vector<uint64_t> rel((size_t)n + 1);
+        for (uint32_t i = 0; i <= n; ++i) rel[i] = offsets[i] - offsets[0];
+        return annotate_host_chunk(c, bases + offsets[0], rel.data(), n, rows, rows_cap, n_rows);
+    }
+    // chunk boundaries (by bytes)
+    std::vector<uint32_t> cut{0};
+    for (uint32_t i = 1; i <= n; ++i)
+        if (offsets[i] - offsets[cut.back()] >= chunk_bytes || i == n) cut.push_back(i);
+    const size_t nchunks = cut.size() - 1;
+    uint64_t max_bytes = 0, max_reads = 0;
+    for (size_t k = 0; k < nchunks; ++k) {
+        max_bytes = std::max(max_bytes, offsets[cut[k + 1]] - offsets[cut[k]]);
+        max_reads = std::max<uint64_t>(max_reads, cut[k + 1] - cut[k]);
+    }
+    struct InBuf { uint8_t* bases = nullptr; uint64_t* offs = nullptr; };
+    InBuf ib[2];
+    int r = BB_OK;
+    for (auto& b : ib) {
+        if (hipMalloc((void**)&b.bases, max_bytes + 16) != hipSuccess || hipMalloc((void**)&b.offs, (max_reads + 1) * 8) != hipSuccess) r = BB_E_NOMEM;
+    }
+    std::vector<unsigned long long> counts_backup(c->counts_len);
+    if (r == BB_OK && hipMemcpy(counts_backup.data(), c->d_counts, sizeof(uint64_t) * c->counts_len, hipMemcpyDeviceToHost) != hipSuccess) r = BB_E_HIP;
+    if (r == BB_OK) {
+        std::mutex mu;
+        std::condition_variable cv;
+        int ready[2] = {-1, -1};   // chunk index whose data sits in buffer b (-1 = free)
+        bool stop = false;
+        int copy_err = BB_OK;
+        std::thread loader([&]() {
+            (void)hipSetDevice(c->device);
+            hipStream_t cs;
+            if (hipStreamCreate(&cs) != hipSuccess) { std::lock_guard<std::mutex> g(mu); copy_err = BB_E_HIP; cv.notify_all(); return; }
+            std::vector<uint64_t> rel(max_reads + 1);
+            for (size_t k = 0; k < nchunks; ++k) {
+                const int b = (int)(k & 1);
+                {
+                    std::unique_lock<std::mutex> g(mu);
+                    cv.wait(g, [&] { return ready[b] == -1 || stop; });
+                    if (stop) break;
+                }
+                const uint32_t f = cut[k], cn = cut[k + 1] - cut[k];
+                for (uint32_t i = 0; i <= cn; ++i) rel[i] = offsets[f + i] - offsets[f];
+                hipError_t e1 = hipMemcpyAsync(ib[b].bases, bases + offsets[f], rel[cn], hipMemcpyHostToDevice, cs);
+                hipError_t e2 = hipMemcpyAsync(ib[b].offs, rel.data(), ((size_t)cn + 1) * 8, hipMemcpyHostToDevice, cs);
+                hipError_t e3 = hipStreamSynchronize(cs);
+                std::lock_guard<std::mutex> g(mu);
+                if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) { copy_err = BB_E_HIP; cv.notify_all(); break; }
+                ready[b] = (int)k;
+                cv.notify_all();
+            }
+            (void)hipStreamDestroy(cs);
+        });
+        uint64_t total = 0;
+        bool overflow = false;
+        for (size_t k = 0; k < nchunks && r == BB_OK; ++k) {
+            const int b = (int)(k & 1);
+            {
+                std::unique_lock<std::mutex> g(mu);
+                cv.wait(g, [&] { return ready[b] == (int)k || copy_err != BB_OK; });
+                if (copy_err != BB_OK) { r = copy_err; break; }
+            }
+            const uint32_t f = cut[k], cn = cut[k + 1] - cut[k];
+            uint64_t want = (uint64_t)cn * 4 + 64, got = 0;
+            if ((r = grow(c, c->d_out_rows, c->cap_out_rows, want))) break;
+            r = bb_annotate_batch_dev(c, ib[b].bases, ib[b].offs, cn, c->d_out_rows, c->cap_out_rows, &got);
+            if (r == BB_E_CAPACITY) {
+                if ((r = grow(c, c->d_out_rows, c->cap_out_rows, got))) break;
+                r = bb_annotate_batch_dev(c, ib[b].bases, ib[b].offs, cn, c->d_out_rows, c->cap_out_rows, &got);
+            }
+            if (r != BB_OK) break;
+            if (!overflow && total + got <= rows_cap && rows) {
+                if (got && hipMemcpy(rows + total, c->d_out_rows, got * sizeof(bb_row), hipMemcpyDeviceToHost) != hipSuccess) { r = BB_E_HIP; break; }
+                for (uint64_t i = 0; i < got; ++i) rows[total + i].read_idx += f;   // chunk-local -> batch-local read index
+            } else {
+                overflow = true;  // keep going to learn the required capacity
+            }
+            total += got;
+            {
+                std::lock_guard<std::mutex> g(mu);
+                ready[b] = -1;
+                cv.notify_all();
+            }
+        }
+        {
+            std::lock_guard<std::mutex> g(mu);
+            stop = true;
+            cv.notify_all();
+        }
+        loader.join();
+        *n_rows = total;
+        if (r == BB_OK && overflow) r = BB_E_CAPACITY;
+    }
+    if (r != BB_OK && r != BB_E_NOMEM)  // nothing of a failed call may stay in the histogram
+        (void)hipMemcpy(c->d_counts, counts_backup.data(), sizeof(uint64_t) * c->counts_len, hipMemcpyHostToDevice);
+    for (auto& b : ib) { if (b.bases) (void)hipFree(b.bases); if (b.offs) (void)hipFree(b.offs); }
+    if (r == BB_E_HIP && c->last_error.empty()) c->last_error = "HIP error while streaming a host batch";
+    return r;
 }
 
 uint32_t bb_counts_len(const bb_ctx* c) { return c ? c->counts_len : 0; }

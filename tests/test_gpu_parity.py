@@ -291,6 +291,45 @@ def test_long_reads():
     assert_same(got, want)
 
 
+def test_streamed_host_batch_equals_device_batch():
+    """A host batch larger than two 256 MB chunks goes through the overlapped upload path; rows, row
+    order, read indices and the histogram must equal the single device-resident batch; a too-small row
+    buffer reports the needed capacity and leaves the histogram untouched."""
+    import ctypes as C
+
+    import torch
+
+    from barbell_amd import annotate as A
+    from barbell_amd._lib import lib
+
+    groups = config_groups("nbd96")
+    n, L = 180_000, 4000  # 720 MB of bases -> 3 chunks
+    dm = A.Demuxer()
+    for g in groups:
+        dm.add_query_group(g)
+    d_off = torch.arange(0, n + 1, dtype=torch.int64, device="cuda") * L
+    d_bases = torch.empty(n * L, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    dm.synth_dev(77, L, L, 0, n, d_off.data_ptr(), d_bases.data_ptr())
+    d_rows = torch.empty(4 * n * 48, dtype=torch.uint8, device="cuda")
+    dm.counts_reset()
+    nr = dm.demux_dev(d_bases.data_ptr(), d_off.data_ptr(), n, d_rows.data_ptr(), 4 * n)
+    want = np.frombuffer(d_rows.cpu().numpy().tobytes()[: nr * 48], dtype=_abi.ROW_DTYPE)
+    cnt_dev = dm.counts()
+    h_bases = d_bases.cpu().numpy()
+    h_off = d_off.cpu().numpy().astype(np.uint64)
+    dm.counts_reset()
+    got = dm.demux_packed(h_bases, h_off)
+    assert_same(got, want)
+    assert (dm.counts() == cnt_dev).all()
+    # capacity error path through the chunked code
+    small = np.zeros(1000, dtype=_abi.ROW_DTYPE)
+    need = C.c_uint64()
+    rc = lib().bb_annotate_batch(dm._ctx(), h_bases.ctypes.data, h_off.ctypes.data, n, small.ctypes.data, len(small), C.byref(need))
+    assert rc == _abi.BB_E_CAPACITY and need.value == len(want)
+    assert (dm.counts() == cnt_dev).all()
+
+
 def test_device_pointer_api_and_device_synth():
     import torch
 
