@@ -15,6 +15,7 @@ EXPORTS = [
     "bb_annotate_batch", "bb_annotate_batch_dev", "bb_counts_len", "bb_counts", "bb_counts_dev", "bb_counts_reset",
     "bb_n_kernels", "bb_kernel_name", "bb_last_kernel_ms", "bb_set_timing", "bb_strerror", "bb_last_error",
     "bb_synth_offsets", "bb_synth_reads_host", "bb_synth_reads_dev",
+    "bb_filter_set", "bb_filter_rows", "bb_filter_rows_dev",
 ]
 
 _lib = None
@@ -69,5 +70,8 @@ def lib():
     L.bb_synth_offsets.argtypes = [u64, u32, u32, u64, u32, vp]
     L.bb_synth_reads_host.argtypes = [C.POINTER(_abi.GroupDesc), u32, u64, u32, u32, u64, u32, vp, vp]
     L.bb_synth_reads_dev.argtypes = [vp, u64, u32, u32, u64, u32, vp, vp]
+    L.bb_filter_set.argtypes = [vp, vp, u32, vp]
+    L.bb_filter_rows.argtypes = [vp, vp, u64, vp]
+    L.bb_filter_rows_dev.argtypes = [vp, vp, u64, vp]
     _lib = L
     return L

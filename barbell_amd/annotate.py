@@ -161,11 +161,14 @@ def synth_reads_host(groups, seed, len_min, len_max, first_read, n):
 
 
 # ---- TSV (searcher.rs:31-142, annotator.rs:13-26,246-251) ------------------------------------------
-def format_rows(rows, read_ids, groups):
+def format_rows(rows, read_ids, groups, verdicts=None):
     """rows -> list of TSV lines (no header), csv-crate style: tab-delimited, no quoting needed for
-    these field types unless a read id contains a tab/quote/newline."""
+    these field types unless a read id contains a tab/quote/newline.  With `verdicts` (filter step)
+    the `cuts` column is filled like the reference's filtered.tsv (searcher.rs:91-106)."""
+    from .filter import format_cuts
+
     out = []
-    for r in rows:
+    for i, r in enumerate(rows):
         g = groups[int(r["group_idx"])]
         label = "flank" if r["barcode_idx"] < 0 else g.labels[int(r["barcode_idx"])]
         rid = read_ids[int(r["read_idx"])]
@@ -177,7 +180,7 @@ def format_rows(rows, read_ids, groups):
             str(int(r["read_start_flank"])), str(int(r["read_end_flank"])),
             str(int(r["bar_start"])), str(int(r["bar_end"])),
             _abi.MATCH_TYPE_STR[int(r["match_type"])], str(int(r["flank_cost"])), str(int(r["barcode_cost"])),
-            label, _abi.STRAND_STR[int(r["strand"])], "",
+            label, _abi.STRAND_STR[int(r["strand"])], "" if verdicts is None else format_cuts(verdicts[i]),
         )))
     return out
 
@@ -204,37 +207,58 @@ def read_fastq(path):
 
 
 def annotate(read_files, out_file, query_groups, alpha=0.4, min_score=0.2, min_score_diff=0.1, max_flank_errors=None,
-             batch_reads=65536, device=0):
+             batch_reads=65536, device=0, filter_patterns=None, filtered_file=None, dropped_file=None):
     """annotate_with_groups + annotate (annotator.rs:207-285): sets the flank threshold of each group
     (explicit --flank-max-errors or the automatic cutoff), streams the FASTQ in batches through the
-    GPU and writes annotation.tsv.  Returns (total_reads, reads_with_rows)."""
+    GPU and writes annotation.tsv.  With `filter_patterns` the filter step (filter.rs:10-119) runs on
+    the rows of every batch while they are in HBM and `filtered_file` / `dropped_file` get the rows
+    of passing / failing reads with their `cuts` column — what `barbell filter` would write from the
+    annotation file.  Returns (total_reads, reads_with_rows)."""
     for g in query_groups:
         if max_flank_errors is not None:
             g.set_flank_threshold(max_flank_errors)
     dm = Demuxer(alpha, False, min_score, min_score_diff, device)
     for g in query_groups:
         dm.add_query_group(g)
+    flt = None
+    if filter_patterns is not None:
+        from .filter import Filter
+
+        flt = Filter(dm, filter_patterns)
     total = found = 0
-    wrote_header = False
-    with open(out_file, "w") as out:
-        ids, seqs = [], []
+    outs = {"anno": open(out_file, "w"),
+            "kept": open(filtered_file, "w") if (flt and filtered_file) else None,
+            "dropped": open(dropped_file, "w") if (flt and dropped_file) else None}
+    wrote = {k: False for k in outs}
 
-        def flush():
-            nonlocal total, found, wrote_header
-            if not ids:
-                return
-            rows = dm.demux_batch(seqs)
-            total += len(ids)
-            found += len(np.unique(rows["read_idx"]))
-            lines = format_rows(rows, ids, query_groups)
-            if lines and not wrote_header:  # csv writer emits the header with the first record only
-                out.write(TSV_HEADER + "\n")
-                wrote_header = True
-            if lines:
-                out.write("\n".join(lines) + "\n")
-            ids.clear()
-            seqs.clear()
+    def emit(key, lines):
+        f = outs[key]
+        if f is None or not lines:
+            return
+        if not wrote[key]:  # csv writer emits the header with the first record only
+            f.write(TSV_HEADER + "\n")
+            wrote[key] = True
+        f.write("\n".join(lines) + "\n")
 
+    ids, seqs = [], []
+
+    def flush():
+        nonlocal total, found
+        if not ids:
+            return
+        rows = dm.demux_batch(seqs)
+        total += len(ids)
+        found += len(np.unique(rows["read_idx"]))
+        emit("anno", format_rows(rows, ids, query_groups))
+        if flt is not None:
+            v = flt.verdicts(rows)
+            keep = v["pass"] == 1
+            emit("kept", format_rows(rows[keep], ids, query_groups, v[keep]))
+            emit("dropped", format_rows(rows[~keep], ids, query_groups, v[~keep]))
+        ids.clear()
+        seqs.clear()
+
+    try:
         for path in read_files:
             for rid, s in read_fastq(path):
                 ids.append(rid)
@@ -242,6 +266,10 @@ def annotate(read_files, out_file, query_groups, alpha=0.4, min_score=0.2, min_s
                 if len(ids) >= batch_reads:
                     flush()
         flush()
+    finally:
+        for f in outs.values():
+            if f is not None:
+                f.close()
     dm.close()
     return total, found
 

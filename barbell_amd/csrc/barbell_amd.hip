@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "../../include/barbell_amd.h"
+#include "../../include/barbell_amd_filter.h"
 #include "../../include/barbell_amd_synth.h"
 #include "bb_common.h"
 #include "bb_kernels.h"
@@ -139,6 +140,14 @@ struct bb_ctx {
     uint8_t* d_in_bases = nullptr; uint64_t cap_in_bases = 0;
     uint64_t* d_in_offsets = nullptr; uint64_t cap_in_offsets = 0;
     bb_row* d_out_rows = nullptr; uint64_t cap_out_rows = 0;
+    // filter step
+    bb_pat_dev* d_fpats = nullptr;
+    bb_pat_elem_dev* d_felems = nullptr;
+    uint8_t* d_flabel_ok = nullptr;
+    uint32_t* d_flabel_ids = nullptr;
+    uint32_t n_fpats = 0;
+    bb_row* d_frows = nullptr; uint64_t cap_frows = 0;
+    bb_row_verdict* d_fout = nullptr; uint64_t cap_fout = 0;
     // synth
     uint8_t* d_synth_table = nullptr;
     bb_synth_params synth{};
@@ -442,7 +451,7 @@ void bb_destroy(bb_ctx* c) {
     (void)hipSetDevice(c->device);
     void* ptrs[] = {c->d_groups, c->d_tables, c->d_counts, c->d_cnt, c->d_base, c->d_sums, c->d_nrows, c->d_rowoff, c->d_hitcount,
                     c->d_lists, c->d_listcnt, c->d_raw, c->d_hits, c->d_rows, c->d_in_bases, c->d_in_offsets, c->d_out_rows,
-                    c->d_synth_table};
+                    c->d_synth_table, c->d_fpats, c->d_felems, c->d_flabel_ok, c->d_flabel_ids, c->d_frows, c->d_fout};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (int i = 0; i <= K_COUNT; ++i)
@@ -705,6 +714,73 @@ const char* bb_kernel_name(int k) { return k >= 0 && k < K_COUNT ? kKernelNames[
 float bb_last_kernel_ms(const bb_ctx* c, int k) { return c && k >= 0 && k < K_COUNT ? c->ms[k] : 0.f; }
 void bb_set_timing(bb_ctx* c, int enable) { if (c) c->timing = enable != 0; }
 const char* bb_last_error(const bb_ctx* c) { return c ? c->last_error.c_str() : ""; }
+
+// ---- filter step (include/barbell_amd_filter.h) ---------------------------------------------------
+int bb_filter_set(bb_ctx* c, const bb_pattern* patterns, uint32_t n_patterns, const uint32_t* label_ids) {
+    if (!c || (!patterns && n_patterns) || !label_ids) return BB_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    std::vector<bb_pat_dev> pats;
+    std::vector<bb_pat_elem_dev> elems;
+    std::vector<uint8_t> ok;
+    for (uint32_t p = 0; p < n_patterns; ++p) {
+        if (!patterns[p].elems || patterns[p].n_elems == 0) return BB_E_INVALID;
+        pats.push_back({(uint32_t)elems.size(), patterns[p].n_elems});
+        std::vector<int32_t> keys;
+        for (uint32_t e = 0; e < patterns[p].n_elems; ++e) {
+            const bb_pattern_elem& s = patterns[p].elems[e];
+            if (s.n_cuts > BB_MAX_CUTS || s.match_type > BB_RFLANK || s.relative_to > BB_REL_PREV_LEFT) return BB_E_UNSUPPORTED;
+            if (s.placeholder >= 0 && std::find(keys.begin(), keys.end(), s.placeholder) == keys.end()) keys.push_back(s.placeholder);
+            bb_pat_elem_dev d;
+            memset(&d, 0, sizeof(d));
+            d.match_type = s.match_type; d.orientation = s.orientation; d.relative_to = s.relative_to; d.n_cuts = s.n_cuts;
+            d.placeholder = s.placeholder; d.lo = s.range_lo; d.hi = s.range_hi;
+            for (int q = 0; q < s.n_cuts; ++q) d.cuts[q] = s.cuts[q];
+            if (s.label_ok) { d.label_off = (uint32_t)ok.size(); ok.insert(ok.end(), s.label_ok, s.label_ok + c->counts_len); }
+            else d.label_off = 0xFFFFFFFFu;
+            elems.push_back(d);
+        }
+        if (keys.size() > 16) return BB_E_UNSUPPORTED;
+    }
+    for (void* q : {(void*)c->d_fpats, (void*)c->d_felems, (void*)c->d_flabel_ok, (void*)c->d_flabel_ids})
+        if (q) (void)hipFree(q);
+    c->d_fpats = nullptr; c->d_felems = nullptr; c->d_flabel_ok = nullptr; c->d_flabel_ids = nullptr;
+    c->n_fpats = n_patterns;
+    HIPCHK(c, hipMalloc((void**)&c->d_fpats, sizeof(bb_pat_dev) * (pats.size() + 1)));
+    HIPCHK(c, hipMalloc((void**)&c->d_felems, sizeof(bb_pat_elem_dev) * (elems.size() + 1)));
+    HIPCHK(c, hipMalloc((void**)&c->d_flabel_ok, ok.size() + 16));
+    HIPCHK(c, hipMalloc((void**)&c->d_flabel_ids, sizeof(uint32_t) * c->counts_len));
+    if (!pats.empty()) HIPCHK(c, hipMemcpy(c->d_fpats, pats.data(), sizeof(bb_pat_dev) * pats.size(), hipMemcpyHostToDevice));
+    if (!elems.empty()) HIPCHK(c, hipMemcpy(c->d_felems, elems.data(), sizeof(bb_pat_elem_dev) * elems.size(), hipMemcpyHostToDevice));
+    if (!ok.empty()) HIPCHK(c, hipMemcpy(c->d_flabel_ok, ok.data(), ok.size(), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->d_flabel_ids, label_ids, sizeof(uint32_t) * c->counts_len, hipMemcpyHostToDevice));
+    return BB_OK;
+}
+
+int bb_filter_rows_dev(bb_ctx* c, const bb_row* d_rows, uint64_t n_rows, bb_row_verdict* d_out) {
+    if (!c || (!d_rows && n_rows) || (!d_out && n_rows)) return BB_E_INVALID;
+    if (!c->d_fpats) { c->last_error = "bb_filter_set has not been called"; return BB_E_INVALID; }
+    if (n_rows == 0) return BB_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipLaunchKernelGGL(k_filter, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, c->stream, d_rows, n_rows,
+                       (const bb_group_dev*)c->d_groups, (const bb_pat_dev*)c->d_fpats, c->n_fpats, (const bb_pat_elem_dev*)c->d_felems,
+                       (const uint8_t*)c->d_flabel_ok, (const uint32_t*)c->d_flabel_ids, d_out);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return BB_OK;
+}
+
+int bb_filter_rows(bb_ctx* c, const bb_row* rows, uint64_t n_rows, bb_row_verdict* out) {
+    if (!c || (!rows && n_rows) || (!out && n_rows)) return BB_E_INVALID;
+    if (n_rows == 0) return BB_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    int r;
+    if ((r = grow(c, c->d_frows, c->cap_frows, n_rows))) return r;
+    if ((r = grow(c, c->d_fout, c->cap_fout, n_rows))) return r;
+    HIPCHK(c, hipMemcpy(c->d_frows, rows, n_rows * sizeof(bb_row), hipMemcpyHostToDevice));
+    if ((r = bb_filter_rows_dev(c, c->d_frows, n_rows, c->d_fout))) return r;
+    HIPCHK(c, hipMemcpy(out, c->d_fout, n_rows * sizeof(bb_row_verdict), hipMemcpyDeviceToHost));
+    return BB_OK;
+}
 
 // ---- synthetic reads (include/barbell_amd_synth.h) ---------------------------------------------
 static int synth_params_from_descs(const bb_group_desc* groups, uint32_t n_groups, uint64_t seed, uint32_t len_min, uint32_t len_max,

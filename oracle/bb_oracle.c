@@ -666,3 +666,73 @@ int bbo_annotate_batch(bbo_ctx* c, const uint8_t* bases, const uint64_t* offsets
     free(per);
     return rcode;
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* filter step: pattern.rs:96-240 + filter.rs:183-214 restated on bb_row       */
+/* ------------------------------------------------------------------------------------------ */
+static uint32_t row_slot(const bbo_ctx* c, const bb_row* r) {
+    uint32_t off = 0;
+    for (uint32_t g = 0; g < r->group_idx; ++g) off += c->g[g].n_seqs + 1;
+    return off + (r->barcode_idx >= 0 ? (uint32_t)r->barcode_idx : c->g[r->group_idx].n_seqs);
+}
+/* match_pattern (pattern.rs:205-240): element e must match row e; returns 1 on match */
+static int match_pattern_rows(const bbo_ctx* c, const bb_row* rows, uint32_t n, const bb_pattern* p, const uint32_t* label_ids) {
+    if (n < p->n_elems) return 0;                                            /* :212-214 */
+    int64_t prev_end = 0; int have_prev = 0;
+    int32_t ph_key[64]; uint32_t ph_label[64]; int n_ph = 0;
+    for (uint32_t e = 0; e < p->n_elems; ++e) {
+        const bb_pattern_elem* el = &p->elems[e];
+        const bb_row* m = &rows[e];                                          /* current_match_idx == e */
+        const uint32_t slot = row_slot(c, m);
+        /* check_match_type_and_label :96-126 */
+        if (m->match_type != el->match_type) return 0;
+        if ((m->match_type == BB_FTAG || m->match_type == BB_RTAG) && el->label_ok && !el->label_ok[slot]) return 0;
+        /* check_placeholder :128-145 */
+        if (el->placeholder >= 0) {
+            int found = -1;
+            for (int q = 0; q < n_ph; ++q) if (ph_key[q] == el->placeholder) found = q;
+            if (found >= 0) { if (ph_label[found] != label_ids[slot]) return 0; }
+            else if (n_ph < 64) { ph_key[n_ph] = el->placeholder; ph_label[n_ph] = label_ids[slot]; ++n_ph; }
+        }
+        /* check_orientation :147-149 */
+        if (el->orientation >= 0 && el->orientation != (int8_t)m->strand) return 0;
+        /* check_relative_position :151-190 */
+        const int64_t m_start = m->read_start_bar, m_end = m->read_end_bar, seq_len = m->read_len;
+        if (el->relative_to == BB_REL_LEFT) {
+            if (m_start < el->range_lo || m_start > el->range_hi) return 0;
+        } else if (el->relative_to == BB_REL_RIGHT) {
+            if (m_end < seq_len - el->range_hi || m_end > seq_len - el->range_lo) return 0;
+        } else if (el->relative_to == BB_REL_PREV_LEFT) {
+            if (have_prev && (m_start < prev_end + el->range_lo || m_start > prev_end + el->range_hi)) return 0;
+        }
+        prev_end = m_end; have_prev = 1;                                      /* :229 */
+    }
+    return 1;
+}
+int bbo_filter_rows(const bbo_ctx* c, const bb_pattern* patterns, uint32_t n_patterns, const uint32_t* label_ids,
+                    const bb_row* rows, uint64_t n_rows, bb_row_verdict* out) {
+    if (!c || (!patterns && n_patterns) || !label_ids || (!rows && n_rows) || (!out && n_rows)) return BB_E_INVALID;
+    uint64_t i = 0;
+    while (i < n_rows) {
+        uint64_t j = i;
+        while (j < n_rows && rows[j].read_idx == rows[i].read_idx) ++j;      /* group of one read (filter.rs:54-85) */
+        const uint32_t n = (uint32_t)(j - i);
+        uint32_t max_matches = 0; const bb_pattern* best = NULL;              /* check_filter_pass filter.rs:183-214 */
+        for (uint32_t p = 0; p < n_patterns; ++p)
+            if (match_pattern_rows(c, rows + i, n, &patterns[p], label_ids) && patterns[p].n_elems > max_matches) {
+                max_matches = patterns[p].n_elems; best = &patterns[p];
+            }
+        for (uint32_t r = 0; r < n; ++r) {
+            bb_row_verdict* v = &out[i + r];
+            memset(v, 0, sizeof(*v));
+            v->pass = max_matches == n;
+            v->match_idx = (uint16_t)r;
+            if (best && r < best->n_elems) {
+                v->n_cuts = best->elems[r].n_cuts;
+                for (uint32_t q = 0; q < v->n_cuts && q < BB_MAX_CUTS; ++q) v->cuts[q] = best->elems[r].cuts[q];
+            }
+        }
+        i = j;
+    }
+    return BB_OK;
+}

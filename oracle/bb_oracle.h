@@ -12,6 +12,7 @@
 #define BB_ORACLE_H
 
 #include "../include/barbell_amd.h"
+#include "../include/barbell_amd_filter.h"
 
 #ifdef __cplusplus
 extern "C" {
@@ -72,6 +73,10 @@ int  bbo_group_get_pattern(const bbo_ctx* ctx, uint32_t group, uint32_t idx, int
  * like the reference's one Demuxer per paraseq worker, annotator.rs:88-101). */
 int  bbo_annotate_batch(bbo_ctx* ctx, const uint8_t* bases, const uint64_t* offsets, uint32_t n_reads,
                         bb_row* rows, uint64_t rows_cap, uint64_t* n_rows, int n_threads);
+/* filter step on a row stream (filter.rs:183-214 check_filter_pass, pattern.rs:96-240 match_pattern);
+ * rows grouped by consecutive read_idx like the reference groups by consecutive read_id (filter.rs:54-85) */
+int  bbo_filter_rows(const bbo_ctx* ctx, const bb_pattern* patterns, uint32_t n_patterns, const uint32_t* label_ids,
+                     const bb_row* rows, uint64_t n_rows, bb_row_verdict* out);
 /* test hook: 1 = trace flank matches on the full DP matrix instead of the (m+k)-column window */
 void bbo_set_full_trace(int on);
 

@@ -66,6 +66,7 @@ def lib():
         L.bbo_annotate_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64,
                                          C.POINTER(C.c_uint64), C.c_int]
         L.bbo_set_full_trace.argtypes = [C.c_int]
+        L.bbo_filter_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
         _lib = L
     return _lib
 
@@ -180,6 +181,17 @@ class Oracle:
 
     def annotate_reads(self, reads, n_threads=1):
         return self.annotate(*_abi.pack_reads(reads), n_threads=n_threads)
+
+    def filter_rows(self, patterns, groups, rows):
+        """check_filter_pass per read (filter.rs:183-214) -> verdict array"""
+        from barbell_amd import filter as F
+
+        arr, label_ids, keep = F.compile_patterns(patterns, groups)
+        rows = np.ascontiguousarray(rows, dtype=_abi.ROW_DTYPE)
+        out = np.zeros(len(rows), dtype=F.VERDICT_DTYPE)
+        rc = lib().bbo_filter_rows(self.h, arr, len(patterns), label_ids.ctypes.data, rows.ctypes.data, len(rows), out.ctypes.data)
+        assert rc == 0, rc
+        return out
 
     def close(self):
         if self.h:

@@ -43,8 +43,21 @@ for name, body in re.findall(r'const\s+(KIT_[A-Z0-9_]+):\s*KitConfig\s*=\s*KitCo
 
 kits = {}
 fn = re.search(r'pub fn get_kit_info.*?\n\}', src, re.S).group(0)
+kit_of_const = {}
 for kit, const in re.findall(r'"([A-Z0-9\-]+)"\s*=>\s*(KIT_[A-Z0-9_]+)', fn):
     kits[kit] = kitconst[const]
+    kit_of_const[kit] = const
+
+# filter pattern sets (kits.rs:175-236) and which set each kit uses (KitConfig::new(.., safe_patterns, maximize_patterns, ..))
+pattern_sets = {}
+for name, body in re.findall(r'static\s+([A-Z_]+_PATTERNS_[A-Z]+):\s*LazyLock<Vec<Pattern>>\s*=\s*LazyLock::new\(\|\|\s*\{\s*vec!\[(.*?)\n\s*\]\s*\}\);', src, re.S):
+    pattern_sets[name] = re.findall(r'pattern_from_str!\(\s*"(.*?)"\s*\)', body, re.S)
+fns = dict(re.findall(r"fn\s+(\w+)\(\)\s*->\s*&'static \[Pattern\]\s*\{\s*&(\w+)\s*\}", src))
+kit_patterns = {}
+for name, body in re.findall(r'const\s+(KIT_[A-Z0-9_]+):\s*KitConfig\s*=\s*KitConfig::new\((.*?)\);', src, re.S):
+    parts = [p.strip() for p in body.split(',') if p.strip()]
+    kit_patterns[name] = {"safe": fns[parts[2]], "maximize": fns[parts[3]]}
+kit_filter = {kit: kit_patterns[const] for kit, const in kit_of_const.items()}
 
 out = {
     "_source": "rickbeeloo/barbell v0.3.3 src/kits/kits.rs (data tables only), extracted by tools/extract_kits.py",
@@ -53,6 +66,8 @@ out = {
     "RBK_special": rbk_special,
     "templates": templates,
     "kits": kits,
+    "pattern_sets": pattern_sets,
+    "kit_filter": kit_filter,
 }
 dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "barbell_amd", "data", "kits.json")
 json.dump(out, open(dst, "w"), indent=1, sort_keys=True)
