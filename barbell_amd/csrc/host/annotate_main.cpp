@@ -1,6 +1,7 @@
 // barbell-amd — command-line driver of the MI355X annotate path.  Mirrors the flags and defaults of
-// the reference's `barbell annotate` (bin/main.rs:64-112); only this subcommand exists (filter / trim /
-// inspect / kit are out of scope).
+// the reference's `barbell annotate` (bin/main.rs:64-112).  The filter step (`barbell filter`,
+// bin/main.rs:114-135) is available fused into annotate: --filter-file / --kit-filter [--maximize] with
+// --filtered / --dropped outputs.  trim / inspect are out of scope.
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -17,7 +18,9 @@ static void usage() {
         "                            [--flank-max-errors INT] [--min-score F=0.2] [--min-score-diff F=0.1]\n"
         "                            [--alpha F=0.4] [--use-extended] [-t THREADS=10] [--verbose]\n"
         "                            [--batch-reads N=65536] [--device D=0]\n"
-        "       barbell-amd kits          list the supported kit names\n",
+        "                            [(-f <PATTERN_FILE>... | --kit-filter [--maximize]) [--filtered FILE] [--dropped FILE]]\n"
+        "       barbell-amd kits          list the supported kit names\n"
+        "       barbell-amd pattern <STR>...   parse filter pattern strings and print their elements\n",
         stderr);
 }
 
@@ -28,9 +31,25 @@ int main(int argc, char** argv) {
         for (const auto& k : supported_kits()) puts(k.c_str());
         return 0;
     }
+    if (cmd == "pattern") {  // parse check: one canonical line per element (type|orientation|label|?N|rel|lo|hi|cuts)
+        try {
+            for (int i = 2; i < argc; ++i) {
+                const Pattern p = pattern_from_str(argv[i]);
+                for (const auto& e : p.elements) {
+                    std::string cuts;
+                    for (const auto& c : e.cuts) cuts += (cuts.empty() ? "" : ",") + c.to_string();
+                    printf("%s|%d|%s|%d|%d|%ld|%ld|%s\n", as_str(e.match_type), e.orientation, e.label ? e.label->c_str() : "*",
+                           e.placeholder, e.relative_to, e.range_lo, e.range_hi, cuts.c_str());
+                }
+                puts("--");
+            }
+        } catch (const BarbellError& e) { fprintf(stderr, "error: %s\n", e.what()); return 1; }
+        return 0;
+    }
     if (cmd == "-h" || cmd == "--help") { usage(); return 0; }
     if (cmd != "annotate") { usage(); return 2; }
-    std::vector<std::string> input, queries, btypes;
+    std::vector<std::string> input, queries, btypes, pattern_files;
+    bool kit_filter = false, maximize = false;
     std::string output = "output.tsv", kit;
     AnnotateConfig cfg;
     std::vector<std::string>* multi = nullptr;
@@ -49,6 +68,11 @@ int main(int argc, char** argv) {
         else if (a == "--alpha") { cfg.alpha = (float)atof(need("--alpha")); multi = nullptr; }
         else if (a == "--batch-reads") { cfg.batch_reads = (size_t)atol(need("--batch-reads")); multi = nullptr; }
         else if (a == "--device") { cfg.device = atoi(need("--device")); multi = nullptr; }
+        else if (a == "-f" || a == "--filter-file") { multi = &pattern_files; }
+        else if (a == "--filtered") { cfg.filtered_file = need("--filtered"); multi = nullptr; }
+        else if (a == "--dropped") { cfg.dropped_file = need("--dropped"); multi = nullptr; }
+        else if (a == "--kit-filter") { kit_filter = true; multi = nullptr; }
+        else if (a == "--maximize") { maximize = true; multi = nullptr; }
         else if (a == "--use-extended") { cfg.use_extended = true; multi = nullptr; }
         else if (a == "--verbose") { cfg.verbose = true; multi = nullptr; }
         else if (a == "-h" || a == "--help") { usage(); return 0; }
@@ -57,7 +81,11 @@ int main(int argc, char** argv) {
     }
     if (input.empty()) { fputs("error: No FASTQ input files provided\n", stderr); return 2; }
     if (kit.empty() == queries.empty()) { fputs("error: give either --kit or --queries (they conflict, bin/main.rs:85-87)\n", stderr); return 2; }
+    if (kit_filter && kit.empty()) { fputs("error: --kit-filter needs --kit\n", stderr); return 2; }
+    if (kit_filter && !pattern_files.empty()) { fputs("error: give either --filter-file or --kit-filter\n", stderr); return 2; }
     try {
+        if (!pattern_files.empty()) cfg.filter_patterns = patterns_from_files(pattern_files);
+        if (kit_filter) cfg.filter_patterns = kit_patterns(kit, maximize);
         AnnotateStats st;
         if (!kit.empty()) {
             st = annotate_with_kit(input, output, kit, cfg);
@@ -72,6 +100,7 @@ int main(int argc, char** argv) {
             st = annotate_with_files(input, queries, types, output, cfg);
         }
         fprintf(stderr, "Done: %zu records, %zu with annotations, %zu rows -> %s\n", st.total, st.found, st.rows, output.c_str());
+        if (!cfg.filter_patterns.empty()) fprintf(stderr, "Filter: %zu kept, %zu dropped\n", st.kept, st.dropped);
     } catch (const BarbellError& e) {
         fprintf(stderr, "error: %s\n", e.what());  // the reference prints the anyhow error and exits non-zero (bin/main.rs:301-304)
         return 1;

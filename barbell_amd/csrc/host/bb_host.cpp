@@ -147,7 +147,143 @@ std::string BarbellMatch::to_tsv() const {
     char buf[512];
     snprintf(buf, sizeof buf, "\t%zu\t%ld\t%zu\t%zu\t%zu\t%zu\t%zu\t%zu\t%s\t%d\t%d\t", read_len, rel_dist_to_end, read_start_bar,
              read_end_bar, read_start_flank, read_end_flank, bar_start, bar_end, as_str(match_type), flank_cost, barcode_cost);
-    return id + buf + label + "\t" + (strand_rc ? "Rc" : "Fwd") + "\t";
+    return id + buf + label + "\t" + (strand_rc ? "Rc" : "Fwd") + "\t" + cuts;
+}
+
+// ---- filter patterns (pattern.rs) -----------------------------------------------------------------
+namespace {
+std::string trim(const std::string& s) {
+    size_t a = 0, b = s.size();
+    while (a < b && isspace((unsigned char)s[a])) ++a;
+    while (b > a && isspace((unsigned char)s[b - 1])) --b;
+    return s.substr(a, b - a);
+}
+std::vector<std::string> split(const std::string& s, const std::string& sep) {
+    std::vector<std::string> out;
+    size_t pos = 0;
+    for (;;) {
+        const size_t q = s.find(sep, pos);
+        out.push_back(s.substr(pos, q == std::string::npos ? std::string::npos : q - pos));
+        if (q == std::string::npos) return out;
+        pos = q + sep.size();
+    }
+}
+bool parse_int(const std::string& s, long& v) {  // str::parse::<isize>: optional sign, digits only
+    if (s.empty()) return false;
+    size_t i = (s[0] == '-' || s[0] == '+') ? 1 : 0;
+    if (i == s.size()) return false;
+    for (size_t j = i; j < s.size(); ++j) if (!isdigit((unsigned char)s[j])) return false;
+    v = atol(s.c_str());
+    return true;
+}
+bool parse_range(std::string s, long& lo, long& hi) {  // pattern.rs:249-261
+    size_t a = 0, b = s.size();
+    while (a < b && (s[a] == '(' || s[a] == ')')) ++a;
+    while (b > a && (s[b - 1] == '(' || s[b - 1] == ')')) --b;
+    const auto parts = split(s.substr(a, b - a), "..");
+    return parts.size() == 2 && parse_int(trim(parts[0]), lo) && parse_int(trim(parts[1]), hi);
+}
+bool parse_position(const std::string& p, int& rel, long& lo, long& hi) {  // pattern.rs:263-279
+    const auto parts = split(p, "(");
+    if (parts.size() != 2) return false;
+    std::string name = parts[0];
+    while (!name.empty() && name[0] == '@') name.erase(0, 1);
+    if (name == "left") rel = BB_REL_LEFT;
+    else if (name == "right") rel = BB_REL_RIGHT;
+    else if (name == "prev_left") rel = BB_REL_PREV_LEFT;
+    else return false;
+    return parse_range(trim(p.substr(parts[0].size())), lo, hi);
+}
+bool parse_element(const std::string& s, PatternElement& el) {  // pattern.rs:287-356
+    const size_t br = s.find('[');
+    if (br == std::string::npos) return false;
+    const std::string name = trim(s.substr(0, br));
+    if (name == "Flank" || name == "flank") throw BarbellError(BB_E_INVALID, "Flank is not valid, use Fflank or Rflank");
+    if (name == "Ftag") el.match_type = BarcodeType::Ftag;
+    else if (name == "Rtag") el.match_type = BarcodeType::Rtag;
+    else if (name == "Fflank") el.match_type = BarcodeType::Fflank;
+    else if (name == "Rflank") el.match_type = BarcodeType::Rflank;
+    else return false;
+    std::string body = s.substr(br + 1);
+    while (!body.empty() && body.back() == ']') body.pop_back();
+    for (const auto& raw : split(body, ",")) {
+        const std::string param = trim(raw);
+        if (param == "fw") el.orientation = BB_FWD;
+        else if (param == "rc") el.orientation = BB_RC;
+        else if (!param.empty() && param[0] == '@') {
+            int rel; long lo, hi;
+            if (parse_position(param, rel, lo, hi)) { el.relative_to = rel; el.range_lo = lo; el.range_hi = hi; }
+        } else if (!param.empty() && param[0] == '?') {
+            long v;
+            if (parse_int(param.substr(1), v) && v >= 0 && param[1] != '-') el.placeholder = (int)v;
+        } else if (!param.empty() && (param[0] == '>' || param[0] == '<')) {
+            if (auto c = Cut::from_pattern_string(param)) el.cuts.push_back(*c);
+        } else if (param == "*") {
+        } else {
+            size_t a = 0, b = param.size();
+            while (a < b && param[a] == '"') ++a;
+            while (b > a && param[b - 1] == '"') --b;
+            el.label = param.substr(a, b - a);
+        }
+    }
+    return true;
+}
+}  // namespace
+
+std::optional<Cut> Cut::from_pattern_string(const std::string& s) {
+    if (s.size() < 2) throw BarbellError(BB_E_INVALID, "cut marker too short: '" + s + "'");  // the reference slices [..2] and panics
+    if (s.compare(0, 2, ">>") != 0 && s.compare(0, 2, "<<") != 0) return std::nullopt;
+    long gid = 0;
+    if (s.size() > 2 && (!parse_int(s.substr(2), gid) || gid < 0 || s[2] == '-')) return std::nullopt;
+    Cut c;
+    c.group_id = (size_t)gid;
+    c.after = s[0] == '>';
+    return c;
+}
+std::string Cut::to_string() const { return std::string(after ? "After(" : "Before(") + std::to_string(group_id) + ")"; }
+
+Pattern pattern_from_str(const std::string& s) {
+    Pattern p;
+    const auto parts = split(s, "__");
+    for (const auto& part : parts) {
+        PatternElement el;
+        if (parse_element(trim(part), el)) p.elements.push_back(std::move(el));
+    }
+    if (p.elements.size() != parts.size())  // basic_verify, pattern.rs:281-285
+        throw BarbellError(BB_E_INVALID, "Pattern parse error: could not convert all elements of '" + s + "'");
+    return p;
+}
+
+std::vector<Pattern> patterns_from_files(const std::vector<std::string>& paths) {
+    if (paths.empty()) throw BarbellError(BB_E_INVALID, "No filter pattern files provided");
+    std::vector<Pattern> out;
+    for (const auto& path : paths) {
+        std::ifstream f(path);
+        if (!f) throw BarbellError(BB_E_INVALID, "Failed to open pattern file: " + path);
+        std::string line;
+        while (std::getline(f, line)) {
+            line = trim(line);
+            if (!line.empty()) out.push_back(pattern_from_str(line));
+        }
+    }
+    if (out.empty()) throw BarbellError(BB_E_INVALID, "No filter patterns found");
+    return out;
+}
+
+std::vector<Pattern> kit_patterns(const std::string& kit_in, bool maximize) {
+    std::string kit = kit_in;
+    for (int pass = 0; pass < 2; ++pass) {
+        for (const auto& k : KIT_FILTER)
+            if (kit == k.kit) {
+                std::vector<Pattern> out;
+                const char* const* set = maximize ? k.maximize : k.safe;
+                const int n = maximize ? k.n_maximize : k.n_safe;
+                for (int i = 0; i < n; ++i) out.push_back(pattern_from_str(set[i]));
+                return out;
+            }
+        std::replace(kit.begin(), kit.end(), '.', '-');
+    }
+    throw BarbellError(BB_E_INVALID, "Unsupported kit: " + kit_in);
 }
 
 // ---- Demuxer ------------------------------------------------------------------------------------
@@ -199,6 +335,7 @@ std::vector<BarbellMatch> Demuxer::demux_batch(const std::vector<std::string>& r
         rc = bb_annotate_batch(ctx_, bases.data(), offsets.data(), n, rows_.data(), rows_.size(), &n_rows);
     }
     if (rc != BB_OK) throw BarbellError(rc, std::string("bb_annotate_batch: ") + bb_strerror(rc) + " " + bb_last_error(ctx_));
+    n_rows_ = n_rows;
     std::vector<BarbellMatch> out;
     out.reserve(n_rows);
     for (uint64_t i = 0; i < n_rows; ++i) {
@@ -217,6 +354,53 @@ std::vector<BarbellMatch> Demuxer::demux_batch(const std::vector<std::string>& r
         out.push_back(std::move(m));
     }
     return out;
+}
+
+void Demuxer::set_filter(const std::vector<Pattern>& patterns) {
+    ensure_ctx();
+    // histogram slot space: per group its labels then "flank" (bb_counts layout); equal strings share an id
+    std::vector<std::string> slot;
+    for (const auto& g : queries_) { slot.insert(slot.end(), g.labels.begin(), g.labels.end()); slot.push_back("flank"); }
+    std::vector<uint32_t> ids(slot.size());
+    for (size_t i = 0; i < slot.size(); ++i) ids[i] = (uint32_t)(std::find(slot.begin(), slot.end(), slot[i]) - slot.begin());
+    std::vector<std::vector<bb_pattern_elem>> elems(patterns.size());
+    std::vector<std::vector<uint8_t>> oks;
+    size_t n_lab = 0;
+    for (const auto& p : patterns) for (const auto& e : p.elements) n_lab += e.label ? 1 : 0;
+    oks.reserve(n_lab);
+    std::vector<bb_pattern> pats(patterns.size());
+    for (size_t i = 0; i < patterns.size(); ++i) {
+        for (const auto& e : patterns[i].elements) {
+            if (e.cuts.size() > BB_MAX_CUTS) throw BarbellError(BB_E_INVALID, "more than 3 cut markers on one pattern element");
+            bb_pattern_elem c{};
+            c.match_type = (uint8_t)e.match_type; c.orientation = (int8_t)e.orientation; c.relative_to = (uint8_t)e.relative_to;
+            c.n_cuts = (uint8_t)e.cuts.size(); c.placeholder = e.placeholder; c.range_lo = e.range_lo; c.range_hi = e.range_hi;
+            if (e.label) {  // exact label or "~substring" (pattern.rs:108-121)
+                std::vector<uint8_t> ok(slot.size());
+                const bool sub = !e.label->empty() && (*e.label)[0] == '~';
+                for (size_t q = 0; q < slot.size(); ++q)
+                    ok[q] = sub ? slot[q].find(e.label->substr(1)) != std::string::npos : slot[q] == *e.label;
+                oks.push_back(std::move(ok));
+                c.label_ok = oks.back().data();
+            }
+            for (size_t q = 0; q < e.cuts.size(); ++q) c.cuts[q] = bb_cut{(uint8_t)(e.cuts[q].after ? BB_CUT_AFTER : BB_CUT_BEFORE), 0, (uint16_t)e.cuts[q].group_id};
+            elems[i].push_back(c);
+        }
+        pats[i] = bb_pattern{elems[i].data(), (uint32_t)elems[i].size()};
+    }
+    const int rc = bb_filter_set(ctx_, pats.data(), (uint32_t)pats.size(), ids.data());
+    if (rc != BB_OK) throw BarbellError(rc, std::string("bb_filter_set: ") + bb_strerror(rc) + " " + bb_last_error(ctx_));
+    has_filter_ = true;
+}
+
+std::vector<bb_row_verdict> Demuxer::filter_last_batch() {
+    if (!has_filter_) throw BarbellError(BB_E_INVALID, "filter_last_batch without set_filter");
+    std::vector<bb_row_verdict> v(n_rows_);
+    if (n_rows_) {
+        const int rc = bb_filter_rows(ctx_, rows_.data(), n_rows_, v.data());
+        if (rc != BB_OK) throw BarbellError(rc, std::string("bb_filter_rows: ") + bb_strerror(rc) + " " + bb_last_error(ctx_));
+    }
+    return v;
 }
 
 // ---- annotate (annotator.rs) ----------------------------------------------------------------------
@@ -261,6 +445,22 @@ AnnotateStats annotate(const std::vector<std::string>& read_files, const std::st
     if (!out) throw BarbellError(BB_E_INVALID, "Failed to create annotation output file '" + out_file + "'");
     Demuxer dm(config.alpha, config.verbose, config.min_score, config.min_score_diff, config.device);
     for (auto& g : query_groups) dm.add_query_group(std::move(g));
+    const bool filtering = !config.filter_patterns.empty();
+    FILE* kept_f = nullptr;
+    FILE* drop_f = nullptr;
+    if (filtering) {
+        dm.set_filter(config.filter_patterns);
+        if (!config.filtered_file.empty() && !(kept_f = fopen(config.filtered_file.c_str(), "w"))) {
+            fclose(out);
+            throw BarbellError(BB_E_INVALID, "Failed to create filtered output file '" + config.filtered_file + "'");
+        }
+        if (!config.dropped_file.empty() && !(drop_f = fopen(config.dropped_file.c_str(), "w"))) {
+            fclose(out);
+            if (kept_f) fclose(kept_f);
+            throw BarbellError(BB_E_INVALID, "Failed to create dropped output file '" + config.dropped_file + "'");
+        }
+    }
+    bool kept_header = false, drop_header = false;
     AnnotateStats st;
     std::vector<std::string> ids;
     std::vector<uint8_t> bases;
@@ -268,8 +468,10 @@ AnnotateStats annotate(const std::vector<std::string>& read_files, const std::st
     bool header = false;
     auto flush = [&]() {
         if (ids.empty()) return;
-        const auto rows = dm.demux_batch(ids, bases, offsets);
+        auto rows = dm.demux_batch(ids, bases, offsets);
         st.total += ids.size();
+        std::vector<bb_row_verdict> verdicts;
+        if (filtering) verdicts = dm.filter_last_batch();
         const std::string* last = nullptr;
         for (const auto& r : rows) {
             if (!header) { fputs(TSV_HEADER, out); fputc('\n', out); header = true; }  // csv writer: header with the first record
@@ -277,6 +479,23 @@ AnnotateStats annotate(const std::vector<std::string>& read_files, const std::st
             fputc('\n', out);
             if (!last || *last != r.read_id) ++st.found;
             last = &r.read_id;
+        }
+        for (size_t i = 0; i < verdicts.size(); ++i) {  // filtered.tsv / dropped.tsv (filter.rs:87-119)
+            const bb_row_verdict& v = verdicts[i];
+            const bool first = i == 0 || rows[i].read_id != rows[i - 1].read_id;
+            if (first) ++(v.pass ? st.kept : st.dropped);
+            FILE* f = v.pass ? kept_f : drop_f;
+            if (!f) continue;
+            bool& hdr = v.pass ? kept_header : drop_header;
+            if (!hdr) { fputs(TSV_HEADER, f); fputc('\n', f); hdr = true; }
+            std::string cuts;
+            for (unsigned q = 0; q < v.n_cuts; ++q) {  // "After(0):1" (searcher.rs:91-106)
+                if (q) cuts += ',';
+                cuts += Cut{v.cuts[q].group_id, v.cuts[q].direction == BB_CUT_AFTER}.to_string() + ":" + std::to_string(v.match_idx);
+            }
+            rows[i].cuts = std::move(cuts);
+            fputs(rows[i].to_tsv().c_str(), f);
+            fputc('\n', f);
         }
         st.rows += rows.size();
         ids.clear(); bases.clear(); offsets.assign(1, 0);
@@ -293,8 +512,15 @@ AnnotateStats annotate(const std::vector<std::string>& read_files, const std::st
             }
         }
         flush();
-    } catch (...) { fclose(out); throw; }
+    } catch (...) {
+        fclose(out);
+        if (kept_f) fclose(kept_f);
+        if (drop_f) fclose(drop_f);
+        throw;
+    }
     fclose(out);
+    if (kept_f) fclose(kept_f);
+    if (drop_f) fclose(drop_f);
     return st;
 }
 

@@ -5,6 +5,8 @@
 //   BarbellMatch + TSV serialisation  src/annotate/searcher.rs:31-142, annotator.rs:13-26
 //   annotate / annotate_with_kit / annotate_with_files / annotate_with_groups   annotator.rs:155-285
 //   kit presets                       src/kits/kits.rs:635-816, 1074-1103 (data in kits_data.inc)
+//   Cut / PatternElement / Pattern / pattern_from_str!   src/filter/pattern.rs:9-30, 69-95, 242-383
+//   filter pattern files, kit default patterns            src/filter/filter.rs:141-181, kits.rs:175-236
 // The per-read call `Demuxer::demux(read_id, read)` (searcher.rs:430) becomes `demux_batch`: one
 // bb_annotate_batch per batch.  All arithmetic of the path runs in the HIP kernels of
 // libbarbell_amd.so; nothing here computes alignments.
@@ -16,6 +18,7 @@
 #include <vector>
 
 #include "../../../include/barbell_amd.h"
+#include "../../../include/barbell_amd_filter.h"
 
 namespace barbell {
 
@@ -42,6 +45,27 @@ std::vector<std::string> get_barcodes(const std::string& from_label, const std::
 const char* lookup_barcode_seq(const std::string& label);
 std::vector<std::string> supported_kits();
 
+// ---- filter patterns (src/filter/pattern.rs) ------------------------------------------------------
+struct Cut {  // pattern.rs:15-19
+    size_t group_id = 0;
+    bool after = false;                                                  // CutDirection::After / Before
+    static std::optional<Cut> from_pattern_string(const std::string& s);  // ">>", "<<", ">>3"  (pattern.rs:69-85)
+    std::string to_string() const;                                       // "After(0)"  (pattern.rs:88-95)
+};
+struct PatternElement {  // pattern.rs:21-30
+    BarcodeType match_type = BarcodeType::Ftag;
+    int orientation = -1;                      // -1 any, BB_FWD, BB_RC
+    std::optional<std::string> label;          // exact, or "~substr"
+    int placeholder = -1;                      // ?N
+    long range_lo = 0, range_hi = 0;
+    int relative_to = BB_REL_NONE;             // @left / @right / @prev_left
+    std::vector<Cut> cuts;
+};
+struct Pattern { std::vector<PatternElement> elements; };
+Pattern pattern_from_str(const std::string& s);                                   // pattern_from_str! (pattern.rs:242-383)
+std::vector<Pattern> patterns_from_files(const std::vector<std::string>& paths);   // filter.rs:137-181
+std::vector<Pattern> kit_patterns(const std::string& kit, bool maximize);         // kits.rs:175-236 (safe unless maximize)
+
 struct BarbellMatch {  // searcher.rs:31-64
     std::string read_id;
     size_t read_len;
@@ -51,7 +75,8 @@ struct BarbellMatch {  // searcher.rs:31-64
     int flank_cost, barcode_cost;
     std::string label;
     bool strand_rc;
-    std::string to_tsv() const;   // csv-crate row, tab-delimited, cuts = ""
+    std::string cuts;             // "After(0):1,Before(0):2" once the filter step ran (searcher.rs:91-106), else ""
+    std::string to_tsv() const;   // csv-crate row, tab-delimited
 };
 extern const char* const TSV_HEADER;
 
@@ -65,6 +90,9 @@ public:
     // rows of all reads of the batch, in input order (rows of one read contiguous, sorted by flank start)
     std::vector<BarbellMatch> demux_batch(const std::vector<std::string>& read_ids, const std::vector<uint8_t>& bases,
                                           const std::vector<uint64_t>& offsets);
+    // filter step on the rows of the LAST demux_batch (filter.rs:183-214 on the GPU): one verdict per row
+    void set_filter(const std::vector<Pattern>& patterns);
+    std::vector<bb_row_verdict> filter_last_batch();
     bb_group_info group_info(size_t g);
     const std::vector<BarcodeGroup>& queries() const { return queries_; }
 
@@ -77,6 +105,8 @@ private:
     std::vector<BarcodeGroup> queries_;
     bb_ctx* ctx_ = nullptr;
     std::vector<bb_row> rows_;
+    uint64_t n_rows_ = 0;
+    bool has_filter_ = false;
 };
 
 struct AnnotateConfig {  // config.rs:3-12 with the CLI defaults of bin/main.rs:64-112
@@ -88,8 +118,12 @@ struct AnnotateConfig {  // config.rs:3-12 with the CLI defaults of bin/main.rs:
     bool use_extended = false;
     size_t batch_reads = 65536;
     int device = 0;
+    // fused filter step: when filter_patterns is non-empty, rows of passing / failing reads go to
+    // filtered_file / dropped_file with their cuts column (what `barbell filter -o/--dropped` writes)
+    std::vector<Pattern> filter_patterns;
+    std::string filtered_file, dropped_file;
 };
-struct AnnotateStats { size_t total = 0, found = 0, rows = 0; };
+struct AnnotateStats { size_t total = 0, found = 0, rows = 0, kept = 0, dropped = 0; };
 
 AnnotateStats annotate(const std::vector<std::string>& read_files, const std::string& out_file,
                        std::vector<BarcodeGroup> query_groups, const AnnotateConfig& config);          // annotator.rs:233-285

@@ -7,6 +7,7 @@ hands them to the HIP library (`bb_filter_set` / `bb_filter_rows`), which runs `
 `check_filter_pass` for every read of a batch on the GPU.  `format_cuts` is the `cuts` column of
 filtered.tsv (searcher.rs:91-106)."""
 import ctypes as C
+import re
 from dataclasses import dataclass, field
 
 import numpy as np
@@ -26,13 +27,13 @@ class Cut:  # pattern.rs:15-19
 
     @staticmethod
     def from_pattern_string(s):  # pattern.rs:69-85: ">>", "<<", ">>3"
-        if len(s) < 2 or s[:2] not in (">>", "<<"):
+        if len(s) < 2:  # the reference slices [..2] and panics here
+            raise ValueError(f"cut marker too short: {s!r}")
+        if s[:2] not in (">>", "<<"):
             return None
         try:
-            gid = 0 if len(s) == 2 else int(s[2:])
+            gid = 0 if len(s) == 2 else _int(s[2:], signed=False)
         except ValueError:
-            return None
-        if gid < 0:
             return None
         return Cut(gid, "After" if s[:2] == ">>" else "Before")
 
@@ -56,12 +57,19 @@ class Pattern:
     elements: list
 
 
+def _int(s, signed=True):
+    """str::parse::<isize>/<usize>: optional sign (no '-' for usize), ASCII digits only"""
+    if not re.fullmatch(r"[+-]?[0-9]+" if signed else r"\+?[0-9]+", s):
+        raise ValueError(s)
+    return int(s)
+
+
 def _parse_range(s):  # pattern.rs:249-261
     parts = s.strip("()").split("..")
     if len(parts) != 2:
         return None
     try:
-        return int(parts[0].strip()), int(parts[1].strip())
+        return _int(parts[0].strip()), _int(parts[1].strip())
     except ValueError:
         return None
 
@@ -100,9 +108,7 @@ def _parse_element(s):  # pattern.rs:287-356
                 el.relative_to, el.range = r
         elif param.startswith("?"):
             try:
-                v = int(param[1:])
-                if v >= 0:
-                    el.placeholder = v
+                el.placeholder = _int(param[1:], signed=False)
             except ValueError:
                 pass
         elif param.startswith(">") or param.startswith("<"):
@@ -131,8 +137,10 @@ def kit_patterns(kit, maximize=False):
     return [pattern_from_str(p) for p in d["pattern_sets"][d["kit_filter"][kit]["maximize" if maximize else "safe"]]]
 
 
-def patterns_from_file(path):  # filter.rs:141-181
-    pats = [pattern_from_str(l.strip()) for l in open(path) if l.strip()]
+def patterns_from_files(paths):  # filter.rs:137-181
+    if not paths:
+        raise ValueError("No filter pattern files provided")
+    pats = [pattern_from_str(l.strip()) for path in paths for l in open(path) if l.strip()]
     if not pats:
         raise ValueError("No filter patterns found")
     return pats

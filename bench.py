@@ -154,12 +154,33 @@ def main():
                                 "no MFMA. PMC instruction counts: profiles/"},
             "histogram_total": int(hist.sum().item()),
         }
+        if args.config == "nbd96":
+            out["filter_step"] = filter_leg(dm, d_rows, int(rows_per_launch), dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, groups, dm, d_bases, L)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def filter_leg(dm, d_rows, n_rows, dev):
+    """SURVEY §8(f-1), outside the timed region: the kit's default filter patterns (kits.rs:175-236,
+    --maximize set) applied to the rows of the last step while they sit in HBM.  16 B verdict per 48 B row."""
+    from barbell_amd.filter import Filter, kit_patterns
+
+    flt = Filter(dm, kit_patterns("SQK-NBD114-96", True))
+    d_v = torch.empty(n_rows * 16, dtype=torch.uint8, device=dev)
+    flt.verdicts_dev(d_rows.data_ptr(), n_rows, d_v.data_ptr())
+    reps = 10
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        flt.verdicts_dev(d_rows.data_ptr(), n_rows, d_v.data_ptr())  # synchronous on the context's stream
+    ms = (time.perf_counter() - t0) / reps * 1e3
+    v = d_v.view(-1, 16)
+    first = v[:, 2:4].view(torch.int16).flatten() == 0          # match_idx == 0: first row of a read
+    return {"patterns": len(flt.patterns), "rows": n_rows, "ms_per_step": ms, "gb_per_s": n_rows * 64 / (ms * 1e-3) / 1e9,
+            "reads_with_rows": int(first.sum().item()), "reads_kept": int((first & (v[:, 0] == 1)).sum().item())}
 
 
 def load_traffic(args, batch, L, dom):

@@ -46,6 +46,33 @@ def test_argument_errors(tmp_path):
     assert r.returncode == 1 and "Unknown or unsupported kit" in r.stderr
 
 
+def _dump(p):
+    from barbell_amd import _abi
+
+    names = {_abi.BB_FTAG: "Ftag", _abi.BB_RTAG: "Rtag", _abi.BB_FFLANK: "Fflank", _abi.BB_RFLANK: "Rflank"}
+    return [f"{names[e.match_type]}|{e.orientation}|{'*' if e.label is None else e.label}|{e.placeholder}|{e.relative_to}|"
+            f"{e.range[0]}|{e.range[1]}|{','.join(str(c) for c in e.cuts)}" for e in p.elements] + ["--"]
+
+
+def test_cpp_pattern_parser_matches_python():
+    """C++ pattern_from_str == Python pattern_from_str on the kit pattern sets, the pattern.rs test strings
+    and malformed input (pattern.rs:242-383)."""
+    from barbell_amd import filter as F
+    from barbell_amd.kits import _data
+
+    strs = [p for ps in _data()["pattern_sets"].values() for p in ps] + [
+        "Ftag[fw, *, @left(0..250)]", "Ftag[fw, ?1, @left(0..250)]__Ftag[<<, rc, ?1, @right(0..250)]",
+        "Fflank[fw, *, @left(0..250)]__Ftag[fw, ~NB, @prev_left(5 .. 250), >>2, <<7]", "Rtag[rc, \"BC01\", @right(-10..+30)]",
+        "Ftag[]", "Rflank[*]", "Ftag[fw, ?x, @middle(0..3), >>-1, <x, @left(1..), ?-1]", "Ftag[>>, <<, >>1]"]
+    out = subprocess.run([CLI, "pattern"] + strs, capture_output=True, text=True, check=True).stdout.splitlines()
+    assert out == [l for s in strs for l in _dump(F.pattern_from_str(s))]
+    for bad in ["Ftag[fw]__Nope[rc]", "Ftag", "Ftag[fw]__", "Flank[fw]", "Ftag[fw, >]"]:
+        with pytest.raises(ValueError):
+            F.pattern_from_str(bad)
+        r = subprocess.run([CLI, "pattern", bad], capture_output=True, text=True)
+        assert r.returncode == 1 and "error:" in r.stderr, bad
+
+
 def test_fails_loudly_without_gpu(tmp_path):
     import torch
 
@@ -104,3 +131,33 @@ def test_cli_custom_dual_end_queries(tmp_path):
     rows = dm.demux_packed(bases, offsets)
     want = (A.TSV_HEADER + "\n" + "\n".join(A.format_rows(rows, ids, groups)) + "\n").encode()
     assert out_cli.read_bytes() == want and b"Rtag" in want
+
+
+@pytest.mark.gpu
+def test_cli_fused_filter_matches_python(tmp_path):
+    """annotate --kit-filter / -f pattern files: filtered.tsv and dropped.tsv byte-identical to the Python
+    host's fused annotate->filter (whose verdicts the oracle checks in test_filter.py)."""
+    from barbell_amd import annotate as A
+    from barbell_amd import filter as F
+
+    kit = "SQK-RBK114-24"
+    groups = kits.groups_from_kit(kit, flank_max_errors=3)
+    bases, offsets = A.synth_reads_host(groups, 77, 300, 2500, 0, 800)
+    ids = [f"r{i}" for i in range(800)]
+    fq = tmp_path / "reads.fastq"
+    write_fastq(fq, ids, bases, offsets)
+    env = dict(os.environ, BARBELL_AMD_NO_TORCH="1")
+    pf = tmp_path / "patterns.txt"
+    pf.write_text("Ftag[fw, *, @left(0..250), >>]\n\n  Ftag[fw, *, @left(0..250), >>]__Ftag[<<, rc, *, @right(0..250)]  \n")
+    for name, flags, pats in (("kit", ["--kit-filter", "--maximize"], F.kit_patterns(kit, True)),
+                              ("file", ["-f", str(pf)], F.patterns_from_files([str(pf)]))):
+        o = {k: tmp_path / f"{name}_{k}.tsv" for k in ("a", "k", "d", "pa", "pk", "pd")}
+        r = subprocess.run([CLI, "annotate", "-i", str(fq), "-o", str(o["a"]), "--kit", kit, "--flank-max-errors", "3", "--batch-reads", "300",
+                            "--filtered", str(o["k"]), "--dropped", str(o["d"])] + flags, capture_output=True, text=True, env=env)
+        assert r.returncode == 0, r.stderr
+        assert "Filter:" in r.stderr
+        A.annotate([str(fq)], str(o["pa"]), kits.groups_from_kit(kit), max_flank_errors=3, batch_reads=500, filter_patterns=pats,
+                   filtered_file=str(o["pk"]), dropped_file=str(o["pd"]))
+        for c, p in (("a", "pa"), ("k", "pk"), ("d", "pd")):
+            assert o[c].read_bytes() == o[p].read_bytes(), (name, c)
+        assert o["k"].stat().st_size > 100 and o["d"].stat().st_size > 100
