@@ -18,6 +18,7 @@
 #include "../../include/barbell_amd_filter.h"
 #include "../../include/barbell_amd_synth.h"
 #include "bb_common.h"
+#include "bb_ctx_view.h"
 #include "bb_kernels.h"
 #include "bb_synth.h"
 
@@ -148,6 +149,8 @@ struct bb_ctx {
     uint32_t n_fpats = 0;
     bb_row* d_frows = nullptr; uint64_t cap_frows = 0;
     bb_row_verdict* d_fout = nullptr; uint64_t cap_fout = 0;
+    // trim step, owned by bb_trim.hip
+    bb_trim_state* trim = nullptr;
     // synth
     uint8_t* d_synth_table = nullptr;
     bb_synth_params synth{};
@@ -454,11 +457,13 @@ void bb_destroy(bb_ctx* c) {
                     c->d_synth_table, c->d_fpats, c->d_felems, c->d_flabel_ok, c->d_flabel_ids, c->d_frows, c->d_fout};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
+    bb_trim_state_free(c->trim);
     for (int i = 0; i <= K_COUNT; ++i)
         if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
+
 
 int bb_n_groups(const bb_ctx* c) { return c ? (int)c->groups.size() : BB_E_INVALID; }
 int bb_group_get_info(const bb_ctx* c, uint32_t g, bb_group_info* info) {
@@ -835,3 +840,8 @@ int bb_synth_reads_dev(bb_ctx* c, uint64_t seed, uint32_t len_min, uint32_t len_
 }
 
 }  // extern "C"
+
+bb_ctx_view bb_ctx_get_view(bb_ctx* c) {
+    return bb_ctx_view{c->device, c->stream, (const bb_group_dev*)c->d_groups, (const uint32_t*)c->d_flabel_ids, &c->last_error, &c->trim};
+}
+

@@ -736,3 +736,208 @@ int bbo_filter_rows(const bbo_ctx* c, const bb_pattern* patterns, uint32_t n_pat
     }
     return BB_OK;
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* trim/split step: trim.rs:127-300 + the record text of trim.rs:447-460       */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct { uint32_t gid, start, end; uint8_t after; uint32_t row; } cut_entry;   /* (start_flank, end_flank, cut, anno) */
+typedef struct { uint32_t gid, first, n; } cut_group;                                   /* entries of one group id, in row order */
+typedef struct { uint32_t start, end; int32_t a[2]; int n_a; } complete_slice;
+
+/* H10: the reference collects groups in a HashMap and stable-sorts them by the start of their first
+ * entry (trim.rs:145-152); ties keep the map's (random) iteration order.  Here ties keep the order
+ * in which the group ids first appear in the rows. */
+static int preprocess_cuts(const bb_row* rows, const bb_row_verdict* v, uint32_t n, uint32_t seq_len, complete_slice** out) {
+    uint32_t n_e = 0;
+    for (uint32_t r = 0; r < n; ++r) n_e += v[r].n_cuts;
+    cut_entry* e = (cut_entry*)malloc(sizeof(cut_entry) * (n_e + 1));
+    cut_group* g = (cut_group*)malloc(sizeof(cut_group) * (n_e + 1));
+    uint32_t* member = (uint32_t*)malloc(sizeof(uint32_t) * (n_e + 1));   /* entries ordered by group, row order inside */
+    uint32_t k = 0, n_g = 0;
+    for (uint32_t r = 0; r < n; ++r)
+        for (uint32_t q = 0; q < v[r].n_cuts; ++q) {
+            e[k].gid = v[r].cuts[q].group_id; e[k].start = rows[r].read_start_flank; e[k].end = rows[r].read_end_flank;
+            e[k].after = v[r].cuts[q].direction == BB_CUT_AFTER; e[k].row = r; ++k;
+        }
+    for (uint32_t i = 0; i < n_e; ++i) {                                   /* groups in first-appearance order */
+        uint32_t j = 0;
+        while (j < n_g && g[j].gid != e[i].gid) ++j;
+        if (j == n_g) { g[n_g].gid = e[i].gid; g[n_g].n = 0; ++n_g; }
+        g[j].n++;
+    }
+    uint32_t pos = 0;
+    for (uint32_t j = 0; j < n_g; ++j) {
+        g[j].first = pos;
+        for (uint32_t i = 0; i < n_e; ++i) if (e[i].gid == g[j].gid) member[pos++] = i;
+    }
+    for (uint32_t i = 1; i < n_g; ++i) {                                    /* stable insertion sort by first entry's start */
+        cut_group t = g[i]; uint32_t j = i;
+        while (j > 0 && e[member[g[j - 1].first]].start > e[member[t.first]].start) { g[j] = g[j - 1]; --j; }
+        g[j] = t;
+    }
+    complete_slice* s = (complete_slice*)malloc(sizeof(complete_slice) * (n_g + 1));
+    uint32_t n_s = 0;
+    for (uint32_t i = 0; i < n_g; ++i) {
+        const cut_entry* m0 = &e[member[g[i].first]];
+        if (g[i].n == 2) {                                                  /* trim.rs:156-181 */
+            const cut_entry* m1 = &e[member[g[i].first + 1]];
+            s[n_s].start = m0->after ? m0->end : m0->start;
+            s[n_s].end = m1->after ? m1->end : m1->start;
+            s[n_s].a[0] = (int32_t)m0->row; s[n_s].a[1] = (int32_t)m1->row; s[n_s].n_a = 2; ++n_s;
+        } else if (g[i].n == 1) {
+            if (!m0->after) {                                               /* Before: look left, trim.rs:186-215 */
+                uint32_t st = 0; int32_t left = -1;
+                if (i > 0) {
+                    const cut_group* pg = &g[i - 1]; uint32_t best = 0;
+                    for (uint32_t q = 0; q < pg->n; ++q)                    /* max_by_key: last maximum */
+                        if (e[member[pg->first + q]].end >= e[member[pg->first + best]].end) best = q;
+                    st = e[member[pg->first + best]].end; left = (int32_t)e[member[pg->first + best]].row;
+                }
+                s[n_s].start = st; s[n_s].end = m0->start; s[n_s].n_a = 0;
+                if (left >= 0) s[n_s].a[s[n_s].n_a++] = left;
+                s[n_s].a[s[n_s].n_a++] = (int32_t)m0->row; ++n_s;
+            } else {                                                        /* After: look right, trim.rs:217-248 */
+                uint32_t en = seq_len; int32_t right = -1;
+                if (i + 1 < n_g) {
+                    const cut_group* ng = &g[i + 1]; uint32_t best = 0;
+                    for (uint32_t q = 0; q < ng->n; ++q)                    /* min_by_key: first minimum */
+                        if (e[member[ng->first + q]].start < e[member[ng->first + best]].start) best = q;
+                    en = e[member[ng->first + best]].start; right = (int32_t)e[member[ng->first + best]].row;
+                }
+                s[n_s].start = m0->end; s[n_s].end = en; s[n_s].n_a = 0;
+                s[n_s].a[s[n_s].n_a++] = (int32_t)m0->row;
+                if (right >= 0) s[n_s].a[s[n_s].n_a++] = right;
+                ++n_s;
+            }
+        }                                                                   /* other sizes: no slice */
+    }
+    free(e); free(g); free(member);
+    *out = s;
+    return (int)n_s;
+}
+
+/* LabelConfig::create_label (trim.rs:58-105) as a key: parts = label_id*2 + strand bit */
+static uint32_t label_key_of(const bbo_ctx* c, const bb_trim_config* cfg, const uint8_t* is_flank, const uint32_t* part_rank,
+                             const uint32_t* label_ids, const bb_row* rows, const complete_slice* s) {
+    if (!cfg->add_labels) return 0;
+    uint32_t parts[2]; int np = 0;
+    for (int i = 0; i < s->n_a; ++i) {
+        const bb_row* m = &rows[s->a[i]];
+        const uint32_t id = label_ids[row_slot(c, m)];
+        if (!cfg->add_flank && is_flank[id]) continue;
+        parts[np++] = id * 2u + (cfg->add_orientation ? (m->strand == BB_RC) : 0u);
+    }
+    if (np == 0) return 0;
+    if (cfg->sort_labels) {
+        if (np == 2 && part_rank[parts[1]] < part_rank[parts[0]]) { uint32_t t = parts[0]; parts[0] = parts[1]; parts[1] = t; }
+    } else if (cfg->only_side != BB_SIDE_NONE) {
+        parts[0] = cfg->only_side == BB_SIDE_LEFT ? parts[0] : parts[np - 1];
+        np = 1;
+    }
+    return (parts[0] + 1u) << 16 | (np == 2 ? parts[1] + 1u : 0u);
+}
+
+static uint8_t comp_base(uint8_t ch) {                                     /* the RC table of trim.rs:486-530 */
+    static const char* pairs = "ATCGRYKMBVDH";                            /* A<->T C<->G R<->Y K<->M B<->V D<->H; S W N X fixed */
+    for (int i = 0; pairs[i]; ++i) {
+        if (ch == (uint8_t)pairs[i]) return (uint8_t)pairs[i ^ 1];
+        if (ch == (uint8_t)(pairs[i] + 32)) return (uint8_t)(pairs[i ^ 1] + 32);
+    }
+    return ch;
+}
+static int n_digits(uint32_t v) { int d = 1; while (v >= 10) { v /= 10; ++d; } return d; }
+
+typedef struct { bb_slice s; uint64_t order; } slice_rec;
+static int cmp_slice_rec(const void* a, const void* b) {
+    const slice_rec* x = (const slice_rec*)a; const slice_rec* y = (const slice_rec*)b;
+    if (x->s.label_key != y->s.label_key) return x->s.label_key < y->s.label_key ? -1 : 1;
+    return x->order < y->order ? -1 : (x->order > y->order);
+}
+
+int bbo_trim_batch(const bbo_ctx* c, const bb_trim_config* cfg, const uint8_t* label_is_flank, const uint32_t* part_rank,
+                   const uint32_t* label_ids, const bb_row* rows, const bb_row_verdict* verdicts, uint64_t n_rows,
+                   const uint8_t* bases, const uint8_t* quals, const uint64_t* offsets, const bb_headers* h, uint32_t n_reads,
+                   uint8_t* text, uint64_t text_cap, uint64_t* text_len, bb_slice* slices, uint64_t slices_cap, uint64_t* n_slices,
+                   bb_label_span* spans, uint32_t spans_cap, uint32_t* n_spans, uint8_t* read_status) {
+    if (!c || !cfg || !label_ids || !text_len || !n_slices || !n_spans || !read_status || !h) return BB_E_INVALID;
+    if (cfg->sort_labels && cfg->only_side != BB_SIDE_NONE) return BB_E_INVALID;             /* trim.rs:330-334 */
+    memset(read_status, BB_TRIM_NONE, n_reads);
+    slice_rec* recs = NULL; uint64_t n_rec = 0, cap_rec = 0;
+    uint64_t i = 0;
+    while (i < n_rows) {
+        uint64_t j = i;
+        while (j < n_rows && rows[j].read_idx == rows[i].read_idx) ++j;
+        const uint32_t read = rows[i].read_idx, n = (uint32_t)(j - i);
+        if (read >= n_reads) { free(recs); return BB_E_INVALID; }
+        if (verdicts[i].pass) {                                             /* filtered.tsv holds passing reads only */
+            const uint32_t seq_len = (uint32_t)(offsets[read + 1] - offsets[read]);
+            complete_slice* sl = NULL;
+            const int n_s = preprocess_cuts(rows + i, verdicts + i, n, seq_len, &sl);
+            int written = 0;
+            for (int q = 0; q < n_s; ++q) {                                 /* process_read_and_anno trim.rs:270-297 */
+                if (sl[q].start >= sl[q].end) continue;
+                if (n_rec == cap_rec) { cap_rec = cap_rec ? cap_rec * 2 : 1024; recs = (slice_rec*)realloc(recs, cap_rec * sizeof(slice_rec)); }
+                bb_slice* o = &recs[n_rec].s;
+                memset(o, 0, sizeof(*o));
+                o->read_idx = read; o->start = sl[q].start; o->end = sl[q].end; o->suffix = (uint16_t)q;
+                o->label_key = label_key_of(c, cfg, label_is_flank, part_rank, label_ids, rows + i, &sl[q]);
+                if (cfg->flip)
+                    for (int a = 0; a < sl[q].n_a; ++a) {                   /* should_flip trim.rs:310-315 */
+                        const bb_row* m = &rows[i + (uint32_t)sl[q].a[a]];
+                        if (m->match_type == BB_FTAG && m->strand == BB_RC) o->flip = 1;
+                    }
+                const uint64_t hl = h->hdr_offsets[read + 1] - h->hdr_offsets[read];
+                const uint32_t L = cfg->skip_trim ? seq_len : o->end - o->start;
+                const uint32_t desc_len = (uint32_t)(hl - h->desc_start[read]);
+                o->rec_len = 1 + h->id_len[read] + (q ? 1 + (uint32_t)n_digits((uint32_t)q) : 0) +
+                             ((cfg->write_full_header && desc_len) ? 1 + desc_len : 0) + 1 + L + 3 + L + 1;
+                recs[n_rec].order = n_rec; ++n_rec; ++written;
+            }
+            free(sl);
+            read_status[read] = written ? BB_TRIM_TRIMMED : BB_TRIM_FAILED;
+        }
+        i = j;
+    }
+    if (n_rec) qsort(recs, n_rec, sizeof(slice_rec), cmp_slice_rec);       /* group by label, read order inside */
+    uint64_t total = 0; uint32_t ns = 0;
+    for (uint64_t r = 0; r < n_rec; ++r) {
+        recs[r].s.out_off = total; total += recs[r].s.rec_len;
+        if (r == 0 || recs[r].s.label_key != recs[r - 1].s.label_key) ++ns;
+    }
+    *text_len = total; *n_slices = n_rec; *n_spans = ns;
+    if (total > text_cap || n_rec > slices_cap || ns > spans_cap) { free(recs); return BB_E_CAPACITY; }
+    ns = 0;
+    for (uint64_t r = 0; r < n_rec; ++r) {
+        const bb_slice* o = &recs[r].s;
+        slices[r] = *o;
+        if (r == 0 || o->label_key != recs[r - 1].s.label_key) {
+            spans[ns].label_key = o->label_key; spans[ns].n_records = 0; spans[ns].first = r; spans[ns].off = o->out_off; spans[ns].len = 0; ++ns;
+        }
+        spans[ns - 1].n_records++; spans[ns - 1].len += o->rec_len;
+        /* the record, trim.rs:447-460 */
+        uint8_t* w = text + o->out_off;
+        const uint32_t read = o->read_idx;
+        const uint8_t* hd = h->hdr + h->hdr_offsets[read];
+        const uint64_t hl = h->hdr_offsets[read + 1] - h->hdr_offsets[read];
+        *w++ = '@';
+        memcpy(w, hd, h->id_len[read]); w += h->id_len[read];
+        if (o->suffix) w += sprintf((char*)w, "_%u", (unsigned)o->suffix);
+        if (cfg->write_full_header && hl > h->desc_start[read]) {
+            *w++ = ' ';
+            memcpy(w, hd + h->desc_start[read], hl - h->desc_start[read]); w += hl - h->desc_start[read];
+        }
+        *w++ = '\n';
+        const uint64_t b0 = offsets[read];
+        const uint32_t seq_len = (uint32_t)(offsets[read + 1] - b0);
+        const uint32_t s0 = cfg->skip_trim ? 0 : o->start, s1 = cfg->skip_trim ? seq_len : o->end, L = s1 - s0;
+        for (uint32_t k = 0; k < L; ++k) w[k] = o->flip ? comp_base(bases[b0 + s1 - 1 - k]) : bases[b0 + s0 + k];
+        w += L;
+        *w++ = '\n'; *w++ = '+'; *w++ = '\n';
+        for (uint32_t k = 0; k < L; ++k) w[k] = o->flip ? quals[b0 + s1 - 1 - k] : quals[b0 + s0 + k];
+        w += L;
+        *w++ = '\n';
+        if ((uint64_t)(w - (text + o->out_off)) != o->rec_len) { free(recs); return BB_E_INVALID; }
+    }
+    free(recs);
+    return BB_OK;
+}

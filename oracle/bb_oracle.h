@@ -13,6 +13,7 @@
 
 #include "../include/barbell_amd.h"
 #include "../include/barbell_amd_filter.h"
+#include "../include/barbell_amd_trim.h"
 
 #ifdef __cplusplus
 extern "C" {
@@ -77,6 +78,13 @@ int  bbo_annotate_batch(bbo_ctx* ctx, const uint8_t* bases, const uint64_t* offs
  * rows grouped by consecutive read_idx like the reference groups by consecutive read_id (filter.rs:54-85) */
 int  bbo_filter_rows(const bbo_ctx* ctx, const bb_pattern* patterns, uint32_t n_patterns, const uint32_t* label_ids,
                      const bb_row* rows, uint64_t n_rows, bb_row_verdict* out);
+/* trim/split step on a batch (trim.rs:127-300 preprocess_cuts + process_read_and_anno, record text
+ * trim.rs:447-460); same outputs as bb_trim_batch, configuration passed directly */
+int  bbo_trim_batch(const bbo_ctx* ctx, const bb_trim_config* cfg, const uint8_t* label_is_flank, const uint32_t* part_rank,
+                    const uint32_t* label_ids, const bb_row* rows, const bb_row_verdict* verdicts, uint64_t n_rows,
+                    const uint8_t* bases, const uint8_t* quals, const uint64_t* offsets, const bb_headers* headers, uint32_t n_reads,
+                    uint8_t* text, uint64_t text_cap, uint64_t* text_len, bb_slice* slices, uint64_t slices_cap, uint64_t* n_slices,
+                    bb_label_span* spans, uint32_t spans_cap, uint32_t* n_spans, uint8_t* read_status);
 /* test hook: 1 = trace flank matches on the full DP matrix instead of the (m+k)-column window */
 void bbo_set_full_trace(int on);
 

@@ -67,6 +67,8 @@ def lib():
                                          C.POINTER(C.c_uint64), C.c_int]
         L.bbo_set_full_trace.argtypes = [C.c_int]
         L.bbo_filter_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+        L.bbo_trim_batch.argtypes = [C.c_void_p] * 7 + [C.c_uint64] + [C.c_void_p] * 4 + [C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p,
+                                     C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 
@@ -192,6 +194,38 @@ class Oracle:
         rc = lib().bbo_filter_rows(self.h, arr, len(patterns), label_ids.ctypes.data, rows.ctypes.data, len(rows), out.ctypes.data)
         assert rc == 0, rc
         return out
+
+    def trim_batch(self, groups, cfg, rows, verdicts, bases, quals, offsets, headers):
+        """process_read_and_anno + record text for every passing read (trim.rs:127-300, 447-460) -> TrimResult"""
+        from barbell_amd import filter as F
+        from barbell_amd import trim as T
+
+        tb = T.LabelTables(groups, cfg)
+        c = T.config_c(cfg)
+        rows = np.ascontiguousarray(rows, dtype=_abi.ROW_DTYPE)
+        verdicts = np.ascontiguousarray(verdicts, dtype=F.VERDICT_DTYPE)
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        quals = np.ascontiguousarray(quals, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = len(offsets) - 1
+        blob, hoff, id_len, desc = headers if isinstance(headers, tuple) else T.pack_headers(headers)
+        blob = np.ascontiguousarray(blob)
+        h = T.HeadersC(blob.ctypes.data, hoff.ctypes.data, id_len.ctypes.data, desc.ctypes.data)
+        status = np.zeros(n, dtype=np.uint8)
+        tl, ns, nsp = C.c_uint64(), C.c_uint64(), C.c_uint32()
+        args = (self.h, C.addressof(c), tb.is_flank.ctypes.data, tb.part_rank.ctypes.data, tb.label_ids.ctypes.data, rows.ctypes.data,
+                verdicts.ctypes.data, len(rows), bases.ctypes.data, quals.ctypes.data, offsets.ctypes.data, C.addressof(h), n)
+        rc = lib().bbo_trim_batch(*args, None, 0, C.addressof(tl), None, 0, C.addressof(ns), None, 0, C.addressof(nsp), status.ctypes.data)
+        assert rc in (0, _abi.BB_E_CAPACITY), rc                      # sizing call
+        text = np.empty(tl.value + 1, dtype=np.uint8)
+        slices = np.zeros(ns.value + 1, dtype=T.SLICE_DTYPE)
+        spans = np.zeros(nsp.value + 1, dtype=T.SPAN_DTYPE)
+        rc = lib().bbo_trim_batch(self.h, C.addressof(c), tb.is_flank.ctypes.data, tb.part_rank.ctypes.data, tb.label_ids.ctypes.data,
+                                  rows.ctypes.data, verdicts.ctypes.data, len(rows), bases.ctypes.data, quals.ctypes.data,
+                                  offsets.ctypes.data, C.addressof(h), n, text.ctypes.data, len(text), C.addressof(tl), slices.ctypes.data,
+                                  len(slices), C.addressof(ns), spans.ctypes.data, len(spans), C.addressof(nsp), status.ctypes.data)
+        assert rc == 0, rc
+        return T.TrimResult(text[: tl.value], slices[: ns.value], spans[: nsp.value], status)
 
     def close(self):
         if self.h:

@@ -1,0 +1,323 @@
+"""Trim/split step.  CPU: the reference's trim tests (src/trim/trim.rs:533-790)
+transcribed as known-answer tests for the oracle's preprocess_cuts / process_read_and_anno restatement,
+plus label formatting and record text.  GPU: text / slices / spans / status of bb_trim_batch bit-identical
+to the oracle's on the rows of synthetic reads, for the trim configurations of the CLI and the kit driver."""
+import os
+
+import numpy as np
+import pytest
+
+from barbell_amd import _abi, filter as F, trim as T
+from barbell_amd.kits import QueryGroup
+from oracle import pyoracle as po
+
+
+def two_groups(flabels, rlabels):
+    pre, suf = b"ACGTACGTAC", b"TTGCATGCAA"
+    alphabet = [b"AAAA", b"CCCC", b"GGGG", b"TTTT", b"ACAC", b"GTGT", b"AGAG", b"CTCT"]
+    return [QueryGroup([pre + alphabet[i] + suf for i in range(len(flabels))], flabels, _abi.BB_FTAG, 2),
+            QueryGroup([suf + alphabet[i] + pre for i in range(len(rlabels))], rlabels, _abi.BB_RTAG, 2)]
+
+
+GROUPS = two_groups(["Fbar", "F1", "F2"], ["Rbar", "R1", "R2", "x_flank_y"])
+_ORC = None
+
+
+def orc():
+    global _ORC
+    if _ORC is None:
+        _ORC = po.Oracle([g.as_tuple() for g in GROUPS])
+    return _ORC
+
+
+def anno(read_idx, start, end, group, label, strand, cuts, read_len):
+    """BarbellMatch::new(start, end, start, end, ...) with cuts [(group_id, 'After'|'Before')] -> (row, verdict)"""
+    r = np.zeros(1, dtype=_abi.ROW_DTYPE)[0]
+    r["read_idx"], r["read_len"] = read_idx, read_len
+    r["read_start_bar"], r["read_end_bar"], r["read_start_flank"], r["read_end_flank"] = start, end, start, end
+    r["group_idx"] = group
+    r["match_type"] = (_abi.BB_FTAG, _abi.BB_RTAG)[group] if label != "flank" else (_abi.BB_FFLANK, _abi.BB_RFLANK)[group]
+    r["barcode_idx"] = -1 if label == "flank" else GROUPS[group].labels.index(label)
+    r["strand"] = strand
+    v = np.zeros(1, dtype=F.VERDICT_DTYPE)[0]
+    v["pass"], v["n_cuts"] = 1, len(cuts)
+    for q, (gid, d) in enumerate(cuts):
+        v["cuts"][q]["direction"], v["cuts"][q]["group_id"] = int(d == "After"), gid
+    return r, v
+
+
+def run(reads, annos, cfg, headers=None, engine=None):
+    """reads: list of (seq, qual); annos: list of (row, verdict).  -> [(seq, qual, label, header_line)] in text order,
+    the raw TrimResult"""
+    rows = np.array([a[0] for a in annos], dtype=_abi.ROW_DTYPE)
+    ver = np.array([a[1] for a in annos], dtype=F.VERDICT_DTYPE)
+    for i in range(len(rows)):
+        ver[i]["match_idx"] = i - int(np.searchsorted(rows["read_idx"], rows[i]["read_idx"]))
+    bases, offsets = _abi.pack_reads([s for s, _ in reads])
+    quals, _ = _abi.pack_reads([q for _, q in reads])
+    headers = headers or [b"read%d" % (i + 1) for i in range(len(reads))]
+    res = (engine or orc().trim_batch)(GROUPS, cfg, rows, ver, bases, quals, offsets, headers) if engine is None else \
+        engine(rows, ver, bases, quals, offsets, headers)
+    return parse(res, cfg), res
+
+
+def parse(res, cfg):
+    tb = T.LabelTables(GROUPS, cfg)
+    out = []
+    txt = res.text.tobytes()
+    for s in res.slices:
+        rec = txt[int(s["out_off"]): int(s["out_off"]) + int(s["rec_len"])]
+        h, sq, plus, ql, last = rec.split(b"\n")
+        assert plus == b"+" and last == b"" and h[:1] == b"@"
+        out.append((sq, ql, tb.label_of_key(int(s["label_key"]), cfg), h[1:]))
+    # spans tile the text and the slices
+    off = first = 0
+    for sp in res.spans:
+        assert (int(sp["off"]), int(sp["first"])) == (off, first)
+        sl = res.slices[first: first + int(sp["n_records"])]
+        assert (sl["label_key"] == sp["label_key"]).all() and int(sl["rec_len"].sum()) == int(sp["len"])
+        off, first = off + int(sp["len"]), first + int(sp["n_records"])
+    assert off == len(res.text) and first == len(res.slices)
+    assert (np.diff(res.spans["label_key"].astype(np.int64)) > 0).all()
+    return out
+
+
+ALL = T.TrimConfig(True, True, True, True, None)  # LabelConfig::new(true, true, true, true, None)
+SEQ1, QUAL1 = b"CCCCCCCCAAAACCCCCCCCCCCC", b"________IIII____________"
+
+
+def kat_single():
+    return [anno(0, 4, 8, 0, "Fbar", 0, [(0, "After")], 24), anno(0, 12, 16, 1, "Rbar", 0, [(0, "Before")], 24)]
+
+
+def test_single_cut():  # trim.rs:539-590
+    out, res = run([(SEQ1, QUAL1)], kat_single(), ALL)
+    assert out == [(b"AAAA", b"IIII", "Fbar_fw__Rbar_fw", b"read1")]
+    assert res.status.tolist() == [T.TRIM_TRIMMED]
+
+
+def test_two_cut_groups_produce_two_slices():  # trim.rs:592-687
+    seq, qual = b"CCCCCCCCAAAAAAAAAAAACCCCCCGGCC", b"________IIIIIIIIIIII______II__"
+    a = [anno(0, 4, 8, 0, "F1", 0, [(1, "After")], 30), anno(0, 20, 24, 1, "R1", 0, [(1, "Before")], 30),
+         anno(0, 24, 26, 0, "F2", 0, [(2, "After")], 30), anno(0, 28, 30, 1, "R2", 0, [(2, "Before")], 30)]
+    out, res = run([(seq, qual)], a, ALL)
+    # text order is by label key; F1.. sorts before F2..
+    assert out == [(b"AAAAAAAAAAAA", b"IIIIIIIIIIII", "F1_fw__R1_fw", b"read1"), (b"GG", b"II", "F2_fw__R2_fw", b"read1_1")]
+    assert res.slices["suffix"].tolist() == [0, 1]
+
+
+def test_trim_skipping():  # trim.rs:689-740
+    cfg = T.TrimConfig(True, True, True, True, None, skip_trim=True)
+    out, _ = run([(SEQ1, QUAL1)], kat_single(), cfg)
+    assert out == [(SEQ1, QUAL1, "Fbar_fw__Rbar_fw", b"read1")]
+
+
+def test_flipping():  # trim.rs:742-800
+    seq, qual = b"CCCCCCCCAGGCCCCCCCCCCCCC", b"________IIIA____________"
+    cfg = T.TrimConfig(True, True, True, True, None, flip=True)
+    a = [anno(0, 4, 8, 0, "Fbar", 1, [(0, "After")], 24), anno(0, 12, 16, 1, "Rbar", 0, [(0, "Before")], 24)]
+    out, res = run([(seq, qual)], a, cfg)
+    assert out == [(b"GCCT", b"AIII", "Fbar_rc__Rbar_fw", b"read1")] and res.slices["flip"].tolist() == [1]
+    a[0][0]["strand"] = 0
+    out, res = run([(seq, qual)], a, cfg)
+    assert out == [(b"AGGC", b"IIIA", "Fbar_fw__Rbar_fw", b"read1")] and res.slices["flip"].tolist() == [0]
+    # an Rtag on Rc does not flip (should_flip, trim.rs:310-315); without --flip nothing flips
+    a[1][0]["strand"] = 1
+    assert run([(seq, qual)], a, cfg)[0][0][0] == b"AGGC"
+    a[0][0]["strand"] = 1
+    assert run([(seq, qual)], a, T.TrimConfig(True, True, True, True, None))[0][0][0] == b"AGGC"
+
+
+def test_single_sided_cuts_and_neighbours():
+    """group of one cut (trim.rs:182-250): After looks right (next group's leftmost start, else read end),
+    Before looks left (previous group's rightmost end, else 0); empty slices are skipped but still count for
+    the suffix (trim.rs:271-273)."""
+    seq = bytes(range(65, 65 + 26)) * 2
+    qual = seq.lower()
+    # After-only
+    out, _ = run([(seq, qual)], [anno(0, 2, 6, 0, "Fbar", 0, [(0, "After")], 52)], ALL)
+    assert out == [(seq[6:], qual[6:], "Fbar_fw", b"read1")]
+    # Before-only
+    out, _ = run([(seq, qual)], [anno(0, 40, 46, 1, "Rbar", 0, [(0, "Before")], 52)], ALL)
+    assert out == [(seq[:40], qual[:40], "Rbar_fw", b"read1")]
+    # After(1) then Before(2): both single; slice 0 = [6, 40) labelled with both, slice 1 = [6, 40) again via look-left
+    a = [anno(0, 2, 6, 0, "F1", 0, [(1, "After")], 52), anno(0, 40, 46, 1, "R1", 0, [(2, "Before")], 52)]
+    out, res = run([(seq, qual)], a, ALL)
+    assert [(o[0], o[2], o[3]) for o in out] == [(seq[6:40], "F1_fw__R1_fw", b"read1"), (seq[6:40], "F1_fw__R1_fw", b"read1_1")]
+    # empty first slice: Before at position 0 -> [0, 0) skipped, the second keeps suffix _1
+    a = [anno(0, 0, 5, 0, "F1", 0, [(1, "Before"), (2, "After")], 52)]
+    out, res = run([(seq, qual)], a, ALL)
+    assert [(o[0], o[3]) for o in out] == [(seq[5:], b"read1_1")]
+    # three cuts in one group: no slice -> failed
+    a = [anno(0, 2, 6, 0, "F1", 0, [(0, "After")], 52), anno(0, 20, 24, 0, "F2", 0, [(0, "After")], 52),
+         anno(0, 40, 46, 1, "R1", 0, [(0, "Before")], 52)]
+    out, res = run([(seq, qual)], a, ALL)
+    assert out == [] and res.status.tolist() == [T.TRIM_FAILED]
+    # passing read without cuts -> failed; read without rows -> none
+    r, v = anno(1, 2, 6, 0, "F1", 0, [], 52)
+    out, res = run([(seq, qual), (seq, qual), (seq, qual)], [(r, v)], ALL)
+    assert out == [] and res.status.tolist() == [T.TRIM_NONE, T.TRIM_FAILED, T.TRIM_NONE]
+    # not passing -> untouched
+    r, v = anno(0, 2, 6, 0, "F1", 0, [(0, "After")], 52)
+    v["pass"] = 0
+    assert run([(seq, qual)], [(r, v)], ALL)[1].status.tolist() == [T.TRIM_NONE]
+
+
+def test_label_config():  # create_label trim.rs:58-105
+    seq, qual = SEQ1, QUAL1
+    a = [anno(0, 4, 8, 1, "Rbar", 1, [(0, "After")], 24), anno(0, 12, 16, 0, "Fbar", 0, [(0, "Before")], 24)]
+    lab = lambda cfg, aa=a: run([(seq, qual)], aa, cfg)[0][0][2]
+    assert lab(T.TrimConfig(True, True, True, False, None)) == "Rbar_rc__Fbar_fw"
+    assert lab(T.TrimConfig(True, True, True, True, None)) == "Fbar_fw__Rbar_rc"          # sorted
+    assert lab(T.TrimConfig(True, False, True, False, None)) == "Rbar__Fbar"
+    assert lab(T.TrimConfig(False, True, True, False, None)) == "none"
+    assert lab(T.TrimConfig(True, True, True, False, "left")) == "Rbar_rc"
+    assert lab(T.TrimConfig(True, True, True, False, "right")) == "Fbar_fw"
+    assert lab(T.TrimConfig.for_kit()) == "Rbar"
+    with pytest.raises(ValueError):
+        T.config_c(T.TrimConfig(True, True, True, True, "left"))
+    # flanks: dropped from the label unless add_flank; "flank" is a substring test (trim.rs:66)
+    b = [anno(0, 4, 8, 0, "flank", 0, [(0, "After")], 24), anno(0, 12, 16, 1, "x_flank_y", 0, [(0, "Before")], 24)]
+    assert lab(T.TrimConfig(True, True, True, False, None), b) == "flank_fw__x_flank_y_fw"
+    assert lab(T.TrimConfig(True, True, False, False, None), b) == "none"
+    c = [anno(0, 4, 8, 0, "flank", 0, [(0, "After")], 24), anno(0, 12, 16, 1, "Rbar", 0, [(0, "Before")], 24)]
+    assert lab(T.TrimConfig(True, False, False, False, "left"), c) == "Rbar"             # flank filtered before the side pick
+
+
+def test_headers_and_grouping():
+    """record header "@{id}{suffix}[ {desc}]" (trim.rs:447-455); records grouped by label, read order inside"""
+    reads = [(SEQ1, QUAL1)] * 4
+    hdr = [b"r0 runid=7  ch=2", b"r1", b"r2\tdesc", b"r3 "]
+    annos = []
+    for i, (f, r) in enumerate([("F2", "R1"), ("F1", "R1"), ("F2", "R1"), ("F1", "R2")]):
+        annos += [anno(i, 4, 8, 0, f, 0, [(0, "After")], 24), anno(i, 12, 16, 1, r, 0, [(0, "Before")], 24)]
+    out, res = run(reads, annos, T.TrimConfig(True, False, True, False, None), headers=hdr)
+    assert [(o[2], o[3]) for o in out] == [("F1__R1", b"r1"), ("F1__R2", b"r3"), ("F2__R1", b"r0 runid=7  ch=2"), ("F2__R1", b"r2 desc")]
+    assert res.spans["n_records"].tolist() == [1, 1, 2]
+    out, _ = run(reads, annos, T.TrimConfig(True, False, True, False, None, write_full_header=False), headers=hdr)
+    assert [o[3] for o in out] == [b"r1", b"r3", b"r0", b"r2"]
+    out, _ = run(reads, annos, T.TrimConfig.for_kit(), headers=hdr)
+    assert [o[2] for o in out] == ["F1", "F1", "F2", "F2"] and [o[3][:2] for o in out] == [b"r1", b"r3", b"r0", b"r2"]
+
+
+def test_reverse_complement_table():  # trim.rs:486-530
+    seq = b"ACGTacgtRYSWKMBDHVNXryswkmbdhvnx.-*U"
+    exp = b"U*-.xnbdhvkmwsryXNBDHVKMWSRYacgtACGT"
+    cfg = T.TrimConfig(True, True, True, True, None, flip=True)
+    n = len(seq)
+    a = [anno(0, 0, 0, 0, "Fbar", 1, [(0, "After")], n)]
+    out, _ = run([(seq, bytes(range(33, 33 + n)))], a, cfg)
+    assert out[0][0] == exp and out[0][1] == bytes(range(33, 33 + n))[::-1]
+
+
+# ---- GPU parity ------------------------------------------------------------------------------------
+def _gpu_engine(dm, cfg):
+    tr = T.Trimmer(dm, cfg)
+    return lambda rows, ver, bases, quals, offsets, headers: tr.trim_batch(rows, ver, bases, quals, offsets, headers)
+
+
+def _same(a, b):
+    assert a.status.tolist() == b.status.tolist()
+    assert len(a.slices) == len(b.slices)
+    for f in T.SLICE_DTYPE.names:
+        assert (a.slices[f] == b.slices[f]).all(), f
+    assert a.spans.tobytes() == b.spans.tobytes()
+    assert a.text.tobytes() == b.text.tobytes()
+
+
+CONFIGS = [T.TrimConfig(), T.TrimConfig.for_kit(), T.TrimConfig(True, True, True, True, None),
+           T.TrimConfig(True, False, False, False, "right", write_full_header=False), T.TrimConfig(False, flip=True),
+           T.TrimConfig(True, True, True, False, None, skip_trim=True, flip=True)]
+
+
+@pytest.mark.gpu
+def test_gpu_kats_match_oracle():
+    """the hand-made cases above through the GPU library"""
+    from barbell_amd import annotate as A
+
+    dm = A.Demuxer()
+    for g in GROUPS:
+        dm.add_query_group(g)
+    F.Filter(dm, [F.pattern_from_str("Ftag[fw, *, >>]")])  # installs the label ids
+    seq = bytes(range(65, 65 + 26)) * 2
+    reads = [(seq, seq.lower())] * 6
+    hdr = [b"r0 runid=7  ch=2", b"r1", b"r2\tdesc", b"r3 ", "r4 x".encode(), b"r5  d e"]
+    annos = [anno(0, 2, 6, 0, "F1", 0, [(1, "After")], 52), anno(0, 40, 46, 1, "R1", 1, [(2, "Before")], 52),
+             anno(1, 0, 5, 0, "F1", 1, [(1, "Before"), (2, "After")], 52),
+             anno(2, 2, 6, 0, "F1", 0, [(0, "After")], 52), anno(2, 20, 24, 0, "F2", 0, [(0, "After")], 52), anno(2, 40, 46, 1, "R1", 0, [(0, "Before")], 52),
+             anno(3, 4, 8, 0, "flank", 0, [(3, "After")], 52), anno(3, 30, 36, 1, "x_flank_y", 0, [(3, "Before")], 52),
+             anno(5, 4, 8, 0, "Fbar", 1, [(0, "After"), (0, "Before")], 52)]
+    for cfg in CONFIGS:
+        _, want = run(reads, annos, cfg, headers=hdr)
+        _, got = run(reads, annos, cfg, headers=hdr, engine=_gpu_engine(dm, cfg))
+        _same(got, want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("config,kit", [("nbd96", "SQK-NBD114-96"), ("rbk24", "SQK-RBK114-24")])
+def test_gpu_trim_matches_oracle_on_synthetic_reads(config, kit):
+    """annotate -> filter (kit maximize patterns) -> trim on the GPU vs the oracle's trim of the same rows:
+    text, slices, spans and read status byte-identical for every trim configuration"""
+    from barbell_amd import annotate as A
+    from tests.common import config_groups
+
+    groups = config_groups(config)
+    n = 3000
+    bases, offsets = A.synth_reads_host(groups, 4242, 200, 3000, 0, n)
+    rng = np.random.default_rng(5)
+    quals = rng.integers(33, 90, size=len(bases), dtype=np.uint8)
+    hdr = [(b"read_%d" % i) + (b" ch=%d start_time=2024" % (i % 512) if i % 3 else b"") for i in range(n)]
+    dm = A.Demuxer()
+    for g in groups:
+        dm.add_query_group(g)
+    rows = dm.demux_packed(bases, offsets)
+    flt = F.Filter(dm, F.kit_patterns(kit, True))
+    ver = flt.verdicts(rows)
+    o = po.Oracle([g.as_tuple() for g in groups])
+    for cfg in CONFIGS:
+        want = o.trim_batch(groups, cfg, rows, ver, bases, quals, offsets, hdr)
+        got = T.Trimmer(dm, cfg).trim_batch(rows, ver, bases, quals, offsets, hdr)
+        _same(got, want)
+        assert (want.status == T.TRIM_TRIMMED).sum() > n // 3
+    # the records of a label are the passing reads in input order, and every byte of a trimmed read
+    # comes from the read: spot-check through the slices
+    cfg = T.TrimConfig.for_kit()
+    got = T.Trimmer(dm, cfg).trim_batch(rows, ver, bases, quals, offsets, hdr)
+    for sp in got.spans:
+        sl = got.slices[int(sp["first"]): int(sp["first"]) + int(sp["n_records"])]
+        assert (np.diff(sl["read_idx"].astype(np.int64)) >= 0).all()
+    txt = got.text.tobytes()
+    for s in got.slices[:: max(1, len(got.slices) // 200)]:
+        rec = txt[int(s["out_off"]): int(s["out_off"]) + int(s["rec_len"])].split(b"\n")
+        b0 = int(offsets[int(s["read_idx"])])
+        assert rec[1] == bases[b0 + int(s["start"]): b0 + int(s["end"])].tobytes()
+        assert rec[3] == quals[b0 + int(s["start"]): b0 + int(s["end"])].tobytes()
+
+
+@pytest.mark.gpu
+def test_gpu_trim_capacity_and_errors():
+    from barbell_amd import annotate as A
+    from barbell_amd._lib import lib
+    import ctypes as C
+
+    dm = A.Demuxer()
+    for g in GROUPS:
+        dm.add_query_group(g)
+    with pytest.raises(A.BarbellError):  # trim before bb_trim_set / bb_filter_set
+        tr = T.Trimmer.__new__(T.Trimmer)
+        tr.dm, tr.cfg, tr.tables = dm, T.TrimConfig(), T.LabelTables(GROUPS, T.TrimConfig())
+        tr.trim_batch(np.zeros(0, _abi.ROW_DTYPE), np.zeros(0, F.VERDICT_DTYPE), np.zeros(4, np.uint8), np.zeros(4, np.uint8),
+                      np.array([0, 4], np.uint64), [b"r"])
+    c = T.TrimConfigC(1, 1, 1, 1, 1, 1, 0, 0)
+    tb = T.LabelTables(GROUPS, T.TrimConfig())
+    assert lib().bb_trim_set(dm._ctx(), C.byref(c), tb.is_flank.ctypes.data, tb.part_rank.ctypes.data, len(tb.labels)) == _abi.BB_E_INVALID
+    F.Filter(dm, [F.pattern_from_str("Ftag[fw, *, >>]")])
+    tr = T.Trimmer(dm, T.TrimConfig())
+    # empty batch
+    res = tr.trim_batch(np.zeros(0, _abi.ROW_DTYPE), np.zeros(0, F.VERDICT_DTYPE), np.zeros(4, np.uint8), np.zeros(4, np.uint8),
+                        np.array([0, 4], np.uint64), [b"r"])
+    assert len(res.text) == 0 and len(res.slices) == 0 and res.status.tolist() == [0]
+    # 33 cut entries on one read -> unsupported, reported loudly
+    annos = [anno(0, i, i + 1, 0, "F1", 0, [(i, "After"), (i, "Before"), (100 + i, "After")], 64) for i in range(11)]
+    with pytest.raises(A.BarbellError):
+        run([(b"A" * 64, b"I" * 64)], annos, T.TrimConfig(), engine=_gpu_engine(dm, T.TrimConfig()))
