@@ -10,6 +10,7 @@ All computation happens in the HIP library; there is no CPU path here.
 """
 import ctypes as C
 import gzip
+import re
 
 import numpy as np
 
@@ -185,15 +186,21 @@ def format_rows(rows, read_ids, groups, verdicts=None):
     return out
 
 
-def split_fastq_header(header):  # src/io/io.rs:6-17
-    parts = header.split(None, 1)
-    if not parts:
-        return "", ""
-    return parts[0], (parts[1].lstrip() if len(parts) > 1 else "")
+_WS = re.compile("[\\t\\n\\x0b\\x0c\\r \\x85\\xa0\\u1680\\u2000-\\u200a\\u2028\\u2029\\u202f\\u205f\\u3000]")  # char::is_whitespace
 
 
-def read_fastq(path):
-    """Yields (read_id, seq bytes).  Plain or gzip FASTQ, 4-line records."""
+def split_fastq_header(header):  # src/io/io.rs:6-17: id up to the first whitespace, description left-trimmed
+    m = _WS.search(header)
+    if not m:
+        return header, ""
+    j = m.start()
+    while j < len(header) and _WS.match(header[j]):
+        j += 1
+    return header[: m.start()], header[j:]
+
+
+def read_fastq_records(path):
+    """Yields (header line without '@', seq, qual) as bytes.  Plain or gzip FASTQ, 4-line records."""
     op = gzip.open if str(path).endswith(".gz") else open
     with op(path, "rb") as f:
         while True:
@@ -202,18 +209,27 @@ def read_fastq(path):
                 return
             s = f.readline().rstrip(b"\r\n")
             f.readline()
-            f.readline()
-            yield split_fastq_header(h[1:].decode().rstrip("\r\n"))[0], s
+            q = f.readline().rstrip(b"\r\n")
+            yield h[1:].rstrip(b"\r\n"), s, q
+
+
+def read_fastq(path):
+    """Yields (read_id, seq bytes)."""
+    for h, s, _ in read_fastq_records(path):
+        yield split_fastq_header(h.decode())[0], s
 
 
 def annotate(read_files, out_file, query_groups, alpha=0.4, min_score=0.2, min_score_diff=0.1, max_flank_errors=None,
-             batch_reads=65536, device=0, filter_patterns=None, filtered_file=None, dropped_file=None):
+             batch_reads=65536, device=0, filter_patterns=None, filtered_file=None, dropped_file=None, trim_folder=None,
+             trim_config=None):
     """annotate_with_groups + annotate (annotator.rs:207-285): sets the flank threshold of each group
     (explicit --flank-max-errors or the automatic cutoff), streams the FASTQ in batches through the
     GPU and writes annotation.tsv.  With `filter_patterns` the filter step (filter.rs:10-119) runs on
     the rows of every batch while they are in HBM and `filtered_file` / `dropped_file` get the rows
     of passing / failing reads with their `cuts` column — what `barbell filter` would write from the
-    annotation file.  Returns (total_reads, reads_with_rows)."""
+    annotation file.  With `trim_folder` (needs the filter) the trim step (trim.rs:317-480) runs on the same
+    batch as well: the GPU cuts the passing reads and renders the FASTQ records grouped by output label, the
+    host appends each group to '{trim_folder}/{label}.trimmed.fastq[.gz]'.  Returns (total_reads, reads_with_rows)."""
     for g in query_groups:
         if max_flank_errors is not None:
             g.set_flank_threshold(max_flank_errors)
@@ -225,6 +241,15 @@ def annotate(read_files, out_file, query_groups, alpha=0.4, min_score=0.2, min_s
         from .filter import Filter
 
         flt = Filter(dm, filter_patterns)
+    trimmer = writers = None
+    if trim_folder is not None:
+        if flt is None:
+            raise ValueError("the trim step needs filter patterns (cuts come from the filter)")
+        from .trim import LabelWriters, TrimConfig, Trimmer
+
+        trim_config = trim_config or TrimConfig()
+        trimmer = Trimmer(dm, trim_config)
+        writers = LabelWriters(trim_folder, trim_config, trimmer.tables)
     total = found = 0
     outs = {"anno": open(out_file, "w"),
             "kept": open(filtered_file, "w") if (flt and filtered_file) else None,
@@ -240,13 +265,14 @@ def annotate(read_files, out_file, query_groups, alpha=0.4, min_score=0.2, min_s
             wrote[key] = True
         f.write("\n".join(lines) + "\n")
 
-    ids, seqs = [], []
+    ids, seqs, hdrs, quals = [], [], [], []
 
     def flush():
         nonlocal total, found
         if not ids:
             return
-        rows = dm.demux_batch(seqs)
+        bases, offsets = _abi.pack_reads(seqs)
+        rows = dm.demux_packed(bases, offsets)
         total += len(ids)
         found += len(np.unique(rows["read_idx"]))
         emit("anno", format_rows(rows, ids, query_groups))
@@ -255,14 +281,24 @@ def annotate(read_files, out_file, query_groups, alpha=0.4, min_score=0.2, min_s
             keep = v["pass"] == 1
             emit("kept", format_rows(rows[keep], ids, query_groups, v[keep]))
             emit("dropped", format_rows(rows[~keep], ids, query_groups, v[~keep]))
+            if trimmer is not None:
+                for i, (sq, q) in enumerate(zip(seqs, quals)):
+                    if len(sq) != len(q):
+                        raise ValueError(f"FASTQ record '{ids[i]}' has {len(q)} quality values for {len(sq)} bases")
+                writers.write(trimmer.trim_batch(rows, v, bases, _abi.pack_reads(quals)[0], offsets, hdrs), ids)
         ids.clear()
         seqs.clear()
+        hdrs.clear()
+        quals.clear()
 
     try:
         for path in read_files:
-            for rid, s in read_fastq(path):
-                ids.append(rid)
+            for h, s, q in read_fastq_records(path):
+                ids.append(split_fastq_header(h.decode())[0])
                 seqs.append(s)
+                if trimmer is not None:
+                    hdrs.append(h)
+                    quals.append(q)
                 if len(ids) >= batch_reads:
                     flush()
         flush()
@@ -270,6 +306,8 @@ def annotate(read_files, out_file, query_groups, alpha=0.4, min_score=0.2, min_s
         for f in outs.values():
             if f is not None:
                 f.close()
+        if writers is not None:
+            writers.close()
     dm.close()
     return total, found
 

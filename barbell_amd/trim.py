@@ -84,7 +84,7 @@ class LabelTables:
         return "__".join(self.part_str(x, cfg) for x in p)
 
 
-_WS = re.compile("[\\t\\n\\x0b\\x0c\\r \\x85\\xa0\\u1680\\u2000-\\u200a\\u2028\\u2029\\u202f\\u205f\\u3000]")  # char::is_whitespace
+from .annotate import _WS, split_fastq_header  # noqa: E402  (char::is_whitespace split of io.rs:6-17)
 
 
 def pack_headers(headers):
@@ -103,15 +103,8 @@ def pack_headers(headers):
                 j += 1
             id_len[i], desc[i] = sp, j
             continue
-        s = h.decode("utf-8")
-        m = _WS.search(s)
-        if not m:
-            id_len[i] = desc[i] = len(h)
-            continue
-        j = m.start()
-        while j < len(s) and _WS.match(s[j]):
-            j += 1
-        id_len[i], desc[i] = len(s[: m.start()].encode()), len(s[:j].encode())
+        rid, d = split_fastq_header(h.decode("utf-8"))
+        id_len[i], desc[i] = len(rid.encode()), len(h) - len(d.encode())
     return np.frombuffer(b"".join(headers), dtype=np.uint8), off, id_len, desc
 
 
@@ -163,6 +156,28 @@ class Trimmer:
                 continue
             self.dm._check(rc)
             return TrimResult(text[: tl.value], slices[: ns.value], spans[: nsp.value], status)
+
+
+    def trim_batch_dev(self, d_rows, d_verdicts, n_rows, d_bases, d_quals, d_offsets, d_hdr, d_hdr_offsets, d_id_len, d_desc_start,
+                       n_reads, d_text, text_cap, d_slices, slices_cap, d_spans, spans_cap, d_status):
+        """device-pointer variant (ints = HIP device pointers) -> (text_len, n_slices, n_spans)"""
+        from ._lib import lib
+
+        h = HeadersC(d_hdr, d_hdr_offsets, d_id_len, d_desc_start)
+        tl, ns, nsp = C.c_uint64(), C.c_uint64(), C.c_uint32()
+        rc = lib().bb_trim_batch_dev(self.dm._ctx(), d_rows, d_verdicts, n_rows, d_bases, d_quals, d_offsets, C.byref(h), n_reads, d_text,
+                                     text_cap, C.byref(tl), d_slices, slices_cap, C.byref(ns), d_spans, spans_cap, C.byref(nsp), d_status)
+        if rc == _abi.BB_E_CAPACITY:
+            from .annotate import BarbellError
+
+            raise BarbellError(rc, f"need text {tl.value} slices {ns.value} spans {nsp.value}")
+        self.dm._check(rc)
+        return int(tl.value), int(ns.value), int(nsp.value)
+
+    def last_ms(self):
+        from ._lib import lib
+
+        return {k: lib().bb_trim_last_ms(self.dm._ctx(), i) for i, k in enumerate(("plan_sort", "render", "total"))}
 
 
 class LabelWriters:

@@ -155,7 +155,9 @@ def main():
             "histogram_total": int(hist.sum().item()),
         }
         if args.config == "nbd96":
-            out["filter_step"] = filter_leg(dm, d_rows, int(rows_per_launch), dev)
+            out["filter_step"], d_v = filter_leg(dm, d_rows, int(rows_per_launch), dev)
+            out["trim_step"] = trim_leg(dm, d_rows, d_v, int(rows_per_launch), d_bases.data_ptr() + ((args.steps - 1) % n_batches) * batch * L,
+                                        d_off_b, batch, L, dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, groups, dm, d_bases, L)
         print(json.dumps(out), flush=True)
@@ -180,7 +182,45 @@ def filter_leg(dm, d_rows, n_rows, dev):
     v = d_v.view(-1, 16)
     first = v[:, 2:4].view(torch.int16).flatten() == 0          # match_idx == 0: first row of a read
     return {"patterns": len(flt.patterns), "rows": n_rows, "ms_per_step": ms, "gb_per_s": n_rows * 64 / (ms * 1e-3) / 1e9,
-            "reads_with_rows": int(first.sum().item()), "reads_kept": int((first & (v[:, 0] == 1)).sum().item())}
+            "reads_with_rows": int(first.sum().item()), "reads_kept": int((first & (v[:, 0] == 1)).sum().item())}, d_v
+
+
+def trim_leg(dm, d_rows, d_v, n_rows, bases_ptr, d_off_b, batch, L, dev):
+    """SURVEY §8(f-2), outside the timed region: the kit driver's trim configuration (use_kit.rs:87-99) on
+    the reads, rows and verdicts of the last step, all resident in HBM: slices planned, grouped by output
+    label and rendered as FASTQ text.  HBM-bound; algorithmic bytes = text written + the same bytes read."""
+    from barbell_amd.trim import TrimConfig, Trimmer
+
+    tr = Trimmer(dm, TrimConfig.for_kit())
+    d_q = torch.randint(33, 74, (batch * L,), dtype=torch.uint8, device=dev)
+    W = 40  # "r000001234 ch=0123 start_time=2024-01-01" style fixed-width header
+    idx = np.arange(batch, dtype=np.int64)
+    hdr = np.tile(np.frombuffer(b"r000000000 ch=0000 st=2024-01-01T00:00Z " [:W], dtype=np.uint8), (batch, 1))
+    for d in range(9):
+        hdr[:, 9 - d] = 48 + (idx // 10 ** d) % 10
+    d_hdr = torch.from_numpy(hdr.reshape(-1)).to(dev)
+    d_hoff = torch.arange(0, batch + 1, dtype=torch.int64, device=dev) * W
+    d_idl = torch.full((batch,), 10, dtype=torch.int32, device=dev)
+    d_ds = torch.full((batch,), 11, dtype=torch.int32, device=dev)
+    text_cap = 2 * batch * L + 128 * batch
+    d_text = torch.empty(text_cap, dtype=torch.uint8, device=dev)
+    d_sl = torch.empty(2 * batch * 32, dtype=torch.uint8, device=dev)
+    d_sp = torch.empty(4096 * 32, dtype=torch.uint8, device=dev)
+    d_st = torch.empty(batch, dtype=torch.uint8, device=dev)
+    call = lambda: tr.trim_batch_dev(d_rows.data_ptr(), d_v.data_ptr(), n_rows, bases_ptr, d_q.data_ptr(), d_off_b.data_ptr(),
+                                     d_hdr.data_ptr(), d_hoff.data_ptr(), d_idl.data_ptr(), d_ds.data_ptr(), batch, d_text.data_ptr(),
+                                     text_cap, d_sl.data_ptr(), 2 * batch, d_sp.data_ptr(), 4096, d_st.data_ptr())
+    call()
+    ms = {"plan_sort": 0.0, "render": 0.0, "total": 0.0}
+    reps = 5
+    for _ in range(reps):
+        tl, ns, nsp = call()
+        for k, v in tr.last_ms().items():
+            ms[k] += v / reps
+    gbs = 2.0 * tl / (ms["render"] * 1e-3) / 1e9
+    return {"config": "kit driver (labels, left side only, full header)", "records": ns, "labels": nsp, "text_bytes": tl,
+            "ms_plan_sort": ms["plan_sort"], "ms_render": ms["render"], "render_gb_per_s": gbs, "render_frac_of_hbm_peak": gbs / HBM_PEAK_GBS,
+            "reads_trimmed": int((d_st == 1).sum().item()), "reads_failed": int((d_st == 2).sum().item())}
 
 
 def load_traffic(args, batch, L, dom):

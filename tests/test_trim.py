@@ -321,3 +321,51 @@ def test_gpu_trim_capacity_and_errors():
     annos = [anno(0, i, i + 1, 0, "F1", 0, [(i, "After"), (i, "Before"), (100 + i, "After")], 64) for i in range(11)]
     with pytest.raises(A.BarbellError):
         run([(b"A" * 64, b"I" * 64)], annos, T.TrimConfig(), engine=_gpu_engine(dm, T.TrimConfig()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("gz", [False, True])
+def test_fused_annotate_filter_trim_files(tmp_path, gz):
+    """`barbell kit`-style run in one pass (use_kit.rs:11-109): FASTQ -> annotation.tsv, filtered.tsv and the
+    per-label trimmed FASTQ files.  The files must equal what the oracle produces for the whole input as one
+    batch (label files are appended in read order, so batching does not show)."""
+    import gzip
+
+    from barbell_amd import annotate as A
+    from tests.common import config_groups
+
+    kit = "SQK-RBK114-24"
+    groups = config_groups("rbk24")
+    n = 1500
+    bases, offsets = A.synth_reads_host(groups, 99, 200, 2500, 0, n)
+    rng = np.random.default_rng(11)
+    quals = rng.integers(33, 90, size=len(bases), dtype=np.uint8)
+    hdr = [(b"read-%05d" % i) + (b" runid=ab12 ch=%d" % (i % 97) if i % 4 else b"") for i in range(n)]
+    fq = tmp_path / "reads.fastq"
+    with open(fq, "wb") as f:
+        for i in range(n):
+            a, b = int(offsets[i]), int(offsets[i + 1])
+            f.write(b"@" + hdr[i] + b"\n" + bases[a:b].tobytes() + b"\n+\n" + quals[a:b].tobytes() + b"\n")
+    out = tmp_path / "out"
+    cfg = T.TrimConfig.for_kit(failed_out=str(tmp_path / "failed.txt"), gzip=gz)
+    total, found = A.annotate([str(fq)], str(tmp_path / "a.tsv"), config_groups("rbk24"), filter_patterns=F.kit_patterns(kit, True),
+                              filtered_file=str(tmp_path / "k.tsv"), trim_folder=str(out), trim_config=cfg, batch_reads=400)
+    assert total == n
+    # expectation: oracle, one batch
+    o = po.Oracle([g.as_tuple() for g in groups])
+    rows = o.annotate(bases, offsets, n_threads=os.cpu_count() or 1)
+    ver = o.filter_rows(F.kit_patterns(kit, True), groups, rows)
+    want = o.trim_batch(groups, cfg, rows, ver, bases, quals, offsets, hdr)
+    tb = T.LabelTables(groups, cfg)
+    exp = {}
+    for sp in want.spans:
+        exp[tb.label_of_key(int(sp["label_key"]), cfg)] = want.text[int(sp["off"]): int(sp["off"] + sp["len"])].tobytes()
+    ext = ".trimmed.fastq.gz" if gz else ".trimmed.fastq"
+    got = {}
+    for fn in os.listdir(out):
+        assert fn.endswith(ext)
+        data = open(out / fn, "rb").read()
+        got[fn[: -len(ext)]] = gzip.decompress(data) if gz else data
+    assert len(exp) > 10 and got == exp
+    failed = [hdr[i].split()[0].decode() for i in np.nonzero(want.status == T.TRIM_FAILED)[0]]
+    assert open(tmp_path / "failed.txt").read().split() == failed
