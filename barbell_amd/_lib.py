@@ -16,6 +16,7 @@ EXPORTS = [
     "bb_n_kernels", "bb_kernel_name", "bb_last_kernel_ms", "bb_set_timing", "bb_strerror", "bb_last_error",
     "bb_synth_offsets", "bb_synth_reads_host", "bb_synth_reads_dev",
     "bb_filter_set", "bb_filter_rows", "bb_filter_rows_dev",
+    "bb_inspect_rows", "bb_inspect_rows_dev",
     "bb_trim_set", "bb_trim_batch", "bb_trim_batch_dev", "bb_trim_last_ms",
 ]
 
@@ -74,6 +75,8 @@ def lib():
     L.bb_filter_set.argtypes = [vp, vp, u32, vp]
     L.bb_filter_rows.argtypes = [vp, vp, u64, vp]
     L.bb_filter_rows_dev.argtypes = [vp, vp, u64, vp]
+    L.bb_inspect_rows.argtypes = [vp, vp, vp, u64, u32, vp]
+    L.bb_inspect_rows_dev.argtypes = [vp, vp, vp, u64, u32, vp]
     L.bb_trim_set.argtypes = [vp, vp, vp, vp, u32]
     trim_args = [vp, vp, vp, u64, vp, vp, vp, vp, u32, vp, u64, vp, vp, u64, vp, vp, u32, vp, vp]
     L.bb_trim_batch.argtypes = trim_args

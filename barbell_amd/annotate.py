@@ -221,7 +221,7 @@ def read_fastq(path):
 
 def annotate(read_files, out_file, query_groups, alpha=0.4, min_score=0.2, min_score_diff=0.1, max_flank_errors=None,
              batch_reads=65536, device=0, filter_patterns=None, filtered_file=None, dropped_file=None, trim_folder=None,
-             trim_config=None):
+             trim_config=None, inspector=None):
     """annotate_with_groups + annotate (annotator.rs:207-285): sets the flank threshold of each group
     (explicit --flank-max-errors or the automatic cutoff), streams the FASTQ in batches through the
     GPU and writes annotation.tsv.  With `filter_patterns` the filter step (filter.rs:10-119) runs on
@@ -229,7 +229,9 @@ def annotate(read_files, out_file, query_groups, alpha=0.4, min_score=0.2, min_s
     of passing / failing reads with their `cuts` column — what `barbell filter` would write from the
     annotation file.  With `trim_folder` (needs the filter) the trim step (trim.rs:317-480) runs on the same
     batch as well: the GPU cuts the passing reads and renders the FASTQ records grouped by output label, the
-    host appends each group to '{trim_folder}/{label}.trimmed.fastq[.gz]'.  Returns (total_reads, reads_with_rows)."""
+    host appends each group to '{trim_folder}/{label}.trimmed.fastq[.gz]'.  `inspector(dm)` may build an
+    inspect_rows.Inspector that is fed the rows of every batch (inspect.rs:119-208 without re-reading the TSV).
+    Returns (total_reads, reads_with_rows)."""
     for g in query_groups:
         if max_flank_errors is not None:
             g.set_flank_threshold(max_flank_errors)
@@ -250,6 +252,7 @@ def annotate(read_files, out_file, query_groups, alpha=0.4, min_score=0.2, min_s
         trim_config = trim_config or TrimConfig()
         trimmer = Trimmer(dm, trim_config)
         writers = LabelWriters(trim_folder, trim_config, trimmer.tables)
+    insp = inspector(dm) if inspector is not None else None
     total = found = 0
     outs = {"anno": open(out_file, "w"),
             "kept": open(filtered_file, "w") if (flt and filtered_file) else None,
@@ -276,6 +279,8 @@ def annotate(read_files, out_file, query_groups, alpha=0.4, min_score=0.2, min_s
         total += len(ids)
         found += len(np.unique(rows["read_idx"]))
         emit("anno", format_rows(rows, ids, query_groups))
+        if insp is not None:
+            insp.add(rows, ids)
         if flt is not None:
             v = flt.verdicts(rows)
             keep = v["pass"] == 1
@@ -308,6 +313,8 @@ def annotate(read_files, out_file, query_groups, alpha=0.4, min_score=0.2, min_s
                 f.close()
         if writers is not None:
             writers.close()
+        if insp is not None:
+            insp.close()
     dm.close()
     return total, found
 

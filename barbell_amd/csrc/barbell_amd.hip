@@ -16,6 +16,7 @@
 
 #include "../../include/barbell_amd.h"
 #include "../../include/barbell_amd_filter.h"
+#include "../../include/barbell_amd_inspect.h"
 #include "../../include/barbell_amd_synth.h"
 #include "bb_common.h"
 #include "bb_ctx_view.h"
@@ -149,6 +150,7 @@ struct bb_ctx {
     uint32_t n_fpats = 0;
     bb_row* d_frows = nullptr; uint64_t cap_frows = 0;
     bb_row_verdict* d_fout = nullptr; uint64_t cap_fout = 0;
+    bb_inspect_elem* d_iout = nullptr; uint64_t cap_iout = 0;
     // trim step, owned by bb_trim.hip
     bb_trim_state* trim = nullptr;
     // synth
@@ -454,7 +456,7 @@ void bb_destroy(bb_ctx* c) {
     (void)hipSetDevice(c->device);
     void* ptrs[] = {c->d_groups, c->d_tables, c->d_counts, c->d_cnt, c->d_base, c->d_sums, c->d_nrows, c->d_rowoff, c->d_hitcount,
                     c->d_lists, c->d_listcnt, c->d_raw, c->d_hits, c->d_rows, c->d_in_bases, c->d_in_offsets, c->d_out_rows,
-                    c->d_synth_table, c->d_fpats, c->d_felems, c->d_flabel_ok, c->d_flabel_ids, c->d_frows, c->d_fout};
+                    c->d_synth_table, c->d_fpats, c->d_felems, c->d_flabel_ok, c->d_flabel_ids, c->d_frows, c->d_fout, c->d_iout};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     bb_trim_state_free(c->trim);
@@ -784,6 +786,33 @@ int bb_filter_rows(bb_ctx* c, const bb_row* rows, uint64_t n_rows, bb_row_verdic
     HIPCHK(c, hipMemcpy(c->d_frows, rows, n_rows * sizeof(bb_row), hipMemcpyHostToDevice));
     if ((r = bb_filter_rows_dev(c, c->d_frows, n_rows, c->d_fout))) return r;
     HIPCHK(c, hipMemcpy(out, c->d_fout, n_rows * sizeof(bb_row_verdict), hipMemcpyDeviceToHost));
+    return BB_OK;
+}
+
+// ---- inspect step (include/barbell_amd_inspect.h) ------------------------------------------------
+int bb_inspect_rows_dev(bb_ctx* c, const bb_row* d_rows, const bb_row_verdict* d_ver, uint64_t n_rows, uint32_t bucket_size,
+                        bb_inspect_elem* d_out) {
+    if (!c || (!d_rows && n_rows) || (!d_out && n_rows) || bucket_size == 0) return BB_E_INVALID;
+    if (n_rows == 0) return BB_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipLaunchKernelGGL(k_inspect, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, c->stream, d_rows, d_ver, n_rows, bucket_size, d_out);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return BB_OK;
+}
+
+int bb_inspect_rows(bb_ctx* c, const bb_row* rows, const bb_row_verdict* ver, uint64_t n_rows, uint32_t bucket_size, bb_inspect_elem* out) {
+    if (!c || (!rows && n_rows) || (!out && n_rows) || bucket_size == 0) return BB_E_INVALID;
+    if (n_rows == 0) return BB_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    int r;
+    if ((r = grow(c, c->d_frows, c->cap_frows, n_rows))) return r;
+    if ((r = grow(c, c->d_fout, c->cap_fout, n_rows))) return r;
+    if ((r = grow(c, c->d_iout, c->cap_iout, n_rows))) return r;
+    HIPCHK(c, hipMemcpy(c->d_frows, rows, n_rows * sizeof(bb_row), hipMemcpyHostToDevice));
+    if (ver) HIPCHK(c, hipMemcpy(c->d_fout, ver, n_rows * sizeof(bb_row_verdict), hipMemcpyHostToDevice));
+    if ((r = bb_inspect_rows_dev(c, c->d_frows, ver ? c->d_fout : nullptr, n_rows, bucket_size, c->d_iout))) return r;
+    HIPCHK(c, hipMemcpy(out, c->d_iout, n_rows * sizeof(bb_inspect_elem), hipMemcpyDeviceToHost));
     return BB_OK;
 }
 

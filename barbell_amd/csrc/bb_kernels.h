@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 
 #include "../../include/barbell_amd_filter.h"
+#include "../../include/barbell_amd_inspect.h"
 #include "bb_common.h"
 #include "bb_synth.h"
 
@@ -1331,4 +1332,28 @@ __global__ __launch_bounds__(256) void k_filter(const bb_row* __restrict__ rows,
         }
         out[t + r] = v;
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_inspect — SURVEY §8(f-4): get_group_structure (inspect.rs:15-117), one lane per row.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t bb_bucket(uint32_t pos, uint32_t bs) { return ((pos ? pos - 1u : 0u) / bs) * bs; }
+__global__ __launch_bounds__(256) void k_inspect(const bb_row* __restrict__ rows, const bb_row_verdict* __restrict__ ver, uint64_t n_rows,
+                                                 uint32_t bs, bb_inspect_elem* __restrict__ out) {
+    const uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (t >= n_rows) return;
+    const bb_row a = rows[t];
+    const bool first = t == 0 || rows[t - 1].read_idx != a.read_idx;
+    const uint32_t start = a.read_start_bar, end = a.read_end_bar, len = a.read_len;
+    const uint32_t d_right = len > end ? len - end : 0u, d_right_s = len > start ? len - start : 0u;
+    bb_inspect_elem e;
+    e.match_type = a.match_type; e.strand = a.strand; e.has_cut = ver ? (ver[t].n_cuts > 0) : 0; e.first = first;
+    bool right = !first ? false : !(a.rel_dist_to_end > 0);
+    if (!first) {
+        const uint32_t pe = rows[t - 1].read_end_bar, d_prev = start > pe ? start - pe : 0u;
+        if (d_prev <= d_right) { e.tag = BB_REL_PREV_LEFT; e.lo = bb_bucket(d_prev, bs); e.hi = e.lo + bs; }
+        else right = true;
+    } else if (!right) { e.tag = BB_REL_LEFT; e.lo = bb_bucket(start, bs); e.hi = e.lo + bs; }
+    if (right) { e.tag = BB_REL_RIGHT; e.lo = bb_bucket(d_right, bs); e.hi = bb_bucket(d_right_s, bs) + bs; }
+    out[t] = e;
 }

@@ -941,3 +941,31 @@ int bbo_trim_batch(const bbo_ctx* c, const bb_trim_config* cfg, const uint8_t* l
     free(recs);
     return BB_OK;
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* inspect step: get_group_structure inspect.rs:9-117 per row                   */
+/* ------------------------------------------------------------------------------------------ */
+static uint32_t bucket_position(uint32_t pos, uint32_t bs) { return ((pos ? pos - 1 : 0) / bs) * bs; }   /* inspect.rs:9-13 */
+static uint32_t sat_sub(uint32_t a, uint32_t b) { return a > b ? a - b : 0; }
+int bbo_inspect_rows(const bb_row* rows, const bb_row_verdict* verdicts, uint64_t n_rows, uint32_t bs, bb_inspect_elem* out) {
+    if ((!rows && n_rows) || (!out && n_rows) || bs == 0) return BB_E_INVALID;
+    for (uint64_t i = 0; i < n_rows; ++i) {
+        const bb_row* a = &rows[i];
+        const int first = i == 0 || rows[i - 1].read_idx != a->read_idx;
+        bb_inspect_elem* e = &out[i];
+        memset(e, 0, sizeof(*e));
+        const uint32_t start = a->read_start_bar, end = a->read_end_bar, len = a->read_len;
+        if (!first) {                                                       /* :41-58 */
+            const uint32_t d_prev = sat_sub(start, rows[i - 1].read_end_bar), d_right = sat_sub(len, end);
+            if (d_prev <= d_right) { e->tag = BB_REL_PREV_LEFT; e->lo = bucket_position(d_prev, bs); e->hi = e->lo + bs; }
+            else { e->tag = BB_REL_RIGHT; e->lo = bucket_position(sat_sub(len, end), bs); e->hi = bucket_position(sat_sub(len, start), bs) + bs; }
+        } else if (a->rel_dist_to_end > 0) {                               /* :59-63 */
+            e->tag = BB_REL_LEFT; e->lo = bucket_position(start, bs); e->hi = e->lo + bs;
+        } else {                                                            /* :64-70 */
+            e->tag = BB_REL_RIGHT; e->lo = bucket_position(sat_sub(len, end), bs); e->hi = bucket_position(sat_sub(len, start), bs) + bs;
+        }
+        e->has_cut = verdicts && verdicts[i].n_cuts > 0;                    /* :72-85 */
+        e->match_type = a->match_type; e->strand = a->strand; e->first = (uint32_t)first;
+    }
+    return BB_OK;
+}

@@ -14,6 +14,7 @@
 #include "../include/barbell_amd.h"
 #include "../include/barbell_amd_filter.h"
 #include "../include/barbell_amd_trim.h"
+#include "../include/barbell_amd_inspect.h"
 
 #ifdef __cplusplus
 extern "C" {
@@ -85,6 +86,8 @@ int  bbo_trim_batch(const bbo_ctx* ctx, const bb_trim_config* cfg, const uint8_t
                     const uint8_t* bases, const uint8_t* quals, const uint64_t* offsets, const bb_headers* headers, uint32_t n_reads,
                     uint8_t* text, uint64_t text_cap, uint64_t* text_len, bb_slice* slices, uint64_t slices_cap, uint64_t* n_slices,
                     bb_label_span* spans, uint32_t spans_cap, uint32_t* n_spans, uint8_t* read_status);
+/* inspect step: get_group_structure (inspect.rs:15-117) per row */
+int  bbo_inspect_rows(const bb_row* rows, const bb_row_verdict* verdicts, uint64_t n_rows, uint32_t bucket_size, bb_inspect_elem* out);
 /* test hook: 1 = trace flank matches on the full DP matrix instead of the (m+k)-column window */
 void bbo_set_full_trace(int on);
 

@@ -69,6 +69,7 @@ def lib():
         L.bbo_filter_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
         L.bbo_trim_batch.argtypes = [C.c_void_p] * 7 + [C.c_uint64] + [C.c_void_p] * 4 + [C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p,
                                      C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+        L.bbo_inspect_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p]
         _lib = L
     return _lib
 
@@ -131,6 +132,18 @@ def collapse(rows, overlap=0.8):
     rows = np.ascontiguousarray(rows, dtype=_abi.ROW_DTYPE).copy()
     n = lib().bbo_collapse(rows.ctypes.data, len(rows), overlap)
     return rows[:n]
+
+
+def inspect_rows(rows, verdicts=None, bucket_size=250):
+    """get_group_structure per row (inspect.rs:15-117) -> INSPECT_DTYPE array"""
+    from barbell_amd import inspect_rows as I
+
+    rows = np.ascontiguousarray(rows, dtype=_abi.ROW_DTYPE)
+    out = np.zeros(len(rows), dtype=I.INSPECT_DTYPE)
+    v = None if verdicts is None else np.ascontiguousarray(verdicts)
+    rc = lib().bbo_inspect_rows(rows.ctypes.data, None if v is None else v.ctypes.data, len(rows), bucket_size, out.ctypes.data)
+    assert rc == 0, rc
+    return out
 
 
 class Oracle:
