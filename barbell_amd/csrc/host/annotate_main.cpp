@@ -1,7 +1,9 @@
 // barbell-amd — command-line driver of the MI355X annotate path.  Mirrors the flags and defaults of
 // the reference's `barbell annotate` (bin/main.rs:64-112).  The filter step (`barbell filter`,
 // bin/main.rs:114-135) is available fused into annotate: --filter-file / --kit-filter [--maximize] with
-// --filtered / --dropped outputs.  trim / inspect are out of scope.
+// --filtered / --dropped outputs, and so are trim (`barbell trim`, bin/main.rs:136-186: --trim-output DIR plus
+// its label flags) and inspect (--inspect / --read-pattern-out).  `barbell-amd kit` is `barbell kit`
+// (bin/main.rs:208-262, use_kit.rs:11-109) in one pass over the reads.
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -19,6 +21,11 @@ static void usage() {
         "                            [--alpha F=0.4] [--use-extended] [-t THREADS=10] [--verbose]\n"
         "                            [--batch-reads N=65536] [--device D=0]\n"
         "                            [(-f <PATTERN_FILE>... | --kit-filter [--maximize]) [--filtered FILE] [--dropped FILE]]\n"
+        "                            [--trim-output DIR [--no-label] [--no-orientation] [--no-flanks] [--sort-labels]\n"
+        "                             [--only-side left|right] [--failed-out FILE] [--skip-trim] [--flip] [--gzip]]\n"
+        "                            [--inspect [-n TOP=10] [--read-pattern-out FILE] [-s BUCKET=250]]\n"
+        "       barbell-amd kit -k <KIT> -i <FASTQ>... -o <OUT_DIR> [--maximize] [--min-score F] [--min-score-diff F]\n"
+        "                       [--flank-max-errors INT] [--failed-out FILE] [--use-extended] [--alpha F] [--gzip] [-t N]\n"
         "       barbell-amd kits          list the supported kit names\n"
         "       barbell-amd pattern <STR>...   parse filter pattern strings and print their elements\n",
         stderr);
@@ -47,9 +54,48 @@ int main(int argc, char** argv) {
         return 0;
     }
     if (cmd == "-h" || cmd == "--help") { usage(); return 0; }
+    if (cmd == "kit") {
+        KitConfig k;
+        std::vector<std::string> input;
+        bool multi_in = false;
+        for (int i = 2; i < argc; ++i) {
+            const std::string a = argv[i];
+            auto need = [&](const char* what) -> const char* { if (i + 1 >= argc) { fprintf(stderr, "error: %s needs a value\n", what); exit(2); } multi_in = false; return argv[++i]; };
+            if (a == "-i" || a == "--input") multi_in = true;
+            else if (a == "-k" || a == "--kit") k.kit_name = need("--kit");
+            else if (a == "-o" || a == "--output") k.output_folder = need("--output");
+            else if (a == "-t" || a == "--threads") k.threads = (size_t)atol(need("--threads"));
+            else if (a == "--min-score") k.min_score = atof(need("--min-score"));
+            else if (a == "--min-score-diff") k.min_score_diff = atof(need("--min-score-diff"));
+            else if (a == "--flank-max-errors") k.max_flank_errors = (size_t)atol(need("--flank-max-errors"));
+            else if (a == "--failed-out") k.failed_out = std::string(need("--failed-out"));
+            else if (a == "--alpha") k.alpha = (float)atof(need("--alpha"));
+            else if (a == "--batch-reads") k.batch_reads = (size_t)atol(need("--batch-reads"));
+            else if (a == "--device") k.device = atoi(need("--device"));
+            else if (a == "--maximize") { k.maximize = true; multi_in = false; }
+            else if (a == "--verbose") { k.verbose = true; multi_in = false; }
+            else if (a == "--use-extended") { k.use_extended = true; multi_in = false; }
+            else if (a == "--gzip") { k.gzip = true; multi_in = false; }
+            else if (!a.empty() && a[0] != '-' && multi_in) input.push_back(a);
+            else { fprintf(stderr, "error: unexpected argument '%s'\n", a.c_str()); usage(); return 2; }
+        }
+        if (k.kit_name.empty() || k.output_folder.empty()) { fputs("error: kit needs --kit and --output\n", stderr); return 2; }
+        if (input.empty()) { fputs("error: No FASTQ input files provided\n", stderr); return 2; }
+        try {
+            printf("Kit name: %s\nKit type: %s\n", k.kit_name.c_str(), k.maximize ? "Maximize" : "Safe");
+            const AnnotateStats st = demux_using_kit(input, k);
+            puts("Top 10 most common patterns");
+            for (const auto& l : inspect_summary(st, 10)) puts(l.c_str());
+            printf("Annotated %zu of %zu reads; filter kept %zu, dropped %zu; trimmed %zu (%zu split, %zu failed)\nDone!\n", st.found, st.total,
+                   st.kept, st.dropped, st.trimmed, st.trimmed_split, st.trim_failed);
+        } catch (const BarbellError& e) { fprintf(stderr, "error: %s\n", e.what()); return 1; }
+        return 0;
+    }
     if (cmd != "annotate") { usage(); return 2; }
     std::vector<std::string> input, queries, btypes, pattern_files;
     bool kit_filter = false, maximize = false;
+    TrimConfig tcfg;
+    size_t top_n = 10;
     std::string output = "output.tsv", kit;
     AnnotateConfig cfg;
     std::vector<std::string>* multi = nullptr;
@@ -72,6 +118,25 @@ int main(int argc, char** argv) {
         else if (a == "--filtered") { cfg.filtered_file = need("--filtered"); multi = nullptr; }
         else if (a == "--dropped") { cfg.dropped_file = need("--dropped"); multi = nullptr; }
         else if (a == "--kit-filter") { kit_filter = true; multi = nullptr; }
+        else if (a == "--trim-output") { cfg.trim_folder = need("--trim-output"); multi = nullptr; }
+        else if (a == "--no-label") { tcfg.add_labels = false; multi = nullptr; }
+        else if (a == "--no-orientation") { tcfg.add_orientation = false; multi = nullptr; }
+        else if (a == "--no-flanks") { tcfg.add_flank = false; multi = nullptr; }
+        else if (a == "--sort-labels") { tcfg.sort_labels = true; multi = nullptr; }
+        else if (a == "--only-side") {
+            const std::string v = need("--only-side"); multi = nullptr;
+            if (v == "left") tcfg.only_side = LabelSide::Left;
+            else if (v == "right") tcfg.only_side = LabelSide::Right;
+            else { fprintf(stderr, "error: --only-side takes left or right\n"); return 2; }
+        }
+        else if (a == "--failed-out") { tcfg.failed_trimmed_writer = std::string(need("--failed-out")); multi = nullptr; }
+        else if (a == "--skip-trim") { tcfg.skip_trim = true; multi = nullptr; }
+        else if (a == "--flip") { tcfg.flip = true; multi = nullptr; }
+        else if (a == "--gzip") { tcfg.gzip = true; multi = nullptr; }
+        else if (a == "--inspect") { cfg.inspect = true; multi = nullptr; }
+        else if (a == "--read-pattern-out") { cfg.read_pattern_out = need("--read-pattern-out"); cfg.inspect = true; multi = nullptr; }
+        else if (a == "-n" || a == "--top-n") { top_n = (size_t)atol(need("--top-n")); multi = nullptr; }
+        else if (a == "-s" || a == "--bucket-size") { cfg.bucket_size = (uint32_t)atol(need("--bucket-size")); multi = nullptr; }
         else if (a == "--maximize") { maximize = true; multi = nullptr; }
         else if (a == "--use-extended") { cfg.use_extended = true; multi = nullptr; }
         else if (a == "--verbose") { cfg.verbose = true; multi = nullptr; }
@@ -82,6 +147,12 @@ int main(int argc, char** argv) {
     if (input.empty()) { fputs("error: No FASTQ input files provided\n", stderr); return 2; }
     if (kit.empty() == queries.empty()) { fputs("error: give either --kit or --queries (they conflict, bin/main.rs:85-87)\n", stderr); return 2; }
     if (kit_filter && kit.empty()) { fputs("error: --kit-filter needs --kit\n", stderr); return 2; }
+    if (!cfg.trim_folder.empty()) {
+        if (tcfg.sort_labels && tcfg.only_side) { fputs("error: --only-side conflicts with --sort-labels (bin/main.rs:160-161)\n", stderr); return 2; }
+        if (!kit_filter && pattern_files.empty()) { fputs("error: --trim-output needs filter patterns (-f or --kit-filter)\n", stderr); return 2; }
+        cfg.trim = tcfg;
+    }
+    if (cfg.bucket_size == 0) { fputs("error: --bucket-size must be positive\n", stderr); return 2; }
     if (kit_filter && !pattern_files.empty()) { fputs("error: give either --filter-file or --kit-filter\n", stderr); return 2; }
     try {
         if (!pattern_files.empty()) cfg.filter_patterns = patterns_from_files(pattern_files);
@@ -101,6 +172,8 @@ int main(int argc, char** argv) {
         }
         fprintf(stderr, "Done: %zu records, %zu with annotations, %zu rows -> %s\n", st.total, st.found, st.rows, output.c_str());
         if (!cfg.filter_patterns.empty()) fprintf(stderr, "Filter: %zu kept, %zu dropped\n", st.kept, st.dropped);
+        if (cfg.trim) fprintf(stderr, "Trim: %zu trimmed, %zu split, %zu failed\n", st.trimmed, st.trimmed_split, st.trim_failed);
+        if (cfg.inspect) for (const auto& l : inspect_summary(st, top_n)) puts(l.c_str());
     } catch (const BarbellError& e) {
         fprintf(stderr, "error: %s\n", e.what());  // the reference prints the anyhow error and exits non-zero (bin/main.rs:301-304)
         return 1;

@@ -9,6 +9,11 @@
 #include <cstdio>
 #include <cstring>
 #include <fstream>
+#include <map>
+#include <memory>
+
+#include <sys/stat.h>
+#include <cerrno>
 
 #include "kits_data.inc"
 
@@ -362,7 +367,12 @@ void Demuxer::set_filter(const std::vector<Pattern>& patterns) {
     std::vector<std::string> slot;
     for (const auto& g : queries_) { slot.insert(slot.end(), g.labels.begin(), g.labels.end()); slot.push_back("flank"); }
     std::vector<uint32_t> ids(slot.size());
-    for (size_t i = 0; i < slot.size(); ++i) ids[i] = (uint32_t)(std::find(slot.begin(), slot.end(), slot[i]) - slot.begin());
+    label_strings_.clear();
+    for (size_t i = 0; i < slot.size(); ++i) {  // dense ids in first-appearance order; equal strings share an id
+        const auto it = std::find(label_strings_.begin(), label_strings_.end(), slot[i]);
+        ids[i] = (uint32_t)(it - label_strings_.begin());
+        if (it == label_strings_.end()) label_strings_.push_back(slot[i]);
+    }
     std::vector<std::vector<bb_pattern_elem>> elems(patterns.size());
     std::vector<std::vector<uint8_t>> oks;
     size_t n_lab = 0;
@@ -403,6 +413,115 @@ std::vector<bb_row_verdict> Demuxer::filter_last_batch() {
     return v;
 }
 
+// ---- trim (trim.rs) -------------------------------------------------------------------------------
+TrimConfig TrimConfig::for_kit(std::optional<std::string> failed_out, bool gzip) {
+    TrimConfig c;
+    c.add_labels = true; c.add_orientation = false; c.add_flank = false; c.sort_labels = false; c.only_side = LabelSide::Left;
+    c.failed_trimmed_writer = std::move(failed_out); c.write_full_header = true; c.skip_trim = false; c.flip = false; c.gzip = gzip;
+    return c;
+}
+
+void FastqBatch::clear() {
+    ids.clear(); bases.clear(); quals.clear(); hdr.clear(); id_len.clear(); desc_start.clear();
+    offsets.assign(1, 0); hdr_offsets.assign(1, 0);
+}
+
+std::string Demuxer::part_str(uint32_t part) const {  // trim.rs:70-80
+    std::string r = label_strings_.at(part >> 1);
+    if (trim_cfg_.add_orientation) r += (part & 1) ? "_rc" : "_fw";
+    return r;
+}
+
+std::string Demuxer::label_of_key(uint32_t key) const {  // trim.rs:88-104 on a bb_slice.label_key
+    if (key == 0) return "none";
+    std::string r = part_str((key >> 16) - 1);
+    if (key & 0xFFFF) r += "__" + part_str((key & 0xFFFF) - 1);
+    return r;
+}
+
+void Demuxer::set_trim(const TrimConfig& cfg) {
+    if (!has_filter_) throw BarbellError(BB_E_INVALID, "set_trim needs set_filter first (cuts and label ids come from the filter)");
+    if (cfg.sort_labels && cfg.only_side)  // trim.rs:330-334
+        throw BarbellError(BB_E_INVALID, "Cannot enable only keeping left/right label and sorting; this is ambiguous");
+    trim_cfg_ = cfg;
+    const size_t n = label_strings_.size();
+    std::vector<uint8_t> is_flank(n);
+    for (size_t i = 0; i < n; ++i) is_flank[i] = label_strings_[i].find("flank") != std::string::npos;  // trim.rs:66
+    std::vector<std::string> parts(2 * n);
+    for (size_t i = 0; i < 2 * n; ++i) parts[i] = part_str((uint32_t)i);
+    std::vector<std::string> sorted(parts);
+    std::sort(sorted.begin(), sorted.end());
+    sorted.erase(std::unique(sorted.begin(), sorted.end()), sorted.end());
+    std::vector<uint32_t> rank(2 * n);
+    for (size_t i = 0; i < 2 * n; ++i) rank[i] = (uint32_t)(std::lower_bound(sorted.begin(), sorted.end(), parts[i]) - sorted.begin());
+    bb_trim_config c{};
+    c.add_labels = cfg.add_labels; c.add_orientation = cfg.add_orientation; c.add_flank = cfg.add_flank; c.sort_labels = cfg.sort_labels;
+    c.only_side = !cfg.only_side ? BB_SIDE_NONE : (*cfg.only_side == LabelSide::Left ? BB_SIDE_LEFT : BB_SIDE_RIGHT);
+    c.write_full_header = cfg.write_full_header; c.skip_trim = cfg.skip_trim; c.flip = cfg.flip;
+    const int rc = bb_trim_set(ctx_, &c, is_flank.data(), rank.data(), (uint32_t)n);
+    if (rc != BB_OK) throw BarbellError(rc, std::string("bb_trim_set: ") + bb_strerror(rc) + " " + bb_last_error(ctx_));
+    has_trim_ = true;
+}
+
+TrimBatch Demuxer::trim_last_batch(const std::vector<bb_row_verdict>& verdicts, const FastqBatch& b) {
+    if (!has_trim_) throw BarbellError(BB_E_INVALID, "trim_last_batch without set_trim");
+    if (verdicts.size() != n_rows_) throw BarbellError(BB_E_INVALID, "verdicts do not belong to the last batch");
+    const uint32_t n = (uint32_t)b.ids.size();
+    TrimBatch t;
+    t.status.assign(n, 0);
+    t.text.resize(2 * b.bases.size() + b.hdr.size() + 16 * (size_t)n + 1024);
+    t.slices.resize(2 * (size_t)n + 64);
+    t.spans.resize(4096);
+    const bb_headers h{b.hdr.data(), b.hdr_offsets.data(), b.id_len.data(), b.desc_start.data()};
+    for (;;) {
+        uint64_t tl = 0, ns = 0;
+        uint32_t nsp = 0;
+        const int rc = bb_trim_batch(ctx_, rows_.data(), verdicts.data(), n_rows_, b.bases.data(), b.quals.data(), b.offsets.data(), &h, n,
+                                     t.text.data(), t.text.size(), &tl, t.slices.data(), t.slices.size(), &ns, t.spans.data(),
+                                     (uint32_t)t.spans.size(), &nsp, t.status.data());
+        if (rc == BB_E_CAPACITY) {
+            if (tl > t.text.size()) t.text.resize(tl);
+            if (ns > t.slices.size()) t.slices.resize(ns);
+            if (nsp > t.spans.size()) t.spans.resize(nsp);
+            continue;
+        }
+        if (rc != BB_OK) throw BarbellError(rc, std::string("bb_trim_batch: ") + bb_strerror(rc) + " " + bb_last_error(ctx_));
+        t.text.resize(tl); t.slices.resize(ns); t.spans.resize(nsp);
+        return t;
+    }
+}
+
+// ---- inspect (inspect.rs) -------------------------------------------------------------------------
+std::vector<std::pair<uint32_t, std::string>> Demuxer::inspect_last_batch(const std::vector<bb_row_verdict>* verdicts, uint32_t bucket_size) {
+    ensure_ctx();
+    std::vector<bb_inspect_elem> el(n_rows_);
+    if (n_rows_) {
+        const int rc = bb_inspect_rows(ctx_, rows_.data(), verdicts ? verdicts->data() : nullptr, n_rows_, bucket_size, el.data());
+        if (rc != BB_OK) throw BarbellError(rc, std::string("bb_inspect_rows: ") + bb_strerror(rc) + " " + bb_last_error(ctx_));
+    }
+    static const char* const TAG[] = {"", "@left", "@right", "@prev_left"};
+    std::vector<std::pair<uint32_t, std::string>> out;
+    for (uint64_t i = 0; i < n_rows_; ++i) {  // "{type}[{fw|rc}, *{cut}, {tag}({lo}..{hi})]" joined by "__" (inspect.rs:90-104)
+        const bb_inspect_elem& e = el[i];
+        char buf[128];
+        snprintf(buf, sizeof buf, "%s[%s, *%s, %s(%u..%u)]", as_str((BarcodeType)e.match_type), e.strand ? "rc" : "fw",
+                 e.has_cut ? (e.strand ? ", >>" : ", <<") : "", TAG[e.tag & 3], e.lo, e.hi);
+        if (e.first) out.emplace_back(rows_[i].read_idx, buf);
+        else { out.back().second += "__"; out.back().second += buf; }
+    }
+    return out;
+}
+
+std::vector<std::string> inspect_summary(const AnnotateStats& st, size_t top_n) {
+    std::vector<std::string> lines{"Found " + std::to_string(st.patterns.size()) + " unique patterns"};
+    for (size_t i = 0; i < st.patterns.size() && i < top_n; ++i) {
+        lines.push_back("\tPattern " + std::to_string(i + 1) + ": " + std::to_string(st.patterns[i].second) + " occurrences");
+        lines.push_back("\t\t" + st.patterns[i].first);
+    }
+    lines.push_back("Showed " + std::to_string(top_n) + " / " + std::to_string(st.patterns.size()) + " patterns");
+    return lines;
+}
+
 // ---- annotate (annotator.rs) ----------------------------------------------------------------------
 namespace {
 // the automatic flank cutoff (edit_model.rs:2-11) is applied inside bb_create when k_cutoff is unset
@@ -426,14 +545,54 @@ struct FastqReader {  // plain or gzip (gzopen reads both), 4-line records; src/
         while (!out.empty() && (out.back() == '\n' || out.back() == '\r')) out.pop_back();
         return true;
     }
-    bool next(std::string& id, std::string& seq) {
-        std::string h, plus, qual;
+    // header = line without '@'; id_len / desc_start: split_fastq_header (io.rs:6-17; ASCII whitespace)
+    bool next(std::string& header, std::string& seq, std::string& qual, size_t& id_len, size_t& desc_start) {
+        std::string h, plus;
         do { if (!line(h)) return false; } while (h.empty());
         if (h[0] != '@') throw BarbellError(BB_E_INVALID, "Input FASTQ parsing failed: record does not start with '@'");
         if (!line(seq) || !line(plus) || !line(qual)) throw BarbellError(BB_E_INVALID, "Input FASTQ parsing failed: truncated record");
-        const size_t ws = h.find_first_of(" \t");  // split_fastq_header, io.rs:6-17
-        id = h.substr(1, ws == std::string::npos ? std::string::npos : ws - 1);
+        header = h.substr(1);
+        const size_t ws = header.find_first_of(" \t\n\v\f\r");
+        id_len = ws == std::string::npos ? header.size() : ws;
+        desc_start = id_len;
+        while (desc_start < header.size() && strchr(" \t\n\v\f\r", header[desc_start])) ++desc_start;
         return true;
+    }
+};
+
+struct LabelWriters {  // the per-label writers of trim_matches (trim.rs:356-446)
+    std::string folder;
+    bool gz;
+    std::map<std::string, gzFile> gzs;
+    std::map<std::string, FILE*> plain;
+    LabelWriters(std::string f, bool g) : folder(std::move(f)), gz(g) {}
+    void write(const std::string& label, const uint8_t* p, size_t n) {
+        const std::string path = folder + "/" + label + (gz ? ".trimmed.fastq.gz" : ".trimmed.fastq");
+        if (gz) {
+            auto it = gzs.find(label);
+            if (it == gzs.end()) {
+                gzFile f = gzopen(path.c_str(), "wb");
+                if (!f) throw BarbellError(BB_E_INVALID, "Failed to create output file '" + path + "'\nTry setting ulimit higher: \"ulimit -n 65000\"");
+                it = gzs.emplace(label, f).first;
+            }
+            for (size_t o = 0; o < n;) {
+                const unsigned chunk = (unsigned)std::min<size_t>(n - o, 1u << 30);
+                if (gzwrite(it->second, p + o, chunk) <= 0) throw BarbellError(BB_E_INVALID, "Failed to write sequence to '" + path + "'");
+                o += chunk;
+            }
+        } else {
+            auto it = plain.find(label);
+            if (it == plain.end()) {
+                FILE* f = fopen(path.c_str(), "wb");
+                if (!f) throw BarbellError(BB_E_INVALID, "Failed to create output file '" + path + "'\nTry setting ulimit higher: \"ulimit -n 65000\"");
+                it = plain.emplace(label, f).first;
+            }
+            if (n && fwrite(p, 1, n, it->second) != n) throw BarbellError(BB_E_INVALID, "Failed to write sequence to '" + path + "'");
+        }
+    }
+    ~LabelWriters() {
+        for (auto& kv : gzs) gzclose(kv.second);
+        for (auto& kv : plain) fclose(kv.second);
     }
 };
 }  // namespace
@@ -462,14 +621,37 @@ AnnotateStats annotate(const std::vector<std::string>& read_files, const std::st
     }
     bool kept_header = false, drop_header = false;
     AnnotateStats st;
-    std::vector<std::string> ids;
-    std::vector<uint8_t> bases;
-    std::vector<uint64_t> offsets{0};
+    const bool trimming = config.trim.has_value();
+    std::unique_ptr<LabelWriters> writers;
+    FILE* failed_f = nullptr;
+    if (trimming) {
+        if (!filtering) { fclose(out); throw BarbellError(BB_E_INVALID, "the trim step needs filter patterns (cuts come from the filter)"); }
+        dm.set_trim(*config.trim);
+        if (mkdir(config.trim_folder.c_str(), 0777) != 0 && errno != EEXIST) {
+            fclose(out);
+            throw BarbellError(BB_E_INVALID, "Failed to create output folder '" + config.trim_folder + "'");
+        }
+        writers = std::make_unique<LabelWriters>(config.trim_folder, config.trim->gzip);
+        if (config.trim->failed_trimmed_writer) failed_f = fopen(config.trim->failed_trimmed_writer->c_str(), "w");
+    }
+    FILE* ppr_f = nullptr;
+    if (config.inspect && !config.read_pattern_out.empty()) ppr_f = fopen(config.read_pattern_out.c_str(), "w");
+    std::map<std::string, size_t> pattern_count;
+    std::vector<std::string> pattern_order;  // first-appearance order, for a deterministic tie order in the summary
+    FastqBatch b;
     bool header = false;
+    auto close_all = [&]() {
+        fclose(out);
+        if (kept_f) fclose(kept_f);
+        if (drop_f) fclose(drop_f);
+        if (failed_f) fclose(failed_f);
+        if (ppr_f) fclose(ppr_f);
+        writers.reset();
+    };
     auto flush = [&]() {
-        if (ids.empty()) return;
-        auto rows = dm.demux_batch(ids, bases, offsets);
-        st.total += ids.size();
+        if (b.ids.empty()) return;
+        auto rows = dm.demux_batch(b.ids, b.bases, b.offsets);
+        st.total += b.ids.size();
         std::vector<bb_row_verdict> verdicts;
         if (filtering) verdicts = dm.filter_last_batch();
         const std::string* last = nullptr;
@@ -479,6 +661,14 @@ AnnotateStats annotate(const std::vector<std::string>& read_files, const std::st
             fputc('\n', out);
             if (!last || *last != r.read_id) ++st.found;
             last = &r.read_id;
+        }
+        if (config.inspect) {  // inspect.rs:128-184 on the annotation rows (no cuts yet)
+            for (auto& rp : dm.inspect_last_batch(nullptr, config.bucket_size)) {
+                if (ppr_f) fprintf(ppr_f, "%s\t%s\n", b.ids[rp.first].c_str(), rp.second.c_str());
+                auto it = pattern_count.find(rp.second);
+                if (it == pattern_count.end()) { pattern_count.emplace(rp.second, 1); pattern_order.push_back(rp.second); }
+                else ++it->second;
+            }
         }
         for (size_t i = 0; i < verdicts.size(); ++i) {  // filtered.tsv / dropped.tsv (filter.rs:87-119)
             const bb_row_verdict& v = verdicts[i];
@@ -497,30 +687,49 @@ AnnotateStats annotate(const std::vector<std::string>& read_files, const std::st
             fputs(rows[i].to_tsv().c_str(), f);
             fputc('\n', f);
         }
+        if (trimming) {  // trim.rs:385-460: the GPU cut and rendered the records, one write per label
+            const TrimBatch t = dm.trim_last_batch(verdicts, b);
+            for (const auto& sp : t.spans) writers->write(dm.label_of_key(sp.label_key), t.text.data() + sp.off, sp.len);
+            std::vector<uint32_t> per_read(b.ids.size(), 0);
+            for (const auto& sl : t.slices) ++per_read[sl.read_idx];
+            for (size_t i = 0; i < b.ids.size(); ++i) {
+                if (t.status[i] == BB_TRIM_TRIMMED) ++st.trimmed;
+                if (per_read[i] > 1) ++st.trimmed_split;
+                if (t.status[i] == BB_TRIM_FAILED) { ++st.trim_failed; if (failed_f) fprintf(failed_f, "%s\n", b.ids[i].c_str()); }
+            }
+        }
         st.rows += rows.size();
-        ids.clear(); bases.clear(); offsets.assign(1, 0);
+        b.clear();
     };
     try {
         for (const auto& path : read_files) {
             FastqReader rd(path);
-            std::string id, seq;
-            while (rd.next(id, seq)) {
-                ids.push_back(id);
-                bases.insert(bases.end(), seq.begin(), seq.end());
-                offsets.push_back(bases.size());
-                if (ids.size() >= config.batch_reads) flush();
+            std::string hd, seq, qual;
+            size_t idl, ds;
+            while (rd.next(hd, seq, qual, idl, ds)) {
+                b.ids.push_back(hd.substr(0, idl));
+                b.bases.insert(b.bases.end(), seq.begin(), seq.end());
+                b.offsets.push_back(b.bases.size());
+                if (trimming) {
+                    if (qual.size() != seq.size())
+                        throw BarbellError(BB_E_INVALID, "FASTQ record '" + b.ids.back() + "' has no matching quality scores");
+                    b.quals.insert(b.quals.end(), qual.begin(), qual.end());
+                    b.hdr.insert(b.hdr.end(), hd.begin(), hd.end());
+                    b.hdr_offsets.push_back(b.hdr.size());
+                    b.id_len.push_back((uint32_t)idl);
+                    b.desc_start.push_back((uint32_t)ds);
+                }
+                if (b.ids.size() >= config.batch_reads) flush();
             }
         }
         flush();
     } catch (...) {
-        fclose(out);
-        if (kept_f) fclose(kept_f);
-        if (drop_f) fclose(drop_f);
+        close_all();
         throw;
     }
-    fclose(out);
-    if (kept_f) fclose(kept_f);
-    if (drop_f) fclose(drop_f);
+    close_all();
+    for (const auto& p : pattern_order) st.patterns.emplace_back(p, pattern_count[p]);
+    std::stable_sort(st.patterns.begin(), st.patterns.end(), [](const auto& a, const auto& c) { return a.second > c.second; });
     return st;
 }
 
@@ -544,6 +753,22 @@ AnnotateStats annotate_with_files(const std::vector<std::string>& read_files, co
     std::vector<BarcodeGroup> groups;
     for (size_t i = 0; i < query_files.size(); ++i) groups.push_back(BarcodeGroup::new_from_fasta(query_files[i], query_types[i]));
     return annotate_with_groups(read_files, out_file, std::move(groups), config);
+}
+
+AnnotateStats demux_using_kit(const std::vector<std::string>& fastq_files, const KitConfig& k) {
+    if (mkdir(k.output_folder.c_str(), 0777) != 0 && errno != EEXIST)
+        throw BarbellError(BB_E_INVALID, "Failed to create output folder '" + k.output_folder + "'");
+    AnnotateConfig c;
+    c.max_flank_errors = k.max_flank_errors; c.alpha = k.alpha; c.n_threads = (unsigned)k.threads; c.verbose = k.verbose;
+    c.min_score = k.min_score; c.min_score_diff = k.min_score_diff; c.use_extended = k.use_extended;
+    c.batch_reads = k.batch_reads; c.device = k.device;
+    c.filter_patterns = kit_patterns(k.kit_name, k.maximize);
+    c.filtered_file = k.output_folder + "/filtered.tsv";
+    c.trim = TrimConfig::for_kit(k.failed_out, k.gzip);
+    c.trim_folder = k.output_folder;
+    c.inspect = true;
+    c.read_pattern_out = k.output_folder + "/pattern_per_read.tsv";
+    return annotate_with_kit(fastq_files, k.output_folder + "/annotation.tsv", k.kit_name, c);
 }
 
 }  // namespace barbell

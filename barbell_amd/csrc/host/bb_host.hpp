@@ -7,11 +7,15 @@
 //   kit presets                       src/kits/kits.rs:635-816, 1074-1103 (data in kits_data.inc)
 //   Cut / PatternElement / Pattern / pattern_from_str!   src/filter/pattern.rs:9-30, 69-95, 242-383
 //   filter pattern files, kit default patterns            src/filter/filter.rs:141-181, kits.rs:175-236
+//   TrimConfig / LabelSide / label + file naming          src/config.rs:19-32, src/trim/trim.rs:24-105, 317-480
+//   get_group_structure strings, inspect summary          src/inspect/inspect.rs:15-208
+//   demux_using_kit                                        src/kits/use_kit.rs:11-109
 // The per-read call `Demuxer::demux(read_id, read)` (searcher.rs:430) becomes `demux_batch`: one
 // bb_annotate_batch per batch.  All arithmetic of the path runs in the HIP kernels of
 // libbarbell_amd.so; nothing here computes alignments.
 #pragma once
 #include <cstdint>
+#include <map>
 #include <optional>
 #include <stdexcept>
 #include <string>
@@ -19,6 +23,8 @@
 
 #include "../../../include/barbell_amd.h"
 #include "../../../include/barbell_amd_filter.h"
+#include "../../../include/barbell_amd_inspect.h"
+#include "../../../include/barbell_amd_trim.h"
 
 namespace barbell {
 
@@ -66,6 +72,29 @@ Pattern pattern_from_str(const std::string& s);                                 
 std::vector<Pattern> patterns_from_files(const std::vector<std::string>& paths);   // filter.rs:137-181
 std::vector<Pattern> kit_patterns(const std::string& kit, bool maximize);         // kits.rs:175-236 (safe unless maximize)
 
+// ---- trim (src/trim/trim.rs, src/config.rs) -------------------------------------------------------
+enum class LabelSide { Left, Right };
+struct TrimConfig {  // config.rs:19-32, CLI defaults bin/main.rs:136-186
+    bool add_labels = true, add_orientation = true, add_flank = true, sort_labels = false;
+    std::optional<LabelSide> only_side;
+    std::optional<std::string> failed_trimmed_writer;
+    bool write_full_header = true, skip_trim = false, flip = false, verbose = false, gzip = false;
+    static TrimConfig for_kit(std::optional<std::string> failed_out, bool gzip);  // use_kit.rs:87-99
+};
+struct TrimBatch {  // what bb_trim_batch returns for one batch
+    std::vector<uint8_t> text;
+    std::vector<bb_slice> slices;
+    std::vector<bb_label_span> spans;
+    std::vector<uint8_t> status;  // BB_TRIM_* per read
+};
+struct FastqBatch {  // one batch of records as the C-ABI wants them
+    std::vector<std::string> ids;
+    std::vector<uint8_t> bases, quals, hdr;
+    std::vector<uint64_t> offsets{0}, hdr_offsets{0};
+    std::vector<uint32_t> id_len, desc_start;
+    void clear();
+};
+
 struct BarbellMatch {  // searcher.rs:31-64
     std::string read_id;
     size_t read_len;
@@ -93,6 +122,12 @@ public:
     // filter step on the rows of the LAST demux_batch (filter.rs:183-214 on the GPU): one verdict per row
     void set_filter(const std::vector<Pattern>& patterns);
     std::vector<bb_row_verdict> filter_last_batch();
+    // trim step (trim.rs:127-300 on the GPU) on the rows + verdicts of the LAST batch; needs set_filter
+    void set_trim(const TrimConfig& cfg);
+    TrimBatch trim_last_batch(const std::vector<bb_row_verdict>& verdicts, const FastqBatch& batch);
+    std::string label_of_key(uint32_t key) const;  // LabelConfig::create_label's string for a bb_slice.label_key
+    // inspect step (inspect.rs:15-117) on the rows of the LAST batch: one pattern string per read with rows
+    std::vector<std::pair<uint32_t, std::string>> inspect_last_batch(const std::vector<bb_row_verdict>* verdicts, uint32_t bucket_size);
     bb_group_info group_info(size_t g);
     const std::vector<BarcodeGroup>& queries() const { return queries_; }
 
@@ -106,7 +141,10 @@ private:
     bb_ctx* ctx_ = nullptr;
     std::vector<bb_row> rows_;
     uint64_t n_rows_ = 0;
-    bool has_filter_ = false;
+    bool has_filter_ = false, has_trim_ = false;
+    TrimConfig trim_cfg_;
+    std::vector<std::string> label_strings_;  // by label id (ids as handed to bb_filter_set)
+    std::string part_str(uint32_t part) const;
 };
 
 struct AnnotateConfig {  // config.rs:3-12 with the CLI defaults of bin/main.rs:64-112
@@ -122,8 +160,34 @@ struct AnnotateConfig {  // config.rs:3-12 with the CLI defaults of bin/main.rs:
     // filtered_file / dropped_file with their cuts column (what `barbell filter -o/--dropped` writes)
     std::vector<Pattern> filter_patterns;
     std::string filtered_file, dropped_file;
+    // fused trim step (needs the filter): per-label '{trim_folder}/{label}.trimmed.fastq[.gz]' (trim.rs:427-446)
+    std::optional<TrimConfig> trim;
+    std::string trim_folder;
+    // fused inspect step: pattern_per_read.tsv + pattern counts of the annotation rows (inspect.rs:119-208)
+    bool inspect = false;
+    std::string read_pattern_out;
+    uint32_t bucket_size = 250;
 };
-struct AnnotateStats { size_t total = 0, found = 0, rows = 0, kept = 0, dropped = 0; };
+struct AnnotateStats {
+    size_t total = 0, found = 0, rows = 0, kept = 0, dropped = 0, trimmed = 0, trimmed_split = 0, trim_failed = 0;
+    std::vector<std::pair<std::string, size_t>> patterns;  // inspect: pattern -> count, most common first
+};
+std::vector<std::string> inspect_summary(const AnnotateStats& st, size_t top_n);  // the lines of inspect.rs:186-205
+
+struct KitConfig {  // config.rs:34-48, CLI defaults bin/main.rs:208-262
+    std::string kit_name, output_folder;
+    size_t threads = 10;
+    bool maximize = false, verbose = false;
+    double min_score = 0.2, min_score_diff = 0.1;
+    std::optional<size_t> max_flank_errors;
+    std::optional<std::string> failed_out;
+    bool use_extended = false;
+    float alpha = 0.4f;
+    bool gzip = false;
+    size_t batch_reads = 65536;
+    int device = 0;
+};
+AnnotateStats demux_using_kit(const std::vector<std::string>& fastq_files, const KitConfig& config);  // use_kit.rs:11-109
 
 AnnotateStats annotate(const std::vector<std::string>& read_files, const std::string& out_file,
                        std::vector<BarcodeGroup> query_groups, const AnnotateConfig& config);          // annotator.rs:233-285

@@ -161,3 +161,83 @@ def test_cli_fused_filter_matches_python(tmp_path):
         for c, p in (("a", "pa"), ("k", "pk"), ("d", "pd")):
             assert o[c].read_bytes() == o[p].read_bytes(), (name, c)
         assert o["k"].stat().st_size > 100 and o["d"].stat().st_size > 100
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("gz", [False, True])
+def test_cli_kit_matches_python_kit_driver(tmp_path, gz):
+    """`barbell-amd kit` (use_kit.rs:11-109): every file of the output folder byte-identical to the Python kit
+    driver's (whose trim output test_trim.py checks against the oracle)."""
+    import gzip as gzmod
+
+    from barbell_amd import annotate as A
+    from barbell_amd.use_kit import demux_using_kit
+
+    kit = "SQK-RBK114-24"
+    groups = kits.groups_from_kit(kit)
+    n = 1100
+    bases, offsets = A.synth_reads_host(groups, 3, 250, 2600, 0, n)
+    rng = np.random.default_rng(2)
+    fq = tmp_path / "reads.fastq"
+    with open(fq, "wb") as f:
+        for i in range(n):
+            s = bytes(bases[int(offsets[i]):int(offsets[i + 1])])
+            q = bytes(rng.integers(33, 90, size=len(s), dtype=np.uint8))
+            f.write(b"@read%d%s\n" % (i, b" ch=%d  st=xyz" % (i % 50) if i % 5 else b"") + s + b"\n+\n" + q + b"\n")
+    env = dict(os.environ, BARBELL_AMD_NO_TORCH="1")
+    oc, op = tmp_path / "cli", tmp_path / "py"
+    flags = ["--maximize", "--failed-out", str(tmp_path / "failed_cli.txt"), "--batch-reads", "333"] + (["--gzip"] if gz else [])
+    r = subprocess.run([CLI, "kit", "-k", kit, "-i", str(fq), "-o", str(oc)] + flags, capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr
+    assert "Top 10 most common patterns" in r.stdout and "Found " in r.stdout and "Done!" in r.stdout
+    logs = []
+    _, _, insp = demux_using_kit([str(fq)], kit, str(op), maximize=True, failed_out=str(tmp_path / "failed_py.txt"), gzip=gz,
+                                 batch_reads=500, log=logs.append)
+    names = sorted(x.name for x in op.iterdir())
+    assert names == sorted(x.name for x in oc.iterdir()) and len(names) > 10
+    for x in names:
+        a, b = (oc / x).read_bytes(), (op / x).read_bytes()
+        if x.endswith(".gz"):
+            a, b = gzmod.decompress(a), gzmod.decompress(b)
+        assert a == b, x
+    assert (tmp_path / "failed_cli.txt").read_bytes() == (tmp_path / "failed_py.txt").read_bytes()
+    # the summary lines printed by the CLI are the inspector's
+    want = insp.summary(10)
+    got = [l for l in r.stdout.splitlines() if l.startswith(("Found", "\tPattern", "\t\t", "Showed"))]
+    counts = lambda ls: [l for l in ls if not l.startswith("\t\t")]
+    assert counts(got) == counts(want) and sorted(got) == sorted(want)
+
+
+@pytest.mark.gpu
+def test_cli_annotate_trim_flags(tmp_path):
+    """annotate --trim-output with the `barbell trim` label flags == the Python host with the same TrimConfig"""
+    from barbell_amd import annotate as A
+    from barbell_amd import filter as F
+    from barbell_amd import trim as T
+
+    kit = "SQK-NBD114-96"
+    groups = kits.groups_from_kit(kit, flank_max_errors=3)
+    bases, offsets = A.synth_reads_host(groups, 12, 300, 2000, 0, 700)
+    ids = [f"r{i}" for i in range(700)]
+    fq = tmp_path / "reads.fastq.gz"
+    write_fastq(fq, ids, bases, offsets, gz=True)
+    env = dict(os.environ, BARBELL_AMD_NO_TORCH="1")
+    for name, flags, cfg in (("default", [], T.TrimConfig()),
+                             ("sorted", ["--sort-labels", "--no-flanks", "--flip"], T.TrimConfig(True, True, False, True, None, flip=True)),
+                             ("right", ["--only-side", "right", "--no-orientation", "--skip-trim"],
+                              T.TrimConfig(True, False, True, False, "right", skip_trim=True)),
+                             ("nolabel", ["--no-label"], T.TrimConfig(False))):
+        oc, op = tmp_path / f"{name}_cli", tmp_path / f"{name}_py"
+        r = subprocess.run([CLI, "annotate", "-i", str(fq), "-o", str(tmp_path / "a.tsv"), "--kit", kit, "--flank-max-errors", "3",
+                            "--kit-filter", "--maximize", "--trim-output", str(oc), "--batch-reads", "256"] + flags,
+                           capture_output=True, text=True, env=env)
+        assert r.returncode == 0, r.stderr
+        A.annotate([str(fq)], str(tmp_path / "pa.tsv"), kits.groups_from_kit(kit), max_flank_errors=3, filter_patterns=F.kit_patterns(kit, True),
+                   trim_folder=str(op), trim_config=cfg, batch_reads=300)
+        names = sorted(x.name for x in op.iterdir())
+        assert names == sorted(x.name for x in oc.iterdir()) and names, name
+        for x in names:
+            assert (oc / x).read_bytes() == (op / x).read_bytes(), (name, x)
+    r = subprocess.run([CLI, "annotate", "-i", str(fq), "--kit", kit, "--kit-filter", "--trim-output", str(tmp_path / "x"), "--sort-labels",
+                        "--only-side", "left"], capture_output=True, text=True, env=env)
+    assert r.returncode == 2
