@@ -7,6 +7,7 @@ import numpy as np
 BB_OK = 0
 BB_E_INVALID, BB_E_ONE_QUERY, BB_E_UNEQUAL_LEN, BB_E_NO_BARCODE, BB_E_NO_FLANK = -1, -2, -3, -4, -5
 BB_E_NOT_IUPAC, BB_E_CAPACITY, BB_E_NO_DEVICE, BB_E_HIP, BB_E_UNSUPPORTED, BB_E_NOMEM = -6, -7, -8, -9, -10, -11
+BB_E_FASTQ = -12
 
 BB_FTAG, BB_RTAG, BB_FFLANK, BB_RFLANK = 0, 1, 2, 3
 BB_FWD, BB_RC = 0, 1

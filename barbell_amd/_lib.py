@@ -17,6 +17,7 @@ EXPORTS = [
     "bb_synth_offsets", "bb_synth_reads_host", "bb_synth_reads_dev",
     "bb_filter_set", "bb_filter_rows", "bb_filter_rows_dev",
     "bb_inspect_rows", "bb_inspect_rows_dev",
+    "bb_fastq_ingest", "bb_fastq_ingest_dev", "bb_fastq_fetch", "bb_fastq_last_ms",
     "bb_trim_set", "bb_trim_batch", "bb_trim_batch_dev", "bb_trim_last_ms",
 ]
 
@@ -77,6 +78,11 @@ def lib():
     L.bb_filter_rows_dev.argtypes = [vp, vp, u64, vp]
     L.bb_inspect_rows.argtypes = [vp, vp, vp, u64, u32, vp]
     L.bb_inspect_rows_dev.argtypes = [vp, vp, vp, u64, u32, vp]
+    L.bb_fastq_ingest.argtypes = [vp, vp, u64, C.c_int, vp, vp]
+    L.bb_fastq_ingest_dev.argtypes = [vp, vp, u64, C.c_int, vp, vp]
+    L.bb_fastq_fetch.argtypes = [vp] * 8
+    L.bb_fastq_last_ms.restype = C.c_float
+    L.bb_fastq_last_ms.argtypes = [vp]
     L.bb_trim_set.argtypes = [vp, vp, vp, vp, u32]
     trim_args = [vp, vp, vp, u64, vp, vp, vp, vp, u32, vp, u64, vp, vp, u64, vp, vp, u32, vp, vp]
     L.bb_trim_batch.argtypes = trim_args

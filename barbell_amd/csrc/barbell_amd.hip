@@ -153,6 +153,8 @@ struct bb_ctx {
     bb_inspect_elem* d_iout = nullptr; uint64_t cap_iout = 0;
     // trim step, owned by bb_trim.hip
     bb_trim_state* trim = nullptr;
+    // FASTQ ingest, owned by bb_fastq.hip
+    bb_fastq_state* fastq = nullptr;
     // synth
     uint8_t* d_synth_table = nullptr;
     bb_synth_params synth{};
@@ -412,6 +414,7 @@ const char* bb_strerror(int code) {
         case BB_E_HIP: return "HIP runtime error";
         case BB_E_UNSUPPORTED: return "query geometry outside the compiled kernel limits";
         case BB_E_NOMEM: return "out of memory";
+        case BB_E_FASTQ: return "malformed FASTQ record";
         default: return "unknown error";
     }
 }
@@ -460,6 +463,7 @@ void bb_destroy(bb_ctx* c) {
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     bb_trim_state_free(c->trim);
+    bb_fastq_state_free(c->fastq);
     for (int i = 0; i <= K_COUNT; ++i)
         if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -871,6 +875,6 @@ int bb_synth_reads_dev(bb_ctx* c, uint64_t seed, uint32_t len_min, uint32_t len_
 }  // extern "C"
 
 bb_ctx_view bb_ctx_get_view(bb_ctx* c) {
-    return bb_ctx_view{c->device, c->stream, (const bb_group_dev*)c->d_groups, (const uint32_t*)c->d_flabel_ids, &c->last_error, &c->trim};
+    return bb_ctx_view{c->device, c->stream, (const bb_group_dev*)c->d_groups, (const uint32_t*)c->d_flabel_ids, &c->last_error, &c->trim, &c->fastq};
 }
 

@@ -7,6 +7,7 @@
 #include "bb_common.h"
 
 struct bb_trim_state;
+struct bb_fastq_state;
 struct bb_ctx_view {
     int device;
     hipStream_t stream;
@@ -14,6 +15,8 @@ struct bb_ctx_view {
     const uint32_t* d_label_ids;  // bb_filter_set's label id per histogram slot; null until it was called
     std::string* last_error;
     bb_trim_state** trim;
+    bb_fastq_state** fastq;
 };
 bb_ctx_view bb_ctx_get_view(bb_ctx* ctx);
 void bb_trim_state_free(bb_trim_state* s);
+void bb_fastq_state_free(bb_fastq_state* s);

@@ -1,0 +1,377 @@
+// bb_fastq.hip — FASTQ ingest on the GPU (include/barbell_amd_fastq.h).
+//
+// One block of raw FASTQ text in HBM -> the packed batch layout of the rest of the library:
+//   k_nl_count / scan / k_nl_write   positions of all '\n' (16 text bytes per lane, 4 KB per workgroup)
+//   k_fq_records                     lane per record: the 4 lines, '@' / '+' checks, "\r\n", header split
+//                                    (id up to the first whitespace, description left-trimmed: io.rs:6-17)
+//   k_scan64 (x2)                    64-bit exclusive scans of sequence and header lengths -> offsets
+//   k_fq_pack                        wave per record: sequence, qualities and header copied into the packed
+//                                    arrays as 16-byte chunks (bb_bytes.h)
+// HBM-bound byte work: the text is read twice (newline pass, pack pass) and ~its size written once.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/barbell_amd_fastq.h"
+#include "bb_bytes.h"
+#include "bb_common.h"
+#include "bb_ctx_view.h"
+
+struct bb_fastq_state {
+    // text staging (host variant)
+    uint8_t* d_text = nullptr; uint64_t cap_text = 0;
+    // newline pass
+    uint32_t *d_cnt = nullptr, *d_cbase = nullptr; uint64_t cap_cnt = 0, cap_cbase = 0;
+    uint64_t* d_nl = nullptr; uint64_t cap_nl = 0;
+    uint64_t* d_misc = nullptr;  // [0] newline total, [1] sums scratch total, [2] bases total, [3] hdr total, [4] bad record
+    // records
+    uint32_t *d_seq_len = nullptr, *d_hdr_len = nullptr, *d_id_len = nullptr, *d_desc = nullptr;
+    uint64_t *d_off = nullptr, *d_hoff = nullptr, *d_sums = nullptr;
+    uint64_t cap_rec = 0, cap_sums = 0;
+    uint8_t *d_bases = nullptr, *d_quals = nullptr, *d_hdr = nullptr;
+    uint64_t cap_bases = 0, cap_quals = 0, cap_hdr = 0;
+    bb_fastq_info last{};
+    float last_ms = 0.f;
+    hipEvent_t ev[2] = {nullptr, nullptr};
+};
+
+namespace {
+
+#define FCHK(v, call)                                                                  \
+    do {                                                                               \
+        hipError_t e_ = (call);                                                        \
+        if (e_ != hipSuccess) {                                                        \
+            *(v).last_error = std::string(#call) + ": " + hipGetErrorString(e_);       \
+            return BB_E_HIP;                                                           \
+        }                                                                              \
+    } while (0)
+
+template <typename T>
+int fgrow(bb_ctx_view& v, T*& p, uint64_t& cap, uint64_t need) {
+    if (need <= cap && p) return BB_OK;
+    if (p) FCHK(v, hipFree(p));
+    p = nullptr;
+    const uint64_t ncap = need + need / 4 + 64;
+    FCHK(v, hipMalloc((void**)&p, ncap * sizeof(T)));
+    cap = ncap;
+    return BB_OK;
+}
+
+__device__ __forceinline__ uint32_t nl_mask16(const uint8_t* __restrict__ text, uint64_t pos, uint64_t len) {
+    if (pos >= len) return 0u;
+    const u32x4 v = *(const u32x4*)(text + pos);  // text is 16-byte aligned and padded by the allocator
+    uint32_t m = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const uint32_t x = v[w] ^ 0x0A0A0A0Au;  // zero byte where '\n'; bytes tested one by one (the SWAR zero test has false positives)
+        m |= (uint32_t)((x & 0xFFu) == 0) << (4 * w) | (uint32_t)((x & 0xFF00u) == 0) << (4 * w + 1) |
+             (uint32_t)((x & 0xFF0000u) == 0) << (4 * w + 2) | (uint32_t)((x & 0xFF000000u) == 0) << (4 * w + 3);
+    }
+    const uint64_t left = len - pos;
+    if (left < 16) m &= (1u << left) - 1u;
+    return m;
+}
+
+__global__ __launch_bounds__(256) void k_nl_count(const uint8_t* __restrict__ text, uint64_t len, uint32_t* __restrict__ cnt) {
+    __shared__ uint32_t s_w[4];
+    const uint64_t pos = ((uint64_t)blockIdx.x * 256u + threadIdx.x) * 16u;
+    uint32_t c = __popc(nl_mask16(text, pos, len));
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) c += __shfl_xor(c, d, 64);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) cnt[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+
+__global__ __launch_bounds__(256) void k_nl_write(const uint8_t* __restrict__ text, uint64_t len, const uint32_t* __restrict__ base,
+                                                  uint64_t* __restrict__ nl) {
+    __shared__ uint32_t s_w[4];
+    const uint64_t pos = ((uint64_t)blockIdx.x * 256u + threadIdx.x) * 16u;
+    uint32_t m = nl_mask16(text, pos, len);
+    const uint32_t c = __popc(m);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t inc = c;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(inc, d, 64); if (lane >= d) inc += y; }
+    if (lane == 63) s_w[wv] = inc;
+    __syncthreads();
+    uint32_t o = base[blockIdx.x] + inc - c;
+    for (int i = 0; i < wv; ++i) o += s_w[i];
+    while (m) {
+        const int b = __ffs(m) - 1;
+        nl[o++] = pos + (uint64_t)b;
+        m &= m - 1u;
+    }
+}
+
+// exclusive scan of u32 -> u32 over the per-block newline counts (few entries: text_len / 4096)
+__global__ __launch_bounds__(64) void k_scan_small(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint32_t n, uint64_t* __restrict__ total) {
+    uint32_t carry = 0;
+    const int lane = threadIdx.x;
+    for (uint32_t b = 0; b < n; b += 64) {
+        const uint32_t x = b + lane < n ? in[b + lane] : 0u;
+        uint32_t inc = x;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(inc, d, 64); if (lane >= d) inc += y; }
+        if (b + lane < n) out[b + lane] = carry + inc - x;
+        carry += __shfl(inc, 63, 64);
+    }
+    if (lane == 0) total[0] = carry;
+}
+
+__device__ __forceinline__ bool is_ws(uint8_t c) { return c == ' ' || (c >= 9 && c <= 13); }
+
+// line i of the block: [start, end) without the newline and without a trailing '\r'
+__device__ __forceinline__ void line_span(const uint8_t* __restrict__ text, const uint64_t* __restrict__ nl, uint64_t i, uint64_t& s, uint64_t& e) {
+    s = i ? nl[i - 1] + 1 : 0;
+    e = nl[i];
+    if (e > s && text[e - 1] == '\r') --e;
+}
+
+__global__ __launch_bounds__(256) void k_fq_records(const uint8_t* __restrict__ text, const uint64_t* __restrict__ nl, uint32_t n_rec,
+                                                    uint32_t* __restrict__ seq_len, uint32_t* __restrict__ hdr_len,
+                                                    uint32_t* __restrict__ id_len, uint32_t* __restrict__ desc_start,
+                                                    unsigned long long* __restrict__ bad) {
+    const uint32_t k = blockIdx.x * 256u + threadIdx.x;
+    if (k >= n_rec) return;
+    uint64_t hs, he, ss, se, ps, pe, qs, qe;
+    line_span(text, nl, 4ull * k, hs, he);
+    line_span(text, nl, 4ull * k + 1, ss, se);
+    line_span(text, nl, 4ull * k + 2, ps, pe);
+    line_span(text, nl, 4ull * k + 3, qs, qe);
+    const bool ok = he > hs && text[hs] == '@' && pe > ps && text[ps] == '+' && (se - ss) == (qe - qs);
+    if (!ok) atomicMin(bad, (unsigned long long)k);
+    const uint32_t hl = he > hs ? (uint32_t)(he - hs - 1) : 0u;  // header without '@'
+    uint32_t idl = hl, ds = hl;
+    for (uint32_t p = 0; p < hl; ++p)
+        if (is_ws(text[hs + 1 + p])) { idl = p; break; }
+    if (idl < hl) {
+        ds = idl;
+        while (ds < hl && is_ws(text[hs + 1 + ds])) ++ds;
+    }
+    seq_len[k] = (uint32_t)(se - ss);
+    hdr_len[k] = hl;
+    id_len[k] = idl;
+    desc_start[k] = ds;
+}
+
+// 64-bit exclusive scan of u32 lengths, 1024 per block; out has n+1 entries (out[n] = total)
+__global__ __launch_bounds__(256) void k_scan64_block(const uint32_t* __restrict__ in, uint64_t* __restrict__ out, uint32_t n, uint64_t* __restrict__ sums) {
+    __shared__ uint64_t s_w[4];
+    const uint32_t b0 = blockIdx.x * 1024u + threadIdx.x * 4u;
+    uint64_t t = 0, pre[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { pre[i] = t; if (b0 + i < n) t += in[b0 + i]; }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint64_t inc = t;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint64_t y = __shfl_up(inc, d, 64); if (lane >= d) inc += y; }
+    if (lane == 63) s_w[wv] = inc;
+    __syncthreads();
+    uint64_t wbase = 0;
+    for (int i = 0; i < wv; ++i) wbase += s_w[i];
+    const uint64_t excl = wbase + inc - t;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) if (b0 + i < n) out[b0 + i] = excl + pre[i];
+    if (threadIdx.x == 255) sums[blockIdx.x] = wbase + inc;
+}
+__global__ __launch_bounds__(64) void k_scan64_sums(uint64_t* __restrict__ sums, uint32_t nb, uint64_t* __restrict__ total) {
+    uint64_t carry = 0;
+    const int lane = threadIdx.x;
+    for (uint32_t b = 0; b < nb; b += 64) {
+        const uint64_t x = b + lane < nb ? sums[b + lane] : 0ull;
+        uint64_t inc = x;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint64_t y = __shfl_up(inc, d, 64); if (lane >= d) inc += y; }
+        if (b + lane < nb) sums[b + lane] = carry + inc - x;
+        carry += __shfl(inc, 63, 64);
+    }
+    if (lane == 0) total[0] = carry;
+}
+__global__ __launch_bounds__(256) void k_scan64_add(uint64_t* __restrict__ out, uint32_t n, const uint64_t* __restrict__ sums, const uint64_t* __restrict__ total) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n) out[i] += sums[i >> 10];
+    if (i == 0) out[n] = total[0];
+}
+
+__global__ __launch_bounds__(256) void k_fq_pack(const uint8_t* __restrict__ text, const uint64_t* __restrict__ nl, uint32_t n_rec,
+                                                 const uint64_t* __restrict__ off, const uint64_t* __restrict__ hoff,
+                                                 uint8_t* __restrict__ bases, uint8_t* __restrict__ quals, uint8_t* __restrict__ hdr) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t k = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (k >= n_rec) return;
+    const uint64_t o = off[k], L = off[k + 1] - o, ho = hoff[k], HL = hoff[k + 1] - ho;
+    const uint64_t hs = (k ? nl[4ull * k - 1] + 1 : 0) + 1;  // past '@'
+    const uint64_t ss = nl[4ull * k] + 1, qs = nl[4ull * k + 2] + 1;
+    wave_copy(bases + o, text + ss, (uint32_t)L, lane);
+    wave_copy(quals + o, text + qs, (uint32_t)L, lane);
+    wave_copy(hdr + ho, text + hs, (uint32_t)HL, lane);
+}
+
+int scan64(bb_ctx_view& v, bb_fastq_state* s, const uint32_t* in, uint64_t* out, uint32_t n, uint64_t* d_total) {
+    const uint32_t nb = (n + 1023) / 1024;
+    int r;
+    if ((r = fgrow(v, s->d_sums, s->cap_sums, (uint64_t)nb + 1))) return r;
+    hipLaunchKernelGGL(k_scan64_block, dim3(nb), dim3(256), 0, v.stream, in, out, n, s->d_sums);
+    hipLaunchKernelGGL(k_scan64_sums, dim3(1), dim3(64), 0, v.stream, s->d_sums, nb, d_total);
+    hipLaunchKernelGGL(k_scan64_add, dim3((n + 255) / 256), dim3(256), 0, v.stream, out, n, (const uint64_t*)s->d_sums, (const uint64_t*)d_total);
+    FCHK(v, hipGetLastError());
+    return BB_OK;
+}
+
+}  // namespace
+
+void bb_fastq_state_free(bb_fastq_state* s) {
+    if (!s) return;
+    for (void* p : {(void*)s->d_text, (void*)s->d_cnt, (void*)s->d_cbase, (void*)s->d_nl, (void*)s->d_misc, (void*)s->d_seq_len, (void*)s->d_hdr_len,
+                    (void*)s->d_id_len, (void*)s->d_desc, (void*)s->d_off, (void*)s->d_hoff, (void*)s->d_sums, (void*)s->d_bases, (void*)s->d_quals,
+                    (void*)s->d_hdr})
+        if (p) (void)hipFree(p);
+    for (auto& e : s->ev) if (e) (void)hipEventDestroy(e);
+    delete s;
+}
+
+extern "C" int bb_fastq_ingest_dev(bb_ctx* ctx, const uint8_t* d_text, uint64_t text_len, int final_block, bb_fastq_info* info,
+                                   bb_fastq_batch_dev* batch) {
+    if (!ctx || !info || !batch || (!d_text && text_len) || ((uintptr_t)d_text & 15u)) return BB_E_INVALID;
+    bb_ctx_view v = bb_ctx_get_view(ctx);
+    if (!*v.fastq) *v.fastq = new bb_fastq_state();
+    bb_fastq_state* s = *v.fastq;
+    FCHK(v, hipSetDevice(v.device));
+    hipStream_t st = v.stream;
+    memset(info, 0, sizeof(*info));
+    info->bad_record = -1;
+    memset(batch, 0, sizeof(*batch));
+    s->last = *info;
+    if (!s->d_misc) FCHK(v, hipMalloc((void**)&s->d_misc, 8 * sizeof(uint64_t)));
+    hipEvent_t* ev = s->ev;
+    if (!ev[0]) for (int i = 0; i < 2; ++i) FCHK(v, hipEventCreate(&ev[i]));
+    FCHK(v, hipEventRecord(ev[0], st));
+    int r;
+    uint64_t n_lines = 0;
+    uint8_t last_byte = '\n';
+    if (text_len) {
+        const uint32_t nb = (uint32_t)((text_len + 4095) / 4096);
+        if ((r = fgrow(v, s->d_cnt, s->cap_cnt, nb))) return r;
+        if ((r = fgrow(v, s->d_cbase, s->cap_cbase, nb))) return r;
+        hipLaunchKernelGGL(k_nl_count, dim3(nb), dim3(256), 0, st, d_text, text_len, s->d_cnt);
+        hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(64), 0, st, (const uint32_t*)s->d_cnt, s->d_cbase, nb, s->d_misc);
+        FCHK(v, hipGetLastError());
+        FCHK(v, hipMemcpyAsync(&n_lines, s->d_misc, 8, hipMemcpyDeviceToHost, st));
+        FCHK(v, hipMemcpyAsync(&last_byte, d_text + text_len - 1, 1, hipMemcpyDeviceToHost, st));
+        FCHK(v, hipStreamSynchronize(st));
+        if ((r = fgrow(v, s->d_nl, s->cap_nl, n_lines + 2))) return r;
+        hipLaunchKernelGGL(k_nl_write, dim3(nb), dim3(256), 0, st, d_text, text_len, (const uint32_t*)s->d_cbase, s->d_nl);
+        FCHK(v, hipGetLastError());
+        if (final_block && last_byte != '\n') {  // last line without a newline: a virtual one at text_len
+            FCHK(v, hipMemcpyAsync(s->d_nl + n_lines, &text_len, 8, hipMemcpyHostToDevice, st));
+            FCHK(v, hipStreamSynchronize(st));
+            ++n_lines;
+        }
+    }
+    if (n_lines / 4 > 0xFFFFFFF0ull) { *v.last_error = "more than 2^32 records in one block"; return BB_E_UNSUPPORTED; }
+    const uint32_t n = (uint32_t)(n_lines / 4);
+    uint64_t consumed = 0;
+    if (n) FCHK(v, hipMemcpy(&consumed, s->d_nl + (4ull * n - 1), 8, hipMemcpyDeviceToHost));
+    consumed = n ? std::min<uint64_t>(consumed + 1, text_len) : 0;
+    if (final_block && consumed < text_len) {  // what is left may only be blank lines
+        std::vector<uint8_t> tail((size_t)std::min<uint64_t>(text_len - consumed, 1 << 20));
+        FCHK(v, hipMemcpy(tail.data(), d_text + consumed, tail.size(), hipMemcpyDeviceToHost));
+        bool blank = text_len - consumed <= tail.size();
+        for (uint8_t ch : tail) if (ch != '\n' && ch != '\r') blank = false;
+        if (!blank) {
+            info->n_records = n; info->consumed = consumed; info->bad_record = (int64_t)n;
+            *v.last_error = "Input FASTQ parsing failed: the stream ends inside record " + std::to_string(n);
+            return BB_E_FASTQ;
+        }
+        consumed = text_len;
+    }
+    info->n_records = n;
+    info->consumed = consumed;
+    if (n) {
+        if (n > s->cap_rec || !s->d_seq_len) {
+            for (void** p : {(void**)&s->d_seq_len, (void**)&s->d_hdr_len, (void**)&s->d_id_len, (void**)&s->d_desc, (void**)&s->d_off, (void**)&s->d_hoff})
+                if (*p) { (void)hipFree(*p); *p = nullptr; }
+            const uint64_t cap = (uint64_t)n + n / 4 + 64;
+            for (uint32_t** p : {&s->d_seq_len, &s->d_hdr_len, &s->d_id_len, &s->d_desc}) FCHK(v, hipMalloc((void**)p, cap * 4));
+            for (uint64_t** p : {&s->d_off, &s->d_hoff}) FCHK(v, hipMalloc((void**)p, (cap + 1) * 8));
+            s->cap_rec = cap;
+        }
+        const unsigned long long none = ~0ull;
+        FCHK(v, hipMemcpyAsync(s->d_misc + 4, &none, 8, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_fq_records, dim3((n + 255) / 256), dim3(256), 0, st, d_text, (const uint64_t*)s->d_nl, n, s->d_seq_len, s->d_hdr_len,
+                           s->d_id_len, s->d_desc, (unsigned long long*)(s->d_misc + 4));
+        if ((r = scan64(v, s, s->d_seq_len, s->d_off, n, s->d_misc + 2))) return r;
+        if ((r = scan64(v, s, s->d_hdr_len, s->d_hoff, n, s->d_misc + 3))) return r;
+        uint64_t h[3];
+        FCHK(v, hipMemcpyAsync(h, s->d_misc + 2, sizeof(h), hipMemcpyDeviceToHost, st));
+        FCHK(v, hipStreamSynchronize(st));
+        if (h[2] != none) {
+            info->bad_record = (int64_t)h[2];
+            *v.last_error = "Input FASTQ parsing failed: record " + std::to_string(h[2]) + " of the block is not a 4-line FASTQ record";
+            return BB_E_FASTQ;
+        }
+        info->n_bases = h[0];
+        info->n_hdr = h[1];
+        if ((r = fgrow(v, s->d_bases, s->cap_bases, h[0] + 16))) return r;
+        if ((r = fgrow(v, s->d_quals, s->cap_quals, h[0] + 16))) return r;
+        if ((r = fgrow(v, s->d_hdr, s->cap_hdr, h[1] + 16))) return r;
+        hipLaunchKernelGGL(k_fq_pack, dim3((n + 3) / 4), dim3(256), 0, st, d_text, (const uint64_t*)s->d_nl, n, (const uint64_t*)s->d_off,
+                           (const uint64_t*)s->d_hoff, s->d_bases, s->d_quals, s->d_hdr);
+        FCHK(v, hipGetLastError());
+    }
+    FCHK(v, hipEventRecord(ev[1], st));
+    FCHK(v, hipStreamSynchronize(st));
+    (void)hipEventElapsedTime(&s->last_ms, ev[0], ev[1]);
+    s->last = *info;
+    batch->d_bases = s->d_bases; batch->d_quals = s->d_quals; batch->d_offsets = s->d_off;
+    batch->d_headers = bb_headers{s->d_hdr, s->d_hoff, s->d_id_len, s->d_desc};
+    return BB_OK;
+}
+
+extern "C" int bb_fastq_ingest(bb_ctx* ctx, const uint8_t* text, uint64_t text_len, int final_block, bb_fastq_info* info,
+                               bb_fastq_batch_dev* batch) {
+    if (!ctx || !info || !batch || (!text && text_len)) return BB_E_INVALID;
+    bb_ctx_view v = bb_ctx_get_view(ctx);
+    if (!*v.fastq) *v.fastq = new bb_fastq_state();
+    bb_fastq_state* s = *v.fastq;
+    FCHK(v, hipSetDevice(v.device));
+    int r;
+    if ((r = fgrow(v, s->d_text, s->cap_text, text_len + 64))) return r;
+    if (text_len) FCHK(v, hipMemcpyAsync(s->d_text, text, text_len, hipMemcpyHostToDevice, v.stream));
+    return bb_fastq_ingest_dev(ctx, s->d_text, text_len, final_block, info, batch);
+}
+
+extern "C" int bb_fastq_fetch(bb_ctx* ctx, uint64_t* offsets, uint8_t* hdr, uint64_t* hdr_offsets, uint32_t* id_len, uint32_t* desc_start,
+                              uint8_t* bases, uint8_t* quals) {
+    if (!ctx) return BB_E_INVALID;
+    bb_ctx_view v = bb_ctx_get_view(ctx);
+    bb_fastq_state* s = *v.fastq;
+    if (!s) { *v.last_error = "no FASTQ block has been ingested"; return BB_E_INVALID; }
+    FCHK(v, hipSetDevice(v.device));
+    const uint64_t n = s->last.n_records;
+    if (n == 0) {
+        if (offsets) offsets[0] = 0;
+        if (hdr_offsets) hdr_offsets[0] = 0;
+        return BB_OK;
+    }
+    hipStream_t st = v.stream;
+    if (offsets) FCHK(v, hipMemcpyAsync(offsets, s->d_off, (n + 1) * 8, hipMemcpyDeviceToHost, st));
+    if (hdr_offsets) FCHK(v, hipMemcpyAsync(hdr_offsets, s->d_hoff, (n + 1) * 8, hipMemcpyDeviceToHost, st));
+    if (id_len) FCHK(v, hipMemcpyAsync(id_len, s->d_id_len, n * 4, hipMemcpyDeviceToHost, st));
+    if (desc_start) FCHK(v, hipMemcpyAsync(desc_start, s->d_desc, n * 4, hipMemcpyDeviceToHost, st));
+    if (hdr && s->last.n_hdr) FCHK(v, hipMemcpyAsync(hdr, s->d_hdr, s->last.n_hdr, hipMemcpyDeviceToHost, st));
+    if (bases && s->last.n_bases) FCHK(v, hipMemcpyAsync(bases, s->d_bases, s->last.n_bases, hipMemcpyDeviceToHost, st));
+    if (quals && s->last.n_bases) FCHK(v, hipMemcpyAsync(quals, s->d_quals, s->last.n_bases, hipMemcpyDeviceToHost, st));
+    FCHK(v, hipStreamSynchronize(st));
+    return BB_OK;
+}
+
+extern "C" float bb_fastq_last_ms(bb_ctx* ctx) {
+    if (!ctx) return 0.f;
+    bb_ctx_view v = bb_ctx_get_view(ctx);
+    return *v.fastq ? (*v.fastq)->last_ms : 0.f;
+}

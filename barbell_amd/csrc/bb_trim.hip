@@ -21,6 +21,7 @@
 
 #include "../../include/barbell_amd_trim.h"
 #include "bb_common.h"
+#include "bb_bytes.h"
 #include "bb_ctx_view.h"
 
 #define BB_TRIM_MAX_E 32  // cut entries per read (a passing read's cuts come from one pattern)
@@ -320,24 +321,6 @@ __device__ __forceinline__ uint8_t comp_char(uint8_t ch) {
     return (uint8_t)(r | (ch & 0x20u));
 }
 
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-// copies L bytes src -> dst with the 64 lanes of a wave: byte head up to a 16-byte boundary of dst,
-// 16-byte chunks (unaligned loads, aligned stores), byte tail
-__device__ __forceinline__ void wave_copy(uint8_t* __restrict__ dst, const uint8_t* __restrict__ src, uint32_t L, int lane) {
-    uint32_t head = (uint32_t)((16u - ((uintptr_t)dst & 15u)) & 15u);
-    if (head > L) head = L;
-    if ((uint32_t)lane < head) dst[lane] = src[lane];
-    const uint32_t body = (L - head) >> 4;
-    const uint8_t* s = src + head;
-    u32x4* d = (u32x4*)(dst + head);
-    for (uint32_t c = (uint32_t)lane; c < body; c += 64u) {
-        u32x4 v;
-        __builtin_memcpy(&v, s + ((uint64_t)c << 4), 16);
-        __builtin_nontemporal_store(v, d + c);
-    }
-    const uint32_t done = head + (body << 4);
-    if (done + (uint32_t)lane < L) dst[done + lane] = src[done + lane];
-}
 template <bool COMP>
 __device__ __forceinline__ void wave_copy_rev(uint8_t* __restrict__ dst, const uint8_t* __restrict__ src, uint32_t L, int lane) {
     for (uint32_t k = (uint32_t)lane; k < L; k += 64u) {

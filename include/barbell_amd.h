@@ -41,6 +41,7 @@ extern "C" {
 #define BB_E_HIP           -9  /* HIP runtime error during a batch (see bb_last_error)               */
 #define BB_E_UNSUPPORTED  -10  /* geometry outside what the kernels were built for (see bb_limits)   */
 #define BB_E_NOMEM        -11
+#define BB_E_FASTQ        -12  /* malformed FASTQ record (barbell_amd_fastq.h)                         */
 
 /* ---- match_type / strand encodings (searcher.rs:31-75, barcodes.rs:8-33) ------------------ */
 #define BB_FTAG   0

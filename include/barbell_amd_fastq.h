@@ -1,0 +1,58 @@
+/*
+ * barbell_amd_fastq.h — C-ABI of FASTQ ingest, the third "next" row of SURVEY.md §8(f): the reference reads
+ * its input through paraseq (`open_fastq_collection`, src/io/io.rs:29-33; record loop annotator.rs:245-262,
+ * trim.rs:364-384) on the CPU.  Here a block of raw (already decompressed) FASTQ text is parsed on the GPU:
+ * newline positions, 4-line records, header split (`split_fastq_header`, io.rs:6-17), and the sequences,
+ * qualities and headers are packed into the contiguous batch layout every other entry point of this library
+ * takes — the batch is born in HBM and never visits the host as parsed records.
+ */
+#ifndef BARBELL_AMD_FASTQ_H
+#define BARBELL_AMD_FASTQ_H
+#include "barbell_amd.h"
+#include "barbell_amd_trim.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct {
+    uint64_t n_records;        /* complete 4-line records found                                         */
+    uint64_t consumed;         /* bytes of text they span; the caller prepends text[consumed..] to the next block */
+    uint64_t n_bases;          /* total sequence bytes (= total quality bytes)                           */
+    uint64_t n_hdr;            /* total header bytes (lines without '@')                                 */
+    int64_t  bad_record;       /* -1, or the first record that is not FASTQ (see BB_E_FASTQ)             */
+} bb_fastq_info;
+
+/* BB_E_FASTQ (barbell_amd.h): a record does not start with '@', its third line not with '+', its sequence
+ * and quality lengths differ, or the stream ends inside a record (checked first); bb_fastq_info.bad_record
+ * says which.                                                                                          */
+
+/* The parsed batch, in HBM, owned by the context and valid until the next ingest call.  Layout = what
+ * bb_annotate_batch_dev (bases, offsets) and bb_trim_batch_dev (quals, headers) take.                   */
+typedef struct {
+    const uint8_t*  d_bases;
+    const uint8_t*  d_quals;
+    const uint64_t* d_offsets;     /* n_records + 1 */
+    bb_headers      d_headers;     /* four device arrays */
+} bb_fastq_batch_dev;
+
+/* Parses text[0, text_len).  final_block != 0: the text is the end of the stream — a last line without
+ * '\n' counts, trailing blank lines are ignored, and a trailing partial record is an error; otherwise
+ * the partial tail is left to the caller (info->consumed).  "\r\n" line ends are accepted.
+ * The host variant uploads the block first; d_text of the _dev variant must be 16-byte aligned.        */
+int bb_fastq_ingest(bb_ctx* ctx, const uint8_t* text, uint64_t text_len, int final_block, bb_fastq_info* info,
+                    bb_fastq_batch_dev* batch);
+int bb_fastq_ingest_dev(bb_ctx* ctx, const uint8_t* d_text, uint64_t text_len, int final_block, bb_fastq_info* info,
+                        bb_fastq_batch_dev* batch);
+
+/* Copies parts of the last ingested batch to the host; any pointer may be NULL (skipped).
+ * Sizes: offsets/hdr_offsets n_records+1, id_len/desc_start n_records, hdr n_hdr, bases/quals n_bases. */
+int bb_fastq_fetch(bb_ctx* ctx, uint64_t* offsets, uint8_t* hdr, uint64_t* hdr_offsets, uint32_t* id_len, uint32_t* desc_start,
+                   uint8_t* bases, uint8_t* quals);
+
+/* GPU milliseconds of the last ingest (parse + pack, without the upload). */
+float bb_fastq_last_ms(bb_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -969,3 +969,56 @@ int bbo_inspect_rows(const bb_row* rows, const bb_row_verdict* verdicts, uint64_
     }
     return BB_OK;
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* FASTQ ingest: 4-line records + split_fastq_header (io.rs:6-17), scalar       */
+/* ------------------------------------------------------------------------------------------ */
+static int is_ws_c(uint8_t c) { return c == ' ' || (c >= 9 && c <= 13); }
+int bbo_fastq_parse(const uint8_t* text, uint64_t len, int final_block, bb_fastq_info* info, uint64_t* offsets, uint8_t* bases,
+                    uint8_t* quals, uint8_t* hdr, uint64_t* hdr_offsets, uint32_t* id_len, uint32_t* desc_start) {
+    if (!info || (!text && len)) return BB_E_INVALID;
+    memset(info, 0, sizeof(*info));
+    info->bad_record = -1;
+    const int fill = offsets && bases && quals && hdr && hdr_offsets && id_len && desc_start;
+    uint64_t pos = 0, n = 0, nb = 0, nh = 0;
+    if (fill) { offsets[0] = 0; hdr_offsets[0] = 0; }
+    for (;;) {
+        uint64_t ls[4], le[4], p = pos;                       /* the next four lines */
+        int got = 0;
+        while (got < 4 && p < len) {
+            uint64_t e = p;
+            while (e < len && text[e] != '\n') ++e;
+            if (e == len && !final_block) break;               /* incomplete line: leave it to the next block */
+            ls[got] = p; le[got] = e; ++got;
+            p = e < len ? e + 1 : len;
+        }
+        if (got < 4) {
+            if (final_block) {
+                int blank = 1;
+                for (uint64_t q = pos; q < len; ++q) if (text[q] != '\n' && text[q] != '\r') blank = 0;
+                if (!blank) { info->n_records = n; info->consumed = pos; info->bad_record = (int64_t)n; return BB_E_FASTQ; }
+                pos = len;
+            }
+            break;
+        }
+        for (int i = 0; i < 4; ++i) if (le[i] > ls[i] && text[le[i] - 1] == '\r') --le[i];
+        if (!(le[0] > ls[0] && text[ls[0]] == '@' && le[2] > ls[2] && text[ls[2]] == '+' && le[1] - ls[1] == le[3] - ls[3])) {
+            if (info->bad_record < 0) info->bad_record = (int64_t)n;
+        }
+        const uint64_t L = le[1] - ls[1], HL = le[0] > ls[0] ? le[0] - ls[0] - 1 : 0;
+        if (fill && info->bad_record < 0) {
+            memcpy(bases + nb, text + ls[1], L);
+            memcpy(quals + nb, text + ls[3], L);
+            memcpy(hdr + nh, text + ls[0] + 1, HL);
+            uint32_t idl = (uint32_t)HL, ds = (uint32_t)HL;
+            for (uint32_t q = 0; q < HL; ++q) if (is_ws_c(text[ls[0] + 1 + q])) { idl = q; break; }
+            if (idl < HL) { ds = idl; while (ds < HL && is_ws_c(text[ls[0] + 1 + ds])) ++ds; }
+            id_len[n] = idl; desc_start[n] = ds;
+            offsets[n + 1] = nb + L; hdr_offsets[n + 1] = nh + HL;
+        }
+        nb += L; nh += HL; ++n;
+        pos = p;
+    }
+    info->n_records = n; info->consumed = pos; info->n_bases = nb; info->n_hdr = nh;
+    return info->bad_record >= 0 ? BB_E_FASTQ : BB_OK;
+}

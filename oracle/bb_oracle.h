@@ -15,6 +15,7 @@
 #include "../include/barbell_amd_filter.h"
 #include "../include/barbell_amd_trim.h"
 #include "../include/barbell_amd_inspect.h"
+#include "../include/barbell_amd_fastq.h"
 
 #ifdef __cplusplus
 extern "C" {
@@ -88,6 +89,10 @@ int  bbo_trim_batch(const bbo_ctx* ctx, const bb_trim_config* cfg, const uint8_t
                     bb_label_span* spans, uint32_t spans_cap, uint32_t* n_spans, uint8_t* read_status);
 /* inspect step: get_group_structure (inspect.rs:15-117) per row */
 int  bbo_inspect_rows(const bb_row* rows, const bb_row_verdict* verdicts, uint64_t n_rows, uint32_t bucket_size, bb_inspect_elem* out);
+/* FASTQ ingest restated: same outputs as bb_fastq_ingest + bb_fastq_fetch; with any array NULL only `info`
+ * is computed (sizing call) */
+int  bbo_fastq_parse(const uint8_t* text, uint64_t len, int final_block, bb_fastq_info* info, uint64_t* offsets, uint8_t* bases,
+                     uint8_t* quals, uint8_t* hdr, uint64_t* hdr_offsets, uint32_t* id_len, uint32_t* desc_start);
 /* test hook: 1 = trace flank matches on the full DP matrix instead of the (m+k)-column window */
 void bbo_set_full_trace(int on);
 

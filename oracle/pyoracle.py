@@ -70,6 +70,7 @@ def lib():
         L.bbo_trim_batch.argtypes = [C.c_void_p] * 7 + [C.c_uint64] + [C.c_void_p] * 4 + [C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p,
                                      C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
         L.bbo_inspect_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p]
+        L.bbo_fastq_parse.argtypes = [C.c_void_p, C.c_uint64, C.c_int] + [C.c_void_p] * 8
         _lib = L
     return _lib
 
@@ -144,6 +145,25 @@ def inspect_rows(rows, verdicts=None, bucket_size=250):
     rc = lib().bbo_inspect_rows(rows.ctypes.data, None if v is None else v.ctypes.data, len(rows), bucket_size, out.ctypes.data)
     assert rc == 0, rc
     return out
+
+
+def fastq_parse(text, final_block=True):
+    """scalar FASTQ block parser -> (rc, info dict, arrays dict)"""
+    from barbell_amd import fastq as Q
+
+    text = np.ascontiguousarray(np.frombuffer(bytes(text), dtype=np.uint8))
+    info = Q.FastqInfo()
+    rc = lib().bbo_fastq_parse(text.ctypes.data, len(text), int(final_block), C.addressof(info), *([None] * 7))
+    d = {k: getattr(info, k) for k in ("n_records", "consumed", "n_bases", "n_hdr", "bad_record")}
+    if rc != 0:
+        return rc, d, None
+    n = info.n_records
+    a = {"offsets": np.zeros(n + 1, np.uint64), "bases": np.zeros(info.n_bases, np.uint8), "quals": np.zeros(info.n_bases, np.uint8),
+         "hdr": np.zeros(info.n_hdr, np.uint8), "hdr_offsets": np.zeros(n + 1, np.uint64), "id_len": np.zeros(n, np.uint32),
+         "desc_start": np.zeros(n, np.uint32)}
+    rc = lib().bbo_fastq_parse(text.ctypes.data, len(text), int(final_block), C.addressof(info),
+                               *[a[k].ctypes.data for k in ("offsets", "bases", "quals", "hdr", "hdr_offsets", "id_len", "desc_start")])
+    return rc, d, a
 
 
 class Oracle:

@@ -24,7 +24,7 @@ def L():
 
 def test_exports_match_headers(L):
     declared = set()
-    for h in ("barbell_amd.h", "barbell_amd_synth.h", "barbell_amd_filter.h", "barbell_amd_trim.h", "barbell_amd_inspect.h"):
+    for h in ("barbell_amd.h", "barbell_amd_synth.h", "barbell_amd_filter.h", "barbell_amd_trim.h", "barbell_amd_inspect.h", "barbell_amd_fastq.h"):
         src = open(os.path.join(ROOT, "include", h)).read()
         src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
         declared |= set(re.findall(r"\b(bb_[a-z_0-9]+)\s*\(", src))

@@ -1,0 +1,169 @@
+"""FASTQ ingest.  CPU: the scalar block parser of the oracle on hand-made blocks (line ends,
+partial blocks, header split of io.rs:6-17 incl. the reference's own split_fastq_header tests, malformed
+records).  GPU: bb_fastq_ingest == oracle on the same blocks and on FASTQ text of synthetic reads cut into
+blocks at arbitrary byte positions; the ingested batch feeds annotate/trim without visiting the host."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from barbell_amd import _abi
+from oracle import pyoracle as po
+
+REC = [(b"r1 runid=ab ch=3", b"ACGTACGT", b"IIIIHHHH"), (b"r2", b"GG", b"@+"), (b"r3\t  two  words ", b"ACGTN", b"!!!!!"),
+       (b"r4 ", b"", b""), (b"", b"A", b"#")]
+
+
+def fq(recs, nl=b"\n", last_nl=True):
+    t = b"".join(b"@" + h + nl + s + nl + b"+" + nl + q + nl for h, s, q in recs)
+    return t if last_nl else t[: -len(nl)]
+
+
+def check(arr, recs):
+    n = len(recs)
+    off, hoff = arr["offsets"], arr["hdr_offsets"]
+    assert len(off) == n + 1 and len(hoff) == n + 1
+    for i, (h, s, q) in enumerate(recs):
+        assert arr["bases"][int(off[i]):int(off[i + 1])].tobytes() == s
+        assert arr["quals"][int(off[i]):int(off[i + 1])].tobytes() == q
+        assert arr["hdr"][int(hoff[i]):int(hoff[i + 1])].tobytes() == h
+        parts = h.split(None, 1)
+        rid = parts[0] if parts and not h[:1].isspace() else b""
+        assert int(arr["id_len"][i]) == len(rid)
+        desc = h[len(rid):].lstrip()
+        assert h[int(arr["desc_start"][i]):] == desc
+
+
+def test_blocks_and_line_ends():
+    for nl in (b"\n", b"\r\n"):
+        for last_nl in (True, False):
+            rc, info, arr = po.fastq_parse(fq(REC, nl, last_nl), True)
+            assert rc == 0 and info["n_records"] == 5 and info["bad_record"] == -1 and info["consumed"] == len(fq(REC, nl, last_nl))
+            check(arr, REC)
+    # trailing blank lines are fine at the end of the stream
+    rc, info, arr = po.fastq_parse(fq(REC) + b"\n\r\n\n", True)
+    assert rc == 0 and info["n_records"] == 5
+    # non-final block: the partial tail is left to the caller
+    text = fq(REC)
+    for cut in (1, 5, len(fq(REC[:2])), len(fq(REC[:2])) + 3, len(text) - 1):
+        rc, info, arr = po.fastq_parse(text[:cut], False)
+        k = sum(1 for i in range(1, 6) if len(fq(REC[:i])) <= cut)
+        assert rc == 0 and info["n_records"] == k and info["consumed"] == len(fq(REC[:k]))
+        if k:
+            check(arr, REC[:k])
+    rc, info, _ = po.fastq_parse(b"", True)
+    assert rc == 0 and info["n_records"] == 0
+
+
+def test_split_fastq_header_cases():  # io.rs:40-58 tests
+    for h, rid, desc in ((b"read1 runid=abc sample=xyz", b"read1", b"runid=abc sample=xyz"), (b"read1", b"read1", b""),
+                         (b"read1   lots of space", b"read1", b"lots of space"), (b"read1\tx", b"read1", b"x")):
+        rc, info, a = po.fastq_parse(fq([(h, b"A", b"I")]), True)
+        assert rc == 0 and h[: int(a["id_len"][0])] == rid and h[int(a["desc_start"][0]):] == desc
+
+
+def test_malformed_records():
+    good = fq(REC[:2])
+    for bad, which in ((good + b"r3\nAC\n+\nII\n", 2), (good + b"@r3\nAC\n-\nII\n", 2), (good + b"@r3\nACG\n+\nII\n", 2),
+                       (b"\n" + good + b"A\nC\nG\n", 0), (good + b"@r3\nAC\n", 2), (good + b"@r3\nAC\n+\n", 2),
+                       (b"\n" + good, 2)):   # a truncated stream is reported first, as the record it breaks off in
+        rc, info, _ = po.fastq_parse(bad, True)
+        assert rc == _abi.BB_E_FASTQ and info["bad_record"] == which, bad
+    # a quality line may start with '@' or '+'
+    rc, info, arr = po.fastq_parse(b"@a\nAC\n+a\n@+\n@b\nG\n+\n+\n", True)
+    assert rc == 0 and info["n_records"] == 2 and arr["quals"].tobytes() == b"@++"
+
+
+# ---- GPU ---------------------------------------------------------------------------------------------
+def gpu_parse(dm, text, final=True):
+    from barbell_amd import fastq as Q
+    from barbell_amd.annotate import BarbellError
+
+    try:
+        info, batch = Q.ingest(dm, text, final)
+    except BarbellError as e:
+        assert e.code == _abi.BB_E_FASTQ
+        return e.code, None, None
+    return 0, info, Q.fetch(dm, info, bases=True, quals=True)
+
+
+def same(info, arr, oinfo, oarr):
+    for k in ("n_records", "consumed", "n_bases", "n_hdr", "bad_record"):
+        assert getattr(info, k) == oinfo[k], k
+    for k in oarr:
+        assert arr[k].tobytes() == oarr[k].tobytes(), k
+
+
+@pytest.mark.gpu
+def test_gpu_ingest_matches_oracle_on_handmade_blocks():
+    from barbell_amd import annotate as A
+    from tests.common import config_groups
+
+    dm = A.Demuxer()
+    for g in config_groups("rbk24"):
+        dm.add_query_group(g)
+    text = fq(REC)
+    cases = [(fq(REC, nl, ln), True) for nl in (b"\n", b"\r\n") for ln in (True, False)]
+    cases += [(fq(REC) + b"\n\r\n\n", True), (b"", True), (b"@a\nAC\n+a\n@+\n@b\nG\n+\n+\n", True)]
+    cases += [(text[:cut], False) for cut in (1, 5, 40, len(text) - 1, len(text))]
+    for t, final in cases:
+        rc, info, arr = gpu_parse(dm, t, final)
+        orc, oinfo, oarr = po.fastq_parse(t, final)
+        assert rc == orc == 0
+        same(info, arr, oinfo, oarr)
+    good = fq(REC[:2])
+    for bad in (good + b"r3\nAC\n+\nII\n", good + b"@r3\nAC\n-\nII\n", good + b"@r3\nACG\n+\nII\n", b"\n" + good, good + b"@r3\nAC\n"):
+        assert gpu_parse(dm, bad, True)[0] == _abi.BB_E_FASTQ
+
+
+@pytest.mark.gpu
+def test_gpu_ingest_blocks_of_synthetic_reads_and_pipeline():
+    """FASTQ text of 6000 synthetic reads cut at arbitrary byte positions: the concatenation of the ingested
+    blocks equals the oracle's parse of the whole text; rows annotated from the HBM-resident batch equal the
+    rows from the host-packed reads."""
+    from barbell_amd import annotate as A, fastq as Q
+    from tests.common import config_groups
+
+    groups = config_groups("nbd96")
+    n = 6000
+    bases, offsets = A.synth_reads_host(groups, 77, 150, 5000, 0, n)
+    rng = np.random.default_rng(3)
+    quals = rng.integers(33, 90, size=len(bases), dtype=np.uint8)
+    recs = []
+    for i in range(n):
+        a, b = int(offsets[i]), int(offsets[i + 1])
+        recs.append(((b"read%d" % i) + (b" ch=%d  x" % (i % 9) if i % 3 else b""), bases[a:b].tobytes(), quals[a:b].tobytes()))
+    text = fq(recs)
+    orc, oinfo, oarr = po.fastq_parse(text, True)
+    assert orc == 0 and oinfo["n_records"] == n and oarr["bases"].tobytes() == bases.tobytes()
+    dm = A.Demuxer()
+    for g in groups:
+        dm.add_query_group(g)
+    rc, info, arr = gpu_parse(dm, text, True)
+    same(info, arr, oinfo, oarr)
+    # arbitrary block boundaries with carry-over
+    cuts = sorted(set(int(x) for x in rng.integers(1, len(text), size=7))) + [len(text)]
+    got = {k: [] for k in ("bases", "quals", "hdr")}
+    ids, carry, prev, total = [], b"", 0, 0
+    for c in cuts:
+        blk = carry + text[prev:c]
+        rc, info, arr = gpu_parse(dm, blk, c == len(text))
+        assert rc == 0
+        carry, prev = blk[int(info.consumed):], c
+        total += int(info.n_records)
+        for k in got:
+            got[k].append(arr[k].tobytes())
+        ids += Q.read_ids(arr)
+    assert total == n and carry == b""
+    for k in got:
+        assert b"".join(got[k]) == oarr[k].tobytes()
+    assert ids == [r[0].split()[0].decode() for r in recs]
+    # device-resident pipeline: ingest -> annotate from the batch's device pointers
+    info, batch = Q.ingest(dm, text, True)
+    import torch
+
+    d_rows = torch.empty(4 * n * 48, dtype=torch.uint8, device="cuda")
+    nr = dm.demux_dev(batch.d_bases, batch.d_offsets, n, d_rows.data_ptr(), 4 * n)
+    rows_dev = np.frombuffer(d_rows[: nr * 48].cpu().numpy().tobytes(), dtype=_abi.ROW_DTYPE)
+    rows_host = dm.demux_packed(bases, offsets)
+    assert rows_dev.tobytes() == rows_host.tobytes()
