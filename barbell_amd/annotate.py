@@ -28,6 +28,34 @@ class BarbellError(RuntimeError):
         super().__init__(f"barbell_amd error {code}: {msg}" + (f" ({detail})" if detail else ""))
 
 
+class DevBuf:
+    """a device allocation through the C-ABI (bb_dev_malloc / bb_dev_free); grows, never shrinks"""
+
+    def __init__(self, dm):
+        self.dm, self.ptr, self.cap = dm, None, 0
+
+    def ensure(self, nbytes):
+        if self.ptr is not None and nbytes <= self.cap:
+            return self.ptr
+        self.release()
+        p = C.c_void_p()
+        want = int(nbytes) + int(nbytes) // 4 + 256
+        self.dm._check(lib().bb_dev_malloc(self.dm._ctx(), want, C.byref(p)))
+        self.ptr, self.cap = p.value, want
+        return self.ptr
+
+    def download(self, arr, nbytes=None):
+        nbytes = arr.nbytes if nbytes is None else nbytes
+        if nbytes:
+            self.dm._check(lib().bb_dev_download(self.dm._ctx(), arr.ctypes.data, self.ptr, nbytes))
+        return arr
+
+    def release(self):
+        if self.ptr is not None and self.dm._h is not None:
+            lib().bb_dev_free(self.dm._h, self.ptr)
+        self.ptr, self.cap = None, 0
+
+
 class Demuxer:
     """Demuxer::new(alpha, verbose, min_score_frac, min_score_diff_frac) (searcher.rs:202)."""
 
@@ -37,6 +65,7 @@ class Demuxer:
         self.device = int(device)
         self.queries = []
         self._h = None
+        self._bufs = {}
 
     def add_query_group(self, group):  # searcher.rs:220-226
         if self._h is not None:
@@ -59,8 +88,17 @@ class Demuxer:
 
     def close(self):
         if self._h is not None:
+            for b in self._bufs.values():
+                b.release()
+            self._bufs = {}
             lib().bb_destroy(self._h)
             self._h = None
+
+    def buf(self, name):
+        """named device buffer owned by this demuxer (rows, verdicts, text, ...)"""
+        if name not in self._bufs:
+            self._bufs[name] = DevBuf(self)
+        return self._bufs[name]
 
     def __del__(self):
         try:
@@ -116,6 +154,20 @@ class Demuxer:
             raise BarbellError(rc, f"need {nr.value} rows")
         self._check(rc)
         return int(nr.value)
+
+    def demux_ingested(self, batch, n_reads):
+        """annotate the batch bb_fastq_ingest left in HBM; rows stay in the "rows" device buffer and a host
+        copy is returned"""
+        cap = max(64, 4 * n_reads)
+        while True:
+            d = self.buf("rows").ensure(cap * 48)
+            nr = C.c_uint64()
+            rc = lib().bb_annotate_batch_dev(self._ctx(), batch.d_bases, batch.d_offsets, n_reads, d, cap, C.byref(nr))
+            if rc == _abi.BB_E_CAPACITY:
+                cap = int(nr.value)
+                continue
+            self._check(rc)
+            return self.buf("rows").download(np.zeros(int(nr.value), dtype=_abi.ROW_DTYPE))
 
     # -- histogram / timing --------------------------------------------------------------------
     def counts(self):
@@ -220,11 +272,11 @@ def read_fastq(path):
 
 
 def annotate(read_files, out_file, query_groups, alpha=0.4, min_score=0.2, min_score_diff=0.1, max_flank_errors=None,
-             batch_reads=65536, device=0, filter_patterns=None, filtered_file=None, dropped_file=None, trim_folder=None,
+             batch_reads=0, block_bytes=512 << 20, device=0, filter_patterns=None, filtered_file=None, dropped_file=None, trim_folder=None,
              trim_config=None, inspector=None):
     """annotate_with_groups + annotate (annotator.rs:207-285): sets the flank threshold of each group
-    (explicit --flank-max-errors or the automatic cutoff), streams the FASTQ in batches through the
-    GPU and writes annotation.tsv.  With `filter_patterns` the filter step (filter.rs:10-119) runs on
+    (explicit --flank-max-errors or the automatic cutoff), hands the FASTQ text to the GPU block by block
+    (`block_bytes`, or `batch_reads` * 4096; records are parsed there, barbell_amd/fastq.py) and writes annotation.tsv.  With `filter_patterns` the filter step (filter.rs:10-119) runs on
     the rows of every batch while they are in HBM and `filtered_file` / `dropped_file` get the rows
     of passing / failing reads with their `cuts` column — what `barbell filter` would write from the
     annotation file.  With `trim_folder` (needs the filter) the trim step (trim.rs:317-480) runs on the same
@@ -268,45 +320,30 @@ def annotate(read_files, out_file, query_groups, alpha=0.4, min_score=0.2, min_s
             wrote[key] = True
         f.write("\n".join(lines) + "\n")
 
-    ids, seqs, hdrs, quals = [], [], [], []
+    from . import fastq as Q
 
-    def flush():
+    def process(info, batch):
         nonlocal total, found
-        if not ids:
-            return
-        bases, offsets = _abi.pack_reads(seqs)
-        rows = dm.demux_packed(bases, offsets)
-        total += len(ids)
+        n = int(info.n_records)
+        ids = Q.read_ids(Q.fetch(dm, info))
+        rows = dm.demux_ingested(batch, n)
+        total += n
         found += len(np.unique(rows["read_idx"]))
         emit("anno", format_rows(rows, ids, query_groups))
+        d_rows = dm.buf("rows").ptr
         if insp is not None:
-            insp.add(rows, ids)
+            insp.add(rows, ids, d_rows=d_rows)
         if flt is not None:
-            v = flt.verdicts(rows)
+            v = flt.verdicts_ingested(d_rows, len(rows))
             keep = v["pass"] == 1
             emit("kept", format_rows(rows[keep], ids, query_groups, v[keep]))
             emit("dropped", format_rows(rows[~keep], ids, query_groups, v[~keep]))
             if trimmer is not None:
-                for i, (sq, q) in enumerate(zip(seqs, quals)):
-                    if len(sq) != len(q):
-                        raise ValueError(f"FASTQ record '{ids[i]}' has {len(q)} quality values for {len(sq)} bases")
-                writers.write(trimmer.trim_batch(rows, v, bases, _abi.pack_reads(quals)[0], offsets, hdrs), ids)
-        ids.clear()
-        seqs.clear()
-        hdrs.clear()
-        quals.clear()
+                writers.write(trimmer.trim_ingested(d_rows, dm.buf("verdicts").ptr, len(rows), batch, info), ids)
 
     try:
-        for path in read_files:
-            for h, s, q in read_fastq_records(path):
-                ids.append(split_fastq_header(h.decode())[0])
-                seqs.append(s)
-                if trimmer is not None:
-                    hdrs.append(h)
-                    quals.append(q)
-                if len(ids) >= batch_reads:
-                    flush()
-        flush()
+        for info, batch in Q.batches(dm, read_files, batch_reads * 4096 if batch_reads else block_bytes):
+            process(info, batch)
     finally:
         for f in outs.values():
             if f is not None:

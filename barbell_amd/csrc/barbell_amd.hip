@@ -793,6 +793,36 @@ int bb_filter_rows(bb_ctx* c, const bb_row* rows, uint64_t n_rows, bb_row_verdic
     return BB_OK;
 }
 
+// ---- device buffers for hosts without a HIP binding ----------------------------------------------
+int bb_dev_malloc(bb_ctx* c, uint64_t bytes, void** d_ptr) {
+    if (!c || !d_ptr) return BB_E_INVALID;
+    *d_ptr = nullptr;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (hipMalloc(d_ptr, bytes ? bytes : 16) != hipSuccess) { (void)hipGetLastError(); c->last_error = "hipMalloc failed"; return BB_E_NOMEM; }
+    return BB_OK;
+}
+void bb_dev_free(bb_ctx* c, void* d_ptr) {
+    if (!c || !d_ptr) return;
+    (void)hipSetDevice(c->device);
+    (void)hipFree(d_ptr);
+}
+int bb_dev_download(bb_ctx* c, void* dst, const void* d_src, uint64_t bytes) {
+    if (!c || ((!dst || !d_src) && bytes)) return BB_E_INVALID;
+    if (!bytes) return BB_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return BB_OK;
+}
+int bb_dev_upload(bb_ctx* c, void* d_dst, const void* src, uint64_t bytes) {
+    if (!c || ((!d_dst || !src) && bytes)) return BB_E_INVALID;
+    if (!bytes) return BB_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return BB_OK;
+}
+
 // ---- inspect step (include/barbell_amd_inspect.h) ------------------------------------------------
 int bb_inspect_rows_dev(bb_ctx* c, const bb_row* d_rows, const bb_row_verdict* d_ver, uint64_t n_rows, uint32_t bucket_size,
                         bb_inspect_elem* d_out) {

@@ -24,7 +24,7 @@ struct bb_fastq_state {
     // text staging (host variant)
     uint8_t* d_text = nullptr; uint64_t cap_text = 0;
     // newline pass
-    uint32_t *d_cnt = nullptr, *d_cbase = nullptr; uint64_t cap_cnt = 0, cap_cbase = 0;
+    uint32_t* d_cnt = nullptr; uint64_t* d_cbase = nullptr; uint64_t cap_cnt = 0, cap_cbase = 0;
     uint64_t* d_nl = nullptr; uint64_t cap_nl = 0;
     uint64_t* d_misc = nullptr;  // [0] newline total, [1] sums scratch total, [2] bases total, [3] hdr total, [4] bad record
     // records
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void k_nl_count(const uint8_t* __restrict__ te
     if (threadIdx.x == 0) cnt[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
 }
 
-__global__ __launch_bounds__(256) void k_nl_write(const uint8_t* __restrict__ text, uint64_t len, const uint32_t* __restrict__ base,
+__global__ __launch_bounds__(256) void k_nl_write(const uint8_t* __restrict__ text, uint64_t len, const uint64_t* __restrict__ base,
                                                   uint64_t* __restrict__ nl) {
     __shared__ uint32_t s_w[4];
     const uint64_t pos = ((uint64_t)blockIdx.x * 256u + threadIdx.x) * 16u;
@@ -98,28 +98,13 @@ __global__ __launch_bounds__(256) void k_nl_write(const uint8_t* __restrict__ te
     for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(inc, d, 64); if (lane >= d) inc += y; }
     if (lane == 63) s_w[wv] = inc;
     __syncthreads();
-    uint32_t o = base[blockIdx.x] + inc - c;
+    uint64_t o = base[blockIdx.x] + inc - c;
     for (int i = 0; i < wv; ++i) o += s_w[i];
     while (m) {
         const int b = __ffs(m) - 1;
         nl[o++] = pos + (uint64_t)b;
         m &= m - 1u;
     }
-}
-
-// exclusive scan of u32 -> u32 over the per-block newline counts (few entries: text_len / 4096)
-__global__ __launch_bounds__(64) void k_scan_small(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint32_t n, uint64_t* __restrict__ total) {
-    uint32_t carry = 0;
-    const int lane = threadIdx.x;
-    for (uint32_t b = 0; b < n; b += 64) {
-        const uint32_t x = b + lane < n ? in[b + lane] : 0u;
-        uint32_t inc = x;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(inc, d, 64); if (lane >= d) inc += y; }
-        if (b + lane < n) out[b + lane] = carry + inc - x;
-        carry += __shfl(inc, 63, 64);
-    }
-    if (lane == 0) total[0] = carry;
 }
 
 __device__ __forceinline__ bool is_ws(uint8_t c) { return c == ' ' || (c >= 9 && c <= 13); }
@@ -256,15 +241,14 @@ extern "C" int bb_fastq_ingest_dev(bb_ctx* ctx, const uint8_t* d_text, uint64_t 
     if (text_len) {
         const uint32_t nb = (uint32_t)((text_len + 4095) / 4096);
         if ((r = fgrow(v, s->d_cnt, s->cap_cnt, nb))) return r;
-        if ((r = fgrow(v, s->d_cbase, s->cap_cbase, nb))) return r;
+        if ((r = fgrow(v, s->d_cbase, s->cap_cbase, (uint64_t)nb + 1))) return r;
         hipLaunchKernelGGL(k_nl_count, dim3(nb), dim3(256), 0, st, d_text, text_len, s->d_cnt);
-        hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(64), 0, st, (const uint32_t*)s->d_cnt, s->d_cbase, nb, s->d_misc);
-        FCHK(v, hipGetLastError());
+        if ((r = scan64(v, s, s->d_cnt, s->d_cbase, nb, s->d_misc))) return r;
         FCHK(v, hipMemcpyAsync(&n_lines, s->d_misc, 8, hipMemcpyDeviceToHost, st));
         FCHK(v, hipMemcpyAsync(&last_byte, d_text + text_len - 1, 1, hipMemcpyDeviceToHost, st));
         FCHK(v, hipStreamSynchronize(st));
         if ((r = fgrow(v, s->d_nl, s->cap_nl, n_lines + 2))) return r;
-        hipLaunchKernelGGL(k_nl_write, dim3(nb), dim3(256), 0, st, d_text, text_len, (const uint32_t*)s->d_cbase, s->d_nl);
+        hipLaunchKernelGGL(k_nl_write, dim3(nb), dim3(256), 0, st, d_text, text_len, (const uint64_t*)s->d_cbase, s->d_nl);
         FCHK(v, hipGetLastError());
         if (final_block && last_byte != '\n') {  // last line without a newline: a virtual one at text_len
             FCHK(v, hipMemcpyAsync(s->d_nl + n_lines, &text_len, 8, hipMemcpyHostToDevice, st));

@@ -19,7 +19,7 @@ static void usage() {
         "Usage: barbell-amd annotate -i <FASTQ>... [-o output.tsv] (--kit <KIT> | -q <FASTA>... [-b Ftag|Rtag ...])\n"
         "                            [--flank-max-errors INT] [--min-score F=0.2] [--min-score-diff F=0.1]\n"
         "                            [--alpha F=0.4] [--use-extended] [-t THREADS=10] [--verbose]\n"
-        "                            [--batch-reads N=65536] [--device D=0]\n"
+        "                            [--block-bytes N=512Mi | --batch-reads N (= N*4096 bytes)] [--device D=0]\n"
         "                            [(-f <PATTERN_FILE>... | --kit-filter [--maximize]) [--filtered FILE] [--dropped FILE]]\n"
         "                            [--trim-output DIR [--no-label] [--no-orientation] [--no-flanks] [--sort-labels]\n"
         "                             [--only-side left|right] [--failed-out FILE] [--skip-trim] [--flip] [--gzip]]\n"
@@ -113,6 +113,7 @@ int main(int argc, char** argv) {
         else if (a == "--min-score-diff") { cfg.min_score_diff = atof(need("--min-score-diff")); multi = nullptr; }
         else if (a == "--alpha") { cfg.alpha = (float)atof(need("--alpha")); multi = nullptr; }
         else if (a == "--batch-reads") { cfg.batch_reads = (size_t)atol(need("--batch-reads")); multi = nullptr; }
+        else if (a == "--block-bytes") { cfg.block_bytes = (size_t)atoll(need("--block-bytes")); multi = nullptr; }
         else if (a == "--device") { cfg.device = atoi(need("--device")); multi = nullptr; }
         else if (a == "-f" || a == "--filter-file") { multi = &pattern_files; }
         else if (a == "--filtered") { cfg.filtered_file = need("--filtered"); multi = nullptr; }

@@ -294,7 +294,10 @@ std::vector<Pattern> kit_patterns(const std::string& kit_in, bool maximize) {
 // ---- Demuxer ------------------------------------------------------------------------------------
 Demuxer::Demuxer(float alpha, bool verbose, double min_score_frac, double min_score_diff_frac, int device)
     : alpha_(alpha), verbose_(verbose), min_score_(min_score_frac), min_score_diff_(min_score_diff_frac), device_(device) {}
-Demuxer::~Demuxer() { if (ctx_) bb_destroy(ctx_); }
+Demuxer::~Demuxer() {
+    for (DevBuf* b : {&d_rows_, &d_ver_, &d_elems_, &d_text_, &d_slices_, &d_spans_, &d_status_}) b->release();
+    if (ctx_) bb_destroy(ctx_);
+}
 
 Demuxer& Demuxer::add_query_group(BarcodeGroup g) {
     if (ctx_) throw BarbellError(BB_E_INVALID, "add_query_group after the first demux call");
@@ -341,9 +344,13 @@ std::vector<BarbellMatch> Demuxer::demux_batch(const std::vector<std::string>& r
     }
     if (rc != BB_OK) throw BarbellError(rc, std::string("bb_annotate_batch: ") + bb_strerror(rc) + " " + bb_last_error(ctx_));
     n_rows_ = n_rows;
+    return rows_to_matches(read_ids);
+}
+
+std::vector<BarbellMatch> Demuxer::rows_to_matches(const std::vector<std::string>& read_ids) const {
     std::vector<BarbellMatch> out;
-    out.reserve(n_rows);
-    for (uint64_t i = 0; i < n_rows; ++i) {
+    out.reserve(n_rows_);
+    for (uint64_t i = 0; i < n_rows_; ++i) {
         const bb_row& r = rows_[i];
         const BarcodeGroup& g = queries_[r.group_idx];
         BarbellMatch m;
@@ -499,6 +506,10 @@ std::vector<std::pair<uint32_t, std::string>> Demuxer::inspect_last_batch(const 
         const int rc = bb_inspect_rows(ctx_, rows_.data(), verdicts ? verdicts->data() : nullptr, n_rows_, bucket_size, el.data());
         if (rc != BB_OK) throw BarbellError(rc, std::string("bb_inspect_rows: ") + bb_strerror(rc) + " " + bb_last_error(ctx_));
     }
+    return elems_to_patterns(el);
+}
+
+std::vector<std::pair<uint32_t, std::string>> Demuxer::elems_to_patterns(const std::vector<bb_inspect_elem>& el) const {
     static const char* const TAG[] = {"", "@left", "@right", "@prev_left"};
     std::vector<std::pair<uint32_t, std::string>> out;
     for (uint64_t i = 0; i < n_rows_; ++i) {  // "{type}[{fw|rc}, *{cut}, {tag}({lo}..{hi})]" joined by "__" (inspect.rs:90-104)
@@ -522,41 +533,143 @@ std::vector<std::string> inspect_summary(const AnnotateStats& st, size_t top_n) 
     return lines;
 }
 
+// ---- device-resident path -------------------------------------------------------------------------
+void DevBuf::ensure(bb_ctx* c, uint64_t bytes) {
+    if (p && bytes <= cap) return;
+    release();
+    ctx = c;
+    const uint64_t want = bytes + bytes / 4 + 256;
+    const int rc = bb_dev_malloc(c, want, &p);
+    if (rc != BB_OK) throw BarbellError(rc, std::string("bb_dev_malloc: ") + bb_strerror(rc));
+    cap = want;
+}
+void DevBuf::release() {
+    if (p) bb_dev_free(ctx, p);
+    p = nullptr; cap = 0;
+}
+
+#define BB_THROW(rc, what) throw BarbellError((rc), std::string(what ": ") + bb_strerror(rc) + " " + bb_last_error(ctx_))
+
+Demuxer::Ingested Demuxer::ingest(const uint8_t* text, uint64_t len, bool final_block) {
+    ensure_ctx();
+    ing_ = Ingested{};
+    n_rows_ = 0;
+    int rc = bb_fastq_ingest(ctx_, text, len, final_block ? 1 : 0, &ing_.info, &batch_);
+    if (rc != BB_OK) BB_THROW(rc, "bb_fastq_ingest");
+    const uint64_t n = ing_.info.n_records;
+    std::vector<uint8_t> hdr(ing_.info.n_hdr);
+    std::vector<uint64_t> hoff(n + 1);
+    std::vector<uint32_t> idl(n);
+    rc = bb_fastq_fetch(ctx_, nullptr, hdr.data(), hoff.data(), idl.data(), nullptr, nullptr, nullptr);
+    if (rc != BB_OK) BB_THROW(rc, "bb_fastq_fetch");
+    ing_.ids.reserve(n);
+    for (uint64_t i = 0; i < n; ++i) ing_.ids.emplace_back((const char*)hdr.data() + hoff[i], idl[i]);
+    return ing_;
+}
+
+std::vector<BarbellMatch> Demuxer::demux_ingested() {
+    const uint32_t n = (uint32_t)ing_.info.n_records;
+    uint64_t cap = 4ull * n + 64, n_rows = 0;
+    d_rows_.ensure(ctx_, cap * sizeof(bb_row));
+    int rc = bb_annotate_batch_dev(ctx_, batch_.d_bases, batch_.d_offsets, n, (bb_row*)d_rows_.p, cap, &n_rows);
+    if (rc == BB_E_CAPACITY) {
+        cap = n_rows;
+        d_rows_.ensure(ctx_, cap * sizeof(bb_row));
+        rc = bb_annotate_batch_dev(ctx_, batch_.d_bases, batch_.d_offsets, n, (bb_row*)d_rows_.p, cap, &n_rows);
+    }
+    if (rc != BB_OK) BB_THROW(rc, "bb_annotate_batch_dev");
+    n_rows_ = n_rows;
+    if (rows_.size() < n_rows) rows_.resize(n_rows);
+    if ((rc = bb_dev_download(ctx_, rows_.data(), d_rows_.p, n_rows * sizeof(bb_row))) != BB_OK) BB_THROW(rc, "bb_dev_download");
+    return rows_to_matches(ing_.ids);
+}
+
+std::vector<bb_row_verdict> Demuxer::filter_ingested() {
+    if (!has_filter_) throw BarbellError(BB_E_INVALID, "filter_ingested without set_filter");
+    std::vector<bb_row_verdict> v(n_rows_);
+    d_ver_.ensure(ctx_, (n_rows_ + 1) * sizeof(bb_row_verdict));
+    if (n_rows_) {
+        int rc = bb_filter_rows_dev(ctx_, (const bb_row*)d_rows_.p, n_rows_, (bb_row_verdict*)d_ver_.p);
+        if (rc != BB_OK) BB_THROW(rc, "bb_filter_rows_dev");
+        if ((rc = bb_dev_download(ctx_, v.data(), d_ver_.p, n_rows_ * sizeof(bb_row_verdict))) != BB_OK) BB_THROW(rc, "bb_dev_download");
+    }
+    return v;
+}
+
+std::vector<std::pair<uint32_t, std::string>> Demuxer::inspect_ingested(bool with_verdicts, uint32_t bucket_size) {
+    std::vector<bb_inspect_elem> el(n_rows_);
+    if (n_rows_) {
+        d_elems_.ensure(ctx_, n_rows_ * sizeof(bb_inspect_elem));
+        int rc = bb_inspect_rows_dev(ctx_, (const bb_row*)d_rows_.p, with_verdicts ? (const bb_row_verdict*)d_ver_.p : nullptr, n_rows_, bucket_size,
+                                     (bb_inspect_elem*)d_elems_.p);
+        if (rc != BB_OK) BB_THROW(rc, "bb_inspect_rows_dev");
+        if ((rc = bb_dev_download(ctx_, el.data(), d_elems_.p, n_rows_ * sizeof(bb_inspect_elem))) != BB_OK) BB_THROW(rc, "bb_dev_download");
+    }
+    return elems_to_patterns(el);
+}
+
+TrimBatch Demuxer::trim_ingested() {
+    if (!has_trim_) throw BarbellError(BB_E_INVALID, "trim_ingested without set_trim");
+    const uint32_t n = (uint32_t)ing_.info.n_records;
+    TrimBatch t;
+    t.status.assign(n, 0);
+    uint64_t text_cap = 2 * ing_.info.n_bases + 2 * ing_.info.n_hdr + 32ull * n + 1024, slices_cap = 2ull * n + 64;
+    uint32_t spans_cap = 4096;
+    d_status_.ensure(ctx_, (uint64_t)n + 16);
+    for (;;) {
+        d_text_.ensure(ctx_, text_cap);
+        d_slices_.ensure(ctx_, slices_cap * sizeof(bb_slice));
+        d_spans_.ensure(ctx_, (uint64_t)spans_cap * sizeof(bb_label_span));
+        uint64_t tl = 0, ns = 0;
+        uint32_t nsp = 0;
+        const int rc = bb_trim_batch_dev(ctx_, (const bb_row*)d_rows_.p, (const bb_row_verdict*)d_ver_.p, n_rows_, batch_.d_bases, batch_.d_quals,
+                                         batch_.d_offsets, &batch_.d_headers, n, (uint8_t*)d_text_.p, text_cap, &tl, (bb_slice*)d_slices_.p, slices_cap,
+                                         &ns, (bb_label_span*)d_spans_.p, spans_cap, &nsp, (uint8_t*)d_status_.p);
+        if (rc == BB_E_CAPACITY) {
+            text_cap = std::max(text_cap, tl); slices_cap = std::max(slices_cap, ns); spans_cap = std::max(spans_cap, nsp);
+            continue;
+        }
+        if (rc != BB_OK) BB_THROW(rc, "bb_trim_batch_dev");
+        t.text.resize(tl); t.slices.resize(ns); t.spans.resize(nsp);
+        int r2;
+        if ((r2 = bb_dev_download(ctx_, t.text.data(), d_text_.p, tl)) != BB_OK) BB_THROW(r2, "bb_dev_download");
+        if ((r2 = bb_dev_download(ctx_, t.slices.data(), d_slices_.p, ns * sizeof(bb_slice))) != BB_OK) BB_THROW(r2, "bb_dev_download");
+        if ((r2 = bb_dev_download(ctx_, t.spans.data(), d_spans_.p, (uint64_t)nsp * sizeof(bb_label_span))) != BB_OK) BB_THROW(r2, "bb_dev_download");
+        if ((r2 = bb_dev_download(ctx_, t.status.data(), d_status_.p, n)) != BB_OK) BB_THROW(r2, "bb_dev_download");
+        return t;
+    }
+}
+
 // ---- annotate (annotator.rs) ----------------------------------------------------------------------
 namespace {
 // the automatic flank cutoff (edit_model.rs:2-11) is applied inside bb_create when k_cutoff is unset
-struct FastqReader {  // plain or gzip (gzopen reads both), 4-line records; src/io/io.rs:29-33
-    gzFile f;
-    std::vector<char> buf;
-    explicit FastqReader(const std::string& path) : f(gzopen(path.c_str(), "rb")), buf(1 << 20) {
+// Raw FASTQ text in blocks: plain or gzip (gzread reads both).  The record parser is on the GPU
+// (bb_fastq_ingest); the partial record at the end of a block is carried over to the next one.
+struct BlockSource {
+    gzFile f = nullptr;
+    std::vector<uint8_t> buf;
+    size_t have = 0;  // bytes of carry at the front of buf
+    explicit BlockSource(const std::string& path) : f(gzopen(path.c_str(), "rb")) {
         if (!f) throw BarbellError(BB_E_INVALID, "Failed to open FASTQ input: " + path);
         gzbuffer(f, 1 << 20);
     }
-    ~FastqReader() { if (f) gzclose(f); }
-    bool line(std::string& out) {
-        out.clear();
-        for (;;) {
-            if (!gzgets(f, buf.data(), (int)buf.size())) return !out.empty();
-            const size_t len = strlen(buf.data());
-            out.append(buf.data(), len);
-            if (len && buf[len - 1] == '\n') break;
-            if (len + 1 < buf.size()) break;  // EOF without newline
+    ~BlockSource() { if (f) gzclose(f); }
+    // appends up to `want` bytes after the carry; returns true when the file is exhausted
+    bool fill(size_t want) {
+        buf.resize(have + want);
+        size_t got = 0;
+        while (got < want) {
+            const int r = gzread(f, buf.data() + have + got, (unsigned)std::min<size_t>(want - got, 1u << 30));
+            if (r < 0) throw BarbellError(BB_E_INVALID, "Error reading FASTQ file");
+            if (r == 0) break;
+            got += (size_t)r;
         }
-        while (!out.empty() && (out.back() == '\n' || out.back() == '\r')) out.pop_back();
-        return true;
+        have += got;
+        return got < want;
     }
-    // header = line without '@'; id_len / desc_start: split_fastq_header (io.rs:6-17; ASCII whitespace)
-    bool next(std::string& header, std::string& seq, std::string& qual, size_t& id_len, size_t& desc_start) {
-        std::string h, plus;
-        do { if (!line(h)) return false; } while (h.empty());
-        if (h[0] != '@') throw BarbellError(BB_E_INVALID, "Input FASTQ parsing failed: record does not start with '@'");
-        if (!line(seq) || !line(plus) || !line(qual)) throw BarbellError(BB_E_INVALID, "Input FASTQ parsing failed: truncated record");
-        header = h.substr(1);
-        const size_t ws = header.find_first_of(" \t\n\v\f\r");
-        id_len = ws == std::string::npos ? header.size() : ws;
-        desc_start = id_len;
-        while (desc_start < header.size() && strchr(" \t\n\v\f\r", header[desc_start])) ++desc_start;
-        return true;
+    void consume(size_t n) {
+        memmove(buf.data(), buf.data() + n, have - n);
+        have -= n;
     }
 };
 
@@ -638,7 +751,6 @@ AnnotateStats annotate(const std::vector<std::string>& read_files, const std::st
     if (config.inspect && !config.read_pattern_out.empty()) ppr_f = fopen(config.read_pattern_out.c_str(), "w");
     std::map<std::string, size_t> pattern_count;
     std::vector<std::string> pattern_order;  // first-appearance order, for a deterministic tie order in the summary
-    FastqBatch b;
     bool header = false;
     auto close_all = [&]() {
         fclose(out);
@@ -648,12 +760,15 @@ AnnotateStats annotate(const std::vector<std::string>& read_files, const std::st
         if (ppr_f) fclose(ppr_f);
         writers.reset();
     };
-    auto flush = [&]() {
-        if (b.ids.empty()) return;
-        auto rows = dm.demux_batch(b.ids, b.bases, b.offsets);
-        st.total += b.ids.size();
+    // one block of text: parsed, annotated, filtered, inspected and trimmed in HBM; only rows, verdicts,
+    // pattern elements and the rendered records come back
+    auto process = [&](const Demuxer::Ingested& ing) {
+        const auto& ids = ing.ids;
+        if (ids.empty()) return;
+        auto rows = dm.demux_ingested();
+        st.total += ids.size();
         std::vector<bb_row_verdict> verdicts;
-        if (filtering) verdicts = dm.filter_last_batch();
+        if (filtering) verdicts = dm.filter_ingested();
         const std::string* last = nullptr;
         for (const auto& r : rows) {
             if (!header) { fputs(TSV_HEADER, out); fputc('\n', out); header = true; }  // csv writer: header with the first record
@@ -663,8 +778,8 @@ AnnotateStats annotate(const std::vector<std::string>& read_files, const std::st
             last = &r.read_id;
         }
         if (config.inspect) {  // inspect.rs:128-184 on the annotation rows (no cuts yet)
-            for (auto& rp : dm.inspect_last_batch(nullptr, config.bucket_size)) {
-                if (ppr_f) fprintf(ppr_f, "%s\t%s\n", b.ids[rp.first].c_str(), rp.second.c_str());
+            for (auto& rp : dm.inspect_ingested(false, config.bucket_size)) {
+                if (ppr_f) fprintf(ppr_f, "%s\t%s\n", ids[rp.first].c_str(), rp.second.c_str());
                 auto it = pattern_count.find(rp.second);
                 if (it == pattern_count.end()) { pattern_count.emplace(rp.second, 1); pattern_order.push_back(rp.second); }
                 else ++it->second;
@@ -688,41 +803,30 @@ AnnotateStats annotate(const std::vector<std::string>& read_files, const std::st
             fputc('\n', f);
         }
         if (trimming) {  // trim.rs:385-460: the GPU cut and rendered the records, one write per label
-            const TrimBatch t = dm.trim_last_batch(verdicts, b);
+            const TrimBatch t = dm.trim_ingested();
             for (const auto& sp : t.spans) writers->write(dm.label_of_key(sp.label_key), t.text.data() + sp.off, sp.len);
-            std::vector<uint32_t> per_read(b.ids.size(), 0);
+            std::vector<uint32_t> per_read(ids.size(), 0);
             for (const auto& sl : t.slices) ++per_read[sl.read_idx];
-            for (size_t i = 0; i < b.ids.size(); ++i) {
+            for (size_t i = 0; i < ids.size(); ++i) {
                 if (t.status[i] == BB_TRIM_TRIMMED) ++st.trimmed;
                 if (per_read[i] > 1) ++st.trimmed_split;
-                if (t.status[i] == BB_TRIM_FAILED) { ++st.trim_failed; if (failed_f) fprintf(failed_f, "%s\n", b.ids[i].c_str()); }
+                if (t.status[i] == BB_TRIM_FAILED) { ++st.trim_failed; if (failed_f) fprintf(failed_f, "%s\n", ids[i].c_str()); }
             }
         }
         st.rows += rows.size();
-        b.clear();
     };
+    const size_t block = config.batch_reads ? std::max<size_t>(config.batch_reads * 4096, 4096) : std::max<size_t>(config.block_bytes, 4096);
     try {
         for (const auto& path : read_files) {
-            FastqReader rd(path);
-            std::string hd, seq, qual;
-            size_t idl, ds;
-            while (rd.next(hd, seq, qual, idl, ds)) {
-                b.ids.push_back(hd.substr(0, idl));
-                b.bases.insert(b.bases.end(), seq.begin(), seq.end());
-                b.offsets.push_back(b.bases.size());
-                if (trimming) {
-                    if (qual.size() != seq.size())
-                        throw BarbellError(BB_E_INVALID, "FASTQ record '" + b.ids.back() + "' has no matching quality scores");
-                    b.quals.insert(b.quals.end(), qual.begin(), qual.end());
-                    b.hdr.insert(b.hdr.end(), hd.begin(), hd.end());
-                    b.hdr_offsets.push_back(b.hdr.size());
-                    b.id_len.push_back((uint32_t)idl);
-                    b.desc_start.push_back((uint32_t)ds);
-                }
-                if (b.ids.size() >= config.batch_reads) flush();
+            BlockSource src(path);
+            for (;;) {
+                const bool eof = src.fill(block);
+                const auto ing = dm.ingest(src.buf.data(), src.have, eof);
+                process(ing);
+                src.consume((size_t)ing.info.consumed);
+                if (eof) break;
             }
         }
-        flush();
     } catch (...) {
         close_all();
         throw;

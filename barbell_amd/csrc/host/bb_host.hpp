@@ -10,6 +10,7 @@
 //   TrimConfig / LabelSide / label + file naming          src/config.rs:19-32, src/trim/trim.rs:24-105, 317-480
 //   get_group_structure strings, inspect summary          src/inspect/inspect.rs:15-208
 //   demux_using_kit                                        src/kits/use_kit.rs:11-109
+//   FASTQ record loop -> GPU block ingest                  src/io/io.rs:6-33, annotator.rs:245-262, trim.rs:364-384
 // The per-read call `Demuxer::demux(read_id, read)` (searcher.rs:430) becomes `demux_batch`: one
 // bb_annotate_batch per batch.  All arithmetic of the path runs in the HIP kernels of
 // libbarbell_amd.so; nothing here computes alignments.
@@ -22,6 +23,7 @@
 #include <vector>
 
 #include "../../../include/barbell_amd.h"
+#include "../../../include/barbell_amd_fastq.h"
 #include "../../../include/barbell_amd_filter.h"
 #include "../../../include/barbell_amd_inspect.h"
 #include "../../../include/barbell_amd_trim.h"
@@ -109,6 +111,16 @@ struct BarbellMatch {  // searcher.rs:31-64
 };
 extern const char* const TSV_HEADER;
 
+// A device allocation owned through the C-ABI (bb_dev_malloc / bb_dev_free); grows, never shrinks.
+struct DevBuf {
+    bb_ctx* ctx = nullptr;
+    void* p = nullptr;
+    uint64_t cap = 0;
+    void ensure(bb_ctx* c, uint64_t bytes);
+    void release();
+    ~DevBuf() { release(); }
+};
+
 class Demuxer {
 public:
     Demuxer(float alpha, bool verbose, double min_score_frac, double min_score_diff_frac, int device = 0);  // searcher.rs:202
@@ -128,6 +140,15 @@ public:
     std::string label_of_key(uint32_t key) const;  // LabelConfig::create_label's string for a bb_slice.label_key
     // inspect step (inspect.rs:15-117) on the rows of the LAST batch: one pattern string per read with rows
     std::vector<std::pair<uint32_t, std::string>> inspect_last_batch(const std::vector<bb_row_verdict>* verdicts, uint32_t bucket_size);
+    // ---- device-resident path: one block of raw FASTQ text -> everything else happens in HBM ----------
+    // ingest() parses the block on the GPU (bb_fastq_ingest) and fetches only the headers; the *_ingested
+    // calls run on the batch it left in HBM and download rows / verdicts / rendered text.
+    struct Ingested { bb_fastq_info info{}; std::vector<std::string> ids; };
+    Ingested ingest(const uint8_t* text, uint64_t len, bool final_block);
+    std::vector<BarbellMatch> demux_ingested();
+    std::vector<bb_row_verdict> filter_ingested();
+    TrimBatch trim_ingested();
+    std::vector<std::pair<uint32_t, std::string>> inspect_ingested(bool with_verdicts, uint32_t bucket_size);
     bb_group_info group_info(size_t g);
     const std::vector<BarcodeGroup>& queries() const { return queries_; }
 
@@ -145,6 +166,11 @@ private:
     TrimConfig trim_cfg_;
     std::vector<std::string> label_strings_;  // by label id (ids as handed to bb_filter_set)
     std::string part_str(uint32_t part) const;
+    std::vector<std::pair<uint32_t, std::string>> elems_to_patterns(const std::vector<bb_inspect_elem>& el) const;
+    std::vector<BarbellMatch> rows_to_matches(const std::vector<std::string>& read_ids) const;
+    bb_fastq_batch_dev batch_{};
+    Ingested ing_;
+    DevBuf d_rows_, d_ver_, d_elems_, d_text_, d_slices_, d_spans_, d_status_;
 };
 
 struct AnnotateConfig {  // config.rs:3-12 with the CLI defaults of bin/main.rs:64-112
@@ -154,7 +180,8 @@ struct AnnotateConfig {  // config.rs:3-12 with the CLI defaults of bin/main.rs:
     bool verbose = false;
     double min_score = 0.2, min_score_diff = 0.1;
     bool use_extended = false;
-    size_t batch_reads = 65536;
+    size_t batch_reads = 0;               // if set: block_bytes = batch_reads * 4096 (kept for CLI compatibility)
+    size_t block_bytes = 512u << 20;      // raw FASTQ text handed to the GPU per ingest call
     int device = 0;
     // fused filter step: when filter_patterns is non-empty, rows of passing / failing reads go to
     // filtered_file / dropped_file with their cuts column (what `barbell filter -o/--dropped` writes)
@@ -184,7 +211,7 @@ struct KitConfig {  // config.rs:34-48, CLI defaults bin/main.rs:208-262
     bool use_extended = false;
     float alpha = 0.4f;
     bool gzip = false;
-    size_t batch_reads = 65536;
+    size_t batch_reads = 0;
     int device = 0;
 };
 AnnotateStats demux_using_kit(const std::vector<std::string>& fastq_files, const KitConfig& config);  // use_kit.rs:11-109

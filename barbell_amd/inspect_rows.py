@@ -27,6 +27,18 @@ def elements(dm, rows, verdicts=None, bucket_size=250):
     return out
 
 
+def elements_dev(dm, d_rows, d_verdicts, n_rows, bucket_size=250):
+    """same for rows (and verdicts) that are already in HBM"""
+    from ._lib import lib
+
+    out = np.zeros(n_rows, dtype=INSPECT_DTYPE)
+    if n_rows:
+        d = dm.buf("elems").ensure(n_rows * 16)
+        dm._check(lib().bb_inspect_rows_dev(dm._ctx(), d_rows, d_verdicts, n_rows, bucket_size, d))
+        dm.buf("elems").download(out)
+    return out
+
+
 def element_str(e):  # inspect.rs:90-101
     cut = (", >>" if e["strand"] else ", <<") if e["has_cut"] else ""
     return f"{_abi.MATCH_TYPE_STR[int(e['match_type'])]}[{'rc' if e['strand'] else 'fw'}, *{cut}, {_TAG[int(e['tag'])]}({int(e['lo'])}..{int(e['hi'])})]"
@@ -60,8 +72,10 @@ class Inspector:
         self.counts = Counter()
         self.out = open(read_pattern_out, "w") if read_pattern_out else None
 
-    def add(self, rows, read_ids, verdicts=None):
-        pats = patterns(elements(self.dm, rows, verdicts, self.bucket_size), rows)
+    def add(self, rows, read_ids, verdicts=None, d_rows=None):
+        el = elements_dev(self.dm, d_rows, None, len(rows), self.bucket_size) if d_rows is not None else \
+            elements(self.dm, rows, verdicts, self.bucket_size)
+        pats = patterns(el, rows)
         self.counts.update(p for _, p in pats)
         if self.out is not None:
             self.out.write("".join(f"{read_ids[i]}\t{p}\n" for i, p in pats))

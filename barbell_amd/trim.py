@@ -170,9 +170,31 @@ class Trimmer:
         if rc == _abi.BB_E_CAPACITY:
             from .annotate import BarbellError
 
-            raise BarbellError(rc, f"need text {tl.value} slices {ns.value} spans {nsp.value}")
+            e = BarbellError(rc, f"need text {tl.value} slices {ns.value} spans {nsp.value}")
+            e.need = (int(tl.value), int(ns.value), int(nsp.value))
+            raise e
         self.dm._check(rc)
         return int(tl.value), int(ns.value), int(nsp.value)
+
+    def trim_ingested(self, d_rows, d_verdicts, n_rows, batch, info):
+        """trim the batch bb_fastq_ingest left in HBM with rows / verdicts that are there too -> TrimResult"""
+        n = int(info.n_records)
+        dm = self.dm
+        tcap, scap, pcap = 2 * int(info.n_bases) + 2 * int(info.n_hdr) + 32 * n + 1024, 2 * n + 64, 4096
+        d_st = dm.buf("status").ensure(n + 16)
+        h = batch.d_headers
+        while True:
+            try:
+                tl, ns, nsp = self.trim_batch_dev(d_rows, d_verdicts, n_rows, batch.d_bases, batch.d_quals, batch.d_offsets, h.hdr, h.hdr_offsets,
+                                                  h.id_len, h.desc_start, n, dm.buf("text").ensure(tcap), tcap, dm.buf("slices").ensure(scap * 32),
+                                                  scap, dm.buf("spans").ensure(pcap * 32), pcap, d_st)
+                break
+            except Exception as e:  # BB_E_CAPACITY carries the needed sizes
+                if getattr(e, "code", None) != _abi.BB_E_CAPACITY:
+                    raise
+                tcap, scap, pcap = max(tcap, e.need[0]), max(scap, e.need[1]), max(pcap, e.need[2])
+        return TrimResult(dm.buf("text").download(np.empty(tl, np.uint8)), dm.buf("slices").download(np.zeros(ns, SLICE_DTYPE)),
+                          dm.buf("spans").download(np.zeros(nsp, SPAN_DTYPE)), dm.buf("status").download(np.zeros(n, np.uint8)))
 
     def last_ms(self):
         from ._lib import lib

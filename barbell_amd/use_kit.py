@@ -14,7 +14,7 @@ from .trim import TrimConfig
 
 
 def demux_using_kit(fastq_files, kit_name, output_folder, maximize=False, verbose=False, min_score=0.2, min_score_diff=0.1,
-                    max_flank_errors=None, failed_out=None, use_extended=False, alpha=0.4, gzip=False, batch_reads=65536, device=0,
+                    max_flank_errors=None, failed_out=None, use_extended=False, alpha=0.4, gzip=False, batch_reads=0, device=0,
                     log=print):
     """KitConfig (config.rs:34-48) as keyword arguments.  Returns (total_reads, reads_with_rows, inspector)."""
     os.makedirs(output_folder, exist_ok=True)

@@ -158,6 +158,7 @@ def main():
             out["filter_step"], d_v = filter_leg(dm, d_rows, int(rows_per_launch), dev)
             out["trim_step"] = trim_leg(dm, d_rows, d_v, int(rows_per_launch), d_bases.data_ptr() + ((args.steps - 1) % n_batches) * batch * L,
                                         d_off_b, batch, L, dev)
+            out["ingest_step"] = ingest_leg(dm, d_bases.data_ptr() + ((args.steps - 1) % n_batches) * batch * L, batch, L, dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, groups, dm, d_bases, L)
         print(json.dumps(out), flush=True)
@@ -221,6 +222,53 @@ def trim_leg(dm, d_rows, d_v, n_rows, bases_ptr, d_off_b, batch, L, dev):
     return {"config": "kit driver (labels, left side only, full header)", "records": ns, "labels": nsp, "text_bytes": tl,
             "ms_plan_sort": ms["plan_sort"], "ms_render": ms["render"], "render_gb_per_s": gbs, "render_frac_of_hbm_peak": gbs / HBM_PEAK_GBS,
             "reads_trimmed": int((d_st == 1).sum().item()), "reads_failed": int((d_st == 2).sum().item())}
+
+
+def ingest_leg(dm, bases_ptr, batch, L, dev):
+    """SURVEY §8(f-3), outside the timed region: the batch as raw FASTQ text in HBM (fixed-width records built
+    with torch from the resident reads) parsed and packed by bb_fastq_ingest_dev; the packed bases must equal
+    the reads they were rendered from.  HBM-bound: text read twice (newline pass, pack pass), ~its size written."""
+    from barbell_amd import fastq as Q
+
+    W = 40
+    idx = np.arange(batch, dtype=np.int64)
+    hdr = np.tile(np.frombuffer(b"@r00000000 ch=0000 st=2024-01-01T00:00Z\n"[: W + 1], dtype=np.uint8), (batch, 1))
+    for d in range(8):
+        hdr[:, 9 - d] = 48 + (idx // 10 ** d) % 10
+    reads = _view_u8(bases_ptr, batch * L, dev).view(batch, L)
+    quals = torch.randint(33, 74, (batch, L), dtype=torch.uint8, device=dev)
+    sep = torch.tensor(list(b"\n+\n"), dtype=torch.uint8, device=dev).repeat(batch, 1)
+    nl = torch.full((batch, 1), 10, dtype=torch.uint8, device=dev)
+    text = torch.cat([torch.from_numpy(hdr).to(dev), reads, sep, quals, nl], dim=1).contiguous().view(-1)
+    del quals, sep, nl
+    n_text = text.numel()
+    info, b = Q.ingest(dm, n_text, True, device_ptr=text.data_ptr())
+    ok = int(info.n_records) == batch and int(info.n_bases) == batch * L and \
+        torch.equal(_view_u8(b.d_bases, batch * L, dev), reads.reshape(-1))
+    ms = 0.0
+    reps = 5
+    for _ in range(reps):
+        Q.ingest(dm, n_text, True, device_ptr=text.data_ptr())
+        ms += lib_ms(dm) / reps
+    moved = 2.0 * n_text + 2.0 * batch * L + batch * W  # newline pass + pack pass reads, packed arrays written
+    return {"records": int(info.n_records), "text_bytes": n_text, "ms": ms, "text_gb_per_s": n_text / (ms * 1e-3) / 1e9,
+            "hbm_gb_per_s": moved / (ms * 1e-3) / 1e9, "frac_of_hbm_peak": moved / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "round_trip_ok": bool(ok)}
+
+
+def lib_ms(dm):
+    from barbell_amd._lib import lib
+
+    return float(lib().bb_fastq_last_ms(dm._ctx()))
+
+
+def _view_u8(ptr, n, dev):
+    """torch uint8 view of n bytes of device memory at ptr (no copy)"""
+    class _A:  # __cuda_array_interface__ carrier
+        pass
+
+    a = _A()
+    a.__cuda_array_interface__ = {"shape": (n,), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+    return torch.as_tensor(a, device=dev)
 
 
 def load_traffic(args, batch, L, dom):

@@ -143,6 +143,13 @@ const char* bb_kernel_name(int k);
 float       bb_last_kernel_ms(const bb_ctx* ctx, int k);
 void        bb_set_timing(bb_ctx* ctx, int enable);
 
+/* Device buffers for callers of the *_dev entry points that have no HIP binding of their own (the Rust
+ * or C++ host): memory on the context's GPU, and copies ordered after the context's stream.         */
+int  bb_dev_malloc(bb_ctx* ctx, uint64_t bytes, void** d_ptr);
+void bb_dev_free(bb_ctx* ctx, void* d_ptr);
+int  bb_dev_download(bb_ctx* ctx, void* dst_host, const void* d_src, uint64_t bytes);
+int  bb_dev_upload(bb_ctx* ctx, void* d_dst, const void* src_host, uint64_t bytes);
+
 const char* bb_strerror(int code);
 const char* bb_last_error(const bb_ctx* ctx);   /* detail of the last BB_E_HIP / BB_E_UNSUPPORTED */
 
