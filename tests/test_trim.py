@@ -369,3 +369,64 @@ def test_fused_annotate_filter_trim_files(tmp_path, gz):
     assert len(exp) > 10 and got == exp
     failed = [hdr[i].split()[0].decode() for i in np.nonzero(want.status == T.TRIM_FAILED)[0]]
     assert open(tmp_path / "failed.txt").read().split() == failed
+
+
+@pytest.mark.gpu
+def test_render_ingest_round_trip_at_scale():
+    """size-independent property at a large batch (300 k reads, 0.6 GB): the FASTQ text the trim step renders,
+    fed back through the GPU FASTQ parser, yields exactly the slices it was cut from (sequence, qualities,
+    header = id[_n][ desc]) — trim and ingest are inverse byte movers."""
+    import torch
+
+    from barbell_amd import annotate as A, fastq as Q
+    from tests.common import config_groups
+
+    groups = config_groups("nbd96")
+    n, L = 300_000, 2000
+    dm = A.Demuxer()
+    for g in groups:
+        dm.add_query_group(g)
+    dev = torch.device("cuda:0")
+    d_off = torch.arange(0, n + 1, dtype=torch.int64, device=dev) * L
+    d_bases = torch.empty(n * L, dtype=torch.uint8, device=dev)
+    dm.synth_dev(4321, L, L, 0, n, d_off.data_ptr(), d_bases.data_ptr())
+    d_q = torch.randint(33, 90, (n * L,), dtype=torch.uint8, device=dev)
+    W = 24
+    idx = np.arange(n)
+    hdr = np.tile(np.frombuffer(b"r0000000 ch=000 st=xyz12", dtype=np.uint8), (n, 1))
+    for d in range(7):
+        hdr[:, 7 - d] = 48 + (idx // 10 ** d) % 10
+    d_hdr = torch.from_numpy(hdr.reshape(-1)).to(dev)
+    d_hoff = torch.arange(0, n + 1, dtype=torch.int64, device=dev) * W
+    d_idl = torch.full((n,), 8, dtype=torch.int32, device=dev)
+    d_ds = torch.full((n,), 9, dtype=torch.int32, device=dev)
+    d_rows = torch.empty(4 * n * 48, dtype=torch.uint8, device=dev)
+    nr = dm.demux_dev(d_bases.data_ptr(), d_off.data_ptr(), n, d_rows.data_ptr(), 4 * n)
+    flt = F.Filter(dm, F.kit_patterns("SQK-NBD114-96", True))
+    d_v = torch.empty(nr * 16, dtype=torch.uint8, device=dev)
+    flt.verdicts_dev(d_rows.data_ptr(), nr, d_v.data_ptr())
+    tr = T.Trimmer(dm, T.TrimConfig())
+    cap = 2 * n * L + 64 * n
+    d_text = torch.empty(cap, dtype=torch.uint8, device=dev)
+    d_sl = torch.empty(2 * n * 32, dtype=torch.uint8, device=dev)
+    d_sp = torch.empty(65536 * 32, dtype=torch.uint8, device=dev)
+    d_st = torch.empty(n, dtype=torch.uint8, device=dev)
+    tl, ns, nsp = tr.trim_batch_dev(d_rows.data_ptr(), d_v.data_ptr(), nr, d_bases.data_ptr(), d_q.data_ptr(), d_off.data_ptr(), d_hdr.data_ptr(),
+                                    d_hoff.data_ptr(), d_idl.data_ptr(), d_ds.data_ptr(), n, d_text.data_ptr(), cap, d_sl.data_ptr(), 2 * n,
+                                    d_sp.data_ptr(), 65536, d_st.data_ptr())
+    assert ns > n // 2 and tl > ns * 1000
+    info, batch = Q.ingest(dm, tl, True, device_ptr=d_text.data_ptr())
+    assert int(info.n_records) == ns and int(info.consumed) == tl
+    a = Q.fetch(dm, info, bases=True, quals=True)
+    sl = np.frombuffer(d_sl[: ns * 32].cpu().numpy().tobytes(), dtype=T.SLICE_DTYPE)
+    lens = (sl["end"] - sl["start"]).astype(np.int64)
+    assert (np.diff(a["offsets"].astype(np.int64)) == lens).all()
+    # every packed byte equals the read byte it was cut from: gather through the slices
+    src0 = sl["read_idx"].astype(np.int64) * L + sl["start"].astype(np.int64)
+    gather = np.repeat(src0 - a["offsets"][:-1].astype(np.int64), lens) + np.arange(int(lens.sum()))
+    bases_h, quals_h = d_bases.cpu().numpy(), d_q.cpu().numpy()
+    assert (a["bases"] == bases_h[gather]).all() and (a["quals"] == quals_h[gather]).all()
+    ids = Q.read_ids(a)
+    exp = [("r%07d" % r) + ("_%d" % s if s else "") for r, s in zip(sl["read_idx"][:2000], sl["suffix"][:2000])]
+    assert ids[:2000] == exp
+    assert (a["desc_start"] - a["id_len"] == 1).all()
