@@ -823,6 +823,19 @@ int bb_dev_upload(bb_ctx* c, void* d_dst, const void* src, uint64_t bytes) {
     return BB_OK;
 }
 
+int bb_host_malloc(bb_ctx* c, uint64_t bytes, void** ptr) {
+    if (!c || !ptr) return BB_E_INVALID;
+    *ptr = nullptr;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (hipHostMalloc(ptr, bytes ? bytes : 16, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); c->last_error = "hipHostMalloc failed"; return BB_E_NOMEM; }
+    return BB_OK;
+}
+void bb_host_free(bb_ctx* c, void* ptr) {
+    if (!c || !ptr) return;
+    (void)hipSetDevice(c->device);
+    (void)hipHostFree(ptr);
+}
+
 // ---- inspect step (include/barbell_amd_inspect.h) ------------------------------------------------
 int bb_inspect_rows_dev(bb_ctx* c, const bb_row* d_rows, const bb_row_verdict* d_ver, uint64_t n_rows, uint32_t bucket_size,
                         bb_inspect_elem* d_out) {

@@ -647,19 +647,33 @@ namespace {
 // (bb_fastq_ingest); the partial record at the end of a block is carried over to the next one.
 struct BlockSource {
     gzFile f = nullptr;
-    std::vector<uint8_t> buf;
-    size_t have = 0;  // bytes of carry at the front of buf
-    explicit BlockSource(const std::string& path) : f(gzopen(path.c_str(), "rb")) {
+    bb_ctx* ctx;          // the block buffer is page-locked (bb_host_malloc): the upload runs at PCIe rate
+    uint8_t* buf = nullptr;
+    size_t cap = 0;
+    size_t have = 0;      // bytes of carry at the front of buf
+    BlockSource(bb_ctx* c, const std::string& path) : f(gzopen(path.c_str(), "rb")), ctx(c) {
         if (!f) throw BarbellError(BB_E_INVALID, "Failed to open FASTQ input: " + path);
         gzbuffer(f, 1 << 20);
     }
-    ~BlockSource() { if (f) gzclose(f); }
+    ~BlockSource() {
+        if (f) gzclose(f);
+        if (buf) bb_host_free(ctx, buf);
+    }
+    void reserve(size_t need) {
+        if (need <= cap) return;
+        const size_t ncap = need + need / 2;
+        void* p = nullptr;
+        if (bb_host_malloc(ctx, ncap, &p) != BB_OK) throw BarbellError(BB_E_NOMEM, "bb_host_malloc failed");
+        if (have) memcpy(p, buf, have);
+        if (buf) bb_host_free(ctx, buf);
+        buf = (uint8_t*)p; cap = ncap;
+    }
     // appends up to `want` bytes after the carry; returns true when the file is exhausted
     bool fill(size_t want) {
-        buf.resize(have + want);
+        reserve(have + want);
         size_t got = 0;
         while (got < want) {
-            const int r = gzread(f, buf.data() + have + got, (unsigned)std::min<size_t>(want - got, 1u << 30));
+            const int r = gzread(f, buf + have + got, (unsigned)std::min<size_t>(want - got, 1u << 30));
             if (r < 0) throw BarbellError(BB_E_INVALID, "Error reading FASTQ file");
             if (r == 0) break;
             got += (size_t)r;
@@ -668,7 +682,7 @@ struct BlockSource {
         return got < want;
     }
     void consume(size_t n) {
-        memmove(buf.data(), buf.data() + n, have - n);
+        memmove(buf, buf + n, have - n);
         have -= n;
     }
 };
@@ -818,10 +832,10 @@ AnnotateStats annotate(const std::vector<std::string>& read_files, const std::st
     const size_t block = config.batch_reads ? std::max<size_t>(config.batch_reads * 4096, 4096) : std::max<size_t>(config.block_bytes, 4096);
     try {
         for (const auto& path : read_files) {
-            BlockSource src(path);
+            BlockSource src(dm.ctx(), path);
             for (;;) {
                 const bool eof = src.fill(block);
-                const auto ing = dm.ingest(src.buf.data(), src.have, eof);
+                const auto ing = dm.ingest(src.buf, src.have, eof);
                 process(ing);
                 src.consume((size_t)ing.info.consumed);
                 if (eof) break;

@@ -145,6 +145,7 @@ public:
     // calls run on the batch it left in HBM and download rows / verdicts / rendered text.
     struct Ingested { bb_fastq_info info{}; std::vector<std::string> ids; };
     Ingested ingest(const uint8_t* text, uint64_t len, bool final_block);
+    bb_ctx* ctx() { ensure_ctx(); return ctx_; }  // for page-locked block buffers (bb_host_malloc)
     std::vector<BarbellMatch> demux_ingested();
     std::vector<bb_row_verdict> filter_ingested();
     TrimBatch trim_ingested();

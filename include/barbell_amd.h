@@ -149,6 +149,10 @@ int  bb_dev_malloc(bb_ctx* ctx, uint64_t bytes, void** d_ptr);
 void bb_dev_free(bb_ctx* ctx, void* d_ptr);
 int  bb_dev_download(bb_ctx* ctx, void* dst_host, const void* d_src, uint64_t bytes);
 int  bb_dev_upload(bb_ctx* ctx, void* d_dst, const void* src_host, uint64_t bytes);
+/* Page-locked host memory: buffers handed to the host-pointer entry points (FASTQ text blocks, rendered
+ * records) move over PCIe at full rate when they come from here.                                    */
+int  bb_host_malloc(bb_ctx* ctx, uint64_t bytes, void** ptr);
+void bb_host_free(bb_ctx* ctx, void* ptr);
 
 const char* bb_strerror(int code);
 const char* bb_last_error(const bb_ctx* ctx);   /* detail of the last BB_E_HIP / BB_E_UNSUPPORTED */
