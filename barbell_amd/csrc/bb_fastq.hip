@@ -200,8 +200,8 @@ __global__ __launch_bounds__(256) void k_fq_pack(const uint8_t* __restrict__ tex
     const uint64_t o = off[k], L = off[k + 1] - o, ho = hoff[k], HL = hoff[k + 1] - ho;
     const uint64_t hs = (k ? nl[4ull * k - 1] + 1 : 0) + 1;  // past '@'
     const uint64_t ss = nl[4ull * k] + 1, qs = nl[4ull * k + 2] + 1;
-    wave_copy<true>(bases + o, text + ss, (uint32_t)L, lane);
-    wave_copy<true>(quals + o, text + qs, (uint32_t)L, lane);
+    wave_copy(bases + o, text + ss, (uint32_t)L, lane);
+    wave_copy(quals + o, text + qs, (uint32_t)L, lane);
     wave_copy(hdr + ho, text + hs, (uint32_t)HL, lane);
 }
 
