@@ -137,6 +137,7 @@ struct bb_ctx {
     uint32_t *d_hitcount = nullptr, *d_lists = nullptr, *d_listcnt = nullptr;
     bb_hit_raw* d_raw = nullptr;
     bb_hit* d_hits = nullptr;
+    bb_hit_pfx* d_pfx = nullptr;  // shared-prefix records of the hits (groups with pfx > 0)
     bb_rowtmp* d_rows = nullptr;
     // staging for the host-pointer variant
     uint8_t* d_in_bases = nullptr; uint64_t cap_in_bases = 0;
@@ -160,6 +161,7 @@ struct bb_ctx {
     bb_synth_params synth{};
     // timing
     bool timing = false;
+    bool use_lists = false;  // per-(group, strand class) hit lists in use for the current batch
     int n_cus = 256;
     uint32_t reg_blocks_mult = 1;  // BARBELL_AMD_REG_BLOCKS: persistent blocks per resident slot (tuning knob)
     uint32_t reg_threads = 512;  // BARBELL_AMD_REG_THREADS: block size of k_barcode_reg (tuning knob)
@@ -254,6 +256,37 @@ int upload_tables(bb_ctx* c) {
                     for (int j = 0; j < mb; ++j)
                         if (bb_text_code((uint8_t)g.pat[s][p][j]) & code) t[((size_t)code * N + p) * WB + (j >> 5)] |= 1u << (j & 31);
         }
+        // shared-prefix split: rows every barcode of the group has in common (the left pad), per strand
+        D.pfx = 0;
+        if (WB == 2 && mb <= 48 && N >= 32 && !getenv("BARBELL_AMD_NO_PFX")) {
+            // forward-strand hits only: the rc patterns are the reverse complements (barcodes.rs:394-441), so their
+            // shared rows are the (shorter) right pad; rc hits keep the two-word kernel
+            int lcp = mb;
+            for (int p = 1; p < N; ++p) {
+                int j = 0;
+                while (j < lcp && bb_text_code((uint8_t)g.pat[0][p][j]) == bb_text_code((uint8_t)g.pat[0][0][j])) ++j;
+                lcp = j;
+            }
+            const int need = mb - 32;
+            if (need >= 1 && need <= lcp && need <= 16) D.pfx = need;
+        }
+        if (D.pfx) {
+            const int P = D.pfx;
+            const uint32_t pp = blob.alloc((size_t)2 * 16 * 4), ps = blob.alloc((size_t)2 * 16 * N * 4);
+            for (int s = 0; s < 2; ++s) {
+                D.off_peq_pfx[s] = pp + (uint32_t)(s * 16 * 4);
+                D.off_peq_sub[s] = ps + (uint32_t)((size_t)s * 16 * N * 4);
+                uint32_t* tp = reinterpret_cast<uint32_t*>(blob.b.data() + D.off_peq_pfx[s]);
+                uint32_t* ts = reinterpret_cast<uint32_t*>(blob.b.data() + D.off_peq_sub[s]);
+                for (int code = 0; code < 16; ++code) {
+                    for (int j = 0; j < P; ++j)
+                        if (bb_text_code((uint8_t)g.pat[s][0][j]) & code) tp[code] |= 1u << j;
+                    for (int p = 0; p < N; ++p)
+                        for (int j = P; j < mb; ++j)
+                            if (bb_text_code((uint8_t)g.pat[s][p][j]) & code) ts[(size_t)code * N + p] |= 1u << (j - P);
+                }
+            }
+        }
     }
     c->counts_len = count_off;
     HIPCHK(c, hipMalloc((void**)&c->d_tables, blob.b.size()));
@@ -263,7 +296,7 @@ int upload_tables(bb_ctx* c) {
     HIPCHK(c, hipMalloc((void**)&c->d_counts, sizeof(unsigned long long) * c->counts_len));
     HIPCHK(c, hipMemset(c->d_counts, 0, sizeof(unsigned long long) * c->counts_len));
     HIPCHK(c, hipMalloc((void**)&c->d_hitcount, 16));
-    HIPCHK(c, hipMalloc((void**)&c->d_listcnt, sizeof(uint32_t) * BB_MAX_GROUPS));
+    HIPCHK(c, hipMalloc((void**)&c->d_listcnt, sizeof(uint32_t) * 2 * BB_MAX_GROUPS));
     // synth tables
     std::vector<std::vector<std::string>> seqs;
     for (auto& g : c->groups) seqs.push_back(g.seqs);
@@ -304,9 +337,14 @@ int ensure_hits(bb_ctx* c, uint64_t need) {
     cap = 0;
     if ((r = grow(c, c->d_hits, cap, need))) return r;
     cap = 0;
+    {
+        bool any_pfx = false;
+        for (auto& d : c->gdev) any_pfx = any_pfx || d.pfx > 0;
+        if (any_pfx) { if ((r = grow(c, c->d_pfx, cap, need))) return r; cap = 0; }
+    }
     if ((r = grow(c, c->d_rows, cap, need))) return r;
     uint64_t lc = 0;
-    if ((r = grow(c, c->d_lists, lc, cap * c->groups.size()))) return r;
+    if ((r = grow(c, c->d_lists, lc, cap * c->groups.size() * 2))) return r;  // slot 2g: forward (or all) hits of group g, 2g+1: rc hits of a split group
     c->cap_hits = (uint32_t)cap;
     return BB_OK;
 }
@@ -346,7 +384,7 @@ void launch_trace(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets, 
                            (const bb_hit_raw*)c->d_raw, n_hits, (const uint32_t*)c->d_base, c->d_hits, g);
 }
 template <int WB, int CW>
-void launch_barcode_reg(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n_hits, uint32_t g, const uint32_t* list) {
+void launch_barcode_reg(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n_hits, uint32_t g, const uint32_t* list, const uint32_t* cnt) {
     const bb_group_dev& D = c->gdev[g];
     const uint32_t N = (uint32_t)D.n_seqs;
     const uint32_t hpb = c->reg_threads / N;
@@ -359,7 +397,25 @@ void launch_barcode_reg(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_off
     (void)d_bases; (void)d_offsets;
     hipLaunchKernelGGL((k_barcode_reg<WB, CW>), dim3(blocks), dim3(threads), smem, c->stream,
                        (const uint8_t*)c->d_tables, (const bb_group_dev*)c->d_groups, g, (const bb_hit*)c->d_hits, list,
-                       (const uint32_t*)c->d_listcnt, n_hits, hpb, c->params.min_score, c->params.min_score_diff, c->d_rows);
+                       cnt, n_hits, hpb, c->params.min_score, c->params.min_score_diff, c->d_rows);
+}
+
+template <int CW>
+void launch_barcode_pfx(bb_ctx* c, uint32_t n_hits, uint32_t g, const uint32_t* list, const uint32_t* cnt) {
+    const bb_group_dev& D = c->gdev[g];
+    const uint32_t N = (uint32_t)D.n_seqs;
+    // CW = 48 fits 168 VGPRs -> 3 waves per SIMD: 768-thread blocks (8 hits x 96 barcodes use every lane); measured
+    // 22.8 vs 26.8 ms against 512-thread blocks at 2 waves per SIMD
+    const uint32_t tmax = CW <= 48 ? 768u : c->reg_threads;
+    const uint32_t hpb = tmax / N;
+    const uint32_t threads = ((hpb * N + 63) / 64) * 64;
+    const size_t smem = (size_t)2 * 16 * N * 4 + (size_t)hpb * 24 + (size_t)hpb * (sizeof(bb_hit) + sizeof(bb_hit_pfx)) + 16;
+    const uint32_t n_iter = (n_hits + hpb - 1) / hpb;
+    const uint32_t resident = (uint32_t)c->n_cus * (threads > 256 ? 1u : 2u) * c->reg_blocks_mult;
+    const uint32_t blocks = n_iter < resident ? n_iter : resident;
+    hipLaunchKernelGGL((k_barcode_pfx<CW>), dim3(blocks), dim3(threads), smem, c->stream, (const uint8_t*)c->d_tables,
+                       (const bb_group_dev*)c->d_groups, g, (const bb_hit*)c->d_hits, (const bb_hit_pfx*)c->d_pfx, list,
+                       cnt, n_hits, hpb, c->params.min_score, c->params.min_score_diff, c->d_rows);
 }
 
 template <int WB>
@@ -367,14 +423,23 @@ void launch_barcode(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets
     const bb_group_dev& D = c->gdev[g];
     const bb_group_info& I = c->groups[g].info;
     const uint32_t N = (uint32_t)D.n_seqs;
-    const uint32_t* list = c->groups.size() > 1 ? c->d_lists + (size_t)g * c->cap_hits : nullptr;
+    // hit lists: slot 2g = forward (or all) hits of the group, slot 2g+1 = rc hits of a shared-prefix group.
+    // The kernels index list_cnt with g; handing them list_cnt + (slot - g) makes that the slot's counter.
+    const uint32_t* list = c->use_lists ? c->d_lists + (size_t)(2 * g) * c->cap_hits : nullptr;
+    const uint32_t* list_rc = c->use_lists ? c->d_lists + (size_t)(2 * g + 1) * c->cap_hits : nullptr;
+    const uint32_t* cnt = c->d_listcnt + g, *cnt_rc = c->d_listcnt + g + 1;
     // widest barcode window the flank traceback can produce: (mask_len - 1 + flank_k) + 2*PADDING
     const uint32_t win_max = I.mask_len + (uint32_t)I.flank_k + 2 * BB_PADDING - 1;
     const size_t peq_bytes = (size_t)2 * 16 * N * WB * 4;
     const bool reg_ok = !c->force_generic && D.m_bar <= 48 && N <= c->reg_threads && peq_bytes <= 48 * 1024 && win_max <= 64;
+    if (reg_ok && WB == 2 && D.pfx > 0) {  // shared-prefix split: forward hits with one word per barcode lane, rc hits as before
+        if (win_max <= 48) { launch_barcode_pfx<48>(c, n_hits, g, list, cnt); launch_barcode_reg<WB, 48>(c, d_bases, d_offsets, n_hits, g, list_rc, cnt_rc); }
+        else { launch_barcode_pfx<64>(c, n_hits, g, list, cnt); launch_barcode_reg<WB, 64>(c, d_bases, d_offsets, n_hits, g, list_rc, cnt_rc); }
+        return;
+    }
     if (reg_ok) {
-        if (win_max <= 48) launch_barcode_reg<WB, 48>(c, d_bases, d_offsets, n_hits, g, list);
-        else launch_barcode_reg<WB, 64>(c, d_bases, d_offsets, n_hits, g, list);
+        if (win_max <= 48) launch_barcode_reg<WB, 48>(c, d_bases, d_offsets, n_hits, g, list, cnt);
+        else launch_barcode_reg<WB, 64>(c, d_bases, d_offsets, n_hits, g, list, cnt);
         return;
     }
     const uint32_t hpb = N >= 256 ? 1 : 256 / N;
@@ -382,14 +447,18 @@ void launch_barcode(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets
     const bool lds = peq_bytes <= 48 * 1024;
     const size_t smem = (lds ? peq_bytes : 0) + (size_t)hpb * N * 8 + (size_t)hpb * 16 + (size_t)hpb * BB_MAX_WIN;
     const uint32_t blocks = (n_hits + hpb - 1) / hpb;
-    if (lds)
-        hipLaunchKernelGGL((k_barcode<WB, true>), dim3(blocks), dim3(threads), smem, c->stream, d_bases, d_offsets,
-                           (const uint8_t*)c->d_tables, (const bb_group_dev*)c->d_groups, g, (const bb_hit*)c->d_hits, list,
-                           (const uint32_t*)c->d_listcnt, n_hits, hpb, c->params.min_score, c->params.min_score_diff, c->d_rows);
-    else
-        hipLaunchKernelGGL((k_barcode<WB, false>), dim3(blocks), dim3(threads), smem, c->stream, d_bases, d_offsets,
-                           (const uint8_t*)c->d_tables, (const bb_group_dev*)c->d_groups, g, (const bb_hit*)c->d_hits, list,
-                           (const uint32_t*)c->d_listcnt, n_hits, hpb, c->params.min_score, c->params.min_score_diff, c->d_rows);
+    for (int cls = 0; cls < (D.pfx > 0 ? 2 : 1); ++cls) {  // a split group has its rc hits in the second list
+        const uint32_t* l = cls ? list_rc : list;
+        const uint32_t* lc = cls ? cnt_rc : cnt;
+        if (lds)
+            hipLaunchKernelGGL((k_barcode<WB, true>), dim3(blocks), dim3(threads), smem, c->stream, d_bases, d_offsets,
+                               (const uint8_t*)c->d_tables, (const bb_group_dev*)c->d_groups, g, (const bb_hit*)c->d_hits, l, lc, n_hits, hpb,
+                               c->params.min_score, c->params.min_score_diff, c->d_rows);
+        else
+            hipLaunchKernelGGL((k_barcode<WB, false>), dim3(blocks), dim3(threads), smem, c->stream, d_bases, d_offsets,
+                               (const uint8_t*)c->d_tables, (const bb_group_dev*)c->d_groups, g, (const bb_hit*)c->d_hits, l, lc, n_hits, hpb,
+                               c->params.min_score, c->params.min_score_diff, c->d_rows);
+    }
 }
 
 void mark(bb_ctx* c, int i) {
@@ -458,7 +527,7 @@ void bb_destroy(bb_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     void* ptrs[] = {c->d_groups, c->d_tables, c->d_counts, c->d_cnt, c->d_base, c->d_sums, c->d_nrows, c->d_rowoff, c->d_hitcount,
-                    c->d_lists, c->d_listcnt, c->d_raw, c->d_hits, c->d_rows, c->d_in_bases, c->d_in_offsets, c->d_out_rows,
+                    c->d_lists, c->d_listcnt, c->d_raw, c->d_hits, c->d_pfx, c->d_rows, c->d_in_bases, c->d_in_offsets, c->d_out_rows,
                     c->d_synth_table, c->d_fpats, c->d_felems, c->d_flabel_ok, c->d_flabel_ids, c->d_frows, c->d_fout, c->d_iout};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -535,13 +604,19 @@ int bb_annotate_batch_dev(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_o
         HIPCHK(c, hipGetLastError());
     }
     mark(c, K_LISTS);
-    if (n_hits && G > 1) {
-        HIPCHK(c, hipMemsetAsync(c->d_listcnt, 0, sizeof(uint32_t) * BB_MAX_GROUPS, c->stream));
+    bool any_pfx = false;
+    for (uint32_t g = 0; g < G; ++g) any_pfx = any_pfx || c->gdev[g].pfx > 0;
+    c->use_lists = G > 1 || any_pfx;
+    if (n_hits && c->use_lists) {
+        HIPCHK(c, hipMemsetAsync(c->d_listcnt, 0, sizeof(uint32_t) * 2 * BB_MAX_GROUPS, c->stream));
         hipLaunchKernelGGL(k_hit_lists, dim3((n_hits + 255) / 256), dim3(256), 0, c->stream, (const bb_hit*)c->d_hits, n_hits,
-                           c->d_rows, c->d_lists, c->cap_hits, c->d_listcnt, G);
+                           c->d_rows, c->d_lists, c->cap_hits, c->d_listcnt, G, (const bb_group_dev*)c->d_groups);
     }
     mark(c, K_BARCODE);
     if (n_hits) {
+        if (any_pfx)  // shared rows of the padded barcodes, once per hit
+            hipLaunchKernelGGL(k_bar_prefix, dim3((n_hits + 255) / 256), dim3(256), 0, c->stream, (const uint8_t*)c->d_tables,
+                               (const bb_group_dev*)c->d_groups, (const bb_hit*)c->d_hits, n_hits, c->d_pfx);
         for (uint32_t g = 0; g < G; ++g) {
             if (c->gdev[g].WB == 1) launch_barcode<1>(c, d_bases, d_offsets, n_hits, g);
             else launch_barcode<2>(c, d_bases, d_offsets, n_hits, g);

@@ -1139,28 +1139,393 @@ __global__ __launch_bounds__(512) void k_barcode_reg(const uint8_t* __restrict__
   }
 }
 
-// Per-group hit lists for k_barcode (only needed with more than one query group).  Hits whose
-// get_matching_region was None (searcher.rs:445-449) are skipped here and marked row-less.
-// One atomic per (wave, group): ballot + prefix popcount.
+// ------------------------------------------------------------------------------------------------
+// Shared-prefix split of the barcode stage (groups with bb_group_dev::pfx > 0, e.g. SQK-NBD114-96: 42-row
+// padded barcodes = 10 shared pad rows + 32 rows per barcode).
+//
+// The first pfx rows of the DP matrix are the same for every barcode of a group (same pattern characters,
+// same window), so they are computed once per hit by k_bar_prefix (one lane per hit) and every barcode lane of
+// k_barcode_pfx runs Myers on ONE 32-bit word (rows pfx+1..m) with the horizontal delta of row pfx as its
+// carry-in (Hyyro's block step: hin < 0 sets bit 0 of Eq for the diagonal-zero vector, the shifted Ph/Mh take
+// hin as their bit 0).  Values are those of the monolithic two-word column step: both are the DP matrix.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_bar_prefix(const uint8_t* __restrict__ tables, const bb_group_dev* __restrict__ groups,
+                                                    const bb_hit* __restrict__ hits, uint32_t n_hits, bb_hit_pfx* __restrict__ out) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= n_hits) return;
+    const uint4 h0 = reinterpret_cast<const uint4*>(hits + t)[0], h1 = reinterpret_cast<const uint4*>(hits + t)[1];
+    const uint32_t ws = h0.w, we = h1.x, grp = (h1.y >> 16) & 0xFFu, strand = h1.y >> 24, valid = h1.z & 0xFFu;
+    const bb_group_dev& G = groups[grp];
+    const int P = G.pfx;
+    if (!valid || P == 0) return;
+    const int32_t wn = (int32_t)(we - ws);
+    if (wn > 64) return;  // such windows go through the generic kernel
+    const uint32_t* peq = reinterpret_cast<const uint32_t*>(tables + G.off_peq_pfx[strand]);
+    uint32_t eqt[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) eqt[i] = peq[i];
+    uint32_t pv = (1u << P) - 1u, mv = 0u;
+    unsigned long long PH = 0ull, MH = 0ull;
+    const uint32_t* win = reinterpret_cast<const uint32_t*>(hits[t].win);
+    uint32_t* sh = out[t].sh;
+    for (int c4 = 0; c4 < wn; c4 += 4) {
+        const uint32_t w4 = win[c4 >> 2];
+        uint32_t o[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c = c4 + q;
+            const uint32_t code = (w4 >> (8 * q)) & 0xFu;
+            uint32_t eq = 0;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) eq = code == (uint32_t)i ? eqt[i] : eq;
+            const uint32_t x = eq & pv;
+            const uint32_t d0 = (((x + pv) ^ pv) | eq | mv);
+            const uint32_t ph = mv | ~(d0 | pv), mh = pv & d0;
+            PH |= (unsigned long long)((ph >> (P - 1)) & 1u) << c;
+            MH |= (unsigned long long)((mh >> (P - 1)) & 1u) << c;
+            const uint32_t isM = d0 & eq, l = ~(isM | ph), hh = (ph & ~isM) | (l & d0);
+            // row r <-> bit P - r: bit reversal inside the P-bit field
+            o[q] = (__brev(l) >> (32 - P)) | ((__brev(hh) >> (32 - P)) << 16);
+            const uint32_t phs = ph << 1, mhs = mh << 1;  // top boundary row: D[0][c] = 0, no horizontal delta
+            pv = mhs | ~(d0 | phs);
+            mv = phs & d0;
+        }
+        if (c4 + 4 <= 64) *reinterpret_cast<uint4*>(sh + c4) = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+    out[t].ph = PH;
+    out[t].mh = MH;
+}
+
+template <int CW>
+__global__ __launch_bounds__(CW <= 48 ? 768 : 512) void k_barcode_pfx(const uint8_t* __restrict__ tables, const bb_group_dev* __restrict__ groups,
+                                                     uint32_t g, const bb_hit* __restrict__ hits, const bb_hit_pfx* __restrict__ pfxs,
+                                                     const uint32_t* __restrict__ hit_list, const uint32_t* __restrict__ list_cnt,
+                                                     uint32_t n_hits_all, uint32_t hpb, double min_score, double min_score_diff,
+                                                     bb_rowtmp* __restrict__ rows) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const bb_group_dev G = groups[g];
+    const uint32_t n_list = hit_list ? list_cnt[g] : n_hits_all;
+    const uint32_t n_iter = (n_list + hpb - 1) / hpb;
+    if (blockIdx.x >= n_iter) return;
+    const int N = G.n_seqs, m = G.m_bar, P = G.pfx, MS = m - P;  // MS rows per lane (<= 32)
+    constexpr int PIECES_H = (int)(sizeof(bb_hit) / 16), PIECES_P = (int)(sizeof(bb_hit_pfx) / 16), PIECES = PIECES_H + PIECES_P;
+    // LDS carve: [hit + prefix records: hpb x 368 B][max u64[hpb]][second u64[hpb]][cnt1 i32[hpb]][top i32[hpb]][peq 2*16*N words]
+    uint4* s_hit = reinterpret_cast<uint4*>(smem);
+    size_t o = (size_t)hpb * PIECES * 16;
+    unsigned long long* s_max = reinterpret_cast<unsigned long long*>(smem + o);
+    o += (size_t)hpb * 8;
+    unsigned long long* s_sec = reinterpret_cast<unsigned long long*>(smem + o);
+    o += (size_t)hpb * 8;
+    int32_t* s_cnt1 = reinterpret_cast<int32_t*>(smem + o);
+    o += (size_t)hpb * 4;
+    int32_t* s_top = reinterpret_cast<int32_t*>(smem + o);
+    o += (size_t)hpb * 4;
+    o = (o + 15) & ~(size_t)15;
+    uint32_t* s_peq = reinterpret_cast<uint32_t*>(smem + o);
+    {
+        const uint32_t* gp = reinterpret_cast<const uint32_t*>(tables + G.off_peq_sub[0]);
+        const int words = 2 * 16 * N;
+        for (int i = threadIdx.x; i < words; i += blockDim.x) s_peq[i] = gp[i];
+    }
+    const int hl = threadIdx.x / N;
+    const int p = threadIdx.x - hl * N;
+    const bool in_blk = hl < (int)hpb;
+    const int hls = in_blk ? hl : 0;
+    // prefetch of the next iteration's records: lane p of a hit fetches piece p (hit record pieces first, then
+    // the prefix record); N >= 32 > PIECES
+    uint4 pre = make_uint4(0u, 0u, 0u, 0u);
+    auto prefetch = [&](uint32_t it) {
+        const uint32_t li = it * hpb + (uint32_t)hl;
+        if (in_blk && p < PIECES && it < n_iter && li < n_list) {
+            const uint32_t idx = hit_list ? hit_list[li] : li;
+            pre = p < PIECES_H ? reinterpret_cast<const uint4*>(hits + idx)[p] : reinterpret_cast<const uint4*>(pfxs + idx)[p - PIECES_H];
+        }
+    };
+    prefetch(blockIdx.x);
+  for (uint32_t it = blockIdx.x; it < n_iter; it += gridDim.x) {
+    const uint32_t li = it * hpb + (uint32_t)hl;
+    const bool exists = in_blk && li < n_list;
+    if (exists && p < PIECES) s_hit[hl * PIECES + p] = pre;
+    if (in_blk && p == 0) { s_max[hl] = 0ull; s_sec[hl] = 0ull; s_cnt1[hl] = 0; s_top[hl] = 0x7FFFFFFF; }
+    __syncthreads();
+    const uint32_t hit_idx = hit_list ? (exists ? hit_list[li] : 0u) : li;
+    prefetch(it + gridDim.x);
+    bb_hit H;  // header only
+    {
+        const uint4 h0 = s_hit[hls * PIECES], h1 = s_hit[hls * PIECES + 1];
+        H.read_idx = h0.x; H.text_start = h0.y; H.text_end = h0.z; H.ws = h0.w;
+        H.we = h1.x; H.cost = (int16_t)(h1.y & 0xFFFFu); H.group = (uint8_t)((h1.y >> 16) & 0xFFu); H.strand = (uint8_t)(h1.y >> 24);
+        H.valid = (uint8_t)(h1.z & 0xFFu); H.read_len = h1.w;
+    }
+    bool active = exists && H.valid != 0;
+    if (exists && !H.valid && p == 0) rows[hit_idx].row._pad[0] = 0;
+    const int32_t wn = active ? (int32_t)(H.we - H.ws) : 0;
+    const uint32_t* s_sh = reinterpret_cast<const uint32_t*>(s_hit + hls * PIECES + PIECES_H + 1);  // sh[64] of the prefix record
+
+    int wmax = wn;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) wmax = max(wmax, __shfl_xor(wmax, d, 64));
+    wmax = __builtin_amdgcn_readfirstlane(wmax);
+
+    // ---- forward pass on the lane's own rows (one word), carry-in from the shared rows ----
+    uint32_t L0[CW], H0[CW];
+    int32_t best_cost = 0x7FFFFFFF, best_pos = -1;
+    {
+        uint32_t wc[CW / 4];
+#pragma unroll
+        for (int q = 0; q < CW / 16; ++q) { uint4 v = s_hit[hls * PIECES + 2 + q]; wc[4 * q] = v.x; wc[4 * q + 1] = v.y; wc[4 * q + 2] = v.z; wc[4 * q + 3] = v.w; }
+        const uint4 hv = s_hit[hls * PIECES + PIECES_H];  // {ph lo, ph hi, mh lo, mh hi}
+        const uint32_t hin_p[2] = {hv.x, hv.y}, hin_m[2] = {hv.z, hv.w};
+        const uint32_t pb = (uint32_t)((active ? H.strand : 0) * 16) * (uint32_t)N + (uint32_t)p;
+        uint32_t pv = MS >= 32 ? 0xFFFFFFFFu : ((1u << MS) - 1u), mv = 0u;
+        const int TB = MS - 1;
+        uint32_t up[2] = {0u, 0u}, dn[2] = {0u, 0u};
+#pragma unroll
+        for (int c0 = 0; c0 < CW; c0 += 8) {
+            if (c0 < wmax) {  // wave-uniform
+#pragma unroll
+                for (int c = c0; c < c0 + 8; ++c) {
+                    const uint32_t code = (wc[c >> 2] >> (8 * (c & 3))) & 0xFu;
+                    const uint32_t eq = s_peq[__umul24(code, (uint32_t)N) + pb];
+                    const uint32_t hp = (hin_p[c >> 5] >> (c & 31)) & 1u, hm = (hin_m[c >> 5] >> (c & 31)) & 1u;
+                    const uint32_t eqx = eq | hm;
+                    const uint32_t x = eqx & pv;
+                    const uint32_t d0 = ((x + pv) ^ pv) | eqx | mv;
+                    const uint32_t ph = mv | ~(d0 | pv), mh = pv & d0;
+                    const uint32_t isM = d0 & eq, l = ~(isM | ph), hh = (ph & ~isM) | (l & d0);
+                    L0[c] = __brev(l); H0[c] = __brev(hh);  // row P+1 <-> bit 31, row P+32 <-> bit 0
+                    up[c >> 5] |= ((ph >> TB) & 1u) << (c & 31);
+                    dn[c >> 5] |= ((mh >> TB) & 1u) << (c & 31);
+                    const uint32_t phs = (ph << 1) | hp, mhs = (mh << 1) | hm;
+                    pv = mhs | ~(d0 | phs);
+                    mv = phs & d0;
+                }
+            }
+        }
+        const unsigned long long wmask = wn >= 64 ? ~0ull : ((1ull << wn) - 1ull);
+        const unsigned long long Pm = (((unsigned long long)up[1] << 32) | up[0]) & wmask;
+        const unsigned long long Mm = (((unsigned long long)dn[1] << 32) | dn[0]) & wmask;
+        const unsigned long long A = Mm | ~Pm;
+        const unsigned long long D = (A + Mm + 1ull) ^ A ^ Mm;
+        unsigned long long R = (Pm & D) | (D & (1ull << wn));
+        if (!active) R = 0ull;
+        while (R) {
+            const int q = ctz64(R);
+            R &= R - 1ull;
+            const unsigned long long lowq = (1ull << q) - 1ull;
+            const int32_t cq = m + __popcll(Pm & lowq) - __popcll(Mm & lowq);
+            if (cq < best_cost) { best_cost = cq; best_pos = q; }
+        }
+        if (active && best_pos >= 0 && best_cost <= G.k1) atomicAdd(&s_cnt1[hl], 1);
+    }
+    bool cand = active && best_pos >= 0 && best_cost <= G.k2;
+    // ---- traceback, phase 1: the lane's own rows, one-hot cursor on one 32-bit word (row P+1 <-> bit 31).
+    // The cursor leaves the word either by the carry of the Del-run addition (the run continues in the shared
+    // rows at the same column) or by a Match/Sub out of row P+1 (next column); either way phase 2 starts at
+    // column cx with the cursor entering row P. ----
+    const int32_t rlo = G.rel_lo, rhi = G.rel_hi;
+    unsigned long long plo = 0ull, phi = 0ull;
+    uint32_t b = 0u, dg = 0u;
+    int32_t ntext = 0, cx = 0;
+    const uint32_t start = 1u << (32 - MS);
+#pragma unroll
+    for (int c0 = CW; c0 >= 8; c0 -= 8) {
+        if (c0 - 7 <= wmax) {  // wave-uniform
+#pragma unroll
+            for (int c = c0; c > c0 - 8; --c) {
+                b = (cand & (best_pos == c)) ? start : b;
+                const uint32_t Lr = L0[c - 1], Hr = H0[c - 1];
+                const uint32_t Dr = Lr & Hr;
+                const uint32_t sum = Dr + b;
+                const bool carry = sum < b;
+                const uint32_t nb = sum & ~Dr;
+                const bool has = nb != 0u, lo = (Lr & nb) != 0u, hi = (Hr & nb) != 0u;
+                plo |= lo ? (1ull << (c - 1)) : 0ull;
+                phi |= hi ? (1ull << (c - 1)) : 0ull;
+                const bool consume = has & !hi;
+                dg |= consume ? nb : 0u;
+                const bool out = consume & ((nb >> 31) != 0u);
+                cx = carry ? c : (out ? c - 1 : cx);
+                b = consume ? (nb << 1) : nb;
+                ntext += has ? 1 : 0;
+            }
+        }
+    }
+    // ---- phase 2: the shared rows (row r <-> bit P - r), move bits of the hit's prefix record in LDS.
+    // The 16 columns below cx are fetched with independent LDS reads and walked with static
+    // register indices (no load -> address dependency per column); a cursor still alive after them (more than
+    // 16 - P insertions inside the shared rows) finishes in the loop underneath. ----
+    uint32_t dgh = 0u;
+    {
+        uint32_t bh = (cand && cx >= 1) ? 1u : 0u;
+        const uint32_t pm = (1u << P) - 1u;
+        // columns cx-16 .. cx-1 (0-based) = sh[cx-16 .. cx-1]; entries below 0 are never used (the walk stops at column 1)
+        const int32_t base = cx - 16;
+        uint32_t w16[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) w16[e] = s_sh[max(base + e, 0)];  // independent reads, issued back to back
+        uint32_t lo2 = 0u, hi2 = 0u;  // bit i: text op plane bits of column cx - i
+        int32_t used = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const uint32_t w = w16[15 - i];
+            const uint32_t Lr = w & 0xFFFFu, Hr = w >> 16;
+            const uint32_t Dr = Lr & Hr;
+            const bool live = bh != 0u && (cx - i) >= 1;
+            const uint32_t nb = live ? (((Dr + bh) & ~Dr) & pm) : 0u;
+            const bool has = nb != 0u, lo = (Lr & nb) != 0u, hi = (Hr & nb) != 0u;
+            lo2 |= lo ? (1u << i) : 0u;
+            hi2 |= hi ? (1u << i) : 0u;
+            const bool consume = has & !hi;
+            dgh |= consume ? nb : 0u;
+            bh = consume ? ((nb << 1) & pm) : nb;
+            ntext += has ? 1 : 0;
+            used += has ? 1 : 0;
+        }
+        // local bit i <-> column cx - i <-> plane bit cx - i - 1: reverse the 16 bits and slide them under cx
+        const unsigned long long rl = (unsigned long long)(__brev(lo2) >> 16), rh = (unsigned long long)(__brev(hi2) >> 16);
+        plo |= cx >= 16 ? (rl << (cx - 16)) : (rl >> (16 - cx));
+        phi |= cx >= 16 ? (rh << (cx - 16)) : (rh >> (16 - cx));
+        int32_t col = cx - 16;
+        if (col < 1) bh = 0u;
+        while (__any(bh != 0u)) {  // rare: more than 16 columns inside the shared rows
+            const uint32_t w = s_sh[col >= 1 ? col - 1 : 0];
+            const uint32_t Lr = w & 0xFFFFu, Hr = w >> 16;
+            const uint32_t Dr = Lr & Hr;
+            const uint32_t nb = bh ? (((Dr + bh) & ~Dr) & pm) : 0u;
+            const bool has = nb != 0u, lo = (Lr & nb) != 0u, hi = (Hr & nb) != 0u;
+            const unsigned long long bit = 1ull << (col >= 1 ? col - 1 : 0);
+            plo |= lo ? bit : 0ull;
+            phi |= hi ? bit : 0ull;
+            const bool consume = has & !hi;
+            dgh |= consume ? nb : 0u;
+            bh = consume ? ((nb << 1) & pm) : nb;
+            ntext += has ? 1 : 0;
+            col -= has ? 1 : 0;
+            if (col < 1) bh = 0u;
+        }
+        (void)used;
+    }
+    const int32_t tstart = cand ? best_pos - ntext : 0;
+    // consumed rows in natural order (row r <-> bit r-1)
+    const unsigned long long diagrow = ((unsigned long long)__brev(dg) << P) | (unsigned long long)(__brev(dgh) >> (32 - P));
+    const unsigned long long delrow = cand ? (low64(m) & ~diagrow) : 0ull;
+    double s_norm = -1.0;
+    {
+        double sc = 0.0, b1 = 0.0, b2 = 0.0;
+        int32_t pj = 0, t = 0;
+        {
+            const int nd = cand ? ctz64(~delrow) : 0;
+            pj = nd; t = nd;
+        }
+#pragma unroll
+        for (int c0 = 1; c0 <= CW; c0 += 8) {
+            if (c0 <= wmax) {  // wave-uniform
+#pragma unroll
+                for (int c = c0; c < c0 + 8; ++c) {
+                    const bool on = cand & (c > tstart) & (c <= best_pos);
+                    const uint32_t lo = (uint32_t)(plo >> (c - 1)) & 1u, hi = (uint32_t)(phi >> (c - 1)) & 1u;
+                    if (on & ((lo | hi) == 0u)) {
+                        const double w = __longlong_as_double((long long)(1022 - t) << 52);
+                        const double pw = __longlong_as_double((long long)(1023 + t) << 52);
+                        sc = sc + w * b2; b2 = b2 + b1; b1 = b1 + pw;
+                    }
+                    const int adv = (on & !((hi == 1u) & (lo == 0u))) ? 1 : 0;
+                    pj += adv;
+                    const int nd = on ? ctz64(~(delrow >> pj)) : 0;
+                    pj += nd;
+                    t += (on ? 1 : 0) + nd;
+                }
+            }
+        }
+        if (cand) s_norm = G.perfect > 0.0 ? sc / G.perfect : 0.0;
+    }
+    __syncthreads();
+    if (active) {
+        const bool pass2 = s_cnt1[hl] <= 1 && G.k1 < G.k2;
+        cand = cand && (pass2 || best_cost <= G.k1);
+    }
+    const unsigned long long key = cand ? (unsigned long long)__double_as_longlong(s_norm) + 1ull : 0ull;
+    if (cand) atomicMax(&s_max[hl], key);
+    __syncthreads();
+    if (cand && key == s_max[hl]) atomicMin(&s_top[hl], p);
+    __syncthreads();
+    if (active) {
+        const int top = s_top[hl];
+        if (cand && p != top) atomicMax(&s_sec[hl], key);
+    }
+    __syncthreads();
+    if (active) {
+        const int top = s_top[hl];
+        const bool have = top != 0x7FFFFFFF;
+        if ((have && p == top) || (!have && p == 0)) {
+            bool valid = have && s_norm >= min_score;
+            const unsigned long long sk = s_sec[hl];
+            if (valid && sk != 0ull) valid = (s_norm - __longlong_as_double((long long)(sk - 1ull))) >= min_score_diff;
+            const uint32_t read_len = H.read_len;
+            bb_rowtmp R;
+            bb_row& r = R.row;
+            r.read_idx = H.read_idx; r.read_len = read_len;
+            r.rel_dist_to_end = rel_dist_to_end((int64_t)H.text_start, (int64_t)read_len);
+            r.read_start_flank = H.text_start; r.read_end_flank = H.text_end;
+            r.flank_cost = H.cost; r.group_idx = H.group; r.strand = H.strand;
+            r._pad[0] = 1; r._pad[1] = r._pad[2] = 0;
+            if (valid) {
+                int32_t txt_lo, txt_hi, bcost;
+                subpath_closed_form(plo, phi, diagrow, tstart, best_pos, m, rlo, rhi, txt_lo, txt_hi, bcost);
+                r.read_start_bar = H.ws + (uint32_t)txt_lo; r.read_end_bar = H.ws + (uint32_t)txt_hi;
+                r.bar_start = H.ws + (uint32_t)rlo; r.bar_end = H.ws + (uint32_t)rhi;
+                r.match_type = (uint8_t)G.type; r.barcode_cost = (int16_t)bcost; r.barcode_idx = (int16_t)top;
+            } else {
+                r.read_start_bar = H.text_start; r.read_end_bar = H.text_end;
+                r.bar_start = 0; r.bar_end = 0;
+                r.match_type = (uint8_t)(G.type == BB_FTAG ? BB_FFLANK : BB_RFLANK);
+                r.barcode_cost = (int16_t)G.m_bar; r.barcode_idx = -1;
+            }
+            rows[hit_idx] = R;
+        }
+    }
+    __syncthreads();
+  }
+}
+
+// Hit lists for the barcode kernels (needed with more than one query group or a shared-prefix group): slot 2g
+// holds the hits of group g — only the forward-strand ones when the group is split (bb_group_dev::pfx > 0),
+// its rc hits then go to slot 2g+1.  Hits whose get_matching_region was None (searcher.rs:445-449) are
+// skipped here and marked row-less.  One atomic per (block, slot): ballots + LDS.
 __global__ __launch_bounds__(256) void k_hit_lists(const bb_hit* __restrict__ hits, uint32_t n_hits, bb_rowtmp* __restrict__ rows,
                                                    uint32_t* __restrict__ lists, uint32_t list_stride, uint32_t* __restrict__ list_cnt,
-                                                   uint32_t n_groups) {
+                                                   uint32_t n_groups, const bb_group_dev* __restrict__ groups) {
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
     const bool in = t < n_hits;
-    bb_hit h;
-    if (in) h = hits[t];
-    const bool valid = in && h.valid;
+    uint32_t grp = 0, strand = 0, vld = 0;
+    if (in) {  // second 16-byte piece of the record: {we, cost|group|strand, valid, read_len}
+        const uint4 h1 = reinterpret_cast<const uint4*>(hits + t)[1];
+        grp = (h1.y >> 16) & 0xFFu; strand = h1.y >> 24; vld = h1.z & 0xFFu;
+    }
+    const bool valid = in && vld;
     if (in && !valid) rows[t].row._pad[0] = 0;
-    const unsigned lane = threadIdx.x & 63u;
-    for (uint32_t g = 0; g < n_groups; ++g) {
-        const bool mine = valid && h.group == g;
-        const unsigned long long mask = __ballot(mine);
-        if (mask == 0ull) continue;
-        uint32_t base = 0;
-        const int leader = __ffsll((long long)mask) - 1;
-        if ((int)lane == leader) base = atomicAdd(&list_cnt[g], (uint32_t)__popcll(mask));
-        base = __shfl(base, leader, 64);
-        if (mine) lists[(size_t)g * list_stride + base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = t;
+    const unsigned lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const uint32_t my_slot = valid ? 2u * grp + ((groups[grp].pfx > 0 && strand) ? 1u : 0u) : 0xFFFFFFFFu;
+    // one atomic per (block, slot): the four waves' counts meet in LDS
+    __shared__ uint32_t s_cnt[4][2 * BB_MAX_GROUPS], s_base[2 * BB_MAX_GROUPS];
+    const uint32_t n_slots = 2u * n_groups;
+    unsigned long long my_mask = 0ull;
+    for (uint32_t slot = 0; slot < n_slots; ++slot) {
+        const unsigned long long mask = __ballot(my_slot == slot);
+        if (lane == 0) s_cnt[wv][slot] = (uint32_t)__popcll(mask);
+        if (my_slot == slot) my_mask = mask;
+    }
+    __syncthreads();
+    if (threadIdx.x < n_slots) {
+        const uint32_t tot = s_cnt[0][threadIdx.x] + s_cnt[1][threadIdx.x] + s_cnt[2][threadIdx.x] + s_cnt[3][threadIdx.x];
+        s_base[threadIdx.x] = tot ? atomicAdd(&list_cnt[threadIdx.x], tot) : 0u;
+    }
+    __syncthreads();
+    if (valid) {
+        uint32_t base = s_base[my_slot];
+        for (unsigned w = 0; w < wv; ++w) base += s_cnt[w][my_slot];
+        lists[(size_t)my_slot * list_stride + base + (uint32_t)__popcll(my_mask & ((1ull << lane) - 1ull))] = t;
     }
 }
 

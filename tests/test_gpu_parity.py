@@ -82,6 +82,53 @@ def test_generic_kernels_match_too(monkeypatch):
         assert_same(got, want)
 
 
+def test_two_word_kernel_without_prefix_split(monkeypatch):
+    """BARBELL_AMD_NO_PFX=1: forward-strand hits of a splittable group (SQK-NBD114-96: 10 shared pad rows + 32
+    rows per barcode) go through the two-word register kernel like the rc hits do."""
+    from barbell_amd import annotate as A
+
+    monkeypatch.setenv("BARBELL_AMD_NO_PFX", "1")
+    for cfg in ("nbd96", "dual"):
+        groups = config_groups(cfg)
+        bases, offsets = A.synth_reads_host(groups, 4711, 300, 2500, 0, 1500)
+        _, got, want = run_both(groups, bases, offsets)
+        assert_same(got, want)
+
+
+def test_prefix_split_with_insertions_in_the_shared_rows():
+    """k_barcode_pfx walks the shared pad rows with a 16-column register window and falls back to a loop when
+    the path needs more: reads with up to 12 extra bases inside the left pad (flank-max-errors 12 keeps the
+    flank hit; windows then exceed 48 columns -> the 64-column variant as well)."""
+    from barbell_amd import kits
+
+    groups = kits.groups_from_kit("SQK-NBD114-96", flank_max_errors=12)
+    rng = np.random.default_rng(77)
+    reads = []
+    for i in range(400):
+        full = bytes(groups[0].seqs[int(rng.integers(0, 96))])        # flank + barcode + flank, 70 nt
+        cut = int(rng.integers(5, 14))                                  # inside the 10 pad rows (flank[4:14])
+        n_ins = int(rng.integers(0, 13))
+        ins = bytes(rng.choice(list(b"ACGT"), size=n_ins).astype(np.uint8))
+        body = full[:cut] + ins + full[cut:]
+        if i % 3 == 0:                                                   # a second lump of insertions
+            c2 = int(rng.integers(4, 12))
+            body = body[:c2] + bytes(rng.choice(list(b"ACGT"), size=int(rng.integers(1, 6))).astype(np.uint8)) + body[c2:]
+        head = bytes(rng.choice(list(b"ACGT"), size=int(rng.integers(0, 30))).astype(np.uint8))
+        tail = bytes(rng.choice(list(b"ACGT"), size=int(rng.integers(100, 400))).astype(np.uint8))
+        rd = head + body + tail
+        if i % 4 == 1:
+            rd = bytes(A_rc(rd))
+        reads.append(rd)
+    bases, offsets = _abi.pack_reads(reads)
+    _, got, want = run_both(groups, bases, offsets)
+    assert_same(got, want)
+    assert len(got) > 300
+
+
+def A_rc(b):
+    return bytes(b.translate(bytes.maketrans(b"ACGT", b"TGCA"))[::-1])
+
+
 def test_empty_and_tiny_reads():
     groups = config_groups("nbd96")
     reads = [b"", b"A", b"ACGT", b"", bytes(groups[0].seqs[5]), bytes(groups[0].seqs[5])[:20], b"N" * 50, b""]
