@@ -615,7 +615,7 @@ int bb_annotate_batch_dev(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_o
     mark(c, K_BARCODE);
     if (n_hits) {
         if (any_pfx)  // shared rows of the padded barcodes, once per hit
-            hipLaunchKernelGGL(k_bar_prefix, dim3((n_hits + 255) / 256), dim3(256), 0, c->stream, (const uint8_t*)c->d_tables,
+            hipLaunchKernelGGL(k_bar_prefix, dim3((n_hits + 127) / 128), dim3(128), 0, c->stream, (const uint8_t*)c->d_tables,
                                (const bb_group_dev*)c->d_groups, (const bb_hit*)c->d_hits, n_hits, c->d_pfx);
         for (uint32_t g = 0; g < G; ++g) {
             if (c->gdev[g].WB == 1) launch_barcode<1>(c, d_bases, d_offsets, n_hits, g);
