@@ -257,13 +257,16 @@ struct hit_buf {
         ST.prev = cur_;                                                                         \
     } while (0)
 
+#ifndef BB_SCAN_LQ
+#define BB_SCAN_LQ 8u  // 16-byte pieces per streamed line: 8 = 128-byte lines (8 KB of LDS per wave), 4 = 64-byte lines
+#endif
 template <int W, int STRAND>
 __device__ __forceinline__ void flank_scan_lane(const uint8_t* __restrict__ bases, const uint64_t* __restrict__ offsets,
                                                 uint32_t n_reads, const uint8_t* __restrict__ tables, int32_t kk, int m, int32_t score0,
                                                 uint32_t off_pv0, uint32_t off_ovh,
                                                 uint32_t g, uint32_t n_groups, uint32_t* __restrict__ cnt,
                                                 bb_hit_raw* __restrict__ hits, uint32_t hit_cap, uint32_t* __restrict__ hit_count,
-                                                const uint32_t* s_peq, uint4* s_line /* this wave's [8][64] */) {
+                                                const uint32_t* s_peq, uint4* s_line /* this wave's [BB_SCAN_LQ][64] */) {
     constexpr int S = (W <= 2 ? 2 : 4);
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t read = blockIdx.x * 256u + threadIdx.x;
@@ -314,11 +317,12 @@ __device__ __forceinline__ void flank_scan_lane(const uint8_t* __restrict__ base
     // geometry of the walk in forward byte coordinates [0, n)
     const uint64_t a0 = (uint64_t)(uintptr_t)rb;
     uint32_t head, nlines;
-    if (STRAND == 0) head = (uint32_t)((128u - (uint32_t)(a0 & 127u)) & 127u);
-    else head = (uint32_t)((a0 + n) & 127u);
+    constexpr uint32_t LB = BB_SCAN_LQ * 16u, LSH = BB_SCAN_LQ == 8 ? 7u : 6u;  // line bytes (128 or 64)
+    if (STRAND == 0) head = (uint32_t)((LB - (uint32_t)(a0 & (LB - 1u))) & (LB - 1u));
+    else head = (uint32_t)((a0 + n) & (LB - 1u));
     if (head > n) head = n;
-    nlines = (n - head) >> 7;
-    const uint32_t tail = n - head - (nlines << 7);
+    nlines = (n - head) >> LSH;
+    const uint32_t tail = n - head - (nlines << LSH);
 
     // partial first line
     for (uint32_t t = 0; t < head; ++t) step(STRAND == 0 ? rb[t] : rb[n - 1 - t]);
@@ -330,16 +334,16 @@ __device__ __forceinline__ void flank_scan_lane(const uint8_t* __restrict__ base
     for (uint32_t l = 0; l < lmax; ++l) {
         const bool on = l < nlines;
         if (on) {
-            const uint8_t* src = STRAND == 0 ? rb + head + (l << 7) : rb + (n - head - ((l + 1) << 7));
+            const uint8_t* src = STRAND == 0 ? rb + head + (l << LSH) : rb + (n - head - ((l + 1) << LSH));
 #pragma unroll
-            for (int q = 0; q < 8; ++q)
+            for (int q = 0; q < (int)BB_SCAN_LQ; ++q)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 16 * q),
                                                  (__attribute__((address_space(3))) void*)(s_line + 64 * q), 16, 0, 0);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (on) {
-            for (int q = 0; q < 8; ++q) {
-                const uint4 v = s_line[64 * (STRAND == 0 ? q : 7 - q) + lane];
+            for (int q = 0; q < (int)BB_SCAN_LQ; ++q) {
+                const uint4 v = s_line[64 * (STRAND == 0 ? q : (int)BB_SCAN_LQ - 1 - q) + lane];
 #pragma unroll
                 for (int b0 = 0; b0 < 16; b0 += 4) {
                     // sc is exact here (either stepped or re-derived); wave-uniform choice of path
@@ -366,7 +370,7 @@ __device__ __forceinline__ void flank_scan_lane(const uint8_t* __restrict__ base
         }
     }
     // partial last line
-    for (uint32_t t = 0; t < tail; ++t) step(STRAND == 0 ? rb[head + (nlines << 7) + t] : rb[tail - 1 - t]);
+    for (uint32_t t = 0; t < tail; ++t) step(STRAND == 0 ? rb[head + (nlines << LSH) + t] : rb[tail - 1 - t]);
 
     // right overhang (oracle [H4]): C[n+o] = D[m-o][n] + floor(alpha*o), o = 1..m
     if (live) {
@@ -428,7 +432,7 @@ __global__ __launch_bounds__(256) void k_flank_scan2(const uint8_t* __restrict__
                                                      uint32_t hit_cap, uint32_t* __restrict__ hit_count) {
     constexpr int S = (W <= 2 ? 2 : 4);
     __shared__ __attribute__((aligned(16))) uint32_t s_peq[256 * S];
-    __shared__ __attribute__((aligned(16))) uint4 s_lines[4][8 * 64];
+    __shared__ __attribute__((aligned(16))) uint4 s_lines[4][BB_SCAN_LQ * 64];
     const bb_group_dev* G = groups + g;
     const uint32_t strand = blockIdx.y;
     {
