@@ -1080,7 +1080,7 @@ __global__ __launch_bounds__(512) void k_barcode_reg(const uint8_t* __restrict__
                     if (on & ((lo | hi) == 0u)) {  // Match column
                         const double w = __longlong_as_double((long long)(1022 - t) << 52);  // 2^-(t+1)
                         const double pw = __longlong_as_double((long long)(1023 + t) << 52);  // 2^t
-                        sc = sc + w * b2; b2 = b2 + b1; b1 = b1 + pw;
+                        sc = __fma_rn(w, b2, sc); b2 = b2 + b1; b1 = b1 + pw;  // w is a power of two: w * b2 is exact, the fma rounds once like the oracle's add
                     }
                     const int adv = (on & !((hi == 1u) & (lo == 0u))) ? 1 : 0;
                     pj += adv;
@@ -1442,7 +1442,7 @@ __global__ __launch_bounds__(CW <= 48 ? 768 : 512) void k_barcode_pfx(const uint
                     if (on & ((lo | hi) == 0u)) {
                         const double w = __longlong_as_double((long long)(1022 - t) << 52);
                         const double pw = __longlong_as_double((long long)(1023 + t) << 52);
-                        sc = sc + w * b2; b2 = b2 + b1; b1 = b1 + pw;
+                        sc = __fma_rn(w, b2, sc); b2 = b2 + b1; b1 = b1 + pw;  // w is a power of two: w * b2 is exact, the fma rounds once like the oracle's add
                     }
                     const int adv = (on & !((hi == 1u) & (lo == 0u))) ? 1 : 0;
                     pj += adv;
