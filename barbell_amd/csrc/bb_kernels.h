@@ -797,6 +797,11 @@ __global__ __launch_bounds__(1024) void k_barcode(const uint8_t* __restrict__ ba
 }
 
 // ------------------------------------------------------------------------------------------------
+// Columns are processed in wave-uniform groups of BB_CG (a group beyond the wave's widest window is skipped):
+// 2 instead of 8 wastes at most one column of a 44..46-column window instead of up to seven.
+#ifndef BB_CG
+#define BB_CG 2
+#endif
 // k_barcode_reg: register-resident, branch-free variant of k_barcode for m_bar <= 48 and windows of
 // at most CW columns (CW = 48 or 64; all ONT kit presets).  Same arithmetic as k_barcode, but
 //   * the two move bit-vectors of every column live in VGPRs (3 registers per column), written and
@@ -958,10 +963,10 @@ __global__ __launch_bounds__(512) void k_barcode_reg(const uint8_t* __restrict__
         const int TB = (m - 1) & 31;
         uint32_t up[2] = {0u, 0u}, dn[2] = {0u, 0u};  // bit c: score rises / falls going from position c to c+1
 #pragma unroll
-        for (int c0 = 0; c0 < CW; c0 += 8) {
+        for (int c0 = 0; c0 < CW; c0 += BB_CG) {
             if (c0 < wmax) {  // wave-uniform
 #pragma unroll
-                for (int c = c0; c < c0 + 8; ++c) {
+                for (int c = c0; c < c0 + BB_CG; ++c) {
                     const uint32_t code = (wc[c >> 2] >> (8 * (c & 3))) & 0xFu;
                     uint32_t eq[WB], d0[WB], ph[WB], mh[WB], l[WB], hh[WB];
                     const uint32_t ei = __umul24(code, NW) + pb;
@@ -1071,10 +1076,10 @@ __global__ __launch_bounds__(512) void k_barcode_reg(const uint8_t* __restrict__
             pj = nd; t = nd;
         }
 #pragma unroll
-        for (int c0 = 1; c0 <= CW; c0 += 8) {
+        for (int c0 = 1; c0 <= CW; c0 += BB_CG) {
             if (c0 <= wmax) {  // wave-uniform
 #pragma unroll
-                for (int c = c0; c < c0 + 8; ++c) {
+                for (int c = c0; c < c0 + BB_CG; ++c) {
                     const bool on = cand & (c > tstart) & (c <= best_pos);
                     const uint32_t lo = (uint32_t)(plo >> (c - 1)) & 1u, hi = (uint32_t)(phi >> (c - 1)) & 1u;
                     if (on & ((lo | hi) == 0u)) {  // Match column
@@ -1295,10 +1300,10 @@ __global__ __launch_bounds__(CW <= 48 ? 768 : 512) void k_barcode_pfx(const uint
         const int TB = MS - 1;
         uint32_t up[2] = {0u, 0u}, dn[2] = {0u, 0u};
 #pragma unroll
-        for (int c0 = 0; c0 < CW; c0 += 8) {
+        for (int c0 = 0; c0 < CW; c0 += BB_CG) {
             if (c0 < wmax) {  // wave-uniform
 #pragma unroll
-                for (int c = c0; c < c0 + 8; ++c) {
+                for (int c = c0; c < c0 + BB_CG; ++c) {
                     const uint32_t code = (wc[c >> 2] >> (8 * (c & 3))) & 0xFu;
                     const uint32_t eq = s_peq[__umul24(code, (uint32_t)N) + pb];
                     const uint32_t hp = (hin_p[c >> 5] >> (c & 31)) & 1u, hm = (hin_m[c >> 5] >> (c & 31)) & 1u;
@@ -1343,10 +1348,10 @@ __global__ __launch_bounds__(CW <= 48 ? 768 : 512) void k_barcode_pfx(const uint
     int32_t ntext = 0, cx = 0;
     const uint32_t start = 1u << (32 - MS);
 #pragma unroll
-    for (int c0 = CW; c0 >= 8; c0 -= 8) {
-        if (c0 - 7 <= wmax) {  // wave-uniform
+    for (int c0 = CW; c0 >= BB_CG; c0 -= BB_CG) {
+        if (c0 - (BB_CG - 1) <= wmax) {  // wave-uniform
 #pragma unroll
-            for (int c = c0; c > c0 - 8; --c) {
+            for (int c = c0; c > c0 - BB_CG; --c) {
                 b = (cand & (best_pos == c)) ? start : b;
                 const uint32_t Lr = L0[c - 1], Hr = H0[c - 1];
                 const uint32_t Dr = Lr & Hr;
@@ -1433,10 +1438,10 @@ __global__ __launch_bounds__(CW <= 48 ? 768 : 512) void k_barcode_pfx(const uint
             pj = nd; t = nd;
         }
 #pragma unroll
-        for (int c0 = 1; c0 <= CW; c0 += 8) {
+        for (int c0 = 1; c0 <= CW; c0 += BB_CG) {
             if (c0 <= wmax) {  // wave-uniform
 #pragma unroll
-                for (int c = c0; c < c0 + 8; ++c) {
+                for (int c = c0; c < c0 + BB_CG; ++c) {
                     const bool on = cand & (c > tstart) & (c <= best_pos);
                     const uint32_t lo = (uint32_t)(plo >> (c - 1)) & 1u, hi = (uint32_t)(phi >> (c - 1)) & 1u;
                     if (on & ((lo | hi) == 0u)) {
