@@ -506,6 +506,7 @@ __global__ __launch_bounds__(256) void k_scan_add(uint32_t* __restrict__ out, ui
 // size live in HBM-backed scratch and made this small kernel the largest HBM consumer of the pipeline
 // (profiles/r01_v3_pmc.txt: 10.9 GB fetched per 2 M reads).  The host picks the LDS variant whenever
 // (m + k + 1) * W * 512 bytes fit in 64 KB.
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 template <int W, bool MOVES_IN_LDS>
 __global__ __launch_bounds__(64) void k_flank_trace(const uint8_t* __restrict__ bases, const uint64_t* __restrict__ offsets,
                                                     const uint8_t* __restrict__ tables, const bb_group_dev* __restrict__ groups,
@@ -548,15 +549,43 @@ __global__ __launch_bounds__(64) void k_flank_trace(const uint8_t* __restrict__ 
         else { int bits = m - 32 * x; pv[x] = bits >= 32 ? 0xFFFFFFFFu : (bits > 0 ? ((1u << bits) - 1u) : 0u); }
         mv[x] = 0;
     }
-    for (int32_t c = 1; c <= w; ++c) {
-        const int32_t p = s0 + c - 1;  // scan position
-        const uint32_t ch = rb[h.strand ? (n - 1 - p) : p];
-        uint32_t eq[W], d0[W], ph[W], mh[W], l[W], hh[W];
-        load_eq<W, S>(peq, ch, eq);
-        myers_step<W>(pv, mv, eq, d0, ph, mh);
-        move_bits<W>(eq, d0, ph, l, hh);
+    // The window's text is fetched 16 scan positions at a time (one unaligned 16-byte load, the next chunk
+    // requested before the current one is consumed): a byte load per column left the DP waiting on ~50
+    // dependent HBM round trips per hit, which was most of this kernel's time.
+    auto load16 = [&](int32_t p0, uint32_t (&wq)[4]) {  // scan positions p0 .. p0+15 -> bytes 0..15 of wq (scan order)
+        const int32_t a = h.strand ? (n - 16 - p0) : p0;  // forward byte offset of the chunk's lowest address
+        if (a >= 0 && a + 16 <= n) {
+            u32x4_t v;
+            __builtin_memcpy(&v, rb + a, 16);
+            if (h.strand) { wq[0] = __builtin_bswap32(v[3]); wq[1] = __builtin_bswap32(v[2]); wq[2] = __builtin_bswap32(v[1]); wq[3] = __builtin_bswap32(v[0]); }
+            else { wq[0] = v[0]; wq[1] = v[1]; wq[2] = v[2]; wq[3] = v[3]; }
+        } else {  // chunk sticks out of the read: byte loads, positions outside the read read as 0 (never used)
+            wq[0] = wq[1] = wq[2] = wq[3] = 0u;
+            for (int b = 0; b < 16; ++b) {
+                const int32_t p = p0 + b;
+                if (p >= 0 && p < n) wq[b >> 2] |= (uint32_t)rb[h.strand ? (n - 1 - p) : p] << (8 * (b & 3));
+            }
+        }
+    };
+    uint32_t cur[4], nxt[4];
+    load16(s0, cur);
+    for (int32_t cb = 0; cb < w; cb += 16) {
+        if (cb + 16 < w) load16(s0 + cb + 16, nxt);
 #pragma unroll
-        for (int x = 0; x < W; ++x) put(c, x, l[x], hh[x]);
+        for (int b = 0; b < 16; ++b) {
+            const int32_t c = cb + b + 1;
+            if (c <= w) {
+                const uint32_t ch = (cur[b >> 2] >> (8 * (b & 3))) & 0xFFu;
+                uint32_t eq[W], d0[W], ph[W], mh[W], l[W], hh[W];
+                load_eq<W, S>(peq, ch, eq);
+                myers_step<W>(pv, mv, eq, d0, ph, mh);
+                move_bits<W>(eq, d0, ph, l, hh);
+#pragma unroll
+                for (int x = 0; x < W; ++x) put(c, x, l[x], hh[x]);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) cur[q] = nxt[q];
     }
     (void)ovh;
     // traceback from (j0, w)
@@ -602,14 +631,25 @@ __global__ __launch_bounds__(64) void k_flank_trace(const uint8_t* __restrict__ 
     dst[0] = src[0]; dst[1] = src[1];
     const int32_t wn = we - ws;
     const uint8_t* lut = tables + G.off_lut;
-    if (wn <= 64) {  // window codes for k_barcode_reg
+    if (wn <= 64) {  // window codes for k_barcode_reg: the window's bytes in four 16-byte loads, then the base-set LUT
+        u32x4_t tv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int32_t a = ws + 16 * q;
+            if (16 * q < wn && a + 16 <= n) __builtin_memcpy(&tv[q], rb + a, 16);
+            else {
+                tv[q] = u32x4_t{0u, 0u, 0u, 0u};
+                for (int b = 0; b < 16; ++b)
+                    if (16 * q + b < wn) tv[q][b >> 2] |= (uint32_t)rb[a + b] << (8 * (b & 3));
+            }
+        }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             uint32_t w4[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
             for (int b = 0; b < 16; ++b) {
                 const int c = 16 * q + b;
-                const uint32_t code = c < wn ? (uint32_t)lut[rb[ws + c]] : 0u;
+                const uint32_t code = c < wn ? (uint32_t)lut[(tv[q][b >> 2] >> (8 * (b & 3))) & 0xFFu] : 0u;
                 w4[b >> 2] |= code << (8 * (b & 3));
             }
             dst[2 + q] = make_uint4(w4[0], w4[1], w4[2], w4[3]);
