@@ -908,6 +908,45 @@ __device__ __forceinline__ void subpath_closed_form(unsigned long long plo, unsi
     bcost = cost;
 }
 
+// Lodhi (p = 3, lambda = 1/2) on the op planes of a traced path, oracle [H8]'s forward recurrence on power-of-two
+// scaled variables: b1 = 2^t a1, b2 = 2^t a2 change only at Match columns and score += 2^-(t+1) * b2 (the
+// product is exact, the fma rounds once like the oracle's add).  Columns (tstart, best_pos] carry the text ops
+// (plo/phi bit c-1: 00 Match, 01 Sub, 10 Ins); delrow = pattern rows consumed by Del; the time t of a column's op
+// counts the Dels before it.  Per column the work is three bit extractions from masks prepared once, the
+// Del-run length after the column's row, and — on Match columns — three f64 operations.
+template <int CW>
+__device__ __forceinline__ double lodhi_replay(unsigned long long plo, unsigned long long phi, unsigned long long delrow,
+                                               int32_t tstart, int32_t best_pos, int wmax) {
+    const unsigned long long onmask = low64(best_pos) & ~low64(tstart);  // bit c-1: column c carries an op
+    const unsigned long long mmask = onmask & ~(plo | phi);                 // Match columns
+    const unsigned long long amask = onmask & ~(phi & ~plo);                // the op consumes a pattern row (not Ins)
+    const uint32_t on_w[2] = {(uint32_t)onmask, (uint32_t)(onmask >> 32)}, m_w[2] = {(uint32_t)mmask, (uint32_t)(mmask >> 32)},
+                   a_w[2] = {(uint32_t)amask, (uint32_t)(amask >> 32)};
+    double sc = 0.0, b1 = 0.0, b2 = 0.0;
+    int32_t pj = onmask ? ctz64(~delrow) : 0;  // leading Dels
+    int32_t t = pj;
+#pragma unroll
+    for (int c0 = 1; c0 <= CW; c0 += BB_CG) {
+        if (c0 <= wmax) {  // wave-uniform
+#pragma unroll
+            for (int c = c0; c < c0 + BB_CG; ++c) {
+                const int k = c - 1;
+                const uint32_t onb = (on_w[k >> 5] >> (k & 31)) & 1u, ab = (a_w[k >> 5] >> (k & 31)) & 1u;
+                if ((m_w[k >> 5] >> (k & 31)) & 1u) {
+                    const double w = __longlong_as_double((long long)(1022 - t) << 52);   // 2^-(t+1)
+                    const double pw = __longlong_as_double((long long)(1023 + t) << 52);  // 2^t
+                    sc = __fma_rn(w, b2, sc); b2 = b2 + b1; b1 = b1 + pw;
+                }
+                pj += (int32_t)ab;
+                const int32_t nd = onb ? ctz64(~(delrow >> pj)) : 0;  // Dels that follow this column's op
+                pj += nd;
+                t += (int32_t)onb + nd;
+            }
+        }
+    }
+    return sc;
+}
+
 template <int WB, int CW>
 __global__ __launch_bounds__(512) void k_barcode_reg(const uint8_t* __restrict__ tables, const bb_group_dev* __restrict__ groups,
                                                      uint32_t g, const bb_hit* __restrict__ hits, const uint32_t* __restrict__ hit_list,
@@ -1108,35 +1147,10 @@ __global__ __launch_bounds__(512) void k_barcode_reg(const uint8_t* __restrict__
     // ---- forward replay: Lodhi only.  Scaled recurrence (see header): b1 = 2^t a1, b2 = 2^t a2 change
     // only at match columns; score += 2^-(t+1) * b2 (exact scaling, same rounding as the oracle's add).
     double s_norm = -1.0;
-    {
-        double sc = 0.0, b1 = 0.0, b2 = 0.0;
-        int32_t pj = 0, t = 0;
-        {   // leading Dels
-            const int nd = cand ? ctz64(~delrow) : 0;
-            pj = nd; t = nd;
-        }
-#pragma unroll
-        for (int c0 = 1; c0 <= CW; c0 += BB_CG) {
-            if (c0 <= wmax) {  // wave-uniform
-#pragma unroll
-                for (int c = c0; c < c0 + BB_CG; ++c) {
-                    const bool on = cand & (c > tstart) & (c <= best_pos);
-                    const uint32_t lo = (uint32_t)(plo >> (c - 1)) & 1u, hi = (uint32_t)(phi >> (c - 1)) & 1u;
-                    if (on & ((lo | hi) == 0u)) {  // Match column
-                        const double w = __longlong_as_double((long long)(1022 - t) << 52);  // 2^-(t+1)
-                        const double pw = __longlong_as_double((long long)(1023 + t) << 52);  // 2^t
-                        sc = __fma_rn(w, b2, sc); b2 = b2 + b1; b1 = b1 + pw;  // w is a power of two: w * b2 is exact, the fma rounds once like the oracle's add
-                    }
-                    const int adv = (on & !((hi == 1u) & (lo == 0u))) ? 1 : 0;
-                    pj += adv;
-                    const int nd = on ? ctz64(~(delrow >> pj)) : 0;   // Dels that follow this column's op
-                    pj += nd;
-                    t += (on ? 1 : 0) + nd;
-                }
-            }
-        }
-        if (cand) s_norm = G.perfect > 0.0 ? sc / G.perfect : 0.0;
-    }
+    if (cand) {
+        const double sc = lodhi_replay<CW>(plo, phi, delrow, tstart, best_pos, wmax);
+        s_norm = G.perfect > 0.0 ? sc / G.perfect : 0.0;
+    } else (void)lodhi_replay<CW>(0ull, 0ull, 0ull, 0, 0, wmax);  // the loop is wave-uniform: idle lanes walk it with empty masks
     // ---- pass decision (searcher.rs:303-328), then per-hit argmax (first maximum) and runner-up:
     // searcher.rs:377,390-396 ----
     __syncthreads();
@@ -1470,35 +1484,10 @@ __global__ __launch_bounds__(CW <= 48 ? 768 : 512) void k_barcode_pfx(const uint
     const unsigned long long diagrow = ((unsigned long long)__brev(dg) << P) | (unsigned long long)(__brev(dgh) >> (32 - P));
     const unsigned long long delrow = cand ? (low64(m) & ~diagrow) : 0ull;
     double s_norm = -1.0;
-    {
-        double sc = 0.0, b1 = 0.0, b2 = 0.0;
-        int32_t pj = 0, t = 0;
-        {
-            const int nd = cand ? ctz64(~delrow) : 0;
-            pj = nd; t = nd;
-        }
-#pragma unroll
-        for (int c0 = 1; c0 <= CW; c0 += BB_CG) {
-            if (c0 <= wmax) {  // wave-uniform
-#pragma unroll
-                for (int c = c0; c < c0 + BB_CG; ++c) {
-                    const bool on = cand & (c > tstart) & (c <= best_pos);
-                    const uint32_t lo = (uint32_t)(plo >> (c - 1)) & 1u, hi = (uint32_t)(phi >> (c - 1)) & 1u;
-                    if (on & ((lo | hi) == 0u)) {
-                        const double w = __longlong_as_double((long long)(1022 - t) << 52);
-                        const double pw = __longlong_as_double((long long)(1023 + t) << 52);
-                        sc = __fma_rn(w, b2, sc); b2 = b2 + b1; b1 = b1 + pw;  // w is a power of two: w * b2 is exact, the fma rounds once like the oracle's add
-                    }
-                    const int adv = (on & !((hi == 1u) & (lo == 0u))) ? 1 : 0;
-                    pj += adv;
-                    const int nd = on ? ctz64(~(delrow >> pj)) : 0;
-                    pj += nd;
-                    t += (on ? 1 : 0) + nd;
-                }
-            }
-        }
-        if (cand) s_norm = G.perfect > 0.0 ? sc / G.perfect : 0.0;
-    }
+    if (cand) {
+        const double sc = lodhi_replay<CW>(plo, phi, delrow, tstart, best_pos, wmax);
+        s_norm = G.perfect > 0.0 ? sc / G.perfect : 0.0;
+    } else (void)lodhi_replay<CW>(0ull, 0ull, 0ull, 0, 0, wmax);  // the loop is wave-uniform: idle lanes walk it with empty masks
     __syncthreads();
     if (active) {
         const bool pass2 = s_cnt1[hl] <= 1 && G.k1 < G.k2;
