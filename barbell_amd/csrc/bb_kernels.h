@@ -922,9 +922,13 @@ __device__ __forceinline__ double lodhi_replay(unsigned long long plo, unsigned 
     const unsigned long long amask = onmask & ~(phi & ~plo);                // the op consumes a pattern row (not Ins)
     const uint32_t on_w[2] = {(uint32_t)onmask, (uint32_t)(onmask >> 32)}, m_w[2] = {(uint32_t)mmask, (uint32_t)(mmask >> 32)},
                    a_w[2] = {(uint32_t)amask, (uint32_t)(amask >> 32)};
+    // rows not consumed by Del; every bit from m up is set, so a shifted copy is never zero and a Del run that
+    // reaches the last row ends at the sentinel
+    const unsigned long long kept = ~delrow;
     double sc = 0.0, b1 = 0.0, b2 = 0.0;
-    int32_t pj = onmask ? ctz64(~delrow) : 0;  // leading Dels
-    int32_t t = pj;
+    int32_t pj = onmask ? __builtin_ctzll(kept) : 0;  // leading Dels
+    // high dword of 2^t, advanced with t; 2^-(t+1) has (1022 - t) << 20 = 0x7FD00000 - (t << 20) there
+    uint32_t e_hi = (uint32_t)(1023 + pj) << 20;
 #pragma unroll
     for (int c0 = 1; c0 <= CW; c0 += BB_CG) {
         if (c0 <= wmax) {  // wave-uniform
@@ -933,14 +937,16 @@ __device__ __forceinline__ double lodhi_replay(unsigned long long plo, unsigned 
                 const int k = c - 1;
                 const uint32_t onb = (on_w[k >> 5] >> (k & 31)) & 1u, ab = (a_w[k >> 5] >> (k & 31)) & 1u;
                 if ((m_w[k >> 5] >> (k & 31)) & 1u) {
-                    const double w = __longlong_as_double((long long)(1022 - t) << 52);   // 2^-(t+1)
-                    const double pw = __longlong_as_double((long long)(1023 + t) << 52);  // 2^t
+                    const double w = __hiloint2double((int)(0x7FD00000u - e_hi), 0);  // 2^-(t+1)
+                    const double pw = __hiloint2double((int)e_hi, 0);                               // 2^t
                     sc = __fma_rn(w, b2, sc); b2 = b2 + b1; b1 = b1 + pw;
                 }
                 pj += (int32_t)ab;
-                const int32_t nd = onb ? ctz64(~(delrow >> pj)) : 0;  // Dels that follow this column's op
+                // Dels that follow this column's op; 0 by itself outside (tstart, best_pos] and on Ins columns,
+                // where pj rests on a kept row (or on the sentinel at m)
+                const int32_t nd = __builtin_ctzll(kept >> pj);
                 pj += nd;
-                t += (int32_t)onb + nd;
+                e_hi += (onb + (uint32_t)nd) << 20;
             }
         }
     }
