@@ -1400,12 +1400,11 @@ __global__ __launch_bounds__(CW <= 48 ? 768 : 512) void k_barcode_pfx(const uint
     bool cand = active && best_pos >= 0 && best_cost <= G.k2;
     // ---- traceback, phase 1: the lane's own rows, one-hot cursor on one 32-bit word (row P+1 <-> bit 31).
     // The cursor leaves the word either by the carry of the Del-run addition (the run continues in the shared
-    // rows at the same column) or by a Match/Sub out of row P+1 (next column); either way phase 2 starts at
-    // column cx with the cursor entering row P. ----
+    // rows at the same column, which then has no text op in this phase) or by a Match/Sub out of row P+1 (next
+    // column); either way phase 2 starts with the cursor entering row P. ----
     const int32_t rlo = G.rel_lo, rhi = G.rel_hi;
     unsigned long long plo = 0ull, phi = 0ull;
     uint32_t b = 0u, dg = 0u;
-    int32_t ntext = 0, cx = 0;
     const uint32_t start = 1u << (32 - MS);
 #pragma unroll
     for (int c0 = CW; c0 >= BB_CG; c0 -= BB_CG) {
@@ -1415,21 +1414,20 @@ __global__ __launch_bounds__(CW <= 48 ? 768 : 512) void k_barcode_pfx(const uint
                 b = (cand & (best_pos == c)) ? start : b;
                 const uint32_t Lr = L0[c - 1], Hr = H0[c - 1];
                 const uint32_t Dr = Lr & Hr;
-                const uint32_t sum = Dr + b;
-                const bool carry = sum < b;
-                const uint32_t nb = sum & ~Dr;
+                const uint32_t nb = (Dr + b) & ~Dr;
                 const bool has = nb != 0u, lo = (Lr & nb) != 0u, hi = (Hr & nb) != 0u;
                 plo |= lo ? (1ull << (c - 1)) : 0ull;
                 phi |= hi ? (1ull << (c - 1)) : 0ull;
                 const bool consume = has & !hi;
                 dg |= consume ? nb : 0u;
-                const bool out = consume & ((nb >> 31) != 0u);
-                cx = carry ? c : (out ? c - 1 : cx);
                 b = consume ? (nb << 1) : nb;
-                ntext += has ? 1 : 0;
             }
         }
     }
+    // Text ops of phase 1 = rows it consumed + its Ins columns.  Whichever way the cursor left the word, the
+    // columns best_pos .. cx+1 carry exactly those ops: phase 2 starts at column cx = best_pos - ntext.
+    int32_t ntext = cand ? __popc(dg) + __popcll(phi & ~plo) : 0;
+    const int32_t cx = cand ? best_pos - ntext : 0;
     // ---- phase 2: the shared rows (row r <-> bit P - r), move bits of the hit's prefix record in LDS.
     // The 16 columns below cx are fetched with independent LDS reads and walked with static
     // register indices (no load -> address dependency per column); a cursor still alive after them (more than
