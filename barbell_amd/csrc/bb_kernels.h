@@ -1119,7 +1119,6 @@ __global__ __launch_bounds__(512) void k_barcode_reg(const uint8_t* __restrict__
                     const bool consume = has & !hi;
                     dg_hi |= consume ? nb : 0u;
                     b_hi = consume ? (nb << 1) : nb;
-                    ntext += has ? 1 : 0;
                 }
             } else {
 #pragma unroll
@@ -1141,11 +1140,12 @@ __global__ __launch_bounds__(512) void k_barcode_reg(const uint8_t* __restrict__
                     dg_hi |= consume ? nb_hi : 0u;
                     const unsigned long long nx = consume ? (nb << 1) : nb;
                     b_lo = (uint32_t)nx; b_hi = (uint32_t)(nx >> 32);
-                    ntext += has ? 1 : 0;
                 }
             }
         }
     }
+    // text ops = rows consumed by a Match/Sub + Ins columns
+    ntext = cand ? __popc(dg_lo) + __popc(dg_hi) + __popcll(phi & ~plo) : 0;
     const int32_t tstart = cand ? best_pos - ntext : 0;   // columns (tstart, best_pos] carry the text ops
     // consumed rows back in natural order (row r <-> bit r-1); rows never consumed were deleted
     const unsigned long long diagrow = ((unsigned long long)__brev(dg_lo) << 32) | __brev(dg_hi);
