@@ -27,6 +27,13 @@
 // d0: diagonal-zero vector, ph/mh: horizontal deltas (before the shift), all for the new column.
 // Top boundary row is all zero (text is free: D[0][i] = 0), so the horizontal carry-in is 0.
 // ------------------------------------------------------------------------------------------------
+// gfx950 three-input boolean: result bit = TT[(a << 2) | (b << 1) | c].  The compiler finds some of these on its
+// own but leaves e.g. pv = mhs | ~(d0 | phs) as or + not + or; spelled out they are one instruction each.
+template <int TT>
+__device__ __forceinline__ uint32_t bitop3(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, TT); }
+#define BB_TT_XOR_OR 0xBE    /* (a ^ b) | c   */
+#define BB_TT_OR_NOR 0xF1    /* a | ~(b | c)  */
+
 template <int W>
 __device__ __forceinline__ void myers_step(uint32_t (&pv)[W], uint32_t (&mv)[W], const uint32_t (&eq)[W],
                                            uint32_t (&d0)[W], uint32_t (&ph)[W], uint32_t (&mh)[W]) {
@@ -36,11 +43,11 @@ __device__ __forceinline__ void myers_step(uint32_t (&pv)[W], uint32_t (&mv)[W],
         uint32_t x = eq[w] & pv[w];
         uint64_t s = (uint64_t)x + (uint64_t)pv[w] + (uint64_t)carry;
         carry = (uint32_t)(s >> 32);
-        d0[w] = (((uint32_t)s) ^ pv[w]) | eq[w] | mv[w];
+        d0[w] = bitop3<BB_TT_XOR_OR>((uint32_t)s, pv[w], eq[w]) | mv[w];
     }
 #pragma unroll
     for (int w = 0; w < W; ++w) {
-        ph[w] = mv[w] | ~(d0[w] | pv[w]);
+        ph[w] = bitop3<BB_TT_OR_NOR>(mv[w], d0[w], pv[w]);
         mh[w] = pv[w] & d0[w];
     }
     uint32_t phs[W], mhs[W];
@@ -51,7 +58,7 @@ __device__ __forceinline__ void myers_step(uint32_t (&pv)[W], uint32_t (&mv)[W],
     }
 #pragma unroll
     for (int w = 0; w < W; ++w) {
-        pv[w] = mhs[w] | ~(d0[w] | phs[w]);
+        pv[w] = bitop3<BB_TT_OR_NOR>(mhs[w], d0[w], phs[w]);
         mv[w] = phs[w] & d0[w];
     }
 }
@@ -66,11 +73,9 @@ template <int W>
 __device__ __forceinline__ void move_bits(const uint32_t (&eq)[W], const uint32_t (&d0)[W], const uint32_t (&ph)[W],
                                           uint32_t (&lo)[W], uint32_t (&hi)[W]) {
 #pragma unroll
-    for (int w = 0; w < W; ++w) {
-        uint32_t isM = d0[w] & eq[w];
-        uint32_t l = ~(isM | ph[w]);
-        lo[w] = l;
-        hi[w] = (ph[w] & ~isM) | (l & d0[w]);
+    for (int w = 0; w < W; ++w) {  // both planes are three-input functions of (d0, eq, ph)
+        lo[w] = bitop3<0x15>(d0[w], eq[w], ph[w]);  // ~((d0 & eq) | ph)
+        hi[w] = bitop3<0x3A>(d0[w], eq[w], ph[w]);  // (ph & ~(d0 & eq)) | (lo & d0)
     }
 }
 
@@ -1369,14 +1374,14 @@ __global__ __launch_bounds__(CW <= 48 ? 768 : 512) void k_barcode_pfx(const uint
                     const uint32_t hp = (hin_p[c >> 5] >> (c & 31)) & 1u, hm = (hin_m[c >> 5] >> (c & 31)) & 1u;
                     const uint32_t eqx = eq | hm;
                     const uint32_t x = eqx & pv;
-                    const uint32_t d0 = ((x + pv) ^ pv) | eqx | mv;
-                    const uint32_t ph = mv | ~(d0 | pv), mh = pv & d0;
-                    const uint32_t isM = d0 & eq, l = ~(isM | ph), hh = (ph & ~isM) | (l & d0);
+                    const uint32_t d0 = bitop3<BB_TT_XOR_OR>(x + pv, pv, eqx) | mv;
+                    const uint32_t ph = bitop3<BB_TT_OR_NOR>(mv, d0, pv), mh = pv & d0;
+                    const uint32_t l = bitop3<0x15>(d0, eq, ph), hh = bitop3<0x3A>(d0, eq, ph);  // move planes (see move_bits)
                     L0[c] = __brev(l); H0[c] = __brev(hh);  // row P+1 <-> bit 31, row P+32 <-> bit 0
                     up[c >> 5] |= ((ph >> TB) & 1u) << (c & 31);
                     dn[c >> 5] |= ((mh >> TB) & 1u) << (c & 31);
                     const uint32_t phs = (ph << 1) | hp, mhs = (mh << 1) | hm;
-                    pv = mhs | ~(d0 | phs);
+                    pv = bitop3<BB_TT_OR_NOR>(mhs, d0, phs);
                     mv = phs & d0;
                 }
             }
