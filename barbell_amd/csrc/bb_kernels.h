@@ -1291,7 +1291,8 @@ __global__ __launch_bounds__(CW <= 48 ? 768 : 512) void k_barcode_pfx(const uint
     const uint32_t n_list = hit_list ? list_cnt[g] : n_hits_all;
     const uint32_t n_iter = (n_list + hpb - 1) / hpb;
     if (blockIdx.x >= n_iter) return;
-    const int N = G.n_seqs, m = G.m_bar, P = G.pfx, MS = m - P;  // MS rows per lane (<= 32)
+    const int N = G.n_seqs, m = G.m_bar, P = G.pfx;
+    constexpr int MS = 32;  // rows per lane: the split is made at pfx = m_bar - 32
     constexpr int PIECES_H = (int)(sizeof(bb_hit) / 16), PIECES_P = (int)(sizeof(bb_hit_pfx) / 16), PIECES = PIECES_H + PIECES_P;
     // LDS carve: [hit + prefix records: hpb x 368 B][max u64[hpb]][second u64[hpb]][cnt1 i32[hpb]][top i32[hpb]][peq 2*16*N words]
     uint4* s_hit = reinterpret_cast<uint4*>(smem);
@@ -1361,9 +1362,10 @@ __global__ __launch_bounds__(CW <= 48 ? 768 : 512) void k_barcode_pfx(const uint
         const uint4 hv = s_hit[hls * PIECES + PIECES_H];  // {ph lo, ph hi, mh lo, mh hi}
         const uint32_t hin_p[2] = {hv.x, hv.y}, hin_m[2] = {hv.z, hv.w};
         const uint32_t pb = (uint32_t)((active ? H.strand : 0) * 16) * (uint32_t)N + (uint32_t)p;
-        uint32_t pv = MS >= 32 ? 0xFFFFFFFFu : ((1u << MS) - 1u), mv = 0u;
-        const int TB = MS - 1;
-        uint32_t up[2] = {0u, 0u}, dn[2] = {0u, 0u};
+        uint32_t pv = 0xFFFFFFFFu, mv = 0u;
+        // bottom-row deltas (bit 31 of ph / mh), newest column at bit 0: one v_alignbit per column and plane;
+        // the column order is restored after the loop
+        uint32_t upr[2] = {0u, 0u}, dnr[2] = {0u, 0u};
 #pragma unroll
         for (int c0 = 0; c0 < CW; c0 += BB_CG) {
             if (c0 < wmax) {  // wave-uniform
@@ -1378,14 +1380,20 @@ __global__ __launch_bounds__(CW <= 48 ? 768 : 512) void k_barcode_pfx(const uint
                     const uint32_t ph = bitop3<BB_TT_OR_NOR>(mv, d0, pv), mh = pv & d0;
                     const uint32_t l = bitop3<0x15>(d0, eq, ph), hh = bitop3<0x3A>(d0, eq, ph);  // move planes (see move_bits)
                     L0[c] = __brev(l); H0[c] = __brev(hh);  // row P+1 <-> bit 31, row P+32 <-> bit 0
-                    up[c >> 5] |= ((ph >> TB) & 1u) << (c & 31);
-                    dn[c >> 5] |= ((mh >> TB) & 1u) << (c & 31);
+                    upr[c >> 5] = __builtin_amdgcn_alignbit(upr[c >> 5], ph, 31);  // (acc << 1) | (ph >> 31)
+                    dnr[c >> 5] = __builtin_amdgcn_alignbit(dnr[c >> 5], mh, 31);
                     const uint32_t phs = (ph << 1) | hp, mhs = (mh << 1) | hm;
                     pv = bitop3<BB_TT_OR_NOR>(mhs, d0, phs);
                     mv = phs & d0;
                 }
             }
         }
+        // columns processed (wave-uniform): the groups below wmax; word w holds its columns newest-first
+        const int pc = min(CW, ((wmax + BB_CG - 1) / BB_CG) * BB_CG);
+        const int n0 = min(pc, 32), n1 = pc - n0;
+        uint32_t up[2], dn[2];
+        up[0] = n0 ? __brev(upr[0]) >> (32 - n0) : 0u; dn[0] = n0 ? __brev(dnr[0]) >> (32 - n0) : 0u;
+        up[1] = n1 ? __brev(upr[1]) >> (32 - n1) : 0u; dn[1] = n1 ? __brev(dnr[1]) >> (32 - n1) : 0u;
         const unsigned long long wmask = wn >= 64 ? ~0ull : ((1ull << wn) - 1ull);
         const unsigned long long Pm = (((unsigned long long)up[1] << 32) | up[0]) & wmask;
         const unsigned long long Mm = (((unsigned long long)dn[1] << 32) | dn[0]) & wmask;
