@@ -1050,8 +1050,10 @@ __global__ __launch_bounds__(512) void k_barcode_reg(const uint8_t* __restrict__
         uint32_t pv[WB], mv[WB];
 #pragma unroll
         for (int x = 0; x < WB; ++x) { int bits = m - 32 * x; pv[x] = bits >= 32 ? 0xFFFFFFFFu : (bits > 0 ? ((1u << bits) - 1u) : 0u); mv[x] = 0; }
-        const int TB = (m - 1) & 31;
-        uint32_t up[2] = {0u, 0u}, dn[2] = {0u, 0u};  // bit c: score rises / falls going from position c to c+1
+        const int TBS = 31 - ((m - 1) & 31);  // shift that brings the bottom row's bit to bit 31
+        // bottom-row deltas, newest column at bit 0 (one shift + one v_alignbit per column and plane); the
+        // column order is restored after the loop.  Bit c of up/dn: score rises / falls going from position c to c+1
+        uint32_t upr[2] = {0u, 0u}, dnr[2] = {0u, 0u};
 #pragma unroll
         for (int c0 = 0; c0 < CW; c0 += BB_CG) {
             if (c0 < wmax) {  // wave-uniform
@@ -1068,11 +1070,16 @@ __global__ __launch_bounds__(512) void k_barcode_reg(const uint8_t* __restrict__
                     L0[c] = __brev(l[0]); H0[c] = __brev(hh[0]);
                     if constexpr (WB == 2) X[c] = (__brev(l[1]) >> 16) | (__brev(hh[1]) & 0xFFFF0000u);
                     else X[c] = 0;
-                    up[c >> 5] |= ((ph[WB - 1] >> TB) & 1u) << (c & 31);
-                    dn[c >> 5] |= ((mh[WB - 1] >> TB) & 1u) << (c & 31);
+                    upr[c >> 5] = __builtin_amdgcn_alignbit(upr[c >> 5], ph[WB - 1] << TBS, 31);
+                    dnr[c >> 5] = __builtin_amdgcn_alignbit(dnr[c >> 5], mh[WB - 1] << TBS, 31);
                 }
             }
         }
+        const int pc = min(CW, ((wmax + BB_CG - 1) / BB_CG) * BB_CG);  // columns processed (wave-uniform)
+        const int n0 = min(pc, 32), n1 = pc - n0;
+        uint32_t up[2], dn[2];
+        up[0] = n0 ? __brev(upr[0]) >> (32 - n0) : 0u; dn[0] = n0 ? __brev(dnr[0]) >> (32 - n0) : 0u;
+        up[1] = n1 ? __brev(upr[1]) >> (32 - n1) : 0u; dn[1] = n1 ? __brev(dnr[1]) >> (32 - n1) : 0u;
         // positions 0..wn; deltas of columns >= wn are garbage and masked off
         const unsigned long long wmask = wn >= 64 ? ~0ull : ((1ull << wn) - 1ull);
         const unsigned long long P = (((unsigned long long)up[1] << 32) | up[0]) & wmask;
