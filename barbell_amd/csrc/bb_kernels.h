@@ -1046,7 +1046,9 @@ __global__ __launch_bounds__(512) void k_barcode_reg(const uint8_t* __restrict__
 #pragma unroll
         for (int q = 0; q < CW / 16; ++q) { uint4 v = s_hit[hls * PIECES + 2 + q]; wc[4 * q] = v.x; wc[4 * q + 1] = v.y; wc[4 * q + 2] = v.z; wc[4 * q + 3] = v.w; }
         const uint32_t NW = (uint32_t)(N * WB);
-        const uint32_t pb = (uint32_t)((active ? H.strand : 0) * 16) * NW + (uint32_t)p * WB;  // word index into s_peq
+        // byte offset into s_peq of this lane's column 0 entry; one v_mad_u32_u24 per column adds code * row bytes
+        const uint32_t pb4 = ((uint32_t)((active ? H.strand : 0) * 16) * NW + (uint32_t)p * WB) * 4u, NW4 = NW * 4u;
+        const uint8_t* s_peq_b = reinterpret_cast<const uint8_t*>(s_peq);
         uint32_t pv[WB], mv[WB];
 #pragma unroll
         for (int x = 0; x < WB; ++x) { int bits = m - 32 * x; pv[x] = bits >= 32 ? 0xFFFFFFFFu : (bits > 0 ? ((1u << bits) - 1u) : 0u); mv[x] = 0; }
@@ -1061,9 +1063,9 @@ __global__ __launch_bounds__(512) void k_barcode_reg(const uint8_t* __restrict__
                 for (int c = c0; c < c0 + BB_CG; ++c) {
                     const uint32_t code = (wc[c >> 2] >> (8 * (c & 3))) & 0xFu;
                     uint32_t eq[WB], d0[WB], ph[WB], mh[WB], l[WB], hh[WB];
-                    const uint32_t ei = __umul24(code, NW) + pb;
-                    if constexpr (WB == 2) { uint2 v = *reinterpret_cast<const uint2*>(s_peq + ei); eq[0] = v.x; eq[1] = v.y; }
-                    else eq[0] = s_peq[ei];
+                    const uint32_t ei = __umul24(code, NW4) + pb4;
+                    if constexpr (WB == 2) { uint2 v = *reinterpret_cast<const uint2*>(s_peq_b + ei); eq[0] = v.x; eq[1] = v.y; }
+                    else eq[0] = *reinterpret_cast<const uint32_t*>(s_peq_b + ei);
                     myers_step<WB>(pv, mv, eq, d0, ph, mh);
                     move_bits<WB>(eq, d0, ph, l, hh);
                     // stored bit-reversed (row r <-> bit 64-r of {L0|H0 : X-part}) for the one-hot traceback below
@@ -1368,7 +1370,8 @@ __global__ __launch_bounds__(CW <= 48 ? 768 : 512) void k_barcode_pfx(const uint
         for (int q = 0; q < CW / 16; ++q) { uint4 v = s_hit[hls * PIECES + 2 + q]; wc[4 * q] = v.x; wc[4 * q + 1] = v.y; wc[4 * q + 2] = v.z; wc[4 * q + 3] = v.w; }
         const uint4 hv = s_hit[hls * PIECES + PIECES_H];  // {ph lo, ph hi, mh lo, mh hi}
         const uint32_t hin_p[2] = {hv.x, hv.y}, hin_m[2] = {hv.z, hv.w};
-        const uint32_t pb = (uint32_t)((active ? H.strand : 0) * 16) * (uint32_t)N + (uint32_t)p;
+        const uint32_t pb4 = ((uint32_t)((active ? H.strand : 0) * 16) * (uint32_t)N + (uint32_t)p) * 4u, N4 = (uint32_t)N * 4u;
+        const uint8_t* s_peq_b = reinterpret_cast<const uint8_t*>(s_peq);
         uint32_t pv = 0xFFFFFFFFu, mv = 0u;
         // bottom-row deltas (bit 31 of ph / mh), newest column at bit 0: one v_alignbit per column and plane;
         // the column order is restored after the loop
@@ -1379,7 +1382,7 @@ __global__ __launch_bounds__(CW <= 48 ? 768 : 512) void k_barcode_pfx(const uint
 #pragma unroll
                 for (int c = c0; c < c0 + BB_CG; ++c) {
                     const uint32_t code = (wc[c >> 2] >> (8 * (c & 3))) & 0xFu;
-                    const uint32_t eq = s_peq[__umul24(code, (uint32_t)N) + pb];
+                    const uint32_t eq = *reinterpret_cast<const uint32_t*>(s_peq_b + (__umul24(code, N4) + pb4));
                     const uint32_t hp = (hin_p[c >> 5] >> (c & 31)) & 1u, hm = (hin_m[c >> 5] >> (c & 31)) & 1u;
                     const uint32_t eqx = eq | hm;
                     const uint32_t x = eqx & pv;
