@@ -1428,16 +1428,18 @@ __global__ __launch_bounds__(CW <= 48 ? 768 : 512) void k_barcode_pfx(const uint
     const int32_t rlo = G.rel_lo, rhi = G.rel_hi;
     unsigned long long plo = 0ull, phi = 0ull;
     uint32_t b = 0u, dg = 0u;
-    const uint32_t start = 1u << (32 - MS);
+    // the cursor enters at row m = bit 0 of the word in column best_pos: that column's bit of this mask is simply
+    // added in with the Del-run sum (v_add3)
+    const unsigned long long smask = (cand && best_pos >= 1) ? 1ull << (best_pos - 1) : 0ull;  // best_pos 0: nothing to walk
+    const uint32_t sm_w[2] = {(uint32_t)smask, (uint32_t)(smask >> 32)};
 #pragma unroll
     for (int c0 = CW; c0 >= BB_CG; c0 -= BB_CG) {
         if (c0 - (BB_CG - 1) <= wmax) {  // wave-uniform
 #pragma unroll
             for (int c = c0; c > c0 - BB_CG; --c) {
-                b = (cand & (best_pos == c)) ? start : b;
                 const uint32_t Lr = L0[c - 1], Hr = H0[c - 1];
                 const uint32_t Dr = Lr & Hr;
-                const uint32_t nb = (Dr + b) & ~Dr;
+                const uint32_t nb = (Dr + b + ((sm_w[(c - 1) >> 5] >> ((c - 1) & 31)) & 1u)) & ~Dr;
                 const bool has = nb != 0u, lo = (Lr & nb) != 0u, hi = (Hr & nb) != 0u;
                 plo |= lo ? (1ull << (c - 1)) : 0ull;
                 phi |= hi ? (1ull << (c - 1)) : 0ull;
