@@ -1384,15 +1384,16 @@ __global__ __launch_bounds__(CW <= 48 ? 768 : 512) void k_barcode_pfx(const uint
                     const uint32_t code = (wc[c >> 2] >> (8 * (c & 3))) & 0xFu;
                     const uint32_t eq = *reinterpret_cast<const uint32_t*>(s_peq_b + (__umul24(code, N4) + pb4));
                     const uint32_t hp = (hin_p[c >> 5] >> (c & 31)) & 1u, hm = (hin_m[c >> 5] >> (c & 31)) & 1u;
-                    const uint32_t eqx = eq | hm;
-                    const uint32_t x = eqx & pv;
-                    const uint32_t d0 = bitop3<BB_TT_XOR_OR>(x + pv, pv, eqx) | mv;
+                    const uint32_t x = bitop3<0xC8>(eq, pv, hm);  // (eq | hm) & pv
+                    const uint32_t d0 = bitop3<BB_TT_XOR_OR>(x + pv, pv, eq) | hm | mv;  // v_bitop3 + v_or3
                     const uint32_t ph = bitop3<BB_TT_OR_NOR>(mv, d0, pv), mh = pv & d0;
                     const uint32_t l = bitop3<0x15>(d0, eq, ph), hh = bitop3<0x3A>(d0, eq, ph);  // move planes (see move_bits)
                     L0[c] = __brev(l); H0[c] = __brev(hh);  // row P+1 <-> bit 31, row P+32 <-> bit 0
                     upr[c >> 5] = __builtin_amdgcn_alignbit(upr[c >> 5], ph, 31);  // (acc << 1) | (ph >> 31)
                     dnr[c >> 5] = __builtin_amdgcn_alignbit(dnr[c >> 5], mh, 31);
-                    const uint32_t phs = (ph << 1) | hp, mhs = (mh << 1) | hm;
+                    uint32_t phs = (ph << 1) | hp;
+                    const uint32_t mhs = (mh << 1) | hm;
+                    asm("" : "+v"(phs));  // keep the shifted vector in one register: v_lshl_or, then one op each for pv and mv
                     pv = bitop3<BB_TT_OR_NOR>(mhs, d0, phs);
                     mv = phs & d0;
                 }
