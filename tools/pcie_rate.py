@@ -14,8 +14,21 @@ dm = A.Demuxer()
 for g in groups:
     dm.add_query_group(g)
 dm.demux_packed(bases[: 1000 * L], offsets[:1001])  # warm up
-for _ in range(3):
-    t = time.perf_counter()
-    rows = dm.demux_packed(bases, offsets)
-    dt = time.perf_counter() - t
-    print(f"{n} reads, {len(rows)} rows: {dt*1e3:.1f} ms -> {n/dt/1e6:.2f} M reads/s PCIe-inclusive ({n*L/dt/1e9:.1f} GB/s of bases)")
+def run(tag, b):
+    for _ in range(3):
+        t = time.perf_counter()
+        rows = dm.demux_packed(b, offsets)
+        dt = time.perf_counter() - t
+        print(f"{tag}: {n} reads, {len(rows)} rows: {dt*1e3:.1f} ms -> {n/dt/1e6:.2f} M reads/s PCIe-inclusive ({n*L/dt/1e9:.1f} GB/s of bases)")
+
+
+run("pageable", bases)
+# the same reads in page-locked memory from bb_host_malloc
+import ctypes as C
+from barbell_amd._lib import lib
+p = C.c_void_p()
+assert lib().bb_host_malloc(dm._ctx(), len(bases), C.byref(p)) == 0
+pinned = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(len(bases),))
+pinned[:] = bases
+run("page-locked", pinned)
+lib().bb_host_free(dm._ctx(), p)
