@@ -45,6 +45,8 @@ struct bb_trim_state {
     bb_label_span* d_spans = nullptr; uint64_t cap_spans = 0;
     uint32_t* d_nspans = nullptr;
     float last_ms[3] = {0, 0, 0};  // plan+sort, render, total
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    bb_label_span* d_sp_host = nullptr; uint64_t cap_sp_host = 0;  // span staging of the host-pointer variant
     // staging for the host-pointer variant
     void* d_stage[12] = {};
     uint64_t cap_stage[12] = {};
@@ -392,6 +394,8 @@ void bb_trim_state_free(bb_trim_state* s) {
                     s->d_cub, (void*)s->d_spans, (void*)s->d_nspans})
         if (p) (void)hipFree(p);
     for (void* p : s->d_stage) if (p) (void)hipFree(p);
+    if (s->d_sp_host) (void)hipFree(s->d_sp_host);
+    for (auto& e : s->ev) if (e) (void)hipEventDestroy(e);
     delete s;
 }
 
@@ -435,8 +439,8 @@ extern "C" int bb_trim_batch_dev(bb_ctx* ctx, const bb_row* d_rows, const bb_row
     *text_len = 0; *n_slices = 0; *n_spans = 0;
     TCHK(v, hipSetDevice(v.device));
     hipStream_t st = v.stream;
-    hipEvent_t ev[3];
-    for (auto& e : ev) TCHK(v, hipEventCreate(&e));
+    hipEvent_t* ev = s->ev;
+    if (!ev[0]) for (int i = 0; i < 3; ++i) TCHK(v, hipEventCreate(&ev[i]));
     TCHK(v, hipEventRecord(ev[0], st));
     if (n_reads) TCHK(v, hipMemsetAsync(d_status, BB_TRIM_NONE, n_reads, st));
     uint64_t ns = 0, tl = 0;
@@ -507,10 +511,7 @@ extern "C" int bb_trim_batch_dev(bb_ctx* ctx, const bb_row* d_rows, const bb_row
     }
     TCHK(v, hipEventRecord(ev[1], st));
     *text_len = tl; *n_slices = ns; *n_spans = nsp;
-    if (tl > text_cap || ns > slices_cap || nsp > spans_cap || (tl && !d_text) || (ns && !d_slices) || (nsp && !d_spans)) {
-        for (auto& e : ev) (void)hipEventDestroy(e);
-        return BB_E_CAPACITY;
-    }
+    if (tl > text_cap || ns > slices_cap || nsp > spans_cap || (tl && !d_text) || (ns && !d_slices) || (nsp && !d_spans)) return BB_E_CAPACITY;
     if (ns) {
         const uint32_t n = (uint32_t)ns;
         // spans: few (one per output label) -> ordered and completed on the host
@@ -533,7 +534,6 @@ extern "C" int bb_trim_batch_dev(bb_ctx* ctx, const bb_row* d_rows, const bb_row
     (void)hipEventElapsedTime(&s->last_ms[0], ev[0], ev[1]);
     (void)hipEventElapsedTime(&s->last_ms[1], ev[1], ev[2]);
     s->last_ms[2] = s->last_ms[0] + s->last_ms[1];
-    for (auto& e : ev) (void)hipEventDestroy(e);
     return BB_OK;
 }
 
@@ -563,9 +563,8 @@ extern "C" int bb_trim_batch(bb_ctx* ctx, const bb_row* rows, const bb_row_verdi
             TCHK(v, hipMemcpyAsync(p, src[i], bytes[i], hipMemcpyHostToDevice, v.stream));
         }
     }
-    bb_label_span* d_sp = nullptr;
-    uint64_t dummy = 0;
-    if ((r = tgrow(v, d_sp, dummy, (uint64_t)spans_cap + 1))) return r;
+    if ((r = tgrow(v, s->d_sp_host, s->cap_sp_host, (uint64_t)spans_cap + 1))) return r;
+    bb_label_span* d_sp = s->d_sp_host;
     bb_headers dh{(const uint8_t*)s->d_stage[5], (const uint64_t*)s->d_stage[6], (const uint32_t*)s->d_stage[7], (const uint32_t*)s->d_stage[8]};
     r = bb_trim_batch_dev(ctx, (const bb_row*)s->d_stage[0], (const bb_row_verdict*)s->d_stage[1], n_rows, (const uint8_t*)s->d_stage[2],
                           (const uint8_t*)s->d_stage[3], (const uint64_t*)s->d_stage[4], &dh, n_reads, (uint8_t*)s->d_stage[10], text_cap, text_len,
@@ -578,7 +577,6 @@ extern "C" int bb_trim_batch(bb_ctx* ctx, const bb_row* rows, const bb_row_verdi
         if (*n_slices) TCHK(v, hipMemcpy(slices, s->d_stage[11], *n_slices * sizeof(bb_slice), hipMemcpyDeviceToHost));
         if (*n_spans) TCHK(v, hipMemcpy(spans, d_sp, (uint64_t)*n_spans * sizeof(bb_label_span), hipMemcpyDeviceToHost));
     }
-    (void)hipFree(d_sp);
     return r;
 }
 
