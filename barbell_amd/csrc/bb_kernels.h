@@ -842,10 +842,11 @@ __global__ __launch_bounds__(1024) void k_barcode(const uint8_t* __restrict__ ba
 }
 
 // ------------------------------------------------------------------------------------------------
-// Columns are processed in wave-uniform groups of BB_CG (a group beyond the wave's widest window is skipped):
-// 2 instead of 8 wastes at most one column of a 44..46-column window instead of up to seven.
+// Columns are processed in wave-uniform groups of BB_CG (a group beyond the wave's widest window is skipped).
+// Measured on the headline workload (windows of 41..46 columns, mostly 44): groups of 8 -> 35.3 ms for the
+// barcode stage, 2 -> 34.3, then at a later state 1 -> 28.0, 2 -> 27.05, 4 -> 26.6.
 #ifndef BB_CG
-#define BB_CG 2
+#define BB_CG 4
 #endif
 // k_barcode_reg: register-resident, branch-free variant of k_barcode for m_bar <= 48 and windows of
 // at most CW columns (CW = 48 or 64; all ONT kit presets).  Same arithmetic as k_barcode, but
