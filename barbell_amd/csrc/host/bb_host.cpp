@@ -14,6 +14,7 @@
 
 #include <sys/stat.h>
 #include <cerrno>
+#include <chrono>
 
 #include "kits_data.inc"
 
@@ -296,6 +297,7 @@ Demuxer::Demuxer(float alpha, bool verbose, double min_score_frac, double min_sc
     : alpha_(alpha), verbose_(verbose), min_score_(min_score_frac), min_score_diff_(min_score_diff_frac), device_(device) {}
 Demuxer::~Demuxer() {
     for (DevBuf* b : {&d_rows_, &d_ver_, &d_elems_, &d_text_, &d_slices_, &d_spans_, &d_status_}) b->release();
+    if (h_text_) bb_host_free(ctx_, h_text_);
     if (ctx_) bb_destroy(ctx_);
 }
 
@@ -494,6 +496,7 @@ TrimBatch Demuxer::trim_last_batch(const std::vector<bb_row_verdict>& verdicts, 
         }
         if (rc != BB_OK) throw BarbellError(rc, std::string("bb_trim_batch: ") + bb_strerror(rc) + " " + bb_last_error(ctx_));
         t.text.resize(tl); t.slices.resize(ns); t.spans.resize(nsp);
+        t.text_len = tl;
         return t;
     }
 }
@@ -630,9 +633,17 @@ TrimBatch Demuxer::trim_ingested() {
             continue;
         }
         if (rc != BB_OK) BB_THROW(rc, "bb_trim_batch_dev");
-        t.text.resize(tl); t.slices.resize(ns); t.spans.resize(nsp);
+        t.slices.resize(ns); t.spans.resize(nsp);
         int r2;
-        if ((r2 = bb_dev_download(ctx_, t.text.data(), d_text_.p, tl)) != BB_OK) BB_THROW(r2, "bb_dev_download");
+        if (tl > h_text_cap_) {  // page-locked and not zero-filled: a 3 GB std::vector costs more than the copy itself
+            if (h_text_) bb_host_free(ctx_, h_text_);
+            h_text_ = nullptr; h_text_cap_ = 0;
+            void* hp = nullptr;
+            if ((r2 = bb_host_malloc(ctx_, tl + tl / 4 + 4096, &hp)) != BB_OK) BB_THROW(r2, "bb_host_malloc");
+            h_text_ = (uint8_t*)hp; h_text_cap_ = tl + tl / 4 + 4096;
+        }
+        t.text_ptr = h_text_; t.text_len = tl;
+        if ((r2 = bb_dev_download(ctx_, h_text_, d_text_.p, tl)) != BB_OK) BB_THROW(r2, "bb_dev_download");
         if ((r2 = bb_dev_download(ctx_, t.slices.data(), d_slices_.p, ns * sizeof(bb_slice))) != BB_OK) BB_THROW(r2, "bb_dev_download");
         if ((r2 = bb_dev_download(ctx_, t.spans.data(), d_spans_.p, (uint64_t)nsp * sizeof(bb_label_span))) != BB_OK) BB_THROW(r2, "bb_dev_download");
         if ((r2 = bb_dev_download(ctx_, t.status.data(), d_status_.p, n)) != BB_OK) BB_THROW(r2, "bb_dev_download");
@@ -776,10 +787,16 @@ AnnotateStats annotate(const std::vector<std::string>& read_files, const std::st
     };
     // one block of text: parsed, annotated, filtered, inspected and trimmed in HBM; only rows, verdicts,
     // pattern elements and the rendered records come back
+    // BARBELL_AMD_PROFILE=1: wall-clock split of the host loop on stderr (read / ingest / annotate / write / filter+trim)
+    const bool prof = getenv("BARBELL_AMD_PROFILE") != nullptr;
+    double t_read = 0, t_ingest = 0, t_demux = 0, t_write = 0, t_rest = 0;
+    auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     auto process = [&](const Demuxer::Ingested& ing) {
         const auto& ids = ing.ids;
         if (ids.empty()) return;
+        double t0 = now();
         auto rows = dm.demux_ingested();
+        t_demux += now() - t0; t0 = now();
         st.total += ids.size();
         std::vector<bb_row_verdict> verdicts;
         if (filtering) verdicts = dm.filter_ingested();
@@ -791,6 +808,7 @@ AnnotateStats annotate(const std::vector<std::string>& read_files, const std::st
             if (!last || *last != r.read_id) ++st.found;
             last = &r.read_id;
         }
+        t_write += now() - t0; t0 = now();
         if (config.inspect) {  // inspect.rs:128-184 on the annotation rows (no cuts yet)
             for (auto& rp : dm.inspect_ingested(false, config.bucket_size)) {
                 if (ppr_f) fprintf(ppr_f, "%s\t%s\n", ids[rp.first].c_str(), rp.second.c_str());
@@ -818,7 +836,7 @@ AnnotateStats annotate(const std::vector<std::string>& read_files, const std::st
         }
         if (trimming) {  // trim.rs:385-460: the GPU cut and rendered the records, one write per label
             const TrimBatch t = dm.trim_ingested();
-            for (const auto& sp : t.spans) writers->write(dm.label_of_key(sp.label_key), t.text.data() + sp.off, sp.len);
+            for (const auto& sp : t.spans) writers->write(dm.label_of_key(sp.label_key), t.data() + sp.off, sp.len);
             std::vector<uint32_t> per_read(ids.size(), 0);
             for (const auto& sl : t.slices) ++per_read[sl.read_idx];
             for (size_t i = 0; i < ids.size(); ++i) {
@@ -828,14 +846,18 @@ AnnotateStats annotate(const std::vector<std::string>& read_files, const std::st
             }
         }
         st.rows += rows.size();
+        t_rest += now() - t0;
     };
     const size_t block = config.batch_reads ? std::max<size_t>(config.batch_reads * 4096, 4096) : std::max<size_t>(config.block_bytes, 4096);
     try {
         for (const auto& path : read_files) {
             BlockSource src(dm.ctx(), path);
             for (;;) {
+                double t0 = now();
                 const bool eof = src.fill(block);
+                t_read += now() - t0; t0 = now();
                 const auto ing = dm.ingest(src.buf, src.have, eof);
+                t_ingest += now() - t0;
                 process(ing);
                 src.consume((size_t)ing.info.consumed);
                 if (eof) break;
@@ -846,6 +868,7 @@ AnnotateStats annotate(const std::vector<std::string>& read_files, const std::st
         throw;
     }
     close_all();
+    if (prof) fprintf(stderr, "profile: read %.3f s, ingest %.3f s, annotate %.3f s, tsv %.3f s, inspect/filter/trim %.3f s\n", t_read, t_ingest, t_demux, t_write, t_rest);
     for (const auto& p : pattern_order) st.patterns.emplace_back(p, pattern_count[p]);
     std::stable_sort(st.patterns.begin(), st.patterns.end(), [](const auto& a, const auto& c) { return a.second > c.second; });
     return st;

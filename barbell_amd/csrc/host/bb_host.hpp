@@ -84,7 +84,10 @@ struct TrimConfig {  // config.rs:19-32, CLI defaults bin/main.rs:136-186
     static TrimConfig for_kit(std::optional<std::string> failed_out, bool gzip);  // use_kit.rs:87-99
 };
 struct TrimBatch {  // what bb_trim_batch returns for one batch
-    std::vector<uint8_t> text;
+    std::vector<uint8_t> text;        // trim_last_batch: the rendered records
+    const uint8_t* text_ptr = nullptr; // trim_ingested: the records in the demuxer's page-locked buffer (valid until the next call)
+    uint64_t text_len = 0;
+    const uint8_t* data() const { return text_ptr ? text_ptr : text.data(); }
     std::vector<bb_slice> slices;
     std::vector<bb_label_span> spans;
     std::vector<uint8_t> status;  // BB_TRIM_* per read
@@ -172,6 +175,8 @@ private:
     bb_fastq_batch_dev batch_{};
     Ingested ing_;
     DevBuf d_rows_, d_ver_, d_elems_, d_text_, d_slices_, d_spans_, d_status_;
+    uint8_t* h_text_ = nullptr;  // page-locked landing buffer of the rendered records (bb_host_malloc)
+    uint64_t h_text_cap_ = 0;
 };
 
 struct AnnotateConfig {  // config.rs:3-12 with the CLI defaults of bin/main.rs:64-112

@@ -36,7 +36,7 @@ with open(fq, "wb") as f:
         f.write(np.concatenate([hdr, b, sep, q, nl], axis=1).tobytes())
 gen_s = time.time() - t0
 size = os.path.getsize(fq)
-env = dict(os.environ, BARBELL_AMD_NO_TORCH="1")
+env = dict(os.environ, BARBELL_AMD_NO_TORCH="1", BARBELL_AMD_PROFILE="1")
 out = {"n_reads": n, "read_len": L, "fastq_bytes": size, "gen_s": gen_s}
 for name, cmd in (("annotate", [cli, "annotate", "-i", fq, "-o", os.path.join(tmp, "e2e_a.tsv"), "--kit", "SQK-NBD114-96", "--flank-max-errors", "3"]),
                   ("kit", [cli, "kit", "-k", "SQK-NBD114-96", "-i", fq, "-o", os.path.join(tmp, "e2e_kit"), "--flank-max-errors", "3", "--maximize"])):
@@ -44,5 +44,5 @@ for name, cmd in (("annotate", [cli, "annotate", "-i", fq, "-o", os.path.join(tm
     r = subprocess.run(cmd, capture_output=True, text=True, env=env)
     dt = time.time() - t0
     assert r.returncode == 0, r.stderr
-    out[name] = {"wall_s": dt, "reads_per_s": n / dt, "fastq_gb_per_s": size / dt / 1e9}
+    out[name] = {"wall_s": dt, "reads_per_s": n / dt, "fastq_gb_per_s": size / dt / 1e9, "profile": [l for l in r.stderr.splitlines() if l.startswith("profile:")]}
 print(json.dumps(out))
