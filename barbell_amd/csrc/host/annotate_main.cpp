@@ -19,7 +19,7 @@ static void usage() {
         "Usage: barbell-amd annotate -i <FASTQ>... [-o output.tsv] (--kit <KIT> | -q <FASTA>... [-b Ftag|Rtag ...])\n"
         "                            [--flank-max-errors INT] [--min-score F=0.2] [--min-score-diff F=0.1]\n"
         "                            [--alpha F=0.4] [--use-extended] [-t THREADS=10] [--verbose]\n"
-        "                            [--block-bytes N=512Mi | --batch-reads N (= N*4096 bytes)] [--device D=0]\n"
+        "                            [--block-bytes N=128Mi | --batch-reads N (= N*4096 bytes)] [--device D=0]\n"
         "                            [(-f <PATTERN_FILE>... | --kit-filter [--maximize]) [--filtered FILE] [--dropped FILE]]\n"
         "                            [--trim-output DIR [--no-label] [--no-orientation] [--no-flanks] [--sort-labels]\n"
         "                             [--only-side left|right] [--failed-out FILE] [--skip-trim] [--flip] [--gzip]]\n"

@@ -10,7 +10,11 @@
 #include <cstring>
 #include <fstream>
 #include <map>
+#include <condition_variable>
+#include <deque>
 #include <memory>
+#include <mutex>
+#include <thread>
 
 #include <sys/stat.h>
 #include <cerrno>
@@ -297,7 +301,7 @@ Demuxer::Demuxer(float alpha, bool verbose, double min_score_frac, double min_sc
     : alpha_(alpha), verbose_(verbose), min_score_(min_score_frac), min_score_diff_(min_score_diff_frac), device_(device) {}
 Demuxer::~Demuxer() {
     for (DevBuf* b : {&d_rows_, &d_ver_, &d_elems_, &d_text_, &d_slices_, &d_spans_, &d_status_}) b->release();
-    if (h_text_) bb_host_free(ctx_, h_text_);
+    for (uint8_t* h : h_text_) if (h) bb_host_free(ctx_, h);
     if (ctx_) bb_destroy(ctx_);
 }
 
@@ -635,15 +639,17 @@ TrimBatch Demuxer::trim_ingested() {
         if (rc != BB_OK) BB_THROW(rc, "bb_trim_batch_dev");
         t.slices.resize(ns); t.spans.resize(nsp);
         int r2;
-        if (tl > h_text_cap_) {  // page-locked and not zero-filled: a 3 GB std::vector costs more than the copy itself
-            if (h_text_) bb_host_free(ctx_, h_text_);
-            h_text_ = nullptr; h_text_cap_ = 0;
+        const int hb = h_text_next_;
+        h_text_next_ ^= 1;
+        if (tl > h_text_cap_[hb]) {  // page-locked and not zero-filled: a 3 GB std::vector costs more than the copy itself
+            if (h_text_[hb]) bb_host_free(ctx_, h_text_[hb]);
+            h_text_[hb] = nullptr; h_text_cap_[hb] = 0;
             void* hp = nullptr;
             if ((r2 = bb_host_malloc(ctx_, tl + tl / 4 + 4096, &hp)) != BB_OK) BB_THROW(r2, "bb_host_malloc");
-            h_text_ = (uint8_t*)hp; h_text_cap_ = tl + tl / 4 + 4096;
+            h_text_[hb] = (uint8_t*)hp; h_text_cap_[hb] = tl + tl / 4 + 4096;
         }
-        t.text_ptr = h_text_; t.text_len = tl;
-        if ((r2 = bb_dev_download(ctx_, h_text_, d_text_.p, tl)) != BB_OK) BB_THROW(r2, "bb_dev_download");
+        t.text_ptr = h_text_[hb]; t.text_len = tl;
+        if ((r2 = bb_dev_download(ctx_, h_text_[hb], d_text_.p, tl)) != BB_OK) BB_THROW(r2, "bb_dev_download");
         if ((r2 = bb_dev_download(ctx_, t.slices.data(), d_slices_.p, ns * sizeof(bb_slice))) != BB_OK) BB_THROW(r2, "bb_dev_download");
         if ((r2 = bb_dev_download(ctx_, t.spans.data(), d_spans_.p, (uint64_t)nsp * sizeof(bb_label_span))) != BB_OK) BB_THROW(r2, "bb_dev_download");
         if ((r2 = bb_dev_download(ctx_, t.status.data(), d_status_.p, n)) != BB_OK) BB_THROW(r2, "bb_dev_download");
@@ -656,46 +662,81 @@ namespace {
 // the automatic flank cutoff (edit_model.rs:2-11) is applied inside bb_create when k_cutoff is unset
 // Raw FASTQ text in blocks: plain or gzip (gzread reads both).  The record parser is on the GPU
 // (bb_fastq_ingest); the partial record at the end of a block is carried over to the next one.
+// Two page-locked buffers: while the GPU works on one block a reader thread fills the other, leaving HEAD bytes
+// of headroom in front of the chunk so the (short) carry can be copied there without moving the chunk.
 struct BlockSource {
+    size_t HEAD = 16u << 20;  // BARBELL_AMD_HEAD_BYTES overrides it (tests of the over-long-carry path)
     gzFile f = nullptr;
-    bb_ctx* ctx;          // the block buffer is page-locked (bb_host_malloc): the upload runs at PCIe rate
-    uint8_t* buf = nullptr;
-    size_t cap = 0;
-    size_t have = 0;      // bytes of carry at the front of buf
-    BlockSource(bb_ctx* c, const std::string& path) : f(gzopen(path.c_str(), "rb")), ctx(c) {
+    bb_ctx* ctx;
+    struct Buf { uint8_t* p = nullptr; size_t cap = 0, got = 0; bool eof = false; } bufs[2];
+    int cur = 0;
+    size_t chunk;
+    std::thread reader;
+    bool pending = false;
+    std::string err;
+    // current block = [data, data + have)
+    uint8_t* data = nullptr;
+    size_t have = 0;
+
+    BlockSource(bb_ctx* c, const std::string& path, size_t chunk_bytes) : f(gzopen(path.c_str(), "rb")), ctx(c), chunk(chunk_bytes) {
         if (!f) throw BarbellError(BB_E_INVALID, "Failed to open FASTQ input: " + path);
         gzbuffer(f, 1 << 20);
+        if (const char* e = getenv("BARBELL_AMD_HEAD_BYTES")) HEAD = (size_t)std::max(16L, atol(e));
+        start_read(0);
     }
     ~BlockSource() {
+        if (reader.joinable()) reader.join();
         if (f) gzclose(f);
-        if (buf) bb_host_free(ctx, buf);
+        for (auto& b : bufs) if (b.p) bb_host_free(ctx, b.p);
     }
-    void reserve(size_t need) {
-        if (need <= cap) return;
-        const size_t ncap = need + need / 2;
-        void* p = nullptr;
-        if (bb_host_malloc(ctx, ncap, &p) != BB_OK) throw BarbellError(BB_E_NOMEM, "bb_host_malloc failed");
-        if (have) memcpy(p, buf, have);
-        if (buf) bb_host_free(ctx, buf);
-        buf = (uint8_t*)p; cap = ncap;
+    void reserve(Buf& b, size_t need) {
+        if (need <= b.cap) return;
+        void* q = nullptr;
+        if (bb_host_malloc(ctx, need, &q) != BB_OK) throw BarbellError(BB_E_NOMEM, "bb_host_malloc failed");
+        if (b.p) bb_host_free(ctx, b.p);
+        b.p = (uint8_t*)q; b.cap = need;
     }
-    // appends up to `want` bytes after the carry; returns true when the file is exhausted
-    bool fill(size_t want) {
-        reserve(have + want);
-        size_t got = 0;
-        while (got < want) {
-            const int r = gzread(f, buf + have + got, (unsigned)std::min<size_t>(want - got, 1u << 30));
-            if (r < 0) throw BarbellError(BB_E_INVALID, "Error reading FASTQ file");
-            if (r == 0) break;
-            got += (size_t)r;
+    void start_read(int i) {  // fills bufs[i] with the next chunk at offset HEAD, in the background
+        Buf& b = bufs[i];
+        reserve(b, HEAD + chunk);
+        pending = true;
+        reader = std::thread([this, &b]() {
+            size_t got = 0;
+            while (got < chunk) {
+                const int r = gzread(f, b.p + HEAD + got, (unsigned)std::min<size_t>(chunk - got, 1u << 30));
+                if (r < 0) { err = "Error reading FASTQ file"; break; }
+                if (r == 0) break;
+                got += (size_t)r;
+            }
+            b.got = got;
+            b.eof = got < chunk;
+        });
+    }
+    // makes the next block current: carry (the unconsumed tail of the previous block) + the chunk that was being
+    // read; returns true when it is the last block of the file
+    bool next(size_t consumed) {
+        reader.join();
+        pending = false;
+        if (!err.empty()) throw BarbellError(BB_E_INVALID, err);
+        Buf& b = bufs[cur];
+        const size_t carry = data ? have - consumed : 0;
+        const uint8_t* carry_src = data ? data + consumed : nullptr;
+        if (carry > HEAD) {  // a single record longer than the headroom (rare): assemble carry + chunk aside
+            std::vector<uint8_t> tmp(carry + b.got);
+            memcpy(tmp.data(), carry_src, carry);  // carry_src may point into `big`: copy before the swap
+            memcpy(tmp.data() + carry, b.p + HEAD, b.got);
+            big.swap(tmp);
+            data = big.data(); have = big.size();
+        } else {
+            if (carry) memcpy(b.p + HEAD - carry, carry_src, carry);
+            data = b.p + HEAD - carry; have = carry + b.got;
         }
-        have += got;
-        return got < want;
+        const bool eof = b.eof;
+        cur ^= 1;
+        if (!eof) start_read(cur);
+        return eof;
     }
-    void consume(size_t n) {
-        memmove(buf, buf + n, have - n);
-        have -= n;
-    }
+    std::vector<uint8_t> big;  // block with an over-long carry
 };
 
 struct LabelWriters {  // the per-label writers of trim_matches (trim.rs:356-446)
@@ -703,7 +744,53 @@ struct LabelWriters {  // the per-label writers of trim_matches (trim.rs:356-446
     bool gz;
     std::map<std::string, gzFile> gzs;
     std::map<std::string, FILE*> plain;
-    LabelWriters(std::string f, bool g) : folder(std::move(f)), gz(g) {}
+    // writes run on their own thread, one batch's spans per job; at most two jobs exist (the demuxer has two
+    // landing buffers), submit() blocks while both are busy
+    struct Span { std::string label; const uint8_t* p; size_t n; };
+    std::deque<std::vector<Span>> jobs;
+    std::mutex mu;
+    std::condition_variable cv;
+    bool stop = false, busy = false;
+    std::string err;
+    std::thread th;
+    LabelWriters(std::string f, bool g) : folder(std::move(f)), gz(g), th([this]() { run(); }) {}
+    void run() {
+        for (;;) {
+            std::vector<Span> job;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [this]() { return stop || !jobs.empty(); });
+                if (jobs.empty()) return;
+                job = std::move(jobs.front());
+                jobs.pop_front();
+                busy = true;
+            }
+            try {
+                for (const auto& sp : job) write(sp.label, sp.p, sp.n);
+            } catch (const std::exception& e) {
+                std::lock_guard<std::mutex> lk(mu);
+                if (err.empty()) err = e.what();
+            }
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                busy = false;
+            }
+            cv.notify_all();
+        }
+    }
+    // waits until at most `max_outstanding` jobs are queued or running, then rethrows a writer error if any
+    void wait(size_t max_outstanding) {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&]() { return jobs.size() + (busy ? 1 : 0) <= max_outstanding; });
+        if (!err.empty()) throw BarbellError(BB_E_INVALID, err);
+    }
+    void submit(std::vector<Span> job) {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            jobs.push_back(std::move(job));
+        }
+        cv.notify_all();
+    }
     void write(const std::string& label, const uint8_t* p, size_t n) {
         const std::string path = folder + "/" + label + (gz ? ".trimmed.fastq.gz" : ".trimmed.fastq");
         if (gz) {
@@ -729,6 +816,12 @@ struct LabelWriters {  // the per-label writers of trim_matches (trim.rs:356-446
         }
     }
     ~LabelWriters() {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            stop = true;
+        }
+        cv.notify_all();
+        if (th.joinable()) th.join();  // drains the queue first
         for (auto& kv : gzs) gzclose(kv.second);
         for (auto& kv : plain) fclose(kv.second);
     }
@@ -789,7 +882,7 @@ AnnotateStats annotate(const std::vector<std::string>& read_files, const std::st
     // pattern elements and the rendered records come back
     // BARBELL_AMD_PROFILE=1: wall-clock split of the host loop on stderr (read / ingest / annotate / write / filter+trim)
     const bool prof = getenv("BARBELL_AMD_PROFILE") != nullptr;
-    double t_read = 0, t_ingest = 0, t_demux = 0, t_write = 0, t_rest = 0;
+    double t_read = 0, t_ingest = 0, t_demux = 0, t_write = 0, t_rest = 0, t_insp = 0, t_ftsv = 0, t_trim = 0, t_fq = 0;
     auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     auto process = [&](const Demuxer::Ingested& ing) {
         const auto& ids = ing.ids;
@@ -809,6 +902,7 @@ AnnotateStats annotate(const std::vector<std::string>& read_files, const std::st
             last = &r.read_id;
         }
         t_write += now() - t0; t0 = now();
+        double t1 = now();
         if (config.inspect) {  // inspect.rs:128-184 on the annotation rows (no cuts yet)
             for (auto& rp : dm.inspect_ingested(false, config.bucket_size)) {
                 if (ppr_f) fprintf(ppr_f, "%s\t%s\n", ids[rp.first].c_str(), rp.second.c_str());
@@ -817,6 +911,7 @@ AnnotateStats annotate(const std::vector<std::string>& read_files, const std::st
                 else ++it->second;
             }
         }
+        t_insp += now() - t1; t1 = now();
         for (size_t i = 0; i < verdicts.size(); ++i) {  // filtered.tsv / dropped.tsv (filter.rs:87-119)
             const bb_row_verdict& v = verdicts[i];
             const bool first = i == 0 || rows[i].read_id != rows[i - 1].read_id;
@@ -834,9 +929,15 @@ AnnotateStats annotate(const std::vector<std::string>& read_files, const std::st
             fputs(rows[i].to_tsv().c_str(), f);
             fputc('\n', f);
         }
+        t_ftsv += now() - t1; t1 = now();
         if (trimming) {  // trim.rs:385-460: the GPU cut and rendered the records, one write per label
+            writers->wait(1);  // the landing buffer about to be reused belongs to the job before the last one
             const TrimBatch t = dm.trim_ingested();
-            for (const auto& sp : t.spans) writers->write(dm.label_of_key(sp.label_key), t.data() + sp.off, sp.len);
+            t_trim += now() - t1; t1 = now();
+            std::vector<LabelWriters::Span> job;
+            for (const auto& sp : t.spans) job.push_back({dm.label_of_key(sp.label_key), t.data() + sp.off, (size_t)sp.len});
+            writers->submit(std::move(job));
+            t_fq += now() - t1;
             std::vector<uint32_t> per_read(ids.size(), 0);
             for (const auto& sl : t.slices) ++per_read[sl.read_idx];
             for (size_t i = 0; i < ids.size(); ++i) {
@@ -851,24 +952,27 @@ AnnotateStats annotate(const std::vector<std::string>& read_files, const std::st
     const size_t block = config.batch_reads ? std::max<size_t>(config.batch_reads * 4096, 4096) : std::max<size_t>(config.block_bytes, 4096);
     try {
         for (const auto& path : read_files) {
-            BlockSource src(dm.ctx(), path);
+            BlockSource src(dm.ctx(), path, block);
+            size_t consumed = 0;
             for (;;) {
                 double t0 = now();
-                const bool eof = src.fill(block);
+                const bool eof = src.next(consumed);  // waits for the chunk the reader thread has been filling
                 t_read += now() - t0; t0 = now();
-                const auto ing = dm.ingest(src.buf, src.have, eof);
+                const auto ing = dm.ingest(src.data, src.have, eof);
                 t_ingest += now() - t0;
                 process(ing);
-                src.consume((size_t)ing.info.consumed);
+                consumed = (size_t)ing.info.consumed;
                 if (eof) break;
             }
         }
+        if (writers) writers->wait(0);  // all records on disk (or the writer's error rethrown) before the files are closed
     } catch (...) {
         close_all();
         throw;
     }
     close_all();
-    if (prof) fprintf(stderr, "profile: read %.3f s, ingest %.3f s, annotate %.3f s, tsv %.3f s, inspect/filter/trim %.3f s\n", t_read, t_ingest, t_demux, t_write, t_rest);
+    if (prof) fprintf(stderr, "profile: read %.3f s, ingest %.3f s, annotate %.3f s, tsv %.3f s, inspect/filter/trim %.3f s (inspect %.3f, filtered tsv %.3f, trim gpu+download %.3f, fastq write %.3f)\n",
+                      t_read, t_ingest, t_demux, t_write, t_rest, t_insp, t_ftsv, t_trim, t_fq);
     for (const auto& p : pattern_order) st.patterns.emplace_back(p, pattern_count[p]);
     std::stable_sort(st.patterns.begin(), st.patterns.end(), [](const auto& a, const auto& c) { return a.second > c.second; });
     return st;

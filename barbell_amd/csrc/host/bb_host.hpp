@@ -175,8 +175,11 @@ private:
     bb_fastq_batch_dev batch_{};
     Ingested ing_;
     DevBuf d_rows_, d_ver_, d_elems_, d_text_, d_slices_, d_spans_, d_status_;
-    uint8_t* h_text_ = nullptr;  // page-locked landing buffer of the rendered records (bb_host_malloc)
-    uint64_t h_text_cap_ = 0;
+    // page-locked landing buffers of the rendered records (bb_host_malloc), used alternately so a writer thread
+    // can still be flushing one batch's records while the next batch is downloaded
+    uint8_t* h_text_[2] = {nullptr, nullptr};
+    uint64_t h_text_cap_[2] = {0, 0};
+    int h_text_next_ = 0;
 };
 
 struct AnnotateConfig {  // config.rs:3-12 with the CLI defaults of bin/main.rs:64-112
@@ -187,7 +190,7 @@ struct AnnotateConfig {  // config.rs:3-12 with the CLI defaults of bin/main.rs:
     double min_score = 0.2, min_score_diff = 0.1;
     bool use_extended = false;
     size_t batch_reads = 0;               // if set: block_bytes = batch_reads * 4096 (kept for CLI compatibility)
-    size_t block_bytes = 512u << 20;      // raw FASTQ text handed to the GPU per ingest call
+    size_t block_bytes = 128u << 20;      // raw FASTQ text handed to the GPU per ingest call (two page-locked buffers of this size)
     int device = 0;
     // fused filter step: when filter_patterns is non-empty, rows of passing / failing reads go to
     // filtered_file / dropped_file with their cuts column (what `barbell filter -o/--dropped` writes)

@@ -104,6 +104,12 @@ def test_cli_tsv_matches_python_and_oracle(tmp_path, gz):
     A.annotate_with_kit([str(fq)], str(out_py), "SQK-NBD114-96", max_flank_errors=3, batch_reads=400)
     cli = out_cli.read_bytes()
     assert cli == out_py.read_bytes()
+    # block reader edge: headroom smaller than the carried-over partial record (slow path), tiny blocks
+    out2 = tmp_path / "cli2.tsv"
+    r = subprocess.run([CLI, "annotate", "-i", str(fq), "-o", str(out2), "--kit", "SQK-NBD114-96", "--flank-max-errors", "3",
+                        "--block-bytes", "5000"], capture_output=True, text=True, env=dict(env, BARBELL_AMD_HEAD_BYTES="64"))
+    assert r.returncode == 0, r.stderr
+    assert out2.read_bytes() == cli
     rows = po.Oracle([g.as_tuple() for g in groups]).annotate(bases, offsets, n_threads=os.cpu_count() or 1)
     want = (A.TSV_HEADER + "\n" + "\n".join(A.format_rows(rows, ids, groups)) + "\n").encode()
     assert cli == want
