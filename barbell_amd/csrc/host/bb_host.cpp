@@ -739,6 +739,87 @@ struct BlockSource {
     std::vector<uint8_t> big;  // block with an over-long carry
 };
 
+// Several gzip files: zlib inflates one stream on one core (~0.3 GB/s), far below what the GPU takes, so the
+// files are inflated whole by a pool of threads, a few files ahead of the consumer, and handed over in input
+// order (the TSV keeps the reads' order).  n_threads comes from -t/--threads like the reference's worker count.
+struct ParallelInflater {
+    std::vector<std::string> paths;
+    std::vector<std::vector<uint8_t>> data;
+    std::vector<int> state;  // 0 = not started, 1 = in progress, 2 = ready, 3 = consumed
+    std::vector<std::thread> pool;
+    std::mutex mu;
+    std::condition_variable cv;
+    size_t next_file = 0, consumed_upto = 0, ahead;
+    std::string err;
+    ParallelInflater(std::vector<std::string> p, unsigned n_threads) : paths(std::move(p)), data(paths.size()), state(paths.size(), 0) {
+        const unsigned nt = std::max(1u, std::min<unsigned>(n_threads, (unsigned)paths.size()));
+        ahead = nt + 2;  // files inflated but not yet consumed: bounds the memory
+        for (unsigned i = 0; i < nt; ++i) pool.emplace_back([this]() { work(); });
+    }
+    void work() {
+        for (;;) {
+            size_t i;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [this]() { return next_file >= paths.size() || next_file < consumed_upto + ahead || !err.empty(); });
+                if (next_file >= paths.size() || !err.empty()) return;
+                i = next_file++;
+                state[i] = 1;
+            }
+            std::vector<uint8_t> buf;
+            std::string e;
+            gzFile f = gzopen(paths[i].c_str(), "rb");
+            if (!f) e = "Failed to open FASTQ input: " + paths[i];
+            else {
+                gzbuffer(f, 1 << 20);
+                size_t cap = 64u << 20, n = 0;
+                buf.resize(cap);
+                for (;;) {
+                    if (n == cap) { cap *= 2; buf.resize(cap); }
+                    const int r = gzread(f, buf.data() + n, (unsigned)std::min<size_t>(cap - n, 1u << 30));
+                    if (r < 0) { e = "Error reading FASTQ file '" + paths[i] + "'"; break; }
+                    if (r == 0) break;
+                    n += (size_t)r;
+                }
+                gzclose(f);
+                buf.resize(n);
+            }
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                if (!e.empty() && err.empty()) err = e;
+                data[i] = std::move(buf);
+                state[i] = 2;
+            }
+            cv.notify_all();
+        }
+    }
+    // blocks until file i is inflated; the caller owns the bytes until release(i)
+    const std::vector<uint8_t>& get(size_t i) {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&]() { return state[i] == 2 || !err.empty(); });
+        if (!err.empty()) throw BarbellError(BB_E_INVALID, err);
+        return data[i];
+    }
+    void release(size_t i) {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            std::vector<uint8_t>().swap(data[i]);
+            state[i] = 3;
+            consumed_upto = i + 1;
+        }
+        cv.notify_all();
+    }
+    ~ParallelInflater() {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            next_file = paths.size();
+            if (err.empty()) err = "cancelled";
+        }
+        cv.notify_all();
+        for (auto& t : pool) if (t.joinable()) t.join();
+    }
+};
+
 struct LabelWriters {  // the per-label writers of trim_matches (trim.rs:356-446)
     std::string folder;
     bool gz;
@@ -950,7 +1031,30 @@ AnnotateStats annotate(const std::vector<std::string>& read_files, const std::st
         t_rest += now() - t0;
     };
     const size_t block = config.batch_reads ? std::max<size_t>(config.batch_reads * 4096, 4096) : std::max<size_t>(config.block_bytes, 4096);
+    bool all_gz = read_files.size() >= 2;
+    for (const auto& path : read_files) all_gz = all_gz && path.size() > 3 && path.compare(path.size() - 3, 3, ".gz") == 0;
     try {
+        if (all_gz) {  // several gzip files: inflate them in parallel, consume them in order
+            ParallelInflater inf(read_files, config.n_threads);
+            for (size_t fi = 0; fi < read_files.size(); ++fi) {
+                double t0 = now();
+                const std::vector<uint8_t>& text = inf.get(fi);
+                t_read += now() - t0;
+                size_t pos = 0;
+                do {  // blocks of the file; the partial record at a block's end starts the next block
+                    const size_t len = std::min(block, text.size() - pos);
+                    const bool eof = pos + len == text.size();
+                    t0 = now();
+                    const auto ing = dm.ingest(text.data() + pos, len, eof);
+                    t_ingest += now() - t0;
+                    process(ing);
+                    if (!eof && ing.info.consumed == 0 && len == block)
+                        throw BarbellError(BB_E_FASTQ, "a FASTQ record of '" + read_files[fi] + "' is longer than the block size; raise --block-bytes");
+                    pos += eof ? len : (size_t)ing.info.consumed;
+                } while (pos < text.size());
+                inf.release(fi);
+            }
+        } else
         for (const auto& path : read_files) {
             BlockSource src(dm.ctx(), path, block);
             size_t consumed = 0;

@@ -247,3 +247,37 @@ def test_cli_annotate_trim_flags(tmp_path):
     r = subprocess.run([CLI, "annotate", "-i", str(fq), "--kit", kit, "--kit-filter", "--trim-output", str(tmp_path / "x"), "--sort-labels",
                         "--only-side", "left"], capture_output=True, text=True, env=env)
     assert r.returncode == 2
+
+
+@pytest.mark.gpu
+def test_cli_many_gzip_files_parallel_inflate(tmp_path):
+    """several .fastq.gz inputs are inflated by a thread pool and consumed in input order: same annotation.tsv and
+    trimmed files as one plain file holding the same records (incl. an empty file in the middle)"""
+    from barbell_amd import annotate as A
+
+    kit = "SQK-NBD114-96"
+    groups = kits.groups_from_kit(kit, flank_max_errors=3)
+    n = 1300
+    bases, offsets = A.synth_reads_host(groups, 555, 300, 2200, 0, n)
+    ids = [f"r{i}" for i in range(n)]
+    whole = tmp_path / "all.fastq"
+    write_fastq(whole, ids, bases, offsets)
+    cuts = [0, 200, 200, 650, 651, 1000, n]
+    parts = []
+    for k in range(len(cuts) - 1):
+        a, b = cuts[k], cuts[k + 1]
+        path = tmp_path / f"part{k}.fastq.gz"
+        sub_off = offsets[a:b + 1] - offsets[a]
+        write_fastq(path, ids[a:b], bases[int(offsets[a]):int(offsets[b])], sub_off, gz=True)
+        parts.append(str(path))
+    env = dict(os.environ, BARBELL_AMD_NO_TORCH="1")
+    outs = {}
+    for name, inputs in (("one", [str(whole)]), ("many", parts)):
+        o = tmp_path / name
+        r = subprocess.run([CLI, "kit", "-k", kit, "-i"] + inputs + ["-o", str(o), "--flank-max-errors", "3", "--maximize", "-t", "4",
+                            "--batch-reads", "100"], capture_output=True, text=True, env=env)
+        assert r.returncode == 0, r.stderr
+        outs[name] = {x.name: x.read_bytes() for x in o.iterdir()}
+    assert outs["one"].keys() == outs["many"].keys() and len(outs["one"]) > 20
+    for k in outs["one"]:
+        assert outs["one"][k] == outs["many"][k], k

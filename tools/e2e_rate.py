@@ -46,3 +46,24 @@ for name, cmd in (("annotate", [cli, "annotate", "-i", fq, "-o", os.path.join(tm
     assert r.returncode == 0, r.stderr
     out[name] = {"wall_s": dt, "reads_per_s": n / dt, "fastq_gb_per_s": size / dt / 1e9, "profile": [l for l in r.stderr.splitlines() if l.startswith("profile:")]}
 print(json.dumps(out))
+
+# several gzip files: parallel inflate (-t 8) against one inflating thread (-t 1)
+if len(sys.argv) > 3 and sys.argv[3] == "gz":
+    parts = []
+    per = (n // 8) * (size // n)
+    with open(fq, "rb") as f:
+        for k in range(8):
+            p = os.path.join(tmp, f"e2e_part{k}.fastq")
+            with open(p, "wb") as o:
+                o.write(f.read(per))
+            subprocess.run(["gzip", "-1", "-f", p], check=True)
+            parts.append(p + ".gz")
+    res = {}
+    for t in (1, 8):
+        t0 = time.time()
+        r = subprocess.run([cli, "annotate", "-i"] + parts + ["-o", os.path.join(tmp, "e2e_gz.tsv"), "--kit", "SQK-NBD114-96", "--flank-max-errors", "3",
+                            "-t", str(t)], capture_output=True, text=True, env=env)
+        dt = time.time() - t0
+        assert r.returncode == 0, r.stderr
+        res[f"threads_{t}"] = {"wall_s": dt, "reads_per_s": 8 * (n // 8) / dt, "gz_bytes": sum(os.path.getsize(p) for p in parts)}
+    print(json.dumps({"gz_8_files": res}))
