@@ -512,7 +512,11 @@ __global__ __launch_bounds__(256) void k_scan_add(uint32_t* __restrict__ out, ui
 // (profiles/r01_v3_pmc.txt: 10.9 GB fetched per 2 M reads).  The host picks the LDS variant whenever
 // (m + k + 1) * W * 512 bytes fit in 64 KB.
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
-template <int W, bool MOVES_IN_LDS>
+// MODE 0: move bits in private memory (any geometry); 1: in LDS, every row of every column; 2: in LDS, only the
+// band of 16 rows around the end cell's diagonal (one word per column and lane: both planes).  A path of cost
+// <= k leaves that diagonal by at most k rows, so for k <= 6 the band holds every cell the walk can visit, and
+// a quarter of the LDS lets four times as many blocks share a CU.
+template <int W, int MODE>
 __global__ __launch_bounds__(64) void k_flank_trace(const uint8_t* __restrict__ bases, const uint64_t* __restrict__ offsets,
                                                     const uint8_t* __restrict__ tables, const bb_group_dev* __restrict__ groups,
                                                     uint32_t n_groups, const bb_hit_raw* __restrict__ raw, uint32_t n_hits,
@@ -539,14 +543,38 @@ __global__ __launch_bounds__(64) void k_flank_trace(const uint8_t* __restrict__ 
     if (s0 < 0) s0 = 0;
     const int32_t w = i0 - s0;  // <= m + k < MAXC
 
-    extern __shared__ uint32_t s_moves[];  // [column][lo|hi][word][64 lanes] when MOVES_IN_LDS
-    uint32_t plo_[MOVES_IN_LDS ? 1 : MAXC][W], phi_[MOVES_IN_LDS ? 1 : MAXC][W];
-    auto put = [&](int c, int x, uint32_t l, uint32_t hh) {
-        if constexpr (MOVES_IN_LDS) { s_moves[((c * 2 + 0) * W + x) * 64 + threadIdx.x] = l; s_moves[((c * 2 + 1) * W + x) * 64 + threadIdx.x] = hh; }
-        else { plo_[c][x] = l; phi_[c][x] = hh; }
+    extern __shared__ uint32_t s_moves[];  // MODE 1: [column][lo|hi][word][64 lanes]; MODE 2: [column][64 lanes]
+    uint32_t plo_[MODE == 0 ? MAXC : 1][W], phi_[MODE == 0 ? MAXC : 1][W];
+    // first row (0-based bit) of column c's band: the diagonal through the end cell (j0, w), k + 1 rows above it
+    auto band_lo = [&](int c) -> int { const int b = (j0 - 1) - (w - c) - (k + 1); return b < 0 ? 0 : b; };
+    auto bits16 = [&](const uint32_t (&v)[W], int sh) -> uint32_t {  // bits [sh, sh + 16) of the W-word vector
+        const int q = sh >> 5, r = sh & 31;
+        uint32_t a = v[0], b = W > 1 ? v[1] : 0u;
+#pragma unroll
+        for (int x = 1; x < W; ++x) { a = q == x ? v[x] : a; b = q == x ? (x + 1 < W ? v[x + 1] : 0u) : b; }
+        return (uint32_t)((((unsigned long long)b << 32) | a) >> r) & 0xFFFFu;
     };
-    auto get_lo = [&](int c, int x) -> uint32_t { if constexpr (MOVES_IN_LDS) return s_moves[((c * 2 + 0) * W + x) * 64 + threadIdx.x]; else return plo_[c][x]; };
-    auto get_hi = [&](int c, int x) -> uint32_t { if constexpr (MOVES_IN_LDS) return s_moves[((c * 2 + 1) * W + x) * 64 + threadIdx.x]; else return phi_[c][x]; };
+    auto put = [&](int c, int x, uint32_t l, uint32_t hh) {
+        if constexpr (MODE == 1) { s_moves[((c * 2 + 0) * W + x) * 64 + threadIdx.x] = l; s_moves[((c * 2 + 1) * W + x) * 64 + threadIdx.x] = hh; }
+        else if constexpr (MODE == 0) { plo_[c][x] = l; phi_[c][x] = hh; }
+    };
+    auto put_band = [&](int c, const uint32_t (&l)[W], const uint32_t (&hh)[W]) {
+        const int sh = band_lo(c);
+        s_moves[c * 64 + threadIdx.x] = bits16(l, sh) | (bits16(hh, sh) << 16);
+    };
+    // 2-bit move of cell (row bit `bit`, column c)
+    auto get_op = [&](int c, int bit) -> uint32_t {
+        if constexpr (MODE == 2) {
+            const uint32_t wv = s_moves[c * 64 + threadIdx.x];
+            const int rel = bit - band_lo(c);
+            return ((wv >> rel) & 1u) | (((wv >> (16 + rel)) & 1u) << 1);
+        } else if constexpr (MODE == 1) {
+            const uint32_t lw = s_moves[((c * 2 + 0) * W + (bit >> 5)) * 64 + threadIdx.x], hw = s_moves[((c * 2 + 1) * W + (bit >> 5)) * 64 + threadIdx.x];
+            return ((lw >> (bit & 31)) & 1u) | (((hw >> (bit & 31)) & 1u) << 1);
+        } else {
+            return ((plo_[c][bit >> 5] >> (bit & 31)) & 1u) | (((phi_[c][bit >> 5] >> (bit & 31)) & 1u) << 1);
+        }
+    };
     uint32_t pv[W], mv[W];
 #pragma unroll
     for (int x = 0; x < W; ++x) {
@@ -585,8 +613,11 @@ __global__ __launch_bounds__(64) void k_flank_trace(const uint8_t* __restrict__ 
                 load_eq<W, S>(peq, ch, eq);
                 myers_step<W>(pv, mv, eq, d0, ph, mh);
                 move_bits<W>(eq, d0, ph, l, hh);
+                if constexpr (MODE == 2) put_band(c, l, hh);
+                else {
 #pragma unroll
-                for (int x = 0; x < W; ++x) put(c, x, l[x], hh[x]);
+                    for (int x = 0; x < W; ++x) put(c, x, l[x], hh[x]);
+                }
             }
         }
 #pragma unroll
@@ -601,9 +632,7 @@ __global__ __launch_bounds__(64) void k_flank_trace(const uint8_t* __restrict__ 
             if (s0 == 0) break;  // left overhang: remaining pattern is outside the read
             op = 3u;
         } else {
-            const int bit = j - 1;
-            const uint32_t lw = get_lo(i, bit >> 5), hw = get_hi(i, bit >> 5);
-            op = ((lw >> (bit & 31)) & 1u) | (((hw >> (bit & 31)) & 1u) << 1);
+            op = get_op(i, j - 1);
         }
         if (op != 2u) --j;
         if (op != 3u) --i;

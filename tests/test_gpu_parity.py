@@ -125,6 +125,36 @@ def test_prefix_split_with_insertions_in_the_shared_rows():
     assert len(got) > 300
 
 
+def test_trace_band_edges():
+    """k_flank_trace keeps only the 16-row band around the end cell's diagonal when flank-max-errors <= 6: flank
+    matches whose k errors are all insertions, or all deletions, push the traced path to the band's two edges"""
+    from barbell_amd import kits
+
+    rng = np.random.default_rng(3)
+    for k in (3, 6):
+        groups = kits.groups_from_kit("SQK-NBD114-96", flank_max_errors=k)
+        reads = []
+        for i in range(300):
+            full = bytearray(groups[0].seqs[int(rng.integers(0, 96))])
+            e = int(rng.integers(0, k + 1))
+            pos = sorted(int(x) for x in rng.integers(1, 13, size=e))       # inside the 14-nt left flank part
+            if i % 2:                                                        # e insertions
+                for q, p in enumerate(pos):
+                    full[p + q:p + q] = bytes(rng.choice(list(b"ACGT"), size=1).astype(np.uint8))
+            else:                                                            # e deletions
+                for q, p in enumerate(pos):
+                    if p - q < len(full):
+                        del full[max(p - q, 0)]
+            head = bytes(rng.choice(list(b"ACGT"), size=int(rng.integers(0, 40))).astype(np.uint8))
+            tail = bytes(rng.choice(list(b"ACGT"), size=int(rng.integers(60, 300))).astype(np.uint8))
+            rd = head + bytes(full) + tail
+            reads.append(A_rc(rd) if i % 3 == 0 else rd)
+        bases, offsets = _abi.pack_reads(reads)
+        _, got, want = run_both(groups, bases, offsets)
+        assert_same(got, want)
+        assert len(got) > 150
+
+
 def A_rc(b):
     return bytes(b.translate(bytes.maketrans(b"ACGT", b"TGCA"))[::-1])
 
