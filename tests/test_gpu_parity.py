@@ -88,6 +88,7 @@ def test_two_word_kernel_without_prefix_split(monkeypatch):
     from barbell_amd import annotate as A
 
     monkeypatch.setenv("BARBELL_AMD_NO_PFX", "1")
+    monkeypatch.setenv("BARBELL_AMD_TRACE_FULL", "1")  # and full-height move bits in k_flank_trace (LDS mode 1)
     for cfg in ("nbd96", "dual"):
         groups = config_groups(cfg)
         bases, offsets = A.synth_reads_host(groups, 4711, 300, 2500, 0, 1500)
