@@ -14,18 +14,34 @@
 
 using namespace barbell;
 
+// --shard R/W: this process takes the input files whose index is R modulo W (one process per GPU with --device R;
+// reads shard trivially, SURVEY §8e — each process writes its own outputs)
+static bool apply_shard(const std::string& spec, std::vector<std::string>& files) {
+    if (spec.empty()) return true;
+    const size_t slash = spec.find('/');
+    if (slash == std::string::npos) return false;
+    const long r = atol(spec.substr(0, slash).c_str()), w = atol(spec.substr(slash + 1).c_str());
+    if (w < 1 || r < 0 || r >= w) return false;
+    std::vector<std::string> mine;
+    for (size_t i = 0; i < files.size(); ++i)
+        if ((long)(i % (size_t)w) == r) mine.push_back(files[i]);
+    files.swap(mine);
+    return true;
+}
+
 static void usage() {
     fputs(
         "Usage: barbell-amd annotate -i <FASTQ>... [-o output.tsv] (--kit <KIT> | -q <FASTA>... [-b Ftag|Rtag ...])\n"
         "                            [--flank-max-errors INT] [--min-score F=0.2] [--min-score-diff F=0.1]\n"
         "                            [--alpha F=0.4] [--use-extended] [-t THREADS=10] [--verbose]\n"
-        "                            [--block-bytes N=128Mi | --batch-reads N (= N*4096 bytes)] [--device D=0]\n"
+        "                            [--block-bytes N=128Mi | --batch-reads N (= N*4096 bytes)] [--device D=0] [--shard R/W]\n"
         "                            [(-f <PATTERN_FILE>... | --kit-filter [--maximize]) [--filtered FILE] [--dropped FILE]]\n"
         "                            [--trim-output DIR [--no-label] [--no-orientation] [--no-flanks] [--sort-labels]\n"
         "                             [--only-side left|right] [--failed-out FILE] [--skip-trim] [--flip] [--gzip]]\n"
         "                            [--inspect [-n TOP=10] [--read-pattern-out FILE] [-s BUCKET=250]]\n"
         "       barbell-amd kit -k <KIT> -i <FASTQ>... -o <OUT_DIR> [--maximize] [--min-score F] [--min-score-diff F]\n"
         "                       [--flank-max-errors INT] [--failed-out FILE] [--use-extended] [--alpha F] [--gzip] [-t N]\n"
+        "                       [--device D=0] [--shard R/W]\n"
         "       barbell-amd kits          list the supported kit names\n"
         "       barbell-amd pattern <STR>...   parse filter pattern strings and print their elements\n",
         stderr);
@@ -57,6 +73,7 @@ int main(int argc, char** argv) {
     if (cmd == "kit") {
         KitConfig k;
         std::vector<std::string> input;
+        std::string shard;
         bool multi_in = false;
         for (int i = 2; i < argc; ++i) {
             const std::string a = argv[i];
@@ -72,6 +89,7 @@ int main(int argc, char** argv) {
             else if (a == "--alpha") k.alpha = (float)atof(need("--alpha"));
             else if (a == "--batch-reads") k.batch_reads = (size_t)atol(need("--batch-reads"));
             else if (a == "--device") k.device = atoi(need("--device"));
+            else if (a == "--shard") shard = need("--shard");
             else if (a == "--maximize") { k.maximize = true; multi_in = false; }
             else if (a == "--verbose") { k.verbose = true; multi_in = false; }
             else if (a == "--use-extended") { k.use_extended = true; multi_in = false; }
@@ -81,6 +99,8 @@ int main(int argc, char** argv) {
         }
         if (k.kit_name.empty() || k.output_folder.empty()) { fputs("error: kit needs --kit and --output\n", stderr); return 2; }
         if (input.empty()) { fputs("error: No FASTQ input files provided\n", stderr); return 2; }
+        if (!apply_shard(shard, input)) { fputs("error: --shard takes R/W with 0 <= R < W\n", stderr); return 2; }
+        if (input.empty()) { puts("Nothing to do for this shard"); return 0; }
         try {
             printf("Kit name: %s\nKit type: %s\n", k.kit_name.c_str(), k.maximize ? "Maximize" : "Safe");
             const AnnotateStats st = demux_using_kit(input, k);
@@ -93,6 +113,7 @@ int main(int argc, char** argv) {
     }
     if (cmd != "annotate") { usage(); return 2; }
     std::vector<std::string> input, queries, btypes, pattern_files;
+    std::string shard;
     bool kit_filter = false, maximize = false;
     TrimConfig tcfg;
     size_t top_n = 10;
@@ -115,6 +136,7 @@ int main(int argc, char** argv) {
         else if (a == "--batch-reads") { cfg.batch_reads = (size_t)atol(need("--batch-reads")); multi = nullptr; }
         else if (a == "--block-bytes") { cfg.block_bytes = (size_t)atoll(need("--block-bytes")); multi = nullptr; }
         else if (a == "--device") { cfg.device = atoi(need("--device")); multi = nullptr; }
+        else if (a == "--shard") { shard = need("--shard"); multi = nullptr; }
         else if (a == "-f" || a == "--filter-file") { multi = &pattern_files; }
         else if (a == "--filtered") { cfg.filtered_file = need("--filtered"); multi = nullptr; }
         else if (a == "--dropped") { cfg.dropped_file = need("--dropped"); multi = nullptr; }
@@ -146,6 +168,8 @@ int main(int argc, char** argv) {
         else { fprintf(stderr, "error: unexpected argument '%s'\n", a.c_str()); usage(); return 2; }
     }
     if (input.empty()) { fputs("error: No FASTQ input files provided\n", stderr); return 2; }
+    if (!apply_shard(shard, input)) { fputs("error: --shard takes R/W with 0 <= R < W\n", stderr); return 2; }
+    if (input.empty()) { fputs("Nothing to do for this shard\n", stderr); return 0; }
     if (kit.empty() == queries.empty()) { fputs("error: give either --kit or --queries (they conflict, bin/main.rs:85-87)\n", stderr); return 2; }
     if (kit_filter && kit.empty()) { fputs("error: --kit-filter needs --kit\n", stderr); return 2; }
     if (!cfg.trim_folder.empty()) {

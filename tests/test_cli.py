@@ -46,6 +46,16 @@ def test_argument_errors(tmp_path):
     assert r.returncode == 1 and "Unknown or unsupported kit" in r.stderr
 
 
+def test_shard_argument(tmp_path):
+    fq = tmp_path / "r.fastq"
+    fq.write_bytes(b"@r1\nACGT\n+\nIIII\n")
+    base = [CLI, "annotate", "-i", str(fq), "-o", str(tmp_path / "o.tsv"), "--kit", "SQK-NBD114-96"]
+    assert subprocess.run(base + ["--shard", "2/2"], capture_output=True).returncode == 2
+    assert subprocess.run(base + ["--shard", "x"], capture_output=True).returncode == 2
+    r = subprocess.run(base + ["--shard", "1/2"], capture_output=True, text=True)   # one file, shard 1 of 2: nothing to do
+    assert r.returncode == 0 and "Nothing to do" in r.stderr
+
+
 def _dump(p):
     from barbell_amd import _abi
 
