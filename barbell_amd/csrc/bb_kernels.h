@@ -943,6 +943,64 @@ __device__ __forceinline__ void subpath_closed_form(unsigned long long plo, unsi
     bcost = cost;
 }
 
+// Common tail of the register-resident barcode kernels, one call per block iteration (every lane of the block
+// takes part: it synchronises): pass decision (searcher.rs:303-328), per-hit argmax = first maximum and runner-up
+// by 64-bit LDS atomics on the score's bit pattern (searcher.rs:377,390-396), thresholds, and the row — tag row
+// with the sub-path of the winning lane (cigar_parse.rs:6-68) or flank-only row (searcher.rs:241-265).
+__device__ __forceinline__ void pick_and_emit(bool active, bool cand, int32_t best_cost, double s_norm, int p, int hl, const bb_hit& H,
+                                              uint32_t hit_idx, const bb_group_dev& G, unsigned long long plo, unsigned long long phi,
+                                              unsigned long long diagrow, int32_t tstart, int32_t best_pos, int32_t* s_cnt1,
+                                              unsigned long long* s_max, unsigned long long* s_sec, int32_t* s_top, double min_score,
+                                              double min_score_diff, bb_rowtmp* __restrict__ rows) {
+    const int m = G.m_bar;
+    const int32_t rlo = G.rel_lo, rhi = G.rel_hi;
+    __syncthreads();
+    if (active) {
+        const bool pass2 = s_cnt1[hl] <= 1 && G.k1 < G.k2;
+        cand = cand && (pass2 || best_cost <= G.k1);
+    }
+    const unsigned long long key = cand ? (unsigned long long)__double_as_longlong(s_norm) + 1ull : 0ull;
+    if (cand) atomicMax(&s_max[hl], key);
+    __syncthreads();
+    if (cand && key == s_max[hl]) atomicMin(&s_top[hl], p);
+    __syncthreads();
+    if (active) {
+        const int top = s_top[hl];
+        if (cand && p != top) atomicMax(&s_sec[hl], key);
+    }
+    __syncthreads();
+    if (active) {
+        const int top = s_top[hl];
+        const bool have = top != 0x7FFFFFFF;
+        if ((have && p == top) || (!have && p == 0)) {
+            bool valid = have && s_norm >= min_score;
+            const unsigned long long sk = s_sec[hl];
+            if (valid && sk != 0ull) valid = (s_norm - __longlong_as_double((long long)(sk - 1ull))) >= min_score_diff;
+            const uint32_t read_len = H.read_len;
+            bb_rowtmp R;
+            bb_row& r = R.row;
+            r.read_idx = H.read_idx; r.read_len = read_len;
+            r.rel_dist_to_end = rel_dist_to_end((int64_t)H.text_start, (int64_t)read_len);
+            r.read_start_flank = H.text_start; r.read_end_flank = H.text_end;
+            r.flank_cost = H.cost; r.group_idx = H.group; r.strand = H.strand;
+            r._pad[0] = 1; r._pad[1] = r._pad[2] = 0;
+            if (valid) {
+                int32_t txt_lo, txt_hi, bcost;
+                subpath_closed_form(plo, phi, diagrow, tstart, best_pos, m, rlo, rhi, txt_lo, txt_hi, bcost);
+                r.read_start_bar = H.ws + (uint32_t)txt_lo; r.read_end_bar = H.ws + (uint32_t)txt_hi;
+                r.bar_start = H.ws + (uint32_t)rlo; r.bar_end = H.ws + (uint32_t)rhi;
+                r.match_type = (uint8_t)G.type; r.barcode_cost = (int16_t)bcost; r.barcode_idx = (int16_t)top;
+            } else {
+                r.read_start_bar = H.text_start; r.read_end_bar = H.text_end;
+                r.bar_start = 0; r.bar_end = 0;
+                r.match_type = (uint8_t)(G.type == BB_FTAG ? BB_FFLANK : BB_RFLANK);
+                r.barcode_cost = (int16_t)G.m_bar; r.barcode_idx = -1;
+            }
+            rows[hit_idx] = R;
+        }
+    }
+}
+
 // Lodhi (p = 3, lambda = 1/2) on the op planes of a traced path, oracle [H8]'s forward recurrence on power-of-two
 // scaled variables: b1 = 2^t a1, b2 = 2^t a2 change only at Match columns and score += 2^-(t+1) * b2 (the
 // product is exact, the fma rounds once like the oracle's add).  Columns (tstart, best_pos] carry the text ops
@@ -1142,7 +1200,6 @@ __global__ __launch_bounds__(512) void k_barcode_reg(const uint8_t* __restrict__
     // falls off the top (b = 0) when row 1 has been consumed.  Outputs: the text op of each column in
     // two bit planes, the rows consumed by a Match/Sub, the number of columns with a text op.
     // Once every cursor of the wave is in the high word (rows <= 32) the step runs on 32-bit words.
-    const int32_t rlo = G.rel_lo, rhi = G.rel_hi;
     unsigned long long plo = 0ull, phi = 0ull;
     uint32_t b_lo = 0u, b_hi = 0u, dg_lo = 0u, dg_hi = 0u;   // cursor and consumed rows, bit-reversed
     int32_t ntext = 0;
@@ -1203,51 +1260,8 @@ __global__ __launch_bounds__(512) void k_barcode_reg(const uint8_t* __restrict__
     } else (void)lodhi_replay<CW>(0ull, 0ull, 0ull, 0, 0, wmax);  // the loop is wave-uniform: idle lanes walk it with empty masks
     // ---- pass decision (searcher.rs:303-328), then per-hit argmax (first maximum) and runner-up:
     // searcher.rs:377,390-396 ----
-    __syncthreads();
-    if (active) {
-        const bool pass2 = s_cnt1[hl] <= 1 && G.k1 < G.k2;
-        cand = cand && (pass2 || best_cost <= G.k1);
-    }
-    const unsigned long long key = cand ? (unsigned long long)__double_as_longlong(s_norm) + 1ull : 0ull;
-    if (cand) atomicMax(&s_max[hl], key);
-    __syncthreads();
-    if (cand && key == s_max[hl]) atomicMin(&s_top[hl], p);
-    __syncthreads();
-    if (active) {
-        const int top = s_top[hl];
-        if (cand && p != top) atomicMax(&s_sec[hl], key);
-    }
-    __syncthreads();
-    if (active) {
-        const int top = s_top[hl];
-        const bool have = top != 0x7FFFFFFF;
-        if ((have && p == top) || (!have && p == 0)) {
-            bool valid = have && s_norm >= min_score;
-            const unsigned long long sk = s_sec[hl];
-            if (valid && sk != 0ull) valid = (s_norm - __longlong_as_double((long long)(sk - 1ull))) >= min_score_diff;
-            const uint32_t read_len = H.read_len;
-            bb_rowtmp R;
-            bb_row& r = R.row;
-            r.read_idx = H.read_idx; r.read_len = read_len;
-            r.rel_dist_to_end = rel_dist_to_end((int64_t)H.text_start, (int64_t)read_len);
-            r.read_start_flank = H.text_start; r.read_end_flank = H.text_end;
-            r.flank_cost = H.cost; r.group_idx = H.group; r.strand = H.strand;
-            r._pad[0] = 1; r._pad[1] = r._pad[2] = 0;
-            if (valid) {
-                int32_t txt_lo, txt_hi, bcost;
-                subpath_closed_form(plo, phi, diagrow, tstart, best_pos, m, rlo, rhi, txt_lo, txt_hi, bcost);
-                r.read_start_bar = H.ws + (uint32_t)txt_lo; r.read_end_bar = H.ws + (uint32_t)txt_hi;
-                r.bar_start = H.ws + (uint32_t)rlo; r.bar_end = H.ws + (uint32_t)rhi;
-                r.match_type = (uint8_t)G.type; r.barcode_cost = (int16_t)bcost; r.barcode_idx = (int16_t)top;
-            } else {
-                r.read_start_bar = H.text_start; r.read_end_bar = H.text_end;
-                r.bar_start = 0; r.bar_end = 0;
-                r.match_type = (uint8_t)(G.type == BB_FTAG ? BB_FFLANK : BB_RFLANK);
-                r.barcode_cost = (int16_t)G.m_bar; r.barcode_idx = -1;
-            }
-            rows[hit_idx] = R;
-        }
-    }
+    pick_and_emit(active, cand, best_cost, s_norm, p, hl, H, hit_idx, G, plo, phi, diagrow, tstart, best_pos, s_cnt1, s_max, s_sec, s_top,
+                  min_score, min_score_diff, rows);
     __syncthreads();  // LDS hit records / reduction cells are rewritten by the next iteration
   }
 }
@@ -1456,7 +1470,6 @@ __global__ __launch_bounds__(CW <= 48 ? 768 : 512) void k_barcode_pfx(const uint
     // The cursor leaves the word either by the carry of the Del-run addition (the run continues in the shared
     // rows at the same column, which then has no text op in this phase) or by a Match/Sub out of row P+1 (next
     // column); either way phase 2 starts with the cursor entering row P. ----
-    const int32_t rlo = G.rel_lo, rhi = G.rel_hi;
     unsigned long long plo = 0ull, phi = 0ull;
     uint32_t b = 0u, dg = 0u;
     // the cursor enters at row m = bit 0 of the word in column best_pos: that column's bit of this mask is simply
@@ -1548,51 +1561,8 @@ __global__ __launch_bounds__(CW <= 48 ? 768 : 512) void k_barcode_pfx(const uint
         const double sc = lodhi_replay<CW>(plo, phi, delrow, tstart, best_pos, wmax);
         s_norm = G.perfect > 0.0 ? sc / G.perfect : 0.0;
     } else (void)lodhi_replay<CW>(0ull, 0ull, 0ull, 0, 0, wmax);  // the loop is wave-uniform: idle lanes walk it with empty masks
-    __syncthreads();
-    if (active) {
-        const bool pass2 = s_cnt1[hl] <= 1 && G.k1 < G.k2;
-        cand = cand && (pass2 || best_cost <= G.k1);
-    }
-    const unsigned long long key = cand ? (unsigned long long)__double_as_longlong(s_norm) + 1ull : 0ull;
-    if (cand) atomicMax(&s_max[hl], key);
-    __syncthreads();
-    if (cand && key == s_max[hl]) atomicMin(&s_top[hl], p);
-    __syncthreads();
-    if (active) {
-        const int top = s_top[hl];
-        if (cand && p != top) atomicMax(&s_sec[hl], key);
-    }
-    __syncthreads();
-    if (active) {
-        const int top = s_top[hl];
-        const bool have = top != 0x7FFFFFFF;
-        if ((have && p == top) || (!have && p == 0)) {
-            bool valid = have && s_norm >= min_score;
-            const unsigned long long sk = s_sec[hl];
-            if (valid && sk != 0ull) valid = (s_norm - __longlong_as_double((long long)(sk - 1ull))) >= min_score_diff;
-            const uint32_t read_len = H.read_len;
-            bb_rowtmp R;
-            bb_row& r = R.row;
-            r.read_idx = H.read_idx; r.read_len = read_len;
-            r.rel_dist_to_end = rel_dist_to_end((int64_t)H.text_start, (int64_t)read_len);
-            r.read_start_flank = H.text_start; r.read_end_flank = H.text_end;
-            r.flank_cost = H.cost; r.group_idx = H.group; r.strand = H.strand;
-            r._pad[0] = 1; r._pad[1] = r._pad[2] = 0;
-            if (valid) {
-                int32_t txt_lo, txt_hi, bcost;
-                subpath_closed_form(plo, phi, diagrow, tstart, best_pos, m, rlo, rhi, txt_lo, txt_hi, bcost);
-                r.read_start_bar = H.ws + (uint32_t)txt_lo; r.read_end_bar = H.ws + (uint32_t)txt_hi;
-                r.bar_start = H.ws + (uint32_t)rlo; r.bar_end = H.ws + (uint32_t)rhi;
-                r.match_type = (uint8_t)G.type; r.barcode_cost = (int16_t)bcost; r.barcode_idx = (int16_t)top;
-            } else {
-                r.read_start_bar = H.text_start; r.read_end_bar = H.text_end;
-                r.bar_start = 0; r.bar_end = 0;
-                r.match_type = (uint8_t)(G.type == BB_FTAG ? BB_FFLANK : BB_RFLANK);
-                r.barcode_cost = (int16_t)G.m_bar; r.barcode_idx = -1;
-            }
-            rows[hit_idx] = R;
-        }
-    }
+    pick_and_emit(active, cand, best_cost, s_norm, p, hl, H, hit_idx, G, plo, phi, diagrow, tstart, best_pos, s_cnt1, s_max, s_sec, s_top,
+                  min_score, min_score_diff, rows);
     __syncthreads();
   }
 }
