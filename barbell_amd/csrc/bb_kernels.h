@@ -1345,7 +1345,7 @@ __global__ __launch_bounds__(CW <= 48 ? 768 : 512) void k_barcode_pfx(const uint
     const uint32_t n_iter = (n_list + hpb - 1) / hpb;
     if (blockIdx.x >= n_iter) return;
     const int N = G.n_seqs, m = G.m_bar, P = G.pfx;
-    constexpr int MS = 32;  // rows per lane: the split is made at pfx = m_bar - 32
+    // rows per lane: 32 — the split is made at pfx = m_bar - 32 (row P+1 <-> bit 31 of the bit-reversed planes, row m <-> bit 0)
     constexpr int PIECES_H = (int)(sizeof(bb_hit) / 16), PIECES_P = (int)(sizeof(bb_hit_pfx) / 16), PIECES = PIECES_H + PIECES_P;
     // LDS carve: [hit + prefix records: hpb x 368 B][max u64[hpb]][second u64[hpb]][cnt1 i32[hpb]][top i32[hpb]][peq 2*16*N words]
     uint4* s_hit = reinterpret_cast<uint4*>(smem);
