@@ -411,7 +411,7 @@ void launch_barcode_pfx(bb_ctx* c, uint32_t n_hits, uint32_t g, const uint32_t* 
     const uint32_t tmax = CW <= 48 ? 768u : c->reg_threads;
     const uint32_t hpb = tmax / N;
     const uint32_t threads = ((hpb * N + 63) / 64) * 64;
-    const size_t smem = (size_t)2 * 16 * N * 4 + (size_t)hpb * 24 + (size_t)hpb * (sizeof(bb_hit) + sizeof(bb_hit_pfx)) + 16;
+    const size_t smem = (size_t)2 * 16 * N * 4 + (size_t)hpb * 24 + (size_t)hpb * (sizeof(bb_hit) + sizeof(bb_hit_pfx)) + (size_t)hpb * CW * 8 + 16;
     const uint32_t n_iter = (n_hits + hpb - 1) / hpb;
     const uint32_t resident = (uint32_t)c->n_cus * (threads > 256 ? 1u : 2u) * c->reg_blocks_mult;
     const uint32_t blocks = n_iter < resident ? n_iter : resident;

@@ -1359,6 +1359,8 @@ __global__ __launch_bounds__(CW <= 48 ? 768 : 512) void k_barcode_pfx(const uint
     int32_t* s_top = reinterpret_cast<int32_t*>(smem + o);
     o += (size_t)hpb * 4;
     o = (o + 15) & ~(size_t)15;
+    uint2* s_tab = reinterpret_cast<uint2*>(smem + o);  // [hpb][CW]: the walk through the shared rows per entry column
+    o += (size_t)hpb * CW * 8;
     uint32_t* s_peq = reinterpret_cast<uint32_t*>(smem + o);
     {
         const uint32_t* gp = reinterpret_cast<const uint32_t*>(tables + G.off_peq_sub[0]);
@@ -1388,6 +1390,38 @@ __global__ __launch_bounds__(CW <= 48 ? 768 : 512) void k_barcode_pfx(const uint
     __syncthreads();
     const uint32_t hit_idx = hit_list ? (exists ? hit_list[li] : 0u) : li;
     prefetch(it + gridDim.x);
+    // The walk of a traced path through the shared rows depends only on the hit and on the column in which the
+    // path enters row P, not on the barcode: the first hpb * CW lanes of the block each walk one (hit, entry column)
+    // once — 16 columns from independent LDS reads, static register indices — and every barcode lane later looks
+    // its entry up instead of walking (the walk was 12 % of this kernel).  Entry: x = text-op planes of the columns
+    // cx, cx-1, .. (bit i <-> column cx - i; lo | hi << 16), y = consumed rows (bits 0..15) | text ops (bits 16..20) |
+    // bit position of a cursor still alive after the 16 columns (bits 24..27, flag in bit 31: the lane then finishes
+    // in a loop).
+    {
+        const uint32_t pm = (1u << P) - 1u;
+        for (uint32_t l = threadIdx.x; l < hpb * (uint32_t)CW; l += blockDim.x) {
+            const uint32_t hw = l / (uint32_t)CW;
+            const int32_t cxw = (int32_t)(l % (uint32_t)CW) + 1;
+            const uint32_t* shw = reinterpret_cast<const uint32_t*>(s_hit + hw * PIECES + PIECES_H + 1);
+            uint32_t bh = 1u, lo2 = 0u, hi2 = 0u, dgw = 0u, n2 = 0u;
+#pragma unroll 1
+            for (int i = 0; i < 16 && bh != 0u && cxw - i >= 1; ++i) {  // rolled: short, and the registers are wanted elsewhere
+                const uint32_t w = shw[cxw - 1 - i];
+                const uint32_t Lr = w & 0xFFFFu, Hr = w >> 16;
+                const uint32_t Dr = Lr & Hr;
+                const uint32_t nb = ((Dr + bh) & ~Dr) & pm;
+                const bool has = nb != 0u, lo = (Lr & nb) != 0u, hi = (Hr & nb) != 0u;
+                lo2 |= lo ? (1u << i) : 0u;
+                hi2 |= hi ? (1u << i) : 0u;
+                const bool consume = has & !hi;
+                dgw |= consume ? nb : 0u;
+                bh = consume ? ((nb << 1) & pm) : nb;
+                n2 += has ? 1u : 0u;
+            }
+            if (cxw - 16 < 1) bh = 0u;
+            s_tab[l] = make_uint2(lo2 | (hi2 << 16), dgw | (n2 << 16) | (bh ? 0x80000000u | ((uint32_t)(__ffs(bh) - 1) << 24) : 0u));
+        }
+    }
     bb_hit H;  // header only
     {
         const uint4 h0 = s_hit[hls * PIECES], h1 = s_hit[hls * PIECES + 1];
@@ -1497,37 +1531,18 @@ __global__ __launch_bounds__(CW <= 48 ? 768 : 512) void k_barcode_pfx(const uint
     // columns best_pos .. cx+1 carry exactly those ops: phase 2 starts at column cx = best_pos - ntext.
     int32_t ntext = cand ? __popc(dg) + __popcll(phi & ~plo) : 0;
     const int32_t cx = cand ? best_pos - ntext : 0;
-    // ---- phase 2: the shared rows (row r <-> bit P - r), move bits of the hit's prefix record in LDS.
-    // The 16 columns below cx are fetched with independent LDS reads and walked with static
-    // register indices (no load -> address dependency per column); a cursor still alive after them (more than
-    // 16 - P insertions inside the shared rows) finishes in the loop underneath. ----
+    // ---- phase 2: the shared rows (row r <-> bit P - r): looked up in the block's walk table; a cursor still
+    // alive after the table's 16 columns (more than 16 - P insertions inside the shared rows) finishes in the
+    // loop underneath on the move bits of the hit's prefix record. ----
     uint32_t dgh = 0u;
+    __syncthreads();  // the walk table: its builders ran alongside the other waves' forward pass and traceback
     {
-        uint32_t bh = (cand && cx >= 1) ? 1u : 0u;
         const uint32_t pm = (1u << P) - 1u;
-        // columns cx-16 .. cx-1 (0-based) = sh[cx-16 .. cx-1]; entries below 0 are never used (the walk stops at column 1)
-        const int32_t base = cx - 16;
-        uint32_t w16[16];
-#pragma unroll
-        for (int e = 0; e < 16; ++e) w16[e] = s_sh[max(base + e, 0)];  // independent reads, issued back to back
-        uint32_t lo2 = 0u, hi2 = 0u;  // bit i: text op plane bits of column cx - i
-        int32_t used = 0;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const uint32_t w = w16[15 - i];
-            const uint32_t Lr = w & 0xFFFFu, Hr = w >> 16;
-            const uint32_t Dr = Lr & Hr;
-            const bool live = bh != 0u && (cx - i) >= 1;
-            const uint32_t nb = live ? (((Dr + bh) & ~Dr) & pm) : 0u;
-            const bool has = nb != 0u, lo = (Lr & nb) != 0u, hi = (Hr & nb) != 0u;
-            lo2 |= lo ? (1u << i) : 0u;
-            hi2 |= hi ? (1u << i) : 0u;
-            const bool consume = has & !hi;
-            dgh |= consume ? nb : 0u;
-            bh = consume ? ((nb << 1) & pm) : nb;
-            ntext += has ? 1 : 0;
-            used += has ? 1 : 0;
-        }
+        const uint2 e = (cand && cx >= 1) ? s_tab[hls * CW + cx - 1] : make_uint2(0u, 0u);
+        const uint32_t lo2 = e.x & 0xFFFFu, hi2 = e.x >> 16;
+        dgh = e.y & 0xFFFFu;
+        uint32_t bh = (e.y >> 31) ? 1u << ((e.y >> 24) & 0xFu) : 0u;
+        ntext += (int32_t)((e.y >> 16) & 0x1Fu);
         // local bit i <-> column cx - i <-> plane bit cx - i - 1: reverse the 16 bits and slide them under cx
         const unsigned long long rl = (unsigned long long)(__brev(lo2) >> 16), rh = (unsigned long long)(__brev(hi2) >> 16);
         plo |= cx >= 16 ? (rl << (cx - 16)) : (rl >> (16 - cx));
@@ -1550,7 +1565,6 @@ __global__ __launch_bounds__(CW <= 48 ? 768 : 512) void k_barcode_pfx(const uint
             col -= has ? 1 : 0;
             if (col < 1) bh = 0u;
         }
-        (void)used;
     }
     const int32_t tstart = cand ? best_pos - ntext : 0;
     // consumed rows in natural order (row r <-> bit r-1)
