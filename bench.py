@@ -105,9 +105,10 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    rows_total = 0
+    rows_total = last_rows = 0
     for s in range(args.steps):
-        rows_total += step(s)
+        last_rows = step(s)
+        rows_total += last_rows
         for k, v in dm.kernel_ms().items():
             kms[k] = kms.get(k, 0.0) + v
     hist = torch.from_numpy(dm.counts().astype(np.int64)).to(cdev)
@@ -160,7 +161,7 @@ def main():
                                         d_off_b, batch, L, dev)
             out["ingest_step"] = ingest_leg(dm, d_bases.data_ptr() + ((args.steps - 1) % n_batches) * batch * L, batch, L, dev)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args, groups, dm, d_bases, L)
+            out["cpu_baseline"] = cpu_baseline(args, groups, dm, d_bases, L, batch, (args.steps - 1) % n_batches, d_rows, last_rows)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
@@ -288,35 +289,87 @@ def load_traffic(args, batch, L, dom):
     return dom_bytes or None, sum(v["hbm_bytes"] * v.get("launches_per_step", 1) for v in ks.values()), os.path.relpath(path, ROOT)
 
 
-def cpu_baseline(args, groups, dm, d_bases, L):
-    """Times the CPU oracle (kind "port") on a bounded sample of the SAME reads and checks that its
-    rows equal the GPU's on that sample."""
+def cpu_baseline(args, groups, dm, d_bases, L, batch, last_batch, d_rows, last_rows):
+    """CPU baseline on a bounded sample of the SAME reads, in the same run.
+
+    * A real `barbell` binary on PATH / $BARBELL_BIN (SURVEY §8d's preferred baseline; none exists in the build
+      image): timed on the sample written as FASTQ, kind "reference", and its annotation.tsv is diffed against the
+      HIP rows (tools/ref_diff.py) -> "reference_parity".  Otherwise "reference_parity": "unpinned beyond KATs".
+    * The CPU oracle (kind "port": scalar DP restatement, OpenMP over reads) is always run on three windows of the
+      LAST timed batch — its first reads, its middle and its last reads, whose byte offsets lie beyond 4 GiB — and each
+      window's rows are compared bit-exact with the full-batch device rows restricted to it."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import ref_diff
+    from barbell_amd import _abi
     from oracle import pyoracle as po
 
     po.build()
     cores = os.cpu_count() or 1
     orc = po.Oracle([g.as_tuple() for g in groups])
-    probe = min(max(64, 8 * cores), 4096)
+    probe = min(max(64, 8 * cores), 4096, batch)
+    base0 = last_batch * batch  # first resident read of the last timed batch
 
-    def sample(n):
-        bases = d_bases[: n * L].cpu().numpy()
-        offsets = (np.arange(n + 1, dtype=np.uint64) * np.uint64(L))
-        return bases, offsets
+    def sample(first, n):
+        bases = d_bases[(base0 + first) * L: (base0 + first + n) * L].cpu().numpy()
+        return bases, (np.arange(n + 1, dtype=np.uint64) * np.uint64(L))
 
-    b, o = sample(probe)
+    b, o = sample(0, probe)
     t = time.perf_counter()
     orc.annotate(b, o, n_threads=cores)
     rate = probe / (time.perf_counter() - t)
-    n = int(min(max(probe, rate * args.cpu_seconds), 2_000_000))
-    b, o = sample(n)
-    t = time.perf_counter()
-    want = orc.annotate(b, o, n_threads=cores)
-    dt = time.perf_counter() - t
-    got = dm.demux_packed(b, o)
-    return {"value": n / dt, "unit": "reads/s", "cores": cores, "kind": "port",
-            "sample": f"first {n} reads of the same synthetic stream, CPU oracle (scalar DP restatement, OpenMP over reads, "
-                      f"{cores} threads), {dt:.1f} s wall",
-            "parity_on_sample": bool(got.tobytes() == want.tobytes()), "rows_on_sample": int(len(want))}
+    n = int(min(max(probe, rate * args.cpu_seconds), batch))
+    w = max(1, n // 3)
+    full = np.frombuffer(d_rows[: last_rows * 48].cpu().numpy().tobytes(), dtype=_abi.ROW_DTYPE)
+    windows, total_dt, total_rows, sample_bases = {}, 0.0, 0, None
+    for name, first in (("head", 0), ("middle", max(0, batch // 2 - w // 2)), ("tail", batch - w)):
+        b, o = sample(first, w)
+        if name == "head":
+            sample_bases = b
+        t = time.perf_counter()
+        want = orc.annotate(b, o, n_threads=cores)
+        total_dt += time.perf_counter() - t
+        got = full[(full["read_idx"] >= first) & (full["read_idx"] < first + w)].copy()
+        got["read_idx"] -= first
+        windows[name] = {"first_read": int(first), "reads": int(w), "first_byte_offset": int(first) * L, "rows": int(len(want)),
+                         "parity": bool(got.tobytes() == want.tobytes())}
+        total_rows += len(want)
+    out = {"value": 3 * w / total_dt, "unit": "reads/s", "cores": cores, "kind": "port",
+           "sample": f"3 windows x {w} reads (head, middle, tail) of the last timed {batch}-read batch of the same synthetic stream, CPU oracle "
+                     f"(scalar DP restatement, OpenMP over reads, {cores} threads), {total_dt:.1f} s wall",
+           "parity_on_sample": all(v["parity"] for v in windows.values()), "parity_windows": windows, "rows_on_sample": int(total_rows),
+           "reference_parity": ref_diff.UNPINNED}
+    bin_ = ref_diff.find_barbell()
+    if bin_:  # real Barbell on the same box: the baseline SURVEY §8d prefers, and the parity check §8c promised
+        import tempfile
+
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import ref_export
+        from barbell_amd import annotate as A
+
+        with tempfile.TemporaryDirectory() as td:
+            cid, _, flags, files = ref_export.CONFIGS[args.config]
+            for f in files:
+                import shutil
+                shutil.copy(os.path.join(ref_export.EX, f), td)
+            nref = min(batch, max(w, int(200_000)))
+            rb, ro = sample(0, nref)
+            ref_export.write_fastq(os.path.join(td, "reads.fastq"), rb, ro)
+            json.dump({"config": args.config, "n_reads": nref, "barbell_args": flags}, open(os.path.join(td, "manifest.json"), "w"))
+            got = full[full["read_idx"] < nref]
+            ids = [f"r{i}" for i in range(nref)]
+            lines = A.format_rows(got, ids, groups)
+            with open(os.path.join(td, "ours.tsv"), "w") as f:
+                if lines:
+                    f.write(A.TSV_HEADER + "\n" + "\n".join(lines) + "\n")
+            try:
+                rep, secs = ref_diff.reference_check(td, bin_, os.path.join(td, "ours.tsv"), threads=cores)
+                out.update({"value": nref / secs, "kind": "reference", "cores": cores, "port_value": 3 * w / total_dt,
+                            "sample": f"real barbell ({bin_}) annotate -t {cores} on the first {nref} reads of the last timed batch written as FASTQ, "
+                                      f"{secs:.1f} s wall incl. its file IO",
+                            "reference_parity": {k: rep[k] for k in ("reference_parity", "mismatch_rate", "bucket_rates", "hazards", "rows_ref", "rows_ours")}})
+            except Exception as e:  # a binary that does not run here is reported, not fatal
+                out["reference_error"] = str(e)[:400]
+    return out
 
 
 if __name__ == "__main__":

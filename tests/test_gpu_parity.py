@@ -276,6 +276,41 @@ def test_large_batch_properties_without_oracle():
     assert len(tags) > 0.7 * n and set(np.unique(tags["strand"]).tolist()) == {0, 1}
 
 
+def test_offsets_beyond_4gib_against_oracle():
+    """One full BASELINE batch (2 M x 4000 nt = 8 GB: byte offsets pass 2^32 half-way) through the device-pointer
+    entry point; the rows of three windows of reads — head, middle and the LAST reads of the batch, whose offsets lie
+    beyond 4 GiB — are compared bit-exact with the oracle run on those reads alone (reads are independent, so the
+    full batch restricted to a window must equal the window annotated by itself)."""
+    import torch
+
+    from barbell_amd import annotate as A
+    from oracle import pyoracle as po
+
+    groups = config_groups("nbd96")
+    n, L, w = 2_000_000, 4000, 6000
+    assert (n - w) * L > 2 ** 32
+    dm = A.Demuxer()
+    for g in groups:
+        dm.add_query_group(g)
+    d_off = torch.arange(0, n + 1, dtype=torch.int64, device="cuda") * L
+    d_bases = torch.empty(n * L, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    dm.synth_dev(0xBA7BE11 ^ 2, L, L, 0, n, d_off.data_ptr(), d_bases.data_ptr())
+    d_rows = torch.empty(4 * n * 48, dtype=torch.uint8, device="cuda")
+    nr = dm.demux_dev(d_bases.data_ptr(), d_off.data_ptr(), n, d_rows.data_ptr(), 4 * n)
+    full = np.frombuffer(d_rows[: nr * 48].cpu().numpy().tobytes(), dtype=_abi.ROW_DTYPE)
+    assert nr > n and int(full["read_idx"].max()) > n - 100
+    orc = po.Oracle([g.as_tuple() for g in groups])
+    offs = np.arange(w + 1, dtype=np.uint64) * np.uint64(L)
+    for first in (0, n // 2 - w // 2, (2 ** 32) // L - w // 2, n - w):   # incl. the window straddling the 4 GiB line
+        host = d_bases[first * L: (first + w) * L].cpu().numpy()
+        want = orc.annotate(host, offs, n_threads=NT)
+        got = full[(full["read_idx"] >= first) & (full["read_idx"] < first + w)].copy()
+        got["read_idx"] -= first
+        assert len(want) > w // 2
+        assert_same(got, want)
+
+
 def test_iupac_queries_and_custom_geometry():
     """Custom query sets: IUPAC codes inside barcodes and flanks, a one-sided flank (no suffix), short
     barcodes with a single-word pattern (WB = 1), few and many barcodes per group."""
