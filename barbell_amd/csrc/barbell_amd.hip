@@ -256,35 +256,41 @@ int upload_tables(bb_ctx* c) {
                     for (int j = 0; j < mb; ++j)
                         if (bb_text_code((uint8_t)g.pat[s][p][j]) & code) t[((size_t)code * N + p) * WB + (j >> 5)] |= 1u << (j & 31);
         }
-        // shared-prefix split: rows every barcode of the group has in common (the left pad), per strand
-        D.pfx = 0;
-        if (WB == 2 && mb <= 48 && N >= 32 && !getenv("BARBELL_AMD_NO_PFX")) {
-            // forward-strand hits only: the rc patterns are the reverse complements (barcodes.rs:394-441), so their
-            // shared rows are the (shorter) right pad; rc hits keep the two-word kernel
-            int lcp = mb;
+        // Row split (bb_common.h): per strand, the leading and trailing rows every barcode of the group has in common
+        // (the pads; the rc patterns are the reverse complements, barcodes.rs:394-441, so their leading rows are the
+        // forward patterns' trailing ones).  P leading rows + 32 rows per lane + T trailing rows = m_bar.
+        for (int s = 0; s < 2; ++s) {
+            D.split[s] = 0; D.pfx[s] = 0; D.tail[s] = 0;
+            if (!(WB == 2 && mb <= 48 && N >= 13 && N <= 768) || getenv("BARBELL_AMD_NO_PFX")) continue;
+            int lcp = mb, lcs = mb;
             for (int p = 1; p < N; ++p) {
                 int j = 0;
-                while (j < lcp && bb_text_code((uint8_t)g.pat[0][p][j]) == bb_text_code((uint8_t)g.pat[0][0][j])) ++j;
+                while (j < lcp && bb_text_code((uint8_t)g.pat[s][p][j]) == bb_text_code((uint8_t)g.pat[s][0][j])) ++j;
                 lcp = j;
+                j = 0;
+                while (j < lcs && bb_text_code((uint8_t)g.pat[s][p][mb - 1 - j]) == bb_text_code((uint8_t)g.pat[s][0][mb - 1 - j])) ++j;
+                lcs = j;
             }
-            const int need = mb - 32;
-            if (need >= 1 && need <= lcp && need <= 16) D.pfx = need;
-        }
-        if (D.pfx) {
-            const int P = D.pfx;
-            const uint32_t pp = blob.alloc((size_t)2 * 16 * 4), ps = blob.alloc((size_t)2 * 16 * N * 4);
-            for (int s = 0; s < 2; ++s) {
-                D.off_peq_pfx[s] = pp + (uint32_t)(s * 16 * 4);
-                D.off_peq_sub[s] = ps + (uint32_t)((size_t)s * 16 * N * 4);
-                uint32_t* tp = reinterpret_cast<uint32_t*>(blob.b.data() + D.off_peq_pfx[s]);
-                uint32_t* ts = reinterpret_cast<uint32_t*>(blob.b.data() + D.off_peq_sub[s]);
-                for (int code = 0; code < 16; ++code) {
-                    for (int j = 0; j < P; ++j)
-                        if (bb_text_code((uint8_t)g.pat[s][0][j]) & code) tp[code] |= 1u << j;
-                    for (int p = 0; p < N; ++p)
-                        for (int j = P; j < mb; ++j)
-                            if (bb_text_code((uint8_t)g.pat[s][p][j]) & code) ts[(size_t)code * N + p] |= 1u << (j - P);
-                }
+            const int need = mb - 32;                        // rows that do not fit the lane's word
+            const int P = std::min(std::min(lcp, need), 16);  // as many as possible in front: they cost nothing per lane
+            const int T = need - P;
+            if (T < 0 || T > BB_MAX_TAIL || T > lcs) continue;
+            if (getenv("BARBELL_AMD_NO_TAIL") && T > 0) continue;  // test knob: only tail-free splits
+            D.split[s] = 1; D.pfx[s] = P; D.tail[s] = T;
+            D.off_peq_pfx[s] = blob.alloc((size_t)16 * 4);
+            D.off_peq_sub[s] = blob.alloc((size_t)16 * N * 4);
+            D.off_tail_lut[s] = blob.alloc(16);
+            uint32_t* tp = reinterpret_cast<uint32_t*>(blob.b.data() + D.off_peq_pfx[s]);
+            uint32_t* ts = reinterpret_cast<uint32_t*>(blob.b.data() + D.off_peq_sub[s]);
+            uint8_t* tl = blob.b.data() + D.off_tail_lut[s];
+            for (int code = 0; code < 16; ++code) {
+                for (int j = 0; j < P; ++j)
+                    if (bb_text_code((uint8_t)g.pat[s][0][j]) & code) tp[code] |= 1u << j;
+                for (int p = 0; p < N; ++p)
+                    for (int j = P; j < P + 32; ++j)
+                        if (bb_text_code((uint8_t)g.pat[s][p][j]) & code) ts[(size_t)code * N + p] |= 1u << (j - P);
+                for (int t = 0; t < T; ++t)
+                    if (bb_text_code((uint8_t)g.pat[s][0][P + 32 + t]) & code) tl[code] |= (uint8_t)(1u << t);
             }
         }
     }
@@ -338,13 +344,13 @@ int ensure_hits(bb_ctx* c, uint64_t need) {
     if ((r = grow(c, c->d_hits, cap, need))) return r;
     cap = 0;
     {
-        bool any_pfx = false;
-        for (auto& d : c->gdev) any_pfx = any_pfx || d.pfx > 0;
-        if (any_pfx) { if ((r = grow(c, c->d_pfx, cap, need))) return r; cap = 0; }
+        bool any_split = false;
+        for (auto& d : c->gdev) any_split = any_split || d.split[0] || d.split[1];
+        if (any_split) { if ((r = grow(c, c->d_pfx, cap, need))) return r; cap = 0; }
     }
     if ((r = grow(c, c->d_rows, cap, need))) return r;
     uint64_t lc = 0;
-    if ((r = grow(c, c->d_lists, lc, cap * c->groups.size() * 2))) return r;  // slot 2g: forward (or all) hits of group g, 2g+1: rc hits of a split group
+    if ((r = grow(c, c->d_lists, lc, cap * c->groups.size() * 2))) return r;  // slot 2g + strand: hits of group g on that strand
     c->cap_hits = (uint32_t)cap;
     return BB_OK;
 }
@@ -403,62 +409,63 @@ void launch_barcode_reg(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_off
 }
 
 template <int CW>
-void launch_barcode_pfx(bb_ctx* c, uint32_t n_hits, uint32_t g, const uint32_t* list, const uint32_t* cnt) {
+void launch_barcode_pfx(bb_ctx* c, uint32_t n_hits, uint32_t g, uint32_t strand, const uint32_t* list, const uint32_t* cnt) {
     const bb_group_dev& D = c->gdev[g];
     const uint32_t N = (uint32_t)D.n_seqs;
     // CW = 48 fits 168 VGPRs -> 3 waves per SIMD: 768-thread blocks (8 hits x 96 barcodes use every lane); measured
     // 22.8 vs 26.8 ms against 512-thread blocks at 2 waves per SIMD
-    const uint32_t tmax = CW <= 48 ? 768u : c->reg_threads;
+    const uint32_t tmax = CW <= 48 ? 768u : 512u;
     const uint32_t hpb = tmax / N;
     const uint32_t threads = ((hpb * N + 63) / 64) * 64;
-    const size_t smem = (size_t)2 * 16 * N * 4 + (size_t)hpb * 24 + (size_t)hpb * (sizeof(bb_hit) + sizeof(bb_hit_pfx)) + (size_t)hpb * CW * 8 + 16;
+    const size_t smem = (size_t)hpb * 24 + (size_t)hpb * (sizeof(bb_hit) + sizeof(bb_hit_pfx)) + (size_t)hpb * CW * 8 + (size_t)16 * N * 4 +
+                        (size_t)D.tail[strand] * 2 * threads * 8 + 64;
     const uint32_t n_iter = (n_hits + hpb - 1) / hpb;
     const uint32_t resident = (uint32_t)c->n_cus * (threads > 256 ? 1u : 2u) * c->reg_blocks_mult;
     const uint32_t blocks = n_iter < resident ? n_iter : resident;
-    hipLaunchKernelGGL((k_barcode_pfx<CW>), dim3(blocks), dim3(threads), smem, c->stream, (const uint8_t*)c->d_tables,
-                       (const bb_group_dev*)c->d_groups, g, (const bb_hit*)c->d_hits, (const bb_hit_pfx*)c->d_pfx, list,
-                       cnt, n_hits, hpb, c->params.min_score, c->params.min_score_diff, c->d_rows);
+#define BB_PFX_ARGS (const uint8_t*)c->d_tables, (const bb_group_dev*)c->d_groups, g, strand, (const bb_hit*)c->d_hits, (const bb_hit_pfx*)c->d_pfx, list, \
+                    cnt, n_hits, hpb, c->params.min_score, c->params.min_score_diff, c->d_rows
+    if (D.tail[strand] > 0) hipLaunchKernelGGL((k_barcode_pfx<CW, true>), dim3(blocks), dim3(threads), smem, c->stream, BB_PFX_ARGS);
+    else hipLaunchKernelGGL((k_barcode_pfx<CW, false>), dim3(blocks), dim3(threads), smem, c->stream, BB_PFX_ARGS);
+#undef BB_PFX_ARGS
 }
 
+// Barcode stage of one query group: the hits of each strand come from their own list (k_hit_lists, slot 2g + strand).
+// The kernels index list_cnt with g; handing them list_cnt + (slot - g) makes that the slot's counter.
 template <int WB>
 void launch_barcode(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n_hits, uint32_t g) {
     const bb_group_dev& D = c->gdev[g];
     const bb_group_info& I = c->groups[g].info;
     const uint32_t N = (uint32_t)D.n_seqs;
-    // hit lists: slot 2g = forward (or all) hits of the group, slot 2g+1 = rc hits of a shared-prefix group.
-    // The kernels index list_cnt with g; handing them list_cnt + (slot - g) makes that the slot's counter.
-    const uint32_t* list = c->use_lists ? c->d_lists + (size_t)(2 * g) * c->cap_hits : nullptr;
-    const uint32_t* list_rc = c->use_lists ? c->d_lists + (size_t)(2 * g + 1) * c->cap_hits : nullptr;
-    const uint32_t* cnt = c->d_listcnt + g, *cnt_rc = c->d_listcnt + g + 1;
     // widest barcode window the flank traceback can produce: (mask_len - 1 + flank_k) + 2*PADDING
     const uint32_t win_max = I.mask_len + (uint32_t)I.flank_k + 2 * BB_PADDING - 1;
     const size_t peq_bytes = (size_t)2 * 16 * N * WB * 4;
     const bool reg_ok = !c->force_generic && D.m_bar <= 48 && N <= c->reg_threads && peq_bytes <= 48 * 1024 && win_max <= 64;
-    if (reg_ok && WB == 2 && D.pfx > 0) {  // shared-prefix split: forward hits with one word per barcode lane, rc hits as before
-        if (win_max <= 48) { launch_barcode_pfx<48>(c, n_hits, g, list, cnt); launch_barcode_reg<WB, 48>(c, d_bases, d_offsets, n_hits, g, list_rc, cnt_rc); }
-        else { launch_barcode_pfx<64>(c, n_hits, g, list, cnt); launch_barcode_reg<WB, 64>(c, d_bases, d_offsets, n_hits, g, list_rc, cnt_rc); }
-        return;
-    }
-    if (reg_ok) {
-        if (win_max <= 48) launch_barcode_reg<WB, 48>(c, d_bases, d_offsets, n_hits, g, list, cnt);
-        else launch_barcode_reg<WB, 64>(c, d_bases, d_offsets, n_hits, g, list, cnt);
-        return;
-    }
-    const uint32_t hpb = N >= 256 ? 1 : 256 / N;
-    const uint32_t threads = ((hpb * N + 63) / 64) * 64;
-    const bool lds = peq_bytes <= 48 * 1024;
-    const size_t smem = (lds ? peq_bytes : 0) + (size_t)hpb * N * 8 + (size_t)hpb * 16 + (size_t)hpb * BB_MAX_WIN;
-    const uint32_t blocks = (n_hits + hpb - 1) / hpb;
-    for (int cls = 0; cls < (D.pfx > 0 ? 2 : 1); ++cls) {  // a split group has its rc hits in the second list
-        const uint32_t* l = cls ? list_rc : list;
-        const uint32_t* lc = cls ? cnt_rc : cnt;
+    for (uint32_t strand = 0; strand < 2; ++strand) {
+        const uint32_t slot = 2 * g + strand;
+        const uint32_t* list = c->d_lists + (size_t)slot * c->cap_hits;
+        const uint32_t* cnt = c->d_listcnt + slot - g;
+        if (!c->force_generic && WB == 2 && D.split[strand] && win_max <= 64) {  // one word per barcode lane
+            if (win_max <= 48) launch_barcode_pfx<48>(c, n_hits, g, strand, list, cnt);
+            else launch_barcode_pfx<64>(c, n_hits, g, strand, list, cnt);
+            continue;
+        }
+        if (reg_ok) {
+            if (win_max <= 48) launch_barcode_reg<WB, 48>(c, d_bases, d_offsets, n_hits, g, list, cnt);
+            else launch_barcode_reg<WB, 64>(c, d_bases, d_offsets, n_hits, g, list, cnt);
+            continue;
+        }
+        const uint32_t hpb = N >= 256 ? 1 : 256 / N;
+        const uint32_t threads = ((hpb * N + 63) / 64) * 64;
+        const bool lds = peq_bytes <= 48 * 1024;
+        const size_t smem = (lds ? peq_bytes : 0) + (size_t)hpb * N * 8 + (size_t)hpb * 16 + (size_t)hpb * BB_MAX_WIN;
+        const uint32_t blocks = (n_hits + hpb - 1) / hpb;
         if (lds)
             hipLaunchKernelGGL((k_barcode<WB, true>), dim3(blocks), dim3(threads), smem, c->stream, d_bases, d_offsets,
-                               (const uint8_t*)c->d_tables, (const bb_group_dev*)c->d_groups, g, (const bb_hit*)c->d_hits, l, lc, n_hits, hpb,
+                               (const uint8_t*)c->d_tables, (const bb_group_dev*)c->d_groups, g, (const bb_hit*)c->d_hits, list, cnt, n_hits, hpb,
                                c->params.min_score, c->params.min_score_diff, c->d_rows);
         else
             hipLaunchKernelGGL((k_barcode<WB, false>), dim3(blocks), dim3(threads), smem, c->stream, d_bases, d_offsets,
-                               (const uint8_t*)c->d_tables, (const bb_group_dev*)c->d_groups, g, (const bb_hit*)c->d_hits, l, lc, n_hits, hpb,
+                               (const uint8_t*)c->d_tables, (const bb_group_dev*)c->d_groups, g, (const bb_hit*)c->d_hits, list, cnt, n_hits, hpb,
                                c->params.min_score, c->params.min_score_diff, c->d_rows);
     }
 }
@@ -606,17 +613,17 @@ int bb_annotate_batch_dev(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_o
         HIPCHK(c, hipGetLastError());
     }
     mark(c, K_LISTS);
-    bool any_pfx = false;
-    for (uint32_t g = 0; g < G; ++g) any_pfx = any_pfx || c->gdev[g].pfx > 0;
-    c->use_lists = G > 1 || any_pfx;
-    if (n_hits && c->use_lists) {
+    bool any_split = false;
+    for (uint32_t g = 0; g < G; ++g) any_split = any_split || c->gdev[g].split[0] || c->gdev[g].split[1];
+    c->use_lists = true;  // one list per (group, strand)
+    if (n_hits) {
         HIPCHK(c, hipMemsetAsync(c->d_listcnt, 0, sizeof(uint32_t) * 2 * BB_MAX_GROUPS, c->stream));
         hipLaunchKernelGGL(k_hit_lists, dim3((n_hits + 255) / 256), dim3(256), 0, c->stream, (const bb_hit*)c->d_hits, n_hits,
                            c->d_rows, c->d_lists, c->cap_hits, c->d_listcnt, G, (const bb_group_dev*)c->d_groups);
     }
     mark(c, K_BARCODE);
     if (n_hits) {
-        if (any_pfx)  // shared rows of the padded barcodes, once per hit
+        if (any_split)  // shared rows of the padded barcodes, once per hit
             hipLaunchKernelGGL(k_bar_prefix, dim3((n_hits + 127) / 128), dim3(128), 0, c->stream, (const uint8_t*)c->d_tables,
                                (const bb_group_dev*)c->d_groups, (const bb_hit*)c->d_hits, n_hits, c->d_pfx);
         for (uint32_t g = 0; g < G; ++g) {

@@ -70,19 +70,28 @@ struct bb_group_dev {
     uint32_t off_pcode[2];       // [strand] m bytes: flank base sets (fwd, complemented)
     uint32_t off_peq_bar[2];     // [strand] [16 codes][n_seqs] x WB words
     uint32_t off_lut;            // 256 bytes: read byte -> 4-bit base set (bb_text_code)
-    // shared-prefix split of the padded barcodes (k_barcode_pfx): the first `pfx` rows (left pad) are the same
-    // for every barcode of the group, the remaining m_bar - pfx <= 32 rows fit one word per lane.  0 = not used.
-    int32_t pfx;
-    uint32_t off_peq_pfx[2];     // [strand] 16 words: Peq of the shared rows
-    uint32_t off_peq_sub[2];     // [strand] [16 codes][n_seqs] words: Peq of rows pfx..m_bar-1
+    // Row split of the padded barcodes (k_barcode_pfx), per strand (the rc patterns are the reverse complements, so
+    // their leading rows are the forward patterns' trailing ones): the first pfx[s] rows and the last tail[s] rows are
+    // the same for every barcode of the group, the 32 rows between them fit one word per barcode lane.
+    //   rows 1..pfx            computed once per hit, column-wise (k_bar_prefix)
+    //   rows pfx+1..pfx+32     one Myers word per (hit, barcode) lane
+    //   last tail rows         row-wise (bit-vectors along the window's columns) per lane after the forward pass
+    int32_t split[2];            // [strand] 1: hits of this strand take the split kernel
+    int32_t pfx[2];              // 0..16
+    int32_t tail[2];             // 0..BB_MAX_TAIL
+    uint32_t off_peq_pfx[2];     // [strand] 16 words: Peq of the leading shared rows
+    uint32_t off_peq_sub[2];     // [strand] [16 codes][n_seqs] words: Peq of rows pfx..pfx+31
+    uint32_t off_tail_lut[2];    // [strand] 16 bytes: bit t of byte[code] = trailing row t matches base set `code`
 };
 
+#define BB_MAX_TAIL 4
 // per-hit output of k_bar_prefix: what the lanes of k_barcode_pfx need of the shared rows
 struct __attribute__((aligned(16))) bb_hit_pfx {
     uint64_t ph, mh;             // bit c: horizontal +1 / -1 delta of row pfx at window column c (carry into row pfx+1)
+    uint64_t teq[BB_MAX_TAIL];   // bit c: trailing row t matches the window's column c
     uint32_t sh[64];             // per column: move bit planes of rows 1..pfx, row r <-> bit pfx-r; lo plane | hi plane << 16
 };
-static_assert(sizeof(bb_hit_pfx) == 272, "bb_hit_pfx: 17 x 16 bytes");
+static_assert(sizeof(bb_hit_pfx) == 304, "bb_hit_pfx: 19 x 16 bytes");
 
 BB_HD int bb_peq_stride_words(int W) { return W <= 2 ? 2 : 4; }
 

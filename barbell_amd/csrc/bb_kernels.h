@@ -1297,34 +1297,49 @@ __global__ __launch_bounds__(128) void k_bar_prefix(const uint8_t* __restrict__ 
     if (t < nb) {
         const uint32_t ws = rec[3], we = rec[4], grp = (rec[5] >> 16) & 0xFFu, strand = rec[5] >> 24, valid = rec[6] & 0xFFu;
         const bb_group_dev& G = groups[grp];
-        const int P = G.pfx;
         const int32_t wn = (int32_t)(we - ws);
-        if (valid && P > 0 && strand == 0 && wn <= 64) {  // rc hits and wide windows do not use the split
+        if (valid && G.split[strand & 1u] && wn <= 64) {  // wide windows do not use the split
             did = true;
-            const uint32_t* peq = reinterpret_cast<const uint32_t*>(tables + G.off_peq_pfx[0]);
+            const int P = G.pfx[strand & 1u], T = G.tail[strand & 1u];
+            constexpr int SH0 = 4 + 2 * BB_MAX_TAIL;  // word index of sh[0] in the record
+            const uint32_t* peq = reinterpret_cast<const uint32_t*>(tables + G.off_peq_pfx[strand & 1u]);
+            const uint32_t* tlut = reinterpret_cast<const uint32_t*>(tables + G.off_tail_lut[strand & 1u]);
             uint32_t eqt[16];
 #pragma unroll
             for (int i = 0; i < 16; ++i) eqt[i] = peq[i];
-            uint32_t pv = (1u << P) - 1u, mv = 0u;
-            unsigned long long PH = 0ull, MH = 0ull;
+            const uint32_t tl0 = tlut[0], tl1 = tlut[1], tl2 = tlut[2], tl3 = tlut[3];  // 16 bytes: trailing rows matched per code
+            uint32_t pv = P ? (P >= 32 ? 0xFFFFFFFFu : (1u << P) - 1u) : 0u, mv = 0u;
+            unsigned long long PH = 0ull, MH = 0ull, TE[BB_MAX_TAIL];
+#pragma unroll
+            for (int q = 0; q < BB_MAX_TAIL; ++q) TE[q] = 0ull;
             for (int c = 0; c < wn; ++c) {
                 const uint32_t code = (rec[8 + (c >> 2)] >> (8 * (c & 3))) & 0xFu;
                 uint32_t eq = 0;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) eq = code == (uint32_t)i ? eqt[i] : eq;
-                const uint32_t x = eq & pv;
-                const uint32_t d0 = (((x + pv) ^ pv) | eq | mv);
-                const uint32_t ph = mv | ~(d0 | pv), mh = pv & d0;
-                PH |= (unsigned long long)((ph >> (P - 1)) & 1u) << c;
-                MH |= (unsigned long long)((mh >> (P - 1)) & 1u) << c;
-                const uint32_t isM = d0 & eq, l = ~(isM | ph), hh = (ph & ~isM) | (l & d0);
-                orow[4 + c] = (__brev(l) >> (32 - P)) | ((__brev(hh) >> (32 - P)) << 16);  // row r <-> bit P - r
-                const uint32_t phs = ph << 1, mhs = mh << 1;  // top boundary row: D[0][c] = 0, no horizontal delta
-                pv = mhs | ~(d0 | phs);
-                mv = phs & d0;
+                const uint32_t tw = (code >> 2) == 0u ? tl0 : (code >> 2) == 1u ? tl1 : (code >> 2) == 2u ? tl2 : tl3;
+                const uint32_t tb = (tw >> (8u * (code & 3u))) & 0xFFu;
+#pragma unroll
+                for (int q = 0; q < BB_MAX_TAIL; ++q) TE[q] |= (unsigned long long)((tb >> q) & 1u) << c;
+                uint32_t shw = 0u;
+                if (P > 0) {
+                    const uint32_t x = eq & pv;
+                    const uint32_t d0 = (((x + pv) ^ pv) | eq | mv);
+                    const uint32_t ph = mv | ~(d0 | pv), mh = pv & d0;
+                    PH |= (unsigned long long)((ph >> (P - 1)) & 1u) << c;
+                    MH |= (unsigned long long)((mh >> (P - 1)) & 1u) << c;
+                    const uint32_t isM = d0 & eq, l = ~(isM | ph), hh = (ph & ~isM) | (l & d0);
+                    shw = (__brev(l) >> (32 - P)) | ((__brev(hh) >> (32 - P)) << 16);  // row r <-> bit P - r
+                    const uint32_t phs = ph << 1, mhs = mh << 1;  // top boundary row: D[0][c] = 0, no horizontal delta
+                    pv = mhs | ~(d0 | phs);
+                    mv = phs & d0;
+                }
+                orow[SH0 + c] = shw;
             }
-            for (int c = wn; c < 64; ++c) orow[4 + c] = 0u;
+            for (int c = wn; c < 64; ++c) orow[SH0 + c] = 0u;
             orow[0] = (uint32_t)PH; orow[1] = (uint32_t)(PH >> 32); orow[2] = (uint32_t)MH; orow[3] = (uint32_t)(MH >> 32);
+#pragma unroll
+            for (int q = 0; q < BB_MAX_TAIL; ++q) { orow[4 + 2 * q] = q < T ? (uint32_t)TE[q] : 0u; orow[5 + 2 * q] = q < T ? (uint32_t)(TE[q] >> 32) : 0u; }
         }
     }
     if (!did) for (int i = 0; i < OW; ++i) orow[i] = 0u;
@@ -1333,9 +1348,9 @@ __global__ __launch_bounds__(128) void k_bar_prefix(const uint8_t* __restrict__ 
     for (uint32_t i = threadIdx.x; i < nb * OW; i += 128u) dst[i] = s_out[(i / OW) * OS + (i % OW)];
 }
 
-template <int CW>
+template <int CW, bool TAIL>
 __global__ __launch_bounds__(CW <= 48 ? 768 : 512) void k_barcode_pfx(const uint8_t* __restrict__ tables, const bb_group_dev* __restrict__ groups,
-                                                     uint32_t g, const bb_hit* __restrict__ hits, const bb_hit_pfx* __restrict__ pfxs,
+                                                     uint32_t g, uint32_t strand, const bb_hit* __restrict__ hits, const bb_hit_pfx* __restrict__ pfxs,
                                                      const uint32_t* __restrict__ hit_list, const uint32_t* __restrict__ list_cnt,
                                                      uint32_t n_hits_all, uint32_t hpb, double min_score, double min_score_diff,
                                                      bb_rowtmp* __restrict__ rows) {
@@ -1344,10 +1359,12 @@ __global__ __launch_bounds__(CW <= 48 ? 768 : 512) void k_barcode_pfx(const uint
     const uint32_t n_list = hit_list ? list_cnt[g] : n_hits_all;
     const uint32_t n_iter = (n_list + hpb - 1) / hpb;
     if (blockIdx.x >= n_iter) return;
-    const int N = G.n_seqs, m = G.m_bar, P = G.pfx;
-    // rows per lane: 32 — the split is made at pfx = m_bar - 32 (row P+1 <-> bit 31 of the bit-reversed planes, row m <-> bit 0)
+    const int N = G.n_seqs, m = G.m_bar, P = groups[g].pfx[strand], T = TAIL ? groups[g].tail[strand] : 0;  // scalar loads: no dynamic index into G
+    // rows per lane: 32 = m_bar - P - T (row P+1 <-> bit 31 of the bit-reversed planes, row P+32 <-> bit 0)
     constexpr int PIECES_H = (int)(sizeof(bb_hit) / 16), PIECES_P = (int)(sizeof(bb_hit_pfx) / 16), PIECES = PIECES_H + PIECES_P;
-    // LDS carve: [hit + prefix records: hpb x 368 B][max u64[hpb]][second u64[hpb]][cnt1 i32[hpb]][top i32[hpb]][peq 2*16*N words]
+    constexpr int SH_PIECE = PIECES_H + 1 + BB_MAX_TAIL / 2;  // first piece of sh[] inside a hit's record pair
+    // LDS carve: [hit + prefix records: hpb x 400 B][max u64[hpb]][second u64[hpb]][cnt1 i32[hpb]][top i32[hpb]][walk table]
+    // [peq 16*N words][move planes of the trailing rows: T x 2 x blockDim u64]
     uint4* s_hit = reinterpret_cast<uint4*>(smem);
     size_t o = (size_t)hpb * PIECES * 16;
     unsigned long long* s_max = reinterpret_cast<unsigned long long*>(smem + o);
@@ -1362,30 +1379,37 @@ __global__ __launch_bounds__(CW <= 48 ? 768 : 512) void k_barcode_pfx(const uint
     uint2* s_tab = reinterpret_cast<uint2*>(smem + o);  // [hpb][CW]: the walk through the shared rows per entry column
     o += (size_t)hpb * CW * 8;
     uint32_t* s_peq = reinterpret_cast<uint32_t*>(smem + o);
+    o += (size_t)16 * N * 4;
+    o = (o + 15) & ~(size_t)15;
+    unsigned long long* s_tail = reinterpret_cast<unsigned long long*>(smem + o);  // [t][lo|hi][thread]
     {
-        const uint32_t* gp = reinterpret_cast<const uint32_t*>(tables + G.off_peq_sub[0]);
-        const int words = 2 * 16 * N;
+        const uint32_t* gp = reinterpret_cast<const uint32_t*>(tables + groups[g].off_peq_sub[strand]);
+        const int words = 16 * N;
         for (int i = threadIdx.x; i < words; i += blockDim.x) s_peq[i] = gp[i];
     }
     const int hl = threadIdx.x / N;
     const int p = threadIdx.x - hl * N;
     const bool in_blk = hl < (int)hpb;
     const int hls = in_blk ? hl : 0;
-    // prefetch of the next iteration's records: lane p of a hit fetches piece p (hit record pieces first, then
-    // the prefix record); N >= 32 > PIECES
+    // prefetch of the next iteration's records: lane p of a hit fetches piece p (hit record pieces first, then the
+    // prefix record).  Groups with fewer barcodes than pieces (2 N >= PIECES) fetch pieces N.. at the start of the
+    // iteration instead, unprefetched — they have many hits per block iteration to hide it behind.
     uint4 pre = make_uint4(0u, 0u, 0u, 0u);
+    auto piece = [&](uint32_t idx, int pc) -> uint4 {
+        return pc < PIECES_H ? reinterpret_cast<const uint4*>(hits + idx)[pc] : reinterpret_cast<const uint4*>(pfxs + idx)[pc - PIECES_H];
+    };
     auto prefetch = [&](uint32_t it) {
         const uint32_t li = it * hpb + (uint32_t)hl;
-        if (in_blk && p < PIECES && it < n_iter && li < n_list) {
-            const uint32_t idx = hit_list ? hit_list[li] : li;
-            pre = p < PIECES_H ? reinterpret_cast<const uint4*>(hits + idx)[p] : reinterpret_cast<const uint4*>(pfxs + idx)[p - PIECES_H];
-        }
+        if (in_blk && p < PIECES && it < n_iter && li < n_list) pre = piece(hit_list ? hit_list[li] : li, p);
     };
     prefetch(blockIdx.x);
   for (uint32_t it = blockIdx.x; it < n_iter; it += gridDim.x) {
     const uint32_t li = it * hpb + (uint32_t)hl;
     const bool exists = in_blk && li < n_list;
-    if (exists && p < PIECES) s_hit[hl * PIECES + p] = pre;
+    if (exists && p < PIECES) {
+        s_hit[hl * PIECES + p] = pre;
+        if (p + N < PIECES) s_hit[hl * PIECES + p + N] = piece(hit_list ? hit_list[li] : li, p + N);
+    }
     if (in_blk && p == 0) { s_max[hl] = 0ull; s_sec[hl] = 0ull; s_cnt1[hl] = 0; s_top[hl] = 0x7FFFFFFF; }
     __syncthreads();
     const uint32_t hit_idx = hit_list ? (exists ? hit_list[li] : 0u) : li;
@@ -1398,11 +1422,11 @@ __global__ __launch_bounds__(CW <= 48 ? 768 : 512) void k_barcode_pfx(const uint
     // bit position of a cursor still alive after the 16 columns (bits 24..27, flag in bit 31: the lane then finishes
     // in a loop).
     {
-        const uint32_t pm = (1u << P) - 1u;
+        const uint32_t pm = (1u << P) - 1u;  // P <= 16
         for (uint32_t l = threadIdx.x; l < hpb * (uint32_t)CW; l += blockDim.x) {
             const uint32_t hw = l / (uint32_t)CW;
             const int32_t cxw = (int32_t)(l % (uint32_t)CW) + 1;
-            const uint32_t* shw = reinterpret_cast<const uint32_t*>(s_hit + hw * PIECES + PIECES_H + 1);
+            const uint32_t* shw = reinterpret_cast<const uint32_t*>(s_hit + hw * PIECES + SH_PIECE);
             uint32_t bh = 1u, lo2 = 0u, hi2 = 0u, dgw = 0u, n2 = 0u;
 #pragma unroll 1
             for (int i = 0; i < 16 && bh != 0u && cxw - i >= 1; ++i) {  // rolled: short, and the registers are wanted elsewhere
@@ -1432,7 +1456,7 @@ __global__ __launch_bounds__(CW <= 48 ? 768 : 512) void k_barcode_pfx(const uint
     bool active = exists && H.valid != 0;
     if (exists && !H.valid && p == 0) rows[hit_idx].row._pad[0] = 0;
     const int32_t wn = active ? (int32_t)(H.we - H.ws) : 0;
-    const uint32_t* s_sh = reinterpret_cast<const uint32_t*>(s_hit + hls * PIECES + PIECES_H + 1);  // sh[64] of the prefix record
+    const uint32_t* s_sh = reinterpret_cast<const uint32_t*>(s_hit + hls * PIECES + SH_PIECE);  // sh[64] of the prefix record
 
     int wmax = wn;
 #pragma unroll
@@ -1448,7 +1472,7 @@ __global__ __launch_bounds__(CW <= 48 ? 768 : 512) void k_barcode_pfx(const uint
         for (int q = 0; q < CW / 16; ++q) { uint4 v = s_hit[hls * PIECES + 2 + q]; wc[4 * q] = v.x; wc[4 * q + 1] = v.y; wc[4 * q + 2] = v.z; wc[4 * q + 3] = v.w; }
         const uint4 hv = s_hit[hls * PIECES + PIECES_H];  // {ph lo, ph hi, mh lo, mh hi}
         const uint32_t hin_p[2] = {hv.x, hv.y}, hin_m[2] = {hv.z, hv.w};
-        const uint32_t pb4 = ((uint32_t)((active ? H.strand : 0) * 16) * (uint32_t)N + (uint32_t)p) * 4u, N4 = (uint32_t)N * 4u;
+        const uint32_t pb4 = (uint32_t)p * 4u, N4 = (uint32_t)N * 4u;
         const uint8_t* s_peq_b = reinterpret_cast<const uint8_t*>(s_peq);
         uint32_t pv = 0xFFFFFFFFu, mv = 0u;
         // bottom-row deltas (bit 31 of ph / mh), newest column at bit 0: one v_alignbit per column and plane;
@@ -1484,8 +1508,29 @@ __global__ __launch_bounds__(CW <= 48 ? 768 : 512) void k_barcode_pfx(const uint
         up[0] = n0 ? __brev(upr[0]) >> (32 - n0) : 0u; dn[0] = n0 ? __brev(dnr[0]) >> (32 - n0) : 0u;
         up[1] = n1 ? __brev(upr[1]) >> (32 - n1) : 0u; dn[1] = n1 ? __brev(dnr[1]) >> (32 - n1) : 0u;
         const unsigned long long wmask = wn >= 64 ? ~0ull : ((1ull << wn) - 1ull);
-        const unsigned long long Pm = (((unsigned long long)up[1] << 32) | up[0]) & wmask;
-        const unsigned long long Mm = (((unsigned long long)dn[1] << 32) | dn[0]) & wmask;
+        unsigned long long Pm = (((unsigned long long)up[1] << 32) | up[0]) & wmask;   // horizontal deltas of row P+32
+        unsigned long long Mm = (((unsigned long long)dn[1] << 32) | dn[0]) & wmask;
+        // The trailing shared rows, row-wise: the same recurrence with the roles of rows and columns exchanged — bit-vectors
+        // run along the window's columns, the state is the horizontal deltas of the row above, the carry-in is the vertical
+        // delta +1 of column 0 (D[r][0] = r), Eq comes from the prefix record (the rows' characters are the same for every
+        // barcode).  ~20 64-bit operations per row and lane instead of a second word in every column step.  The rows' move
+        // planes (as column masks) are parked in LDS for the start of the traceback.
+        if constexpr (TAIL) {
+            const uint2* teq = reinterpret_cast<const uint2*>(s_hit + hls * PIECES + PIECES_H + 1);
+#pragma unroll 1
+            for (int t = 0; t < T; ++t) {
+                const uint2 e2 = teq[t];
+                const unsigned long long Eq = ((unsigned long long)e2.y << 32) | e2.x;
+                const unsigned long long D0 = (((Eq & Pm) + Pm) ^ Pm) | Eq | Mm;
+                const unsigned long long Pvv = Mm | ~(D0 | Pm), Mvv = Pm & D0;
+                const unsigned long long Pvs = (Pvv << 1) | 1ull, Mvs = Mvv << 1;
+                const unsigned long long Ph = Mvs | ~(D0 | Pvs), Mh = Pvs & D0;
+                const unsigned long long isM = D0 & Eq, tl = ~(isM | Ph), th = (Ph & ~isM) | (tl & D0);
+                s_tail[(size_t)(2 * t) * blockDim.x + threadIdx.x] = tl;
+                s_tail[(size_t)(2 * t + 1) * blockDim.x + threadIdx.x] = th;
+                Pm = Ph & wmask; Mm = Mh & wmask;
+            }
+        }
         const unsigned long long A = Mm | ~Pm;
         const unsigned long long D = (A + Mm + 1ull) ^ A ^ Mm;
         unsigned long long R = (Pm & D) | (D & (1ull << wn));
@@ -1506,9 +1551,27 @@ __global__ __launch_bounds__(CW <= 48 ? 768 : 512) void k_barcode_pfx(const uint
     // column); either way phase 2 starts with the cursor entering row P. ----
     unsigned long long plo = 0ull, phi = 0ull;
     uint32_t b = 0u, dg = 0u;
-    // the cursor enters at row m = bit 0 of the word in column best_pos: that column's bit of this mask is simply
+    // ---- phase 0: the trailing shared rows, from (row m, column best_pos) on their column masks: one step per loop
+    // iteration (Match/Sub: row and column, Ins: column, Del: row) until the cursor reaches row P+32 — typically T
+    // iterations.  Rows left over when the window's first column is passed are deleted, like everything above them. ----
+    int32_t c_ent = best_pos;   // column in which the cursor enters the lane's word
+    int32_t tr = cand ? T - 1 : -1;
+    uint32_t dgt = 0u;          // trailing rows consumed by a Match/Sub
+    while (TAIL && __any(tr >= 0 && c_ent >= 1)) {
+        const bool on = tr >= 0 && c_ent >= 1;
+        const int rr = on ? tr : 0, sh = on ? c_ent - 1 : 0;
+        const unsigned long long l64 = s_tail[(size_t)(2 * rr) * blockDim.x + threadIdx.x], h64 = s_tail[(size_t)(2 * rr + 1) * blockDim.x + threadIdx.x];
+        const uint32_t lo = (uint32_t)(l64 >> sh) & 1u, hi = (uint32_t)(h64 >> sh) & 1u;
+        const bool del = on && (lo & hi) != 0u, text = on && !del, diag = on && hi == 0u;
+        plo |= text ? (unsigned long long)lo << sh : 0ull;
+        phi |= text ? (unsigned long long)hi << sh : 0ull;
+        dgt |= diag ? 1u << rr : 0u;
+        tr -= (del || diag) ? 1 : 0;
+        c_ent -= text ? 1 : 0;
+    }
+    // the cursor enters at row P+32 = bit 0 of the word in column c_ent: that column's bit of this mask is simply
     // added in with the Del-run sum (v_add3)
-    const unsigned long long smask = (cand && best_pos >= 1) ? 1ull << (best_pos - 1) : 0ull;  // best_pos 0: nothing to walk
+    const unsigned long long smask = (cand && tr < 0 && c_ent >= 1) ? 1ull << (c_ent - 1) : 0ull;  // column 0: nothing to walk
     const uint32_t sm_w[2] = {(uint32_t)smask, (uint32_t)(smask >> 32)};
 #pragma unroll
     for (int c0 = CW; c0 >= BB_CG; c0 -= BB_CG) {
@@ -1529,7 +1592,7 @@ __global__ __launch_bounds__(CW <= 48 ? 768 : 512) void k_barcode_pfx(const uint
     }
     // Text ops of phase 1 = rows it consumed + its Ins columns.  Whichever way the cursor left the word, the
     // columns best_pos .. cx+1 carry exactly those ops: phase 2 starts at column cx = best_pos - ntext.
-    int32_t ntext = cand ? __popc(dg) + __popcll(phi & ~plo) : 0;
+    int32_t ntext = cand ? __popc(dg) + __popc(dgt) + __popcll(phi & ~plo) : 0;
     const int32_t cx = cand ? best_pos - ntext : 0;
     // ---- phase 2: the shared rows (row r <-> bit P - r): looked up in the block's walk table; a cursor still
     // alive after the table's 16 columns (more than 16 - P insertions inside the shared rows) finishes in the
@@ -1568,7 +1631,8 @@ __global__ __launch_bounds__(CW <= 48 ? 768 : 512) void k_barcode_pfx(const uint
     }
     const int32_t tstart = cand ? best_pos - ntext : 0;
     // consumed rows in natural order (row r <-> bit r-1)
-    const unsigned long long diagrow = ((unsigned long long)__brev(dg) << P) | (unsigned long long)(__brev(dgh) >> (32 - P));
+    const unsigned long long diagrow = ((unsigned long long)__brev(dg) << P) | (P ? (unsigned long long)(__brev(dgh) >> (32 - P)) : 0ull) |
+                                       ((unsigned long long)dgt << (P + 32));
     const unsigned long long delrow = cand ? (low64(m) & ~diagrow) : 0ull;
     double s_norm = -1.0;
     if (cand) {
@@ -1581,10 +1645,10 @@ __global__ __launch_bounds__(CW <= 48 ? 768 : 512) void k_barcode_pfx(const uint
   }
 }
 
-// Hit lists for the barcode kernels (needed with more than one query group or a shared-prefix group): slot 2g
-// holds the hits of group g — only the forward-strand ones when the group is split (bb_group_dev::pfx > 0),
-// its rc hits then go to slot 2g+1.  Hits whose get_matching_region was None (searcher.rs:445-449) are
-// skipped here and marked row-less.  One atomic per (block, slot): ballots + LDS.
+// Hit lists for the barcode kernels: slot 2g + s holds the hits of group g on strand s (the row split of a group —
+// bb_group_dev::pfx / tail — differs per strand, and every launch is uniform in it).  Hits whose
+// get_matching_region was None (searcher.rs:445-449) are skipped here and marked row-less.  One atomic per
+// (block, slot): ballots + LDS.
 __global__ __launch_bounds__(256) void k_hit_lists(const bb_hit* __restrict__ hits, uint32_t n_hits, bb_rowtmp* __restrict__ rows,
                                                    uint32_t* __restrict__ lists, uint32_t list_stride, uint32_t* __restrict__ list_cnt,
                                                    uint32_t n_groups, const bb_group_dev* __restrict__ groups) {
@@ -1598,7 +1662,7 @@ __global__ __launch_bounds__(256) void k_hit_lists(const bb_hit* __restrict__ hi
     const bool valid = in && vld;
     if (in && !valid) rows[t].row._pad[0] = 0;
     const unsigned lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-    const uint32_t my_slot = valid ? 2u * grp + ((groups[grp].pfx > 0 && strand) ? 1u : 0u) : 0xFFFFFFFFu;
+    const uint32_t my_slot = valid ? 2u * grp + (strand & 1u) : 0xFFFFFFFFu;
     // one atomic per (block, slot): the four waves' counts meet in LDS
     __shared__ uint32_t s_cnt[4][2 * BB_MAX_GROUPS], s_base[2 * BB_MAX_GROUPS];
     const uint32_t n_slots = 2u * n_groups;
