@@ -7,7 +7,7 @@ import os
 from . import _abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libbarbell_amd.so")
+SO_PATH = os.environ.get("BARBELL_AMD_SO") or os.path.join(_HERE, "libbarbell_amd.so")  # BARBELL_AMD_SO: an experimental build (dev knob)
 
 # every symbol include/barbell_amd.h and include/barbell_amd_synth.h declare
 EXPORTS = [

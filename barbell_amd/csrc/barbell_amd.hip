@@ -417,7 +417,7 @@ void launch_barcode_pfx(bb_ctx* c, uint32_t n_hits, uint32_t g, uint32_t strand,
     const uint32_t tmax = CW <= 48 ? 768u : 512u;
     const uint32_t hpb = tmax / N;
     const uint32_t threads = ((hpb * N + 63) / 64) * 64;
-    const size_t smem = (size_t)hpb * 24 + (size_t)hpb * (sizeof(bb_hit) + sizeof(bb_hit_pfx)) + (size_t)hpb * CW * 8 + (size_t)16 * N * 4 +
+    const size_t smem = (size_t)hpb * 24 + (size_t)hpb * (sizeof(bb_hit) + sizeof(bb_hit_pfx)) + (size_t)hpb * CW * 16 + (size_t)16 * N * 4 +
                         (size_t)D.tail[strand] * 2 * threads * 8 + 64;
     const uint32_t n_iter = (n_hits + hpb - 1) / hpb;
     const uint32_t resident = (uint32_t)c->n_cus * (threads > 256 ? 1u : 2u) * c->reg_blocks_mult;

@@ -986,7 +986,11 @@ __device__ __forceinline__ void pick_and_emit(bool active, bool cand, int32_t be
             r._pad[0] = 1; r._pad[1] = r._pad[2] = 0;
             if (valid) {
                 int32_t txt_lo, txt_hi, bcost;
+#ifdef BB_EXP_NO_SUBPATH
+                txt_lo = tstart; txt_hi = best_pos; bcost = __popcll(plo);
+#else
                 subpath_closed_form(plo, phi, diagrow, tstart, best_pos, m, rlo, rhi, txt_lo, txt_hi, bcost);
+#endif
                 r.read_start_bar = H.ws + (uint32_t)txt_lo; r.read_end_bar = H.ws + (uint32_t)txt_hi;
                 r.bar_start = H.ws + (uint32_t)rlo; r.bar_end = H.ws + (uint32_t)rhi;
                 r.match_type = (uint8_t)G.type; r.barcode_cost = (int16_t)bcost; r.barcode_idx = (int16_t)top;
@@ -1378,6 +1382,8 @@ __global__ __launch_bounds__(CW <= 48 ? 768 : 512) void k_barcode_pfx(const uint
     o = (o + 15) & ~(size_t)15;
     uint2* s_tab = reinterpret_cast<uint2*>(smem + o);  // [hpb][CW]: the walk through the shared rows per entry column
     o += (size_t)hpb * CW * 8;
+    uint2* s_col = reinterpret_cast<uint2*>(smem + o);  // [hpb][CW]: what every barcode lane of a hit needs of a column
+    o += (size_t)hpb * CW * 8;
     uint32_t* s_peq = reinterpret_cast<uint32_t*>(smem + o);
     o += (size_t)16 * N * 4;
     o = (o + 15) & ~(size_t)15;
@@ -1414,6 +1420,19 @@ __global__ __launch_bounds__(CW <= 48 ? 768 : 512) void k_barcode_pfx(const uint
     __syncthreads();
     const uint32_t hit_idx = hit_list ? (exists ? hit_list[li] : 0u) : li;
     prefetch(it + gridDim.x);
+    // Per (hit, column), once for the hit's N barcode lanes: x = byte offset of the column's base-set row in the Peq table,
+    // y = carry-in of the shared rows (bit 0: horizontal +1, bit 1: horizontal -1 of row P).  The lanes then spend one
+    // 8-byte LDS read and three full-rate operations per column instead of three bit-field extractions and a
+    // multiply-add (all half rate, profiles/valu_ceiling.json).
+    for (uint32_t l = threadIdx.x; l < hpb * (uint32_t)CW; l += blockDim.x) {
+        const uint32_t hw = l / (uint32_t)CW, c = l % (uint32_t)CW;
+        const uint32_t* rec = reinterpret_cast<const uint32_t*>(s_hit + hw * PIECES);
+        const uint32_t code = (rec[8 + (c >> 2)] >> (8u * (c & 3u))) & 0xFu;
+        const uint32_t* hv = reinterpret_cast<const uint32_t*>(s_hit + hw * PIECES + PIECES_H);  // {ph lo, ph hi, mh lo, mh hi}
+        const uint32_t hp = (hv[c >> 5] >> (c & 31u)) & 1u, hm = (hv[2 + (c >> 5)] >> (c & 31u)) & 1u;
+        s_col[l] = make_uint2(code * (uint32_t)N * 4u, hp | (hm << 1));
+    }
+    __syncthreads();
     // The walk of a traced path through the shared rows depends only on the hit and on the column in which the
     // path enters row P, not on the barcode: the first hpb * CW lanes of the block each walk one (hit, entry column)
     // once — 16 columns from independent LDS reads, static register indices — and every barcode lane later looks
@@ -1467,12 +1486,8 @@ __global__ __launch_bounds__(CW <= 48 ? 768 : 512) void k_barcode_pfx(const uint
     uint32_t L0[CW], H0[CW];
     int32_t best_cost = 0x7FFFFFFF, best_pos = -1;
     {
-        uint32_t wc[CW / 4];
-#pragma unroll
-        for (int q = 0; q < CW / 16; ++q) { uint4 v = s_hit[hls * PIECES + 2 + q]; wc[4 * q] = v.x; wc[4 * q + 1] = v.y; wc[4 * q + 2] = v.z; wc[4 * q + 3] = v.w; }
-        const uint4 hv = s_hit[hls * PIECES + PIECES_H];  // {ph lo, ph hi, mh lo, mh hi}
-        const uint32_t hin_p[2] = {hv.x, hv.y}, hin_m[2] = {hv.z, hv.w};
-        const uint32_t pb4 = (uint32_t)p * 4u, N4 = (uint32_t)N * 4u;
+        const uint2* colv = s_col + hls * CW;
+        const uint32_t pb4 = (uint32_t)p * 4u;
         const uint8_t* s_peq_b = reinterpret_cast<const uint8_t*>(s_peq);
         uint32_t pv = 0xFFFFFFFFu, mv = 0u;
         // bottom-row deltas (bit 31 of ph / mh), newest column at bit 0: one v_alignbit per column and plane;
@@ -1483,9 +1498,9 @@ __global__ __launch_bounds__(CW <= 48 ? 768 : 512) void k_barcode_pfx(const uint
             if (c0 < wmax) {  // wave-uniform
 #pragma unroll
                 for (int c = c0; c < c0 + BB_CG; ++c) {
-                    const uint32_t code = (wc[c >> 2] >> (8 * (c & 3))) & 0xFu;
-                    const uint32_t eq = *reinterpret_cast<const uint32_t*>(s_peq_b + (__umul24(code, N4) + pb4));
-                    const uint32_t hp = (hin_p[c >> 5] >> (c & 31)) & 1u, hm = (hin_m[c >> 5] >> (c & 31)) & 1u;
+                    const uint2 cv = colv[c];
+                    const uint32_t eq = *reinterpret_cast<const uint32_t*>(s_peq_b + (cv.x + pb4));
+                    const uint32_t hp = cv.y & 1u, hm = cv.y >> 1;
                     const uint32_t x = bitop3<0xC8>(eq, pv, hm);  // (eq | hm) & pv
                     const uint32_t d0 = bitop3<BB_TT_XOR_OR>(x + pv, pv, eq) | hm | mv;  // v_bitop3 + v_or3
                     const uint32_t ph = bitop3<BB_TT_OR_NOR>(mv, d0, pv), mh = pv & d0;
@@ -1573,6 +1588,15 @@ __global__ __launch_bounds__(CW <= 48 ? 768 : 512) void k_barcode_pfx(const uint
     // added in with the Del-run sum (v_add3)
     const unsigned long long smask = (cand && tr < 0 && c_ent >= 1) ? 1ull << (c_ent - 1) : 0ull;  // column 0: nothing to walk
     const uint32_t sm_w[2] = {(uint32_t)smask, (uint32_t)(smask >> 32)};
+#ifdef BB_EXP_NO_TRACE
+    { uint32_t acc = 0; for (int c = 0; c < CW; ++c) acc ^= L0[c] + H0[c]; plo = acc; dg = acc & 0xFF; }
+#else
+    // Mask arithmetic only (profiles/valu_ceiling.json: v_cmp / v_cndmask / shifts issue at half the rate of and/or/add):
+    // nb is one-hot or zero, so "the landing cell has lo" is (Lr & nb) != 0 — brought to bit 31 by negation and shifted
+    // into the column accumulators with one v_alignbit per plane (word 1: columns 33.., word 0: columns 1..32, newest
+    // column at bit 0 = its final place); a Match/Sub step is cm = nb & ~Hr (one-hot or zero): consumed rows |= cm,
+    // and the cursor moves by b = nb + cm (nb << 1 when it consumed, nb when it did not).
+    uint32_t pl_acc[2] = {0u, 0u}, ph_acc[2] = {0u, 0u};
 #pragma unroll
     for (int c0 = CW; c0 >= BB_CG; c0 -= BB_CG) {
         if (c0 - (BB_CG - 1) <= wmax) {  // wave-uniform
@@ -1580,16 +1604,19 @@ __global__ __launch_bounds__(CW <= 48 ? 768 : 512) void k_barcode_pfx(const uint
             for (int c = c0; c > c0 - BB_CG; --c) {
                 const uint32_t Lr = L0[c - 1], Hr = H0[c - 1];
                 const uint32_t Dr = Lr & Hr;
-                const uint32_t nb = (Dr + b + ((sm_w[(c - 1) >> 5] >> ((c - 1) & 31)) & 1u)) & ~Dr;
-                const bool has = nb != 0u, lo = (Lr & nb) != 0u, hi = (Hr & nb) != 0u;
-                plo |= lo ? (1ull << (c - 1)) : 0ull;
-                phi |= hi ? (1ull << (c - 1)) : 0ull;
-                const bool consume = has & !hi;
-                dg |= consume ? nb : 0u;
-                b = consume ? (nb << 1) : nb;
+                const uint32_t nb = bitop3<0x0C>(Dr, Dr + b + ((sm_w[(c - 1) >> 5] >> ((c - 1) & 31)) & 1u), 0u);  // ~Dr & sum
+                const uint32_t tl = Lr & nb, th = Hr & nb;
+                const uint32_t cm = bitop3<0x0C>(Hr, nb, 0u);  // ~Hr & nb
+                pl_acc[(c - 1) >> 5] = __builtin_amdgcn_alignbit(pl_acc[(c - 1) >> 5], 0u - tl, 31);
+                ph_acc[(c - 1) >> 5] = __builtin_amdgcn_alignbit(ph_acc[(c - 1) >> 5], 0u - th, 31);
+                dg |= cm;
+                b = nb + cm;
             }
         }
     }
+    plo |= ((unsigned long long)pl_acc[1] << 32) | pl_acc[0];
+    phi |= ((unsigned long long)ph_acc[1] << 32) | ph_acc[0];
+#endif
     // Text ops of phase 1 = rows it consumed + its Ins columns.  Whichever way the cursor left the word, the
     // columns best_pos .. cx+1 carry exactly those ops: phase 2 starts at column cx = best_pos - ntext.
     int32_t ntext = cand ? __popc(dg) + __popc(dgt) + __popcll(phi & ~plo) : 0;
@@ -1635,10 +1662,14 @@ __global__ __launch_bounds__(CW <= 48 ? 768 : 512) void k_barcode_pfx(const uint
                                        ((unsigned long long)dgt << (P + 32));
     const unsigned long long delrow = cand ? (low64(m) & ~diagrow) : 0ull;
     double s_norm = -1.0;
+#ifdef BB_EXP_NO_REPLAY
+    if (cand) s_norm = (double)(__popcll(plo) + best_cost) * 0.01;
+#else
     if (cand) {
         const double sc = lodhi_replay<CW>(plo, phi, delrow, tstart, best_pos, wmax);
         s_norm = G.perfect > 0.0 ? sc / G.perfect : 0.0;
     } else (void)lodhi_replay<CW>(0ull, 0ull, 0ull, 0, 0, wmax);  // the loop is wave-uniform: idle lanes walk it with empty masks
+#endif
     pick_and_emit(active, cand, best_cost, s_norm, p, hl, H, hit_idx, G, plo, phi, diagrow, tstart, best_pos, s_cnt1, s_max, s_sec, s_top,
                   min_score, min_score_diff, rows);
     __syncthreads();

@@ -44,6 +44,7 @@ def main():
     ap.add_argument("--read-len", type=int, default=4000)
     ap.add_argument("--config", default="nbd96", choices=["nbd96", "dual", "rbk24", "rbk96x"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N>1 (nccl = RCCL over xGMI; gloo only for single-GPU dry runs)")
@@ -160,12 +161,68 @@ def main():
             out["trim_step"] = trim_leg(dm, d_rows, d_v, int(rows_per_launch), d_bases.data_ptr() + ((args.steps - 1) % n_batches) * batch * L,
                                         d_off_b, batch, L, dev)
             out["ingest_step"] = ingest_leg(dm, d_bases.data_ptr() + ((args.steps - 1) % n_batches) * batch * L, batch, L, dev)
+        if world == 1 and args.config == "nbd96" and not args.no_other_configs:
+            # BASELINE configs[3] / configs[4] (driver-run numbers for the other query geometries; `value` stays configs[1])
+            out["other_configs"] = {c: other_config_leg(c, dev_idx, dev, L, args) for c in ("dual", "rbk96x")}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, groups, dm, d_bases, L, batch, (args.steps - 1) % n_batches, d_rows, last_rows)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def other_config_leg(cfg, dev_idx, dev, L, args, n=1_000_000, steps=3):
+    """One of the other BASELINE query sets on its own resident reads: `dual` = configs[3] (native_left/right.fasta,
+    --flank-max-errors 5, two groups), `rbk96x` = configs[4] made meaningful (SQK-RBK114-96 --use-extended: two groups,
+    90-nt flanks, automatic cutoff; --use-extended is a no-op for SQK-NBD114-96).  n reads x L resident, one batch,
+    `steps` timed passes; a sample of the rows is compared with the oracle."""
+    from barbell_amd import _abi
+    from barbell_amd import annotate as A
+    from oracle import pyoracle as po
+    from tests.common import config_groups
+
+    groups = config_groups(cfg)
+    dm = A.Demuxer(device=dev_idx)
+    for g in groups:
+        dm.add_query_group(g)
+    seed = 0xBA7BE11 ^ {"dual": 4, "rbk96x": 5}[cfg]
+    d_off = torch.arange(0, n + 1, dtype=torch.int64, device=dev) * L
+    d_bases = torch.empty(n * L, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    dm.synth_dev(seed, L, L, 0, n, d_off.data_ptr(), d_bases.data_ptr())
+    cap = 6 * n
+    d_rows = torch.empty(cap * 48, dtype=torch.uint8, device=dev)
+    nr = dm.demux_dev(d_bases.data_ptr(), d_off.data_ptr(), n, d_rows.data_ptr(), cap)  # warm-up
+    dm.set_timing(True)
+    kms = {}
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        nr = dm.demux_dev(d_bases.data_ptr(), d_off.data_ptr(), n, d_rows.data_ptr(), cap)
+        for k, v in dm.kernel_ms().items():
+            kms[k] = kms.get(k, 0.0) + v / steps
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    dom = max(kms, key=kms.get)
+    out = {"reads_per_s": n / dt, "ms_per_step": dt * 1e3, "reads": n, "read_len": L, "steps": steps, "rows_per_step": nr, "groups": len(groups),
+           "dominant_kernel": dom, "dominant_kernel_ms": kms[dom], "kernel_ms_per_step": kms}
+    if not args.no_cpu_baseline:
+        cores = os.cpu_count() or 1
+        w = 4096 if cfg == "dual" else 2048
+        full = np.frombuffer(d_rows[: nr * 48].cpu().numpy().tobytes(), dtype=_abi.ROW_DTYPE)
+        orc = po.Oracle([g.as_tuple() for g in groups])
+        ok, rows = True, 0
+        for first in (0, n - w):
+            want = orc.annotate(d_bases[first * L: (first + w) * L].cpu().numpy(), np.arange(w + 1, dtype=np.uint64) * np.uint64(L), n_threads=cores)
+            got = full[(full["read_idx"] >= first) & (full["read_idx"] < first + w)].copy()
+            got["read_idx"] -= first
+            ok = ok and got.tobytes() == want.tobytes()
+            rows += len(want)
+        out["parity_on_sample"] = bool(ok)
+        out["sample"] = f"first and last {w} reads of the batch against the CPU oracle ({rows} rows)"
+    dm.close()
+    return out
 
 
 def filter_leg(dm, d_rows, n_rows, dev):
