@@ -34,9 +34,32 @@ __device__ __forceinline__ uint32_t bitop3(uint32_t a, uint32_t b, uint32_t c) {
 #define BB_TT_XOR_OR 0xBE    /* (a ^ b) | c   */
 #define BB_TT_OR_NOR 0xF1    /* a | ~(b | c)  */
 
+// 64-bit shift by one in ONE instruction (v_lshlrev_b64, half rate like v_lshlrev_b32 / v_alignbit_b32 — measured in
+// profiles/valu_ceiling.json — but it does both words); left to itself the compiler splits it into lshl + alignbit
+__device__ __forceinline__ unsigned long long shl1_64(unsigned long long x) {
+    unsigned long long r;
+    asm("v_lshlrev_b64 %0, 1, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+#ifndef BB_MYERS64
+#define BB_MYERS64 1  // two-word step: carry chain as one 64-bit add (v_lshl_add_u64), the two shifts as v_lshlrev_b64
+#endif
 template <int W>
 __device__ __forceinline__ void myers_step(uint32_t (&pv)[W], uint32_t (&mv)[W], const uint32_t (&eq)[W],
                                            uint32_t (&d0)[W], uint32_t (&ph)[W], uint32_t (&mh)[W]) {
+    if constexpr (W == 2 && BB_MYERS64) {
+        const unsigned long long x = ((unsigned long long)(eq[1] & pv[1]) << 32) | (eq[0] & pv[0]);
+        const unsigned long long s = x + (((unsigned long long)pv[1] << 32) | pv[0]);
+        d0[0] = bitop3<BB_TT_XOR_OR>((uint32_t)s, pv[0], eq[0]) | mv[0];
+        d0[1] = bitop3<BB_TT_XOR_OR>((uint32_t)(s >> 32), pv[1], eq[1]) | mv[1];
+        ph[0] = bitop3<BB_TT_OR_NOR>(mv[0], d0[0], pv[0]); ph[1] = bitop3<BB_TT_OR_NOR>(mv[1], d0[1], pv[1]);
+        mh[0] = pv[0] & d0[0]; mh[1] = pv[1] & d0[1];
+        const unsigned long long phs = shl1_64(((unsigned long long)ph[1] << 32) | ph[0]);
+        const unsigned long long mhs = shl1_64(((unsigned long long)mh[1] << 32) | mh[0]);
+        pv[0] = bitop3<BB_TT_OR_NOR>((uint32_t)mhs, d0[0], (uint32_t)phs); pv[1] = bitop3<BB_TT_OR_NOR>((uint32_t)(mhs >> 32), d0[1], (uint32_t)(phs >> 32));
+        mv[0] = (uint32_t)phs & d0[0]; mv[1] = (uint32_t)(phs >> 32) & d0[1];
+        return;
+    }
     uint32_t carry = 0;
 #pragma unroll
     for (int w = 0; w < W; ++w) {
@@ -262,6 +285,9 @@ struct hit_buf {
         ST.prev = cur_;                                                                         \
     } while (0)
 
+#ifndef BB_SCAN_UNALIGNED
+#define BB_SCAN_UNALIGNED 1
+#endif
 #ifndef BB_SCAN_LQ
 #define BB_SCAN_LQ 8u  // 16-byte pieces per streamed line: 8 = 128-byte lines (8 KB of LDS per wave), 4 = 64-byte lines
 #endif
@@ -323,9 +349,14 @@ __device__ __forceinline__ void flank_scan_lane(const uint8_t* __restrict__ base
     const uint64_t a0 = (uint64_t)(uintptr_t)rb;
     uint32_t head, nlines;
     constexpr uint32_t LB = BB_SCAN_LQ * 16u, LSH = BB_SCAN_LQ == 8 ? 7u : 6u;  // line bytes (128 or 64)
+#if BB_SCAN_UNALIGNED
+    (void)a0;
+    head = 0u;  // lines start at the read's first (last) byte whatever its alignment: no per-lane head loop
+#else
     if (STRAND == 0) head = (uint32_t)((LB - (uint32_t)(a0 & (LB - 1u))) & (LB - 1u));
     else head = (uint32_t)((a0 + n) & (LB - 1u));
     if (head > n) head = n;
+#endif
     nlines = (n - head) >> LSH;
     const uint32_t tail = n - head - (nlines << LSH);
 
