@@ -20,6 +20,7 @@ EXPORTS = [
     "bb_dev_malloc", "bb_dev_free", "bb_dev_download", "bb_dev_upload", "bb_host_malloc", "bb_host_free",
     "bb_fastq_ingest", "bb_fastq_ingest_dev", "bb_fastq_fetch", "bb_fastq_last_ms",
     "bb_trim_set", "bb_trim_batch", "bb_trim_batch_dev", "bb_trim_last_ms",
+    "bb_format_set_labels", "bb_format_rows_dev",
 ]
 
 _lib = None
@@ -98,5 +99,7 @@ def lib():
     L.bb_trim_batch_dev.argtypes = trim_args
     L.bb_trim_last_ms.restype = C.c_float
     L.bb_trim_last_ms.argtypes = [vp, C.c_int]
+    L.bb_format_set_labels.argtypes = [vp, vp, vp]
+    L.bb_format_rows_dev.argtypes = [vp, vp, vp, u64, C.c_int, vp, vp, u64, vp, vp]
     _lib = L
     return L

@@ -306,40 +306,45 @@ def annotate(read_files, out_file, query_groups, alpha=0.4, min_score=0.2, min_s
         writers = LabelWriters(trim_folder, trim_config, trimmer.tables)
     insp = inspector(dm) if inspector is not None else None
     total = found = 0
-    outs = {"anno": open(out_file, "w"),
-            "kept": open(filtered_file, "w") if (flt and filtered_file) else None,
-            "dropped": open(dropped_file, "w") if (flt and dropped_file) else None}
+    outs = {"anno": open(out_file, "wb"),
+            "kept": open(filtered_file, "wb") if (flt and filtered_file) else None,
+            "dropped": open(dropped_file, "wb") if (flt and dropped_file) else None}
     wrote = {k: False for k in outs}
 
-    def emit(key, lines):
+    from . import fastq as Q
+
+    from .format import FMT_DROPPED, FMT_KEPT, RowFormatter
+
+    fmt = RowFormatter(dm, query_groups)
+    need_ids = insp is not None or trimmer is not None
+
+    def emit_bytes(key, text):
         f = outs[key]
-        if f is None or not lines:
+        if f is None or not text:
             return
         if not wrote[key]:  # csv writer emits the header with the first record only
-            f.write(TSV_HEADER + "\n")
+            f.write((TSV_HEADER + "\n").encode())
             wrote[key] = True
-        f.write("\n".join(lines) + "\n")
-
-    from . import fastq as Q
+        f.write(text)
 
     def process(info, batch):
         nonlocal total, found
         n = int(info.n_records)
-        ids = Q.read_ids(Q.fetch(dm, info))
         rows = dm.demux_ingested(batch, n)
         total += n
         found += len(np.unique(rows["read_idx"]))
-        emit("anno", format_rows(rows, ids, query_groups))
         d_rows = dm.buf("rows").ptr
+        emit_bytes("anno", fmt.render(d_rows, len(rows), batch)[0])  # the TSV lines are rendered on the GPU
+        ids = Q.read_ids(Q.fetch(dm, info)) if need_ids else None
         if insp is not None:
             insp.add(rows, ids, d_rows=d_rows)
         if flt is not None:
-            v = flt.verdicts_ingested(d_rows, len(rows))
-            keep = v["pass"] == 1
-            emit("kept", format_rows(rows[keep], ids, query_groups, v[keep]))
-            emit("dropped", format_rows(rows[~keep], ids, query_groups, v[~keep]))
+            flt.verdicts_ingested(d_rows, len(rows), download=trimmer is not None)
+            d_v = dm.buf("verdicts").ptr
+            emit_bytes("kept", fmt.render(d_rows, len(rows), batch, FMT_KEPT, d_v)[0])
+            emit_bytes("dropped", fmt.render(d_rows, len(rows), batch, FMT_DROPPED, d_v)[0])
             if trimmer is not None:
-                writers.write(trimmer.trim_ingested(d_rows, dm.buf("verdicts").ptr, len(rows), batch, info), ids)
+                writers.write(trimmer.trim_ingested(d_rows, d_v, len(rows), batch, info), ids)
 
     try:
         for info, batch in Q.batches(dm, read_files, batch_reads * 4096 if batch_reads else block_bytes):

@@ -156,6 +156,8 @@ struct bb_ctx {
     bb_trim_state* trim = nullptr;
     // FASTQ ingest, owned by bb_fastq.hip
     bb_fastq_state* fastq = nullptr;
+    // TSV renderer, owned by bb_format.hip
+    bb_format_state* format = nullptr;
     // synth
     uint8_t* d_synth_table = nullptr;
     bb_synth_params synth{};
@@ -542,6 +544,7 @@ void bb_destroy(bb_ctx* c) {
         if (p) (void)hipFree(p);
     bb_trim_state_free(c->trim);
     bb_fastq_state_free(c->fastq);
+    bb_format_state_free(c->format);
     for (int i = 0; i <= K_COUNT; ++i)
         if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -1002,6 +1005,6 @@ int bb_synth_reads_dev(bb_ctx* c, uint64_t seed, uint32_t len_min, uint32_t len_
 }  // extern "C"
 
 bb_ctx_view bb_ctx_get_view(bb_ctx* c) {
-    return bb_ctx_view{c->device, c->stream, (const bb_group_dev*)c->d_groups, (const uint32_t*)c->d_flabel_ids, &c->last_error, &c->trim, &c->fastq};
+    return bb_ctx_view{c->device, c->stream, (const bb_group_dev*)c->d_groups, (const uint32_t*)c->d_flabel_ids, &c->last_error, &c->trim, &c->fastq, &c->format};
 }
 

@@ -8,6 +8,7 @@
 
 struct bb_trim_state;
 struct bb_fastq_state;
+struct bb_format_state;
 struct bb_ctx_view {
     int device;
     hipStream_t stream;
@@ -16,7 +17,9 @@ struct bb_ctx_view {
     std::string* last_error;
     bb_trim_state** trim;
     bb_fastq_state** fastq;
+    bb_format_state** format;
 };
 bb_ctx_view bb_ctx_get_view(bb_ctx* ctx);
 void bb_trim_state_free(bb_trim_state* s);
 void bb_fastq_state_free(bb_fastq_state* s);
+void bb_format_state_free(bb_format_state* s);

@@ -41,6 +41,13 @@ __device__ __forceinline__ unsigned long long shl1_64(unsigned long long x) {
     asm("v_lshlrev_b64 %0, 1, %1" : "=v"(r) : "v"(x));
     return r;
 }
+// 64-bit add in ONE instruction without the carry flag (the compiler's v_add_co / v_addc pair needs a wait state between
+// its halves on gfx950 and both are half rate)
+__device__ __forceinline__ unsigned long long add_64(unsigned long long x, unsigned long long y) {
+    unsigned long long r;
+    asm("v_lshl_add_u64 %0, %1, 0, %2" : "=v"(r) : "v"(x), "v"(y));
+    return r;
+}
 #ifndef BB_MYERS64
 #define BB_MYERS64 1  // two-word step: carry chain as one 64-bit add (v_lshl_add_u64), the two shifts as v_lshlrev_b64
 #endif
@@ -49,7 +56,7 @@ __device__ __forceinline__ void myers_step(uint32_t (&pv)[W], uint32_t (&mv)[W],
                                            uint32_t (&d0)[W], uint32_t (&ph)[W], uint32_t (&mh)[W]) {
     if constexpr (W == 2 && BB_MYERS64) {
         const unsigned long long x = ((unsigned long long)(eq[1] & pv[1]) << 32) | (eq[0] & pv[0]);
-        const unsigned long long s = x + (((unsigned long long)pv[1] << 32) | pv[0]);
+        const unsigned long long s = add_64(x, ((unsigned long long)pv[1] << 32) | pv[0]);
         d0[0] = bitop3<BB_TT_XOR_OR>((uint32_t)s, pv[0], eq[0]) | mv[0];
         d0[1] = bitop3<BB_TT_XOR_OR>((uint32_t)(s >> 32), pv[1], eq[1]) | mv[1];
         ph[0] = bitop3<BB_TT_OR_NOR>(mv[0], d0[0], pv[0]); ph[1] = bitop3<BB_TT_OR_NOR>(mv[1], d0[1], pv[1]);

@@ -234,15 +234,17 @@ class Filter:
             self.dm._check(lib().bb_filter_rows(self.dm._ctx(), rows.ctypes.data, len(rows), out.ctypes.data))
         return out
 
-    def verdicts_ingested(self, d_rows, n_rows):
-        """verdicts for rows already in HBM; they stay in the demuxer's "verdicts" buffer, a host copy is returned"""
+    def verdicts_ingested(self, d_rows, n_rows, download=True):
+        """verdicts for rows already in HBM; they stay in the demuxer's "verdicts" buffer, a host copy is returned
+        (unless download=False: the TSV renderer and the trim step read them where they are)"""
         from ._lib import lib
 
-        out = np.zeros(n_rows, dtype=VERDICT_DTYPE)
+        out = np.zeros(n_rows if download else 0, dtype=VERDICT_DTYPE)
         d = self.dm.buf("verdicts").ensure((n_rows + 1) * 16)
         if n_rows:
             self.dm._check(lib().bb_filter_rows_dev(self.dm._ctx(), d_rows, n_rows, d))
-            self.dm.buf("verdicts").download(out)
+            if download:
+                self.dm.buf("verdicts").download(out)
         return out
 
     def verdicts_dev(self, d_rows, n_rows, d_out):

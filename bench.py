@@ -150,10 +150,7 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": kavg[dom],
                          "traffic_all_kernels_per_step": traffic_all, "traffic_source": traffic_src},
             "kernel_ms_per_step": kavg,
-            "compute": {"flank_gcups": cells_flank / (kavg.get("k_flank_scan", 0.0) * 1e-3 + 1e-12) / 1e9,
-                        "int_valu_peak_lane_ops_per_s": 256 * 4 * 16 * 2.4e9,
-                        "note": "integer VALU issue bound (bit-parallel Myers; one wave64 VALU op per 4 cycles per SIMD); "
-                                "no MFMA. PMC instruction counts: profiles/"},
+            "compute": compute_section(args, kavg, cells_flank, batch, L),
             "histogram_total": int(hist.sum().item()),
         }
         if args.config == "nbd96":
@@ -327,6 +324,38 @@ def _view_u8(ptr, n, dev):
     a = _A()
     a.__cuda_array_interface__ = {"shape": (n,), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
     return torch.as_tensor(a, device=dev)
+
+
+def compute_section(args, kavg, cells_flank, batch, L):
+    """What actually bounds the path: integer VALU issue.  Ceilings are MEASURED (tools/valu_ceiling.hip ->
+    profiles/valu_ceiling.json: G wave64-instructions/s of the whole chip per instruction class, 1-8 waves per SIMD);
+    per-kernel VALU instruction counts per launch come from the committed SQ counter passes (tools/profile_round.sh ->
+    tools/collect_valu.py -> profiles/valu_<config>.json; they cannot be counted live).  valu_issue_frac = achieved
+    wave-instructions/s over the ceiling of the class mix's two ends: a kernel of only full-rate instructions could reach
+    the first, one of only half-rate instructions the second."""
+    out = {"flank_gcups": cells_flank / (kavg.get("k_flank_scan", 0.0) * 1e-3 + 1e-12) / 1e9,
+           "note": "integer VALU issue bound (bit-parallel Myers); no MFMA. Ceilings measured per instruction class: profiles/valu_ceiling.json"}
+    try:
+        ceil = json.load(open(os.path.join(ROOT, "profiles", "valu_ceiling.json")))
+        peak = lambda k: max(x["G"] for x in ceil["classes"][k]["ind"].values())
+        full, half = peak("v_add_u32"), peak("v_lshl_or_b32")
+        out["valu_ceiling_G_wave_instr_per_s"] = {"full_rate_classes": full, "half_rate_classes": half, "source": "profiles/valu_ceiling.json"}
+        v = json.load(open(os.path.join(ROOT, "profiles", f"valu_{args.config}.json")))
+        if v.get("batch_reads") == batch and v.get("read_len") == L:
+            slot = {"k_flank_scan": ["k_flank_scan2"], "k_flank_trace": ["k_flank_trace"], "k_barcode": ["k_bar_prefix", "k_barcode_pfx", "k_barcode_reg", "k_rows"]}
+            per = {}
+            for name, pre in slot.items():
+                n = sum(e.get("SQ_INSTS_VALU", 0.0) for k, e in v["kernels"].items() if any(k.startswith(p) for p in pre))
+                ms = kavg.get(name, 0.0)
+                if n and ms:
+                    g = n / (ms * 1e-3) / 1e9
+                    per[name] = {"valu_wave_instr_per_launch": n, "G_wave_instr_per_s": g, "valu_issue_frac_of_full_rate_ceiling": g / full,
+                                 "valu_issue_frac_of_half_rate_ceiling": g / half}
+            out["kernels"] = per
+            out["counts_source"] = f"profiles/valu_{args.config}.json"
+    except Exception as e:  # the profile files are evidence, not a dependency of the measurement
+        out["ceiling_error"] = str(e)[:200]
+    return out
 
 
 def load_traffic(args, batch, L, dom):
