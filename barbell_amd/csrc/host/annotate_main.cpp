@@ -29,12 +29,29 @@ static bool apply_shard(const std::string& spec, std::vector<std::string>& files
     return true;
 }
 
+// --devices 0,1,2 (a device may repeat: 0,0 = two contexts on GPU 0)
+static std::vector<int> parse_devices(const std::string& spec) {
+    std::vector<int> out;
+    size_t pos = 0;
+    while (pos <= spec.size()) {
+        const size_t c = spec.find(',', pos);
+        const std::string tok = spec.substr(pos, c == std::string::npos ? std::string::npos : c - pos);
+        if (tok.empty() || tok.find_first_not_of("0123456789") != std::string::npos) { fprintf(stderr, "error: --devices takes a comma-separated list of device ordinals\n"); exit(2); }
+        out.push_back(atoi(tok.c_str()));
+        if (c == std::string::npos) break;
+        pos = c + 1;
+    }
+    return out;
+}
+
 static void usage() {
     fputs(
         "Usage: barbell-amd annotate -i <FASTQ>... [-o output.tsv] (--kit <KIT> | -q <FASTA>... [-b Ftag|Rtag ...])\n"
         "                            [--flank-max-errors INT] [--min-score F=0.2] [--min-score-diff F=0.1]\n"
         "                            [--alpha F=0.4] [--use-extended] [-t THREADS=10] [--verbose]\n"
         "                            [--block-bytes N=128Mi | --batch-reads N (= N*4096 bytes)] [--device D=0] [--shard R/W]\n"
+        "                            [--devices D0,D1,.. (one FASTQ stream over several contexts, block i -> context i mod G; RCCL all-reduce of the counts)]\n"
+        "                            [--streams S=2 (contexts per device when --devices is not given)] [--counts FILE]\n"
         "                            [(-f <PATTERN_FILE>... | --kit-filter [--maximize]) [--filtered FILE] [--dropped FILE]]\n"
         "                            [--trim-output DIR [--no-label] [--no-orientation] [--no-flanks] [--sort-labels]\n"
         "                             [--only-side left|right] [--failed-out FILE] [--skip-trim] [--flip] [--gzip]]\n"
@@ -89,6 +106,9 @@ int main(int argc, char** argv) {
             else if (a == "--alpha") k.alpha = (float)atof(need("--alpha"));
             else if (a == "--batch-reads") k.batch_reads = (size_t)atol(need("--batch-reads"));
             else if (a == "--device") k.device = atoi(need("--device"));
+            else if (a == "--devices") { k.devices = parse_devices(need("--devices")); }
+            else if (a == "--streams") k.streams_per_device = (unsigned)atoi(need("--streams"));
+            else if (a == "--counts") k.counts_file = need("--counts");
             else if (a == "--shard") shard = need("--shard");
             else if (a == "--maximize") { k.maximize = true; multi_in = false; }
             else if (a == "--verbose") { k.verbose = true; multi_in = false; }
@@ -136,6 +156,9 @@ int main(int argc, char** argv) {
         else if (a == "--batch-reads") { cfg.batch_reads = (size_t)atol(need("--batch-reads")); multi = nullptr; }
         else if (a == "--block-bytes") { cfg.block_bytes = (size_t)atoll(need("--block-bytes")); multi = nullptr; }
         else if (a == "--device") { cfg.device = atoi(need("--device")); multi = nullptr; }
+        else if (a == "--devices") { cfg.devices = parse_devices(need("--devices")); multi = nullptr; }
+        else if (a == "--streams") { cfg.streams_per_device = (unsigned)atoi(need("--streams")); multi = nullptr; }
+        else if (a == "--counts") { cfg.counts_file = need("--counts"); multi = nullptr; }
         else if (a == "--shard") { shard = need("--shard"); multi = nullptr; }
         else if (a == "-f" || a == "--filter-file") { multi = &pattern_files; }
         else if (a == "--filtered") { cfg.filtered_file = need("--filtered"); multi = nullptr; }
@@ -195,7 +218,8 @@ int main(int argc, char** argv) {
             }
             st = annotate_with_files(input, queries, types, output, cfg);
         }
-        fprintf(stderr, "Done: %zu records, %zu with annotations, %zu rows -> %s\n", st.total, st.found, st.rows, output.c_str());
+        fprintf(stderr, "Done: %zu records, %zu with annotations, %zu rows -> %s (%.2f s in the pipeline, %.2f M reads/s; histogram summed by %s)\n", st.total, st.found,
+                st.rows, output.c_str(), st.seconds_pipeline, st.seconds_pipeline > 0 ? st.total / st.seconds_pipeline / 1e6 : 0.0, st.counts_reduce.c_str());
         if (!cfg.filter_patterns.empty()) fprintf(stderr, "Filter: %zu kept, %zu dropped\n", st.kept, st.dropped);
         if (cfg.trim) fprintf(stderr, "Trim: %zu trimmed, %zu split, %zu failed\n", st.trimmed, st.trimmed_split, st.trim_failed);
         if (cfg.inspect) for (const auto& l : inspect_summary(st, top_n)) puts(l.c_str());

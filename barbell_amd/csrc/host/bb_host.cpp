@@ -17,6 +17,8 @@
 #include <thread>
 
 #include <sys/stat.h>
+#include <fcntl.h>
+#include <unistd.h>
 #include <cerrno>
 #include <chrono>
 
@@ -300,7 +302,7 @@ std::vector<Pattern> kit_patterns(const std::string& kit_in, bool maximize) {
 Demuxer::Demuxer(float alpha, bool verbose, double min_score_frac, double min_score_diff_frac, int device)
     : alpha_(alpha), verbose_(verbose), min_score_(min_score_frac), min_score_diff_(min_score_diff_frac), device_(device) {}
 Demuxer::~Demuxer() {
-    for (DevBuf* b : {&d_rows_, &d_ver_, &d_elems_, &d_text_, &d_slices_, &d_spans_, &d_status_}) b->release();
+    for (DevBuf* b : {&d_rows_, &d_ver_, &d_elems_, &d_text_, &d_slices_, &d_spans_, &d_status_, &d_tsv_}) b->release();
     for (uint8_t* h : h_text_) if (h) bb_host_free(ctx_, h);
     if (ctx_) bb_destroy(ctx_);
 }
@@ -327,6 +329,26 @@ void Demuxer::ensure_ctx() {
     bb_params p{alpha_, min_score_, min_score_diff_, device_};
     const int rc = bb_create(descs.data(), (uint32_t)descs.size(), &p, &ctx_);
     if (rc != BB_OK) { ctx_ = nullptr; throw BarbellError(rc, std::string("bb_create: ") + bb_strerror(rc)); }
+    // label strings for the TSV renderer (they do not cross bb_create)
+    std::string blob;
+    std::vector<uint32_t> off{0};
+    for (const auto& l : slot_labels()) { blob += l; off.push_back((uint32_t)blob.size()); }
+    blob.push_back('\0');
+    const int r2 = bb_format_set_labels(ctx_, (const uint8_t*)blob.data(), off.data());
+    if (r2 != BB_OK) throw BarbellError(r2, std::string("bb_format_set_labels: ") + bb_strerror(r2));
+}
+
+std::vector<std::string> Demuxer::slot_labels() const {
+    std::vector<std::string> out;
+    for (const auto& g : queries_) { out.insert(out.end(), g.labels.begin(), g.labels.end()); out.push_back("flank"); }
+    return out;
+}
+std::vector<uint64_t> Demuxer::counts() {
+    ensure_ctx();
+    std::vector<uint64_t> c(bb_counts_len(ctx_));
+    const int rc = bb_counts(ctx_, c.data());
+    if (rc != BB_OK) throw BarbellError(rc, bb_strerror(rc));
+    return c;
 }
 
 bb_group_info Demuxer::group_info(size_t g) {
@@ -557,12 +579,13 @@ void DevBuf::release() {
 
 #define BB_THROW(rc, what) throw BarbellError((rc), std::string(what ": ") + bb_strerror(rc) + " " + bb_last_error(ctx_))
 
-Demuxer::Ingested Demuxer::ingest(const uint8_t* text, uint64_t len, bool final_block) {
+Demuxer::Ingested Demuxer::ingest(const uint8_t* text, uint64_t len, bool final_block, bool want_ids) {
     ensure_ctx();
     ing_ = Ingested{};
     n_rows_ = 0;
     int rc = bb_fastq_ingest(ctx_, text, len, final_block ? 1 : 0, &ing_.info, &batch_);
     if (rc != BB_OK) BB_THROW(rc, "bb_fastq_ingest");
+    if (!want_ids) return ing_;  // the TSV renderer reads the ids where they are
     const uint64_t n = ing_.info.n_records;
     std::vector<uint8_t> hdr(ing_.info.n_hdr);
     std::vector<uint64_t> hoff(n + 1);
@@ -572,6 +595,41 @@ Demuxer::Ingested Demuxer::ingest(const uint8_t* text, uint64_t len, bool final_
     ing_.ids.reserve(n);
     for (uint64_t i = 0; i < n; ++i) ing_.ids.emplace_back((const char*)hdr.data() + hoff[i], idl[i]);
     return ing_;
+}
+
+uint64_t Demuxer::annotate_ingested() {
+    const uint32_t n = (uint32_t)ing_.info.n_records;
+    uint64_t cap = 4ull * n + 64, n_rows = 0;
+    d_rows_.ensure(ctx_, cap * sizeof(bb_row));
+    int rc = bb_annotate_batch_dev(ctx_, batch_.d_bases, batch_.d_offsets, n, (bb_row*)d_rows_.p, cap, &n_rows);
+    if (rc == BB_E_CAPACITY) {
+        cap = n_rows;
+        d_rows_.ensure(ctx_, cap * sizeof(bb_row));
+        rc = bb_annotate_batch_dev(ctx_, batch_.d_bases, batch_.d_offsets, n, (bb_row*)d_rows_.p, cap, &n_rows);
+    }
+    if (rc != BB_OK) BB_THROW(rc, "bb_annotate_batch_dev");
+    n_rows_ = n_rows;
+    if (rows_.size() < n_rows) rows_.resize(n_rows);
+    if ((rc = bb_dev_download(ctx_, rows_.data(), d_rows_.p, n_rows * sizeof(bb_row))) != BB_OK) BB_THROW(rc, "bb_dev_download");
+    return n_rows;
+}
+
+uint64_t Demuxer::format_ingested(int mode, std::vector<uint8_t>& out) {
+    if (n_rows_ == 0) return 0;
+    uint64_t cap = std::max<uint64_t>(1u << 16, 160 * n_rows_), tl = 0, nl = 0;
+    for (;;) {
+        d_tsv_.ensure(ctx_, cap);
+        const int rc = bb_format_rows_dev(ctx_, (const bb_row*)d_rows_.p, mode == BB_FMT_ALL ? nullptr : (const bb_row_verdict*)d_ver_.p, n_rows_, mode,
+                                          &batch_.d_headers, (uint8_t*)d_tsv_.p, cap, &tl, &nl);
+        if (rc == BB_E_CAPACITY) { cap = tl; continue; }
+        if (rc != BB_OK) BB_THROW(rc, "bb_format_rows_dev");
+        break;
+    }
+    const size_t at = out.size();
+    out.resize(at + tl);
+    int rc;
+    if (tl && (rc = bb_dev_download(ctx_, out.data() + at, d_tsv_.p, tl)) != BB_OK) BB_THROW(rc, "bb_dev_download");
+    return nl;
 }
 
 std::vector<BarbellMatch> Demuxer::demux_ingested() {
@@ -660,83 +718,51 @@ TrimBatch Demuxer::trim_ingested() {
 // ---- annotate (annotator.rs) ----------------------------------------------------------------------
 namespace {
 // the automatic flank cutoff (edit_model.rs:2-11) is applied inside bb_create when k_cutoff is unset
-// Raw FASTQ text in blocks: plain or gzip (gzread reads both).  The record parser is on the GPU
-// (bb_fastq_ingest); the partial record at the end of a block is carried over to the next one.
-// Two page-locked buffers: while the GPU works on one block a reader thread fills the other, leaving HEAD bytes
-// of headroom in front of the chunk so the (short) carry can be copied there without moving the chunk.
-struct BlockSource {
+// Raw FASTQ text in blocks of whole records, in page-locked memory, in stream order.
+//
+// Chunks of `chunk` bytes are read by a pool of reader threads (pread at fixed offsets for plain files, a copy out of
+// the inflated image for gzip files — ParallelInflater below) into a ring of page-locked slots, each with HEAD bytes of
+// headroom in front; every reader also counts its chunk's line ends.  A sequencer (next(), one caller) takes the chunks
+// in order and turns them into blocks that hold complete 4-line records only: with the running number of complete lines
+// it knows how many trailing lines of a chunk belong to a record that ends in the next chunk, finds that cut by walking
+// back over those few lines, and copies the short tail into the next slot's headroom — exactly the `consumed` the GPU
+// parser (bb_fastq_ingest) would have reported, without waiting for it, so block i+1 can go to another GPU while block i
+// is still being parsed.  The last block of a file is handed over whole (the parser's final-block rules apply to it).
+struct BlockFeeder {
+    struct Block { uint64_t index = 0; const uint8_t* data = nullptr; size_t len = 0; int slot = -1; std::shared_ptr<std::vector<uint8_t>> big; };
+    struct Task { size_t file = 0; uint64_t off = 0; size_t len = 0; uint64_t seq = 0; bool last = false; const uint8_t* mem = nullptr; };
+    struct Slot { uint8_t* p = nullptr; size_t cap = 0, got = 0, nl = 0; bool last = false; int state = 0; uint64_t seq = 0; int refs = 0; size_t file = 0; };
     size_t HEAD = 16u << 20;  // BARBELL_AMD_HEAD_BYTES overrides it (tests of the over-long-carry path)
-    gzFile f = nullptr;
     bb_ctx* ctx;
-    struct Buf { uint8_t* p = nullptr; size_t cap = 0, got = 0; bool eof = false; } bufs[2];
-    int cur = 0;
+    std::vector<std::string> paths;
+    std::vector<char> is_gz;
+    std::vector<int> fds;
+    std::vector<uint64_t> sizes;      // plain: st_size; gzip: inflated size once known
+    std::vector<char> size_known;
     size_t chunk;
-    std::thread reader;
-    bool pending = false;
+    std::vector<Slot> slots;
+    std::vector<std::thread> readers;
+    std::unique_ptr<struct ParallelInflater> inflater;
+    std::mutex mu;
+    std::condition_variable cv;
+    // claim cursor
+    size_t cur_file = 0; uint64_t cur_off = 0, next_seq = 0;
+    std::vector<uint64_t> chunks_left;  // per gzip file: chunks not yet copied out of the inflated image
+    bool stop = false, claims_done = false;
     std::string err;
-    // current block = [data, data + have)
-    uint8_t* data = nullptr;
-    size_t have = 0;
+    // sequencer state
+    uint64_t want_seq = 0, n_blocks = 0;
+    const uint8_t* carry_ptr = nullptr; size_t carry_len = 0, carry_lines = 0; int carry_slot = -1;
+    bool done = false;
 
-    BlockSource(bb_ctx* c, const std::string& path, size_t chunk_bytes) : f(gzopen(path.c_str(), "rb")), ctx(c), chunk(chunk_bytes) {
-        if (!f) throw BarbellError(BB_E_INVALID, "Failed to open FASTQ input: " + path);
-        gzbuffer(f, 1 << 20);
-        if (const char* e = getenv("BARBELL_AMD_HEAD_BYTES")) HEAD = (size_t)std::max(16L, atol(e));
-        start_read(0);
-    }
-    ~BlockSource() {
-        if (reader.joinable()) reader.join();
-        if (f) gzclose(f);
-        for (auto& b : bufs) if (b.p) bb_host_free(ctx, b.p);
-    }
-    void reserve(Buf& b, size_t need) {
-        if (need <= b.cap) return;
-        void* q = nullptr;
-        if (bb_host_malloc(ctx, need, &q) != BB_OK) throw BarbellError(BB_E_NOMEM, "bb_host_malloc failed");
-        if (b.p) bb_host_free(ctx, b.p);
-        b.p = (uint8_t*)q; b.cap = need;
-    }
-    void start_read(int i) {  // fills bufs[i] with the next chunk at offset HEAD, in the background
-        Buf& b = bufs[i];
-        reserve(b, HEAD + chunk);
-        pending = true;
-        reader = std::thread([this, &b]() {
-            size_t got = 0;
-            while (got < chunk) {
-                const int r = gzread(f, b.p + HEAD + got, (unsigned)std::min<size_t>(chunk - got, 1u << 30));
-                if (r < 0) { err = "Error reading FASTQ file"; break; }
-                if (r == 0) break;
-                got += (size_t)r;
-            }
-            b.got = got;
-            b.eof = got < chunk;
-        });
-    }
-    // makes the next block current: carry (the unconsumed tail of the previous block) + the chunk that was being
-    // read; returns true when it is the last block of the file
-    bool next(size_t consumed) {
-        reader.join();
-        pending = false;
-        if (!err.empty()) throw BarbellError(BB_E_INVALID, err);
-        Buf& b = bufs[cur];
-        const size_t carry = data ? have - consumed : 0;
-        const uint8_t* carry_src = data ? data + consumed : nullptr;
-        if (carry > HEAD) {  // a single record longer than the headroom (rare): assemble carry + chunk aside
-            std::vector<uint8_t> tmp(carry + b.got);
-            memcpy(tmp.data(), carry_src, carry);  // carry_src may point into `big`: copy before the swap
-            memcpy(tmp.data() + carry, b.p + HEAD, b.got);
-            big.swap(tmp);
-            data = big.data(); have = big.size();
-        } else {
-            if (carry) memcpy(b.p + HEAD - carry, carry_src, carry);
-            data = b.p + HEAD - carry; have = carry + b.got;
-        }
-        const bool eof = b.eof;
-        cur ^= 1;
-        if (!eof) start_read(cur);
-        return eof;
-    }
-    std::vector<uint8_t> big;  // block with an over-long carry
+    BlockFeeder(bb_ctx* c, const std::vector<std::string>& files, size_t chunk_bytes, unsigned n_slots, unsigned n_readers, unsigned n_inflate);
+    ~BlockFeeder();
+    void reader_loop();
+    bool claim(Task& t);
+    bool next(Block& b);
+    void release(int slot);
+    void unref(int slot);
+    void fail(const std::string& e) { { std::lock_guard<std::mutex> lk(mu); if (err.empty() && !e.empty()) err = e; stop = true; } cv.notify_all(); }
 };
 
 // Several gzip files: zlib inflates one stream on one core (~0.3 GB/s), far below what the GPU takes, so the
@@ -744,6 +770,7 @@ struct BlockSource {
 // order (the TSV keeps the reads' order).  n_threads comes from -t/--threads like the reference's worker count.
 struct ParallelInflater {
     std::vector<std::string> paths;
+    std::vector<char> gz;    // files that are not gzip are skipped (the feeder reads them directly)
     std::vector<std::vector<uint8_t>> data;
     std::vector<int> state;  // 0 = not started, 1 = in progress, 2 = ready, 3 = consumed
     std::vector<std::thread> pool;
@@ -751,7 +778,8 @@ struct ParallelInflater {
     std::condition_variable cv;
     size_t next_file = 0, consumed_upto = 0, ahead;
     std::string err;
-    ParallelInflater(std::vector<std::string> p, unsigned n_threads) : paths(std::move(p)), data(paths.size()), state(paths.size(), 0) {
+    ParallelInflater(std::vector<std::string> p, std::vector<char> is_gz, unsigned n_threads)
+        : paths(std::move(p)), gz(std::move(is_gz)), data(paths.size()), state(paths.size(), 0) {
         const unsigned nt = std::max(1u, std::min<unsigned>(n_threads, (unsigned)paths.size()));
         ahead = nt + 2;  // files inflated but not yet consumed: bounds the memory
         for (unsigned i = 0; i < nt; ++i) pool.emplace_back([this]() { work(); });
@@ -764,6 +792,7 @@ struct ParallelInflater {
                 cv.wait(lk, [this]() { return next_file >= paths.size() || next_file < consumed_upto + ahead || !err.empty(); });
                 if (next_file >= paths.size() || !err.empty()) return;
                 i = next_file++;
+                if (!gz[i]) { state[i] = 3; continue; }
                 state[i] = 1;
             }
             std::vector<uint8_t> buf;
@@ -805,7 +834,7 @@ struct ParallelInflater {
             std::lock_guard<std::mutex> lk(mu);
             std::vector<uint8_t>().swap(data[i]);
             state[i] = 3;
-            consumed_upto = i + 1;
+            consumed_upto = std::max(consumed_upto, i + 1);
         }
         cv.notify_all();
     }
@@ -827,7 +856,7 @@ struct LabelWriters {  // the per-label writers of trim_matches (trim.rs:356-446
     std::map<std::string, FILE*> plain;
     // writes run on their own thread, one batch's spans per job; at most two jobs exist (the demuxer has two
     // landing buffers), submit() blocks while both are busy
-    struct Span { std::string label; const uint8_t* p; size_t n; };
+    struct Span { std::string label; const uint8_t* p; size_t n; std::shared_ptr<std::vector<uint8_t>> keep; };
     std::deque<std::vector<Span>> jobs;
     std::mutex mu;
     std::condition_variable cv;
@@ -907,20 +936,235 @@ struct LabelWriters {  // the per-label writers of trim_matches (trim.rs:356-446
         for (auto& kv : plain) fclose(kv.second);
     }
 };
+
+static size_t count_nl(const uint8_t* p, size_t n) {
+    size_t c = 0;
+    const uint8_t* e = p + n;
+    while (p < e) {
+        const void* q = memchr(p, '\n', (size_t)(e - p));
+        if (!q) break;
+        ++c;
+        p = (const uint8_t*)q + 1;
+    }
+    return c;
+}
+static bool sniff_gzip(const std::string& path) {  // magic bytes, not the file name (the reference's reader sniffs too)
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) throw BarbellError(BB_E_INVALID, "Failed to open FASTQ input: " + path);
+    unsigned char m[2] = {0, 0};
+    const size_t n = fread(m, 1, 2, f);
+    fclose(f);
+    return n == 2 && m[0] == 0x1f && m[1] == 0x8b;
+}
+
+BlockFeeder::BlockFeeder(bb_ctx* c, const std::vector<std::string>& files, size_t chunk_bytes, unsigned n_slots, unsigned n_readers, unsigned n_inflate)
+    : ctx(c), paths(files), chunk(chunk_bytes) {
+    if (const char* e = getenv("BARBELL_AMD_HEAD_BYTES")) HEAD = (size_t)std::max(16L, atol(e));
+    is_gz.resize(paths.size()); fds.assign(paths.size(), -1); sizes.assign(paths.size(), 0); size_known.assign(paths.size(), 0);
+    chunks_left.assign(paths.size(), 0);
+    std::vector<std::string> gz_paths;
+    for (size_t i = 0; i < paths.size(); ++i) {
+        is_gz[i] = sniff_gzip(paths[i]) ? 1 : 0;
+        if (is_gz[i]) continue;
+        fds[i] = open(paths[i].c_str(), O_RDONLY);
+        struct stat st;
+        if (fds[i] < 0 || fstat(fds[i], &st) != 0) throw BarbellError(BB_E_INVALID, "Failed to open FASTQ input: " + paths[i]);
+        sizes[i] = (uint64_t)st.st_size; size_known[i] = 1;
+    }
+    bool any_gz = false;
+    for (char g : is_gz) any_gz = any_gz || g;
+    if (any_gz) inflater = std::make_unique<ParallelInflater>(paths, is_gz, n_inflate);
+    slots.resize(std::max(3u, n_slots));
+    for (size_t i = 0; i < slots.size(); ++i) {
+        void* q = nullptr;
+        if (bb_host_malloc(ctx, HEAD + chunk, &q) != BB_OK) throw BarbellError(BB_E_NOMEM, "bb_host_malloc failed");
+        slots[i].p = (uint8_t*)q; slots[i].cap = HEAD + chunk; slots[i].seq = i;
+    }
+    for (unsigned i = 0; i < std::max(1u, n_readers); ++i) readers.emplace_back([this]() { reader_loop(); });
+}
+BlockFeeder::~BlockFeeder() {
+    { std::lock_guard<std::mutex> lk(mu); stop = true; }
+    cv.notify_all();
+    for (auto& t : readers) if (t.joinable()) t.join();
+    inflater.reset();
+    for (auto& sl : slots) if (sl.p) bb_host_free(ctx, sl.p);
+    for (int fd : fds) if (fd >= 0) close(fd);
+}
+// next chunk of the stream; gzip files are inflated whole (a few files ahead) and chunked from memory
+bool BlockFeeder::claim(Task& t) {
+    for (;;) {
+        size_t f;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            if (stop) return false;
+            if (cur_file >= paths.size()) { if (!claims_done) { claims_done = true; cv.notify_all(); } return false; }
+            f = cur_file;
+            if (size_known[f]) {
+                if (sizes[f] == 0 && cur_off == 0) {  // empty file: an empty last chunk keeps the sequence simple
+                    t = Task{f, 0, 0, next_seq++, true, nullptr};
+                    ++cur_file;
+                    return true;
+                }
+                const size_t len = (size_t)std::min<uint64_t>(chunk, sizes[f] - cur_off);
+                t = Task{f, cur_off, len, next_seq++, cur_off + len == sizes[f], nullptr};
+                cur_off += len;
+                if (t.last) { ++cur_file; cur_off = 0; }
+                return true;
+            }
+        }
+        const std::vector<uint8_t>& img = inflater->get(f);  // blocks until inflated (thread-safe, several readers may wait)
+        std::lock_guard<std::mutex> lk(mu);
+        if (!size_known[f]) { sizes[f] = img.size(); size_known[f] = 1; chunks_left[f] = std::max<uint64_t>(1, (img.size() + chunk - 1) / chunk); }
+    }
+}
+void BlockFeeder::reader_loop() {
+    try {
+        Task t;
+        while (claim(t)) {
+            Slot& sl = slots[t.seq % slots.size()];
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&]() { return stop || (sl.state == 0 && sl.seq == t.seq); });
+                if (stop) return;
+                sl.state = 1;
+            }
+            uint8_t* dst = sl.p + HEAD;
+            if (is_gz[t.file]) {
+                const std::vector<uint8_t>& img = inflater->get(t.file);
+                if (t.len) memcpy(dst, img.data() + t.off, t.len);
+                bool last_copy;
+                { std::lock_guard<std::mutex> lk(mu); last_copy = --chunks_left[t.file] == 0; }
+                if (last_copy) inflater->release(t.file);  // every chunk of the image has been copied out
+            } else {
+                size_t got = 0;
+                while (got < t.len) {
+                    const ssize_t r = pread(fds[t.file], dst + got, t.len - got, (off_t)(t.off + got));
+                    if (r < 0) { if (errno == EINTR) continue; throw BarbellError(BB_E_INVALID, "Error reading FASTQ file '" + paths[t.file] + "'"); }
+                    if (r == 0) throw BarbellError(BB_E_INVALID, "FASTQ file '" + paths[t.file] + "' shrank while it was read");
+                    got += (size_t)r;
+                }
+            }
+            const size_t nl = count_nl(dst, t.len);
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                sl.got = t.len; sl.nl = nl; sl.last = t.last; sl.file = t.file; sl.state = 2;
+            }
+            cv.notify_all();
+        }
+    } catch (const std::exception& e) { fail(e.what()); }
+}
+void BlockFeeder::unref(int i) {
+    bool freed = false;
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        Slot& sl = slots[(size_t)i];
+        if (--sl.refs == 0) { sl.state = 0; sl.seq += slots.size(); freed = true; }
+    }
+    if (freed) cv.notify_all();
+}
+void BlockFeeder::release(int slot) { if (slot >= 0) unref(slot); }
+
+bool BlockFeeder::next(Block& b) {
+    for (;;) {
+        if (done) return false;
+        Slot* sl;
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            sl = &slots[want_seq % slots.size()];
+            cv.wait(lk, [&]() { return !err.empty() || (sl->state == 2 && sl->seq == want_seq) || (claims_done && want_seq >= next_seq); });
+            if (!err.empty()) throw BarbellError(BB_E_INVALID, err);
+            if (!(sl->state == 2 && sl->seq == want_seq)) { done = true; return false; }  // every chunk has been sequenced
+            sl->refs = 2;  // the worker that uploads the block + the sequencer (its tail is the next block's carry)
+        }
+        const int si = (int)(want_seq % slots.size());
+        ++want_seq;
+        uint8_t* body = sl->p + HEAD;
+        size_t cut = sl->got;  // bytes of this chunk that go into this block
+        size_t lines_left = 0;
+        if (!sl->last) {
+            const size_t total = carry_lines + sl->nl;
+            const size_t r = total % 4;            // complete lines after the last complete record
+            if (total < 4 || sl->nl <= r) {         // no record ends inside this chunk
+                if (carry_len + sl->got > 0) throw BarbellError(BB_E_FASTQ, "a FASTQ record of '" + paths[sl->file] + "' is longer than the block size; raise --block-bytes");
+            }
+            // the cut is just after line end number (nl - r) of the chunk: walk back over the partial last line and r lines
+            const uint8_t* e = body + sl->got;
+            for (size_t k = 0; k <= r; ++k) {
+                const void* q = memrchr(body, '\n', (size_t)(e - body));
+                e = (const uint8_t*)q;  // not null: nl > r
+            }
+            cut = (size_t)(e - body) + 1;
+            lines_left = r;
+        }
+        // assemble: carry (in the previous slot's tail, or aside) + chunk[0, cut)
+        Block out;
+        if (carry_len > HEAD) {  // a carry longer than the headroom (a huge record): assemble aside
+            auto big = std::make_shared<std::vector<uint8_t>>(carry_len + cut);
+            memcpy(big->data(), carry_ptr, carry_len);
+            memcpy(big->data() + carry_len, body, cut);
+            out.data = big->data(); out.len = big->size(); out.big = big; out.slot = -1;
+            unref(si);  // the worker does not need the slot
+        } else {
+            if (carry_len) memcpy(body - carry_len, carry_ptr, carry_len);
+            out.data = body - carry_len; out.len = carry_len + cut; out.slot = si;
+        }
+        if (carry_slot >= 0) unref(carry_slot);  // the previous slot's tail has been copied
+        // the new carry
+        carry_ptr = body + cut; carry_len = sl->got - cut; carry_lines = lines_left;
+        if (carry_len) carry_slot = si;
+        else { carry_slot = -1; unref(si); }
+        if (sl->last) { carry_lines = 0; }
+        if (out.len == 0) { if (out.slot >= 0) unref(out.slot); continue; }  // an empty file
+        out.index = n_blocks++;
+        b = out;
+        return true;
+    }
+}
 }  // namespace
+
+// What one block of the stream turns into; produced by the worker that owns the block's context, committed to the
+// output files by the main thread in block order.
+namespace {
+struct BlockResult {
+    size_t n_reads = 0, found = 0, rows = 0, kept = 0, dropped = 0, trimmed = 0, split = 0, trim_failed = 0;
+    std::vector<uint8_t> anno, kept_tsv, drop_tsv;              // TSV lines rendered on the GPU
+    std::vector<std::pair<std::string, std::string>> ppr;       // (read id, pattern) for pattern_per_read.tsv
+    std::vector<std::string> patterns;                          // pattern of every read with rows (inspect counts)
+    std::vector<std::string> failed_ids;
+    std::shared_ptr<std::vector<uint8_t>> text;                 // rendered records of the trim step
+    struct Span { std::string label; size_t off, n; };
+    std::vector<Span> spans;
+    double t_ingest = 0, t_gpu = 0, t_rest = 0;
+};
+}  // namespace
+
+// bb_rccl.cpp: sums the per-context histograms.  Contexts on distinct devices are all-reduced with RCCL over xGMI
+// (ncclAllReduce, uint64 sum, in place on bb_counts_dev); contexts that share a device are first summed on the host.
+std::vector<uint64_t> allreduce_counts(const std::vector<Demuxer*>& dms, std::string& how);
 
 AnnotateStats annotate(const std::vector<std::string>& read_files, const std::string& out_file,
                        std::vector<BarcodeGroup> query_groups, const AnnotateConfig& config) {
     if (read_files.empty()) throw BarbellError(BB_E_INVALID, "No FASTQ input files provided");  // io.rs:20-26
+    const bool filtering = !config.filter_patterns.empty();
+    const bool trimming = config.trim.has_value();
+    if (trimming && !filtering) throw BarbellError(BB_E_INVALID, "the trim step needs filter patterns (cuts come from the filter)");
+    // contexts: block i of the stream -> context i mod G
+    std::vector<int> devs = config.devices;
+    if (devs.empty()) devs.assign(std::max(1u, config.streams_per_device), config.device);
+    const size_t G = devs.size();
+    std::vector<std::unique_ptr<Demuxer>> dms;
+    for (size_t w = 0; w < G; ++w) {
+        dms.push_back(std::make_unique<Demuxer>(config.alpha, config.verbose, config.min_score, config.min_score_diff, devs[w]));
+        for (const auto& g : query_groups) dms.back()->add_query_group(g);
+        dms.back()->ctx();  // create now: geometry / device errors surface before any output file exists
+        if (filtering) dms.back()->set_filter(config.filter_patterns);
+        if (trimming) dms.back()->set_trim(*config.trim);
+    }
     FILE* out = fopen(out_file.c_str(), "w");
     if (!out) throw BarbellError(BB_E_INVALID, "Failed to create annotation output file '" + out_file + "'");
-    Demuxer dm(config.alpha, config.verbose, config.min_score, config.min_score_diff, config.device);
-    for (auto& g : query_groups) dm.add_query_group(std::move(g));
-    const bool filtering = !config.filter_patterns.empty();
     FILE* kept_f = nullptr;
     FILE* drop_f = nullptr;
     if (filtering) {
-        dm.set_filter(config.filter_patterns);
         if (!config.filtered_file.empty() && !(kept_f = fopen(config.filtered_file.c_str(), "w"))) {
             fclose(out);
             throw BarbellError(BB_E_INVALID, "Failed to create filtered output file '" + config.filtered_file + "'");
@@ -931,14 +1175,10 @@ AnnotateStats annotate(const std::vector<std::string>& read_files, const std::st
             throw BarbellError(BB_E_INVALID, "Failed to create dropped output file '" + config.dropped_file + "'");
         }
     }
-    bool kept_header = false, drop_header = false;
     AnnotateStats st;
-    const bool trimming = config.trim.has_value();
     std::unique_ptr<LabelWriters> writers;
     FILE* failed_f = nullptr;
     if (trimming) {
-        if (!filtering) { fclose(out); throw BarbellError(BB_E_INVALID, "the trim step needs filter patterns (cuts come from the filter)"); }
-        dm.set_trim(*config.trim);
         if (mkdir(config.trim_folder.c_str(), 0777) != 0 && errno != EEXIST) {
             fclose(out);
             throw BarbellError(BB_E_INVALID, "Failed to create output folder '" + config.trim_folder + "'");
@@ -950,7 +1190,7 @@ AnnotateStats annotate(const std::vector<std::string>& read_files, const std::st
     if (config.inspect && !config.read_pattern_out.empty()) ppr_f = fopen(config.read_pattern_out.c_str(), "w");
     std::map<std::string, size_t> pattern_count;
     std::vector<std::string> pattern_order;  // first-appearance order, for a deterministic tie order in the summary
-    bool header = false;
+    bool header = false, kept_header = false, drop_header = false;
     auto close_all = [&]() {
         fclose(out);
         if (kept_f) fclose(kept_f);
@@ -959,124 +1199,194 @@ AnnotateStats annotate(const std::vector<std::string>& read_files, const std::st
         if (ppr_f) fclose(ppr_f);
         writers.reset();
     };
-    // one block of text: parsed, annotated, filtered, inspected and trimmed in HBM; only rows, verdicts,
-    // pattern elements and the rendered records come back
-    // BARBELL_AMD_PROFILE=1: wall-clock split of the host loop on stderr (read / ingest / annotate / write / filter+trim)
     const bool prof = getenv("BARBELL_AMD_PROFILE") != nullptr;
-    double t_read = 0, t_ingest = 0, t_demux = 0, t_write = 0, t_rest = 0, t_insp = 0, t_ftsv = 0, t_trim = 0, t_fq = 0;
     auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    auto process = [&](const Demuxer::Ingested& ing) {
-        const auto& ids = ing.ids;
-        if (ids.empty()) return;
+    const bool want_ids = ppr_f != nullptr || failed_f != nullptr;
+
+    // ---- one block on its context: parsed, annotated, rendered, filtered, inspected and trimmed in HBM -------------
+    auto process = [&](Demuxer& dm, const BlockFeeder::Block& blk, BlockFeeder& feeder) -> BlockResult {
+        BlockResult R;
         double t0 = now();
-        auto rows = dm.demux_ingested();
-        t_demux += now() - t0; t0 = now();
-        st.total += ids.size();
+        const auto ing = dm.ingest(blk.data, blk.len, true, want_ids);  // blocks hold whole records only
+        feeder.release(blk.slot);                                       // the text is in HBM: the slot can be refilled
+        R.t_ingest = now() - t0; t0 = now();
+        const auto& ids = ing.ids;
+        R.n_reads = (size_t)ing.info.n_records;
+        if (R.n_reads == 0) return R;
+        const uint64_t n_rows = dm.annotate_ingested();
+        R.rows = (size_t)n_rows;
+        const bb_row* rows = dm.rows();
+        for (uint64_t i = 0; i < n_rows; ++i) R.found += i == 0 || rows[i].read_idx != rows[i - 1].read_idx;
+        dm.format_ingested(BB_FMT_ALL, R.anno);
+        R.t_gpu = now() - t0; t0 = now();
         std::vector<bb_row_verdict> verdicts;
-        if (filtering) verdicts = dm.filter_ingested();
-        const std::string* last = nullptr;
-        for (const auto& r : rows) {
-            if (!header) { fputs(TSV_HEADER, out); fputc('\n', out); header = true; }  // csv writer: header with the first record
-            fputs(r.to_tsv().c_str(), out);
-            fputc('\n', out);
-            if (!last || *last != r.read_id) ++st.found;
-            last = &r.read_id;
+        if (filtering) {
+            verdicts = dm.filter_ingested();
+            for (uint64_t i = 0; i < n_rows; ++i)
+                if (i == 0 || rows[i].read_idx != rows[i - 1].read_idx) ++(verdicts[i].pass ? R.kept : R.dropped);
+            if (kept_f) dm.format_ingested(BB_FMT_KEPT, R.kept_tsv);
+            if (drop_f) dm.format_ingested(BB_FMT_DROPPED, R.drop_tsv);
         }
-        t_write += now() - t0; t0 = now();
-        double t1 = now();
         if (config.inspect) {  // inspect.rs:128-184 on the annotation rows (no cuts yet)
             for (auto& rp : dm.inspect_ingested(false, config.bucket_size)) {
-                if (ppr_f) fprintf(ppr_f, "%s\t%s\n", ids[rp.first].c_str(), rp.second.c_str());
-                auto it = pattern_count.find(rp.second);
-                if (it == pattern_count.end()) { pattern_count.emplace(rp.second, 1); pattern_order.push_back(rp.second); }
-                else ++it->second;
+                if (ppr_f) R.ppr.emplace_back(ids[rp.first], rp.second);
+                R.patterns.push_back(std::move(rp.second));
             }
         }
-        t_insp += now() - t1; t1 = now();
-        for (size_t i = 0; i < verdicts.size(); ++i) {  // filtered.tsv / dropped.tsv (filter.rs:87-119)
-            const bb_row_verdict& v = verdicts[i];
-            const bool first = i == 0 || rows[i].read_id != rows[i - 1].read_id;
-            if (first) ++(v.pass ? st.kept : st.dropped);
-            FILE* f = v.pass ? kept_f : drop_f;
-            if (!f) continue;
-            bool& hdr = v.pass ? kept_header : drop_header;
-            if (!hdr) { fputs(TSV_HEADER, f); fputc('\n', f); hdr = true; }
-            std::string cuts;
-            for (unsigned q = 0; q < v.n_cuts; ++q) {  // "After(0):1" (searcher.rs:91-106)
-                if (q) cuts += ',';
-                cuts += Cut{v.cuts[q].group_id, v.cuts[q].direction == BB_CUT_AFTER}.to_string() + ":" + std::to_string(v.match_idx);
-            }
-            rows[i].cuts = std::move(cuts);
-            fputs(rows[i].to_tsv().c_str(), f);
-            fputc('\n', f);
-        }
-        t_ftsv += now() - t1; t1 = now();
         if (trimming) {  // trim.rs:385-460: the GPU cut and rendered the records, one write per label
-            writers->wait(1);  // the landing buffer about to be reused belongs to the job before the last one
             const TrimBatch t = dm.trim_ingested();
-            t_trim += now() - t1; t1 = now();
-            std::vector<LabelWriters::Span> job;
-            for (const auto& sp : t.spans) job.push_back({dm.label_of_key(sp.label_key), t.data() + sp.off, (size_t)sp.len});
-            writers->submit(std::move(job));
-            t_fq += now() - t1;
-            std::vector<uint32_t> per_read(ids.size(), 0);
+            R.text = std::make_shared<std::vector<uint8_t>>(t.data(), t.data() + t.text_len);  // the landing buffer is reused two blocks later
+            for (const auto& sp : t.spans) R.spans.push_back({dm.label_of_key(sp.label_key), (size_t)sp.off, (size_t)sp.len});
+            std::vector<uint32_t> per_read(R.n_reads, 0);
             for (const auto& sl : t.slices) ++per_read[sl.read_idx];
-            for (size_t i = 0; i < ids.size(); ++i) {
-                if (t.status[i] == BB_TRIM_TRIMMED) ++st.trimmed;
-                if (per_read[i] > 1) ++st.trimmed_split;
-                if (t.status[i] == BB_TRIM_FAILED) { ++st.trim_failed; if (failed_f) fprintf(failed_f, "%s\n", ids[i].c_str()); }
+            for (size_t i = 0; i < R.n_reads; ++i) {
+                if (t.status[i] == BB_TRIM_TRIMMED) ++R.trimmed;
+                if (per_read[i] > 1) ++R.split;
+                if (t.status[i] == BB_TRIM_FAILED) { ++R.trim_failed; if (failed_f) R.failed_ids.push_back(ids[i]); }
             }
         }
-        st.rows += rows.size();
-        t_rest += now() - t0;
+        R.t_rest = now() - t0;
+        return R;
     };
-    const size_t block = config.batch_reads ? std::max<size_t>(config.batch_reads * 4096, 4096) : std::max<size_t>(config.block_bytes, 4096);
-    bool all_gz = read_files.size() >= 2;
-    for (const auto& path : read_files) all_gz = all_gz && path.size() > 3 && path.compare(path.size() - 3, 3, ".gz") == 0;
-    try {
-        if (all_gz) {  // several gzip files: inflate them in parallel, consume them in order
-            ParallelInflater inf(read_files, config.n_threads);
-            for (size_t fi = 0; fi < read_files.size(); ++fi) {
-                double t0 = now();
-                const std::vector<uint8_t>& text = inf.get(fi);
-                t_read += now() - t0;
-                size_t pos = 0;
-                do {  // blocks of the file; the partial record at a block's end starts the next block
-                    const size_t len = std::min(block, text.size() - pos);
-                    const bool eof = pos + len == text.size();
-                    t0 = now();
-                    const auto ing = dm.ingest(text.data() + pos, len, eof);
-                    t_ingest += now() - t0;
-                    process(ing);
-                    if (!eof && ing.info.consumed == 0 && len == block)
-                        throw BarbellError(BB_E_FASTQ, "a FASTQ record of '" + read_files[fi] + "' is longer than the block size; raise --block-bytes");
-                    pos += eof ? len : (size_t)ing.info.consumed;
-                } while (pos < text.size());
-                inf.release(fi);
-            }
-        } else
-        for (const auto& path : read_files) {
-            BlockSource src(dm.ctx(), path, block);
-            size_t consumed = 0;
-            for (;;) {
-                double t0 = now();
-                const bool eof = src.next(consumed);  // waits for the chunk the reader thread has been filling
-                t_read += now() - t0; t0 = now();
-                const auto ing = dm.ingest(src.data, src.have, eof);
-                t_ingest += now() - t0;
-                process(ing);
-                consumed = (size_t)ing.info.consumed;
-                if (eof) break;
-            }
+    double t_commit = 0, t_ingest = 0, t_gpu = 0, t_rest = 0;
+    auto commit = [&](BlockResult& R) {
+        const double t0 = now();
+        st.total += R.n_reads; st.found += R.found; st.rows += R.rows; st.kept += R.kept; st.dropped += R.dropped;
+        st.trimmed += R.trimmed; st.trimmed_split += R.split; st.trim_failed += R.trim_failed;
+        auto put = [](FILE* f, bool& hdr, const std::vector<uint8_t>& text) {
+            if (!f || text.empty()) return;
+            if (!hdr) { fputs(TSV_HEADER, f); fputc('\n', f); hdr = true; }  // csv writer: header with the first record
+            if (fwrite(text.data(), 1, text.size(), f) != text.size()) throw BarbellError(BB_E_INVALID, "Failed to write annotation rows");
+        };
+        put(out, header, R.anno);
+        put(kept_f, kept_header, R.kept_tsv);
+        put(drop_f, drop_header, R.drop_tsv);
+        for (auto& pr : R.ppr) fprintf(ppr_f, "%s\t%s\n", pr.first.c_str(), pr.second.c_str());
+        for (auto& pat : R.patterns) {
+            auto it = pattern_count.find(pat);
+            if (it == pattern_count.end()) { pattern_count.emplace(pat, 1); pattern_order.push_back(pat); }
+            else ++it->second;
         }
+        for (auto& id : R.failed_ids) fprintf(failed_f, "%s\n", id.c_str());
+        if (writers && !R.spans.empty()) {
+            writers->wait(2);  // bounds the rendered text waiting for the writer thread
+            std::vector<LabelWriters::Span> job;
+            for (const auto& sp : R.spans) job.push_back({sp.label, R.text->data() + sp.off, sp.n, R.text});
+            writers->submit(std::move(job));
+        }
+        t_ingest += R.t_ingest; t_gpu += R.t_gpu; t_rest += R.t_rest;
+        t_commit += now() - t0;
+    };
+
+    // ---- the pipeline: readers -> sequencer (dispatcher thread) -> G workers -> ordered commit (this thread) -------
+    const size_t block = config.batch_reads ? std::max<size_t>(config.batch_reads * 4096, 4096) : std::max<size_t>(config.block_bytes, 4096);
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<std::deque<BlockFeeder::Block>> inq(G);
+    std::map<uint64_t, BlockResult> results;
+    bool feed_done = false, abort = false;
+    uint64_t n_blocks = 0, next_commit = 0;
+    std::exception_ptr first_err;
+    auto set_err = [&](std::exception_ptr e) { { std::lock_guard<std::mutex> lk(mu); if (!first_err) first_err = e; abort = true; } cv.notify_all(); };
+    double t_start = 0, t_end = 0;
+    try {
+        BlockFeeder feeder(dms[0]->ctx(), read_files, block, (unsigned)(3 * G + 2), std::min<unsigned>(std::max(1u, config.n_threads), 16u), config.n_threads);
+        t_start = now();
+        std::thread dispatcher([&]() {
+            try {
+                BlockFeeder::Block b;
+                while (feeder.next(b)) {
+                    std::unique_lock<std::mutex> lk(mu);
+                    auto& q = inq[b.index % G];
+                    cv.wait(lk, [&]() { return abort || q.size() < 2; });
+                    if (abort) return;
+                    q.push_back(b);
+                    ++n_blocks;
+                    cv.notify_all();
+                }
+            } catch (...) { set_err(std::current_exception()); }
+            { std::lock_guard<std::mutex> lk(mu); feed_done = true; }
+            cv.notify_all();
+        });
+        std::vector<std::thread> workers;
+        for (size_t w = 0; w < G; ++w)
+            workers.emplace_back([&, w]() {
+                try {
+                    for (;;) {
+                        BlockFeeder::Block b;
+                        {
+                            std::unique_lock<std::mutex> lk(mu);
+                            cv.wait(lk, [&]() { return abort || !inq[w].empty() || feed_done; });
+                            if (abort) return;
+                            if (inq[w].empty()) return;  // feed_done
+                            b = inq[w].front();
+                            // do not run far ahead of the committer (bounds the rendered text held in `results`); the block the
+                            // committer waits for is always inside the window, so this cannot deadlock
+                            cv.wait(lk, [&]() { return abort || b.index < next_commit + 2 * G + 2; });
+                            if (abort) return;
+                            inq[w].pop_front();
+                        }
+                        cv.notify_all();
+                        BlockResult R = process(*dms[w], b, feeder);
+                        {
+                            std::lock_guard<std::mutex> lk(mu);
+                            results.emplace(b.index, std::move(R));
+                        }
+                        cv.notify_all();
+                    }
+                } catch (...) { set_err(std::current_exception()); }
+            });
+        try {
+            for (;;) {
+                BlockResult R;
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&]() { return abort || results.count(next_commit) || (feed_done && next_commit >= n_blocks); });
+                    if (abort) break;
+                    if (!results.count(next_commit)) break;  // all committed
+                    R = std::move(results[next_commit]);
+                    results.erase(next_commit);
+                }
+                commit(R);
+                { std::lock_guard<std::mutex> lk(mu); ++next_commit; }
+                cv.notify_all();
+            }
+        } catch (...) { set_err(std::current_exception()); }
+        { std::lock_guard<std::mutex> lk(mu); if (first_err) abort = true; }
+        cv.notify_all();
+        feeder.fail(first_err ? "cancelled" : "");  // unblocks readers if we are bailing out (no-op message at the normal end)
+        dispatcher.join();
+        for (auto& t : workers) t.join();
+        t_end = now();
+        if (first_err) std::rethrow_exception(first_err);
         if (writers) writers->wait(0);  // all records on disk (or the writer's error rethrown) before the files are closed
     } catch (...) {
         close_all();
         throw;
     }
     close_all();
-    if (prof) fprintf(stderr, "profile: read %.3f s, ingest %.3f s, annotate %.3f s, tsv %.3f s, inspect/filter/trim %.3f s (inspect %.3f, filtered tsv %.3f, trim gpu+download %.3f, fastq write %.3f)\n",
-                      t_read, t_ingest, t_demux, t_write, t_rest, t_insp, t_ftsv, t_trim, t_fq);
+    st.seconds_pipeline = t_end - t_start;
+    // per-barcode histogram over all contexts (the one collective of the path)
+    {
+        std::vector<Demuxer*> ptrs;
+        for (auto& d : dms) ptrs.push_back(d.get());
+        const std::vector<uint64_t> total = allreduce_counts(ptrs, st.counts_reduce);
+        const std::vector<std::string> labels = dms[0]->slot_labels();
+        for (size_t i = 0; i < total.size(); ++i) st.counts.emplace_back(labels[i], total[i]);
+        if (!config.counts_file.empty()) {
+            FILE* cf = fopen(config.counts_file.c_str(), "w");
+            if (!cf) throw BarbellError(BB_E_INVALID, "Failed to create counts file '" + config.counts_file + "'");
+            size_t gi = 0, left = dms[0]->queries().empty() ? 0 : dms[0]->queries()[0].labels.size() + 1;
+            for (size_t i = 0; i < total.size(); ++i) {
+                fprintf(cf, "%zu\t%s\t%llu\n", gi, labels[i].c_str(), (unsigned long long)total[i]);
+                if (--left == 0 && gi + 1 < dms[0]->queries().size()) { ++gi; left = dms[0]->queries()[gi].labels.size() + 1; }
+            }
+            fclose(cf);
+        }
+    }
+    if (prof) fprintf(stderr, "profile: pipeline %.3f s for %zu reads (%.2f M reads/s) on %zu context(s); summed over blocks: upload+parse %.3f s, annotate+render %.3f s, "
+                      "filter/inspect/trim %.3f s; commit (file writes) %.3f s\n",
+                      st.seconds_pipeline, st.total, st.seconds_pipeline > 0 ? st.total / st.seconds_pipeline / 1e6 : 0.0, G, t_ingest, t_gpu, t_rest, t_commit);
     for (const auto& p : pattern_order) st.patterns.emplace_back(p, pattern_count[p]);
     std::stable_sort(st.patterns.begin(), st.patterns.end(), [](const auto& a, const auto& c) { return a.second > c.second; });
     return st;
@@ -1110,7 +1420,7 @@ AnnotateStats demux_using_kit(const std::vector<std::string>& fastq_files, const
     AnnotateConfig c;
     c.max_flank_errors = k.max_flank_errors; c.alpha = k.alpha; c.n_threads = (unsigned)k.threads; c.verbose = k.verbose;
     c.min_score = k.min_score; c.min_score_diff = k.min_score_diff; c.use_extended = k.use_extended;
-    c.batch_reads = k.batch_reads; c.device = k.device;
+    c.batch_reads = k.batch_reads; c.device = k.device; c.devices = k.devices; c.streams_per_device = k.streams_per_device; c.counts_file = k.counts_file;
     c.filter_patterns = kit_patterns(k.kit_name, k.maximize);
     c.filtered_file = k.output_folder + "/filtered.tsv";
     c.trim = TrimConfig::for_kit(k.failed_out, k.gzip);

@@ -25,6 +25,7 @@
 #include "../../../include/barbell_amd.h"
 #include "../../../include/barbell_amd_fastq.h"
 #include "../../../include/barbell_amd_filter.h"
+#include "../../../include/barbell_amd_format.h"
 #include "../../../include/barbell_amd_inspect.h"
 #include "../../../include/barbell_amd_trim.h"
 
@@ -147,7 +148,17 @@ public:
     // ingest() parses the block on the GPU (bb_fastq_ingest) and fetches only the headers; the *_ingested
     // calls run on the batch it left in HBM and download rows / verdicts / rendered text.
     struct Ingested { bb_fastq_info info{}; std::vector<std::string> ids; };
-    Ingested ingest(const uint8_t* text, uint64_t len, bool final_block);
+    Ingested ingest(const uint8_t* text, uint64_t len, bool final_block, bool want_ids = true);
+    // annotate the ingested batch; rows stay in HBM, their POD copy is rows() (no strings are built)
+    uint64_t annotate_ingested();
+    const bb_row* rows() const { return rows_.data(); }
+    uint64_t n_rows() const { return n_rows_; }
+    // TSV lines of the last batch's rows rendered on the GPU (bb_format_rows_dev): appended to `out`, returns the line count
+    uint64_t format_ingested(int mode, std::vector<uint8_t>& out);
+    // per-(group, barcode | flank) histogram of this context (bb_counts) and its labels, slot order
+    std::vector<uint64_t> counts();
+    std::vector<std::string> slot_labels() const;
+    int device() const { return device_; }
     bb_ctx* ctx() { ensure_ctx(); return ctx_; }  // for page-locked block buffers (bb_host_malloc)
     std::vector<BarbellMatch> demux_ingested();
     std::vector<bb_row_verdict> filter_ingested();
@@ -174,7 +185,7 @@ private:
     std::vector<BarbellMatch> rows_to_matches(const std::vector<std::string>& read_ids) const;
     bb_fastq_batch_dev batch_{};
     Ingested ing_;
-    DevBuf d_rows_, d_ver_, d_elems_, d_text_, d_slices_, d_spans_, d_status_;
+    DevBuf d_rows_, d_ver_, d_elems_, d_text_, d_slices_, d_spans_, d_status_, d_tsv_;
     // page-locked landing buffers of the rendered records (bb_host_malloc), used alternately so a writer thread
     // can still be flushing one batch's records while the next batch is downloaded
     uint8_t* h_text_[2] = {nullptr, nullptr};
@@ -192,6 +203,13 @@ struct AnnotateConfig {  // config.rs:3-12 with the CLI defaults of bin/main.rs:
     size_t batch_reads = 0;               // if set: block_bytes = batch_reads * 4096 (kept for CLI compatibility)
     size_t block_bytes = 128u << 20;      // raw FASTQ text handed to the GPU per ingest call (two page-locked buffers of this size)
     int device = 0;
+    // One FASTQ stream over several contexts: block i of the stream goes to context i mod G, rows are merged in
+    // block order, the per-barcode histogram is all-reduced (RCCL when the devices are distinct).  Empty = {device}
+    // repeated streams_per_device times; a device may appear more than once (several contexts on one GPU overlap the
+    // upload of one block with the kernels of another).
+    std::vector<int> devices;
+    unsigned streams_per_device = 2;
+    std::string counts_file;              // label <TAB> count of the all-reduced histogram
     // fused filter step: when filter_patterns is non-empty, rows of passing / failing reads go to
     // filtered_file / dropped_file with their cuts column (what `barbell filter -o/--dropped` writes)
     std::vector<Pattern> filter_patterns;
@@ -207,6 +225,9 @@ struct AnnotateConfig {  // config.rs:3-12 with the CLI defaults of bin/main.rs:
 struct AnnotateStats {
     size_t total = 0, found = 0, rows = 0, kept = 0, dropped = 0, trimmed = 0, trimmed_split = 0, trim_failed = 0;
     std::vector<std::pair<std::string, size_t>> patterns;  // inspect: pattern -> count, most common first
+    std::vector<std::pair<std::string, uint64_t>> counts;  // (label, rows) summed over all contexts, slot order
+    std::string counts_reduce;                              // "rccl" | "host" | "single": how the histogram was summed
+    double seconds_pipeline = 0;                            // first block read .. last block committed (steady state, no start-up)
 };
 std::vector<std::string> inspect_summary(const AnnotateStats& st, size_t top_n);  // the lines of inspect.rs:186-205
 
@@ -222,6 +243,9 @@ struct KitConfig {  // config.rs:34-48, CLI defaults bin/main.rs:208-262
     bool gzip = false;
     size_t batch_reads = 0;
     int device = 0;
+    std::vector<int> devices;
+    unsigned streams_per_device = 2;
+    std::string counts_file;
 };
 AnnotateStats demux_using_kit(const std::vector<std::string>& fastq_files, const KitConfig& config);  // use_kit.rs:11-109
 

@@ -291,3 +291,49 @@ def test_cli_many_gzip_files_parallel_inflate(tmp_path):
     assert outs["one"].keys() == outs["many"].keys() and len(outs["one"]) > 20
     for k in outs["one"]:
         assert outs["one"][k] == outs["many"][k], k
+
+
+@pytest.mark.gpu
+def test_one_stream_over_several_contexts(tmp_path):
+    """SURVEY §8e / VERDICT r01 #6: one FASTQ stream, block i -> context i mod G, rows merged in block order, histogram
+    summed over the contexts.  With one GPU in the box the contexts share device 0 (--devices 0,0,0): annotation.tsv,
+    filtered.tsv, the per-barcode FASTQ files and the counts must be byte-identical to the single-context run, and equal
+    to the rows' own label counts; BARBELL_AMD_FORCE_RCCL=1 sends a single context's histogram through ncclAllReduce."""
+    from barbell_amd import annotate as A
+
+    groups = kits.groups_from_kit("SQK-NBD114-96", flank_max_errors=3)
+    n = 3000
+    bases, offsets = A.synth_reads_host(groups, 99, 500, 3000, 0, n)
+    ids = [f"r{i}" for i in range(n)]
+    fqs = []
+    for part in range(2):  # two input files: the stream continues across them
+        fq = tmp_path / f"reads{part}.fastq"
+        lo, hi = part * n // 2, (part + 1) * n // 2
+        write_fastq(fq, ids[lo:hi], bases[int(offsets[lo]):int(offsets[hi])], offsets[lo:hi + 1] - offsets[lo])
+        fqs.append(str(fq))
+    env = dict(os.environ, BARBELL_AMD_NO_TORCH="1")
+    outs = {}
+    for name, extra, e in (("one", ["--devices", "0"], env), ("three", ["--devices", "0,0,0"], env), ("default", [], env),
+                           ("rccl1", ["--devices", "0"], dict(env, BARBELL_AMD_FORCE_RCCL="1"))):
+        d = tmp_path / name
+        d.mkdir()
+        r = subprocess.run([CLI, "annotate", "-i"] + fqs + ["-o", str(d / "a.tsv"), "--kit", "SQK-NBD114-96", "--flank-max-errors", "3",
+                            "--block-bytes", "300000", "--kit-filter", "--maximize", "--filtered", str(d / "f.tsv"), "--trim-output", str(d / "trim"),
+                            "--counts", str(d / "counts.tsv")] + extra, capture_output=True, text=True, env=e)
+        assert r.returncode == 0, r.stderr
+        files = {"a": (d / "a.tsv").read_bytes(), "f": (d / "f.tsv").read_bytes(), "c": (d / "counts.tsv").read_bytes()}
+        for f in sorted(os.listdir(d / "trim")):
+            files["trim/" + f] = (d / "trim" / f).read_bytes()
+        outs[name] = (files, r.stderr)
+    assert "histogram summed by single" in outs["one"][1] and "summed by host" in outs["three"][1] and "summed by rccl" in outs["rccl1"][1]
+    for name in ("three", "default", "rccl1"):
+        assert outs[name][0].keys() == outs["one"][0].keys()
+        for k in outs["one"][0]:
+            assert outs[name][0][k] == outs["one"][0][k], (name, k)
+    # counts.tsv = rows per label of annotation.tsv
+    rows = [l.split("\t") for l in outs["one"][0]["a"].decode().splitlines()[1:]]
+    from collections import Counter
+    want = Counter(r[12] for r in rows)
+    got = {l.split("\t")[1]: int(l.split("\t")[2]) for l in outs["one"][0]["c"].decode().splitlines()}
+    assert sum(got.values()) == len(rows) and all(got[k] == v for k, v in want.items())
+    assert len(outs["one"][0]) > 20  # many per-barcode files
