@@ -128,6 +128,8 @@ int main(int argc, char** argv) {
             for (const auto& l : inspect_summary(st, 10)) puts(l.c_str());
             printf("Annotated %zu of %zu reads; filter kept %zu, dropped %zu; trimmed %zu (%zu split, %zu failed)\nDone!\n", st.found, st.total,
                    st.kept, st.dropped, st.trimmed, st.trimmed_split, st.trim_failed);
+            fprintf(stderr, "Done: %zu records (%.2f s in the pipeline, %.2f M reads/s; histogram summed by %s)\n", st.total, st.seconds_pipeline,
+                    st.seconds_pipeline > 0 ? st.total / st.seconds_pipeline / 1e6 : 0.0, st.counts_reduce.c_str());
         } catch (const BarbellError& e) { fprintf(stderr, "error: %s\n", e.what()); return 1; }
         return 0;
     }
