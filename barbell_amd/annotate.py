@@ -253,7 +253,9 @@ def split_fastq_header(header):  # src/io/io.rs:6-17: id up to the first whitesp
 
 def read_fastq_records(path):
     """Yields (header line without '@', seq, qual) as bytes.  Plain or gzip FASTQ, 4-line records."""
-    op = gzip.open if str(path).endswith(".gz") else open
+    from .fastq import is_gzip
+
+    op = gzip.open if is_gzip(path) else open
     with op(path, "rb") as f:
         while True:
             h = f.readline()

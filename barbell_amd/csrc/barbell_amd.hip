@@ -368,15 +368,16 @@ int scan_u32(bb_ctx* c, const uint32_t* in, uint32_t* out, uint64_t n) {
 
 template <int W>
 void launch_scan(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n, uint32_t g) {
-    if (!c->scan_v1) {
+    if (!c->scan_v1 || W > 4) {
         hipLaunchKernelGGL(k_flank_scan2<W>, dim3((n + 255) / 256, 2), dim3(256), 0, c->stream, d_bases, d_offsets, n,
                            (const uint8_t*)c->d_tables, (const bb_group_dev*)c->d_groups, g, (uint32_t)c->groups.size(), c->d_cnt,
                            c->d_raw, c->cap_hits, c->d_hitcount);
         return;
     }
-    hipLaunchKernelGGL(k_flank_scan<W>, dim3((n + 255) / 256), dim3(256), 0, c->stream, d_bases, d_offsets, n,
-                       (const uint8_t*)c->d_tables, (const bb_group_dev*)c->d_groups, g, (uint32_t)c->groups.size(), c->d_cnt,
-                       c->d_raw, c->cap_hits, c->d_hitcount);
+    if constexpr (W <= 4)  // the first-generation kernel exists for the tuned widths only
+        hipLaunchKernelGGL(k_flank_scan<W>, dim3((n + 255) / 256), dim3(256), 0, c->stream, d_bases, d_offsets, n,
+                           (const uint8_t*)c->d_tables, (const bb_group_dev*)c->d_groups, g, (uint32_t)c->groups.size(), c->d_cnt,
+                           c->d_raw, c->cap_hits, c->d_hitcount);
 }
 template <int W>
 void launch_trace(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n_hits, uint32_t g) {
@@ -387,9 +388,10 @@ void launch_trace(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets, 
                       (const bb_hit_raw*)c->d_raw, n_hits, (const uint32_t*)c->d_base, c->d_hits, g
     if (D.flank_k <= 6 && !c->force_generic && !getenv("BARBELL_AMD_TRACE_FULL"))  // band of 2(k+1)+1 <= 15 rows in 16 bits
         hipLaunchKernelGGL((k_flank_trace<W, 2>), dim3((n_hits + 63) / 64), dim3(64), lds_band, c->stream, BB_TRACE_ARGS);
-    else if (lds <= 64 * 1024 && !c->force_generic)
-        hipLaunchKernelGGL((k_flank_trace<W, 1>), dim3((n_hits + 63) / 64), dim3(64), lds, c->stream, BB_TRACE_ARGS);
-    else
+    else if (W <= 4 && lds <= 64 * 1024 && !c->force_generic) {
+        if constexpr (W <= 4)  // the full-height LDS variant never fits beyond 4 words
+            hipLaunchKernelGGL((k_flank_trace<W, 1>), dim3((n_hits + 63) / 64), dim3(64), lds, c->stream, BB_TRACE_ARGS);
+    } else
         hipLaunchKernelGGL((k_flank_trace<W, 0>), dim3((n_hits + 63) / 64), dim3(64), 0, c->stream, BB_TRACE_ARGS);
 #undef BB_TRACE_ARGS
 }
@@ -478,6 +480,8 @@ void mark(bb_ctx* c, int i) {
 
 }  // namespace
 
+static thread_local std::string g_create_error;  // why the last bb_create on this thread failed (bb_last_error(NULL))
+
 extern "C" {
 
 const char* bb_strerror(int code) {
@@ -500,7 +504,9 @@ const char* bb_strerror(int code) {
 }
 
 int bb_create(const bb_group_desc* groups, uint32_t n_groups, const bb_params* params, bb_ctx** out) {
-    if (!groups || !params || !out || n_groups == 0 || n_groups > BB_MAX_GROUPS) return BB_E_INVALID;
+    g_create_error.clear();
+    if (!groups || !params || !out || n_groups == 0) return BB_E_INVALID;
+    if (n_groups > BB_MAX_GROUPS) { g_create_error = "more than 8 query groups"; return BB_E_UNSUPPORTED; }
     if (!(params->alpha >= 0.0f)) return BB_E_INVALID;
     bb_ctx* c = new bb_ctx();
     c->params = *params;
@@ -512,9 +518,17 @@ int bb_create(const bb_group_desc* groups, uint32_t n_groups, const bb_params* p
         int r = prep_group(groups[i], params->alpha, c->groups[i]);
         if (r != BB_OK) { delete c; return r; }
         const bb_group_info& I = c->groups[i].info;
-        if (I.flank_len > 32 * BB_MAX_W || I.pattern_len > 32 * BB_MAX_WB || I.flank_k > 63 ||
-            I.mask_len + (uint32_t)I.flank_k + 2 * BB_PADDING > BB_MAX_WIN || groups[i].n_seqs > 1024 ||
-            groups[i].n_seqs > 32767) {
+        // geometry the kernels were not built for (the reference has no such limits, barcodes.rs:105-197): the table in
+        // include/barbell_amd.h; the detail is left for bb_last_error(NULL)
+        char why[200] = "";
+        if (I.flank_len > 32 * BB_MAX_W) snprintf(why, sizeof why, "group %u: flank of %u nt (prefix + barcode mask + suffix) exceeds %d", i, I.flank_len, 32 * BB_MAX_W);
+        else if (I.pattern_len > 32 * BB_MAX_WB) snprintf(why, sizeof why, "group %u: padded barcode pattern of %u nt exceeds %d", i, I.pattern_len, 32 * BB_MAX_WB);
+        else if (I.flank_k > 63) snprintf(why, sizeof why, "group %u: flank error budget %d exceeds 63", i, I.flank_k);
+        else if (I.mask_len + (uint32_t)I.flank_k + 2 * BB_PADDING > BB_MAX_WIN)
+            snprintf(why, sizeof why, "group %u: barcode window (barcode %u + flank errors %d + 20) exceeds %d columns", i, I.mask_len, I.flank_k, BB_MAX_WIN);
+        else if (groups[i].n_seqs > 1024) snprintf(why, sizeof why, "group %u: %u sequences exceed 1024", i, groups[i].n_seqs);
+        if (why[0]) {
+            g_create_error = why;
             delete c;
             return BB_E_UNSUPPORTED;
         }
@@ -591,7 +605,11 @@ int bb_annotate_batch_dev(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_o
                 case 1: launch_scan<1>(c, d_bases, d_offsets, n, g); break;
                 case 2: launch_scan<2>(c, d_bases, d_offsets, n, g); break;
                 case 3: launch_scan<3>(c, d_bases, d_offsets, n, g); break;
-                default: launch_scan<4>(c, d_bases, d_offsets, n, g); break;
+                case 4: launch_scan<4>(c, d_bases, d_offsets, n, g); break;
+                case 5: launch_scan<5>(c, d_bases, d_offsets, n, g); break;
+                case 6: launch_scan<6>(c, d_bases, d_offsets, n, g); break;
+                case 7: launch_scan<7>(c, d_bases, d_offsets, n, g); break;
+                default: launch_scan<8>(c, d_bases, d_offsets, n, g); break;
             }
         }
         HIPCHK(c, hipGetLastError());
@@ -610,7 +628,11 @@ int bb_annotate_batch_dev(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_o
                 case 1: launch_trace<1>(c, d_bases, d_offsets, n_hits, g); break;
                 case 2: launch_trace<2>(c, d_bases, d_offsets, n_hits, g); break;
                 case 3: launch_trace<3>(c, d_bases, d_offsets, n_hits, g); break;
-                default: launch_trace<4>(c, d_bases, d_offsets, n_hits, g); break;
+                case 4: launch_trace<4>(c, d_bases, d_offsets, n_hits, g); break;
+                case 5: launch_trace<5>(c, d_bases, d_offsets, n_hits, g); break;
+                case 6: launch_trace<6>(c, d_bases, d_offsets, n_hits, g); break;
+                case 7: launch_trace<7>(c, d_bases, d_offsets, n_hits, g); break;
+                default: launch_trace<8>(c, d_bases, d_offsets, n_hits, g); break;
             }
         }
         HIPCHK(c, hipGetLastError());
@@ -811,7 +833,7 @@ int bb_n_kernels(void) { return K_COUNT; }
 const char* bb_kernel_name(int k) { return k >= 0 && k < K_COUNT ? kKernelNames[k] : ""; }
 float bb_last_kernel_ms(const bb_ctx* c, int k) { return c && k >= 0 && k < K_COUNT ? c->ms[k] : 0.f; }
 void bb_set_timing(bb_ctx* c, int enable) { if (c) c->timing = enable != 0; }
-const char* bb_last_error(const bb_ctx* c) { return c ? c->last_error.c_str() : ""; }
+const char* bb_last_error(const bb_ctx* c) { return c ? c->last_error.c_str() : g_create_error.c_str(); }
 
 // ---- filter step (include/barbell_amd_filter.h) ---------------------------------------------------
 int bb_filter_set(bb_ctx* c, const bb_pattern* patterns, uint32_t n_patterns, const uint32_t* label_ids) {

@@ -12,7 +12,7 @@
 #endif
 
 #define BB_PADDING 10      // src/lib.rs:10
-#define BB_MAX_W 4         // flank pattern words (m <= 128)
+#define BB_MAX_W 8         // flank pattern words (m <= 256); W <= 4 are the tuned instantiations, 5..8 the wide ones
 #define BB_MAX_WB 2        // padded barcode pattern words (m_bar <= 64)
 #define BB_MAX_WIN 128     // barcode window columns
 #define BB_MAX_GROUPS 8
@@ -93,7 +93,7 @@ struct __attribute__((aligned(16))) bb_hit_pfx {
 };
 static_assert(sizeof(bb_hit_pfx) == 304, "bb_hit_pfx: 19 x 16 bytes");
 
-BB_HD int bb_peq_stride_words(int W) { return W <= 2 ? 2 : 4; }
+BB_HD int bb_peq_stride_words(int W) { return W <= 2 ? 2 : (W <= 4 ? 4 : 8); }
 
 // unordered flank hit, written by the scan kernel
 struct bb_hit_raw {

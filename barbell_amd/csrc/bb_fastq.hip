@@ -116,7 +116,23 @@ __global__ __launch_bounds__(256) void k_nl_write(const uint16_t* __restrict__ m
     }
 }
 
-__device__ __forceinline__ bool is_ws(uint8_t c) { return c == ' ' || (c >= 9 && c <= 13); }
+// byte length of the whitespace character (char::is_whitespace, io.rs:6-17: Unicode White_Space, UTF-8 encoded) that
+// starts at p[0]; 0 if there is none.  n = bytes available.
+__device__ __forceinline__ uint32_t ws_len(const uint8_t* __restrict__ p, uint32_t n) {
+    const uint8_t c = p[0];
+    if (c == ' ' || (c >= 9 && c <= 13)) return 1u;
+    if (c < 0xC2u) return 0u;
+    if (c == 0xC2u) return (n >= 2u && (p[1] == 0x85u || p[1] == 0xA0u)) ? 2u : 0u;          // U+0085, U+00A0
+    if (n < 3u) return 0u;
+    const uint8_t d = p[1], e = p[2];
+    if (c == 0xE1u) return (d == 0x9Au && e == 0x80u) ? 3u : 0u;                               // U+1680
+    if (c == 0xE2u) {
+        if (d == 0x80u) return (e <= 0x8Au && e >= 0x80u) || e == 0xA8u || e == 0xA9u || e == 0xAFu ? 3u : 0u;  // U+2000-200A, 2028, 2029, 202F
+        return (d == 0x81u && e == 0x9Fu) ? 3u : 0u;                                           // U+205F
+    }
+    if (c == 0xE3u) return (d == 0x80u && e == 0x80u) ? 3u : 0u;                               // U+3000
+    return 0u;
+}
 
 // line i of the block: [start, end) without the newline and without a trailing '\r'
 __device__ __forceinline__ void line_span(const uint8_t* __restrict__ text, const uint64_t* __restrict__ nl, uint64_t i, uint64_t& s, uint64_t& e) {
@@ -141,10 +157,10 @@ __global__ __launch_bounds__(256) void k_fq_records(const uint8_t* __restrict__ 
     const uint32_t hl = he > hs ? (uint32_t)(he - hs - 1) : 0u;  // header without '@'
     uint32_t idl = hl, ds = hl;
     for (uint32_t p = 0; p < hl; ++p)
-        if (is_ws(text[hs + 1 + p])) { idl = p; break; }
+        if (ws_len(text + hs + 1 + p, hl - p)) { idl = p; break; }
     if (idl < hl) {
         ds = idl;
-        while (ds < hl && is_ws(text[hs + 1 + ds])) ++ds;
+        for (uint32_t w; ds < hl && (w = ws_len(text + hs + 1 + ds, hl - ds)) != 0u;) ds += w;
     }
     seq_len[k] = (uint32_t)(se - ss);
     hdr_len[k] = hl;

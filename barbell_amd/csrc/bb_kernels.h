@@ -123,12 +123,19 @@ __device__ __forceinline__ void load_eq(const uint32_t* tab, uint32_t c, uint32_
         uint2 v = *reinterpret_cast<const uint2*>(tab + c * 2);
         eq[0] = v.x;
         if constexpr (W > 1) eq[1] = v.y;
-    } else {
+    } else if constexpr (S == 4) {
         uint4 v = *reinterpret_cast<const uint4*>(tab + c * 4);
         eq[0] = v.x;
         if constexpr (W > 1) eq[1] = v.y;
         if constexpr (W > 2) eq[2] = v.z;
         if constexpr (W > 3) eq[3] = v.w;
+    } else {
+        const uint4 v = *reinterpret_cast<const uint4*>(tab + c * 8), u = *reinterpret_cast<const uint4*>(tab + c * 8 + 4);
+        eq[0] = v.x; eq[1] = v.y; eq[2] = v.z; eq[3] = v.w;
+        eq[4] = u.x;
+        if constexpr (W > 5) eq[5] = u.y;
+        if constexpr (W > 6) eq[6] = u.z;
+        if constexpr (W > 7) eq[7] = u.w;
     }
 }
 
@@ -175,7 +182,7 @@ __global__ __launch_bounds__(256) void k_flank_scan(const uint8_t* __restrict__ 
                                                     const bb_group_dev* __restrict__ groups, uint32_t g, uint32_t n_groups,
                                                     uint32_t* __restrict__ cnt, bb_hit_raw* __restrict__ hits,
                                                     uint32_t hit_cap, uint32_t* __restrict__ hit_count) {
-    constexpr int S = (W <= 2 ? 2 : 4);
+    constexpr int S = (W <= 2 ? 2 : (W <= 4 ? 4 : 8));
     __shared__ __attribute__((aligned(16))) uint32_t s_peq[2][256 * S];
     const bb_group_dev G = groups[g];
     {
@@ -305,7 +312,7 @@ __device__ __forceinline__ void flank_scan_lane(const uint8_t* __restrict__ base
                                                 uint32_t g, uint32_t n_groups, uint32_t* __restrict__ cnt,
                                                 bb_hit_raw* __restrict__ hits, uint32_t hit_cap, uint32_t* __restrict__ hit_count,
                                                 const uint32_t* s_peq, uint4* s_line /* this wave's [BB_SCAN_LQ][64] */) {
-    constexpr int S = (W <= 2 ? 2 : 4);
+    constexpr int S = (W <= 2 ? 2 : (W <= 4 ? 4 : 8));
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t read = blockIdx.x * 256u + threadIdx.x;
     const bool live = read < n_reads;
@@ -473,7 +480,7 @@ __global__ __launch_bounds__(256) void k_flank_scan2(const uint8_t* __restrict__
                                                      const bb_group_dev* __restrict__ groups, uint32_t g, uint32_t n_groups,
                                                      uint32_t* __restrict__ cnt, bb_hit_raw* __restrict__ hits,
                                                      uint32_t hit_cap, uint32_t* __restrict__ hit_count) {
-    constexpr int S = (W <= 2 ? 2 : 4);
+    constexpr int S = (W <= 2 ? 2 : (W <= 4 ? 4 : 8));
     __shared__ __attribute__((aligned(16))) uint32_t s_peq[256 * S];
     __shared__ __attribute__((aligned(16))) uint4 s_lines[4][BB_SCAN_LQ * 64];
     const bb_group_dev* G = groups + g;
@@ -559,7 +566,7 @@ __global__ __launch_bounds__(64) void k_flank_trace(const uint8_t* __restrict__ 
                                                     const uint8_t* __restrict__ tables, const bb_group_dev* __restrict__ groups,
                                                     uint32_t n_groups, const bb_hit_raw* __restrict__ raw, uint32_t n_hits,
                                                     const uint32_t* __restrict__ slot_base, bb_hit* __restrict__ hits, uint32_t g_sel) {
-    constexpr int S = (W <= 2 ? 2 : 4);
+    constexpr int S = (W <= 2 ? 2 : (W <= 4 ? 4 : 8));
     constexpr int MAXC = 32 * W + 64;
     const uint32_t t = blockIdx.x * 64u + threadIdx.x;
     if (t >= n_hits) return;

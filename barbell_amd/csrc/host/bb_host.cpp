@@ -428,7 +428,11 @@ void Demuxer::set_filter(const std::vector<Pattern>& patterns) {
                 oks.push_back(std::move(ok));
                 c.label_ok = oks.back().data();
             }
-            for (size_t q = 0; q < e.cuts.size(); ++q) c.cuts[q] = bb_cut{(uint8_t)(e.cuts[q].after ? BB_CUT_AFTER : BB_CUT_BEFORE), 0, (uint16_t)e.cuts[q].group_id};
+            if (e.cuts.size() > BB_MAX_CUTS) throw BarbellError(BB_E_UNSUPPORTED, "more than 3 cut markers on one pattern element (kernel limit, include/barbell_amd_filter.h)");
+            for (size_t q = 0; q < e.cuts.size(); ++q) {
+                if (e.cuts[q].group_id > 0xFFFF) throw BarbellError(BB_E_UNSUPPORTED, "cut group id above 65535 (kernel limit, include/barbell_amd_filter.h)");
+                c.cuts[q] = bb_cut{(uint8_t)(e.cuts[q].after ? BB_CUT_AFTER : BB_CUT_BEFORE), 0, (uint16_t)e.cuts[q].group_id};
+            }
             elems[i].push_back(c);
         }
         pats[i] = bb_pattern{elems[i].data(), (uint32_t)elems[i].size()};
@@ -773,13 +777,14 @@ struct ParallelInflater {
     std::vector<char> gz;    // files that are not gzip are skipped (the feeder reads them directly)
     std::vector<std::vector<uint8_t>> data;
     std::vector<int> state;  // 0 = not started, 1 = in progress, 2 = ready, 3 = consumed
+    std::vector<uint64_t> inflated_size;
     std::vector<std::thread> pool;
     std::mutex mu;
     std::condition_variable cv;
     size_t next_file = 0, consumed_upto = 0, ahead;
     std::string err;
     ParallelInflater(std::vector<std::string> p, std::vector<char> is_gz, unsigned n_threads)
-        : paths(std::move(p)), gz(std::move(is_gz)), data(paths.size()), state(paths.size(), 0) {
+        : paths(std::move(p)), gz(std::move(is_gz)), data(paths.size()), state(paths.size(), 0), inflated_size(paths.size(), 0) {
         const unsigned nt = std::max(1u, std::min<unsigned>(n_threads, (unsigned)paths.size()));
         ahead = nt + 2;  // files inflated but not yet consumed: bounds the memory
         for (unsigned i = 0; i < nt; ++i) pool.emplace_back([this]() { work(); });
@@ -816,6 +821,7 @@ struct ParallelInflater {
             {
                 std::lock_guard<std::mutex> lk(mu);
                 if (!e.empty() && err.empty()) err = e;
+                inflated_size[i] = buf.size();
                 data[i] = std::move(buf);
                 state[i] = 2;
             }
@@ -828,6 +834,14 @@ struct ParallelInflater {
         cv.wait(lk, [&]() { return state[i] == 2 || !err.empty(); });
         if (!err.empty()) throw BarbellError(BB_E_INVALID, err);
         return data[i];
+    }
+    // size of the inflated file, once known; stays valid after release(i) (another reader may have consumed the file
+    // while this one was still waiting to learn its size)
+    uint64_t size_of(size_t i) {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&]() { return state[i] >= 2 || !err.empty(); });
+        if (state[i] < 2) throw BarbellError(BB_E_INVALID, err);
+        return inflated_size[i];
     }
     void release(size_t i) {
         {
@@ -1012,9 +1026,9 @@ bool BlockFeeder::claim(Task& t) {
                 return true;
             }
         }
-        const std::vector<uint8_t>& img = inflater->get(f);  // blocks until inflated (thread-safe, several readers may wait)
+        const uint64_t isz = inflater->size_of(f);  // blocks until inflated (thread-safe, several readers may wait)
         std::lock_guard<std::mutex> lk(mu);
-        if (!size_known[f]) { sizes[f] = img.size(); size_known[f] = 1; chunks_left[f] = std::max<uint64_t>(1, (img.size() + chunk - 1) / chunk); }
+        if (!size_known[f]) { sizes[f] = isz; size_known[f] = 1; chunks_left[f] = std::max<uint64_t>(1, (isz + chunk - 1) / chunk); }
     }
 }
 void BlockFeeder::reader_loop() {

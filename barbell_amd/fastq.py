@@ -58,8 +58,19 @@ def fetch(dm, info, bases=False, quals=False):
 
 def read_ids(a):
     """read ids (header up to the first whitespace) of a fetched batch"""
+    from .annotate import BarbellError
+
     blob, off, idl = a["hdr"].tobytes(), a["hdr_offsets"], a["id_len"]
-    return [blob[int(off[i]): int(off[i]) + int(idl[i])].decode() for i in range(len(idl))]
+    try:
+        return [blob[int(off[i]): int(off[i]) + int(idl[i])].decode() for i in range(len(idl))]
+    except UnicodeDecodeError as e:  # the reference: "FASTQ header is not valid UTF-8" (annotator.rs:124-125)
+        raise BarbellError(_abi.BB_E_FASTQ, f"FASTQ header is not valid UTF-8 ({e})") from None
+
+
+def is_gzip(path):
+    """gzip by its magic bytes, not by its name (the C++ host's gzopen and the reference's reader sniff too)"""
+    with open(path, "rb") as f:
+        return f.read(2) == b"\x1f\x8b"
 
 
 class BlockReader:
@@ -71,7 +82,7 @@ class BlockReader:
 
     def __iter__(self):
         for path in self.paths:
-            op = gzip.open if str(path).endswith(".gz") else open
+            op = gzip.open if is_gzip(path) else open
             with op(path, "rb") as f:
                 nxt = f.read(self.block_bytes)
                 while True:

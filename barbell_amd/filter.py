@@ -183,11 +183,16 @@ def compile_patterns(patterns, groups):
     label_ids = np.array([ids.setdefault(l, len(ids)) for l in labels], dtype=np.uint32)
     arr = (PatternC * max(1, len(patterns)))()
     keep = []
+    for p in patterns:
+        if len({e.placeholder for e in p.elements if e.placeholder >= 0}) > 16:
+            raise ValueError("more than 16 distinct ?N placeholders in one pattern (kernel limit, include/barbell_amd_filter.h)")
     for i, p in enumerate(patterns):
         elems = (PatternElemC * len(p.elements))()
         for j, e in enumerate(p.elements):
             if len(e.cuts) > MAX_CUTS:
-                raise ValueError("more than 3 cut markers on one pattern element")
+                raise ValueError("more than 3 cut markers on one pattern element (kernel limit, include/barbell_amd_filter.h)")
+            if any(cut.group_id > 0xFFFF for cut in e.cuts):
+                raise ValueError("cut group id above 65535 (kernel limit, include/barbell_amd_filter.h)")
             c = elems[j]
             c.match_type, c.orientation, c.relative_to, c.n_cuts = e.match_type, e.orientation, e.relative_to, len(e.cuts)
             c.placeholder, c.range_lo, c.range_hi = e.placeholder, e.range[0], e.range[1]

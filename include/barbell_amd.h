@@ -39,9 +39,20 @@ extern "C" {
 #define BB_E_CAPACITY      -7  /* caller's row buffer too small; *n_rows holds the required count    */
 #define BB_E_NO_DEVICE     -8  /* no gfx950 device / HIP runtime failure at create                   */
 #define BB_E_HIP           -9  /* HIP runtime error during a batch (see bb_last_error)               */
-#define BB_E_UNSUPPORTED  -10  /* geometry outside what the kernels were built for (see bb_limits)   */
+#define BB_E_UNSUPPORTED  -10  /* geometry outside what the kernels were built for (table below)    */
 #define BB_E_NOMEM        -11
 #define BB_E_FASTQ        -12  /* malformed FASTQ record (barbell_amd_fastq.h)                         */
+
+/* ---- limits (the reference's BarcodeGroup::new, barcodes.rs:105-197, has none; every shipped kit fits) --------
+ *   query groups per context                      <= 8
+ *   sequences per group                           <= 1024
+ *   flank = prefix + barcode mask + suffix        <= 256 nt (<= 128 nt run the tuned scan/trace instantiations)
+ *   padded barcode pattern (10 + barcode + 10)    <= 64 nt  (<= 48 nt and windows <= 64 columns: register-resident kernels)
+ *   flank error budget (--flank-max-errors)       <= 63
+ *   barcode window = barcode + flank errors + 20  <= 128 columns
+ *   filter: cut markers per pattern element <= 3, cut group id <= 65535, distinct ?N placeholders per pattern <= 16
+ *   trim: cut entries per read <= 32
+ * bb_create returns BB_E_UNSUPPORTED beyond them and leaves the reason for bb_last_error(NULL).                */
 
 /* ---- match_type / strand encodings (searcher.rs:31-75, barcodes.rs:8-33) ------------------ */
 #define BB_FTAG   0
@@ -155,7 +166,8 @@ int  bb_host_malloc(bb_ctx* ctx, uint64_t bytes, void** ptr);
 void bb_host_free(bb_ctx* ctx, void* ptr);
 
 const char* bb_strerror(int code);
-const char* bb_last_error(const bb_ctx* ctx);   /* detail of the last BB_E_HIP / BB_E_UNSUPPORTED */
+const char* bb_last_error(const bb_ctx* ctx);   /* detail of the last BB_E_HIP / BB_E_UNSUPPORTED; ctx == NULL: of the
+                                                   last failed bb_create on this thread                          */
 
 #ifdef __cplusplus
 }

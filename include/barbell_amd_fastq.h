@@ -38,7 +38,10 @@ typedef struct {
 /* Parses text[0, text_len).  final_block != 0: the text is the end of the stream — a last line without
  * '\n' counts, trailing blank lines are ignored, and a trailing partial record is an error; otherwise
  * the partial tail is left to the caller (info->consumed).  "\r\n" line ends are accepted.
- * The host variant uploads the block first; d_text of the _dev variant must be 16-byte aligned.        */
+ * The host variant uploads the block first; d_text of the _dev variant must be 16-byte aligned and the allocation
+ * must extend at least 15 bytes past text_len (the newline pass reads whole 16-byte pieces; the padding's content
+ * does not matter).  Header split: the read id ends at the first `char::is_whitespace` character (ASCII and the
+ * UTF-8 encoded Unicode White_Space code points, io.rs:6-17); header bytes are not validated as UTF-8.            */
 int bb_fastq_ingest(bb_ctx* ctx, const uint8_t* text, uint64_t text_len, int final_block, bb_fastq_info* info,
                     bb_fastq_batch_dev* batch);
 int bb_fastq_ingest_dev(bb_ctx* ctx, const uint8_t* d_text, uint64_t text_len, int final_block, bb_fastq_info* info,

@@ -14,6 +14,11 @@
 extern "C" {
 #endif
 
+/* Limits of the filter kernel the reference does not have (its `cuts: Option<Vec<Cut>>` and placeholder map are
+ * unbounded, pattern.rs:21-30,128-145); bb_filter_set and both host parsers reject what exceeds them with
+ * BB_E_UNSUPPORTED instead of truncating: <= BB_MAX_CUTS cut markers per pattern element, cut group ids <= 65535,
+ * <= 16 distinct ?N placeholders per pattern.  The trim planner takes <= 32 cut entries per read (bb_trim_batch
+ * returns BB_E_UNSUPPORTED beyond).  None of the kit pattern sets comes near them.                         */
 #define BB_MAX_CUTS 3          /* cut markers per pattern element / per row                      */
 #define BB_CUT_BEFORE 0        /* "<<" : cut at match start (pattern.rs:9-12)                    */
 #define BB_CUT_AFTER  1        /* ">>" : cut at match end                                        */

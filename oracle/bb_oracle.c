@@ -973,7 +973,20 @@ int bbo_inspect_rows(const bb_row* rows, const bb_row_verdict* verdicts, uint64_
 /* ------------------------------------------------------------------------------------------ */
 /* FASTQ ingest: 4-line records + split_fastq_header (io.rs:6-17), scalar       */
 /* ------------------------------------------------------------------------------------------ */
-static int is_ws_c(uint8_t c) { return c == ' ' || (c >= 9 && c <= 13); }
+/* byte length of the char::is_whitespace character (Unicode White_Space, UTF-8) starting at p, 0 if none (io.rs:6-17) */
+static uint32_t ws_len_c(const uint8_t* p, uint64_t n) {
+    uint8_t c = p[0];
+    if (c == ' ' || (c >= 9 && c <= 13)) return 1;
+    if (c == 0xC2) return (n >= 2 && (p[1] == 0x85 || p[1] == 0xA0)) ? 2 : 0;
+    if (n < 3) return 0;
+    if (c == 0xE1) return (p[1] == 0x9A && p[2] == 0x80) ? 3 : 0;
+    if (c == 0xE2) {
+        if (p[1] == 0x80) return ((p[2] >= 0x80 && p[2] <= 0x8A) || p[2] == 0xA8 || p[2] == 0xA9 || p[2] == 0xAF) ? 3 : 0;
+        return (p[1] == 0x81 && p[2] == 0x9F) ? 3 : 0;
+    }
+    if (c == 0xE3) return (p[1] == 0x80 && p[2] == 0x80) ? 3 : 0;
+    return 0;
+}
 int bbo_fastq_parse(const uint8_t* text, uint64_t len, int final_block, bb_fastq_info* info, uint64_t* offsets, uint8_t* bases,
                     uint8_t* quals, uint8_t* hdr, uint64_t* hdr_offsets, uint32_t* id_len, uint32_t* desc_start) {
     if (!info || (!text && len)) return BB_E_INVALID;
@@ -1011,8 +1024,8 @@ int bbo_fastq_parse(const uint8_t* text, uint64_t len, int final_block, bb_fastq
             memcpy(quals + nb, text + ls[3], L);
             memcpy(hdr + nh, text + ls[0] + 1, HL);
             uint32_t idl = (uint32_t)HL, ds = (uint32_t)HL;
-            for (uint32_t q = 0; q < HL; ++q) if (is_ws_c(text[ls[0] + 1 + q])) { idl = q; break; }
-            if (idl < HL) { ds = idl; while (ds < HL && is_ws_c(text[ls[0] + 1 + ds])) ++ds; }
+            for (uint32_t q = 0; q < HL; ++q) if (ws_len_c(text + ls[0] + 1 + q, HL - q)) { idl = q; break; }
+            if (idl < HL) { ds = idl; for (uint32_t w; ds < HL && (w = ws_len_c(text + ls[0] + 1 + ds, HL - ds)) != 0;) ds += w; }
             id_len[n] = idl; desc_start[n] = ds;
             offsets[n + 1] = nb + L; hdr_offsets[n + 1] = nh + HL;
         }

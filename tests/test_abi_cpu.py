@@ -24,7 +24,7 @@ def L():
 
 def test_exports_match_headers(L):
     declared = set()
-    for h in ("barbell_amd.h", "barbell_amd_synth.h", "barbell_amd_filter.h", "barbell_amd_trim.h", "barbell_amd_inspect.h", "barbell_amd_fastq.h"):
+    for h in ("barbell_amd.h", "barbell_amd_synth.h", "barbell_amd_filter.h", "barbell_amd_trim.h", "barbell_amd_inspect.h", "barbell_amd_fastq.h", "barbell_amd_format.h"):
         src = open(os.path.join(ROOT, "include", h)).read()
         src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
         declared |= set(re.findall(r"\b(bb_[a-z_0-9]+)\s*\(", src))
@@ -56,7 +56,17 @@ def test_create_validates_before_touching_the_gpu(L):
     assert create([([b"@@@@@@@@@", b"AAACCCGGG"], 0, None)])[0] == _abi.BB_E_NOT_IUPAC
     assert create([([b"CAATTTGGT", b"AAACCCGGG"], 0, None)])[0] == _abi.BB_E_NO_FLANK
     assert create([([b"AAACCCGGG", b"AAACCCGGG"], 0, None)])[0] == _abi.BB_E_NO_BARCODE
-    assert create([([b"A" * 200 + b"C" + b"G" * 30, b"A" * 200 + b"T" + b"G" * 30], 0, None)])[0] == _abi.BB_E_UNSUPPORTED
+    # geometry limits (include/barbell_amd.h): flanks up to 256 nt are accepted (rc NO_DEVICE here, no GPU), longer ones and
+    # barcodes longer than 44 nt are refused with the reason left for bb_last_error(NULL)
+    wide = create([([b"A" * 200 + b"C" + b"G" * 30, b"A" * 200 + b"T" + b"G" * 30], 0, 20)])[0]
+    assert wide in (_abi.BB_OK, _abi.BB_E_NO_DEVICE)
+    assert create([([b"A" * 200 + b"C" + b"G" * 30, b"A" * 200 + b"T" + b"G" * 30], 0, None)])[0] == _abi.BB_E_UNSUPPORTED  # automatic cutoff 92 > 63
+    assert b"error budget 92" in L.bb_last_error(None)
+    assert create([([b"A" * 250 + b"C" + b"G" * 30, b"A" * 250 + b"T" + b"G" * 30], 0, None)])[0] == _abi.BB_E_UNSUPPORTED
+    assert b"flank of 281 nt" in L.bb_last_error(None)
+    assert create([([b"ACGTACGTAC" + b"C" * 50 + b"GTGTGTGTGT", b"ACGTACGTAC" + b"T" * 50 + b"GTGTGTGTGT"], 0, None)])[0] == _abi.BB_E_UNSUPPORTED
+    assert b"padded barcode pattern of 70 nt" in L.bb_last_error(None)
+    assert create([([b"AAATTTGGG", b"AAACTTGGG"], 0, None)] * 9)[0] == _abi.BB_E_UNSUPPORTED and b"8 query groups" in L.bb_last_error(None)
 
 
 def test_no_cpu_fallback(L):

@@ -62,6 +62,42 @@ def test_split_fastq_header_cases():  # io.rs:40-58 tests
         assert rc == 0 and h[: int(a["id_len"][0])] == rid and h[int(a["desc_start"][0]):] == desc
 
 
+UNI = [("r1\u00a0desc one".encode(), b"r1", b"desc one"), ("r2\u2028\u3000 x\u2009y".encode(), b"r2", "x\u2009y".encode()),
+       ("r3\u0085".encode(), b"r3", b""), ("caf\u00e9 ch=1".encode(), "caf\u00e9".encode(), b"ch=1"), ("r5\u1680\u205f\u202fz".encode(), b"r5", b"z"),
+       (b"r6\xc2", b"r6\xc2", b""), ("r7\u200bx".encode(), "r7\u200bx".encode(), b"")]  # U+200B is not White_Space
+
+
+def test_split_fastq_header_unicode_whitespace():
+    """char::is_whitespace is Unicode White_Space (io.rs:6-17): the id also ends at U+0085, U+00A0, U+1680, U+2000-200A,
+    U+2028/9, U+202F, U+205F, U+3000 (UTF-8 encoded); other multi-byte characters belong to the id"""
+    from barbell_amd.annotate import split_fastq_header
+
+    for h, rid, desc in UNI:
+        rc, info, a = po.fastq_parse(fq([(h, b"A", b"I")]), True)
+        assert rc == 0 and h[: int(a["id_len"][0])] == rid and h[int(a["desc_start"][0]):] == desc, h
+        if h != b"r6\xc2":
+            assert tuple(x.encode() for x in split_fastq_header(h.decode())) == (rid, desc)
+
+
+@pytest.mark.gpu
+def test_gpu_header_split_unicode_whitespace():
+    from barbell_amd import annotate as A
+    from barbell_amd import fastq as Q
+
+    dm = A.Demuxer()
+    for g in __import__("tests.common", fromlist=["x"]).config_groups("nbd96"):
+        dm.add_query_group(g)
+    text = fq([(h, b"ACGT", b"IIII") for h, _, _ in UNI])
+    info, batch = Q.ingest(dm, text, True)
+    a = Q.fetch(dm, info)
+    rc, _, want = po.fastq_parse(text, True)
+    assert rc == 0
+    for k in ("id_len", "desc_start", "hdr_offsets"):
+        assert a[k].tolist() == want[k].tolist(), k
+    with pytest.raises(A.BarbellError):
+        Q.read_ids(a)   # "r6\xc2" is not valid UTF-8: reported, not a UnicodeDecodeError
+
+
 def test_malformed_records():
     good = fq(REC[:2])
     for bad, which in ((good + b"r3\nAC\n+\nII\n", 2), (good + b"@r3\nAC\n-\nII\n", 2), (good + b"@r3\nACG\n+\nII\n", 2),

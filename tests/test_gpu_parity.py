@@ -311,6 +311,22 @@ def test_offsets_beyond_4gib_against_oracle():
         assert_same(got, want)
 
 
+def test_wide_flanks_up_to_256():
+    """custom adapters longer than any kit's: flanks of 150 and 230 nt (W = 5 and 8 words in the scan / trace)"""
+    from barbell_amd import annotate as A
+    from barbell_amd.kits import QueryGroup
+
+    rng = np.random.default_rng(5)
+    rnd = lambda n: bytes(rng.choice(list(b"ACGT"), n).tolist())
+    for pre_n, suf_n, k in ((90, 36, 8), (120, 86, 12)):
+        pre, suf = rnd(pre_n), rnd(suf_n)
+        g = [QueryGroup([pre + rnd(24) + suf for _ in range(24)], [f"w{i}" for i in range(24)], _abi.BB_FTAG, k)]
+        bases, offsets = A.synth_reads_host(g, 31 + pre_n, 700, 2500, 0, 250)
+        dm, got, want = run_both(g, bases, offsets)
+        assert dm.group_info(0).flank_len == pre_n + 24 + suf_n and len(want) > 100
+        assert_same(got, want)
+
+
 def test_iupac_queries_and_custom_geometry():
     """Custom query sets: IUPAC codes inside barcodes and flanks, a one-sided flank (no suffix), short
     barcodes with a single-word pattern (WB = 1), few and many barcodes per group."""
