@@ -135,6 +135,9 @@ struct bb_ctx {
     uint32_t cap_reads = 0, cap_hits = 0;
     uint32_t *d_cnt = nullptr, *d_base = nullptr, *d_sums = nullptr, *d_nrows = nullptr, *d_rowoff = nullptr;
     uint32_t *d_hitcount = nullptr, *d_lists = nullptr, *d_listcnt = nullptr;
+    uint32_t *d_fb_lists = nullptr, *d_fbcnt = nullptr;  // hits the fast barcode kernel's bounds left undecided, per (group, strand)
+    bool fast_path = true;       // BARBELL_AMD_NO_FAST=1: score every barcode of every hit exactly (the fallback kernel only)
+    double fast_margin = 1e-9;   // BARBELL_AMD_FAST_MARGIN: slack of the bound test in k_rows (tests: a huge value sends every hit to the fallback)
     bb_hit_raw* d_raw = nullptr;
     bb_hit* d_hits = nullptr;
     bb_hit_pfx* d_pfx = nullptr;  // shared-prefix records of the hits (groups with pfx > 0)
@@ -167,6 +170,7 @@ struct bb_ctx {
     int n_cus = 256;
     uint32_t reg_blocks_mult = 1;  // BARBELL_AMD_REG_BLOCKS: persistent blocks per resident slot (tuning knob)
     uint32_t reg_threads = 512;  // BARBELL_AMD_REG_THREADS: block size of k_barcode_reg (tuning knob)
+    uint32_t pfx_threads = 0;    // BARBELL_AMD_PFX_THREADS: block size of k_barcode_pfx (0 = as many lanes as fit a CU)
     bool scan_v1 = false;        // BARBELL_AMD_SCAN_V1=1: the first-generation scan kernel (per-lane 16-byte loads)
     bool force_generic = false;  // BARBELL_AMD_GENERIC=1: use the generic (any-geometry) kernels, for tests
     hipEvent_t ev[K_COUNT + 1]{};
@@ -305,6 +309,7 @@ int upload_tables(bb_ctx* c) {
     HIPCHK(c, hipMemset(c->d_counts, 0, sizeof(unsigned long long) * c->counts_len));
     HIPCHK(c, hipMalloc((void**)&c->d_hitcount, 16));
     HIPCHK(c, hipMalloc((void**)&c->d_listcnt, sizeof(uint32_t) * 2 * BB_MAX_GROUPS));
+    HIPCHK(c, hipMalloc((void**)&c->d_fbcnt, sizeof(uint32_t) * 2 * BB_MAX_GROUPS));
     // synth tables
     std::vector<std::vector<std::string>> seqs;
     for (auto& g : c->groups) seqs.push_back(g.seqs);
@@ -352,7 +357,9 @@ int ensure_hits(bb_ctx* c, uint64_t need) {
     }
     if ((r = grow(c, c->d_rows, cap, need))) return r;
     uint64_t lc = 0;
-    if ((r = grow(c, c->d_lists, lc, cap * c->groups.size() * 2))) return r;  // slot 2g + strand: hits of group g on that strand
+    if ((r = grow(c, c->d_lists, lc, cap * c->groups.size() * 2))) return r;
+    lc = 0;
+    if ((r = grow(c, c->d_fb_lists, lc, cap * c->groups.size() * 2))) return r;  // slot 2g + strand: hits of group g on that strand
     c->cap_hits = (uint32_t)cap;
     return BB_OK;
 }
@@ -413,30 +420,39 @@ void launch_barcode_reg(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_off
 }
 
 template <int CW>
-void launch_barcode_pfx(bb_ctx* c, uint32_t n_hits, uint32_t g, uint32_t strand, const uint32_t* list, const uint32_t* cnt) {
+void launch_barcode_pfx(bb_ctx* c, uint32_t n_hits, uint32_t g, uint32_t strand, const uint32_t* list, const uint32_t* cnt, bool fast) {
     const bb_group_dev& D = c->gdev[g];
     const uint32_t N = (uint32_t)D.n_seqs;
     // CW = 48 fits 168 VGPRs -> 3 waves per SIMD: 768-thread blocks (8 hits x 96 barcodes use every lane); measured
     // 22.8 vs 26.8 ms against 512-thread blocks at 2 waves per SIMD
-    const uint32_t tmax = CW <= 48 ? 768u : 512u;
-    const uint32_t hpb = tmax / N;
+    uint32_t tmax = CW <= 48 ? 768u : 512u;
+    if (c->pfx_threads && c->pfx_threads <= tmax) tmax = c->pfx_threads;  // BARBELL_AMD_PFX_THREADS (tuning knob)
+    const uint32_t hpb = std::max(1u, tmax / N);
     const uint32_t threads = ((hpb * N + 63) / 64) * 64;
     const size_t smem = (size_t)hpb * 24 + (size_t)hpb * (sizeof(bb_hit) + sizeof(bb_hit_pfx)) + (size_t)hpb * CW * 16 + (size_t)16 * N * 4 +
                         (size_t)D.tail[strand] * 2 * threads * 8 + 64;
     const uint32_t n_iter = (n_hits + hpb - 1) / hpb;
-    const uint32_t resident = (uint32_t)c->n_cus * (threads > 256 ? 1u : 2u) * c->reg_blocks_mult;
+    const uint32_t per_cu = std::max(1u, (CW <= 48 ? 768u : 512u) / threads);  // blocks that fit a CU at this kernel's register count
+    const uint32_t resident = (uint32_t)c->n_cus * per_cu * c->reg_blocks_mult;
     const uint32_t blocks = n_iter < resident ? n_iter : resident;
 #define BB_PFX_ARGS (const uint8_t*)c->d_tables, (const bb_group_dev*)c->d_groups, g, strand, (const bb_hit*)c->d_hits, (const bb_hit_pfx*)c->d_pfx, list, \
                     cnt, n_hits, hpb, c->params.min_score, c->params.min_score_diff, c->d_rows
-    if (D.tail[strand] > 0) hipLaunchKernelGGL((k_barcode_pfx<CW, true>), dim3(blocks), dim3(threads), smem, c->stream, BB_PFX_ARGS);
-    else hipLaunchKernelGGL((k_barcode_pfx<CW, false>), dim3(blocks), dim3(threads), smem, c->stream, BB_PFX_ARGS);
+    if (D.tail[strand] > 0) {
+        if (fast) hipLaunchKernelGGL((k_barcode_pfx<CW, true, true>), dim3(blocks), dim3(threads), smem, c->stream, BB_PFX_ARGS);
+        else hipLaunchKernelGGL((k_barcode_pfx<CW, true, false>), dim3(blocks), dim3(threads), smem, c->stream, BB_PFX_ARGS);
+    } else {
+        if (fast) hipLaunchKernelGGL((k_barcode_pfx<CW, false, true>), dim3(blocks), dim3(threads), smem, c->stream, BB_PFX_ARGS);
+        else hipLaunchKernelGGL((k_barcode_pfx<CW, false, false>), dim3(blocks), dim3(threads), smem, c->stream, BB_PFX_ARGS);
+    }
 #undef BB_PFX_ARGS
 }
 
 // Barcode stage of one query group: the hits of each strand come from their own list (k_hit_lists, slot 2g + strand).
 // The kernels index list_cnt with g; handing them list_cnt + (slot - g) makes that the slot's counter.
+// pass 0: every hit of the group — split strands through the fast kernel when enabled (bounds + k_rows), the others
+// through the exact kernels; pass 1 (after k_rows): the exact split kernel on the hits the bounds left undecided.
 template <int WB>
-void launch_barcode(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n_hits, uint32_t g) {
+void launch_barcode(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n_hits, uint32_t g, int pass) {
     const bb_group_dev& D = c->gdev[g];
     const bb_group_info& I = c->groups[g].info;
     const uint32_t N = (uint32_t)D.n_seqs;
@@ -447,12 +463,19 @@ void launch_barcode(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets
     for (uint32_t strand = 0; strand < 2; ++strand) {
         const uint32_t slot = 2 * g + strand;
         const uint32_t* list = c->d_lists + (size_t)slot * c->cap_hits;
-        const uint32_t* cnt = c->d_listcnt + slot - g;
+        const uint32_t* cnt = c->d_listcnt + slot - g;  // the kernels index list_cnt with g
         if (!c->force_generic && WB == 2 && D.split[strand] && win_max <= 64) {  // one word per barcode lane
-            if (win_max <= 48) launch_barcode_pfx<48>(c, n_hits, g, strand, list, cnt);
-            else launch_barcode_pfx<64>(c, n_hits, g, strand, list, cnt);
+            if (pass == 1) {
+                if (!c->fast_path) continue;
+                list = c->d_fb_lists + (size_t)slot * c->cap_hits;
+                cnt = c->d_fbcnt + slot - g;
+            }
+            const bool fast = pass == 0 && c->fast_path;
+            if (win_max <= 48) launch_barcode_pfx<48>(c, n_hits, g, strand, list, cnt, fast);
+            else launch_barcode_pfx<64>(c, n_hits, g, strand, list, cnt, fast);
             continue;
         }
+        if (pass == 1) continue;
         if (reg_ok) {
             if (win_max <= 48) launch_barcode_reg<WB, 48>(c, d_bases, d_offsets, n_hits, g, list, cnt);
             else launch_barcode_reg<WB, 64>(c, d_bases, d_offsets, n_hits, g, list, cnt);
@@ -512,6 +535,9 @@ int bb_create(const bb_group_desc* groups, uint32_t n_groups, const bb_params* p
     c->params = *params;
     c->force_generic = getenv("BARBELL_AMD_GENERIC") && atoi(getenv("BARBELL_AMD_GENERIC")) != 0;
     c->scan_v1 = getenv("BARBELL_AMD_SCAN_V1") && atoi(getenv("BARBELL_AMD_SCAN_V1")) != 0;
+    if (getenv("BARBELL_AMD_NO_FAST") && atoi(getenv("BARBELL_AMD_NO_FAST")) != 0) c->fast_path = false;
+    if (getenv("BARBELL_AMD_FAST_MARGIN")) c->fast_margin = atof(getenv("BARBELL_AMD_FAST_MARGIN"));
+    if (getenv("BARBELL_AMD_PFX_THREADS")) { int t = atoi(getenv("BARBELL_AMD_PFX_THREADS")); if (t >= 64 && t <= 768) c->pfx_threads = (uint32_t)t; }
     if (getenv("BARBELL_AMD_REG_THREADS")) { int t = atoi(getenv("BARBELL_AMD_REG_THREADS")); if (t >= 64 && t <= 512) c->reg_threads = (uint32_t)t; }
     c->groups.resize(n_groups);
     for (uint32_t i = 0; i < n_groups; ++i) {
@@ -552,7 +578,7 @@ void bb_destroy(bb_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     void* ptrs[] = {c->d_groups, c->d_tables, c->d_counts, c->d_cnt, c->d_base, c->d_sums, c->d_nrows, c->d_rowoff, c->d_hitcount,
-                    c->d_lists, c->d_listcnt, c->d_raw, c->d_hits, c->d_pfx, c->d_rows, c->d_in_bases, c->d_in_offsets, c->d_out_rows,
+                    c->d_lists, c->d_listcnt, c->d_fb_lists, c->d_fbcnt, c->d_raw, c->d_hits, c->d_pfx, c->d_rows, c->d_in_bases, c->d_in_offsets, c->d_out_rows,
                     c->d_synth_table, c->d_fpats, c->d_felems, c->d_flabel_ok, c->d_flabel_ids, c->d_frows, c->d_fout, c->d_iout};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -651,9 +677,18 @@ int bb_annotate_batch_dev(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_o
         if (any_split)  // shared rows of the padded barcodes, once per hit
             hipLaunchKernelGGL(k_bar_prefix, dim3((n_hits + 127) / 128), dim3(128), 0, c->stream, (const uint8_t*)c->d_tables,
                                (const bb_group_dev*)c->d_groups, (const bb_hit*)c->d_hits, n_hits, c->d_pfx);
-        for (uint32_t g = 0; g < G; ++g) {
-            if (c->gdev[g].WB == 1) launch_barcode<1>(c, d_bases, d_offsets, n_hits, g);
-            else launch_barcode<2>(c, d_bases, d_offsets, n_hits, g);
+        for (int pass = 0; pass < 2; ++pass) {
+            if (pass == 1) {
+                if (!(any_split && c->fast_path)) break;
+                // the exact score of every hit's best-bounded barcode; rows of the hits the bounds decide
+                HIPCHK(c, hipMemsetAsync(c->d_fbcnt, 0, sizeof(uint32_t) * 2 * BB_MAX_GROUPS, c->stream));
+                hipLaunchKernelGGL(k_rows, dim3((n_hits + 255) / 256), dim3(256), 0, c->stream, (const bb_group_dev*)c->d_groups, (const bb_hit*)c->d_hits,
+                                   n_hits, c->d_rows, c->params.min_score, c->params.min_score_diff, c->fast_margin, c->d_fb_lists, c->cap_hits, c->d_fbcnt);
+            }
+            for (uint32_t g = 0; g < G; ++g) {
+                if (c->gdev[g].WB == 1) launch_barcode<1>(c, d_bases, d_offsets, n_hits, g, pass);
+                else launch_barcode<2>(c, d_bases, d_offsets, n_hits, g, pass);
+            }
         }
         HIPCHK(c, hipGetLastError());
     }

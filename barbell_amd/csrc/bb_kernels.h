@@ -16,6 +16,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <cstddef>
+
 #include "../../include/barbell_amd_filter.h"
 #include "../../include/barbell_amd_inspect.h"
 #include "bb_common.h"
@@ -743,6 +745,20 @@ struct __attribute__((aligned(16))) bb_rowtmp {  // one per flank hit: the provi
     bb_row row;
 };
 static_assert(sizeof(bb_rowtmp) == 48, "bb_rowtmp is three 16-byte pieces");
+// What the fast barcode kernel leaves in a hit's row slot for k_rows: the traced path of the barcode with the highest
+// score BOUND (column planes, consumed rows) and the second-highest bound.  `marker` sits where bb_row keeps the
+// pipeline's row flag (_pad[0], byte 45): 0 = no row, 1 = row, 2 = this record.
+struct __attribute__((aligned(16))) bb_winrec {
+    unsigned long long plo, phi, diagrow;
+    double ub_second;
+    uint8_t tstart, best_pos;
+    uint16_t top;
+    uint8_t flags;
+    uint8_t _pad0[8];
+    uint8_t marker;
+    uint8_t _pad[2];
+};
+static_assert(sizeof(bb_winrec) == 48 && offsetof(bb_winrec, marker) == 45, "bb_winrec overlays bb_rowtmp");
 
 __device__ __forceinline__ int32_t rel_dist_to_end(int64_t pos, int64_t read_len) {  // searcher.rs:183-199
     if (pos < 0) return 1;
@@ -992,6 +1008,10 @@ __device__ __forceinline__ void subpath_closed_form(unsigned long long plo, unsi
 // takes part: it synchronises): pass decision (searcher.rs:303-328), per-hit argmax = first maximum and runner-up
 // by 64-bit LDS atomics on the score's bit pattern (searcher.rs:377,390-396), thresholds, and the row — tag row
 // with the sub-path of the winning lane (cigar_parse.rs:6-68) or flank-only row (searcher.rs:241-265).
+// DEFER (k_barcode_pfx's fast variant): `s_norm` is an UPPER BOUND of the lane's normalised score; instead of a row the lane
+// with the highest bound leaves a bb_winrec in the hit's row slot — its traced path, the runner-up's bound — and k_rows
+// scores that one path exactly and decides (or hands the hit to the exact kernel).
+template <bool DEFER = false>
 __device__ __forceinline__ void pick_and_emit(bool active, bool cand, int32_t best_cost, double s_norm, int p, int hl, const bb_hit& H,
                                               uint32_t hit_idx, const bb_group_dev& G, unsigned long long plo, unsigned long long phi,
                                               unsigned long long diagrow, int32_t tstart, int32_t best_pos, int32_t* s_cnt1,
@@ -1018,6 +1038,18 @@ __device__ __forceinline__ void pick_and_emit(bool active, bool cand, int32_t be
         const int top = s_top[hl];
         const bool have = top != 0x7FFFFFFF;
         if ((have && p == top) || (!have && p == 0)) {
+            if constexpr (DEFER) {
+                if (have) {
+                    bb_winrec W;
+                    W.plo = plo; W.phi = phi; W.diagrow = diagrow;
+                    const unsigned long long sk2 = s_sec[hl];
+                    W.ub_second = sk2 ? __longlong_as_double((long long)(sk2 - 1ull)) : -1.0;   // -1: no other candidate
+                    W.tstart = (uint8_t)tstart; W.best_pos = (uint8_t)best_pos; W.top = (uint16_t)top;
+                    W.flags = 0; W.marker = 2; W._pad[0] = W._pad[1] = 0;
+                    *reinterpret_cast<bb_winrec*>(rows + hit_idx) = W;
+                    return;
+                }
+            }
             bool valid = have && s_norm >= min_score;
             const unsigned long long sk = s_sec[hl];
             if (valid && sk != 0ull) valid = (s_norm - __longlong_as_double((long long)(sk - 1ull))) >= min_score_diff;
@@ -1031,11 +1063,7 @@ __device__ __forceinline__ void pick_and_emit(bool active, bool cand, int32_t be
             r._pad[0] = 1; r._pad[1] = r._pad[2] = 0;
             if (valid) {
                 int32_t txt_lo, txt_hi, bcost;
-#ifdef BB_EXP_NO_SUBPATH
-                txt_lo = tstart; txt_hi = best_pos; bcost = __popcll(plo);
-#else
                 subpath_closed_form(plo, phi, diagrow, tstart, best_pos, m, rlo, rhi, txt_lo, txt_hi, bcost);
-#endif
                 r.read_start_bar = H.ws + (uint32_t)txt_lo; r.read_end_bar = H.ws + (uint32_t)txt_hi;
                 r.bar_start = H.ws + (uint32_t)rlo; r.bar_end = H.ws + (uint32_t)rhi;
                 r.match_type = (uint8_t)G.type; r.barcode_cost = (int16_t)bcost; r.barcode_idx = (int16_t)top;
@@ -1071,7 +1099,11 @@ __device__ __forceinline__ double lodhi_replay(unsigned long long plo, unsigned 
     int32_t pj = onmask ? __builtin_ctzll(kept) : 0;  // leading Dels
     // high dword of 2^t, advanced with t; 2^-(t+1) has (1022 - t) << 20 = 0x7FD00000 - (t << 20) there
     uint32_t e_hi = (uint32_t)(1023 + pj) << 20;
+#ifdef BB_REPLAY_FULL_UNROLL
+#pragma clang loop unroll(full)
+#else
 #pragma unroll
+#endif
     for (int c0 = 1; c0 <= CW; c0 += BB_CG) {
         if (c0 <= wmax) {  // wave-uniform
 #pragma unroll
@@ -1089,6 +1121,34 @@ __device__ __forceinline__ double lodhi_replay(unsigned long long plo, unsigned 
                 const int32_t nd = __builtin_ctzll(kept >> pj);
                 pj += nd;
                 e_hi += (onb + (uint32_t)nd) << 20;
+            }
+        }
+    }
+    return sc;
+}
+
+// Upper bound of the Lodhi score of a traced path from its COLUMN planes alone: the same recurrence on the string of
+// text-consuming ops only (the Del ops dropped).  Dropping ops can only shorten the span of a match triple, and every
+// triple's weight 2^-(span) only grows — so the value is >= the exact score of lodhi_replay, up to f64 rounding (the
+// caller keeps a margin).  Time = column index (only differences of times enter), so every power of two is a
+// compile-time constant and nothing of the per-column Del bookkeeping of the exact replay is left: a bit test and three
+// f64 operations per Match column.
+template <int CW>
+__device__ __forceinline__ double lodhi_bound(unsigned long long plo, unsigned long long phi, int32_t tstart, int32_t best_pos, int wmax) {
+    const unsigned long long mmask = low64(best_pos) & ~low64(tstart) & ~(plo | phi);   // Match columns (bit c-1)
+    const uint32_t m_w[2] = {(uint32_t)mmask, (uint32_t)(mmask >> 32)};
+    double sc = 0.0, b1 = 0.0, b2 = 0.0;
+#pragma unroll
+    for (int c0 = 1; c0 <= CW; c0 += BB_CG) {
+        if (c0 <= wmax) {  // wave-uniform
+#pragma unroll
+            for (int c = c0; c < c0 + BB_CG; ++c) {
+                const int k = c - 1;
+                if ((m_w[k >> 5] >> (k & 31)) & 1u) {
+                    const double w = __hiloint2double((int)((uint32_t)(1022 - c) << 20), 0);   // 2^-(c+1)
+                    const double pw = __hiloint2double((int)((uint32_t)(1023 + c) << 20), 0);  // 2^c
+                    sc = __fma_rn(w, b2, sc); b2 = b2 + b1; b1 = b1 + pw;
+                }
             }
         }
     }
@@ -1397,7 +1457,7 @@ __global__ __launch_bounds__(128) void k_bar_prefix(const uint8_t* __restrict__ 
     for (uint32_t i = threadIdx.x; i < nb * OW; i += 128u) dst[i] = s_out[(i / OW) * OS + (i % OW)];
 }
 
-template <int CW, bool TAIL>
+template <int CW, bool TAIL, bool FAST>
 __global__ __launch_bounds__(CW <= 48 ? 768 : 512) void k_barcode_pfx(const uint8_t* __restrict__ tables, const bb_group_dev* __restrict__ groups,
                                                      uint32_t g, uint32_t strand, const bb_hit* __restrict__ hits, const bb_hit_pfx* __restrict__ pfxs,
                                                      const uint32_t* __restrict__ hit_list, const uint32_t* __restrict__ list_cnt,
@@ -1633,9 +1693,6 @@ __global__ __launch_bounds__(CW <= 48 ? 768 : 512) void k_barcode_pfx(const uint
     // added in with the Del-run sum (v_add3)
     const unsigned long long smask = (cand && tr < 0 && c_ent >= 1) ? 1ull << (c_ent - 1) : 0ull;  // column 0: nothing to walk
     const uint32_t sm_w[2] = {(uint32_t)smask, (uint32_t)(smask >> 32)};
-#ifdef BB_EXP_NO_TRACE
-    { uint32_t acc = 0; for (int c = 0; c < CW; ++c) acc ^= L0[c] + H0[c]; plo = acc; dg = acc & 0xFF; }
-#else
     // Mask arithmetic only (profiles/valu_ceiling.json: v_cmp / v_cndmask / shifts issue at half the rate of and/or/add):
     // nb is one-hot or zero, so "the landing cell has lo" is (Lr & nb) != 0 — brought to bit 31 by negation and shifted
     // into the column accumulators with one v_alignbit per plane (word 1: columns 33.., word 0: columns 1..32, newest
@@ -1661,7 +1718,6 @@ __global__ __launch_bounds__(CW <= 48 ? 768 : 512) void k_barcode_pfx(const uint
     }
     plo |= ((unsigned long long)pl_acc[1] << 32) | pl_acc[0];
     phi |= ((unsigned long long)ph_acc[1] << 32) | ph_acc[0];
-#endif
     // Text ops of phase 1 = rows it consumed + its Ins columns.  Whichever way the cursor left the word, the
     // columns best_pos .. cx+1 carry exactly those ops: phase 2 starts at column cx = best_pos - ntext.
     int32_t ntext = cand ? __popc(dg) + __popc(dgt) + __popcll(phi & ~plo) : 0;
@@ -1707,18 +1763,81 @@ __global__ __launch_bounds__(CW <= 48 ? 768 : 512) void k_barcode_pfx(const uint
                                        ((unsigned long long)dgt << (P + 32));
     const unsigned long long delrow = cand ? (low64(m) & ~diagrow) : 0ull;
     double s_norm = -1.0;
-#ifdef BB_EXP_NO_REPLAY
-    if (cand) s_norm = (double)(__popcll(plo) + best_cost) * 0.01;
-#else
-    if (cand) {
-        const double sc = lodhi_replay<CW>(plo, phi, delrow, tstart, best_pos, wmax);
-        s_norm = G.perfect > 0.0 ? sc / G.perfect : 0.0;
-    } else (void)lodhi_replay<CW>(0ull, 0ull, 0ull, 0, 0, wmax);  // the loop is wave-uniform: idle lanes walk it with empty masks
-#endif
-    pick_and_emit(active, cand, best_cost, s_norm, p, hl, H, hit_idx, G, plo, phi, diagrow, tstart, best_pos, s_cnt1, s_max, s_sec, s_top,
-                  min_score, min_score_diff, rows);
+    if constexpr (FAST) {  // a bound for every lane; the exact score of the best-bounded lane only, later (k_rows)
+        const double ub = lodhi_bound<CW>(cand ? plo : 0ull, cand ? phi : 0ull, cand ? tstart : 0, cand ? best_pos : 0, wmax);
+        if (cand) s_norm = G.perfect > 0.0 ? ub / G.perfect : 0.0;
+        (void)delrow;
+    } else {
+        if (cand) {
+            const double sc = lodhi_replay<CW>(plo, phi, delrow, tstart, best_pos, wmax);
+            s_norm = G.perfect > 0.0 ? sc / G.perfect : 0.0;
+        } else (void)lodhi_replay<CW>(0ull, 0ull, 0ull, 0, 0, wmax);  // the loop is wave-uniform: idle lanes walk it with empty masks
+    }
+    pick_and_emit<FAST>(active, cand, best_cost, s_norm, p, hl, H, hit_idx, G, plo, phi, diagrow, tstart, best_pos, s_cnt1, s_max, s_sec, s_top,
+                        min_score, min_score_diff, rows);
     __syncthreads();
   }
+}
+
+// k_rows: one lane per flank hit whose row slot holds a bb_winrec (marker 2).  Scores the recorded path exactly
+// (lodhi_replay: the oracle's f64 recurrence) and decides with the runner-up's BOUND:
+//   * top - bound(second) >= min_score_diff (with a margin far above f64 rounding): no other barcode can reach the top's
+//     score or come within min_score_diff of it, so the recorded barcode is the first maximum and the difference test of
+//     searcher.rs:393-395 passes whatever the others' exact scores are -> tag row if top >= min_score, else flank-only row;
+//   * top < min_score and bound(second) < min_score: no barcode reaches min_score -> flank-only row;
+//   * otherwise the bounds do not decide: the hit goes to the exact kernel (all barcodes scored exactly) through the
+//     fallback list of its (group, strand).
+__global__ __launch_bounds__(256) void k_rows(const bb_group_dev* __restrict__ groups, const bb_hit* __restrict__ hits, uint32_t n_hits,
+                                              bb_rowtmp* __restrict__ rows, double min_score, double min_score_diff, double margin,
+                                              uint32_t* __restrict__ fb_lists, uint32_t list_stride, uint32_t* __restrict__ fb_cnt) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    const bool in = t < n_hits;
+    bb_winrec W;
+    if (in) W = *reinterpret_cast<const bb_winrec*>(rows + t);
+    const bool mine = in && W.marker == 2;
+    int wmax = mine ? (int)W.best_pos : 0;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) wmax = max(wmax, __shfl_xor(wmax, d, 64));
+    wmax = __builtin_amdgcn_readfirstlane(wmax);
+    const uint4 h0 = mine ? reinterpret_cast<const uint4*>(hits + t)[0] : make_uint4(0u, 0u, 0u, 0u);
+    const uint4 h1 = mine ? reinterpret_cast<const uint4*>(hits + t)[1] : make_uint4(0u, 0u, 0u, 0u);
+    const uint32_t grp = (h1.y >> 16) & 0xFFu, strand = (h1.y >> 24) & 1u;
+    const bb_group_dev& G = groups[mine ? grp : 0u];
+    const int m = G.m_bar;
+    const unsigned long long delrow = mine ? (low64(m) & ~W.diagrow) : 0ull;
+    const double sc = lodhi_replay<64>(mine ? W.plo : 0ull, mine ? W.phi : 0ull, delrow, mine ? (int32_t)W.tstart : 0, mine ? (int32_t)W.best_pos : 0, wmax);
+    if (!mine) return;
+    const double s_norm = G.perfect > 0.0 ? sc / G.perfect : 0.0;
+    const bool clear = W.ub_second < 0.0 || (s_norm - W.ub_second) >= min_score_diff + margin;
+    const bool none = s_norm < min_score && W.ub_second < min_score - margin;
+    if (!clear && !none) {  // the bounds do not decide this hit
+        const uint32_t slot = 2u * grp + strand;
+        const uint32_t at = atomicAdd(&fb_cnt[slot], 1u);
+        fb_lists[(size_t)slot * list_stride + at] = t;
+        return;
+    }
+    const bool valid = clear && s_norm >= min_score;
+    bb_rowtmp R;
+    bb_row& r = R.row;
+    const uint32_t read_len = h1.w, text_start = h0.y, text_end = h0.z, ws = h0.w;
+    r.read_idx = h0.x; r.read_len = read_len;
+    r.rel_dist_to_end = rel_dist_to_end((int64_t)text_start, (int64_t)read_len);
+    r.read_start_flank = text_start; r.read_end_flank = text_end;
+    r.flank_cost = (int16_t)(h1.y & 0xFFFFu); r.group_idx = (uint8_t)grp; r.strand = (uint8_t)strand;
+    r._pad[0] = 1; r._pad[1] = r._pad[2] = 0;
+    if (valid) {
+        int32_t txt_lo, txt_hi, bcost;
+        subpath_closed_form(W.plo, W.phi, W.diagrow, (int)W.tstart, (int)W.best_pos, m, G.rel_lo, G.rel_hi, txt_lo, txt_hi, bcost);
+        r.read_start_bar = ws + (uint32_t)txt_lo; r.read_end_bar = ws + (uint32_t)txt_hi;
+        r.bar_start = ws + (uint32_t)G.rel_lo; r.bar_end = ws + (uint32_t)G.rel_hi;
+        r.match_type = (uint8_t)G.type; r.barcode_cost = (int16_t)bcost; r.barcode_idx = (int16_t)W.top;
+    } else {
+        r.read_start_bar = text_start; r.read_end_bar = text_end;
+        r.bar_start = 0; r.bar_end = 0;
+        r.match_type = (uint8_t)(G.type == BB_FTAG ? BB_FFLANK : BB_RFLANK);
+        r.barcode_cost = (int16_t)G.m_bar; r.barcode_idx = -1;
+    }
+    rows[t] = R;
 }
 
 // Hit lists for the barcode kernels: slot 2g + s holds the hits of group g on strand s (the row split of a group —

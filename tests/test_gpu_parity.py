@@ -96,6 +96,41 @@ def test_two_word_kernel_without_prefix_split(monkeypatch):
         assert_same(got, want)
 
 
+@pytest.mark.parametrize("knob", [("BARBELL_AMD_NO_FAST", "1"), ("BARBELL_AMD_FAST_MARGIN", "10"), ("BARBELL_AMD_NO_TAIL", "1")])
+def test_barcode_stage_variants(monkeypatch, knob):
+    """The split barcode kernel has a fast variant (score BOUNDS for every barcode, the exact score of the best-bounded
+    one in k_rows, hits the bounds do not decide redone by the exact variant).  NO_FAST: exact variant only; a huge
+    FAST_MARGIN: the bounds decide nothing, every hit with two candidates takes the fallback; NO_TAIL: strands that
+    need trailing shared rows (rc hits of SQK-NBD114-96, both strands of the 44-row kits) use the two-word kernel."""
+    from barbell_amd import annotate as A
+
+    monkeypatch.setenv(*knob)
+    for cfg, n in (("nbd96", 1500), ("dual", 600), ("rbk96x", 300), ("rbk24", 400)):
+        groups = config_groups(cfg)
+        bases, offsets = A.synth_reads_host(groups, 1234, 300, 2500, 0, n)
+        _, got, want = run_both(groups, bases, offsets)
+        assert len(want) > n // 3
+        assert_same(got, want)
+
+
+def test_noisy_reads_exercise_the_fallback():
+    """reads with heavy errors inside the constructs: the runner-up's bound often comes within min_score_diff of the top,
+    so a good share of hits is decided by the exact kernel"""
+    from barbell_amd import annotate as A
+
+    groups = config_groups("nbd96")
+    bases, offsets = A.synth_reads_host(groups, 99, 300, 1500, 0, 1500)
+    rng = np.random.default_rng(3)
+    b = bases.copy()
+    pos = rng.random(len(b)) < 0.12          # 12 % substitutions everywhere
+    b[pos] = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), int(pos.sum()))
+    _, got, want = run_both(groups, b, offsets, min_score_frac=0.05, min_score_diff_frac=0.02)
+    assert len(want) > 100
+    assert_same(got, want)
+    _, got, want = run_both(groups, b, offsets)
+    assert_same(got, want)
+
+
 def test_prefix_split_with_insertions_in_the_shared_rows():
     """k_barcode_pfx walks the shared pad rows with a 16-column register window and falls back to a loop when
     the path needs more: reads with up to 12 extra bases inside the left pad (flank-max-errors 12 keeps the
