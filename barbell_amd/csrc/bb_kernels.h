@@ -1008,10 +1008,6 @@ __device__ __forceinline__ void subpath_closed_form(unsigned long long plo, unsi
 // takes part: it synchronises): pass decision (searcher.rs:303-328), per-hit argmax = first maximum and runner-up
 // by 64-bit LDS atomics on the score's bit pattern (searcher.rs:377,390-396), thresholds, and the row — tag row
 // with the sub-path of the winning lane (cigar_parse.rs:6-68) or flank-only row (searcher.rs:241-265).
-// DEFER (k_barcode_pfx's fast variant): `s_norm` is an UPPER BOUND of the lane's normalised score; instead of a row the lane
-// with the highest bound leaves a bb_winrec in the hit's row slot — its traced path, the runner-up's bound — and k_rows
-// scores that one path exactly and decides (or hands the hit to the exact kernel).
-template <bool DEFER = false>
 __device__ __forceinline__ void pick_and_emit(bool active, bool cand, int32_t best_cost, double s_norm, int p, int hl, const bb_hit& H,
                                               uint32_t hit_idx, const bb_group_dev& G, unsigned long long plo, unsigned long long phi,
                                               unsigned long long diagrow, int32_t tstart, int32_t best_pos, int32_t* s_cnt1,
@@ -1038,18 +1034,6 @@ __device__ __forceinline__ void pick_and_emit(bool active, bool cand, int32_t be
         const int top = s_top[hl];
         const bool have = top != 0x7FFFFFFF;
         if ((have && p == top) || (!have && p == 0)) {
-            if constexpr (DEFER) {
-                if (have) {
-                    bb_winrec W;
-                    W.plo = plo; W.phi = phi; W.diagrow = diagrow;
-                    const unsigned long long sk2 = s_sec[hl];
-                    W.ub_second = sk2 ? __longlong_as_double((long long)(sk2 - 1ull)) : -1.0;   // -1: no other candidate
-                    W.tstart = (uint8_t)tstart; W.best_pos = (uint8_t)best_pos; W.top = (uint16_t)top;
-                    W.flags = 0; W.marker = 2; W._pad[0] = W._pad[1] = 0;
-                    *reinterpret_cast<bb_winrec*>(rows + hit_idx) = W;
-                    return;
-                }
-            }
             bool valid = have && s_norm >= min_score;
             const unsigned long long sk = s_sec[hl];
             if (valid && sk != 0ull) valid = (s_norm - __longlong_as_double((long long)(sk - 1ull))) >= min_score_diff;
@@ -1134,25 +1118,29 @@ __device__ __forceinline__ double lodhi_replay(unsigned long long plo, unsigned 
 // compile-time constant and nothing of the per-column Del bookkeeping of the exact replay is left: a bit test and three
 // f64 operations per Match column.
 template <int CW>
-__device__ __forceinline__ double lodhi_bound(unsigned long long plo, unsigned long long phi, int32_t tstart, int32_t best_pos, int wmax) {
+__device__ __forceinline__ float lodhi_bound(unsigned long long plo, unsigned long long phi, int32_t tstart, int32_t best_pos, int wmax) {
+    // f32 (full-rate v_fma_f32 / v_add_f32; f64 is half rate) and branch-free: a column that is not a Match adds zeros.
+    // All terms are positive, every operation rounds to nearest with relative error <= 2^-24, fewer than 200 of them
+    // enter any result: the computed value is within a factor (1 +- 2^-16) of the real one; the return value is
+    // scaled up by (1 + 2^-14) so that it stays an upper bound.
     const unsigned long long mmask = low64(best_pos) & ~low64(tstart) & ~(plo | phi);   // Match columns (bit c-1)
     const uint32_t m_w[2] = {(uint32_t)mmask, (uint32_t)(mmask >> 32)};
-    double sc = 0.0, b1 = 0.0, b2 = 0.0;
+    float sc = 0.0f, b1 = 0.0f, b2 = 0.0f;
 #pragma unroll
     for (int c0 = 1; c0 <= CW; c0 += BB_CG) {
         if (c0 <= wmax) {  // wave-uniform
 #pragma unroll
             for (int c = c0; c < c0 + BB_CG; ++c) {
                 const int k = c - 1;
-                if ((m_w[k >> 5] >> (k & 31)) & 1u) {
-                    const double w = __hiloint2double((int)((uint32_t)(1022 - c) << 20), 0);   // 2^-(c+1)
-                    const double pw = __hiloint2double((int)((uint32_t)(1023 + c) << 20), 0);  // 2^c
-                    sc = __fma_rn(w, b2, sc); b2 = b2 + b1; b1 = b1 + pw;
-                }
+                const uint32_t on = 0u - ((m_w[k >> 5] >> (k & 31)) & 1u);                        // all ones on a Match column
+                const float w = __uint_as_float(((uint32_t)(126 - c) << 23) & on);                // 2^-(c+1) or 0
+                const float pw = __uint_as_float(((uint32_t)(127 + c) << 23) & on);               // 2^c or 0
+                const float b1m = __uint_as_float(__float_as_uint(b1) & on);
+                sc = __fmaf_rn(w, b2, sc); b2 = b2 + b1m; b1 = b1 + pw;
             }
         }
     }
-    return sc;
+    return sc * (1.0f + 1.0f / 16384.0f);
 }
 
 template <int WB, int CW>
@@ -1485,6 +1473,10 @@ __global__ __launch_bounds__(CW <= 48 ? 768 : 512) void k_barcode_pfx(const uint
     int32_t* s_top = reinterpret_cast<int32_t*>(smem + o);
     o += (size_t)hpb * 4;
     o = (o + 15) & ~(size_t)15;
+    unsigned long long* s_maxB = reinterpret_cast<unsigned long long*>(smem + o);  // fast variant: top-2 of the pass-2 candidate set
+    o += (size_t)hpb * 8;
+    unsigned long long* s_secB = reinterpret_cast<unsigned long long*>(smem + o);
+    o += (size_t)hpb * 8;
     uint2* s_tab = reinterpret_cast<uint2*>(smem + o);  // [hpb][CW]: the walk through the shared rows per entry column
     o += (size_t)hpb * CW * 8;
     uint2* s_col = reinterpret_cast<uint2*>(smem + o);  // [hpb][CW]: what every barcode lane of a hit needs of a column
@@ -1521,7 +1513,7 @@ __global__ __launch_bounds__(CW <= 48 ? 768 : 512) void k_barcode_pfx(const uint
         s_hit[hl * PIECES + p] = pre;
         if (p + N < PIECES) s_hit[hl * PIECES + p + N] = piece(hit_list ? hit_list[li] : li, p + N);
     }
-    if (in_blk && p == 0) { s_max[hl] = 0ull; s_sec[hl] = 0ull; s_cnt1[hl] = 0; s_top[hl] = 0x7FFFFFFF; }
+    if (in_blk && p == 0) { s_max[hl] = 0ull; s_sec[hl] = 0ull; s_cnt1[hl] = 0; s_top[hl] = 0x7FFFFFFF; s_maxB[hl] = 0ull; s_secB[hl] = 0ull; }
     __syncthreads();
     const uint32_t hit_idx = hit_list ? (exists ? hit_list[li] : 0u) : li;
     prefetch(it + gridDim.x);
@@ -1662,7 +1654,7 @@ __global__ __launch_bounds__(CW <= 48 ? 768 : 512) void k_barcode_pfx(const uint
             const int32_t cq = m + __popcll(Pm & lowq) - __popcll(Mm & lowq);
             if (cq < best_cost) { best_cost = cq; best_pos = q; }
         }
-        if (active && best_pos >= 0 && best_cost <= G.k1) atomicAdd(&s_cnt1[hl], 1);
+        if constexpr (!FAST) { if (active && best_pos >= 0 && best_cost <= G.k1) atomicAdd(&s_cnt1[hl], 1); }
     }
     bool cand = active && best_pos >= 0 && best_cost <= G.k2;
     // ---- traceback, phase 1: the lane's own rows, one-hot cursor on one 32-bit word (row P+1 <-> bit 31).
@@ -1699,6 +1691,9 @@ __global__ __launch_bounds__(CW <= 48 ? 768 : 512) void k_barcode_pfx(const uint
     // column at bit 0 = its final place); a Match/Sub step is cm = nb & ~Hr (one-hot or zero): consumed rows |= cm,
     // and the cursor moves by b = nb + cm (nb << 1 when it consumed, nb when it did not).
     uint32_t pl_acc[2] = {0u, 0u}, ph_acc[2] = {0u, 0u};
+#ifdef BB_EXP_NO_TRACE
+    for (int c = 0; c < CW; ++c) { pl_acc[0] ^= L0[c]; ph_acc[0] += H0[c]; } dg = pl_acc[0] & ph_acc[0] & 0xFFFF;
+#else
 #pragma unroll
     for (int c0 = CW; c0 >= BB_CG; c0 -= BB_CG) {
         if (c0 - (BB_CG - 1) <= wmax) {  // wave-uniform
@@ -1716,6 +1711,7 @@ __global__ __launch_bounds__(CW <= 48 ? 768 : 512) void k_barcode_pfx(const uint
             }
         }
     }
+#endif
     plo |= ((unsigned long long)pl_acc[1] << 32) | pl_acc[0];
     phi |= ((unsigned long long)ph_acc[1] << 32) | ph_acc[0];
     // Text ops of phase 1 = rows it consumed + its Ins columns.  Whichever way the cursor left the word, the
@@ -1762,19 +1758,63 @@ __global__ __launch_bounds__(CW <= 48 ? 768 : 512) void k_barcode_pfx(const uint
     const unsigned long long diagrow = ((unsigned long long)__brev(dg) << P) | (P ? (unsigned long long)(__brev(dgh) >> (32 - P)) : 0ull) |
                                        ((unsigned long long)dgt << (P + 32));
     const unsigned long long delrow = cand ? (low64(m) & ~diagrow) : 0ull;
-    double s_norm = -1.0;
-    if constexpr (FAST) {  // a bound for every lane; the exact score of the best-bounded lane only, later (k_rows)
-        const double ub = lodhi_bound<CW>(cand ? plo : 0ull, cand ? phi : 0ull, cand ? tstart : 0, cand ? best_pos : 0, wmax);
-        if (cand) s_norm = G.perfect > 0.0 ? ub / G.perfect : 0.0;
+    if constexpr (FAST) {
+        // A bound for every lane; the exact score of the best-bounded lane only, later (k_rows).  Per hit the two highest
+        // bounds of BOTH candidate sets of searcher.rs:303-328 — pass 1: lowest cost <= k1, pass 2: every lane with a local
+        // minimum — are collected with one pair of returning LDS atomics per set and lane (key = bound bits : 0xFFFF - p, so
+        // the maximum is also the FIRST maximum; whatever a lane's atomicMax displaces or fails to displace, min(old, key),
+        // is a candidate for second place, and the true second always shows up as one).  Which set counts is known after
+        // the single barrier: pass 2 iff pass 1 has fewer than two members, i.e. its second place is empty.
+        const float ubf = lodhi_bound<CW>(cand ? plo : 0ull, cand ? phi : 0ull, cand ? tstart : 0, cand ? best_pos : 0, wmax);
         (void)delrow;
+        const unsigned long long key = ((unsigned long long)__float_as_uint(ubf) << 16) | (unsigned long long)(0xFFFFu - (uint32_t)p);
+        if (cand) {
+            const unsigned long long o2 = atomicMax(&s_maxB[hl], key);
+            atomicMax(&s_secB[hl], o2 < key ? o2 : key);
+            if (best_cost <= G.k1) {
+                const unsigned long long o1 = atomicMax(&s_max[hl], key);
+                atomicMax(&s_sec[hl], o1 < key ? o1 : key);
+            }
+        }
+        __syncthreads();
+        if (active) {
+            const bool pass2 = s_sec[hl] == 0ull && G.k1 < G.k2;
+            const unsigned long long mx = pass2 ? s_maxB[hl] : s_max[hl], sx = pass2 ? s_secB[hl] : s_sec[hl];
+            if (mx != 0ull) {
+                if ((uint32_t)p == 0xFFFFu - (uint32_t)(mx & 0xFFFFull)) {
+                    bb_winrec W;
+                    W.plo = plo; W.phi = phi; W.diagrow = diagrow;
+                    W.ub_second = sx ? (double)__uint_as_float((uint32_t)(sx >> 16)) / G.perfect : -1.0;   // -1: no other candidate
+                    W.tstart = (uint8_t)tstart; W.best_pos = (uint8_t)best_pos; W.top = (uint16_t)p;
+                    W.flags = 0; W.marker = 2; W._pad[0] = W._pad[1] = 0;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) W._pad0[q] = 0;
+                    *reinterpret_cast<bb_winrec*>(rows + hit_idx) = W;
+                }
+            } else if (p == 0) {  // no candidate at all: flank-only row (searcher.rs:353-362)
+                bb_rowtmp R;
+                bb_row& r = R.row;
+                r.read_idx = H.read_idx; r.read_len = H.read_len;
+                r.rel_dist_to_end = rel_dist_to_end((int64_t)H.text_start, (int64_t)H.read_len);
+                r.read_start_flank = H.text_start; r.read_end_flank = H.text_end;
+                r.flank_cost = H.cost; r.group_idx = H.group; r.strand = H.strand;
+                r._pad[0] = 1; r._pad[1] = r._pad[2] = 0;
+                r.read_start_bar = H.text_start; r.read_end_bar = H.text_end;
+                r.bar_start = 0; r.bar_end = 0;
+                r.match_type = (uint8_t)(G.type == BB_FTAG ? BB_FFLANK : BB_RFLANK);
+                r.barcode_cost = (int16_t)G.m_bar; r.barcode_idx = -1;
+                rows[hit_idx] = R;
+            }
+        }
     } else {
+        double s_norm = -1.0;
         if (cand) {
             const double sc = lodhi_replay<CW>(plo, phi, delrow, tstart, best_pos, wmax);
             s_norm = G.perfect > 0.0 ? sc / G.perfect : 0.0;
         } else (void)lodhi_replay<CW>(0ull, 0ull, 0ull, 0, 0, wmax);  // the loop is wave-uniform: idle lanes walk it with empty masks
+        pick_and_emit(active, cand, best_cost, s_norm, p, hl, H, hit_idx, G, plo, phi, diagrow, tstart, best_pos, s_cnt1, s_max, s_sec, s_top,
+                      min_score, min_score_diff, rows);
     }
-    pick_and_emit<FAST>(active, cand, best_cost, s_norm, p, hl, H, hit_idx, G, plo, phi, diagrow, tstart, best_pos, s_cnt1, s_max, s_sec, s_top,
-                        min_score, min_score_diff, rows);
     __syncthreads();
   }
 }
