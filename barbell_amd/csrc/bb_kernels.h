@@ -938,6 +938,12 @@ __global__ __launch_bounds__(1024) void k_barcode(const uint8_t* __restrict__ ba
 #ifndef BB_CG
 #define BB_CG 4
 #endif
+// k_barcode_pfx: columns below this are processed without the per-group guard (kit windows are 41..63 columns wide;
+// columns beyond a narrower window see base set 0 and their results are masked off).  Measured with 40: the larger
+// basic block costs 59 spilled registers and 5 ms; 0 = every group guarded.
+#ifndef BB_FIXED_COLS
+#define BB_FIXED_COLS 0
+#endif
 // k_barcode_reg: register-resident, branch-free variant of k_barcode for m_bar <= 48 and windows of
 // at most CW columns (CW = 48 or 64; all ONT kit presets).  Same arithmetic as k_barcode, but
 //   * the two move bit-vectors of every column live in VGPRs (3 registers per column), written and
@@ -1128,7 +1134,7 @@ __device__ __forceinline__ float lodhi_bound(unsigned long long plo, unsigned lo
     float sc = 0.0f, b1 = 0.0f, b2 = 0.0f;
 #pragma unroll
     for (int c0 = 1; c0 <= CW; c0 += BB_CG) {
-        if (c0 <= wmax) {  // wave-uniform
+        if (c0 <= BB_FIXED_COLS || c0 <= wmax) {  // wave-uniform
 #pragma unroll
             for (int c = c0; c < c0 + BB_CG; ++c) {
                 const int k = c - 1;
@@ -1445,6 +1451,11 @@ __global__ __launch_bounds__(128) void k_bar_prefix(const uint8_t* __restrict__ 
     for (uint32_t i = threadIdx.x; i < nb * OW; i += 128u) dst[i] = s_out[(i / OW) * OS + (i % OW)];
 }
 
+#ifdef BB_EXP_NO_BARRIERS
+#define BB_PFX_SYNC() ((void)0)
+#else
+#define BB_PFX_SYNC() __syncthreads()
+#endif
 template <int CW, bool TAIL, bool FAST>
 __global__ __launch_bounds__(CW <= 48 ? 768 : 512) void k_barcode_pfx(const uint8_t* __restrict__ tables, const bb_group_dev* __restrict__ groups,
                                                      uint32_t g, uint32_t strand, const bb_hit* __restrict__ hits, const bb_hit_pfx* __restrict__ pfxs,
@@ -1514,7 +1525,7 @@ __global__ __launch_bounds__(CW <= 48 ? 768 : 512) void k_barcode_pfx(const uint
         if (p + N < PIECES) s_hit[hl * PIECES + p + N] = piece(hit_list ? hit_list[li] : li, p + N);
     }
     if (in_blk && p == 0) { s_max[hl] = 0ull; s_sec[hl] = 0ull; s_cnt1[hl] = 0; s_top[hl] = 0x7FFFFFFF; s_maxB[hl] = 0ull; s_secB[hl] = 0ull; }
-    __syncthreads();
+    BB_PFX_SYNC();
     const uint32_t hit_idx = hit_list ? (exists ? hit_list[li] : 0u) : li;
     prefetch(it + gridDim.x);
     // Per (hit, column), once for the hit's N barcode lanes: x = byte offset of the column's base-set row in the Peq table,
@@ -1529,7 +1540,7 @@ __global__ __launch_bounds__(CW <= 48 ? 768 : 512) void k_barcode_pfx(const uint
         const uint32_t hp = (hv[c >> 5] >> (c & 31u)) & 1u, hm = (hv[2 + (c >> 5)] >> (c & 31u)) & 1u;
         s_col[l] = make_uint2(code * (uint32_t)N * 4u, hp | (hm << 1));
     }
-    __syncthreads();
+    BB_PFX_SYNC();
     // The walk of a traced path through the shared rows depends only on the hit and on the column in which the
     // path enters row P, not on the barcode: the first hpb * CW lanes of the block each walk one (hit, entry column)
     // once — 16 columns from independent LDS reads, static register indices — and every barcode lane later looks
@@ -1545,7 +1556,11 @@ __global__ __launch_bounds__(CW <= 48 ? 768 : 512) void k_barcode_pfx(const uint
             const uint32_t* shw = reinterpret_cast<const uint32_t*>(s_hit + hw * PIECES + SH_PIECE);
             uint32_t bh = 1u, lo2 = 0u, hi2 = 0u, dgw = 0u, n2 = 0u;
 #pragma unroll 1
+#ifdef BB_EXP_NO_WALK
+            for (int i = 0; i < 1 && bh != 0u && cxw - i >= 1; ++i) {
+#else
             for (int i = 0; i < 16 && bh != 0u && cxw - i >= 1; ++i) {  // rolled: short, and the registers are wanted elsewhere
+#endif
                 const uint32_t w = shw[cxw - 1 - i];
                 const uint32_t Lr = w & 0xFFFFu, Hr = w >> 16;
                 const uint32_t Dr = Lr & Hr;
@@ -1592,7 +1607,7 @@ __global__ __launch_bounds__(CW <= 48 ? 768 : 512) void k_barcode_pfx(const uint
         uint32_t upr[2] = {0u, 0u}, dnr[2] = {0u, 0u};
 #pragma unroll
         for (int c0 = 0; c0 < CW; c0 += BB_CG) {
-            if (c0 < wmax) {  // wave-uniform
+            if (c0 < BB_FIXED_COLS || c0 < wmax) {  // wave-uniform; the first BB_FIXED_COLS columns unconditionally (straight-line code)
 #pragma unroll
                 for (int c = c0; c < c0 + BB_CG; ++c) {
                     const uint2 cv = colv[c];
@@ -1614,7 +1629,7 @@ __global__ __launch_bounds__(CW <= 48 ? 768 : 512) void k_barcode_pfx(const uint
             }
         }
         // columns processed (wave-uniform): the groups below wmax; word w holds its columns newest-first
-        const int pc = min(CW, ((wmax + BB_CG - 1) / BB_CG) * BB_CG);
+        const int pc = min(CW, ((max(wmax, BB_FIXED_COLS) + BB_CG - 1) / BB_CG) * BB_CG);
         const int n0 = min(pc, 32), n1 = pc - n0;
         uint32_t up[2], dn[2];
         up[0] = n0 ? __brev(upr[0]) >> (32 - n0) : 0u; dn[0] = n0 ? __brev(dnr[0]) >> (32 - n0) : 0u;
@@ -1696,7 +1711,7 @@ __global__ __launch_bounds__(CW <= 48 ? 768 : 512) void k_barcode_pfx(const uint
 #else
 #pragma unroll
     for (int c0 = CW; c0 >= BB_CG; c0 -= BB_CG) {
-        if (c0 - (BB_CG - 1) <= wmax) {  // wave-uniform
+        if (c0 <= BB_FIXED_COLS || c0 - (BB_CG - 1) <= wmax) {  // wave-uniform
 #pragma unroll
             for (int c = c0; c > c0 - BB_CG; --c) {
                 const uint32_t Lr = L0[c - 1], Hr = H0[c - 1];
@@ -1722,7 +1737,7 @@ __global__ __launch_bounds__(CW <= 48 ? 768 : 512) void k_barcode_pfx(const uint
     // alive after the table's 16 columns (more than 16 - P insertions inside the shared rows) finishes in the
     // loop underneath on the move bits of the hit's prefix record. ----
     uint32_t dgh = 0u;
-    __syncthreads();  // the walk table: its builders ran alongside the other waves' forward pass and traceback
+    BB_PFX_SYNC();  // the walk table: its builders ran alongside the other waves' forward pass and traceback
     {
         const uint32_t pm = (1u << P) - 1u;
         const uint2 e = (cand && cx >= 1) ? s_tab[hls * CW + cx - 1] : make_uint2(0u, 0u);
@@ -1776,7 +1791,7 @@ __global__ __launch_bounds__(CW <= 48 ? 768 : 512) void k_barcode_pfx(const uint
                 atomicMax(&s_sec[hl], o1 < key ? o1 : key);
             }
         }
-        __syncthreads();
+        BB_PFX_SYNC();
         if (active) {
             const bool pass2 = s_sec[hl] == 0ull && G.k1 < G.k2;
             const unsigned long long mx = pass2 ? s_maxB[hl] : s_max[hl], sx = pass2 ? s_secB[hl] : s_sec[hl];
@@ -1815,7 +1830,7 @@ __global__ __launch_bounds__(CW <= 48 ? 768 : 512) void k_barcode_pfx(const uint
         pick_and_emit(active, cand, best_cost, s_norm, p, hl, H, hit_idx, G, plo, phi, diagrow, tstart, best_pos, s_cnt1, s_max, s_sec, s_top,
                       min_score, min_score_diff, rows);
     }
-    __syncthreads();
+    BB_PFX_SYNC();
   }
 }
 

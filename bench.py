@@ -420,7 +420,7 @@ def load_traffic(args, batch, L, dom):
         return None, None, None
     ks = t["kernels"]
     # the k_barcode timing slot covers k_bar_prefix + k_barcode_pfx (forward hits) + k_barcode_reg (rc hits)
-    pre = "k_bar" if dom == "k_barcode" else dom
+    pre = ("k_bar", "k_rows") if dom == "k_barcode" else (dom,)
     dom_bytes = sum(v["hbm_bytes"] for k, v in ks.items() if k.startswith(pre))
     return dom_bytes or None, sum(v["hbm_bytes"] * v.get("launches_per_step", 1) for v in ks.values()), os.path.relpath(path, ROOT)
 
