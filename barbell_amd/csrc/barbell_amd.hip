@@ -676,7 +676,7 @@ int bb_annotate_batch_dev(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_o
     if (n_hits) {
         if (any_split)  // shared rows of the padded barcodes, once per hit
             hipLaunchKernelGGL(k_bar_prefix, dim3((n_hits + 127) / 128), dim3(128), 0, c->stream, (const uint8_t*)c->d_tables,
-                               (const bb_group_dev*)c->d_groups, (const bb_hit*)c->d_hits, n_hits, c->d_pfx);
+                               (const bb_group_dev*)c->d_groups, (const bb_hit*)c->d_hits, n_hits, c->d_pfx, G);
         for (int pass = 0; pass < 2; ++pass) {
             if (pass == 1) {
                 if (!(any_split && c->fast_path)) break;

@@ -364,7 +364,7 @@ __device__ __forceinline__ void flank_scan_lane(const uint8_t* __restrict__ base
     // geometry of the walk in forward byte coordinates [0, n)
     const uint64_t a0 = (uint64_t)(uintptr_t)rb;
     uint32_t head, nlines;
-    constexpr uint32_t LB = BB_SCAN_LQ * 16u, LSH = BB_SCAN_LQ == 8 ? 7u : 6u;  // line bytes (128 or 64)
+    constexpr uint32_t LB = BB_SCAN_LQ * 16u, LSH = BB_SCAN_LQ == 16 ? 8u : BB_SCAN_LQ == 8 ? 7u : 6u;  // line bytes (256, 128 or 64)
 #if BB_SCAN_UNALIGNED
     (void)a0;
     head = 0u;  // lines start at the read's first (last) byte whatever its alignment: no per-lane head loop
@@ -1382,10 +1382,19 @@ __global__ __launch_bounds__(512) void k_barcode_reg(const uint8_t* __restrict__
 // 128 hits per block; records enter and leave through LDS so that global traffic is whole lines (a lane-per-
 // record access pattern with 96-byte / 272-byte strides moved 4 GB per 2.6 M hits instead of ~1 GB).
 __global__ __launch_bounds__(128) void k_bar_prefix(const uint8_t* __restrict__ tables, const bb_group_dev* __restrict__ groups,
-                                                    const bb_hit* __restrict__ hits, uint32_t n_hits, bb_hit_pfx* __restrict__ out) {
+                                                    const bb_hit* __restrict__ hits, uint32_t n_hits, bb_hit_pfx* __restrict__ out, uint32_t n_groups) {
     constexpr int HW = (int)(sizeof(bb_hit) / 4), OW = (int)(sizeof(bb_hit_pfx) / 4), OS = OW + 1;  // odd row stride: no bank conflicts
     __shared__ uint32_t s_in[128 * (HW + 1)];
     __shared__ uint32_t s_out[128 * OS];
+    __shared__ uint32_t s_eqt[BB_MAX_GROUPS * 2 * 16];  // Peq of the leading shared rows per (group, strand, base set)
+    __shared__ uint8_t s_tlut[BB_MAX_GROUPS * 2 * 16];  // trailing rows matched per (group, strand, base set)
+    for (uint32_t i = threadIdx.x; i < n_groups * 32u; i += 128u) {
+        const bb_group_dev& Gi = groups[i >> 5];
+        const uint32_t st = (i >> 4) & 1u, code = i & 15u;
+        const bool sp = Gi.split[st] != 0;
+        s_eqt[i] = sp ? reinterpret_cast<const uint32_t*>(tables + Gi.off_peq_pfx[st])[code] : 0u;
+        s_tlut[i] = sp ? (tables + Gi.off_tail_lut[st])[code] : (uint8_t)0;
+    }
     const uint32_t b0 = blockIdx.x * 128u;
     const uint32_t nb = min(128u, n_hits - b0);
     {
@@ -1405,25 +1414,20 @@ __global__ __launch_bounds__(128) void k_bar_prefix(const uint8_t* __restrict__ 
             did = true;
             const int P = G.pfx[strand & 1u], T = G.tail[strand & 1u];
             constexpr int SH0 = 4 + 2 * BB_MAX_TAIL;  // word index of sh[0] in the record
-            const uint32_t* peq = reinterpret_cast<const uint32_t*>(tables + G.off_peq_pfx[strand & 1u]);
-            const uint32_t* tlut = reinterpret_cast<const uint32_t*>(tables + G.off_tail_lut[strand & 1u]);
-            uint32_t eqt[16];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) eqt[i] = peq[i];
-            const uint32_t tl0 = tlut[0], tl1 = tlut[1], tl2 = tlut[2], tl3 = tlut[3];  // 16 bytes: trailing rows matched per code
+            const uint32_t* eqt = s_eqt + (grp * 2u + (strand & 1u)) * 16u;   // LDS lookups (a 16-way select per column cost 32 instructions)
+            const uint8_t* tlut = s_tlut + (grp * 2u + (strand & 1u)) * 16u;
             uint32_t pv = P ? (P >= 32 ? 0xFFFFFFFFu : (1u << P) - 1u) : 0u, mv = 0u;
             unsigned long long PH = 0ull, MH = 0ull, TE[BB_MAX_TAIL];
 #pragma unroll
             for (int q = 0; q < BB_MAX_TAIL; ++q) TE[q] = 0ull;
             for (int c = 0; c < wn; ++c) {
                 const uint32_t code = (rec[8 + (c >> 2)] >> (8 * (c & 3))) & 0xFu;
-                uint32_t eq = 0;
+                const uint32_t eq = eqt[code];
+                if (T > 0) {
+                    const uint32_t tb = tlut[code];
 #pragma unroll
-                for (int i = 0; i < 16; ++i) eq = code == (uint32_t)i ? eqt[i] : eq;
-                const uint32_t tw = (code >> 2) == 0u ? tl0 : (code >> 2) == 1u ? tl1 : (code >> 2) == 2u ? tl2 : tl3;
-                const uint32_t tb = (tw >> (8u * (code & 3u))) & 0xFFu;
-#pragma unroll
-                for (int q = 0; q < BB_MAX_TAIL; ++q) TE[q] |= (unsigned long long)((tb >> q) & 1u) << c;
+                    for (int q = 0; q < BB_MAX_TAIL; ++q) TE[q] |= (unsigned long long)((tb >> q) & 1u) << c;
+                }
                 uint32_t shw = 0u;
                 if (P > 0) {
                     const uint32_t x = eq & pv;
