@@ -2,9 +2,11 @@
 
 `Demuxer` has the reference's constructor and `add_query_group` (src/annotate/searcher.rs:202-226);
 instead of `demux(read_id, read) -> Vec<BarbellMatch>` per read (searcher.rs:430) it offers
-`demux_batch(reads)`: one C-ABI call per batch, rows identical to what the per-read loop of
-`DemuxProcessor::process_record` (src/annotate/annotator.rs:123-135) would have produced, in input
-order.  `annotate()` mirrors `annotate_with_groups`/`annotate` (annotator.rs:207-285): FASTQ in,
+`demux_batch(reads)`: one C-ABI call per batch, rows in input order and bit-identical to the CPU oracle's
+(oracle/bb_oracle.c), which restates the per-read loop of `DemuxProcessor::process_record`
+(src/annotate/annotator.rs:123-135).  Identity with real Barbell is NOT established beyond the reference's own
+known-answer tests — its search/score crates are absent from the build image (oracle/README.md, hazards H1-H8);
+tools/ref_diff.py checks it in one command wherever a `barbell` binary exists.  `annotate()` mirrors `annotate_with_groups`/`annotate` (annotator.rs:207-285): FASTQ in,
 annotation.tsv out, with the byte-exact schema of `BarbellMatch`'s serde layout (searcher.rs:31-64).
 All computation happens in the HIP library; there is no CPU path here.
 """
