@@ -2,8 +2,8 @@
 
 `Demuxer` has the reference's constructor and `add_query_group` (src/annotate/searcher.rs:202-226);
 instead of `demux(read_id, read) -> Vec<BarbellMatch>` per read (searcher.rs:430) it offers
-`demux_batch(reads)`: one C-ABI call per batch, rows in input order and bit-identical to the CPU oracle's
-(oracle/bb_oracle.c), which restates the per-read loop of `DemuxProcessor::process_record`
+`demux_batch(reads)`: one C-ABI call per batch, rows in input order and bit-identical to the CPU restatement's
+(the test checker under oracle/), which restates the per-read loop of `DemuxProcessor::process_record`
 (src/annotate/annotator.rs:123-135).  Identity with real Barbell is NOT established beyond the reference's own
 known-answer tests — its search/score crates are absent from the build image (oracle/README.md, hazards H1-H8);
 tools/ref_diff.py checks it in one command wherever a `barbell` binary exists.  `annotate()` mirrors `annotate_with_groups`/`annotate` (annotator.rs:207-285): FASTQ in,
