@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstddef>
+#include <type_traits>
 
 #include "../../include/barbell_amd_filter.h"
 #include "../../include/barbell_amd_inspect.h"
@@ -1622,10 +1623,20 @@ __global__ __launch_bounds__(CW <= 48 ? 768 : 512) void k_barcode_pfx(const uint
                     const uint32_t ph = bitop3<BB_TT_OR_NOR>(mv, d0, pv), mh = pv & d0;
                     const uint32_t l = bitop3<0x15>(d0, eq, ph), hh = bitop3<0x3A>(d0, eq, ph);  // move planes (see move_bits)
                     L0[c] = __brev(l); H0[c] = __brev(hh);  // row P+1 <-> bit 31, row P+32 <-> bit 0
+#ifndef BB_PFX_NO_SHIFT64
+                    // {accumulator : vector} shifted as ONE 64-bit value: the vector's top bit (the bottom row's delta) lands in
+                    // the accumulator and the vector is shifted, in one half-rate instruction instead of v_alignbit + v_lshl_or
+                    const unsigned long long tp = shl1_64(((unsigned long long)upr[c >> 5] << 32) | ph);
+                    const unsigned long long tm = shl1_64(((unsigned long long)dnr[c >> 5] << 32) | mh);
+                    upr[c >> 5] = (uint32_t)(tp >> 32); dnr[c >> 5] = (uint32_t)(tm >> 32);
+                    uint32_t phs = (uint32_t)tp | hp;
+                    const uint32_t mhs = (uint32_t)tm | hm;
+#else
                     upr[c >> 5] = __builtin_amdgcn_alignbit(upr[c >> 5], ph, 31);  // (acc << 1) | (ph >> 31)
                     dnr[c >> 5] = __builtin_amdgcn_alignbit(dnr[c >> 5], mh, 31);
                     uint32_t phs = (ph << 1) | hp;
                     const uint32_t mhs = (mh << 1) | hm;
+#endif
                     asm("" : "+v"(phs));  // keep the shifted vector in one register: v_lshl_or, then one op each for pv and mv
                     pv = bitop3<BB_TT_OR_NOR>(mhs, d0, phs);
                     mv = phs & d0;
