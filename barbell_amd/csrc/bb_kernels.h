@@ -70,6 +70,44 @@ __device__ __forceinline__ void myers_step(uint32_t (&pv)[W], uint32_t (&mv)[W],
         mv[0] = (uint32_t)phs & d0[0]; mv[1] = (uint32_t)(phs >> 32) & d0[1];
         return;
     }
+    uint32_t phs[W], mhs[W];
+    if constexpr (W >= 3 && W <= 4 && BB_MYERS64) {
+        // words in pairs: 64-bit adds, the carry out of a pair from the majority function of its high words' bit 31
+        // (x, pv, ~sum), the shifts as 64-bit shifts with one v_alignbit across the pair boundary
+        uint32_t carry = 0;
+#pragma unroll
+        for (int w = 0; w < W; w += 2) {
+            if (w + 1 < W) {
+                const uint32_t x0 = eq[w] & pv[w], x1 = eq[w + 1] & pv[w + 1];
+                unsigned long long sum = add_64(((unsigned long long)x1 << 32) | x0, ((unsigned long long)pv[w + 1] << 32) | pv[w]);
+                if (w) sum = add_64(sum, (unsigned long long)carry);  // carry of the pair below (0/1)
+                d0[w] = bitop3<BB_TT_XOR_OR>((uint32_t)sum, pv[w], eq[w]) | mv[w];
+                d0[w + 1] = bitop3<BB_TT_XOR_OR>((uint32_t)(sum >> 32), pv[w + 1], eq[w + 1]) | mv[w + 1];
+                carry = bitop3<0xD4>(x1, pv[w + 1], (uint32_t)(sum >> 32)) >> 31;  // (x & pv) | ((x | pv) & ~sum)
+            } else {
+                const uint32_t x = eq[w] & pv[w];
+                const uint32_t sum = x + pv[w] + carry;
+                d0[w] = bitop3<BB_TT_XOR_OR>(sum, pv[w], eq[w]) | mv[w];
+            }
+        }
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+            ph[w] = bitop3<BB_TT_OR_NOR>(mv[w], d0[w], pv[w]);
+            mh[w] = pv[w] & d0[w];
+        }
+#pragma unroll
+        for (int w = 0; w < W; w += 2) {
+            if (w + 1 < W) {
+                const unsigned long long p2 = shl1_64(((unsigned long long)ph[w + 1] << 32) | ph[w]);
+                const unsigned long long m2 = shl1_64(((unsigned long long)mh[w + 1] << 32) | mh[w]);
+                phs[w] = (uint32_t)p2 | (w ? (ph[w - 1] >> 31) : 0u); phs[w + 1] = (uint32_t)(p2 >> 32);
+                mhs[w] = (uint32_t)m2 | (w ? (mh[w - 1] >> 31) : 0u); mhs[w + 1] = (uint32_t)(m2 >> 32);
+            } else {
+                phs[w] = __builtin_amdgcn_alignbit(ph[w], ph[w - 1], 31);
+                mhs[w] = __builtin_amdgcn_alignbit(mh[w], mh[w - 1], 31);
+            }
+        }
+    } else {
     uint32_t carry = 0;
 #pragma unroll
     for (int w = 0; w < W; ++w) {
@@ -83,11 +121,11 @@ __device__ __forceinline__ void myers_step(uint32_t (&pv)[W], uint32_t (&mv)[W],
         ph[w] = bitop3<BB_TT_OR_NOR>(mv[w], d0[w], pv[w]);
         mh[w] = pv[w] & d0[w];
     }
-    uint32_t phs[W], mhs[W];
 #pragma unroll
     for (int w = W - 1; w >= 0; --w) {
         phs[w] = (ph[w] << 1) | (w ? (ph[w - 1] >> 31) : 0u);
         mhs[w] = (mh[w] << 1) | (w ? (mh[w - 1] >> 31) : 0u);
+    }
     }
 #pragma unroll
     for (int w = 0; w < W; ++w) {

@@ -353,7 +353,7 @@ def test_wide_flanks_up_to_256():
 
     rng = np.random.default_rng(5)
     rnd = lambda n: bytes(rng.choice(list(b"ACGT"), n).tolist())
-    for pre_n, suf_n, k in ((90, 36, 8), (120, 86, 12)):
+    for pre_n, suf_n, k in ((70, 30, 7), (90, 36, 8), (120, 86, 12)):   # W = 4 (two 64-bit pairs), 5, 8
         pre, suf = rnd(pre_n), rnd(suf_n)
         g = [QueryGroup([pre + rnd(24) + suf for _ in range(24)], [f"w{i}" for i in range(24)], _abi.BB_FTAG, k)]
         bases, offsets = A.synth_reads_host(g, 31 + pre_n, 700, 2500, 0, 250)
