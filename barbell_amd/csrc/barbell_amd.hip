@@ -308,8 +308,8 @@ int upload_tables(bb_ctx* c) {
     HIPCHK(c, hipMalloc((void**)&c->d_counts, sizeof(unsigned long long) * c->counts_len));
     HIPCHK(c, hipMemset(c->d_counts, 0, sizeof(unsigned long long) * c->counts_len));
     HIPCHK(c, hipMalloc((void**)&c->d_hitcount, 16));
-    HIPCHK(c, hipMalloc((void**)&c->d_listcnt, sizeof(uint32_t) * 2 * BB_MAX_GROUPS));
-    HIPCHK(c, hipMalloc((void**)&c->d_fbcnt, sizeof(uint32_t) * 2 * BB_MAX_GROUPS));
+    HIPCHK(c, hipMalloc((void**)&c->d_listcnt, sizeof(uint32_t) * 4 * BB_MAX_GROUPS));
+    HIPCHK(c, hipMalloc((void**)&c->d_fbcnt, sizeof(uint32_t) * 4 * BB_MAX_GROUPS));
     // synth tables
     std::vector<std::vector<std::string>> seqs;
     for (auto& g : c->groups) seqs.push_back(g.seqs);
@@ -357,9 +357,9 @@ int ensure_hits(bb_ctx* c, uint64_t need) {
     }
     if ((r = grow(c, c->d_rows, cap, need))) return r;
     uint64_t lc = 0;
-    if ((r = grow(c, c->d_lists, lc, cap * c->groups.size() * 2))) return r;
+    if ((r = grow(c, c->d_lists, lc, cap * c->groups.size() * 4))) return r;
     lc = 0;
-    if ((r = grow(c, c->d_fb_lists, lc, cap * c->groups.size() * 2))) return r;  // slot 2g + strand: hits of group g on that strand
+    if ((r = grow(c, c->d_fb_lists, lc, cap * c->groups.size() * 4))) return r;  // slot 4g + 2 wide + strand (k_hit_lists)
     c->cap_hits = (uint32_t)cap;
     return BB_OK;
 }
@@ -447,7 +447,9 @@ void launch_barcode_pfx(bb_ctx* c, uint32_t n_hits, uint32_t g, uint32_t strand,
 #undef BB_PFX_ARGS
 }
 
-// Barcode stage of one query group: the hits of each strand come from their own list (k_hit_lists, slot 2g + strand).
+// Barcode stage of one query group: the hits of each strand and window class come from their own list (k_hit_lists,
+// slot 4g + 2 wide + strand): windows of at most 48 columns run the 48-column instantiations whatever the widest
+// possible window of the group is.
 // The kernels index list_cnt with g; handing them list_cnt + (slot - g) makes that the slot's counter.
 // pass 0: every hit of the group — split strands through the fast kernel when enabled (bounds + k_rows), the others
 // through the exact kernels; pass 1 (after k_rows): the exact split kernel on the hits the bounds left undecided.
@@ -460,8 +462,10 @@ void launch_barcode(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets
     const uint32_t win_max = I.mask_len + (uint32_t)I.flank_k + 2 * BB_PADDING - 1;
     const size_t peq_bytes = (size_t)2 * 16 * N * WB * 4;
     const bool reg_ok = !c->force_generic && D.m_bar <= 48 && N <= c->reg_threads && peq_bytes <= 48 * 1024 && win_max <= 64;
-    for (uint32_t strand = 0; strand < 2; ++strand) {
-        const uint32_t slot = 2 * g + strand;
+    for (uint32_t sw = 0; sw < 4; ++sw) {
+        const uint32_t strand = sw & 1u, wide = sw >> 1;
+        if (wide && win_max <= 48) continue;  // no such hits
+        const uint32_t slot = 4 * g + sw;
         const uint32_t* list = c->d_lists + (size_t)slot * c->cap_hits;
         const uint32_t* cnt = c->d_listcnt + slot - g;  // the kernels index list_cnt with g
         if (!c->force_generic && WB == 2 && D.split[strand] && win_max <= 64) {  // one word per barcode lane
@@ -471,13 +475,13 @@ void launch_barcode(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets
                 cnt = c->d_fbcnt + slot - g;
             }
             const bool fast = pass == 0 && c->fast_path;
-            if (win_max <= 48) launch_barcode_pfx<48>(c, n_hits, g, strand, list, cnt, fast);
+            if (!wide) launch_barcode_pfx<48>(c, n_hits, g, strand, list, cnt, fast);
             else launch_barcode_pfx<64>(c, n_hits, g, strand, list, cnt, fast);
             continue;
         }
         if (pass == 1) continue;
         if (reg_ok) {
-            if (win_max <= 48) launch_barcode_reg<WB, 48>(c, d_bases, d_offsets, n_hits, g, list, cnt);
+            if (!wide) launch_barcode_reg<WB, 48>(c, d_bases, d_offsets, n_hits, g, list, cnt);
             else launch_barcode_reg<WB, 64>(c, d_bases, d_offsets, n_hits, g, list, cnt);
             continue;
         }
@@ -668,7 +672,7 @@ int bb_annotate_batch_dev(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_o
     for (uint32_t g = 0; g < G; ++g) any_split = any_split || c->gdev[g].split[0] || c->gdev[g].split[1];
     c->use_lists = true;  // one list per (group, strand)
     if (n_hits) {
-        HIPCHK(c, hipMemsetAsync(c->d_listcnt, 0, sizeof(uint32_t) * 2 * BB_MAX_GROUPS, c->stream));
+        HIPCHK(c, hipMemsetAsync(c->d_listcnt, 0, sizeof(uint32_t) * 4 * BB_MAX_GROUPS, c->stream));
         hipLaunchKernelGGL(k_hit_lists, dim3((n_hits + 255) / 256), dim3(256), 0, c->stream, (const bb_hit*)c->d_hits, n_hits,
                            c->d_rows, c->d_lists, c->cap_hits, c->d_listcnt, G, (const bb_group_dev*)c->d_groups);
     }
@@ -681,7 +685,7 @@ int bb_annotate_batch_dev(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_o
             if (pass == 1) {
                 if (!(any_split && c->fast_path)) break;
                 // the exact score of every hit's best-bounded barcode; rows of the hits the bounds decide
-                HIPCHK(c, hipMemsetAsync(c->d_fbcnt, 0, sizeof(uint32_t) * 2 * BB_MAX_GROUPS, c->stream));
+                HIPCHK(c, hipMemsetAsync(c->d_fbcnt, 0, sizeof(uint32_t) * 4 * BB_MAX_GROUPS, c->stream));
                 hipLaunchKernelGGL(k_rows, dim3((n_hits + 255) / 256), dim3(256), 0, c->stream, (const bb_group_dev*)c->d_groups, (const bb_hit*)c->d_hits,
                                    n_hits, c->d_rows, c->params.min_score, c->params.min_score_diff, c->fast_margin, c->d_fb_lists, c->cap_hits, c->d_fbcnt);
             }

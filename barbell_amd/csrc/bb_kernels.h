@@ -1919,7 +1919,7 @@ __global__ __launch_bounds__(256) void k_rows(const bb_group_dev* __restrict__ g
     const bool clear = W.ub_second < 0.0 || (s_norm - W.ub_second) >= min_score_diff + margin;
     const bool none = s_norm < min_score && W.ub_second < min_score - margin;
     if (!clear && !none) {  // the bounds do not decide this hit
-        const uint32_t slot = 2u * grp + strand;
+        const uint32_t slot = 4u * grp + ((h1.x - h0.w) > 48u ? 2u : 0u) + strand;  // {we - ws}: the window class of k_hit_lists
         const uint32_t at = atomicAdd(&fb_cnt[slot], 1u);
         fb_lists[(size_t)slot * list_stride + at] = t;
         return;
@@ -1948,8 +1948,11 @@ __global__ __launch_bounds__(256) void k_rows(const bb_group_dev* __restrict__ g
     rows[t] = R;
 }
 
-// Hit lists for the barcode kernels: slot 2g + s holds the hits of group g on strand s (the row split of a group —
-// bb_group_dev::pfx / tail — differs per strand, and every launch is uniform in it).  Hits whose
+// Hit lists for the barcode kernels: slot 4g + 2w + s holds the hits of group g on strand s (the row split of a group —
+// bb_group_dev::pfx / tail — differs per strand, and every launch is uniform in it) whose barcode window is at most 48
+// columns wide (w = 0) or wider (w = 1): the kernels keep the move bits of every column in registers, and the 48-column
+// instantiation runs at 3 waves per SIMD where the 64-column one has room for 2 — with large flank error budgets the
+// WIDEST possible window exceeds 48 columns while nearly every actual window does not.  Hits whose
 // get_matching_region was None (searcher.rs:445-449) are skipped here and marked row-less.  One atomic per
 // (block, slot): ballots + LDS.
 __global__ __launch_bounds__(256) void k_hit_lists(const bb_hit* __restrict__ hits, uint32_t n_hits, bb_rowtmp* __restrict__ rows,
@@ -1957,18 +1960,19 @@ __global__ __launch_bounds__(256) void k_hit_lists(const bb_hit* __restrict__ hi
                                                    uint32_t n_groups, const bb_group_dev* __restrict__ groups) {
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
     const bool in = t < n_hits;
-    uint32_t grp = 0, strand = 0, vld = 0;
-    if (in) {  // second 16-byte piece of the record: {we, cost|group|strand, valid, read_len}
+    uint32_t grp = 0, strand = 0, vld = 0, wide = 0;
+    if (in) {  // second 16-byte piece of the record: {we, cost|group|strand, valid, read_len}; ws is the last word of the first
         const uint4 h1 = reinterpret_cast<const uint4*>(hits + t)[1];
-        grp = (h1.y >> 16) & 0xFFu; strand = h1.y >> 24; vld = h1.z & 0xFFu;
+        const uint32_t ws = reinterpret_cast<const uint32_t*>(hits + t)[3];
+        grp = (h1.y >> 16) & 0xFFu; strand = h1.y >> 24; vld = h1.z & 0xFFu; wide = (h1.x - ws) > 48u ? 1u : 0u;
     }
     const bool valid = in && vld;
     if (in && !valid) rows[t].row._pad[0] = 0;
     const unsigned lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-    const uint32_t my_slot = valid ? 2u * grp + (strand & 1u) : 0xFFFFFFFFu;
+    const uint32_t my_slot = valid ? 4u * grp + 2u * wide + (strand & 1u) : 0xFFFFFFFFu;
     // one atomic per (block, slot): the four waves' counts meet in LDS
-    __shared__ uint32_t s_cnt[4][2 * BB_MAX_GROUPS], s_base[2 * BB_MAX_GROUPS];
-    const uint32_t n_slots = 2u * n_groups;
+    __shared__ uint32_t s_cnt[4][4 * BB_MAX_GROUPS], s_base[4 * BB_MAX_GROUPS];
+    const uint32_t n_slots = 4u * n_groups;
     unsigned long long my_mask = 0ull;
     for (uint32_t slot = 0; slot < n_slots; ++slot) {
         const unsigned long long mask = __ballot(my_slot == slot);

@@ -346,6 +346,35 @@ def test_offsets_beyond_4gib_against_oracle():
         assert_same(got, want)
 
 
+def test_wide_barcode_windows_take_the_64_column_kernels():
+    """a large flank error budget makes the widest POSSIBLE barcode window exceed 48 columns; hits are split by their actual
+    window (k_hit_lists): <= 48 columns -> 48-column kernels, wider -> 64-column kernels.  Reads with 6..16 bases inserted
+    inside the barcode produce the wide ones."""
+    from barbell_amd import annotate as A
+
+    groups = config_groups("rbk96x")
+    rng = np.random.default_rng(21)
+    rnd = lambda n: bytes(rng.choice(list(b"ACGT"), n).tolist())
+    reads = []
+    for i in range(400):
+        g = groups[i % 2]
+        seq = g.seqs[int(rng.integers(len(g.seqs)))]
+        cut = 16 + int(rng.integers(4, 20))                    # inside the barcode (prefix is 16 nt)
+        ins = rnd(int(rng.integers(6, 17))) if i % 3 else b""
+        construct = seq[:cut] + ins + seq[cut:]
+        body = rnd(int(rng.integers(300, 900)))
+        if i % 4 == 0:                                          # reverse-complement strand, construct at the 3' end
+            comp = bytes.maketrans(b"ACGT", b"TGCA")
+            reads.append(body + construct.translate(comp)[::-1] + rnd(int(rng.integers(0, 30))))
+        else:
+            reads.append(rnd(int(rng.integers(0, 40))) + construct + body)
+    bases, offsets = _abi.pack_reads(reads)
+    dm, got, want = run_both(groups, bases, offsets)
+    assert_same(got, want)
+    wide = (want["read_end_bar"].astype(np.int64) - want["read_start_bar"]) > 30
+    assert len(want) > 300 and int(wide.sum()) > 20   # tag rows that span an inserted barcode
+
+
 def test_wide_flanks_up_to_256():
     """custom adapters longer than any kit's: flanks of 150 and 230 nt (W = 5 and 8 words in the scan / trace)"""
     from barbell_amd import annotate as A
