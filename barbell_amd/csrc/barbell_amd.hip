@@ -136,6 +136,8 @@ struct bb_ctx {
     uint32_t *d_cnt = nullptr, *d_base = nullptr, *d_sums = nullptr, *d_nrows = nullptr, *d_rowoff = nullptr;
     uint32_t *d_hitcount = nullptr, *d_lists = nullptr, *d_listcnt = nullptr;
     uint32_t *d_fb_lists = nullptr, *d_fbcnt = nullptr;  // hits the fast barcode kernel's bounds left undecided, per (group, strand)
+    uint32_t* d_flags = nullptr; uint64_t cap_flags = 0;  // filtered scan: one bit per 32 text bytes and strand (k_flank_filter)
+    int scan_filter = -1;        // BARBELL_AMD_SCAN_FILTER: 0 never, 1 wherever it is valid (tests), unset: where the prefix says enough
     bool fast_path = true;       // BARBELL_AMD_NO_FAST=1: score every barcode of every hit exactly (the fallback kernel only)
     double fast_margin = 1e-9;   // BARBELL_AMD_FAST_MARGIN: slack of the bound test in k_rows (tests: a huge value sends every hit to the fallback)
     bb_hit_raw* d_raw = nullptr;
@@ -237,6 +239,67 @@ int upload_tables(bb_ctx* c) {
                     uint8_t pc = bb_text_code((uint8_t)g.flank[j]);
                     if (s) pc = bb_comp_code(pc);  // rc strand: complement(pattern) vs reversed text
                     if (pc & tc) t[ch * S + (j >> 5)] |= 1u << (j & 31);
+                }
+            }
+        }
+        // Filtered scan (bb_kernels.h, k_flank_filter): worth it when the window's score is rarely <= k in unrelated text.
+        // Every window position is tried on 32 K pseudo-random bases with the filter's own recurrence (runs of flagged
+        // columns per text column); the quietest one is taken.
+        D.filt_rows = 0; D.filt_off = 0;
+        {
+            const int R = std::min(15, m), k = D.flank_k;
+            if (c->scan_filter != 0 && m >= 2 && k < m) {
+                const uint32_t* t = reinterpret_cast<const uint32_t*>(blob.b.data() + D.off_peq_flank[0]);
+                const uint32_t maskR = (1u << R) - 1u;
+                const int L = 1 << 15;
+                // cost of a window position in full-height columns: every flagged column, plus the lead-in, quarter granularity
+                // and margins of every flagged run
+                const long per_run = m + 3 * k + 40;
+                int best_u = 0;
+                long best_cost = (long)L * per_run;
+                for (int u = 0; u + R <= m; ++u) {
+                    uint32_t eqs[4];
+                    for (int b = 0; b < 4; ++b) {
+                        const uint32_t* e = t + (size_t)"ACGT"[b] * S;
+                        uint64_t two = e[u >> 5];
+                        if ((u >> 5) + 1 < W) two |= (uint64_t)e[(u >> 5) + 1] << 32;
+                        eqs[b] = (uint32_t)(two >> (u & 31)) & maskR;
+                    }
+                    uint32_t pv = maskR, mv = 0, x = 0x9E3779B9u;
+                    int sc = R;
+                    long cost = 0;
+                    bool in = false;
+                    for (int i = 0; i < L && cost < best_cost; ++i) {
+                        x = x * 1664525u + 1013904223u;
+                        const uint32_t eq = eqs[x >> 30];
+                        const uint32_t xx = eq & pv, d0 = (((xx + pv) ^ pv) | eq | mv) & maskR;
+                        const uint32_t ph = (mv | ~(d0 | pv)) & maskR, mh = pv & d0;
+                        sc += (int)((ph >> (R - 1)) & 1u) - (int)((mh >> (R - 1)) & 1u);
+                        const uint32_t phs = ph << 1, mhs = mh << 1;
+                        pv = (mhs | ~(d0 | phs)) & maskR; mv = phs & d0 & maskR;
+                        const bool f = sc <= k;
+                        cost += f ? (in ? 1 : per_run) : 0;
+                        in = f;
+                    }
+                    if (cost < best_cost) { best_cost = cost; best_u = u; }
+                }
+                // the filter itself costs about half a W=2 scan; verification columns are full-height columns
+                bool use = W >= 2 && (double)best_cost / L < 0.3;
+                if (c->scan_filter == 1) use = true;
+                if (use) {
+                    D.filt_rows = R; D.filt_off = best_u;
+                    int o_max = 0;  // most rows that can hang over a read end within the budget (edit_model: floor(alpha * o))
+                    for (int o = 1; o <= m; ++o)
+                        if (overhang_cost(alpha, o) <= k) o_max = o;
+                    const int u = best_u;
+                    uint32_t mode = 0;
+                    if (u == 0) mode |= BB_FILT_TRUE_INIT;
+                    if (!(u == 0 || u >= o_max)) mode |= BB_FILT_FWD_BEGIN_ALWAYS;
+                    if (u == 0 && o_max < R) mode |= BB_FILT_RC_BEGIN_HINT;
+                    else if (u < o_max) mode |= BB_FILT_RC_BEGIN_ALWAYS;
+                    if (o_max > m - u - R) mode |= BB_FILT_END_ALWAYS;
+                    if (getenv("BARBELL_AMD_FILTER_ENDS")) mode = (mode & BB_FILT_TRUE_INIT) | BB_FILT_FWD_BEGIN_ALWAYS | BB_FILT_RC_BEGIN_ALWAYS | BB_FILT_END_ALWAYS;  // test knob: both ends of every read
+                    D.filt_mode = (int32_t)mode;
                 }
             }
         }
@@ -374,7 +437,15 @@ int scan_u32(bb_ctx* c, const uint32_t* in, uint32_t* out, uint64_t n) {
 }
 
 template <int W>
-void launch_scan(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n, uint32_t g) {
+void launch_scan(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n, uint32_t g, uint64_t flag_words) {
+    if (c->gdev[g].filt_rows > 0 && !c->scan_v1) {
+        hipLaunchKernelGGL(k_flank_filter, dim3((n + 255) / 256), dim3(256), 0, c->stream, d_bases, d_offsets, n, (const uint8_t*)c->d_tables,
+                           (const bb_group_dev*)c->d_groups, g, c->d_flags, flag_words);
+        hipLaunchKernelGGL(k_flank_verify<W>, dim3((n + 255) / 256, 2), dim3(256), 0, c->stream, d_bases, d_offsets, n,
+                           (const uint8_t*)c->d_tables, (const bb_group_dev*)c->d_groups, g, (uint32_t)c->groups.size(),
+                           (const uint32_t*)c->d_flags, flag_words, c->d_cnt, c->d_raw, c->cap_hits, c->d_hitcount);
+        return;
+    }
     if (!c->scan_v1 || W > 4) {
         hipLaunchKernelGGL(k_flank_scan2<W>, dim3((n + 255) / 256, 2), dim3(256), 0, c->stream, d_bases, d_offsets, n,
                            (const uint8_t*)c->d_tables, (const bb_group_dev*)c->d_groups, g, (uint32_t)c->groups.size(), c->d_cnt,
@@ -539,6 +610,7 @@ int bb_create(const bb_group_desc* groups, uint32_t n_groups, const bb_params* p
     c->params = *params;
     c->force_generic = getenv("BARBELL_AMD_GENERIC") && atoi(getenv("BARBELL_AMD_GENERIC")) != 0;
     c->scan_v1 = getenv("BARBELL_AMD_SCAN_V1") && atoi(getenv("BARBELL_AMD_SCAN_V1")) != 0;
+    if (getenv("BARBELL_AMD_SCAN_FILTER")) c->scan_filter = atoi(getenv("BARBELL_AMD_SCAN_FILTER")) != 0 ? 1 : 0;
     if (getenv("BARBELL_AMD_NO_FAST") && atoi(getenv("BARBELL_AMD_NO_FAST")) != 0) c->fast_path = false;
     if (getenv("BARBELL_AMD_FAST_MARGIN")) c->fast_margin = atof(getenv("BARBELL_AMD_FAST_MARGIN"));
     if (getenv("BARBELL_AMD_PFX_THREADS")) { int t = atoi(getenv("BARBELL_AMD_PFX_THREADS")); if (t >= 64 && t <= 768) c->pfx_threads = (uint32_t)t; }
@@ -582,7 +654,7 @@ void bb_destroy(bb_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     void* ptrs[] = {c->d_groups, c->d_tables, c->d_counts, c->d_cnt, c->d_base, c->d_sums, c->d_nrows, c->d_rowoff, c->d_hitcount,
-                    c->d_lists, c->d_listcnt, c->d_fb_lists, c->d_fbcnt, c->d_raw, c->d_hits, c->d_pfx, c->d_rows, c->d_in_bases, c->d_in_offsets, c->d_out_rows,
+                    c->d_lists, c->d_listcnt, c->d_fb_lists, c->d_fbcnt, c->d_flags, c->d_raw, c->d_hits, c->d_pfx, c->d_rows, c->d_in_bases, c->d_in_offsets, c->d_out_rows,
                     c->d_synth_table, c->d_fpats, c->d_felems, c->d_flabel_ok, c->d_flabel_ids, c->d_frows, c->d_fout, c->d_iout};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -626,20 +698,34 @@ int bb_annotate_batch_dev(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_o
     if ((r = ensure_hits(c, (uint64_t)n * 3 + 1024))) return r;
     const uint64_t M = (uint64_t)n * G * 2 + 1;
     uint32_t n_hits = 0;
+    uint64_t flag_words = 0;  // per strand
+    {
+        bool any_filt = false;
+        for (uint32_t g = 0; g < G; ++g) any_filt = any_filt || c->gdev[g].filt_rows > 0;
+        if (any_filt && !c->scan_v1) {  // the flag words of a read sit at (offset >> 9) + 3 * read: the batch's byte span sizes the array
+            uint64_t ends[2] = {0, 0};
+            HIPCHK(c, hipMemcpyAsync(&ends[0], d_offsets, 8, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipMemcpyAsync(&ends[1], d_offsets + n, 8, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            if (ends[1] < ends[0]) { c->last_error = "offsets are not ascending"; return BB_E_INVALID; }
+            flag_words = ((ends[1] - ends[0]) >> 9) + 3ull * n + 3;
+            if ((r = grow(c, c->d_flags, c->cap_flags, 2 * flag_words))) return r;
+        }
+    }
     for (int attempt = 0;; ++attempt) {
         mark(c, K_SCAN);
         HIPCHK(c, hipMemsetAsync(c->d_hitcount, 0, 16, c->stream));
         HIPCHK(c, hipMemsetAsync(c->d_cnt + (M - 1), 0, 4, c->stream));
         for (uint32_t g = 0; g < G; ++g) {
             switch (c->gdev[g].W) {
-                case 1: launch_scan<1>(c, d_bases, d_offsets, n, g); break;
-                case 2: launch_scan<2>(c, d_bases, d_offsets, n, g); break;
-                case 3: launch_scan<3>(c, d_bases, d_offsets, n, g); break;
-                case 4: launch_scan<4>(c, d_bases, d_offsets, n, g); break;
-                case 5: launch_scan<5>(c, d_bases, d_offsets, n, g); break;
-                case 6: launch_scan<6>(c, d_bases, d_offsets, n, g); break;
-                case 7: launch_scan<7>(c, d_bases, d_offsets, n, g); break;
-                default: launch_scan<8>(c, d_bases, d_offsets, n, g); break;
+                case 1: launch_scan<1>(c, d_bases, d_offsets, n, g, flag_words); break;
+                case 2: launch_scan<2>(c, d_bases, d_offsets, n, g, flag_words); break;
+                case 3: launch_scan<3>(c, d_bases, d_offsets, n, g, flag_words); break;
+                case 4: launch_scan<4>(c, d_bases, d_offsets, n, g, flag_words); break;
+                case 5: launch_scan<5>(c, d_bases, d_offsets, n, g, flag_words); break;
+                case 6: launch_scan<6>(c, d_bases, d_offsets, n, g, flag_words); break;
+                case 7: launch_scan<7>(c, d_bases, d_offsets, n, g, flag_words); break;
+                default: launch_scan<8>(c, d_bases, d_offsets, n, g, flag_words); break;
             }
         }
         HIPCHK(c, hipGetLastError());

@@ -61,7 +61,7 @@ struct bb_group_dev {
     int32_t type;             // BB_FTAG / BB_RTAG
     int32_t score0;           // D[m][0] of the flank scan (floor(alpha*m))
     int32_t count_off;        // offset of this group's counters in the histogram
-    int32_t _pad;
+    int32_t filt_rows;        // > 0: the flank scan runs as filter (filt_rows <= 15 rows of the flank, both strands in one pass) + windowed verification
     double perfect;
     // byte offsets into the table blob
     uint32_t off_peq_flank[2];   // [strand] 256 entries x PEQ_STRIDE(W) words, indexed by read byte
@@ -82,7 +82,16 @@ struct bb_group_dev {
     uint32_t off_peq_pfx[2];     // [strand] 16 words: Peq of the leading shared rows
     uint32_t off_peq_sub[2];     // [strand] [16 codes][n_seqs] words: Peq of rows pfx..pfx+31
     uint32_t off_tail_lut[2];    // [strand] 16 bytes: bit t of byte[code] = trailing row t matches base set `code`
+    int32_t filt_off;            // first flank row of the filter's window (rows filt_off .. filt_off + filt_rows - 1)
+    int32_t filt_mode;           // BB_FILT_* bits
 };
+// Which fixed intervals k_flank_verify scans besides the flagged ones (o_max = most rows that can hang over a read end at
+// a cost <= k; u, R = the window; see upload_tables):
+#define BB_FILT_TRUE_INIT 1u         /* u == 0: the forward block is rows 1..R of the scan's own matrix, overhang column included */
+#define BB_FILT_FWD_BEGIN_ALWAYS 2u  /* 0 < u < o_max: a forward match hanging over the read's start may leave the window unflagged */
+#define BB_FILT_RC_BEGIN_ALWAYS 4u   /* the same for the rc strand (u < o_max and no hint available: o_max >= R or u > 0) */
+#define BB_FILT_RC_BEGIN_HINT 8u     /* u == 0, o_max < R: k_flank_filter says per read whether the rc strand's start needs scanning */
+#define BB_FILT_END_ALWAYS 16u       /* o_max > m - u - R: a match may hang over a strand's end with the window outside the read */
 
 #define BB_MAX_TAIL 4
 // per-hit output of k_bar_prefix: what the lanes of k_barcode_pfx need of the shared rows

@@ -32,6 +32,7 @@
 // ------------------------------------------------------------------------------------------------
 // gfx950 three-input boolean: result bit = TT[(a << 2) | (b << 1) | c].  The compiler finds some of these on its
 // own but leaves e.g. pv = mhs | ~(d0 | phs) as or + not + or; spelled out they are one instruction each.
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 template <int TT>
 __device__ __forceinline__ uint32_t bitop3(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, TT); }
 #define BB_TT_XOR_OR 0xBE    /* (a ^ b) | c   */
@@ -340,8 +341,72 @@ struct hit_buf {
         ST.prev = cur_;                                                                         \
     } while (0)
 
+// End of a (read, strand) scan, shared by the streaming scan and the windowed verification: the right-overhang
+// positions after the last column, the pending local minimum, the count, and the flush of the buffered hits.
+template <int W, int STRAND>
+__device__ __forceinline__ void scan_finish(bool live, uint32_t n, int m, int32_t kk, int32_t sc, uint32_t (&pv)[W], uint32_t (&mv)[W],
+                                            uint32_t idx, lm_lane& st, hit_buf& hb, const int32_t* __restrict__ ovh, uint32_t read,
+                                            uint32_t g, uint32_t n_groups, uint32_t* __restrict__ cnt, bb_hit_raw* __restrict__ hits,
+                                            uint32_t hit_cap, uint32_t* __restrict__ hit_count, bool at_end = true) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const int TB = (m - 1) & 31;
+    // right overhang (oracle [H4]): C[n+o] = D[m-o][n] + floor(alpha*o), o = 1..m
+    if (live) {
+        int32_t d = sc;
+        for (int o = 1; at_end && o <= m; ++o) {
+            d -= (int32_t)((pv[W - 1] >> TB) & 1u) - (int32_t)((mv[W - 1] >> TB) & 1u);
+#pragma unroll
+            for (int w = W - 1; w >= 0; --w) {
+                pv[w] = (pv[w] << 1) | (w ? (pv[w - 1] >> 31) : 0u);
+                mv[w] = (mv[w] << 1) | (w ? (mv[w - 1] >> 31) : 0u);
+            }
+            ++idx;
+            BB_LM_STEP_BUF(st, d + ovh[o], idx);
+        }
+        if (at_end && st.dec && st.prev <= kk) {
+            const uint32_t e_ = n + (uint32_t)m, k_ = st.nrep;
+            if (k_ < 4u) {
+                hb.e0 = k_ == 0u ? e_ : hb.e0; hb.e1 = k_ == 1u ? e_ : hb.e1;
+                hb.e2 = k_ == 2u ? e_ : hb.e2; hb.e3 = k_ == 3u ? e_ : hb.e3;
+                hb.costs |= ((uint32_t)st.prev & 0xFFu) << (8u * k_);
+            } else {
+                emit_hit(hits, hit_cap, hit_count, read, e_, st.prev, g, (uint32_t)STRAND, k_);
+            }
+            st.nrep = k_ + 1u;
+        }
+        cnt[((uint64_t)read * n_groups + g) * 2 + STRAND] = st.nrep;
+    }
+    // flush the buffered hits: one atomic per wave
+    {
+        const uint32_t mine = live ? min(st.nrep, 4u) : 0u;
+        uint32_t incl = mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t y = (uint32_t)__shfl_up((int)incl, d, 64); if ((int)lane >= d) incl += y; }
+        const uint32_t total = (uint32_t)__shfl((int)incl, 63, 64);
+        uint32_t base = 0;
+        if (total) {
+            if (lane == 0) base = atomicAdd(hit_count, total);
+            base = (uint32_t)__shfl((int)base, 0, 64);
+            uint32_t slot = base + incl - mine;
+            const uint32_t es[4] = {hb.e0, hb.e1, hb.e2, hb.e3};
+#pragma unroll
+            for (uint32_t k = 0; k < 4; ++k) {
+                if (k < mine && slot + k < hit_cap) {
+                    bb_hit_raw h;
+                    h.read_idx = read; h.e = es[k]; h.cost = (int16_t)((hb.costs >> (8u * k)) & 0xFFu);
+                    h.group = (uint8_t)g; h.strand = (uint8_t)STRAND; h.ordinal = k;
+                    hits[slot + k] = h;
+                }
+            }
+        }
+    }
+}
+
+// 2: line-aligned pieces, the partial first/last line of a read predicated (production); 1: pieces start at the read's
+// own first byte (0.2 ms faster, but consecutive pieces share a 64-byte sector and half of the second requests miss
+// L2: 25.1 instead of 16.5 GB per 2 M reads); 0: line-aligned pieces, partial lines walked with per-lane byte loops
 #ifndef BB_SCAN_UNALIGNED
-#define BB_SCAN_UNALIGNED 1
+#define BB_SCAN_UNALIGNED 2
 #endif
 #ifndef BB_SCAN_LQ
 #define BB_SCAN_LQ 8u  // 16-byte pieces per streamed line: 8 = 128-byte lines (8 KB of LDS per wave), 4 = 64-byte lines
@@ -402,8 +467,78 @@ __device__ __forceinline__ void flank_scan_lane(const uint8_t* __restrict__ base
 
     // geometry of the walk in forward byte coordinates [0, n)
     const uint64_t a0 = (uint64_t)(uintptr_t)rb;
-    uint32_t head, nlines;
     constexpr uint32_t LB = BB_SCAN_LQ * 16u, LSH = BB_SCAN_LQ == 16 ? 8u : BB_SCAN_LQ == 8 ? 7u : 6u;  // line bytes (256, 128 or 64)
+    // one group of 4 columns of the 16-byte piece v, starting at byte b0 (scan order): wave-uniform choice of path;
+    // sc is exact on entry (either stepped or re-derived)
+    auto group4 = [&](const uint4& v, int b0) {
+        if (__any(sc <= kk + 4)) {
+#pragma unroll
+            for (int b = b0; b < b0 + 4; ++b) {
+                const int bb = STRAND == 0 ? b : 15 - b;
+                const uint32_t word = (bb >> 2) == 0 ? v.x : (bb >> 2) == 1 ? v.y : (bb >> 2) == 2 ? v.z : v.w;
+                step((word >> (8 * (bb & 3))) & 0xFFu);
+            }
+        } else {
+#pragma unroll
+            for (int b = b0; b < b0 + 4; ++b) {
+                const int bb = STRAND == 0 ? b : 15 - b;
+                const uint32_t word = (bb >> 2) == 0 ? v.x : (bb >> 2) == 1 ? v.y : (bb >> 2) == 2 ? v.z : v.w;
+                step_fast((word >> (8 * (bb & 3))) & 0xFFu);
+            }
+            idx += 4;
+            sc = score_now();
+            st.prev = sc;  // > k: the lazily evaluated `dec` needs no update (see lm_lane)
+        }
+    };
+#if BB_SCAN_UNALIGNED == 2
+    // Line-aligned streaming: the lane's lines are the LB-byte-aligned lines of HBM that hold its read, in scan order;
+    // `mis` bytes of the first line (scan order) lie before the read's first scanned byte, and the last line may end
+    // early.  Those two partial lines go through the same LDS path with the bytes outside the read predicated off, so
+    // every line of the batch is requested once per strand and no lane runs a byte loop of its own.  (A line that
+    // holds one byte of the read lies in that byte's page: the bytes outside the read are fetched, never used.)
+    const uint32_t mis = STRAND == 0 ? (uint32_t)(a0 & (LB - 1u)) : (uint32_t)((LB - (uint32_t)((a0 + n) & (LB - 1u))) & (LB - 1u));
+    const uint32_t nlines = n ? (mis + n + LB - 1u) >> LSH : 0u;
+    const uint8_t* line0 = STRAND == 0 ? rb - mis : rb + n + mis - LB;  // first line in scan order
+    uint32_t lmax = nlines;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) lmax = max(lmax, (uint32_t)__shfl_xor((int)lmax, d, 64));
+    lmax = __builtin_amdgcn_readfirstlane(lmax);
+    for (uint32_t l = 0; l < lmax; ++l) {
+        const bool on = l < nlines;
+        if (on) {
+            const uint8_t* src = STRAND == 0 ? line0 + (l << LSH) : line0 - (l << LSH);
+#pragma unroll
+            for (int q = 0; q < (int)BB_SCAN_LQ; ++q)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 16 * q),
+                                                 (__attribute__((address_space(3))) void*)(s_line + 64 * q), 16, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // scan-order byte range of this line that belongs to the read
+        const uint32_t lo = l == 0u ? mis : 0u;
+        const uint32_t hi = on ? min(LB, mis + n - (l << LSH)) : 0u;
+        if (!__any(on && (lo != 0u || hi != LB))) {
+            if (on) {
+                for (int q = 0; q < (int)BB_SCAN_LQ; ++q) {
+                    const uint4 v = s_line[64 * (STRAND == 0 ? q : (int)BB_SCAN_LQ - 1 - q) + lane];
+#pragma unroll
+                    for (int b0 = 0; b0 < 16; b0 += 4) group4(v, b0);
+                }
+            }
+        } else {  // a partial line somewhere in the wave: every column tracked, bytes outside the read skipped
+            for (int q = 0; q < (int)BB_SCAN_LQ; ++q) {
+                const uint4 v = s_line[64 * (STRAND == 0 ? q : (int)BB_SCAN_LQ - 1 - q) + lane];
+#pragma unroll
+                for (int b = 0; b < 16; ++b) {
+                    const int bb = STRAND == 0 ? b : 15 - b;
+                    const uint32_t word = (bb >> 2) == 0 ? v.x : (bb >> 2) == 1 ? v.y : (bb >> 2) == 2 ? v.z : v.w;
+                    const uint32_t p = 16u * (uint32_t)q + (uint32_t)b;
+                    if (p >= lo && p < hi) step((word >> (8 * (bb & 3))) & 0xFFu);
+                }
+            }
+        }
+    }
+#else
+    uint32_t head, nlines;
 #if BB_SCAN_UNALIGNED
     (void)a0;
     head = 0u;  // lines start at the read's first (last) byte whatever its alignment: no per-lane head loop
@@ -436,83 +571,15 @@ __device__ __forceinline__ void flank_scan_lane(const uint8_t* __restrict__ base
             for (int q = 0; q < (int)BB_SCAN_LQ; ++q) {
                 const uint4 v = s_line[64 * (STRAND == 0 ? q : (int)BB_SCAN_LQ - 1 - q) + lane];
 #pragma unroll
-                for (int b0 = 0; b0 < 16; b0 += 4) {
-                    // sc is exact here (either stepped or re-derived); wave-uniform choice of path
-                    if (__any(sc <= kk + 4)) {
-#pragma unroll
-                        for (int b = b0; b < b0 + 4; ++b) {
-                            const int bb = STRAND == 0 ? b : 15 - b;
-                            const uint32_t word = (bb >> 2) == 0 ? v.x : (bb >> 2) == 1 ? v.y : (bb >> 2) == 2 ? v.z : v.w;
-                            step((word >> (8 * (bb & 3))) & 0xFFu);
-                        }
-                    } else {
-#pragma unroll
-                        for (int b = b0; b < b0 + 4; ++b) {
-                            const int bb = STRAND == 0 ? b : 15 - b;
-                            const uint32_t word = (bb >> 2) == 0 ? v.x : (bb >> 2) == 1 ? v.y : (bb >> 2) == 2 ? v.z : v.w;
-                            step_fast((word >> (8 * (bb & 3))) & 0xFFu);
-                        }
-                        idx += 4;
-                        sc = score_now();
-                        st.prev = sc;  // > k: the lazily evaluated `dec` needs no update (see lm_lane)
-                    }
-                }
+                for (int b0 = 0; b0 < 16; b0 += 4) group4(v, b0);
             }
         }
     }
     // partial last line
     for (uint32_t t = 0; t < tail; ++t) step(STRAND == 0 ? rb[head + (nlines << LSH) + t] : rb[tail - 1 - t]);
+#endif
 
-    // right overhang (oracle [H4]): C[n+o] = D[m-o][n] + floor(alpha*o), o = 1..m
-    if (live) {
-        int32_t d = sc;
-        for (int o = 1; o <= m; ++o) {
-            d -= (int32_t)((pv[W - 1] >> TB) & 1u) - (int32_t)((mv[W - 1] >> TB) & 1u);
-#pragma unroll
-            for (int w = W - 1; w >= 0; --w) {
-                pv[w] = (pv[w] << 1) | (w ? (pv[w - 1] >> 31) : 0u);
-                mv[w] = (mv[w] << 1) | (w ? (mv[w - 1] >> 31) : 0u);
-            }
-            ++idx;
-            BB_LM_STEP_BUF(st, d + ovh[o], idx);
-        }
-        if (st.dec && st.prev <= kk) {
-            const uint32_t e_ = n + (uint32_t)m, k_ = st.nrep;
-            if (k_ < 4u) {
-                hb.e0 = k_ == 0u ? e_ : hb.e0; hb.e1 = k_ == 1u ? e_ : hb.e1;
-                hb.e2 = k_ == 2u ? e_ : hb.e2; hb.e3 = k_ == 3u ? e_ : hb.e3;
-                hb.costs |= ((uint32_t)st.prev & 0xFFu) << (8u * k_);
-            } else {
-                emit_hit(hits, hit_cap, hit_count, read, e_, st.prev, g, (uint32_t)STRAND, k_);
-            }
-            st.nrep = k_ + 1u;
-        }
-        cnt[((uint64_t)read * n_groups + g) * 2 + STRAND] = st.nrep;
-    }
-    // flush the buffered hits: one atomic per wave
-    {
-        const uint32_t mine = live ? min(st.nrep, 4u) : 0u;
-        uint32_t incl = mine;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { const uint32_t y = (uint32_t)__shfl_up((int)incl, d, 64); if ((int)lane >= d) incl += y; }
-        const uint32_t total = (uint32_t)__shfl((int)incl, 63, 64);
-        uint32_t base = 0;
-        if (total) {
-            if (lane == 0) base = atomicAdd(hit_count, total);
-            base = (uint32_t)__shfl((int)base, 0, 64);
-            uint32_t slot = base + incl - mine;
-            const uint32_t es[4] = {hb.e0, hb.e1, hb.e2, hb.e3};
-#pragma unroll
-            for (uint32_t k = 0; k < 4; ++k) {
-                if (k < mine && slot + k < hit_cap) {
-                    bb_hit_raw h;
-                    h.read_idx = read; h.e = es[k]; h.cost = (int16_t)((hb.costs >> (8u * k)) & 0xFFu);
-                    h.group = (uint8_t)g; h.strand = (uint8_t)STRAND; h.ordinal = k;
-                    hits[slot + k] = h;
-                }
-            }
-        }
-    }
+    scan_finish<W, STRAND>(live, n, m, kk, sc, pv, mv, idx, st, hb, ovh, read, g, n_groups, cnt, hits, hit_cap, hit_count);
 }
 
 template <int W>
@@ -539,6 +606,301 @@ __global__ __launch_bounds__(256) void k_flank_scan2(const uint8_t* __restrict__
         flank_scan_lane<W, 0>(bases, offsets, n_reads, tables, kk, m, score0, o_pv0, o_ovh, g, n_groups, cnt, hits, hit_cap, hit_count, s_peq, line);
     else
         flank_scan_lane<W, 1>(bases, offsets, n_reads, tables, kk, m, score0, o_pv0, o_ovh, g, n_groups, cnt, hits, hit_cap, hit_count, s_peq, line);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Filtered scan (groups with bb_group_dev::filt_rows > 0): Ukkonen's cut-off — rows below the last cell <= k of a
+// column need not be computed — restructured for lanes that cannot diverge cheaply.
+//
+//   k_flank_filter  one lane per READ, one pass over the text for BOTH strands: Myers on R <= 15 consecutive rows u..u+R-1
+//                   of the flank alone (their own semi-global problem), the forward strand's in bits 0..R-1 and the reverse-complement strand's in bits 16..16+R-1
+//                   of ONE 32-bit word (carries die in the guard bits between the blocks).  Exact matching of a prefix is
+//                   direction-free: the rc strand's rows 0..R-1 against the reversed text are the reversed rows against
+//                   the forward text, so its block simply holds the rows in reverse order.  The lane tracks D[R][i] of
+//                   both blocks and records, per 16-byte piece of each streamed line, whether it was ever <= k
+//                   (one bit per piece and strand, 4 lines to a word).
+//   k_flank_verify  one lane per (read, strand): the full-height scan of k_flank_scan2 — same step, same local-minimum
+//                   state machine, same overhang handling and hit buffering — but only over the columns where a hit
+//                   is possible: a match of cost c <= k ending at column e holds an alignment of rows u..u+R-1 of cost
+//                   <= c ending at some column b (so b is flagged) with e - b in [m-u-R-k, m-u-R+k]; matches that use the left overhang
+//                   end by column m+k; the right-overhang positions follow the last column.  Each such interval is
+//                   entered with m+k columns of lead-in from the all-insertions column (values <= k are exact after
+//                   that, larger ones stay > k — the argument of k_flank_trace), and the state machine only ever acts
+//                   on values <= k or on the step into / out of them, so it emits exactly the hits of the full scan.
+// The reads are streamed once instead of twice and ~45 % of the scan's instructions go away; where the R-row prefix
+// says too little (k close to R: the score is <= k everywhere) the host keeps the full scan (upload_tables).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t filt_word_base(uint64_t off, uint64_t off0, uint32_t read) { return ((off - off0) >> 9) + 3ull * read; }
+
+__global__ __launch_bounds__(256) void k_flank_filter(const uint8_t* __restrict__ bases, const uint64_t* __restrict__ offsets, uint32_t n_reads,
+                                                      const uint8_t* __restrict__ tables, const bb_group_dev* __restrict__ groups, uint32_t g,
+                                                      uint32_t* __restrict__ flags, uint64_t words_per_strand) {
+    __shared__ uint32_t s_fpeq[256];
+    __shared__ __attribute__((aligned(16))) uint4 s_lines[4][BB_SCAN_LQ * 64];
+    static_assert(BB_SCAN_LQ == 8u, "piece bits assume 128-byte lines");
+    const bb_group_dev* G = groups + g;
+    const int R = G->filt_rows;
+    const int32_t kk = min(G->flank_k, R);  // k >= R: every column qualifies
+    // blocks right-aligned under the guard bits 15 and 31: forward rows at bits 15-R..14, rc rows (reversed) at bits 31-R..30
+    const uint32_t maskR = (1u << R) - 1u, SA = 15u - (uint32_t)R, BM = (maskR << SA) | (maskR << (SA + 16u));
+    {
+        const uint32_t S = G->W <= 2 ? 2u : (G->W <= 4 ? 4u : 8u);
+        const uint32_t* f = reinterpret_cast<const uint32_t*>(tables + G->off_peq_flank[0]);
+        const uint32_t* r = reinterpret_cast<const uint32_t*>(tables + G->off_peq_flank[1]);
+        const uint32_t c = threadIdx.x, u = (uint32_t)G->filt_off, uw = u >> 5, ub = u & 31u;
+        auto rows = [&](const uint32_t* t) {  // rows u .. u+R-1 of entry c
+            const uint32_t lo = t[c * S + uw], hi = ub && uw + 1u < (uint32_t)G->W ? t[c * S + uw + 1u] : 0u;
+            return ((lo >> ub) | (ub ? hi << (32u - ub) : 0u)) & maskR;
+        };
+        s_fpeq[c] = (rows(f) << SA) | ((__brev(rows(r)) >> (32 - R)) << (SA + 16u));
+    }
+    __syncthreads();
+    uint4* s_line = s_lines[threadIdx.x >> 6];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t read = blockIdx.x * 256u + threadIdx.x;
+    const bool live = read < n_reads;
+    const uint64_t off0 = offsets[0];
+    const uint64_t off = live ? offsets[read] : off0;
+    const uint32_t n = live ? (uint32_t)(offsets[read + 1] - off) : 0u;
+    const uint8_t* rb = bases + off;
+    constexpr uint32_t LB = 128u, LSH = 7u;
+    const uint32_t mis = (uint32_t)((uint64_t)(uintptr_t)rb & (LB - 1u));
+    const uint32_t nlines = n ? (mis + n + LB - 1u) >> LSH : 0u;
+    const uint8_t* line0 = rb - mis;
+    uint32_t* fl0 = flags + filt_word_base(off, off0, read);
+    uint32_t* fl1 = fl0 + words_per_strand;
+
+    // The forward block of a window that starts at row 0 is rows 1..R of the scan's own matrix — column 0 included, i.e. the
+    // left-overhang column (G->off_pv0, floor(alpha * R)) — so matches that hang over the read's start are flagged like any
+    // other.  Every other block is the window's own semi-global problem (column 0: D[j][0] = j).
+    const bool own_rows = (G->filt_mode & BB_FILT_TRUE_INIT) != 0;
+    const int32_t* ovh = reinterpret_cast<const int32_t*>(tables + G->off_ovh);
+    uint32_t pv = own_rows ? ((reinterpret_cast<const uint32_t*>(tables + G->off_pv0)[0] & maskR) << SA) | (maskR << (SA + 16u)) : BM, mv = 0u;
+    // Both blocks' D[R][i], biased by 15 - k, in the two halves of one register (the bottom rows' delta bits sit at bits 14
+    // and 30: one mask, one shift): a half's bit 4 is clear exactly while its score is <= k, so AND-ing the register over
+    // the columns of a piece leaves bit 4 / bit 20 clear iff the piece holds such a column.
+    const uint32_t TOPS = 0x40004000u;
+    uint32_t sc2 = ((uint32_t)(R + 15 - kk) << 16) | (uint32_t)((own_rows ? (int)__popc(reinterpret_cast<const uint32_t*>(tables + G->off_pv0)[0] & maskR) : R) + 15 - kk);
+    uint32_t keep = sc2 | ~0x00100010u;  // column 0 counts for the first piece
+    uint32_t bitsA = 0u, bitsB = 0u;
+    auto step = [&](uint32_t eq) {
+        const uint32_t x = eq & pv;
+        const uint32_t d0 = bitop3<BB_TT_XOR_OR>(x + pv, pv, eq) | mv;
+        const uint32_t ph = bitop3<BB_TT_OR_NOR>(mv, d0, pv) & BM, mh = pv & d0;
+        sc2 = sc2 + ((ph & TOPS) >> 14) - ((mh & TOPS) >> 14);
+        keep &= sc2;
+        const uint32_t phs = ph << 1, mhs = mh << 1;
+        pv = bitop3<BB_TT_OR_NOR>(mhs, d0, phs) & BM;
+        mv = phs & d0;
+    };
+    auto commit = [&](uint32_t bit) {  // end of a piece
+        bitsA |= ((~keep >> 4) & 1u) << bit; bitsB |= ((~keep >> 20) & 1u) << bit;
+        keep = 0xFFFFFFFFu;
+    };
+    uint32_t lmax = nlines;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) lmax = max(lmax, (uint32_t)__shfl_xor((int)lmax, d, 64));
+    lmax = __builtin_amdgcn_readfirstlane(lmax);
+    for (uint32_t l = 0; l < lmax; ++l) {
+        const bool on = l < nlines;
+        if (on) {
+            const uint8_t* src = line0 + (l << LSH);
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 16 * q),
+                                                 (__attribute__((address_space(3))) void*)(s_line + 64 * q), 16, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const uint32_t lo = l == 0u ? mis : 0u;
+        const uint32_t hi = on ? min(LB, mis + n - (l << LSH)) : 0u;
+        const uint32_t qb = (l & 3u) * 8u;  // bit of this line's first 16-byte piece
+        if (!__any(on && (lo != 0u || hi != LB))) {
+            if (on) {
+                for (int q = 0; q < 8; ++q) {
+                    const uint4 v = s_line[64 * q + lane];
+#pragma unroll
+                    for (int b = 0; b < 16; ++b) {
+                        const uint32_t word = (b >> 2) == 0 ? v.x : (b >> 2) == 1 ? v.y : (b >> 2) == 2 ? v.z : v.w;
+                        step(s_fpeq[(word >> (8 * (b & 3))) & 0xFFu]);
+                    }
+                    commit(qb + (uint32_t)q);
+                }
+            }
+        } else {  // a partial line somewhere in the wave: bytes outside the read skipped
+            for (int q = 0; q < 8; ++q) {
+                const uint4 v = s_line[64 * q + lane];
+#pragma unroll
+                for (int b = 0; b < 16; ++b) {
+                    const uint32_t word = (b >> 2) == 0 ? v.x : (b >> 2) == 1 ? v.y : (b >> 2) == 2 ? v.z : v.w;
+                    const uint32_t p = 16u * (uint32_t)q + (uint32_t)b;
+                    if (p >= lo && p < hi) step(s_fpeq[(word >> (8 * (b & 3))) & 0xFFu]);
+                }
+                commit(qb + (uint32_t)q);
+            }
+        }
+        if (on && ((l & 3u) == 3u || l + 1u == nlines)) {
+            fl0[l >> 2] = bitsA; fl1[l >> 2] = bitsB;
+            bitsA = 0u; bitsB = 0u;
+        }
+    }
+    // Matches of the rc strand that hang over ITS start (the read's last bytes) with o < R rows: rows o..R-1 of the window
+    // end at the read's end, i.e. the rc block's first R-o rows do in its last column: D[R-o][n] + floor(alpha * o) <= k is
+    // necessary.  One bit in the word after the rc strand's piece words tells k_flank_verify to scan the rc strand's
+    // first columns (groups with BB_FILT_RC_BEGIN_HINT; windows that start deeper never hang, see upload_tables).
+    if (live && n && (G->filt_mode & BB_FILT_RC_BEGIN_HINT)) {
+        const uint32_t pb = (pv >> (SA + 16u)) & maskR, mb = (mv >> (SA + 16u)) & maskR;
+        uint32_t hint = 0u;
+        for (int o = 1; o < R; ++o) {
+            const uint32_t low = (1u << (R - o)) - 1u;
+            if ((int32_t)__popc(pb & low) - (int32_t)__popc(mb & low) + ovh[o] <= G->flank_k) hint = 1u;
+        }
+        fl1[(nlines + 3u) >> 2] = hint;
+    }
+}
+
+template <int W, int STRAND>
+__device__ __forceinline__ void flank_verify_lane(const uint8_t* __restrict__ bases, const uint64_t* __restrict__ offsets, uint32_t n_reads,
+                                                  const uint8_t* __restrict__ tables, const bb_group_dev* __restrict__ G, uint32_t g,
+                                                  uint32_t n_groups, const uint32_t* __restrict__ flags, uint32_t* __restrict__ cnt,
+                                                  bb_hit_raw* __restrict__ hits, uint32_t hit_cap, uint32_t* __restrict__ hit_count,
+                                                  const uint32_t* s_peq) {
+    constexpr int S = (W <= 2 ? 2 : (W <= 4 ? 4 : 8));
+    const uint32_t read = blockIdx.x * 256u + threadIdx.x;
+    const bool live = read < n_reads;
+    const uint64_t off0 = offsets[0];
+    const uint64_t off = live ? offsets[read] : off0;
+    const uint32_t n = live ? (uint32_t)(offsets[read + 1] - off) : 0u;
+    const uint8_t* rb = bases + off;
+    const int32_t kk = G->flank_k, score0 = G->score0;
+    const int m = G->m, R = G->filt_rows, U = G->filt_off;
+    const int TB = (m - 1) & 31;
+    const uint32_t* pv0 = reinterpret_cast<const uint32_t*>(tables + G->off_pv0);
+    const int32_t* ovh = reinterpret_cast<const int32_t*>(tables + G->off_ovh);
+
+    uint32_t pv[W], mv[W];
+#pragma unroll
+    for (int w = 0; w < W; ++w) { pv[w] = pv0[w]; mv[w] = 0; }
+    int32_t sc = score0;
+    lm_lane st = {score0, 1u, 0u};
+    hit_buf hb = {0u, 0u, 0u, 0u, 0u};
+    uint32_t idx = 0;  // columns consumed = scan position of the next byte
+    auto step = [&](uint32_t ch) {
+        uint32_t eq[W], d0[W], ph[W], mh[W];
+        load_eq<W, S>(s_peq, ch, eq);
+        myers_step<W>(pv, mv, eq, d0, ph, mh);
+        sc += (int32_t)((ph[W - 1] >> TB) & 1u) - (int32_t)((mh[W - 1] >> TB) & 1u);
+        ++idx;
+        BB_LM_STEP_BUF(st, sc, idx);
+    };
+    // 16 scan positions p0.. as 4 words in scan order (the rc strand reads the text backwards)
+    auto load16 = [&](uint32_t p0, uint32_t (&wq)[4]) {
+        const int64_t a = STRAND ? (int64_t)n - 16 - (int64_t)p0 : (int64_t)p0;
+        if (a >= 0 && a + 16 <= (int64_t)n) {
+            u32x4_t v;
+            __builtin_memcpy(&v, rb + a, 16);
+            if (STRAND) { wq[0] = __builtin_bswap32(v[3]); wq[1] = __builtin_bswap32(v[2]); wq[2] = __builtin_bswap32(v[1]); wq[3] = __builtin_bswap32(v[0]); }
+            else { wq[0] = v[0]; wq[1] = v[1]; wq[2] = v[2]; wq[3] = v[3]; }
+        } else {
+            wq[0] = wq[1] = wq[2] = wq[3] = 0u;
+            for (int b = 0; b < 16; ++b) {
+                const uint32_t p = p0 + (uint32_t)b;
+                if (p < n) wq[b >> 2] |= (uint32_t)rb[STRAND ? (n - 1u - p) : p] << (8 * (b & 3));
+            }
+        }
+    };
+    // ---- interval source: [1] columns 1..m+k+1 (left overhang), [2] the flagged pieces in scan order, [3] the last
+    // columns (the overhang positions continue from column n).  Intervals are in scan positions [a, b): column c <-> position c-1.
+    const uint32_t misf = (uint32_t)((uint64_t)(uintptr_t)rb & 127u);
+    const uint32_t nlines = n ? (misf + n + 127u) >> 7 : 0u;
+    const int32_t nwords = (int32_t)((nlines + 3u) >> 2);
+    const uint32_t* fl = flags + filt_word_base(off, off0, read);
+    int32_t wi = STRAND ? nwords : -1;  // word in hand
+    uint32_t bits = 0u;
+    const uint32_t fmode = (uint32_t)G->filt_mode;
+    bool need_end = (fmode & BB_FILT_END_ALWAYS) != 0;
+    const bool need_begin = (fmode & (STRAND ? BB_FILT_RC_BEGIN_ALWAYS : BB_FILT_FWD_BEGIN_ALWAYS)) != 0 ||
+                            (STRAND == 1 && (fmode & BB_FILT_RC_BEGIN_HINT) && live && n && fl[nwords] != 0u);
+    int phase = live && n ? (need_begin ? 0 : 1) : 3;
+    uint32_t cur = 0u, stop = 0u;  // the run in progress covers positions [.., stop); cur = idx
+    auto next_interval = [&](int64_t& a, int64_t& b) -> bool {  // columns [a, b] (1-based, unclamped)
+        if (phase == 0) { phase = 1; a = 1; b = (int64_t)m + kk + 1; return true; }
+        if (phase == 1) {
+            for (;;) {
+                if (bits == 0u) {
+                    if (STRAND ? wi <= 0 : wi + 1 >= nwords) break;
+                    wi += STRAND ? -1 : 1;
+                    bits = fl[wi];
+                    continue;
+                }
+                const int bi = STRAND ? 31 - __clz((int)bits) : __ffs((int)bits) - 1;
+                bits &= ~(1u << bi);
+                const int64_t q0 = (int64_t)(((uint32_t)wi * 32u + (uint32_t)bi) * 16u) - (int64_t)misf;  // first forward position of the piece
+                const int64_t f0 = q0 < 0 ? 0 : q0, f1 = q0 + 16 > (int64_t)n ? (int64_t)n : q0 + 16;  // forward positions [f0, f1): columns f0+1..f1
+                if (f1 <= f0) continue;
+                // a flag close to the strand's last columns: the match may run past them (right overhang)
+                if (STRAND == 0 ? f1 + (m - U - R) + kk + 2 > (int64_t)n : f0 < (int64_t)(m - U) + kk + 2) need_end = true;
+                if (STRAND == 0) { a = f0 + 1 + (m - U - R) - kk - 1; b = f1 + (m - U - R) + kk + 1; }
+                else { a = (int64_t)n - f1 + (m - U) - kk - 1; b = (int64_t)n - f0 - 1 + (m - U) + kk + 1; }
+                return true;
+            }
+            phase = 2;
+        }
+        if (phase == 2) { phase = 3; if (need_end) { a = (int64_t)n - 1; b = (int64_t)n; return true; } }
+        return false;
+    };
+    bool done = !(live && n);
+    while (__any(!done)) {
+        if (!done && cur >= stop) {
+            // take intervals until one needs columns beyond the run in hand
+            for (;;) {
+                int64_t a, b;
+                if (!next_interval(a, b)) { done = true; break; }
+                if (a < 1) a = 1;
+                if (b > (int64_t)n) b = (int64_t)n;
+                if (b < a || (uint32_t)b <= stop) continue;  // empty, or inside what has been scanned
+                const int64_t s0 = a - 1 - (m + kk) < 0 ? 0 : a - 1 - (m + kk);
+                if ((uint32_t)s0 > cur) {  // a gap: restart from the all-insertions column m + k columns ahead of the interval
+#pragma unroll
+                    for (int x = 0; x < W; ++x) { const int bt = m - 32 * x; pv[x] = bt >= 32 ? 0xFFFFFFFFu : (bt > 0 ? ((1u << bt) - 1u) : 0u); mv[x] = 0u; }
+                    sc = m; st.prev = m;
+                    cur = (uint32_t)s0; idx = cur;
+                }
+                stop = (uint32_t)b;
+                break;
+            }
+        }
+        const bool work = !done && cur < stop;
+        uint32_t wq[4] = {0u, 0u, 0u, 0u};
+        if (work) load16(cur, wq);
+        const uint32_t cntb = work ? min(16u, stop - cur) : 0u;
+#pragma unroll
+        for (int b = 0; b < 16; ++b)
+            if ((uint32_t)b < cntb) step((wq[b >> 2] >> (8 * (b & 3))) & 0xFFu);
+        cur += cntb;
+    }
+    // the overhang positions continue from column n: only if a run got there (otherwise none of them can be <= k)
+    scan_finish<W, STRAND>(live, n, m, kk, sc, pv, mv, idx, st, hb, ovh, read, g, n_groups, cnt, hits, hit_cap, hit_count, idx == n);
+}
+
+template <int W>
+__global__ __launch_bounds__(256) void k_flank_verify(const uint8_t* __restrict__ bases, const uint64_t* __restrict__ offsets, uint32_t n_reads,
+                                                      const uint8_t* __restrict__ tables, const bb_group_dev* __restrict__ groups, uint32_t g,
+                                                      uint32_t n_groups, const uint32_t* __restrict__ flags, uint64_t words_per_strand,
+                                                      uint32_t* __restrict__ cnt, bb_hit_raw* __restrict__ hits, uint32_t hit_cap,
+                                                      uint32_t* __restrict__ hit_count) {
+    constexpr int S = (W <= 2 ? 2 : (W <= 4 ? 4 : 8));
+    __shared__ __attribute__((aligned(16))) uint32_t s_peq[256 * S];
+    const bb_group_dev* G = groups + g;
+    const uint32_t strand = blockIdx.y;
+    {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(tables + G->off_peq_flank[strand]);
+        for (int i = threadIdx.x; i < 256 * S; i += 256) s_peq[i] = src[i];
+    }
+    __syncthreads();
+    if (strand == 0)
+        flank_verify_lane<W, 0>(bases, offsets, n_reads, tables, G, g, n_groups, flags, cnt, hits, hit_cap, hit_count, s_peq);
+    else
+        flank_verify_lane<W, 1>(bases, offsets, n_reads, tables, G, g, n_groups, flags + words_per_strand, cnt, hits, hit_cap, hit_count, s_peq);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -597,7 +959,6 @@ __global__ __launch_bounds__(256) void k_scan_add(uint32_t* __restrict__ out, ui
 // size live in HBM-backed scratch and made this small kernel the largest HBM consumer of the pipeline
 // (profiles/r01_v3_pmc.txt: 10.9 GB fetched per 2 M reads).  The host picks the LDS variant whenever
 // (m + k + 1) * W * 512 bytes fit in 64 KB.
-typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 // MODE 0: move bits in private memory (any geometry); 1: in LDS, every row of every column; 2: in LDS, only the
 // band of 16 rows around the end cell's diagonal (one word per column and lane: both planes).  A path of cost
 // <= k leaves that diagonal by at most k rows, so for k <= 6 the band holds every cell the walk can visit, and

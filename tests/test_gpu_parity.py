@@ -113,6 +113,48 @@ def test_barcode_stage_variants(monkeypatch, knob):
         assert_same(got, want)
 
 
+@pytest.mark.parametrize("mode", ["0", "1", "ends"])
+def test_scan_filter_variants(monkeypatch, mode):
+    """The flank scan runs either as the full-height streaming scan (0) or as filter + windowed verification (1: forced
+    for every group, also where a 15-row window says nothing and every quarter is flagged).  Same hits either way:
+    ragged and tiny reads, reads shorter than the flank, constructs at the very ends (overhang), low-complexity text
+    and repeats of the filter's own rows (dense flags), overhang factors 0 / 0.4 / 1."""
+    from barbell_amd import annotate as A
+
+    monkeypatch.setenv("BARBELL_AMD_SCAN_FILTER", "1" if mode == "ends" else mode)
+    if mode == "ends":  # both ends of every read scanned, whatever the filter's hints say
+        monkeypatch.setenv("BARBELL_AMD_FILTER_ENDS", "1")
+    for cfg, n, lmin, lmax in (("nbd96", 1500, 1, 700), ("nbd96", 800, 3000, 4200), ("dual", 500, 200, 3000), ("rbk96x", 200, 600, 2000), ("rbk24", 300, 50, 1500)):
+        groups = config_groups(cfg)
+        bases, offsets = A.synth_reads_host(groups, 77 + n, lmin, lmax, 0, n)
+        _, got, want = run_both(groups, bases, offsets)
+        assert len(want) > n // 4
+        assert_same(got, want)
+    groups = config_groups("nbd96")
+    flank = bytes(groups[0].seqs[0])
+    rng = np.random.default_rng(11)
+    reads = []
+    for i in range(600):
+        kind = i % 6
+        body = bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), int(rng.integers(0, 900))))
+        if kind == 0: r = flank[int(rng.integers(0, 30)):] + body                 # construct cut at the read's start
+        elif kind == 1: r = body + flank[: len(flank) - int(rng.integers(0, 30))]  # ... and at its end
+        elif kind == 2: r = (b"A" * 300 + body)[: 50 + int(rng.integers(0, 700))]  # homopolymers
+        elif kind == 3: r = flank[:14] * int(rng.integers(1, 40)) + body           # the filter's rows over and over
+        elif kind == 4: r = body[:200] + flank + body[200:] + flank[::-1]
+        else: r = body[: int(rng.integers(0, 20))]                                 # shorter than anything
+        reads.append(r)
+    bases = np.frombuffer(b"".join(reads), dtype=np.uint8).copy()
+    offsets = np.concatenate([[0], np.cumsum([len(r) for r in reads])]).astype(np.uint64)
+    for alpha in (0.0, 0.4, 1.0):
+        _, got, want = run_both(groups, bases, offsets, alpha=alpha)
+        assert len(want) > 100
+        assert_same(got, want)
+    # misaligned batch start: the flag words are addressed relative to offsets[0]
+    _, got, want = run_both(groups, bases[3:], offsets[1:] - np.uint64(3))
+    assert_same(got, want)
+
+
 def test_noisy_reads_exercise_the_fallback():
     """reads with heavy errors inside the constructs: the runner-up's bound often comes within min_score_diff of the top,
     so a good share of hits is decided by the exact kernel"""
