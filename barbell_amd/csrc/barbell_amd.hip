@@ -285,6 +285,9 @@ int upload_tables(bb_ctx* c) {
                 }
                 // the filter itself costs about half a W=2 scan; verification columns are full-height columns
                 bool use = W >= 2 && (double)best_cost / L < 0.3;
+                if (getenv("BARBELL_AMD_VERBOSE"))
+                    fprintf(stderr, "barbell_amd: group %zu flank %d nt, k %d: filter window rows %d..%d, %.4f verification columns per text column -> %s\n", gi, m, k,
+                            best_u, best_u + R - 1, (double)best_cost / L, use ? "filtered scan" : "full scan");
                 if (c->scan_filter == 1) use = true;
                 if (use) {
                     D.filt_rows = R; D.filt_off = best_u;
@@ -439,6 +442,7 @@ int scan_u32(bb_ctx* c, const uint32_t* in, uint32_t* out, uint64_t n) {
 template <int W>
 void launch_scan(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n, uint32_t g, uint64_t flag_words) {
     if (c->gdev[g].filt_rows > 0 && !c->scan_v1) {
+        (void)hipMemsetAsync(c->d_flags, 0, (size_t)2 * flag_words * sizeof(uint32_t), c->stream);  // the filter writes the words that hold a flag
         hipLaunchKernelGGL(k_flank_filter, dim3((n + 255) / 256), dim3(256), 0, c->stream, d_bases, d_offsets, n, (const uint8_t*)c->d_tables,
                            (const bb_group_dev*)c->d_groups, g, c->d_flags, flag_words);
         hipLaunchKernelGGL(k_flank_verify<W>, dim3((n + 255) / 256, 2), dim3(256), 0, c->stream, d_bases, d_offsets, n,

@@ -739,7 +739,8 @@ __global__ __launch_bounds__(256) void k_flank_filter(const uint8_t* __restrict_
             }
         }
         if (on && ((l & 3u) == 3u || l + 1u == nlines)) {
-            fl0[l >> 2] = bitsA; fl1[l >> 2] = bitsB;
+            if (bitsA) fl0[l >> 2] = bitsA;  // the array is zeroed before the launch: only words with a flag are written
+            if (bitsB) fl1[l >> 2] = bitsB;
             bitsA = 0u; bitsB = 0u;
         }
     }
@@ -754,7 +755,7 @@ __global__ __launch_bounds__(256) void k_flank_filter(const uint8_t* __restrict_
             const uint32_t low = (1u << (R - o)) - 1u;
             if ((int32_t)__popc(pb & low) - (int32_t)__popc(mb & low) + ovh[o] <= G->flank_k) hint = 1u;
         }
-        fl1[(nlines + 3u) >> 2] = hint;
+        if (hint) fl1[(nlines + 3u) >> 2] = hint;
     }
 }
 
@@ -963,22 +964,24 @@ __global__ __launch_bounds__(256) void k_scan_add(uint32_t* __restrict__ out, ui
 // band of 16 rows around the end cell's diagonal (one word per column and lane: both planes).  A path of cost
 // <= k leaves that diagonal by at most k rows, so for k <= 6 the band holds every cell the walk can visit, and
 // a quarter of the LDS lets four times as many blocks share a CU.
+#define BB_TRACE_REC_STRIDE 25  // words per staged bb_hit (24) + 1: lanes land in different banks
 template <int W, int MODE>
-__global__ __launch_bounds__(64) void k_flank_trace(const uint8_t* __restrict__ bases, const uint64_t* __restrict__ offsets,
-                                                    const uint8_t* __restrict__ tables, const bb_group_dev* __restrict__ groups,
-                                                    uint32_t n_groups, const bb_hit_raw* __restrict__ raw, uint32_t n_hits,
-                                                    const uint32_t* __restrict__ slot_base, bb_hit* __restrict__ hits, uint32_t g_sel) {
+__device__ __forceinline__ uint32_t flank_trace_lane(const uint8_t* __restrict__ bases, const uint64_t* __restrict__ offsets,
+                                                     const uint8_t* __restrict__ tables, const bb_group_dev* __restrict__ groups,
+                                                     uint32_t n_groups, const bb_hit_raw* __restrict__ raw, uint32_t n_hits,
+                                                     const uint32_t* __restrict__ slot_base, uint32_t g_sel, uint32_t* __restrict__ orec,
+                                                     uint32_t* s_moves) {
     constexpr int S = (W <= 2 ? 2 : (W <= 4 ? 4 : 8));
     constexpr int MAXC = 32 * W + 64;
     const uint32_t t = blockIdx.x * 64u + threadIdx.x;
-    if (t >= n_hits) return;
+    if (t >= n_hits) return 0xFFFFFFFFu;
     const bb_hit_raw h = raw[t];
-    if (groups[h.group].W != W || (g_sel != 0xFFFFFFFFu && h.group != g_sel)) return;
-    const bb_group_dev G = groups[h.group];
+    if (groups[h.group].W != W || (g_sel != 0xFFFFFFFFu && h.group != g_sel)) return 0xFFFFFFFFu;
+    const bb_group_dev& G = groups[h.group];  // not a copy: indexing a private copy by the strand put the struct into scratch memory
     const uint64_t off = offsets[h.read_idx];
     const int32_t n = (int32_t)(offsets[h.read_idx + 1] - off);
     const uint8_t* rb = bases + off;
-    const int m = G.m, k = G.flank_k;
+    const int m = G.m, k = G.flank_k, bar_lo = G.bar_lo, bar_hi = G.bar_hi;
     const uint32_t* peq = reinterpret_cast<const uint32_t*>(tables + G.off_peq_flank[h.strand]);
     const uint32_t* pv0 = reinterpret_cast<const uint32_t*>(tables + G.off_pv0);
     const int32_t* ovh = reinterpret_cast<const int32_t*>(tables + G.off_ovh);
@@ -990,7 +993,7 @@ __global__ __launch_bounds__(64) void k_flank_trace(const uint8_t* __restrict__ 
     if (s0 < 0) s0 = 0;
     const int32_t w = i0 - s0;  // <= m + k < MAXC
 
-    extern __shared__ uint32_t s_moves[];  // MODE 1: [column][lo|hi][word][64 lanes]; MODE 2: [column][64 lanes]
+    // s_moves: MODE 1: [column][lo|hi][word][64 lanes]; MODE 2: [column][64 lanes]
     uint32_t plo_[MODE == 0 ? MAXC : 1][W], phi_[MODE == 0 ? MAXC : 1][W];
     // first row (0-based bit) of column c's band: the diagonal through the end cell (j0, w), k + 1 rows above it
     auto band_lo = [&](int c) -> int { const int b = (j0 - 1) - (w - c) - (k + 1); return b < 0 ? 0 : b; };
@@ -1083,7 +1086,7 @@ __global__ __launch_bounds__(64) void k_flank_trace(const uint8_t* __restrict__ 
         }
         if (op != 2u) --j;
         if (op != 3u) --i;
-        if (j >= G.bar_lo && j <= G.bar_hi) {  // path cell Pos(j, s0+i) of this op
+        if (j >= bar_lo && j <= bar_hi) {  // path cell Pos(j, s0+i) of this op
             const int32_t sp = s0 + i;
             int32_t f = h.strand ? (n - 1 - sp) : sp;
             if (f < 0) f = 0;
@@ -1107,9 +1110,11 @@ __global__ __launch_bounds__(64) void k_flank_trace(const uint8_t* __restrict__ 
     out._pad[0] = out._pad[1] = out._pad[2] = 0;
     out.read_len = (uint32_t)n;
     const uint32_t slot = slot_base[((uint64_t)h.read_idx * n_groups + h.group) * 2 + h.strand] + h.ordinal;
-    uint4* dst = reinterpret_cast<uint4*>(hits + slot);
-    const uint4* src = reinterpret_cast<const uint4*>(&out);
-    dst[0] = src[0]; dst[1] = src[1];
+    {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(&out);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) orec[q] = src[q];
+    }
     const int32_t wn = we - ws;
     const uint8_t* lut = tables + G.off_lut;
     if (wn <= 64) {  // window codes for k_barcode_reg: the window's bytes in four 16-byte loads, then the base-set LUT
@@ -1133,7 +1138,34 @@ __global__ __launch_bounds__(64) void k_flank_trace(const uint8_t* __restrict__ 
                 const uint32_t code = c < wn ? (uint32_t)lut[(tv[q][b >> 2] >> (8 * (b & 3))) & 0xFFu] : 0u;
                 w4[b >> 2] |= code << (8 * (b & 3));
             }
-            dst[2 + q] = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+            orec[8 + 4 * q] = w4[0]; orec[9 + 4 * q] = w4[1]; orec[10 + 4 * q] = w4[2]; orec[11 + 4 * q] = w4[3];
+        }
+    } else {
+#pragma unroll
+        for (int q = 8; q < 24; ++q) orec[q] = 0u;
+    }
+    return slot;
+}
+// The 96-byte records leave through LDS: six adjacent lanes write one record's six 16-byte pieces, so a record goes out
+// as one contiguous burst (a lane writing its own record piece by piece cost ~315 bytes of HBM writes per record,
+// profiles/r02_v23 traffic).
+template <int W, int MODE>
+__global__ __launch_bounds__(64) void k_flank_trace(const uint8_t* __restrict__ bases, const uint64_t* __restrict__ offsets,
+                                                    const uint8_t* __restrict__ tables, const bb_group_dev* __restrict__ groups,
+                                                    uint32_t n_groups, const bb_hit_raw* __restrict__ raw, uint32_t n_hits,
+                                                    const uint32_t* __restrict__ slot_base, bb_hit* __restrict__ hits, uint32_t g_sel) {
+    extern __shared__ uint32_t s_dyn[];
+    __shared__ uint32_t s_rec[64 * BB_TRACE_REC_STRIDE];
+    __shared__ uint32_t s_slot[64];
+    static_assert(sizeof(bb_hit) == 96, "six 16-byte pieces");
+    s_slot[threadIdx.x] = flank_trace_lane<W, MODE>(bases, offsets, tables, groups, n_groups, raw, n_hits, slot_base, g_sel,
+                                                    s_rec + threadIdx.x * BB_TRACE_REC_STRIDE, s_dyn);
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < 64u * 6u; i += 64u) {
+        const uint32_t hl = i / 6u, pc = i - hl * 6u, slot = s_slot[hl];
+        if (slot != 0xFFFFFFFFu) {
+            const uint32_t* r = s_rec + hl * BB_TRACE_REC_STRIDE + 4u * pc;
+            reinterpret_cast<uint4*>(hits + slot)[pc] = make_uint4(r[0], r[1], r[2], r[3]);
         }
     }
 }
@@ -2387,12 +2419,12 @@ __global__ __launch_bounds__(256) void k_collapse(bb_rowtmp* __restrict__ rows, 
     bb_rowtmp* R = rows + b0;
     int n = 0;
     for (uint32_t i = 0; i < b1 - b0; ++i)  // drop hits without a row, keep order
-        if (R[i].row._pad[0]) { if ((int)i != n) R[n].row = R[i].row; ++n; }
+        if (R[i].row._pad[0]) { if ((int)i != n) R[n].row = R[i].row; ++n; }  // (a read's rows are only written when they move)
     for (int i = 1; i < n; ++i) {  // stable insertion sort by read_start_flank (interval.rs:12)
         const bb_row x = R[i].row;
         int j = i - 1;
         while (j >= 0 && R[j].row.read_start_flank > x.read_start_flank) { R[j + 1].row = R[j].row; --j; }
-        R[j + 1].row = x;
+        if (j + 1 != i) R[j + 1].row = x;
     }
     int out = 0, gs = 0;
     for (int i = 1; i <= n; ++i) {
@@ -2405,8 +2437,8 @@ __global__ __launch_bounds__(256) void k_collapse(bb_rowtmp* __restrict__ rows, 
             int best = gs;
             for (int q = gs + 1; q < i; ++q)
                 if (rows_cmp(R[q].row, R[best].row) < 0) best = q;
-            const bb_row b = R[best].row;
-            R[out++].row = b;
+            if (best != out) { const bb_row b = R[best].row; R[out].row = b; }
+            ++out;
             gs = i;
         }
     }
