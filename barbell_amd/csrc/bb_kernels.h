@@ -1909,25 +1909,27 @@ __global__ __launch_bounds__(CW <= 48 ? 768 : 512) void k_barcode_pfx(const uint
     constexpr int SH_PIECE = PIECES_H + 1 + BB_MAX_TAIL / 2;  // first piece of sh[] inside a hit's record pair
     // LDS carve: [hit + prefix records: hpb x 400 B][max u64[hpb]][second u64[hpb]][cnt1 i32[hpb]][top i32[hpb]][walk table]
     // [peq 16*N words][move planes of the trailing rows: T x 2 x blockDim u64]
-    uint4* s_hit = reinterpret_cast<uint4*>(smem);
-    size_t o = (size_t)hpb * PIECES * 16;
-    unsigned long long* s_max = reinterpret_cast<unsigned long long*>(smem + o);
-    o += (size_t)hpb * 8;
-    unsigned long long* s_sec = reinterpret_cast<unsigned long long*>(smem + o);
-    o += (size_t)hpb * 8;
-    int32_t* s_cnt1 = reinterpret_cast<int32_t*>(smem + o);
-    o += (size_t)hpb * 4;
-    int32_t* s_top = reinterpret_cast<int32_t*>(smem + o);
-    o += (size_t)hpb * 4;
+    // Everything a set of hpb hits owns exists twice ([2][..]): while the lanes work on one set, the next set's records
+    // land in the other half and its per-column tables are built there, so an iteration needs two barriers, not five.
+    uint4* s_hit2 = reinterpret_cast<uint4*>(smem);
+    size_t o = (size_t)2 * hpb * PIECES * 16;
+    unsigned long long* s_max2 = reinterpret_cast<unsigned long long*>(smem + o);
+    o += (size_t)2 * hpb * 8;
+    unsigned long long* s_sec2 = reinterpret_cast<unsigned long long*>(smem + o);
+    o += (size_t)2 * hpb * 8;
+    unsigned long long* s_maxB2 = reinterpret_cast<unsigned long long*>(smem + o);  // fast variant: top-2 of the pass-2 candidate set
+    o += (size_t)2 * hpb * 8;
+    unsigned long long* s_secB2 = reinterpret_cast<unsigned long long*>(smem + o);
+    o += (size_t)2 * hpb * 8;
+    int32_t* s_cnt12 = reinterpret_cast<int32_t*>(smem + o);
+    o += (size_t)2 * hpb * 4;
+    int32_t* s_top2 = reinterpret_cast<int32_t*>(smem + o);
+    o += (size_t)2 * hpb * 4;
     o = (o + 15) & ~(size_t)15;
-    unsigned long long* s_maxB = reinterpret_cast<unsigned long long*>(smem + o);  // fast variant: top-2 of the pass-2 candidate set
-    o += (size_t)hpb * 8;
-    unsigned long long* s_secB = reinterpret_cast<unsigned long long*>(smem + o);
-    o += (size_t)hpb * 8;
-    uint2* s_tab = reinterpret_cast<uint2*>(smem + o);  // [hpb][CW]: the walk through the shared rows per entry column
-    o += (size_t)hpb * CW * 8;
-    uint2* s_col = reinterpret_cast<uint2*>(smem + o);  // [hpb][CW]: what every barcode lane of a hit needs of a column
-    o += (size_t)hpb * CW * 8;
+    uint2* s_tab2 = reinterpret_cast<uint2*>(smem + o);  // [2][hpb][CW]: the walk through the shared rows per entry column
+    o += (size_t)2 * hpb * CW * 8;
+    uint2* s_col2 = reinterpret_cast<uint2*>(smem + o);  // [2][hpb][CW]: what every barcode lane of a hit needs of a column
+    o += (size_t)2 * hpb * CW * 8;
     uint32_t* s_peq = reinterpret_cast<uint32_t*>(smem + o);
     o += (size_t)16 * N * 4;
     o = (o + 15) & ~(size_t)15;
@@ -1952,31 +1954,39 @@ __global__ __launch_bounds__(CW <= 48 ? 768 : 512) void k_barcode_pfx(const uint
         const uint32_t li = it * hpb + (uint32_t)hl;
         if (in_blk && p < PIECES && it < n_iter && li < n_list) pre = piece(hit_list ? hit_list[li] : li, p);
     };
-    prefetch(blockIdx.x);
-  for (uint32_t it = blockIdx.x; it < n_iter; it += gridDim.x) {
-    const uint32_t li = it * hpb + (uint32_t)hl;
-    const bool exists = in_blk && li < n_list;
-    if (exists && p < PIECES) {
-        s_hit[hl * PIECES + p] = pre;
-        if (p + N < PIECES) s_hit[hl * PIECES + p + N] = piece(hit_list ? hit_list[li] : li, p + N);
-    }
-    if (in_blk && p == 0) { s_max[hl] = 0ull; s_sec[hl] = 0ull; s_cnt1[hl] = 0; s_top[hl] = 0x7FFFFFFF; s_maxB[hl] = 0ull; s_secB[hl] = 0ull; }
-    BB_PFX_SYNC();
-    const uint32_t hit_idx = hit_list ? (exists ? hit_list[li] : 0u) : li;
-    prefetch(it + gridDim.x);
+    // set `it` -> half h: lane p of a hit stores piece p of its record pair (prefetched in `pre`)
+    auto store_set = [&](uint32_t it, uint32_t h) {
+        const uint32_t li = it * hpb + (uint32_t)hl;
+        if (in_blk && p < PIECES && it < n_iter && li < n_list) {
+            uint4* dst = s_hit2 + ((size_t)h * hpb + hl) * PIECES;
+            dst[p] = pre;
+            if (p + N < PIECES) dst[p + N] = piece(hit_list ? hit_list[li] : li, p + N);
+        }
+    };
+    // per-column table and reduction cells of the set in half h (all lanes)
+    auto build_cols = [&](uint32_t h) {
+        const uint4* hitb = s_hit2 + (size_t)h * hpb * PIECES;
+        uint2* colb = s_col2 + (size_t)h * hpb * CW;
+        if (in_blk && p == 0) {
+            const uint32_t x = h * hpb + (uint32_t)hl;
+            s_max2[x] = 0ull; s_sec2[x] = 0ull; s_cnt12[x] = 0; s_top2[x] = 0x7FFFFFFF; s_maxB2[x] = 0ull; s_secB2[x] = 0ull;
+        }
     // Per (hit, column), once for the hit's N barcode lanes: x = byte offset of the column's base-set row in the Peq table,
     // y = carry-in of the shared rows (bit 0: horizontal +1, bit 1: horizontal -1 of row P).  The lanes then spend one
     // 8-byte LDS read and three full-rate operations per column instead of three bit-field extractions and a
     // multiply-add (all half rate, profiles/valu_ceiling.json).
     for (uint32_t l = threadIdx.x; l < hpb * (uint32_t)CW; l += blockDim.x) {
         const uint32_t hw = l / (uint32_t)CW, c = l % (uint32_t)CW;
-        const uint32_t* rec = reinterpret_cast<const uint32_t*>(s_hit + hw * PIECES);
+        const uint32_t* rec = reinterpret_cast<const uint32_t*>(hitb + hw * PIECES);
         const uint32_t code = (rec[8 + (c >> 2)] >> (8u * (c & 3u))) & 0xFu;
-        const uint32_t* hv = reinterpret_cast<const uint32_t*>(s_hit + hw * PIECES + PIECES_H);  // {ph lo, ph hi, mh lo, mh hi}
+        const uint32_t* hv = reinterpret_cast<const uint32_t*>(hitb + hw * PIECES + PIECES_H);  // {ph lo, ph hi, mh lo, mh hi}
         const uint32_t hp = (hv[c >> 5] >> (c & 31u)) & 1u, hm = (hv[2 + (c >> 5)] >> (c & 31u)) & 1u;
-        s_col[l] = make_uint2(code * (uint32_t)N * 4u, hp | (hm << 1));
+        colb[l] = make_uint2(code * (uint32_t)N * 4u, hp | (hm << 1));
     }
-    BB_PFX_SYNC();
+    };
+    auto build_walks = [&](uint32_t h) {
+        const uint4* hitb = s_hit2 + (size_t)h * hpb * PIECES;
+        uint2* tabb = s_tab2 + (size_t)h * hpb * CW;
     // The walk of a traced path through the shared rows depends only on the hit and on the column in which the
     // path enters row P, not on the barcode: the first hpb * CW lanes of the block each walk one (hit, entry column)
     // once — 16 columns from independent LDS reads, static register indices — and every barcode lane later looks
@@ -1989,7 +1999,7 @@ __global__ __launch_bounds__(CW <= 48 ? 768 : 512) void k_barcode_pfx(const uint
         for (uint32_t l = threadIdx.x; l < hpb * (uint32_t)CW; l += blockDim.x) {
             const uint32_t hw = l / (uint32_t)CW;
             const int32_t cxw = (int32_t)(l % (uint32_t)CW) + 1;
-            const uint32_t* shw = reinterpret_cast<const uint32_t*>(s_hit + hw * PIECES + SH_PIECE);
+            const uint32_t* shw = reinterpret_cast<const uint32_t*>(hitb + hw * PIECES + SH_PIECE);
             uint32_t bh = 1u, lo2 = 0u, hi2 = 0u, dgw = 0u, n2 = 0u;
 #pragma unroll 1
 #ifdef BB_EXP_NO_WALK
@@ -2010,9 +2020,30 @@ __global__ __launch_bounds__(CW <= 48 ? 768 : 512) void k_barcode_pfx(const uint
                 n2 += has ? 1u : 0u;
             }
             if (cxw - 16 < 1) bh = 0u;
-            s_tab[l] = make_uint2(lo2 | (hi2 << 16), dgw | (n2 << 16) | (bh ? 0x80000000u | ((uint32_t)(__ffs(bh) - 1) << 24) : 0u));
+            tabb[l] = make_uint2(lo2 | (hi2 << 16), dgw | (n2 << 16) | (bh ? 0x80000000u | ((uint32_t)(__ffs(bh) - 1) << 24) : 0u));
         }
     }
+    };
+    prefetch(blockIdx.x);
+    store_set(blockIdx.x, 0u);
+    prefetch(blockIdx.x + gridDim.x);
+    BB_PFX_SYNC();
+    build_cols(0u);
+    build_walks(0u);
+    BB_PFX_SYNC();
+    uint32_t half = 0u;
+  for (uint32_t it = blockIdx.x; it < n_iter; it += gridDim.x, half ^= 1u) {
+    const uint32_t li = it * hpb + (uint32_t)hl;
+    const bool exists = in_blk && li < n_list;
+    const uint32_t hit_idx = hit_list ? (exists ? hit_list[li] : 0u) : li;
+    // the next set's records go to the other half (its last readers finished before the barrier this wave just left)
+    store_set(it + gridDim.x, half ^ 1u);
+    prefetch(it + 2u * gridDim.x);
+    const uint4* s_hit = s_hit2 + (size_t)half * hpb * PIECES;
+    const uint2* s_col = s_col2 + (size_t)half * hpb * CW;
+    const uint2* s_tab = s_tab2 + (size_t)half * hpb * CW;
+    unsigned long long* s_max = s_max2 + half * hpb, *s_sec = s_sec2 + half * hpb, *s_maxB = s_maxB2 + half * hpb, *s_secB = s_secB2 + half * hpb;
+    int32_t* s_cnt1 = s_cnt12 + half * hpb, *s_top = s_top2 + half * hpb;
     bb_hit H;  // header only
     {
         const uint4 h0 = s_hit[hls * PIECES], h1 = s_hit[hls * PIECES + 1];
@@ -2183,7 +2214,7 @@ __global__ __launch_bounds__(CW <= 48 ? 768 : 512) void k_barcode_pfx(const uint
     // alive after the table's 16 columns (more than 16 - P insertions inside the shared rows) finishes in the
     // loop underneath on the move bits of the hit's prefix record. ----
     uint32_t dgh = 0u;
-    BB_PFX_SYNC();  // the walk table: its builders ran alongside the other waves' forward pass and traceback
+    BB_PFX_SYNC();  // barrier A: every wave is done with the previous set; the next set's records are in place
     {
         const uint32_t pm = (1u << P) - 1u;
         const uint2 e = (cand && cx >= 1) ? s_tab[hls * CW + cx - 1] : make_uint2(0u, 0u);
@@ -2237,7 +2268,8 @@ __global__ __launch_bounds__(CW <= 48 ? 768 : 512) void k_barcode_pfx(const uint
                 atomicMax(&s_sec[hl], o1 < key ? o1 : key);
             }
         }
-        BB_PFX_SYNC();
+        build_cols(half ^ 1u);
+        BB_PFX_SYNC();  // barrier B: the set's candidates are posted, the next set's column table is complete
         if (active) {
             const bool pass2 = s_sec[hl] == 0ull && G.k1 < G.k2;
             const unsigned long long mx = pass2 ? s_maxB[hl] : s_max[hl], sx = pass2 ? s_secB[hl] : s_sec[hl];
@@ -2267,7 +2299,10 @@ __global__ __launch_bounds__(CW <= 48 ? 768 : 512) void k_barcode_pfx(const uint
                 rows[hit_idx] = R;
             }
         }
+        build_walks(half ^ 1u);  // read after the next barrier A; built while the slower waves finish this set
     } else {
+        build_cols(half ^ 1u);
+        build_walks(half ^ 1u);
         double s_norm = -1.0;
         if (cand) {
             const double sc = lodhi_replay<CW>(plo, phi, delrow, tstart, best_pos, wmax);
@@ -2275,8 +2310,8 @@ __global__ __launch_bounds__(CW <= 48 ? 768 : 512) void k_barcode_pfx(const uint
         } else (void)lodhi_replay<CW>(0ull, 0ull, 0ull, 0, 0, wmax);  // the loop is wave-uniform: idle lanes walk it with empty masks
         pick_and_emit(active, cand, best_cost, s_norm, p, hl, H, hit_idx, G, plo, phi, diagrow, tstart, best_pos, s_cnt1, s_max, s_sec, s_top,
                       min_score, min_score_diff, rows);
+        BB_PFX_SYNC();
     }
-    BB_PFX_SYNC();
   }
 }
 
