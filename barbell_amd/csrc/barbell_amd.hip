@@ -136,6 +136,7 @@ struct bb_ctx {
     uint32_t *d_cnt = nullptr, *d_base = nullptr, *d_sums = nullptr, *d_nrows = nullptr, *d_rowoff = nullptr;
     uint32_t *d_hitcount = nullptr, *d_lists = nullptr, *d_listcnt = nullptr;
     uint32_t *d_fb_lists = nullptr, *d_fbcnt = nullptr;  // hits the fast barcode kernel's bounds left undecided, per (group, strand)
+    uint32_t* d_vqueue = nullptr;  // k_flank_verify's item counters (one per strand)
     uint32_t* d_flags = nullptr; uint64_t cap_flags = 0;  // filtered scan: one bit per 32 text bytes and strand (k_flank_filter)
     int scan_filter = -1;        // BARBELL_AMD_SCAN_FILTER: 0 never, 1 wherever it is valid (tests), unset: where the prefix says enough
     bool fast_path = true;       // BARBELL_AMD_NO_FAST=1: score every barcode of every hit exactly (the fallback kernel only)
@@ -245,7 +246,13 @@ int upload_tables(bb_ctx* c) {
         // Filtered scan (bb_kernels.h, k_flank_filter): worth it when the window's score is rarely <= k in unrelated text.
         // Every window position is tried on 32 K pseudo-random bases with the filter's own recurrence (runs of flagged
         // columns per text column); the quietest one is taken.
-        D.filt_rows = 0; D.filt_off = 0;
+        D.filt_rows = 0; D.filt_off = 0; D.filt_mode = 0;
+        {
+            int o_max = 0;
+            for (int o = 1; o <= m; ++o)
+                if (overhang_cost(alpha, o) <= D.flank_k) o_max = o;
+            D.ovh_steps = std::min(m, o_max + 1);
+        }
         {
             const int R = std::min(15, m), k = D.flank_k;
             if (c->scan_filter != 0 && m >= 2 && k < m) {
@@ -376,6 +383,7 @@ int upload_tables(bb_ctx* c) {
     HIPCHK(c, hipMalloc((void**)&c->d_hitcount, 16));
     HIPCHK(c, hipMalloc((void**)&c->d_listcnt, sizeof(uint32_t) * 4 * BB_MAX_GROUPS));
     HIPCHK(c, hipMalloc((void**)&c->d_fbcnt, sizeof(uint32_t) * 4 * BB_MAX_GROUPS));
+    HIPCHK(c, hipMalloc((void**)&c->d_vqueue, sizeof(uint32_t) * 4));
     // synth tables
     std::vector<std::vector<std::string>> seqs;
     for (auto& g : c->groups) seqs.push_back(g.seqs);
@@ -445,9 +453,11 @@ void launch_scan(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets, u
         (void)hipMemsetAsync(c->d_flags, 0, (size_t)2 * flag_words * sizeof(uint32_t), c->stream);  // the filter writes the words that hold a flag
         hipLaunchKernelGGL(k_flank_filter, dim3((n + 255) / 256), dim3(256), 0, c->stream, d_bases, d_offsets, n, (const uint8_t*)c->d_tables,
                            (const bb_group_dev*)c->d_groups, g, c->d_flags, flag_words);
-        hipLaunchKernelGGL(k_flank_verify<W>, dim3((n + 255) / 256, 2), dim3(256), 0, c->stream, d_bases, d_offsets, n,
+        (void)hipMemsetAsync(c->d_vqueue, 0, 2 * sizeof(uint32_t), c->stream);
+        const uint32_t vblocks = std::min((n + 255u) / 256u, (uint32_t)c->n_cus * 3u);  // persistent: lanes draw (read, strand) items from a queue
+        hipLaunchKernelGGL(k_flank_verify<W>, dim3(vblocks, 2), dim3(256), 0, c->stream, d_bases, d_offsets, n,
                            (const uint8_t*)c->d_tables, (const bb_group_dev*)c->d_groups, g, (uint32_t)c->groups.size(),
-                           (const uint32_t*)c->d_flags, flag_words, c->d_cnt, c->d_raw, c->cap_hits, c->d_hitcount);
+                           (const uint32_t*)c->d_flags, flag_words, c->d_cnt, c->d_raw, c->cap_hits, c->d_hitcount, c->d_vqueue);
         return;
     }
     if (!c->scan_v1 || W > 4) {
@@ -659,7 +669,7 @@ void bb_destroy(bb_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     void* ptrs[] = {c->d_groups, c->d_tables, c->d_counts, c->d_cnt, c->d_base, c->d_sums, c->d_nrows, c->d_rowoff, c->d_hitcount,
-                    c->d_lists, c->d_listcnt, c->d_fb_lists, c->d_fbcnt, c->d_flags, c->d_raw, c->d_hits, c->d_pfx, c->d_rows, c->d_in_bases, c->d_in_offsets, c->d_out_rows,
+                    c->d_lists, c->d_listcnt, c->d_fb_lists, c->d_fbcnt, c->d_flags, c->d_vqueue, c->d_raw, c->d_hits, c->d_pfx, c->d_rows, c->d_in_bases, c->d_in_offsets, c->d_out_rows,
                     c->d_synth_table, c->d_fpats, c->d_felems, c->d_flabel_ok, c->d_flabel_ids, c->d_frows, c->d_fout, c->d_iout};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);

@@ -84,6 +84,8 @@ struct bb_group_dev {
     uint32_t off_tail_lut[2];    // [strand] 16 bytes: bit t of byte[code] = trailing row t matches base set `code`
     int32_t filt_off;            // first flank row of the filter's window (rows filt_off .. filt_off + filt_rows - 1)
     int32_t filt_mode;           // BB_FILT_* bits
+    int32_t ovh_steps;           // overhang positions worth visiting after the last column: min(m, 1 + max{o : floor(alpha*o) <= k})
+    int32_t _pad2;
 };
 // Which fixed intervals k_flank_verify scans besides the flagged ones (o_max = most rows that can hang over a read end at
 // a cost <= k; u, R = the window; see upload_tables):

@@ -341,19 +341,36 @@ struct hit_buf {
         ST.prev = cur_;                                                                         \
     } while (0)
 
+#define BB_VERIFY_STAGE 320u  // hit records per wave in k_flank_verify's LDS staging area (>= 64 lanes x 4 buffered hits + one round)
+// wave-wide: the staged records go out with one atomic and 16-byte stores of consecutive lanes
+__device__ __forceinline__ void stage_flush(const bb_hit_raw* stage, uint32_t fill, bb_hit_raw* __restrict__ hits, uint32_t hit_cap,
+                                            uint32_t* __restrict__ hit_count) {
+    const uint32_t lane = threadIdx.x & 63u;
+    if (fill == 0u) return;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    uint32_t base = 0u;
+    if (lane == 0u) base = atomicAdd(hit_count, fill);
+    base = (uint32_t)__shfl((int)base, 0, 64);
+    for (uint32_t i = lane; i < fill; i += 64u)
+        if (base + i < hit_cap) hits[base + i] = stage[i];
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+}
 // End of a (read, strand) scan, shared by the streaming scan and the windowed verification: the right-overhang
 // positions after the last column, the pending local minimum, the count, and the flush of the buffered hits.
 template <int W, int STRAND>
 __device__ __forceinline__ void scan_finish(bool live, uint32_t n, int m, int32_t kk, int32_t sc, uint32_t (&pv)[W], uint32_t (&mv)[W],
                                             uint32_t idx, lm_lane& st, hit_buf& hb, const int32_t* __restrict__ ovh, uint32_t read,
                                             uint32_t g, uint32_t n_groups, uint32_t* __restrict__ cnt, bb_hit_raw* __restrict__ hits,
-                                            uint32_t hit_cap, uint32_t* __restrict__ hit_count, bool at_end = true) {
+                                            uint32_t hit_cap, uint32_t* __restrict__ hit_count, bool at_end = true, int ovh_steps = 0x7FFFFFFF,
+                                            bb_hit_raw* stage = nullptr, uint32_t* stage_fill = nullptr) {
     const uint32_t lane = threadIdx.x & 63u;
     const int TB = (m - 1) & 31;
     // right overhang (oracle [H4]): C[n+o] = D[m-o][n] + floor(alpha*o), o = 1..m
     if (live) {
         int32_t d = sc;
-        for (int o = 1; at_end && o <= m; ++o) {
+        // positions beyond the last o with floor(alpha * o) <= k cost more than k: the first of them closes a pending minimum,
+        // the rest change nothing (ovh_steps = that o + 1, capped at m)
+        for (int o = 1; at_end && o <= m && o <= ovh_steps; ++o) {
             d -= (int32_t)((pv[W - 1] >> TB) & 1u) - (int32_t)((mv[W - 1] >> TB) & 1u);
 #pragma unroll
             for (int w = W - 1; w >= 0; --w) {
@@ -384,7 +401,23 @@ __device__ __forceinline__ void scan_finish(bool live, uint32_t n, int m, int32_
         for (int d = 1; d < 64; d <<= 1) { const uint32_t y = (uint32_t)__shfl_up((int)incl, d, 64); if ((int)lane >= d) incl += y; }
         const uint32_t total = (uint32_t)__shfl((int)incl, 63, 64);
         uint32_t base = 0;
-        if (total) {
+        if (stage) {
+            // the wave's LDS staging area (BB_VERIFY_STAGE records): filled item by item, written out with one atomic when the
+            // next item's hits would not fit (and by the caller at the end)
+            uint32_t fill = *stage_fill;
+            if (fill + total > BB_VERIFY_STAGE) { stage_flush(stage, fill, hits, hit_cap, hit_count); fill = 0u; }
+            const uint32_t es[4] = {hb.e0, hb.e1, hb.e2, hb.e3};
+#pragma unroll
+            for (uint32_t k = 0; k < 4; ++k) {
+                if (k < mine) {
+                    bb_hit_raw h;
+                    h.read_idx = read; h.e = es[k]; h.cost = (int16_t)((hb.costs >> (8u * k)) & 0xFFu);
+                    h.group = (uint8_t)g; h.strand = (uint8_t)STRAND; h.ordinal = k;
+                    stage[fill + incl - mine + k] = h;
+                }
+            }
+            *stage_fill = fill + total;
+        } else if (total) {
             if (lane == 0) base = atomicAdd(hit_count, total);
             base = (uint32_t)__shfl((int)base, 0, 64);
             uint32_t slot = base + incl - mine;
@@ -414,7 +447,7 @@ __device__ __forceinline__ void scan_finish(bool live, uint32_t n, int m, int32_
 template <int W, int STRAND>
 __device__ __forceinline__ void flank_scan_lane(const uint8_t* __restrict__ bases, const uint64_t* __restrict__ offsets,
                                                 uint32_t n_reads, const uint8_t* __restrict__ tables, int32_t kk, int m, int32_t score0,
-                                                uint32_t off_pv0, uint32_t off_ovh,
+                                                uint32_t off_pv0, uint32_t off_ovh, int ovh_steps,
                                                 uint32_t g, uint32_t n_groups, uint32_t* __restrict__ cnt,
                                                 bb_hit_raw* __restrict__ hits, uint32_t hit_cap, uint32_t* __restrict__ hit_count,
                                                 const uint32_t* s_peq, uint4* s_line /* this wave's [BB_SCAN_LQ][64] */) {
@@ -579,7 +612,7 @@ __device__ __forceinline__ void flank_scan_lane(const uint8_t* __restrict__ base
     for (uint32_t t = 0; t < tail; ++t) step(STRAND == 0 ? rb[head + (nlines << LSH) + t] : rb[tail - 1 - t]);
 #endif
 
-    scan_finish<W, STRAND>(live, n, m, kk, sc, pv, mv, idx, st, hb, ovh, read, g, n_groups, cnt, hits, hit_cap, hit_count);
+    scan_finish<W, STRAND>(live, n, m, kk, sc, pv, mv, idx, st, hb, ovh, read, g, n_groups, cnt, hits, hit_cap, hit_count, true, ovh_steps);
 }
 
 template <int W>
@@ -603,9 +636,9 @@ __global__ __launch_bounds__(256) void k_flank_scan2(const uint8_t* __restrict__
     const int m = G->m;
     const uint32_t o_pv0 = G->off_pv0, o_ovh = G->off_ovh;
     if (strand == 0)
-        flank_scan_lane<W, 0>(bases, offsets, n_reads, tables, kk, m, score0, o_pv0, o_ovh, g, n_groups, cnt, hits, hit_cap, hit_count, s_peq, line);
+        flank_scan_lane<W, 0>(bases, offsets, n_reads, tables, kk, m, score0, o_pv0, o_ovh, G->ovh_steps, g, n_groups, cnt, hits, hit_cap, hit_count, s_peq, line);
     else
-        flank_scan_lane<W, 1>(bases, offsets, n_reads, tables, kk, m, score0, o_pv0, o_ovh, g, n_groups, cnt, hits, hit_cap, hit_count, s_peq, line);
+        flank_scan_lane<W, 1>(bases, offsets, n_reads, tables, kk, m, score0, o_pv0, o_ovh, G->ovh_steps, g, n_groups, cnt, hits, hit_cap, hit_count, s_peq, line);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -759,28 +792,44 @@ __global__ __launch_bounds__(256) void k_flank_filter(const uint8_t* __restrict_
     }
 }
 
+// Items = (read, strand) pairs, handed to lanes from a queue (one counter per strand): a read's verification work ranges
+// from nothing to several intervals plus both ends, and a wave that gave every lane one fixed read waited for its busiest
+// lane (a third of the lane-iterations did work).  A lane takes the next item as soon as its own is finished; finishing
+// (overhang positions, count, flush of the buffered hits) is wave-wide code, run whenever some lane has an item to close.
 template <int W, int STRAND>
 __device__ __forceinline__ void flank_verify_lane(const uint8_t* __restrict__ bases, const uint64_t* __restrict__ offsets, uint32_t n_reads,
                                                   const uint8_t* __restrict__ tables, const bb_group_dev* __restrict__ G, uint32_t g,
                                                   uint32_t n_groups, const uint32_t* __restrict__ flags, uint32_t* __restrict__ cnt,
                                                   bb_hit_raw* __restrict__ hits, uint32_t hit_cap, uint32_t* __restrict__ hit_count,
-                                                  const uint32_t* s_peq) {
+                                                  uint32_t* __restrict__ queue, const uint32_t* s_peq, bb_hit_raw* stage) {
     constexpr int S = (W <= 2 ? 2 : (W <= 4 ? 4 : 8));
-    const uint32_t read = blockIdx.x * 256u + threadIdx.x;
-    const bool live = read < n_reads;
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t stage_fill = 0u;               // wave-uniform
+    uint32_t pool_next = 0u, pool_end = 0u;  // wave-uniform: items [pool_next, pool_end) of the queue belong to this wave
     const uint64_t off0 = offsets[0];
-    const uint64_t off = live ? offsets[read] : off0;
-    const uint32_t n = live ? (uint32_t)(offsets[read + 1] - off) : 0u;
-    const uint8_t* rb = bases + off;
     const int32_t kk = G->flank_k, score0 = G->score0;
     const int m = G->m, R = G->filt_rows, U = G->filt_off;
     const int TB = (m - 1) & 31;
     const uint32_t* pv0 = reinterpret_cast<const uint32_t*>(tables + G->off_pv0);
     const int32_t* ovh = reinterpret_cast<const int32_t*>(tables + G->off_ovh);
+    const uint32_t fmode = (uint32_t)G->filt_mode;
+    const int ovh_steps = G->ovh_steps;
 
+    // ---- the item in hand
+    enum : uint32_t { FREE = 0u, WORK = 1u, FIN = 2u, EXHAUSTED = 3u };
+    uint32_t state = FREE;
+    uint32_t read = 0u, n = 0u;
+    const uint8_t* rb = bases;
+    const uint32_t* fl = flags;
+    uint32_t misf = 0u;
+    int32_t nwords = 0, wi = 0;
+    uint32_t bits = 0u;
+    int phase = 3;
+    bool need_end = false;
+    uint32_t cur = 0u, stop = 0u;  // the run in progress covers positions [.., stop); cur = idx
     uint32_t pv[W], mv[W];
 #pragma unroll
-    for (int w = 0; w < W; ++w) { pv[w] = pv0[w]; mv[w] = 0; }
+    for (int w = 0; w < W; ++w) { pv[w] = 0u; mv[w] = 0u; }
     int32_t sc = score0;
     lm_lane st = {score0, 1u, 0u};
     hit_buf hb = {0u, 0u, 0u, 0u, 0u};
@@ -809,21 +858,10 @@ __device__ __forceinline__ void flank_verify_lane(const uint8_t* __restrict__ ba
             }
         }
     };
-    // ---- interval source: [1] columns 1..m+k+1 (left overhang), [2] the flagged pieces in scan order, [3] the last
-    // columns (the overhang positions continue from column n).  Intervals are in scan positions [a, b): column c <-> position c-1.
-    const uint32_t misf = (uint32_t)((uint64_t)(uintptr_t)rb & 127u);
-    const uint32_t nlines = n ? (misf + n + 127u) >> 7 : 0u;
-    const int32_t nwords = (int32_t)((nlines + 3u) >> 2);
-    const uint32_t* fl = flags + filt_word_base(off, off0, read);
-    int32_t wi = STRAND ? nwords : -1;  // word in hand
-    uint32_t bits = 0u;
-    const uint32_t fmode = (uint32_t)G->filt_mode;
-    bool need_end = (fmode & BB_FILT_END_ALWAYS) != 0;
-    const bool need_begin = (fmode & (STRAND ? BB_FILT_RC_BEGIN_ALWAYS : BB_FILT_FWD_BEGIN_ALWAYS)) != 0 ||
-                            (STRAND == 1 && (fmode & BB_FILT_RC_BEGIN_HINT) && live && n && fl[nwords] != 0u);
-    int phase = live && n ? (need_begin ? 0 : 1) : 3;
-    uint32_t cur = 0u, stop = 0u;  // the run in progress covers positions [.., stop); cur = idx
-    auto next_interval = [&](int64_t& a, int64_t& b) -> bool {  // columns [a, b] (1-based, unclamped)
+    // ---- interval source: [1] columns 1..m+k+1 (left overhang; only where the flags cannot vouch for the strand's start),
+    // [2] the flagged pieces in scan order, [3] the last columns (the overhang positions continue from column n; only
+    // where a flag lies close to the strand's end).  Columns [a, b], 1-based, unclamped.
+    auto next_interval = [&](int64_t& a, int64_t& b) -> bool {
         if (phase == 0) { phase = 1; a = 1; b = (int64_t)m + kk + 1; return true; }
         if (phase == 1) {
             for (;;) {
@@ -849,13 +887,56 @@ __device__ __forceinline__ void flank_verify_lane(const uint8_t* __restrict__ ba
         if (phase == 2) { phase = 3; if (need_end) { a = (int64_t)n - 1; b = (int64_t)n; return true; } }
         return false;
     };
-    bool done = !(live && n);
-    while (__any(!done)) {
-        if (!done && cur >= stop) {
+    for (;;) {
+        // ---- free lanes take the next items of this strand's queue: the wave draws 64 at a time (one atomic), lanes
+        // help themselves from that pool; a lane the pool cannot serve this round tries again in the next
+        {
+            const bool want = state == FREE;
+            const unsigned long long wm = __ballot(want);
+            if (wm) {
+                if (pool_next == pool_end) {
+                    uint32_t base = 0u;
+                    if (lane == 0u) base = atomicAdd(queue, 64u);
+                    pool_next = (uint32_t)__builtin_amdgcn_readfirstlane((int)__shfl((int)base, 0, 64));
+                    pool_end = pool_next + 64u;
+                }
+                const uint32_t rank = (uint32_t)__popcll(wm & ((1ull << lane) - 1ull)), avail = pool_end - pool_next;
+                const uint32_t took = min((uint32_t)__popcll(wm), avail);
+                if (want && rank < avail) {
+                    read = pool_next + rank;
+                    if (read < n_reads) {
+                        const uint64_t off = offsets[read];
+                        n = (uint32_t)(offsets[read + 1] - off);
+                        rb = bases + off;
+                        misf = (uint32_t)((uint64_t)(uintptr_t)rb & 127u);
+                        const uint32_t nlines = n ? (misf + n + 127u) >> 7 : 0u;
+                        nwords = (int32_t)((nlines + 3u) >> 2);
+                        fl = flags + filt_word_base(off, off0, read);
+                        wi = STRAND ? nwords : -1;
+                        bits = 0u;
+                        need_end = (fmode & BB_FILT_END_ALWAYS) != 0;
+                        const bool need_begin = (fmode & (STRAND ? BB_FILT_RC_BEGIN_ALWAYS : BB_FILT_FWD_BEGIN_ALWAYS)) != 0 ||
+                                                (STRAND == 1 && (fmode & BB_FILT_RC_BEGIN_HINT) && n && fl[nwords] != 0u);
+                        phase = n ? (need_begin ? 0 : 1) : 3;
+                        cur = 0u; stop = 0u; idx = 0u;
+#pragma unroll
+                        for (int w = 0; w < W; ++w) { pv[w] = pv0[w]; mv[w] = 0u; }
+                        sc = score0;
+                        st.prev = score0; st.dec = 1u; st.nrep = 0u;
+                        hb.e0 = hb.e1 = hb.e2 = hb.e3 = hb.costs = 0u;
+                        state = n ? WORK : FIN;
+                    } else state = EXHAUSTED;
+                }
+                pool_next += took;
+            }
+        }
+        if (!__any(state != EXHAUSTED)) break;
+        // ---- one chunk of up to 16 columns per working lane
+        if (state == WORK && cur >= stop) {
             // take intervals until one needs columns beyond the run in hand
             for (;;) {
                 int64_t a, b;
-                if (!next_interval(a, b)) { done = true; break; }
+                if (!next_interval(a, b)) { state = FIN; break; }
                 if (a < 1) a = 1;
                 if (b > (int64_t)n) b = (int64_t)n;
                 if (b < a || (uint32_t)b <= stop) continue;  // empty, or inside what has been scanned
@@ -870,17 +951,26 @@ __device__ __forceinline__ void flank_verify_lane(const uint8_t* __restrict__ ba
                 break;
             }
         }
-        const bool work = !done && cur < stop;
-        uint32_t wq[4] = {0u, 0u, 0u, 0u};
-        if (work) load16(cur, wq);
-        const uint32_t cntb = work ? min(16u, stop - cur) : 0u;
+        {
+            const bool work = state == WORK && cur < stop;
+            uint32_t wq[4] = {0u, 0u, 0u, 0u};
+            if (work) load16(cur, wq);
+            const uint32_t cntb = work ? min(16u, stop - cur) : 0u;
 #pragma unroll
-        for (int b = 0; b < 16; ++b)
-            if ((uint32_t)b < cntb) step((wq[b >> 2] >> (8 * (b & 3))) & 0xFFu);
-        cur += cntb;
+            for (int b = 0; b < 16; ++b)
+                if ((uint32_t)b < cntb) step((wq[b >> 2] >> (8 * (b & 3))) & 0xFFu);
+            cur += cntb;
+        }
+        // ---- close finished items: the overhang positions continue from column n, but only if a run got there (otherwise
+        // none of them can be <= k); count; flush of the buffered hits (wave-wide prefix sums: every lane takes part)
+        if (__any(state == FIN)) {
+            const bool fin = state == FIN;
+            scan_finish<W, STRAND>(fin, n, m, kk, sc, pv, mv, idx, st, hb, ovh, read, g, n_groups, cnt, hits, hit_cap, hit_count, idx == n, ovh_steps,
+                                   stage, &stage_fill);
+            if (fin) state = FREE;
+        }
     }
-    // the overhang positions continue from column n: only if a run got there (otherwise none of them can be <= k)
-    scan_finish<W, STRAND>(live, n, m, kk, sc, pv, mv, idx, st, hb, ovh, read, g, n_groups, cnt, hits, hit_cap, hit_count, idx == n);
+    stage_flush(stage, stage_fill, hits, hit_cap, hit_count);
 }
 
 template <int W>
@@ -888,9 +978,10 @@ __global__ __launch_bounds__(256) void k_flank_verify(const uint8_t* __restrict_
                                                       const uint8_t* __restrict__ tables, const bb_group_dev* __restrict__ groups, uint32_t g,
                                                       uint32_t n_groups, const uint32_t* __restrict__ flags, uint64_t words_per_strand,
                                                       uint32_t* __restrict__ cnt, bb_hit_raw* __restrict__ hits, uint32_t hit_cap,
-                                                      uint32_t* __restrict__ hit_count) {
+                                                      uint32_t* __restrict__ hit_count, uint32_t* __restrict__ queues) {
     constexpr int S = (W <= 2 ? 2 : (W <= 4 ? 4 : 8));
     __shared__ __attribute__((aligned(16))) uint32_t s_peq[256 * S];
+    __shared__ __attribute__((aligned(16))) bb_hit_raw s_stage[4][BB_VERIFY_STAGE];
     const bb_group_dev* G = groups + g;
     const uint32_t strand = blockIdx.y;
     {
@@ -898,10 +989,11 @@ __global__ __launch_bounds__(256) void k_flank_verify(const uint8_t* __restrict_
         for (int i = threadIdx.x; i < 256 * S; i += 256) s_peq[i] = src[i];
     }
     __syncthreads();
+    bb_hit_raw* stage = s_stage[threadIdx.x >> 6];
     if (strand == 0)
-        flank_verify_lane<W, 0>(bases, offsets, n_reads, tables, G, g, n_groups, flags, cnt, hits, hit_cap, hit_count, s_peq);
+        flank_verify_lane<W, 0>(bases, offsets, n_reads, tables, G, g, n_groups, flags, cnt, hits, hit_cap, hit_count, queues, s_peq, stage);
     else
-        flank_verify_lane<W, 1>(bases, offsets, n_reads, tables, G, g, n_groups, flags + words_per_strand, cnt, hits, hit_cap, hit_count, s_peq);
+        flank_verify_lane<W, 1>(bases, offsets, n_reads, tables, G, g, n_groups, flags + words_per_strand, cnt, hits, hit_cap, hit_count, queues + 1, s_peq, stage);
 }
 
 // ------------------------------------------------------------------------------------------------
