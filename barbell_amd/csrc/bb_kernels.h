@@ -2020,8 +2020,8 @@ __global__ __launch_bounds__(CW <= 48 ? 768 : 512) void k_barcode_pfx(const uint
     o = (o + 15) & ~(size_t)15;
     uint2* s_tab2 = reinterpret_cast<uint2*>(smem + o);  // [2][hpb][CW]: the walk through the shared rows per entry column
     o += (size_t)2 * hpb * CW * 8;
-    uint2* s_col2 = reinterpret_cast<uint2*>(smem + o);  // [2][hpb][CW]: what every barcode lane of a hit needs of a column
-    o += (size_t)2 * hpb * CW * 8;
+    uint4* s_col2 = reinterpret_cast<uint4*>(smem + o);  // [2][hpb][CW]: what every barcode lane of a hit needs of a column
+    o += (size_t)2 * hpb * CW * 16;
     uint32_t* s_peq = reinterpret_cast<uint32_t*>(smem + o);
     o += (size_t)16 * N * 4;
     o = (o + 15) & ~(size_t)15;
@@ -2058,22 +2058,22 @@ __global__ __launch_bounds__(CW <= 48 ? 768 : 512) void k_barcode_pfx(const uint
     // per-column table and reduction cells of the set in half h (all lanes)
     auto build_cols = [&](uint32_t h) {
         const uint4* hitb = s_hit2 + (size_t)h * hpb * PIECES;
-        uint2* colb = s_col2 + (size_t)h * hpb * CW;
+        uint4* colb = s_col2 + (size_t)h * hpb * CW;
         if (in_blk && p == 0) {
             const uint32_t x = h * hpb + (uint32_t)hl;
             s_max2[x] = 0ull; s_sec2[x] = 0ull; s_cnt12[x] = 0; s_top2[x] = 0x7FFFFFFF; s_maxB2[x] = 0ull; s_secB2[x] = 0ull;
         }
     // Per (hit, column), once for the hit's N barcode lanes: x = byte offset of the column's base-set row in the Peq table,
-    // y = carry-in of the shared rows (bit 0: horizontal +1, bit 1: horizontal -1 of row P).  The lanes then spend one
-    // 8-byte LDS read and three full-rate operations per column instead of three bit-field extractions and a
-    // multiply-add (all half rate, profiles/valu_ceiling.json).
+    // y / z = carry-in of the shared rows (horizontal +1 / -1 of row P) as words of their own.  The lanes then spend one
+    // 16-byte LDS read (a broadcast: the lanes of a hit read the same address) and one addition per column instead of
+    // three bit-field extractions and a multiply-add (all half rate, profiles/valu_ceiling.json).
     for (uint32_t l = threadIdx.x; l < hpb * (uint32_t)CW; l += blockDim.x) {
         const uint32_t hw = l / (uint32_t)CW, c = l % (uint32_t)CW;
         const uint32_t* rec = reinterpret_cast<const uint32_t*>(hitb + hw * PIECES);
         const uint32_t code = (rec[8 + (c >> 2)] >> (8u * (c & 3u))) & 0xFu;
         const uint32_t* hv = reinterpret_cast<const uint32_t*>(hitb + hw * PIECES + PIECES_H);  // {ph lo, ph hi, mh lo, mh hi}
         const uint32_t hp = (hv[c >> 5] >> (c & 31u)) & 1u, hm = (hv[2 + (c >> 5)] >> (c & 31u)) & 1u;
-        colb[l] = make_uint2(code * (uint32_t)N * 4u, hp | (hm << 1));
+        colb[l] = make_uint4(code * (uint32_t)N * 4u, hp, hm, 0u);  // the carry-in bits as words of their own: no extraction per lane
     }
     };
     auto build_walks = [&](uint32_t h) {
@@ -2132,7 +2132,7 @@ __global__ __launch_bounds__(CW <= 48 ? 768 : 512) void k_barcode_pfx(const uint
     store_set(it + gridDim.x, half ^ 1u);
     prefetch(it + 2u * gridDim.x);
     const uint4* s_hit = s_hit2 + (size_t)half * hpb * PIECES;
-    const uint2* s_col = s_col2 + (size_t)half * hpb * CW;
+    const uint4* s_col = s_col2 + (size_t)half * hpb * CW;
     const uint2* s_tab = s_tab2 + (size_t)half * hpb * CW;
     unsigned long long* s_max = s_max2 + half * hpb, *s_sec = s_sec2 + half * hpb, *s_maxB = s_maxB2 + half * hpb, *s_secB = s_secB2 + half * hpb;
     int32_t* s_cnt1 = s_cnt12 + half * hpb, *s_top = s_top2 + half * hpb;
@@ -2157,7 +2157,7 @@ __global__ __launch_bounds__(CW <= 48 ? 768 : 512) void k_barcode_pfx(const uint
     uint32_t L0[CW], H0[CW];
     int32_t best_cost = 0x7FFFFFFF, best_pos = -1;
     {
-        const uint2* colv = s_col + hls * CW;
+        const uint4* colv = s_col + hls * CW;
         const uint32_t pb4 = (uint32_t)p * 4u;
         const uint8_t* s_peq_b = reinterpret_cast<const uint8_t*>(s_peq);
         uint32_t pv = 0xFFFFFFFFu, mv = 0u;
@@ -2169,9 +2169,9 @@ __global__ __launch_bounds__(CW <= 48 ? 768 : 512) void k_barcode_pfx(const uint
             if (c0 < BB_FIXED_COLS || c0 < wmax) {  // wave-uniform; the first BB_FIXED_COLS columns unconditionally (straight-line code)
 #pragma unroll
                 for (int c = c0; c < c0 + BB_CG; ++c) {
-                    const uint2 cv = colv[c];
+                    const uint4 cv = colv[c];
                     const uint32_t eq = *reinterpret_cast<const uint32_t*>(s_peq_b + (cv.x + pb4));
-                    const uint32_t hp = cv.y & 1u, hm = cv.y >> 1;
+                    const uint32_t hp = cv.y, hm = cv.z;
                     const uint32_t x = bitop3<0xC8>(eq, pv, hm);  // (eq | hm) & pv
                     const uint32_t d0 = bitop3<BB_TT_XOR_OR>(x + pv, pv, eq) | hm | mv;  // v_bitop3 + v_or3
                     const uint32_t ph = bitop3<BB_TT_OR_NOR>(mv, d0, pv), mh = pv & d0;
