@@ -1979,6 +1979,35 @@ __global__ __launch_bounds__(128) void k_bar_prefix(const uint8_t* __restrict__ 
     for (uint32_t i = threadIdx.x; i < nb * OW; i += 128u) dst[i] = s_out[(i / OW) * OS + (i % OW)];
 }
 
+// Wave-wide maximum of a u32 on the VALU's data-parallel primitives (no LDS): quad swaps, half-row and row mirrors give
+// every lane of a 16-lane row the row's maximum, two row broadcasts carry it to the last row; the result is lane 63's.
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xF, 0xF, false));   // quad_perm [2,3,0,1]
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x141, 0xF, 0xF, false));  // row_half_mirror
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x140, 0xF, 0xF, false));  // row_mirror
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x142, 0xA, 0xF, false));  // row_bcast15 -> rows 1, 3
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x143, 0xC, 0xF, false));  // row_bcast31 -> rows 2, 3
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+// The two largest keys among the wave's lanes with `in` (keys = value bits : 0xFFFF - p with p ascending along the lanes
+// of a hit, so the first lane holding the largest value also holds the largest key); 0 where there is none.  Wave-uniform.
+__device__ __forceinline__ void wave_top2(bool in, uint32_t vbits, unsigned long long key, unsigned long long& k1, unsigned long long& k2) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t v = in ? vbits + 1u : 0u;  // members are > 0 (value bits are those of a finite non-negative float)
+    const uint32_t m1 = wave_max_u32(v);
+    k1 = 0ull; k2 = 0ull;
+    if (m1 == 0u) return;
+    const int l1 = (int)__ffsll((long long)__ballot(v == m1)) - 1;
+    k1 = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(key >> 32), l1) << 32) |
+         (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)key, l1);
+    const uint32_t v2 = (int)lane == l1 ? 0u : v;
+    const uint32_t m2 = wave_max_u32(v2);
+    if (m2 == 0u) return;
+    const int l2 = (int)__ffsll((long long)__ballot(v2 == m2)) - 1;
+    k2 = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(key >> 32), l2) << 32) |
+         (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)key, l2);
+}
 #ifdef BB_EXP_NO_BARRIERS
 #define BB_PFX_SYNC() ((void)0)
 #else
@@ -2352,7 +2381,32 @@ __global__ __launch_bounds__(CW <= 48 ? 768 : 512) void k_barcode_pfx(const uint
         const float ubf = lodhi_bound<CW>(cand ? plo : 0ull, cand ? phi : 0ull, cand ? tstart : 0, cand ? best_pos : 0, wmax);
         (void)delrow;
         const unsigned long long key = ((unsigned long long)__float_as_uint(ubf) << 16) | (unsigned long long)(0xFFFFu - (uint32_t)p);
-        if (cand) {
+        if (N >= 64) {
+            // A wave holds lanes of at most two hits.  96 lanes posting to one LDS address serialise inside the LDS unit (and
+            // hold up the other waves' table reads): the wave finds its own top-2 per (hit, candidate set) on the VALU first
+            // and four lanes post them.
+            const uint32_t lane = threadIdx.x & 63u;
+            const int hA = __builtin_amdgcn_readfirstlane(hl);
+            const bool c2 = cand, c1 = cand && best_cost <= G.k1;
+            const uint32_t vb = __float_as_uint(ubf);
+            unsigned long long t[4], u[4];  // combos: 0 = (hit A, pass 1), 1 = (A, pass 2), 2 = (B, pass 1), 3 = (B, pass 2)
+            wave_top2(c1 && hl == hA, vb, key, t[0], u[0]);
+            wave_top2(c2 && hl == hA, vb, key, t[1], u[1]);
+            wave_top2(c1 && hl != hA, vb, key, t[2], u[2]);
+            wave_top2(c2 && hl != hA, vb, key, t[3], u[3]);
+            if (lane < 4u) {
+                const unsigned long long kt = lane == 0u ? t[0] : lane == 1u ? t[1] : lane == 2u ? t[2] : t[3];
+                const unsigned long long ku = lane == 0u ? u[0] : lane == 1u ? u[1] : lane == 2u ? u[2] : u[3];
+                if (kt != 0ull) {
+                    const int hx = hA + (int)(lane >> 1);
+                    unsigned long long* pm = (lane & 1u) ? &s_maxB[hx] : &s_max[hx];
+                    unsigned long long* ps = (lane & 1u) ? &s_secB[hx] : &s_sec[hx];
+                    const unsigned long long o = atomicMax(pm, kt);
+                    atomicMax(ps, o < kt ? o : kt);
+                    if (ku != 0ull) atomicMax(ps, ku);
+                }
+            }
+        } else if (cand) {
             const unsigned long long o2 = atomicMax(&s_maxB[hl], key);
             atomicMax(&s_secB[hl], o2 < key ? o2 : key);
             if (best_cost <= G.k1) {
