@@ -254,61 +254,75 @@ int upload_tables(bb_ctx* c) {
             D.ovh_steps = std::min(m, o_max + 1);
         }
         {
-            const int R = std::min(15, m), k = D.flank_k;
+            const int k = D.flank_k;
             if (c->scan_filter != 0 && m >= 2 && k < m) {
                 const uint32_t* t = reinterpret_cast<const uint32_t*>(blob.b.data() + D.off_peq_flank[0]);
-                const uint32_t maskR = (1u << R) - 1u;
                 const int L = 1 << 15;
-                // cost of a window position in full-height columns: every flagged column, plus the lead-in, quarter granularity
-                // and margins of every flagged run
-                const long per_run = m + 3 * k + 40;
-                int best_u = 0;
-                long best_cost = (long)L * per_run;
-                for (int u = 0; u + R <= m; ++u) {
-                    uint32_t eqs[4];
-                    for (int b = 0; b < 4; ++b) {
-                        const uint32_t* e = t + (size_t)"ACGT"[b] * S;
-                        uint64_t two = e[u >> 5];
-                        if ((u >> 5) + 1 < W) two |= (uint64_t)e[(u >> 5) + 1] << 32;
-                        eqs[b] = (uint32_t)(two >> (u & 31)) & maskR;
+                // cost of a window position in full-height columns per text column: every flagged column, plus the lead-in,
+                // piece granularity and margins of every flagged run
+                const long per_run = m + 3 * k + 24;
+                auto best_window = [&](int R, int& best_u) -> double {
+                    const uint32_t maskR = R >= 32 ? 0xFFFFFFFFu : (1u << R) - 1u;
+                    long best_cost = (long)L * per_run;
+                    best_u = 0;
+                    for (int u = 0; u + R <= m; ++u) {
+                        uint32_t eqs[4];
+                        for (int b = 0; b < 4; ++b) {
+                            const uint32_t* e = t + (size_t)"ACGT"[b] * S;
+                            uint64_t two = e[u >> 5];
+                            if ((u >> 5) + 1 < W) two |= (uint64_t)e[(u >> 5) + 1] << 32;
+                            eqs[b] = (uint32_t)(two >> (u & 31)) & maskR;
+                        }
+                        uint32_t pv = maskR, mv = 0, x = 0x9E3779B9u;
+                        int sc = R;
+                        long cost = 0;
+                        bool in = false;
+                        for (int i = 0; i < L && cost < best_cost; ++i) {
+                            x = x * 1664525u + 1013904223u;
+                            const uint32_t eq = eqs[x >> 30];
+                            const uint32_t xx = eq & pv, d0 = (((xx + pv) ^ pv) | eq | mv) & maskR;
+                            const uint32_t ph = (mv | ~(d0 | pv)) & maskR, mh = pv & d0;
+                            sc += (int)((ph >> (R - 1)) & 1u) - (int)((mh >> (R - 1)) & 1u);
+                            const uint32_t phs = ph << 1, mhs = mh << 1;
+                            pv = (mhs | ~(d0 | phs)) & maskR; mv = phs & d0 & maskR;
+                            const bool f = sc <= k;
+                            cost += f ? (in ? 1 : per_run) : 0;
+                            in = f;
+                        }
+                        if (cost < best_cost) { best_cost = cost; best_u = u; }
                     }
-                    uint32_t pv = maskR, mv = 0, x = 0x9E3779B9u;
-                    int sc = R;
-                    long cost = 0;
-                    bool in = false;
-                    for (int i = 0; i < L && cost < best_cost; ++i) {
-                        x = x * 1664525u + 1013904223u;
-                        const uint32_t eq = eqs[x >> 30];
-                        const uint32_t xx = eq & pv, d0 = (((xx + pv) ^ pv) | eq | mv) & maskR;
-                        const uint32_t ph = (mv | ~(d0 | pv)) & maskR, mh = pv & d0;
-                        sc += (int)((ph >> (R - 1)) & 1u) - (int)((mh >> (R - 1)) & 1u);
-                        const uint32_t phs = ph << 1, mhs = mh << 1;
-                        pv = (mhs | ~(d0 | phs)) & maskR; mv = phs & d0 & maskR;
-                        const bool f = sc <= k;
-                        cost += f ? (in ? 1 : per_run) : 0;
-                        in = f;
-                    }
-                    if (cost < best_cost) { best_cost = cost; best_u = u; }
-                }
-                // the filter itself costs about half a W=2 scan; verification columns are full-height columns
-                bool use = W >= 2 && (double)best_cost / L < 0.3;
+                    return (double)best_cost / L;
+                };
+                // Everything in units of one full two-word scan of both strands (46 instructions per column): the packed filter
+                // (15 rows per strand in one word) 0.43, the wide one (31 rows, a word per strand) 0.80, the full scan 0.5 per
+                // word, verification = its columns at the full scan's price, with the waves' imbalance on top.
+                const double full = W == 1 ? 0.6 : 0.5 * W;
+                const int R15 = std::min(15, m), R31 = std::min(31, m);
+                int u15 = 0, u31 = 0;
+                const double c15 = best_window(R15, u15);
+                const double c31 = R31 > R15 ? best_window(R31, u31) : 1e9;
+                const double t15 = 0.43 + 1.3 * c15 * full, t31 = 0.80 + 1.3 * c31 * full;
+                int pick = 0;  // 0 full scan, 1 packed, 2 wide
+                if (W >= 2 && std::min(t15, t31) < 0.9 * full) pick = t15 <= t31 ? 1 : 2;
                 if (getenv("BARBELL_AMD_VERBOSE"))
-                    fprintf(stderr, "barbell_amd: group %zu flank %d nt, k %d: filter window rows %d..%d, %.4f verification columns per text column -> %s\n", gi, m, k,
-                            best_u, best_u + R - 1, (double)best_cost / L, use ? "filtered scan" : "full scan");
-                if (c->scan_filter == 1) use = true;
-                if (use) {
-                    D.filt_rows = R; D.filt_off = best_u;
+                    fprintf(stderr, "barbell_amd: group %zu flank %d nt, k %d: 15-row window at row %d: %.4f verification columns per column (cost %.2f), "
+                            "31-row window at row %d: %.4f (cost %.2f), full scan %.2f -> %s\n", gi, m, k, u15, c15, t15, u31, c31 > 1e8 ? -1.0 : c31, t31, full,
+                            pick == 0 ? "full scan" : pick == 1 ? "filtered scan (both strands in one word)" : "filtered scan (a word per strand)");
+                if (c->scan_filter == 1 && pick == 0) pick = 1;
+                if (getenv("BARBELL_AMD_FILTER_WIDE") && R31 > R15) pick = 2;  // test knob
+                if (pick) {
+                    const int R = pick == 1 ? R15 : R31, u = pick == 1 ? u15 : u31;
+                    D.filt_rows = R; D.filt_off = u;
                     int o_max = 0;  // most rows that can hang over a read end within the budget (edit_model: floor(alpha * o))
                     for (int o = 1; o <= m; ++o)
                         if (overhang_cost(alpha, o) <= k) o_max = o;
-                    const int u = best_u;
-                    uint32_t mode = 0;
+                    uint32_t mode = pick == 2 ? BB_FILT_WIDE : 0u;
                     if (u == 0) mode |= BB_FILT_TRUE_INIT;
                     if (!(u == 0 || u >= o_max)) mode |= BB_FILT_FWD_BEGIN_ALWAYS;
                     if (u == 0 && o_max < R) mode |= BB_FILT_RC_BEGIN_HINT;
                     else if (u < o_max) mode |= BB_FILT_RC_BEGIN_ALWAYS;
                     if (o_max > m - u - R) mode |= BB_FILT_END_ALWAYS;
-                    if (getenv("BARBELL_AMD_FILTER_ENDS")) mode = (mode & BB_FILT_TRUE_INIT) | BB_FILT_FWD_BEGIN_ALWAYS | BB_FILT_RC_BEGIN_ALWAYS | BB_FILT_END_ALWAYS;  // test knob: both ends of every read
+                    if (getenv("BARBELL_AMD_FILTER_ENDS")) mode = (mode & (BB_FILT_TRUE_INIT | BB_FILT_WIDE)) | BB_FILT_FWD_BEGIN_ALWAYS | BB_FILT_RC_BEGIN_ALWAYS | BB_FILT_END_ALWAYS;  // test knob: both ends of every read
                     D.filt_mode = (int32_t)mode;
                 }
             }
@@ -451,8 +465,12 @@ template <int W>
 void launch_scan(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n, uint32_t g, uint64_t flag_words) {
     if (c->gdev[g].filt_rows > 0 && !c->scan_v1) {
         (void)hipMemsetAsync(c->d_flags, 0, (size_t)2 * flag_words * sizeof(uint32_t), c->stream);  // the filter writes the words that hold a flag
-        hipLaunchKernelGGL(k_flank_filter, dim3((n + 255) / 256), dim3(256), 0, c->stream, d_bases, d_offsets, n, (const uint8_t*)c->d_tables,
-                           (const bb_group_dev*)c->d_groups, g, c->d_flags, flag_words);
+        if (c->gdev[g].filt_mode & BB_FILT_WIDE)
+            hipLaunchKernelGGL(k_flank_filter<true>, dim3((n + 255) / 256), dim3(256), 0, c->stream, d_bases, d_offsets, n, (const uint8_t*)c->d_tables,
+                               (const bb_group_dev*)c->d_groups, g, c->d_flags, flag_words);
+        else
+            hipLaunchKernelGGL(k_flank_filter<false>, dim3((n + 255) / 256), dim3(256), 0, c->stream, d_bases, d_offsets, n, (const uint8_t*)c->d_tables,
+                               (const bb_group_dev*)c->d_groups, g, c->d_flags, flag_words);
         (void)hipMemsetAsync(c->d_vqueue, 0, 2 * sizeof(uint32_t), c->stream);
         const uint32_t vblocks = std::min((n + 255u) / 256u, (uint32_t)c->n_cus * 3u);  // persistent: lanes draw (read, strand) items from a queue
         hipLaunchKernelGGL(k_flank_verify<W>, dim3(vblocks, 2), dim3(256), 0, c->stream, d_bases, d_offsets, n,

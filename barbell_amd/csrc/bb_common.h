@@ -93,6 +93,7 @@ struct bb_group_dev {
 #define BB_FILT_FWD_BEGIN_ALWAYS 2u  /* 0 < u < o_max: a forward match hanging over the read's start may leave the window unflagged */
 #define BB_FILT_RC_BEGIN_ALWAYS 4u   /* the same for the rc strand (u < o_max and no hint available: o_max >= R or u > 0) */
 #define BB_FILT_RC_BEGIN_HINT 8u     /* u == 0, o_max < R: k_flank_filter says per read whether the rc strand's start needs scanning */
+#define BB_FILT_WIDE 32u             /* one word per strand (windows of up to 31 rows) instead of both strands' 15-row blocks in one word */
 #define BB_FILT_END_ALWAYS 16u       /* o_max > m - u - R: a match may hang over a strand's end with the window outside the read */
 
 #define BB_MAX_TAIL 4

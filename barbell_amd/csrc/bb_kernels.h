@@ -665,17 +665,21 @@ __global__ __launch_bounds__(256) void k_flank_scan2(const uint8_t* __restrict__
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint64_t filt_word_base(uint64_t off, uint64_t off0, uint32_t read) { return ((off - off0) >> 9) + 3ull * read; }
 
+// WIDE: windows of up to 31 rows, one word per strand (two Myers words per column: ~37 instructions instead of ~20) — for
+// flanks whose 15-row windows say too little at the group's k but whose 31-row windows do (upload_tables decides).
+template <bool WIDE>
 __global__ __launch_bounds__(256) void k_flank_filter(const uint8_t* __restrict__ bases, const uint64_t* __restrict__ offsets, uint32_t n_reads,
                                                       const uint8_t* __restrict__ tables, const bb_group_dev* __restrict__ groups, uint32_t g,
                                                       uint32_t* __restrict__ flags, uint64_t words_per_strand) {
-    __shared__ uint32_t s_fpeq[256];
+    __shared__ uint32_t s_fpeq[WIDE ? 512 : 256];
     __shared__ __attribute__((aligned(16))) uint4 s_lines[4][BB_SCAN_LQ * 64];
     static_assert(BB_SCAN_LQ == 8u, "piece bits assume 128-byte lines");
     const bb_group_dev* G = groups + g;
     const int R = G->filt_rows;
     const int32_t kk = min(G->flank_k, R);  // k >= R: every column qualifies
     // blocks right-aligned under the guard bits 15 and 31: forward rows at bits 15-R..14, rc rows (reversed) at bits 31-R..30
-    const uint32_t maskR = (1u << R) - 1u, SA = 15u - (uint32_t)R, BM = (maskR << SA) | (maskR << (SA + 16u));
+    // (WIDE: each strand's rows at bits 0..R-1 of its own word, R <= 31)
+    const uint32_t maskR = (1u << R) - 1u, SA = WIDE ? 0u : 15u - (uint32_t)R, BM = WIDE ? maskR : (maskR << SA) | (maskR << (SA + 16u));
     {
         const uint32_t S = G->W <= 2 ? 2u : (G->W <= 4 ? 4u : 8u);
         const uint32_t* f = reinterpret_cast<const uint32_t*>(tables + G->off_peq_flank[0]);
@@ -685,7 +689,8 @@ __global__ __launch_bounds__(256) void k_flank_filter(const uint8_t* __restrict_
             const uint32_t lo = t[c * S + uw], hi = ub && uw + 1u < (uint32_t)G->W ? t[c * S + uw + 1u] : 0u;
             return ((lo >> ub) | (ub ? hi << (32u - ub) : 0u)) & maskR;
         };
-        s_fpeq[c] = (rows(f) << SA) | ((__brev(rows(r)) >> (32 - R)) << (SA + 16u));
+        if constexpr (WIDE) { s_fpeq[2 * c] = rows(f); s_fpeq[2 * c + 1] = __brev(rows(r)) >> (32 - R); }
+        else s_fpeq[c] = (rows(f) << SA) | ((__brev(rows(r)) >> (32 - R)) << (SA + 16u));
     }
     __syncthreads();
     uint4* s_line = s_lines[threadIdx.x >> 6];
@@ -708,26 +713,63 @@ __global__ __launch_bounds__(256) void k_flank_filter(const uint8_t* __restrict_
     // other.  Every other block is the window's own semi-global problem (column 0: D[j][0] = j).
     const bool own_rows = (G->filt_mode & BB_FILT_TRUE_INIT) != 0;
     const int32_t* ovh = reinterpret_cast<const int32_t*>(tables + G->off_ovh);
-    uint32_t pv = own_rows ? ((reinterpret_cast<const uint32_t*>(tables + G->off_pv0)[0] & maskR) << SA) | (maskR << (SA + 16u)) : BM, mv = 0u;
+    const uint32_t pvA0 = own_rows ? reinterpret_cast<const uint32_t*>(tables + G->off_pv0)[0] & maskR : maskR;
+    const int scA0 = own_rows ? (int)__popc(pvA0) : R;
+    uint32_t pv = WIDE ? pvA0 : (pvA0 << SA) | (maskR << (SA + 16u)), mv = 0u;
+    uint32_t pvB = maskR, mvB = 0u;  // WIDE: the rc strand's word
     // Both blocks' D[R][i], biased by 15 - k, in the two halves of one register (the bottom rows' delta bits sit at bits 14
     // and 30: one mask, one shift): a half's bit 4 is clear exactly while its score is <= k, so AND-ing the register over
-    // the columns of a piece leaves bit 4 / bit 20 clear iff the piece holds such a column.
+    // the columns of a piece leaves bit 4 / bit 20 clear iff the piece holds such a column.  (WIDE: one register per strand,
+    // bias 31 - k, bit 5.)
     const uint32_t TOPS = 0x40004000u;
-    uint32_t sc2 = ((uint32_t)(R + 15 - kk) << 16) | (uint32_t)((own_rows ? (int)__popc(reinterpret_cast<const uint32_t*>(tables + G->off_pv0)[0] & maskR) : R) + 15 - kk);
-    uint32_t keep = sc2 | ~0x00100010u;  // column 0 counts for the first piece
+    const int bias = (WIDE ? 31 : 15) - kk;
+    uint32_t sc2 = WIDE ? (uint32_t)(scA0 + bias) : ((uint32_t)(R + bias) << 16) | (uint32_t)(scA0 + bias);
+    uint32_t scB = (uint32_t)(R + bias);
+    uint32_t keep = WIDE ? sc2 | ~0x20u : sc2 | ~0x00100010u;  // column 0 counts for the first piece
+    uint32_t keepB = scB | ~0x20u;
     uint32_t bitsA = 0u, bitsB = 0u;
-    auto step = [&](uint32_t eq) {
-        const uint32_t x = eq & pv;
-        const uint32_t d0 = bitop3<BB_TT_XOR_OR>(x + pv, pv, eq) | mv;
-        const uint32_t ph = bitop3<BB_TT_OR_NOR>(mv, d0, pv) & BM, mh = pv & d0;
-        sc2 = sc2 + ((ph & TOPS) >> 14) - ((mh & TOPS) >> 14);
-        keep &= sc2;
-        const uint32_t phs = ph << 1, mhs = mh << 1;
-        pv = bitop3<BB_TT_OR_NOR>(mhs, d0, phs) & BM;
-        mv = phs & d0;
+    auto step = [&](uint32_t chr) {
+        if constexpr (WIDE) {
+            const uint2 e2 = *reinterpret_cast<const uint2*>(s_fpeq + 2u * chr);
+            {
+                const uint32_t eq = e2.x, x = eq & pv;
+                const uint32_t d0 = bitop3<BB_TT_XOR_OR>(x + pv, pv, eq) | mv;
+                const uint32_t ph = bitop3<BB_TT_OR_NOR>(mv, d0, pv) & BM, mh = pv & d0;
+                sc2 = sc2 + (ph >> (R - 1)) - (mh >> (R - 1));
+                keep &= sc2;
+                const uint32_t phs = ph << 1, mhs = mh << 1;
+                pv = bitop3<BB_TT_OR_NOR>(mhs, d0, phs) & BM;
+                mv = phs & d0;
+            }
+            {
+                const uint32_t eq = e2.y, x = eq & pvB;
+                const uint32_t d0 = bitop3<BB_TT_XOR_OR>(x + pvB, pvB, eq) | mvB;
+                const uint32_t ph = bitop3<BB_TT_OR_NOR>(mvB, d0, pvB) & BM, mh = pvB & d0;
+                scB = scB + (ph >> (R - 1)) - (mh >> (R - 1));
+                keepB &= scB;
+                const uint32_t phs = ph << 1, mhs = mh << 1;
+                pvB = bitop3<BB_TT_OR_NOR>(mhs, d0, phs) & BM;
+                mvB = phs & d0;
+            }
+        } else {
+            const uint32_t eq = s_fpeq[chr];
+            const uint32_t x = eq & pv;
+            const uint32_t d0 = bitop3<BB_TT_XOR_OR>(x + pv, pv, eq) | mv;
+            const uint32_t ph = bitop3<BB_TT_OR_NOR>(mv, d0, pv) & BM, mh = pv & d0;
+            sc2 = sc2 + ((ph & TOPS) >> 14) - ((mh & TOPS) >> 14);
+            keep &= sc2;
+            const uint32_t phs = ph << 1, mhs = mh << 1;
+            pv = bitop3<BB_TT_OR_NOR>(mhs, d0, phs) & BM;
+            mv = phs & d0;
+        }
     };
     auto commit = [&](uint32_t bit) {  // end of a piece
-        bitsA |= ((~keep >> 4) & 1u) << bit; bitsB |= ((~keep >> 20) & 1u) << bit;
+        if constexpr (WIDE) {
+            bitsA |= ((~keep >> 5) & 1u) << bit; bitsB |= ((~keepB >> 5) & 1u) << bit;
+            keepB = 0xFFFFFFFFu;
+        } else {
+            bitsA |= ((~keep >> 4) & 1u) << bit; bitsB |= ((~keep >> 20) & 1u) << bit;
+        }
         keep = 0xFFFFFFFFu;
     };
     uint32_t lmax = nlines;
@@ -754,7 +796,7 @@ __global__ __launch_bounds__(256) void k_flank_filter(const uint8_t* __restrict_
 #pragma unroll
                     for (int b = 0; b < 16; ++b) {
                         const uint32_t word = (b >> 2) == 0 ? v.x : (b >> 2) == 1 ? v.y : (b >> 2) == 2 ? v.z : v.w;
-                        step(s_fpeq[(word >> (8 * (b & 3))) & 0xFFu]);
+                        step((word >> (8 * (b & 3))) & 0xFFu);
                     }
                     commit(qb + (uint32_t)q);
                 }
@@ -766,7 +808,7 @@ __global__ __launch_bounds__(256) void k_flank_filter(const uint8_t* __restrict_
                 for (int b = 0; b < 16; ++b) {
                     const uint32_t word = (b >> 2) == 0 ? v.x : (b >> 2) == 1 ? v.y : (b >> 2) == 2 ? v.z : v.w;
                     const uint32_t p = 16u * (uint32_t)q + (uint32_t)b;
-                    if (p >= lo && p < hi) step(s_fpeq[(word >> (8 * (b & 3))) & 0xFFu]);
+                    if (p >= lo && p < hi) step((word >> (8 * (b & 3))) & 0xFFu);
                 }
                 commit(qb + (uint32_t)q);
             }
@@ -782,7 +824,7 @@ __global__ __launch_bounds__(256) void k_flank_filter(const uint8_t* __restrict_
     // necessary.  One bit in the word after the rc strand's piece words tells k_flank_verify to scan the rc strand's
     // first columns (groups with BB_FILT_RC_BEGIN_HINT; windows that start deeper never hang, see upload_tables).
     if (live && n && (G->filt_mode & BB_FILT_RC_BEGIN_HINT)) {
-        const uint32_t pb = (pv >> (SA + 16u)) & maskR, mb = (mv >> (SA + 16u)) & maskR;
+        const uint32_t pb = WIDE ? pvB & maskR : (pv >> (SA + 16u)) & maskR, mb = WIDE ? mvB & maskR : (mv >> (SA + 16u)) & maskR;
         uint32_t hint = 0u;
         for (int o = 1; o < R; ++o) {
             const uint32_t low = (1u << (R - o)) - 1u;

@@ -113,17 +113,20 @@ def test_barcode_stage_variants(monkeypatch, knob):
         assert_same(got, want)
 
 
-@pytest.mark.parametrize("mode", ["0", "1", "ends"])
+@pytest.mark.parametrize("mode", ["0", "1", "ends", "wide"])
 def test_scan_filter_variants(monkeypatch, mode):
     """The flank scan runs either as the full-height streaming scan (0) or as filter + windowed verification (1: forced
     for every group, also where a 15-row window says nothing and every quarter is flagged).  Same hits either way:
     ragged and tiny reads, reads shorter than the flank, constructs at the very ends (overhang), low-complexity text
-    and repeats of the filter's own rows (dense flags), overhang factors 0 / 0.4 / 1."""
+    and repeats of the filter's own rows (dense flags), overhang factors 0 / 0.4 / 1; "ends": both ends of every read
+    verified; "wide": the 31-row filter (a word per strand) forced."""
     from barbell_amd import annotate as A
 
-    monkeypatch.setenv("BARBELL_AMD_SCAN_FILTER", "1" if mode == "ends" else mode)
+    monkeypatch.setenv("BARBELL_AMD_SCAN_FILTER", "1" if mode in ("ends", "wide") else mode)
     if mode == "ends":  # both ends of every read scanned, whatever the filter's hints say
         monkeypatch.setenv("BARBELL_AMD_FILTER_ENDS", "1")
+    if mode == "wide":  # 31-row windows, a word per strand
+        monkeypatch.setenv("BARBELL_AMD_FILTER_WIDE", "1")
     for cfg, n, lmin, lmax in (("nbd96", 1500, 1, 700), ("nbd96", 800, 3000, 4200), ("dual", 500, 200, 3000), ("rbk96x", 200, 600, 2000), ("rbk24", 300, 50, 1500)):
         groups = config_groups(cfg)
         bases, offsets = A.synth_reads_host(groups, 77 + n, lmin, lmax, 0, n)
