@@ -492,8 +492,9 @@ void launch_scan(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets, u
 template <int W>
 void launch_trace(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n_hits, uint32_t g) {
     const bb_group_dev& D = c->gdev[g];
-    const size_t lds = (size_t)(D.m + D.flank_k + 2) * 2 * W * 64 * 4;  // columns 0..m+k, lo+hi, W words, 64 lanes
-    const size_t lds_band = (size_t)(D.m + D.flank_k + 2) * 64 * 4;      // one word per column and lane
+    const size_t lds_rec = (size_t)64 * BB_TRACE_REC_STRIDE * 4;          // the staged hit records share the move bits' LDS
+    const size_t lds = std::max(lds_rec, (size_t)(D.m + D.flank_k + 2) * 2 * W * 64 * 4);  // columns 0..m+k, lo+hi, W words, 64 lanes
+    const size_t lds_band = std::max(lds_rec, (size_t)(D.m + D.flank_k + 2) * 64 * 4);      // one word per column and lane
 #define BB_TRACE_ARGS d_bases, d_offsets, (const uint8_t*)c->d_tables, (const bb_group_dev*)c->d_groups, (uint32_t)c->groups.size(), \
                       (const bb_hit_raw*)c->d_raw, n_hits, (const uint32_t*)c->d_base, c->d_hits, g
     if (D.flank_k <= 6 && !c->force_generic && !getenv("BARBELL_AMD_TRACE_FULL"))  // band of 2(k+1)+1 <= 15 rows in 16 bits
@@ -502,7 +503,7 @@ void launch_trace(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets, 
         if constexpr (W <= 4)  // the full-height LDS variant never fits beyond 4 words
             hipLaunchKernelGGL((k_flank_trace<W, 1>), dim3((n_hits + 63) / 64), dim3(64), lds, c->stream, BB_TRACE_ARGS);
     } else
-        hipLaunchKernelGGL((k_flank_trace<W, 0>), dim3((n_hits + 63) / 64), dim3(64), 0, c->stream, BB_TRACE_ARGS);
+        hipLaunchKernelGGL((k_flank_trace<W, 0>), dim3((n_hits + 63) / 64), dim3(64), lds_rec, c->stream, BB_TRACE_ARGS);
 #undef BB_TRACE_ARGS
 }
 template <int WB, int CW>

@@ -1289,9 +1289,11 @@ __global__ __launch_bounds__(64) void k_flank_trace(const uint8_t* __restrict__ 
                                                     uint32_t n_groups, const bb_hit_raw* __restrict__ raw, uint32_t n_hits,
                                                     const uint32_t* __restrict__ slot_base, bb_hit* __restrict__ hits, uint32_t g_sel) {
     extern __shared__ uint32_t s_dyn[];
-    __shared__ uint32_t s_rec[64 * BB_TRACE_REC_STRIDE];
     __shared__ uint32_t s_slot[64];
     static_assert(sizeof(bb_hit) == 96, "six 16-byte pieces");
+    // the staged records reuse the move bits' LDS (>= 64 * BB_TRACE_REC_STRIDE words, launch_trace): the block is one wave,
+    // a lane writes its record after every lane's walk is over, and LDS operations of a wave execute in order
+    uint32_t* s_rec = s_dyn;
     s_slot[threadIdx.x] = flank_trace_lane<W, MODE>(bases, offsets, tables, groups, n_groups, raw, n_hits, slot_base, g_sel,
                                                     s_rec + threadIdx.x * BB_TRACE_REC_STRIDE, s_dyn);
     __syncthreads();
