@@ -341,7 +341,8 @@ struct hit_buf {
         ST.prev = cur_;                                                                         \
     } while (0)
 
-#define BB_VERIFY_STAGE 320u  // hit records per wave in k_flank_verify's LDS staging area (>= 64 lanes x 4 buffered hits + one round)
+#define BB_VERIFY_FLW 12u     // flag words per lane cached in LDS by k_flank_verify (reads up to ~5.5 kb; longer ones read theirs from HBM)
+#define BB_VERIFY_STAGE 128u  // hit records per wave in k_flank_verify's LDS staging area (a round with more goes out directly)
 // wave-wide: the staged records go out with one atomic and 16-byte stores of consecutive lanes
 __device__ __forceinline__ void stage_flush(const bb_hit_raw* stage, uint32_t fill, bb_hit_raw* __restrict__ hits, uint32_t hit_cap,
                                             uint32_t* __restrict__ hit_count) {
@@ -401,7 +402,7 @@ __device__ __forceinline__ void scan_finish(bool live, uint32_t n, int m, int32_
         for (int d = 1; d < 64; d <<= 1) { const uint32_t y = (uint32_t)__shfl_up((int)incl, d, 64); if ((int)lane >= d) incl += y; }
         const uint32_t total = (uint32_t)__shfl((int)incl, 63, 64);
         uint32_t base = 0;
-        if (stage) {
+        if (stage && total <= BB_VERIFY_STAGE) {
             // the wave's LDS staging area (BB_VERIFY_STAGE records): filled item by item, written out with one atomic when the
             // next item's hits would not fit (and by the caller at the end)
             uint32_t fill = *stage_fill;
@@ -843,7 +844,8 @@ __device__ __forceinline__ void flank_verify_lane(const uint8_t* __restrict__ ba
                                                   const uint8_t* __restrict__ tables, const bb_group_dev* __restrict__ G, uint32_t g,
                                                   uint32_t n_groups, const uint32_t* __restrict__ flags, uint32_t* __restrict__ cnt,
                                                   bb_hit_raw* __restrict__ hits, uint32_t hit_cap, uint32_t* __restrict__ hit_count,
-                                                  uint32_t* __restrict__ queue, const uint32_t* s_peq, bb_hit_raw* stage) {
+                                                  uint32_t* __restrict__ queue, const uint32_t* s_peq, bb_hit_raw* stage,
+                                                  uint32_t* s_flw /* this wave's [BB_VERIFY_FLW][64] */) {
     constexpr int S = (W <= 2 ? 2 : (W <= 4 ? 4 : 8));
     const uint32_t lane = threadIdx.x & 63u;
     uint32_t stage_fill = 0u;               // wave-uniform
@@ -863,6 +865,7 @@ __device__ __forceinline__ void flank_verify_lane(const uint8_t* __restrict__ ba
     uint32_t read = 0u, n = 0u;
     const uint8_t* rb = bases;
     const uint32_t* fl = flags;
+    bool fl_cached = false;  // the item's flag words (and the hint word) sit in the lane's LDS column
     uint32_t misf = 0u;
     int32_t nwords = 0, wi = 0;
     uint32_t bits = 0u;
@@ -910,7 +913,7 @@ __device__ __forceinline__ void flank_verify_lane(const uint8_t* __restrict__ ba
                 if (bits == 0u) {
                     if (STRAND ? wi <= 0 : wi + 1 >= nwords) break;
                     wi += STRAND ? -1 : 1;
-                    bits = fl[wi];
+                    bits = fl_cached ? s_flw[(uint32_t)wi * 64u + lane] : fl[wi];
                     continue;
                 }
                 const int bi = STRAND ? 31 - __clz((int)bits) : __ffs((int)bits) - 1;
@@ -954,11 +957,17 @@ __device__ __forceinline__ void flank_verify_lane(const uint8_t* __restrict__ ba
                         const uint32_t nlines = n ? (misf + n + 127u) >> 7 : 0u;
                         nwords = (int32_t)((nlines + 3u) >> 2);
                         fl = flags + filt_word_base(off, off0, read);
+                        // all of the item's words now, back to back (they share one or two sectors; fetched one by one as the walk
+                        // reaches them, each cost a sector again: the lines do not survive in L2 between a lane's iterations)
+                        fl_cached = nwords < (int32_t)BB_VERIFY_FLW;
+                        if (fl_cached)
+                            for (int32_t w = 0; w <= nwords; ++w) s_flw[(uint32_t)w * 64u + lane] = fl[w];
                         wi = STRAND ? nwords : -1;
                         bits = 0u;
                         need_end = (fmode & BB_FILT_END_ALWAYS) != 0;
                         const bool need_begin = (fmode & (STRAND ? BB_FILT_RC_BEGIN_ALWAYS : BB_FILT_FWD_BEGIN_ALWAYS)) != 0 ||
-                                                (STRAND == 1 && (fmode & BB_FILT_RC_BEGIN_HINT) && n && fl[nwords] != 0u);
+                                                (STRAND == 1 && (fmode & BB_FILT_RC_BEGIN_HINT) && n &&
+                                                 (fl_cached ? s_flw[(uint32_t)nwords * 64u + lane] : fl[nwords]) != 0u);
                         phase = n ? (need_begin ? 0 : 1) : 3;
                         cur = 0u; stop = 0u; idx = 0u;
 #pragma unroll
@@ -994,13 +1003,23 @@ __device__ __forceinline__ void flank_verify_lane(const uint8_t* __restrict__ ba
             }
         }
         {
+            // 32 columns per round, their text in two 16-byte loads issued together (one or two sectors: taken 16 bytes a
+            // round, the same sector was fetched again and again — it does not survive in L2 between a lane's rounds)
             const bool work = state == WORK && cur < stop;
-            uint32_t wq[4] = {0u, 0u, 0u, 0u};
+            uint32_t wq[4] = {0u, 0u, 0u, 0u}, wr[4] = {0u, 0u, 0u, 0u};
+            const uint32_t cntb = work ? min(32u, stop - cur) : 0u;
             if (work) load16(cur, wq);
-            const uint32_t cntb = work ? min(16u, stop - cur) : 0u;
+            if (cntb > 16u) load16(cur + 16u, wr);
+#pragma unroll 1
+            for (int hb2 = 0; hb2 < 2; ++hb2) {
+                if (__any(cntb > (uint32_t)(16 * hb2))) {
 #pragma unroll
-            for (int b = 0; b < 16; ++b)
-                if ((uint32_t)b < cntb) step((wq[b >> 2] >> (8 * (b & 3))) & 0xFFu);
+                    for (int b = 0; b < 16; ++b) {
+                        const uint32_t w = hb2 ? wr[b >> 2] : wq[b >> 2];
+                        if ((uint32_t)(16 * hb2 + b) < cntb) step((w >> (8 * (b & 3))) & 0xFFu);
+                    }
+                }
+            }
             cur += cntb;
         }
         // ---- close finished items: the overhang positions continue from column n, but only if a run got there (otherwise
@@ -1024,6 +1043,7 @@ __global__ __launch_bounds__(256) void k_flank_verify(const uint8_t* __restrict_
     constexpr int S = (W <= 2 ? 2 : (W <= 4 ? 4 : 8));
     __shared__ __attribute__((aligned(16))) uint32_t s_peq[256 * S];
     __shared__ __attribute__((aligned(16))) bb_hit_raw s_stage[4][BB_VERIFY_STAGE];
+    __shared__ uint32_t s_flws[4][BB_VERIFY_FLW * 64];
     const bb_group_dev* G = groups + g;
     const uint32_t strand = blockIdx.y;
     {
@@ -1033,9 +1053,9 @@ __global__ __launch_bounds__(256) void k_flank_verify(const uint8_t* __restrict_
     __syncthreads();
     bb_hit_raw* stage = s_stage[threadIdx.x >> 6];
     if (strand == 0)
-        flank_verify_lane<W, 0>(bases, offsets, n_reads, tables, G, g, n_groups, flags, cnt, hits, hit_cap, hit_count, queues, s_peq, stage);
+        flank_verify_lane<W, 0>(bases, offsets, n_reads, tables, G, g, n_groups, flags, cnt, hits, hit_cap, hit_count, queues, s_peq, stage, s_flws[threadIdx.x >> 6]);
     else
-        flank_verify_lane<W, 1>(bases, offsets, n_reads, tables, G, g, n_groups, flags + words_per_strand, cnt, hits, hit_cap, hit_count, queues + 1, s_peq, stage);
+        flank_verify_lane<W, 1>(bases, offsets, n_reads, tables, G, g, n_groups, flags + words_per_strand, cnt, hits, hit_cap, hit_count, queues + 1, s_peq, stage, s_flws[threadIdx.x >> 6]);
 }
 
 // ------------------------------------------------------------------------------------------------
