@@ -489,21 +489,44 @@ void launch_scan(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets, u
                            (const uint8_t*)c->d_tables, (const bb_group_dev*)c->d_groups, g, (uint32_t)c->groups.size(), c->d_cnt,
                            c->d_raw, c->cap_hits, c->d_hitcount);
 }
-template <int W>
-void launch_trace(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n_hits, uint32_t g) {
+// Which variant of k_flank_trace a group takes (bb_kernels.h): 2 = 16-row band in LDS (k <= 6), 1 = every row in LDS,
+// 3 = checkpointed columns, 0 = private memory.
+static int trace_mode(const bb_ctx* c, uint32_t g) {
     const bb_group_dev& D = c->gdev[g];
-    const size_t lds_rec = (size_t)64 * BB_TRACE_REC_STRIDE * 4;          // the staged hit records share the move bits' LDS
-    const size_t lds = std::max(lds_rec, (size_t)(D.m + D.flank_k + 2) * 2 * W * 64 * 4);  // columns 0..m+k, lo+hi, W words, 64 lanes
-    const size_t lds_band = std::max(lds_rec, (size_t)(D.m + D.flank_k + 2) * 64 * 4);      // one word per column and lane
+    const int W = D.W;
+    const size_t lds = (size_t)(D.m + D.flank_k + 2) * 2 * W * 64 * 4;  // columns 0..m+k, lo+hi, W words, 64 lanes
+    const size_t lds_ck = (size_t)(((D.m + D.flank_k) / BB_TRACE_CKB + 1) * 2 * W + BB_TRACE_CKB * 2 * W) * 64 * 4;
+    if (D.flank_k <= 6 && !c->force_generic && !getenv("BARBELL_AMD_TRACE_FULL")) return 2;  // band of 2(k+1)+1 <= 15 rows in 16 bits
+    if (W <= 4 && lds <= 64 * 1024 && !c->force_generic) return 1;
+    if (lds_ck <= 64 * 1024 && !c->force_generic && !getenv("BARBELL_AMD_TRACE_NOCKPT")) return 3;
+    return 0;
+}
+// One launch for every group of the same width and variant (the raw hits of all groups share one array: a launch per
+// group walks it once per group with the other groups' lanes idle).
+template <int W>
+void launch_trace(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n_hits, uint32_t gmask, int mode) {
+    const size_t lds_rec = (size_t)64 * BB_TRACE_REC_STRIDE * 4;  // the staged hit records share the move bits' LDS
+    size_t lds = lds_rec;
+    int mk_max = 0;
+    for (uint32_t g = 0; g < c->groups.size(); ++g) {
+        if (!((gmask >> g) & 1u)) continue;
+        const bb_group_dev& D = c->gdev[g];
+        const int mk = D.m + D.flank_k;
+        mk_max = std::max(mk_max, mk);
+        const size_t need = mode == 2 ? (size_t)(mk + 2) * 64 * 4                                   // one word per column and lane
+                          : mode == 1 ? (size_t)(mk + 2) * 2 * W * 64 * 4                            // columns 0..m+k, lo+hi, W words
+                          : mode == 3 ? (size_t)((mk / BB_TRACE_CKB + 1) * 2 * W + BB_TRACE_CKB * 2 * W) * 64 * 4  // checkpoints + one block's move bits
+                          : 0;
+        lds = std::max(lds, need);
+    }
 #define BB_TRACE_ARGS d_bases, d_offsets, (const uint8_t*)c->d_tables, (const bb_group_dev*)c->d_groups, (uint32_t)c->groups.size(), \
-                      (const bb_hit_raw*)c->d_raw, n_hits, (const uint32_t*)c->d_base, c->d_hits, g
-    if (D.flank_k <= 6 && !c->force_generic && !getenv("BARBELL_AMD_TRACE_FULL"))  // band of 2(k+1)+1 <= 15 rows in 16 bits
-        hipLaunchKernelGGL((k_flank_trace<W, 2>), dim3((n_hits + 63) / 64), dim3(64), lds_band, c->stream, BB_TRACE_ARGS);
-    else if (W <= 4 && lds <= 64 * 1024 && !c->force_generic) {
+                      (const bb_hit_raw*)c->d_raw, n_hits, (const uint32_t*)c->d_base, c->d_hits, gmask, mk_max
+    if (mode == 2) hipLaunchKernelGGL((k_flank_trace<W, 2>), dim3((n_hits + 63) / 64), dim3(64), lds, c->stream, BB_TRACE_ARGS);
+    else if (mode == 1) {
         if constexpr (W <= 4)  // the full-height LDS variant never fits beyond 4 words
             hipLaunchKernelGGL((k_flank_trace<W, 1>), dim3((n_hits + 63) / 64), dim3(64), lds, c->stream, BB_TRACE_ARGS);
-    } else
-        hipLaunchKernelGGL((k_flank_trace<W, 0>), dim3((n_hits + 63) / 64), dim3(64), lds_rec, c->stream, BB_TRACE_ARGS);
+    } else if (mode == 3) hipLaunchKernelGGL((k_flank_trace<W, 3>), dim3((n_hits + 63) / 64), dim3(64), lds, c->stream, BB_TRACE_ARGS);
+    else hipLaunchKernelGGL((k_flank_trace<W, 0>), dim3((n_hits + 63) / 64), dim3(64), lds, c->stream, BB_TRACE_ARGS);
 #undef BB_TRACE_ARGS
 }
 template <int WB, int CW>
@@ -773,16 +796,23 @@ int bb_annotate_batch_dev(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_o
     if ((r = scan_u32(c, c->d_cnt, c->d_base, M))) return r;
     mark(c, K_TRACE);
     if (n_hits) {
+        uint32_t done = 0;
         for (uint32_t g = 0; g < G; ++g) {
-            switch (c->gdev[g].W) {
-                case 1: launch_trace<1>(c, d_bases, d_offsets, n_hits, g); break;
-                case 2: launch_trace<2>(c, d_bases, d_offsets, n_hits, g); break;
-                case 3: launch_trace<3>(c, d_bases, d_offsets, n_hits, g); break;
-                case 4: launch_trace<4>(c, d_bases, d_offsets, n_hits, g); break;
-                case 5: launch_trace<5>(c, d_bases, d_offsets, n_hits, g); break;
-                case 6: launch_trace<6>(c, d_bases, d_offsets, n_hits, g); break;
-                case 7: launch_trace<7>(c, d_bases, d_offsets, n_hits, g); break;
-                default: launch_trace<8>(c, d_bases, d_offsets, n_hits, g); break;
+            if ((done >> g) & 1u) continue;
+            const int W = c->gdev[g].W, mode = trace_mode(c, g);
+            uint32_t gmask = 0;
+            for (uint32_t g2 = g; g2 < G; ++g2)
+                if (c->gdev[g2].W == W && trace_mode(c, g2) == mode) gmask |= 1u << g2;
+            done |= gmask;
+            switch (W) {
+                case 1: launch_trace<1>(c, d_bases, d_offsets, n_hits, gmask, mode); break;
+                case 2: launch_trace<2>(c, d_bases, d_offsets, n_hits, gmask, mode); break;
+                case 3: launch_trace<3>(c, d_bases, d_offsets, n_hits, gmask, mode); break;
+                case 4: launch_trace<4>(c, d_bases, d_offsets, n_hits, gmask, mode); break;
+                case 5: launch_trace<5>(c, d_bases, d_offsets, n_hits, gmask, mode); break;
+                case 6: launch_trace<6>(c, d_bases, d_offsets, n_hits, gmask, mode); break;
+                case 7: launch_trace<7>(c, d_bases, d_offsets, n_hits, gmask, mode); break;
+                default: launch_trace<8>(c, d_bases, d_offsets, n_hits, gmask, mode); break;
             }
         }
         HIPCHK(c, hipGetLastError());

@@ -1118,19 +1118,24 @@ __global__ __launch_bounds__(256) void k_scan_add(uint32_t* __restrict__ out, ui
 // band of 16 rows around the end cell's diagonal (one word per column and lane: both planes).  A path of cost
 // <= k leaves that diagonal by at most k rows, so for k <= 6 the band holds every cell the walk can visit, and
 // a quarter of the LDS lets four times as many blocks share a CU.
+// MODE 3 (k > 6 where the full height does not fit): no move bits during the forward pass, only the column state (Pv, Mv)
+// every 8 columns in LDS; the walk then goes back block by block — the wave recomputes the 8 columns of a block from its
+// checkpoint with their move bits into a small LDS window and every lane walks through its part of the block — so the DP
+// is computed twice, and nothing lives in private memory (the k = 20 tracebacks of the rapid kits: 3.9 -> ms below).
+#define BB_TRACE_CKB 8
 #define BB_TRACE_REC_STRIDE 25  // words per staged bb_hit (24) + 1: lanes land in different banks
 template <int W, int MODE>
 __device__ __forceinline__ uint32_t flank_trace_lane(const uint8_t* __restrict__ bases, const uint64_t* __restrict__ offsets,
                                                      const uint8_t* __restrict__ tables, const bb_group_dev* __restrict__ groups,
                                                      uint32_t n_groups, const bb_hit_raw* __restrict__ raw, uint32_t n_hits,
-                                                     const uint32_t* __restrict__ slot_base, uint32_t g_sel, uint32_t* __restrict__ orec,
+                                                     const uint32_t* __restrict__ slot_base, uint32_t gmask, int mk_max, uint32_t* __restrict__ orec,
                                                      uint32_t* s_moves) {
     constexpr int S = (W <= 2 ? 2 : (W <= 4 ? 4 : 8));
     constexpr int MAXC = 32 * W + 64;
     const uint32_t t = blockIdx.x * 64u + threadIdx.x;
     if (t >= n_hits) return 0xFFFFFFFFu;
     const bb_hit_raw h = raw[t];
-    if (groups[h.group].W != W || (g_sel != 0xFFFFFFFFu && h.group != g_sel)) return 0xFFFFFFFFu;
+    if (!((gmask >> h.group) & 1u)) return 0xFFFFFFFFu;  // the launch's groups: same W, same mode (launch_trace)
     const bb_group_dev& G = groups[h.group];  // not a copy: indexing a private copy by the strand put the struct into scratch memory
     const uint64_t off = offsets[h.read_idx];
     const int32_t n = (int32_t)(offsets[h.read_idx + 1] - off);
@@ -1204,6 +1209,11 @@ __device__ __forceinline__ uint32_t flank_trace_lane(const uint8_t* __restrict__
             }
         }
     };
+    auto ck_store = [&](int blk) {
+#pragma unroll
+        for (int x = 0; x < W; ++x) { s_moves[((blk * 2 * W) + x) * 64 + threadIdx.x] = pv[x]; s_moves[((blk * 2 * W) + W + x) * 64 + threadIdx.x] = mv[x]; }
+    };
+    if constexpr (MODE == 3) ck_store(0);
     uint32_t cur[4], nxt[4];
     load16(s0, cur);
     for (int32_t cb = 0; cb < w; cb += 16) {
@@ -1218,6 +1228,7 @@ __device__ __forceinline__ uint32_t flank_trace_lane(const uint8_t* __restrict__
                 myers_step<W>(pv, mv, eq, d0, ph, mh);
                 move_bits<W>(eq, d0, ph, l, hh);
                 if constexpr (MODE == 2) put_band(c, l, hh);
+                else if constexpr (MODE == 3) { if ((c & (BB_TRACE_CKB - 1)) == 0) ck_store(c / BB_TRACE_CKB); }
                 else {
 #pragma unroll
                     for (int x = 0; x < W; ++x) put(c, x, l[x], hh[x]);
@@ -1230,14 +1241,7 @@ __device__ __forceinline__ uint32_t flank_trace_lane(const uint8_t* __restrict__
     (void)ovh;
     // traceback from (j0, w)
     int32_t j = j0, i = w, cnt = 0, first_txt = 0, last_txt = 0;
-    while (j > 0) {
-        uint32_t op;
-        if (i == 0) {
-            if (s0 == 0) break;  // left overhang: remaining pattern is outside the read
-            op = 3u;
-        } else {
-            op = get_op(i, j - 1);
-        }
+    auto take = [&](uint32_t op) {
         if (op != 2u) --j;
         if (op != 3u) --i;
         if (j >= bar_lo && j <= bar_hi) {  // path cell Pos(j, s0+i) of this op
@@ -1248,6 +1252,56 @@ __device__ __forceinline__ uint32_t flank_trace_lane(const uint8_t* __restrict__
             first_txt = f;
             ++cnt;
         }
+    };
+    if constexpr (MODE == 3) {
+        const int NB = (m + k) / BB_TRACE_CKB + 1;          // checkpoints 0 .. NB-1 of this lane's group (the LDS is sized for the launch's largest)
+        uint32_t* win = s_moves + NB * 2 * W * 64;           // [column of the block][lo | hi][word][64 lanes]
+        uint32_t tq[4], tn[4] = {0u, 0u, 0u, 0u};            // the block's text; the next (lower) block's, requested a block ahead
+        {
+            const int32_t cl = ((w - 1) / BB_TRACE_CKB) * BB_TRACE_CKB;  // this lane's last block
+            if (w > 0) load16(s0 + cl, tn);
+        }
+        for (int blk = (mk_max - 1) / BB_TRACE_CKB; blk >= 0; --blk) {  // wave-uniform: the largest m + k of the launch's groups
+            const int32_t c0 = blk * BB_TRACE_CKB;           // the block holds columns c0+1 .. c0+8
+            if (c0 < w) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) tq[q] = tn[q];
+                if (c0 >= BB_TRACE_CKB) load16(s0 + c0 - BB_TRACE_CKB, tn);
+            }
+            if (c0 < w && j > 0 && i > c0) {
+#pragma unroll
+                for (int x = 0; x < W; ++x) { pv[x] = s_moves[((blk * 2 * W) + x) * 64 + threadIdx.x]; mv[x] = s_moves[((blk * 2 * W) + W + x) * 64 + threadIdx.x]; }
+#pragma unroll
+                for (int b = 0; b < BB_TRACE_CKB; ++b) {
+                    if (c0 + b + 1 <= w) {
+                        const uint32_t ch = (tq[b >> 2] >> (8 * (b & 3))) & 0xFFu;
+                        uint32_t eq[W], d0[W], ph[W], mh[W], l[W], hh[W];
+                        load_eq<W, S>(peq, ch, eq);
+                        myers_step<W>(pv, mv, eq, d0, ph, mh);
+                        move_bits<W>(eq, d0, ph, l, hh);
+#pragma unroll
+                        for (int x = 0; x < W; ++x) { win[((b * 2 + 0) * W + x) * 64 + threadIdx.x] = l[x]; win[((b * 2 + 1) * W + x) * 64 + threadIdx.x] = hh[x]; }
+                    }
+                }
+                while (j > 0 && i > c0) {
+                    const int cc = i - c0 - 1, bit = j - 1;
+                    const uint32_t lw = win[((cc * 2 + 0) * W + (bit >> 5)) * 64 + threadIdx.x], hw = win[((cc * 2 + 1) * W + (bit >> 5)) * 64 + threadIdx.x];
+                    take(((lw >> (bit & 31)) & 1u) | (((hw >> (bit & 31)) & 1u) << 1));
+                }
+            }
+        }
+        while (j > 0 && s0 != 0) take(3u);  // column 0 reached inside the read: the rows left are deleted (s0 == 0: left overhang, they lie outside)
+    } else {
+    while (j > 0) {
+        uint32_t op;
+        if (i == 0) {
+            if (s0 == 0) break;  // left overhang: remaining pattern is outside the read
+            op = 3u;
+        } else {
+            op = get_op(i, j - 1);
+        }
+        take(op);
+    }
     }
     const int32_t ts = s0 + i, te = i0;
     bb_hit out;
@@ -1307,14 +1361,14 @@ template <int W, int MODE>
 __global__ __launch_bounds__(64) void k_flank_trace(const uint8_t* __restrict__ bases, const uint64_t* __restrict__ offsets,
                                                     const uint8_t* __restrict__ tables, const bb_group_dev* __restrict__ groups,
                                                     uint32_t n_groups, const bb_hit_raw* __restrict__ raw, uint32_t n_hits,
-                                                    const uint32_t* __restrict__ slot_base, bb_hit* __restrict__ hits, uint32_t g_sel) {
+                                                    const uint32_t* __restrict__ slot_base, bb_hit* __restrict__ hits, uint32_t gmask, int mk_max) {
     extern __shared__ uint32_t s_dyn[];
     __shared__ uint32_t s_slot[64];
     static_assert(sizeof(bb_hit) == 96, "six 16-byte pieces");
     // the staged records reuse the move bits' LDS (>= 64 * BB_TRACE_REC_STRIDE words, launch_trace): the block is one wave,
     // a lane writes its record after every lane's walk is over, and LDS operations of a wave execute in order
     uint32_t* s_rec = s_dyn;
-    s_slot[threadIdx.x] = flank_trace_lane<W, MODE>(bases, offsets, tables, groups, n_groups, raw, n_hits, slot_base, g_sel,
+    s_slot[threadIdx.x] = flank_trace_lane<W, MODE>(bases, offsets, tables, groups, n_groups, raw, n_hits, slot_base, gmask, mk_max,
                                                     s_rec + threadIdx.x * BB_TRACE_REC_STRIDE, s_dyn);
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < 64u * 6u; i += 64u) {
