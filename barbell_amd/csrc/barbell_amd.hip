@@ -558,7 +558,7 @@ void launch_barcode_pfx(bb_ctx* c, uint32_t n_hits, uint32_t g, uint32_t strand,
     const uint32_t threads = ((hpb * N + 63) / 64) * 64;
     // two halves of everything a set of hpb hits owns (records, reduction cells, per-column tables) + Peq + trailing-row planes
     const size_t smem = (size_t)2 * hpb * 40 + 16 + (size_t)2 * hpb * (sizeof(bb_hit) + sizeof(bb_hit_pfx)) + (size_t)2 * hpb * CW * 24 + (size_t)16 * N * 4 +
-                        (size_t)D.tail[strand] * 2 * threads * 8 + 64;
+                        (size_t)D.tail[strand] * 2 * threads * 8 + 64 + (fast ? 256 * 32 + 32 : 0);
     const uint32_t n_iter = (n_hits + hpb - 1) / hpb;
     const uint32_t per_cu = std::max(1u, (CW <= 48 ? 768u : 512u) / threads);  // blocks that fit a CU at this kernel's register count
     const uint32_t resident = (uint32_t)c->n_cus * per_cu * c->reg_blocks_mult;

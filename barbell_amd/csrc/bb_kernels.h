@@ -1791,6 +1791,47 @@ __device__ __forceinline__ float lodhi_bound(unsigned long long plo, unsigned lo
     return sc * (1.0f + 1.0f / 16384.0f);
 }
 
+// The same bound, eight columns at a time.  Over the columns 8q+1 .. 8q+8 the recurrence is affine in (sc, b2, b1), and
+// with u2 = b2 / 2^8q, u1 = b1 / 2^8q its coefficients depend on the byte of Match bits only:
+//   sc += A u2 + B u1 + C;   u2 = (u2 + n u1 + D) / 256;   u1 = (u1 + E) / 256
+// (A = sum 2^-(r+1), B = sum 2^-(r+1) cnt(r), C = sum 2^-(r+1) P2(r) over the byte's Match positions r = 1..8, with cnt(r) the
+// Matches before r, P1(r) = sum of 2^r' over them, P2(r) = sum of P1 over them; n = all Matches, D = P2(9), E = P1(9)).
+// One 32-byte table entry and eight f32 operations per byte instead of nine instructions per column; the entries are
+// rounded up, every term is positive, fewer than 60 roundings enter a result: the (1 + 2^-14) scale keeps it a bound.
+struct __attribute__((aligned(32))) bb_lb_entry { float A, B, C, n, D, E, _p0, _p1; };
+__device__ __forceinline__ void lodhi_bound_table_entry(uint32_t byte, bb_lb_entry& e) {
+    double A = 0.0, B = 0.0, C = 0.0, D = 0.0, E = 0.0, cnt = 0.0, P1 = 0.0, P2 = 0.0;
+    for (int r = 1; r <= 8; ++r) {
+        if ((byte >> (r - 1)) & 1u) {
+            const double w = __hiloint2double((int)((uint32_t)(1023 - (r + 1)) << 20), 0);  // 2^-(r+1)
+            A += w; B += w * cnt; C += w * P2;
+            P2 += P1; cnt += 1.0; P1 += (double)(1u << r);
+        }
+    }
+    D = P2; E = P1;
+    e.A = __double2float_ru(A); e.B = __double2float_ru(B); e.C = __double2float_ru(C); e.n = (float)cnt;
+    e.D = __double2float_ru(D); e.E = __double2float_ru(E); e._p0 = 0.0f; e._p1 = 0.0f;
+}
+template <int CW>
+__device__ __forceinline__ float lodhi_bound_tab(unsigned long long plo, unsigned long long phi, int32_t tstart, int32_t best_pos, int wmax,
+                                                 const bb_lb_entry* tab) {
+    const unsigned long long mmask = low64(best_pos) & ~low64(tstart) & ~(plo | phi);   // Match columns (bit c-1)
+    const uint32_t m_w[2] = {(uint32_t)mmask, (uint32_t)(mmask >> 32)};
+    float sc = 0.0f, u1 = 0.0f, u2 = 0.0f;
+#pragma unroll
+    for (int q = 0; q < CW / 8; ++q) {
+        if (8 * q < wmax) {  // wave-uniform
+            const uint32_t byte = (m_w[q >> 2] >> (8 * (q & 3))) & 0xFFu;
+            const float4 t0 = *reinterpret_cast<const float4*>(&tab[byte].A);
+            const float2 t1 = *reinterpret_cast<const float2*>(&tab[byte].D);
+            sc = __fmaf_rn(t0.x, u2, __fmaf_rn(t0.y, u1, sc + t0.z));
+            u2 = (__fmaf_rn(t0.w, u1, u2) + t1.x) * (1.0f / 256.0f);
+            u1 = (u1 + t1.y) * (1.0f / 256.0f);
+        }
+    }
+    return sc * (1.0f + 1.0f / 16384.0f);
+}
+
 template <int WB, int CW>
 __global__ __launch_bounds__(512) void k_barcode_reg(const uint8_t* __restrict__ tables, const bb_group_dev* __restrict__ groups,
                                                      uint32_t g, const bb_hit* __restrict__ hits, const uint32_t* __restrict__ hit_list,
@@ -2172,11 +2213,16 @@ __global__ __launch_bounds__(CW <= 48 ? 768 : 512) void k_barcode_pfx(const uint
     uint32_t* s_peq = reinterpret_cast<uint32_t*>(smem + o);
     o += (size_t)16 * N * 4;
     o = (o + 15) & ~(size_t)15;
+    o = (o + 31) & ~(size_t)31;
+    bb_lb_entry* s_lb = reinterpret_cast<bb_lb_entry*>(smem + o);  // FAST: the bound's table (one entry per byte of Match bits)
+    o += FAST ? 256 * sizeof(bb_lb_entry) : 0;
     unsigned long long* s_tail = reinterpret_cast<unsigned long long*>(smem + o);  // [t][lo|hi][thread]
     {
         const uint32_t* gp = reinterpret_cast<const uint32_t*>(tables + groups[g].off_peq_sub[strand]);
         const int words = 16 * N;
         for (int i = threadIdx.x; i < words; i += blockDim.x) s_peq[i] = gp[i];
+        if constexpr (FAST)
+            for (uint32_t i = threadIdx.x; i < 256u; i += blockDim.x) lodhi_bound_table_entry(i, s_lb[i]);
     }
     const int hl = threadIdx.x / N;
     const int p = threadIdx.x - hl * N;
@@ -2496,7 +2542,7 @@ __global__ __launch_bounds__(CW <= 48 ? 768 : 512) void k_barcode_pfx(const uint
         // the maximum is also the FIRST maximum; whatever a lane's atomicMax displaces or fails to displace, min(old, key),
         // is a candidate for second place, and the true second always shows up as one).  Which set counts is known after
         // the single barrier: pass 2 iff pass 1 has fewer than two members, i.e. its second place is empty.
-        const float ubf = lodhi_bound<CW>(cand ? plo : 0ull, cand ? phi : 0ull, cand ? tstart : 0, cand ? best_pos : 0, wmax);
+        const float ubf = lodhi_bound_tab<CW>(cand ? plo : 0ull, cand ? phi : 0ull, cand ? tstart : 0, cand ? best_pos : 0, wmax, s_lb);
         (void)delrow;
         const unsigned long long key = ((unsigned long long)__float_as_uint(ubf) << 16) | (unsigned long long)(0xFFFFu - (uint32_t)p);
         if (N >= 64) {
