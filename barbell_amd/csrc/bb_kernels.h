@@ -2554,10 +2554,18 @@ __global__ __launch_bounds__(CW <= 48 ? 768 : 512) void k_barcode_pfx(const uint
             const bool c2 = cand, c1 = cand && best_cost <= G.k1;
             const uint32_t vb = __float_as_uint(ubf);
             unsigned long long t[4], u[4];  // combos: 0 = (hit A, pass 1), 1 = (A, pass 2), 2 = (B, pass 1), 3 = (B, pass 2)
-            wave_top2(c1 && hl == hA, vb, key, t[0], u[0]);
+            // the two candidate sets differ only if some candidate costs more than k1, and two waves in three hold one hit:
+            // usually one reduction serves all
+            const bool sets_differ = __any(c2 && !c1), two_hits = __any(hl != hA);
             wave_top2(c2 && hl == hA, vb, key, t[1], u[1]);
-            wave_top2(c1 && hl != hA, vb, key, t[2], u[2]);
-            wave_top2(c2 && hl != hA, vb, key, t[3], u[3]);
+            if (sets_differ) wave_top2(c1 && hl == hA, vb, key, t[0], u[0]);
+            else { t[0] = t[1]; u[0] = u[1]; }
+            t[2] = t[3] = u[2] = u[3] = 0ull;
+            if (two_hits) {
+                wave_top2(c2 && hl != hA, vb, key, t[3], u[3]);
+                if (sets_differ) wave_top2(c1 && hl != hA, vb, key, t[2], u[2]);
+                else { t[2] = t[3]; u[2] = u[3]; }
+            }
             if (lane < 4u) {
                 const unsigned long long kt = lane == 0u ? t[0] : lane == 1u ? t[1] : lane == 2u ? t[2] : t[3];
                 const unsigned long long ku = lane == 0u ? u[0] : lane == 1u ? u[1] : lane == 2u ? u[2] : u[3];
