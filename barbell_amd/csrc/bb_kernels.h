@@ -2169,11 +2169,7 @@ __device__ __forceinline__ void wave_top2(bool in, uint32_t vbits, unsigned long
     k2 = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(key >> 32), l2) << 32) |
          (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)key, l2);
 }
-#ifdef BB_EXP_NO_BARRIERS
-#define BB_PFX_SYNC() ((void)0)
-#else
 #define BB_PFX_SYNC() __syncthreads()
-#endif
 template <int CW, bool TAIL, bool FAST>
 __global__ __launch_bounds__(CW <= 48 ? 768 : 512) void k_barcode_pfx(const uint8_t* __restrict__ tables, const bb_group_dev* __restrict__ groups,
                                                      uint32_t g, uint32_t strand, const bb_hit* __restrict__ hits, const bb_hit_pfx* __restrict__ pfxs,
@@ -2289,11 +2285,7 @@ __global__ __launch_bounds__(CW <= 48 ? 768 : 512) void k_barcode_pfx(const uint
             const uint32_t* shw = reinterpret_cast<const uint32_t*>(hitb + hw * PIECES + SH_PIECE);
             uint32_t bh = 1u, lo2 = 0u, hi2 = 0u, dgw = 0u, n2 = 0u;
 #pragma unroll 1
-#ifdef BB_EXP_NO_WALK
-            for (int i = 0; i < 1 && bh != 0u && cxw - i >= 1; ++i) {
-#else
             for (int i = 0; i < 16 && bh != 0u && cxw - i >= 1; ++i) {  // rolled: short, and the registers are wanted elsewhere
-#endif
                 const uint32_t w = shw[cxw - 1 - i];
                 const uint32_t Lr = w & 0xFFFFu, Hr = w >> 16;
                 const uint32_t Dr = Lr & Hr;
@@ -2470,9 +2462,6 @@ __global__ __launch_bounds__(CW <= 48 ? 768 : 512) void k_barcode_pfx(const uint
     // column at bit 0 = its final place); a Match/Sub step is cm = nb & ~Hr (one-hot or zero): consumed rows |= cm,
     // and the cursor moves by b = nb + cm (nb << 1 when it consumed, nb when it did not).
     uint32_t pl_acc[2] = {0u, 0u}, ph_acc[2] = {0u, 0u};
-#ifdef BB_EXP_NO_TRACE
-    for (int c = 0; c < CW; ++c) { pl_acc[0] ^= L0[c]; ph_acc[0] += H0[c]; } dg = pl_acc[0] & ph_acc[0] & 0xFFFF;
-#else
 #pragma unroll
     for (int c0 = CW; c0 >= BB_CG; c0 -= BB_CG) {
         if (c0 <= BB_FIXED_COLS || c0 - (BB_CG - 1) <= wmax) {  // wave-uniform
@@ -2490,7 +2479,6 @@ __global__ __launch_bounds__(CW <= 48 ? 768 : 512) void k_barcode_pfx(const uint
             }
         }
     }
-#endif
     plo |= ((unsigned long long)pl_acc[1] << 32) | pl_acc[0];
     phi |= ((unsigned long long)ph_acc[1] << 32) | ph_acc[0];
     // Text ops of phase 1 = rows it consumed + its Ins columns.  Whichever way the cursor left the word, the
