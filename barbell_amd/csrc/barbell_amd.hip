@@ -192,6 +192,8 @@ namespace {
         }                                                                                        \
     } while (0)
 
+#define BB_LDS_MAX (144 * 1024)  // dynamic LDS a block may ask for (160 KB per CU on gfx950, some of it static)
+
 template <typename T>
 int grow(bb_ctx* c, T*& p, uint64_t& cap, uint64_t need) {
     if (need <= cap && p) return BB_OK;
@@ -496,7 +498,8 @@ static int trace_mode(const bb_ctx* c, uint32_t g) {
     const int W = D.W;
     const size_t lds = (size_t)(D.m + D.flank_k + 2) * 2 * W * 64 * 4;  // columns 0..m+k, lo+hi, W words, 64 lanes
     const size_t lds_ck = (size_t)(((D.m + D.flank_k) / BB_TRACE_CKB + 1) * 2 * W + BB_TRACE_CKB * 2 * W) * 64 * 4;
-    if (D.flank_k <= 6 && !c->force_generic && !getenv("BARBELL_AMD_TRACE_FULL")) return 2;  // band of 2(k+1)+1 <= 15 rows in 16 bits
+    const size_t lds_band = (size_t)(D.m + D.flank_k + 2) * 64 * 4;
+    if (D.flank_k <= 6 && lds_band <= 64 * 1024 && !c->force_generic && !getenv("BARBELL_AMD_TRACE_FULL")) return 2;  // band of 2(k+1)+1 <= 15 rows in 16 bits
     if (W <= 4 && lds <= 64 * 1024 && !c->force_generic) return 1;
     if (lds_ck <= 64 * 1024 && !c->force_generic && !getenv("BARBELL_AMD_TRACE_NOCKPT")) return 3;
     return 0;
@@ -554,24 +557,37 @@ void launch_barcode_pfx(bb_ctx* c, uint32_t n_hits, uint32_t g, uint32_t strand,
     // 22.8 vs 26.8 ms against 512-thread blocks at 2 waves per SIMD
     uint32_t tmax = CW <= 48 ? 768u : 512u;
     if (c->pfx_threads && c->pfx_threads <= tmax) tmax = c->pfx_threads;  // BARBELL_AMD_PFX_THREADS (tuning knob)
-    const uint32_t hpb = std::max(1u, tmax / N);
-    const uint32_t threads = ((hpb * N + 63) / 64) * 64;
+    uint32_t hpb = std::max(1u, tmax / N);
+    uint32_t threads = ((hpb * N + 63) / 64) * 64;
     // two halves of everything a set of hpb hits owns (records, reduction cells, per-column tables) + Peq + trailing-row planes
-    const size_t smem = (size_t)2 * hpb * 40 + 16 + (size_t)2 * hpb * (sizeof(bb_hit) + sizeof(bb_hit_pfx)) + (size_t)2 * hpb * CW * 24 + (size_t)16 * N * 4 +
-                        (size_t)D.tail[strand] * 2 * threads * 8 + 64 + (fast ? 256 * 32 + 32 : 0);
+    auto smem_for = [&](uint32_t h, uint32_t t) {
+        return (size_t)2 * h * 40 + 16 + (size_t)2 * h * (sizeof(bb_hit) + sizeof(bb_hit_pfx)) + (size_t)2 * h * CW * 24 + (size_t)16 * N * 4 +
+               (size_t)D.tail[strand] * 2 * t * 8 + 64 + (fast ? 256 * 32 + 32 : 0);
+    };
+    // groups of few barcodes put many hits into a block: fewer of them when the block's LDS would not fit (the per-hit
+    // share is ~3.6 KB; 64 KB is what a launch gets without asking, BB_LDS_MAX what the CU has to give)
+    while (hpb > 1 && smem_for(hpb, threads) > BB_LDS_MAX) { --hpb; threads = ((hpb * N + 63) / 64) * 64; }
+    const size_t smem = smem_for(hpb, threads);
     const uint32_t n_iter = (n_hits + hpb - 1) / hpb;
     const uint32_t per_cu = std::max(1u, (CW <= 48 ? 768u : 512u) / threads);  // blocks that fit a CU at this kernel's register count
     const uint32_t resident = (uint32_t)c->n_cus * per_cu * c->reg_blocks_mult;
     const uint32_t blocks = n_iter < resident ? n_iter : resident;
 #define BB_PFX_ARGS (const uint8_t*)c->d_tables, (const bb_group_dev*)c->d_groups, g, strand, (const bb_hit*)c->d_hits, (const bb_hit_pfx*)c->d_pfx, list, \
                     cnt, n_hits, hpb, c->params.min_score, c->params.min_score_diff, c->d_rows
+#define BB_PFX_LAUNCH(TAIL_, FAST_)                                                                                          \
+    do {                                                                                                                    \
+        if (smem > 64 * 1024)                                                                                               \
+            (void)hipFuncSetAttribute((const void*)k_barcode_pfx<CW, TAIL_, FAST_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
+        hipLaunchKernelGGL((k_barcode_pfx<CW, TAIL_, FAST_>), dim3(blocks), dim3(threads), smem, c->stream, BB_PFX_ARGS);   \
+    } while (0)
     if (D.tail[strand] > 0) {
-        if (fast) hipLaunchKernelGGL((k_barcode_pfx<CW, true, true>), dim3(blocks), dim3(threads), smem, c->stream, BB_PFX_ARGS);
-        else hipLaunchKernelGGL((k_barcode_pfx<CW, true, false>), dim3(blocks), dim3(threads), smem, c->stream, BB_PFX_ARGS);
+        if (fast) BB_PFX_LAUNCH(true, true);
+        else BB_PFX_LAUNCH(true, false);
     } else {
-        if (fast) hipLaunchKernelGGL((k_barcode_pfx<CW, false, true>), dim3(blocks), dim3(threads), smem, c->stream, BB_PFX_ARGS);
-        else hipLaunchKernelGGL((k_barcode_pfx<CW, false, false>), dim3(blocks), dim3(threads), smem, c->stream, BB_PFX_ARGS);
+        if (fast) BB_PFX_LAUNCH(false, true);
+        else BB_PFX_LAUNCH(false, false);
     }
+#undef BB_PFX_LAUNCH
 #undef BB_PFX_ARGS
 }
 

@@ -813,7 +813,9 @@ __global__ __launch_bounds__(256) void k_flank_filter(const uint8_t* __restrict_
                     const uint32_t p = 16u * (uint32_t)q + (uint32_t)b;
                     if (p >= lo && p < hi) step((word >> (8 * (b & 3))) & 0xFFu);
                 }
-                commit(qb + (uint32_t)q);
+                // a piece without a byte of the read leaves `keep` alone: what column 0 says (the left-overhang column of a
+                // window that starts at row 0) belongs to the first piece that holds read bytes, whichever that is
+                if (16u * (uint32_t)q + 16u > lo && 16u * (uint32_t)q < hi) commit(qb + (uint32_t)q);
             }
         }
         if (on && ((l & 3u) == 3u || l + 1u == nlines)) {

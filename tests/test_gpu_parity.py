@@ -156,6 +156,18 @@ def test_scan_filter_variants(monkeypatch, mode):
     # misaligned batch start: the flag words are addressed relative to offsets[0]
     _, got, want = run_both(groups, bases[3:], offsets[1:] - np.uint64(3))
     assert_same(got, want)
+    # k = 0 with free overhang: only column 0 of a window at row 0 says that a construct hangs over the read's start, and
+    # the reads start anywhere within their first streamed line (found by the 400-seed soak of test_fuzz_geometry)
+    from barbell_amd import kits
+    from tests.common import EX
+    g0 = [kits.group_from_fasta(os.path.join(EX, "native_left.fasta"), _abi.BB_FTAG, 0)]  # 44 informative rows before the mask
+    q = bytes(g0[0].seqs[5])
+    reads = [q[int(rng.integers(15, 40)):] + bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), int(rng.integers(20, 400)))) for _ in range(400)]
+    bases = np.frombuffer(b"".join(reads), dtype=np.uint8).copy()
+    offsets = np.concatenate([[0], np.cumsum([len(r) for r in reads])]).astype(np.uint64)
+    _, got, want = run_both(g0, bases, offsets, alpha=0.0)
+    assert len(want) > 300
+    assert_same(got, want)
 
 
 def test_noisy_reads_exercise_the_fallback():
@@ -473,7 +485,7 @@ def test_iupac_queries_and_custom_geometry():
         assert_same(got, want)
 
 
-@pytest.mark.parametrize("seed", list(range(40)))
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("BARBELL_FUZZ_SEEDS", "120")))))
 def test_fuzz_geometry(seed):
     """Random query geometry (barcode length, one- or two-sided flanks, group count and size, k, alpha,
     thresholds) within the library's documented limits, reads with planted noisy constructs."""
