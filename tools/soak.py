@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""dev aid (GPU box): randomised soak of the annotate path against the oracle — kit / custom query sets with random flank
+error budgets and overhang factors, read mixtures (synthetic constructs, constructs cut at either end, homopolymers,
+repeats of flank pieces, tiny reads), random scan variants (BARBELL_AMD_SCAN_FILTER / _WIDE / _ENDS).
+usage: soak.py FIRST_SEED N_SEEDS"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from barbell_amd import _abi, annotate as A, kits  # noqa: E402
+from tests.common import EX  # noqa: E402
+from tests.test_gpu_parity import run_both  # noqa: E402
+
+first, count = int(sys.argv[1]), int(sys.argv[2])
+bad = 0
+for seed in range(first, first + count):
+    rng = np.random.default_rng(seed)
+    cfg = rng.choice(["nbd96", "nbd24", "dual", "rbk24", "left"])
+    k = None if rng.random() < 0.2 else int(rng.integers(0, 9))
+    if cfg == "nbd96": groups = kits.groups_from_kit("SQK-NBD114-96", flank_max_errors=k)
+    elif cfg == "nbd24": groups = kits.groups_from_kit("SQK-NBD114-24", flank_max_errors=k)
+    elif cfg == "rbk24": groups = kits.groups_from_kit("SQK-RBK114-24", flank_max_errors=k if k is None or rng.random() < 0.7 else None)
+    elif cfg == "left": groups = [kits.group_from_fasta(os.path.join(EX, "native_left.fasta"), _abi.BB_FTAG, k)]
+    else: groups = [kits.group_from_fasta(os.path.join(EX, "native_left.fasta"), _abi.BB_FTAG, k),
+                    kits.group_from_fasta(os.path.join(EX, "native_right.fasta"), _abi.BB_RTAG, k)]
+    mode = rng.choice(["", "1", "wide", "ends", "0"])
+    for v in ("BARBELL_AMD_SCAN_FILTER", "BARBELL_AMD_FILTER_WIDE", "BARBELL_AMD_FILTER_ENDS"):
+        os.environ.pop(v, None)
+    if mode in ("1", "wide", "ends"): os.environ["BARBELL_AMD_SCAN_FILTER"] = "1"
+    if mode == "0": os.environ["BARBELL_AMD_SCAN_FILTER"] = "0"
+    if mode == "wide": os.environ["BARBELL_AMD_FILTER_WIDE"] = "1"
+    if mode == "ends": os.environ["BARBELL_AMD_FILTER_ENDS"] = "1"
+    alpha = float(rng.choice([0.0, 0.3, 0.5, 0.7, 1.0]))
+    n = int(rng.integers(100, 500))
+    lmax = int(rng.integers(40, 3000))
+    b1, o1 = A.synth_reads_host(groups, seed, max(1, lmax // 8), lmax, 0, n)
+    reads = [b1[int(o1[i]):int(o1[i + 1])].tobytes() for i in range(n)]
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    for i in range(n // 2):
+        g = groups[int(rng.integers(0, len(groups)))]
+        q = bytes(g.seqs[int(rng.integers(0, len(g.seqs)))])
+        body = bytes(rng.choice(acgt, int(rng.integers(0, 600))))
+        kind = int(rng.integers(0, 7))
+        if kind == 0: r = q[int(rng.integers(0, len(q))):] + body
+        elif kind == 1: r = body + q[: len(q) - int(rng.integers(0, len(q)))]
+        elif kind == 2: r = bytes([b"ACGT"[int(rng.integers(0, 4))]]) * int(rng.integers(1, 400)) + body[:50]
+        elif kind == 3: r = q[: int(rng.integers(4, 20))] * int(rng.integers(1, 30)) + body
+        elif kind == 4: r = body[:100] + q + body[100:] + q[::-1]
+        elif kind == 5: r = q[int(rng.integers(0, len(q))): len(q) - int(rng.integers(0, 10))]
+        else: r = body[: int(rng.integers(0, 30))]
+        reads.append(r)
+    order = rng.permutation(len(reads))
+    reads = [reads[i] for i in order]
+    bases = np.frombuffer(b"".join(reads), dtype=np.uint8).copy() if any(reads) else np.zeros(0, np.uint8)
+    offsets = np.concatenate([[0], np.cumsum([len(r) for r in reads])]).astype(np.uint64)
+    try:
+        _, got, want = run_both(groups, bases, offsets, alpha=alpha)
+    except A.BarbellError as e:
+        print(f"seed {seed} {cfg} k={k} alpha={alpha} mode='{mode}': {e}")
+        if e.code != _abi.BB_E_UNSUPPORTED: bad += 1
+        continue
+    ok = got.tobytes() == want.tobytes()
+    if not ok:
+        bad += 1
+        print(f"MISMATCH seed {seed} {cfg} k={k} alpha={alpha} mode='{mode}' rows {len(got)} vs {len(want)}")
+print(f"{count} seeds, {bad} bad")
+sys.exit(1 if bad else 0)
