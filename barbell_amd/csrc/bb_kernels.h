@@ -648,23 +648,25 @@ __global__ __launch_bounds__(256) void k_flank_scan2(const uint8_t* __restrict__
 // Filtered scan (groups with bb_group_dev::filt_rows > 0): Ukkonen's cut-off — rows below the last cell <= k of a
 // column need not be computed — restructured for lanes that cannot diverge cheaply.
 //
-//   k_flank_filter  one lane per READ, one pass over the text for BOTH strands: Myers on R <= 15 consecutive rows u..u+R-1
-//                   of the flank alone (their own semi-global problem), the forward strand's in bits 0..R-1 and the reverse-complement strand's in bits 16..16+R-1
-//                   of ONE 32-bit word (carries die in the guard bits between the blocks).  Exact matching of a prefix is
-//                   direction-free: the rc strand's rows 0..R-1 against the reversed text are the reversed rows against
-//                   the forward text, so its block simply holds the rows in reverse order.  The lane tracks D[R][i] of
-//                   both blocks and records, per 16-byte piece of each streamed line, whether it was ever <= k
-//                   (one bit per piece and strand, 4 lines to a word).
-//   k_flank_verify  one lane per (read, strand): the full-height scan of k_flank_scan2 — same step, same local-minimum
-//                   state machine, same overhang handling and hit buffering — but only over the columns where a hit
-//                   is possible: a match of cost c <= k ending at column e holds an alignment of rows u..u+R-1 of cost
-//                   <= c ending at some column b (so b is flagged) with e - b in [m-u-R-k, m-u-R+k]; matches that use the left overhang
-//                   end by column m+k; the right-overhang positions follow the last column.  Each such interval is
-//                   entered with m+k columns of lead-in from the all-insertions column (values <= k are exact after
-//                   that, larger ones stay > k — the argument of k_flank_trace), and the state machine only ever acts
-//                   on values <= k or on the step into / out of them, so it emits exactly the hits of the full scan.
-// The reads are streamed once instead of twice and ~45 % of the scan's instructions go away; where the R-row prefix
-// says too little (k close to R: the score is <= k everywhere) the host keeps the full scan (upload_tables).
+//   k_flank_filter  one lane per READ, one pass over the text for BOTH strands: Myers on R <= 15 consecutive rows
+//                   u..u+R-1 of the flank alone (their own semi-global problem), the forward strand's right-aligned
+//                   under bit 15 and the reverse-complement strand's under bit 31 of ONE 32-bit word (carries die in
+//                   the guard bits 15 and 31).  Exact matching of a sub-pattern is direction-free: the rc strand's rows
+//                   against the reversed text are the reversed rows against the forward text, so its block simply
+//                   holds the rows in reverse order.  The lane tracks D[R][i] of both blocks and records, per 16-byte
+//                   piece of each streamed line, whether it was ever <= k (one bit per piece and strand, 4 lines to a
+//                   word; a read's words sit at (offset >> 9) + 3 * read, the word after them holds the rc-begin hint).
+//   k_flank_verify  lanes draw (read, strand) items from a queue: the full-height scan of k_flank_scan2 — same step,
+//                   same local-minimum state machine, same overhang handling and hit buffering — but only over the
+//                   columns where a hit is possible: a match of cost c <= k ending at column e holds an alignment of
+//                   rows u..u+R-1 of cost <= c ending at some column b (so b is flagged) with e - b in
+//                   [m-u-R-k, m-u-R+k]; the read's ends are scanned where bb_group_dev::filt_mode or the flags near them
+//                   ask for it (left / right overhang).  Each interval is entered with m+k columns of lead-in from the
+//                   all-insertions column (values <= k are exact after that, larger ones stay > k — the argument of
+//                   k_flank_trace), and the state machine only ever acts on values <= k or on the step into / out of
+//                   them, so it emits exactly the hits of the full scan.
+// The reads are streamed once instead of twice and more than half of the scan's instructions go away; where no window
+// says enough (k close to R: the score is <= k everywhere) the host keeps the full scan (upload_tables).
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint64_t filt_word_base(uint64_t off, uint64_t off0, uint32_t read) { return ((off - off0) >> 9) + 3ull * read; }
 
