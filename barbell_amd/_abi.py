@@ -34,6 +34,62 @@ class Params(C.Structure):
     ]
 
 
+class Policy(C.Structure):
+    """bb_policy (include/barbell_amd_policy.h): the switchable assumptions about sassy / cigar-lodhi-rs"""
+    _fields_ = [
+        ("lm_rule", C.c_uint8), ("rc_order", C.c_uint8), ("trace_prio", C.c_uint8 * 4), ("ovh_round", C.c_uint8), ("bar_tie", C.c_uint8),
+        ("lodhi_p", C.c_uint8), ("lodhi_exp", C.c_uint8 * 4), ("_pad", C.c_uint8 * 3), ("lodhi_lambda", C.c_double),
+    ]
+
+
+LM_RULES = ("right", "left", "strict")
+OVH_ROUNDS = ("floor", "ceil", "near")
+POLICY_DEFAULT = "lm=right,rc=scan,trace=MISD,ovh=floor,tie=first,lodhi=3:0.5:1111"
+
+
+def policy_from_str(text=None):
+    """the text form of include/barbell_amd_policy.h (same grammar as bb_policy_parse) -> Policy; None / "" = default"""
+    p = Policy(0, 0, (C.c_uint8 * 4)(0, 2, 1, 3), 0, 0, 3, (C.c_uint8 * 4)(1, 1, 1, 1), (C.c_uint8 * 3)(), 0.5)
+    if isinstance(text, Policy):
+        return text
+    for tok in (text or "").replace(" ", ",").split(","):
+        if not tok:
+            continue
+        k, _, v = tok.partition("=")
+        if k == "lm":
+            p.lm_rule = LM_RULES.index(v)
+        elif k == "rc":
+            p.rc_order = ("scan", "fwd").index(v)
+        elif k == "trace":
+            if sorted(v) != sorted("MSID"):
+                raise ValueError(f"trace={v}: a permutation of MSID")
+            for i, ch in enumerate(v):
+                p.trace_prio[i] = "MSID".index(ch)
+        elif k == "ovh":
+            r, _, w = v.partition(":")
+            if w not in ("", "f32", "f64"):
+                raise ValueError(tok)
+            p.ovh_round = OVH_ROUNDS.index(r) | (4 if w == "f64" else 0)
+        elif k == "tie":
+            p.bar_tie = ("first", "last").index(v)
+        elif k == "lodhi":
+            pp, lam, e = v.split(":")
+            if len(e) != 4 or not 1 <= int(pp) <= 4 or not 0.0 < float(lam) <= 1.0 or any(c not in "0123" for c in e):
+                raise ValueError(tok)
+            p.lodhi_p, p.lodhi_lambda = int(pp), float(lam)
+            for i, ch in enumerate(e):
+                p.lodhi_exp[i] = int(ch)
+        else:
+            raise ValueError(f"unknown policy key in {tok!r}")
+    return p
+
+
+def policy_to_str(p):
+    return (f"lm={LM_RULES[p.lm_rule]},rc={('scan', 'fwd')[p.rc_order]},trace={''.join('MSID'[x] for x in p.trace_prio)},"
+            f"ovh={OVH_ROUNDS[p.ovh_round & 3]}{':f64' if p.ovh_round & 4 else ''},tie={('first', 'last')[p.bar_tie]},"
+            f"lodhi={p.lodhi_p}:{p.lodhi_lambda!r}:{''.join(str(x) for x in p.lodhi_exp)}")
+
+
 class GroupInfo(C.Structure):
     _fields_ = [
         ("flank_len", C.c_uint32), ("prefix_len", C.c_uint32), ("suffix_len", C.c_uint32), ("mask_len", C.c_uint32),

@@ -11,7 +11,7 @@ SO_PATH = os.environ.get("BARBELL_AMD_SO") or os.path.join(_HERE, "libbarbell_am
 
 # every symbol include/barbell_amd.h and include/barbell_amd_synth.h declare
 EXPORTS = [
-    "bb_create", "bb_destroy", "bb_n_groups", "bb_group_get_info", "bb_group_get_flank", "bb_group_get_pattern",
+    "bb_create", "bb_create_policy", "bb_get_policy", "bb_destroy", "bb_n_groups", "bb_group_get_info", "bb_group_get_flank", "bb_group_get_pattern",
     "bb_annotate_batch", "bb_annotate_batch_dev", "bb_counts_len", "bb_counts", "bb_counts_dev", "bb_counts_reset",
     "bb_n_kernels", "bb_kernel_name", "bb_last_kernel_ms", "bb_set_timing", "bb_strerror", "bb_last_error",
     "bb_synth_offsets", "bb_synth_reads_host", "bb_synth_reads_dev",
@@ -47,6 +47,8 @@ def lib():
     L = C.CDLL(SO_PATH)
     vp, u32, u64, i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int
     L.bb_create.argtypes = [C.POINTER(_abi.GroupDesc), u32, C.POINTER(_abi.Params), C.POINTER(vp)]
+    L.bb_create_policy.argtypes = [C.POINTER(_abi.GroupDesc), u32, C.POINTER(_abi.Params), C.POINTER(_abi.Policy), C.POINTER(vp)]
+    L.bb_get_policy.argtypes = [vp, C.POINTER(_abi.Policy)]
     L.bb_destroy.argtypes = [vp]
     L.bb_destroy.restype = None
     L.bb_n_groups.argtypes = [vp]

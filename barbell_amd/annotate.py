@@ -61,7 +61,10 @@ class DevBuf:
 class Demuxer:
     """Demuxer::new(alpha, verbose, min_score_frac, min_score_diff_frac) (searcher.rs:202)."""
 
-    def __init__(self, alpha=0.4, verbose=False, min_score_frac=0.2, min_score_diff_frac=0.1, device=0):
+    def __init__(self, alpha=0.4, verbose=False, min_score_frac=0.2, min_score_diff_frac=0.1, device=0, policy=None):
+        # policy: text form or _abi.Policy (include/barbell_amd_policy.h) — what the un-vendored crates are assumed to do
+        # where Barbell's own code does not pin it; None = the default (or $BARBELL_AMD_POLICY)
+        self.policy = None if policy is None else _abi.policy_from_str(policy)
         self.alpha, self.verbose = float(alpha), bool(verbose)
         self.min_score_frac, self.min_score_diff_frac = float(min_score_frac), float(min_score_diff_frac)
         self.device = int(device)
@@ -82,9 +85,12 @@ class Demuxer:
             arr, keep = _abi.make_group_descs([g.as_tuple() for g in self.queries])
             p = _abi.Params(self.alpha, self.min_score_frac, self.min_score_diff_frac, self.device)
             h = C.c_void_p()
-            rc = L.bb_create(arr, len(self.queries), C.byref(p), C.byref(h))
+            if self.policy is None:
+                rc = L.bb_create(arr, len(self.queries), C.byref(p), C.byref(h))
+            else:
+                rc = L.bb_create_policy(arr, len(self.queries), C.byref(p), C.byref(self.policy), C.byref(h))
             if rc != 0:
-                raise BarbellError(rc)
+                raise BarbellError(rc, L.bb_last_error(None).decode())
             self._h = h
         return self._h
 

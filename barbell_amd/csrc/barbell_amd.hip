@@ -45,21 +45,38 @@ uint8_t rc_char(uint8_t c) {
         if ((uint8_t)from[i] == c) return (uint8_t)to[i];
     return c;
 }
-int overhang_cost(float alpha, int len) { return (int)floorf((float)len * alpha); }
+// policy [H4]: cost of `len` pattern characters hanging over a text end = round(alpha * len); mode and width by policy
+int overhang_cost(const bb_policy& P, float alpha, int len) {
+    if (P.ovh_round & BB_OVH_F64) {
+        const double v = (double)len * (double)alpha;
+        switch (P.ovh_round & 3) { case BB_OVH_CEIL: return (int)ceil(v); case BB_OVH_NEAR: return (int)nearbyint(v); default: return (int)floor(v); }
+    }
+    const float v = (float)len * alpha;
+    switch (P.ovh_round & 3) { case BB_OVH_CEIL: return (int)ceilf(v); case BB_OVH_NEAR: return (int)nearbyintf(v); default: return (int)floorf(v); }
+}
 // edit_model.rs:2-11
 int edit_cut_off(int l) {
     double a = (double)l;
     double v = ceil(0.5100 * a - 1.7312 * sqrt(a));
     return v > 0.0 ? (int)v : 0;
 }
-// score of an all-Match CIGAR of length n under the Lodhi(3, 0.5) recurrences (same op order as k_barcode)
-double lodhi_all_match(int n) {
-    double a1 = 0.0, a2 = 0.0, sc = 0.0;
-    for (int c = 0; c < n; ++c) { sc = sc + 0.5 * a2; a2 = 0.5 * (a2 + a1); a1 = 0.5 * (a1 + 1.0); }
+// score of an all-Match CIGAR of length n (searcher.rs:229-239) under the policy's Lodhi recurrences (policy [H8];
+// Lodhi::new(3, 0.5) by default; same op order as k_barcode)
+double lodhi_all_match(const bb_policy& P, int n) {
+    double d = 1.0;
+    for (int e = 0; e < P.lodhi_exp[BB_OP_MATCH]; ++e) d = e == 0 ? P.lodhi_lambda : d * P.lodhi_lambda;
+    const int lp = P.lodhi_p;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, sc = 0.0;
+    for (int c = 0; c < n; ++c) {
+        sc = sc + d * (lp >= 4 ? a2 : lp == 3 ? a1 : lp == 2 ? a0 : 1.0);
+        if (lp >= 4) a2 = d * (a2 + a1);
+        if (lp >= 3) a1 = d * (a1 + a0);
+        if (lp >= 2) a0 = d * (a0 + 1.0);
+    }
     return sc;
 }
 
-int prep_group(const bb_group_desc& d, float alpha, HostGroup& g) {
+int prep_group(const bb_group_desc& d, const bb_policy& pol, HostGroup& g) {
     if (!d.seqs || !d.seq_lens || d.n_seqs == 0) return BB_E_INVALID;
     if (d.n_seqs == 1) return BB_E_ONE_QUERY;
     const uint32_t L = d.seq_lens[0], n = d.n_seqs;
@@ -104,8 +121,7 @@ int prep_group(const bb_group_desc& d, float alpha, HostGroup& g) {
     I.flank_k = d.flank_k >= 0 ? d.flank_k : edit_cut_off((int)(pre + suf));
     I.bar_k1 = (int32_t)((float)I.pattern_len * 0.4f);
     I.bar_k2 = (int32_t)I.pattern_len;
-    I.perfect_score = lodhi_all_match((int)(I.pad_hi - I.pad_lo));
-    (void)alpha;
+    I.perfect_score = lodhi_all_match(pol, (int)(I.pad_hi - I.pad_lo));
     return BB_OK;
 }
 
@@ -124,6 +140,8 @@ struct bb_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bb_params params{};
+    bb_policy policy{};          // include/barbell_amd_policy.h: the switchable assumptions about sassy / cigar-lodhi-rs
+    bool generic_barcode = false;  // the policy asks for what only the any-policy barcode kernel (k_barcode) computes
     std::vector<HostGroup> groups;
     std::vector<bb_group_dev> gdev;
     bb_group_dev* d_groups = nullptr;
@@ -174,7 +192,6 @@ struct bb_ctx {
     uint32_t reg_blocks_mult = 1;  // BARBELL_AMD_REG_BLOCKS: persistent blocks per resident slot (tuning knob)
     uint32_t reg_threads = 512;  // BARBELL_AMD_REG_THREADS: block size of k_barcode_reg (tuning knob)
     uint32_t pfx_threads = 0;    // BARBELL_AMD_PFX_THREADS: block size of k_barcode_pfx (0 = as many lanes as fit a CU)
-    bool scan_v1 = false;        // BARBELL_AMD_SCAN_V1=1: the first-generation scan kernel (per-lane 16-byte loads)
     bool force_generic = false;  // BARBELL_AMD_GENERIC=1: use the generic (any-geometry) kernels, for tests
     hipEvent_t ev[K_COUNT + 1]{};
     float ms[K_COUNT]{};
@@ -221,6 +238,7 @@ int upload_tables(bb_ctx* c) {
     c->gdev.resize(c->groups.size());
     uint32_t count_off = 0;
     const float alpha = c->params.alpha;
+    const bb_policy& pol = c->policy;
     for (size_t gi = 0; gi < c->groups.size(); ++gi) {
         const HostGroup& g = c->groups[gi];
         bb_group_dev& D = c->gdev[gi];
@@ -231,7 +249,11 @@ int upload_tables(bb_ctx* c) {
         D.bar_lo = (int)g.info.bar_lo; D.bar_hi = (int)g.info.bar_hi;
         D.m_bar = mb; D.WB = WB; D.n_seqs = N; D.k1 = g.info.bar_k1; D.k2 = g.info.bar_k2;
         D.rel_lo = (int)(g.info.bar_lo - g.info.pad_lo); D.rel_hi = (int)(g.info.bar_hi - g.info.pad_lo);
-        D.type = g.type; D.score0 = overhang_cost(alpha, m); D.count_off = (int)count_off; D.perfect = g.info.perfect_score;
+        D.type = g.type; D.score0 = overhang_cost(pol, alpha, m); D.count_off = (int)count_off; D.perfect = g.info.perfect_score;
+        D.pol_lm = pol.lm_rule; D.pol_rc_fwd = pol.rc_order == BB_RC_FWD_ORDER; D.pol_tie_last = pol.bar_tie == BB_TIE_LAST;
+        D.pol_prio = pol.trace_prio[0] | (pol.trace_prio[1] << 2) | (pol.trace_prio[2] << 4) | (pol.trace_prio[3] << 6);
+        D.pol_lodhi_exp = pol.lodhi_exp[0] | (pol.lodhi_exp[1] << 8) | (pol.lodhi_exp[2] << 16) | (pol.lodhi_exp[3] << 24);
+        D.pol_lodhi_p = pol.lodhi_p; D.pol_lambda = pol.lodhi_lambda;
         count_off += (uint32_t)N + 1;
         for (int s = 0; s < 2; ++s) {
             D.off_peq_flank[s] = blob.alloc((size_t)256 * S * 4);
@@ -252,7 +274,7 @@ int upload_tables(bb_ctx* c) {
         {
             int o_max = 0;
             for (int o = 1; o <= m; ++o)
-                if (overhang_cost(alpha, o) <= D.flank_k) o_max = o;
+                if (overhang_cost(pol, alpha, o) <= D.flank_k) o_max = o;
             D.ovh_steps = std::min(m, o_max + 1);
         }
         {
@@ -317,7 +339,7 @@ int upload_tables(bb_ctx* c) {
                     D.filt_rows = R; D.filt_off = u;
                     int o_max = 0;  // most rows that can hang over a read end within the budget (edit_model: floor(alpha * o))
                     for (int o = 1; o <= m; ++o)
-                        if (overhang_cost(alpha, o) <= k) o_max = o;
+                        if (overhang_cost(pol, alpha, o) <= k) o_max = o;
                     uint32_t mode = pick == 2 ? BB_FILT_WIDE : 0u;
                     if (u == 0) mode |= BB_FILT_TRUE_INIT;
                     if (!(u == 0 || u >= o_max)) mode |= BB_FILT_FWD_BEGIN_ALWAYS;
@@ -333,12 +355,12 @@ int upload_tables(bb_ctx* c) {
         {
             uint32_t* t = reinterpret_cast<uint32_t*>(blob.b.data() + D.off_pv0);
             for (int j = 1; j <= m; ++j)
-                if (overhang_cost(alpha, j) - overhang_cost(alpha, j - 1) == 1) t[(j - 1) >> 5] |= 1u << ((j - 1) & 31);
+                if (overhang_cost(pol, alpha, j) - overhang_cost(pol, alpha, j - 1) == 1) t[(j - 1) >> 5] |= 1u << ((j - 1) & 31);
         }
         D.off_ovh = blob.alloc((size_t)(m + 1) * 4);
         {
             int32_t* t = reinterpret_cast<int32_t*>(blob.b.data() + D.off_ovh);
-            for (int o = 0; o <= m; ++o) t[o] = overhang_cost(alpha, o);
+            for (int o = 0; o <= m; ++o) t[o] = overhang_cost(pol, alpha, o);
         }
         D.off_lut = blob.alloc(256);
         for (int ch = 0; ch < 256; ++ch) blob.b[D.off_lut + ch] = bb_text_code((uint8_t)ch);
@@ -356,7 +378,9 @@ int upload_tables(bb_ctx* c) {
         // forward patterns' trailing ones).  P leading rows + 32 rows per lane + T trailing rows = m_bar.
         for (int s = 0; s < 2; ++s) {
             D.split[s] = 0; D.pfx[s] = 0; D.tail[s] = 0;
-            if (!(WB == 2 && mb <= 48 && N >= 13 && N <= 768) || getenv("BARBELL_AMD_NO_PFX")) continue;
+            if (!(WB == 2 && mb <= 48 && N >= 13 && N <= 768) || getenv("BARBELL_AMD_NO_PFX") || c->generic_barcode) continue;
+            // windows wider than 48 columns run the 64-column instantiation in 512-lane blocks: a hit's N lanes must fit one
+            if (N > 512 && g.info.mask_len + (uint32_t)g.info.flank_k + 2 * BB_PADDING - 1 > 48) continue;
             int lcp = mb, lcs = mb;
             for (int p = 1; p < N; ++p) {
                 int j = 0;
@@ -465,7 +489,7 @@ int scan_u32(bb_ctx* c, const uint32_t* in, uint32_t* out, uint64_t n) {
 
 template <int W>
 void launch_scan(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n, uint32_t g, uint64_t flag_words) {
-    if (c->gdev[g].filt_rows > 0 && !c->scan_v1) {
+    if (c->gdev[g].filt_rows > 0) {
         (void)hipMemsetAsync(c->d_flags, 0, (size_t)2 * flag_words * sizeof(uint32_t), c->stream);  // the filter writes the words that hold a flag
         if (c->gdev[g].filt_mode & BB_FILT_WIDE)
             hipLaunchKernelGGL(k_flank_filter<true>, dim3((n + 255) / 256), dim3(256), 0, c->stream, d_bases, d_offsets, n, (const uint8_t*)c->d_tables,
@@ -480,16 +504,9 @@ void launch_scan(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets, u
                            (const uint32_t*)c->d_flags, flag_words, c->d_cnt, c->d_raw, c->cap_hits, c->d_hitcount, c->d_vqueue);
         return;
     }
-    if (!c->scan_v1 || W > 4) {
-        hipLaunchKernelGGL(k_flank_scan2<W>, dim3((n + 255) / 256, 2), dim3(256), 0, c->stream, d_bases, d_offsets, n,
-                           (const uint8_t*)c->d_tables, (const bb_group_dev*)c->d_groups, g, (uint32_t)c->groups.size(), c->d_cnt,
-                           c->d_raw, c->cap_hits, c->d_hitcount);
-        return;
-    }
-    if constexpr (W <= 4)  // the first-generation kernel exists for the tuned widths only
-        hipLaunchKernelGGL(k_flank_scan<W>, dim3((n + 255) / 256), dim3(256), 0, c->stream, d_bases, d_offsets, n,
-                           (const uint8_t*)c->d_tables, (const bb_group_dev*)c->d_groups, g, (uint32_t)c->groups.size(), c->d_cnt,
-                           c->d_raw, c->cap_hits, c->d_hitcount);
+    hipLaunchKernelGGL(k_flank_scan2<W>, dim3((n + 255) / 256, 2), dim3(256), 0, c->stream, d_bases, d_offsets, n,
+                       (const uint8_t*)c->d_tables, (const bb_group_dev*)c->d_groups, g, (uint32_t)c->groups.size(), c->d_cnt,
+                       c->d_raw, c->cap_hits, c->d_hitcount);
 }
 // Which variant of k_flank_trace a group takes (bb_kernels.h): 2 = 16-row band in LDS (k <= 6), 1 = every row in LDS,
 // 3 = checkpointed columns, 0 = private memory.
@@ -605,14 +622,14 @@ void launch_barcode(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets
     // widest barcode window the flank traceback can produce: (mask_len - 1 + flank_k) + 2*PADDING
     const uint32_t win_max = I.mask_len + (uint32_t)I.flank_k + 2 * BB_PADDING - 1;
     const size_t peq_bytes = (size_t)2 * 16 * N * WB * 4;
-    const bool reg_ok = !c->force_generic && D.m_bar <= 48 && N <= c->reg_threads && peq_bytes <= 48 * 1024 && win_max <= 64;
+    const bool reg_ok = !c->force_generic && !c->generic_barcode && D.m_bar <= 48 && N <= c->reg_threads && peq_bytes <= 48 * 1024 && win_max <= 64;
     for (uint32_t sw = 0; sw < 4; ++sw) {
         const uint32_t strand = sw & 1u, wide = sw >> 1;
         if (wide && win_max <= 48) continue;  // no such hits
         const uint32_t slot = 4 * g + sw;
         const uint32_t* list = c->d_lists + (size_t)slot * c->cap_hits;
         const uint32_t* cnt = c->d_listcnt + slot - g;  // the kernels index list_cnt with g
-        if (!c->force_generic && WB == 2 && D.split[strand] && win_max <= 64) {  // one word per barcode lane
+        if (!c->force_generic && !c->generic_barcode && WB == 2 && D.split[strand] && win_max <= 64) {  // one word per barcode lane
             if (pass == 1) {
                 if (!c->fast_path) continue;
                 list = c->d_fb_lists + (size_t)slot * c->cap_hits;
@@ -675,14 +692,31 @@ const char* bb_strerror(int code) {
 }
 
 int bb_create(const bb_group_desc* groups, uint32_t n_groups, const bb_params* params, bb_ctx** out) {
+    // BARBELL_AMD_POLICY: the text form of include/barbell_amd_policy.h, for callers that cannot pass a struct (the CLI)
+    bb_policy pol;
+    bb_policy_default(&pol);
+    if (const char* e = getenv("BARBELL_AMD_POLICY")) {
+        if (bb_policy_parse(e, &pol) != 0) { g_create_error = std::string("BARBELL_AMD_POLICY: cannot parse \"") + e + "\""; return BB_E_INVALID; }
+    }
+    return bb_create_policy(groups, n_groups, params, &pol, out);
+}
+
+int bb_create_policy(const bb_group_desc* groups, uint32_t n_groups, const bb_params* params, const bb_policy* policy, bb_ctx** out) {
     g_create_error.clear();
     if (!groups || !params || !out || n_groups == 0) return BB_E_INVALID;
     if (n_groups > BB_MAX_GROUPS) { g_create_error = "more than 8 query groups"; return BB_E_UNSUPPORTED; }
     if (!(params->alpha >= 0.0f)) return BB_E_INVALID;
+    if (policy && bb_policy_validate(policy) != 0) { g_create_error = "policy: field out of range"; return BB_E_INVALID; }
     bb_ctx* c = new bb_ctx();
     c->params = *params;
+    if (policy) c->policy = *policy; else bb_policy_default(&c->policy);
+    // The register-resident barcode kernels hard-wire the default traceback preference (two v_bitop3 truth tables) and
+    // Lodhi(3, 1/2) (exact power-of-two scaling); their local-minimum rule, tie rule and decay exponents are run-time.
+    // Anything else runs the any-policy kernel k_barcode.  The fast path's score bound counts one column per text op: an
+    // upper bound only while no text op's exponent is 0.
+    c->generic_barcode = !bb_policy_trace_is_default(&c->policy) || c->policy.lodhi_p != 3 || c->policy.lodhi_lambda != 0.5;
+    if (c->policy.lodhi_exp[BB_OP_MATCH] == 0 || c->policy.lodhi_exp[BB_OP_SUB] == 0 || c->policy.lodhi_exp[BB_OP_INS] == 0) c->fast_path = false;
     c->force_generic = getenv("BARBELL_AMD_GENERIC") && atoi(getenv("BARBELL_AMD_GENERIC")) != 0;
-    c->scan_v1 = getenv("BARBELL_AMD_SCAN_V1") && atoi(getenv("BARBELL_AMD_SCAN_V1")) != 0;
     if (getenv("BARBELL_AMD_SCAN_FILTER")) c->scan_filter = atoi(getenv("BARBELL_AMD_SCAN_FILTER")) != 0 ? 1 : 0;
     if (getenv("BARBELL_AMD_NO_FAST") && atoi(getenv("BARBELL_AMD_NO_FAST")) != 0) c->fast_path = false;
     if (getenv("BARBELL_AMD_FAST_MARGIN")) c->fast_margin = atof(getenv("BARBELL_AMD_FAST_MARGIN"));
@@ -690,7 +724,7 @@ int bb_create(const bb_group_desc* groups, uint32_t n_groups, const bb_params* p
     if (getenv("BARBELL_AMD_REG_THREADS")) { int t = atoi(getenv("BARBELL_AMD_REG_THREADS")); if (t >= 64 && t <= 512) c->reg_threads = (uint32_t)t; }
     c->groups.resize(n_groups);
     for (uint32_t i = 0; i < n_groups; ++i) {
-        int r = prep_group(groups[i], params->alpha, c->groups[i]);
+        int r = prep_group(groups[i], c->policy, c->groups[i]);
         if (r != BB_OK) { delete c; return r; }
         const bb_group_info& I = c->groups[i].info;
         // geometry the kernels were not built for (the reference has no such limits, barcodes.rs:105-197): the table in
@@ -741,6 +775,11 @@ void bb_destroy(bb_ctx* c) {
 }
 
 
+int bb_get_policy(const bb_ctx* c, bb_policy* out) {
+    if (!c || !out) return BB_E_INVALID;
+    *out = c->policy;
+    return BB_OK;
+}
 int bb_n_groups(const bb_ctx* c) { return c ? (int)c->groups.size() : BB_E_INVALID; }
 int bb_group_get_info(const bb_ctx* c, uint32_t g, bb_group_info* info) {
     if (!c || g >= c->groups.size() || !info) return BB_E_INVALID;
@@ -775,7 +814,7 @@ int bb_annotate_batch_dev(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_o
     {
         bool any_filt = false;
         for (uint32_t g = 0; g < G; ++g) any_filt = any_filt || c->gdev[g].filt_rows > 0;
-        if (any_filt && !c->scan_v1) {  // the flag words of a read sit at (offset >> 9) + 3 * read: the batch's byte span sizes the array
+        if (any_filt) {  // the flag words of a read sit at (offset >> 9) + 3 * read: the batch's byte span sizes the array
             uint64_t ends[2] = {0, 0};
             HIPCHK(c, hipMemcpyAsync(&ends[0], d_offsets, 8, hipMemcpyDeviceToHost, c->stream));
             HIPCHK(c, hipMemcpyAsync(&ends[1], d_offsets + n, 8, hipMemcpyDeviceToHost, c->stream));

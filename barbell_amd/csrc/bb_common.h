@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #include "../../include/barbell_amd.h"
+#include "../../include/barbell_amd_policy.h"
 
 #if defined(__HIPCC__)
 #define BB_HD __host__ __device__ __forceinline__
@@ -85,8 +86,18 @@ struct bb_group_dev {
     int32_t filt_off;            // first flank row of the filter's window (rows filt_off .. filt_off + filt_rows - 1)
     int32_t filt_mode;           // BB_FILT_* bits
     int32_t ovh_steps;           // overhang positions worth visiting after the last column: min(m, 1 + max{o : floor(alpha*o) <= k})
+    // The context's policy (include/barbell_amd_policy.h), the same in every group; wave-uniform scalars in the kernels.
+    int32_t pol_lm;              // [H1] BB_LM_*
+    int32_t pol_rc_fwd;          // [H2] 1: rc matches of a read in ascending forward position
+    int32_t pol_prio;            // [H3] traceback preference, 2 bits per rank (first choice in bits 0-1); BB_PRIO_DEFAULT = M, I, S, D
+    int32_t pol_tie_last;        // [H7] 1: the last of several equally cheap local minima of a barcode pattern
+    int32_t pol_lodhi_exp;       // [H8] decay exponents, one byte per op (M, S, I, D); 0x01010101 by default
+    int32_t pol_lodhi_p;         // [H8] subsequence length (the register-resident kernels: 3 only)
     int32_t _pad2;
+    double pol_lambda;           // [H8] (the register-resident kernels: 0.5 only)
 };
+#define BB_PRIO_DEFAULT (BB_OP_MATCH | (BB_OP_INS << 2) | (BB_OP_SUB << 4) | (BB_OP_DEL << 6))
+#define BB_LODHI_EXP_DEFAULT 0x01010101
 // Which fixed intervals k_flank_verify scans besides the flagged ones (o_max = most rows that can hang over a read end at
 // a cost <= k; u, R = the window; see upload_tables):
 #define BB_FILT_TRUE_INIT 1u         /* u == 0: the forward block is rows 1..R of the scan's own matrix, overhang column included */

@@ -4,7 +4,7 @@
 //   flank scan     sassy's search of the N-masked flank over the whole read, both strands (searcher.rs:438): either
 //                  k_flank_filter (15 or 31 rows of the flank, both strands in one pass over the text, flags per 16 bytes)
 //                  + k_flank_verify (the full-height scan around flagged columns only), or k_flank_scan2 (the full-height
-//                  scan of every column, one lane per (read, strand)); k_flank_scan is the first-generation kernel.
+//                  scan of every column, one lane per (read, strand)).
 //                  Local-minimum ends <= k are the raw flank hits.
 //   scan           exclusive scan of per-(read,group,strand) hit counts -> deterministic slots.
 //   k_flank_trace  one lane per flank hit: (m+k)-column DP with move bits, traceback,
@@ -153,6 +153,29 @@ __device__ __forceinline__ void move_bits(const uint32_t (&eq)[W], const uint32_
     }
 }
 
+// The same planes for any preference order (policy [H3]): prio holds the four ops, first choice in bits 0-1; an op is
+// applicable at a cell iff  Match: d0 & eq,  Sub: ~d0 (diagonal is g-1),  Ins: ph (left is g-1),  Del: pvn, the NEW
+// column's vertical +1 delta (above is g-1).  Used by the kernels that honour every policy (k_flank_trace, k_barcode);
+// the default order takes the two-instruction form above.
+template <int W>
+__device__ __forceinline__ void move_bits_prio(uint32_t prio, const uint32_t (&eq)[W], const uint32_t (&d0)[W], const uint32_t (&ph)[W],
+                                               const uint32_t (&pvn)[W], uint32_t (&lo)[W], uint32_t (&hi)[W]) {
+    if (prio == (uint32_t)BB_PRIO_DEFAULT) { move_bits<W>(eq, d0, ph, lo, hi); return; }  // wave-uniform
+#pragma unroll
+    for (int w = 0; w < W; ++w) {
+        const uint32_t vM = d0[w] & eq[w], vS = ~d0[w], vI = ph[w], vD = pvn[w];
+        uint32_t taken = 0u, sS = 0u, sI = 0u, sD = 0u;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t op = (prio >> (2 * q)) & 3u;
+            const uint32_t v = (op == BB_OP_MATCH ? vM : op == BB_OP_SUB ? vS : op == BB_OP_INS ? vI : vD) & ~taken;
+            taken |= v;
+            sS |= op == BB_OP_SUB ? v : 0u; sI |= op == BB_OP_INS ? v : 0u; sD |= op == BB_OP_DEL ? v : 0u;
+        }
+        lo[w] = sS | sD; hi[w] = sI | sD;
+    }
+}
+
 template <int W>
 __device__ __forceinline__ uint32_t get_bit(const uint32_t (&v)[W], int bit) {
     uint32_t word = v[0];
@@ -183,13 +206,14 @@ __device__ __forceinline__ void load_eq(const uint32_t* tab, uint32_t c, uint32_
     }
 }
 
-// streaming local-minimum rule (oracle [H1]); evaluated lazily: only steps that touch the
-// <= k zone matter, and entering the zone from above is a strict decrease, so `dec` is always
-// fresh when it is read.
+// streaming local-minimum rule (policy [H1], include/barbell_amd_policy.h); evaluated lazily: only steps that touch the
+// <= k zone matter, and entering the zone from above is a strict decrease, so `dec` and `cand` (the position of the
+// last strict decrease: the left end of the plateau in progress) are always fresh when they are read.
 struct lm_lane {
     int32_t prev;
     uint32_t dec;
     uint32_t nrep;
+    uint32_t cand;
 };
 
 __device__ __forceinline__ void emit_hit(bb_hit_raw* hits, uint32_t cap, uint32_t* count, uint32_t read, uint32_t e,
@@ -202,113 +226,13 @@ __device__ __forceinline__ void emit_hit(bb_hit_raw* hits, uint32_t cap, uint32_
     }
 }
 
-#define BB_LM_STEP(ST, CUR, IDX, STRAND)                                                        \
-    do {                                                                                        \
-        int32_t cur_ = (CUR);                                                                   \
-        if (min(cur_, ST.prev) <= kk) {                                                         \
-            if (cur_ > ST.prev) {                                                               \
-                if (ST.dec && ST.prev <= kk)                                                    \
-                    emit_hit(hits, hit_cap, hit_count, read, (IDX)-1, ST.prev, g, STRAND, ST.nrep++); \
-                ST.dec = 0;                                                                     \
-            } else if (cur_ < ST.prev) {                                                        \
-                ST.dec = 1;                                                                     \
-            }                                                                                   \
-        }                                                                                       \
-        ST.prev = cur_;                                                                         \
-    } while (0)
-
-// ------------------------------------------------------------------------------------------------
-// k_flank_scan: grid = ceil(n_reads/256) blocks of 256 lanes, one read per lane, one launch per group.
-// ------------------------------------------------------------------------------------------------
-template <int W>
-__global__ __launch_bounds__(256) void k_flank_scan(const uint8_t* __restrict__ bases, const uint64_t* __restrict__ offsets,
-                                                    uint32_t n_reads, const uint8_t* __restrict__ tables,
-                                                    const bb_group_dev* __restrict__ groups, uint32_t g, uint32_t n_groups,
-                                                    uint32_t* __restrict__ cnt, bb_hit_raw* __restrict__ hits,
-                                                    uint32_t hit_cap, uint32_t* __restrict__ hit_count) {
-    constexpr int S = (W <= 2 ? 2 : (W <= 4 ? 4 : 8));
-    __shared__ __attribute__((aligned(16))) uint32_t s_peq[2][256 * S];
-    const bb_group_dev G = groups[g];
-    {
-        const uint32_t* src0 = reinterpret_cast<const uint32_t*>(tables + G.off_peq_flank[0]);
-        const uint32_t* src1 = reinterpret_cast<const uint32_t*>(tables + G.off_peq_flank[1]);
-        for (int i = threadIdx.x; i < 256 * S; i += 256) { s_peq[0][i] = src0[i]; s_peq[1][i] = src1[i]; }
-    }
-    __syncthreads();
-    const uint32_t read = blockIdx.x * 256u + threadIdx.x;
-    if (read >= n_reads) return;
-    const uint64_t off = offsets[read];
-    const uint32_t n = (uint32_t)(offsets[read + 1] - off);
-    const uint8_t* rb = bases + off;
-    const int32_t kk = G.flank_k;
-    const int m = G.m;
-    const int TW = (m - 1) >> 5, TB = (m - 1) & 31;
-    const uint32_t* pv0 = reinterpret_cast<const uint32_t*>(tables + G.off_pv0);
-    const int32_t* ovh = reinterpret_cast<const int32_t*>(tables + G.off_ovh);
-
-    uint32_t fpv[W], fmv[W], rpv[W], rmv[W];
-#pragma unroll
-    for (int w = 0; w < W; ++w) { fpv[w] = rpv[w] = pv0[w]; fmv[w] = rmv[w] = 0; }
-    int32_t fs = G.score0, rs = G.score0;
-    lm_lane fl = {G.score0, 1u, 0u}, rl = {G.score0, 1u, 0u};
-
-    auto step2 = [&](uint32_t cf, uint32_t cr, uint32_t idx) {
-        uint32_t eq[W], d0[W], ph[W], mh[W];
-        load_eq<W, S>(s_peq[0], cf, eq);
-        myers_step<W>(fpv, fmv, eq, d0, ph, mh);
-        fs += (int32_t)((ph[TW] >> TB) & 1u) - (int32_t)((mh[TW] >> TB) & 1u);
-        BB_LM_STEP(fl, fs, idx, 0u);
-        load_eq<W, S>(s_peq[1], cr, eq);
-        myers_step<W>(rpv, rmv, eq, d0, ph, mh);
-        rs += (int32_t)((ph[TW] >> TB) & 1u) - (int32_t)((mh[TW] >> TB) & 1u);
-        BB_LM_STEP(rl, rs, idx, 1u);
-    };
-
-    const uint32_t nblk = n >> 4;
-    for (uint32_t b = 0; b < nblk; ++b) {
-        uint32_t f[4], r[4];
-        __builtin_memcpy(f, rb + 16u * b, 16);
-        __builtin_memcpy(r, rb + (n - 16u * (b + 1)), 16);
-#pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            uint32_t cf = (f[s >> 2] >> (8 * (s & 3))) & 0xFFu;
-            uint32_t cr = (r[(15 - s) >> 2] >> (8 * ((15 - s) & 3))) & 0xFFu;
-            step2(cf, cr, 16u * b + (uint32_t)s + 1u);
-        }
-    }
-    for (uint32_t t = 16u * nblk; t < n; ++t) step2(rb[t], rb[n - 1 - t], t + 1u);
-
-    // right overhang (oracle [H4]): C[n+o] = D[m-o][n] + floor(alpha*o), o = 1..m
-    {
-        int32_t fd = fs, rd = rs;
-        for (int o = 1; o <= m; ++o) {
-            fd -= (int32_t)((fpv[TW] >> TB) & 1u) - (int32_t)((fmv[TW] >> TB) & 1u);
-            rd -= (int32_t)((rpv[TW] >> TB) & 1u) - (int32_t)((rmv[TW] >> TB) & 1u);
-#pragma unroll
-            for (int w = W - 1; w >= 0; --w) {
-                fpv[w] = (fpv[w] << 1) | (w ? (fpv[w - 1] >> 31) : 0u);
-                fmv[w] = (fmv[w] << 1) | (w ? (fmv[w - 1] >> 31) : 0u);
-                rpv[w] = (rpv[w] << 1) | (w ? (rpv[w - 1] >> 31) : 0u);
-                rmv[w] = (rmv[w] << 1) | (w ? (rmv[w - 1] >> 31) : 0u);
-            }
-            int32_t oc = ovh[o];
-            BB_LM_STEP(fl, fd + oc, n + (uint32_t)o, 0u);
-            BB_LM_STEP(rl, rd + oc, n + (uint32_t)o, 1u);
-        }
-        if (fl.dec && fl.prev <= kk) emit_hit(hits, hit_cap, hit_count, read, n + (uint32_t)m, fl.prev, g, 0u, fl.nrep++);
-        if (rl.dec && rl.prev <= kk) emit_hit(hits, hit_cap, hit_count, read, n + (uint32_t)m, rl.prev, g, 1u, rl.nrep++);
-    }
-    cnt[((uint64_t)read * n_groups + g) * 2 + 0] = fl.nrep;
-    cnt[((uint64_t)read * n_groups + g) * 2 + 1] = rl.nrep;
-}
-
 // ------------------------------------------------------------------------------------------------
 // k_flank_scan2: the production scan.  One lane = one (read, strand); grid.y = strand, so a block
 // needs one strand's Peq table.  Reads are streamed from HBM in whole, 128-byte-aligned lines:
 // each lane's next line is copied global->LDS with eight 16-byte LDS-DMA loads
 // (global_load_lds_dwordx4: per-lane source address, wave-linear LDS destination, no VGPR staging),
 // then consumed 16 bytes at a time with conflict-free ds_read_b128.  Every line of the batch is
-// therefore requested from HBM exactly once per strand (k_flank_scan's per-lane 16-byte loads
+// therefore requested from HBM exactly once per strand (round 1's first scan kernel, with per-lane 16-byte loads,
 // re-fetched each line ~7x: profiles/r01_v1_pmc.txt).  The partial first/last line of a read is
 // walked with byte loads.  The reverse-complement strand walks lines and bytes downwards.
 // ------------------------------------------------------------------------------------------------
@@ -319,13 +243,14 @@ struct hit_buf {
     uint32_t e0, e1, e2, e3;
     uint32_t costs;  // 4 x 8 bit
 };
+// lm_left / lm_strict: wave-uniform flags of the policy's rule (BB_LM_PLATEAU_LEFT / BB_LM_STRICT), in scope at every use
 #define BB_LM_STEP_BUF(ST, CUR, IDX)                                                            \
     do {                                                                                        \
         int32_t cur_ = (CUR);                                                                   \
         if (min(cur_, ST.prev) <= kk) {                                                         \
             if (cur_ > ST.prev) {                                                               \
                 if (ST.dec && ST.prev <= kk) {                                                  \
-                    const uint32_t e_ = (IDX)-1u, k_ = ST.nrep;                                 \
+                    const uint32_t e_ = lm_left ? ST.cand : (IDX)-1u, k_ = ST.nrep;             \
                     if (k_ < 4u) {                                                              \
                         hb.e0 = k_ == 0u ? e_ : hb.e0; hb.e1 = k_ == 1u ? e_ : hb.e1;           \
                         hb.e2 = k_ == 2u ? e_ : hb.e2; hb.e3 = k_ == 3u ? e_ : hb.e3;           \
@@ -337,7 +262,9 @@ struct hit_buf {
                 }                                                                               \
                 ST.dec = 0;                                                                     \
             } else if (cur_ < ST.prev) {                                                        \
-                ST.dec = 1;                                                                     \
+                ST.dec = 1; ST.cand = (IDX);                                                    \
+            } else if (lm_strict) {                                                             \
+                ST.dec = 0;                                                                     \
             }                                                                                   \
         }                                                                                       \
         ST.prev = cur_;                                                                         \
@@ -364,10 +291,11 @@ template <int W, int STRAND>
 __device__ __forceinline__ void scan_finish(bool live, uint32_t n, int m, int32_t kk, int32_t sc, uint32_t (&pv)[W], uint32_t (&mv)[W],
                                             uint32_t idx, lm_lane& st, hit_buf& hb, const int32_t* __restrict__ ovh, uint32_t read,
                                             uint32_t g, uint32_t n_groups, uint32_t* __restrict__ cnt, bb_hit_raw* __restrict__ hits,
-                                            uint32_t hit_cap, uint32_t* __restrict__ hit_count, bool at_end = true, int ovh_steps = 0x7FFFFFFF,
+                                            uint32_t hit_cap, uint32_t* __restrict__ hit_count, int pol_lm, bool at_end = true, int ovh_steps = 0x7FFFFFFF,
                                             bb_hit_raw* stage = nullptr, uint32_t* stage_fill = nullptr) {
     const uint32_t lane = threadIdx.x & 63u;
     const int TB = (m - 1) & 31;
+    const bool lm_left = pol_lm == BB_LM_PLATEAU_LEFT, lm_strict = pol_lm == BB_LM_STRICT;
     // right overhang (oracle [H4]): C[n+o] = D[m-o][n] + floor(alpha*o), o = 1..m
     if (live) {
         int32_t d = sc;
@@ -384,7 +312,7 @@ __device__ __forceinline__ void scan_finish(bool live, uint32_t n, int m, int32_
             BB_LM_STEP_BUF(st, d + ovh[o], idx);
         }
         if (at_end && st.dec && st.prev <= kk) {
-            const uint32_t e_ = n + (uint32_t)m, k_ = st.nrep;
+            const uint32_t e_ = lm_left ? st.cand : n + (uint32_t)m, k_ = st.nrep;
             if (k_ < 4u) {
                 hb.e0 = k_ == 0u ? e_ : hb.e0; hb.e1 = k_ == 1u ? e_ : hb.e1;
                 hb.e2 = k_ == 2u ? e_ : hb.e2; hb.e3 = k_ == 3u ? e_ : hb.e3;
@@ -450,7 +378,7 @@ __device__ __forceinline__ void scan_finish(bool live, uint32_t n, int m, int32_
 template <int W, int STRAND>
 __device__ __forceinline__ void flank_scan_lane(const uint8_t* __restrict__ bases, const uint64_t* __restrict__ offsets,
                                                 uint32_t n_reads, const uint8_t* __restrict__ tables, int32_t kk, int m, int32_t score0,
-                                                uint32_t off_pv0, uint32_t off_ovh, int ovh_steps,
+                                                uint32_t off_pv0, uint32_t off_ovh, int ovh_steps, int pol_lm,
                                                 uint32_t g, uint32_t n_groups, uint32_t* __restrict__ cnt,
                                                 bb_hit_raw* __restrict__ hits, uint32_t hit_cap, uint32_t* __restrict__ hit_count,
                                                 const uint32_t* s_peq, uint4* s_line /* this wave's [BB_SCAN_LQ][64] */) {
@@ -469,9 +397,10 @@ __device__ __forceinline__ void flank_scan_lane(const uint8_t* __restrict__ base
 #pragma unroll
     for (int w = 0; w < W; ++w) { pv[w] = pv0[w]; mv[w] = 0; }
     int32_t sc = score0;
-    lm_lane st = {score0, 1u, 0u};
+    lm_lane st = {score0, 1u, 0u, 0u};
     hit_buf hb = {0u, 0u, 0u, 0u, 0u};
     uint32_t idx = 0;  // scan position (characters consumed)
+    const bool lm_left = pol_lm == BB_LM_PLATEAU_LEFT, lm_strict = pol_lm == BB_LM_STRICT;
 
     auto step = [&](uint32_t ch) {
         uint32_t eq[W], d0[W], ph[W], mh[W];
@@ -615,7 +544,7 @@ __device__ __forceinline__ void flank_scan_lane(const uint8_t* __restrict__ base
     for (uint32_t t = 0; t < tail; ++t) step(STRAND == 0 ? rb[head + (nlines << LSH) + t] : rb[tail - 1 - t]);
 #endif
 
-    scan_finish<W, STRAND>(live, n, m, kk, sc, pv, mv, idx, st, hb, ovh, read, g, n_groups, cnt, hits, hit_cap, hit_count, true, ovh_steps);
+    scan_finish<W, STRAND>(live, n, m, kk, sc, pv, mv, idx, st, hb, ovh, read, g, n_groups, cnt, hits, hit_cap, hit_count, pol_lm, true, ovh_steps);
 }
 
 template <int W>
@@ -639,9 +568,9 @@ __global__ __launch_bounds__(256) void k_flank_scan2(const uint8_t* __restrict__
     const int m = G->m;
     const uint32_t o_pv0 = G->off_pv0, o_ovh = G->off_ovh;
     if (strand == 0)
-        flank_scan_lane<W, 0>(bases, offsets, n_reads, tables, kk, m, score0, o_pv0, o_ovh, G->ovh_steps, g, n_groups, cnt, hits, hit_cap, hit_count, s_peq, line);
+        flank_scan_lane<W, 0>(bases, offsets, n_reads, tables, kk, m, score0, o_pv0, o_ovh, G->ovh_steps, G->pol_lm, g, n_groups, cnt, hits, hit_cap, hit_count, s_peq, line);
     else
-        flank_scan_lane<W, 1>(bases, offsets, n_reads, tables, kk, m, score0, o_pv0, o_ovh, G->ovh_steps, g, n_groups, cnt, hits, hit_cap, hit_count, s_peq, line);
+        flank_scan_lane<W, 1>(bases, offsets, n_reads, tables, kk, m, score0, o_pv0, o_ovh, G->ovh_steps, G->pol_lm, g, n_groups, cnt, hits, hit_cap, hit_count, s_peq, line);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -863,7 +792,8 @@ __device__ __forceinline__ void flank_verify_lane(const uint8_t* __restrict__ ba
     const uint32_t* pv0 = reinterpret_cast<const uint32_t*>(tables + G->off_pv0);
     const int32_t* ovh = reinterpret_cast<const int32_t*>(tables + G->off_ovh);
     const uint32_t fmode = (uint32_t)G->filt_mode;
-    const int ovh_steps = G->ovh_steps;
+    const int ovh_steps = G->ovh_steps, pol_lm = G->pol_lm;
+    const bool lm_left = pol_lm == BB_LM_PLATEAU_LEFT, lm_strict = pol_lm == BB_LM_STRICT;
 
     // ---- the item in hand
     enum : uint32_t { FREE = 0u, WORK = 1u, FIN = 2u, EXHAUSTED = 3u };
@@ -882,7 +812,7 @@ __device__ __forceinline__ void flank_verify_lane(const uint8_t* __restrict__ ba
 #pragma unroll
     for (int w = 0; w < W; ++w) { pv[w] = 0u; mv[w] = 0u; }
     int32_t sc = score0;
-    lm_lane st = {score0, 1u, 0u};
+    lm_lane st = {score0, 1u, 0u, 0u};
     hit_buf hb = {0u, 0u, 0u, 0u, 0u};
     uint32_t idx = 0;  // columns consumed = scan position of the next byte
     auto step = [&](uint32_t ch) {
@@ -979,7 +909,7 @@ __device__ __forceinline__ void flank_verify_lane(const uint8_t* __restrict__ ba
 #pragma unroll
                         for (int w = 0; w < W; ++w) { pv[w] = pv0[w]; mv[w] = 0u; }
                         sc = score0;
-                        st.prev = score0; st.dec = 1u; st.nrep = 0u;
+                        st.prev = score0; st.dec = 1u; st.nrep = 0u; st.cand = 0u;
                         hb.e0 = hb.e1 = hb.e2 = hb.e3 = hb.costs = 0u;
                         state = n ? WORK : FIN;
                     } else state = EXHAUSTED;
@@ -1032,7 +962,7 @@ __device__ __forceinline__ void flank_verify_lane(const uint8_t* __restrict__ ba
         // none of them can be <= k); count; flush of the buffered hits (wave-wide prefix sums: every lane takes part)
         if (__any(state == FIN)) {
             const bool fin = state == FIN;
-            scan_finish<W, STRAND>(fin, n, m, kk, sc, pv, mv, idx, st, hb, ovh, read, g, n_groups, cnt, hits, hit_cap, hit_count, idx == n, ovh_steps,
+            scan_finish<W, STRAND>(fin, n, m, kk, sc, pv, mv, idx, st, hb, ovh, read, g, n_groups, cnt, hits, hit_cap, hit_count, pol_lm, idx == n, ovh_steps,
                                    stage, &stage_fill);
             if (fin) state = FREE;
         }
@@ -1147,6 +1077,7 @@ __device__ __forceinline__ uint32_t flank_trace_lane(const uint8_t* __restrict__
     const int32_t n = (int32_t)(offsets[h.read_idx + 1] - off);
     const uint8_t* rb = bases + off;
     const int m = G.m, k = G.flank_k, bar_lo = G.bar_lo, bar_hi = G.bar_hi;
+    const uint32_t prio = (uint32_t)__builtin_amdgcn_readfirstlane(groups[0].pol_prio);  // the context's policy: the same in every group
     const uint32_t* peq = reinterpret_cast<const uint32_t*>(tables + G.off_peq_flank[h.strand]);
     const uint32_t* pv0 = reinterpret_cast<const uint32_t*>(tables + G.off_pv0);
     const int32_t* ovh = reinterpret_cast<const int32_t*>(tables + G.off_ovh);
@@ -1232,7 +1163,7 @@ __device__ __forceinline__ uint32_t flank_trace_lane(const uint8_t* __restrict__
                 uint32_t eq[W], d0[W], ph[W], mh[W], l[W], hh[W];
                 load_eq<W, S>(peq, ch, eq);
                 myers_step<W>(pv, mv, eq, d0, ph, mh);
-                move_bits<W>(eq, d0, ph, l, hh);
+                move_bits_prio<W>(prio, eq, d0, ph, pv, l, hh);
                 if constexpr (MODE == 2) put_band(c, l, hh);
                 else if constexpr (MODE == 3) { if ((c & (BB_TRACE_CKB - 1)) == 0) ck_store(c / BB_TRACE_CKB); }
                 else {
@@ -1284,7 +1215,7 @@ __device__ __forceinline__ uint32_t flank_trace_lane(const uint8_t* __restrict__
                         uint32_t eq[W], d0[W], ph[W], mh[W], l[W], hh[W];
                         load_eq<W, S>(peq, ch, eq);
                         myers_step<W>(pv, mv, eq, d0, ph, mh);
-                        move_bits<W>(eq, d0, ph, l, hh);
+                        move_bits_prio<W>(prio, eq, d0, ph, pv, l, hh);
 #pragma unroll
                         for (int x = 0; x < W; ++x) { win[((b * 2 + 0) * W + x) * 64 + threadIdx.x] = l[x]; win[((b * 2 + 1) * W + x) * 64 + threadIdx.x] = hh[x]; }
                     }
@@ -1323,7 +1254,10 @@ __device__ __forceinline__ uint32_t flank_trace_lane(const uint8_t* __restrict__
     out.ws = (uint32_t)ws; out.we = (uint32_t)we;
     out._pad[0] = out._pad[1] = out._pad[2] = 0;
     out.read_len = (uint32_t)n;
-    const uint32_t slot = slot_base[((uint64_t)h.read_idx * n_groups + h.group) * 2 + h.strand] + h.ordinal;
+    // order of a read's matches: group, forward matches, rc matches — the rc ones as the rc scan found them or, policy
+    // [H2], in ascending forward position (the scan runs over the reversed text: the reverse of its order)
+    const uint64_t sb = ((uint64_t)h.read_idx * n_groups + h.group) * 2 + h.strand;
+    const uint32_t slot = (h.strand && groups[0].pol_rc_fwd) ? slot_base[sb + 1] - 1u - h.ordinal : slot_base[sb] + h.ordinal;
     {
         const uint32_t* src = reinterpret_cast<const uint32_t*>(&out);
 #pragma unroll
@@ -1460,6 +1394,9 @@ __global__ __launch_bounds__(1024) void k_barcode(const uint8_t* __restrict__ ba
     }
     __syncthreads();
 
+    // the context's policy (include/barbell_amd_policy.h): this kernel honours all of it
+    const uint32_t prio = (uint32_t)G.pol_prio;
+    const bool lm_left = G.pol_lm == BB_LM_PLATEAU_LEFT, lm_strict = G.pol_lm == BB_LM_STRICT, tie_last = G.pol_tie_last != 0;
     // ---- forward pass with move bits ----
     uint32_t lo[BB_MAX_WIN + 1][WB], hi[BB_MAX_WIN + 1][WB];
     int32_t best_cost = 0x7FFFFFFF, best_pos = -1;
@@ -1470,7 +1407,7 @@ __global__ __launch_bounds__(1024) void k_barcode(const uint8_t* __restrict__ ba
 #pragma unroll
         for (int x = 0; x < WB; ++x) { int bits = m - 32 * x; pv[x] = bits >= 32 ? 0xFFFFFFFFu : (bits > 0 ? ((1u << bits) - 1u) : 0u); mv[x] = 0; }
         const int TW = (m - 1) >> 5, TB = (m - 1) & 31;
-        int32_t score = m, prev = m;
+        int32_t score = m, prev = m, lmc = 0;
         uint32_t dec = 1;
         for (int32_t c = 1; c <= wn; ++c) {
             const uint32_t code = s_win[hl * BB_MAX_WIN + c - 1];
@@ -1479,18 +1416,19 @@ __global__ __launch_bounds__(1024) void k_barcode(const uint8_t* __restrict__ ba
 #pragma unroll
             for (int x = 0; x < WB; ++x) eq[x] = e[x];
             myers_step<WB>(pv, mv, eq, d0, ph, mh);
-            move_bits<WB>(eq, d0, ph, l, hh);
+            move_bits_prio<WB>(prio, eq, d0, ph, pv, l, hh);
 #pragma unroll
             for (int x = 0; x < WB; ++x) { lo[c][x] = l[x]; hi[c][x] = hh[x]; }
             score += (int32_t)((ph[TW] >> TB) & 1u) - (int32_t)((mh[TW] >> TB) & 1u);
-            // local minima (every position is <= k2 = m): first strictly-lowest (searcher.rs:294-300)
+            // local minima (every position is <= k2 = m; policy [H1]): first strictly-lowest (searcher.rs:294-300; policy [H7])
             if (score > prev) {
-                if (dec && prev < best_cost) { best_cost = prev; best_pos = c - 1; }
+                if (dec && (prev < best_cost || (tie_last && prev == best_cost))) { best_cost = prev; best_pos = lm_left ? lmc : c - 1; }
                 dec = 0;
-            } else if (score < prev) dec = 1;
+            } else if (score < prev) { dec = 1; lmc = c; }
+            else if (lm_strict) dec = 0;
             prev = score;
         }
-        if (dec && prev < best_cost) { best_cost = prev; best_pos = wn; }
+        if (dec && (prev < best_cost || (tie_last && prev == best_cost))) { best_cost = prev; best_pos = lm_left ? lmc : wn; }
         if (best_pos >= 0 && best_cost <= G.k1) atomicAdd(&s_int[hl * 4 + 0], 1);
         if (best_pos >= 0 && best_cost <= G.k2) atomicAdd(&s_int[hl * 4 + 2], 1);
     }
@@ -1522,14 +1460,33 @@ __global__ __launch_bounds__(1024) void k_barcode(const uint8_t* __restrict__ ba
                 if (op != 2u) --j;
                 if (op != 3u) --i;
             }
-            // forward walk: Lodhi (oracle [H8]) + map_pat_to_text_with_cost (cigar_parse.rs:6-68)
-            double a1 = 0.0, a2 = 0.0, sc = 0.0;
+            // forward walk: Lodhi (policy [H8]: subsequence length p, lambda, decay exponent per op — the checker's sequence of
+            // f64 operations, no contraction) + map_pat_to_text_with_cost (cigar_parse.rs:6-68)
+            const int lp = G.pol_lodhi_p;
+            double dk[4];
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                double d = 1.0;
+                const int ex = (G.pol_lodhi_exp >> (8 * o)) & 0xFF;
+                for (int e = 0; e < ex; ++e) d = e == 0 ? G.pol_lambda : d * G.pol_lambda;
+                dk[o] = d;
+            }
+            double a0 = 0.0, a1 = 0.0, a2 = 0.0, sc = 0.0;   // A[0], A[1], A[2] of the checker
             int32_t pj = 0, ti = i;
             bool any = false;
             for (int t = nops - 1; t >= 0; --t) {
                 const uint32_t op = ops[t];
-                if (op == 0u) { sc = sc + 0.5 * a2; a2 = 0.5 * (a2 + a1); a1 = 0.5 * (a1 + 1.0); }
-                else { a2 = 0.5 * a2; a1 = 0.5 * a1; }
+                const double d = op == 0u ? dk[0] : op == 1u ? dk[1] : op == 2u ? dk[2] : dk[3];
+                if (op == 0u) {
+                    sc = sc + d * (lp >= 4 ? a2 : lp == 3 ? a1 : lp == 2 ? a0 : 1.0);
+                    if (lp >= 4) a2 = d * (a2 + a1);
+                    if (lp >= 3) a1 = d * (a1 + a0);
+                    if (lp >= 2) a0 = d * (a0 + 1.0);
+                } else {
+                    if (lp >= 4) a2 = d * a2;
+                    if (lp >= 3) a1 = d * a1;
+                    if (lp >= 2) a0 = d * a0;
+                }
                 if (pj >= G.rel_lo && pj < G.rel_hi) {
                     if (!any) { any = true; pat_lo = pj; txt_lo = ti; }
                     pat_hi = pj + 1; txt_hi = ti + 1; bcost += op != 0u;
@@ -1722,9 +1679,11 @@ __device__ __forceinline__ void pick_and_emit(bool active, bool cand, int32_t be
 // (plo/phi bit c-1: 00 Match, 01 Sub, 10 Ins); delrow = pattern rows consumed by Del; the time t of a column's op
 // counts the Dels before it.  Per column the work is three bit extractions from masks prepared once, the
 // Del-run length after the column's row, and — on Match columns — three f64 operations.
-template <int CW>
+// GEN (policy [H8] with decay exponents other than 1 per op; expk = one byte per op M, S, I, D): the time t advances by
+// the column's exponent, a Match weighs 2^-(t + eM) — lambda stays 1/2, so every product is still exact.
+template <int CW, bool GEN = false>
 __device__ __forceinline__ double lodhi_replay(unsigned long long plo, unsigned long long phi, unsigned long long delrow,
-                                               int32_t tstart, int32_t best_pos, int wmax) {
+                                               int32_t tstart, int32_t best_pos, int wmax, uint32_t expk = BB_LODHI_EXP_DEFAULT) {
     const unsigned long long onmask = low64(best_pos) & ~low64(tstart);  // bit c-1: column c carries an op
     const unsigned long long mmask = onmask & ~(plo | phi);                 // Match columns
     const unsigned long long amask = onmask & ~(phi & ~plo);                // the op consumes a pattern row (not Ins)
@@ -1735,8 +1694,11 @@ __device__ __forceinline__ double lodhi_replay(unsigned long long plo, unsigned 
     const unsigned long long kept = ~delrow;
     double sc = 0.0, b1 = 0.0, b2 = 0.0;
     int32_t pj = onmask ? __builtin_ctzll(kept) : 0;  // leading Dels
+    const uint32_t eM = expk & 0xFFu, eD = expk >> 24;
+    const uint32_t lo_w[2] = {(uint32_t)plo, (uint32_t)(plo >> 32)}, hi_w[2] = {(uint32_t)phi, (uint32_t)(phi >> 32)};
     // high dword of 2^t, advanced with t; 2^-(t+1) has (1022 - t) << 20 = 0x7FD00000 - (t << 20) there
-    uint32_t e_hi = (uint32_t)(1023 + pj) << 20;
+    uint32_t e_hi = (uint32_t)(1023 + (GEN ? pj * (int32_t)eD : pj)) << 20;
+    const uint32_t w_base = GEN ? 0x7FE00000u - (eM << 20) : 0x7FD00000u;
 #ifdef BB_REPLAY_FULL_UNROLL
 #pragma clang loop unroll(full)
 #else
@@ -1749,7 +1711,7 @@ __device__ __forceinline__ double lodhi_replay(unsigned long long plo, unsigned 
                 const int k = c - 1;
                 const uint32_t onb = (on_w[k >> 5] >> (k & 31)) & 1u, ab = (a_w[k >> 5] >> (k & 31)) & 1u;
                 if ((m_w[k >> 5] >> (k & 31)) & 1u) {
-                    const double w = __hiloint2double((int)(0x7FD00000u - e_hi), 0);  // 2^-(t+1)
+                    const double w = __hiloint2double((int)(w_base - e_hi), 0);  // 2^-(t+1) (GEN: 2^-(t+eM))
                     const double pw = __hiloint2double((int)e_hi, 0);                               // 2^t
                     sc = __fma_rn(w, b2, sc); b2 = b2 + b1; b1 = b1 + pw;
                 }
@@ -1758,7 +1720,10 @@ __device__ __forceinline__ double lodhi_replay(unsigned long long plo, unsigned 
                 // where pj rests on a kept row (or on the sentinel at m)
                 const int32_t nd = __builtin_ctzll(kept >> pj);
                 pj += nd;
-                e_hi += (onb + (uint32_t)nd) << 20;
+                if constexpr (GEN) {
+                    const uint32_t code = ((lo_w[k >> 5] >> (k & 31)) & 1u) | (((hi_w[k >> 5] >> (k & 31)) & 1u) << 1);  // 0 Match, 1 Sub, 2 Ins
+                    e_hi += ((onb ? (expk >> (8u * code)) & 0xFFu : 0u) + (uint32_t)nd * eD) << 20;
+                } else e_hi += (onb + (uint32_t)nd) << 20;
             }
         }
     }
@@ -1836,6 +1801,34 @@ __device__ __forceinline__ float lodhi_bound_tab(unsigned long long plo, unsigne
         }
     }
     return sc * (1.0f + 1.0f / 16384.0f);
+}
+
+// Policy [H1] / [H7] on the column masks of a lane's bottom row (P / M bit q: the cost rises / falls going from end
+// position q to q+1, positions 0..wn, cost m at position 0): the reported positions bit-parallel, then the first
+// strictly-lowest of them (searcher.rs:294-300) or the last lowest, then — plateaus at their left end — the position
+// after the last change below it.
+__device__ __forceinline__ void pick_minimum(unsigned long long P, unsigned long long M, int wn, int m, bool active, int pol_lm, bool tie_last,
+                                             int32_t& best_cost, int32_t& best_pos) {
+#ifdef BB_POLICY_STATIC_DEFAULT  // measurement aid: the default policy as compile-time constants
+    pol_lm = BB_LM_PLATEAU_RIGHT; tie_last = false;
+#endif
+    // dec(q) = "last strict change before position q was a decrease" (initially true):
+    // dec(q+1) = M[q] | (~(P|M)[q] & dec(q))  ==  carry chain of (M | ~P) + M + 1;  strict minima only: dec(q+1) = M[q]
+    const unsigned long long A = M | ~P;
+    const unsigned long long D = pol_lm == BB_LM_STRICT ? (M << 1) | 1ull : (A + M + 1ull) ^ A ^ M;   // bit q = dec(q)
+    unsigned long long R = (P & D) | (D & (1ull << wn));    // reported positions (plateau right ends, or the window end)
+    if (!active) R = 0ull;
+    while (R) {  // 1-4 iterations
+        const int q = ctz64(R);
+        R &= R - 1ull;
+        const unsigned long long lowq = (1ull << q) - 1ull;
+        const int32_t cq = m + __popcll(P & lowq) - __popcll(M & lowq);
+        if (cq < best_cost || (tie_last && cq == best_cost)) { best_cost = cq; best_pos = q; }
+    }
+    if (pol_lm == BB_LM_PLATEAU_LEFT && best_pos > 0) {
+        const unsigned long long ch = (P | M) & ((1ull << best_pos) - 1ull);
+        best_pos = ch ? 64 - clz64(ch) : 0;
+    }
 }
 
 template <int WB, int CW>
@@ -1966,19 +1959,7 @@ __global__ __launch_bounds__(512) void k_barcode_reg(const uint8_t* __restrict__
         const unsigned long long wmask = wn >= 64 ? ~0ull : ((1ull << wn) - 1ull);
         const unsigned long long P = (((unsigned long long)up[1] << 32) | up[0]) & wmask;
         const unsigned long long M = (((unsigned long long)dn[1] << 32) | dn[0]) & wmask;
-        // dec(q) = "last strict change before position q was a decrease" (initially true):
-        // dec(q+1) = M[q] | (~(P|M)[q] & dec(q))  ==  carry chain of (M | ~P) + M + 1
-        const unsigned long long A = M | ~P;
-        const unsigned long long D = (A + M + 1ull) ^ A ^ M;      // bit q = dec(q)
-        unsigned long long R = (P & D) | (D & (1ull << wn));    // reported positions (plateau right ends, or the window end)
-        if (!active) R = 0ull;
-        while (R) {  // first strictly-lowest reported position (searcher.rs:294-300); 1-4 iterations
-            const int q = ctz64(R);
-            R &= R - 1ull;
-            const unsigned long long lowq = (1ull << q) - 1ull;
-            const int32_t cq = m + __popcll(P & lowq) - __popcll(M & lowq);
-            if (cq < best_cost) { best_cost = cq; best_pos = q; }
-        }
+        pick_minimum(P, M, wn, m, active, G.pol_lm, G.pol_tie_last != 0, best_cost, best_pos);
         if (active && best_pos >= 0 && best_cost <= G.k1) atomicAdd(&s_cnt1[hl], 1);
     }
     // Every lane with a local minimum traces and scores (a wave executes those instructions for all
@@ -2046,10 +2027,13 @@ __global__ __launch_bounds__(512) void k_barcode_reg(const uint8_t* __restrict__
     // ---- forward replay: Lodhi only.  Scaled recurrence (see header): b1 = 2^t a1, b2 = 2^t a2 change
     // only at match columns; score += 2^-(t+1) * b2 (exact scaling, same rounding as the oracle's add).
     double s_norm = -1.0;
-    if (cand) {
-        const double sc = lodhi_replay<CW>(plo, phi, delrow, tstart, best_pos, wmax);
-        s_norm = G.perfect > 0.0 ? sc / G.perfect : 0.0;
-    } else (void)lodhi_replay<CW>(0ull, 0ull, 0ull, 0, 0, wmax);  // the loop is wave-uniform: idle lanes walk it with empty masks
+    {
+        const bool on = cand;  // the loop is wave-uniform: idle lanes walk it with empty masks
+        const double sc = (uint32_t)G.pol_lodhi_exp == (uint32_t)BB_LODHI_EXP_DEFAULT
+                              ? lodhi_replay<CW>(on ? plo : 0ull, on ? phi : 0ull, on ? delrow : 0ull, on ? tstart : 0, on ? best_pos : 0, wmax)
+                              : lodhi_replay<CW, true>(on ? plo : 0ull, on ? phi : 0ull, on ? delrow : 0ull, on ? tstart : 0, on ? best_pos : 0, wmax, (uint32_t)G.pol_lodhi_exp);
+        if (cand) s_norm = G.perfect > 0.0 ? sc / G.perfect : 0.0;
+    }
     // ---- pass decision (searcher.rs:303-328), then per-hit argmax (first maximum) and runner-up:
     // searcher.rs:377,390-396 ----
     pick_and_emit(active, cand, best_cost, s_norm, p, hl, H, hit_idx, G, plo, phi, diagrow, tstart, best_pos, s_cnt1, s_max, s_sec, s_top,
@@ -2418,17 +2402,7 @@ __global__ __launch_bounds__(CW <= 48 ? 768 : 512) void k_barcode_pfx(const uint
                 Pm = Ph & wmask; Mm = Mh & wmask;
             }
         }
-        const unsigned long long A = Mm | ~Pm;
-        const unsigned long long D = (A + Mm + 1ull) ^ A ^ Mm;
-        unsigned long long R = (Pm & D) | (D & (1ull << wn));
-        if (!active) R = 0ull;
-        while (R) {
-            const int q = ctz64(R);
-            R &= R - 1ull;
-            const unsigned long long lowq = (1ull << q) - 1ull;
-            const int32_t cq = m + __popcll(Pm & lowq) - __popcll(Mm & lowq);
-            if (cq < best_cost) { best_cost = cq; best_pos = q; }
-        }
+        pick_minimum(Pm, Mm, wn, m, active, G.pol_lm, G.pol_tie_last != 0, best_cost, best_pos);
         if constexpr (!FAST) { if (active && best_pos >= 0 && best_cost <= G.k1) atomicAdd(&s_cnt1[hl], 1); }
     }
     bool cand = active && best_pos >= 0 && best_cost <= G.k2;
@@ -2616,10 +2590,13 @@ __global__ __launch_bounds__(CW <= 48 ? 768 : 512) void k_barcode_pfx(const uint
         build_cols(half ^ 1u);
         build_walks(half ^ 1u);
         double s_norm = -1.0;
-        if (cand) {
-            const double sc = lodhi_replay<CW>(plo, phi, delrow, tstart, best_pos, wmax);
-            s_norm = G.perfect > 0.0 ? sc / G.perfect : 0.0;
-        } else (void)lodhi_replay<CW>(0ull, 0ull, 0ull, 0, 0, wmax);  // the loop is wave-uniform: idle lanes walk it with empty masks
+        {
+            const bool on = cand;  // the loop is wave-uniform: idle lanes walk it with empty masks
+            const double sc = (uint32_t)G.pol_lodhi_exp == (uint32_t)BB_LODHI_EXP_DEFAULT
+                                  ? lodhi_replay<CW>(on ? plo : 0ull, on ? phi : 0ull, on ? delrow : 0ull, on ? tstart : 0, on ? best_pos : 0, wmax)
+                                  : lodhi_replay<CW, true>(on ? plo : 0ull, on ? phi : 0ull, on ? delrow : 0ull, on ? tstart : 0, on ? best_pos : 0, wmax, (uint32_t)G.pol_lodhi_exp);
+            if (cand) s_norm = G.perfect > 0.0 ? sc / G.perfect : 0.0;
+        }
         pick_and_emit(active, cand, best_cost, s_norm, p, hl, H, hit_idx, G, plo, phi, diagrow, tstart, best_pos, s_cnt1, s_max, s_sec, s_top,
                       min_score, min_score_diff, rows);
         BB_PFX_SYNC();
@@ -2653,7 +2630,10 @@ __global__ __launch_bounds__(256) void k_rows(const bb_group_dev* __restrict__ g
     const bb_group_dev& G = groups[mine ? grp : 0u];
     const int m = G.m_bar;
     const unsigned long long delrow = mine ? (low64(m) & ~W.diagrow) : 0ull;
-    const double sc = lodhi_replay<64>(mine ? W.plo : 0ull, mine ? W.phi : 0ull, delrow, mine ? (int32_t)W.tstart : 0, mine ? (int32_t)W.best_pos : 0, wmax);
+    const uint32_t expk = (uint32_t)groups[0].pol_lodhi_exp;  // the context's policy: the same in every group
+    const double sc = expk == (uint32_t)BB_LODHI_EXP_DEFAULT
+                          ? lodhi_replay<64>(mine ? W.plo : 0ull, mine ? W.phi : 0ull, delrow, mine ? (int32_t)W.tstart : 0, mine ? (int32_t)W.best_pos : 0, wmax)
+                          : lodhi_replay<64, true>(mine ? W.plo : 0ull, mine ? W.phi : 0ull, delrow, mine ? (int32_t)W.tstart : 0, mine ? (int32_t)W.best_pos : 0, wmax, expk);
     if (!mine) return;
     const double s_norm = G.perfect > 0.0 ? sc / G.perfect : 0.0;
     const bool clear = W.ub_second < 0.0 || (s_norm - W.ub_second) >= min_score_diff + margin;

@@ -51,9 +51,28 @@ def main():
                     help="torch.distributed backend for N>1 (nccl = RCCL over xGMI; gloo only for single-GPU dry runs)")
     ap.add_argument("--device-mod", type=int, default=0,
                     help="dry-run aid: map LOCAL_RANK onto LOCAL_RANK %% device-mod GPUs (0 = one GPU per rank)")
+    ap.add_argument("--print-histogram", action="store_true", help="carry the all-reduced per-barcode histogram in the JSON line")
+    ap.add_argument("--first-read", type=int, default=0,
+                    help="index of rank 0's first read in the synthetic stream (tests: a one-rank run of another rank's shard)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # started as plain `python bench.py --gpus N`: become N ranks (one process per GPU) instead of silently running one
+        import socket
+        import subprocess
+
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd, env=env))
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != max(1, args.gpus):
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                 f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...)")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
@@ -68,6 +87,7 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group("gloo")
+        assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
 
     from barbell_amd import annotate as A
     from tests.common import config_groups
@@ -81,7 +101,7 @@ def main():
     n_batches = max(1, args.reads // batch)
     n_res = n_batches * batch
     L = args.read_len
-    first_read = rank * n_res  # contiguous shard of the read stream per rank
+    first_read = args.first_read + rank * n_res  # contiguous shard of the read stream per rank
 
     # ---- synthetic reads generated straight into HBM (fixed length -> offsets are i*L) ----
     d_off = torch.arange(0, n_res + 1, dtype=torch.int64, device=dev) * L
@@ -154,6 +174,8 @@ def main():
             "compute": compute_section(args, kavg, cells_flank, batch, L),
             "histogram_total": int(hist.sum().item()),
         }
+        if args.print_histogram:
+            out["histogram"] = [int(x) for x in hist.cpu().tolist()]
         if args.config == "nbd96":
             out["filter_step"], d_v = filter_leg(dm, d_rows, int(rows_per_launch), dev)
             out["trim_step"] = trim_leg(dm, d_rows, d_v, int(rows_per_launch), d_bases.data_ptr() + ((args.steps - 1) % n_batches) * batch * L,

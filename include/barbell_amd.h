@@ -24,6 +24,8 @@
 #include <stdint.h>
 #include <stddef.h>
 
+#include "barbell_amd_policy.h"
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -116,6 +118,11 @@ typedef struct bb_ctx bb_ctx;        /* opaque; one per host thread / GPU stream
 /* Replaces Demuxer::new + add_query_group + BarcodeGroup::new.  Returns BB_OK or an error code. */
 int bb_create(const bb_group_desc* groups, uint32_t n_groups, const bb_params* params, bb_ctx** out);
 void bb_destroy(bb_ctx* ctx);
+/* The same under an explicit policy (barbell_amd_policy.h: what sassy 0.2.1 / cigar-lodhi-rs 0.1.0 are ASSUMED to do where
+ * Barbell's own code does not pin it; searcher.rs:209-211,282-301,364-396,438).  NULL = the default.  bb_create takes
+ * the policy from the environment variable BARBELL_AMD_POLICY (text form) when it is set, the default otherwise.      */
+int bb_create_policy(const bb_group_desc* groups, uint32_t n_groups, const bb_params* params, const bb_policy* policy, bb_ctx** out);
+int bb_get_policy(const bb_ctx* ctx, bb_policy* out);
 
 int bb_n_groups(const bb_ctx* ctx);
 int bb_group_get_info(const bb_ctx* ctx, uint32_t group, bb_group_info* info);

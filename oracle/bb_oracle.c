@@ -38,6 +38,21 @@
 static int g_full_trace = 0;
 void bbo_set_full_trace(int on) { g_full_trace = on; }
 
+/* The switchable assumptions (include/barbell_amd_policy.h).  g_pol serves the stand-alone entry points (bbo_search,
+ * bbo_lodhi) and is the policy of contexts made by bbo_create; bbo_create_policy carries its own. */
+static bb_policy g_pol;
+static int g_pol_set = 0;
+static const bb_policy* cur_pol(void) {
+    if (!g_pol_set) { bb_policy_default(&g_pol); g_pol_set = 1; }
+    return &g_pol;
+}
+int bbo_set_policy(const bb_policy* p) {
+    if (!p) { bb_policy_default(&g_pol); g_pol_set = 1; return BB_OK; }
+    if (bb_policy_validate(p)) return BB_E_INVALID;
+    g_pol = *p; g_pol_set = 1;
+    return BB_OK;
+}
+
 /* ------------------------------------------------------------------------------------------ */
 /* [H6] IUPAC profile.  4-bit base sets A=1 C=2 G=4 T=8; case-insensitive; X = empty set;      */
 /* anything that is not an IUPAC letter is invalid (0xFF) for queries (barcodes.rs:45-47) and  */
@@ -81,8 +96,16 @@ static uint8_t rc_char(uint8_t c) {
     return c;
 }
 
-/* [H4] overhang cost of `len` pattern characters outside the text: floor(alpha * len) in f32 */
-static inline int overhang_cost(float alpha, int len) { return (int)floorf((float)len * alpha); }
+/* [H4] overhang cost of `len` pattern characters outside the text: round(alpha * len), rounding mode and width of
+ * the product by policy (default: floor, f32) */
+static inline int overhang_cost(const bb_policy* P, float alpha, int len) {
+    if (P->ovh_round & BB_OVH_F64) {
+        const double v = (double)len * (double)alpha;
+        switch (P->ovh_round & 3) { case BB_OVH_CEIL: return (int)ceil(v); case BB_OVH_NEAR: return (int)nearbyint(v); default: return (int)floor(v); }
+    }
+    const float v = (float)len * alpha;
+    switch (P->ovh_round & 3) { case BB_OVH_CEIL: return (int)ceilf(v); case BB_OVH_NEAR: return (int)nearbyintf(v); default: return (int)floorf(v); }
+}
 
 /* ------------------------------------------------------------------------------------------ */
 /* DP primitives                                                                               */
@@ -115,20 +138,24 @@ static void end_push(end_list* l, int e, int cost) {
  * `decreasing` and its cost <= k (so a plateau is reported at its right end); at the end of the
  * sequence the last position is reported under the same condition.  `decreasing` starts true.
  * This streaming form is what the scan kernels implement.
+ * Policy [H1]: BB_LM_PLATEAU_LEFT reports the same minima at the LEFT end of their plateau (the position of the last
+ * strict decrease, `cand`); BB_LM_STRICT lets a plateau clear `decreasing`, so only strict minima are reported.
  */
-typedef struct { int decreasing; int32_t prev; int started; } lm_state;
+typedef struct { int decreasing; int32_t prev; int started; int cand; int rule; } lm_state;
 static inline void lm_step(lm_state* s, int idx, int32_t cur, int k, end_list* out) {
-    if (!s->started) { s->started = 1; s->decreasing = 1; s->prev = cur; return; }
+    if (!s->started) { s->started = 1; s->decreasing = 1; s->prev = cur; s->cand = idx; return; }
     if (cur > s->prev) {
-        if (s->decreasing && s->prev <= k) end_push(out, idx - 1, s->prev);
+        if (s->decreasing && s->prev <= k) end_push(out, s->rule == BB_LM_PLATEAU_LEFT ? s->cand : idx - 1, s->prev);
         s->decreasing = 0;
     } else if (cur < s->prev) {
-        s->decreasing = 1;
+        s->decreasing = 1; s->cand = idx;
+    } else if (s->rule == BB_LM_STRICT) {
+        s->decreasing = 0;
     }
     s->prev = cur;
 }
 static inline void lm_finish(lm_state* s, int last_idx, int k, end_list* out) {
-    if (s->started && s->decreasing && s->prev <= k) end_push(out, last_idx, s->prev);
+    if (s->started && s->decreasing && s->prev <= k) end_push(out, s->rule == BB_LM_PLATEAU_LEFT ? s->cand : last_idx, s->prev);
 }
 
 /*
@@ -137,11 +164,11 @@ static inline void lm_finish(lm_state* s, int last_idx, int k, end_list* out) {
  *   left : D[j][0] = floor(alpha*j)           (pattern prefix of length j before the text)
  *   right: C[n+o] = D[m-o][n] + floor(alpha*o), o = 1..m (pattern suffix of length o after it)
  */
-static void scan_strand(const uint8_t* pcode, int m, const uint8_t* tcode, int n, int k, float alpha,
+static void scan_strand(const bb_policy* P, const uint8_t* pcode, int m, const uint8_t* tcode, int n, int k, float alpha,
                         end_list* out) {
     int32_t* col = (int32_t*)malloc(sizeof(int32_t) * (size_t)(m + 1));
-    for (int j = 0; j <= m; ++j) col[j] = alpha >= 0.f ? overhang_cost(alpha, j) : j;
-    lm_state st = {0, 0, 0};
+    for (int j = 0; j <= m; ++j) col[j] = alpha >= 0.f ? overhang_cost(P, alpha, j) : j;
+    lm_state st = {0, 0, 0, 0, P->lm_rule};
     lm_step(&st, 0, col[m], k, out);
     for (int i = 1; i <= n; ++i) {
         dp_column(pcode, m, tcode[i - 1], col);
@@ -149,7 +176,7 @@ static void scan_strand(const uint8_t* pcode, int m, const uint8_t* tcode, int n
     }
     int last = n;
     if (alpha >= 0.f) {
-        for (int o = 1; o <= m; ++o) lm_step(&st, n + o, col[m - o] + overhang_cost(alpha, o), k, out);
+        for (int o = 1; o <= m; ++o) lm_step(&st, n + o, col[m - o] + overhang_cost(P, alpha, o), k, out);
         last = n + m;
     }
     lm_finish(&st, last, k, out);
@@ -169,11 +196,11 @@ static void scan_strand(const uint8_t* pcode, int m, const uint8_t* tcode, int n
  * every cell the walk can visit (tests/test_oracle_props.py checks it against the full matrix).
  * `e` is the scan end index (0..n, or n+o for a right overhang of o characters).
  */
-static void trace_match(const uint8_t* pcode, int m, const uint8_t* tcode, int n, int k, float alpha,
+static void trace_match(const bb_policy* P, const uint8_t* pcode, int m, const uint8_t* tcode, int n, int k, float alpha,
                         int e, int cost, bbo_match* out) {
     int o = e > n ? e - n : 0;
     int j0 = m - o, i0 = e > n ? n : e;
-    int g = cost - (o ? overhang_cost(alpha, o) : 0);
+    int g = cost - (o ? overhang_cost(P, alpha, o) : 0);
     int s0 = i0 - (m + k);
     if (s0 < 0 || g_full_trace) s0 = 0;
     int w = i0 - s0;
@@ -181,7 +208,7 @@ static void trace_match(const uint8_t* pcode, int m, const uint8_t* tcode, int n
     int32_t* D = (int32_t*)malloc(sizeof(int32_t) * (size_t)(m + 1) * stride);
     int32_t* col = (int32_t*)malloc(sizeof(int32_t) * (size_t)(m + 1));
     for (int j = 0; j <= m; ++j) {
-        col[j] = (s0 == 0 && alpha >= 0.f) ? overhang_cost(alpha, j) : j;
+        col[j] = (s0 == 0 && alpha >= 0.f) ? overhang_cost(P, alpha, j) : j;
         D[(size_t)j * stride] = col[j];
     }
     for (int c = 1; c <= w; ++c) {
@@ -194,11 +221,16 @@ static void trace_match(const uint8_t* pcode, int m, const uint8_t* tcode, int n
     int nops = 0, j = j0, i = w;
     while (j > 0) {
         if (i == 0 && s0 == 0 && alpha >= 0.f) break; /* left overhang: rest of pattern is outside */
-        if (i > 0 && DD(j - 1, i - 1) == g && (pcode[j - 1] & tcode[s0 + i - 1])) { rev[nops++] = BBO_MATCH; --j; --i; continue; }
-        if (i > 0 && DD(j, i - 1) == g - 1) { rev[nops++] = BBO_INS; --i; --g; continue; }
-        if (i > 0 && DD(j - 1, i - 1) == g - 1) { rev[nops++] = BBO_SUB; --j; --i; --g; continue; }
-        if (DD(j - 1, i) == g - 1) { rev[nops++] = BBO_DEL; --j; --g; continue; }
-        fprintf(stderr, "bb_oracle: trace failed at (%d,%d)\n", j, i); abort();
+        int took = 0;
+        for (int q = 0; q < 4 && !took; ++q) {  /* policy [H3]: the first applicable op in order of preference */
+            switch (P->trace_prio[q]) {
+                case BBO_MATCH: if (i > 0 && DD(j - 1, i - 1) == g && (pcode[j - 1] & tcode[s0 + i - 1])) { rev[nops++] = BBO_MATCH; --j; --i; took = 1; } break;
+                case BBO_INS:   if (i > 0 && DD(j, i - 1) == g - 1) { rev[nops++] = BBO_INS; --i; --g; took = 1; } break;
+                case BBO_SUB:   if (i > 0 && DD(j - 1, i - 1) == g - 1) { rev[nops++] = BBO_SUB; --j; --i; --g; took = 1; } break;
+                default:        if (DD(j - 1, i) == g - 1) { rev[nops++] = BBO_DEL; --j; --g; took = 1; } break;
+            }
+        }
+        if (!took) { fprintf(stderr, "bb_oracle: trace failed at (%d,%d)\n", j, i); abort(); }
     }
 #undef DD
     out->pattern_start = j; out->pattern_end = j0;
@@ -217,17 +249,17 @@ static void trace_match(const uint8_t* pcode, int m, const uint8_t* tcode, int n
  * [H5] rc: complement(pattern) (same index order) is searched in reversed(text); text_start/end are
  * mirrored back to forward coordinates, ops stay in pattern order.
  */
-int bbo_search(const uint8_t* pat, int m, const uint8_t* text, int n, int k, float alpha, int rc, bbo_match** out) {
+static int search_pol(const bb_policy* P, const uint8_t* pat, int m, const uint8_t* text, int n, int k, float alpha, int rc, bbo_match** out) {
     uint8_t* pc = (uint8_t*)malloc((size_t)(m ? m : 1));
     uint8_t* tc = (uint8_t*)malloc((size_t)(n ? n : 1));
     for (int j = 0; j < m; ++j) pc[j] = text_code(pat[j]);
     for (int i = 0; i < n; ++i) tc[i] = text_code(text[i]);
     end_list ends = {0, 0, 0};
-    scan_strand(pc, m, tc, n, k, alpha, &ends);
+    scan_strand(P, pc, m, tc, n, k, alpha, &ends);
     int nf = ends.n, total = nf;
     bbo_match* ms = (bbo_match*)calloc((size_t)(nf ? nf : 1), sizeof(bbo_match));
     for (int t = 0; t < nf; ++t) {
-        trace_match(pc, m, tc, n, k, alpha, ends.v[t].e, ends.v[t].cost, &ms[t]);
+        trace_match(P, pc, m, tc, n, k, alpha, ends.v[t].e, ends.v[t].cost, &ms[t]);
         ms[t].strand = BB_FWD; ms[t].pattern_idx = 0; ms[t].rc_text_len = n;
     }
     if (rc) {
@@ -236,13 +268,14 @@ int bbo_search(const uint8_t* pat, int m, const uint8_t* text, int n, int k, flo
         for (int j = 0; j < m; ++j) pcc[j] = comp_code(pc[j]);
         for (int i = 0; i < n; ++i) trv[i] = tc[n - 1 - i];
         end_list re = {0, 0, 0};
-        scan_strand(pcc, m, trv, n, k, alpha, &re);
+        scan_strand(P, pcc, m, trv, n, k, alpha, &re);
         total = nf + re.n;
         ms = (bbo_match*)realloc(ms, sizeof(bbo_match) * (size_t)(total ? total : 1));
         for (int t = 0; t < re.n; ++t) {
-            bbo_match* mm = &ms[nf + t];
+            /* policy [H2]: the rc matches as the rc scan finds them, or in ascending forward position */
+            bbo_match* mm = &ms[nf + (P->rc_order == BB_RC_FWD_ORDER ? re.n - 1 - t : t)];
             memset(mm, 0, sizeof(*mm));
-            trace_match(pcc, m, trv, n, k, alpha, re.v[t].e, re.v[t].cost, mm);
+            trace_match(P, pcc, m, trv, n, k, alpha, re.v[t].e, re.v[t].cost, mm);
             int ts = mm->text_start, te = mm->text_end;
             mm->text_start = n - te; mm->text_end = n - ts;
             mm->strand = BB_RC; mm->pattern_idx = 0; mm->rc_text_len = n;
@@ -252,6 +285,9 @@ int bbo_search(const uint8_t* pat, int m, const uint8_t* text, int n, int k, flo
     free(ends.v); free(pc); free(tc);
     *out = ms;
     return total;
+}
+int bbo_search(const uint8_t* pat, int m, const uint8_t* text, int n, int k, float alpha, int rc, bbo_match** out) {
+    return search_pol(cur_pol(), pat, m, text, n, k, alpha, rc, out);
 }
 void bbo_free_matches(bbo_match* ms, int n) {
     if (!ms) return;
@@ -325,22 +361,32 @@ int bbo_get_matching_region(const bbo_match* m, int start, int end, int* lo, int
  *        score += lambda*A2 ; A2 = lambda*(A2 + A1) ; A1 = lambda*(A1 + 1)     (match column)
  *                             A2 = lambda*A2        ; A1 = lambda*A1           (other column)
  * The HIP kernel runs the identical sequence of f64 operations (no FMA contraction).
+ * Policy [H8] generalises the three things the crate may do differently: the subsequence length p (A[q] = weighted count
+ * of matched (q+1)-subsequences ending at or before the column), lambda, and the decay exponent of a column per op
+ * (d = lambda^exp[op]; exp = 1,1,1,1 is the formula above, 2,2,1,1 weighs a triple by lambda^(span in the pattern +
+ * span in the text)).  The default (p = 3, lambda = 0.5, exponents 1) performs exactly the operations written above.
  */
-double bbo_lodhi(const uint8_t* ops, int n_ops) {
-    const double lambda = 0.5;
-    double a1 = 0.0, a2 = 0.0, score = 0.0;
+static double lodhi_pol(const bb_policy* P, const uint8_t* ops, int n_ops) {
+    const int p = P->lodhi_p;
+    double dk[4], A[4] = {0.0, 0.0, 0.0, 0.0}, score = 0.0;
+    for (int o = 0; o < 4; ++o) {  /* lambda^exp by repeated multiplication (exp 1: lambda itself, exp 0: 1.0) */
+        double d = 1.0;
+        for (int e = 0; e < P->lodhi_exp[o]; ++e) d = e == 0 ? P->lodhi_lambda : d * P->lodhi_lambda;
+        dk[o] = d;
+    }
     for (int c = 0; c < n_ops; ++c) {
+        const double d = dk[ops[c] & 3];
         if (ops[c] == BBO_MATCH) {
-            score = score + lambda * a2;
-            a2 = lambda * (a2 + a1);
-            a1 = lambda * (a1 + 1.0);
+            score = score + d * (p >= 2 ? A[p - 2] : 1.0);
+            for (int q = p - 2; q >= 1; --q) A[q] = d * (A[q] + A[q - 1]);
+            if (p >= 2) A[0] = d * (A[0] + 1.0);
         } else {
-            a2 = lambda * a2;
-            a1 = lambda * a1;
+            for (int q = p - 2; q >= 0; --q) A[q] = d * A[q];
         }
     }
     return score;
 }
+double bbo_lodhi(const uint8_t* ops, int n_ops) { return lodhi_pol(cur_pol(), ops, n_ops); }
 
 /* edit_model.rs:2-11 */
 int bbo_edit_cut_off(int l) {
@@ -423,9 +469,9 @@ typedef struct {
     uint8_t type; int32_t flank_k, k1, k2; double perfect;
 } ogroup;
 
-struct bbo_ctx { uint32_t n_groups; ogroup* g; bb_params p; };
+struct bbo_ctx { uint32_t n_groups; ogroup* g; bb_params p; bb_policy pol; };
 
-static int prep_group(const bb_group_desc* d, ogroup* g) {
+static int prep_group(const bb_policy* P, const bb_group_desc* d, ogroup* g) {
     memset(g, 0, sizeof(*g));
     if (!d->seqs || !d->seq_lens || d->n_seqs == 0) return BB_E_INVALID;
     if (d->n_seqs == 1) return BB_E_ONE_QUERY;                     /* barcodes.rs:113-117 */
@@ -476,19 +522,24 @@ static int prep_group(const bb_group_desc* d, ogroup* g) {
     /* searcher.rs:229-239: all-Match CIGAR of length pad_hi - pad_lo (pad_hi NOT clamped) */
     uint32_t lbar = g->pad_hi - g->pad_lo;
     uint8_t* perfect = (uint8_t*)calloc(lbar, 1);
-    g->perfect = bbo_lodhi(perfect, (int)lbar);
+    g->perfect = lodhi_pol(P, perfect, (int)lbar);
     free(perfect);
     return BB_OK;
 }
 static void free_group(ogroup* g) { free(g->flank); free(g->pat_fwd); free(g->pat_rc); }
 
 int bbo_create(const bb_group_desc* groups, uint32_t n_groups, const bb_params* params, bbo_ctx** out) {
+    return bbo_create_policy(groups, n_groups, params, cur_pol(), out);
+}
+int bbo_create_policy(const bb_group_desc* groups, uint32_t n_groups, const bb_params* params, const bb_policy* policy, bbo_ctx** out) {
     if (!groups || !params || !out || n_groups == 0) return BB_E_INVALID;
+    if (policy && bb_policy_validate(policy)) return BB_E_INVALID;
     bbo_ctx* c = (bbo_ctx*)calloc(1, sizeof(*c));
     c->g = (ogroup*)calloc(n_groups, sizeof(ogroup));
     c->n_groups = n_groups; c->p = *params;
+    if (policy) c->pol = *policy; else bb_policy_default(&c->pol);
     for (uint32_t i = 0; i < n_groups; ++i) {
-        int rcode = prep_group(&groups[i], &c->g[i]);
+        int rcode = prep_group(&c->pol, &groups[i], &c->g[i]);
         if (rcode != BB_OK) { for (uint32_t k = 0; k <= i; ++k) free_group(&c->g[k]); free(c->g); free(c); return rcode; }
     }
     *out = c;
@@ -526,14 +577,14 @@ int bbo_group_get_pattern(const bbo_ctx* c, uint32_t gi, uint32_t idx, int rc, u
 /* the first strictly-lowest-cost one per pattern (searcher.rs:294-300).                        */
 /* returns 1 and fills `best` if the pattern has a match <= k                                   */
 /* ------------------------------------------------------------------------------------------ */
-static int best_match_for_pattern(const uint8_t* pcode, int m, const uint8_t* wcode, int wn, int k, bbo_match* best) {
+static int best_match_for_pattern(const bb_policy* P, const uint8_t* pcode, int m, const uint8_t* wcode, int wn, int k, bbo_match* best) {
     end_list ends = {0, 0, 0};
-    scan_strand(pcode, m, wcode, wn, k, -1.f, &ends);
+    scan_strand(P, pcode, m, wcode, wn, k, -1.f, &ends);
     int bi = -1;
-    for (int t = 0; t < ends.n; ++t)
-        if (bi < 0 || ends.v[t].cost < ends.v[bi].cost) bi = t; /* searcher.rs:294-300 */
+    for (int t = 0; t < ends.n; ++t)  /* searcher.rs:294-300; policy [H7]: BB_TIE_LAST = the Vec in descending position order */
+        if (bi < 0 || ends.v[t].cost < ends.v[bi].cost || (P->bar_tie == BB_TIE_LAST && ends.v[t].cost == ends.v[bi].cost)) bi = t;
     if (bi >= 0) {
-        trace_match(pcode, m, wcode, wn, k, -1.f, ends.v[bi].e, ends.v[bi].cost, best);
+        trace_match(P, pcode, m, wcode, wn, k, -1.f, ends.v[bi].e, ends.v[bi].cost, best);
         best->strand = BB_FWD; best->rc_text_len = wn;
     }
     free(ends.v);
@@ -568,7 +619,7 @@ static void demux_read(const bbo_ctx* c, uint32_t read_idx, const uint8_t* read,
     for (uint32_t gi = 0; gi < c->n_groups; ++gi) {                                   /* :433 */
         const ogroup* g = &c->g[gi];
         bbo_match* fms = NULL;
-        int nfm = bbo_search(g->flank, (int)g->flank_len, read, (int)n, g->flank_k, c->p.alpha, 1, &fms); /* :438 */
+        int nfm = search_pol(&c->pol, g->flank, (int)g->flank_len, read, (int)n, g->flank_k, c->p.alpha, 1, &fms); /* :438 */
         for (int f = 0; f < nfm; ++f) {                                               /* :440 */
             const bbo_match* fm = &fms[f];
             int lo, hi;
@@ -588,7 +639,7 @@ static void demux_read(const bbo_ctx* c, uint32_t read_idx, const uint8_t* read,
                 for (uint32_t p = 0; p < g->n_seqs; ++p) {
                     for (int j = 0; j < m; ++j) pcode[j] = text_code(pats[(size_t)p * m + j]);
                     if (has[p]) { free(best[p].ops); best[p].ops = NULL; has[p] = 0; }
-                    has[p] = (uint8_t)best_match_for_pattern(pcode, m, wcode, wn, k, &best[p]);
+                    has[p] = (uint8_t)best_match_for_pattern(&c->pol, pcode, m, wcode, wn, k, &best[p]);
                     matched += has[p];
                 }
                 if (matched <= 1 && g->k1 < g->k2 && pass == 0) k = g->k2; else break; /* :303-306 */
@@ -602,7 +653,7 @@ static void demux_read(const bbo_ctx* c, uint32_t read_idx, const uint8_t* read,
                 double* sc = (double*)malloc(sizeof(double) * g->n_seqs);
                 for (uint32_t p = 0; p < g->n_seqs; ++p) {
                     if (!has[p]) continue;
-                    double s = bbo_lodhi(best[p].ops, best[p].n_ops);
+                    double s = lodhi_pol(&c->pol, best[p].ops, best[p].n_ops);
                     sc[p] = g->perfect > 0.0 ? s / g->perfect : 0.0;                   /* :368-372 */
                     if (top < 0 || sc[p] > top_s) { top = (int)p; top_s = sc[p]; }
                 }

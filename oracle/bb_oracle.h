@@ -12,6 +12,7 @@
 #define BB_ORACLE_H
 
 #include "../include/barbell_amd.h"
+#include "../include/barbell_amd_policy.h"
 #include "../include/barbell_amd_filter.h"
 #include "../include/barbell_amd_trim.h"
 #include "../include/barbell_amd_inspect.h"
@@ -68,6 +69,10 @@ uint8_t bbo_iupac_code(uint8_t c);
 /* whole-path API with the same shape as the product's C-ABI */
 typedef struct bbo_ctx bbo_ctx;
 int  bbo_create(const bb_group_desc* groups, uint32_t n_groups, const bb_params* params, bbo_ctx** out);
+/* the same under an explicit policy (include/barbell_amd_policy.h; NULL = default); bbo_create uses the policy last set
+ * with bbo_set_policy, which also governs the stand-alone bbo_search / bbo_lodhi (NULL resets it to the default) */
+int  bbo_create_policy(const bb_group_desc* groups, uint32_t n_groups, const bb_params* params, const bb_policy* policy, bbo_ctx** out);
+int  bbo_set_policy(const bb_policy* policy);
 void bbo_destroy(bbo_ctx* ctx);
 int  bbo_group_get_info(const bbo_ctx* ctx, uint32_t group, bb_group_info* info);
 int  bbo_group_get_flank(const bbo_ctx* ctx, uint32_t group, uint8_t* out);

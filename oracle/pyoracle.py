@@ -59,6 +59,8 @@ def lib():
         L.bbo_iupac_code.restype = C.c_uint8
         L.bbo_iupac_code.argtypes = [C.c_uint8]
         L.bbo_create.argtypes = [C.POINTER(_abi.GroupDesc), C.c_uint32, C.POINTER(_abi.Params), C.POINTER(C.c_void_p)]
+        L.bbo_create_policy.argtypes = [C.POINTER(_abi.GroupDesc), C.c_uint32, C.POINTER(_abi.Params), C.POINTER(_abi.Policy), C.POINTER(C.c_void_p)]
+        L.bbo_set_policy.argtypes = [C.POINTER(_abi.Policy)]
         L.bbo_destroy.argtypes = [C.c_void_p]
         L.bbo_group_get_info.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(_abi.GroupInfo)]
         L.bbo_group_get_flank.argtypes = [C.c_void_p, C.c_uint32, C.c_char_p]
@@ -129,6 +131,21 @@ def lodhi(ops):
     return lib().bbo_lodhi(bytes(ops), len(ops))
 
 
+class policy:
+    """with pyoracle.policy("lm=left"): ... — the policy of the stand-alone entry points (search, lodhi) and of Oracle()
+    objects made without one (include/barbell_amd_policy.h)"""
+
+    def __init__(self, text=None):
+        self.p = _abi.policy_from_str(text)
+
+    def __enter__(self):
+        assert lib().bbo_set_policy(C.byref(self.p)) == 0
+        return self.p
+
+    def __exit__(self, *a):
+        lib().bbo_set_policy(None)
+
+
 def collapse(rows, overlap=0.8):
     rows = np.ascontiguousarray(rows, dtype=_abi.ROW_DTYPE).copy()
     n = lib().bbo_collapse(rows.ctypes.data, len(rows), overlap)
@@ -169,12 +186,16 @@ def fastq_parse(text, final_block=True):
 class Oracle:
     """Same shape as barbell_amd.Demuxer, CPU restatement underneath."""
 
-    def __init__(self, groups, alpha=0.4, min_score=0.2, min_score_diff=0.1):
+    def __init__(self, groups, alpha=0.4, min_score=0.2, min_score_diff=0.1, policy=None):
         L = lib()
         arr, keep = _abi.make_group_descs(groups)
         p = _abi.Params(alpha, min_score, min_score_diff, -1)
         h = C.c_void_p()
-        rc = L.bbo_create(arr, len(groups), C.byref(p), C.byref(h))
+        if policy is None:
+            rc = L.bbo_create(arr, len(groups), C.byref(p), C.byref(h))
+        else:
+            self.policy = _abi.policy_from_str(policy)
+            rc = L.bbo_create_policy(arr, len(groups), C.byref(p), C.byref(self.policy), C.byref(h))
         self.rc = rc
         self.h = h if rc == 0 else None
         self.n_groups = len(groups)

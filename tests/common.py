@@ -19,3 +19,19 @@ def config_groups(name):
     if name == "nbd96x":  # configs[4] literally: --use-extended is a no-op for SQK-NBD114-96
         return kits.groups_from_kit("SQK-NBD114-96", use_extended=True, flank_max_errors=3)
     raise KeyError(name)
+
+
+def noisy_reads(cfg, seed, n, lmin, lmax, rate=0.08):
+    """synthetic reads of a config with `rate` substitutions everywhere (scores land near the thresholds, equal-cost
+    alternatives appear): (groups, bases, offsets)"""
+    import numpy as np
+
+    from barbell_amd import annotate as A
+
+    groups = config_groups(cfg)
+    bases, offsets = A.synth_reads_host(groups, seed, lmin, lmax, 0, n)
+    rng = np.random.default_rng(seed)
+    b = bases.copy()
+    pos = rng.random(len(b)) < rate
+    b[pos] = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), int(pos.sum()))
+    return groups, b, offsets

@@ -74,7 +74,6 @@ def test_generic_kernels_match_too(monkeypatch):
     from barbell_amd import annotate as A
 
     monkeypatch.setenv("BARBELL_AMD_GENERIC", "1")
-    monkeypatch.setenv("BARBELL_AMD_SCAN_V1", "1")   # first-generation scan kernel (both strands per lane)
     for cfg in ("nbd96", "dual"):
         groups = config_groups(cfg)
         bases, offsets = A.synth_reads_host(groups, 31337, 400, 2500, 0, 500)

@@ -3,6 +3,15 @@
 from oracle import pyoracle as po
 
 P = b"AAAAACCCAAAA"
+# the five vectors as data (pattern, text, k, (-, text span of pattern rows [5, 8) or None, sub-path cost)); the first match of
+# Searcher::<Iupac>::new_rc().search is the one the reference's tests look at
+KATS = [
+    (P, b"GGGGAAAAACCCAAAAGGGGG", 0, (None, None, 0)),
+    (P, b"GGGGAAAAACGCAAAA", 1, (None, None, 1)),
+    (P, b"ACGCAAAAGGGGGGGGGGGG", 5, (None, (1, 4), 1)),
+    (P, b"GAAAAACGC", 5, (None, (6, 9), 1)),
+    (P, b"GCAAAAGGGGGGGGGGGG", 8, (None, (0, 2), 2)),
+]
 
 
 def revcomp(s):  # cigar_parse.rs:90-102
