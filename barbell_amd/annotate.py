@@ -283,7 +283,7 @@ def read_fastq(path):
 
 def annotate(read_files, out_file, query_groups, alpha=0.4, min_score=0.2, min_score_diff=0.1, max_flank_errors=None,
              batch_reads=0, block_bytes=512 << 20, device=0, filter_patterns=None, filtered_file=None, dropped_file=None, trim_folder=None,
-             trim_config=None, inspector=None):
+             trim_config=None, inspector=None, policy=None):
     """annotate_with_groups + annotate (annotator.rs:207-285): sets the flank threshold of each group
     (explicit --flank-max-errors or the automatic cutoff), hands the FASTQ text to the GPU block by block
     (`block_bytes`, or `batch_reads` * 4096; records are parsed there, barbell_amd/fastq.py) and writes annotation.tsv.  With `filter_patterns` the filter step (filter.rs:10-119) runs on
@@ -297,7 +297,7 @@ def annotate(read_files, out_file, query_groups, alpha=0.4, min_score=0.2, min_s
     for g in query_groups:
         if max_flank_errors is not None:
             g.set_flank_threshold(max_flank_errors)
-    dm = Demuxer(alpha, False, min_score, min_score_diff, device)
+    dm = Demuxer(alpha, False, min_score, min_score_diff, device, policy=policy)
     for g in query_groups:
         dm.add_query_group(g)
     flt = None

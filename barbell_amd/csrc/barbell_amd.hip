@@ -591,19 +591,24 @@ void launch_barcode_pfx(bb_ctx* c, uint32_t n_hits, uint32_t g, uint32_t strand,
     const uint32_t blocks = n_iter < resident ? n_iter : resident;
 #define BB_PFX_ARGS (const uint8_t*)c->d_tables, (const bb_group_dev*)c->d_groups, g, strand, (const bb_hit*)c->d_hits, (const bb_hit_pfx*)c->d_pfx, list, \
                     cnt, n_hits, hpb, c->params.min_score, c->params.min_score_diff, c->d_rows
-#define BB_PFX_LAUNCH(TAIL_, FAST_)                                                                                          \
+#define BB_PFX_LAUNCH4(TAIL_, FAST_, DEF_)                                                                                   \
     do {                                                                                                                    \
         if (smem > 64 * 1024)                                                                                               \
-            (void)hipFuncSetAttribute((const void*)k_barcode_pfx<CW, TAIL_, FAST_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
-        hipLaunchKernelGGL((k_barcode_pfx<CW, TAIL_, FAST_>), dim3(blocks), dim3(threads), smem, c->stream, BB_PFX_ARGS);   \
+            (void)hipFuncSetAttribute((const void*)k_barcode_pfx<CW, TAIL_, FAST_, DEF_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
+        hipLaunchKernelGGL((k_barcode_pfx<CW, TAIL_, FAST_, DEF_>), dim3(blocks), dim3(threads), smem, c->stream, BB_PFX_ARGS);   \
     } while (0)
+#define BB_PFX_LAUNCH(TAIL_, FAST_) BB_PFX_LAUNCH4(TAIL_, FAST_, false)
+    const bool defpol = CW == 48 && fast && c->policy.lm_rule == BB_LM_PLATEAU_RIGHT && c->policy.bar_tie == BB_TIE_FIRST;
     if (D.tail[strand] > 0) {
-        if (fast) BB_PFX_LAUNCH(true, true);
+        if (defpol) { if constexpr (CW == 48) BB_PFX_LAUNCH4(true, true, true); }
+        else if (fast) BB_PFX_LAUNCH(true, true);
         else BB_PFX_LAUNCH(true, false);
     } else {
-        if (fast) BB_PFX_LAUNCH(false, true);
+        if (defpol) { if constexpr (CW == 48) BB_PFX_LAUNCH4(false, true, true); }
+        else if (fast) BB_PFX_LAUNCH(false, true);
         else BB_PFX_LAUNCH(false, false);
     }
+#undef BB_PFX_LAUNCH4
 #undef BB_PFX_LAUNCH
 #undef BB_PFX_ARGS
 }

@@ -1809,9 +1809,7 @@ __device__ __forceinline__ float lodhi_bound_tab(unsigned long long plo, unsigne
 // after the last change below it.
 __device__ __forceinline__ void pick_minimum(unsigned long long P, unsigned long long M, int wn, int m, bool active, int pol_lm, bool tie_last,
                                              int32_t& best_cost, int32_t& best_pos) {
-#ifdef BB_POLICY_STATIC_DEFAULT  // measurement aid: the default policy as compile-time constants
-    pol_lm = BB_LM_PLATEAU_RIGHT; tie_last = false;
-#endif
+
     // dec(q) = "last strict change before position q was a decrease" (initially true):
     // dec(q+1) = M[q] | (~(P|M)[q] & dec(q))  ==  carry chain of (M | ~P) + M + 1;  strict minima only: dec(q+1) = M[q]
     const unsigned long long A = M | ~P;
@@ -1823,7 +1821,7 @@ __device__ __forceinline__ void pick_minimum(unsigned long long P, unsigned long
         R &= R - 1ull;
         const unsigned long long lowq = (1ull << q) - 1ull;
         const int32_t cq = m + __popcll(P & lowq) - __popcll(M & lowq);
-        if (cq < best_cost || (tie_last && cq == best_cost)) { best_cost = cq; best_pos = q; }
+        if (cq - (tie_last ? 1 : 0) < best_cost) { best_cost = cq; best_pos = q; }  // tie_last: cq <= best_cost
     }
     if (pol_lm == BB_LM_PLATEAU_LEFT && best_pos > 0) {
         const unsigned long long ch = (P | M) & ((1ull << best_pos) - 1ull);
@@ -2158,7 +2156,9 @@ __device__ __forceinline__ void wave_top2(bool in, uint32_t vbits, unsigned long
          (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)key, l2);
 }
 #define BB_PFX_SYNC() __syncthreads()
-template <int CW, bool TAIL, bool FAST>
+// DEFPOL: the default local-minimum and tie rules as compile-time constants (measured: the run-time form costs the 48-column
+// fast variants 1 % — 16.40 against 16.24 ms per 2 M-read step); the host launches it when the context's policy has them
+template <int CW, bool TAIL, bool FAST, bool DEFPOL = false>
 __global__ __launch_bounds__(CW <= 48 ? 768 : 512) void k_barcode_pfx(const uint8_t* __restrict__ tables, const bb_group_dev* __restrict__ groups,
                                                      uint32_t g, uint32_t strand, const bb_hit* __restrict__ hits, const bb_hit_pfx* __restrict__ pfxs,
                                                      const uint32_t* __restrict__ hit_list, const uint32_t* __restrict__ list_cnt,
@@ -2402,7 +2402,7 @@ __global__ __launch_bounds__(CW <= 48 ? 768 : 512) void k_barcode_pfx(const uint
                 Pm = Ph & wmask; Mm = Mh & wmask;
             }
         }
-        pick_minimum(Pm, Mm, wn, m, active, G.pol_lm, G.pol_tie_last != 0, best_cost, best_pos);
+        pick_minimum(Pm, Mm, wn, m, active, DEFPOL ? BB_LM_PLATEAU_RIGHT : G.pol_lm, DEFPOL ? false : G.pol_tie_last != 0, best_cost, best_pos);
         if constexpr (!FAST) { if (active && best_pos >= 0 && best_cost <= G.k1) atomicAdd(&s_cnt1[hl], 1); }
     }
     bool cand = active && best_pos >= 0 && best_cost <= G.k2;

@@ -44,6 +44,19 @@ static std::vector<int> parse_devices(const std::string& spec) {
     return out;
 }
 
+// --policy: the text form of include/barbell_amd_policy.h (what the un-vendored crates are assumed to do where Barbell's own
+// code does not pin it); checked here, handed to every context through BARBELL_AMD_POLICY (bb_create reads it)
+static bool set_policy(const char* text) {
+    bb_policy p;
+    bb_policy_default(&p);
+    if (bb_policy_parse(text, &p) != 0) {
+        fprintf(stderr, "error: --policy '%s': expected e.g. lm=left,rc=fwd,trace=MSID,ovh=ceil,tie=last,lodhi=3:0.5:2211\n", text);
+        return false;
+    }
+    setenv("BARBELL_AMD_POLICY", text, 1);
+    return true;
+}
+
 static void usage() {
     fputs(
         "Usage: barbell-amd annotate -i <FASTQ>... [-o output.tsv] (--kit <KIT> | -q <FASTA>... [-b Ftag|Rtag ...])\n"
@@ -52,6 +65,7 @@ static void usage() {
         "                            [--block-bytes N=128Mi | --batch-reads N (= N*4096 bytes)] [--device D=0] [--shard R/W]\n"
         "                            [--devices D0,D1,.. (one FASTQ stream over several contexts, block i -> context i mod G; RCCL all-reduce of the counts)]\n"
         "                            [--streams S=2 (contexts per device when --devices is not given)] [--counts FILE]\n"
+        "                            [--policy lm=..,rc=..,trace=..,ovh=..,tie=..,lodhi=.. (include/barbell_amd_policy.h)]\n"
         "                            [(-f <PATTERN_FILE>... | --kit-filter [--maximize]) [--filtered FILE] [--dropped FILE]]\n"
         "                            [--trim-output DIR [--no-label] [--no-orientation] [--no-flanks] [--sort-labels]\n"
         "                             [--only-side left|right] [--failed-out FILE] [--skip-trim] [--flip] [--gzip]]\n"
@@ -109,6 +123,7 @@ int main(int argc, char** argv) {
             else if (a == "--devices") { k.devices = parse_devices(need("--devices")); }
             else if (a == "--streams") k.streams_per_device = (unsigned)atoi(need("--streams"));
             else if (a == "--counts") k.counts_file = need("--counts");
+            else if (a == "--policy") { if (!set_policy(need("--policy"))) return 2; }
             else if (a == "--shard") shard = need("--shard");
             else if (a == "--maximize") { k.maximize = true; multi_in = false; }
             else if (a == "--verbose") { k.verbose = true; multi_in = false; }
@@ -161,6 +176,7 @@ int main(int argc, char** argv) {
         else if (a == "--devices") { cfg.devices = parse_devices(need("--devices")); multi = nullptr; }
         else if (a == "--streams") { cfg.streams_per_device = (unsigned)atoi(need("--streams")); multi = nullptr; }
         else if (a == "--counts") { cfg.counts_file = need("--counts"); multi = nullptr; }
+        else if (a == "--policy") { if (!set_policy(need("--policy"))) return 2; multi = nullptr; }
         else if (a == "--shard") { shard = need("--shard"); multi = nullptr; }
         else if (a == "-f" || a == "--filter-file") { multi = &pattern_files; }
         else if (a == "--filtered") { cfg.filtered_file = need("--filtered"); multi = nullptr; }

@@ -757,6 +757,7 @@ struct BlockFeeder {
     // sequencer state
     uint64_t want_seq = 0, n_blocks = 0;
     const uint8_t* carry_ptr = nullptr; size_t carry_len = 0, carry_lines = 0; int carry_slot = -1;
+    std::vector<uint8_t> carry_buf;  // a carry that spans whole chunks (a record longer than a chunk) is kept here
     bool done = false;
 
     BlockFeeder(bb_ctx* c, const std::vector<std::string>& files, size_t chunk_bytes, unsigned n_slots, unsigned n_readers, unsigned n_inflate);
@@ -978,6 +979,12 @@ BlockFeeder::BlockFeeder(bb_ctx* c, const std::vector<std::string>& files, size_
     chunks_left.assign(paths.size(), 0);
     std::vector<std::string> gz_paths;
     for (size_t i = 0; i < paths.size(); ++i) {
+        // Pipes, process substitutions and /dev/stdin have no size and cannot be read at offsets (and a sniff would eat their
+        // first bytes): they are read sequentially, whole, through zlib like a gzip file — gzread passes plain text through
+        // and inflates gzip, whichever arrives (the reference's paraseq reader streams both as well, io.rs:29-33).
+        struct stat pst;
+        if (stat(paths[i].c_str(), &pst) != 0) throw BarbellError(BB_E_INVALID, "Failed to open FASTQ input: " + paths[i]);
+        if (!S_ISREG(pst.st_mode)) { is_gz[i] = 1; continue; }
         is_gz[i] = sniff_gzip(paths[i]) ? 1 : 0;
         if (is_gz[i]) continue;
         fds[i] = open(paths[i].c_str(), O_RDONLY);
@@ -1098,8 +1105,17 @@ bool BlockFeeder::next(Block& b) {
         if (!sl->last) {
             const size_t total = carry_lines + sl->nl;
             const size_t r = total % 4;            // complete lines after the last complete record
-            if (total < 4 || sl->nl <= r) {         // no record ends inside this chunk
-                if (carry_len + sl->got > 0) throw BarbellError(BB_E_FASTQ, "a FASTQ record of '" + paths[sl->file] + "' is longer than the block size; raise --block-bytes");
+            if (total < 4 || sl->nl <= r) {         // no record ends inside this chunk (a record longer than the block, or a tiny --block-bytes):
+                // the whole chunk joins the carry, kept aside, and the next chunk continues the record
+                std::vector<uint8_t> nb(carry_len + sl->got);
+                if (carry_len) memcpy(nb.data(), carry_ptr, carry_len);
+                if (sl->got) memcpy(nb.data() + carry_len, body, sl->got);
+                carry_buf.swap(nb);
+                if (carry_slot >= 0) unref(carry_slot);
+                carry_slot = -1;
+                carry_ptr = carry_buf.data(); carry_len = carry_buf.size(); carry_lines = total;
+                unref(si); unref(si);  // neither a worker nor the sequencer keeps the slot
+                continue;
             }
             // the cut is just after line end number (nl - r) of the chunk: walk back over the partial last line and r lines
             const uint8_t* e = body + sl->got;

@@ -135,15 +135,19 @@ class policy:
     """with pyoracle.policy("lm=left"): ... — the policy of the stand-alone entry points (search, lodhi) and of Oracle()
     objects made without one (include/barbell_amd_policy.h)"""
 
+    _stack = []
+
     def __init__(self, text=None):
         self.p = _abi.policy_from_str(text)
 
     def __enter__(self):
         assert lib().bbo_set_policy(C.byref(self.p)) == 0
+        policy._stack.append(self.p)
         return self.p
 
     def __exit__(self, *a):
-        lib().bbo_set_policy(None)
+        policy._stack.pop()
+        lib().bbo_set_policy(C.byref(policy._stack[-1]) if policy._stack else None)   # nested uses restore the outer one
 
 
 def collapse(rows, overlap=0.8):

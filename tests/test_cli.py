@@ -120,10 +120,42 @@ def test_cli_tsv_matches_python_and_oracle(tmp_path, gz):
                         "--block-bytes", "5000"], capture_output=True, text=True, env=dict(env, BARBELL_AMD_HEAD_BYTES="64"))
     assert r.returncode == 0, r.stderr
     assert out2.read_bytes() == cli
+    # blocks shorter than a record (reads of up to 2.5 kb, 5 kb of text each, in 1500-byte blocks): the record is carried over
+    # several chunks instead of aborting the run
+    out3 = tmp_path / "cli3.tsv"
+    r = subprocess.run([CLI, "annotate", "-i", str(fq), "-o", str(out3), "--kit", "SQK-NBD114-96", "--flank-max-errors", "3",
+                        "--block-bytes", "1500"], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr
+    assert out3.read_bytes() == cli
+    # a pipe instead of a file (no size, no offsets; plain or gzip): read sequentially, same output
+    fifo = tmp_path / "reads.pipe"
+    os.mkfifo(fifo)
+    import threading
+
+    def feed():
+        with open(fifo, "wb") as w:
+            w.write(fq.read_bytes())
+
+    th = threading.Thread(target=feed)
+    th.start()
+    out4 = tmp_path / "cli4.tsv"
+    r = subprocess.run([CLI, "annotate", "-i", str(fifo), "-o", str(out4), "--kit", "SQK-NBD114-96", "--flank-max-errors", "3"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    th.join()
+    assert r.returncode == 0, r.stderr
+    assert out4.read_bytes() == cli
     rows = po.Oracle([g.as_tuple() for g in groups]).annotate(bases, offsets, n_threads=os.cpu_count() or 1)
     want = (A.TSV_HEADER + "\n" + "\n".join(A.format_rows(rows, ids, groups)) + "\n").encode()
     assert cli == want
     assert cli.split(b"\n")[0].decode() == A.TSV_HEADER and cli.count(b"\n") == len(rows) + 1
+    # --policy reaches every context: the checker under the same policy gives the same bytes
+    pol = "lm=left,trace=MSID,lodhi=3:0.5:2211"
+    out5 = tmp_path / "cli5.tsv"
+    r = subprocess.run([CLI, "annotate", "-i", str(fq), "-o", str(out5), "--kit", "SQK-NBD114-96", "--flank-max-errors", "3", "--policy", pol],
+                       capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr
+    rows = po.Oracle([g.as_tuple() for g in groups], policy=pol).annotate(bases, offsets, n_threads=os.cpu_count() or 1)
+    assert out5.read_bytes() == (A.TSV_HEADER + "\n" + "\n".join(A.format_rows(rows, ids, groups)) + "\n").encode() != cli
 
 
 @pytest.mark.gpu

@@ -12,6 +12,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
+sys.path.insert(0, os.path.join(ROOT, "tools", "ref_golden"))
 
 import ref_diff  # noqa: E402
 import ref_export  # noqa: E402
@@ -23,14 +24,21 @@ GOLD = os.path.join(ROOT, "tests", "golden")
 UNPINNED = "reference parity unpinned beyond KATs"
 
 
-def oracle_tsv(export_dir, cfg, path):
+def golden_policy():
+    """tests/golden/policy.txt: the policy (include/barbell_amd_policy.h) tools/ref_fit.py found to reproduce the committed golden
+    vectors; absent = the default.  Goes in together with ref_kat.jsonl / ref_tsv/."""
+    p = os.path.join(GOLD, "policy.txt")
+    return open(p).read().strip() if os.path.exists(p) else None
+
+
+def oracle_tsv(export_dir, cfg, path, policy=None):
     """the oracle's annotation.tsv of an exported read set (rows in input order)"""
     groups = ref_export.config_groups(cfg)
     ids, seqs = [], []
     for rid, s in A.read_fastq(os.path.join(export_dir, "reads.fastq")):
         ids.append(rid)
         seqs.append(s)
-    rows = po.Oracle([g.as_tuple() for g in groups]).annotate_reads(seqs, n_threads=os.cpu_count() or 1)
+    rows = po.Oracle([g.as_tuple() for g in groups], policy=policy).annotate_reads(seqs, n_threads=os.cpu_count() or 1)
     lines = A.format_rows(rows, ids, groups)
     with open(path, "w") as f:
         if lines:
@@ -145,7 +153,78 @@ def test_ref_kat_vectors():
     path = os.path.join(GOLD, "ref_kat.jsonl")
     if not os.path.exists(path):
         pytest.skip(UNPINNED + " (tests/golden/ref_kat.jsonl absent: see tools/ref_golden/README.md)")
-    assert check_kat_file(path) > 0
+    assert check_kat_file(path, golden_policy()) > 0
+
+
+def test_kat_inputs_discriminate_every_alternative():
+    """tools/ref_golden/kat_inputs.tsv (what kat.rs feeds the real crates) tells every setting of every policy field apart:
+    under the CPU checker no two settings of a field give the same answers on all inputs — except traceback orders that
+    differ only by swapping Match and Sub while adjacent, which can never differ (Match needs a zero diagonal step, Sub a
+    non-zero one).  So the crates' answers single out one policy."""
+    import gen_kat_inputs as G
+    import ref_fit
+
+    inputs = G.load()
+    assert [G.format_line(t) for t in G.all_inputs()] == [G.format_line(t) for t in inputs], "kat_inputs.tsv is stale: run gen_kat_inputs.py"
+    d = ref_fit.default_policy()
+
+    def sig(pol, kinds):
+        out = []
+        for inp in inputs:
+            if inp[0] in kinds:
+                a = ref_fit.checker_answer(inp, ref_fit.to_text(pol))
+                out.append(sorted(ref_fit.kept_per_pattern(a["matches"], last=pol["tie"] == "last").items()) if a["kind"] == "search_set"
+                           else a["bits"] if a["kind"] == "lodhi" else a["matches"])
+        return json.dumps(out)
+
+    for field, kinds in (("lm", ("search", "search_set")), ("rc", ("search",)), ("ovh", ("search",)), ("tie", ("search_set",)), ("lodhi", ("lodhi",))):
+        sigs = {sig(dict(d, **{field: v}), kinds) for v in ref_fit.SPACE[field]}
+        assert len(sigs) == len(ref_fit.SPACE[field]), field
+    groups = {}
+    for v in ref_fit.SPACE["trace"]:
+        groups.setdefault(sig(dict(d, trace=v), ("search", "search_set")), []).append(v)
+    for g in groups.values():
+        assert len(g) == 1 or (len(g) == 2 and g[0].replace("MS", "SM") == g[1].replace("MS", "SM")), g
+    assert len(groups) == 18
+
+
+def test_fit_recovers_a_planted_policy_from_kat_vectors(tmp_path):
+    """answers written by the checker under a non-default policy stand in for the crates': tools/ref_fit.py names a policy that
+    explains all of them, equal to the planted one in every field"""
+    import gen_kat_inputs as G
+    import ref_fit
+
+    planted = "lm=left,rc=fwd,trace=MDSI,ovh=near:f64,tie=last,lodhi=3:0.5:2211"
+    vectors = [ref_fit.checker_answer(inp, planted) for inp in G.load()]
+    for v in vectors:  # tie=last models a crate whose Vec comes in descending position order (Barbell keeps its first strictly lowest)
+        if v["kind"] == "search_set":
+            v["matches"].reverse()
+    f = tmp_path / "kat.jsonl"
+    f.write_text("\n".join(json.dumps(v) for v in vectors) + "\n")
+    assert check_kat_file(str(f), planted) == len(vectors)
+    with pytest.raises(AssertionError):
+        check_kat_file(str(f))                    # the default policy does not explain them
+    pol, rep = ref_fit.fit_kat(vectors)
+    assert all(r["explained"] == r["vectors"] for r in rep.values()), rep
+    assert ref_fit.to_text(pol) == planted
+    assert not any(r["not_told_apart"] for r in rep.values()), rep
+
+
+def test_fit_recovers_a_planted_policy_from_a_tsv(tmp_path):
+    """the same through the whole path: a ref.tsv replayed from the checker under a non-default policy on the noisy export
+    config; ref_diff --fit's search ends on a policy under which every read's rows are identical"""
+    import ref_fit
+
+    planted = "lm=left,trace=MSID,tie=last,lodhi=3:0.5:1121"
+    d = ref_export.export_config("nbd96n", str(tmp_path), 400)
+    oracle_tsv(d, "nbd96n", os.path.join(d, "ref.tsv"), policy=planted)
+    ours = str(tmp_path / "default.tsv")
+    ids, _ = oracle_tsv(d, "nbd96n", ours)
+    rep = ref_diff.diff_rows(ref_diff.parse_tsv(os.path.join(d, "ref.tsv")), ref_diff.parse_tsv(ours), ids)
+    assert rep["reads_differ"] > 5                                  # the default does not reproduce it
+    pol, rep = ref_fit.fit_tsv(d, 400)
+    assert rep["reads_identical"] == 400, rep
+    assert pol["lm"] == "left" and pol["trace"] in ("MSID", "SMID")
 
 
 def test_kat_ingest_selfcheck(tmp_path):
@@ -181,8 +260,14 @@ def test_kat_ingest_selfcheck(tmp_path):
         check_kat_file(str(f))
 
 
-def check_kat_file(path):
+def check_kat_file(path, policy=None):
+    with po.policy(policy):
+        return _check_kat_file(path, policy)
+
+
+def _check_kat_file(path, policy):
     n = 0
+    tie_last = "tie=last" in (policy or "")
     for line in open(path):
         v = json.loads(line)
         if v["kind"] == "lodhi":
@@ -196,13 +281,11 @@ def check_kat_file(path):
                      w["ops"], w["path"]) for w in v["matches"]]
             assert [_match_tuple(m) for m in ms] == want, v
         elif v["kind"] == "search_set":
-            per = {}
-            for w in v["matches"]:
-                per.setdefault(w["pattern_idx"], []).append((w["text_start"], w["text_end"], w["cost"], w["ops"]))
-            for idx, p in enumerate(v["patterns"]):
-                ms, h = po.search(p.encode(), v["text"].encode(), v["k"], alpha=None, rc=False)
-                po.free_matches(h)
-                assert [(m.text_start, m.text_end, m.cost, m.cigar) for m in ms] == per.get(idx, []), (idx, v)
+            # what collect_candidates_for_region keeps per pattern (searcher.rs:294-300: the first strictly lowest of the Vec)
+            import ref_fit
+
+            ours = ref_fit.checker_answer(ref_fit.input_of(v), policy)
+            assert ref_fit.kept_per_pattern(v["matches"]) == ref_fit.kept_per_pattern(ours["matches"], last=tie_last), v
         n += 1
     return n
 
@@ -220,7 +303,7 @@ def test_golden_tsv_oracle(tmp_path):
         n = int(json.load(open(os.path.join(GOLD, "ref_tsv", cfg + ".json")))["n_reads"])
         d = ref_export.export_config(cfg, str(tmp_path), n)
         ours = str(tmp_path / (cfg + ".oracle.tsv"))
-        ids, _ = oracle_tsv(d, cfg, ours)
+        ids, _ = oracle_tsv(d, cfg, ours, policy=golden_policy())
         rep = ref_diff.diff_rows(ref_diff.parse_tsv(os.path.join(GOLD, "ref_tsv", cfg + ".tsv")), ref_diff.parse_tsv(ours), ids)
         assert rep["identical"], json.dumps({k: rep[k] for k in ("buckets", "hazards", "examples")}, indent=1)
 
@@ -234,7 +317,7 @@ def test_golden_tsv_hip(tmp_path):
         n = int(json.load(open(os.path.join(GOLD, "ref_tsv", cfg + ".json")))["n_reads"])
         d = ref_export.export_config(cfg, str(tmp_path), n)
         ours = str(tmp_path / (cfg + ".hip.tsv"))
-        A.annotate([os.path.join(d, "reads.fastq")], ours, ref_export.config_groups(cfg))
+        A.annotate([os.path.join(d, "reads.fastq")], ours, ref_export.config_groups(cfg), policy=golden_policy())
         rep = ref_diff.diff_rows(ref_diff.parse_tsv(os.path.join(GOLD, "ref_tsv", cfg + ".tsv")), ref_diff.parse_tsv(ours),
                                  ref_diff.fastq_ids(os.path.join(d, "reads.fastq")))
         assert rep["identical"], json.dumps({k: rep[k] for k in ("buckets", "hazards", "examples")}, indent=1)

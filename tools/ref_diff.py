@@ -18,6 +18,8 @@ third-party hazard behind it (oracle/README.md):
   order       same rows, different order within the read       -> H2 (match order / stable-sort ties)
 
   tools/ref_diff.py EXPORT_DIR/<config> [--barbell BIN] [--ours TSV | --ours-bin barbell-amd] [-t THREADS] [--json OUT]
+  tools/ref_diff.py EXPORT_DIR/<config> --fit     which policy (include/barbell_amd_policy.h) reproduces ref.tsv: the hazards
+                                                  above are switchable in kernels and checker alike, tools/ref_fit.py picks
 
 `--barbell` defaults to $BARBELL_BIN or `barbell` on PATH; its output is cached as EXPORT_DIR/<config>/ref.tsv.
 `--ours` is a TSV made by this repo (barbell-amd annotate / barbell_amd.annotate.annotate); without it the product CLI
@@ -84,6 +86,7 @@ def group_by_read(rows, order):
 
 
 def diff_rows(ref_rows, our_rows, ids, max_examples=10):
+    """per-read comparison; reads named in neither file count as equal"""
     order = {rid: i for i, rid in enumerate(ids)}
     ref, ours = group_by_read(ref_rows, order), group_by_read(our_rows, order)
     rep = {"reads_total": len(ids), "reads_with_rows_ref": len(ref), "reads_with_rows_ours": len(ours), "rows_ref": len(ref_rows),
@@ -170,7 +173,23 @@ def main():
     ap.add_argument("-t", "--threads", type=int)
     ap.add_argument("--rerun", action="store_true", help="run the reference even if ref.tsv is cached")
     ap.add_argument("--json")
+    ap.add_argument("--fit", action="store_true",
+                    help="search the policy space (include/barbell_amd_policy.h) with the CPU checker for the setting that reproduces ref.tsv "
+                         "(tools/ref_fit.py); prints it and how many reads it explains")
+    ap.add_argument("--fit-reads", type=int, default=2000)
     a = ap.parse_args()
+    if a.fit:
+        import ref_fit
+
+        if find_barbell(a.barbell) and (a.rerun or not os.path.exists(os.path.join(a.export_dir, "ref.tsv"))):
+            man = json.load(open(os.path.join(a.export_dir, "manifest.json")))
+            run_annotate(find_barbell(a.barbell), man["barbell_args"], "reads.fastq", "ref.tsv", a.threads or os.cpu_count() or 1, a.export_dir)
+        if not os.path.exists(os.path.join(a.export_dir, "ref.tsv")):
+            print("no `barbell` binary (BARBELL_BIN / PATH) and no cached ref.tsv: reference parity " + UNPINNED, file=sys.stderr)
+            return 2
+        pol, rep = ref_fit.fit_tsv(a.export_dir, a.fit_reads, log=lambda m: print(m, file=sys.stderr))
+        print(json.dumps({"policy": ref_fit.to_text(pol), "report": rep}, indent=1))
+        return 0 if rep["reads_identical"] == rep["reads"] else 1
     rep, _ = reference_check(a.export_dir, a.barbell, a.ours, a.ours_bin, a.threads, a.rerun)
     txt = json.dumps(rep, indent=1)
     if a.json:

@@ -8,7 +8,7 @@ cigar-lodhi-rs 0.1.0; /root/reference/Cargo.toml:20,36), so GPU == oracle is all
 `barbell annotate` command line (flags of /root/reference/bin/main.rs:64-112) that produces the golden
 annotation.tsv.  No GPU is needed (read synthesis is host code of libbarbell_amd.so).
 
-  tools/ref_export.py OUT_DIR [--reads 10000] [--configs rbk24,nbd96,dual,rbk96x,nbd96x]
+  tools/ref_export.py OUT_DIR [--reads 10000] [--configs rbk24,nbd96,dual,rbk96x,nbd96x,nbd96n,dualn]
 
 OUT_DIR/<config>/reads.fastq         the reads, ids r0 .. r{n-1}, constant quality
 OUT_DIR/<config>/manifest.json       {"barbell_args": [...], "n_reads", "seed", "read_len": [lo, hi], ...}
@@ -36,17 +36,23 @@ CONFIGS = {
              ["native_left.fasta", "native_right.fasta"]),
     "rbk96x": (5, (4000, 4000), ["--kit", "SQK-RBK114-96", "--use-extended"], []),
     "nbd96x": (6, (4000, 4000), ["--kit", "SQK-NBD114-96", "--use-extended", "--flank-max-errors", "3"], []),
+    # the same two query sets on short reads with 8 % substitutions everywhere: on clean synthetic reads the decisions sit far
+    # from the score thresholds and the Lodhi / tie assumptions (include/barbell_amd_policy.h, H7, H8) never show; here they do
+    "nbd96n": (7, (300, 1500), ["--kit", "SQK-NBD114-96", "--flank-max-errors", "3"], []),
+    "dualn": (8, (300, 1500), ["-q", "native_left.fasta", "native_right.fasta", "-b", "Ftag", "Rtag", "--flank-max-errors", "5"],
+              ["native_left.fasta", "native_right.fasta"]),
 }
+NOISE = {"nbd96n": 0.08, "dualn": 0.08}
 
 
 def config_groups(name):
     from barbell_amd import _abi, kits
 
-    if name == "nbd96":
+    if name in ("nbd96", "nbd96n"):
         return kits.groups_from_kit("SQK-NBD114-96", flank_max_errors=3)
     if name == "rbk24":
         return kits.groups_from_kit("SQK-RBK114-24")
-    if name == "dual":
+    if name in ("dual", "dualn"):
         return [kits.group_from_fasta(os.path.join(EX, "native_left.fasta"), _abi.BB_FTAG, 5),
                 kits.group_from_fasta(os.path.join(EX, "native_right.fasta"), _abi.BB_RTAG, 5)]
     if name == "rbk96x":
@@ -77,6 +83,13 @@ def export_config(name, out_dir, n_reads):
     groups = config_groups(name)
     seed = 0xBA7BE11 ^ cid
     bases, offsets = A.synth_reads_host(groups, seed, lo, hi, 0, n_reads)
+    if name in NOISE:
+        import numpy as np
+
+        rng = np.random.default_rng(seed)
+        pos = rng.random(len(bases)) < NOISE[name]
+        bases = bases.copy()
+        bases[pos] = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), int(pos.sum()))
     write_fastq(os.path.join(d, "reads.fastq"), bases, offsets)
     for f in files:
         shutil.copy(os.path.join(EX, f), os.path.join(d, f))
@@ -96,7 +109,7 @@ def main():
     ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
     ap.add_argument("out_dir")
     ap.add_argument("--reads", type=int, default=10000)
-    ap.add_argument("--configs", default="rbk24,nbd96,dual,rbk96x,nbd96x")
+    ap.add_argument("--configs", default="rbk24,nbd96,dual,rbk96x,nbd96x,nbd96n,dualn")
     a = ap.parse_args()
     for c in a.configs.split(","):
         print(export_config(c, a.out_dir, a.reads))
