@@ -222,6 +222,11 @@ def synth_reads_host(groups, seed, len_min, len_max, first_read, n):
 
 
 # ---- TSV (searcher.rs:31-142, annotator.rs:13-26,246-251) ------------------------------------------
+def _csv_field(x):
+    """csv crate, QuoteStyle::Necessary (annotator.rs:246-251): a field holding the delimiter, a quote, CR or LF is quoted, quotes doubled"""
+    return '"' + x.replace('"', '""') + '"' if any(ch in x for ch in '\t"\n\r') else x
+
+
 def format_rows(rows, read_ids, groups, verdicts=None):
     """rows -> list of TSV lines (no header), csv-crate style: tab-delimited, no quoting needed for
     these field types unless a read id contains a tab/quote/newline.  With `verdicts` (filter step)
@@ -232,9 +237,8 @@ def format_rows(rows, read_ids, groups, verdicts=None):
     for i, r in enumerate(rows):
         g = groups[int(r["group_idx"])]
         label = "flank" if r["barcode_idx"] < 0 else g.labels[int(r["barcode_idx"])]
-        rid = read_ids[int(r["read_idx"])]
-        if any(ch in rid for ch in '\t"\n\r'):
-            rid = '"' + rid.replace('"', '""') + '"'
+        rid = _csv_field(read_ids[int(r["read_idx"])])
+        label = _csv_field(label)
         out.append("\t".join((
             rid, str(int(r["read_len"])), str(int(r["rel_dist_to_end"])),
             str(int(r["read_start_bar"])), str(int(r["read_end_bar"])),

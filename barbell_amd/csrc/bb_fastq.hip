@@ -20,6 +20,7 @@
 #include "bb_bytes.h"
 #include "bb_common.h"
 #include "bb_ctx_view.h"
+#include "bb_scan.h"
 
 struct bb_fastq_state {
     // text staging (host variant)
@@ -168,45 +169,6 @@ __global__ __launch_bounds__(256) void k_fq_records(const uint8_t* __restrict__ 
     desc_start[k] = ds;
 }
 
-// 64-bit exclusive scan of u32 lengths, 1024 per block; out has n+1 entries (out[n] = total)
-__global__ __launch_bounds__(256) void k_scan64_block(const uint32_t* __restrict__ in, uint64_t* __restrict__ out, uint32_t n, uint64_t* __restrict__ sums) {
-    __shared__ uint64_t s_w[4];
-    const uint32_t b0 = blockIdx.x * 1024u + threadIdx.x * 4u;
-    uint64_t t = 0, pre[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { pre[i] = t; if (b0 + i < n) t += in[b0 + i]; }
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    uint64_t inc = t;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const uint64_t y = __shfl_up(inc, d, 64); if (lane >= d) inc += y; }
-    if (lane == 63) s_w[wv] = inc;
-    __syncthreads();
-    uint64_t wbase = 0;
-    for (int i = 0; i < wv; ++i) wbase += s_w[i];
-    const uint64_t excl = wbase + inc - t;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) if (b0 + i < n) out[b0 + i] = excl + pre[i];
-    if (threadIdx.x == 255) sums[blockIdx.x] = wbase + inc;
-}
-__global__ __launch_bounds__(64) void k_scan64_sums(uint64_t* __restrict__ sums, uint32_t nb, uint64_t* __restrict__ total) {
-    uint64_t carry = 0;
-    const int lane = threadIdx.x;
-    for (uint32_t b = 0; b < nb; b += 64) {
-        const uint64_t x = b + lane < nb ? sums[b + lane] : 0ull;
-        uint64_t inc = x;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { const uint64_t y = __shfl_up(inc, d, 64); if (lane >= d) inc += y; }
-        if (b + lane < nb) sums[b + lane] = carry + inc - x;
-        carry += __shfl(inc, 63, 64);
-    }
-    if (lane == 0) total[0] = carry;
-}
-__global__ __launch_bounds__(256) void k_scan64_add(uint64_t* __restrict__ out, uint32_t n, const uint64_t* __restrict__ sums, const uint64_t* __restrict__ total) {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i < n) out[i] += sums[i >> 10];
-    if (i == 0) out[n] = total[0];
-}
-
 __global__ __launch_bounds__(256) void k_fq_pack(const uint8_t* __restrict__ text, const uint64_t* __restrict__ nl, uint32_t n_rec,
                                                  const uint64_t* __restrict__ off, const uint64_t* __restrict__ hoff,
                                                  uint8_t* __restrict__ bases, uint8_t* __restrict__ quals, uint8_t* __restrict__ hdr) {
@@ -225,10 +187,7 @@ int scan64(bb_ctx_view& v, bb_fastq_state* s, const uint32_t* in, uint64_t* out,
     const uint32_t nb = (n + 1023) / 1024;
     int r;
     if ((r = fgrow(v, s->d_sums, s->cap_sums, (uint64_t)nb + 1))) return r;
-    hipLaunchKernelGGL(k_scan64_block, dim3(nb), dim3(256), 0, v.stream, in, out, n, s->d_sums);
-    hipLaunchKernelGGL(k_scan64_sums, dim3(1), dim3(64), 0, v.stream, s->d_sums, nb, d_total);
-    hipLaunchKernelGGL(k_scan64_add, dim3((n + 255) / 256), dim3(256), 0, v.stream, out, n, (const uint64_t*)s->d_sums, (const uint64_t*)d_total);
-    FCHK(v, hipGetLastError());
+    FCHK(v, bb_scan64(v.stream, in, out, n, s->d_sums, d_total));
     return BB_OK;
 }
 

@@ -2,12 +2,13 @@
 // Byte-exact with the csv-crate serialisation of BarbellMatch (searcher.rs:31-142, annotator.rs:13-26) as restated by
 // barbell_amd/annotate.py::format_rows and host/bb_host.cpp::BarbellMatch::to_tsv (tests/test_format.py).
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
 
 #include <string>
+#include <vector>
 
 #include "../../include/barbell_amd_format.h"
 #include "bb_ctx_view.h"
+#include "bb_scan.h"
 
 struct bb_format_state {
     uint8_t* d_blob = nullptr;
@@ -156,9 +157,6 @@ __global__ __launch_bounds__(256) void k_fmt_render(const bb_row* __restrict__ r
     *p++ = '\n';
 }
 
-__global__ void k_fmt_total(const uint32_t* __restrict__ len, const uint64_t* __restrict__ pos, uint64_t n, uint64_t* __restrict__ tot) {
-    tot[0] = n ? pos[n - 1] + len[n - 1] : 0ull;
-}
 __global__ __launch_bounds__(256) void k_fmt_count(const uint32_t* __restrict__ len, uint64_t n, unsigned long long* __restrict__ cnt) {
     const uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x;
     const unsigned long long m = __ballot(t < n && len[t] != 0u);
@@ -184,10 +182,23 @@ extern "C" int bb_format_set_labels(bb_ctx* ctx, const uint8_t* blob, const uint
     if (s->d_blob) (void)hipFree(s->d_blob);
     if (s->d_off) (void)hipFree(s->d_off);
     s->d_blob = nullptr; s->d_off = nullptr;
-    FCHK(v, hipMalloc((void**)&s->d_blob, (size_t)offsets[n] + 16));
+    // labels are installed as the csv crate would write them (QuoteStyle::Necessary, annotator.rs:246-251): a label holding the
+    // delimiter, a quote, CR or LF (they come from FASTA headers) is quoted and its quotes doubled — once, here
+    std::string q;
+    std::vector<uint32_t> qoff((size_t)n + 1, 0u);
+    for (uint32_t i = 0; i < n; ++i) {
+        qoff[i] = (uint32_t)q.size();
+        bool need = false;
+        for (uint32_t j = offsets[i]; j < offsets[i + 1]; ++j) need = need || blob[j] == '"' || blob[j] == '\t' || blob[j] == '\n' || blob[j] == '\r';
+        if (need) q.push_back('"');
+        for (uint32_t j = offsets[i]; j < offsets[i + 1]; ++j) { q.push_back((char)blob[j]); if (need && blob[j] == '"') q.push_back('"'); }
+        if (need) q.push_back('"');
+    }
+    qoff[n] = (uint32_t)q.size();
+    FCHK(v, hipMalloc((void**)&s->d_blob, q.size() + 16));
     FCHK(v, hipMalloc((void**)&s->d_off, sizeof(uint32_t) * ((size_t)n + 1)));
-    FCHK(v, hipMemcpy(s->d_blob, blob, offsets[n], hipMemcpyHostToDevice));
-    FCHK(v, hipMemcpy(s->d_off, offsets, sizeof(uint32_t) * ((size_t)n + 1), hipMemcpyHostToDevice));
+    if (!q.empty()) FCHK(v, hipMemcpy(s->d_blob, q.data(), q.size(), hipMemcpyHostToDevice));
+    FCHK(v, hipMemcpy(s->d_off, qoff.data(), sizeof(uint32_t) * ((size_t)n + 1), hipMemcpyHostToDevice));
     if (!s->d_tot) FCHK(v, hipMalloc((void**)&s->d_tot, 16));
     s->n_slots = n;
     return BB_OK;
@@ -206,18 +217,15 @@ extern "C" int bb_format_rows_dev(bb_ctx* ctx, const bb_row* d_rows, const bb_ro
     FCHK(v, hipSetDevice(v.device));
     int r;
     if ((r = fgrow(v, s->d_len, s->cap_len, n_rows))) return r;
-    if ((r = fgrow(v, s->d_pos, s->cap_pos, n_rows))) return r;
+    if ((r = fgrow(v, s->d_pos, s->cap_pos, n_rows + 1))) return r;
     const uint32_t nb = (uint32_t)((n_rows + 255) / 256);
     hipLaunchKernelGGL(k_fmt_len, dim3(nb), dim3(256), 0, v.stream, d_rows, d_ver, n_rows, mode, v.d_groups, (const uint32_t*)s->d_off, *h, s->d_len);
-    size_t need = 0;
-    FCHK(v, hipcub::DeviceScan::ExclusiveSum(nullptr, need, (const uint32_t*)s->d_len, s->d_pos, (int)n_rows, v.stream));
-    {
-        uint8_t* cub = (uint8_t*)s->d_cub;
-        if ((r = fgrow(v, cub, s->cap_cub, need + 16))) return r;
-        s->d_cub = cub;
+    {   // line positions = 64-bit exclusive scan of the lengths (bb_scan.h); its total lands in d_tot[0]
+        uint8_t* scr = (uint8_t*)s->d_cub;
+        if ((r = fgrow(v, scr, s->cap_cub, ((n_rows + 1023) / 1024 + 2) * sizeof(uint64_t)))) return r;
+        s->d_cub = scr;
+        FCHK(v, bb_scan64(v.stream, (const uint32_t*)s->d_len, s->d_pos, (uint32_t)n_rows, (uint64_t*)s->d_cub, s->d_tot));
     }
-    FCHK(v, hipcub::DeviceScan::ExclusiveSum(s->d_cub, need, (const uint32_t*)s->d_len, s->d_pos, (int)n_rows, v.stream));
-    hipLaunchKernelGGL(k_fmt_total, dim3(1), dim3(1), 0, v.stream, (const uint32_t*)s->d_len, (const uint64_t*)s->d_pos, n_rows, s->d_tot);
     FCHK(v, hipMemsetAsync(s->d_tot + 1, 0, 8, v.stream));
     hipLaunchKernelGGL(k_fmt_count, dim3(nb), dim3(256), 0, v.stream, (const uint32_t*)s->d_len, n_rows, (unsigned long long*)(s->d_tot + 1));
     uint64_t tot[2] = {0, 0};

@@ -5,14 +5,13 @@
 //                       (trim.rs:127-254) on the read's <= 32 cut entries and counts surviving slices
 //   scan                exclusive scan of the counts -> slot of every read's first record
 //   k_trim_plan<true>   same walk, writes bb_slice {read, start, end, label key, suffix, flip, rec_len}
-//   radix sort          stable sort of the records by label key (hipCUB) -> records of one output
+//   radix sort          stable LSD sort of the records by label key (bb_scan.h) -> records of one output
 //                       file contiguous, read order inside (the order trim_matches writes them in)
 //   k_trim_gather + 64-bit scan of rec_len -> out_off of every record, span starts
 //   k_trim_render       one wave per record: header bytes, then the read slice and its qualities as
 //                       16-byte chunks (aligned stores, unaligned loads); flip = reverse complement
 // HBM-bound byte work: algorithmic bytes per record = 2 x (2 L + header) (read once, written once).
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
 
 #include <algorithm>
 #include <cstring>
@@ -23,6 +22,7 @@
 #include "bb_common.h"
 #include "bb_bytes.h"
 #include "bb_ctx_view.h"
+#include "bb_scan.h"
 
 #define BB_TRIM_MAX_E 32  // cut entries per read (a passing read's cuts come from one pattern)
 
@@ -211,50 +211,6 @@ __global__ __launch_bounds__(128) void k_trim_plan(const bb_row* __restrict__ ro
         cnt[t] = written;
         status[read] = written ? BB_TRIM_TRIMMED : BB_TRIM_FAILED;
     }
-}
-
-// exclusive scan u32 -> u32 (counts per row -> record slots), 2048 elements per block
-__global__ __launch_bounds__(256) void k_tscan_block(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint64_t n, uint32_t* __restrict__ sums) {
-    __shared__ uint32_t s_w[4];
-    const uint64_t b0 = (uint64_t)blockIdx.x * 2048u + (uint64_t)threadIdx.x * 8u;
-    uint32_t v[8], t = 0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] = b0 + i < n ? in[b0 + i] : 0u;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) { const uint32_t x = v[i]; v[i] = t; t += x; }
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    uint32_t inc = t;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(inc, d, 64); if (lane >= d) inc += y; }
-    if (lane == 63) s_w[wv] = inc;
-    __syncthreads();
-    uint32_t wbase = 0;
-    for (int i = 0; i < wv; ++i) wbase += s_w[i];
-    const uint32_t excl = wbase + inc - t;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) if (b0 + i < n) out[b0 + i] = v[i] + excl;
-    if (threadIdx.x == 255) sums[blockIdx.x] = wbase + inc;
-}
-// single-wave scan of the block sums; T = uint32_t or uint64_t.  total[0] = grand total.
-template <typename T>
-__global__ __launch_bounds__(64) void k_tscan_sums(T* __restrict__ sums, uint32_t nb, T* __restrict__ total) {
-    T carry = 0;
-    const int lane = threadIdx.x;
-    for (uint32_t b = 0; b < nb; b += 64) {
-        const T x = b + lane < nb ? sums[b + lane] : (T)0;
-        T inc = x;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { const T y = __shfl_up(inc, d, 64); if (lane >= d) inc += y; }
-        if (b + lane < nb) sums[b + lane] = carry + inc - x;
-        carry += __shfl(inc, 63, 64);
-    }
-    if (lane == 0) total[0] = carry;
-}
-__global__ __launch_bounds__(256) void k_tscan_add(uint32_t* __restrict__ out, uint64_t n, const uint32_t* __restrict__ sums) {
-    const uint64_t b0 = (uint64_t)blockIdx.x * 2048u + (uint64_t)threadIdx.x * 8u;
-    const uint32_t a = sums[blockIdx.x];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) if (b0 + i < n) out[b0 + i] += a;
 }
 
 __global__ __launch_bounds__(256) void k_iota(uint32_t* __restrict__ v, uint32_t n) {
@@ -456,10 +412,7 @@ extern "C" int bb_trim_batch_dev(bb_ctx* ctx, const bb_row* d_rows, const bb_row
         hipLaunchKernelGGL(k_trim_plan<false>, pg, dim3(128), 0, st, d_rows, d_ver, n_rows, v.d_groups, v.d_label_ids,
                            (const uint8_t*)s->d_is_flank, (const uint32_t*)s->d_part_rank, s->cfg, d_offsets, h->hdr_offsets, h->id_len,
                            h->desc_start, n_reads, s->d_cnt, (const uint32_t*)nullptr, (bb_slice*)nullptr, (uint32_t*)nullptr, d_status, s->d_err);
-        hipLaunchKernelGGL(k_tscan_block, dim3(nb), dim3(256), 0, st, (const uint32_t*)s->d_cnt, s->d_base, n_rows, s->d_sums);
-        hipLaunchKernelGGL(k_tscan_sums<uint32_t>, dim3(1), dim3(64), 0, st, s->d_sums, nb, s->d_err + 2);
-        hipLaunchKernelGGL(k_tscan_add, dim3(nb), dim3(256), 0, st, s->d_base, n_rows, (const uint32_t*)s->d_sums);
-        TCHK(v, hipGetLastError());
+        TCHK(v, bb_scan32(st, (const uint32_t*)s->d_cnt, s->d_base, n_rows, s->d_sums, s->d_err + 2));
         uint32_t herr[4];
         TCHK(v, hipMemcpyAsync(herr, s->d_err, sizeof(herr), hipMemcpyDeviceToHost, st));
         TCHK(v, hipStreamSynchronize(st));
@@ -483,22 +436,32 @@ extern "C" int bb_trim_batch_dev(bb_ctx* ctx, const bb_row* d_rows, const bb_row
                            (const uint8_t*)s->d_is_flank, (const uint32_t*)s->d_part_rank, s->cfg, d_offsets, h->hdr_offsets, h->id_len,
                            h->desc_start, n_reads, s->d_cnt, (const uint32_t*)s->d_base, s->d_tmp, s->d_k0, d_status, s->d_err);
         hipLaunchKernelGGL(k_iota, dim3((n + 255) / 256), dim3(256), 0, st, s->d_v0, n);
-        size_t cub_bytes = 0;
-        TCHK(v, hipcub::DeviceRadixSort::SortPairs(nullptr, cub_bytes, (const uint32_t*)s->d_k0, s->d_k1, (const uint32_t*)s->d_v0, s->d_v1, (int)n, 0, 32, st));
-        if (cub_bytes > s->cap_cub || !s->d_cub) {
-            if (s->d_cub) (void)hipFree(s->d_cub);
-            s->d_cub = nullptr;
-            TCHK(v, hipMalloc(&s->d_cub, cub_bytes + 256));
-            s->cap_cub = cub_bytes + 256;
+        // stable sort of (label key, record index): the key is (part0 + 1) << 16 | (part1 + 1) with part < 2 * n_label_ids, so only
+        // the low digits of its two 16-bit fields can be occupied (SQK-NBD114-96: one 8-bit digit each, two passes)
+        uint32_t *k_sorted = nullptr, *v_sorted = nullptr;
+        {
+            uint32_t shifts[4];
+            int n_shifts = 0;
+            const uint32_t field_max = 2u * s->n_label_ids + 1u;
+            for (uint32_t f = 0; f < 2; ++f)
+                for (uint32_t sh = 0; sh < 16u && (field_max >> sh) != 0u; sh += 8u) shifts[n_shifts++] = 16u * f + sh;
+            const uint64_t ntiles = (n + BB_RS_TILE - 1) / BB_RS_TILE, hist_words = 256 * ntiles + 2 + (256 * ntiles) / 2048 + 4;
+            if (hist_words * 4 > s->cap_cub || !s->d_cub) {
+                if (s->d_cub) (void)hipFree(s->d_cub);
+                s->d_cub = nullptr;
+                TCHK(v, hipMalloc(&s->d_cub, hist_words * 4 + 256));
+                s->cap_cub = hist_words * 4 + 256;
+            }
+            uint32_t* d_hist = (uint32_t*)s->d_cub;
+            TCHK(v, bb_radix_sort_pairs(st, s->d_k0, s->d_v0, s->d_k1, s->d_v1, n, shifts, n_shifts, d_hist, d_hist + 256 * ntiles + 2, &k_sorted, &v_sorted));
         }
-        TCHK(v, hipcub::DeviceRadixSort::SortPairs(s->d_cub, cub_bytes, (const uint32_t*)s->d_k0, s->d_k1, (const uint32_t*)s->d_v0, s->d_v1, (int)n, 0, 32, st));
         const uint32_t gb = (n + 1023) / 1024;
         if ((r = tgrow(v, s->d_sums64, s->cap_sums64, (uint64_t)gb + 1))) return r;
         const uint64_t span_cap_int = std::max<uint64_t>(spans_cap, 65536);
         if ((r = tgrow(v, s->d_spans, s->cap_spans, span_cap_int))) return r;
         TCHK(v, hipMemsetAsync(s->d_nspans, 0, 4 * sizeof(uint64_t), st));
-        hipLaunchKernelGGL(k_trim_gather, dim3(gb), dim3(256), 0, st, (const bb_slice*)s->d_tmp, (const uint32_t*)s->d_v1, n, s->d_sorted, s->d_sums64);
-        hipLaunchKernelGGL(k_tscan_sums<uint64_t>, dim3(1), dim3(64), 0, st, s->d_sums64, gb, (uint64_t*)s->d_nspans + 1);
+        hipLaunchKernelGGL(k_trim_gather, dim3(gb), dim3(256), 0, st, (const bb_slice*)s->d_tmp, (const uint32_t*)v_sorted, n, s->d_sorted, s->d_sums64);
+        hipLaunchKernelGGL(k_scan_sums_t<uint64_t>, dim3(1), dim3(64), 0, st, s->d_sums64, gb, (uint64_t*)s->d_nspans + 1);
         hipLaunchKernelGGL(k_trim_offsets, dim3((n + 255) / 256), dim3(256), 0, st, s->d_sorted, n, (const uint64_t*)s->d_sums64, s->d_spans,
                            (uint32_t)s->cap_spans, s->d_nspans);
         TCHK(v, hipGetLastError());

@@ -149,17 +149,18 @@ BarcodeGroup BarcodeGroup::new_from_fasta(const std::string& fasta_file, Barcode
 }
 
 // ---- BarbellMatch -------------------------------------------------------------------------------
+static std::string csv_field(const std::string& x) {  // csv crate, QuoteStyle::Necessary (annotator.rs:246-251)
+    if (x.find_first_of("\t\"\n\r") == std::string::npos) return x;
+    std::string q = "\"";
+    for (char c : x) { if (c == '"') q += '"'; q += c; }
+    return q + "\"";
+}
 std::string BarbellMatch::to_tsv() const {
-    std::string id = read_id;
-    if (id.find_first_of("\t\"\n\r") != std::string::npos) {  // csv-crate quoting
-        std::string q = "\"";
-        for (char c : id) { if (c == '"') q += '"'; q += c; }
-        id = q + "\"";
-    }
+    const std::string id = csv_field(read_id);
     char buf[512];
     snprintf(buf, sizeof buf, "\t%zu\t%ld\t%zu\t%zu\t%zu\t%zu\t%zu\t%zu\t%s\t%d\t%d\t", read_len, rel_dist_to_end, read_start_bar,
              read_end_bar, read_start_flank, read_end_flank, bar_start, bar_end, as_str(match_type), flank_cost, barcode_cost);
-    return id + buf + label + "\t" + (strand_rc ? "Rc" : "Fwd") + "\t" + cuts;
+    return id + buf + csv_field(label) + "\t" + (strand_rc ? "Rc" : "Fwd") + "\t" + cuts;
 }
 
 // ---- filter patterns (pattern.rs) -----------------------------------------------------------------

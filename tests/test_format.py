@@ -39,11 +39,15 @@ def test_rendered_lines_equal_host_format(cfg):
     rows = dm.demux_ingested(batch, n)
     assert len(rows) > n // 2
     d_rows = dm.buf("rows").ptr
+    if cfg == "dual":  # labels come from FASTA headers: one the csv writer has to quote (delimiter, quote), like the ids above
+        tags = rows[(rows["group_idx"] == 0) & (rows["barcode_idx"] >= 0)]["barcode_idx"]
+        groups[0].labels[int(np.bincount(tags).argmax())] = 'bar"code\t7'
     fmt = RowFormatter(dm, groups)
     sids = [i.decode() for i in ids]
     text, nl = fmt.render(d_rows, len(rows), batch)
     want = "".join(l + "\n" for l in A.format_rows(rows, sids, groups)).encode()
     assert nl == len(rows) and text == want
+    assert cfg != "dual" or b'\t"bar""code\t7"\t' in text
     pats = F.kit_patterns("SQK-NBD114-96", True) if cfg == "nbd96" else [F.pattern_from_str("Ftag[fw, *, @left(0..250), >>]"),
                                                                            F.pattern_from_str("Ftag[fw, *, @left(0..250), >>]__Rtag[<<, fw, *, @right(0..250)]")]
     flt = F.Filter(dm, pats)
