@@ -467,6 +467,10 @@ typedef struct {
     uint32_t bar_lo, bar_hi, pad_lo, pad_hi, m_bar;
     uint8_t *pat_fwd, *pat_rc; /* n_seqs x m_bar ASCII */
     uint8_t type; int32_t flank_k, k1, k2; double perfect;
+    /* match masks of the bit-parallel timing path (bbo_annotate_batch_fast): bit j of word w <-> pattern character 64 w + j */
+    int W64;               /* 64-bit words of the flank */
+    uint64_t* fpeq[2];     /* [strand][16 text codes][W64]; strand 1 = complement(flank) */
+    uint64_t* bpeq[2];     /* [strand][n_seqs][16 text codes], padded barcodes (<= 64 characters) */
 } ogroup;
 
 struct bbo_ctx { uint32_t n_groups; ogroup* g; bb_params p; bb_policy pol; };
@@ -524,9 +528,28 @@ static int prep_group(const bb_policy* P, const bb_group_desc* d, ogroup* g) {
     uint8_t* perfect = (uint8_t*)calloc(lbar, 1);
     g->perfect = lodhi_pol(P, perfect, (int)lbar);
     free(perfect);
+    g->W64 = (int)((L + 63) / 64);
+    for (int st = 0; st < 2; ++st) {
+        g->fpeq[st] = (uint64_t*)calloc((size_t)16 * g->W64, sizeof(uint64_t));
+        for (uint32_t j = 0; j < L; ++j) {
+            uint8_t pc = text_code(g->flank[j]);
+            if (st) pc = comp_code(pc);
+            for (int code = 0; code < 16; ++code)
+                if (pc & code) g->fpeq[st][(size_t)code * g->W64 + (j >> 6)] |= 1ull << (j & 63);
+        }
+        g->bpeq[st] = NULL;
+        if (g->m_bar <= 64) {
+            g->bpeq[st] = (uint64_t*)calloc((size_t)n * 16, sizeof(uint64_t));
+            const uint8_t* pats = st ? g->pat_rc : g->pat_fwd;
+            for (uint32_t s2 = 0; s2 < n; ++s2)
+                for (uint32_t j = 0; j < g->m_bar; ++j)
+                    for (int code = 0; code < 16; ++code)
+                        if (text_code(pats[(size_t)s2 * g->m_bar + j]) & code) g->bpeq[st][(size_t)s2 * 16 + code] |= 1ull << j;
+        }
+    }
     return BB_OK;
 }
-static void free_group(ogroup* g) { free(g->flank); free(g->pat_fwd); free(g->pat_rc); }
+static void free_group(ogroup* g) { free(g->flank); free(g->pat_fwd); free(g->pat_rc); for (int st = 0; st < 2; ++st) { free(g->fpeq[st]); free(g->bpeq[st]); } }
 
 int bbo_create(const bb_group_desc* groups, uint32_t n_groups, const bb_params* params, bbo_ctx** out) {
     return bbo_create_policy(groups, n_groups, params, cur_pol(), out);
@@ -591,6 +614,130 @@ static int best_match_for_pattern(const bb_policy* P, const uint8_t* pcode, int 
     return bi >= 0;
 }
 
+/* ------------------------------------------------------------------------------------------ */
+/* Bit-parallel variants of scan_strand and best_match_for_pattern (Myers 1999 / Hyyro 2003, 64-bit words): the SAME    */
+/* results, computed a word of DP cells at a time.  They exist for ONE purpose: bench.py's cpu_baseline, so that the    */
+/* reported CPU figure is not a scalar O(m n) loop against a reference that runs AVX2 sassy.  They are checked against  */
+/* the scalar functions above (tests/test_oracle_fast.py) and are never what a parity test compares the GPU with.        */
+/* ------------------------------------------------------------------------------------------ */
+#define BBO_MAXW64 4
+/* one strand of the flank scan: end positions by the policy's local-minimum rule, exactly scan_strand's */
+static int scan_strand_fast(const bb_policy* P, const uint64_t* peq, int W, int m, const uint8_t* tcode, int n, int reverse, int k, float alpha,
+                            end_list* out) {
+    uint64_t pv[BBO_MAXW64], mv[BBO_MAXW64];
+    if (W > BBO_MAXW64) return 0;
+    for (int w = 0; w < W; ++w) { pv[w] = 0; mv[w] = 0; }
+    for (int j = 1; j <= m; ++j) {
+        const int dlt = alpha >= 0.f ? overhang_cost(P, alpha, j) - overhang_cost(P, alpha, j - 1) : 1;
+        if (dlt < 0 || dlt > 1) return 0;                         /* not a 0/1 column: the caller takes the scalar scan */
+        if (dlt) pv[(j - 1) >> 6] |= 1ull << ((j - 1) & 63);
+    }
+    int32_t score = alpha >= 0.f ? overhang_cost(P, alpha, m) : m;
+    const int TW = (m - 1) >> 6, TB = (m - 1) & 63;
+    lm_state st = {0, 0, 0, 0, P->lm_rule};
+    lm_step(&st, 0, score, k, out);
+    for (int i = 1; i <= n; ++i) {
+        const uint64_t* e = peq + (size_t)tcode[reverse ? n - i : i - 1] * W;
+        uint64_t carry = 0, pin = 0, min_ = 0;
+        for (int w = 0; w < W; ++w) {
+            const uint64_t eq = e[w], x = eq & pv[w];
+            const unsigned __int128 sum = (unsigned __int128)x + pv[w] + carry;
+            carry = (uint64_t)(sum >> 64);
+            const uint64_t d0 = (((uint64_t)sum ^ pv[w]) | eq | mv[w]);
+            const uint64_t ph = mv[w] | ~(d0 | pv[w]), mh = pv[w] & d0;
+            if (w == TW) score += (int32_t)((ph >> TB) & 1u) - (int32_t)((mh >> TB) & 1u);
+            const uint64_t phs = (ph << 1) | pin, mhs = (mh << 1) | min_;
+            pin = ph >> 63; min_ = mh >> 63;
+            pv[w] = mhs | ~(d0 | phs);
+            mv[w] = phs & d0;
+        }
+        lm_step(&st, i, score, k, out);
+    }
+    int last = n;
+    if (alpha >= 0.f) {
+        int32_t d = score;                                        /* D[m-o][n]: walk the last column's vertical deltas upwards */
+        for (int o = 1; o <= m; ++o) {
+            const int b = m - o;
+            d -= (int32_t)((pv[b >> 6] >> (b & 63)) & 1u) - (int32_t)((mv[b >> 6] >> (b & 63)) & 1u);
+            lm_step(&st, n + o, d + overhang_cost(P, alpha, o), k, out);
+        }
+        last = n + m;
+    }
+    lm_finish(&st, last, k, out);
+    return 1;
+}
+/* the flank search with bit-parallel scans; matches traced by trace_match like search_pol's */
+static int search_fast(const bb_policy* P, const ogroup* g, const uint8_t* tc, int n, float alpha, bbo_match** out) {
+    const int m = (int)g->flank_len, k = g->flank_k;
+    uint8_t* pc = (uint8_t*)malloc((size_t)m); uint8_t* pcc = (uint8_t*)malloc((size_t)m);
+    uint8_t* trv = (uint8_t*)malloc((size_t)(n ? n : 1));
+    for (int j = 0; j < m; ++j) { pc[j] = text_code(g->flank[j]); pcc[j] = comp_code(pc[j]); }
+    for (int i = 0; i < n; ++i) trv[i] = tc[n - 1 - i];
+    end_list ef = {0, 0, 0}, er = {0, 0, 0};
+    if (!scan_strand_fast(P, g->fpeq[0], g->W64, m, tc, n, 0, k, alpha, &ef)) { ef.n = 0; scan_strand(P, pc, m, tc, n, k, alpha, &ef); }
+    if (!scan_strand_fast(P, g->fpeq[1], g->W64, m, tc, n, 1, k, alpha, &er)) { er.n = 0; scan_strand(P, pcc, m, trv, n, k, alpha, &er); }
+    const int total = ef.n + er.n;
+    bbo_match* ms = (bbo_match*)calloc((size_t)(total ? total : 1), sizeof(bbo_match));
+    for (int t = 0; t < ef.n; ++t) {
+        trace_match(P, pc, m, tc, n, k, alpha, ef.v[t].e, ef.v[t].cost, &ms[t]);
+        ms[t].strand = BB_FWD; ms[t].rc_text_len = n;
+    }
+    for (int t = 0; t < er.n; ++t) {
+        bbo_match* mm = &ms[ef.n + (P->rc_order == BB_RC_FWD_ORDER ? er.n - 1 - t : t)];
+        trace_match(P, pcc, m, trv, n, k, alpha, er.v[t].e, er.v[t].cost, mm);
+        const int ts = mm->text_start, te = mm->text_end;
+        mm->text_start = n - te; mm->text_end = n - ts;
+        mm->strand = BB_RC; mm->rc_text_len = n;
+    }
+    free(ef.v); free(er.v); free(pc); free(pcc); free(trv);
+    *out = ms;
+    return total;
+}
+/* best_match_for_pattern on one 64-bit word (m <= 64, window <= BB_FAST_MAXWIN columns), default traceback preference: the
+ * forward pass keeps the preferred move of every cell as two bit planes (Match: d0 & eq; else Ins: ph; else Sub: ~d0; else
+ * Del — trace_match's order), the walk back reads them */
+#define BB_FAST_MAXWIN 160
+static int best_match_for_pattern_fast(const bb_policy* P, const uint64_t* peq16, int m, const uint8_t* wcode, int wn, int k, bbo_match* best) {
+    uint64_t lo[BB_FAST_MAXWIN + 1], hi[BB_FAST_MAXWIN + 1];
+    uint64_t pv = m >= 64 ? ~0ull : ((1ull << m) - 1ull), mv = 0;
+    int32_t score = m, prev = m, best_cost = 0x7FFFFFFF, best_pos = -1, cand = 0;
+    int dec = 1;
+    const int TB = m - 1;
+    for (int c = 1; c <= wn; ++c) {
+        const uint64_t eq = peq16[wcode[c - 1]], x = eq & pv;
+        const uint64_t d0 = (((x + pv) ^ pv) | eq | mv);
+        const uint64_t ph = mv | ~(d0 | pv), mh = pv & d0;
+        const uint64_t isM = d0 & eq, l = ~(isM | ph);
+        lo[c] = l; hi[c] = (ph & ~isM) | (l & d0);
+        score += (int32_t)((ph >> TB) & 1u) - (int32_t)((mh >> TB) & 1u);
+        const uint64_t phs = ph << 1, mhs = mh << 1;
+        pv = mhs | ~(d0 | phs); mv = phs & d0;
+        if (score > prev) {                                                            /* lm_step + searcher.rs:294-300 in one */
+            if (dec && prev <= k && (prev < best_cost || (P->bar_tie == BB_TIE_LAST && prev == best_cost))) { best_cost = prev; best_pos = P->lm_rule == BB_LM_PLATEAU_LEFT ? cand : c - 1; }
+            dec = 0;
+        } else if (score < prev) { dec = 1; cand = c; }
+        else if (P->lm_rule == BB_LM_STRICT) dec = 0;
+        prev = score;
+    }
+    if (dec && prev <= k && (prev < best_cost || (P->bar_tie == BB_TIE_LAST && prev == best_cost))) { best_cost = prev; best_pos = P->lm_rule == BB_LM_PLATEAU_LEFT ? cand : wn; }
+    if (best_pos < 0) return 0;
+    uint8_t rev[64 + BB_FAST_MAXWIN + 2];
+    int nops = 0, j = m, i = best_pos;
+    while (j > 0) {
+        uint8_t op = BBO_DEL;
+        if (i > 0) op = (uint8_t)(((lo[i] >> (j - 1)) & 1u) | (((hi[i] >> (j - 1)) & 1u) << 1));
+        rev[nops++] = op;
+        if (op != BBO_INS) --j;
+        if (op != BBO_DEL) --i;
+    }
+    memset(best, 0, sizeof(*best));
+    best->pattern_start = 0; best->pattern_end = m; best->text_start = i; best->text_end = best_pos;
+    best->cost = best_cost; best->n_ops = nops; best->strand = BB_FWD; best->rc_text_len = wn;
+    best->ops = (uint8_t*)malloc((size_t)(nops ? nops : 1));
+    for (int t = 0; t < nops; ++t) best->ops[t] = rev[nops - 1 - t];
+    return 1;
+}
+
 typedef struct { bb_row* v; int n, cap; } row_list;
 static void row_push(row_list* l, const bb_row* r) {
     if (l->n == l->cap) { l->cap = l->cap ? 2 * l->cap : 8; l->v = (bb_row*)realloc(l->v, sizeof(bb_row) * (size_t)l->cap); }
@@ -612,14 +759,15 @@ static void push_flank_only(row_list* rows, uint32_t read_idx, uint32_t read_len
 }
 
 /* Demuxer::demux (searcher.rs:430-490) for one read; rows appended to `rows` (already collapsed) */
-static void demux_read(const bbo_ctx* c, uint32_t read_idx, const uint8_t* read, uint32_t n, row_list* rows) {
+static void demux_read(const bbo_ctx* c, uint32_t read_idx, const uint8_t* read, uint32_t n, row_list* rows, int fast) {
     int first_row = rows->n;
     uint8_t* rcode = (uint8_t*)malloc(n ? n : 1);
     for (uint32_t i = 0; i < n; ++i) rcode[i] = text_code(read[i]);
     for (uint32_t gi = 0; gi < c->n_groups; ++gi) {                                   /* :433 */
         const ogroup* g = &c->g[gi];
         bbo_match* fms = NULL;
-        int nfm = search_pol(&c->pol, g->flank, (int)g->flank_len, read, (int)n, g->flank_k, c->p.alpha, 1, &fms); /* :438 */
+        int nfm = fast && g->W64 <= BBO_MAXW64 ? search_fast(&c->pol, g, rcode, (int)n, c->p.alpha, &fms)
+                                                 : search_pol(&c->pol, g->flank, (int)g->flank_len, read, (int)n, g->flank_k, c->p.alpha, 1, &fms); /* :438 */
         for (int f = 0; f < nfm; ++f) {                                               /* :440 */
             const bbo_match* fm = &fms[f];
             int lo, hi;
@@ -639,7 +787,10 @@ static void demux_read(const bbo_ctx* c, uint32_t read_idx, const uint8_t* read,
                 for (uint32_t p = 0; p < g->n_seqs; ++p) {
                     for (int j = 0; j < m; ++j) pcode[j] = text_code(pats[(size_t)p * m + j]);
                     if (has[p]) { free(best[p].ops); best[p].ops = NULL; has[p] = 0; }
-                    has[p] = (uint8_t)best_match_for_pattern(&c->pol, pcode, m, wcode, wn, k, &best[p]);
+                    if (fast && g->bpeq[fm->strand] && wn <= BB_FAST_MAXWIN && bb_policy_trace_is_default(&c->pol))
+                        has[p] = (uint8_t)best_match_for_pattern_fast(&c->pol, g->bpeq[fm->strand] + (size_t)p * 16, m, wcode, wn, k, &best[p]);
+                    else
+                        has[p] = (uint8_t)best_match_for_pattern(&c->pol, pcode, m, wcode, wn, k, &best[p]);
                     matched += has[p];
                 }
                 if (matched <= 1 && g->k1 < g->k2 && pass == 0) k = g->k2; else break; /* :303-306 */
@@ -693,8 +844,18 @@ static void demux_read(const bbo_ctx* c, uint32_t read_idx, const uint8_t* read,
     rows->n = first_row + bbo_collapse(rows->v + first_row, rows->n - first_row, 0.8f); /* :489 */
 }
 
+static int annotate_batch_impl(bbo_ctx* c, const uint8_t* bases, const uint64_t* offsets, uint32_t n_reads,
+                               bb_row* rows, uint64_t rows_cap, uint64_t* n_rows, int n_threads, int fast);
 int bbo_annotate_batch(bbo_ctx* c, const uint8_t* bases, const uint64_t* offsets, uint32_t n_reads,
                        bb_row* rows, uint64_t rows_cap, uint64_t* n_rows, int n_threads) {
+    return annotate_batch_impl(c, bases, offsets, n_reads, rows, rows_cap, n_rows, n_threads, 0);
+}
+int bbo_annotate_batch_fast(bbo_ctx* c, const uint8_t* bases, const uint64_t* offsets, uint32_t n_reads,
+                            bb_row* rows, uint64_t rows_cap, uint64_t* n_rows, int n_threads) {
+    return annotate_batch_impl(c, bases, offsets, n_reads, rows, rows_cap, n_rows, n_threads, 1);
+}
+static int annotate_batch_impl(bbo_ctx* c, const uint8_t* bases, const uint64_t* offsets, uint32_t n_reads,
+                               bb_row* rows, uint64_t rows_cap, uint64_t* n_rows, int n_threads, int fast) {
     if (!c || (!bases && n_reads) || !offsets || !n_rows) return BB_E_INVALID;
     row_list* per = (row_list*)calloc(n_reads ? n_reads : 1, sizeof(row_list));
 #ifdef _OPENMP
@@ -702,7 +863,7 @@ int bbo_annotate_batch(bbo_ctx* c, const uint8_t* bases, const uint64_t* offsets
 #pragma omp parallel for schedule(dynamic, 16) num_threads(n_threads)
 #endif
     for (long i = 0; i < (long)n_reads; ++i)
-        demux_read(c, (uint32_t)i, bases + offsets[i], (uint32_t)(offsets[i + 1] - offsets[i]), &per[i]);
+        demux_read(c, (uint32_t)i, bases + offsets[i], (uint32_t)(offsets[i + 1] - offsets[i]), &per[i], fast);
     (void)n_threads;
     uint64_t total = 0;
     for (uint32_t i = 0; i < n_reads; ++i) total += (uint64_t)per[i].n;

@@ -81,6 +81,11 @@ int  bbo_group_get_pattern(const bbo_ctx* ctx, uint32_t group, uint32_t idx, int
  * like the reference's one Demuxer per paraseq worker, annotator.rs:88-101). */
 int  bbo_annotate_batch(bbo_ctx* ctx, const uint8_t* bases, const uint64_t* offsets, uint32_t n_reads,
                         bb_row* rows, uint64_t rows_cap, uint64_t* n_rows, int n_threads);
+/* The same rows from bit-parallel scans (64-bit Myers / Hyyro words instead of scalar DP cells).  TIMING ONLY: bench.py's
+ * cpu_baseline reports it so the CPU figure is not a scalar loop against a reference that runs AVX2 sassy; the parity tests
+ * compare the GPU with bbo_annotate_batch, and tests/test_oracle_fast.py compares this function with it. */
+int  bbo_annotate_batch_fast(bbo_ctx* ctx, const uint8_t* bases, const uint64_t* offsets, uint32_t n_reads,
+                             bb_row* rows, uint64_t rows_cap, uint64_t* n_rows, int n_threads);
 /* filter step on a row stream (filter.rs:183-214 check_filter_pass, pattern.rs:96-240 match_pattern);
  * rows grouped by consecutive read_idx like the reference groups by consecutive read_id (filter.rs:54-85) */
 int  bbo_filter_rows(const bbo_ctx* ctx, const bb_pattern* patterns, uint32_t n_patterns, const uint32_t* label_ids,

@@ -67,6 +67,7 @@ def lib():
         L.bbo_group_get_pattern.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_char_p]
         L.bbo_annotate_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64,
                                          C.POINTER(C.c_uint64), C.c_int]
+        L.bbo_annotate_batch_fast.argtypes = L.bbo_annotate_batch.argtypes
         L.bbo_set_full_trace.argtypes = [C.c_int]
         L.bbo_filter_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
         L.bbo_trim_batch.argtypes = [C.c_void_p] * 7 + [C.c_uint64] + [C.c_void_p] * 4 + [C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p,
@@ -223,7 +224,8 @@ class Oracle:
         assert lib().bbo_group_get_pattern(self.h, g, idx, int(rc), buf) == 0
         return buf.raw
 
-    def annotate(self, bases, offsets, n_threads=1):
+    def annotate(self, bases, offsets, n_threads=1, fast=False):
+        """fast=True: the bit-parallel timing path (bench.py's cpu_baseline); same rows"""
         bases = np.ascontiguousarray(bases, dtype=np.uint8)
         offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
         n = len(offsets) - 1
@@ -231,8 +233,8 @@ class Oracle:
         while True:
             rows = np.zeros(cap, dtype=_abi.ROW_DTYPE)
             nr = C.c_uint64()
-            rc = lib().bbo_annotate_batch(self.h, bases.ctypes.data, offsets.ctypes.data, n, rows.ctypes.data, cap,
-                                          C.byref(nr), n_threads)
+            fn = lib().bbo_annotate_batch_fast if fast else lib().bbo_annotate_batch
+            rc = fn(self.h, bases.ctypes.data, offsets.ctypes.data, n, rows.ctypes.data, cap, C.byref(nr), n_threads)
             if rc == _abi.BB_E_CAPACITY:
                 cap = int(nr.value)
                 continue
