@@ -197,6 +197,13 @@ class Demuxer:
         L = lib()
         return {L.bb_kernel_name(k).decode(): L.bb_last_kernel_ms(self._ctx(), k) for k in range(L.bb_n_kernels())}
 
+    def scan_stats(self, g=0):
+        """how the flank scan of group g ran on the last batch: {flagged_pieces, total_pieces, kind}; kind 0 = full scan, 1 = filter +
+        verification, 2 = the filter flagged too much of the batch and the full scan took over (bb_last_scan_stats)"""
+        f, t, k = C.c_uint64(), C.c_uint64(), C.c_int()
+        self._check(lib().bb_last_scan_stats(self._ctx(), g, C.byref(f), C.byref(t), C.byref(k)))
+        return {"flagged_pieces": f.value, "total_pieces": t.value, "kind": k.value}
+
     # -- synthetic reads -----------------------------------------------------------------------
     def synth_dev(self, seed, len_min, len_max, first_read, n, d_offsets, d_bases):
         self._check(lib().bb_synth_reads_dev(self._ctx(), seed, len_min, len_max, first_read, n, d_offsets, d_bases))

@@ -155,6 +155,10 @@ struct bb_ctx {
     uint32_t *d_hitcount = nullptr, *d_lists = nullptr, *d_listcnt = nullptr;
     uint32_t *d_fb_lists = nullptr, *d_fbcnt = nullptr;  // hits the fast barcode kernel's bounds left undecided, per (group, strand)
     uint32_t* d_vqueue = nullptr;  // k_flank_verify's item counters (one per strand)
+    unsigned long long* d_nflag = nullptr;  // flagged 16-byte pieces of the batch in hand, per group (k_flank_filter)
+    double adapt_frac = 0.13;    // BARBELL_AMD_ADAPT_FRAC: flagged fraction of a batch's pieces above which the full scan takes over
+    uint64_t last_flagged[BB_MAX_GROUPS]{}, last_pieces[BB_MAX_GROUPS]{};
+    uint8_t last_scan_kind[BB_MAX_GROUPS]{};  // 0 full scan, 1 filter + verification, 2 filter, then the full scan (too many flags)
     uint32_t* d_flags = nullptr; uint64_t cap_flags = 0;  // filtered scan: one bit per 32 text bytes and strand (k_flank_filter)
     int scan_filter = -1;        // BARBELL_AMD_SCAN_FILTER: 0 never, 1 wherever it is valid (tests), unset: where the prefix says enough
     bool fast_path = true;       // BARBELL_AMD_NO_FAST=1: score every barcode of every hit exactly (the fallback kernel only)
@@ -424,6 +428,7 @@ int upload_tables(bb_ctx* c) {
     HIPCHK(c, hipMalloc((void**)&c->d_listcnt, sizeof(uint32_t) * 4 * BB_MAX_GROUPS));
     HIPCHK(c, hipMalloc((void**)&c->d_fbcnt, sizeof(uint32_t) * 4 * BB_MAX_GROUPS));
     HIPCHK(c, hipMalloc((void**)&c->d_vqueue, sizeof(uint32_t) * 4));
+    HIPCHK(c, hipMalloc((void**)&c->d_nflag, sizeof(unsigned long long) * BB_MAX_GROUPS));
     // synth tables
     std::vector<std::vector<std::string>> seqs;
     for (auto& g : c->groups) seqs.push_back(g.seqs);
@@ -488,15 +493,32 @@ int scan_u32(bb_ctx* c, const uint32_t* in, uint32_t* out, uint64_t n) {
 }
 
 template <int W>
-void launch_scan(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n, uint32_t g, uint64_t flag_words) {
+void launch_scan(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n, uint32_t g, uint64_t flag_words, uint64_t batch_bytes) {
+    c->last_scan_kind[g] = 0; c->last_flagged[g] = 0; c->last_pieces[g] = 2 * ((batch_bytes + 15) / 16);
     if (c->gdev[g].filt_rows > 0) {
         (void)hipMemsetAsync(c->d_flags, 0, (size_t)2 * flag_words * sizeof(uint32_t), c->stream);  // the filter writes the words that hold a flag
+        (void)hipMemsetAsync(c->d_nflag + g, 0, sizeof(unsigned long long), c->stream);
         if (c->gdev[g].filt_mode & BB_FILT_WIDE)
             hipLaunchKernelGGL(k_flank_filter<true>, dim3((n + 255) / 256), dim3(256), 0, c->stream, d_bases, d_offsets, n, (const uint8_t*)c->d_tables,
-                               (const bb_group_dev*)c->d_groups, g, c->d_flags, flag_words);
+                               (const bb_group_dev*)c->d_groups, g, c->d_flags, flag_words, c->d_nflag + g);
         else
             hipLaunchKernelGGL(k_flank_filter<false>, dim3((n + 255) / 256), dim3(256), 0, c->stream, d_bases, d_offsets, n, (const uint8_t*)c->d_tables,
-                               (const bb_group_dev*)c->d_groups, g, c->d_flags, flag_words);
+                               (const bb_group_dev*)c->d_groups, g, c->d_flags, flag_words, c->d_nflag + g);
+        // The choice made at bb_create on pseudo-random text is re-made on the batch in hand: the verification's cost grows with
+        // the number of flagged pieces (each costs its columns plus m + k of lead-in; low-complexity text, adapter-like decoys
+        // and chimeric reads flag many), the full scan's does not.  Above the break-even (measured: DESIGN.md §4) the flags are
+        // dropped and the full-height streaming scan does the batch.
+        unsigned long long nf = 0;
+        (void)hipMemcpyAsync(&nf, c->d_nflag + g, sizeof(nf), hipMemcpyDeviceToHost, c->stream);
+        (void)hipStreamSynchronize(c->stream);
+        c->last_flagged[g] = nf; c->last_scan_kind[g] = 1;
+        if (c->scan_filter != 1 && (double)nf > c->adapt_frac * (double)c->last_pieces[g]) {
+            c->last_scan_kind[g] = 2;
+            hipLaunchKernelGGL(k_flank_scan2<W>, dim3((n + 255) / 256, 2), dim3(256), 0, c->stream, d_bases, d_offsets, n,
+                               (const uint8_t*)c->d_tables, (const bb_group_dev*)c->d_groups, g, (uint32_t)c->groups.size(), c->d_cnt,
+                               c->d_raw, c->cap_hits, c->d_hitcount);
+            return;
+        }
         (void)hipMemsetAsync(c->d_vqueue, 0, 2 * sizeof(uint32_t), c->stream);
         const uint32_t vblocks = std::min((n + 255u) / 256u, (uint32_t)c->n_cus * 3u);  // persistent: lanes draw (read, strand) items from a queue
         hipLaunchKernelGGL(k_flank_verify<W>, dim3(vblocks, 2), dim3(256), 0, c->stream, d_bases, d_offsets, n,
@@ -725,6 +747,7 @@ int bb_create_policy(const bb_group_desc* groups, uint32_t n_groups, const bb_pa
     if (getenv("BARBELL_AMD_SCAN_FILTER")) c->scan_filter = atoi(getenv("BARBELL_AMD_SCAN_FILTER")) != 0 ? 1 : 0;
     if (getenv("BARBELL_AMD_NO_FAST") && atoi(getenv("BARBELL_AMD_NO_FAST")) != 0) c->fast_path = false;
     if (getenv("BARBELL_AMD_FAST_MARGIN")) c->fast_margin = atof(getenv("BARBELL_AMD_FAST_MARGIN"));
+    if (getenv("BARBELL_AMD_ADAPT_FRAC")) c->adapt_frac = atof(getenv("BARBELL_AMD_ADAPT_FRAC"));
     if (getenv("BARBELL_AMD_PFX_THREADS")) { int t = atoi(getenv("BARBELL_AMD_PFX_THREADS")); if (t >= 64 && t <= 768) c->pfx_threads = (uint32_t)t; }
     if (getenv("BARBELL_AMD_REG_THREADS")) { int t = atoi(getenv("BARBELL_AMD_REG_THREADS")); if (t >= 64 && t <= 512) c->reg_threads = (uint32_t)t; }
     c->groups.resize(n_groups);
@@ -766,7 +789,7 @@ void bb_destroy(bb_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     void* ptrs[] = {c->d_groups, c->d_tables, c->d_counts, c->d_cnt, c->d_base, c->d_sums, c->d_nrows, c->d_rowoff, c->d_hitcount,
-                    c->d_lists, c->d_listcnt, c->d_fb_lists, c->d_fbcnt, c->d_flags, c->d_vqueue, c->d_raw, c->d_hits, c->d_pfx, c->d_rows, c->d_in_bases, c->d_in_offsets, c->d_out_rows,
+                    c->d_lists, c->d_listcnt, c->d_fb_lists, c->d_fbcnt, c->d_flags, c->d_vqueue, c->d_nflag, c->d_raw, c->d_hits, c->d_pfx, c->d_rows, c->d_in_bases, c->d_in_offsets, c->d_out_rows,
                     c->d_synth_table, c->d_fpats, c->d_felems, c->d_flabel_ok, c->d_flabel_ids, c->d_frows, c->d_fout, c->d_iout};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -815,7 +838,7 @@ int bb_annotate_batch_dev(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_o
     if ((r = ensure_hits(c, (uint64_t)n * 3 + 1024))) return r;
     const uint64_t M = (uint64_t)n * G * 2 + 1;
     uint32_t n_hits = 0;
-    uint64_t flag_words = 0;  // per strand
+    uint64_t flag_words = 0, batch_bytes = (uint64_t)n * 4000;  // per strand; the byte span is read below where the filter needs it
     {
         bool any_filt = false;
         for (uint32_t g = 0; g < G; ++g) any_filt = any_filt || c->gdev[g].filt_rows > 0;
@@ -826,6 +849,7 @@ int bb_annotate_batch_dev(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_o
             HIPCHK(c, hipStreamSynchronize(c->stream));
             if (ends[1] < ends[0]) { c->last_error = "offsets are not ascending"; return BB_E_INVALID; }
             flag_words = ((ends[1] - ends[0]) >> 9) + 3ull * n + 3;
+            batch_bytes = ends[1] - ends[0];
             if ((r = grow(c, c->d_flags, c->cap_flags, 2 * flag_words))) return r;
         }
     }
@@ -835,14 +859,14 @@ int bb_annotate_batch_dev(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_o
         HIPCHK(c, hipMemsetAsync(c->d_cnt + (M - 1), 0, 4, c->stream));
         for (uint32_t g = 0; g < G; ++g) {
             switch (c->gdev[g].W) {
-                case 1: launch_scan<1>(c, d_bases, d_offsets, n, g, flag_words); break;
-                case 2: launch_scan<2>(c, d_bases, d_offsets, n, g, flag_words); break;
-                case 3: launch_scan<3>(c, d_bases, d_offsets, n, g, flag_words); break;
-                case 4: launch_scan<4>(c, d_bases, d_offsets, n, g, flag_words); break;
-                case 5: launch_scan<5>(c, d_bases, d_offsets, n, g, flag_words); break;
-                case 6: launch_scan<6>(c, d_bases, d_offsets, n, g, flag_words); break;
-                case 7: launch_scan<7>(c, d_bases, d_offsets, n, g, flag_words); break;
-                default: launch_scan<8>(c, d_bases, d_offsets, n, g, flag_words); break;
+                case 1: launch_scan<1>(c, d_bases, d_offsets, n, g, flag_words, batch_bytes); break;
+                case 2: launch_scan<2>(c, d_bases, d_offsets, n, g, flag_words, batch_bytes); break;
+                case 3: launch_scan<3>(c, d_bases, d_offsets, n, g, flag_words, batch_bytes); break;
+                case 4: launch_scan<4>(c, d_bases, d_offsets, n, g, flag_words, batch_bytes); break;
+                case 5: launch_scan<5>(c, d_bases, d_offsets, n, g, flag_words, batch_bytes); break;
+                case 6: launch_scan<6>(c, d_bases, d_offsets, n, g, flag_words, batch_bytes); break;
+                case 7: launch_scan<7>(c, d_bases, d_offsets, n, g, flag_words, batch_bytes); break;
+                default: launch_scan<8>(c, d_bases, d_offsets, n, g, flag_words, batch_bytes); break;
             }
         }
         HIPCHK(c, hipGetLastError());
@@ -1078,6 +1102,13 @@ int bb_counts_reset(bb_ctx* c) {
     return BB_OK;
 }
 
+int bb_last_scan_stats(const bb_ctx* c, uint32_t g, uint64_t* flagged_pieces, uint64_t* total_pieces, int* kind) {
+    if (!c || g >= c->groups.size()) return BB_E_INVALID;
+    if (flagged_pieces) *flagged_pieces = c->last_flagged[g];
+    if (total_pieces) *total_pieces = c->last_pieces[g];
+    if (kind) *kind = c->last_scan_kind[g];
+    return BB_OK;
+}
 int bb_n_kernels(void) { return K_COUNT; }
 const char* bb_kernel_name(int k) { return k >= 0 && k < K_COUNT ? kKernelNames[k] : ""; }
 float bb_last_kernel_ms(const bb_ctx* c, int k) { return c && k >= 0 && k < K_COUNT ? c->ms[k] : 0.f; }

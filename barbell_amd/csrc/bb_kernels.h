@@ -604,7 +604,7 @@ __device__ __forceinline__ uint64_t filt_word_base(uint64_t off, uint64_t off0, 
 template <bool WIDE>
 __global__ __launch_bounds__(256) void k_flank_filter(const uint8_t* __restrict__ bases, const uint64_t* __restrict__ offsets, uint32_t n_reads,
                                                       const uint8_t* __restrict__ tables, const bb_group_dev* __restrict__ groups, uint32_t g,
-                                                      uint32_t* __restrict__ flags, uint64_t words_per_strand) {
+                                                      uint32_t* __restrict__ flags, uint64_t words_per_strand, unsigned long long* __restrict__ n_flagged) {
     __shared__ uint32_t s_fpeq[WIDE ? 512 : 256];
     __shared__ __attribute__((aligned(16))) uint4 s_lines[4][BB_SCAN_LQ * 64];
     static_assert(BB_SCAN_LQ == 8u, "piece bits assume 128-byte lines");
@@ -661,7 +661,7 @@ __global__ __launch_bounds__(256) void k_flank_filter(const uint8_t* __restrict_
     uint32_t scB = (uint32_t)(R + bias);
     uint32_t keep = WIDE ? sc2 | ~0x20u : sc2 | ~0x00100010u;  // column 0 counts for the first piece
     uint32_t keepB = scB | ~0x20u;
-    uint32_t bitsA = 0u, bitsB = 0u;
+    uint32_t bitsA = 0u, bitsB = 0u, nflag = 0u;
     auto step = [&](uint32_t chr) {
         if constexpr (WIDE) {
             const uint2 e2 = *reinterpret_cast<const uint2*>(s_fpeq + 2u * chr);
@@ -752,8 +752,15 @@ __global__ __launch_bounds__(256) void k_flank_filter(const uint8_t* __restrict_
         if (on && ((l & 3u) == 3u || l + 1u == nlines)) {
             if (bitsA) fl0[l >> 2] = bitsA;  // the array is zeroed before the launch: only words with a flag are written
             if (bitsB) fl1[l >> 2] = bitsB;
+            nflag += (uint32_t)__popc(bitsA) + (uint32_t)__popc(bitsB);
             bitsA = 0u; bitsB = 0u;
         }
+    }
+    {   // flagged pieces of the batch (both strands): the host compares them with the break-even of the windowed verification
+        uint32_t t = nflag;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) t += (uint32_t)__shfl_xor((int)t, d, 64);
+        if (lane == 0u && t) atomicAdd(n_flagged, (unsigned long long)t);
     }
     // Matches of the rc strand that hang over ITS start (the read's last bytes) with o < R rows: rows o..R-1 of the window
     // end at the read's end, i.e. the rc block's first R-o rows do in its last column: D[R-o][n] + floor(alpha * o) <= k is

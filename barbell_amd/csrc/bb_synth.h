@@ -18,6 +18,14 @@ struct bb_synth_params {
     bb_synth_group g[BB_MAX_GROUPS];
 };
 
+// Stress mixes (bench.py `stress`, tests): the top byte of the seed selects what the read bodies and the read mix look like —
+// the filtered flank scan's cost depends on how often unrelated text comes within k edits of a window of the flank.
+#define BB_SYNTH_MODE(seed) ((uint32_t)((seed) >> 56))
+#define BB_SYNTH_LOWCPLX 1u    // ~30 % of every body is homopolymer / dinucleotide runs of 20..60 nt
+#define BB_SYNTH_DECOYS 2u     // a near-copy (2-3 substitutions) of the constructs' shared prefix every ~200 nt
+#define BB_SYNTH_ARTEFACTS 3u  // the artefact class (a second barcode mid-read) raised from 5 % to 50 % of the reads
+#define BB_SYNTH_DECOYS_DENSE 4u  // the same near-copies every ~60 nt: most 16-byte pieces near a flagged one
+
 struct bb_rng {
     uint64_t s;
     BB_HD uint64_t next() {
@@ -76,7 +84,32 @@ BB_HD void bb_synth_fill(const bb_synth_params& P, const uint8_t* table, uint64_
         uint32_t lim = L - p < 32 ? L - p : 32;
         for (uint32_t q = 0; q < lim; ++q) out[p + q] = (uint8_t)ACGT[(r >> (2 * q)) & 3];
     }
+    const uint32_t mode = BB_SYNTH_MODE(P.seed);
+    if (mode == BB_SYNTH_LOWCPLX) {
+        for (uint32_t p = 0; p < L;) {
+            uint64_t r = rng.next();
+            const uint32_t gap = 40u + (uint32_t)(r % 100u), run = 20u + (uint32_t)((r >> 8) % 41u);   // mean 90 random, 40 repeat
+            p += gap;
+            const uint8_t a = (uint8_t)ACGT[(r >> 16) & 3], b = ((r >> 20) & 1) ? (uint8_t)ACGT[(r >> 18) & 3] : a;
+            for (uint32_t q = 0; q < run && p + q < L; ++q) out[p + q] = (q & 1) ? b : a;
+            p += run;
+        }
+    } else if (mode == BB_SYNTH_DECOYS || mode == BB_SYNTH_DECOYS_DENSE) {
+        const uint8_t* s0 = table + P.g[0].off;
+        const uint8_t* s1 = s0 + P.g[0].seq_len;
+        uint32_t lcp = 0;
+        while (lcp < P.g[0].seq_len && s0[lcp] == s1[lcp]) ++lcp;
+        if (lcp >= 6) {
+            for (uint32_t p = 100; p + lcp < L;) {
+                uint64_t r = rng.next();
+                for (uint32_t q = 0; q < lcp; ++q) out[p + q] = ((r >> 32) & 1) ? bb_comp_ascii(s0[lcp - 1 - q]) : s0[q];
+                for (uint32_t e = 0; e < 2u + (uint32_t)((r >> 33) & 1); ++e) out[p + (uint32_t)((r >> (8 * e)) & 0xFF) % lcp] = (uint8_t)ACGT[(r >> (24 + 2 * e)) & 3];
+                p += mode == BB_SYNTH_DECOYS ? 150u + (uint32_t)((r >> 40) % 100u) : 40u + (uint32_t)((r >> 40) % 40u);
+            }
+        }
+    }
     uint32_t cls = (uint32_t)(rng.next() % 100u);
+    if (mode == BB_SYNTH_ARTEFACTS && cls >= 45 && cls < 90) cls = 97;  // 45 % of the 80 + 10 classes become artefacts
     uint32_t g5 = 0, g3 = P.n_groups > 1 ? 1 : 0;
     bool rc3 = P.n_groups == 1;
     uint32_t b1 = (uint32_t)(rng.next() % P.g[g5].n_seqs);

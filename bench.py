@@ -46,6 +46,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
+    ap.add_argument("--no-stress", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N>1 (nccl = RCCL over xGMI; gloo only for single-GPU dry runs)")
@@ -184,6 +185,10 @@ def main():
         if world == 1 and args.config == "nbd96" and not args.no_other_configs:
             # BASELINE configs[3] / configs[4] (driver-run numbers for the other query geometries; `value` stays configs[1])
             out["other_configs"] = {c: other_config_leg(c, dev_idx, dev, L, args) for c in ("dual", "rbk96x")}
+        if world == 1 and args.config == "nbd96" and not args.no_stress:
+            # the same pipeline where the filtered scan's assumption (unrelated text rarely comes within k edits of a flank window)
+            # is strained; outside `value`
+            out["stress"] = {name: stress_leg(mode, dev_idx, dev, L, args) for name, mode in (("low_complexity_30pct", 1), ("prefix_decoys_every_200nt", 2), ("artefacts_50pct", 3), ("prefix_decoys_every_60nt", 4))}
         if world == 1 and args.config == "nbd96" and not args.no_e2e:
             out["e2e_step"] = e2e_leg(d_bases, min(n_res, 4_000_000), L, dev)
         if world == 1 and not args.no_cpu_baseline:
@@ -243,6 +248,50 @@ def other_config_leg(cfg, dev_idx, dev, L, args, n=1_000_000, steps=3):
             rows += len(want)
         out["parity_on_sample"] = bool(ok)
         out["sample"] = f"first and last {w} reads of the batch against the CPU oracle ({rows} rows)"
+    dm.close()
+    return out
+
+
+def stress_leg(mode, dev_idx, dev, L, args, n=1_000_000, steps=3):
+    """SQK-NBD114-96 on reads whose bodies / read mix strain the filtered flank scan (bb_synth.h: the seed's top byte selects the mix):
+    reads/s, how much of the batch the filter flagged, which scan ran (bb_last_scan_stats), the scan stage's time, and a parity sample."""
+    from barbell_amd import _abi
+    from barbell_amd import annotate as A
+    from oracle import pyoracle as po
+    from tests.common import config_groups
+
+    groups = config_groups("nbd96")
+    dm = A.Demuxer(device=dev_idx)
+    for g in groups:
+        dm.add_query_group(g)
+    seed = (mode << 56) | (0xBA7BE11 ^ 2)
+    d_off = torch.arange(0, n + 1, dtype=torch.int64, device=dev) * L
+    d_bases = torch.empty(n * L, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    dm.synth_dev(seed, L, L, 0, n, d_off.data_ptr(), d_bases.data_ptr())
+    cap = 6 * n
+    d_rows = torch.empty(cap * 48, dtype=torch.uint8, device=dev)
+    nr = dm.demux_dev(d_bases.data_ptr(), d_off.data_ptr(), n, d_rows.data_ptr(), cap)
+    dm.set_timing(True)
+    kms = {}
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        nr = dm.demux_dev(d_bases.data_ptr(), d_off.data_ptr(), n, d_rows.data_ptr(), cap)
+        for k, v in dm.kernel_ms().items():
+            kms[k] = kms.get(k, 0.0) + v / steps
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    st = dm.scan_stats(0)
+    out = {"reads_per_s": n / dt, "ms_per_step": dt * 1e3, "reads": n, "rows_per_step": nr, "flagged_fraction": st["flagged_pieces"] / max(1, st["total_pieces"]),
+           "scan": ("full scan", "filter + verification", "filter, then full scan (flags above break-even)")[st["kind"]], "scan_stage_ms": kms["k_flank_scan"],
+           "barcode_stage_ms": kms["k_barcode"]}
+    if not args.no_cpu_baseline:
+        w = 2048
+        full = np.frombuffer(d_rows[: nr * 48].cpu().numpy().tobytes(), dtype=_abi.ROW_DTYPE)
+        want = po.Oracle([g.as_tuple() for g in groups]).annotate(d_bases[: w * L].cpu().numpy(), np.arange(w + 1, dtype=np.uint64) * np.uint64(L),
+                                                                  n_threads=os.cpu_count() or 1, fast=True)
+        out["parity_on_sample"] = bool(full[full["read_idx"] < w].tobytes() == want.tobytes())
     dm.close()
     return out
 

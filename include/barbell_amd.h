@@ -161,6 +161,12 @@ const char* bb_kernel_name(int k);
 float       bb_last_kernel_ms(const bb_ctx* ctx, int k);
 void        bb_set_timing(bb_ctx* ctx, int enable);
 
+/* How the flank scan (searcher.rs:438) of group `group` ran on the last batch: kind 0 = full-height scan of every column, 1 = 15/31-row
+ * filter + full-height verification around the flagged 16-byte pieces, 2 = the filter flagged more than the break-even
+ * fraction of the batch's pieces (low-complexity text, adapter-like decoys), so the full scan did the batch.  Results are the
+ * same whichever ran; the counts tell a caller how far its data is from the synthetic benchmark's.                       */
+int bb_last_scan_stats(const bb_ctx* ctx, uint32_t group, uint64_t* flagged_pieces, uint64_t* total_pieces, int* kind);
+
 /* Device buffers for callers of the *_dev entry points that have no HIP binding of their own (the Rust
  * or C++ host): memory on the context's GPU, and copies ordered after the context's stream.         */
 int  bb_dev_malloc(bb_ctx* ctx, uint64_t bytes, void** d_ptr);

@@ -624,3 +624,24 @@ def test_geometry_matches_oracle_on_device_ctx():
             assert bytes(a) == bytes(b)
             assert dm.flank(gi) == o.flank(gi)
             assert dm.pattern(gi, 3, True) == o.pattern(gi, 3, True)
+
+
+@pytest.mark.parametrize("mode", [1, 2, 3])
+@pytest.mark.parametrize("frac", [None, "0", "1"])
+def test_stress_mixes_and_adaptive_scan(monkeypatch, mode, frac):
+    """The read mixes bench.py's `stress` object measures (bb_synth.h: low-complexity bodies, near-copies of the constructs' shared
+    prefix every ~200 nt, half the reads chimeric) against the checker, with the per-batch choice between verification and the full
+    scan left alone, forced to the full scan (BARBELL_AMD_ADAPT_FRAC=0: any flag is too many) and switched off (=1)."""
+    from barbell_amd import annotate as A
+
+    if frac is not None:
+        monkeypatch.setenv("BARBELL_AMD_ADAPT_FRAC", frac)
+    groups = config_groups("nbd96")
+    bases, offsets = A.synth_reads_host(groups, (mode << 56) | 4321, 300, 3000, 0, 900)
+    dm, got, want = run_both(groups, bases, offsets)
+    assert len(want) > 300
+    assert_same(got, want)
+    st = dm.scan_stats(0)
+    assert st["total_pieces"] > 0 and st["kind"] == (2 if frac == "0" and st["flagged_pieces"] else 1 if frac in ("0", "1") else st["kind"])
+    if mode == 1:
+        assert st["flagged_pieces"] / st["total_pieces"] > 0.001
