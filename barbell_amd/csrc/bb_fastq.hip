@@ -142,18 +142,21 @@ __device__ __forceinline__ void line_span(const uint8_t* __restrict__ text, cons
     if (e > s && text[e - 1] == '\r') --e;
 }
 
-__global__ __launch_bounds__(256) void k_fq_records(const uint8_t* __restrict__ text, const uint64_t* __restrict__ nl, uint32_t n_rec,
+// lpr = lines per record: 4, or 2 for the compact form (header and sequence lines only: BB_FASTQ_TWO_LINE)
+__global__ __launch_bounds__(256) void k_fq_records(const uint8_t* __restrict__ text, const uint64_t* __restrict__ nl, uint32_t n_rec, uint32_t lpr,
                                                     uint32_t* __restrict__ seq_len, uint32_t* __restrict__ hdr_len,
                                                     uint32_t* __restrict__ id_len, uint32_t* __restrict__ desc_start,
                                                     unsigned long long* __restrict__ bad) {
     const uint32_t k = blockIdx.x * 256u + threadIdx.x;
     if (k >= n_rec) return;
-    uint64_t hs, he, ss, se, ps, pe, qs, qe;
-    line_span(text, nl, 4ull * k, hs, he);
-    line_span(text, nl, 4ull * k + 1, ss, se);
-    line_span(text, nl, 4ull * k + 2, ps, pe);
-    line_span(text, nl, 4ull * k + 3, qs, qe);
-    const bool ok = he > hs && text[hs] == '@' && pe > ps && text[ps] == '+' && (se - ss) == (qe - qs);
+    uint64_t hs, he, ss, se, ps = 0, pe = 0, qs = 0, qe = 0;
+    line_span(text, nl, (uint64_t)lpr * k, hs, he);
+    line_span(text, nl, (uint64_t)lpr * k + 1, ss, se);
+    if (lpr == 4u) {
+        line_span(text, nl, 4ull * k + 2, ps, pe);
+        line_span(text, nl, 4ull * k + 3, qs, qe);
+    }
+    const bool ok = he > hs && text[hs] == '@' && (lpr != 4u || (pe > ps && text[ps] == '+' && (se - ss) == (qe - qs)));
     if (!ok) atomicMin(bad, (unsigned long long)k);
     const uint32_t hl = he > hs ? (uint32_t)(he - hs - 1) : 0u;  // header without '@'
     uint32_t idl = hl, ds = hl;
@@ -169,17 +172,18 @@ __global__ __launch_bounds__(256) void k_fq_records(const uint8_t* __restrict__ 
     desc_start[k] = ds;
 }
 
-__global__ __launch_bounds__(256) void k_fq_pack(const uint8_t* __restrict__ text, const uint64_t* __restrict__ nl, uint32_t n_rec,
+__global__ __launch_bounds__(256) void k_fq_pack(const uint8_t* __restrict__ text, const uint64_t* __restrict__ nl, uint32_t n_rec, uint32_t lpr,
                                                  const uint64_t* __restrict__ off, const uint64_t* __restrict__ hoff,
                                                  uint8_t* __restrict__ bases, uint8_t* __restrict__ quals, uint8_t* __restrict__ hdr) {
     const int lane = threadIdx.x & 63;
     const uint32_t k = blockIdx.x * 4u + (threadIdx.x >> 6);
     if (k >= n_rec) return;
     const uint64_t o = off[k], L = off[k + 1] - o, ho = hoff[k], HL = hoff[k + 1] - ho;
-    const uint64_t hs = (k ? nl[4ull * k - 1] + 1 : 0) + 1;  // past '@'
-    const uint64_t ss = nl[4ull * k] + 1, qs = nl[4ull * k + 2] + 1;
+    const uint64_t l0 = (uint64_t)lpr * k;
+    const uint64_t hs = (k ? nl[l0 - 1] + 1 : 0) + 1;  // past '@'
+    const uint64_t ss = nl[l0] + 1;
     wave_copy(bases + o, text + ss, (uint32_t)L, lane);
-    wave_copy(quals + o, text + qs, (uint32_t)L, lane);
+    if (lpr == 4u) wave_copy(quals + o, text + nl[l0 + 2] + 1, (uint32_t)L, lane);
     wave_copy(hdr + ho, text + hs, (uint32_t)HL, lane);
 }
 
@@ -206,6 +210,8 @@ void bb_fastq_state_free(bb_fastq_state* s) {
 extern "C" int bb_fastq_ingest_dev(bb_ctx* ctx, const uint8_t* d_text, uint64_t text_len, int final_block, bb_fastq_info* info,
                                    bb_fastq_batch_dev* batch) {
     if (!ctx || !info || !batch || (!d_text && text_len) || ((uintptr_t)d_text & 15u)) return BB_E_INVALID;
+    const uint32_t lpr = (final_block & BB_FASTQ_TWO_LINE) ? 2u : 4u;  // lines per record
+    final_block &= BB_FASTQ_FINAL;
     bb_ctx_view v = bb_ctx_get_view(ctx);
     if (!*v.fastq) *v.fastq = new bb_fastq_state();
     bb_fastq_state* s = *v.fastq;
@@ -241,10 +247,10 @@ extern "C" int bb_fastq_ingest_dev(bb_ctx* ctx, const uint8_t* d_text, uint64_t 
             ++n_lines;
         }
     }
-    if (n_lines / 4 > 0xFFFFFFF0ull) { *v.last_error = "more than 2^32 records in one block"; return BB_E_UNSUPPORTED; }
-    const uint32_t n = (uint32_t)(n_lines / 4);
+    if (n_lines / lpr > 0xFFFFFFF0ull) { *v.last_error = "more than 2^32 records in one block"; return BB_E_UNSUPPORTED; }
+    const uint32_t n = (uint32_t)(n_lines / lpr);
     uint64_t consumed = 0;
-    if (n) FCHK(v, hipMemcpy(&consumed, s->d_nl + (4ull * n - 1), 8, hipMemcpyDeviceToHost));
+    if (n) FCHK(v, hipMemcpy(&consumed, s->d_nl + ((uint64_t)lpr * n - 1), 8, hipMemcpyDeviceToHost));
     consumed = n ? std::min<uint64_t>(consumed + 1, text_len) : 0;
     if (final_block && consumed < text_len) {  // what is left may only be blank lines
         std::vector<uint8_t> tail((size_t)std::min<uint64_t>(text_len - consumed, 1 << 20));
@@ -271,7 +277,7 @@ extern "C" int bb_fastq_ingest_dev(bb_ctx* ctx, const uint8_t* d_text, uint64_t 
         }
         const unsigned long long none = ~0ull;
         FCHK(v, hipMemcpyAsync(s->d_misc + 4, &none, 8, hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(k_fq_records, dim3((n + 255) / 256), dim3(256), 0, st, d_text, (const uint64_t*)s->d_nl, n, s->d_seq_len, s->d_hdr_len,
+        hipLaunchKernelGGL(k_fq_records, dim3((n + 255) / 256), dim3(256), 0, st, d_text, (const uint64_t*)s->d_nl, n, lpr, s->d_seq_len, s->d_hdr_len,
                            s->d_id_len, s->d_desc, (unsigned long long*)(s->d_misc + 4));
         if ((r = scan64(v, s, s->d_seq_len, s->d_off, n, s->d_misc + 2))) return r;
         if ((r = scan64(v, s, s->d_hdr_len, s->d_hoff, n, s->d_misc + 3))) return r;
@@ -280,15 +286,15 @@ extern "C" int bb_fastq_ingest_dev(bb_ctx* ctx, const uint8_t* d_text, uint64_t 
         FCHK(v, hipStreamSynchronize(st));
         if (h[2] != none) {
             info->bad_record = (int64_t)h[2];
-            *v.last_error = "Input FASTQ parsing failed: record " + std::to_string(h[2]) + " of the block is not a 4-line FASTQ record";
+            *v.last_error = "Input FASTQ parsing failed: record " + std::to_string(h[2]) + " of the block is not a " + std::to_string(lpr) + "-line FASTQ record";
             return BB_E_FASTQ;
         }
         info->n_bases = h[0];
         info->n_hdr = h[1];
         if ((r = fgrow(v, s->d_bases, s->cap_bases, h[0] + 16))) return r;
-        if ((r = fgrow(v, s->d_quals, s->cap_quals, h[0] + 16))) return r;
+        if (lpr == 4u && (r = fgrow(v, s->d_quals, s->cap_quals, h[0] + 16))) return r;
         if ((r = fgrow(v, s->d_hdr, s->cap_hdr, h[1] + 16))) return r;
-        hipLaunchKernelGGL(k_fq_pack, dim3((n + 3) / 4), dim3(256), 0, st, d_text, (const uint64_t*)s->d_nl, n, (const uint64_t*)s->d_off,
+        hipLaunchKernelGGL(k_fq_pack, dim3((n + 3) / 4), dim3(256), 0, st, d_text, (const uint64_t*)s->d_nl, n, lpr, (const uint64_t*)s->d_off,
                            (const uint64_t*)s->d_hoff, s->d_bases, s->d_quals, s->d_hdr);
         FCHK(v, hipGetLastError());
     }
@@ -296,7 +302,7 @@ extern "C" int bb_fastq_ingest_dev(bb_ctx* ctx, const uint8_t* d_text, uint64_t 
     FCHK(v, hipStreamSynchronize(st));
     (void)hipEventElapsedTime(&s->last_ms, ev[0], ev[1]);
     s->last = *info;
-    batch->d_bases = s->d_bases; batch->d_quals = s->d_quals; batch->d_offsets = s->d_off;
+    batch->d_bases = s->d_bases; batch->d_quals = lpr == 4u ? s->d_quals : nullptr; batch->d_offsets = s->d_off;
     batch->d_headers = bb_headers{s->d_hdr, s->d_hoff, s->d_id_len, s->d_desc};
     return BB_OK;
 }

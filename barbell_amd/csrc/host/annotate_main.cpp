@@ -66,6 +66,7 @@ static void usage() {
         "                            [--devices D0,D1,.. (one FASTQ stream over several contexts, block i -> context i mod G; RCCL all-reduce of the counts)]\n"
         "                            [--streams S=2 (contexts per device when --devices is not given)] [--counts FILE]\n"
         "                            [--policy lm=..,rc=..,trace=..,ovh=..,tie=..,lodhi=.. (include/barbell_amd_policy.h)]\n"
+        "                            [--no-compact (upload the quality lines too; without --trim-output they are dropped on the host)]\n"
         "                            [(-f <PATTERN_FILE>... | --kit-filter [--maximize]) [--filtered FILE] [--dropped FILE]]\n"
         "                            [--trim-output DIR [--no-label] [--no-orientation] [--no-flanks] [--sort-labels]\n"
         "                             [--only-side left|right] [--failed-out FILE] [--skip-trim] [--flip] [--gzip]]\n"
@@ -176,6 +177,7 @@ int main(int argc, char** argv) {
         else if (a == "--devices") { cfg.devices = parse_devices(need("--devices")); multi = nullptr; }
         else if (a == "--streams") { cfg.streams_per_device = (unsigned)atoi(need("--streams")); multi = nullptr; }
         else if (a == "--counts") { cfg.counts_file = need("--counts"); multi = nullptr; }
+        else if (a == "--no-compact") { cfg.compact_upload = false; multi = nullptr; }
         else if (a == "--policy") { if (!set_policy(need("--policy"))) return 2; multi = nullptr; }
         else if (a == "--shard") { shard = need("--shard"); multi = nullptr; }
         else if (a == "-f" || a == "--filter-file") { multi = &pattern_files; }

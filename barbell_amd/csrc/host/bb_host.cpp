@@ -16,6 +16,7 @@
 #include <mutex>
 #include <thread>
 
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <fcntl.h>
 #include <unistd.h>
@@ -584,11 +585,11 @@ void DevBuf::release() {
 
 #define BB_THROW(rc, what) throw BarbellError((rc), std::string(what ": ") + bb_strerror(rc) + " " + bb_last_error(ctx_))
 
-Demuxer::Ingested Demuxer::ingest(const uint8_t* text, uint64_t len, bool final_block, bool want_ids) {
+Demuxer::Ingested Demuxer::ingest(const uint8_t* text, uint64_t len, bool final_block, bool want_ids, bool two_line) {
     ensure_ctx();
     ing_ = Ingested{};
     n_rows_ = 0;
-    int rc = bb_fastq_ingest(ctx_, text, len, final_block ? 1 : 0, &ing_.info, &batch_);
+    int rc = bb_fastq_ingest(ctx_, text, len, (final_block ? BB_FASTQ_FINAL : 0) | (two_line ? BB_FASTQ_TWO_LINE : 0), &ing_.info, &batch_);
     if (rc != BB_OK) BB_THROW(rc, "bb_fastq_ingest");
     if (!want_ids) return ing_;  // the TSV renderer reads the ids where they are
     const uint64_t n = ing_.info.n_records;
@@ -736,12 +737,16 @@ namespace {
 struct BlockFeeder {
     struct Block { uint64_t index = 0; const uint8_t* data = nullptr; size_t len = 0; int slot = -1; std::shared_ptr<std::vector<uint8_t>> big; };
     struct Task { size_t file = 0; uint64_t off = 0; size_t len = 0; uint64_t seq = 0; bool last = false; const uint8_t* mem = nullptr; };
-    struct Slot { uint8_t* p = nullptr; size_t cap = 0, got = 0, nl = 0; bool last = false; int state = 0; uint64_t seq = 0; int refs = 0; size_t file = 0; };
+    struct Slot { uint8_t* p = nullptr; size_t cap = 0, got = 0, nl = 0; bool last = false; int state = 0; uint64_t seq = 0; int refs = 0; size_t file = 0;
+                  // two-line mode: raw newlines of the chunk, the phase (line index mod 4) the reader took its first byte to be in
+                  // (-1: none recognisable), where the raw bytes came from (to redo the chunk if the guess was wrong), malformed flag
+                  size_t raw_nl = 0; int phase0 = 0; uint64_t off = 0; size_t raw_len = 0; bool bad = false; };
     size_t HEAD = 16u << 20;  // BARBELL_AMD_HEAD_BYTES overrides it (tests of the over-long-carry path)
     bb_ctx* ctx;
     std::vector<std::string> paths;
     std::vector<char> is_gz;
     std::vector<int> fds;
+    std::vector<const uint8_t*> maps; // two-line mode, plain files: the file mapped (the readers compact out of the page cache)
     std::vector<uint64_t> sizes;      // plain: st_size; gzip: inflated size once known
     std::vector<char> size_known;
     size_t chunk;
@@ -760,8 +765,18 @@ struct BlockFeeder {
     const uint8_t* carry_ptr = nullptr; size_t carry_len = 0, carry_lines = 0; int carry_slot = -1;
     std::vector<uint8_t> carry_buf;  // a carry that spans whole chunks (a record longer than a chunk) is kept here
     bool done = false;
+    // Two-line mode (annotate without the trim step: annotator.rs:125-127 never looks at the quality line): the readers drop the
+    // '+' and quality lines while they stage a chunk, so half the bytes cross PCIe and the GPU parses 2-line records
+    // (BB_FASTQ_TWO_LINE).  Dropping lines is a pure per-byte filter on "index of the byte's line mod 4", so the compacted chunks
+    // concatenate to the compacted stream; a reader only has to know the phase of its chunk's first byte.  It reads it off the
+    // text ("@..." two lines above "+..."; a sequence line cannot start with '+', so the test is unambiguous for FASTQ) and the
+    // sequencer, which knows the true phase from the running line count, checks every guess and redoes a chunk that was wrong.
+    bool two_line = false;
+    size_t lpr = 4;                       // lines per record in the staged text
+    size_t seq_file = (size_t)-1; uint64_t seq_raw_lines = 0;   // sequencer: file in hand, its raw lines so far
 
-    BlockFeeder(bb_ctx* c, const std::vector<std::string>& files, size_t chunk_bytes, unsigned n_slots, unsigned n_readers, unsigned n_inflate);
+    BlockFeeder(bb_ctx* c, const std::vector<std::string>& files, size_t chunk_bytes, unsigned n_slots, unsigned n_readers, unsigned n_inflate,
+                bool two_line_mode = false);
     ~BlockFeeder();
     void reader_loop();
     bool claim(Task& t);
@@ -953,6 +968,43 @@ struct LabelWriters {  // the per-label writers of trim_matches (trim.rs:356-446
     }
 };
 
+// keeps the bytes of the lines in phase 0 and 1 (header, sequence) of a chunk whose first byte lies in a line of phase ph0; in
+// place when out == buf (the write position never passes the read position), or straight from a mapping of the file.  nl_kept / nl_all: newlines kept / seen; bad: a line that starts
+// inside the chunk in phase 0 / 2 does not start with '@' / '+'.
+static size_t compact_two_line(uint8_t* out, const uint8_t* buf, size_t n, int ph0, size_t& nl_kept, size_t& nl_all, bool& bad) {
+    size_t d = 0, p = 0;
+    int ph = ph0 & 3;
+    bool line_start = false;  // the first line may be the tail of one that began in the previous chunk
+    nl_kept = nl_all = 0; bad = false;
+    while (p < n) {
+        if (line_start && ((ph == 0 && buf[p] != '@' && buf[p] != '\n' && buf[p] != '\r') || (ph == 2 && buf[p] != '+'))) bad = true;
+        const uint8_t* q = (const uint8_t*)memchr(buf + p, '\n', n - p);
+        const size_t e = q ? (size_t)(q - buf) + 1 : n;
+        if (ph < 2) {
+            if (out + d != buf + p) memmove(out + d, buf + p, e - p);
+            d += e - p;
+            if (q) ++nl_kept;
+        }
+        if (q) { ++nl_all; ph = (ph + 1) & 3; line_start = true; }
+        p = e;
+    }
+    return d;
+}
+// phase of a chunk's first byte, read off the text: the first line that starts with '@' and has a line starting with '+' two
+// lines below is a header (phase 0); -1 if no such pair is found among the chunk's first lines
+static int guess_phase(const uint8_t* buf, size_t n, bool at_file_start) {
+    if (at_file_start) return 0;
+    size_t st[16], ns = 0, p = 0;
+    while (ns < 16 && p < n) {
+        const void* q = memchr(buf + p, '\n', n - p);
+        if (!q) break;
+        p = (size_t)((const uint8_t*)q - buf) + 1;
+        if (p < n) st[ns++] = p;
+    }
+    for (size_t j = 0; j + 2 < ns; ++j)
+        if (buf[st[j]] == '@' && buf[st[j + 2]] == '+') return (int)((4 - ((j + 1) & 3)) & 3);  // line j+1 of the chunk is in phase 0
+    return -1;
+}
 static size_t count_nl(const uint8_t* p, size_t n) {
     size_t c = 0;
     const uint8_t* e = p + n;
@@ -973,10 +1025,12 @@ static bool sniff_gzip(const std::string& path) {  // magic bytes, not the file 
     return n == 2 && m[0] == 0x1f && m[1] == 0x8b;
 }
 
-BlockFeeder::BlockFeeder(bb_ctx* c, const std::vector<std::string>& files, size_t chunk_bytes, unsigned n_slots, unsigned n_readers, unsigned n_inflate)
-    : ctx(c), paths(files), chunk(chunk_bytes) {
+BlockFeeder::BlockFeeder(bb_ctx* c, const std::vector<std::string>& files, size_t chunk_bytes, unsigned n_slots, unsigned n_readers, unsigned n_inflate,
+                         bool two_line_mode)
+    : ctx(c), paths(files), chunk(chunk_bytes), two_line(two_line_mode), lpr(two_line_mode ? 2 : 4) {
     if (const char* e = getenv("BARBELL_AMD_HEAD_BYTES")) HEAD = (size_t)std::max(16L, atol(e));
     is_gz.resize(paths.size()); fds.assign(paths.size(), -1); sizes.assign(paths.size(), 0); size_known.assign(paths.size(), 0);
+    maps.assign(paths.size(), nullptr);
     chunks_left.assign(paths.size(), 0);
     std::vector<std::string> gz_paths;
     for (size_t i = 0; i < paths.size(); ++i) {
@@ -992,6 +1046,10 @@ BlockFeeder::BlockFeeder(bb_ctx* c, const std::vector<std::string>& files, size_
         struct stat st;
         if (fds[i] < 0 || fstat(fds[i], &st) != 0) throw BarbellError(BB_E_INVALID, "Failed to open FASTQ input: " + paths[i]);
         sizes[i] = (uint64_t)st.st_size; size_known[i] = 1;
+        if (two_line && st.st_size > 0) {  // the readers compact straight out of the page cache: one pass over the text, no copy of the dropped half
+            void* m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fds[i], 0);
+            if (m != MAP_FAILED) { maps[i] = (const uint8_t*)m; (void)madvise(m, (size_t)st.st_size, MADV_SEQUENTIAL); }
+        }
     }
     bool any_gz = false;
     for (char g : is_gz) any_gz = any_gz || g;
@@ -1010,6 +1068,7 @@ BlockFeeder::~BlockFeeder() {
     for (auto& t : readers) if (t.joinable()) t.join();
     inflater.reset();
     for (auto& sl : slots) if (sl.p) bb_host_free(ctx, sl.p);
+    for (size_t i = 0; i < maps.size(); ++i) if (maps[i]) munmap((void*)maps[i], (size_t)sizes[i]);
     for (int fd : fds) if (fd >= 0) close(fd);
 }
 // next chunk of the stream; gzip files are inflated whole (a few files ahead) and chunked from memory
@@ -1051,25 +1110,42 @@ void BlockFeeder::reader_loop() {
                 sl.state = 1;
             }
             uint8_t* dst = sl.p + HEAD;
+            const uint8_t* src = nullptr;   // the chunk's raw bytes where they can be read in place (inflated image, mapped file)
+            if (is_gz[t.file]) src = inflater->get(t.file).data() + t.off;
+            else if (maps[t.file]) src = maps[t.file] + t.off;
+            size_t got_len = t.len, nl = 0, raw_nl = 0;
+            int ph0 = 0;
+            bool bad = false;
+            if (two_line && src) {
+                ph0 = guess_phase(src, t.len, t.off == 0);
+                if (ph0 >= 0) got_len = compact_two_line(dst, src, t.len, ph0, nl, raw_nl, bad);
+                else { if (t.len) memcpy(dst, src, t.len); raw_nl = count_nl(dst, t.len); }   // left raw: the sequencer compacts it with the true phase
+            } else {
+                if (src) { if (t.len) memcpy(dst, src, t.len); }
+                else {
+                    size_t got = 0;
+                    while (got < t.len) {
+                        const ssize_t r = pread(fds[t.file], dst + got, t.len - got, (off_t)(t.off + got));
+                        if (r < 0) { if (errno == EINTR) continue; throw BarbellError(BB_E_INVALID, "Error reading FASTQ file '" + paths[t.file] + "'"); }
+                        if (r == 0) throw BarbellError(BB_E_INVALID, "FASTQ file '" + paths[t.file] + "' shrank while it was read");
+                        got += (size_t)r;
+                    }
+                }
+                if (two_line) {
+                    ph0 = guess_phase(dst, t.len, t.off == 0);
+                    if (ph0 >= 0) got_len = compact_two_line(dst, dst, t.len, ph0, nl, raw_nl, bad);
+                    else raw_nl = count_nl(dst, t.len);
+                } else nl = count_nl(dst, t.len);
+            }
             if (is_gz[t.file]) {
-                const std::vector<uint8_t>& img = inflater->get(t.file);
-                if (t.len) memcpy(dst, img.data() + t.off, t.len);
                 bool last_copy;
                 { std::lock_guard<std::mutex> lk(mu); last_copy = --chunks_left[t.file] == 0; }
                 if (last_copy) inflater->release(t.file);  // every chunk of the image has been copied out
-            } else {
-                size_t got = 0;
-                while (got < t.len) {
-                    const ssize_t r = pread(fds[t.file], dst + got, t.len - got, (off_t)(t.off + got));
-                    if (r < 0) { if (errno == EINTR) continue; throw BarbellError(BB_E_INVALID, "Error reading FASTQ file '" + paths[t.file] + "'"); }
-                    if (r == 0) throw BarbellError(BB_E_INVALID, "FASTQ file '" + paths[t.file] + "' shrank while it was read");
-                    got += (size_t)r;
-                }
             }
-            const size_t nl = count_nl(dst, t.len);
             {
                 std::lock_guard<std::mutex> lk(mu);
-                sl.got = t.len; sl.nl = nl; sl.last = t.last; sl.file = t.file; sl.state = 2;
+                sl.got = got_len; sl.nl = nl; sl.last = t.last; sl.file = t.file; sl.raw_nl = raw_nl; sl.phase0 = ph0; sl.off = t.off; sl.raw_len = t.len;
+                sl.bad = bad; sl.state = 2;
             }
             cv.notify_all();
         }
@@ -1101,12 +1177,33 @@ bool BlockFeeder::next(Block& b) {
         const int si = (int)(want_seq % slots.size());
         ++want_seq;
         uint8_t* body = sl->p + HEAD;
+        if (two_line) {   // the reader's guess of the chunk's first phase against the running line count of the file
+            if (sl->file != seq_file) { seq_file = sl->file; seq_raw_lines = 0; }
+            const int truth = (int)(seq_raw_lines & 3u);
+            if (sl->phase0 != truth) {
+                if (sl->phase0 >= 0) {  // compacted under a wrong phase: the raw bytes are needed again
+                    if (is_gz[sl->file]) throw BarbellError(BB_E_FASTQ, "'" + paths[sl->file] + "': line layout not recognised while dropping quality lines; rerun with --no-compact");
+                    if (maps[sl->file]) memcpy(body, maps[sl->file] + sl->off, sl->raw_len);
+                    else {
+                        size_t got = 0;
+                        while (got < sl->raw_len) {
+                            const ssize_t r = pread(fds[sl->file], body + got, sl->raw_len - got, (off_t)(sl->off + got));
+                            if (r <= 0) { if (r < 0 && errno == EINTR) continue; throw BarbellError(BB_E_INVALID, "Error reading FASTQ file '" + paths[sl->file] + "'"); }
+                            got += (size_t)r;
+                        }
+                    }
+                }
+                sl->got = compact_two_line(body, body, sl->raw_len, truth, sl->nl, sl->raw_nl, sl->bad);
+            }
+            if (sl->bad) throw BarbellError(BB_E_FASTQ, "Input FASTQ parsing failed: '" + paths[sl->file] + "' holds a record that is not a 4-line FASTQ record");
+            seq_raw_lines += sl->raw_nl;
+        }
         size_t cut = sl->got;  // bytes of this chunk that go into this block
         size_t lines_left = 0;
         if (!sl->last) {
             const size_t total = carry_lines + sl->nl;
-            const size_t r = total % 4;            // complete lines after the last complete record
-            if (total < 4 || sl->nl <= r) {         // no record ends inside this chunk (a record longer than the block, or a tiny --block-bytes):
+            const size_t r = total % lpr;          // complete lines after the last complete record
+            if (total < lpr || sl->nl <= r) {       // no record ends inside this chunk (a record longer than the block, or a tiny --block-bytes):
                 // the whole chunk joins the carry, kept aside, and the next chunk continues the record
                 std::vector<uint8_t> nb(carry_len + sl->got);
                 if (carry_len) memcpy(nb.data(), carry_ptr, carry_len);
@@ -1230,6 +1327,7 @@ AnnotateStats annotate(const std::vector<std::string>& read_files, const std::st
         if (ppr_f) fclose(ppr_f);
         writers.reset();
     };
+    const bool two_line = config.compact_upload && !trimming;  // nothing downstream of annotate / filter / inspect reads qualities
     const bool prof = getenv("BARBELL_AMD_PROFILE") != nullptr;
     auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const bool want_ids = ppr_f != nullptr || failed_f != nullptr;
@@ -1238,7 +1336,7 @@ AnnotateStats annotate(const std::vector<std::string>& read_files, const std::st
     auto process = [&](Demuxer& dm, const BlockFeeder::Block& blk, BlockFeeder& feeder) -> BlockResult {
         BlockResult R;
         double t0 = now();
-        const auto ing = dm.ingest(blk.data, blk.len, true, want_ids);  // blocks hold whole records only
+        const auto ing = dm.ingest(blk.data, blk.len, true, want_ids, two_line);  // blocks hold whole records only
         feeder.release(blk.slot);                                       // the text is in HBM: the slot can be refilled
         R.t_ingest = now() - t0; t0 = now();
         const auto& ids = ing.ids;
@@ -1321,7 +1419,9 @@ AnnotateStats annotate(const std::vector<std::string>& read_files, const std::st
     auto set_err = [&](std::exception_ptr e) { { std::lock_guard<std::mutex> lk(mu); if (!first_err) first_err = e; abort = true; } cv.notify_all(); };
     double t_start = 0, t_end = 0;
     try {
-        BlockFeeder feeder(dms[0]->ctx(), read_files, block, (unsigned)(3 * G + 2), std::min<unsigned>(std::max(1u, config.n_threads), 16u), config.n_threads);
+        // two-line mode: a slot is about half full and a chunk costs its reader a pass over the text, so twice the slots and readers
+        BlockFeeder feeder(dms[0]->ctx(), read_files, block, (unsigned)((two_line ? 2 : 1) * (3 * G + 2)),
+                           std::min<unsigned>(std::max(1u, config.n_threads), two_line ? 32u : 16u), config.n_threads, two_line);
         t_start = now();
         std::thread dispatcher([&]() {
             try {

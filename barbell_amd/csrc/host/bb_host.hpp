@@ -148,7 +148,7 @@ public:
     // ingest() parses the block on the GPU (bb_fastq_ingest) and fetches only the headers; the *_ingested
     // calls run on the batch it left in HBM and download rows / verdicts / rendered text.
     struct Ingested { bb_fastq_info info{}; std::vector<std::string> ids; };
-    Ingested ingest(const uint8_t* text, uint64_t len, bool final_block, bool want_ids = true);
+    Ingested ingest(const uint8_t* text, uint64_t len, bool final_block, bool want_ids = true, bool two_line = false);
     // annotate the ingested batch; rows stay in HBM, their POD copy is rows() (no strings are built)
     uint64_t annotate_ingested();
     const bb_row* rows() const { return rows_.data(); }
@@ -201,7 +201,8 @@ struct AnnotateConfig {  // config.rs:3-12 with the CLI defaults of bin/main.rs:
     double min_score = 0.2, min_score_diff = 0.1;
     bool use_extended = false;
     size_t batch_reads = 0;               // if set: block_bytes = batch_reads * 4096 (kept for CLI compatibility)
-    size_t block_bytes = 128u << 20;      // raw FASTQ text handed to the GPU per ingest call (two page-locked buffers of this size)
+    size_t block_bytes = 128u << 20;      // raw FASTQ text handed to the GPU per ingest call (page-locked slots of this size: 3 per context + 2)
+    bool compact_upload = true;           // without the trim step: drop the '+' and quality lines on the host (half the PCIe bytes); --no-compact
     int device = 0;
     // One FASTQ stream over several contexts: block i of the stream goes to context i mod G, rows are merged in
     // block order, the per-barcode histogram is all-reduced (RCCL when the devices are distinct).  Empty = {device}

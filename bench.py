@@ -330,7 +330,7 @@ def e2e_leg(d_bases, n, L, dev):
         env = dict(os.environ, BARBELL_AMD_NO_TORCH="1")
         t0 = time.perf_counter()
         r = subprocess.run([cli, "annotate", "-i", fq, "-o", os.path.join(td, "a.tsv"), "--kit", "SQK-NBD114-96", "--flank-max-errors", "3", "--streams", "3",
-                            "--block-bytes", str(256 << 20), "-t", "16"], capture_output=True, text=True, env=env)
+                            "--block-bytes", str(256 << 20), "-t", "32"], capture_output=True, text=True, env=env)
         wall = time.perf_counter() - t0
         if r.returncode != 0:
             return {"error": r.stderr[-400:]}
@@ -339,7 +339,7 @@ def e2e_leg(d_bases, n, L, dev):
         return {"reads": n, "fastq_bytes": size, "tsv_bytes": os.path.getsize(os.path.join(td, "a.tsv")), "rows": int(m.group(3)),
                 "steady_state_reads_per_s": n / pipe, "steady_state_fastq_gb_per_s": size / pipe / 1e9, "pipeline_s": pipe,
                 "process_wall_s": wall, "process_wall_reads_per_s": n / wall, "fastq_write_s": gen_s,
-                "command": "barbell-amd annotate --kit SQK-NBD114-96 --flank-max-errors 3 --streams 3 --block-bytes 256Mi -t 16",
+                "command": "barbell-amd annotate --kit SQK-NBD114-96 --flank-max-errors 3 --streams 3 --block-bytes 256Mi -t 32",
                 "note": "C++ host, FASTQ text from the page cache to annotation.tsv; PCIe-bound (8 KB of text per read); not the headline value"}
 
 

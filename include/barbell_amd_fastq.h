@@ -35,7 +35,14 @@ typedef struct {
     bb_headers      d_headers;     /* four device arrays */
 } bb_fastq_batch_dev;
 
-/* Parses text[0, text_len).  final_block != 0: the text is the end of the stream — a last line without
+/* `final_block` is a set of flags (0 / 1 as before): */
+#define BB_FASTQ_FINAL    1   /* the text is the end of the stream                                                              */
+#define BB_FASTQ_TWO_LINE 2   /* compact form: records are their header and sequence lines only ("@id ..\nACGT..\n") — what the
+                                 annotate path needs (annotator.rs:125-127 never looks at the quality line), half the bytes to move
+                                 over PCIe; the host side drops the '+' and quality lines while it stages the text (bb_host.cpp).
+                                 batch->d_quals is NULL for such a block.                                                       */
+
+/* Parses text[0, text_len).  final_block & BB_FASTQ_FINAL: the text is the end of the stream — a last line without
  * '\n' counts, trailing blank lines are ignored, and a trailing partial record is an error; otherwise
  * the partial tail is left to the caller (info->consumed).  "\r\n" line ends are accepted.
  * The host variant uploads the block first; d_text of the _dev variant must be 16-byte aligned and the allocation

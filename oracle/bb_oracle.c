@@ -1202,22 +1202,24 @@ static uint32_t ws_len_c(const uint8_t* p, uint64_t n) {
 int bbo_fastq_parse(const uint8_t* text, uint64_t len, int final_block, bb_fastq_info* info, uint64_t* offsets, uint8_t* bases,
                     uint8_t* quals, uint8_t* hdr, uint64_t* hdr_offsets, uint32_t* id_len, uint32_t* desc_start) {
     if (!info || (!text && len)) return BB_E_INVALID;
+    const int lpr = (final_block & BB_FASTQ_TWO_LINE) ? 2 : 4;    /* lines per record: the compact form has header + sequence only */
+    final_block &= BB_FASTQ_FINAL;
     memset(info, 0, sizeof(*info));
     info->bad_record = -1;
-    const int fill = offsets && bases && quals && hdr && hdr_offsets && id_len && desc_start;
+    const int fill = offsets && bases && (quals || lpr == 2) && hdr && hdr_offsets && id_len && desc_start;
     uint64_t pos = 0, n = 0, nb = 0, nh = 0;
     if (fill) { offsets[0] = 0; hdr_offsets[0] = 0; }
     for (;;) {
         uint64_t ls[4], le[4], p = pos;                       /* the next four lines */
         int got = 0;
-        while (got < 4 && p < len) {
+        while (got < lpr && p < len) {
             uint64_t e = p;
             while (e < len && text[e] != '\n') ++e;
             if (e == len && !final_block) break;               /* incomplete line: leave it to the next block */
             ls[got] = p; le[got] = e; ++got;
             p = e < len ? e + 1 : len;
         }
-        if (got < 4) {
+        if (got < lpr) {
             if (final_block) {
                 int blank = 1;
                 for (uint64_t q = pos; q < len; ++q) if (text[q] != '\n' && text[q] != '\r') blank = 0;
@@ -1226,14 +1228,14 @@ int bbo_fastq_parse(const uint8_t* text, uint64_t len, int final_block, bb_fastq
             }
             break;
         }
-        for (int i = 0; i < 4; ++i) if (le[i] > ls[i] && text[le[i] - 1] == '\r') --le[i];
-        if (!(le[0] > ls[0] && text[ls[0]] == '@' && le[2] > ls[2] && text[ls[2]] == '+' && le[1] - ls[1] == le[3] - ls[3])) {
+        for (int i = 0; i < lpr; ++i) if (le[i] > ls[i] && text[le[i] - 1] == '\r') --le[i];
+        if (!(le[0] > ls[0] && text[ls[0]] == '@' && (lpr == 2 || (le[2] > ls[2] && text[ls[2]] == '+' && le[1] - ls[1] == le[3] - ls[3])))) {
             if (info->bad_record < 0) info->bad_record = (int64_t)n;
         }
         const uint64_t L = le[1] - ls[1], HL = le[0] > ls[0] ? le[0] - ls[0] - 1 : 0;
         if (fill && info->bad_record < 0) {
             memcpy(bases + nb, text + ls[1], L);
-            memcpy(quals + nb, text + ls[3], L);
+            if (lpr == 4) memcpy(quals + nb, text + ls[3], L);
             memcpy(hdr + nh, text + ls[0] + 1, HL);
             uint32_t idl = (uint32_t)HL, ds = (uint32_t)HL;
             for (uint32_t q = 0; q < HL; ++q) if (ws_len_c(text + ls[0] + 1 + q, HL - q)) { idl = q; break; }

@@ -127,6 +127,12 @@ def test_cli_tsv_matches_python_and_oracle(tmp_path, gz):
                         "--block-bytes", "1500"], capture_output=True, text=True, env=env)
     assert r.returncode == 0, r.stderr
     assert out3.read_bytes() == cli
+    # the quality lines are dropped on the host by default (annotate never reads them); --no-compact uploads them: same bytes out
+    out6 = tmp_path / "cli6.tsv"
+    r = subprocess.run([CLI, "annotate", "-i", str(fq), "-o", str(out6), "--kit", "SQK-NBD114-96", "--flank-max-errors", "3", "--no-compact",
+                        "--block-bytes", "70000"], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr
+    assert out6.read_bytes() == cli
     # a pipe instead of a file (no size, no offsets; plain or gzip): read sequentially, same output
     fifo = tmp_path / "reads.pipe"
     os.mkfifo(fifo)
@@ -369,3 +375,41 @@ def test_one_stream_over_several_contexts(tmp_path):
     got = {l.split("\t")[1]: int(l.split("\t")[2]) for l in outs["one"][0]["c"].decode().splitlines()}
     assert sum(got.values()) == len(rows) and all(got[k] == v for k, v in want.items())
     assert len(outs["one"][0]) > 20  # many per-barcode files
+
+
+@pytest.mark.gpu
+def test_cli_drops_quality_lines_that_look_like_headers(tmp_path):
+    """Two-line staging (the readers drop '+' and quality lines; the chunk's line phase is read off the text): quality lines that
+    start with '@' or '+', CRLF line ends, many chunk boundaries — the TSV equals the one made with --no-compact and the Python host's."""
+    from barbell_amd import annotate as A
+
+    groups = kits.groups_from_kit("SQK-NBD114-96", flank_max_errors=3)
+    n = 700
+    bases, offsets = A.synth_reads_host(groups, 31, 120, 900, 0, n)
+    rng = np.random.default_rng(5)
+    fq = tmp_path / "tricky.fastq"
+    with open(fq, "wb") as f:
+        for i in range(n):
+            s = bytes(bases[int(offsets[i]):int(offsets[i + 1])])
+            q = bytearray(rng.integers(33, 75, size=len(s), dtype=np.uint8).tobytes())
+            q[0] = b"@+@I"[i % 4]
+            nl = b"\r\n" if i % 5 == 0 else b"\n"
+            f.write(b"@t%d extra" % i + nl + s + nl + (b"+t%d" % i if i % 2 else b"+") + nl + bytes(q) + nl)
+    env = dict(os.environ, BARBELL_AMD_NO_TORCH="1")
+    outs = []
+    for extra in (["--block-bytes", "4096"], ["--block-bytes", "4096", "--no-compact"], ["--block-bytes", "30011", "-t", "3"], []):
+        o = tmp_path / ("o%d.tsv" % len(outs))
+        r = subprocess.run([CLI, "annotate", "-i", str(fq), "-o", str(o), "--kit", "SQK-NBD114-96", "--flank-max-errors", "3"] + extra,
+                           capture_output=True, text=True, env=env)
+        assert r.returncode == 0, r.stderr
+        outs.append(o.read_bytes())
+    assert outs[0] == outs[1] == outs[2] == outs[3] and outs[0].count(b"\n") > n // 2
+    py = tmp_path / "py.tsv"
+    A.annotate_with_kit([str(fq)], str(py), "SQK-NBD114-96", max_flank_errors=3)
+    assert py.read_bytes() == outs[0]
+    # a file that is not 4-line FASTQ is refused in either mode
+    bad = tmp_path / "bad.fastq"
+    bad.write_bytes(fq.read_bytes()[:5000] + b"@x\nACGT\n-\nIIII\n" + fq.read_bytes()[5000:])
+    for extra in ([], ["--no-compact"]):
+        r = subprocess.run([CLI, "annotate", "-i", str(bad), "-o", str(tmp_path / "b.tsv"), "--kit", "SQK-NBD114-96"] + extra, capture_output=True, text=True, env=env)
+        assert r.returncode == 1 and "FASTQ" in r.stderr

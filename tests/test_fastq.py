@@ -203,3 +203,65 @@ def test_gpu_ingest_blocks_of_synthetic_reads_and_pipeline():
     rows_dev = np.frombuffer(d_rows[: nr * 48].cpu().numpy().tobytes(), dtype=_abi.ROW_DTYPE)
     rows_host = dm.demux_packed(bases, offsets)
     assert rows_dev.tobytes() == rows_host.tobytes()
+
+
+# ---- the compact two-line form (BB_FASTQ_TWO_LINE): header and sequence lines only ---------------------------------
+def two_line(recs, nl=b"\n", last_nl=True):
+    t = b"".join(b"@" + h + nl + s + nl for h, s, q in recs)
+    return t if last_nl else t[: -len(nl)]
+
+
+def test_two_line_form_parses_like_the_four_line_form():
+    for nl in (b"\n", b"\r\n"):
+        for ln in (True, False):
+            rc4, i4, a4 = po.fastq_parse(fq(REC, nl, ln), 1)
+            rc2, i2, a2 = po.fastq_parse(two_line(REC, nl, ln), 1 | 2)
+            assert rc4 == rc2 == 0 and i2["n_records"] == i4["n_records"] == len(REC)
+            for k in ("offsets", "bases", "hdr", "hdr_offsets", "id_len", "desc_start"):
+                assert a2[k].tobytes() == a4[k].tobytes(), k
+    t = two_line(REC)
+    rc, info, _ = po.fastq_parse(t[:-3], 2)          # not final: the partial record is left to the caller
+    assert rc == 0 and info["n_records"] == len(REC) - 1 and t[info["consumed"]:].startswith(b"@")
+    assert po.fastq_parse(t + b"r9\nAC\n", 3)[0] == _abi.BB_E_FASTQ   # a header without '@'
+    assert po.fastq_parse(t + b"@r9\n", 3)[0] == _abi.BB_E_FASTQ       # the stream ends inside a record
+
+
+@pytest.mark.gpu
+def test_gpu_two_line_form():
+    from barbell_amd import annotate as A, fastq as Q
+    from tests.common import config_groups
+
+    groups = config_groups("nbd96")
+    dm = A.Demuxer()
+    for g in groups:
+        dm.add_query_group(g)
+
+    def parse2(text, flags):
+        try:
+            info, batch = Q.ingest(dm, text, flags)
+        except A.BarbellError as e:
+            return e.code, None, None, None
+        return 0, info, Q.fetch(dm, info, bases=True), batch
+
+    for t, flags in [(two_line(REC, nl, ln), 3) for nl in (b"\n", b"\r\n") for ln in (True, False)] + [(two_line(REC)[:-3], 2), (b"", 3), (two_line(REC) + b"\n", 3)]:
+        rc, info, arr, batch = parse2(t, flags)
+        orc, oinfo, oarr = po.fastq_parse(t, flags)
+        assert rc == orc == 0 and not batch.d_quals
+        for k in ("n_records", "consumed", "n_bases", "n_hdr", "bad_record"):
+            assert getattr(info, k) == oinfo[k], k
+        for k in ("offsets", "bases", "hdr", "hdr_offsets", "id_len", "desc_start"):
+            assert arr[k].tobytes() == oarr[k].tobytes(), k
+    assert parse2(two_line(REC) + b"r9\nAC\n", 3)[0] == _abi.BB_E_FASTQ
+    # synthetic reads: rows annotated from the two-line batch == rows from the four-line batch
+    n = 3000
+    bases, offsets = A.synth_reads_host(groups, 5, 150, 5000, 0, n)
+    recs = [((b"read%d ch=%d" % (i, i % 7)), bases[int(offsets[i]):int(offsets[i + 1])].tobytes(), b"I" * int(offsets[i + 1] - offsets[i])) for i in range(n)]
+    import torch
+
+    outs = []
+    for text, flags in ((fq(recs), 1), (two_line(recs), 3)):
+        info, batch = Q.ingest(dm, text, flags)
+        d_rows = torch.empty(4 * n * 48, dtype=torch.uint8, device="cuda")
+        nr = dm.demux_dev(batch.d_bases, batch.d_offsets, n, d_rows.data_ptr(), 4 * n)
+        outs.append(d_rows[: nr * 48].cpu().numpy().tobytes())
+    assert outs[0] == outs[1] and len(outs[0]) > 48 * n // 2

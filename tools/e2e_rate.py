@@ -80,13 +80,13 @@ def run(name, cmd):
 base = [cli, "annotate", "-i", fq, "-o", os.path.join(a.dir, "e2e_a.tsv"), "--kit", "SQK-NBD114-96", "--flank-max-errors", "3"]
 for streams in (1, 2, 3):
     for bb in (128 << 20, 256 << 20):
-        run(f"annotate_streams{streams}_block{bb >> 20}Mi_t16", base + ["--streams", str(streams), "--block-bytes", str(bb), "-t", "16"])
+        run(f"annotate_streams{streams}_block{bb >> 20}Mi_t32", base + ["--streams", str(streams), "--block-bytes", str(bb), "-t", "32"])
 best = max(out["runs"], key=lambda k: out["runs"][k]["steady_state_reads_per_s"] or 0)
 out["best"] = {"run": best, **{k: out["runs"][best][k] for k in ("steady_state_reads_per_s", "wall_reads_per_s", "fastq_gb_per_s_steady")}}
 out["tsv_bytes"] = os.path.getsize(os.path.join(a.dir, "e2e_a.tsv"))
 if a.kit_run:
     run("kit_streams2_block256Mi", [cli, "kit", "-k", "SQK-NBD114-96", "-i", fq, "-o", os.path.join(a.dir, "e2e_kit"), "--flank-max-errors", "3", "--maximize",
-                                    "--streams", "2", "-t", "16"])
+                                    "--streams", "2", "-t", "32"])
 txt = json.dumps(out)
 if a.json:
     open(a.json, "w").write(txt + "\n")
