@@ -5,6 +5,8 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <atomic>
+#include <unordered_map>
 #include <cctype>
 #include <cstdio>
 #include <cstring>
@@ -305,7 +307,11 @@ Demuxer::Demuxer(float alpha, bool verbose, double min_score_frac, double min_sc
     : alpha_(alpha), verbose_(verbose), min_score_(min_score_frac), min_score_diff_(min_score_diff_frac), device_(device) {}
 Demuxer::~Demuxer() {
     for (DevBuf* b : {&d_rows_, &d_ver_, &d_elems_, &d_text_, &d_slices_, &d_spans_, &d_status_, &d_tsv_}) b->release();
-    for (uint8_t* h : h_text_) if (h) bb_host_free(ctx_, h);
+    {   // every holder of a landing buffer (the file writers) must be gone by now
+        std::lock_guard<std::mutex> lk(text_pool_->mu);
+        for (uint8_t* h : text_pool_->all) bb_host_free(ctx_, h);
+        text_pool_->all.clear(); text_pool_->free_.clear();
+    }
     if (ctx_) bb_destroy(ctx_);
 }
 
@@ -703,17 +709,27 @@ TrimBatch Demuxer::trim_ingested() {
         if (rc != BB_OK) BB_THROW(rc, "bb_trim_batch_dev");
         t.slices.resize(ns); t.spans.resize(nsp);
         int r2;
-        const int hb = h_text_next_;
-        h_text_next_ ^= 1;
-        if (tl > h_text_cap_[hb]) {  // page-locked and not zero-filled: a 3 GB std::vector costs more than the copy itself
-            if (h_text_[hb]) bb_host_free(ctx_, h_text_[hb]);
-            h_text_[hb] = nullptr; h_text_cap_[hb] = 0;
-            void* hp = nullptr;
-            if ((r2 = bb_host_malloc(ctx_, tl + tl / 4 + 4096, &hp)) != BB_OK) BB_THROW(r2, "bb_host_malloc");
-            h_text_[hb] = (uint8_t*)hp; h_text_cap_[hb] = tl + tl / 4 + 4096;
+        uint8_t* hp = nullptr;
+        uint64_t hcap = 0;
+        {
+            std::lock_guard<std::mutex> lk(text_pool_->mu);
+            for (size_t i = 0; i < text_pool_->free_.size(); ++i)
+                if (text_pool_->free_[i].second >= tl) { hp = text_pool_->free_[i].first; hcap = text_pool_->free_[i].second; text_pool_->free_.erase(text_pool_->free_.begin() + (long)i); break; }
         }
-        t.text_ptr = h_text_[hb]; t.text_len = tl;
-        if ((r2 = bb_dev_download(ctx_, h_text_[hb], d_text_.p, tl)) != BB_OK) BB_THROW(r2, "bb_dev_download");
+        if (!hp) {  // page-locked and not zero-filled: a 3 GB std::vector costs more than the copy itself
+            void* q = nullptr;
+            hcap = tl + tl / 4 + 4096;
+            if ((r2 = bb_host_malloc(ctx_, hcap, &q)) != BB_OK) BB_THROW(r2, "bb_host_malloc");
+            hp = (uint8_t*)q;
+            std::lock_guard<std::mutex> lk(text_pool_->mu);
+            text_pool_->all.push_back(hp);
+        }
+        {
+            std::shared_ptr<TextPool> pool = text_pool_;
+            t.text_hold = std::shared_ptr<void>((void*)hp, [pool, hp, hcap](void*) { std::lock_guard<std::mutex> lk(pool->mu); pool->free_.emplace_back(hp, hcap); });
+        }
+        t.text_ptr = hp; t.text_len = tl;
+        if ((r2 = bb_dev_download(ctx_, hp, d_text_.p, tl)) != BB_OK) BB_THROW(r2, "bb_dev_download");
         if ((r2 = bb_dev_download(ctx_, t.slices.data(), d_slices_.p, ns * sizeof(bb_slice))) != BB_OK) BB_THROW(r2, "bb_dev_download");
         if ((r2 = bb_dev_download(ctx_, t.spans.data(), d_spans_.p, (uint64_t)nsp * sizeof(bb_label_span))) != BB_OK) BB_THROW(r2, "bb_dev_download");
         if ((r2 = bb_dev_download(ctx_, t.status.data(), d_status_.p, n)) != BB_OK) BB_THROW(r2, "bb_dev_download");
@@ -883,63 +899,79 @@ struct ParallelInflater {
 struct LabelWriters {  // the per-label writers of trim_matches (trim.rs:356-446)
     std::string folder;
     bool gz;
-    std::map<std::string, gzFile> gzs;
-    std::map<std::string, FILE*> plain;
-    // writes run on their own thread, one batch's spans per job; at most two jobs exist (the demuxer has two
-    // landing buffers), submit() blocks while both are busy
-    struct Span { std::string label; const uint8_t* p; size_t n; std::shared_ptr<std::vector<uint8_t>> keep; };
-    std::deque<std::vector<Span>> jobs;
+    // Writes run on K threads of their own (one write() stream moves ~6 GB/s of page cache, the GPU renders records several
+    // times faster): a label's file belongs to one thread — label hash mod K — so the records of a file stay in batch order
+    // and no two threads share a handle.  A batch is done when the last of its spans is written; at most `max_outstanding`
+    // batches exist (wait()), which bounds the rendered text held in page-locked buffers.
+    struct Span { std::string label; const uint8_t* p; size_t n; std::shared_ptr<void> keep; };
+    struct Item { Span sp; std::shared_ptr<std::atomic<int>> left; };
+    struct Lane {
+        std::deque<Item> q;
+        std::map<std::string, gzFile> gzs;
+        std::map<std::string, FILE*> plain;
+        std::thread th;
+    };
+    std::vector<std::unique_ptr<Lane>> lanes;
     std::mutex mu;
     std::condition_variable cv;
-    bool stop = false, busy = false;
+    bool stop = false;
+    size_t outstanding = 0;  // batches submitted and not yet fully written
     std::string err;
-    std::thread th;
-    LabelWriters(std::string f, bool g) : folder(std::move(f)), gz(g), th([this]() { run(); }) {}
-    void run() {
+    LabelWriters(std::string f, bool g, unsigned k = 0) : folder(std::move(f)), gz(g) {
+        if (k == 0) { const char* e = getenv("BARBELL_AMD_WRITERS"); k = e ? (unsigned)std::max(1, atoi(e)) : 8u; }
+        for (unsigned i = 0; i < k; ++i) lanes.emplace_back(new Lane());
+        for (unsigned i = 0; i < k; ++i) lanes[i]->th = std::thread([this, i]() { run(*lanes[i]); });
+    }
+    void run(Lane& L) {
         for (;;) {
-            std::vector<Span> job;
+            Item it;
             {
                 std::unique_lock<std::mutex> lk(mu);
-                cv.wait(lk, [this]() { return stop || !jobs.empty(); });
-                if (jobs.empty()) return;
-                job = std::move(jobs.front());
-                jobs.pop_front();
-                busy = true;
+                cv.wait(lk, [&]() { return stop || !L.q.empty(); });
+                if (L.q.empty()) return;
+                it = std::move(L.q.front());
+                L.q.pop_front();
             }
             try {
-                for (const auto& sp : job) write(sp.label, sp.p, sp.n);
+                write(L, it.sp.label, it.sp.p, it.sp.n);
             } catch (const std::exception& e) {
                 std::lock_guard<std::mutex> lk(mu);
                 if (err.empty()) err = e.what();
             }
-            {
-                std::lock_guard<std::mutex> lk(mu);
-                busy = false;
+            it.sp.keep.reset();
+            if (it.left->fetch_sub(1) == 1) {
+                { std::lock_guard<std::mutex> lk(mu); --outstanding; }
+                cv.notify_all();
             }
-            cv.notify_all();
         }
     }
-    // waits until at most `max_outstanding` jobs are queued or running, then rethrows a writer error if any
+    // waits until at most `max_outstanding` batches are queued or being written, then rethrows a writer error if any
     void wait(size_t max_outstanding) {
         std::unique_lock<std::mutex> lk(mu);
-        cv.wait(lk, [&]() { return jobs.size() + (busy ? 1 : 0) <= max_outstanding; });
+        cv.wait(lk, [&]() { return outstanding <= max_outstanding; });
         if (!err.empty()) throw BarbellError(BB_E_INVALID, err);
     }
     void submit(std::vector<Span> job) {
+        if (job.empty()) return;
+        auto left = std::make_shared<std::atomic<int>>((int)job.size());
         {
             std::lock_guard<std::mutex> lk(mu);
-            jobs.push_back(std::move(job));
+            ++outstanding;
+            for (auto& sp : job) {
+                Lane& L = *lanes[std::hash<std::string>{}(sp.label) % lanes.size()];
+                L.q.push_back(Item{std::move(sp), left});
+            }
         }
         cv.notify_all();
     }
-    void write(const std::string& label, const uint8_t* p, size_t n) {
+    void write(Lane& L, const std::string& label, const uint8_t* p, size_t n) {
         const std::string path = folder + "/" + label + (gz ? ".trimmed.fastq.gz" : ".trimmed.fastq");
         if (gz) {
-            auto it = gzs.find(label);
-            if (it == gzs.end()) {
+            auto it = L.gzs.find(label);
+            if (it == L.gzs.end()) {
                 gzFile f = gzopen(path.c_str(), "wb");
                 if (!f) throw BarbellError(BB_E_INVALID, "Failed to create output file '" + path + "'\nTry setting ulimit higher: \"ulimit -n 65000\"");
-                it = gzs.emplace(label, f).first;
+                it = L.gzs.emplace(label, f).first;
             }
             for (size_t o = 0; o < n;) {
                 const unsigned chunk = (unsigned)std::min<size_t>(n - o, 1u << 30);
@@ -947,11 +979,12 @@ struct LabelWriters {  // the per-label writers of trim_matches (trim.rs:356-446
                 o += chunk;
             }
         } else {
-            auto it = plain.find(label);
-            if (it == plain.end()) {
+            auto it = L.plain.find(label);
+            if (it == L.plain.end()) {
                 FILE* f = fopen(path.c_str(), "wb");
                 if (!f) throw BarbellError(BB_E_INVALID, "Failed to create output file '" + path + "'\nTry setting ulimit higher: \"ulimit -n 65000\"");
-                it = plain.emplace(label, f).first;
+                setvbuf(f, nullptr, _IONBF, 0);  // spans are large and contiguous: straight to write()
+                it = L.plain.emplace(label, f).first;
             }
             if (n && fwrite(p, 1, n, it->second) != n) throw BarbellError(BB_E_INVALID, "Failed to write sequence to '" + path + "'");
         }
@@ -962,9 +995,11 @@ struct LabelWriters {  // the per-label writers of trim_matches (trim.rs:356-446
             stop = true;
         }
         cv.notify_all();
-        if (th.joinable()) th.join();  // drains the queue first
-        for (auto& kv : gzs) gzclose(kv.second);
-        for (auto& kv : plain) fclose(kv.second);
+        for (auto& L : lanes) if (L->th.joinable()) L->th.join();  // each drains its queue first
+        for (auto& L : lanes) {
+            for (auto& kv : L->gzs) gzclose(kv.second);
+            for (auto& kv : L->plain) fclose(kv.second);
+        }
     }
 };
 
@@ -1256,10 +1291,11 @@ namespace {
 struct BlockResult {
     size_t n_reads = 0, found = 0, rows = 0, kept = 0, dropped = 0, trimmed = 0, split = 0, trim_failed = 0;
     std::vector<uint8_t> anno, kept_tsv, drop_tsv;              // TSV lines rendered on the GPU
-    std::vector<std::pair<std::string, std::string>> ppr;       // (read id, pattern) for pattern_per_read.tsv
-    std::vector<std::string> patterns;                          // pattern of every read with rows (inspect counts)
-    std::vector<std::string> failed_ids;
-    std::shared_ptr<std::vector<uint8_t>> text;                 // rendered records of the trim step
+    std::string ppr;                                            // the block's lines of pattern_per_read.tsv, rendered by the worker
+    std::vector<std::pair<std::string, size_t>> patterns;       // (pattern, reads of the block that show it), first-appearance order
+    std::string failed_ids;                                     // one id per line
+    std::shared_ptr<void> text;                                 // holds the page-locked buffer of the rendered records
+    const uint8_t* text_ptr = nullptr;
     struct Span { std::string label; size_t off, n; };
     std::vector<Span> spans;
     double t_ingest = 0, t_gpu = 0, t_rest = 0;
@@ -1357,21 +1393,25 @@ AnnotateStats annotate(const std::vector<std::string>& read_files, const std::st
             if (drop_f) dm.format_ingested(BB_FMT_DROPPED, R.drop_tsv);
         }
         if (config.inspect) {  // inspect.rs:128-184 on the annotation rows (no cuts yet)
+            // counted per block here, merged by the commit stage (it used to look every read's string up in one map)
+            std::unordered_map<std::string, size_t> idx;
             for (auto& rp : dm.inspect_ingested(false, config.bucket_size)) {
-                if (ppr_f) R.ppr.emplace_back(ids[rp.first], rp.second);
-                R.patterns.push_back(std::move(rp.second));
+                if (ppr_f) { R.ppr += ids[rp.first]; R.ppr += '\t'; R.ppr += rp.second; R.ppr += '\n'; }
+                auto it = idx.find(rp.second);
+                if (it == idx.end()) { idx.emplace(rp.second, R.patterns.size()); R.patterns.emplace_back(std::move(rp.second), 1); }
+                else ++R.patterns[it->second].second;
             }
         }
         if (trimming) {  // trim.rs:385-460: the GPU cut and rendered the records, one write per label
             const TrimBatch t = dm.trim_ingested();
-            R.text = std::make_shared<std::vector<uint8_t>>(t.data(), t.data() + t.text_len);  // the landing buffer is reused two blocks later
+            R.text = t.text_hold; R.text_ptr = t.data();  // the page-locked landing buffer goes back to the demuxer's pool when the writers are done
             for (const auto& sp : t.spans) R.spans.push_back({dm.label_of_key(sp.label_key), (size_t)sp.off, (size_t)sp.len});
             std::vector<uint32_t> per_read(R.n_reads, 0);
             for (const auto& sl : t.slices) ++per_read[sl.read_idx];
             for (size_t i = 0; i < R.n_reads; ++i) {
                 if (t.status[i] == BB_TRIM_TRIMMED) ++R.trimmed;
                 if (per_read[i] > 1) ++R.split;
-                if (t.status[i] == BB_TRIM_FAILED) { ++R.trim_failed; if (failed_f) R.failed_ids.push_back(ids[i]); }
+                if (t.status[i] == BB_TRIM_FAILED) { ++R.trim_failed; if (failed_f) { R.failed_ids += ids[i]; R.failed_ids += '\n'; } }
             }
         }
         R.t_rest = now() - t0;
@@ -1390,17 +1430,17 @@ AnnotateStats annotate(const std::vector<std::string>& read_files, const std::st
         put(out, header, R.anno);
         put(kept_f, kept_header, R.kept_tsv);
         put(drop_f, drop_header, R.drop_tsv);
-        for (auto& pr : R.ppr) fprintf(ppr_f, "%s\t%s\n", pr.first.c_str(), pr.second.c_str());
-        for (auto& pat : R.patterns) {
-            auto it = pattern_count.find(pat);
-            if (it == pattern_count.end()) { pattern_count.emplace(pat, 1); pattern_order.push_back(pat); }
-            else ++it->second;
+        if (ppr_f && !R.ppr.empty()) fwrite(R.ppr.data(), 1, R.ppr.size(), ppr_f);
+        for (auto& pc : R.patterns) {
+            auto it = pattern_count.find(pc.first);
+            if (it == pattern_count.end()) { pattern_count.emplace(pc.first, pc.second); pattern_order.push_back(pc.first); }
+            else it->second += pc.second;
         }
-        for (auto& id : R.failed_ids) fprintf(failed_f, "%s\n", id.c_str());
+        if (failed_f && !R.failed_ids.empty()) fwrite(R.failed_ids.data(), 1, R.failed_ids.size(), failed_f);
         if (writers && !R.spans.empty()) {
-            writers->wait(2);  // bounds the rendered text waiting for the writer thread
+            writers->wait(3);  // bounds the rendered text waiting for the writer threads
             std::vector<LabelWriters::Span> job;
-            for (const auto& sp : R.spans) job.push_back({sp.label, R.text->data() + sp.off, sp.n, R.text});
+            for (const auto& sp : R.spans) job.push_back({sp.label, R.text_ptr + sp.off, sp.n, R.text});
             writers->submit(std::move(job));
         }
         t_ingest += R.t_ingest; t_gpu += R.t_gpu; t_rest += R.t_rest;

@@ -17,6 +17,9 @@
 #pragma once
 #include <cstdint>
 #include <map>
+#include <mutex>
+#include <memory>
+#include <mutex>
 #include <optional>
 #include <stdexcept>
 #include <string>
@@ -86,7 +89,8 @@ struct TrimConfig {  // config.rs:19-32, CLI defaults bin/main.rs:136-186
 };
 struct TrimBatch {  // what bb_trim_batch returns for one batch
     std::vector<uint8_t> text;        // trim_last_batch: the rendered records
-    const uint8_t* text_ptr = nullptr; // trim_ingested: the records in the demuxer's page-locked buffer (valid until the next call)
+    const uint8_t* text_ptr = nullptr; // trim_ingested: the records in a page-locked buffer of the demuxer's pool
+    std::shared_ptr<void> text_hold;   // ... which goes back to the pool when the last holder (the file writers) lets go
     uint64_t text_len = 0;
     const uint8_t* data() const { return text_ptr ? text_ptr : text.data(); }
     std::vector<bb_slice> slices;
@@ -188,9 +192,14 @@ private:
     DevBuf d_rows_, d_ver_, d_elems_, d_text_, d_slices_, d_spans_, d_status_, d_tsv_;
     // page-locked landing buffers of the rendered records (bb_host_malloc), used alternately so a writer thread
     // can still be flushing one batch's records while the next batch is downloaded
-    uint8_t* h_text_[2] = {nullptr, nullptr};
-    uint64_t h_text_cap_[2] = {0, 0};
-    int h_text_next_ = 0;
+    // A pool: the writer threads may still be flushing several batches' records while the next one is downloaded; a buffer returns
+    // when its last holder lets go (no copy of the rendered text on the host).
+    struct TextPool {
+        std::mutex mu;
+        std::vector<std::pair<uint8_t*, uint64_t>> free_;
+        std::vector<uint8_t*> all;
+    };
+    std::shared_ptr<TextPool> text_pool_ = std::make_shared<TextPool>();
 };
 
 struct AnnotateConfig {  // config.rs:3-12 with the CLI defaults of bin/main.rs:64-112

@@ -85,8 +85,12 @@ best = max(out["runs"], key=lambda k: out["runs"][k]["steady_state_reads_per_s"]
 out["best"] = {"run": best, **{k: out["runs"][best][k] for k in ("steady_state_reads_per_s", "wall_reads_per_s", "fastq_gb_per_s_steady")}}
 out["tsv_bytes"] = os.path.getsize(os.path.join(a.dir, "e2e_a.tsv"))
 if a.kit_run:
-    run("kit_streams2_block256Mi", [cli, "kit", "-k", "SQK-NBD114-96", "-i", fq, "-o", os.path.join(a.dir, "e2e_kit"), "--flank-max-errors", "3", "--maximize",
-                                    "--streams", "2", "-t", "32"])
+    import shutil
+
+    for streams in (2, 3, 4):
+        shutil.rmtree(os.path.join(a.dir, "e2e_kit"), ignore_errors=True)
+        run(f"kit_streams{streams}", [cli, "kit", "-k", "SQK-NBD114-96", "-i", fq, "-o", os.path.join(a.dir, "e2e_kit"), "--flank-max-errors", "3", "--maximize",
+                                      "--streams", str(streams), "-t", "32"])
 txt = json.dumps(out)
 if a.json:
     open(a.json, "w").write(txt + "\n")
