@@ -656,22 +656,26 @@ void launch_barcode(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets
         const uint32_t slot = 4 * g + sw;
         const uint32_t* list = c->d_lists + (size_t)slot * c->cap_hits;
         const uint32_t* cnt = c->d_listcnt + slot - g;  // the kernels index list_cnt with g
-        if (!c->force_generic && !c->generic_barcode && WB == 2 && D.split[strand] && win_max <= 64) {  // one word per barcode lane
-            if (pass == 1) {
-                if (!c->fast_path) continue;
-                list = c->d_fb_lists + (size_t)slot * c->cap_hits;
-                cnt = c->d_fbcnt + slot - g;
+        if constexpr (WB == 2) {
+            if (!c->force_generic && !c->generic_barcode && D.split[strand] && win_max <= 64) {  // one word per barcode lane
+                if (pass == 1) {
+                    if (!c->fast_path) continue;
+                    list = c->d_fb_lists + (size_t)slot * c->cap_hits;
+                    cnt = c->d_fbcnt + slot - g;
+                }
+                const bool fast = pass == 0 && c->fast_path;
+                if (!wide) launch_barcode_pfx<48>(c, n_hits, g, strand, list, cnt, fast);
+                else launch_barcode_pfx<64>(c, n_hits, g, strand, list, cnt, fast);
+                continue;
             }
-            const bool fast = pass == 0 && c->fast_path;
-            if (!wide) launch_barcode_pfx<48>(c, n_hits, g, strand, list, cnt, fast);
-            else launch_barcode_pfx<64>(c, n_hits, g, strand, list, cnt, fast);
-            continue;
         }
         if (pass == 1) continue;
-        if (reg_ok) {
-            if (!wide) launch_barcode_reg<WB, 48>(c, d_bases, d_offsets, n_hits, g, list, cnt);
-            else launch_barcode_reg<WB, 64>(c, d_bases, d_offsets, n_hits, g, list, cnt);
-            continue;
+        if constexpr (WB <= 2) {
+            if (reg_ok) {
+                if (!wide) launch_barcode_reg<WB, 48>(c, d_bases, d_offsets, n_hits, g, list, cnt);
+                else launch_barcode_reg<WB, 64>(c, d_bases, d_offsets, n_hits, g, list, cnt);
+                continue;
+            }
         }
         const uint32_t hpb = N >= 256 ? 1 : 256 / N;
         const uint32_t threads = ((hpb * N + 63) / 64) * 64;
@@ -760,7 +764,7 @@ int bb_create_policy(const bb_group_desc* groups, uint32_t n_groups, const bb_pa
         char why[200] = "";
         if (I.flank_len > 32 * BB_MAX_W) snprintf(why, sizeof why, "group %u: flank of %u nt (prefix + barcode mask + suffix) exceeds %d", i, I.flank_len, 32 * BB_MAX_W);
         else if (I.pattern_len > 32 * BB_MAX_WB) snprintf(why, sizeof why, "group %u: padded barcode pattern of %u nt exceeds %d", i, I.pattern_len, 32 * BB_MAX_WB);
-        else if (I.flank_k > 63) snprintf(why, sizeof why, "group %u: flank error budget %d exceeds 63", i, I.flank_k);
+        else if (I.flank_k > BB_MAX_FLANK_K) snprintf(why, sizeof why, "group %u: flank error budget %d exceeds %d", i, I.flank_k, BB_MAX_FLANK_K);
         else if (I.mask_len + (uint32_t)I.flank_k + 2 * BB_PADDING > BB_MAX_WIN)
             snprintf(why, sizeof why, "group %u: barcode window (barcode %u + flank errors %d + 20) exceeds %d columns", i, I.mask_len, I.flank_k, BB_MAX_WIN);
         else if (groups[i].n_seqs > 1024) snprintf(why, sizeof why, "group %u: %u sequences exceed 1024", i, groups[i].n_seqs);
@@ -924,8 +928,12 @@ int bb_annotate_batch_dev(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_o
                                    n_hits, c->d_rows, c->params.min_score, c->params.min_score_diff, c->fast_margin, c->d_fb_lists, c->cap_hits, c->d_fbcnt);
             }
             for (uint32_t g = 0; g < G; ++g) {
-                if (c->gdev[g].WB == 1) launch_barcode<1>(c, d_bases, d_offsets, n_hits, g, pass);
-                else launch_barcode<2>(c, d_bases, d_offsets, n_hits, g, pass);
+                switch (c->gdev[g].WB) {
+                    case 1: launch_barcode<1>(c, d_bases, d_offsets, n_hits, g, pass); break;
+                    case 2: launch_barcode<2>(c, d_bases, d_offsets, n_hits, g, pass); break;
+                    case 3: launch_barcode<3>(c, d_bases, d_offsets, n_hits, g, pass); break;
+                    default: launch_barcode<4>(c, d_bases, d_offsets, n_hits, g, pass); break;
+                }
             }
         }
         HIPCHK(c, hipGetLastError());

@@ -14,10 +14,11 @@
 
 #define BB_PADDING 10      // src/lib.rs:10
 #define BB_MAX_W 8         // flank pattern words (m <= 256); W <= 4 are the tuned instantiations, 5..8 the wide ones
-#define BB_MAX_WB 2        // padded barcode pattern words (m_bar <= 64)
-#define BB_MAX_WIN 128     // barcode window columns
+#define BB_MAX_WB 4        // padded barcode pattern words (m_bar <= 128; <= 64 run the tuned kernels, longer ones the any-geometry kernel)
+#define BB_MAX_WIN 256     // barcode window columns (<= 64 run the tuned kernels)
+#define BB_MAX_FLANK_K 127 // flank error budget
 #define BB_MAX_GROUPS 8
-#define BB_MAX_OPS (64 + BB_MAX_WIN)  // unit ops of one barcode alignment
+#define BB_MAX_OPS (32 * BB_MAX_WB + BB_MAX_WIN)  // unit ops of one barcode alignment
 
 // IUPAC base sets A=1 C=2 G=4 T=8 (case-insensitive, U=T, X = empty, non-letters invalid = 0xFF)
 BB_HD uint8_t bb_iupac(uint8_t c) {

@@ -1074,7 +1074,7 @@ __device__ __forceinline__ uint32_t flank_trace_lane(const uint8_t* __restrict__
                                                      const uint32_t* __restrict__ slot_base, uint32_t gmask, int mk_max, uint32_t* __restrict__ orec,
                                                      uint32_t* s_moves) {
     constexpr int S = (W <= 2 ? 2 : (W <= 4 ? 4 : 8));
-    constexpr int MAXC = 32 * W + 64;
+    constexpr int MAXC = 32 * W + BB_MAX_FLANK_K + 1;  // columns of the private-memory variant: m + k
     const uint32_t t = blockIdx.x * 64u + threadIdx.x;
     if (t >= n_hits) return 0xFFFFFFFFu;
     const bb_hit_raw h = raw[t];

@@ -49,9 +49,10 @@ extern "C" {
  *   query groups per context                      <= 8
  *   sequences per group                           <= 1024
  *   flank = prefix + barcode mask + suffix        <= 256 nt (<= 128 nt run the tuned scan/trace instantiations)
- *   padded barcode pattern (10 + barcode + 10)    <= 64 nt  (<= 48 nt and windows <= 64 columns: register-resident kernels)
- *   flank error budget (--flank-max-errors)       <= 63
- *   barcode window = barcode + flank errors + 20  <= 128 columns
+ *   padded barcode pattern (10 + barcode + 10)    <= 128 nt (<= 48 nt and windows <= 64 columns: register-resident kernels;
+ *                                                            beyond that the any-geometry kernel: correct, several times slower)
+ *   flank error budget (--flank-max-errors)       <= 127 (the automatic cutoff of a 256-nt flank is 103)
+ *   barcode window = barcode + flank errors + 20  <= 256 columns
  *   filter: cut markers per pattern element <= 3, cut group id <= 65535, distinct ?N placeholders per pattern <= 16
  *   trim: cut entries per read <= 32
  * bb_create returns BB_E_UNSUPPORTED beyond them and leaves the reason for bb_last_error(NULL).                */

@@ -697,7 +697,8 @@ static int search_fast(const bb_policy* P, const ogroup* g, const uint8_t* tc, i
  * forward pass keeps the preferred move of every cell as two bit planes (Match: d0 & eq; else Ins: ph; else Sub: ~d0; else
  * Del — trace_match's order), the walk back reads them */
 #define BB_FAST_MAXWIN 160
-static int best_match_for_pattern_fast(const bb_policy* P, const uint64_t* peq16, int m, const uint8_t* wcode, int wn, int k, bbo_match* best) {
+static int best_match_for_pattern_fast(const bb_policy* P, const uint64_t* peq16, int m, const uint8_t* wcode, int wn, int k, bbo_match* best,
+                                       uint8_t* ops_store /* m + wn + 2 bytes of the caller's: no allocation per pattern */) {
     uint64_t lo[BB_FAST_MAXWIN + 1], hi[BB_FAST_MAXWIN + 1];
     uint64_t pv = m >= 64 ? ~0ull : ((1ull << m) - 1ull), mv = 0;
     int32_t score = m, prev = m, best_cost = 0x7FFFFFFF, best_pos = -1, cand = 0;
@@ -733,7 +734,7 @@ static int best_match_for_pattern_fast(const bb_policy* P, const uint64_t* peq16
     memset(best, 0, sizeof(*best));
     best->pattern_start = 0; best->pattern_end = m; best->text_start = i; best->text_end = best_pos;
     best->cost = best_cost; best->n_ops = nops; best->strand = BB_FWD; best->rc_text_len = wn;
-    best->ops = (uint8_t*)malloc((size_t)(nops ? nops : 1));
+    best->ops = ops_store;
     for (int t = 0; t < nops; ++t) best->ops[t] = rev[nops - 1 - t];
     return 1;
 }
@@ -781,14 +782,18 @@ static void demux_read(const bbo_ctx* c, uint32_t read_idx, const uint8_t* read,
             bbo_match* best = (bbo_match*)calloc(g->n_seqs, sizeof(bbo_match));
             uint8_t* has = (uint8_t*)calloc(g->n_seqs, 1);
             uint8_t* pcode = (uint8_t*)malloc((size_t)m);
+            const int fast_bar = fast && g->bpeq[fm->strand] && wn <= BB_FAST_MAXWIN && bb_policy_trace_is_default(&c->pol);
+            const size_t ops_stride = (size_t)(m + wn + 2);
+            uint8_t* ops_arena = fast_bar ? (uint8_t*)malloc(ops_stride * g->n_seqs) : NULL;   /* the candidates' op strings, one block */
             int k = g->k1, matched = 0;
             for (int pass = 0; pass < 2; ++pass) {                                    /* :282-328 */
                 matched = 0;
                 for (uint32_t p = 0; p < g->n_seqs; ++p) {
                     for (int j = 0; j < m; ++j) pcode[j] = text_code(pats[(size_t)p * m + j]);
-                    if (has[p]) { free(best[p].ops); best[p].ops = NULL; has[p] = 0; }
-                    if (fast && g->bpeq[fm->strand] && wn <= BB_FAST_MAXWIN && bb_policy_trace_is_default(&c->pol))
-                        has[p] = (uint8_t)best_match_for_pattern_fast(&c->pol, g->bpeq[fm->strand] + (size_t)p * 16, m, wcode, wn, k, &best[p]);
+                    if (has[p]) { if (!fast_bar) free(best[p].ops); best[p].ops = NULL; has[p] = 0; }
+                    if (fast_bar)
+                        has[p] = (uint8_t)best_match_for_pattern_fast(&c->pol, g->bpeq[fm->strand] + (size_t)p * 16, m, wcode, wn, k, &best[p],
+                                                                      ops_arena + ops_stride * p);
                     else
                         has[p] = (uint8_t)best_match_for_pattern(&c->pol, pcode, m, wcode, wn, k, &best[p]);
                     matched += has[p];
@@ -835,7 +840,8 @@ static void demux_read(const bbo_ctx* c, uint32_t read_idx, const uint8_t* read,
                 }
                 free(sc);
             }
-            for (uint32_t p = 0; p < g->n_seqs; ++p) if (has[p]) free(best[p].ops);
+            if (!fast_bar) for (uint32_t p = 0; p < g->n_seqs; ++p) if (has[p]) free(best[p].ops);
+            free(ops_arena);
             free(best); free(has); free(pcode);
         }
         bbo_free_matches(fms, nfm);

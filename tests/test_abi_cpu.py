@@ -56,16 +56,19 @@ def test_create_validates_before_touching_the_gpu(L):
     assert create([([b"@@@@@@@@@", b"AAACCCGGG"], 0, None)])[0] == _abi.BB_E_NOT_IUPAC
     assert create([([b"CAATTTGGT", b"AAACCCGGG"], 0, None)])[0] == _abi.BB_E_NO_FLANK
     assert create([([b"AAACCCGGG", b"AAACCCGGG"], 0, None)])[0] == _abi.BB_E_NO_BARCODE
-    # geometry limits (include/barbell_amd.h): flanks up to 256 nt are accepted (rc NO_DEVICE here, no GPU), longer ones and
-    # barcodes longer than 44 nt are refused with the reason left for bb_last_error(NULL)
-    wide = create([([b"A" * 200 + b"C" + b"G" * 30, b"A" * 200 + b"T" + b"G" * 30], 0, 20)])[0]
-    assert wide in (_abi.BB_OK, _abi.BB_E_NO_DEVICE)
-    assert create([([b"A" * 200 + b"C" + b"G" * 30, b"A" * 200 + b"T" + b"G" * 30], 0, None)])[0] == _abi.BB_E_UNSUPPORTED  # automatic cutoff 92 > 63
-    assert b"error budget 92" in L.bb_last_error(None)
+    # geometry limits (include/barbell_amd.h): what the reference accepts and only the any-geometry kernels compute is accepted
+    # (rc NO_DEVICE here, no GPU) — a 231-nt flank with its automatic cutoff 92, 70-nt padded barcodes; beyond the tables' sizes
+    # the refusal leaves its reason for bb_last_error(NULL)
+    ok = (_abi.BB_OK, _abi.BB_E_NO_DEVICE)
+    assert create([([b"A" * 200 + b"C" + b"G" * 30, b"A" * 200 + b"T" + b"G" * 30], 0, 20)])[0] in ok
+    assert create([([b"A" * 200 + b"C" + b"G" * 30, b"A" * 200 + b"T" + b"G" * 30], 0, None)])[0] in ok          # automatic cutoff 92
+    assert create([([b"ACGTACGTAC" + b"C" * 50 + b"GTGTGTGTGT", b"ACGTACGTAC" + b"T" * 50 + b"GTGTGTGTGT"], 0, None)])[0] in ok  # 70-nt patterns
+    assert create([([b"A" * 200 + b"C" + b"G" * 30, b"A" * 200 + b"T" + b"G" * 30], 0, 128)])[0] == _abi.BB_E_UNSUPPORTED
+    assert b"error budget 128" in L.bb_last_error(None)
     assert create([([b"A" * 250 + b"C" + b"G" * 30, b"A" * 250 + b"T" + b"G" * 30], 0, None)])[0] == _abi.BB_E_UNSUPPORTED
     assert b"flank of 281 nt" in L.bb_last_error(None)
-    assert create([([b"ACGTACGTAC" + b"C" * 50 + b"GTGTGTGTGT", b"ACGTACGTAC" + b"T" * 50 + b"GTGTGTGTGT"], 0, None)])[0] == _abi.BB_E_UNSUPPORTED
-    assert b"padded barcode pattern of 70 nt" in L.bb_last_error(None)
+    assert create([([b"ACGTACGTAC" + b"C" * 110 + b"GTGTGTGTGT", b"ACGTACGTAC" + b"T" * 110 + b"GTGTGTGTGT"], 0, None)])[0] == _abi.BB_E_UNSUPPORTED
+    assert b"padded barcode pattern of 130 nt" in L.bb_last_error(None)
     assert create([([b"AAATTTGGG", b"AAACTTGGG"], 0, None)] * 9)[0] == _abi.BB_E_UNSUPPORTED and b"8 query groups" in L.bb_last_error(None)
 
 

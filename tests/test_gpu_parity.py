@@ -645,3 +645,39 @@ def test_stress_mixes_and_adaptive_scan(monkeypatch, mode, frac):
     assert st["total_pieces"] > 0 and st["kind"] == (2 if frac == "0" and st["flagged_pieces"] else 1 if frac in ("0", "1") else st["kind"])
     if mode == 1:
         assert st["flagged_pieces"] / st["total_pieces"] > 0.001
+
+
+def test_geometry_beyond_the_tuned_kernels():
+    """What the reference's BarcodeGroup::new (barcodes.rs:105-197) accepts and only the any-geometry kernels compute: padded barcodes
+    longer than 64 nt (three Myers words per lane), a 150-nt flank under its automatic error budget (> 63), windows wider than
+    128 columns; ~600 barcodes with wide windows (the 64-column split kernel cannot hold a hit's lanes in one block)."""
+    from barbell_amd import annotate as A
+    from barbell_amd.kits import QueryGroup
+
+    rng = np.random.default_rng(2024)
+
+    def rnd(n):
+        return bytes(rng.choice(list(b"ACGT"), int(n)).tolist())
+
+    def group(pre, blen, suf, n, typ, k):
+        seqs = []
+        while len(seqs) < n:
+            b = rnd(blen)
+            if b not in [q[len(pre):len(pre) + blen] for q in seqs]:
+                seqs.append(pre + b + suf)
+        return QueryGroup(seqs, [f"b{i}" for i in range(n)], typ, k)
+
+    cases = [
+        [group(rnd(20), 60, rnd(15), 24, 0, 6)],        # 80-nt padded patterns
+        [group(rnd(90), 20, rnd(60), 16, 0, None)],     # 170-nt flank, automatic cutoff (> 63), windows up to ~190 columns
+        [group(rnd(14), 24, rnd(8), 600, 0, 8)],        # 600 barcodes, windows up to 51 columns
+    ]
+    for groups in cases:
+        dm = A.Demuxer()
+        for g in groups:
+            dm.add_query_group(g)
+        info = dm.group_info(0)
+        bases, offsets = A.synth_reads_host(groups, 9, 200, 1500, 0, 250)
+        _, got, want = run_both(groups, bases, offsets)
+        assert len(want) > 100, (info.pattern_len, info.flank_k)
+        assert_same(got, want)
