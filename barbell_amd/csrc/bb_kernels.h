@@ -54,6 +54,13 @@ __device__ __forceinline__ unsigned long long add_64(unsigned long long x, unsig
     asm("v_lshl_add_u64 %0, %1, 0, %2" : "=v"(r) : "v"(x), "v"(y));
     return r;
 }
+// x << 1 as x + x: v_add_u32 issues at the full rate, v_lshlrev_b32 at half of it (profiles/valu_ceiling.json); written as inline
+// assembly because the compiler canonicalises x + x back into the shift
+__device__ __forceinline__ uint32_t shl1_32(uint32_t x) {
+    uint32_t r;
+    asm("v_add_u32 %0, %1, %1" : "=v"(r) : "v"(x));
+    return r;
+}
 #ifndef BB_MYERS64
 #define BB_MYERS64 1  // two-word step: carry chain as one 64-bit add (v_lshl_add_u64), the two shifts as v_lshlrev_b64
 #endif
@@ -671,7 +678,7 @@ __global__ __launch_bounds__(256) void k_flank_filter(const uint8_t* __restrict_
                 const uint32_t ph = bitop3<BB_TT_OR_NOR>(mv, d0, pv) & BM, mh = pv & d0;
                 sc2 = sc2 + (ph >> (R - 1)) - (mh >> (R - 1));
                 keep &= sc2;
-                const uint32_t phs = ph << 1, mhs = mh << 1;
+                const uint32_t phs = shl1_32(ph), mhs = shl1_32(mh);
                 pv = bitop3<BB_TT_OR_NOR>(mhs, d0, phs) & BM;
                 mv = phs & d0;
             }
@@ -681,7 +688,7 @@ __global__ __launch_bounds__(256) void k_flank_filter(const uint8_t* __restrict_
                 const uint32_t ph = bitop3<BB_TT_OR_NOR>(mvB, d0, pvB) & BM, mh = pvB & d0;
                 scB = scB + (ph >> (R - 1)) - (mh >> (R - 1));
                 keepB &= scB;
-                const uint32_t phs = ph << 1, mhs = mh << 1;
+                const uint32_t phs = shl1_32(ph), mhs = shl1_32(mh);
                 pvB = bitop3<BB_TT_OR_NOR>(mhs, d0, phs) & BM;
                 mvB = phs & d0;
             }
@@ -692,7 +699,7 @@ __global__ __launch_bounds__(256) void k_flank_filter(const uint8_t* __restrict_
             const uint32_t ph = bitop3<BB_TT_OR_NOR>(mv, d0, pv) & BM, mh = pv & d0;
             sc2 = sc2 + ((ph & TOPS) >> 14) - ((mh & TOPS) >> 14);
             keep &= sc2;
-            const uint32_t phs = ph << 1, mhs = mh << 1;
+            const uint32_t phs = shl1_32(ph), mhs = shl1_32(mh);
             pv = bitop3<BB_TT_OR_NOR>(mhs, d0, phs) & BM;
             mv = phs & d0;
         }
@@ -2115,7 +2122,7 @@ __global__ __launch_bounds__(128) void k_bar_prefix(const uint8_t* __restrict__ 
                     MH |= (unsigned long long)((mh >> (P - 1)) & 1u) << c;
                     const uint32_t isM = d0 & eq, l = ~(isM | ph), hh = (ph & ~isM) | (l & d0);
                     shw = (__brev(l) >> (32 - P)) | ((__brev(hh) >> (32 - P)) << 16);  // row r <-> bit P - r
-                    const uint32_t phs = ph << 1, mhs = mh << 1;  // top boundary row: D[0][c] = 0, no horizontal delta
+                    const uint32_t phs = shl1_32(ph), mhs = shl1_32(mh);  // top boundary row: D[0][c] = 0, no horizontal delta
                     pv = mhs | ~(d0 | phs);
                     mv = phs & d0;
                 }
