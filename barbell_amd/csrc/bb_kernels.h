@@ -2361,28 +2361,23 @@ __global__ __launch_bounds__(CW <= 48 ? 768 : 512) void k_barcode_pfx(const uint
                     const uint4 cv = colv[c];
                     const uint32_t eq = *reinterpret_cast<const uint32_t*>(s_peq_b + (cv.x + pb4));
                     const uint32_t hp = cv.y, hm = cv.z;
-                    const uint32_t x = bitop3<0xC8>(eq, pv, hm);  // (eq | hm) & pv
-                    const uint32_t d0 = bitop3<BB_TT_XOR_OR>(x + pv, pv, eq) | hm | mv;  // v_bitop3 + v_or3
-                    const uint32_t ph = bitop3<BB_TT_OR_NOR>(mv, d0, pv), mh = pv & d0;
+                    // Every boolean step as ONE three-input v_bitop3 (at three waves per SIMD v_bitop3 issues at 941 G/s, v_and / v_or
+                    // at 760: profiles/valu_ceiling.json): 10 v_bitop3 + 1 add + 2 v_bfrev + 2 v_lshlrev_b64 per column (was 8 + 5 + 2 + 2)
+                    const uint32_t x = bitop3<0xC8>(eq, pv, hm);                       // (eq | hm) & pv
+                    const uint32_t t = bitop3<BB_TT_XOR_OR>(x + pv, pv, eq);           // ((x + pv) ^ pv) | eq
+                    const uint32_t d0 = bitop3<0xFE>(t, hm, mv);                       // t | hm | mv
+                    const uint32_t ph = bitop3<BB_TT_OR_NOR>(mv, d0, pv), mh = bitop3<0xC0>(pv, d0, 0u);   // mv | ~(d0 | pv),  pv & d0
                     const uint32_t l = bitop3<0x15>(d0, eq, ph), hh = bitop3<0x3A>(d0, eq, ph);  // move planes (see move_bits)
                     L0[c] = __brev(l); H0[c] = __brev(hh);  // row P+1 <-> bit 31, row P+32 <-> bit 0
-#ifndef BB_PFX_NO_SHIFT64
                     // {accumulator : vector} shifted as ONE 64-bit value: the vector's top bit (the bottom row's delta) lands in
                     // the accumulator and the vector is shifted, in one half-rate instruction instead of v_alignbit + v_lshl_or
                     const unsigned long long tp = shl1_64(((unsigned long long)upr[c >> 5] << 32) | ph);
                     const unsigned long long tm = shl1_64(((unsigned long long)dnr[c >> 5] << 32) | mh);
                     upr[c >> 5] = (uint32_t)(tp >> 32); dnr[c >> 5] = (uint32_t)(tm >> 32);
-                    uint32_t phs = (uint32_t)tp | hp;
-                    const uint32_t mhs = (uint32_t)tm | hm;
-#else
-                    upr[c >> 5] = __builtin_amdgcn_alignbit(upr[c >> 5], ph, 31);  // (acc << 1) | (ph >> 31)
-                    dnr[c >> 5] = __builtin_amdgcn_alignbit(dnr[c >> 5], mh, 31);
-                    uint32_t phs = (ph << 1) | hp;
-                    const uint32_t mhs = (mh << 1) | hm;
-#endif
-                    asm("" : "+v"(phs));  // keep the shifted vector in one register: v_lshl_or, then one op each for pv and mv
-                    pv = bitop3<BB_TT_OR_NOR>(mhs, d0, phs);
-                    mv = phs & d0;
+                    // with phs = (ph << 1) | hp and mhs = (mh << 1) | hm (carry-in of the shared rows in bit 0):
+                    const uint32_t nph = bitop3<0x01>((uint32_t)tp, hp, d0);           // ~(phs | d0)
+                    mv = bitop3<0xA8>((uint32_t)tp, hp, d0);                           // phs & d0
+                    pv = bitop3<0xFE>(nph, (uint32_t)tm, hm);                          // mhs | ~(d0 | phs)
                 }
             }
         }
