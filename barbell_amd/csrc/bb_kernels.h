@@ -277,6 +277,9 @@ struct hit_buf {
         ST.prev = cur_;                                                                         \
     } while (0)
 
+#ifndef BB_VERIFY_CHUNKS
+#define BB_VERIFY_CHUNKS 2   // 16-byte text loads per lane and round in k_flank_verify (4: 2.60 -> 1.96 GB of HBM traffic per step, but 4.67 -> 4.84 ms: lanes with short intervals idle through the longer rounds)
+#endif
 #define BB_VERIFY_FLW 12u     // flag words per lane cached in LDS by k_flank_verify (reads up to ~5.5 kb; longer ones read theirs from HBM)
 #define BB_VERIFY_STAGE 128u  // hit records per wave in k_flank_verify's LDS staging area (a round with more goes out directly)
 // wave-wide: the staged records go out with one atomic and 16-byte stores of consecutive lanes
@@ -953,19 +956,23 @@ __device__ __forceinline__ void flank_verify_lane(const uint8_t* __restrict__ ba
             }
         }
         {
-            // 32 columns per round, their text in two 16-byte loads issued together (one or two sectors: taken 16 bytes a
-            // round, the same sector was fetched again and again — it does not survive in L2 between a lane's rounds)
+            // BB_VERIFY_CHUNKS x 16 columns per round, their text in 16-byte loads issued together: a verified interval (~100 columns
+            // around a flagged piece) comes in one or two rounds, so the lines it lies in are requested once (taken 16 or 32 bytes a
+            // round the same sectors were fetched again: they do not survive in L2 between a lane's rounds)
             const bool work = state == WORK && cur < stop;
-            uint32_t wq[4] = {0u, 0u, 0u, 0u}, wr[4] = {0u, 0u, 0u, 0u};
-            const uint32_t cntb = work ? min(32u, stop - cur) : 0u;
-            if (work) load16(cur, wq);
-            if (cntb > 16u) load16(cur + 16u, wr);
-#pragma unroll 1
-            for (int hb2 = 0; hb2 < 2; ++hb2) {
+            uint32_t wt[BB_VERIFY_CHUNKS][4];
+            const uint32_t cntb = work ? min(16u * BB_VERIFY_CHUNKS, stop - cur) : 0u;
+#pragma unroll
+            for (int q = 0; q < BB_VERIFY_CHUNKS; ++q) {
+                wt[q][0] = wt[q][1] = wt[q][2] = wt[q][3] = 0u;
+                if (cntb > (uint32_t)(16 * q)) load16(cur + 16u * (uint32_t)q, wt[q]);
+            }
+#pragma unroll
+            for (int hb2 = 0; hb2 < BB_VERIFY_CHUNKS; ++hb2) {
                 if (__any(cntb > (uint32_t)(16 * hb2))) {
 #pragma unroll
                     for (int b = 0; b < 16; ++b) {
-                        const uint32_t w = hb2 ? wr[b >> 2] : wq[b >> 2];
+                        const uint32_t w = wt[hb2][b >> 2];
                         if ((uint32_t)(16 * hb2 + b) < cntb) step((w >> (8 * (b & 3))) & 0xFFu);
                     }
                 }

@@ -493,7 +493,8 @@ def load_traffic(args, batch, L, dom):
     # the k_barcode timing slot covers k_bar_prefix + k_barcode_pfx (forward hits) + k_barcode_reg (rc hits)
     pre = ("k_bar", "k_rows") if dom == "k_barcode" else (dom,)
     dom_bytes = sum(v["hbm_bytes"] for k, v in ks.items() if k.startswith(pre))
-    return dom_bytes or None, sum(v["hbm_bytes"] * v.get("launches_per_step", 1) for v in ks.values()), os.path.relpath(path, ROOT)
+    return (dom_bytes or None, sum(v["hbm_bytes"] * v.get("launches_per_step", 1) for v in ks.values() if v.get("in_step", True)),
+            os.path.relpath(path, ROOT))
 
 
 def cpu_baseline(args, groups, dm, d_bases, L, batch, last_batch, d_rows, last_rows):
