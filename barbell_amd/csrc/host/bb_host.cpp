@@ -1089,6 +1089,12 @@ BlockFeeder::BlockFeeder(bb_ctx* c, const std::vector<std::string>& files, size_
     bool any_gz = false;
     for (char g : is_gz) any_gz = any_gz || g;
     if (any_gz) inflater = std::make_unique<ParallelInflater>(paths, is_gz, n_inflate);
+    if (!any_gz) {  // every size is known: no slot needs to be larger than the largest file (small inputs do not page-lock gigabytes)
+        uint64_t mx = 4096;
+        for (uint64_t z : sizes) mx = std::max(mx, z);
+        chunk = (size_t)std::min<uint64_t>(chunk, (mx + 4095) & ~(uint64_t)4095);
+        HEAD = std::min(HEAD, (chunk + 15) & ~(size_t)15);
+    }
     slots.resize(std::max(3u, n_slots));
     for (size_t i = 0; i < slots.size(); ++i) {
         void* q = nullptr;

@@ -210,7 +210,9 @@ struct AnnotateConfig {  // config.rs:3-12 with the CLI defaults of bin/main.rs:
     double min_score = 0.2, min_score_diff = 0.1;
     bool use_extended = false;
     size_t batch_reads = 0;               // if set: block_bytes = batch_reads * 4096 (kept for CLI compatibility)
-    size_t block_bytes = 128u << 20;      // raw FASTQ text handed to the GPU per ingest call (page-locked slots of this size: 3 per context + 2)
+    size_t block_bytes = 128u << 20;      // raw FASTQ text handed to the GPU per ingest call.  Page-locked memory: 3 slots per context + 2 (twice
+                                          // that when the quality lines are dropped on the host), each block_bytes + 16 MiB or the largest input
+                                          // file if that is smaller — 1.2 GiB at the defaults (2 contexts), 6 GiB at --streams 3 --block-bytes 256Mi
     bool compact_upload = true;           // without the trim step: drop the '+' and quality lines on the host (half the PCIe bytes); --no-compact
     int device = 0;
     // One FASTQ stream over several contexts: block i of the stream goes to context i mod G, rows are merged in

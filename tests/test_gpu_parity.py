@@ -27,6 +27,8 @@ def run_both(groups, bases, offsets, **kw):
         okw["min_score"] = kw["min_score_frac"]
     if "min_score_diff_frac" in kw:
         okw["min_score_diff"] = kw["min_score_diff_frac"]
+    if "policy" in kw:
+        okw["policy"] = kw["policy"]
     want = po.Oracle([g.as_tuple() for g in groups], **okw).annotate(bases, offsets, n_threads=NT)
     return dm, got, want
 

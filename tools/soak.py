@@ -34,6 +34,16 @@ for seed in range(first, first + count):
     if mode == "wide": os.environ["BARBELL_AMD_FILTER_WIDE"] = "1"
     if mode == "ends": os.environ["BARBELL_AMD_FILTER_ENDS"] = "1"
     alpha = float(rng.choice([0.0, 0.3, 0.5, 0.7, 1.0]))
+    # a random policy (include/barbell_amd_policy.h) for a third of the seeds, a forced per-batch scan choice for some
+    policy = None
+    if rng.random() < 0.35:
+        policy = ",".join([f"lm={rng.choice(['right', 'left', 'strict'])}", f"rc={rng.choice(['scan', 'fwd'])}",
+                           f"trace={rng.choice(['MISD', 'MISD', 'MSID', 'MDSI', 'IMSD', 'DMIS', 'SMID'])}",
+                           f"ovh={rng.choice(['floor', 'ceil', 'near', 'floor:f64', 'near:f64'])}", f"tie={rng.choice(['first', 'last'])}",
+                           f"lodhi={rng.choice(['3:0.5:1111', '3:0.5:1111', '3:0.5:2211', '3:0.5:1121', '3:0.5:1110', '2:0.5:1111', '3:0.7:1111', '4:0.5:1212'])}"])
+    os.environ.pop("BARBELL_AMD_ADAPT_FRAC", None)
+    if rng.random() < 0.3: os.environ["BARBELL_AMD_ADAPT_FRAC"] = str(rng.choice(["0", "1", "0.01"]))
+    noise = float(rng.choice([0.0, 0.0, 0.03, 0.08]))
     n = int(rng.integers(100, 500))
     lmax = int(rng.integers(40, 3000))
     b1, o1 = A.synth_reads_host(groups, seed, max(1, lmax // 8), lmax, 0, n)
@@ -55,16 +65,20 @@ for seed in range(first, first + count):
     order = rng.permutation(len(reads))
     reads = [reads[i] for i in order]
     bases = np.frombuffer(b"".join(reads), dtype=np.uint8).copy() if any(reads) else np.zeros(0, np.uint8)
+    if noise and len(bases):
+        pos = rng.random(len(bases)) < noise
+        bases[pos] = rng.choice(acgt, int(pos.sum()))
     offsets = np.concatenate([[0], np.cumsum([len(r) for r in reads])]).astype(np.uint64)
     try:
-        _, got, want = run_both(groups, bases, offsets, alpha=alpha)
+        kw = dict(alpha=alpha) if policy is None else dict(alpha=alpha, policy=policy)
+        _, got, want = run_both(groups, bases, offsets, **kw)
     except A.BarbellError as e:
-        print(f"seed {seed} {cfg} k={k} alpha={alpha} mode='{mode}': {e}")
+        print(f"seed {seed} {cfg} k={k} alpha={alpha} mode='{mode}' policy={policy}: {e}")
         if e.code != _abi.BB_E_UNSUPPORTED: bad += 1
         continue
     ok = got.tobytes() == want.tobytes()
     if not ok:
         bad += 1
-        print(f"MISMATCH seed {seed} {cfg} k={k} alpha={alpha} mode='{mode}' rows {len(got)} vs {len(want)}")
+        print(f"MISMATCH seed {seed} {cfg} k={k} alpha={alpha} mode='{mode}' policy={policy} adapt={os.environ.get('BARBELL_AMD_ADAPT_FRAC')} noise={noise} rows {len(got)} vs {len(want)}")
 print(f"{count} seeds, {bad} bad")
 sys.exit(1 if bad else 0)
