@@ -18,8 +18,8 @@ EXPORTS = [
     "bb_filter_set", "bb_filter_rows", "bb_filter_rows_dev",
     "bb_inspect_rows", "bb_inspect_rows_dev",
     "bb_dev_malloc", "bb_dev_free", "bb_dev_download", "bb_dev_upload", "bb_host_malloc", "bb_host_free",
-    "bb_fastq_ingest", "bb_fastq_ingest_dev", "bb_fastq_fetch", "bb_fastq_last_ms",
-    "bb_trim_set", "bb_trim_batch", "bb_trim_batch_dev", "bb_trim_last_ms",
+    "bb_fastq_ingest", "bb_fastq_ingest_dev", "bb_fastq_fetch", "bb_fastq_fetch_lines", "bb_fastq_last_ms",
+    "bb_trim_set", "bb_trim_batch", "bb_trim_batch_dev", "bb_trim_plan_dev", "bb_trim_last_ms",
     "bb_format_set_labels", "bb_format_rows_dev",
 ]
 
@@ -100,6 +100,8 @@ def lib():
     trim_args = [vp, vp, vp, u64, vp, vp, vp, vp, u32, vp, u64, vp, vp, u64, vp, vp, u32, vp, vp]
     L.bb_trim_batch.argtypes = trim_args
     L.bb_trim_batch_dev.argtypes = trim_args
+    L.bb_trim_plan_dev.argtypes = [vp, vp, vp, u64, vp, vp, u32, vp, vp, u64, vp, vp, u32, vp, vp]
+    L.bb_fastq_fetch_lines.argtypes = [vp, vp]
     L.bb_trim_last_ms.restype = C.c_float
     L.bb_trim_last_ms.argtypes = [vp, C.c_int]
     L.bb_format_set_labels.argtypes = [vp, vp, vp]

@@ -28,7 +28,7 @@ struct bb_fastq_state {
     // newline pass
     uint32_t* d_cnt = nullptr; uint64_t* d_cbase = nullptr; uint64_t cap_cnt = 0, cap_cbase = 0;
     uint16_t* d_masks = nullptr; uint64_t cap_masks = 0;
-    uint64_t* d_nl = nullptr; uint64_t cap_nl = 0;
+    uint64_t* d_nl = nullptr; uint64_t cap_nl = 0; uint32_t last_lpr = 4;
     uint64_t* d_misc = nullptr;  // [0] newline total, [1] sums scratch total, [2] bases total, [3] hdr total, [4] bad record
     // records
     uint32_t *d_seq_len = nullptr, *d_hdr_len = nullptr, *d_id_len = nullptr, *d_desc = nullptr;
@@ -302,6 +302,7 @@ extern "C" int bb_fastq_ingest_dev(bb_ctx* ctx, const uint8_t* d_text, uint64_t 
     FCHK(v, hipStreamSynchronize(st));
     (void)hipEventElapsedTime(&s->last_ms, ev[0], ev[1]);
     s->last = *info;
+    s->last_lpr = lpr;
     batch->d_bases = s->d_bases; batch->d_quals = lpr == 4u ? s->d_quals : nullptr; batch->d_offsets = s->d_off;
     batch->d_headers = bb_headers{s->d_hdr, s->d_hoff, s->d_id_len, s->d_desc};
     return BB_OK;
@@ -342,6 +343,20 @@ extern "C" int bb_fastq_fetch(bb_ctx* ctx, uint64_t* offsets, uint8_t* hdr, uint
     if (bases && s->last.n_bases) FCHK(v, hipMemcpyAsync(bases, s->d_bases, s->last.n_bases, hipMemcpyDeviceToHost, st));
     if (quals && s->last.n_bases) FCHK(v, hipMemcpyAsync(quals, s->d_quals, s->last.n_bases, hipMemcpyDeviceToHost, st));
     FCHK(v, hipStreamSynchronize(st));
+    return BB_OK;
+}
+
+extern "C" int bb_fastq_fetch_lines(bb_ctx* ctx, uint64_t* line_ends) {
+    if (!ctx) return BB_E_INVALID;
+    bb_ctx_view v = bb_ctx_get_view(ctx);
+    bb_fastq_state* s = *v.fastq;
+    if (!s) { *v.last_error = "no FASTQ block has been ingested"; return BB_E_INVALID; }
+    const uint64_t n = s->last.n_records * s->last_lpr;
+    if (n == 0) return BB_OK;
+    if (!line_ends) return BB_E_INVALID;
+    FCHK(v, hipSetDevice(v.device));
+    FCHK(v, hipMemcpyAsync(line_ends, s->d_nl, n * 8, hipMemcpyDeviceToHost, v.stream));
+    FCHK(v, hipStreamSynchronize(v.stream));
     return BB_OK;
 }
 

@@ -382,10 +382,11 @@ extern "C" int bb_trim_set(bb_ctx* ctx, const bb_trim_config* cfg, const uint8_t
     return BB_OK;
 }
 
-extern "C" int bb_trim_batch_dev(bb_ctx* ctx, const bb_row* d_rows, const bb_row_verdict* d_ver, uint64_t n_rows, const uint8_t* d_bases,
-                                 const uint8_t* d_quals, const uint64_t* d_offsets, const bb_headers* h, uint32_t n_reads, uint8_t* d_text,
-                                 uint64_t text_cap, uint64_t* text_len, bb_slice* d_slices, uint64_t slices_cap, uint64_t* n_slices,
-                                 bb_label_span* d_spans, uint32_t spans_cap, uint32_t* n_spans, uint8_t* d_status) {
+// plan_only: everything but the record text — slices in text order with their offsets and lengths, spans, statuses
+static int trim_impl(bb_ctx* ctx, const bb_row* d_rows, const bb_row_verdict* d_ver, uint64_t n_rows, const uint8_t* d_bases,
+                     const uint8_t* d_quals, const uint64_t* d_offsets, const bb_headers* h, uint32_t n_reads, uint8_t* d_text,
+                     uint64_t text_cap, uint64_t* text_len, bb_slice* d_slices, uint64_t slices_cap, uint64_t* n_slices,
+                     bb_label_span* d_spans, uint32_t spans_cap, uint32_t* n_spans, uint8_t* d_status, bool plan_only) {
     if (!ctx || !text_len || !n_slices || !n_spans || !h || (n_reads && (!d_offsets || !d_status)) || (n_rows && (!d_rows || !d_ver)))
         return BB_E_INVALID;
     bb_ctx_view v = bb_ctx_get_view(ctx);
@@ -474,7 +475,7 @@ extern "C" int bb_trim_batch_dev(bb_ctx* ctx, const bb_row* d_rows, const bb_row
     }
     TCHK(v, hipEventRecord(ev[1], st));
     *text_len = tl; *n_slices = ns; *n_spans = nsp;
-    if (tl > text_cap || ns > slices_cap || nsp > spans_cap || (tl && !d_text) || (ns && !d_slices) || (nsp && !d_spans)) return BB_E_CAPACITY;
+    if ((!plan_only && (tl > text_cap || (tl && !d_text))) || ns > slices_cap || nsp > spans_cap || (ns && !d_slices) || (nsp && !d_spans)) return BB_E_CAPACITY;
     if (ns) {
         const uint32_t n = (uint32_t)ns;
         // spans: few (one per output label) -> ordered and completed on the host
@@ -488,8 +489,11 @@ extern "C" int bb_trim_batch_dev(bb_ctx* ctx, const bb_row* d_rows, const bb_row
         }
         TCHK(v, hipMemcpyAsync(d_spans, sp.data(), sizeof(bb_label_span) * nsp, hipMemcpyHostToDevice, st));
         TCHK(v, hipMemcpyAsync(d_slices, s->d_sorted, sizeof(bb_slice) * ns, hipMemcpyDeviceToDevice, st));
-        hipLaunchKernelGGL(k_trim_render, dim3((n + 3) / 4), dim3(256), 0, st, (const bb_slice*)s->d_sorted, n, d_bases, d_quals, d_offsets, h->hdr,
-                           h->hdr_offsets, h->id_len, h->desc_start, s->cfg, d_text);
+        if (!plan_only) {
+            if (!d_bases || !d_quals) { *v.last_error = "bb_trim_batch_dev needs bases and qualities (a two-line FASTQ block has none: bb_trim_plan_dev)"; return BB_E_INVALID; }
+            hipLaunchKernelGGL(k_trim_render, dim3((n + 3) / 4), dim3(256), 0, st, (const bb_slice*)s->d_sorted, n, d_bases, d_quals, d_offsets, h->hdr,
+                               h->hdr_offsets, h->id_len, h->desc_start, s->cfg, d_text);
+        }
         TCHK(v, hipGetLastError());
     }
     TCHK(v, hipEventRecord(ev[2], st));
@@ -498,6 +502,21 @@ extern "C" int bb_trim_batch_dev(bb_ctx* ctx, const bb_row* d_rows, const bb_row
     (void)hipEventElapsedTime(&s->last_ms[1], ev[1], ev[2]);
     s->last_ms[2] = s->last_ms[0] + s->last_ms[1];
     return BB_OK;
+}
+
+extern "C" int bb_trim_batch_dev(bb_ctx* ctx, const bb_row* d_rows, const bb_row_verdict* d_ver, uint64_t n_rows, const uint8_t* d_bases,
+                                 const uint8_t* d_quals, const uint64_t* d_offsets, const bb_headers* h, uint32_t n_reads, uint8_t* d_text,
+                                 uint64_t text_cap, uint64_t* text_len, bb_slice* d_slices, uint64_t slices_cap, uint64_t* n_slices,
+                                 bb_label_span* d_spans, uint32_t spans_cap, uint32_t* n_spans, uint8_t* d_status) {
+    return trim_impl(ctx, d_rows, d_ver, n_rows, d_bases, d_quals, d_offsets, h, n_reads, d_text, text_cap, text_len, d_slices, slices_cap, n_slices,
+                     d_spans, spans_cap, n_spans, d_status, false);
+}
+
+extern "C" int bb_trim_plan_dev(bb_ctx* ctx, const bb_row* d_rows, const bb_row_verdict* d_ver, uint64_t n_rows, const uint64_t* d_offsets,
+                                const bb_headers* h, uint32_t n_reads, uint64_t* text_len, bb_slice* d_slices, uint64_t slices_cap,
+                                uint64_t* n_slices, bb_label_span* d_spans, uint32_t spans_cap, uint32_t* n_spans, uint8_t* d_status) {
+    return trim_impl(ctx, d_rows, d_ver, n_rows, nullptr, nullptr, d_offsets, h, n_reads, nullptr, 0, text_len, d_slices, slices_cap, n_slices,
+                     d_spans, spans_cap, n_spans, d_status, true);
 }
 
 extern "C" int bb_trim_batch(bb_ctx* ctx, const bb_row* rows, const bb_row_verdict* ver, uint64_t n_rows, const uint8_t* bases,

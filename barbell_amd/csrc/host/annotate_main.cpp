@@ -69,11 +69,12 @@ static void usage() {
         "                            [--no-compact (upload the quality lines too; without --trim-output they are dropped on the host)]\n"
         "                            [(-f <PATTERN_FILE>... | --kit-filter [--maximize]) [--filtered FILE] [--dropped FILE]]\n"
         "                            [--trim-output DIR [--no-label] [--no-orientation] [--no-flanks] [--sort-labels]\n"
-        "                             [--only-side left|right] [--failed-out FILE] [--skip-trim] [--flip] [--gzip]]\n"
+        "                             [--only-side left|right] [--failed-out FILE] [--skip-trim] [--flip] [--gzip]\n"
+        "                             [--gpu-render (records rendered in HBM and downloaded; default: the GPU plans, the file writers cut them out of the staged text)]]\n"
         "                            [--inspect [-n TOP=10] [--read-pattern-out FILE] [-s BUCKET=250]]\n"
         "       barbell-amd kit -k <KIT> -i <FASTQ>... -o <OUT_DIR> [--maximize] [--min-score F] [--min-score-diff F]\n"
         "                       [--flank-max-errors INT] [--failed-out FILE] [--use-extended] [--alpha F] [--gzip] [-t N]\n"
-        "                       [--device D=0] [--shard R/W]\n"
+        "                       [--device D=0] [--shard R/W] [--gpu-render]\n"
         "       barbell-amd kits          list the supported kit names\n"
         "       barbell-amd pattern <STR>...   parse filter pattern strings and print their elements\n",
         stderr);
@@ -130,6 +131,7 @@ int main(int argc, char** argv) {
             else if (a == "--verbose") { k.verbose = true; multi_in = false; }
             else if (a == "--use-extended") { k.use_extended = true; multi_in = false; }
             else if (a == "--gzip") { k.gzip = true; multi_in = false; }
+            else if (a == "--gpu-render") { k.host_cut = false; multi_in = false; }
             else if (!a.empty() && a[0] != '-' && multi_in) input.push_back(a);
             else { fprintf(stderr, "error: unexpected argument '%s'\n", a.c_str()); usage(); return 2; }
         }
@@ -178,6 +180,7 @@ int main(int argc, char** argv) {
         else if (a == "--streams") { cfg.streams_per_device = (unsigned)atoi(need("--streams")); multi = nullptr; }
         else if (a == "--counts") { cfg.counts_file = need("--counts"); multi = nullptr; }
         else if (a == "--no-compact") { cfg.compact_upload = false; multi = nullptr; }
+        else if (a == "--gpu-render") { cfg.host_cut = false; multi = nullptr; }
         else if (a == "--policy") { if (!set_policy(need("--policy"))) return 2; multi = nullptr; }
         else if (a == "--shard") { shard = need("--shard"); multi = nullptr; }
         else if (a == "-f" || a == "--filter-file") { multi = &pattern_files; }

@@ -501,10 +501,7 @@ void Demuxer::set_trim(const TrimConfig& cfg) {
     sorted.erase(std::unique(sorted.begin(), sorted.end()), sorted.end());
     std::vector<uint32_t> rank(2 * n);
     for (size_t i = 0; i < 2 * n; ++i) rank[i] = (uint32_t)(std::lower_bound(sorted.begin(), sorted.end(), parts[i]) - sorted.begin());
-    bb_trim_config c{};
-    c.add_labels = cfg.add_labels; c.add_orientation = cfg.add_orientation; c.add_flank = cfg.add_flank; c.sort_labels = cfg.sort_labels;
-    c.only_side = !cfg.only_side ? BB_SIDE_NONE : (*cfg.only_side == LabelSide::Left ? BB_SIDE_LEFT : BB_SIDE_RIGHT);
-    c.write_full_header = cfg.write_full_header; c.skip_trim = cfg.skip_trim; c.flip = cfg.flip;
+    const bb_trim_config c = trim_config_pod();
     const int rc = bb_trim_set(ctx_, &c, is_flank.data(), rank.data(), (uint32_t)n);
     if (rc != BB_OK) throw BarbellError(rc, std::string("bb_trim_set: ") + bb_strerror(rc) + " " + bb_last_error(ctx_));
     has_trim_ = true;
@@ -685,6 +682,44 @@ std::vector<std::pair<uint32_t, std::string>> Demuxer::inspect_ingested(bool wit
     return elems_to_patterns(el);
 }
 
+// The same, interned: a few hundred distinct patterns cover millions of reads, so a read's elements (their bytes are the key) are
+// looked up first and the pattern text is only formatted the first time it is seen in the batch.
+void Demuxer::inspect_ingested_interned(bool with_verdicts, uint32_t bucket_size, std::vector<std::string>& patterns,
+                                        std::vector<std::pair<uint32_t, uint32_t>>& per_read) {
+    static const char* const TAG[] = {"", "@left", "@right", "@prev_left"};
+    patterns.clear(); per_read.clear();
+    if (!n_rows_) return;
+    std::vector<bb_inspect_elem> el(n_rows_);
+    d_elems_.ensure(ctx_, n_rows_ * sizeof(bb_inspect_elem));
+    int rc = bb_inspect_rows_dev(ctx_, (const bb_row*)d_rows_.p, with_verdicts ? (const bb_row_verdict*)d_ver_.p : nullptr, n_rows_, bucket_size,
+                                 (bb_inspect_elem*)d_elems_.p);
+    if (rc != BB_OK) BB_THROW(rc, "bb_inspect_rows_dev");
+    if ((rc = bb_dev_download(ctx_, el.data(), d_elems_.p, n_rows_ * sizeof(bb_inspect_elem))) != BB_OK) BB_THROW(rc, "bb_dev_download");
+    std::unordered_map<std::string, uint32_t> seen;
+    std::string key;
+    for (uint64_t i = 0; i < n_rows_;) {
+        uint64_t j = i + 1;
+        while (j < n_rows_ && !el[j].first) ++j;
+        key.assign((const char*)&el[i], (size_t)(j - i) * sizeof(bb_inspect_elem));  // `first` is 1, 0, 0, .. in every key: harmless
+        auto it = seen.find(key);
+        if (it == seen.end()) {
+            std::string text;
+            for (uint64_t k = i; k < j; ++k) {
+                const bb_inspect_elem& e = el[k];
+                char buf[128];
+                snprintf(buf, sizeof buf, "%s[%s, *%s, %s(%u..%u)]", as_str((BarcodeType)e.match_type), e.strand ? "rc" : "fw",
+                         e.has_cut ? (e.strand ? ", >>" : ", <<") : "", TAG[e.tag & 3], e.lo, e.hi);
+                if (k > i) text += "__";
+                text += buf;
+            }
+            it = seen.emplace(key, (uint32_t)patterns.size()).first;
+            patterns.push_back(std::move(text));
+        }
+        per_read.emplace_back(rows_[i].read_idx, it->second);
+        i = j;
+    }
+}
+
 TrimBatch Demuxer::trim_ingested() {
     if (!has_trim_) throw BarbellError(BB_E_INVALID, "trim_ingested without set_trim");
     const uint32_t n = (uint32_t)ing_.info.n_records;
@@ -735,6 +770,101 @@ TrimBatch Demuxer::trim_ingested() {
         if ((r2 = bb_dev_download(ctx_, t.status.data(), d_status_.p, n)) != BB_OK) BB_THROW(r2, "bb_dev_download");
         return t;
     }
+}
+
+bb_trim_config Demuxer::trim_config_pod() const {
+    const TrimConfig& cfg = trim_cfg_;
+    bb_trim_config c{};
+    c.add_labels = cfg.add_labels; c.add_orientation = cfg.add_orientation; c.add_flank = cfg.add_flank; c.sort_labels = cfg.sort_labels;
+    c.only_side = !cfg.only_side ? BB_SIDE_NONE : (*cfg.only_side == LabelSide::Left ? BB_SIDE_LEFT : BB_SIDE_RIGHT);
+    c.write_full_header = cfg.write_full_header; c.skip_trim = cfg.skip_trim; c.flip = cfg.flip;
+    return c;
+}
+
+TrimPlan Demuxer::trim_plan_ingested() {
+    if (!has_trim_) throw BarbellError(BB_E_INVALID, "trim_plan_ingested without set_trim");
+    const uint32_t n = (uint32_t)ing_.info.n_records;
+    TrimPlan t;
+    t.status.assign(n, 0);
+    uint64_t slices_cap = 2ull * n + 64;
+    uint32_t spans_cap = 4096;
+    d_status_.ensure(ctx_, (uint64_t)n + 16);
+    for (;;) {
+        d_slices_.ensure(ctx_, slices_cap * sizeof(bb_slice));
+        d_spans_.ensure(ctx_, (uint64_t)spans_cap * sizeof(bb_label_span));
+        uint64_t tl = 0, ns = 0;
+        uint32_t nsp = 0;
+        const int rc = bb_trim_plan_dev(ctx_, (const bb_row*)d_rows_.p, (const bb_row_verdict*)d_ver_.p, n_rows_, batch_.d_offsets, &batch_.d_headers, n,
+                                        &tl, (bb_slice*)d_slices_.p, slices_cap, &ns, (bb_label_span*)d_spans_.p, spans_cap, &nsp, (uint8_t*)d_status_.p);
+        if (rc == BB_E_CAPACITY) { slices_cap = std::max(slices_cap, ns); spans_cap = std::max(spans_cap, nsp); continue; }
+        if (rc != BB_OK) BB_THROW(rc, "bb_trim_plan_dev");
+        t.text_len = tl;
+        t.slices.resize(ns); t.spans.resize(nsp);
+        int r2;
+        if (ns && (r2 = bb_dev_download(ctx_, t.slices.data(), d_slices_.p, ns * sizeof(bb_slice))) != BB_OK) BB_THROW(r2, "bb_dev_download");
+        if (nsp && (r2 = bb_dev_download(ctx_, t.spans.data(), d_spans_.p, (uint64_t)nsp * sizeof(bb_label_span))) != BB_OK) BB_THROW(r2, "bb_dev_download");
+        if (n && (r2 = bb_dev_download(ctx_, t.status.data(), d_status_.p, n)) != BB_OK) BB_THROW(r2, "bb_dev_download");
+        if (ns) {  // what the writers need to find a record's lines in the block's text
+            t.line_ends.resize(4ull * n); t.id_len.resize(n); t.desc_start.resize(n);
+            if ((r2 = bb_fastq_fetch_lines(ctx_, t.line_ends.data())) != BB_OK) BB_THROW(r2, "bb_fastq_fetch_lines");
+            if ((r2 = bb_fastq_fetch(ctx_, nullptr, nullptr, nullptr, t.id_len.data(), t.desc_start.data(), nullptr, nullptr)) != BB_OK) BB_THROW(r2, "bb_fastq_fetch");
+        }
+        return t;
+    }
+}
+
+namespace {
+struct CompTable {  // trim.rs:486-530: A<->T C<->G R<->Y K<->M B<->V D<->H in both cases, every other byte stays
+    uint8_t t[256];
+    CompTable() {
+        for (int i = 0; i < 256; ++i) t[i] = (uint8_t)i;
+        const char* pairs = "ATCGRYKMBVDH";
+        for (int i = 0; pairs[i]; i += 2) {
+            const uint8_t a = (uint8_t)pairs[i], b = (uint8_t)pairs[i + 1];
+            t[a] = b; t[b] = a; t[a | 0x20] = (uint8_t)(b | 0x20); t[b | 0x20] = (uint8_t)(a | 0x20);
+        }
+    }
+};
+const CompTable kComp;
+}  // namespace
+
+size_t render_trim_record(uint8_t* dst, const uint8_t* text, const TrimPlan& plan, const bb_slice& s, const bb_trim_config& cfg) {
+    const uint64_t* nl = plan.line_ends.data() + 4ull * s.read_idx;
+    auto span = [&](int j, uint64_t& a, uint64_t& b) {  // line j of the record without its line end
+        a = (s.read_idx || j) ? nl[j - 1] + 1 : 0;
+        b = nl[j];
+        if (b > a && text[b - 1] == '\r') --b;
+    };
+    uint64_t hs, he, ss, se, qs, qe;
+    span(0, hs, he); span(1, ss, se); span(3, qs, qe);
+    const uint32_t hl = he > hs ? (uint32_t)(he - hs - 1) : 0u, idl = plan.id_len[s.read_idx], ds = plan.desc_start[s.read_idx];
+    uint8_t* w = dst;
+    *w++ = '@';
+    memcpy(w, text + hs + 1, idl); w += idl;
+    if (s.suffix) {  // "_n" (trim.rs:271)
+        char tmp[8];
+        const int k = snprintf(tmp, sizeof(tmp), "_%u", (unsigned)s.suffix);
+        memcpy(w, tmp, (size_t)k); w += k;
+    }
+    if (cfg.write_full_header && hl > ds) { *w++ = ' '; memcpy(w, text + hs + 1 + ds, hl - ds); w += hl - ds; }
+    *w++ = '\n';
+    const uint32_t seq_len = (uint32_t)(se - ss);
+    const uint32_t s0 = cfg.skip_trim ? 0u : s.start, L = (cfg.skip_trim ? seq_len : s.end) - s0;
+    const uint8_t* sp = text + ss + s0;
+    const uint8_t* qp = text + qs + s0;
+    if (!s.flip) {
+        memcpy(w, sp, L); w += L;
+        *w++ = '\n'; *w++ = '+'; *w++ = '\n';
+        memcpy(w, qp, L); w += L;
+    } else {
+        for (uint32_t k = 0; k < L; ++k) w[k] = kComp.t[sp[L - 1u - k]];
+        w += L;
+        *w++ = '\n'; *w++ = '+'; *w++ = '\n';
+        for (uint32_t k = 0; k < L; ++k) w[k] = qp[L - 1u - k];
+        w += L;
+    }
+    *w++ = '\n';
+    return (size_t)(w - dst);
 }
 
 // ---- annotate (annotator.rs) ----------------------------------------------------------------------
@@ -899,19 +1029,26 @@ struct ParallelInflater {
 struct LabelWriters {  // the per-label writers of trim_matches (trim.rs:356-446)
     std::string folder;
     bool gz;
-    // Writes run on K threads of their own (one write() stream moves ~6 GB/s of page cache, the GPU renders records several
-    // times faster): a label's file belongs to one thread — label hash mod K — so the records of a file stay in batch order
-    // and no two threads share a handle.  A batch is done when the last of its spans is written; at most `max_outstanding`
-    // batches exist (wait()), which bounds the rendered text held in page-locked buffers.
-    struct Span { std::string label; const uint8_t* p; size_t n; std::shared_ptr<void> keep; };
+    // Writes run on K threads of their own (one write() stream moves ~3-6 GB/s of page cache, the GPU plans or renders records many
+    // times faster).  A label's file is worked on by one thread at a time and its spans in submission order, so the records of a file
+    // stay in batch order and no two threads share a handle; WHICH thread is decided when the work is there (labels with queued spans
+    // wait in `ready`, a free thread takes the next one and drains it), so that no thread idles while another has twelve labels of
+    // a block to itself.  A batch is done when the last of its spans is written; at most `max_outstanding` batches exist (wait()),
+    // which bounds the text held in page-locked buffers.
+    // A span is either bytes to write as they are (rendered on the GPU) or, with `cut`, the records slices[first, first + n_records) to be cut out
+    // of the block's own text first (host_cut): the thread renders them into its buffer — n bytes, laid out by the plan's offsets — and writes that
+    struct Cut { const uint8_t* text; TrimPlan plan; bb_trim_config cfg; std::shared_ptr<void> hold; };
+    struct Span { std::string label; const uint8_t* p; size_t n; std::shared_ptr<void> keep; std::shared_ptr<const Cut> cut; uint64_t first = 0, off = 0; uint32_t n_records = 0; };
     struct Item { Span sp; std::shared_ptr<std::atomic<int>> left; };
-    struct Lane {
+    struct LabelQ {
         std::deque<Item> q;
-        std::map<std::string, gzFile> gzs;
-        std::map<std::string, FILE*> plain;
-        std::thread th;
+        bool busy = false, listed = false;
+        gzFile gzf = nullptr;
+        FILE* plain = nullptr;
     };
-    std::vector<std::unique_ptr<Lane>> lanes;
+    std::map<std::string, std::unique_ptr<LabelQ>> labels;
+    std::deque<LabelQ*> ready;
+    std::vector<std::thread> threads;
     std::mutex mu;
     std::condition_variable cv;
     bool stop = false;
@@ -919,29 +1056,52 @@ struct LabelWriters {  // the per-label writers of trim_matches (trim.rs:356-446
     std::string err;
     LabelWriters(std::string f, bool g, unsigned k = 0) : folder(std::move(f)), gz(g) {
         if (k == 0) { const char* e = getenv("BARBELL_AMD_WRITERS"); k = e ? (unsigned)std::max(1, atoi(e)) : 8u; }
-        for (unsigned i = 0; i < k; ++i) lanes.emplace_back(new Lane());
-        for (unsigned i = 0; i < k; ++i) lanes[i]->th = std::thread([this, i]() { run(*lanes[i]); });
+        for (unsigned i = 0; i < k; ++i) threads.emplace_back([this]() { run(); });
     }
-    void run(Lane& L) {
+    void run() {
+        std::vector<uint8_t> buf;
         for (;;) {
-            Item it;
+            LabelQ* L;
             {
                 std::unique_lock<std::mutex> lk(mu);
-                cv.wait(lk, [&]() { return stop || !L.q.empty(); });
-                if (L.q.empty()) return;
-                it = std::move(L.q.front());
-                L.q.pop_front();
+                cv.wait(lk, [&]() { return stop || !ready.empty(); });
+                if (ready.empty()) return;
+                L = ready.front();
+                ready.pop_front();
+                L->listed = false; L->busy = true;
             }
-            try {
-                write(L, it.sp.label, it.sp.p, it.sp.n);
-            } catch (const std::exception& e) {
-                std::lock_guard<std::mutex> lk(mu);
-                if (err.empty()) err = e.what();
-            }
-            it.sp.keep.reset();
-            if (it.left->fetch_sub(1) == 1) {
-                { std::lock_guard<std::mutex> lk(mu); --outstanding; }
-                cv.notify_all();
+            for (;;) {
+                Item it;
+                {
+                    std::lock_guard<std::mutex> lk(mu);
+                    if (L->q.empty()) { L->busy = false; break; }
+                    it = std::move(L->q.front());
+                    L->q.pop_front();
+                }
+                try {
+                    if (it.sp.cut) {
+                        const Cut& c = *it.sp.cut;
+                        if (buf.size() < it.sp.n) buf.resize(it.sp.n + it.sp.n / 4);
+                        size_t total = 0;
+                        for (uint64_t k = it.sp.first; k < it.sp.first + it.sp.n_records; ++k) {
+                            const bb_slice& sl = c.plan.slices[k];
+                            const size_t got = render_trim_record(buf.data() + (sl.out_off - it.sp.off), c.text, c.plan, sl, c.cfg);
+                            if (got != sl.rec_len) throw BarbellError(BB_E_INVALID, "internal: a record cut on the host differs in length from the GPU's plan");
+                            total += got;
+                        }
+                        if (total != it.sp.n) throw BarbellError(BB_E_INVALID, "internal: records of a label do not fill its span");
+                        write(*L, it.sp.label, buf.data(), it.sp.n);
+                    } else write(*L, it.sp.label, it.sp.p, it.sp.n);
+                } catch (const std::exception& e) {
+                    std::lock_guard<std::mutex> lk(mu);
+                    if (err.empty()) err = e.what();
+                }
+                it.sp.keep.reset();
+                it.sp.cut.reset();
+                if (it.left->fetch_sub(1) == 1) {
+                    { std::lock_guard<std::mutex> lk(mu); --outstanding; }
+                    cv.notify_all();
+                }
             }
         }
     }
@@ -958,35 +1118,34 @@ struct LabelWriters {  // the per-label writers of trim_matches (trim.rs:356-446
             std::lock_guard<std::mutex> lk(mu);
             ++outstanding;
             for (auto& sp : job) {
-                Lane& L = *lanes[std::hash<std::string>{}(sp.label) % lanes.size()];
-                L.q.push_back(Item{std::move(sp), left});
+                auto& slot = labels[sp.label];
+                if (!slot) slot = std::make_unique<LabelQ>();
+                LabelQ* L = slot.get();
+                L->q.push_back(Item{std::move(sp), left});
+                if (!L->busy && !L->listed) { L->listed = true; ready.push_back(L); }   // a busy label's thread finds the new span itself
             }
         }
         cv.notify_all();
     }
-    void write(Lane& L, const std::string& label, const uint8_t* p, size_t n) {
+    void write(LabelQ& L, const std::string& label, const uint8_t* p, size_t n) {
         const std::string path = folder + "/" + label + (gz ? ".trimmed.fastq.gz" : ".trimmed.fastq");
         if (gz) {
-            auto it = L.gzs.find(label);
-            if (it == L.gzs.end()) {
-                gzFile f = gzopen(path.c_str(), "wb");
-                if (!f) throw BarbellError(BB_E_INVALID, "Failed to create output file '" + path + "'\nTry setting ulimit higher: \"ulimit -n 65000\"");
-                it = L.gzs.emplace(label, f).first;
+            if (!L.gzf) {
+                L.gzf = gzopen(path.c_str(), "wb");
+                if (!L.gzf) throw BarbellError(BB_E_INVALID, "Failed to create output file '" + path + "'\nTry setting ulimit higher: \"ulimit -n 65000\"");
             }
             for (size_t o = 0; o < n;) {
                 const unsigned chunk = (unsigned)std::min<size_t>(n - o, 1u << 30);
-                if (gzwrite(it->second, p + o, chunk) <= 0) throw BarbellError(BB_E_INVALID, "Failed to write sequence to '" + path + "'");
+                if (gzwrite(L.gzf, p + o, chunk) <= 0) throw BarbellError(BB_E_INVALID, "Failed to write sequence to '" + path + "'");
                 o += chunk;
             }
         } else {
-            auto it = L.plain.find(label);
-            if (it == L.plain.end()) {
-                FILE* f = fopen(path.c_str(), "wb");
-                if (!f) throw BarbellError(BB_E_INVALID, "Failed to create output file '" + path + "'\nTry setting ulimit higher: \"ulimit -n 65000\"");
-                setvbuf(f, nullptr, _IONBF, 0);  // spans are large and contiguous: straight to write()
-                it = L.plain.emplace(label, f).first;
+            if (!L.plain) {
+                L.plain = fopen(path.c_str(), "wb");
+                if (!L.plain) throw BarbellError(BB_E_INVALID, "Failed to create output file '" + path + "'\nTry setting ulimit higher: \"ulimit -n 65000\"");
+                setvbuf(L.plain, nullptr, _IONBF, 0);  // spans are large and contiguous: straight to write()
             }
-            if (n && fwrite(p, 1, n, it->second) != n) throw BarbellError(BB_E_INVALID, "Failed to write sequence to '" + path + "'");
+            if (n && fwrite(p, 1, n, L.plain) != n) throw BarbellError(BB_E_INVALID, "Failed to write sequence to '" + path + "'");
         }
     }
     ~LabelWriters() {
@@ -995,10 +1154,10 @@ struct LabelWriters {  // the per-label writers of trim_matches (trim.rs:356-446
             stop = true;
         }
         cv.notify_all();
-        for (auto& L : lanes) if (L->th.joinable()) L->th.join();  // each drains its queue first
-        for (auto& L : lanes) {
-            for (auto& kv : L->gzs) gzclose(kv.second);
-            for (auto& kv : L->plain) fclose(kv.second);
+        for (auto& t : threads) if (t.joinable()) t.join();  // they drain the ready list first
+        for (auto& kv : labels) {
+            if (kv.second->gzf) gzclose(kv.second->gzf);
+            if (kv.second->plain) fclose(kv.second->plain);
         }
     }
 };
@@ -1302,9 +1461,10 @@ struct BlockResult {
     std::string failed_ids;                                     // one id per line
     std::shared_ptr<void> text;                                 // holds the page-locked buffer of the rendered records
     const uint8_t* text_ptr = nullptr;
-    struct Span { std::string label; size_t off, n; };
+    struct Span { std::string label; size_t off, n; uint64_t first = 0; uint32_t n_records = 0; };
     std::vector<Span> spans;
-    double t_ingest = 0, t_gpu = 0, t_rest = 0;
+    std::shared_ptr<const LabelWriters::Cut> cut;              // host_cut: the plan + the block's text, records cut by the writer threads
+    double t_ingest = 0, t_gpu = 0, t_rest = 0, t_filter = 0, t_inspect = 0, t_trim = 0;
 };
 }  // namespace
 
@@ -1347,13 +1507,14 @@ AnnotateStats annotate(const std::vector<std::string>& read_files, const std::st
     }
     AnnotateStats st;
     std::unique_ptr<LabelWriters> writers;
+    const bool host_cut = trimming && config.host_cut && !getenv("BARBELL_AMD_GPU_RENDER");
     FILE* failed_f = nullptr;
     if (trimming) {
         if (mkdir(config.trim_folder.c_str(), 0777) != 0 && errno != EEXIST) {
             fclose(out);
             throw BarbellError(BB_E_INVALID, "Failed to create output folder '" + config.trim_folder + "'");
         }
-        writers = std::make_unique<LabelWriters>(config.trim_folder, config.trim->gzip);
+        writers = std::make_unique<LabelWriters>(config.trim_folder, config.trim->gzip, getenv("BARBELL_AMD_WRITERS") ? 0u : (host_cut ? 16u : 8u));
         if (config.trim->failed_trimmed_writer) failed_f = fopen(config.trim->failed_trimmed_writer->c_str(), "w");
     }
     FILE* ppr_f = nullptr;
@@ -1370,16 +1531,22 @@ AnnotateStats annotate(const std::vector<std::string>& read_files, const std::st
         writers.reset();
     };
     const bool two_line = config.compact_upload && !trimming;  // nothing downstream of annotate / filter / inspect reads qualities
+
     const bool prof = getenv("BARBELL_AMD_PROFILE") != nullptr;
     auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const bool want_ids = ppr_f != nullptr || failed_f != nullptr;
 
     // ---- one block on its context: parsed, annotated, rendered, filtered, inspected and trimmed in HBM -------------
-    auto process = [&](Demuxer& dm, const BlockFeeder::Block& blk, BlockFeeder& feeder) -> BlockResult {
+    auto process = [&](Demuxer& dm, const BlockFeeder::Block& blk, const std::shared_ptr<BlockFeeder>& feeder) -> BlockResult {
         BlockResult R;
         double t0 = now();
         const auto ing = dm.ingest(blk.data, blk.len, true, want_ids, two_line);  // blocks hold whole records only
-        feeder.release(blk.slot);                                       // the text is in HBM: the slot can be refilled
+        std::shared_ptr<void> text_hold;   // host_cut: the slot stays until the writer threads have cut the block's records out of it
+        if (host_cut) {
+            const int slot = blk.slot;
+            auto big = blk.big;
+            text_hold = std::shared_ptr<void>((void*)blk.data, [feeder, slot, big](void*) { feeder->release(slot); });
+        } else feeder->release(blk.slot);                               // the text is in HBM: the slot can be refilled
         R.t_ingest = now() - t0; t0 = now();
         const auto& ids = ing.ids;
         R.n_reads = (size_t)ing.info.n_records;
@@ -1391,6 +1558,7 @@ AnnotateStats annotate(const std::vector<std::string>& read_files, const std::st
         dm.format_ingested(BB_FMT_ALL, R.anno);
         R.t_gpu = now() - t0; t0 = now();
         std::vector<bb_row_verdict> verdicts;
+        double t1 = now();
         if (filtering) {
             verdicts = dm.filter_ingested();
             for (uint64_t i = 0; i < n_rows; ++i)
@@ -1398,17 +1566,34 @@ AnnotateStats annotate(const std::vector<std::string>& read_files, const std::st
             if (kept_f) dm.format_ingested(BB_FMT_KEPT, R.kept_tsv);
             if (drop_f) dm.format_ingested(BB_FMT_DROPPED, R.drop_tsv);
         }
+        R.t_filter = now() - t1; t1 = now();
         if (config.inspect) {  // inspect.rs:128-184 on the annotation rows (no cuts yet)
             // counted per block here, merged by the commit stage (it used to look every read's string up in one map)
-            std::unordered_map<std::string, size_t> idx;
-            for (auto& rp : dm.inspect_ingested(false, config.bucket_size)) {
-                if (ppr_f) { R.ppr += ids[rp.first]; R.ppr += '\t'; R.ppr += rp.second; R.ppr += '\n'; }
-                auto it = idx.find(rp.second);
-                if (it == idx.end()) { idx.emplace(rp.second, R.patterns.size()); R.patterns.emplace_back(std::move(rp.second), 1); }
-                else ++R.patterns[it->second].second;
+            std::vector<std::string> distinct;
+            std::vector<std::pair<uint32_t, uint32_t>> per_read;   // (read, index into distinct), read order; distinct is in first-appearance order
+            dm.inspect_ingested_interned(false, config.bucket_size, distinct, per_read);
+            for (auto& d : distinct) R.patterns.emplace_back(d, 0);
+            if (ppr_f) R.ppr.reserve(per_read.size() * 64);
+            for (const auto& rp : per_read) {
+                if (ppr_f) { R.ppr += ids[rp.first]; R.ppr += '\t'; R.ppr += distinct[rp.second]; R.ppr += '\n'; }
+                ++R.patterns[rp.second].second;
             }
         }
-        if (trimming) {  // trim.rs:385-460: the GPU cut and rendered the records, one write per label
+        R.t_inspect = now() - t1; t1 = now();
+        if (trimming && host_cut) {  // trim.rs:385-460: the GPU decided slices, labels and the layout of every label's records; the writers copy
+            auto cut = std::make_shared<LabelWriters::Cut>();
+            cut->text = blk.data; cut->plan = dm.trim_plan_ingested(); cut->cfg = dm.trim_config_pod(); cut->hold = text_hold;
+            const TrimPlan& t = cut->plan;
+            for (const auto& sp : t.spans) R.spans.push_back({dm.label_of_key(sp.label_key), (size_t)sp.off, (size_t)sp.len, sp.first, sp.n_records});
+            std::vector<uint32_t> per_read(R.n_reads, 0);
+            for (const auto& sl : t.slices) ++per_read[sl.read_idx];
+            for (size_t i = 0; i < R.n_reads; ++i) {
+                if (t.status[i] == BB_TRIM_TRIMMED) ++R.trimmed;
+                if (per_read[i] > 1) ++R.split;
+                if (t.status[i] == BB_TRIM_FAILED) { ++R.trim_failed; if (failed_f) { R.failed_ids += ids[i]; R.failed_ids += '\n'; } }
+            }
+            R.cut = std::move(cut);
+        } else if (trimming) {  // the GPU cut and rendered the records, one write per label
             const TrimBatch t = dm.trim_ingested();
             R.text = t.text_hold; R.text_ptr = t.data();  // the page-locked landing buffer goes back to the demuxer's pool when the writers are done
             for (const auto& sp : t.spans) R.spans.push_back({dm.label_of_key(sp.label_key), (size_t)sp.off, (size_t)sp.len});
@@ -1420,10 +1605,12 @@ AnnotateStats annotate(const std::vector<std::string>& read_files, const std::st
                 if (t.status[i] == BB_TRIM_FAILED) { ++R.trim_failed; if (failed_f) { R.failed_ids += ids[i]; R.failed_ids += '\n'; } }
             }
         }
+        R.t_trim = now() - t1;
         R.t_rest = now() - t0;
         return R;
     };
-    double t_commit = 0, t_ingest = 0, t_gpu = 0, t_rest = 0;
+    double t_starved = 0;  // workers waiting for a block from the reader pool (under `mu`)
+    double t_commit = 0, t_ingest = 0, t_gpu = 0, t_rest = 0, t_filter = 0, t_inspect = 0, t_trim = 0, t_wwait = 0;
     auto commit = [&](BlockResult& R) {
         const double t0 = now();
         st.total += R.n_reads; st.found += R.found; st.rows += R.rows; st.kept += R.kept; st.dropped += R.dropped;
@@ -1444,12 +1631,18 @@ AnnotateStats annotate(const std::vector<std::string>& read_files, const std::st
         }
         if (failed_f && !R.failed_ids.empty()) fwrite(R.failed_ids.data(), 1, R.failed_ids.size(), failed_f);
         if (writers && !R.spans.empty()) {
+            const double tw = now();
             writers->wait(3);  // bounds the rendered text waiting for the writer threads
+            t_wwait += now() - tw;
             std::vector<LabelWriters::Span> job;
-            for (const auto& sp : R.spans) job.push_back({sp.label, R.text_ptr + sp.off, sp.n, R.text});
+            for (const auto& sp : R.spans) {
+                if (R.cut) job.push_back({sp.label, nullptr, sp.n, nullptr, R.cut, sp.first, sp.off, sp.n_records});
+                else job.push_back({sp.label, R.text_ptr + sp.off, sp.n, R.text, nullptr, 0, 0, 0});
+            }
+            R.cut.reset();
             writers->submit(std::move(job));
         }
-        t_ingest += R.t_ingest; t_gpu += R.t_gpu; t_rest += R.t_rest;
+        t_ingest += R.t_ingest; t_gpu += R.t_gpu; t_rest += R.t_rest; t_filter += R.t_filter; t_inspect += R.t_inspect; t_trim += R.t_trim;
         t_commit += now() - t0;
     };
 
@@ -1466,8 +1659,10 @@ AnnotateStats annotate(const std::vector<std::string>& read_files, const std::st
     double t_start = 0, t_end = 0;
     try {
         // two-line mode: a slot is about half full and a chunk costs its reader a pass over the text, so twice the slots and readers
-        BlockFeeder feeder(dms[0]->ctx(), read_files, block, (unsigned)((two_line ? 2 : 1) * (3 * G + 2)),
-                           std::min<unsigned>(std::max(1u, config.n_threads), two_line ? 32u : 16u), config.n_threads, two_line);
+        // host_cut: a slot also waits for the writer threads (at most 4 blocks there), and the last holder may be one of them
+        auto feeder_p = std::make_shared<BlockFeeder>(dms[0]->ctx(), read_files, block, (unsigned)((two_line ? 2 : 1) * (3 * G + 2) + (host_cut ? 6 : 0)),
+                                                      std::min<unsigned>(std::max(1u, config.n_threads), 32u), config.n_threads, two_line);
+        BlockFeeder& feeder = *feeder_p;
         t_start = now();
         std::thread dispatcher([&]() {
             try {
@@ -1492,8 +1687,10 @@ AnnotateStats annotate(const std::vector<std::string>& read_files, const std::st
                     for (;;) {
                         BlockFeeder::Block b;
                         {
+                            const double tw0 = now();
                             std::unique_lock<std::mutex> lk(mu);
                             cv.wait(lk, [&]() { return abort || !inq[w].empty() || feed_done; });
+                            t_starved += now() - tw0;
                             if (abort) return;
                             if (inq[w].empty()) return;  // feed_done
                             b = inq[w].front();
@@ -1504,7 +1701,7 @@ AnnotateStats annotate(const std::vector<std::string>& read_files, const std::st
                             inq[w].pop_front();
                         }
                         cv.notify_all();
-                        BlockResult R = process(*dms[w], b, feeder);
+                        BlockResult R = process(*dms[w], b, feeder_p);
                         {
                             std::lock_guard<std::mutex> lk(mu);
                             results.emplace(b.index, std::move(R));
@@ -1562,8 +1759,9 @@ AnnotateStats annotate(const std::vector<std::string>& read_files, const std::st
         }
     }
     if (prof) fprintf(stderr, "profile: pipeline %.3f s for %zu reads (%.2f M reads/s) on %zu context(s); summed over blocks: upload+parse %.3f s, annotate+render %.3f s, "
-                      "filter/inspect/trim %.3f s; commit (file writes) %.3f s\n",
-                      st.seconds_pipeline, st.total, st.seconds_pipeline > 0 ? st.total / st.seconds_pipeline / 1e6 : 0.0, G, t_ingest, t_gpu, t_rest, t_commit);
+                      "filter/inspect/trim %.3f s (%.3f / %.3f / %.3f); commit (file writes) %.3f s, of which waiting for the label writers %.3f s; workers waiting for input %.3f s\n",
+                      st.seconds_pipeline, st.total, st.seconds_pipeline > 0 ? st.total / st.seconds_pipeline / 1e6 : 0.0, G, t_ingest, t_gpu, t_rest,
+                      t_filter, t_inspect, t_trim, t_commit, t_wwait, t_starved);
     for (const auto& p : pattern_order) st.patterns.emplace_back(p, pattern_count[p]);
     std::stable_sort(st.patterns.begin(), st.patterns.end(), [](const auto& a, const auto& c) { return a.second > c.second; });
     return st;
@@ -1603,6 +1801,7 @@ AnnotateStats demux_using_kit(const std::vector<std::string>& fastq_files, const
     c.trim = TrimConfig::for_kit(k.failed_out, k.gzip);
     c.trim_folder = k.output_folder;
     c.inspect = true;
+    c.host_cut = k.host_cut;
     c.read_pattern_out = k.output_folder + "/pattern_per_read.tsv";
     return annotate_with_kit(fastq_files, k.output_folder + "/annotation.tsv", k.kit_name, c);
 }

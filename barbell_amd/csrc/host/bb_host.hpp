@@ -97,6 +97,19 @@ struct TrimBatch {  // what bb_trim_batch returns for one batch
     std::vector<bb_label_span> spans;
     std::vector<uint8_t> status;  // BB_TRIM_* per read
 };
+// trim_plan_ingested: everything the trim step decides, nothing it copies — for a caller that still holds the block's FASTQ text
+// (the CLI: the page-locked slot the block was uploaded from).  render_trim_record cuts one record out of that text.
+struct TrimPlan {
+    std::vector<bb_slice> slices;       // text order: grouped by label, read order inside a label; out_off / rec_len set
+    std::vector<bb_label_span> spans;
+    std::vector<uint8_t> status;        // BB_TRIM_* per read
+    std::vector<uint64_t> line_ends;    // bb_fastq_fetch_lines: 4 per record
+    std::vector<uint32_t> id_len, desc_start;
+    uint64_t text_len = 0;              // bytes of all records
+};
+// the record of `s` exactly as bb_trim_batch renders it (trim.rs:447-460), cut out of the block's text; returns its length (== s.rec_len)
+size_t render_trim_record(uint8_t* dst, const uint8_t* block_text, const TrimPlan& plan, const bb_slice& s, const bb_trim_config& cfg);
+
 struct FastqBatch {  // one batch of records as the C-ABI wants them
     std::vector<std::string> ids;
     std::vector<uint8_t> bases, quals, hdr;
@@ -167,7 +180,11 @@ public:
     std::vector<BarbellMatch> demux_ingested();
     std::vector<bb_row_verdict> filter_ingested();
     TrimBatch trim_ingested();
+    TrimPlan trim_plan_ingested();   // bb_trim_plan_dev + the block's line ends: no record text crosses PCIe
+    bb_trim_config trim_config_pod() const;
     std::vector<std::pair<uint32_t, std::string>> inspect_ingested(bool with_verdicts, uint32_t bucket_size);
+    void inspect_ingested_interned(bool with_verdicts, uint32_t bucket_size, std::vector<std::string>& patterns,
+                                   std::vector<std::pair<uint32_t, uint32_t>>& per_read);  // per_read: (read, index into patterns)
     bb_group_info group_info(size_t g);
     const std::vector<BarcodeGroup>& queries() const { return queries_; }
 
@@ -214,6 +231,9 @@ struct AnnotateConfig {  // config.rs:3-12 with the CLI defaults of bin/main.rs:
                                           // that when the quality lines are dropped on the host), each block_bytes + 16 MiB or the largest input
                                           // file if that is smaller — 1.2 GiB at the defaults (2 contexts), 6 GiB at --streams 3 --block-bytes 256Mi
     bool compact_upload = true;           // without the trim step: drop the '+' and quality lines on the host (half the PCIe bytes); --no-compact
+    bool host_cut = true;                 // trim step: the GPU plans (slices, labels, offsets), the threads that write the per-label files cut the
+                                          // records out of the block's own page-locked text — the rendered records (as many bytes as went up) do
+                                          // not come back over PCIe.  false (--gpu-render): bb_trim_batch_dev renders them in HBM and they are downloaded
     int device = 0;
     // One FASTQ stream over several contexts: block i of the stream goes to context i mod G, rows are merged in
     // block order, the per-barcode histogram is all-reduced (RCCL when the devices are distinct).  Empty = {device}
@@ -253,6 +273,7 @@ struct KitConfig {  // config.rs:34-48, CLI defaults bin/main.rs:208-262
     bool use_extended = false;
     float alpha = 0.4f;
     bool gzip = false;
+    bool host_cut = true;   // AnnotateConfig::host_cut
     size_t batch_reads = 0;
     int device = 0;
     std::vector<int> devices;

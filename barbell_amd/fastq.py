@@ -56,6 +56,15 @@ def fetch(dm, info, bases=False, quals=False):
     return a
 
 
+def fetch_lines(dm, info, lines_per_record=4):
+    """bb_fastq_fetch_lines: offsets of the line ends of the last ingested block's records (lines_per_record * n_records)"""
+    from ._lib import lib
+
+    out = np.zeros(int(info.n_records) * lines_per_record, dtype=np.uint64)
+    dm._check(lib().bb_fastq_fetch_lines(dm._ctx(), out.ctypes.data))
+    return out
+
+
 def read_ids(a):
     """read ids (header up to the first whitespace) of a fetched batch"""
     from .annotate import BarbellError

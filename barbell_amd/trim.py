@@ -196,6 +196,29 @@ class Trimmer:
         return TrimResult(dm.buf("text").download(np.empty(tl, np.uint8)), dm.buf("slices").download(np.zeros(ns, SLICE_DTYPE)),
                           dm.buf("spans").download(np.zeros(nsp, SPAN_DTYPE)), dm.buf("status").download(np.zeros(n, np.uint8)))
 
+    def plan_ingested(self, d_rows, d_verdicts, n_rows, batch, info):
+        """bb_trim_plan_dev on the ingested batch: everything trim decides, none of the record text -> TrimResult whose
+        `text` is None and `text_len` the bytes the records take.  `cut_records` turns it into the same bytes on the host."""
+        from ._lib import lib
+
+        n = int(info.n_records)
+        dm = self.dm
+        scap, pcap = 2 * n + 64, 4096
+        d_st = dm.buf("status").ensure(n + 16)
+        tl, ns, nsp = C.c_uint64(), C.c_uint64(), C.c_uint32()
+        while True:
+            rc = lib().bb_trim_plan_dev(dm._ctx(), d_rows, d_verdicts, n_rows, batch.d_offsets, C.byref(batch.d_headers), n, C.byref(tl),
+                                        dm.buf("slices").ensure(scap * 32), scap, C.byref(ns), dm.buf("spans").ensure(pcap * 32), pcap,
+                                        C.byref(nsp), d_st)
+            if rc != _abi.BB_E_CAPACITY:
+                break
+            scap, pcap = max(scap, ns.value), max(pcap, nsp.value)
+        dm._check(rc)
+        res = TrimResult(None, dm.buf("slices").download(np.zeros(ns.value, SLICE_DTYPE)), dm.buf("spans").download(np.zeros(nsp.value, SPAN_DTYPE)),
+                         dm.buf("status").download(np.zeros(n, np.uint8)))
+        res.text_len = int(tl.value)
+        return res
+
     def last_ms(self):
         from ._lib import lib
 
@@ -236,3 +259,40 @@ class LabelWriters:
             w.close()
         if self.failed is not None:
             self.failed.close()
+
+
+_COMP = bytes.maketrans(b"ATCGRYKMBVDHatcgrykmbvdh", b"TAGCYRMKVBHDtagcyrmkvbhd")  # trim.rs:486-530
+
+
+def cut_records(text, line_ends, id_len, desc_start, plan, cfg):
+    """The records of a plan (Trimmer.plan_ingested) cut out of the block's own FASTQ text on the host, laid out as bb_trim_batch
+    lays them out (trim.rs:447-460) — what `barbell-amd kit` does in its writer threads so that neither the qualities' copy nor the
+    rendered records cross PCIe.  line_ends: fastq.fetch_lines (4 per record); id_len / desc_start: fastq.fetch."""
+    out = bytearray(plan.text_len)
+    text = memoryview(text)
+
+    def line(k, j):
+        a = int(line_ends[4 * k + j - 1]) + 1 if (k or j) else 0
+        b = int(line_ends[4 * k + j])
+        if b > a and text[b - 1] == 13:
+            b -= 1
+        return a, b
+
+    for s in plan.slices:
+        k = int(s["read_idx"])
+        hs, he = line(k, 0)
+        ss, se = line(k, 1)
+        qs, qe = line(k, 3)
+        hdr = bytes(text[hs + 1:he])
+        rec = b"@" + hdr[: int(id_len[k])] + (b"_%d" % int(s["suffix"]) if s["suffix"] else b"")
+        if cfg.write_full_header and len(hdr) > int(desc_start[k]):
+            rec += b" " + hdr[int(desc_start[k]):]
+        a, b = (0, se - ss) if cfg.skip_trim else (int(s["start"]), int(s["end"]))
+        seq, qual = bytes(text[ss + a:ss + b]), bytes(text[qs + a:qs + b])
+        if s["flip"]:
+            seq, qual = seq.translate(_COMP)[::-1], qual[::-1]
+        rec += b"\n" + seq + b"\n+\n" + qual + b"\n"
+        assert len(rec) == int(s["rec_len"])
+        o = int(s["out_off"])
+        out[o:o + len(rec)] = rec
+    return bytes(out)

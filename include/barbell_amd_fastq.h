@@ -59,6 +59,12 @@ int bb_fastq_ingest_dev(bb_ctx* ctx, const uint8_t* d_text, uint64_t text_len, i
 int bb_fastq_fetch(bb_ctx* ctx, uint64_t* offsets, uint8_t* hdr, uint64_t* hdr_offsets, uint32_t* id_len, uint32_t* desc_start,
                    uint8_t* bases, uint8_t* quals);
 
+/* Line ends of the last ingested block: line_ends[j] = offset of the '\n' that ends line j of the block's text, j < lines_per_record *
+ * n_records (4, or 2 for a BB_FASTQ_TWO_LINE block); record k's header line is text[line_ends[lpr*k-1]+1 .. line_ends[lpr*k]) (from 0
+ * for k = 0), a '\r' before the '\n' belongs to the line end.  For a final block whose last line has no '\n' the entry is text_len.
+ * With it a caller that still holds the block's text can cut records out of it without parsing it again (bb_trim_plan_dev).        */
+int bb_fastq_fetch_lines(bb_ctx* ctx, uint64_t* line_ends);
+
 /* GPU milliseconds of the last ingest (parse + pack, without the upload). */
 float bb_fastq_last_ms(bb_ctx* ctx);
 

@@ -218,10 +218,11 @@ def test_cli_fused_filter_matches_python(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("gz", [False, True])
-def test_cli_kit_matches_python_kit_driver(tmp_path, gz):
+@pytest.mark.parametrize("gz,render", [(False, "host"), (True, "host"), (False, "gpu")])
+def test_cli_kit_matches_python_kit_driver(tmp_path, gz, render):
     """`barbell-amd kit` (use_kit.rs:11-109): every file of the output folder byte-identical to the Python kit
-    driver's (whose trim output test_trim.py checks against the oracle)."""
+    driver's (whose trim output test_trim.py checks against the oracle) — with the records cut out of the staged text by the
+    writer threads after the GPU's plan (the default) and rendered in HBM and downloaded (--gpu-render)."""
     import gzip as gzmod
 
     from barbell_amd import annotate as A
@@ -240,7 +241,8 @@ def test_cli_kit_matches_python_kit_driver(tmp_path, gz):
             f.write(b"@read%d%s\n" % (i, b" ch=%d  st=xyz" % (i % 50) if i % 5 else b"") + s + b"\n+\n" + q + b"\n")
     env = dict(os.environ, BARBELL_AMD_NO_TORCH="1")
     oc, op = tmp_path / "cli", tmp_path / "py"
-    flags = ["--maximize", "--failed-out", str(tmp_path / "failed_cli.txt"), "--batch-reads", "333"] + (["--gzip"] if gz else [])
+    flags = ["--maximize", "--failed-out", str(tmp_path / "failed_cli.txt"), "--batch-reads", "333"] + (["--gzip"] if gz else []) + \
+        (["--gpu-render"] if render == "gpu" else [])
     r = subprocess.run([CLI, "kit", "-k", kit, "-i", str(fq), "-o", str(oc)] + flags, capture_output=True, text=True, env=env)
     assert r.returncode == 0, r.stderr
     assert "Top 10 most common patterns" in r.stdout and "Found " in r.stdout and "Done!" in r.stdout
@@ -281,11 +283,15 @@ def test_cli_annotate_trim_flags(tmp_path):
                              ("right", ["--only-side", "right", "--no-orientation", "--skip-trim"],
                               T.TrimConfig(True, False, True, False, "right", skip_trim=True)),
                              ("nolabel", ["--no-label"], T.TrimConfig(False))):
-        oc, op = tmp_path / f"{name}_cli", tmp_path / f"{name}_py"
-        r = subprocess.run([CLI, "annotate", "-i", str(fq), "-o", str(tmp_path / "a.tsv"), "--kit", kit, "--flank-max-errors", "3",
-                            "--kit-filter", "--maximize", "--trim-output", str(oc), "--batch-reads", "256"] + flags,
-                           capture_output=True, text=True, env=env)
-        assert r.returncode == 0, r.stderr
+        oc, op, og = tmp_path / f"{name}_cli", tmp_path / f"{name}_py", tmp_path / f"{name}_cli_gpu"
+        for o, extra in ((oc, []), (og, ["--gpu-render"])):
+            r = subprocess.run([CLI, "annotate", "-i", str(fq), "-o", str(tmp_path / "a.tsv"), "--kit", kit, "--flank-max-errors", "3",
+                                "--kit-filter", "--maximize", "--trim-output", str(o), "--batch-reads", "256"] + flags + extra,
+                               capture_output=True, text=True, env=env)
+            assert r.returncode == 0, r.stderr
+        assert sorted(x.name for x in og.iterdir()) == sorted(x.name for x in oc.iterdir())
+        for x in oc.iterdir():
+            assert x.read_bytes() == (og / x.name).read_bytes(), (name, x.name)
         A.annotate([str(fq)], str(tmp_path / "pa.tsv"), kits.groups_from_kit(kit), max_flank_errors=3, filter_patterns=F.kit_patterns(kit, True),
                    trim_folder=str(op), trim_config=cfg, batch_reads=300)
         names = sorted(x.name for x in op.iterdir())

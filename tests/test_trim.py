@@ -430,3 +430,49 @@ def test_render_ingest_round_trip_at_scale():
     exp = [("r%07d" % r) + ("_%d" % s if s else "") for r, s in zip(sl["read_idx"][:2000], sl["suffix"][:2000])]
     assert ids[:2000] == exp
     assert (a["desc_start"] - a["id_len"] == 1).all()
+
+
+@pytest.mark.gpu
+def test_plan_and_line_ends_cut_the_same_records():
+    """bb_trim_plan_dev + bb_fastq_fetch_lines: the records cut out of the block's own text on the host (what `barbell-amd kit`'s
+    writer threads do) are byte for byte the text bb_trim_batch_dev renders in HBM — for awkward text (CRLF records, tabs and runs
+    of blanks in headers, '+id' lines, no final newline) and every trim configuration."""
+    from barbell_amd import annotate as A, fastq as Q
+    from tests.common import config_groups
+
+    groups = config_groups("nbd96")
+    n = 1500
+    bases, offsets = A.synth_reads_host(groups, 5, 200, 3000, 0, n)
+    rng = np.random.default_rng(11)
+    parts = []
+    for i in range(n):
+        s = bases[int(offsets[i]):int(offsets[i + 1])].tobytes()
+        q = rng.integers(33, 90, size=len(s), dtype=np.uint8).tobytes()
+        h = b"read%d" % i + (b"", b" ch=3", b"\tx=1  y", b"   lead", b" ")[i % 5]
+        nl = b"\r\n" if i % 7 == 3 else b"\n"
+        parts.append(b"@" + h + nl + s + nl + (b"+" + h if i % 11 == 0 else b"+") + nl + q + nl)
+    text = b"".join(parts)
+    text = text[:-1]  # no newline after the last quality line
+    for cfg in CONFIGS:
+        dm = A.Demuxer()
+        for g in groups:
+            dm.add_query_group(g)
+        flt = F.Filter(dm, F.kit_patterns("SQK-NBD114-96", True))
+        tr = T.Trimmer(dm, cfg)
+        info, batch = Q.ingest(dm, text, True)
+        assert int(info.n_records) == n
+        rows = dm.demux_ingested(batch, n)
+        d_rows = dm.buf("rows").ptr
+        flt.verdicts_ingested(d_rows, len(rows), download=False)
+        d_v = dm.buf("verdicts").ptr
+        full = tr.trim_ingested(d_rows, d_v, len(rows), batch, info)
+        plan = tr.plan_ingested(d_rows, d_v, len(rows), batch, info)
+        assert plan.text_len == len(full.text) and plan.text_len > 100 * n
+        assert plan.slices.tobytes() == full.slices.tobytes() and plan.spans.tobytes() == full.spans.tobytes()
+        assert plan.status.tobytes() == full.status.tobytes()
+        a = Q.fetch(dm, info)
+        lines = Q.fetch_lines(dm, info)
+        assert len(lines) == 4 * n and int(lines[-1]) == len(text)  # the virtual line end of the unterminated last line
+        got = T.cut_records(text, lines, a["id_len"], a["desc_start"], plan, cfg)
+        assert got == full.text.tobytes()
+        dm.close()

@@ -27,6 +27,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("n_reads", nargs="?", type=int, default=4_000_000)
 ap.add_argument("read_len", nargs="?", type=int, default=4000)
 ap.add_argument("--kit-run", action="store_true", help="also time `barbell-amd kit` (annotate + inspect + filter + trim)")
+ap.add_argument("--only-kit", action="store_true", help="skip the annotate runs")
+ap.add_argument("--kit-env", action="append", default=[], help="NAME=VALUE[,NAME=VALUE..]: one more kit run (3 streams) under this environment")
 ap.add_argument("--json")
 ap.add_argument("--dir", default=os.environ.get("TMPDIR", "/tmp"))
 a = ap.parse_args()
@@ -78,19 +80,32 @@ def run(name, cmd):
 
 
 base = [cli, "annotate", "-i", fq, "-o", os.path.join(a.dir, "e2e_a.tsv"), "--kit", "SQK-NBD114-96", "--flank-max-errors", "3"]
-for streams in (1, 2, 3):
-    for bb in (128 << 20, 256 << 20):
-        run(f"annotate_streams{streams}_block{bb >> 20}Mi_t32", base + ["--streams", str(streams), "--block-bytes", str(bb), "-t", "32"])
-best = max(out["runs"], key=lambda k: out["runs"][k]["steady_state_reads_per_s"] or 0)
-out["best"] = {"run": best, **{k: out["runs"][best][k] for k in ("steady_state_reads_per_s", "wall_reads_per_s", "fastq_gb_per_s_steady")}}
-out["tsv_bytes"] = os.path.getsize(os.path.join(a.dir, "e2e_a.tsv"))
-if a.kit_run:
+if not a.only_kit:
+    for streams in (1, 2, 3):
+        for bb in (128 << 20, 256 << 20):
+            run(f"annotate_streams{streams}_block{bb >> 20}Mi_t32", base + ["--streams", str(streams), "--block-bytes", str(bb), "-t", "32"])
+    best = max(out["runs"], key=lambda k: out["runs"][k]["steady_state_reads_per_s"] or 0)
+    out["best"] = {"run": best, **{k: out["runs"][best][k] for k in ("steady_state_reads_per_s", "wall_reads_per_s", "fastq_gb_per_s_steady")}}
+    out["tsv_bytes"] = os.path.getsize(os.path.join(a.dir, "e2e_a.tsv"))
+if a.kit_run or a.only_kit:
     import shutil
 
     for streams in (2, 3, 4):
         shutil.rmtree(os.path.join(a.dir, "e2e_kit"), ignore_errors=True)
         run(f"kit_streams{streams}", [cli, "kit", "-k", "SQK-NBD114-96", "-i", fq, "-o", os.path.join(a.dir, "e2e_kit"), "--flank-max-errors", "3", "--maximize",
                                       "--streams", str(streams), "-t", "32"])
+    kit_cmd = lambda streams, extra=(): [cli, "kit", "-k", "SQK-NBD114-96", "-i", fq, "-o", os.path.join(a.dir, "e2e_kit"), "--flank-max-errors", "3", "--maximize",
+                                         "--streams", str(streams), "-t", "32"] + list(extra)
+    shutil.rmtree(os.path.join(a.dir, "e2e_kit"), ignore_errors=True)
+    run("kit_streams3_gpu_render", kit_cmd(3, ["--gpu-render"]))
+    shutil.rmtree(os.path.join(a.dir, "e2e_kit"), ignore_errors=True)
+    run("kit_streams3_block256Mi", kit_cmd(3, ["--batch-reads", "65536"]))
+    base_env = env
+    for spec in a.kit_env:
+        env = dict(base_env, **dict(kv.split("=", 1) for kv in spec.split(",")))
+        shutil.rmtree(os.path.join(a.dir, "e2e_kit"), ignore_errors=True)
+        run("kit_streams3_" + spec, kit_cmd(3))
+    env = base_env
 txt = json.dumps(out)
 if a.json:
     open(a.json, "w").write(txt + "\n")
