@@ -21,6 +21,7 @@
 #include "bb_common.h"
 #include "bb_ctx_view.h"
 #include "bb_kernels.h"
+#include "bb_lane.h"
 #include "bb_synth.h"
 
 namespace {
@@ -196,6 +197,7 @@ struct bb_ctx {
     uint32_t reg_blocks_mult = 1;  // BARBELL_AMD_REG_BLOCKS: persistent blocks per resident slot (tuning knob)
     uint32_t reg_threads = 512;  // BARBELL_AMD_REG_THREADS: block size of k_barcode_reg (tuning knob)
     uint32_t pfx_threads = 0;    // BARBELL_AMD_PFX_THREADS: block size of k_barcode_pfx (0 = as many lanes as fit a CU)
+    bool lane_kernel = false;    // BARBELL_AMD_LANE=1: the fast barcode stage with one lane per hit (k_barcode_lane) instead of one per (hit, barcode)
     bool force_generic = false;  // BARBELL_AMD_GENERIC=1: use the generic (any-geometry) kernels, for tests
     hipEvent_t ev[K_COUNT + 1]{};
     float ms[K_COUNT]{};
@@ -592,6 +594,24 @@ template <int CW>
 void launch_barcode_pfx(bb_ctx* c, uint32_t n_hits, uint32_t g, uint32_t strand, const uint32_t* list, const uint32_t* cnt, bool fast) {
     const bb_group_dev& D = c->gdev[g];
     const uint32_t N = (uint32_t)D.n_seqs;
+    if constexpr (CW == 48) {
+        if (fast && c->lane_kernel && D.pfx[strand] <= 16) {
+            const uint32_t T = (uint32_t)D.tail[strand];
+            const size_t smem = (((size_t)N * 64 + 31) & ~(size_t)31) + 256 * 32 + (size_t)256 * (CW + 1) * 4 + 16 + (size_t)T * 2 * 256 * 8;
+            const uint32_t blocks = (n_hits + 255) / 256;
+#define BB_LANE_LAUNCH(TAIL_)                                                                                                                     \
+    do {                                                                                                                                          \
+        if (smem > 64 * 1024)                                                                                                                     \
+            (void)hipFuncSetAttribute((const void*)k_barcode_lane<CW, TAIL_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);            \
+        hipLaunchKernelGGL((k_barcode_lane<CW, TAIL_>), dim3(blocks), dim3(256), smem, c->stream, (const uint8_t*)c->d_tables,                    \
+                           (const bb_group_dev*)c->d_groups, g, strand, (const bb_hit*)c->d_hits, (const bb_hit_pfx*)c->d_pfx, list, cnt, n_hits, \
+                           c->d_rows);                                                                                                            \
+    } while (0)
+            if (T > 0) BB_LANE_LAUNCH(true); else BB_LANE_LAUNCH(false);
+#undef BB_LANE_LAUNCH
+            return;
+        }
+    }
     // CW = 48 fits 168 VGPRs -> 3 waves per SIMD: 768-thread blocks (8 hits x 96 barcodes use every lane); measured
     // 22.8 vs 26.8 ms against 512-thread blocks at 2 waves per SIMD
     uint32_t tmax = CW <= 48 ? 768u : 512u;
@@ -752,6 +772,7 @@ int bb_create_policy(const bb_group_desc* groups, uint32_t n_groups, const bb_pa
     if (getenv("BARBELL_AMD_NO_FAST") && atoi(getenv("BARBELL_AMD_NO_FAST")) != 0) c->fast_path = false;
     if (getenv("BARBELL_AMD_FAST_MARGIN")) c->fast_margin = atof(getenv("BARBELL_AMD_FAST_MARGIN"));
     if (getenv("BARBELL_AMD_ADAPT_FRAC")) c->adapt_frac = atof(getenv("BARBELL_AMD_ADAPT_FRAC"));
+    if (const char* e = getenv("BARBELL_AMD_LANE")) c->lane_kernel = atoi(e) != 0;
     if (getenv("BARBELL_AMD_PFX_THREADS")) { int t = atoi(getenv("BARBELL_AMD_PFX_THREADS")); if (t >= 64 && t <= 768) c->pfx_threads = (uint32_t)t; }
     if (getenv("BARBELL_AMD_REG_THREADS")) { int t = atoi(getenv("BARBELL_AMD_REG_THREADS")); if (t >= 64 && t <= 512) c->reg_threads = (uint32_t)t; }
     c->groups.resize(n_groups);

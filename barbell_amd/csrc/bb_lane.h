@@ -1,0 +1,299 @@
+// bb_lane.h — the fast barcode stage with ONE LANE PER FLANK HIT (searcher.rs:267-337 on one word per lane).
+//
+// k_barcode_pfx gives a hit's N barcodes to N lanes: everything a hit owns is built once per block iteration in LDS
+// (per-column records, the walks through the shared rows, the top-2 cells) and the twelve waves of a block meet at two
+// barriers per iteration — 41 % of that kernel's wave time is parked (profiles/valu_nbd96.json), at three waves per
+// SIMD where and/or/add issue at 70 % of their rate.  Here a lane keeps ITS hit (window codes, carry-in bits of the
+// shared rows, trailing-row masks) in registers and walks through the group's barcodes one after the other:
+//   * the barcode index is wave-uniform, so a column's Eq word is one LDS read at  barcode * 64 + code * 4  (four
+//     distinct words in four banks: a broadcast), the address being the column's code byte (kept as code << 2) added
+//     to a scalar;
+//   * the top-2 of both candidate sets are running maxima in registers — no cross-lane reduction, no atomics;
+//   * no barrier after the tables are loaded, no per-iteration table builds; the walk through the shared rows is
+//     done by the lane on its own prefix record's move bits (its row of a per-block LDS array);
+//   * the path of the best-bounded barcode is not carried along (14 registers and as many selects per barcode) but
+//     recomputed in one extra trip of the same loop body with a per-lane barcode index.
+// Output = k_barcode_pfx<.., FAST = true>'s: a bb_winrec (marker 2) for k_rows, or the flank-only row.
+#pragma once
+
+template <int CW, bool TAIL>
+__global__ __launch_bounds__(256, 2) void k_barcode_lane(const uint8_t* __restrict__ tables, const bb_group_dev* __restrict__ groups, uint32_t g,
+                                                      uint32_t strand, const bb_hit* __restrict__ hits, const bb_hit_pfx* __restrict__ pfxs,
+                                                      const uint32_t* __restrict__ hit_list, const uint32_t* __restrict__ list_cnt,
+                                                      uint32_t n_hits_all, bb_rowtmp* __restrict__ rows) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint32_t n_list = hit_list ? list_cnt[g] : n_hits_all;
+    if (blockIdx.x * 256u >= n_list) return;
+    const bb_group_dev& G = groups[g];
+    const int N = G.n_seqs, m = G.m_bar, P = G.pfx[strand], T = TAIL ? G.tail[strand] : 0;
+    const int32_t k1 = G.k1, k2 = G.k2;
+    const int pol_lm = G.pol_lm;
+    const bool tie_last = G.pol_tie_last != 0;
+    constexpr int SHS = CW + 1;  // odd row stride: the lanes' rows start in different banks
+    // LDS: [Peq: N x 16 words, barcode-major][bound table 256 x 32 B][shared-row move bits: 256 x SHS words][trailing-row planes]
+    uint32_t* s_peq = reinterpret_cast<uint32_t*>(smem);
+    size_t o = ((size_t)N * 64 + 31) & ~(size_t)31;
+    bb_lb_entry* s_lb = reinterpret_cast<bb_lb_entry*>(smem + o);
+    o += 256 * sizeof(bb_lb_entry);
+    uint32_t* s_sh = reinterpret_cast<uint32_t*>(smem + o);
+    o += (size_t)256 * SHS * 4;
+    o = (o + 15) & ~(size_t)15;
+    unsigned long long* s_tail = reinterpret_cast<unsigned long long*>(smem + o);  // [t][lo|hi][thread]
+    {
+        const uint32_t* gp = reinterpret_cast<const uint32_t*>(tables + G.off_peq_sub[strand]);  // [code][barcode]
+        for (int i = threadIdx.x; i < 16 * N; i += 256) {
+            const int code = i / N, p = i - code * N;
+            s_peq[p * 16 + code] = gp[i];
+        }
+        for (uint32_t i = threadIdx.x; i < 256u; i += 256u) lodhi_bound_table_entry(i, s_lb[i]);
+    }
+    const uint32_t li = blockIdx.x * 256u + threadIdx.x;
+    const bool exists = li < n_list;
+    const uint32_t hit_idx = hit_list ? (exists ? hit_list[li] : 0u) : (exists ? li : 0u);
+    // ---- the lane's hit: header, window codes (as LDS byte offsets of their Peq word), carry-in bits, trailing rows ----
+    uint32_t cw[CW / 4];
+    int32_t wn;
+    bool active;
+    {
+        const uint4* hp4 = reinterpret_cast<const uint4*>(hits + hit_idx);
+        const uint4 h0 = hp4[0], h1 = hp4[1];
+        const bool valid = (h1.z & 0xFFu) != 0u;
+        active = exists && valid;
+        if (exists && !valid) rows[hit_idx].row._pad[0] = 0;
+        wn = active ? (int32_t)(h1.x - h0.w) : 0;   // we - ws
+#pragma unroll
+        for (int q = 0; q < CW / 16; ++q) {
+            const uint4 w = hp4[2 + q];
+            cw[4 * q] = (w.x & 0x0F0F0F0Fu) << 2; cw[4 * q + 1] = (w.y & 0x0F0F0F0Fu) << 2;
+            cw[4 * q + 2] = (w.z & 0x0F0F0F0Fu) << 2; cw[4 * q + 3] = (w.w & 0x0F0F0F0Fu) << 2;
+        }
+    }
+    uint32_t hpw[2], hmw[2];
+    unsigned long long TE[BB_MAX_TAIL];
+    uint32_t* my_sh = s_sh + threadIdx.x * SHS;
+    {
+        const uint4* pp4 = reinterpret_cast<const uint4*>(pfxs + hit_idx);
+        const uint4 a = pp4[0];
+        hpw[0] = a.x; hpw[1] = a.y; hmw[0] = a.z; hmw[1] = a.w;
+#pragma unroll
+        for (int q = 0; q < BB_MAX_TAIL / 2; ++q) {
+            const uint4 t4 = pp4[1 + q];
+            TE[2 * q] = ((unsigned long long)t4.y << 32) | t4.x; TE[2 * q + 1] = ((unsigned long long)t4.w << 32) | t4.z;
+        }
+        constexpr int SH4 = 1 + BB_MAX_TAIL / 2;  // first 16-byte piece of sh[]
+#pragma unroll
+        for (int q = 0; q < CW / 4; ++q) {
+            const uint4 w = pp4[SH4 + q];
+            my_sh[4 * q] = w.x; my_sh[4 * q + 1] = w.y; my_sh[4 * q + 2] = w.z; my_sh[4 * q + 3] = w.w;
+        }
+    }
+    int wmax = wn;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) wmax = max(wmax, __shfl_xor(wmax, d, 64));
+    wmax = __builtin_amdgcn_readfirstlane(wmax);
+    __syncthreads();  // the tables; the only barrier of the kernel
+
+    const uint8_t* s_peq_b = reinterpret_cast<const uint8_t*>(s_peq);
+    // running top-2 of the two candidate sets (searcher.rs:303-328): bound bits + 1 (0 = empty), first maximum's barcode
+    uint32_t b1A = 0u, b2A = 0u, pA = 0u, b1B = 0u, b2B = 0u, pB = 0u;
+    uint32_t ptop = 0u;
+    bool want = false;  // the final trip: this lane has a winner to trace again
+#pragma unroll 1
+    for (int it = 0; it <= N; ++it) {
+        const bool last = it == N;
+        if (last) {
+            const bool pass2 = b2A == 0u && k1 < k2;
+            const uint32_t mx = pass2 ? b1B : b1A;
+            ptop = pass2 ? pB : pA;
+            want = active && mx != 0u;
+            if (!__any(want)) break;
+        }
+        const uint32_t pbase = (last ? ptop : (uint32_t)it) * 64u;  // byte offset of the barcode's 16 Peq words
+        const bool on = last ? want : active;
+        // ---- forward pass on the lane's own rows (one word), carry-in from the shared rows ----
+        uint32_t L0[CW], H0[CW];
+        int32_t best_cost = 0x7FFFFFFF, best_pos = -1;
+        unsigned long long Pm, Mm;
+        {
+            uint32_t pv = 0xFFFFFFFFu, mv = 0u;
+            uint32_t upr[2] = {0u, 0u}, dnr[2] = {0u, 0u};
+            // the Eq words of a column group are requested a group ahead (before the wave-uniform branch that would otherwise keep
+            // the scheduler from hoisting them): with two waves per SIMD an exposed LDS round trip halves the issue rate
+            uint32_t eqn[BB_CG];
+#pragma unroll
+            for (int q = 0; q < BB_CG; ++q) eqn[q] = *reinterpret_cast<const uint32_t*>(s_peq_b + (pbase + ((cw[q >> 2] >> (8 * (q & 3))) & 0xFFu)));
+#pragma unroll
+            for (int c0 = 0; c0 < CW; c0 += BB_CG) {
+                uint32_t eqc[BB_CG];
+#pragma unroll
+                for (int q = 0; q < BB_CG; ++q) eqc[q] = eqn[q];
+                if (c0 + BB_CG < CW) {
+#pragma unroll
+                    for (int q = 0; q < BB_CG; ++q) {
+                        const int c = c0 + BB_CG + q;
+                        eqn[q] = *reinterpret_cast<const uint32_t*>(s_peq_b + (pbase + ((cw[c >> 2] >> (8 * (c & 3))) & 0xFFu)));
+                    }
+                }
+                if (c0 < wmax) {  // wave-uniform
+#pragma unroll
+                    for (int c = c0; c < c0 + BB_CG; ++c) {
+                        const uint32_t eq = eqc[c - c0];
+                        const uint32_t hp = (hpw[c >> 5] >> (c & 31)) & 1u, hm = (hmw[c >> 5] >> (c & 31)) & 1u;
+                        const uint32_t x = bitop3<0xC8>(eq, pv, hm);                       // (eq | hm) & pv
+                        const uint32_t t = bitop3<BB_TT_XOR_OR>(x + pv, pv, eq);           // ((x + pv) ^ pv) | eq
+                        const uint32_t d0 = bitop3<0xFE>(t, hm, mv);                       // t | hm | mv
+                        const uint32_t ph = bitop3<BB_TT_OR_NOR>(mv, d0, pv), mh = bitop3<0xC0>(pv, d0, 0u);
+                        const uint32_t l = bitop3<0x15>(d0, eq, ph), hh = bitop3<0x3A>(d0, eq, ph);  // move planes (see move_bits)
+                        L0[c] = __brev(l); H0[c] = __brev(hh);  // row P+1 <-> bit 31, row P+32 <-> bit 0
+                        const unsigned long long tp = shl1_64(((unsigned long long)upr[c >> 5] << 32) | ph);
+                        const unsigned long long tm = shl1_64(((unsigned long long)dnr[c >> 5] << 32) | mh);
+                        upr[c >> 5] = (uint32_t)(tp >> 32); dnr[c >> 5] = (uint32_t)(tm >> 32);
+                        const uint32_t nph = bitop3<0x01>((uint32_t)tp, hp, d0);           // ~(phs | d0)
+                        mv = bitop3<0xA8>((uint32_t)tp, hp, d0);                           // phs & d0
+                        pv = bitop3<0xFE>(nph, (uint32_t)tm, hm);                          // mhs | ~(d0 | phs)
+                    }
+                }
+            }
+            const int pc = min(CW, ((wmax + BB_CG - 1) / BB_CG) * BB_CG);
+            const int n0 = min(pc, 32), n1 = pc - n0;
+            uint32_t up[2], dn[2];
+            up[0] = n0 ? __brev(upr[0]) >> (32 - n0) : 0u; dn[0] = n0 ? __brev(dnr[0]) >> (32 - n0) : 0u;
+            up[1] = n1 ? __brev(upr[1]) >> (32 - n1) : 0u; dn[1] = n1 ? __brev(dnr[1]) >> (32 - n1) : 0u;
+            const unsigned long long wmask = wn >= 64 ? ~0ull : ((1ull << wn) - 1ull);
+            Pm = (((unsigned long long)up[1] << 32) | up[0]) & wmask;   // horizontal deltas of row P+32
+            Mm = (((unsigned long long)dn[1] << 32) | dn[0]) & wmask;
+            if constexpr (TAIL) {  // the trailing shared rows, row-wise (see k_barcode_pfx)
+#pragma unroll
+                for (int t = 0; t < BB_MAX_TAIL; ++t) {
+                    if (t < T) {
+                        const unsigned long long Eq = TE[t];
+                        const unsigned long long D0 = (((Eq & Pm) + Pm) ^ Pm) | Eq | Mm;
+                        const unsigned long long Pvv = Mm | ~(D0 | Pm), Mvv = Pm & D0;
+                        const unsigned long long Pvs = (Pvv << 1) | 1ull, Mvs = Mvv << 1;
+                        const unsigned long long Ph = Mvs | ~(D0 | Pvs), Mh = Pvs & D0;
+                        const unsigned long long isM = D0 & Eq, tl = ~(isM | Ph), th = (Ph & ~isM) | (tl & D0);
+                        s_tail[(size_t)(2 * t) * 256u + threadIdx.x] = tl;
+                        s_tail[(size_t)(2 * t + 1) * 256u + threadIdx.x] = th;
+                        Pm = Ph & wmask; Mm = Mh & wmask;
+                    }
+                }
+            }
+            pick_minimum(Pm, Mm, wn, m, on, pol_lm, tie_last, best_cost, best_pos);
+        }
+        const bool cand = on && best_pos >= 0 && best_cost <= k2;
+        if (!__any(cand)) continue;
+        // ---- traceback, phase 0: the trailing shared rows ----
+        unsigned long long plo = 0ull, phi = 0ull;
+        uint32_t b = 0u, dg = 0u;
+        int32_t c_ent = best_pos;
+        int32_t tr = cand ? T - 1 : -1;
+        uint32_t dgt = 0u;
+        while (TAIL && __any(tr >= 0 && c_ent >= 1)) {
+            const bool onn = tr >= 0 && c_ent >= 1;
+            const int rr = onn ? tr : 0, sh = onn ? c_ent - 1 : 0;
+            const unsigned long long l64 = s_tail[(size_t)(2 * rr) * 256u + threadIdx.x], h64 = s_tail[(size_t)(2 * rr + 1) * 256u + threadIdx.x];
+            const uint32_t lo = (uint32_t)(l64 >> sh) & 1u, hi = (uint32_t)(h64 >> sh) & 1u;
+            const bool del = onn && (lo & hi) != 0u, text = onn && !del, diag = onn && hi == 0u;
+            plo |= text ? (unsigned long long)lo << sh : 0ull;
+            phi |= text ? (unsigned long long)hi << sh : 0ull;
+            dgt |= diag ? 1u << rr : 0u;
+            tr -= (del || diag) ? 1 : 0;
+            c_ent -= text ? 1 : 0;
+        }
+        const unsigned long long smask = (cand && tr < 0 && c_ent >= 1) ? 1ull << (c_ent - 1) : 0ull;
+        const uint32_t sm_w[2] = {(uint32_t)smask, (uint32_t)(smask >> 32)};
+        // ---- phase 1: the lane's own rows, one-hot cursor (see k_barcode_pfx) ----
+        uint32_t pl_acc[2] = {0u, 0u}, ph_acc[2] = {0u, 0u};
+#pragma unroll
+        for (int c0 = CW; c0 >= BB_CG; c0 -= BB_CG) {
+            if (c0 - (BB_CG - 1) <= wmax) {  // wave-uniform
+#pragma unroll
+                for (int c = c0; c > c0 - BB_CG; --c) {
+                    const uint32_t Lr = L0[c - 1], Hr = H0[c - 1];
+                    const uint32_t Dr = Lr & Hr;
+                    const uint32_t nb = bitop3<0x0C>(Dr, Dr + b + ((sm_w[(c - 1) >> 5] >> ((c - 1) & 31)) & 1u), 0u);  // ~Dr & sum
+                    const uint32_t tl = Lr & nb, th = Hr & nb;
+                    const uint32_t cm = bitop3<0x0C>(Hr, nb, 0u);  // ~Hr & nb
+                    pl_acc[(c - 1) >> 5] = __builtin_amdgcn_alignbit(pl_acc[(c - 1) >> 5], 0u - tl, 31);
+                    ph_acc[(c - 1) >> 5] = __builtin_amdgcn_alignbit(ph_acc[(c - 1) >> 5], 0u - th, 31);
+                    dg |= cm;
+                    b = nb + cm;
+                }
+            }
+        }
+        plo |= ((unsigned long long)pl_acc[1] << 32) | pl_acc[0];
+        phi |= ((unsigned long long)ph_acc[1] << 32) | ph_acc[0];
+        if (last) {
+            int32_t ntext = cand ? __popc(dg) + __popc(dgt) + __popcll(phi & ~plo) : 0;
+            const int32_t cx = cand ? best_pos - ntext : 0;
+            // ---- phase 2: the shared rows (row r <-> bit P - r), walked on the lane's own prefix record ----
+            uint32_t dgh = 0u;
+            {
+                const uint32_t pm = (1u << P) - 1u;  // P <= 16
+                uint32_t bh = (cand && cx >= 1 && P > 0) ? 1u : 0u;
+                int32_t col = cx;
+                while (__any(bh != 0u)) {
+                    const uint32_t w = my_sh[col >= 1 ? col - 1 : 0];
+                    const uint32_t Lr = w & 0xFFFFu, Hr = w >> 16;
+                    const uint32_t Dr = Lr & Hr;
+                    const uint32_t nb = bh ? (((Dr + bh) & ~Dr) & pm) : 0u;
+                    const bool has = nb != 0u, lo = (Lr & nb) != 0u, hi = (Hr & nb) != 0u;
+                    const unsigned long long bit = 1ull << (col >= 1 ? col - 1 : 0);
+                    plo |= lo ? bit : 0ull;
+                    phi |= hi ? bit : 0ull;
+                    const bool consume = has & !hi;
+                    dgh |= consume ? nb : 0u;
+                    bh = consume ? ((nb << 1) & pm) : nb;
+                    ntext += has ? 1 : 0;
+                    col -= has ? 1 : 0;
+                    if (col < 1) bh = 0u;
+                }
+            }
+            const int32_t tstart = cand ? best_pos - ntext : 0;
+            if (cand) {  // always, for a lane with `want`: the same barcode was a candidate in its own trip
+                const bool pass2 = b2A == 0u && k1 < k2;
+                const uint32_t sx = pass2 ? b2B : b2A;
+                bb_winrec W;
+                W.plo = plo; W.phi = phi;
+                W.diagrow = ((unsigned long long)__brev(dg) << P) | (P ? (unsigned long long)(__brev(dgh) >> (32 - P)) : 0ull) | ((unsigned long long)dgt << (P + 32));
+                W.ub_second = sx ? (double)__uint_as_float(sx - 1u) / G.perfect : -1.0;   // -1: no other candidate
+                W.tstart = (uint8_t)tstart; W.best_pos = (uint8_t)best_pos; W.top = (uint16_t)ptop;
+                W.flags = 0; W.marker = 2; W._pad[0] = W._pad[1] = 0;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) W._pad0[q] = 0;
+                *reinterpret_cast<bb_winrec*>(rows + hit_idx) = W;
+            }
+            break;
+        }
+        // The bound without the walk through the shared rows.  The cursor enters row P in column cx; whatever the walk does there, it
+        // consumes at most P rows by a Match, in distinct columns <= cx.  The kernel's weights decay with the span of a subsequence
+        // (lambda < 1 per column) and the bound's with the span in text columns, so of all placements of at most min(P, cx) Match
+        // columns left of the cursor the contiguous run ending at cx gives every subsequence its shortest span: the bound of THAT
+        // placement is an upper bound of the exact score — and equals the bound of the true path whenever the shared rows match
+        // without gaps (the usual case: they are the flank the hit was found with).  Only the winner's walk is ever done (final trip).
+        const int32_t ntext1 = cand ? __popc(dg) + __popc(dgt) + __popcll(phi & ~plo) : 0;
+        const int32_t tstart = cand ? max(best_pos - ntext1 - P, 0) : 0;
+        const float ubf = lodhi_bound_tab<CW>(cand ? plo : 0ull, cand ? phi : 0ull, cand ? tstart : 0, cand ? best_pos : 0, CW, s_lb);  // all bytes: no branches between the table reads
+        const uint32_t v = __float_as_uint(ubf) + 1u;
+        if (cand) {  // first maximum wins: strictly greater replaces
+            if (v > b1B) { b2B = b1B; b1B = v; pB = (uint32_t)it; } else if (v > b2B) b2B = v;
+            if (best_cost <= k1) { if (v > b1A) { b2A = b1A; b1A = v; pA = (uint32_t)it; } else if (v > b2A) b2A = v; }
+        }
+    }
+    if (active && !want) {  // no candidate at all: flank-only row (searcher.rs:353-362)
+        const uint4* hp4 = reinterpret_cast<const uint4*>(hits + hit_idx);
+        const uint4 h0 = hp4[0], h1 = hp4[1];
+        bb_rowtmp R;
+        bb_row& r = R.row;
+        r.read_idx = h0.x; r.read_len = h1.w;
+        r.rel_dist_to_end = rel_dist_to_end((int64_t)h0.y, (int64_t)h1.w);
+        r.read_start_flank = h0.y; r.read_end_flank = h0.z;
+        r.flank_cost = (int16_t)(h1.y & 0xFFFFu); r.group_idx = (uint8_t)((h1.y >> 16) & 0xFFu); r.strand = (uint8_t)(h1.y >> 24);
+        r._pad[0] = 1; r._pad[1] = r._pad[2] = 0;
+        r.read_start_bar = h0.y; r.read_end_bar = h0.z;
+        r.bar_start = 0; r.bar_end = 0;
+        r.match_type = (uint8_t)(G.type == BB_FTAG ? BB_FFLANK : BB_RFLANK);
+        r.barcode_cost = (int16_t)G.m_bar; r.barcode_idx = -1;
+        rows[hit_idx] = R;
+    }
+}
