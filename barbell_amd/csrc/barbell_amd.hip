@@ -197,7 +197,7 @@ struct bb_ctx {
     uint32_t reg_blocks_mult = 1;  // BARBELL_AMD_REG_BLOCKS: persistent blocks per resident slot (tuning knob)
     uint32_t reg_threads = 512;  // BARBELL_AMD_REG_THREADS: block size of k_barcode_reg (tuning knob)
     uint32_t pfx_threads = 0;    // BARBELL_AMD_PFX_THREADS: block size of k_barcode_pfx (0 = as many lanes as fit a CU)
-    bool lane_kernel = false;    // BARBELL_AMD_LANE=1: the fast barcode stage with one lane per hit (k_barcode_lane) instead of one per (hit, barcode)
+    bool lane_kernel = true;     // BARBELL_AMD_LANE=0: the fast barcode stage with one lane per (hit, barcode) (k_barcode_pfx) instead of one lane per hit (k_barcode_lane)
     bool force_generic = false;  // BARBELL_AMD_GENERIC=1: use the generic (any-geometry) kernels, for tests
     hipEvent_t ev[K_COUNT + 1]{};
     float ms[K_COUNT]{};
@@ -597,7 +597,7 @@ void launch_barcode_pfx(bb_ctx* c, uint32_t n_hits, uint32_t g, uint32_t strand,
     if constexpr (CW == 48) {
         if (fast && c->lane_kernel && D.pfx[strand] <= 16) {
             const uint32_t T = (uint32_t)D.tail[strand];
-            const size_t smem = (((size_t)N * 64 + 31) & ~(size_t)31) + 256 * 32 + (size_t)256 * (CW + 1) * 4 + 16 + (size_t)T * 2 * 256 * 8;
+            const size_t smem = (((size_t)N * 64 + 31) & ~(size_t)31) + 256 * 32 + 16 + (size_t)T * 2 * 256 * 8;
             const uint32_t blocks = (n_hits + 255) / 256;
 #define BB_LANE_LAUNCH(TAIL_)                                                                                                                     \
     do {                                                                                                                                          \

@@ -16,8 +16,14 @@
 // Output = k_barcode_pfx<.., FAST = true>'s: a bb_winrec (marker 2) for k_rows, or the flank-only row.
 #pragma once
 
+#ifndef BB_LANE_NOHOIST
+#define BB_LANE_NOHOIST 1
+#endif
+#ifndef BB_LANE_WAVES
+#define BB_LANE_WAVES 3
+#endif
 template <int CW, bool TAIL>
-__global__ __launch_bounds__(256, 2) void k_barcode_lane(const uint8_t* __restrict__ tables, const bb_group_dev* __restrict__ groups, uint32_t g,
+__global__ __launch_bounds__(256, BB_LANE_WAVES) void k_barcode_lane(const uint8_t* __restrict__ tables, const bb_group_dev* __restrict__ groups, uint32_t g,
                                                       uint32_t strand, const bb_hit* __restrict__ hits, const bb_hit_pfx* __restrict__ pfxs,
                                                       const uint32_t* __restrict__ hit_list, const uint32_t* __restrict__ list_cnt,
                                                       uint32_t n_hits_all, bb_rowtmp* __restrict__ rows) {
@@ -29,14 +35,11 @@ __global__ __launch_bounds__(256, 2) void k_barcode_lane(const uint8_t* __restri
     const int32_t k1 = G.k1, k2 = G.k2;
     const int pol_lm = G.pol_lm;
     const bool tie_last = G.pol_tie_last != 0;
-    constexpr int SHS = CW + 1;  // odd row stride: the lanes' rows start in different banks
-    // LDS: [Peq: N x 16 words, barcode-major][bound table 256 x 32 B][shared-row move bits: 256 x SHS words][trailing-row planes]
+    // LDS: [Peq: N x 16 words, barcode-major][bound table 256 x 32 B][trailing-row planes]
     uint32_t* s_peq = reinterpret_cast<uint32_t*>(smem);
     size_t o = ((size_t)N * 64 + 31) & ~(size_t)31;
     bb_lb_entry* s_lb = reinterpret_cast<bb_lb_entry*>(smem + o);
     o += 256 * sizeof(bb_lb_entry);
-    uint32_t* s_sh = reinterpret_cast<uint32_t*>(smem + o);
-    o += (size_t)256 * SHS * 4;
     o = (o + 15) & ~(size_t)15;
     unsigned long long* s_tail = reinterpret_cast<unsigned long long*>(smem + o);  // [t][lo|hi][thread]
     {
@@ -47,9 +50,35 @@ __global__ __launch_bounds__(256, 2) void k_barcode_lane(const uint8_t* __restri
         }
         for (uint32_t i = threadIdx.x; i < 256u; i += 256u) lodhi_bound_table_entry(i, s_lb[i]);
     }
-    const uint32_t li = blockIdx.x * 256u + threadIdx.x;
-    const bool exists = li < n_list;
-    const uint32_t hit_idx = hit_list ? (exists ? hit_list[li] : 0u) : (exists ? li : 0u);
+    // Which hit a lane takes: the block's 256 hits, those with windows of at most CW - 4 columns first.  A wave walks as many
+    // column groups as its widest window needs; 99 % of the windows of SQK-NBD114-96 are 44 columns wide, but one 45-column window
+    // among a wave's 64 costs all of them a twelfth group, forward and back.  Sorted, three waves in four skip it.
+    __shared__ uint32_t s_perm[256];
+    __shared__ uint32_t s_wcnt[8];
+    uint32_t hit_idx;
+    bool exists;
+    {
+        const uint32_t li = blockIdx.x * 256u + threadIdx.x;
+        const bool ex0 = li < n_list;
+        const uint32_t h0i = hit_list ? (ex0 ? hit_list[li] : 0u) : (ex0 ? li : 0u);
+        const bool narrow = ex0 && (hits[h0i].we - hits[h0i].ws) <= (uint32_t)(CW - BB_CG);
+        const bool wide = ex0 && !narrow;
+        const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+        const unsigned long long bn = __ballot(narrow), bw = __ballot(wide);
+        if (lane == 0) { s_wcnt[wv] = (uint32_t)__popcll(bn); s_wcnt[4 + wv] = (uint32_t)__popcll(bw); }
+        s_perm[threadIdx.x] = 0xFFFFFFFFu;
+        __syncthreads();
+        uint32_t base_n = 0u, base_w = 0u, tot_n = 0u;
+#pragma unroll
+        for (uint32_t q = 0; q < 4u; ++q) { base_n += q < wv ? s_wcnt[q] : 0u; base_w += q < wv ? s_wcnt[4 + q] : 0u; tot_n += s_wcnt[q]; }
+        const unsigned long long below = (1ull << lane) - 1ull;
+        if (narrow) s_perm[base_n + (uint32_t)__popcll(bn & below)] = h0i;
+        if (wide) s_perm[tot_n + base_w + (uint32_t)__popcll(bw & below)] = h0i;
+        __syncthreads();
+        hit_idx = s_perm[threadIdx.x];
+        exists = hit_idx != 0xFFFFFFFFu;
+        if (!exists) hit_idx = 0u;
+    }
     // ---- the lane's hit: header, window codes (as LDS byte offsets of their Peq word), carry-in bits, trailing rows ----
     uint32_t cw[CW / 4];
     int32_t wn;
@@ -70,7 +99,7 @@ __global__ __launch_bounds__(256, 2) void k_barcode_lane(const uint8_t* __restri
     }
     uint32_t hpw[2], hmw[2];
     unsigned long long TE[BB_MAX_TAIL];
-    uint32_t* my_sh = s_sh + threadIdx.x * SHS;
+    const uint32_t* my_sh = pfxs[hit_idx].sh;  // read in the final trip only (the winner's walk through the shared rows): from L2
     {
         const uint4* pp4 = reinterpret_cast<const uint4*>(pfxs + hit_idx);
         const uint4 a = pp4[0];
@@ -79,12 +108,6 @@ __global__ __launch_bounds__(256, 2) void k_barcode_lane(const uint8_t* __restri
         for (int q = 0; q < BB_MAX_TAIL / 2; ++q) {
             const uint4 t4 = pp4[1 + q];
             TE[2 * q] = ((unsigned long long)t4.y << 32) | t4.x; TE[2 * q + 1] = ((unsigned long long)t4.w << 32) | t4.z;
-        }
-        constexpr int SH4 = 1 + BB_MAX_TAIL / 2;  // first 16-byte piece of sh[]
-#pragma unroll
-        for (int q = 0; q < CW / 4; ++q) {
-            const uint4 w = pp4[SH4 + q];
-            my_sh[4 * q] = w.x; my_sh[4 * q + 1] = w.y; my_sh[4 * q + 2] = w.z; my_sh[4 * q + 3] = w.w;
         }
     }
     int wmax = wn;
@@ -109,6 +132,14 @@ __global__ __launch_bounds__(256, 2) void k_barcode_lane(const uint8_t* __restri
             if (!__any(want)) break;
         }
         const uint32_t pbase = (last ? ptop : (uint32_t)it) * 64u;  // byte offset of the barcode's 16 Peq words
+#if BB_LANE_NOHOIST
+        // The per-column fields of these words (48 Peq offsets, 96 carry-in bits) are the same in every trip and the compiler keeps them
+        // all in registers across the loop (256 VGPRs, two waves per SIMD).  Opaque to it, they are extracted where they are used:
+        // three half-rate extractions more per column for ~130 registers less.
+        asm volatile("" : "+v"(hpw[0]), "+v"(hpw[1]), "+v"(hmw[0]), "+v"(hmw[1]));
+#pragma unroll
+        for (int q = 0; q < CW / 4; ++q) asm volatile("" : "+v"(cw[q]));
+#endif
         const bool on = last ? want : active;
         // ---- forward pass on the lane's own rows (one word), carry-in from the shared rows ----
         uint32_t L0[CW], H0[CW];
