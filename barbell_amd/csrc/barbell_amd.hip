@@ -22,6 +22,7 @@
 #include "bb_ctx_view.h"
 #include "bb_kernels.h"
 #include "bb_lane.h"
+#define BB_LANE_MAX_FLANK_K 8   // flank edit budget up to which k_barcode_lane's walk-free bound decides as often as the traced one (measured: k = 3, 5 yes; k = 20 no)
 #include "bb_synth.h"
 
 namespace {
@@ -197,7 +198,9 @@ struct bb_ctx {
     uint32_t reg_blocks_mult = 1;  // BARBELL_AMD_REG_BLOCKS: persistent blocks per resident slot (tuning knob)
     uint32_t reg_threads = 512;  // BARBELL_AMD_REG_THREADS: block size of k_barcode_reg (tuning knob)
     uint32_t pfx_threads = 0;    // BARBELL_AMD_PFX_THREADS: block size of k_barcode_pfx (0 = as many lanes as fit a CU)
-    bool lane_kernel = true;     // BARBELL_AMD_LANE=0: the fast barcode stage with one lane per (hit, barcode) (k_barcode_pfx) instead of one lane per hit (k_barcode_lane)
+    int lane_kernel = 1;         // BARBELL_AMD_LANE: 1 = the fast barcode stage with one lane per hit (k_barcode_lane) for groups whose flank budget is small
+                                 // (its bound assumes the shared rows match, which they do when the flank was found with few edits: at k = 20 eight times
+                                 // as many hits go on to the exact kernel), 0 = one lane per (hit, barcode) everywhere (k_barcode_pfx), 2 = one lane per hit everywhere
     bool force_generic = false;  // BARBELL_AMD_GENERIC=1: use the generic (any-geometry) kernels, for tests
     hipEvent_t ev[K_COUNT + 1]{};
     float ms[K_COUNT]{};
@@ -594,8 +597,8 @@ template <int CW>
 void launch_barcode_pfx(bb_ctx* c, uint32_t n_hits, uint32_t g, uint32_t strand, const uint32_t* list, const uint32_t* cnt, bool fast) {
     const bb_group_dev& D = c->gdev[g];
     const uint32_t N = (uint32_t)D.n_seqs;
-    if constexpr (CW == 48) {
-        if (fast && c->lane_kernel && D.pfx[strand] <= 16) {
+    {
+        if (fast && D.pfx[strand] <= 16 && (c->lane_kernel == 2 || (c->lane_kernel == 1 && c->groups[g].info.flank_k <= BB_LANE_MAX_FLANK_K))) {
             const uint32_t T = (uint32_t)D.tail[strand];
             const size_t smem = (((size_t)N * 64 + 31) & ~(size_t)31) + 256 * 32 + 16 + (size_t)T * 2 * 256 * 8;
             const uint32_t blocks = (n_hits + 255) / 256;
@@ -772,7 +775,7 @@ int bb_create_policy(const bb_group_desc* groups, uint32_t n_groups, const bb_pa
     if (getenv("BARBELL_AMD_NO_FAST") && atoi(getenv("BARBELL_AMD_NO_FAST")) != 0) c->fast_path = false;
     if (getenv("BARBELL_AMD_FAST_MARGIN")) c->fast_margin = atof(getenv("BARBELL_AMD_FAST_MARGIN"));
     if (getenv("BARBELL_AMD_ADAPT_FRAC")) c->adapt_frac = atof(getenv("BARBELL_AMD_ADAPT_FRAC"));
-    if (const char* e = getenv("BARBELL_AMD_LANE")) c->lane_kernel = atoi(e) != 0;
+    if (const char* e = getenv("BARBELL_AMD_LANE")) c->lane_kernel = std::max(0, std::min(2, atoi(e)));
     if (getenv("BARBELL_AMD_PFX_THREADS")) { int t = atoi(getenv("BARBELL_AMD_PFX_THREADS")); if (t >= 64 && t <= 768) c->pfx_threads = (uint32_t)t; }
     if (getenv("BARBELL_AMD_REG_THREADS")) { int t = atoi(getenv("BARBELL_AMD_REG_THREADS")); if (t >= 64 && t <= 512) c->reg_threads = (uint32_t)t; }
     c->groups.resize(n_groups);

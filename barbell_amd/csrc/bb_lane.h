@@ -19,11 +19,9 @@
 #ifndef BB_LANE_NOHOIST
 #define BB_LANE_NOHOIST 1
 #endif
-#ifndef BB_LANE_WAVES
-#define BB_LANE_WAVES 3
-#endif
+// waves per SIMD the register budget is set for: the move planes are 2 x CW registers — 48 columns fit three waves (<= 168 VGPRs), 64 two
 template <int CW, bool TAIL>
-__global__ __launch_bounds__(256, BB_LANE_WAVES) void k_barcode_lane(const uint8_t* __restrict__ tables, const bb_group_dev* __restrict__ groups, uint32_t g,
+__global__ __launch_bounds__(256, CW <= 48 ? 3 : 2) void k_barcode_lane(const uint8_t* __restrict__ tables, const bb_group_dev* __restrict__ groups, uint32_t g,
                                                       uint32_t strand, const bb_hit* __restrict__ hits, const bb_hit_pfx* __restrict__ pfxs,
                                                       const uint32_t* __restrict__ hit_list, const uint32_t* __restrict__ list_cnt,
                                                       uint32_t n_hits_all, bb_rowtmp* __restrict__ rows) {
