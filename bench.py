@@ -463,7 +463,7 @@ def compute_section(args, kavg, cells_flank, batch, L):
         out["valu_ceiling_G_wave_instr_per_s"] = {"full_rate_classes": full, "half_rate_classes": half, "source": "profiles/valu_ceiling.json"}
         v = json.load(open(os.path.join(ROOT, "profiles", f"valu_{args.config}.json")))
         if v.get("batch_reads") == batch and v.get("read_len") == L:
-            slot = {"k_flank_scan": ["k_flank_scan2", "k_flank_filter", "k_flank_verify"], "k_flank_trace": ["k_flank_trace"], "k_barcode": ["k_bar_prefix", "k_barcode_pfx", "k_barcode_reg", "k_rows"]}
+            slot = {"k_flank_scan": ["k_flank_scan2", "k_flank_filter", "k_flank_verify"], "k_flank_trace": ["k_flank_trace"], "k_barcode": ["k_bar_prefix", "k_barcode_lane", "k_barcode_pfx", "k_barcode_reg", "k_rows"]}
             per = {}
             for name, pre in slot.items():
                 n = sum(e.get("SQ_INSTS_VALU", 0.0) for k, e in v["kernels"].items() if any(k.startswith(p) for p in pre))
@@ -490,7 +490,7 @@ def load_traffic(args, batch, L, dom):
     if t.get("batch_reads") != batch or t.get("read_len") != L:
         return None, None, None
     ks = t["kernels"]
-    # the k_barcode timing slot covers k_bar_prefix + k_barcode_pfx (forward hits) + k_barcode_reg (rc hits)
+    # the k_barcode timing slot covers k_bar_prefix + k_barcode_lane | k_barcode_pfx (both strands) + k_rows + the exact kernel on undecided hits
     pre = ("k_bar", "k_rows") if dom == "k_barcode" else (dom,)
     dom_bytes = sum(v["hbm_bytes"] for k, v in ks.items() if k.startswith(pre))
     return (dom_bytes or None, sum(v["hbm_bytes"] * v.get("launches_per_step", 1) for v in ks.values() if v.get("in_step", True)),
