@@ -141,6 +141,11 @@ struct Blob {
 struct bb_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    // k_barcode_lane's waves all take the same time, so a launch ends with a round of waves that fills a fraction of the GPU (13.3 rounds
+    // for the forward hits of a 2 M-read batch: 5 % of the kernel).  The rc hits' launch goes to a second stream and fills that tail.
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool use_side = false;       // between fork and join of a barcode pass
     bb_params params{};
     bb_policy policy{};          // include/barbell_amd_policy.h: the switchable assumptions about sassy / cigar-lodhi-rs
     bool generic_barcode = false;  // the policy asks for what only the any-policy barcode kernel (k_barcode) computes
@@ -602,11 +607,12 @@ void launch_barcode_pfx(bb_ctx* c, uint32_t n_hits, uint32_t g, uint32_t strand,
             const uint32_t T = (uint32_t)D.tail[strand];
             const size_t smem = (((size_t)N * 64 + 31) & ~(size_t)31) + 256 * 32 + 16 + (size_t)T * 2 * 256 * 8;
             const uint32_t blocks = (n_hits + 255) / 256;
+            hipStream_t st = (c->use_side && strand == 1) ? c->side : c->stream;
 #define BB_LANE_LAUNCH(TAIL_)                                                                                                                     \
     do {                                                                                                                                          \
         if (smem > 64 * 1024)                                                                                                                     \
             (void)hipFuncSetAttribute((const void*)k_barcode_lane<CW, TAIL_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);            \
-        hipLaunchKernelGGL((k_barcode_lane<CW, TAIL_>), dim3(blocks), dim3(256), smem, c->stream, (const uint8_t*)c->d_tables,                    \
+        hipLaunchKernelGGL((k_barcode_lane<CW, TAIL_>), dim3(blocks), dim3(256), smem, st, (const uint8_t*)c->d_tables,                           \
                            (const bb_group_dev*)c->d_groups, g, strand, (const bb_hit*)c->d_hits, (const bb_hit_pfx*)c->d_pfx, list, cnt, n_hits, \
                            c->d_rows);                                                                                                            \
     } while (0)
@@ -805,6 +811,9 @@ int bb_create_policy(const bb_group_desc* groups, uint32_t n_groups, const bb_pa
     { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0) c->n_cus = prop.multiProcessorCount; }
     if (getenv("BARBELL_AMD_REG_BLOCKS")) { int t = atoi(getenv("BARBELL_AMD_REG_BLOCKS")); if (t >= 1 && t <= 16) c->reg_blocks_mult = (uint32_t)t; }
     if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return BB_E_NO_DEVICE; }
+    if (!getenv("BARBELL_AMD_NO_SIDE_STREAM") &&
+        (hipStreamCreate(&c->side) != hipSuccess || hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+         hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess)) { bb_destroy(c); return BB_E_NO_DEVICE; }
     for (int i = 0; i <= K_COUNT; ++i)
         if (hipEventCreate(&c->ev[i]) != hipSuccess) { delete c; return BB_E_NO_DEVICE; }
     int r = upload_tables(c);
@@ -826,6 +835,9 @@ void bb_destroy(bb_ctx* c) {
     bb_format_state_free(c->format);
     for (int i = 0; i <= K_COUNT; ++i)
         if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->side) (void)hipStreamDestroy(c->side);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -951,6 +963,9 @@ int bb_annotate_batch_dev(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_o
                 hipLaunchKernelGGL(k_rows, dim3((n_hits + 255) / 256), dim3(256), 0, c->stream, (const bb_group_dev*)c->d_groups, (const bb_hit*)c->d_hits,
                                    n_hits, c->d_rows, c->params.min_score, c->params.min_score_diff, c->fast_margin, c->d_fb_lists, c->cap_hits, c->d_fbcnt);
             }
+            const bool fork = pass == 0 && c->side != nullptr;
+            if (fork) { HIPCHK(c, hipEventRecord(c->ev_fork, c->stream)); HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_fork, 0)); }
+            c->use_side = fork;
             for (uint32_t g = 0; g < G; ++g) {
                 switch (c->gdev[g].WB) {
                     case 1: launch_barcode<1>(c, d_bases, d_offsets, n_hits, g, pass); break;
@@ -959,6 +974,8 @@ int bb_annotate_batch_dev(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_o
                     default: launch_barcode<4>(c, d_bases, d_offsets, n_hits, g, pass); break;
                 }
             }
+            c->use_side = false;
+            if (fork) { HIPCHK(c, hipEventRecord(c->ev_join, c->side)); HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0)); }
         }
         HIPCHK(c, hipGetLastError());
     }
