@@ -646,7 +646,7 @@ void launch_barcode_pfx(bb_ctx* c, uint32_t n_hits, uint32_t g, uint32_t strand,
     do {                                                                                                                    \
         if (smem > 64 * 1024)                                                                                               \
             (void)hipFuncSetAttribute((const void*)k_barcode_pfx<CW, TAIL_, FAST_, DEF_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
-        hipLaunchKernelGGL((k_barcode_pfx<CW, TAIL_, FAST_, DEF_>), dim3(blocks), dim3(threads), smem, c->stream, BB_PFX_ARGS);   \
+        hipLaunchKernelGGL((k_barcode_pfx<CW, TAIL_, FAST_, DEF_>), dim3(blocks), dim3(threads), smem, (c->use_side && strand == 1) ? c->side : c->stream, BB_PFX_ARGS);   \
     } while (0)
 #define BB_PFX_LAUNCH(TAIL_, FAST_) BB_PFX_LAUNCH4(TAIL_, FAST_, false)
     const bool defpol = CW == 48 && fast && c->policy.lm_rule == BB_LM_PLATEAU_RIGHT && c->policy.bar_tie == BB_TIE_FIRST;
@@ -945,14 +945,22 @@ int bb_annotate_batch_dev(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_o
     bool any_split = false;
     for (uint32_t g = 0; g < G; ++g) any_split = any_split || c->gdev[g].split[0] || c->gdev[g].split[1];
     c->use_lists = true;  // one list per (group, strand)
+    const bool prefix_aside = n_hits && any_split && c->side != nullptr;  // k_bar_prefix needs the hits, not their lists: alongside k_hit_lists
+    if (prefix_aside) {
+        HIPCHK(c, hipEventRecord(c->ev_fork, c->stream)); HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_fork, 0));
+        hipLaunchKernelGGL(k_bar_prefix, dim3((n_hits + 127) / 128), dim3(128), 0, c->side, (const uint8_t*)c->d_tables,
+                           (const bb_group_dev*)c->d_groups, (const bb_hit*)c->d_hits, n_hits, c->d_pfx, G);
+        HIPCHK(c, hipEventRecord(c->ev_join, c->side));
+    }
     if (n_hits) {
         HIPCHK(c, hipMemsetAsync(c->d_listcnt, 0, sizeof(uint32_t) * 4 * BB_MAX_GROUPS, c->stream));
         hipLaunchKernelGGL(k_hit_lists, dim3((n_hits + 255) / 256), dim3(256), 0, c->stream, (const bb_hit*)c->d_hits, n_hits,
                            c->d_rows, c->d_lists, c->cap_hits, c->d_listcnt, G, (const bb_group_dev*)c->d_groups);
     }
     mark(c, K_BARCODE);
+    if (prefix_aside) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
     if (n_hits) {
-        if (any_split)  // shared rows of the padded barcodes, once per hit
+        if (any_split && !prefix_aside)  // shared rows of the padded barcodes, once per hit
             hipLaunchKernelGGL(k_bar_prefix, dim3((n_hits + 127) / 128), dim3(128), 0, c->stream, (const uint8_t*)c->d_tables,
                                (const bb_group_dev*)c->d_groups, (const bb_hit*)c->d_hits, n_hits, c->d_pfx, G);
         for (int pass = 0; pass < 2; ++pass) {
@@ -963,7 +971,7 @@ int bb_annotate_batch_dev(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_o
                 hipLaunchKernelGGL(k_rows, dim3((n_hits + 255) / 256), dim3(256), 0, c->stream, (const bb_group_dev*)c->d_groups, (const bb_hit*)c->d_hits,
                                    n_hits, c->d_rows, c->params.min_score, c->params.min_score_diff, c->fast_margin, c->d_fb_lists, c->cap_hits, c->d_fbcnt);
             }
-            const bool fork = pass == 0 && c->side != nullptr;
+            const bool fork = c->side != nullptr;  // pass 1: the two strands' exact launches are small (the undecided hits) and overlap entirely
             if (fork) { HIPCHK(c, hipEventRecord(c->ev_fork, c->stream)); HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_fork, 0)); }
             c->use_side = fork;
             for (uint32_t g = 0; g < G; ++g) {
