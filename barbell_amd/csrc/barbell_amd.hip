@@ -540,7 +540,7 @@ void launch_scan(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets, u
                        (const uint8_t*)c->d_tables, (const bb_group_dev*)c->d_groups, g, (uint32_t)c->groups.size(), c->d_cnt,
                        c->d_raw, c->cap_hits, c->d_hitcount);
 }
-// Which variant of k_flank_trace a group takes (bb_kernels.h): 2 = 16-row band in LDS (k <= 6), 1 = every row in LDS,
+// Which variant of k_flank_trace a group takes (bb_kernels.h): 4 = 8-row band in LDS (k <= 3), 2 = 16-row band in LDS (k <= 6), 1 = every row in LDS,
 // 3 = checkpointed columns, 0 = private memory.
 static int trace_mode(const bb_ctx* c, uint32_t g) {
     const bb_group_dev& D = c->gdev[g];
@@ -548,6 +548,7 @@ static int trace_mode(const bb_ctx* c, uint32_t g) {
     const size_t lds = (size_t)(D.m + D.flank_k + 2) * 2 * W * 64 * 4;  // columns 0..m+k, lo+hi, W words, 64 lanes
     const size_t lds_ck = (size_t)(((D.m + D.flank_k) / BB_TRACE_CKB + 1) * 2 * W + BB_TRACE_CKB * 2 * W) * 64 * 4;
     const size_t lds_band = (size_t)(D.m + D.flank_k + 2) * 64 * 4;
+    if (D.flank_k <= 3 && lds_band <= 64 * 1024 && !c->force_generic && !getenv("BARBELL_AMD_TRACE_FULL") && !getenv("BARBELL_AMD_TRACE_BAND16")) return 4;  // 2(k+1) <= 8 rows in 8 bits
     if (D.flank_k <= 6 && lds_band <= 64 * 1024 && !c->force_generic && !getenv("BARBELL_AMD_TRACE_FULL")) return 2;  // band of 2(k+1)+1 <= 15 rows in 16 bits
     if (W <= 4 && lds <= 64 * 1024 && !c->force_generic) return 1;
     if (lds_ck <= 64 * 1024 && !c->force_generic && !getenv("BARBELL_AMD_TRACE_NOCKPT")) return 3;
@@ -565,7 +566,8 @@ void launch_trace(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets, 
         const bb_group_dev& D = c->gdev[g];
         const int mk = D.m + D.flank_k;
         mk_max = std::max(mk_max, mk);
-        const size_t need = mode == 2 ? (size_t)(mk + 2) * 64 * 4                                   // one word per column and lane
+        const size_t need = mode == 4 ? (size_t)(mk + 2) * 64 * 2                                   // 16 bits per column and lane
+                          : mode == 2 ? (size_t)(mk + 2) * 64 * 4                                   // one word per column and lane
                           : mode == 1 ? (size_t)(mk + 2) * 2 * W * 64 * 4                            // columns 0..m+k, lo+hi, W words
                           : mode == 3 ? (size_t)((mk / BB_TRACE_CKB + 1) * 2 * W + BB_TRACE_CKB * 2 * W) * 64 * 4  // checkpoints + one block's move bits
                           : 0;
@@ -573,7 +575,8 @@ void launch_trace(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets, 
     }
 #define BB_TRACE_ARGS d_bases, d_offsets, (const uint8_t*)c->d_tables, (const bb_group_dev*)c->d_groups, (uint32_t)c->groups.size(), \
                       (const bb_hit_raw*)c->d_raw, n_hits, (const uint32_t*)c->d_base, c->d_hits, gmask, mk_max
-    if (mode == 2) hipLaunchKernelGGL((k_flank_trace<W, 2>), dim3((n_hits + 63) / 64), dim3(64), lds, c->stream, BB_TRACE_ARGS);
+    if (mode == 4) hipLaunchKernelGGL((k_flank_trace<W, 4>), dim3((n_hits + 63) / 64), dim3(64), lds, c->stream, BB_TRACE_ARGS);
+    else if (mode == 2) hipLaunchKernelGGL((k_flank_trace<W, 2>), dim3((n_hits + 63) / 64), dim3(64), lds, c->stream, BB_TRACE_ARGS);
     else if (mode == 1) {
         if constexpr (W <= 4)  // the full-height LDS variant never fits beyond 4 words
             hipLaunchKernelGGL((k_flank_trace<W, 1>), dim3((n_hits + 63) / 64), dim3(64), lds, c->stream, BB_TRACE_ARGS);

@@ -1075,6 +1075,9 @@ __global__ __launch_bounds__(256) void k_scan_add(uint32_t* __restrict__ out, ui
 // band of 16 rows around the end cell's diagonal (one word per column and lane: both planes).  A path of cost
 // <= k leaves that diagonal by at most k rows, so for k <= 6 the band holds every cell the walk can visit, and
 // a quarter of the LDS lets four times as many blocks share a CU.
+// MODE 4: the band for k <= 3 — 2 (k + 1) <= 8 rows, both planes of a column in 16 bits: half the LDS again.  The kernel waits on memory
+// two thirds of its time (one lane per hit: the raw hit, the read's offset, four text chunks, the Peq rows), and its LDS decides how many
+// waves share a CU in the meantime (13 KB per 64-lane block: 12; 6.5 KB: 24).
 // MODE 3 (k > 6 where the full height does not fit): no move bits during the forward pass, only the column state (Pv, Mv)
 // every 8 columns in LDS; the walk then goes back block by block — the wave recomputes the 8 columns of a block from its
 // checkpoint with their move bits into a small LDS window and every lane walks through its part of the block — so the DP
@@ -1127,7 +1130,8 @@ __device__ __forceinline__ uint32_t flank_trace_lane(const uint8_t* __restrict__
     };
     auto put_band = [&](int c, const uint32_t (&l)[W], const uint32_t (&hh)[W]) {
         const int sh = band_lo(c);
-        s_moves[c * 64 + threadIdx.x] = bits16(l, sh) | (bits16(hh, sh) << 16);
+        if constexpr (MODE == 4) reinterpret_cast<uint16_t*>(s_moves)[c * 64 + threadIdx.x] = (uint16_t)((bits16(l, sh) & 0xFFu) | ((bits16(hh, sh) & 0xFFu) << 8));
+        else s_moves[c * 64 + threadIdx.x] = bits16(l, sh) | (bits16(hh, sh) << 16);
     };
     // 2-bit move of cell (row bit `bit`, column c)
     auto get_op = [&](int c, int bit) -> uint32_t {
@@ -1135,6 +1139,10 @@ __device__ __forceinline__ uint32_t flank_trace_lane(const uint8_t* __restrict__
             const uint32_t wv = s_moves[c * 64 + threadIdx.x];
             const int rel = bit - band_lo(c);
             return ((wv >> rel) & 1u) | (((wv >> (16 + rel)) & 1u) << 1);
+        } else if constexpr (MODE == 4) {
+            const uint32_t wv = reinterpret_cast<const uint16_t*>(s_moves)[c * 64 + threadIdx.x];
+            const int rel = bit - band_lo(c);
+            return ((wv >> rel) & 1u) | (((wv >> (8 + rel)) & 1u) << 1);
         } else if constexpr (MODE == 1) {
             const uint32_t lw = s_moves[((c * 2 + 0) * W + (bit >> 5)) * 64 + threadIdx.x], hw = s_moves[((c * 2 + 1) * W + (bit >> 5)) * 64 + threadIdx.x];
             return ((lw >> (bit & 31)) & 1u) | (((hw >> (bit & 31)) & 1u) << 1);
@@ -1185,7 +1193,7 @@ __device__ __forceinline__ uint32_t flank_trace_lane(const uint8_t* __restrict__
                 load_eq<W, S>(peq, ch, eq);
                 myers_step<W>(pv, mv, eq, d0, ph, mh);
                 move_bits_prio<W>(prio, eq, d0, ph, pv, l, hh);
-                if constexpr (MODE == 2) put_band(c, l, hh);
+                if constexpr (MODE == 2 || MODE == 4) put_band(c, l, hh);
                 else if constexpr (MODE == 3) { if ((c & (BB_TRACE_CKB - 1)) == 0) ck_store(c / BB_TRACE_CKB); }
                 else {
 #pragma unroll
