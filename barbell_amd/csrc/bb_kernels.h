@@ -1180,29 +1180,61 @@ __device__ __forceinline__ uint32_t flank_trace_lane(const uint8_t* __restrict__
         for (int x = 0; x < W; ++x) { s_moves[((blk * 2 * W) + x) * 64 + threadIdx.x] = pv[x]; s_moves[((blk * 2 * W) + W + x) * 64 + threadIdx.x] = mv[x]; }
     };
     if constexpr (MODE == 3) ck_store(0);
-    uint32_t cur[4], nxt[4];
-    load16(s0, cur);
-    for (int32_t cb = 0; cb < w; cb += 16) {
-        if (cb + 16 < w) load16(s0 + cb + 16, nxt);
+    auto column = [&](int32_t c, uint32_t ch) {
+        uint32_t eq[W], d0[W], ph[W], mh[W], l[W], hh[W];
+        load_eq<W, S>(peq, ch, eq);
+        myers_step<W>(pv, mv, eq, d0, ph, mh);
+        move_bits_prio<W>(prio, eq, d0, ph, pv, l, hh);
+        if constexpr (MODE == 2 || MODE == 4) put_band(c, l, hh);
+        else if constexpr (MODE == 3) { if ((c & (BB_TRACE_CKB - 1)) == 0) ck_store(c / BB_TRACE_CKB); }
+        else {
 #pragma unroll
-        for (int b = 0; b < 16; ++b) {
-            const int32_t c = cb + b + 1;
-            if (c <= w) {
-                const uint32_t ch = (cur[b >> 2] >> (8 * (b & 3))) & 0xFFu;
-                uint32_t eq[W], d0[W], ph[W], mh[W], l[W], hh[W];
-                load_eq<W, S>(peq, ch, eq);
-                myers_step<W>(pv, mv, eq, d0, ph, mh);
-                move_bits_prio<W>(prio, eq, d0, ph, pv, l, hh);
-                if constexpr (MODE == 2 || MODE == 4) put_band(c, l, hh);
-                else if constexpr (MODE == 3) { if ((c & (BB_TRACE_CKB - 1)) == 0) ck_store(c / BB_TRACE_CKB); }
-                else {
+            for (int x = 0; x < W; ++x) put(c, x, l[x], hh[x]);
+        }
+    };
+    if constexpr ((MODE == 2 || MODE == 4) && W <= 2) {
+        // band variants (k <= 6: at most 32 W + 6 columns): every chunk of the window's text requested before the first column. Its
+        // 50-70 bytes lie in one or two lines; fetched a chunk at a time as the DP got there, a line was often gone from L2 again by
+        // the next request once 24 waves per CU were in flight (1.2 -> 1.7 GB of HBM reads per step with the 8-row band).
+        constexpr int NCH = 4;  // 64 columns at once; the rest (m + k > 64: two-word flanks of more than 58 characters) one by one
+        uint32_t buf[NCH][4];
 #pragma unroll
-                    for (int x = 0; x < W; ++x) put(c, x, l[x], hh[x]);
+        for (int q = 0; q < NCH; ++q) {
+            buf[q][0] = buf[q][1] = buf[q][2] = buf[q][3] = 0u;
+            if (16 * q < w) load16(s0 + 16 * q, buf[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < NCH; ++q) {
+            if (__any(16 * q < w)) {
+#pragma unroll
+                for (int b = 0; b < 16; ++b) {
+                    const int32_t c = 16 * q + b + 1;
+                    if (c <= w) column(c, (buf[q][b >> 2] >> (8 * (b & 3))) & 0xFFu);
                 }
             }
         }
+        for (int32_t cb = 16 * NCH; cb < w; cb += 16) {
+            uint32_t cur[4];
+            load16(s0 + cb, cur);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) cur[q] = nxt[q];
+            for (int b = 0; b < 16; ++b) {
+                const int32_t c = cb + b + 1;
+                if (c <= w) column(c, (cur[b >> 2] >> (8 * (b & 3))) & 0xFFu);
+            }
+        }
+    } else {
+        uint32_t cur[4], nxt[4];
+        load16(s0, cur);
+        for (int32_t cb = 0; cb < w; cb += 16) {
+            if (cb + 16 < w) load16(s0 + cb + 16, nxt);
+#pragma unroll
+            for (int b = 0; b < 16; ++b) {
+                const int32_t c = cb + b + 1;
+                if (c <= w) column(c, (cur[b >> 2] >> (8 * (b & 3))) & 0xFFu);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) cur[q] = nxt[q];
+        }
     }
     (void)ovh;
     // traceback from (j0, w)
