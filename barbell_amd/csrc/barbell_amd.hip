@@ -146,6 +146,7 @@ struct bb_ctx {
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool use_side = false;       // between fork and join of a barcode pass
+    bool lazy_prefix = false;    // this batch: every split (group, strand) takes k_barcode_lane, prefix records only for the hits that go on to the exact kernel
     bb_params params{};
     bb_policy policy{};          // include/barbell_amd_policy.h: the switchable assumptions about sassy / cigar-lodhi-rs
     bool generic_barcode = false;  // the policy asks for what only the any-policy barcode kernel (k_barcode) computes
@@ -601,12 +602,17 @@ void launch_barcode_reg(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_off
                        cnt, n_hits, hpb, c->params.min_score, c->params.min_score_diff, c->d_rows);
 }
 
+// pass 0 of a split (group, strand): k_barcode_lane (which computes the shared rows itself) or k_barcode_pfx (which reads k_bar_prefix's records)
+static bool takes_lane(const bb_ctx* c, uint32_t g, uint32_t strand) {
+    const bb_group_dev& D = c->gdev[g];
+    return c->fast_path && D.pfx[strand] <= 16 && (c->lane_kernel == 2 || (c->lane_kernel == 1 && c->groups[g].info.flank_k <= BB_LANE_MAX_FLANK_K));
+}
 template <int CW>
 void launch_barcode_pfx(bb_ctx* c, uint32_t n_hits, uint32_t g, uint32_t strand, const uint32_t* list, const uint32_t* cnt, bool fast) {
     const bb_group_dev& D = c->gdev[g];
     const uint32_t N = (uint32_t)D.n_seqs;
     {
-        if (fast && D.pfx[strand] <= 16 && (c->lane_kernel == 2 || (c->lane_kernel == 1 && c->groups[g].info.flank_k <= BB_LANE_MAX_FLANK_K))) {
+        if (fast && takes_lane(c, g, strand)) {
             const uint32_t T = (uint32_t)D.tail[strand];
             const size_t smem = (((size_t)N * 64 + 31) & ~(size_t)31) + 256 * 32 + 16 + (size_t)T * 2 * 256 * 8;
             const uint32_t blocks = (n_hits + 255) / 256;
@@ -694,6 +700,9 @@ void launch_barcode(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets
                     if (!c->fast_path) continue;
                     list = c->d_fb_lists + (size_t)slot * c->cap_hits;
                     cnt = c->d_fbcnt + slot - g;
+                    if (c->lazy_prefix)  // no k_bar_prefix has run over all hits: the records of the undecided ones, now
+                        hipLaunchKernelGGL(k_bar_prefix_list, dim3(256), dim3(128), 0, (c->use_side && strand == 1) ? c->side : c->stream, (const uint8_t*)c->d_tables,
+                                           (const bb_group_dev*)c->d_groups, (const bb_hit*)c->d_hits, list, c->d_fbcnt + slot, c->d_pfx);
                 }
                 const bool fast = pass == 0 && c->fast_path;
                 if (!wide) launch_barcode_pfx<48>(c, n_hits, g, strand, list, cnt, fast);
@@ -947,8 +956,16 @@ int bb_annotate_batch_dev(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_o
     mark(c, K_LISTS);
     bool any_split = false;
     for (uint32_t g = 0; g < G; ++g) any_split = any_split || c->gdev[g].split[0] || c->gdev[g].split[1];
+    bool any_split_prefix = any_split;  // k_bar_prefix over every hit
     c->use_lists = true;  // one list per (group, strand)
-    const bool prefix_aside = n_hits && any_split && c->side != nullptr;  // k_bar_prefix needs the hits, not their lists: alongside k_hit_lists
+    bool all_lane = any_split;
+    for (uint32_t g = 0; g < G; ++g)
+        for (uint32_t sd = 0; sd < 2; ++sd)
+            if (c->gdev[g].split[sd] && !(c->gdev[g].WB == 2 && !c->force_generic && !c->generic_barcode && takes_lane(c, g, sd) &&
+                                          c->groups[g].info.mask_len + (uint32_t)c->groups[g].info.flank_k + 2 * BB_PADDING - 1 <= 64)) all_lane = false;
+    c->lazy_prefix = all_lane && !getenv("BARBELL_AMD_FULL_PREFIX");
+    if (c->lazy_prefix) any_split_prefix = false;
+    const bool prefix_aside = n_hits && any_split_prefix && c->side != nullptr;  // k_bar_prefix needs the hits, not their lists: alongside k_hit_lists
     if (prefix_aside) {
         HIPCHK(c, hipEventRecord(c->ev_fork, c->stream)); HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_fork, 0));
         hipLaunchKernelGGL(k_bar_prefix, dim3((n_hits + 127) / 128), dim3(128), 0, c->side, (const uint8_t*)c->d_tables,
@@ -963,7 +980,7 @@ int bb_annotate_batch_dev(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_o
     mark(c, K_BARCODE);
     if (prefix_aside) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
     if (n_hits) {
-        if (any_split && !prefix_aside)  // shared rows of the padded barcodes, once per hit
+        if (any_split_prefix && !prefix_aside)  // shared rows of the padded barcodes, once per hit
             hipLaunchKernelGGL(k_bar_prefix, dim3((n_hits + 127) / 128), dim3(128), 0, c->stream, (const uint8_t*)c->d_tables,
                                (const bb_group_dev*)c->d_groups, (const bb_hit*)c->d_hits, n_hits, c->d_pfx, G);
         for (int pass = 0; pass < 2; ++pass) {

@@ -19,6 +19,61 @@
 #ifndef BB_LANE_NOHOIST
 #define BB_LANE_NOHOIST 1
 #endif
+// One column of the DP on the leading shared rows (k_bar_prefix's step: P <= 16 rows in one word, no carry-in — row 0 is the text's free start):
+// the horizontal deltas of row P (-> the lane rows' carry-in) and the column's move planes, row r <-> bit P - r, lo | hi << 16.
+__device__ __forceinline__ void shared_rows_column(uint32_t eq, int P, uint32_t& pv, uint32_t& mv, uint32_t& hp, uint32_t& hm, uint32_t& shw) {
+    const uint32_t x = eq & pv;
+    const uint32_t d0 = (((x + pv) ^ pv) | eq | mv);
+    const uint32_t ph = mv | ~(d0 | pv), mh = pv & d0;
+    hp = (ph >> (P - 1)) & 1u; hm = (mh >> (P - 1)) & 1u;
+    const uint32_t isM = d0 & eq, l = ~(isM | ph), hh = (ph & ~isM) | (l & d0);
+    shw = (__brev(l) >> (32 - P)) | ((__brev(hh) >> (32 - P)) << 16);
+    const uint32_t phs = shl1_32(ph), mhs = shl1_32(mh);
+    pv = mhs | ~(d0 | phs);
+    mv = phs & d0;
+}
+
+// The winner's walk through the shared rows, columns LO+1 .. HI (1-based): their move planes recomputed into HI - LO registers (the DP
+// from column 1: a dozen instructions per column), then one step per column from HI down, for the lanes whose cursor is in that column.
+template <int LO, int HI, int NW>
+__device__ __forceinline__ void shared_rows_walk(const uint32_t* s_eqt, const uint32_t (&cw)[NW], int P, uint32_t pm, int wmax, uint32_t& bh, int32_t& col,
+                                                 int32_t& ntext, uint32_t& dgh, uint32_t (&pl_w)[2], uint32_t (&ph_w)[2]) {
+    uint32_t shw[HI - LO];
+    {
+        uint32_t pv = P >= 32 ? 0xFFFFFFFFu : (1u << P) - 1u, mv = 0u;
+#pragma unroll
+        for (int c = 0; c < HI; ++c) {
+            uint32_t w = 0u;
+            if (c < wmax) {  // wave-uniform
+                uint32_t hp, hm;
+                shared_rows_column(s_eqt[(cw[c >> 2] >> (8 * (c & 3) + 2)) & 0xFu] & 0xFFFFu, P, pv, mv, hp, hm, w);
+            }
+            if (c >= LO) shw[c - LO] = w;
+        }
+    }
+#pragma unroll
+    for (int c = HI; c > LO; --c) {
+        if (c <= wmax) {
+            const bool on = bh != 0u && col == c;
+            const uint32_t w = shw[c - 1 - LO];
+            const uint32_t Lr = w & 0xFFFFu, Hr = w >> 16;
+            const uint32_t Dr = Lr & Hr;
+            const uint32_t nb = on ? (((Dr + bh) & ~Dr) & pm) : 0u;
+            const bool has = nb != 0u, lo = (Lr & nb) != 0u, hi = (Hr & nb) != 0u;
+            pl_w[(c - 1) >> 5] |= lo ? 1u << ((c - 1) & 31) : 0u;
+            ph_w[(c - 1) >> 5] |= hi ? 1u << ((c - 1) & 31) : 0u;
+            const bool consume = has & !hi;
+            dgh |= consume ? nb : 0u;
+            if (on) {
+                bh = consume ? ((nb << 1) & pm) : nb;
+                ntext += has ? 1 : 0;
+                col -= has ? 1 : 0;
+                if (col < 1) bh = 0u;
+            }
+        }
+    }
+}
+
 // waves per SIMD the register budget is set for: the move planes are 2 x CW registers — 48 columns fit three waves (<= 168 VGPRs), 64 two
 template <int CW, bool TAIL>
 __global__ __launch_bounds__(256, CW <= 48 ? 3 : 2) void k_barcode_lane(const uint8_t* __restrict__ tables, const bb_group_dev* __restrict__ groups, uint32_t g,
@@ -40,6 +95,12 @@ __global__ __launch_bounds__(256, CW <= 48 ? 3 : 2) void k_barcode_lane(const ui
     o += 256 * sizeof(bb_lb_entry);
     o = (o + 15) & ~(size_t)15;
     unsigned long long* s_tail = reinterpret_cast<unsigned long long*>(smem + o);  // [t][lo|hi][thread]
+    __shared__ uint32_t s_eqt[16];   // Peq of the leading shared rows per base set; trailing rows matched per base set in bits 16..
+    if (threadIdx.x < 16u) {
+        const uint32_t e = reinterpret_cast<const uint32_t*>(tables + G.off_peq_pfx[strand])[threadIdx.x];
+        const uint32_t tl = (tables + G.off_tail_lut[strand])[threadIdx.x];
+        s_eqt[threadIdx.x] = (e & 0xFFFFu) | (tl << 16);
+    }
     {
         const uint32_t* gp = reinterpret_cast<const uint32_t*>(tables + G.off_peq_sub[strand]);  // [code][barcode]
         for (int i = threadIdx.x; i < 16 * N; i += 256) {
@@ -95,40 +156,45 @@ __global__ __launch_bounds__(256, CW <= 48 ? 3 : 2) void k_barcode_lane(const ui
             cw[4 * q + 2] = (w.z & 0x0F0F0F0Fu) << 2; cw[4 * q + 3] = (w.w & 0x0F0F0F0Fu) << 2;
         }
     }
-    uint32_t hpw[2], hmw[2];
+    uint32_t hpw[2] = {0u, 0u}, hmw[2] = {0u, 0u};
     unsigned long long TE[BB_MAX_TAIL];
-    const uint32_t* my_sh = pfxs[hit_idx].sh;  // read in the final trip only (the winner's walk through the shared rows): from L2
-    {
-        const uint4* pp4 = reinterpret_cast<const uint4*>(pfxs + hit_idx);
-        const uint4 a = pp4[0];
-        hpw[0] = a.x; hpw[1] = a.y; hmw[0] = a.z; hmw[1] = a.w;
 #pragma unroll
-        for (int q = 0; q < BB_MAX_TAIL / 2; ++q) {
-            const uint4 t4 = pp4[1 + q];
-            TE[2 * q] = ((unsigned long long)t4.y << 32) | t4.x; TE[2 * q + 1] = ((unsigned long long)t4.w << 32) | t4.z;
-        }
-    }
+    for (int q = 0; q < BB_MAX_TAIL; ++q) TE[q] = 0ull;
     int wmax = wn;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) wmax = max(wmax, __shfl_xor(wmax, d, 64));
     wmax = __builtin_amdgcn_readfirstlane(wmax);
     __syncthreads();  // the tables; the only barrier of the kernel
+    // The leading shared rows once per hit, by the lane itself (k_bar_prefix's recurrence: 12 instructions per column against the 96 x 40
+    // of the barcode loop): their carry-in masks and the trailing rows' match masks stay in registers, and no prefix record is read.
+    {
+        uint32_t pv = P ? (P >= 32 ? 0xFFFFFFFFu : (1u << P) - 1u) : 0u, mv = 0u;
+#pragma unroll
+        for (int c = 0; c < CW; ++c) {
+            if (c < wmax) {  // wave-uniform
+                const uint32_t e = s_eqt[(cw[c >> 2] >> (8 * (c & 3) + 2)) & 0xFu];
+                const bool in = c < wn;
+                if (TAIL) {
+#pragma unroll
+                    for (int q = 0; q < BB_MAX_TAIL; ++q) TE[q] |= (in && ((e >> (16 + q)) & 1u)) ? 1ull << c : 0ull;
+                }
+                if (P > 0) {
+                    uint32_t hp, hm, shw;
+                    shared_rows_column(e & 0xFFFFu, P, pv, mv, hp, hm, shw);
+                    hpw[c >> 5] |= in ? hp << (c & 31) : 0u;
+                    hmw[c >> 5] |= in ? hm << (c & 31) : 0u;
+                }
+            }
+        }
+    }
 
     const uint8_t* s_peq_b = reinterpret_cast<const uint8_t*>(s_peq);
     // running top-2 of the two candidate sets (searcher.rs:303-328): bound bits + 1 (0 = empty), first maximum's barcode
     uint32_t b1A = 0u, b2A = 0u, pA = 0u, b1B = 0u, b2B = 0u, pB = 0u;
     uint32_t ptop = 0u;
     bool want = false;  // the final trip: this lane has a winner to trace again
-#pragma unroll 1
-    for (int it = 0; it <= N; ++it) {
-        const bool last = it == N;
-        if (last) {
-            const bool pass2 = b2A == 0u && k1 < k2;
-            const uint32_t mx = pass2 ? b1B : b1A;
-            ptop = pass2 ? pB : pA;
-            want = active && mx != 0u;
-            if (!__any(want)) break;
-        }
+    // one trip: barcode `it` for every lane, or (last) each lane's own winner again
+    auto trip = [&](const int it, const bool last) __attribute__((always_inline)) {
         const uint32_t pbase = (last ? ptop : (uint32_t)it) * 64u;  // byte offset of the barcode's 16 Peq words
 #if BB_LANE_NOHOIST
         // The per-column fields of these words (48 Peq offsets, 96 carry-in bits) are the same in every trip and the compiler keeps them
@@ -210,7 +276,7 @@ __global__ __launch_bounds__(256, CW <= 48 ? 3 : 2) void k_barcode_lane(const ui
             pick_minimum(Pm, Mm, wn, m, on, pol_lm, tie_last, best_cost, best_pos);
         }
         const bool cand = on && best_pos >= 0 && best_cost <= k2;
-        if (!__any(cand)) continue;
+        if (!__any(cand)) return;
         // ---- traceback, phase 0: the trailing shared rows ----
         unsigned long long plo = 0ull, phi = 0ull;
         uint32_t b = 0u, dg = 0u;
@@ -257,26 +323,20 @@ __global__ __launch_bounds__(256, CW <= 48 ? 3 : 2) void k_barcode_lane(const ui
             const int32_t cx = cand ? best_pos - ntext : 0;
             // ---- phase 2: the shared rows (row r <-> bit P - r), walked on the lane's own prefix record ----
             uint32_t dgh = 0u;
-            {
+            if (P > 0) {
+                // the shared rows' move planes again, into registers (the lane rows' planes are dead by now), and the walk column by
+                // column from the top: a lane takes part from the column its cursor entered row P in.  Half the window at a time — 24
+                // registers instead of 48 keep the kernel at three waves per SIMD without spills — and the upper half only if some
+                // lane's cursor enters there (a winner's does not: its lane rows have consumed ~32 columns by then).
                 const uint32_t pm = (1u << P) - 1u;  // P <= 16
-                uint32_t bh = (cand && cx >= 1 && P > 0) ? 1u : 0u;
+                uint32_t bh = (cand && cx >= 1) ? 1u : 0u;
                 int32_t col = cx;
-                while (__any(bh != 0u)) {
-                    const uint32_t w = my_sh[col >= 1 ? col - 1 : 0];
-                    const uint32_t Lr = w & 0xFFFFu, Hr = w >> 16;
-                    const uint32_t Dr = Lr & Hr;
-                    const uint32_t nb = bh ? (((Dr + bh) & ~Dr) & pm) : 0u;
-                    const bool has = nb != 0u, lo = (Lr & nb) != 0u, hi = (Hr & nb) != 0u;
-                    const unsigned long long bit = 1ull << (col >= 1 ? col - 1 : 0);
-                    plo |= lo ? bit : 0ull;
-                    phi |= hi ? bit : 0ull;
-                    const bool consume = has & !hi;
-                    dgh |= consume ? nb : 0u;
-                    bh = consume ? ((nb << 1) & pm) : nb;
-                    ntext += has ? 1 : 0;
-                    col -= has ? 1 : 0;
-                    if (col < 1) bh = 0u;
-                }
+                uint32_t pl_w[2] = {0u, 0u}, ph_w[2] = {0u, 0u};
+                constexpr int HALF = CW / 2;
+                if (__any(bh != 0u && col > HALF)) shared_rows_walk<HALF, CW>(s_eqt, cw, P, pm, wmax, bh, col, ntext, dgh, pl_w, ph_w);
+                shared_rows_walk<0, HALF>(s_eqt, cw, P, pm, wmax, bh, col, ntext, dgh, pl_w, ph_w);
+                plo |= ((unsigned long long)pl_w[1] << 32) | pl_w[0];
+                phi |= ((unsigned long long)ph_w[1] << 32) | ph_w[0];
             }
             const int32_t tstart = cand ? best_pos - ntext : 0;
             if (cand) {  // always, for a lane with `want`: the same barcode was a candidate in its own trip
@@ -292,7 +352,7 @@ __global__ __launch_bounds__(256, CW <= 48 ? 3 : 2) void k_barcode_lane(const ui
                 for (int q = 0; q < 8; ++q) W._pad0[q] = 0;
                 *reinterpret_cast<bb_winrec*>(rows + hit_idx) = W;
             }
-            break;
+            return;
         }
         // The bound without the walk through the shared rows.  The cursor enters row P in column cx; whatever the walk does there, it
         // consumes at most P rows by a Match, in distinct columns <= cx.  The kernel's weights decay with the span of a subsequence
@@ -308,6 +368,15 @@ __global__ __launch_bounds__(256, CW <= 48 ? 3 : 2) void k_barcode_lane(const ui
             if (v > b1B) { b2B = b1B; b1B = v; pB = (uint32_t)it; } else if (v > b2B) b2B = v;
             if (best_cost <= k1) { if (v > b1A) { b2A = b1A; b1A = v; pA = (uint32_t)it; } else if (v > b2A) b2A = v; }
         }
+    };
+#pragma unroll 1
+    for (int it = 0; it < N; ++it) trip(it, false);
+    {
+        const bool pass2 = b2A == 0u && k1 < k2;
+        const uint32_t mx = pass2 ? b1B : b1A;
+        ptop = pass2 ? pB : pA;
+        want = active && mx != 0u;
+        if (__any(want)) trip(N, true);
     }
     if (active && !want) {  // no candidate at all: flank-only row (searcher.rs:353-362)
         const uint4* hp4 = reinterpret_cast<const uint4*>(hits + hit_idx);
@@ -324,5 +393,50 @@ __global__ __launch_bounds__(256, CW <= 48 ? 3 : 2) void k_barcode_lane(const ui
         r.match_type = (uint8_t)(G.type == BB_FTAG ? BB_FFLANK : BB_RFLANK);
         r.barcode_cost = (int16_t)G.m_bar; r.barcode_idx = -1;
         rows[hit_idx] = R;
+    }
+}
+
+// The prefix records of the hits on a list (the hits k_rows left undecided: k_barcode_pfx's exact variant reads them), where no
+// k_bar_prefix has run over every hit because k_barcode_lane computes its own.  A lane per listed hit, records written in place: the
+// lists are a few per cent of the hits, coalescing does not matter here.
+__global__ __launch_bounds__(128) void k_bar_prefix_list(const uint8_t* __restrict__ tables, const bb_group_dev* __restrict__ groups,
+                                                         const bb_hit* __restrict__ hits, const uint32_t* __restrict__ list,
+                                                         const uint32_t* __restrict__ cnt, bb_hit_pfx* __restrict__ out) {
+    const uint32_t n = *cnt;
+    for (uint32_t i = blockIdx.x * 128u + threadIdx.x; i < n; i += gridDim.x * 128u) {
+        const uint32_t idx = list[i];
+        const bb_hit& H = hits[idx];
+        const uint32_t strand = H.strand & 1u;
+        const bb_group_dev& G = groups[H.group];
+        const int32_t wn = (int32_t)(H.we - H.ws);
+        bb_hit_pfx R;
+        R.ph = R.mh = 0ull;
+#pragma unroll
+        for (int q = 0; q < BB_MAX_TAIL; ++q) R.teq[q] = 0ull;
+        if (H.valid && G.split[strand] && wn <= 64) {
+            const int P = G.pfx[strand], T = G.tail[strand];
+            const uint32_t* eqt = reinterpret_cast<const uint32_t*>(tables + G.off_peq_pfx[strand]);
+            const uint8_t* tlut = tables + G.off_tail_lut[strand];
+            uint32_t pv = P ? (P >= 32 ? 0xFFFFFFFFu : (1u << P) - 1u) : 0u, mv = 0u;
+            for (int c = 0; c < 64; ++c) {
+                uint32_t shw = 0u;
+                if (c < wn) {
+                    const uint32_t code = H.win[c] & 0xFu;
+                    const uint32_t tb = tlut[code];
+                    for (int q = 0; q < T; ++q) R.teq[q] |= (unsigned long long)((tb >> q) & 1u) << c;
+                    if (P > 0) {
+                        uint32_t hp, hm;
+                        shared_rows_column(eqt[code], P, pv, mv, hp, hm, shw);
+                        R.ph |= (unsigned long long)hp << c; R.mh |= (unsigned long long)hm << c;
+                    }
+                }
+                out[idx].sh[c] = shw;
+            }
+        } else {
+            for (int c = 0; c < 64; ++c) out[idx].sh[c] = 0u;
+        }
+        out[idx].ph = R.ph; out[idx].mh = R.mh;
+#pragma unroll
+        for (int q = 0; q < BB_MAX_TAIL; ++q) out[idx].teq[q] = R.teq[q];
     }
 }
