@@ -146,6 +146,7 @@ struct bb_ctx {
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool use_side = false;       // between fork and join of a barcode pass
+    uint32_t pfx_fast_launches = 0;  // per batch: fast k_barcode_pfx launches (their records need k_rows; k_barcode_lane decides in its final trip)
     bool lazy_prefix = false;    // this batch: every split (group, strand) takes k_barcode_lane, prefix records only for the hits that go on to the exact kernel
     bb_params params{};
     bb_policy policy{};          // include/barbell_amd_policy.h: the switchable assumptions about sassy / cigar-lodhi-rs
@@ -623,13 +624,14 @@ void launch_barcode_pfx(bb_ctx* c, uint32_t n_hits, uint32_t g, uint32_t strand,
             (void)hipFuncSetAttribute((const void*)k_barcode_lane<CW, TAIL_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);            \
         hipLaunchKernelGGL((k_barcode_lane<CW, TAIL_>), dim3(blocks), dim3(256), smem, st, (const uint8_t*)c->d_tables,                           \
                            (const bb_group_dev*)c->d_groups, g, strand, (const bb_hit*)c->d_hits, (const bb_hit_pfx*)c->d_pfx, list, cnt, n_hits, \
-                           c->d_rows);                                                                                                            \
+                           c->d_rows, c->params.min_score, c->params.min_score_diff, c->fast_margin, c->d_fb_lists, c->cap_hits, c->d_fbcnt);     \
     } while (0)
             if (T > 0) BB_LANE_LAUNCH(true); else BB_LANE_LAUNCH(false);
 #undef BB_LANE_LAUNCH
             return;
         }
     }
+    if (fast) ++c->pfx_fast_launches;  // these leave records for k_rows
     // CW = 48 fits 168 VGPRs -> 3 waves per SIMD: 768-thread blocks (8 hits x 96 barcodes use every lane); measured
     // 22.8 vs 26.8 ms against 512-thread blocks at 2 waves per SIMD
     uint32_t tmax = CW <= 48 ? 768u : 512u;
@@ -986,10 +988,13 @@ int bb_annotate_batch_dev(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_o
         for (int pass = 0; pass < 2; ++pass) {
             if (pass == 1) {
                 if (!(any_split && c->fast_path)) break;
-                // the exact score of every hit's best-bounded barcode; rows of the hits the bounds decide
-                HIPCHK(c, hipMemsetAsync(c->d_fbcnt, 0, sizeof(uint32_t) * 4 * BB_MAX_GROUPS, c->stream));
-                hipLaunchKernelGGL(k_rows, dim3((n_hits + 255) / 256), dim3(256), 0, c->stream, (const bb_group_dev*)c->d_groups, (const bb_hit*)c->d_hits,
-                                   n_hits, c->d_rows, c->params.min_score, c->params.min_score_diff, c->fast_margin, c->d_fb_lists, c->cap_hits, c->d_fbcnt);
+                // the exact score of every hit's best-bounded barcode; rows of the hits the bounds decide (k_barcode_lane has done that itself)
+                if (c->pfx_fast_launches)
+                    hipLaunchKernelGGL(k_rows, dim3((n_hits + 255) / 256), dim3(256), 0, c->stream, (const bb_group_dev*)c->d_groups, (const bb_hit*)c->d_hits,
+                                       n_hits, c->d_rows, c->params.min_score, c->params.min_score_diff, c->fast_margin, c->d_fb_lists, c->cap_hits, c->d_fbcnt);
+            } else {
+                c->pfx_fast_launches = 0;
+                if (any_split && c->fast_path) HIPCHK(c, hipMemsetAsync(c->d_fbcnt, 0, sizeof(uint32_t) * 4 * BB_MAX_GROUPS, c->stream));  // before the fork
             }
             const bool fork = c->side != nullptr;  // pass 1: the two strands' exact launches are small (the undecided hits) and overlap entirely
             if (fork) { HIPCHK(c, hipEventRecord(c->ev_fork, c->stream)); HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_fork, 0)); }

@@ -2668,20 +2668,12 @@ __global__ __launch_bounds__(CW <= 48 ? 768 : 512) void k_barcode_pfx(const uint
 //   * top < min_score and bound(second) < min_score: no barcode reaches min_score -> flank-only row;
 //   * otherwise the bounds do not decide: the hit goes to the exact kernel (all barcodes scored exactly) through the
 //     fallback list of its (group, strand).
-__global__ __launch_bounds__(256) void k_rows(const bb_group_dev* __restrict__ groups, const bb_hit* __restrict__ hits, uint32_t n_hits,
-                                              bb_rowtmp* __restrict__ rows, double min_score, double min_score_diff, double margin,
-                                              uint32_t* __restrict__ fb_lists, uint32_t list_stride, uint32_t* __restrict__ fb_cnt) {
-    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
-    const bool in = t < n_hits;
-    bb_winrec W;
-    if (in) W = *reinterpret_cast<const bb_winrec*>(rows + t);
-    const bool mine = in && W.marker == 2;
-    int wmax = mine ? (int)W.best_pos : 0;
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) wmax = max(wmax, __shfl_xor(wmax, d, 64));
-    wmax = __builtin_amdgcn_readfirstlane(wmax);
-    const uint4 h0 = mine ? reinterpret_cast<const uint4*>(hits + t)[0] : make_uint4(0u, 0u, 0u, 0u);
-    const uint4 h1 = mine ? reinterpret_cast<const uint4*>(hits + t)[1] : make_uint4(0u, 0u, 0u, 0u);
+// The decision of k_rows for one hit, as a function: k_barcode_lane's final trip calls it on the record it would otherwise have
+// written (no winrec round trip, no k_rows launch for its hits).  Wave-wide: lanes without a record pass mine = false.
+__device__ __forceinline__ void rows_decide(bool mine, const bb_winrec& W, const uint4 h0, const uint4 h1, uint32_t t, int wmax,
+                                            const bb_group_dev* __restrict__ groups, bb_rowtmp* __restrict__ rows, double min_score,
+                                            double min_score_diff, double margin, uint32_t* __restrict__ fb_lists, uint32_t list_stride,
+                                            uint32_t* __restrict__ fb_cnt) {
     const uint32_t grp = (h1.y >> 16) & 0xFFu, strand = (h1.y >> 24) & 1u;
     const bb_group_dev& G = groups[mine ? grp : 0u];
     const int m = G.m_bar;
@@ -2698,6 +2690,7 @@ __global__ __launch_bounds__(256) void k_rows(const bb_group_dev* __restrict__ g
         const uint32_t slot = 4u * grp + ((h1.x - h0.w) > 48u ? 2u : 0u) + strand;  // {we - ws}: the window class of k_hit_lists
         const uint32_t at = atomicAdd(&fb_cnt[slot], 1u);
         fb_lists[(size_t)slot * list_stride + at] = t;
+        rows[t].row._pad[0] = 0;  // no row yet (and no stale record in the slot): the exact kernel writes it
         return;
     }
     const bool valid = clear && s_norm >= min_score;
@@ -2722,6 +2715,24 @@ __global__ __launch_bounds__(256) void k_rows(const bb_group_dev* __restrict__ g
         r.barcode_cost = (int16_t)G.m_bar; r.barcode_idx = -1;
     }
     rows[t] = R;
+}
+
+__global__ __launch_bounds__(256) void k_rows(const bb_group_dev* __restrict__ groups, const bb_hit* __restrict__ hits, uint32_t n_hits,
+                                              bb_rowtmp* __restrict__ rows, double min_score, double min_score_diff, double margin,
+                                              uint32_t* __restrict__ fb_lists, uint32_t list_stride, uint32_t* __restrict__ fb_cnt) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    const bool in = t < n_hits;
+    bb_winrec W;
+    if (in) W = *reinterpret_cast<const bb_winrec*>(rows + t);
+    const bool mine = in && W.marker == 2;
+    int wmax = mine ? (int)W.best_pos : 0;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) wmax = max(wmax, __shfl_xor(wmax, d, 64));
+    wmax = __builtin_amdgcn_readfirstlane(wmax);
+    if (!__any(mine)) return;
+    const uint4 h0 = mine ? reinterpret_cast<const uint4*>(hits + t)[0] : make_uint4(0u, 0u, 0u, 0u);
+    const uint4 h1 = mine ? reinterpret_cast<const uint4*>(hits + t)[1] : make_uint4(0u, 0u, 0u, 0u);
+    rows_decide(mine, W, h0, h1, t, wmax, groups, rows, min_score, min_score_diff, margin, fb_lists, list_stride, fb_cnt);
 }
 
 // Hit lists for the barcode kernels: slot 4g + 2w + s holds the hits of group g on strand s (the row split of a group —

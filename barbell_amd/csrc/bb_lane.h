@@ -79,7 +79,8 @@ template <int CW, bool TAIL>
 __global__ __launch_bounds__(256, CW <= 48 ? 3 : 2) void k_barcode_lane(const uint8_t* __restrict__ tables, const bb_group_dev* __restrict__ groups, uint32_t g,
                                                       uint32_t strand, const bb_hit* __restrict__ hits, const bb_hit_pfx* __restrict__ pfxs,
                                                       const uint32_t* __restrict__ hit_list, const uint32_t* __restrict__ list_cnt,
-                                                      uint32_t n_hits_all, bb_rowtmp* __restrict__ rows) {
+                                                      uint32_t n_hits_all, bb_rowtmp* __restrict__ rows, double min_score, double min_score_diff,
+                                                      double margin, uint32_t* __restrict__ fb_lists, uint32_t list_stride, uint32_t* __restrict__ fb_cnt) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t n_list = hit_list ? list_cnt[g] : n_hits_all;
     if (blockIdx.x * 256u >= n_list) return;
@@ -339,7 +340,8 @@ __global__ __launch_bounds__(256, CW <= 48 ? 3 : 2) void k_barcode_lane(const ui
                 phi |= ((unsigned long long)ph_w[1] << 32) | ph_w[0];
             }
             const int32_t tstart = cand ? best_pos - ntext : 0;
-            if (cand) {  // always, for a lane with `want`: the same barcode was a candidate in its own trip
+            {   // what k_rows would do with the record, here (cand: always, for a lane with `want` — the same barcode was a candidate in its
+                // own trip): the exact score of the winner's path, the decision by the runner-up's bound, the row or the fallback list
                 const bool pass2 = b2A == 0u && k1 < k2;
                 const uint32_t sx = pass2 ? b2B : b2A;
                 bb_winrec W;
@@ -348,9 +350,13 @@ __global__ __launch_bounds__(256, CW <= 48 ? 3 : 2) void k_barcode_lane(const ui
                 W.ub_second = sx ? (double)__uint_as_float(sx - 1u) / G.perfect : -1.0;   // -1: no other candidate
                 W.tstart = (uint8_t)tstart; W.best_pos = (uint8_t)best_pos; W.top = (uint16_t)ptop;
                 W.flags = 0; W.marker = 2; W._pad[0] = W._pad[1] = 0;
+                int bmax = cand ? best_pos : 0;
 #pragma unroll
-                for (int q = 0; q < 8; ++q) W._pad0[q] = 0;
-                *reinterpret_cast<bb_winrec*>(rows + hit_idx) = W;
+                for (int d = 32; d >= 1; d >>= 1) bmax = max(bmax, __shfl_xor(bmax, d, 64));
+                bmax = __builtin_amdgcn_readfirstlane(bmax);
+                const uint4* hp4 = reinterpret_cast<const uint4*>(hits + hit_idx);
+                const uint4 h0 = cand ? hp4[0] : make_uint4(0u, 0u, 0u, 0u), h1 = cand ? hp4[1] : make_uint4(0u, 0u, 0u, 0u);
+                rows_decide(cand, W, h0, h1, hit_idx, bmax, groups, rows, min_score, min_score_diff, margin, fb_lists, list_stride, fb_cnt);
             }
             return;
         }
