@@ -229,7 +229,8 @@ struct AnnotateConfig {  // config.rs:3-12 with the CLI defaults of bin/main.rs:
     size_t batch_reads = 0;               // if set: block_bytes = batch_reads * 4096 (kept for CLI compatibility)
     size_t block_bytes = 128u << 20;      // raw FASTQ text handed to the GPU per ingest call.  Page-locked memory: 3 slots per context + 2 (twice
                                           // that when the quality lines are dropped on the host), each block_bytes + 16 MiB or the largest input
-                                          // file if that is smaller — 1.2 GiB at the defaults (2 contexts), 6 GiB at --streams 3 --block-bytes 256Mi
+                                          // file if that is smaller — 1.2 GiB at the defaults (2 contexts), 6 GiB at --streams 3 --block-bytes 256Mi;
+                                          // with the trim step and host_cut six slots more (blocks wait in them for the file writers)
     bool compact_upload = true;           // without the trim step: drop the '+' and quality lines on the host (half the PCIe bytes); --no-compact
     bool host_cut = true;                 // trim step: the GPU plans (slices, labels, offsets), the threads that write the per-label files cut the
                                           // records out of the block's own page-locked text — the rendered records (as many bytes as went up) do
