@@ -98,14 +98,18 @@ def test_two_word_kernel_without_prefix_split(monkeypatch):
 
 
 @pytest.mark.parametrize("knob", [("BARBELL_AMD_NO_FAST", "1"), ("BARBELL_AMD_FAST_MARGIN", "10"), ("BARBELL_AMD_NO_TAIL", "1"),
-                                  ("BARBELL_AMD_LANE", "0"), ("BARBELL_AMD_LANE", "2")])
+                                  ("BARBELL_AMD_LANE", "0"), ("BARBELL_AMD_LANE", "2"), ("BARBELL_AMD_FULL_PREFIX", "1"),
+                                  ("BARBELL_AMD_NO_SIDE_STREAM", "1"), ("BARBELL_AMD_TRACE_BAND16", "1")])
 def test_barcode_stage_variants(monkeypatch, knob):
     """The split barcode kernel has a fast variant (score BOUNDS for every barcode, the exact score of the best-bounded
     one in k_rows, hits the bounds do not decide redone by the exact variant).  NO_FAST: exact variant only; a huge
     FAST_MARGIN: the bounds decide nothing, every hit with two candidates takes the fallback; NO_TAIL: strands that
     need trailing shared rows (rc hits of SQK-NBD114-96, both strands of the 44-row kits) use the two-word kernel;
     LANE = 0 / 2: the bounds by one lane per (hit, barcode) (k_barcode_pfx) everywhere / by one lane per hit
-    (k_barcode_lane, walk-free bound, 48- and 64-column instantiations) everywhere — the default picks per group."""
+    (k_barcode_lane, walk-free bound, 48- and 64-column instantiations) everywhere — the default picks per group;
+    FULL_PREFIX: k_bar_prefix over every hit although k_barcode_lane computes its own shared rows (the records then serve the
+    exact kernel instead of k_bar_prefix_list's); NO_SIDE_STREAM: every launch on one stream; TRACE_BAND16: the 16-row band in
+    k_flank_trace also where 8 rows suffice."""
     from barbell_amd import annotate as A
 
     monkeypatch.setenv(*knob)
