@@ -623,7 +623,7 @@ void launch_barcode_pfx(bb_ctx* c, uint32_t n_hits, uint32_t g, uint32_t strand,
         if (smem > 64 * 1024)                                                                                                                     \
             (void)hipFuncSetAttribute((const void*)k_barcode_lane<CW, TAIL_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);            \
         hipLaunchKernelGGL((k_barcode_lane<CW, TAIL_>), dim3(blocks), dim3(256), smem, st, (const uint8_t*)c->d_tables,                           \
-                           (const bb_group_dev*)c->d_groups, g, strand, (const bb_hit*)c->d_hits, (const bb_hit_pfx*)c->d_pfx, list, cnt, n_hits, \
+                           (const bb_group_dev*)c->d_groups, g, strand, (const bb_hit*)c->d_hits, list, cnt, n_hits,                             \
                            c->d_rows, c->params.min_score, c->params.min_score_diff, c->fast_margin, c->d_fb_lists, c->cap_hits, c->d_fbcnt);     \
     } while (0)
             if (T > 0) BB_LANE_LAUNCH(true); else BB_LANE_LAUNCH(false);

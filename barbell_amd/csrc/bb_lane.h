@@ -9,11 +9,16 @@
 //     distinct words in four banks: a broadcast), the address being the column's code byte (kept as code << 2) added
 //     to a scalar;
 //   * the top-2 of both candidate sets are running maxima in registers — no cross-lane reduction, no atomics;
-//   * no barrier after the tables are loaded, no per-iteration table builds; the walk through the shared rows is
-//     done by the lane on its own prefix record's move bits (its row of a per-block LDS array);
+//   * no barrier after the tables are loaded, no per-iteration table builds; the bound needs no walk through the shared
+//     rows (at most P Match columns ending where the cursor enters row P: see the trip's comment);
+//   * the shared rows are the lane's own business: their DP runs once per hit in the prologue (carry-in masks in registers,
+//     no prefix record read), and the final trip recomputes their move planes into registers for the winner's walk;
 //   * the path of the best-bounded barcode is not carried along (14 registers and as many selects per barcode) but
-//     recomputed in one extra trip of the same loop body with a per-lane barcode index.
-// Output = k_barcode_pfx<.., FAST = true>'s: a bb_winrec (marker 2) for k_rows, or the flank-only row.
+//     recomputed in one extra trip of the same body with a per-lane barcode index — a second instantiation of the body
+//     AFTER the barcode loop, so that what only it needs (the walk's planes, the exact replay's f64 state) does not raise
+//     the register pressure of the loop;
+//   * that final trip also decides (rows_decide: exact score of the winner's path against the runner-up's bound).
+// Output = k_barcode_pfx<.., FAST = true> + k_rows': the hit's row, or its index on the fallback list of the exact kernel.
 #pragma once
 
 #ifndef BB_LANE_NOHOIST
@@ -77,7 +82,7 @@ __device__ __forceinline__ void shared_rows_walk(const uint32_t* s_eqt, const ui
 // waves per SIMD the register budget is set for: the move planes are 2 x CW registers — 48 columns fit three waves (<= 168 VGPRs), 64 two
 template <int CW, bool TAIL>
 __global__ __launch_bounds__(256, CW <= 48 ? 3 : 2) void k_barcode_lane(const uint8_t* __restrict__ tables, const bb_group_dev* __restrict__ groups, uint32_t g,
-                                                      uint32_t strand, const bb_hit* __restrict__ hits, const bb_hit_pfx* __restrict__ pfxs,
+                                                      uint32_t strand, const bb_hit* __restrict__ hits,
                                                       const uint32_t* __restrict__ hit_list, const uint32_t* __restrict__ list_cnt,
                                                       uint32_t n_hits_all, bb_rowtmp* __restrict__ rows, double min_score, double min_score_diff,
                                                       double margin, uint32_t* __restrict__ fb_lists, uint32_t list_stride, uint32_t* __restrict__ fb_cnt) {
