@@ -204,6 +204,13 @@ class Demuxer:
         self._check(lib().bb_last_scan_stats(self._ctx(), g, C.byref(f), C.byref(t), C.byref(k)))
         return {"flagged_pieces": f.value, "total_pieces": t.value, "kind": k.value}
 
+    def barcode_stats(self, g=0, strand=0):
+        """the barcode stage of the last batch for (group, strand): {hits, undecided, lane_kernel} — flank hits listed, how many the fast
+        kernel's bounds left to the exact pass, and whether the pair's next batch takes the one-lane-per-hit kernel (bb_last_barcode_stats)"""
+        h, u, k = C.c_uint64(), C.c_uint64(), C.c_int()
+        self._check(lib().bb_last_barcode_stats(self._ctx(), g, strand, C.byref(h), C.byref(u), C.byref(k)))
+        return {"hits": h.value, "undecided": u.value, "lane_kernel": bool(k.value)}
+
     # -- synthetic reads -----------------------------------------------------------------------
     def synth_dev(self, seed, len_min, len_max, first_read, n, d_offsets, d_bases):
         self._check(lib().bb_synth_reads_dev(self._ctx(), seed, len_min, len_max, first_read, n, d_offsets, d_bases))

@@ -146,6 +146,13 @@ struct bb_ctx {
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool use_side = false;       // between fork and join of a barcode pass
+    // Per (group, strand): k_barcode_lane's walk-free bound decides as often as the traced one while the shared rows match (they are the
+    // flank the hit was found with) — on text where they do not, more hits go on to the exact kernel.  Each batch's undecided fraction
+    // is read back with the row count; above BARBELL_AMD_LANE_FB_FRAC (0.2) the pair takes k_barcode_pfx for the next 32 batches.
+    uint8_t lane_off[BB_MAX_GROUPS][2]{};   // batches left on k_barcode_pfx
+    uint8_t lane_used[BB_MAX_GROUPS][2]{};  // this batch: the pair ran k_barcode_lane
+    double lane_fb_frac = 0.2;
+    uint64_t last_listed[BB_MAX_GROUPS][2]{}, last_undecided[BB_MAX_GROUPS][2]{};  // of the last batch (bb_last_barcode_stats)
     uint32_t pfx_fast_launches = 0;  // per batch: fast k_barcode_pfx launches (their records need k_rows; k_barcode_lane decides in its final trip)
     bool lazy_prefix = false;    // this batch: every split (group, strand) takes k_barcode_lane, prefix records only for the hits that go on to the exact kernel
     bb_params params{};
@@ -606,7 +613,8 @@ void launch_barcode_reg(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_off
 // pass 0 of a split (group, strand): k_barcode_lane (which computes the shared rows itself) or k_barcode_pfx (which reads k_bar_prefix's records)
 static bool takes_lane(const bb_ctx* c, uint32_t g, uint32_t strand) {
     const bb_group_dev& D = c->gdev[g];
-    return c->fast_path && D.pfx[strand] <= 16 && (c->lane_kernel == 2 || (c->lane_kernel == 1 && c->groups[g].info.flank_k <= BB_LANE_MAX_FLANK_K));
+    return c->fast_path && D.pfx[strand] <= 16 &&
+           (c->lane_kernel == 2 || (c->lane_kernel == 1 && c->groups[g].info.flank_k <= BB_LANE_MAX_FLANK_K && c->lane_off[g][strand] == 0));
 }
 template <int CW>
 void launch_barcode_pfx(bb_ctx* c, uint32_t n_hits, uint32_t g, uint32_t strand, const uint32_t* list, const uint32_t* cnt, bool fast) {
@@ -628,6 +636,7 @@ void launch_barcode_pfx(bb_ctx* c, uint32_t n_hits, uint32_t g, uint32_t strand,
     } while (0)
             if (T > 0) BB_LANE_LAUNCH(true); else BB_LANE_LAUNCH(false);
 #undef BB_LANE_LAUNCH
+            c->lane_used[g][strand] = 1;
             return;
         }
     }
@@ -795,6 +804,7 @@ int bb_create_policy(const bb_group_desc* groups, uint32_t n_groups, const bb_pa
     if (getenv("BARBELL_AMD_NO_FAST") && atoi(getenv("BARBELL_AMD_NO_FAST")) != 0) c->fast_path = false;
     if (getenv("BARBELL_AMD_FAST_MARGIN")) c->fast_margin = atof(getenv("BARBELL_AMD_FAST_MARGIN"));
     if (getenv("BARBELL_AMD_ADAPT_FRAC")) c->adapt_frac = atof(getenv("BARBELL_AMD_ADAPT_FRAC"));
+    if (const char* e = getenv("BARBELL_AMD_LANE_FB_FRAC")) c->lane_fb_frac = atof(e);
     if (const char* e = getenv("BARBELL_AMD_LANE")) c->lane_kernel = std::max(0, std::min(2, atoi(e)));
     if (getenv("BARBELL_AMD_PFX_THREADS")) { int t = atoi(getenv("BARBELL_AMD_PFX_THREADS")); if (t >= 64 && t <= 768) c->pfx_threads = (uint32_t)t; }
     if (getenv("BARBELL_AMD_REG_THREADS")) { int t = atoi(getenv("BARBELL_AMD_REG_THREADS")); if (t >= 64 && t <= 512) c->reg_threads = (uint32_t)t; }
@@ -1018,9 +1028,25 @@ int bb_annotate_batch_dev(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_o
     HIPCHK(c, hipMemsetAsync(c->d_nrows + n, 0, 4, c->stream));
     if ((r = scan_u32(c, c->d_nrows, c->d_rowoff, (uint64_t)n + 1))) return r;
     uint32_t total = 0;
+    uint32_t h_listed[4 * BB_MAX_GROUPS], h_undecided[4 * BB_MAX_GROUPS];
+    const bool fb_stats = n_hits && c->fast_path && c->lane_kernel == 1;
+    if (fb_stats) {
+        HIPCHK(c, hipMemcpyAsync(h_listed, c->d_listcnt, sizeof(uint32_t) * 4 * G, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(h_undecided, c->d_fbcnt, sizeof(uint32_t) * 4 * G, hipMemcpyDeviceToHost, c->stream));
+    }
     HIPCHK(c, hipMemcpyAsync(&total, c->d_rowoff + n, 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     *n_rows = total;
+    for (uint32_t g = 0; g < G; ++g)
+        for (uint32_t sd = 0; sd < 2; ++sd) {
+            if (c->lane_off[g][sd]) --c->lane_off[g][sd];
+            if (fb_stats) {
+                const uint64_t listed = (uint64_t)h_listed[4 * g + sd] + h_listed[4 * g + 2 + sd], und = (uint64_t)h_undecided[4 * g + sd] + h_undecided[4 * g + 2 + sd];
+                c->last_listed[g][sd] = listed; c->last_undecided[g][sd] = und;
+                if (c->lane_used[g][sd] && listed >= 1024 && (double)und > c->lane_fb_frac * (double)listed) c->lane_off[g][sd] = 32;
+            }
+            c->lane_used[g][sd] = 0;
+        }
     mark(c, K_EMIT);
     if (total > rows_cap || (total && !d_rows)) return BB_E_CAPACITY;
     if (total)
@@ -1181,6 +1207,14 @@ int bb_counts_reset(bb_ctx* c) {
     if (!c) return BB_E_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipMemset(c->d_counts, 0, sizeof(uint64_t) * c->counts_len));
+    return BB_OK;
+}
+
+int bb_last_barcode_stats(const bb_ctx* c, uint32_t g, uint32_t strand, uint64_t* hits, uint64_t* undecided, int* lane_kernel) {
+    if (!c || g >= c->groups.size() || strand > 1) return BB_E_INVALID;
+    if (hits) *hits = c->last_listed[g][strand];
+    if (undecided) *undecided = c->last_undecided[g][strand];
+    if (lane_kernel) *lane_kernel = c->lane_kernel == 2 || (c->lane_kernel == 1 && c->groups[g].info.flank_k <= BB_LANE_MAX_FLANK_K && c->lane_off[g][strand] == 0);
     return BB_OK;
 }
 

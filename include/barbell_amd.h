@@ -168,6 +168,12 @@ void        bb_set_timing(bb_ctx* ctx, int enable);
  * same whichever ran; the counts tell a caller how far its data is from the synthetic benchmark's.                       */
 int bb_last_scan_stats(const bb_ctx* ctx, uint32_t group, uint64_t* flagged_pieces, uint64_t* total_pieces, int* kind);
 
+/* The barcode stage of the last batch, per (group, strand): flank hits listed for it, how many of them the fast kernel's bounds left
+ * undecided (those are scored exactly by the second pass), and whether the pair's NEXT batch takes the one-lane-per-hit kernel
+ * (k_barcode_lane: its bound assumes the shared pad rows match; above 20 % undecided the pair goes back to k_barcode_pfx for 32
+ * batches).  Counts are only collected in the default kernel choice (BARBELL_AMD_LANE=1).  Rows do not depend on any of this.   */
+int bb_last_barcode_stats(const bb_ctx* ctx, uint32_t group, uint32_t strand, uint64_t* hits, uint64_t* undecided, int* lane_kernel);
+
 /* Device buffers for callers of the *_dev entry points that have no HIP binding of their own (the Rust
  * or C++ host): memory on the context's GPU, and copies ordered after the context's stream.         */
 int  bb_dev_malloc(bb_ctx* ctx, uint64_t bytes, void** d_ptr);

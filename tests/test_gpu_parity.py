@@ -690,3 +690,32 @@ def test_geometry_beyond_the_tuned_kernels():
         _, got, want = run_both(groups, bases, offsets)
         assert len(want) > 100, (info.pattern_len, info.flank_k)
         assert_same(got, want)
+
+
+def test_lane_kernel_backs_off_when_its_bound_decides_too_little(monkeypatch):
+    """k_barcode_lane's walk-free bound is only as sharp as the shared pad rows match.  The undecided fraction of every batch is read
+    back; above the threshold the (group, strand) pair takes k_barcode_pfx for the next 32 batches.  With the threshold at 0 the first
+    batch with any undecided hit flips the pair; rows are the oracle's before and after."""
+    from barbell_amd import annotate as A
+    from oracle import pyoracle as po
+    from tests.common import noisy_reads
+
+    monkeypatch.setenv("BARBELL_AMD_LANE_FB_FRAC", "0")
+    groups = config_groups("nbd96")
+    dm = A.Demuxer()
+    for g in groups:
+        dm.add_query_group(g)
+    orc = po.Oracle([g.as_tuple() for g in groups])
+    flipped = False
+    for batch in range(3):
+        _, bases, offsets = noisy_reads("nbd96", 77 + batch, 3000, 300, 1500, rate=0.1)
+        got = dm.demux_packed(bases, offsets)
+        want = orc.annotate(bases, offsets, n_threads=NT)
+        assert_same(got, want)
+        st = [dm.barcode_stats(0, s) for s in (0, 1)]
+        assert all(x["hits"] > 500 for x in st)
+        if batch == 0:
+            assert any(x["undecided"] > 0 for x in st)  # noisy reads: some hits always go on to the exact pass
+        flipped = flipped or any(not x["lane_kernel"] for x in st)
+    assert flipped
+    dm.close()
