@@ -698,7 +698,7 @@ void launch_barcode(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets
     // widest barcode window the flank traceback can produce: (mask_len - 1 + flank_k) + 2*PADDING
     const uint32_t win_max = I.mask_len + (uint32_t)I.flank_k + 2 * BB_PADDING - 1;
     const size_t peq_bytes = (size_t)2 * 16 * N * WB * 4;
-    const bool reg_ok = !c->force_generic && !c->generic_barcode && D.m_bar <= 48 && N <= c->reg_threads && peq_bytes <= 48 * 1024 && win_max <= 64;
+    const bool reg_ok = !c->force_generic && !c->generic_barcode && D.m_bar <= 48 && N <= c->reg_threads && peq_bytes <= 48 * 1024 && win_max <= 63;
     for (uint32_t sw = 0; sw < 4; ++sw) {
         const uint32_t strand = sw & 1u, wide = sw >> 1;
         if (wide && win_max <= 48) continue;  // no such hits
@@ -706,7 +706,7 @@ void launch_barcode(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets
         const uint32_t* list = c->d_lists + (size_t)slot * c->cap_hits;
         const uint32_t* cnt = c->d_listcnt + slot - g;  // the kernels index list_cnt with g
         if constexpr (WB == 2) {
-            if (!c->force_generic && !c->generic_barcode && D.split[strand] && win_max <= 64) {  // one word per barcode lane
+            if (!c->force_generic && !c->generic_barcode && D.split[strand] && win_max <= 63) {  // one word per barcode lane (end positions 0..wn live in a 64-bit mask: wn <= 63)
                 if (pass == 1) {
                     if (!c->fast_path) continue;
                     list = c->d_fb_lists + (size_t)slot * c->cap_hits;
@@ -974,7 +974,7 @@ int bb_annotate_batch_dev(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_o
     for (uint32_t g = 0; g < G; ++g)
         for (uint32_t sd = 0; sd < 2; ++sd)
             if (c->gdev[g].split[sd] && !(c->gdev[g].WB == 2 && !c->force_generic && !c->generic_barcode && takes_lane(c, g, sd) &&
-                                          c->groups[g].info.mask_len + (uint32_t)c->groups[g].info.flank_k + 2 * BB_PADDING - 1 <= 64)) all_lane = false;
+                                          c->groups[g].info.mask_len + (uint32_t)c->groups[g].info.flank_k + 2 * BB_PADDING - 1 <= 63)) all_lane = false;
     c->lazy_prefix = all_lane && !getenv("BARBELL_AMD_FULL_PREFIX");
     if (c->lazy_prefix) any_split_prefix = false;
     const bool prefix_aside = n_hits && any_split_prefix && c->side != nullptr;  // k_bar_prefix needs the hits, not their lists: alongside k_hit_lists

@@ -719,3 +719,29 @@ def test_lane_kernel_backs_off_when_its_bound_decides_too_little(monkeypatch):
         flipped = flipped or any(not x["lane_kernel"] for x in st)
     assert flipped
     dm.close()
+
+
+def test_windows_of_exactly_64_columns():
+    """A flank budget of 21 on SQK-NBD114-96 makes 64-column barcode windows possible (mask 24 + k 21 + 2 x padding 10 - 1): end
+    positions 0..64 do not fit the 64-bit column masks of the register kernels, so such groups take the any-geometry kernel.
+    Reads whose barcode carries 21 inserted bases produce the widest windows; rows must be the oracle's."""
+    from barbell_amd import annotate as A
+    from barbell_amd import kits
+
+    groups = kits.groups_from_kit("SQK-NBD114-96", flank_max_errors=21)
+    rng = np.random.default_rng(64)
+    g0 = groups[0]
+    reads = []
+    for i in range(60):
+        q = bytes(g0.seqs[int(rng.integers(0, len(g0.seqs)))])
+        # the construct with 17..21 random bases inserted in the middle of the barcode (the masked region of the flank: cheap insertions)
+        mid = len(q) // 2
+        ins = bytes(rng.choice(list(b"ACGT"), int(rng.integers(17, 22))).tolist())
+        body = bytes(rng.choice(list(b"ACGT"), int(rng.integers(150, 400))).tolist())
+        reads.append(q[:mid] + ins + q[mid:] + body)
+    bases, offsets = _abi.pack_reads(reads)
+    dm, got, want = run_both(groups, bases, offsets)
+    assert len(want) > 40
+    assert max(int(r["read_end_bar"]) - int(r["read_start_bar"]) for r in want) >= 24
+    assert_same(got, want)
+    dm.close()
