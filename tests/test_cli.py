@@ -419,3 +419,32 @@ def test_cli_drops_quality_lines_that_look_like_headers(tmp_path):
     for extra in ([], ["--no-compact"]):
         r = subprocess.run([CLI, "annotate", "-i", str(bad), "-o", str(tmp_path / "b.tsv"), "--kit", "SQK-NBD114-96"] + extra, capture_output=True, text=True, env=env)
         assert r.returncode == 1 and "FASTQ" in r.stderr
+
+
+@pytest.mark.gpu
+def test_cli_kit_tiny_blocks_cut_from_assembled_blocks(tmp_path):
+    """`barbell-amd kit` with 4 KB blocks and records of ~5 KB: every record spans blocks, so the text a block's records are cut out of
+    is the sequencer's assembled copy, not a page-locked slot; the output folder is byte-identical to the default run's and to
+    --gpu-render's."""
+    kit = "SQK-RBK114-24"
+    groups = kits.groups_from_kit(kit)
+    from barbell_amd import annotate as A
+
+    n = 300
+    bases, offsets = A.synth_reads_host(groups, 11, 2300, 2600, 0, n)
+    rng = np.random.default_rng(5)
+    fq = tmp_path / "reads.fastq"
+    with open(fq, "wb") as f:
+        for i in range(n):
+            s = bytes(bases[int(offsets[i]):int(offsets[i + 1])])
+            q = bytes(rng.integers(33, 90, size=len(s), dtype=np.uint8))
+            f.write(b"@r%d d=%d\n" % (i, i) + s + b"\n+\n" + q + b"\n")
+    env = dict(os.environ, BARBELL_AMD_NO_TORCH="1")
+    outs = {}
+    for name, flags in (("default", []), ("tiny", ["--batch-reads", "1"]), ("tiny_gpu", ["--batch-reads", "1", "--gpu-render"])):
+        o = tmp_path / name
+        r = subprocess.run([CLI, "kit", "-k", kit, "-i", str(fq), "-o", str(o), "--maximize"] + flags, capture_output=True, text=True, env=env)
+        assert r.returncode == 0, r.stderr
+        outs[name] = {x.name: x.read_bytes() for x in o.iterdir()}
+    assert len(outs["default"]) > 5
+    assert outs["tiny"] == outs["default"] and outs["tiny_gpu"] == outs["default"]
