@@ -339,6 +339,11 @@ def e2e_leg(d_bases, n, L, dev):
         # `barbell-amd kit` on the same file: annotate + inspect + filter + trim, ~6.5 KB of per-barcode FASTQ written per read
         kit = {}
         try:
+            import shutil
+
+            free = shutil.disk_usage(td).free
+            if free < 1.1 * size:  # the per-barcode files are ~0.8 x the FASTQ
+                raise RuntimeError(f"skipped: {free >> 30} GiB free in {td}, the kit run writes ~{int(0.8 * size) >> 30} GiB")
             t0 = time.perf_counter()
             rk = subprocess.run([cli, "kit", "-k", "SQK-NBD114-96", "-i", fq, "-o", os.path.join(td, "kit"), "--flank-max-errors", "3", "--maximize",
                                  "--streams", "3", "-t", "32"], capture_output=True, text=True, env=env)
