@@ -38,18 +38,18 @@ class Policy(C.Structure):
     """bb_policy (include/barbell_amd_policy.h): the switchable assumptions about sassy / cigar-lodhi-rs"""
     _fields_ = [
         ("lm_rule", C.c_uint8), ("rc_order", C.c_uint8), ("trace_prio", C.c_uint8 * 4), ("ovh_round", C.c_uint8), ("bar_tie", C.c_uint8),
-        ("lodhi_p", C.c_uint8), ("lodhi_exp", C.c_uint8 * 4), ("_pad", C.c_uint8 * 3), ("lodhi_lambda", C.c_double),
+        ("lodhi_p", C.c_uint8), ("lodhi_exp", C.c_uint8 * 4), ("rc_path", C.c_uint8), ("_pad", C.c_uint8 * 2), ("lodhi_lambda", C.c_double),
     ]
 
 
 LM_RULES = ("right", "left", "strict")
 OVH_ROUNDS = ("floor", "ceil", "near")
-POLICY_DEFAULT = "lm=right,rc=scan,trace=MISD,ovh=floor,tie=first,lodhi=3:0.5:1111"
+POLICY_DEFAULT = "lm=right,rc=scan,trace=MISD,ovh=floor,tie=first,lodhi=3:0.5:1111,rcpath=fwd"
 
 
 def policy_from_str(text=None):
     """the text form of include/barbell_amd_policy.h (same grammar as bb_policy_parse) -> Policy; None / "" = default"""
-    p = Policy(0, 0, (C.c_uint8 * 4)(0, 2, 1, 3), 0, 0, 3, (C.c_uint8 * 4)(1, 1, 1, 1), (C.c_uint8 * 3)(), 0.5)
+    p = Policy(0, 0, (C.c_uint8 * 4)(0, 2, 1, 3), 0, 0, 3, (C.c_uint8 * 4)(1, 1, 1, 1), 0, (C.c_uint8 * 2)(), 0.5)
     if isinstance(text, Policy):
         return text
     for tok in (text or "").replace(" ", ",").split(","):
@@ -79,6 +79,8 @@ def policy_from_str(text=None):
             p.lodhi_p, p.lodhi_lambda = int(pp), float(lam)
             for i, ch in enumerate(e):
                 p.lodhi_exp[i] = int(ch)
+        elif k == "rcpath":
+            p.rc_path = ("fwd", "mirror").index(v)
         else:
             raise ValueError(f"unknown policy key in {tok!r}")
     return p
@@ -87,7 +89,7 @@ def policy_from_str(text=None):
 def policy_to_str(p):
     return (f"lm={LM_RULES[p.lm_rule]},rc={('scan', 'fwd')[p.rc_order]},trace={''.join('MSID'[x] for x in p.trace_prio)},"
             f"ovh={OVH_ROUNDS[p.ovh_round & 3]}{':f64' if p.ovh_round & 4 else ''},tie={('first', 'last')[p.bar_tie]},"
-            f"lodhi={p.lodhi_p}:{p.lodhi_lambda!r}:{''.join(str(x) for x in p.lodhi_exp)}")
+            f"lodhi={p.lodhi_p}:{p.lodhi_lambda!r}:{''.join(str(x) for x in p.lodhi_exp)},rcpath={('fwd', 'mirror')[p.rc_path]}")
 
 
 class GroupInfo(C.Structure):

@@ -19,25 +19,13 @@
 #include "../../include/barbell_amd_inspect.h"
 #include "../../include/barbell_amd_synth.h"
 #include "bb_common.h"
-#include "bb_ctx_view.h"
-#include "bb_kernels.h"
-#include "bb_lane.h"
-#define BB_LANE_MAX_FLANK_K 8   // flank edit budget up to which k_barcode_lane's walk-free bound decides as often as the traced one (measured: k = 3, 5 yes; k = 20 no)
+#include "bb_ctx.h"
+#include "bb_launch.h"
+#include "bb_k_rows.h"
+#include "bb_k_misc.h"
 #include "bb_synth.h"
 
 namespace {
-
-enum { K_SCAN = 0, K_PREFIX, K_TRACE, K_LISTS, K_BARCODE, K_COLLAPSE, K_EMIT, K_COUNT };
-const char* const kKernelNames[K_COUNT] = {"k_flank_scan", "k_scan_*", "k_flank_trace", "k_hit_lists",
-                                           "k_barcode",    "k_collapse", "k_emit"};
-
-struct HostGroup {
-    std::vector<std::string> seqs;
-    std::string flank;
-    std::vector<std::string> pat[2];
-    bb_group_info info;
-    uint8_t type;
-};
 
 // barcodes.rs:394-441
 uint8_t rc_char(uint8_t c) {
@@ -136,115 +124,6 @@ struct Blob {
     }
 };
 
-}  // namespace
-
-struct bb_ctx {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    // k_barcode_lane's waves all take the same time, so a launch ends with a round of waves that fills a fraction of the GPU (13.3 rounds
-    // for the forward hits of a 2 M-read batch: 5 % of the kernel).  The rc hits' launch goes to a second stream and fills that tail.
-    hipStream_t side = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    bool use_side = false;       // between fork and join of a barcode pass
-    // Per (group, strand): k_barcode_lane's walk-free bound decides as often as the traced one while the shared rows match (they are the
-    // flank the hit was found with) — on text where they do not, more hits go on to the exact kernel.  Each batch's undecided fraction
-    // is read back with the row count; above BARBELL_AMD_LANE_FB_FRAC (0.2) the pair takes k_barcode_pfx for the next 32 batches.
-    uint8_t lane_off[BB_MAX_GROUPS][2]{};   // batches left on k_barcode_pfx
-    uint8_t lane_used[BB_MAX_GROUPS][2]{};  // this batch: the pair ran k_barcode_lane
-    double lane_fb_frac = 0.2;
-    uint64_t last_listed[BB_MAX_GROUPS][2]{}, last_undecided[BB_MAX_GROUPS][2]{};  // of the last batch (bb_last_barcode_stats)
-    uint32_t pfx_fast_launches = 0;  // per batch: fast k_barcode_pfx launches (their records need k_rows; k_barcode_lane decides in its final trip)
-    bool lazy_prefix = false;    // this batch: every split (group, strand) takes k_barcode_lane, prefix records only for the hits that go on to the exact kernel
-    bb_params params{};
-    bb_policy policy{};          // include/barbell_amd_policy.h: the switchable assumptions about sassy / cigar-lodhi-rs
-    bool generic_barcode = false;  // the policy asks for what only the any-policy barcode kernel (k_barcode) computes
-    std::vector<HostGroup> groups;
-    std::vector<bb_group_dev> gdev;
-    bb_group_dev* d_groups = nullptr;
-    uint8_t* d_tables = nullptr;
-    uint32_t counts_len = 0;
-    unsigned long long* d_counts = nullptr;
-    // work buffers
-    uint64_t cap_m = 0;  // entries of cnt/base (n*G*2+1)
-    uint32_t cap_reads = 0, cap_hits = 0;
-    uint32_t *d_cnt = nullptr, *d_base = nullptr, *d_sums = nullptr, *d_nrows = nullptr, *d_rowoff = nullptr;
-    uint32_t *d_hitcount = nullptr, *d_lists = nullptr, *d_listcnt = nullptr;
-    uint32_t *d_fb_lists = nullptr, *d_fbcnt = nullptr;  // hits the fast barcode kernel's bounds left undecided, per (group, strand)
-    uint32_t* d_vqueue = nullptr;  // k_flank_verify's item counters (one per strand)
-    unsigned long long* d_nflag = nullptr;  // flagged 16-byte pieces of the batch in hand, per group (k_flank_filter)
-    double adapt_frac = 0.13;    // BARBELL_AMD_ADAPT_FRAC: flagged fraction of a batch's pieces above which the full scan takes over
-    uint64_t last_flagged[BB_MAX_GROUPS]{}, last_pieces[BB_MAX_GROUPS]{};
-    uint8_t last_scan_kind[BB_MAX_GROUPS]{};  // 0 full scan, 1 filter + verification, 2 filter, then the full scan (too many flags)
-    uint32_t* d_flags = nullptr; uint64_t cap_flags = 0;  // filtered scan: one bit per 32 text bytes and strand (k_flank_filter)
-    int scan_filter = -1;        // BARBELL_AMD_SCAN_FILTER: 0 never, 1 wherever it is valid (tests), unset: where the prefix says enough
-    bool fast_path = true;       // BARBELL_AMD_NO_FAST=1: score every barcode of every hit exactly (the fallback kernel only)
-    double fast_margin = 1e-9;   // BARBELL_AMD_FAST_MARGIN: slack of the bound test in k_rows (tests: a huge value sends every hit to the fallback)
-    bb_hit_raw* d_raw = nullptr;
-    bb_hit* d_hits = nullptr;
-    bb_hit_pfx* d_pfx = nullptr;  // shared-prefix records of the hits (groups with pfx > 0)
-    bb_rowtmp* d_rows = nullptr;
-    // staging for the host-pointer variant
-    uint8_t* d_in_bases = nullptr; uint64_t cap_in_bases = 0;
-    uint64_t* d_in_offsets = nullptr; uint64_t cap_in_offsets = 0;
-    bb_row* d_out_rows = nullptr; uint64_t cap_out_rows = 0;
-    // filter step
-    bb_pat_dev* d_fpats = nullptr;
-    bb_pat_elem_dev* d_felems = nullptr;
-    uint8_t* d_flabel_ok = nullptr;
-    uint32_t* d_flabel_ids = nullptr;
-    uint32_t n_fpats = 0;
-    bb_row* d_frows = nullptr; uint64_t cap_frows = 0;
-    bb_row_verdict* d_fout = nullptr; uint64_t cap_fout = 0;
-    bb_inspect_elem* d_iout = nullptr; uint64_t cap_iout = 0;
-    // trim step, owned by bb_trim.hip
-    bb_trim_state* trim = nullptr;
-    // FASTQ ingest, owned by bb_fastq.hip
-    bb_fastq_state* fastq = nullptr;
-    // TSV renderer, owned by bb_format.hip
-    bb_format_state* format = nullptr;
-    // synth
-    uint8_t* d_synth_table = nullptr;
-    bb_synth_params synth{};
-    // timing
-    bool timing = false;
-    bool use_lists = false;  // per-(group, strand class) hit lists in use for the current batch
-    int n_cus = 256;
-    uint32_t reg_blocks_mult = 1;  // BARBELL_AMD_REG_BLOCKS: persistent blocks per resident slot (tuning knob)
-    uint32_t reg_threads = 512;  // BARBELL_AMD_REG_THREADS: block size of k_barcode_reg (tuning knob)
-    uint32_t pfx_threads = 0;    // BARBELL_AMD_PFX_THREADS: block size of k_barcode_pfx (0 = as many lanes as fit a CU)
-    int lane_kernel = 1;         // BARBELL_AMD_LANE: 1 = the fast barcode stage with one lane per hit (k_barcode_lane) for groups whose flank budget is small
-                                 // (its bound assumes the shared rows match, which they do when the flank was found with few edits: at k = 20 eight times
-                                 // as many hits go on to the exact kernel), 0 = one lane per (hit, barcode) everywhere (k_barcode_pfx), 2 = one lane per hit everywhere
-    bool force_generic = false;  // BARBELL_AMD_GENERIC=1: use the generic (any-geometry) kernels, for tests
-    hipEvent_t ev[K_COUNT + 1]{};
-    float ms[K_COUNT]{};
-    std::string last_error;
-};
-
-namespace {
-
-#define HIPCHK(ctx, call)                                                                        \
-    do {                                                                                         \
-        hipError_t e_ = (call);                                                                  \
-        if (e_ != hipSuccess) {                                                                  \
-            (ctx)->last_error = std::string(#call) + ": " + hipGetErrorString(e_);               \
-            return BB_E_HIP;                                                                     \
-        }                                                                                        \
-    } while (0)
-
-#define BB_LDS_MAX (144 * 1024)  // dynamic LDS a block may ask for (160 KB per CU on gfx950, some of it static)
-
-template <typename T>
-int grow(bb_ctx* c, T*& p, uint64_t& cap, uint64_t need) {
-    if (need <= cap && p) return BB_OK;
-    if (p) HIPCHK(c, hipFree(p));
-    p = nullptr;
-    uint64_t ncap = need + need / 4 + 64;
-    HIPCHK(c, hipMalloc((void**)&p, ncap * sizeof(T)));
-    cap = ncap;
-    return BB_OK;
-}
-
 void build_synth_tables(const std::vector<std::vector<std::string>>& seqs, bb_synth_params& P, std::vector<uint8_t>& table) {
     P.n_groups = (uint32_t)seqs.size();
     table.clear();
@@ -276,7 +155,7 @@ int upload_tables(bb_ctx* c) {
         D.pol_lm = pol.lm_rule; D.pol_rc_fwd = pol.rc_order == BB_RC_FWD_ORDER; D.pol_tie_last = pol.bar_tie == BB_TIE_LAST;
         D.pol_prio = pol.trace_prio[0] | (pol.trace_prio[1] << 2) | (pol.trace_prio[2] << 4) | (pol.trace_prio[3] << 6);
         D.pol_lodhi_exp = pol.lodhi_exp[0] | (pol.lodhi_exp[1] << 8) | (pol.lodhi_exp[2] << 16) | (pol.lodhi_exp[3] << 24);
-        D.pol_lodhi_p = pol.lodhi_p; D.pol_lambda = pol.lodhi_lambda;
+        D.pol_lodhi_p = pol.lodhi_p; D.pol_lambda = pol.lodhi_lambda; D.pol_rc_mirror = pol.rc_path == BB_RCPATH_MIRROR;
         count_off += (uint32_t)N + 1;
         for (int s = 0; s < 2; ++s) {
             D.off_peq_flank[s] = blob.alloc((size_t)256 * S * 4);
@@ -502,249 +381,6 @@ int ensure_hits(bb_ctx* c, uint64_t need) {
     return BB_OK;
 }
 
-int scan_u32(bb_ctx* c, const uint32_t* in, uint32_t* out, uint64_t n) {
-    const uint32_t nb = (uint32_t)((n + 2047) / 2048);
-    hipLaunchKernelGGL(k_scan_block, dim3(nb), dim3(256), 0, c->stream, in, out, n, c->d_sums);
-    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(64), 0, c->stream, c->d_sums, nb);
-    hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(256), 0, c->stream, out, n, (const uint32_t*)c->d_sums);
-    HIPCHK(c, hipGetLastError());
-    return BB_OK;
-}
-
-template <int W>
-void launch_scan(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n, uint32_t g, uint64_t flag_words, uint64_t batch_bytes) {
-    c->last_scan_kind[g] = 0; c->last_flagged[g] = 0; c->last_pieces[g] = 2 * ((batch_bytes + 15) / 16);
-    if (c->gdev[g].filt_rows > 0) {
-        (void)hipMemsetAsync(c->d_flags, 0, (size_t)2 * flag_words * sizeof(uint32_t), c->stream);  // the filter writes the words that hold a flag
-        (void)hipMemsetAsync(c->d_nflag + g, 0, sizeof(unsigned long long), c->stream);
-        if (c->gdev[g].filt_mode & BB_FILT_WIDE)
-            hipLaunchKernelGGL(k_flank_filter<true>, dim3((n + 255) / 256), dim3(256), 0, c->stream, d_bases, d_offsets, n, (const uint8_t*)c->d_tables,
-                               (const bb_group_dev*)c->d_groups, g, c->d_flags, flag_words, c->d_nflag + g);
-        else
-            hipLaunchKernelGGL(k_flank_filter<false>, dim3((n + 255) / 256), dim3(256), 0, c->stream, d_bases, d_offsets, n, (const uint8_t*)c->d_tables,
-                               (const bb_group_dev*)c->d_groups, g, c->d_flags, flag_words, c->d_nflag + g);
-        // The choice made at bb_create on pseudo-random text is re-made on the batch in hand: the verification's cost grows with
-        // the number of flagged pieces (each costs its columns plus m + k of lead-in; low-complexity text, adapter-like decoys
-        // and chimeric reads flag many), the full scan's does not.  Above the break-even (measured: DESIGN.md §4) the flags are
-        // dropped and the full-height streaming scan does the batch.
-        unsigned long long nf = 0;
-        (void)hipMemcpyAsync(&nf, c->d_nflag + g, sizeof(nf), hipMemcpyDeviceToHost, c->stream);
-        (void)hipStreamSynchronize(c->stream);
-        c->last_flagged[g] = nf; c->last_scan_kind[g] = 1;
-        if (c->scan_filter != 1 && (double)nf > c->adapt_frac * (double)c->last_pieces[g]) {
-            c->last_scan_kind[g] = 2;
-            hipLaunchKernelGGL(k_flank_scan2<W>, dim3((n + 255) / 256, 2), dim3(256), 0, c->stream, d_bases, d_offsets, n,
-                               (const uint8_t*)c->d_tables, (const bb_group_dev*)c->d_groups, g, (uint32_t)c->groups.size(), c->d_cnt,
-                               c->d_raw, c->cap_hits, c->d_hitcount);
-            return;
-        }
-        (void)hipMemsetAsync(c->d_vqueue, 0, 2 * sizeof(uint32_t), c->stream);
-        const uint32_t vblocks = std::min((n + 255u) / 256u, (uint32_t)c->n_cus * 3u);  // persistent: lanes draw (read, strand) items from a queue
-        hipLaunchKernelGGL(k_flank_verify<W>, dim3(vblocks, 2), dim3(256), 0, c->stream, d_bases, d_offsets, n,
-                           (const uint8_t*)c->d_tables, (const bb_group_dev*)c->d_groups, g, (uint32_t)c->groups.size(),
-                           (const uint32_t*)c->d_flags, flag_words, c->d_cnt, c->d_raw, c->cap_hits, c->d_hitcount, c->d_vqueue);
-        return;
-    }
-    hipLaunchKernelGGL(k_flank_scan2<W>, dim3((n + 255) / 256, 2), dim3(256), 0, c->stream, d_bases, d_offsets, n,
-                       (const uint8_t*)c->d_tables, (const bb_group_dev*)c->d_groups, g, (uint32_t)c->groups.size(), c->d_cnt,
-                       c->d_raw, c->cap_hits, c->d_hitcount);
-}
-// Which variant of k_flank_trace a group takes (bb_kernels.h): 4 = 8-row band in LDS (k <= 3), 2 = 16-row band in LDS (k <= 6), 1 = every row in LDS,
-// 3 = checkpointed columns, 0 = private memory.
-static int trace_mode(const bb_ctx* c, uint32_t g) {
-    const bb_group_dev& D = c->gdev[g];
-    const int W = D.W;
-    const size_t lds = (size_t)(D.m + D.flank_k + 2) * 2 * W * 64 * 4;  // columns 0..m+k, lo+hi, W words, 64 lanes
-    const size_t lds_ck = (size_t)(((D.m + D.flank_k) / BB_TRACE_CKB + 1) * 2 * W + BB_TRACE_CKB * 2 * W) * 64 * 4;
-    const size_t lds_band = (size_t)(D.m + D.flank_k + 2) * 64 * 4;
-    if (D.flank_k <= 3 && lds_band <= 64 * 1024 && !c->force_generic && !getenv("BARBELL_AMD_TRACE_FULL") && !getenv("BARBELL_AMD_TRACE_BAND16")) return 4;  // 2(k+1) <= 8 rows in 8 bits
-    if (D.flank_k <= 6 && lds_band <= 64 * 1024 && !c->force_generic && !getenv("BARBELL_AMD_TRACE_FULL")) return 2;  // band of 2(k+1)+1 <= 15 rows in 16 bits
-    if (W <= 4 && lds <= 64 * 1024 && !c->force_generic) return 1;
-    if (lds_ck <= 64 * 1024 && !c->force_generic && !getenv("BARBELL_AMD_TRACE_NOCKPT")) return 3;
-    return 0;
-}
-// One launch for every group of the same width and variant (the raw hits of all groups share one array: a launch per
-// group walks it once per group with the other groups' lanes idle).
-template <int W>
-void launch_trace(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n_hits, uint32_t gmask, int mode) {
-    const size_t lds_rec = (size_t)64 * BB_TRACE_REC_STRIDE * 4;  // the staged hit records share the move bits' LDS
-    size_t lds = lds_rec;
-    int mk_max = 0;
-    for (uint32_t g = 0; g < c->groups.size(); ++g) {
-        if (!((gmask >> g) & 1u)) continue;
-        const bb_group_dev& D = c->gdev[g];
-        const int mk = D.m + D.flank_k;
-        mk_max = std::max(mk_max, mk);
-        const size_t need = mode == 4 ? (size_t)(mk + 2) * 64 * 2                                   // 16 bits per column and lane
-                          : mode == 2 ? (size_t)(mk + 2) * 64 * 4                                   // one word per column and lane
-                          : mode == 1 ? (size_t)(mk + 2) * 2 * W * 64 * 4                            // columns 0..m+k, lo+hi, W words
-                          : mode == 3 ? (size_t)((mk / BB_TRACE_CKB + 1) * 2 * W + BB_TRACE_CKB * 2 * W) * 64 * 4  // checkpoints + one block's move bits
-                          : 0;
-        lds = std::max(lds, need);
-    }
-#define BB_TRACE_ARGS d_bases, d_offsets, (const uint8_t*)c->d_tables, (const bb_group_dev*)c->d_groups, (uint32_t)c->groups.size(), \
-                      (const bb_hit_raw*)c->d_raw, n_hits, (const uint32_t*)c->d_base, c->d_hits, gmask, mk_max
-    if (mode == 4) hipLaunchKernelGGL((k_flank_trace<W, 4>), dim3((n_hits + 63) / 64), dim3(64), lds, c->stream, BB_TRACE_ARGS);
-    else if (mode == 2) hipLaunchKernelGGL((k_flank_trace<W, 2>), dim3((n_hits + 63) / 64), dim3(64), lds, c->stream, BB_TRACE_ARGS);
-    else if (mode == 1) {
-        if constexpr (W <= 4)  // the full-height LDS variant never fits beyond 4 words
-            hipLaunchKernelGGL((k_flank_trace<W, 1>), dim3((n_hits + 63) / 64), dim3(64), lds, c->stream, BB_TRACE_ARGS);
-    } else if (mode == 3) hipLaunchKernelGGL((k_flank_trace<W, 3>), dim3((n_hits + 63) / 64), dim3(64), lds, c->stream, BB_TRACE_ARGS);
-    else hipLaunchKernelGGL((k_flank_trace<W, 0>), dim3((n_hits + 63) / 64), dim3(64), lds, c->stream, BB_TRACE_ARGS);
-#undef BB_TRACE_ARGS
-}
-template <int WB, int CW>
-void launch_barcode_reg(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n_hits, uint32_t g, const uint32_t* list, const uint32_t* cnt) {
-    const bb_group_dev& D = c->gdev[g];
-    const uint32_t N = (uint32_t)D.n_seqs;
-    const uint32_t hpb = c->reg_threads / N;
-    const uint32_t threads = ((hpb * N + 63) / 64) * 64;
-    const size_t smem = (size_t)2 * 16 * N * WB * 4 + (size_t)hpb * 24 + (size_t)hpb * sizeof(bb_hit) + 16;
-    const uint32_t n_iter = (n_hits + hpb - 1) / hpb;
-    // persistent blocks: the Peq table is loaded once per block and the next hit records are prefetched
-    const uint32_t resident = (uint32_t)c->n_cus * (threads > 256 ? 1u : 2u) * c->reg_blocks_mult;
-    const uint32_t blocks = n_iter < resident ? n_iter : resident;
-    (void)d_bases; (void)d_offsets;
-    hipLaunchKernelGGL((k_barcode_reg<WB, CW>), dim3(blocks), dim3(threads), smem, c->stream,
-                       (const uint8_t*)c->d_tables, (const bb_group_dev*)c->d_groups, g, (const bb_hit*)c->d_hits, list,
-                       cnt, n_hits, hpb, c->params.min_score, c->params.min_score_diff, c->d_rows);
-}
-
-// pass 0 of a split (group, strand): k_barcode_lane (which computes the shared rows itself) or k_barcode_pfx (which reads k_bar_prefix's records)
-static bool takes_lane(const bb_ctx* c, uint32_t g, uint32_t strand) {
-    const bb_group_dev& D = c->gdev[g];
-    return c->fast_path && D.pfx[strand] <= 16 &&
-           (c->lane_kernel == 2 || (c->lane_kernel == 1 && c->groups[g].info.flank_k <= BB_LANE_MAX_FLANK_K && c->lane_off[g][strand] == 0));
-}
-template <int CW>
-void launch_barcode_pfx(bb_ctx* c, uint32_t n_hits, uint32_t g, uint32_t strand, const uint32_t* list, const uint32_t* cnt, bool fast) {
-    const bb_group_dev& D = c->gdev[g];
-    const uint32_t N = (uint32_t)D.n_seqs;
-    {
-        if (fast && takes_lane(c, g, strand)) {
-            const uint32_t T = (uint32_t)D.tail[strand];
-            const size_t smem = (((size_t)N * 64 + 31) & ~(size_t)31) + 256 * 32 + 16 + (size_t)T * 2 * 256 * 8;
-            const uint32_t blocks = (n_hits + 255) / 256;
-            hipStream_t st = (c->use_side && strand == 1) ? c->side : c->stream;
-#define BB_LANE_LAUNCH(TAIL_)                                                                                                                     \
-    do {                                                                                                                                          \
-        if (smem > 64 * 1024)                                                                                                                     \
-            (void)hipFuncSetAttribute((const void*)k_barcode_lane<CW, TAIL_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);            \
-        hipLaunchKernelGGL((k_barcode_lane<CW, TAIL_>), dim3(blocks), dim3(256), smem, st, (const uint8_t*)c->d_tables,                           \
-                           (const bb_group_dev*)c->d_groups, g, strand, (const bb_hit*)c->d_hits, list, cnt, n_hits,                             \
-                           c->d_rows, c->params.min_score, c->params.min_score_diff, c->fast_margin, c->d_fb_lists, c->cap_hits, c->d_fbcnt);     \
-    } while (0)
-            if (T > 0) BB_LANE_LAUNCH(true); else BB_LANE_LAUNCH(false);
-#undef BB_LANE_LAUNCH
-            c->lane_used[g][strand] = 1;
-            return;
-        }
-    }
-    if (fast) ++c->pfx_fast_launches;  // these leave records for k_rows
-    // CW = 48 fits 168 VGPRs -> 3 waves per SIMD: 768-thread blocks (8 hits x 96 barcodes use every lane); measured
-    // 22.8 vs 26.8 ms against 512-thread blocks at 2 waves per SIMD
-    uint32_t tmax = CW <= 48 ? 768u : 512u;
-    if (c->pfx_threads && c->pfx_threads <= tmax) tmax = c->pfx_threads;  // BARBELL_AMD_PFX_THREADS (tuning knob)
-    uint32_t hpb = std::max(1u, tmax / N);
-    uint32_t threads = ((hpb * N + 63) / 64) * 64;
-    // two halves of everything a set of hpb hits owns (records, reduction cells, per-column tables) + Peq + trailing-row planes
-    auto smem_for = [&](uint32_t h, uint32_t t) {
-        return (size_t)2 * h * 40 + 16 + (size_t)2 * h * (sizeof(bb_hit) + sizeof(bb_hit_pfx)) + (size_t)2 * h * CW * 24 + (size_t)16 * N * 4 +
-               (size_t)D.tail[strand] * 2 * t * 8 + 64 + (fast ? 256 * 32 + 32 : 0);
-    };
-    // groups of few barcodes put many hits into a block: fewer of them when the block's LDS would not fit (the per-hit
-    // share is ~3.6 KB; 64 KB is what a launch gets without asking, BB_LDS_MAX what the CU has to give)
-    while (hpb > 1 && smem_for(hpb, threads) > BB_LDS_MAX) { --hpb; threads = ((hpb * N + 63) / 64) * 64; }
-    const size_t smem = smem_for(hpb, threads);
-    const uint32_t n_iter = (n_hits + hpb - 1) / hpb;
-    const uint32_t per_cu = std::max(1u, (CW <= 48 ? 768u : 512u) / threads);  // blocks that fit a CU at this kernel's register count
-    const uint32_t resident = (uint32_t)c->n_cus * per_cu * c->reg_blocks_mult;
-    const uint32_t blocks = n_iter < resident ? n_iter : resident;
-#define BB_PFX_ARGS (const uint8_t*)c->d_tables, (const bb_group_dev*)c->d_groups, g, strand, (const bb_hit*)c->d_hits, (const bb_hit_pfx*)c->d_pfx, list, \
-                    cnt, n_hits, hpb, c->params.min_score, c->params.min_score_diff, c->d_rows
-#define BB_PFX_LAUNCH4(TAIL_, FAST_, DEF_)                                                                                   \
-    do {                                                                                                                    \
-        if (smem > 64 * 1024)                                                                                               \
-            (void)hipFuncSetAttribute((const void*)k_barcode_pfx<CW, TAIL_, FAST_, DEF_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
-        hipLaunchKernelGGL((k_barcode_pfx<CW, TAIL_, FAST_, DEF_>), dim3(blocks), dim3(threads), smem, (c->use_side && strand == 1) ? c->side : c->stream, BB_PFX_ARGS);   \
-    } while (0)
-#define BB_PFX_LAUNCH(TAIL_, FAST_) BB_PFX_LAUNCH4(TAIL_, FAST_, false)
-    const bool defpol = CW == 48 && fast && c->policy.lm_rule == BB_LM_PLATEAU_RIGHT && c->policy.bar_tie == BB_TIE_FIRST;
-    if (D.tail[strand] > 0) {
-        if (defpol) { if constexpr (CW == 48) BB_PFX_LAUNCH4(true, true, true); }
-        else if (fast) BB_PFX_LAUNCH(true, true);
-        else BB_PFX_LAUNCH(true, false);
-    } else {
-        if (defpol) { if constexpr (CW == 48) BB_PFX_LAUNCH4(false, true, true); }
-        else if (fast) BB_PFX_LAUNCH(false, true);
-        else BB_PFX_LAUNCH(false, false);
-    }
-#undef BB_PFX_LAUNCH4
-#undef BB_PFX_LAUNCH
-#undef BB_PFX_ARGS
-}
-
-// Barcode stage of one query group: the hits of each strand and window class come from their own list (k_hit_lists,
-// slot 4g + 2 wide + strand): windows of at most 48 columns run the 48-column instantiations whatever the widest
-// possible window of the group is.
-// The kernels index list_cnt with g; handing them list_cnt + (slot - g) makes that the slot's counter.
-// pass 0: every hit of the group — split strands through the fast kernel when enabled (bounds + k_rows), the others
-// through the exact kernels; pass 1 (after k_rows): the exact split kernel on the hits the bounds left undecided.
-template <int WB>
-void launch_barcode(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n_hits, uint32_t g, int pass) {
-    const bb_group_dev& D = c->gdev[g];
-    const bb_group_info& I = c->groups[g].info;
-    const uint32_t N = (uint32_t)D.n_seqs;
-    // widest barcode window the flank traceback can produce: (mask_len - 1 + flank_k) + 2*PADDING
-    const uint32_t win_max = I.mask_len + (uint32_t)I.flank_k + 2 * BB_PADDING - 1;
-    const size_t peq_bytes = (size_t)2 * 16 * N * WB * 4;
-    const bool reg_ok = !c->force_generic && !c->generic_barcode && D.m_bar <= 48 && N <= c->reg_threads && peq_bytes <= 48 * 1024 && win_max <= 63;
-    for (uint32_t sw = 0; sw < 4; ++sw) {
-        const uint32_t strand = sw & 1u, wide = sw >> 1;
-        if (wide && win_max <= 48) continue;  // no such hits
-        const uint32_t slot = 4 * g + sw;
-        const uint32_t* list = c->d_lists + (size_t)slot * c->cap_hits;
-        const uint32_t* cnt = c->d_listcnt + slot - g;  // the kernels index list_cnt with g
-        if constexpr (WB == 2) {
-            if (!c->force_generic && !c->generic_barcode && D.split[strand] && win_max <= 63) {  // one word per barcode lane (end positions 0..wn live in a 64-bit mask: wn <= 63)
-                if (pass == 1) {
-                    if (!c->fast_path) continue;
-                    list = c->d_fb_lists + (size_t)slot * c->cap_hits;
-                    cnt = c->d_fbcnt + slot - g;
-                    if (c->lazy_prefix)  // no k_bar_prefix has run over all hits: the records of the undecided ones, now
-                        hipLaunchKernelGGL(k_bar_prefix_list, dim3(256), dim3(128), 0, (c->use_side && strand == 1) ? c->side : c->stream, (const uint8_t*)c->d_tables,
-                                           (const bb_group_dev*)c->d_groups, (const bb_hit*)c->d_hits, list, c->d_fbcnt + slot, c->d_pfx);
-                }
-                const bool fast = pass == 0 && c->fast_path;
-                if (!wide) launch_barcode_pfx<48>(c, n_hits, g, strand, list, cnt, fast);
-                else launch_barcode_pfx<64>(c, n_hits, g, strand, list, cnt, fast);
-                continue;
-            }
-        }
-        if (pass == 1) continue;
-        if constexpr (WB <= 2) {
-            if (reg_ok) {
-                if (!wide) launch_barcode_reg<WB, 48>(c, d_bases, d_offsets, n_hits, g, list, cnt);
-                else launch_barcode_reg<WB, 64>(c, d_bases, d_offsets, n_hits, g, list, cnt);
-                continue;
-            }
-        }
-        const uint32_t hpb = N >= 256 ? 1 : 256 / N;
-        const uint32_t threads = ((hpb * N + 63) / 64) * 64;
-        const bool lds = peq_bytes <= 48 * 1024;
-        const size_t smem = (lds ? peq_bytes : 0) + (size_t)hpb * N * 8 + (size_t)hpb * 16 + (size_t)hpb * BB_MAX_WIN;
-        const uint32_t blocks = (n_hits + hpb - 1) / hpb;
-        if (lds)
-            hipLaunchKernelGGL((k_barcode<WB, true>), dim3(blocks), dim3(threads), smem, c->stream, d_bases, d_offsets,
-                               (const uint8_t*)c->d_tables, (const bb_group_dev*)c->d_groups, g, (const bb_hit*)c->d_hits, list, cnt, n_hits, hpb,
-                               c->params.min_score, c->params.min_score_diff, c->d_rows);
-        else
-            hipLaunchKernelGGL((k_barcode<WB, false>), dim3(blocks), dim3(threads), smem, c->stream, d_bases, d_offsets,
-                               (const uint8_t*)c->d_tables, (const bb_group_dev*)c->d_groups, g, (const bb_hit*)c->d_hits, list, cnt, n_hits, hpb,
-                               c->params.min_score, c->params.min_score_diff, c->d_rows);
-    }
-}
-
 void mark(bb_ctx* c, int i) {
     if (c->timing) (void)hipEventRecord(c->ev[i], c->stream);
 }
@@ -793,11 +429,12 @@ int bb_create_policy(const bb_group_desc* groups, uint32_t n_groups, const bb_pa
     bb_ctx* c = new bb_ctx();
     c->params = *params;
     if (policy) c->policy = *policy; else bb_policy_default(&c->policy);
-    // The register-resident barcode kernels hard-wire the default traceback preference (two v_bitop3 truth tables) and
-    // Lodhi(3, 1/2) (exact power-of-two scaling); their local-minimum rule, tie rule and decay exponents are run-time.
-    // Anything else runs the any-policy kernel k_barcode.  The fast path's score bound counts one column per text op: an
-    // upper bound only while no text op's exponent is 0.
-    c->generic_barcode = !bb_policy_trace_is_default(&c->policy) || c->policy.lodhi_p != 3 || c->policy.lodhi_lambda != 0.5;
+    // The register-resident barcode kernels hard-wire Lodhi(3, 1/2) (exact power-of-two scaling: searcher.rs:209 pins both); their
+    // traceback preference is a compile-time class (18 of them, one set of fast kernels each: bb_prio.h, bb_tu_class.hip), their
+    // local-minimum rule, tie rule and decay exponents are run-time.  Another p or lambda runs the any-policy kernel k_barcode.
+    // The fast path's score bound counts one column per text op: an upper bound only while no text op's exponent is 0.
+    c->generic_barcode = c->policy.lodhi_p != 3 || c->policy.lodhi_lambda != 0.5;
+    c->prio_class = bb_prio_class(BB_PRIO_PACK(c->policy.trace_prio[0], c->policy.trace_prio[1], c->policy.trace_prio[2], c->policy.trace_prio[3]));
     if (c->policy.lodhi_exp[BB_OP_MATCH] == 0 || c->policy.lodhi_exp[BB_OP_SUB] == 0 || c->policy.lodhi_exp[BB_OP_INS] == 0) c->fast_path = false;
     c->force_generic = getenv("BARBELL_AMD_GENERIC") && atoi(getenv("BARBELL_AMD_GENERIC")) != 0;
     if (getenv("BARBELL_AMD_SCAN_FILTER")) c->scan_filter = atoi(getenv("BARBELL_AMD_SCAN_FILTER")) != 0 ? 1 : 0;
@@ -922,16 +559,7 @@ int bb_annotate_batch_dev(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_o
         HIPCHK(c, hipMemsetAsync(c->d_hitcount, 0, 16, c->stream));
         HIPCHK(c, hipMemsetAsync(c->d_cnt + (M - 1), 0, 4, c->stream));
         for (uint32_t g = 0; g < G; ++g) {
-            switch (c->gdev[g].W) {
-                case 1: launch_scan<1>(c, d_bases, d_offsets, n, g, flag_words, batch_bytes); break;
-                case 2: launch_scan<2>(c, d_bases, d_offsets, n, g, flag_words, batch_bytes); break;
-                case 3: launch_scan<3>(c, d_bases, d_offsets, n, g, flag_words, batch_bytes); break;
-                case 4: launch_scan<4>(c, d_bases, d_offsets, n, g, flag_words, batch_bytes); break;
-                case 5: launch_scan<5>(c, d_bases, d_offsets, n, g, flag_words, batch_bytes); break;
-                case 6: launch_scan<6>(c, d_bases, d_offsets, n, g, flag_words, batch_bytes); break;
-                case 7: launch_scan<7>(c, d_bases, d_offsets, n, g, flag_words, batch_bytes); break;
-                default: launch_scan<8>(c, d_bases, d_offsets, n, g, flag_words, batch_bytes); break;
-            }
+            bb_launch_scan(c, d_bases, d_offsets, n, g, flag_words, batch_bytes);
         }
         HIPCHK(c, hipGetLastError());
         mark(c, K_PREFIX);
@@ -941,27 +569,18 @@ int bb_annotate_batch_dev(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_o
         if (attempt > 2) { c->last_error = "flank hit buffer overflow"; return BB_E_HIP; }
         if ((r = ensure_hits(c, (uint64_t)n_hits + 1024))) return r;
     }
-    if ((r = scan_u32(c, c->d_cnt, c->d_base, M))) return r;
+    if ((r = bb_scan_u32(c, c->d_cnt, c->d_base, M))) return r;
     mark(c, K_TRACE);
     if (n_hits) {
         uint32_t done = 0;
         for (uint32_t g = 0; g < G; ++g) {
             if ((done >> g) & 1u) continue;
-            const int W = c->gdev[g].W, mode = trace_mode(c, g);
+            const int W = c->gdev[g].W, mode = bb_trace_mode(c, g);
             uint32_t gmask = 0;
             for (uint32_t g2 = g; g2 < G; ++g2)
-                if (c->gdev[g2].W == W && trace_mode(c, g2) == mode) gmask |= 1u << g2;
+                if (c->gdev[g2].W == W && bb_trace_mode(c, g2) == mode) gmask |= 1u << g2;
             done |= gmask;
-            switch (W) {
-                case 1: launch_trace<1>(c, d_bases, d_offsets, n_hits, gmask, mode); break;
-                case 2: launch_trace<2>(c, d_bases, d_offsets, n_hits, gmask, mode); break;
-                case 3: launch_trace<3>(c, d_bases, d_offsets, n_hits, gmask, mode); break;
-                case 4: launch_trace<4>(c, d_bases, d_offsets, n_hits, gmask, mode); break;
-                case 5: launch_trace<5>(c, d_bases, d_offsets, n_hits, gmask, mode); break;
-                case 6: launch_trace<6>(c, d_bases, d_offsets, n_hits, gmask, mode); break;
-                case 7: launch_trace<7>(c, d_bases, d_offsets, n_hits, gmask, mode); break;
-                default: launch_trace<8>(c, d_bases, d_offsets, n_hits, gmask, mode); break;
-            }
+            bb_launch_trace(c, d_bases, d_offsets, n_hits, gmask, mode, W);
         }
         HIPCHK(c, hipGetLastError());
     }
@@ -973,15 +592,17 @@ int bb_annotate_batch_dev(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_o
     bool all_lane = any_split;
     for (uint32_t g = 0; g < G; ++g)
         for (uint32_t sd = 0; sd < 2; ++sd)
-            if (c->gdev[g].split[sd] && !(c->gdev[g].WB == 2 && !c->force_generic && !c->generic_barcode && takes_lane(c, g, sd) &&
-                                          c->groups[g].info.mask_len + (uint32_t)c->groups[g].info.flank_k + 2 * BB_PADDING - 1 <= 63)) all_lane = false;
+            if (c->gdev[g].split[sd]) {
+                const uint32_t win_max = c->groups[g].info.mask_len + (uint32_t)c->groups[g].info.flank_k + 2 * BB_PADDING - 1;
+                if (!(c->gdev[g].WB == 2 && !c->force_generic && !c->generic_barcode && bb_takes_lane(c, g, sd, false) && win_max <= 63 &&
+                      (win_max <= 48 || bb_takes_lane(c, g, sd, true)))) all_lane = false;
+            }
     c->lazy_prefix = all_lane && !getenv("BARBELL_AMD_FULL_PREFIX");
     if (c->lazy_prefix) any_split_prefix = false;
     const bool prefix_aside = n_hits && any_split_prefix && c->side != nullptr;  // k_bar_prefix needs the hits, not their lists: alongside k_hit_lists
     if (prefix_aside) {
         HIPCHK(c, hipEventRecord(c->ev_fork, c->stream)); HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_fork, 0));
-        hipLaunchKernelGGL(k_bar_prefix, dim3((n_hits + 127) / 128), dim3(128), 0, c->side, (const uint8_t*)c->d_tables,
-                           (const bb_group_dev*)c->d_groups, (const bb_hit*)c->d_hits, n_hits, c->d_pfx, G);
+        bb_launch_bar_prefix(c, n_hits, c->side);
         HIPCHK(c, hipEventRecord(c->ev_join, c->side));
     }
     if (n_hits) {
@@ -993,8 +614,7 @@ int bb_annotate_batch_dev(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_o
     if (prefix_aside) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
     if (n_hits) {
         if (any_split_prefix && !prefix_aside)  // shared rows of the padded barcodes, once per hit
-            hipLaunchKernelGGL(k_bar_prefix, dim3((n_hits + 127) / 128), dim3(128), 0, c->stream, (const uint8_t*)c->d_tables,
-                               (const bb_group_dev*)c->d_groups, (const bb_hit*)c->d_hits, n_hits, c->d_pfx, G);
+            bb_launch_bar_prefix(c, n_hits, c->stream);
         for (int pass = 0; pass < 2; ++pass) {
             if (pass == 1) {
                 if (!(any_split && c->fast_path)) break;
@@ -1010,12 +630,7 @@ int bb_annotate_batch_dev(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_o
             if (fork) { HIPCHK(c, hipEventRecord(c->ev_fork, c->stream)); HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_fork, 0)); }
             c->use_side = fork;
             for (uint32_t g = 0; g < G; ++g) {
-                switch (c->gdev[g].WB) {
-                    case 1: launch_barcode<1>(c, d_bases, d_offsets, n_hits, g, pass); break;
-                    case 2: launch_barcode<2>(c, d_bases, d_offsets, n_hits, g, pass); break;
-                    case 3: launch_barcode<3>(c, d_bases, d_offsets, n_hits, g, pass); break;
-                    default: launch_barcode<4>(c, d_bases, d_offsets, n_hits, g, pass); break;
-                }
+                bb_launch_barcode(c, d_bases, d_offsets, n_hits, g, pass);
             }
             c->use_side = false;
             if (fork) { HIPCHK(c, hipEventRecord(c->ev_join, c->side)); HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0)); }
@@ -1026,7 +641,7 @@ int bb_annotate_batch_dev(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_o
     hipLaunchKernelGGL(k_collapse, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->d_rows, (const uint32_t*)c->d_base, n, G,
                        c->d_nrows);
     HIPCHK(c, hipMemsetAsync(c->d_nrows + n, 0, 4, c->stream));
-    if ((r = scan_u32(c, c->d_nrows, c->d_rowoff, (uint64_t)n + 1))) return r;
+    if ((r = bb_scan_u32(c, c->d_nrows, c->d_rowoff, (uint64_t)n + 1))) return r;
     uint32_t total = 0;
     uint32_t h_listed[4 * BB_MAX_GROUPS], h_undecided[4 * BB_MAX_GROUPS];
     const bool fb_stats = n_hits && c->fast_path && c->lane_kernel == 1;
@@ -1214,7 +829,8 @@ int bb_last_barcode_stats(const bb_ctx* c, uint32_t g, uint32_t strand, uint64_t
     if (!c || g >= c->groups.size() || strand > 1) return BB_E_INVALID;
     if (hits) *hits = c->last_listed[g][strand];
     if (undecided) *undecided = c->last_undecided[g][strand];
-    if (lane_kernel) *lane_kernel = c->lane_kernel == 2 || (c->lane_kernel == 1 && c->groups[g].info.flank_k <= BB_LANE_MAX_FLANK_K && c->lane_off[g][strand] == 0);
+    // what the pair's next batch runs: the one-lane-per-hit kernel of the policy's traceback class, where the group is split and the class was built
+    if (lane_kernel) *lane_kernel = c->gdev[g].split[strand] && c->gdev[g].WB == 2 && !c->force_generic && !c->generic_barcode && bb_takes_lane(c, g, strand, false);
     return BB_OK;
 }
 

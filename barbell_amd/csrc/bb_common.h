@@ -1,9 +1,11 @@
 // bb_common.h — shared host/device definitions of the MI355X annotate hot path.
 // Everything here is first-party; nothing is shared with oracle/.
 #pragma once
+#include <stddef.h>
 #include <stdint.h>
 
 #include "../../include/barbell_amd.h"
+#include "../../include/barbell_amd_filter.h"
 #include "../../include/barbell_amd_policy.h"
 
 #if defined(__HIPCC__)
@@ -94,7 +96,7 @@ struct bb_group_dev {
     int32_t pol_tie_last;        // [H7] 1: the last of several equally cheap local minima of a barcode pattern
     int32_t pol_lodhi_exp;       // [H8] decay exponents, one byte per op (M, S, I, D); 0x01010101 by default
     int32_t pol_lodhi_p;         // [H8] subsequence length (the register-resident kernels: 3 only)
-    int32_t _pad2;
+    int32_t pol_rc_mirror;       // [H5] 1: path pattern indices of rc flank matches are mirrored (get_matching_region selects rows m-1-bar_hi .. m-1-bar_lo)
     double pol_lambda;           // [H8] (the register-resident kernels: 0.5 only)
 };
 #define BB_PRIO_DEFAULT (BB_OP_MATCH | (BB_OP_INS << 2) | (BB_OP_SUB << 4) | (BB_OP_DEL << 6))
@@ -141,3 +143,33 @@ struct __attribute__((aligned(16))) bb_hit {
     uint8_t win[64];                // filled when we - ws <= 64
 };
 static_assert(sizeof(bb_hit) == 96, "bb_hit: 32-byte header + 64 window codes");
+
+// ---- row slots of the barcode stage (one per flank hit) ----
+struct __attribute__((aligned(16))) bb_rowtmp {  // one per flank hit: the provisional row; row._pad[0] = 1 when the hit has a row
+    bb_row row;
+};
+static_assert(sizeof(bb_rowtmp) == 48, "bb_rowtmp is three 16-byte pieces");
+// What the fast barcode kernel leaves in a hit's row slot for k_rows: the traced path of the barcode with the highest
+// score BOUND (column planes, consumed rows) and the second-highest bound.  `marker` sits where bb_row keeps the
+// pipeline's row flag (_pad[0], byte 45): 0 = no row, 1 = row, 2 = this record.
+struct __attribute__((aligned(16))) bb_winrec {
+    unsigned long long plo, phi, diagrow;
+    double ub_second;
+    uint8_t tstart, best_pos;
+    uint16_t top;
+    uint8_t flags;
+    uint8_t _pad0[8];
+    uint8_t marker;
+    uint8_t _pad[2];
+};
+static_assert(sizeof(bb_winrec) == 48 && offsetof(bb_winrec, marker) == 45, "bb_winrec overlays bb_rowtmp");
+
+// ---- filter patterns on the device (k_filter; pattern.rs:96-240) ----
+struct bb_pat_elem_dev {
+    uint8_t match_type; int8_t orientation; uint8_t relative_to; uint8_t n_cuts;
+    int32_t placeholder;
+    int64_t lo, hi;
+    uint32_t label_off;  // byte offset into the label_ok blob, 0xFFFFFFFF = any label
+    bb_cut cuts[BB_MAX_CUTS];
+};
+struct bb_pat_dev { uint32_t first, n; };

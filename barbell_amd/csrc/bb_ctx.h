@@ -1,0 +1,134 @@
+// bb_ctx.h — the context behind the C ABI's opaque bb_ctx, shared by the translation units that launch kernels on it
+// (barbell_amd.hip: the batch pipeline; bb_tu_scan.hip, bb_tu_trace.hip, bb_tu_bar.hip, bb_tu_class.hip: one stage each).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/barbell_amd.h"
+#include "../../include/barbell_amd_filter.h"
+#include "../../include/barbell_amd_inspect.h"
+#include "../../include/barbell_amd_synth.h"
+#include "bb_common.h"
+#include "bb_ctx_view.h"
+#include "bb_synth.h"
+
+enum { K_SCAN = 0, K_PREFIX, K_TRACE, K_LISTS, K_BARCODE, K_COLLAPSE, K_EMIT, K_COUNT };
+static const char* const kKernelNames[K_COUNT] = {"k_flank_scan", "k_scan_*", "k_flank_trace", "k_hit_lists",
+                                           "k_barcode",    "k_collapse", "k_emit"};
+
+struct HostGroup {
+    std::vector<std::string> seqs;
+    std::string flank;
+    std::vector<std::string> pat[2];
+    bb_group_info info;
+    uint8_t type;
+};
+
+struct bb_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    // k_barcode_lane's waves all take the same time, so a launch ends with a round of waves that fills a fraction of the GPU (13.3 rounds
+    // for the forward hits of a 2 M-read batch: 5 % of the kernel).  The rc hits' launch goes to a second stream and fills that tail.
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool use_side = false;       // between fork and join of a barcode pass
+    // Per (group, strand): k_barcode_lane's walk-free bound decides as often as the traced one while the shared rows match (they are the
+    // flank the hit was found with) — on text where they do not, more hits go on to the exact kernel.  Each batch's undecided fraction
+    // is read back with the row count; above BARBELL_AMD_LANE_FB_FRAC (0.2) the pair takes k_barcode_pfx for the next 32 batches.
+    uint8_t lane_off[BB_MAX_GROUPS][2]{};   // batches left on k_barcode_pfx
+    uint8_t lane_used[BB_MAX_GROUPS][2]{};  // this batch: the pair ran k_barcode_lane
+    double lane_fb_frac = 0.2;
+    uint64_t last_listed[BB_MAX_GROUPS][2]{}, last_undecided[BB_MAX_GROUPS][2]{};  // of the last batch (bb_last_barcode_stats)
+    uint32_t pfx_fast_launches = 0;  // per batch: fast k_barcode_pfx launches (their records need k_rows; k_barcode_lane decides in its final trip)
+    bool lazy_prefix = false;    // this batch: every split (group, strand) takes k_barcode_lane, prefix records only for the hits that go on to the exact kernel
+    bb_params params{};
+    bb_policy policy{};          // include/barbell_amd_policy.h: the switchable assumptions about sassy / cigar-lodhi-rs
+    bool generic_barcode = false;  // the policy asks for what only the any-policy barcode kernel (k_barcode) computes: Lodhi p != 3 or lambda != 0.5
+    int prio_class = 0;          // class of the policy's traceback order (bb_prio.h): which unit's fast barcode kernels run
+    std::vector<HostGroup> groups;
+    std::vector<bb_group_dev> gdev;
+    bb_group_dev* d_groups = nullptr;
+    uint8_t* d_tables = nullptr;
+    uint32_t counts_len = 0;
+    unsigned long long* d_counts = nullptr;
+    // work buffers
+    uint64_t cap_m = 0;  // entries of cnt/base (n*G*2+1)
+    uint32_t cap_reads = 0, cap_hits = 0;
+    uint32_t *d_cnt = nullptr, *d_base = nullptr, *d_sums = nullptr, *d_nrows = nullptr, *d_rowoff = nullptr;
+    uint32_t *d_hitcount = nullptr, *d_lists = nullptr, *d_listcnt = nullptr;
+    uint32_t *d_fb_lists = nullptr, *d_fbcnt = nullptr;  // hits the fast barcode kernel's bounds left undecided, per (group, strand)
+    uint32_t* d_vqueue = nullptr;  // k_flank_verify's item counters (one per strand)
+    unsigned long long* d_nflag = nullptr;  // flagged 16-byte pieces of the batch in hand, per group (k_flank_filter)
+    double adapt_frac = 0.13;    // BARBELL_AMD_ADAPT_FRAC: flagged fraction of a batch's pieces above which the full scan takes over
+    uint64_t last_flagged[BB_MAX_GROUPS]{}, last_pieces[BB_MAX_GROUPS]{};
+    uint8_t last_scan_kind[BB_MAX_GROUPS]{};  // 0 full scan, 1 filter + verification, 2 filter, then the full scan (too many flags)
+    uint32_t* d_flags = nullptr; uint64_t cap_flags = 0;  // filtered scan: one bit per 32 text bytes and strand (k_flank_filter)
+    int scan_filter = -1;        // BARBELL_AMD_SCAN_FILTER: 0 never, 1 wherever it is valid (tests), unset: where the prefix says enough
+    bool fast_path = true;       // BARBELL_AMD_NO_FAST=1: score every barcode of every hit exactly (the fallback kernel only)
+    double fast_margin = 1e-9;   // BARBELL_AMD_FAST_MARGIN: slack of the bound test in k_rows (tests: a huge value sends every hit to the fallback)
+    bb_hit_raw* d_raw = nullptr;
+    bb_hit* d_hits = nullptr;
+    bb_hit_pfx* d_pfx = nullptr;  // shared-prefix records of the hits (groups with pfx > 0)
+    bb_rowtmp* d_rows = nullptr;
+    // staging for the host-pointer variant
+    uint8_t* d_in_bases = nullptr; uint64_t cap_in_bases = 0;
+    uint64_t* d_in_offsets = nullptr; uint64_t cap_in_offsets = 0;
+    bb_row* d_out_rows = nullptr; uint64_t cap_out_rows = 0;
+    // filter step
+    bb_pat_dev* d_fpats = nullptr;
+    bb_pat_elem_dev* d_felems = nullptr;
+    uint8_t* d_flabel_ok = nullptr;
+    uint32_t* d_flabel_ids = nullptr;
+    uint32_t n_fpats = 0;
+    bb_row* d_frows = nullptr; uint64_t cap_frows = 0;
+    bb_row_verdict* d_fout = nullptr; uint64_t cap_fout = 0;
+    bb_inspect_elem* d_iout = nullptr; uint64_t cap_iout = 0;
+    // trim step, owned by bb_trim.hip
+    bb_trim_state* trim = nullptr;
+    // FASTQ ingest, owned by bb_fastq.hip
+    bb_fastq_state* fastq = nullptr;
+    // TSV renderer, owned by bb_format.hip
+    bb_format_state* format = nullptr;
+    // synth
+    uint8_t* d_synth_table = nullptr;
+    bb_synth_params synth{};
+    // timing
+    bool timing = false;
+    bool use_lists = false;  // per-(group, strand class) hit lists in use for the current batch
+    int n_cus = 256;
+    uint32_t reg_blocks_mult = 1;  // BARBELL_AMD_REG_BLOCKS: persistent blocks per resident slot (tuning knob)
+    uint32_t reg_threads = 512;  // BARBELL_AMD_REG_THREADS: block size of k_barcode_reg (tuning knob)
+    uint32_t pfx_threads = 0;    // BARBELL_AMD_PFX_THREADS: block size of k_barcode_pfx (0 = as many lanes as fit a CU)
+    int lane_kernel = 1;         // BARBELL_AMD_LANE: 1 = the fast barcode stage with one lane per hit (k_barcode_lane) for groups whose flank budget is small
+                                 // (its bound assumes the shared rows match, which they do when the flank was found with few edits: at k = 20 eight times
+                                 // as many hits go on to the exact kernel), 0 = one lane per (hit, barcode) everywhere (k_barcode_pfx), 2 = one lane per hit everywhere
+    bool force_generic = false;  // BARBELL_AMD_GENERIC=1: use the generic (any-geometry) kernels, for tests
+    hipEvent_t ev[K_COUNT + 1]{};
+    float ms[K_COUNT]{};
+    std::string last_error;
+};
+
+#define HIPCHK(ctx, call)                                                                        \
+    do {                                                                                         \
+        hipError_t e_ = (call);                                                                  \
+        if (e_ != hipSuccess) {                                                                  \
+            (ctx)->last_error = std::string(#call) + ": " + hipGetErrorString(e_);               \
+            return BB_E_HIP;                                                                     \
+        }                                                                                        \
+    } while (0)
+
+#define BB_LDS_MAX (144 * 1024)  // dynamic LDS a block may ask for (160 KB per CU on gfx950, some of it static)
+
+template <typename T>
+int grow(bb_ctx* c, T*& p, uint64_t& cap, uint64_t need) {
+    if (need <= cap && p) return BB_OK;
+    if (p) HIPCHK(c, hipFree(p));
+    p = nullptr;
+    uint64_t ncap = need + need / 4 + 64;
+    HIPCHK(c, hipMalloc((void**)&p, ncap * sizeof(T)));
+    cap = ncap;
+    return BB_OK;
+}
+

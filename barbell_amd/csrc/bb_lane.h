@@ -20,27 +20,15 @@
 //   * that final trip also decides (rows_decide: exact score of the winner's path against the runner-up's bound).
 // Output = k_barcode_pfx<.., FAST = true> + k_rows': the hit's row, or its index on the fallback list of the exact kernel.
 #pragma once
+#include "bb_k_bar_common.h"
 
 #ifndef BB_LANE_NOHOIST
 #define BB_LANE_NOHOIST 1
 #endif
-// One column of the DP on the leading shared rows (k_bar_prefix's step: P <= 16 rows in one word, no carry-in — row 0 is the text's free start):
-// the horizontal deltas of row P (-> the lane rows' carry-in) and the column's move planes, row r <-> bit P - r, lo | hi << 16.
-__device__ __forceinline__ void shared_rows_column(uint32_t eq, int P, uint32_t& pv, uint32_t& mv, uint32_t& hp, uint32_t& hm, uint32_t& shw) {
-    const uint32_t x = eq & pv;
-    const uint32_t d0 = (((x + pv) ^ pv) | eq | mv);
-    const uint32_t ph = mv | ~(d0 | pv), mh = pv & d0;
-    hp = (ph >> (P - 1)) & 1u; hm = (mh >> (P - 1)) & 1u;
-    const uint32_t isM = d0 & eq, l = ~(isM | ph), hh = (ph & ~isM) | (l & d0);
-    shw = (__brev(l) >> (32 - P)) | ((__brev(hh) >> (32 - P)) << 16);
-    const uint32_t phs = shl1_32(ph), mhs = shl1_32(mh);
-    pv = mhs | ~(d0 | phs);
-    mv = phs & d0;
-}
 
 // The winner's walk through the shared rows, columns LO+1 .. HI (1-based): their move planes recomputed into HI - LO registers (the DP
 // from column 1: a dozen instructions per column), then one step per column from HI down, for the lanes whose cursor is in that column.
-template <int LO, int HI, int NW>
+template <uint32_t PRIO, int LO, int HI, int NW>
 __device__ __forceinline__ void shared_rows_walk(const uint32_t* s_eqt, const uint32_t (&cw)[NW], int P, uint32_t pm, int wmax, uint32_t& bh, int32_t& col,
                                                  int32_t& ntext, uint32_t& dgh, uint32_t (&pl_w)[2], uint32_t (&ph_w)[2]) {
     uint32_t shw[HI - LO];
@@ -51,7 +39,7 @@ __device__ __forceinline__ void shared_rows_walk(const uint32_t* s_eqt, const ui
             uint32_t w = 0u;
             if (c < wmax) {  // wave-uniform
                 uint32_t hp, hm;
-                shared_rows_column(s_eqt[(cw[c >> 2] >> (8 * (c & 3) + 2)) & 0xFu] & 0xFFFFu, P, pv, mv, hp, hm, w);
+                shared_rows_column<PRIO>(PRIO, s_eqt[(cw[c >> 2] >> (8 * (c & 3) + 2)) & 0xFu] & 0xFFFFu, P, pv, mv, hp, hm, w);
             }
             if (c >= LO) shw[c - LO] = w;
         }
@@ -80,7 +68,8 @@ __device__ __forceinline__ void shared_rows_walk(const uint32_t* s_eqt, const ui
 }
 
 // waves per SIMD the register budget is set for: the move planes are 2 x CW registers — 48 columns fit three waves (<= 168 VGPRs), 64 two
-template <int CW, bool TAIL>
+// PRIO: the class of the policy's traceback order (bb_prio.h): the move planes are one v_bitop3 each with the class's truth tables
+template <int CW, bool TAIL, uint32_t PRIO>
 __global__ __launch_bounds__(256, CW <= 48 ? 3 : 2) void k_barcode_lane(const uint8_t* __restrict__ tables, const bb_group_dev* __restrict__ groups, uint32_t g,
                                                       uint32_t strand, const bb_hit* __restrict__ hits,
                                                       const uint32_t* __restrict__ hit_list, const uint32_t* __restrict__ list_cnt,
@@ -186,7 +175,7 @@ __global__ __launch_bounds__(256, CW <= 48 ? 3 : 2) void k_barcode_lane(const ui
                 }
                 if (P > 0) {
                     uint32_t hp, hm, shw;
-                    shared_rows_column(e & 0xFFFFu, P, pv, mv, hp, hm, shw);
+                    shared_rows_column<PRIO>(PRIO, e & 0xFFFFu, P, pv, mv, hp, hm, shw);
                     hpw[c >> 5] |= in ? hp << (c & 31) : 0u;
                     hmw[c >> 5] |= in ? hm << (c & 31) : 0u;
                 }
@@ -244,14 +233,16 @@ __global__ __launch_bounds__(256, CW <= 48 ? 3 : 2) void k_barcode_lane(const ui
                         const uint32_t t = bitop3<BB_TT_XOR_OR>(x + pv, pv, eq);           // ((x + pv) ^ pv) | eq
                         const uint32_t d0 = bitop3<0xFE>(t, hm, mv);                       // t | hm | mv
                         const uint32_t ph = bitop3<BB_TT_OR_NOR>(mv, d0, pv), mh = bitop3<0xC0>(pv, d0, 0u);
-                        const uint32_t l = bitop3<0x15>(d0, eq, ph), hh = bitop3<0x3A>(d0, eq, ph);  // move planes (see move_bits)
-                        L0[c] = __brev(l); H0[c] = __brev(hh);  // row P+1 <-> bit 31, row P+32 <-> bit 0
+                        uint32_t l, hh;
+                        if constexpr (!bb_prio_needs_pvn(PRIO)) move_planes<PRIO>(d0, eq, ph, 0u, l, hh);  // Del last (the default): planes of (d0, eq, ph)
                         const unsigned long long tp = shl1_64(((unsigned long long)upr[c >> 5] << 32) | ph);
                         const unsigned long long tm = shl1_64(((unsigned long long)dnr[c >> 5] << 32) | mh);
                         upr[c >> 5] = (uint32_t)(tp >> 32); dnr[c >> 5] = (uint32_t)(tm >> 32);
                         const uint32_t nph = bitop3<0x01>((uint32_t)tp, hp, d0);           // ~(phs | d0)
                         mv = bitop3<0xA8>((uint32_t)tp, hp, d0);                           // phs & d0
                         pv = bitop3<0xFE>(nph, (uint32_t)tm, hm);                          // mhs | ~(d0 | phs)
+                        if constexpr (bb_prio_needs_pvn(PRIO)) move_planes<PRIO>(d0, eq, ph, pv, l, hh);   // orders that test Del: its bit is the new column's vertical +1
+                        L0[c] = __brev(l); H0[c] = __brev(hh);  // row P+1 <-> bit 31, row P+32 <-> bit 0
                     }
                 }
             }
@@ -272,7 +263,8 @@ __global__ __launch_bounds__(256, CW <= 48 ? 3 : 2) void k_barcode_lane(const ui
                         const unsigned long long Pvv = Mm | ~(D0 | Pm), Mvv = Pm & D0;
                         const unsigned long long Pvs = (Pvv << 1) | 1ull, Mvs = Mvv << 1;
                         const unsigned long long Ph = Mvs | ~(D0 | Pvs), Mh = Pvs & D0;
-                        const unsigned long long isM = D0 & Eq, tl = ~(isM | Ph), th = (Ph & ~isM) | (tl & D0);
+                        unsigned long long tl, th;  // row-wise: Ins tests the new row's horizontal +1 (Ph), Del the vertical +1 between the two rows (Pvv)
+                        move_planes_any64<PRIO>(PRIO, D0, Eq, Ph, Pvv, tl, th);
                         s_tail[(size_t)(2 * t) * 256u + threadIdx.x] = tl;
                         s_tail[(size_t)(2 * t + 1) * 256u + threadIdx.x] = th;
                         Pm = Ph & wmask; Mm = Mh & wmask;
@@ -339,8 +331,8 @@ __global__ __launch_bounds__(256, CW <= 48 ? 3 : 2) void k_barcode_lane(const ui
                 int32_t col = cx;
                 uint32_t pl_w[2] = {0u, 0u}, ph_w[2] = {0u, 0u};
                 constexpr int HALF = CW / 2;
-                if (__any(bh != 0u && col > HALF)) shared_rows_walk<HALF, CW>(s_eqt, cw, P, pm, wmax, bh, col, ntext, dgh, pl_w, ph_w);
-                shared_rows_walk<0, HALF>(s_eqt, cw, P, pm, wmax, bh, col, ntext, dgh, pl_w, ph_w);
+                if (__any(bh != 0u && col > HALF)) shared_rows_walk<PRIO, HALF, CW>(s_eqt, cw, P, pm, wmax, bh, col, ntext, dgh, pl_w, ph_w);
+                shared_rows_walk<PRIO, 0, HALF>(s_eqt, cw, P, pm, wmax, bh, col, ntext, dgh, pl_w, ph_w);
                 plo |= ((unsigned long long)pl_w[1] << 32) | pl_w[0];
                 phi |= ((unsigned long long)ph_w[1] << 32) | ph_w[0];
             }
@@ -404,50 +396,5 @@ __global__ __launch_bounds__(256, CW <= 48 ? 3 : 2) void k_barcode_lane(const ui
         r.match_type = (uint8_t)(G.type == BB_FTAG ? BB_FFLANK : BB_RFLANK);
         r.barcode_cost = (int16_t)G.m_bar; r.barcode_idx = -1;
         rows[hit_idx] = R;
-    }
-}
-
-// The prefix records of the hits on a list (the hits k_rows left undecided: k_barcode_pfx's exact variant reads them), where no
-// k_bar_prefix has run over every hit because k_barcode_lane computes its own.  A lane per listed hit, records written in place: the
-// lists are a few per cent of the hits, coalescing does not matter here.
-__global__ __launch_bounds__(128) void k_bar_prefix_list(const uint8_t* __restrict__ tables, const bb_group_dev* __restrict__ groups,
-                                                         const bb_hit* __restrict__ hits, const uint32_t* __restrict__ list,
-                                                         const uint32_t* __restrict__ cnt, bb_hit_pfx* __restrict__ out) {
-    const uint32_t n = *cnt;
-    for (uint32_t i = blockIdx.x * 128u + threadIdx.x; i < n; i += gridDim.x * 128u) {
-        const uint32_t idx = list[i];
-        const bb_hit& H = hits[idx];
-        const uint32_t strand = H.strand & 1u;
-        const bb_group_dev& G = groups[H.group];
-        const int32_t wn = (int32_t)(H.we - H.ws);
-        bb_hit_pfx R;
-        R.ph = R.mh = 0ull;
-#pragma unroll
-        for (int q = 0; q < BB_MAX_TAIL; ++q) R.teq[q] = 0ull;
-        if (H.valid && G.split[strand] && wn <= 64) {
-            const int P = G.pfx[strand], T = G.tail[strand];
-            const uint32_t* eqt = reinterpret_cast<const uint32_t*>(tables + G.off_peq_pfx[strand]);
-            const uint8_t* tlut = tables + G.off_tail_lut[strand];
-            uint32_t pv = P ? (P >= 32 ? 0xFFFFFFFFu : (1u << P) - 1u) : 0u, mv = 0u;
-            for (int c = 0; c < 64; ++c) {
-                uint32_t shw = 0u;
-                if (c < wn) {
-                    const uint32_t code = H.win[c] & 0xFu;
-                    const uint32_t tb = tlut[code];
-                    for (int q = 0; q < T; ++q) R.teq[q] |= (unsigned long long)((tb >> q) & 1u) << c;
-                    if (P > 0) {
-                        uint32_t hp, hm;
-                        shared_rows_column(eqt[code], P, pv, mv, hp, hm, shw);
-                        R.ph |= (unsigned long long)hp << c; R.mh |= (unsigned long long)hm << c;
-                    }
-                }
-                out[idx].sh[c] = shw;
-            }
-        } else {
-            for (int c = 0; c < 64; ++c) out[idx].sh[c] = 0u;
-        }
-        out[idx].ph = R.ph; out[idx].mh = R.mh;
-#pragma unroll
-        for (int q = 0; q < BB_MAX_TAIL; ++q) out[idx].teq[q] = R.teq[q];
     }
 }

@@ -1,0 +1,37 @@
+// bb_launch.h — what the batch pipeline (barbell_amd.hip) calls in the translation units that hold the kernels of a stage.
+// One stage per unit so that they compile side by side (make -j) and a change to one kernel rebuilds one object:
+//   bb_tu_scan.hip    k_flank_filter / k_flank_verify / k_flank_scan2 (W = 1..8), the u32 scans
+//   bb_tu_trace.hip   k_flank_trace<W, MODE>
+//   bb_tu_bar.hip     k_bar_prefix(_list), k_barcode, k_barcode_reg, the run-time-order k_barcode_pfx variants; dispatch of a group's
+//                     barcode stage, incl. the per-class fast kernels below
+//   bb_tu_class.hip   compiled once per class of traceback orders (-DBB_TU_CLASS=0..17, bb_prio.h): k_barcode_lane<48, TAIL, PRIO> and
+//                     the fast k_barcode_pfx<48, TAIL, true, *, PRIO>; class 0 (the default order) also the 64-column k_barcode_lane
+#pragma once
+#include "bb_ctx.h"
+#include "bb_prio.h"
+
+#define BB_LANE_MAX_FLANK_K 8   // flank edit budget up to which k_barcode_lane's walk-free bound decides as often as the traced one (measured: k = 3, 5 yes; k = 20 no)
+
+int bb_scan_u32(bb_ctx* c, const uint32_t* in, uint32_t* out, uint64_t n);
+void bb_launch_scan(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n, uint32_t g, uint64_t flag_words, uint64_t batch_bytes);
+int bb_trace_mode(const bb_ctx* c, uint32_t g);
+void bb_launch_trace(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n_hits, uint32_t gmask, int mode, int W);
+bool bb_takes_lane(const bb_ctx* c, uint32_t g, uint32_t strand, bool wide);
+void bb_launch_bar_prefix(bb_ctx* c, uint32_t n_hits, hipStream_t st);
+void bb_launch_barcode(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n_hits, uint32_t g, int pass);
+
+// ---- the per-class units ----
+struct bb_lane_args {
+    const uint8_t* tables; const bb_group_dev* groups; uint32_t g, strand; const bb_hit* hits; const uint32_t* list; const uint32_t* cnt;
+    uint32_t n_hits; bb_rowtmp* rows; double min_score, min_score_diff, margin; uint32_t* fb_lists; uint32_t list_stride; uint32_t* fb_cnt;
+};
+struct bb_pfx_args {
+    const uint8_t* tables; const bb_group_dev* groups; uint32_t g, strand; const bb_hit* hits; const bb_hit_pfx* pfxs; const uint32_t* list;
+    const uint32_t* cnt; uint32_t n_hits, hpb; double min_score, min_score_diff; bb_rowtmp* rows;
+};
+// false: this unit has no such instantiation (cw = 64 outside class 0) — the caller takes another kernel
+typedef bool (*bb_lane_launch_fn)(int cw, bool tail, uint32_t blocks, size_t smem, hipStream_t st, const bb_lane_args& a);
+typedef bool (*bb_pfx_launch_fn)(bool tail, bool defpol, uint32_t blocks, uint32_t threads, size_t smem, hipStream_t st, const bb_pfx_args& a);
+struct bb_class_unit { bb_lane_launch_fn lane; bb_pfx_launch_fn pfx_fast; };
+// null members: the class was not built into this library (a development build with fewer classes)
+const bb_class_unit& bb_class_unit_of(int cls);

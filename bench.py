@@ -47,6 +47,7 @@ def main():
     ap.add_argument("--no-other-configs", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--no-stress", action="store_true")
+    ap.add_argument("--no-policy-variants", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N>1 (nccl = RCCL over xGMI; gloo only for single-GPU dry runs)")
@@ -192,6 +193,10 @@ def main():
             # the same pipeline where the filtered scan's assumption (unrelated text rarely comes within k edits of a flank window)
             # is strained; outside `value`
             out["stress"] = {name: _guarded(stress_leg, mode, dev_idx, dev, L, args) for name, mode in (("low_complexity_30pct", 1), ("prefix_decoys_every_200nt", 2), ("artefacts_50pct", 3), ("prefix_decoys_every_60nt", 4))}
+        if world == 1 and args.config == "nbd96" and not args.no_policy_variants:
+            # the same workload under every setting of the assumptions about sassy / cigar-lodhi-rs that Barbell's own code does not pin
+            # (include/barbell_amd_policy.h): what the headline becomes if the real crates turn out to differ from the default; outside `value`
+            out["policy_variants"] = _guarded(policy_variants_leg, dev_idx, dev, L, args)
         if world == 1 and args.config == "nbd96" and not args.no_e2e:
             out["e2e_step"] = _guarded(e2e_leg, d_bases, min(n_res, 4_000_000), L, dev)
         if world == 1 and not args.no_cpu_baseline:
@@ -253,6 +258,69 @@ def other_config_leg(cfg, dev_idx, dev, L, args, n=1_000_000, steps=3):
         out["sample"] = f"first and last {w} reads of the batch against the CPU oracle ({rows} rows)"
     dm.close()
     return out
+
+
+def policy_variants_leg(dev_idx, dev, L, args, n=1_000_000, steps=3):
+    """SQK-NBD114-96, n resident reads, `steps` timed passes per policy (tests/common.py::GPU_POLICIES: every alternative of every hazard
+    alone — all 18 distinguishable traceback orders among them — and two mixtures): reads/s, the barcode stage's time, which kernel decided
+    the hits, and the rows of the first reads against the CPU checker under the same policy.  `min_vs_default` is over the settings Barbell's
+    own code leaves open; Lodhi's p and lambda are pinned by searcher.rs:209 (Lodhi::new(3, 0.5)) and only listed."""
+    from barbell_amd import _abi
+    from barbell_amd import annotate as A
+    from oracle import pyoracle as po
+    from tests.common import GPU_POLICIES, config_groups
+
+    groups = config_groups("nbd96")
+    d_off = torch.arange(0, n + 1, dtype=torch.int64, device=dev) * L
+    d_bases = torch.empty(n * L, dtype=torch.uint8, device=dev)
+    cap = 6 * n
+    d_rows = torch.empty(cap * 48, dtype=torch.uint8, device=dev)
+    w = 2048
+    sample = None
+    res, base = {}, None
+    for pol in ["default"] + list(GPU_POLICIES):
+        ptxt = "" if pol == "default" else pol
+        dm = A.Demuxer(device=dev_idx, policy=ptxt)
+        for g in groups:
+            dm.add_query_group(g)
+        if sample is None:
+            torch.cuda.synchronize()
+            dm.synth_dev(SEED, L, L, 0, n, d_off.data_ptr(), d_bases.data_ptr())
+            sample = d_bases[: w * L].cpu().numpy()
+        nr = dm.demux_dev(d_bases.data_ptr(), d_off.data_ptr(), n, d_rows.data_ptr(), cap)
+        dm.set_timing(True)
+        kms = {}
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            nr = dm.demux_dev(d_bases.data_ptr(), d_off.data_ptr(), n, d_rows.data_ptr(), cap)
+            for k, v in dm.kernel_ms().items():
+                kms[k] = kms.get(k, 0.0) + v / steps
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        p = _abi.policy_from_str(ptxt)
+        pinned = p.lodhi_p != 3 or p.lodhi_lambda != 0.5
+        st = [dm.barcode_stats(0, s) for s in (0, 1)]
+        e = {"reads_per_s": n / dt, "ms_per_step": dt * 1e3, "barcode_stage_ms": kms["k_barcode"], "rows_per_step": nr,
+             "kernel": "k_barcode (any-policy)" if pinned else ("k_barcode_lane" if all(s["lane_kernel"] for s in st) else "k_barcode_pfx"),
+             "undecided_hits_frac": sum(s["undecided"] for s in st) / max(1, sum(s["hits"] for s in st))}
+        if pinned:
+            e["pinned_by_barbell"] = "searcher.rs:209 constructs Lodhi::new(3, 0.5): not an open assumption; listed, not in min_vs_default"
+        if not args.no_cpu_baseline:
+            full = np.frombuffer(d_rows[: nr * 48].cpu().numpy().tobytes(), dtype=_abi.ROW_DTYPE)
+            want = po.Oracle([g.as_tuple() for g in groups], policy=ptxt or None).annotate(sample, np.arange(w + 1, dtype=np.uint64) * np.uint64(L),
+                                                                                    n_threads=os.cpu_count() or 1, fast=True)
+            e["parity_on_sample"] = bool(full[full["read_idx"] < w].tobytes() == want.tobytes())
+        dm.close()
+        if pol == "default":
+            base = e["reads_per_s"]
+        e["vs_default"] = e["reads_per_s"] / base
+        res[pol] = e
+    open_ = {k: v for k, v in res.items() if "pinned_by_barbell" not in v}
+    worst = min(open_, key=lambda k: open_[k]["vs_default"])
+    return {"reads": n, "read_len": L, "steps": steps, "sample": f"first {w} reads against the CPU checker under the same policy", "n_policies": len(res),
+            "min_vs_default": open_[worst]["vs_default"], "min_policy": worst, "all_parity": all(v.get("parity_on_sample", True) for v in res.values()),
+            "policies": res}
 
 
 def stress_leg(mode, dev_idx, dev, L, args, n=1_000_000, steps=3):

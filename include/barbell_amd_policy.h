@@ -12,7 +12,8 @@
  *
  * Text form (BARBELL_AMD_POLICY, `barbell-amd --policy`, tools/ref_diff.py): comma separated key=value, any subset:
  *     lm=right|left|strict   rc=scan|fwd   trace=MISD (a permutation of M S I D)   ovh=floor|ceil|near[:f64]
- *     tie=first|last         lodhi=<p>:<lambda>:<eM><eS><eI><eD>      e.g. "lm=left,trace=MSID,lodhi=3:0.5:2211"
+ *     tie=first|last         lodhi=<p>:<lambda>:<eM><eS><eI><eD>      rcpath=fwd|mirror
+ *     e.g. "lm=left,trace=MSID,lodhi=3:0.5:2211,rcpath=mirror"
  */
 #ifndef BARBELL_AMD_POLICY_H
 #define BARBELL_AMD_POLICY_H
@@ -45,6 +46,11 @@ extern "C" {
 #define BB_OVH_CEIL  1
 #define BB_OVH_NEAR  2         /* to nearest, ties to even */
 #define BB_OVH_F64   4         /* flag: the product is formed in f64 instead of f32 */
+/* [H5] pattern indices of the path cells (`Match::to_path()`, consumed by get_matching_region, cigar_parse.rs:71-82, with
+ * bar_region = (prefix_len, prefix_len + mask_len - 1), barcodes.rs:192) of a Strand::Rc flank match */
+#define BB_RCPATH_FWD    0     /* those of the forward flank: rc searched as complement(flank) in the reversed text           */
+#define BB_RCPATH_MIRROR 1     /* mirrored, i -> m - 1 - i: rc searched as reverse_complement(flank) in the forward text, the
+                                  region then selects rows m-1-bar_hi .. m-1-bar_lo of the flank (NB96: (8,31) for (14,37))   */
 /* [H7] which of several equally cheap matches of one barcode pattern collect_candidates keeps (searcher.rs:294-300
  * keeps the first STRICTLY lowest of the Vec sassy returns; `last` models a Vec in descending position order) */
 #define BB_TIE_FIRST 0
@@ -61,7 +67,8 @@ typedef struct {
                                     columns c1 < c2 < c3 weighs lambda^(sum of the exponents of the columns c1..c3).
                                     1,1,1,1 = span counted in alignment columns; 2,2,1,1 = span in the pattern plus span
                                     in the text (the two-string kernel of Lodhi et al. restricted to the alignment)  */
-    uint8_t _pad[3];
+    uint8_t rc_path;        /* [H5] BB_RCPATH_*                                                          */
+    uint8_t _pad[2];
     double  lodhi_lambda;   /* [H8] Lodhi::new(.., 0.5)                                                  */
 } bb_policy;                /* 24 bytes */
 
@@ -75,7 +82,7 @@ static inline void bb_policy_default(bb_policy* p) {
 /* 0 = usable */
 static inline int bb_policy_validate(const bb_policy* p) {
     unsigned seen = 0;
-    if (p->lm_rule > BB_LM_STRICT || p->rc_order > BB_RC_FWD_ORDER || p->bar_tie > BB_TIE_LAST) return -1;
+    if (p->lm_rule > BB_LM_STRICT || p->rc_order > BB_RC_FWD_ORDER || p->bar_tie > BB_TIE_LAST || p->rc_path > BB_RCPATH_MIRROR) return -1;
     if ((p->ovh_round & 3) > BB_OVH_NEAR || (p->ovh_round & ~7u)) return -1;
     for (int i = 0; i < 4; ++i) { if (p->trace_prio[i] > 3) return -1; seen |= 1u << p->trace_prio[i]; }
     if (seen != 15u) return -1;
@@ -91,7 +98,7 @@ static inline int bb_policy_lodhi_is_default(const bb_policy* p) {
     return p->lodhi_p == 3 && p->lodhi_lambda == 0.5 && p->lodhi_exp[0] == 1 && p->lodhi_exp[1] == 1 && p->lodhi_exp[2] == 1 && p->lodhi_exp[3] == 1;
 }
 static inline int bb_policy_is_default(const bb_policy* p) {
-    return p->lm_rule == 0 && p->rc_order == 0 && p->ovh_round == 0 && p->bar_tie == 0 && bb_policy_trace_is_default(p) && bb_policy_lodhi_is_default(p);
+    return p->lm_rule == 0 && p->rc_order == 0 && p->ovh_round == 0 && p->bar_tie == 0 && p->rc_path == 0 && bb_policy_trace_is_default(p) && bb_policy_lodhi_is_default(p);
 }
 
 /* text form -> struct (fields not named keep their value in *p); 0 ok, -1 malformed */
@@ -100,7 +107,14 @@ static inline int bb_policy_parse(const char* s, bb_policy* p) {
     if (!s) return 0;
     if (strlen(s) >= sizeof(buf)) return -1;
     strcpy(buf, s);
-    for (char* tok = strtok(buf, ", "); tok; tok = strtok(NULL, ", ")) {
+    /* split at ',' and ' ' without strtok's hidden state: contexts may be created from several threads at once */
+    for (char* tok = buf; *tok;) {
+        while (*tok == ',' || *tok == ' ') ++tok;
+        if (!*tok) break;
+        char* end = tok;
+        while (*end && *end != ',' && *end != ' ') ++end;
+        char* next = *end ? end + 1 : end;
+        *end = 0;
         char* eq = strchr(tok, '=');
         if (!eq) return -1;
         *eq = 0;
@@ -137,19 +151,25 @@ static inline int bb_policy_parse(const char* s, bb_policy* p) {
         } else if (!strcmp(tok, "lodhi")) {
             int pp = 0; double lam = 0.0; char e[8] = "";
             if (sscanf(v, "%d:%lf:%4[0-9]", &pp, &lam, e) != 3 || strlen(e) != 4) return -1;
+            if (pp < 1 || pp > 4) return -1;  /* before narrowing: 259 must not pass as 3 */
             p->lodhi_p = (uint8_t)pp; p->lodhi_lambda = lam;
             for (int i = 0; i < 4; ++i) p->lodhi_exp[i] = (uint8_t)(e[i] - '0');
+        } else if (!strcmp(tok, "rcpath")) {
+            if (!strcmp(v, "fwd")) p->rc_path = BB_RCPATH_FWD;
+            else if (!strcmp(v, "mirror")) p->rc_path = BB_RCPATH_MIRROR;
+            else return -1;
         } else return -1;
+        tok = next;
     }
     return bb_policy_validate(p);
 }
 static inline void bb_policy_format(const bb_policy* p, char* out, size_t n) {
     static const char* const lm[] = {"right", "left", "strict"};
     static const char* const ov[] = {"floor", "ceil", "near", "?"};
-    snprintf(out, n, "lm=%s,rc=%s,trace=%c%c%c%c,ovh=%s%s,tie=%s,lodhi=%d:%.17g:%d%d%d%d", lm[p->lm_rule % 3], p->rc_order ? "fwd" : "scan",
+    snprintf(out, n, "lm=%s,rc=%s,trace=%c%c%c%c,ovh=%s%s,tie=%s,lodhi=%d:%.17g:%d%d%d%d,rcpath=%s", lm[p->lm_rule % 3], p->rc_order ? "fwd" : "scan",
              "MSID"[p->trace_prio[0] & 3], "MSID"[p->trace_prio[1] & 3], "MSID"[p->trace_prio[2] & 3], "MSID"[p->trace_prio[3] & 3],
              ov[p->ovh_round & 3], (p->ovh_round & BB_OVH_F64) ? ":f64" : "", p->bar_tie ? "last" : "first", (int)p->lodhi_p, p->lodhi_lambda,
-             (int)p->lodhi_exp[0], (int)p->lodhi_exp[1], (int)p->lodhi_exp[2], (int)p->lodhi_exp[3]);
+             (int)p->lodhi_exp[0], (int)p->lodhi_exp[1], (int)p->lodhi_exp[2], (int)p->lodhi_exp[3], p->rc_path ? "mirror" : "fwd");
 }
 
 #ifdef __cplusplus

@@ -279,6 +279,7 @@ static int search_pol(const bb_policy* P, const uint8_t* pat, int m, const uint8
             int ts = mm->text_start, te = mm->text_end;
             mm->text_start = n - te; mm->text_end = n - ts;
             mm->strand = BB_RC; mm->pattern_idx = 0; mm->rc_text_len = n;
+            mm->rc_mirror_len = P->rc_path == BB_RCPATH_MIRROR ? m : 0;
         }
         free(re.v); free(pcc); free(trv);
     }
@@ -301,13 +302,15 @@ void bbo_free_matches(bbo_match* ms, int n) {
  * from "after advancing".  [H5] For Rc matches the walk runs in reversed-text coordinates
  * (i' ascending from n - text_end) and each text index is mirrored to max(0, n-1-i'), so pattern
  * indices stay comparable with the forward flank and text indices run downwards
- * (cigar_parse.rs:79-81 takes min/max).
+ * (cigar_parse.rs:79-81 takes min/max).  Policy [H5] BB_RCPATH_MIRROR: the pattern indices of an Rc match are those of the
+ * reverse-complemented pattern instead, i -> m - 1 - i (what a search of rc(pattern) in the forward text would yield), so
+ * get_matching_region's bar_region selects the mirrored rows.
  */
 int bbo_to_path(const bbo_match* m, bbo_pos* path) {
     int j = m->pattern_start;
     int i = m->strand == BB_RC ? m->rc_text_len - m->text_end : m->text_start;
     for (int t = 0; t < m->n_ops; ++t) {
-        path[t].i = j;
+        path[t].i = m->rc_mirror_len ? m->rc_mirror_len - 1 - j : j;   /* policy [H5]: mirrored pattern indices for Rc matches */
         if (m->strand == BB_RC) { int f = m->rc_text_len - 1 - i; path[t].j = f < 0 ? 0 : f; }
         else path[t].j = i;
         switch (m->ops[t]) {
@@ -688,14 +691,15 @@ static int search_fast(const bb_policy* P, const ogroup* g, const uint8_t* tc, i
         const int ts = mm->text_start, te = mm->text_end;
         mm->text_start = n - te; mm->text_end = n - ts;
         mm->strand = BB_RC; mm->rc_text_len = n;
+        mm->rc_mirror_len = P->rc_path == BB_RCPATH_MIRROR ? m : 0;
     }
     free(ef.v); free(er.v); free(pc); free(pcc); free(trv);
     *out = ms;
     return total;
 }
-/* best_match_for_pattern on one 64-bit word (m <= 64, window <= BB_FAST_MAXWIN columns), default traceback preference: the
- * forward pass keeps the preferred move of every cell as two bit planes (Match: d0 & eq; else Ins: ph; else Sub: ~d0; else
- * Del — trace_match's order), the walk back reads them */
+/* best_match_for_pattern on one 64-bit word (m <= 64, window <= BB_FAST_MAXWIN columns): the forward pass keeps the preferred
+ * move of every cell as two bit planes (by default Match: d0 & eq; else Ins: ph; else Sub: ~d0; else Del — trace_match's
+ * order, any policy order alike), the walk back reads them */
 #define BB_FAST_MAXWIN 160
 static int best_match_for_pattern_fast(const bb_policy* P, const uint64_t* peq16, int m, const uint8_t* wcode, int wn, int k, bbo_match* best,
                                        uint8_t* ops_store /* m + wn + 2 bytes of the caller's: no allocation per pattern */) {
@@ -708,11 +712,16 @@ static int best_match_for_pattern_fast(const bb_policy* P, const uint64_t* peq16
         const uint64_t eq = peq16[wcode[c - 1]], x = eq & pv;
         const uint64_t d0 = (((x + pv) ^ pv) | eq | mv);
         const uint64_t ph = mv | ~(d0 | pv), mh = pv & d0;
-        const uint64_t isM = d0 & eq, l = ~(isM | ph);
-        lo[c] = l; hi[c] = (ph & ~isM) | (l & d0);
         score += (int32_t)((ph >> TB) & 1u) - (int32_t)((mh >> TB) & 1u);
         const uint64_t phs = ph << 1, mhs = mh << 1;
         pv = mhs | ~(d0 | phs); mv = phs & d0;
+        {   /* policy [H3]: per cell the first applicable op of the order — Match: d0 & eq, Sub: ~d0, Ins: ph, Del: the new column's
+             * vertical +1 — trace_match's cost compares as bit-vectors */
+            uint64_t v[4], s[4] = {0, 0, 0, 0}, taken = 0;
+            v[BBO_MATCH] = d0 & eq; v[BBO_SUB] = ~d0; v[BBO_INS] = ph; v[BBO_DEL] = pv;
+            for (int q = 0; q < 4; ++q) { const int op = P->trace_prio[q]; const uint64_t x = v[op] & ~taken; taken |= x; s[op] |= x; }
+            lo[c] = s[BBO_SUB] | s[BBO_DEL]; hi[c] = s[BBO_INS] | s[BBO_DEL];
+        }
         if (score > prev) {                                                            /* lm_step + searcher.rs:294-300 in one */
             if (dec && prev <= k && (prev < best_cost || (P->bar_tie == BB_TIE_LAST && prev == best_cost))) { best_cost = prev; best_pos = P->lm_rule == BB_LM_PLATEAU_LEFT ? cand : c - 1; }
             dec = 0;
@@ -782,7 +791,7 @@ static void demux_read(const bbo_ctx* c, uint32_t read_idx, const uint8_t* read,
             bbo_match* best = (bbo_match*)calloc(g->n_seqs, sizeof(bbo_match));
             uint8_t* has = (uint8_t*)calloc(g->n_seqs, 1);
             uint8_t* pcode = (uint8_t*)malloc((size_t)m);
-            const int fast_bar = fast && g->bpeq[fm->strand] && wn <= BB_FAST_MAXWIN && bb_policy_trace_is_default(&c->pol);
+            const int fast_bar = fast && g->bpeq[fm->strand] && wn <= BB_FAST_MAXWIN;
             const size_t ops_stride = (size_t)(m + wn + 2);
             uint8_t* ops_arena = fast_bar ? (uint8_t*)malloc(ops_stride * g->n_seqs) : NULL;   /* the candidates' op strings, one block */
             int k = g->k1, matched = 0;

@@ -38,6 +38,7 @@ typedef struct {
     int32_t n_ops;
     uint8_t* ops;                        /* unit ops in pattern order (malloc'd)             */
     int32_t rc_text_len;                 /* text length, needed by to_path for Rc matches    */
+    int32_t rc_mirror_len;               /* policy [H5]: 0, or the pattern length m of an Rc match whose path indices are m-1-i */
 } bbo_match;
 
 typedef struct { int32_t i, j; } bbo_pos;   /* Pos(pattern idx, text idx) */

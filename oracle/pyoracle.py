@@ -27,7 +27,7 @@ class Match(C.Structure):
         ("text_start", C.c_int32), ("text_end", C.c_int32),
         ("pattern_start", C.c_int32), ("pattern_end", C.c_int32),
         ("cost", C.c_int32), ("strand", C.c_int32), ("pattern_idx", C.c_int32),
-        ("n_ops", C.c_int32), ("ops", C.POINTER(C.c_uint8)), ("rc_text_len", C.c_int32),
+        ("n_ops", C.c_int32), ("ops", C.POINTER(C.c_uint8)), ("rc_text_len", C.c_int32), ("rc_mirror_len", C.c_int32),
     ]
 
 

@@ -1,3 +1,4 @@
+import itertools
 import os
 
 from barbell_amd import _abi, kits
@@ -35,3 +36,23 @@ def noisy_reads(cfg, seed, n, lmin, lmax, rate=0.08):
     pos = rng.random(len(b)) < rate
     b[pos] = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), int(pos.sum()))
     return groups, b, offsets
+
+
+# ---- the policy space (include/barbell_amd_policy.h): what tests/test_policy.py checks and bench.py's policy_variants leg times ----
+# The 18 distinguishable traceback orders (barbell_amd/csrc/bb_prio.h): Match and Sub exclude each other, so orders that differ by
+# swapping ADJACENT M and S take the same op at every cell; a class is named by its order with M before S where adjacent.
+TRACE_CLASSES = ["MISD"] + sorted("".join(p) for p in itertools.permutations("MSID") if "SM" not in "".join(p) and "".join(p) != "MISD")
+assert len(TRACE_CLASSES) == 18
+ALTERNATIVES = {   # hazard -> the non-default settings (the default is the first value of each key in POLICY_DEFAULT)
+    "H1": ["lm=left", "lm=strict"],
+    "H2": ["rc=fwd"],
+    "H3": ["trace=" + c for c in TRACE_CLASSES[1:]] + ["trace=SMID"],   # SMID: the non-canonical spelling of MSID's class
+    "H5": ["rcpath=mirror"],
+    "H4": ["ovh=ceil", "ovh=near", "ovh=floor:f64", "ovh=ceil:f64"],
+    "H7": ["tie=last"],
+    "H8": ["lodhi=3:0.5:2211", "lodhi=3:0.5:1110", "lodhi=2:0.5:1111", "lodhi=3:0.7:1111", "lodhi=4:0.5:1111"],
+}
+GPU_POLICIES = [a for alts in ALTERNATIVES.values() for a in alts] + [
+    "lm=left,rc=fwd,trace=MSID,ovh=ceil,tie=last,lodhi=3:0.5:2211,rcpath=mirror",      # everything at once, register-resident Lodhi family
+    "lm=strict,tie=last,lodhi=3:0.5:1121",
+]

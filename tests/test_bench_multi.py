@@ -10,7 +10,7 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-COMMON = ["--reads", "200000", "--batch", "100000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-other-configs", "--no-e2e",
+COMMON = ["--reads", "200000", "--batch", "100000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-other-configs", "--no-e2e", "--no-policy-variants",
           "--print-histogram"]
 
 

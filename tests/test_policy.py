@@ -12,18 +12,9 @@ import pytest
 
 from barbell_amd import _abi
 from oracle import pyoracle as po
-from tests.common import config_groups
+from tests.common import ALTERNATIVES, GPU_POLICIES, TRACE_CLASSES, config_groups
 
 NT = os.cpu_count() or 1
-ALTERNATIVES = {   # hazard -> the non-default settings (the default is the first value of each key in POLICY_DEFAULT)
-    "H1": ["lm=left", "lm=strict"],
-    "H2": ["rc=fwd"],
-    "H3": ["trace=MSID", "trace=MDSI", "trace=MIDS", "trace=SMID"],
-    "H4": ["ovh=ceil", "ovh=near", "ovh=floor:f64", "ovh=ceil:f64"],
-    "H7": ["tie=last"],
-    "H8": ["lodhi=3:0.5:2211", "lodhi=3:0.5:1110", "lodhi=2:0.5:1111", "lodhi=3:0.7:1111", "lodhi=4:0.5:1111"],
-}
-
 
 def test_text_form_round_trips_and_rejects_nonsense():
     for alts in ALTERNATIVES.values():
@@ -31,7 +22,7 @@ def test_text_form_round_trips_and_rejects_nonsense():
             p = _abi.policy_from_str(a)
             assert _abi.policy_to_str(_abi.policy_from_str(_abi.policy_to_str(p))) == _abi.policy_to_str(p)
     assert _abi.policy_to_str(_abi.policy_from_str()) == _abi.POLICY_DEFAULT
-    for bad in ("lm=up", "trace=MMID", "lodhi=3:0.5:111", "lodhi=9:0.5:1111", "what=1"):
+    for bad in ("lm=up", "trace=MMID", "lodhi=3:0.5:111", "lodhi=9:0.5:1111", "lodhi=259:0.5:1111", "what=1", "rcpath=up"):
         with pytest.raises(ValueError):
             _abi.policy_from_str(bad)
         bad_p = _abi.Policy()
@@ -92,6 +83,58 @@ def test_h3_traceback_preference():
     assert want == ((5, 8), (0, 2), 2) and got != want
 
 
+def test_h3_every_class_is_distinguishable_and_spellings_of_a_class_agree():
+    """18 classes: for every pair some input tells them apart (the checker's scalar traceback, trace_match), and the two spellings
+    of a class (adjacent M / S swapped) never differ.  Inputs: short patterns against texts with a repeated character around one edit,
+    where several alignments of the same cost exist."""
+    import random
+
+    rng = random.Random(5)
+    cases = []
+    for _ in range(400):
+        m = rng.randint(4, 9)
+        pat = bytes(rng.choice(b"AC") for _ in range(m))
+        text = bytearray(pat)
+        for _ in range(rng.randint(1, 3)):
+            p = rng.randrange(len(text) + 1)
+            r = rng.random()
+            if r < 0.4 and len(text) > 2: del text[min(p, len(text) - 1)]
+            elif r < 0.8: text.insert(p, rng.choice(b"AC"))
+            else: text[min(p, len(text) - 1)] = rng.choice(b"AC")
+        cases.append((pat, bytes(rng.choice(b"AC") for _ in range(2)) + bytes(text) + bytes(rng.choice(b"AC") for _ in range(2)), 3))
+    sig = {}
+    for order in ["".join(p) for p in itertools.permutations("MSID")]:
+        with po.policy("trace=" + order):
+            sig[order] = tuple(tuple(m[4] for m in _search(pat, text, k, rc=False)) for pat, text, k in cases)
+    canon = lambda o: o.replace("SM", "MS")
+    for a, b in itertools.combinations(sig, 2):
+        assert (sig[a] == sig[b]) == (canon(a) == canon(b)), (a, b)
+    assert len({canon(o) for o in sig}) == 18 and sorted({canon(o) for o in sig}) == sorted(TRACE_CLASSES)
+
+
+def test_h5_pattern_indices_of_rc_matches():
+    """get_matching_region (cigar_parse.rs:71-82) on an Rc match: with rcpath=mirror the region (start, end) selects the rows
+    m-1-end .. m-1-start of the flank, i.e. another stretch of the text, unless the region is symmetric."""
+    pat = b"AACCGGTTACGTTTGCA"          # 17 nt, region rows 2..6 (asymmetric: mirrored it is rows 10..14)
+    rc = bytes({65: 84, 67: 71, 71: 67, 84: 65}[c] for c in pat[::-1])
+    text = b"GGGGGGGG" + rc + b"GGGGGGGG"
+    spans = {}
+    for pol in ("rcpath=fwd", "rcpath=mirror"):
+        with po.policy(pol):
+            ms, h = po.search(pat, text, 0, rc=True)
+            k = [i for i, m in enumerate(ms) if m.strand == 1]
+            assert len(k) == 1
+            spans[pol] = po.get_matching_region(h, k[0], 2, 6)
+            sym = po.get_matching_region(h, k[0], 5, 11)   # rows 5..11 of 17 are their own mirror image
+            fwd = po.get_matching_region(h, [i for i, m in enumerate(ms) if m.strand == 0][0], 2, 6) if any(m.strand == 0 for m in ms) else None
+            po.free_matches(h)
+            spans[pol + ":sym"] = sym
+            assert fwd is None
+    # the rc occurrence starts at text 8; flank row r sits at text 8 + 16 - r
+    assert spans["rcpath=fwd"] == (8 + 16 - 6, 8 + 16 - 2) and spans["rcpath=mirror"] == (8 + 2, 8 + 6)
+    assert spans["rcpath=fwd:sym"] == spans["rcpath=mirror:sym"]
+
+
 def test_h4_overhang_rounding():
     # a pattern whose last three characters hang over the text end: cost round(alpha * 3)
     costs = {}
@@ -146,7 +189,7 @@ def test_reference_kats_hold_under_policies_that_do_not_touch_them():
     alternative must reproduce all five."""
     from tests.test_oracle_kat import KATS  # (pattern, text, k, region, expected sub-cost / spans)
 
-    for pol in ALTERNATIVES["H2"] + ALTERNATIVES["H4"] + ALTERNATIVES["H7"] + ALTERNATIVES["H8"] + ["lm=left"]:
+    for pol in ALTERNATIVES["H2"] + ALTERNATIVES["H4"] + ALTERNATIVES["H5"] + ALTERNATIVES["H7"] + ALTERNATIVES["H8"] + ["lm=left"]:
         with po.policy(pol):
             for pat, text, k, want in KATS:
                 ms, h = po.search(pat, text, k, rc=True)
@@ -156,12 +199,6 @@ def test_reference_kats_hold_under_policies_that_do_not_touch_them():
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-GPU_POLICIES = [a for alts in ALTERNATIVES.values() for a in alts] + [
-    "lm=left,rc=fwd,trace=MSID,ovh=ceil,tie=last,lodhi=3:0.5:2211",      # everything at once, register-resident Lodhi family
-    "lm=strict,tie=last,lodhi=3:0.5:1121",
-]
-
-
 @pytest.mark.gpu
 @pytest.mark.parametrize("pol", GPU_POLICIES)
 def test_hip_equals_checker_under_policy(pol):
@@ -182,6 +219,55 @@ def test_hip_equals_checker_under_policy(pol):
         dm.close()
 
 
+# one class of each kind of bb_prio.h (which three bits the planes are functions of: the order's last op) besides the default's
+KIND_CLASSES = ["trace=MSID", "trace=MDSI", "trace=DSIM", "trace=MIDS,rcpath=mirror"]
+VARIANT_KNOBS = [None, ("BARBELL_AMD_LANE", "0"), ("BARBELL_AMD_LANE", "2"), ("BARBELL_AMD_NO_FAST", "1"), ("BARBELL_AMD_FAST_MARGIN", "10"),
+                 ("BARBELL_AMD_NO_PFX", "1"), ("BARBELL_AMD_GENERIC", "1"), ("BARBELL_AMD_NO_TAIL", "1")]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("knob", VARIANT_KNOBS, ids=lambda k: "default" if k is None else f"{k[0][12:]}={k[1]}")
+@pytest.mark.parametrize("pol", KIND_CLASSES)
+def test_every_barcode_kernel_under_other_trace_orders(monkeypatch, pol, knob):
+    """The traceback order reaches every barcode kernel: k_barcode_lane and the fast k_barcode_pfx as a compile-time class
+    (bb_tu_class.hip), the exact k_barcode_pfx, the prefix kernels, k_barcode_reg and k_barcode at run time — each forced in turn, on
+    every BASELINE query set (rbk96x: k = 20, the 64-column kernels, the checkpointed flank traceback), noisy reads."""
+    from barbell_amd import annotate as A
+    from tests.test_gpu_parity import assert_same
+    from tests.common import noisy_reads
+
+    if knob:
+        monkeypatch.setenv(*knob)
+    for cfg, n, rate in (("nbd96", 900, 0.08), ("dual", 400, 0.06), ("rbk96x", 200, 0.04), ("rbk24", 300, 0.05)):
+        groups, bases, offsets = noisy_reads(cfg, 4321, n, 200, 2500, rate)
+        dm = A.Demuxer(policy=pol)
+        for g in groups:
+            dm.add_query_group(g)
+        got = dm.demux_packed(bases, offsets)
+        want = po.Oracle([g.as_tuple() for g in groups], policy=pol).annotate(bases, offsets, n_threads=NT)
+        assert len(want) > n // 4
+        assert_same(got, want)
+        dm.close()
+
+
+@pytest.mark.gpu
+def test_no_trace_order_leaves_the_fast_kernels():
+    """bb_last_barcode_stats: under every one of the 18 classes the SQK-NBD114-96 hits are decided by k_barcode_lane (the any-policy
+    kernel k_barcode is for Lodhi p / lambda other than (3, 0.5) only)."""
+    from barbell_amd import annotate as A
+
+    groups = config_groups("nbd96")
+    bases, offsets = A.synth_reads_host(groups, 17, 1000, 3000, 0, 2000)
+    for cls in TRACE_CLASSES:
+        dm = A.Demuxer(policy="trace=" + cls)
+        for g in groups:
+            dm.add_query_group(g)
+        dm.demux_packed(bases, offsets)
+        st = [dm.barcode_stats(0, s) for s in (0, 1)]
+        assert all(s["lane_kernel"] for s in st) and sum(s["hits"] for s in st) > 1000, (cls, st)
+        dm.close()
+
+
 @pytest.mark.gpu
 def test_policy_through_the_environment_and_getter(monkeypatch):
     import ctypes as C
@@ -196,7 +282,7 @@ def test_policy_through_the_environment_and_getter(monkeypatch):
         dm.add_query_group(g)
     p = _abi.Policy()
     assert lib().bb_get_policy(dm._ctx(), C.byref(p)) == 0
-    assert _abi.policy_to_str(p) == "lm=left,rc=scan,trace=MISD,ovh=floor,tie=first,lodhi=3:0.5:2211"
+    assert _abi.policy_to_str(p) == "lm=left,rc=scan,trace=MISD,ovh=floor,tie=first,lodhi=3:0.5:2211,rcpath=fwd"
     bases, offsets = A.synth_reads_host(groups, 5, 300, 1500, 0, 300)
     got = dm.demux_packed(bases, offsets)
     want = po.Oracle([g.as_tuple() for g in groups], policy="lm=left,lodhi=3:0.5:2211").annotate(bases, offsets, n_threads=NT)
