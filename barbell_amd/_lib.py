@@ -13,7 +13,7 @@ SO_PATH = os.environ.get("BARBELL_AMD_SO") or os.path.join(_HERE, "libbarbell_am
 EXPORTS = [
     "bb_create", "bb_create_policy", "bb_get_policy", "bb_destroy", "bb_n_groups", "bb_group_get_info", "bb_group_get_flank", "bb_group_get_pattern",
     "bb_annotate_batch", "bb_annotate_batch_dev", "bb_counts_len", "bb_counts", "bb_counts_dev", "bb_counts_reset",
-    "bb_last_scan_stats", "bb_last_barcode_stats", "bb_n_kernels", "bb_kernel_name", "bb_last_kernel_ms", "bb_set_timing", "bb_strerror", "bb_last_error",
+    "bb_last_scan_stats", "bb_last_barcode_stats", "bb_n_kernels", "bb_kernel_name", "bb_last_kernel_ms", "bb_set_timing", "bb_last_dominant_kernel", "bb_strerror", "bb_last_error",
     "bb_synth_offsets", "bb_synth_reads_host", "bb_synth_reads_dev",
     "bb_filter_set", "bb_filter_rows", "bb_filter_rows_dev",
     "bb_inspect_rows", "bb_inspect_rows_dev",
@@ -72,6 +72,7 @@ def lib():
     L.bb_last_kernel_ms.restype = C.c_float
     L.bb_set_timing.argtypes = [vp, i32]
     L.bb_set_timing.restype = None
+    L.bb_last_dominant_kernel.argtypes = [vp, C.c_char_p, C.c_size_t, C.POINTER(C.c_float)]
     L.bb_strerror.argtypes = [i32]
     L.bb_strerror.restype = C.c_char_p
     L.bb_last_error.argtypes = [vp]

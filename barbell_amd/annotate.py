@@ -197,6 +197,13 @@ class Demuxer:
         L = lib()
         return {L.bb_kernel_name(k).decode(): L.bb_last_kernel_ms(self._ctx(), k) for k in range(L.bb_n_kernels())}
 
+    def dominant_kernel(self):
+        """with timing on: (name as rocprofv3 prints it, ms) of the longest single kernel launch of the last batch's barcode stage
+        (bb_last_dominant_kernel); ("", 0.0) if there was none"""
+        buf, ms = C.create_string_buffer(96), C.c_float()
+        self._check(lib().bb_last_dominant_kernel(self._ctx(), buf, 96, C.byref(ms)))
+        return buf.value.decode(), float(ms.value)
+
     def scan_stats(self, g=0):
         """how the flank scan of group g ran on the last batch: {flagged_pieces, total_pieces, kind}; kind 0 = full scan, 1 = filter +
         verification, 2 = the filter flagged too much of the batch and the full scan took over (bb_last_scan_stats)"""

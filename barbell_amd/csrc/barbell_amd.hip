@@ -432,10 +432,10 @@ int bb_create_policy(const bb_group_desc* groups, uint32_t n_groups, const bb_pa
     // The register-resident barcode kernels hard-wire Lodhi(3, 1/2) (exact power-of-two scaling: searcher.rs:209 pins both); their
     // traceback preference is a compile-time class (18 of them, one set of fast kernels each: bb_prio.h, bb_tu_class.hip), their
     // local-minimum rule, tie rule and decay exponents are run-time.  Another p or lambda runs the any-policy kernel k_barcode.
-    // The fast path's score bound counts one column per text op: an upper bound only while no text op's exponent is 0.
+    // The fast path's score bound advances the time by eM on a Match column and by min(eS, eI) on any other text column (its table is
+    // built from the policy's exponents): an upper bound under every setting of them.
     c->generic_barcode = c->policy.lodhi_p != 3 || c->policy.lodhi_lambda != 0.5;
     c->prio_class = bb_prio_class(BB_PRIO_PACK(c->policy.trace_prio[0], c->policy.trace_prio[1], c->policy.trace_prio[2], c->policy.trace_prio[3]));
-    if (c->policy.lodhi_exp[BB_OP_MATCH] == 0 || c->policy.lodhi_exp[BB_OP_SUB] == 0 || c->policy.lodhi_exp[BB_OP_INS] == 0) c->fast_path = false;
     c->force_generic = getenv("BARBELL_AMD_GENERIC") && atoi(getenv("BARBELL_AMD_GENERIC")) != 0;
     if (getenv("BARBELL_AMD_SCAN_FILTER")) c->scan_filter = atoi(getenv("BARBELL_AMD_SCAN_FILTER")) != 0 ? 1 : 0;
     if (getenv("BARBELL_AMD_NO_FAST") && atoi(getenv("BARBELL_AMD_NO_FAST")) != 0) c->fast_path = false;
@@ -496,6 +496,7 @@ void bb_destroy(bb_ctx* c) {
     bb_format_state_free(c->format);
     for (int i = 0; i <= K_COUNT; ++i)
         if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    for (auto& e : c->lev) { if (e.a) (void)hipEventDestroy(e.a); if (e.b) (void)hipEventDestroy(e.b); }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->side) (void)hipStreamDestroy(c->side);
@@ -559,7 +560,7 @@ int bb_annotate_batch_dev(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_o
         HIPCHK(c, hipMemsetAsync(c->d_hitcount, 0, 16, c->stream));
         HIPCHK(c, hipMemsetAsync(c->d_cnt + (M - 1), 0, 4, c->stream));
         for (uint32_t g = 0; g < G; ++g) {
-            bb_launch_scan(c, d_bases, d_offsets, n, g, flag_words, batch_bytes);
+            if ((r = bb_launch_scan(c, d_bases, d_offsets, n, g, flag_words, batch_bytes))) return r;
         }
         HIPCHK(c, hipGetLastError());
         mark(c, K_PREFIX);
@@ -611,6 +612,7 @@ int bb_annotate_batch_dev(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_o
                            c->d_rows, c->d_lists, c->cap_hits, c->d_listcnt, G, (const bb_group_dev*)c->d_groups);
     }
     mark(c, K_BARCODE);
+    c->n_lev = 0;
     if (prefix_aside) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
     if (n_hits) {
         if (any_split_prefix && !prefix_aside)  // shared rows of the padded barcodes, once per hit
@@ -671,8 +673,14 @@ int bb_annotate_batch_dev(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_o
     mark(c, K_COUNT);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (c->timing)
+    if (c->timing) {
         for (int i = 0; i < K_COUNT; ++i) (void)hipEventElapsedTime(&c->ms[i], c->ev[i], c->ev[i + 1]);
+        c->dom_ms = 0.f; c->dom_name[0] = 0;
+        for (uint32_t i = 0; i < c->n_lev; ++i) {
+            float t = 0.f;
+            if (hipEventElapsedTime(&t, c->lev[i].a, c->lev[i].b) == hipSuccess && t > c->dom_ms) { c->dom_ms = t; memcpy(c->dom_name, c->lev[i].name, sizeof c->dom_name); }
+        }
+    }
     return BB_OK;
 }
 
@@ -845,6 +853,12 @@ int bb_n_kernels(void) { return K_COUNT; }
 const char* bb_kernel_name(int k) { return k >= 0 && k < K_COUNT ? kKernelNames[k] : ""; }
 float bb_last_kernel_ms(const bb_ctx* c, int k) { return c && k >= 0 && k < K_COUNT ? c->ms[k] : 0.f; }
 void bb_set_timing(bb_ctx* c, int enable) { if (c) c->timing = enable != 0; }
+int bb_last_dominant_kernel(const bb_ctx* c, char* name, size_t name_cap, float* ms) {
+    if (!c || !name || !name_cap || !ms) return BB_E_INVALID;
+    snprintf(name, name_cap, "%s", c->dom_name);
+    *ms = c->dom_ms;
+    return BB_OK;
+}
 const char* bb_last_error(const bb_ctx* c) { return c ? c->last_error.c_str() : g_create_error.c_str(); }
 
 // ---- filter step (include/barbell_amd_filter.h) ---------------------------------------------------

@@ -107,6 +107,12 @@ struct bb_ctx {
     bool force_generic = false;  // BARBELL_AMD_GENERIC=1: use the generic (any-geometry) kernels, for tests
     hipEvent_t ev[K_COUNT + 1]{};
     float ms[K_COUNT]{};
+    // timing on: every launch of the barcode stage's main kernels between two events on ITS stream, named as rocprofv3 names it, so that the
+    // roofline's kernel is a kernel and not a stage (bb_last_dominant_kernel)
+    struct LaunchEv { hipEvent_t a = nullptr, b = nullptr; char name[72] = ""; };
+    LaunchEv lev[8 * BB_MAX_GROUPS];
+    uint32_t n_lev = 0;
+    float dom_ms = 0.f; char dom_name[72] = "";
     std::string last_error;
 };
 

@@ -237,26 +237,33 @@ __device__ __forceinline__ float lodhi_bound(unsigned long long plo, unsigned lo
     return sc * (1.0f + 1.0f / 16384.0f);
 }
 
-// The same bound, eight columns at a time.  Over the columns 8q+1 .. 8q+8 the recurrence is affine in (sc, b2, b1), and
-// with u2 = b2 / 2^8q, u1 = b1 / 2^8q its coefficients depend on the byte of Match bits only:
-//   sc += A u2 + B u1 + C;   u2 = (u2 + n u1 + D) / 256;   u1 = (u1 + E) / 256
-// (A = sum 2^-(r+1), B = sum 2^-(r+1) cnt(r), C = sum 2^-(r+1) P2(r) over the byte's Match positions r = 1..8, with cnt(r) the
-// Matches before r, P1(r) = sum of 2^r' over them, P2(r) = sum of P1 over them; n = all Matches, D = P2(9), E = P1(9)).
-// One 32-byte table entry and eight f32 operations per byte instead of nine instructions per column; the entries are
-// rounded up, every term is positive, fewer than 60 roundings enter a result: the (1 + 2^-14) scale keeps it a bound.
-struct __attribute__((aligned(32))) bb_lb_entry { float A, B, C, n, D, E, _p0, _p1; };
-__device__ __forceinline__ void lodhi_bound_table_entry(uint32_t byte, bb_lb_entry& e) {
-    double A = 0.0, B = 0.0, C = 0.0, D = 0.0, E = 0.0, cnt = 0.0, P1 = 0.0, P2 = 0.0;
+// The same bound, eight columns at a time, under the policy's decay exponents ([H8]; default 1 per op).  A text column advances the
+// time by its op's exponent: eM on a Match column, at least eX = min(eS, eI) on any other (the bound sees Match bits only: taking the
+// smaller of the two can only shorten spans); Del columns are dropped as before.  Over the columns 8q+1 .. 8q+8 the recurrence is
+// affine in (sc, b2, b1), and with u2 = b2 / 2^tau, u1 = b1 / 2^tau (tau = the time before the byte) its coefficients depend on the
+// byte of Match bits only:
+//   sc += A u2 + B u1 + C;   u2 = (u2 + n u1 + D) S;   u1 = (u1 + E) S
+// With s(r) = the time after position r of the byte: A = sum 2^-s(r), B = sum 2^-s(r) cnt(r), C = sum 2^-s(r) P2(r) over the byte's Match
+// positions r = 1..8, cnt(r) the Matches before r, P1(r) = sum of 2^(s(r') - eM) over them, P2(r) = sum of P1 over them; n = all
+// Matches, D = P2(9), E = P1(9), S = 2^-s(8) (1/256 for the default exponents).  Two 16-byte table reads and eight f32 operations per
+// byte instead of nine instructions per column; the entries are rounded up, every term is positive, fewer than 60 roundings enter a
+// result: the (1 + 2^-14) scale keeps it a bound.
+struct __attribute__((aligned(32))) bb_lb_entry { float A, B, C, n, D, E, S, _p1; };
+__device__ __forceinline__ void lodhi_bound_table_entry(uint32_t byte, uint32_t expk, bb_lb_entry& e) {
+    const int eM = (int)(expk & 0xFFu), eS = (int)((expk >> 8) & 0xFFu), eI = (int)((expk >> 16) & 0xFFu), eX = eS < eI ? eS : eI;
+    auto p2 = [](int k) -> double { return __hiloint2double((int)((uint32_t)(1023 + k) << 20), 0); };  // 2^k, |k| < 1023
+    double A = 0.0, B = 0.0, C = 0.0, cnt = 0.0, P1 = 0.0, P2 = 0.0;
+    int s = 0;
     for (int r = 1; r <= 8; ++r) {
         if ((byte >> (r - 1)) & 1u) {
-            const double w = __hiloint2double((int)((uint32_t)(1023 - (r + 1)) << 20), 0);  // 2^-(r+1)
+            s += eM;
+            const double w = p2(-s);
             A += w; B += w * cnt; C += w * P2;
-            P2 += P1; cnt += 1.0; P1 += (double)(1u << r);
-        }
+            P2 += P1; cnt += 1.0; P1 += p2(s - eM);
+        } else s += eX;
     }
-    D = P2; E = P1;
     e.A = __double2float_ru(A); e.B = __double2float_ru(B); e.C = __double2float_ru(C); e.n = (float)cnt;
-    e.D = __double2float_ru(D); e.E = __double2float_ru(E); e._p0 = 0.0f; e._p1 = 0.0f;
+    e.D = __double2float_ru(P2); e.E = __double2float_ru(P1); e.S = (float)p2(-s); e._p1 = 0.0f;
 }
 template <int CW>
 __device__ __forceinline__ float lodhi_bound_tab(unsigned long long plo, unsigned long long phi, int32_t tstart, int32_t best_pos, int wmax,
@@ -269,10 +276,10 @@ __device__ __forceinline__ float lodhi_bound_tab(unsigned long long plo, unsigne
         if (8 * q < wmax) {  // wave-uniform
             const uint32_t byte = (m_w[q >> 2] >> (8 * (q & 3))) & 0xFFu;
             const float4 t0 = *reinterpret_cast<const float4*>(&tab[byte].A);
-            const float2 t1 = *reinterpret_cast<const float2*>(&tab[byte].D);
+            const float4 t1 = *reinterpret_cast<const float4*>(&tab[byte].D);
             sc = __fmaf_rn(t0.x, u2, __fmaf_rn(t0.y, u1, sc + t0.z));
-            u2 = (__fmaf_rn(t0.w, u1, u2) + t1.x) * (1.0f / 256.0f);
-            u1 = (u1 + t1.y) * (1.0f / 256.0f);
+            u2 = (__fmaf_rn(t0.w, u1, u2) + t1.x) * t1.z;
+            u1 = (u1 + t1.y) * t1.z;
         }
     }
     return sc * (1.0f + 1.0f / 16384.0f);

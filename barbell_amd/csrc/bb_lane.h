@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256, CW <= 48 ? 3 : 2) void k_barcode_lane(const ui
             const int code = i / N, p = i - code * N;
             s_peq[p * 16 + code] = gp[i];
         }
-        for (uint32_t i = threadIdx.x; i < 256u; i += 256u) lodhi_bound_table_entry(i, s_lb[i]);
+        for (uint32_t i = threadIdx.x; i < 256u; i += 256u) lodhi_bound_table_entry(i, (uint32_t)G.pol_lodhi_exp, s_lb[i]);
     }
     // Which hit a lane takes: the block's 256 hits, those with windows of at most CW - 4 columns first.  A wave walks as many
     // column groups as its widest window needs; 99 % of the windows of SQK-NBD114-96 are 44 columns wide, but one 45-column window
@@ -354,6 +354,13 @@ __global__ __launch_bounds__(256, CW <= 48 ? 3 : 2) void k_barcode_lane(const ui
                 const uint4* hp4 = reinterpret_cast<const uint4*>(hits + hit_idx);
                 const uint4 h0 = cand ? hp4[0] : make_uint4(0u, 0u, 0u, 0u), h1 = cand ? hp4[1] : make_uint4(0u, 0u, 0u, 0u);
                 rows_decide(cand, W, h0, h1, hit_idx, bmax, groups, rows, min_score, min_score_diff, margin, fb_lists, list_stride, fb_cnt);
+                if (want && !cand) {  // cannot happen — the winner was a candidate in its own trip; should an edit ever break that, the hit goes to
+                                      // the exact kernel instead of keeping whatever an earlier batch left in its slot
+                    const uint32_t slot = 4u * g + (wn > 48 ? 2u : 0u) + strand;
+                    const uint32_t at = atomicAdd(&fb_cnt[slot], 1u);
+                    fb_lists[(size_t)slot * list_stride + at] = hit_idx;
+                    rows[hit_idx].row._pad[0] = 0;
+                }
             }
             return;
         }

@@ -2,6 +2,8 @@
 // kernels, k_barcode (any geometry), k_barcode_reg, the exact and 64-column variants of k_barcode_pfx.  The fast 48-column kernels are
 // instantiated per class of traceback orders in bb_tu_class.hip (bb_launch.h).
 #include <algorithm>
+#include <cstdarg>
+#include <cstdio>
 #include <cstdlib>
 
 #include "bb_launch.h"
@@ -21,6 +23,21 @@ const bb_class_unit& bb_class_unit_of(int cls) {
     static const bb_class_unit units[BB_PRIO_CLASSES] = {BB_FOR_CLASSES(BB_UNIT_ENTRY)};
     static const bb_class_unit none = {nullptr, nullptr};
     return cls >= 0 && cls < BB_PRIO_CLASSES ? units[cls] : none;
+}
+
+void bb_launch_timed_begin(bb_ctx* c, hipStream_t st, const char* fmt, ...) {
+    if (!c->timing || c->n_lev >= sizeof(c->lev) / sizeof(c->lev[0])) return;
+    bb_ctx::LaunchEv& e = c->lev[c->n_lev];
+    if (!e.a && (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess)) return;
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(e.name, sizeof e.name, fmt, ap);
+    va_end(ap);
+    (void)hipEventRecord(e.a, st);
+    ++c->n_lev;
+}
+void bb_launch_timed_end(bb_ctx* c, hipStream_t st) {
+    if (c->timing && c->n_lev) (void)hipEventRecord(c->lev[c->n_lev - 1].b, st);
 }
 
 // pass 0 of a split (group, strand): k_barcode_lane (which computes the shared rows itself) or k_barcode_pfx (which reads k_bar_prefix's
@@ -65,7 +82,10 @@ void launch_barcode_pfx(bb_ctx* c, uint32_t n_hits, uint32_t g, uint32_t strand,
         const size_t smem = (((size_t)N * 64 + 31) & ~(size_t)31) + 256 * 32 + 16 + (size_t)T * 2 * 256 * 8;
         const bb_lane_args a{(const uint8_t*)c->d_tables, (const bb_group_dev*)c->d_groups, g, strand, (const bb_hit*)c->d_hits, list, cnt, n_hits, c->d_rows,
                              c->params.min_score, c->params.min_score_diff, c->fast_margin, c->d_fb_lists, c->cap_hits, c->d_fbcnt};
-        if (U.lane(CW, T > 0, (n_hits + 255) / 256, smem, st, a)) { c->lane_used[g][strand] = 1; return; }
+        const uint32_t lev0 = c->n_lev;
+        bb_launch_timed_begin(c, st, "k_barcode_lane<%d, %s, %uu>", CW, T > 0 ? "true" : "false", BB_PRIO_TABLE.cls[c->prio_class]);
+        if (U.lane(CW, T > 0, (n_hits + 255) / 256, smem, st, a)) { bb_launch_timed_end(c, st); c->lane_used[g][strand] = 1; return; }
+        c->n_lev = lev0;
     }
     if (fast) ++c->pfx_fast_launches;  // these leave records for k_rows
     // CW = 48 fits 168 VGPRs -> 3 waves per SIMD: 768-thread blocks (8 hits x 96 barcodes use every lane); measured
@@ -93,7 +113,10 @@ void launch_barcode_pfx(bb_ctx* c, uint32_t n_hits, uint32_t g, uint32_t strand,
         const bb_pfx_args a{(const uint8_t*)c->d_tables, (const bb_group_dev*)c->d_groups, g, strand, (const bb_hit*)c->d_hits, (const bb_hit_pfx*)c->d_pfx, list,
                             cnt, n_hits, hpb, c->params.min_score, c->params.min_score_diff, c->d_rows};
         const bool defpol = c->policy.lm_rule == BB_LM_PLATEAU_RIGHT && c->policy.bar_tie == BB_TIE_FIRST;
-        if (U.pfx_fast(D.tail[strand] > 0, defpol, blocks, threads, smem, st, a)) return;
+        bb_launch_timed_begin(c, st, "k_barcode_pfx<48, %s, true, %s, %uu>", D.tail[strand] > 0 ? "true" : "false", defpol && c->prio_class == 0 ? "true" : "false",
+                              BB_PRIO_TABLE.cls[c->prio_class]);
+        if (U.pfx_fast(D.tail[strand] > 0, defpol, blocks, threads, smem, st, a)) { bb_launch_timed_end(c, st); return; }
+        --c->n_lev;
     }
 #define BB_PFX_ARGS (const uint8_t*)c->d_tables, (const bb_group_dev*)c->d_groups, g, strand, (const bb_hit*)c->d_hits, (const bb_hit_pfx*)c->d_pfx, list, \
                     cnt, n_hits, hpb, c->params.min_score, c->params.min_score_diff, c->d_rows
@@ -103,8 +126,10 @@ void launch_barcode_pfx(bb_ctx* c, uint32_t n_hits, uint32_t g, uint32_t strand,
             (void)hipFuncSetAttribute((const void*)k_barcode_pfx<CW, TAIL_, FAST_, false, BB_PRIO_RT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
         hipLaunchKernelGGL((k_barcode_pfx<CW, TAIL_, FAST_, false, BB_PRIO_RT>), dim3(blocks), dim3(threads), smem, st, BB_PFX_ARGS);   \
     } while (0)
+    bb_launch_timed_begin(c, st, "k_barcode_pfx<%d, %s, %s, false, %uu>", CW, D.tail[strand] > 0 ? "true" : "false", fast ? "true" : "false", (unsigned)BB_PRIO_RT);
     if (D.tail[strand] > 0) { if (fast) BB_PFX_LAUNCH(true, true); else BB_PFX_LAUNCH(true, false); }
     else { if (fast) BB_PFX_LAUNCH(false, true); else BB_PFX_LAUNCH(false, false); }
+    bb_launch_timed_end(c, st);
 #undef BB_PFX_LAUNCH
 #undef BB_PFX_ARGS
 }

@@ -17,7 +17,7 @@ int bb_scan_u32(bb_ctx* c, const uint32_t* in, uint32_t* out, uint64_t n) {
 
 namespace {
 template <int W>
-void launch_scan(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n, uint32_t g, uint64_t flag_words, uint64_t batch_bytes) {
+int launch_scan(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n, uint32_t g, uint64_t flag_words, uint64_t batch_bytes) {
     c->last_scan_kind[g] = 0; c->last_flagged[g] = 0; c->last_pieces[g] = 2 * ((batch_bytes + 15) / 16);
     if (c->gdev[g].filt_rows > 0) {
         (void)hipMemsetAsync(c->d_flags, 0, (size_t)2 * flag_words * sizeof(uint32_t), c->stream);  // the filter writes the words that hold a flag
@@ -33,38 +33,39 @@ void launch_scan(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets, u
         // and chimeric reads flag many), the full scan's does not.  Above the break-even (measured: DESIGN.md §4) the flags are
         // dropped and the full-height streaming scan does the batch.
         unsigned long long nf = 0;
-        (void)hipMemcpyAsync(&nf, c->d_nflag + g, sizeof(nf), hipMemcpyDeviceToHost, c->stream);
-        (void)hipStreamSynchronize(c->stream);
+        HIPCHK(c, hipMemcpyAsync(&nf, c->d_nflag + g, sizeof(nf), hipMemcpyDeviceToHost, c->stream));  // a failure must not be read as "no flags"
+        HIPCHK(c, hipStreamSynchronize(c->stream));
         c->last_flagged[g] = nf; c->last_scan_kind[g] = 1;
         if (c->scan_filter != 1 && (double)nf > c->adapt_frac * (double)c->last_pieces[g]) {
             c->last_scan_kind[g] = 2;
             hipLaunchKernelGGL(k_flank_scan2<W>, dim3((n + 255) / 256, 2), dim3(256), 0, c->stream, d_bases, d_offsets, n,
                                (const uint8_t*)c->d_tables, (const bb_group_dev*)c->d_groups, g, (uint32_t)c->groups.size(), c->d_cnt,
                                c->d_raw, c->cap_hits, c->d_hitcount);
-            return;
+            return BB_OK;
         }
         (void)hipMemsetAsync(c->d_vqueue, 0, 2 * sizeof(uint32_t), c->stream);
         const uint32_t vblocks = std::min((n + 255u) / 256u, (uint32_t)c->n_cus * 3u);  // persistent: lanes draw (read, strand) items from a queue
         hipLaunchKernelGGL(k_flank_verify<W>, dim3(vblocks, 2), dim3(256), 0, c->stream, d_bases, d_offsets, n,
                            (const uint8_t*)c->d_tables, (const bb_group_dev*)c->d_groups, g, (uint32_t)c->groups.size(),
                            (const uint32_t*)c->d_flags, flag_words, c->d_cnt, c->d_raw, c->cap_hits, c->d_hitcount, c->d_vqueue);
-        return;
+        return BB_OK;
     }
     hipLaunchKernelGGL(k_flank_scan2<W>, dim3((n + 255) / 256, 2), dim3(256), 0, c->stream, d_bases, d_offsets, n,
                        (const uint8_t*)c->d_tables, (const bb_group_dev*)c->d_groups, g, (uint32_t)c->groups.size(), c->d_cnt,
                        c->d_raw, c->cap_hits, c->d_hitcount);
+    return BB_OK;
 }
 }  // namespace
 
-void bb_launch_scan(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n, uint32_t g, uint64_t flag_words, uint64_t batch_bytes) {
+int bb_launch_scan(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n, uint32_t g, uint64_t flag_words, uint64_t batch_bytes) {
     switch (c->gdev[g].W) {
-        case 1: launch_scan<1>(c, d_bases, d_offsets, n, g, flag_words, batch_bytes); break;
-        case 2: launch_scan<2>(c, d_bases, d_offsets, n, g, flag_words, batch_bytes); break;
-        case 3: launch_scan<3>(c, d_bases, d_offsets, n, g, flag_words, batch_bytes); break;
-        case 4: launch_scan<4>(c, d_bases, d_offsets, n, g, flag_words, batch_bytes); break;
-        case 5: launch_scan<5>(c, d_bases, d_offsets, n, g, flag_words, batch_bytes); break;
-        case 6: launch_scan<6>(c, d_bases, d_offsets, n, g, flag_words, batch_bytes); break;
-        case 7: launch_scan<7>(c, d_bases, d_offsets, n, g, flag_words, batch_bytes); break;
-        default: launch_scan<8>(c, d_bases, d_offsets, n, g, flag_words, batch_bytes); break;
+        case 1: return launch_scan<1>(c, d_bases, d_offsets, n, g, flag_words, batch_bytes);
+        case 2: return launch_scan<2>(c, d_bases, d_offsets, n, g, flag_words, batch_bytes);
+        case 3: return launch_scan<3>(c, d_bases, d_offsets, n, g, flag_words, batch_bytes);
+        case 4: return launch_scan<4>(c, d_bases, d_offsets, n, g, flag_words, batch_bytes);
+        case 5: return launch_scan<5>(c, d_bases, d_offsets, n, g, flag_words, batch_bytes);
+        case 6: return launch_scan<6>(c, d_bases, d_offsets, n, g, flag_words, batch_bytes);
+        case 7: return launch_scan<7>(c, d_bases, d_offsets, n, g, flag_words, batch_bytes);
+        default: return launch_scan<8>(c, d_bases, d_offsets, n, g, flag_words, batch_bytes);
     }
 }

@@ -880,13 +880,26 @@ namespace {
 // back over those few lines, and copies the short tail into the next slot's headroom — exactly the `consumed` the GPU
 // parser (bb_fastq_ingest) would have reported, without waiting for it, so block i+1 can go to another GPU while block i
 // is still being parsed.  The last block of a file is handed over whole (the parser's final-block rules apply to it).
+// What a reader reports about the lines of one chunk it compacted (two-line mode), so that the sequencer can check what the GPU parser
+// checks in the 4-line form — a record's sequence and quality lines are equally long, the file ends on a record boundary — although the
+// quality lines never leave the host.  Pairs that lie inside the chunk are compared by the reader; what crosses a chunk boundary is
+// stitched from these fields, in order (BlockFeeder::stitch).  Line lengths exclude the line end ("\n" or "\r\n").
+struct TwoLineSummary {
+    size_t head_raw = 0; uint8_t head_last = 0;   // bytes before the chunk's first '\n' (the whole chunk if it has none), the last of them
+    size_t tail_raw = 0; uint8_t tail_last = 0;   // bytes after its last '\n' (a line that ends in a later chunk, or at the end of the file)
+    int64_t len1 = -1, len2 = -1;                 // lengths of the second and third line that END in the chunk
+    int64_t pend = -1;                            // length of the last sequence line, not the chunk's first line, whose quality line does not end in the chunk
+    bool pend_cleared = false;                    // some quality line other than the chunk's first two lines ends in the chunk: nothing older is pending after it
+    int64_t last2[2] = {-1, -1};                  // lengths of the last two lines that end in the chunk (-2: that line is the chunk's first)
+};
+
 struct BlockFeeder {
     struct Block { uint64_t index = 0; const uint8_t* data = nullptr; size_t len = 0; int slot = -1; std::shared_ptr<std::vector<uint8_t>> big; };
     struct Task { size_t file = 0; uint64_t off = 0; size_t len = 0; uint64_t seq = 0; bool last = false; const uint8_t* mem = nullptr; };
     struct Slot { uint8_t* p = nullptr; size_t cap = 0, got = 0, nl = 0; bool last = false; int state = 0; uint64_t seq = 0; int refs = 0; size_t file = 0;
                   // two-line mode: raw newlines of the chunk, the phase (line index mod 4) the reader took its first byte to be in
                   // (-1: none recognisable), where the raw bytes came from (to redo the chunk if the guess was wrong), malformed flag
-                  size_t raw_nl = 0; int phase0 = 0; uint64_t off = 0; size_t raw_len = 0; bool bad = false; };
+                  size_t raw_nl = 0; int phase0 = 0; uint64_t off = 0; size_t raw_len = 0; bool bad = false; TwoLineSummary sum; };
     size_t HEAD = 16u << 20;  // BARBELL_AMD_HEAD_BYTES overrides it (tests of the over-long-carry path)
     bb_ctx* ctx;
     std::vector<std::string> paths;
@@ -920,6 +933,9 @@ struct BlockFeeder {
     bool two_line = false;
     size_t lpr = 4;                       // lines per record in the staged text
     size_t seq_file = (size_t)-1; uint64_t seq_raw_lines = 0;   // sequencer: file in hand, its raw lines so far
+    // stitch(): a line in progress across chunk ends, the sequence length waiting for its quality line, the last two lines' lengths
+    size_t st_part = 0; uint8_t st_part_last = 0; int64_t st_pend = -1, st_last2[2] = {-1, -1};
+    void stitch(const Slot& sl, int ph0);
 
     BlockFeeder(bb_ctx* c, const std::vector<std::string>& files, size_t chunk_bytes, unsigned n_slots, unsigned n_readers, unsigned n_inflate,
                 bool two_line_mode = false);
@@ -1165,15 +1181,33 @@ struct LabelWriters {  // the per-label writers of trim_matches (trim.rs:356-446
 // keeps the bytes of the lines in phase 0 and 1 (header, sequence) of a chunk whose first byte lies in a line of phase ph0; in
 // place when out == buf (the write position never passes the read position), or straight from a mapping of the file.  nl_kept / nl_all: newlines kept / seen; bad: a line that starts
 // inside the chunk in phase 0 / 2 does not start with '@' / '+'.
-static size_t compact_two_line(uint8_t* out, const uint8_t* buf, size_t n, int ph0, size_t& nl_kept, size_t& nl_all, bool& bad) {
+static size_t compact_two_line(uint8_t* out, const uint8_t* buf, size_t n, int ph0, size_t& nl_kept, size_t& nl_all, bool& bad, TwoLineSummary& S) {
     size_t d = 0, p = 0;
     int ph = ph0 & 3;
     bool line_start = false;  // the first line may be the tail of one that began in the previous chunk
     nl_kept = nl_all = 0; bad = false;
+    S = TwoLineSummary();
+    int64_t seq_len = -1;     // the sequence line of the record in hand, if it began in this chunk after the first line
     while (p < n) {
         if (line_start && ((ph == 0 && buf[p] != '@' && buf[p] != '\n' && buf[p] != '\r') || (ph == 2 && buf[p] != '+'))) bad = true;
         const uint8_t* q = (const uint8_t*)memchr(buf + p, '\n', n - p);
         const size_t e = q ? (size_t)(q - buf) + 1 : n;
+        if (q) {
+            const size_t raw = (size_t)(q - buf) - p;   // without the '\n'
+            if (nl_all == 0) { S.head_raw = raw; S.head_last = raw ? buf[p + raw - 1] : 0; S.last2[1] = -2; }
+            else {
+                const int64_t len = (int64_t)raw - (raw && buf[p + raw - 1] == '\r' ? 1 : 0);
+                if (nl_all == 1) S.len1 = len;
+                if (nl_all == 2) S.len2 = len;
+                if (ph == 1) seq_len = len;
+                if (ph == 3) {
+                    if (seq_len >= 0) { if (seq_len != len) bad = true; }   // both lines of the pair inside the chunk
+                    if (nl_all >= 3 || seq_len >= 0) S.pend_cleared = true;
+                    seq_len = -1;
+                }
+                S.last2[0] = S.last2[1]; S.last2[1] = len;
+            }
+        } else { S.tail_raw = n - p; S.tail_last = buf[n - 1]; if (nl_all == 0) { S.head_raw = n - p; S.head_last = buf[n - 1]; } }
         if (ph < 2) {
             if (out + d != buf + p) memmove(out + d, buf + p, e - p);
             d += e - p;
@@ -1182,7 +1216,47 @@ static size_t compact_two_line(uint8_t* out, const uint8_t* buf, size_t n, int p
         if (q) { ++nl_all; ph = (ph + 1) & 3; line_start = true; }
         p = e;
     }
+    S.pend = seq_len;
     return d;
+}
+// The sequencer's half of the two-line mode's record checks: the chunks' summaries in stream order (their first byte in phase ph0 of its file).
+void BlockFeeder::stitch(const Slot& sl, int ph0) {
+    const TwoLineSummary& S = sl.sum;
+    auto fail = [&](const char* what) {
+        throw BarbellError(BB_E_FASTQ, "Input FASTQ parsing failed: '" + paths[sl.file] + "' " + what);
+    };
+    if (sl.raw_nl == 0) {   // no line ends here: the chunk continues the line in progress
+        if (sl.raw_len) { st_part += S.head_raw; st_part_last = S.head_last; }
+    } else {
+        const size_t raw0 = st_part + S.head_raw;
+        const uint8_t last0 = S.head_raw ? S.head_last : st_part_last;
+        const int64_t L0 = (int64_t)raw0 - (raw0 && last0 == '\r' ? 1 : 0);
+        if (ph0 == 1) st_pend = L0;
+        if (ph0 == 3) { if (st_pend >= 0 && st_pend != L0) fail("holds a record whose quality line is not as long as its sequence"); st_pend = -1; }
+        if (ph0 == 2 && sl.raw_nl >= 2) { if (st_pend >= 0 && st_pend != S.len1) fail("holds a record whose quality line is not as long as its sequence"); st_pend = -1; }
+        if (ph0 == 1 && sl.raw_nl >= 3) { if (L0 != S.len2) fail("holds a record whose quality line is not as long as its sequence"); st_pend = -1; }
+        if (S.pend_cleared) st_pend = -1;
+        if (S.pend >= 0) st_pend = S.pend;
+        // the last two lines that have ended, for the check at the end of the file
+        const int64_t a = S.last2[0] == -2 ? L0 : S.last2[0], b = S.last2[1] == -2 ? L0 : S.last2[1];
+        if (sl.raw_nl >= 2) { st_last2[0] = a; st_last2[1] = b; } else { st_last2[0] = st_last2[1]; st_last2[1] = b; }
+        st_part = S.tail_raw; st_part_last = S.tail_last;
+    }
+    if (sl.last) {  // the file's end: a last line without '\n' counts; at most two blank lines may follow the last record (the GPU parser ignores them)
+        uint64_t lines = seq_raw_lines + sl.raw_nl;
+        int64_t tail_len = -1;
+        if (st_part) { tail_len = (int64_t)st_part - (st_part_last == '\r' ? 1 : 0); ++lines; }
+        const int r = (int)(lines & 3u);
+        if (r == 0) {
+            if (tail_len >= 0 && st_pend >= 0 && st_pend != tail_len) fail("holds a record whose quality line is not as long as its sequence");
+        } else {
+            // r surplus lines: they must all be blank
+            const int64_t l1 = tail_len >= 0 ? tail_len : st_last2[1], l2 = tail_len >= 0 ? st_last2[1] : st_last2[0];
+            const bool blank = r == 1 ? l1 == 0 : (r == 2 ? l1 == 0 && l2 == 0 : false);
+            if (!blank) fail("ends inside a record (truncated file?)");
+        }
+        st_part = 0; st_part_last = 0; st_pend = -1; st_last2[0] = st_last2[1] = -1;
+    }
 }
 // phase of a chunk's first byte, read off the text: the first line that starts with '@' and has a line starting with '+' two
 // lines below is a header (phase 0); -1 if no such pair is found among the chunk's first lines
@@ -1312,13 +1386,21 @@ void BlockFeeder::reader_loop() {
             uint8_t* dst = sl.p + HEAD;
             const uint8_t* src = nullptr;   // the chunk's raw bytes where they can be read in place (inflated image, mapped file)
             if (is_gz[t.file]) src = inflater->get(t.file).data() + t.off;
-            else if (maps[t.file]) src = maps[t.file] + t.off;
+            else if (maps[t.file]) {
+                // a mapped file that has been truncated since it was opened would fault (SIGBUS) when its lost pages are touched: look at its
+                // size again before every chunk and fail like the pread path does (a file cut while a chunk is being read is still a race)
+                struct stat stn;
+                if (fstat(fds[t.file], &stn) != 0 || (uint64_t)stn.st_size < t.off + t.len)
+                    throw BarbellError(BB_E_INVALID, "FASTQ file '" + paths[t.file] + "' shrank while it was read");
+                src = maps[t.file] + t.off;
+            }
             size_t got_len = t.len, nl = 0, raw_nl = 0;
             int ph0 = 0;
             bool bad = false;
+            TwoLineSummary sum;
             if (two_line && src) {
                 ph0 = guess_phase(src, t.len, t.off == 0);
-                if (ph0 >= 0) got_len = compact_two_line(dst, src, t.len, ph0, nl, raw_nl, bad);
+                if (ph0 >= 0) got_len = compact_two_line(dst, src, t.len, ph0, nl, raw_nl, bad, sum);
                 else { if (t.len) memcpy(dst, src, t.len); raw_nl = count_nl(dst, t.len); }   // left raw: the sequencer compacts it with the true phase
             } else {
                 if (src) { if (t.len) memcpy(dst, src, t.len); }
@@ -1333,7 +1415,7 @@ void BlockFeeder::reader_loop() {
                 }
                 if (two_line) {
                     ph0 = guess_phase(dst, t.len, t.off == 0);
-                    if (ph0 >= 0) got_len = compact_two_line(dst, dst, t.len, ph0, nl, raw_nl, bad);
+                    if (ph0 >= 0) got_len = compact_two_line(dst, dst, t.len, ph0, nl, raw_nl, bad, sum);
                     else raw_nl = count_nl(dst, t.len);
                 } else nl = count_nl(dst, t.len);
             }
@@ -1345,7 +1427,7 @@ void BlockFeeder::reader_loop() {
             {
                 std::lock_guard<std::mutex> lk(mu);
                 sl.got = got_len; sl.nl = nl; sl.last = t.last; sl.file = t.file; sl.raw_nl = raw_nl; sl.phase0 = ph0; sl.off = t.off; sl.raw_len = t.len;
-                sl.bad = bad; sl.state = 2;
+                sl.bad = bad; sl.sum = sum; sl.state = 2;
             }
             cv.notify_all();
         }
@@ -1393,9 +1475,10 @@ bool BlockFeeder::next(Block& b) {
                         }
                     }
                 }
-                sl->got = compact_two_line(body, body, sl->raw_len, truth, sl->nl, sl->raw_nl, sl->bad);
+                sl->got = compact_two_line(body, body, sl->raw_len, truth, sl->nl, sl->raw_nl, sl->bad, sl->sum);
             }
             if (sl->bad) throw BarbellError(BB_E_FASTQ, "Input FASTQ parsing failed: '" + paths[sl->file] + "' holds a record that is not a 4-line FASTQ record");
+            stitch(*sl, truth);
             seq_raw_lines += sl->raw_nl;
         }
         size_t cut = sl->got;  // bytes of this chunk that go into this block

@@ -161,6 +161,10 @@ int         bb_n_kernels(void);
 const char* bb_kernel_name(int k);
 float       bb_last_kernel_ms(const bb_ctx* ctx, int k);
 void        bb_set_timing(bb_ctx* ctx, int enable);
+/* With timing on: the longest single kernel launch of the last batch's barcode stage (searcher.rs:267-426) — its name as rocprofv3
+ * prints it, e.g. "k_barcode_lane<48, false, 216u>", and its duration between two events on the stream it was launched on (launches
+ * on the second stream overlap it; the stage's time is bb_last_kernel_ms's "k_barcode").  Empty name: no such launch.             */
+int         bb_last_dominant_kernel(const bb_ctx* ctx, char* name, size_t name_cap, float* ms);
 
 /* How the flank scan (searcher.rs:438) of group `group` ran on the last batch: kind 0 = full-height scan of every column, 1 = 15/31-row
  * filter + full-height verification around the flagged 16-byte pieces, 2 = the filter flagged more than the break-even

@@ -50,7 +50,7 @@ ALTERNATIVES = {   # hazard -> the non-default settings (the default is the firs
     "H5": ["rcpath=mirror"],
     "H4": ["ovh=ceil", "ovh=near", "ovh=floor:f64", "ovh=ceil:f64"],
     "H7": ["tie=last"],
-    "H8": ["lodhi=3:0.5:2211", "lodhi=3:0.5:1110", "lodhi=2:0.5:1111", "lodhi=3:0.7:1111", "lodhi=4:0.5:1111"],
+    "H8": ["lodhi=3:0.5:2211", "lodhi=3:0.5:1110", "lodhi=3:0.5:2131", "lodhi=2:0.5:1111", "lodhi=3:0.7:1111", "lodhi=4:0.5:1111"],
 }
 GPU_POLICIES = [a for alts in ALTERNATIVES.values() for a in alts] + [
     "lm=left,rc=fwd,trace=MSID,ovh=ceil,tie=last,lodhi=3:0.5:2211,rcpath=mirror",      # everything at once, register-resident Lodhi family

@@ -419,6 +419,40 @@ def test_cli_drops_quality_lines_that_look_like_headers(tmp_path):
     for extra in ([], ["--no-compact"]):
         r = subprocess.run([CLI, "annotate", "-i", str(bad), "-o", str(tmp_path / "b.tsv"), "--kit", "SQK-NBD114-96"] + extra, capture_output=True, text=True, env=env)
         assert r.returncode == 1 and "FASTQ" in r.stderr
+    # What the GPU parser checks in the 4-line form holds in the two-line form too, where the quality lines never leave the host: a quality
+    # line as long as its sequence, a file that ends on a record boundary (interrupted copies are common).  Whatever the chunk size — the
+    # pair of lines may lie in different chunks — and in either mode.
+    text = fq.read_bytes()
+    recs = text.split(b"\n@t")          # record i starts with "@t<i>" (the first keeps its '@')
+    cases = {}
+    for i in (0, 3, 350, n - 1):         # a quality line one character short: first record, a CRLF-free one, mid-file, the last
+        r = recs[i]
+        cr = r.endswith(b"\r") or r.endswith(b"\r\n")
+        body = r.rstrip(b"\r\n")
+        short = body[:-1] + (b"\r\n" if cr else b"\n") if i == n - 1 else body[:-1] + (b"\r" if cr else b"")
+        cases["short_q_%d" % i] = b"\n@t".join(recs[:i] + [short] + recs[i + 1:])
+    last = text.rfind(b"\n@t") + 1
+    rec = text[last:]
+    lines = rec.split(b"\n")
+    cases["cut_mid_sequence"] = text[:last] + lines[0] + b"\n" + lines[1][: len(lines[1]) // 2]
+    cases["cut_after_plus"] = text[:last] + lines[0] + b"\n" + lines[1] + b"\n" + lines[2] + b"\n"
+    cases["cut_mid_quality"] = text[: len(text) - 40]
+    cases["cut_after_header"] = text[:last] + lines[0] + b"\n"
+    for name, data in cases.items():
+        p = tmp_path / (name + ".fastq")
+        p.write_bytes(data)
+        for extra in ([], ["--no-compact"], ["--block-bytes", "4096"], ["--block-bytes", "1500", "-t", "3"]):
+            r = subprocess.run([CLI, "annotate", "-i", str(p), "-o", str(tmp_path / "b.tsv"), "--kit", "SQK-NBD114-96"] + extra, capture_output=True, text=True, env=env)
+            assert r.returncode == 1 and "FASTQ" in r.stderr, (name, extra, r.returncode, r.stderr[-300:])
+    # still fine: no final newline, a blank line after the last record
+    for name, data in (("no_final_newline", text.rstrip(b"\r\n")), ("one_blank", text + b"\n"), ("one_blank_crlf", text + b"\r\n")):
+        p = tmp_path / (name + ".fastq")
+        p.write_bytes(data)
+        for extra in ([], ["--block-bytes", "1500"], ["--no-compact"]):
+            o = tmp_path / "ok.tsv"
+            r = subprocess.run([CLI, "annotate", "-i", str(p), "-o", str(o), "--kit", "SQK-NBD114-96", "--flank-max-errors", "3"] + extra, capture_output=True, text=True, env=env)
+            assert r.returncode == 0, (name, extra, r.stderr[-300:])
+            assert o.read_bytes() == outs[0], (name, extra)
 
 
 @pytest.mark.gpu

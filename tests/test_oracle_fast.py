@@ -24,7 +24,8 @@ def test_fast_equals_scalar(cfg, n, lmin, lmax, rate):
 
 
 @pytest.mark.parametrize("kw", [dict(alpha=0.0), dict(alpha=1.0), dict(policy="lm=left,tie=last,ovh=ceil,rc=fwd,lodhi=3:0.5:2211"),
-                                dict(policy="lm=strict,ovh=near:f64"), dict(policy="trace=MSID")])
+                                dict(policy="lm=strict,ovh=near:f64"), dict(policy="trace=MSID"),
+                                dict(policy="trace=DSIM"), dict(policy="trace=MIDS,rcpath=mirror"), dict(policy="trace=IDMS,lodhi=3:0.5:2131"), dict(policy="trace=MDSI")])
 def test_fast_equals_scalar_variants(kw):
     groups, bases, offsets = noisy_reads("nbd96", 7, 400, 1, 700, 0.06)
     o = po.Oracle([g.as_tuple() for g in groups], **kw)

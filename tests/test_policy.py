@@ -251,6 +251,28 @@ def test_every_barcode_kernel_under_other_trace_orders(monkeypatch, pol, knob):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("pol", ["lodhi=3:0.5:1011", "lodhi=3:0.5:1101", "lodhi=3:0.5:0111", "lodhi=3:0.5:3302,trace=MDIS"])
+def test_fast_path_with_zero_and_unequal_decay_exponents(pol):
+    """The fast path's bound is built from the policy's exponents (lodhi_bound_table_entry: eM on Match columns, min(eS, eI) on the other
+    text columns) and stays an upper bound when an exponent is 0 or the two differ — looser then (more hits go on to the exact kernel), never
+    wrong.  Not among the bench's policy variants: no reading of a Lodhi kernel makes a substituted column free and an inserted one not."""
+    from barbell_amd import annotate as A
+    from tests.test_gpu_parity import assert_same
+    from tests.common import noisy_reads
+
+    for cfg, n, rate in (("nbd96", 800, 0.08), ("rbk96x", 150, 0.04)):
+        groups, bases, offsets = noisy_reads(cfg, 99, n, 300, 2500, rate)
+        dm = A.Demuxer(policy=pol)
+        for g in groups:
+            dm.add_query_group(g)
+        got = dm.demux_packed(bases, offsets)
+        want = po.Oracle([g.as_tuple() for g in groups], policy=pol).annotate(bases, offsets, n_threads=NT)
+        assert len(want) > n // 4
+        assert_same(got, want)
+        dm.close()
+
+
+@pytest.mark.gpu
 def test_no_trace_order_leaves_the_fast_kernels():
     """bb_last_barcode_stats: under every one of the 18 classes the SQK-NBD114-96 hits are decided by k_barcode_lane (the any-policy
     kernel k_barcode is for Lodhi p / lambda other than (3, 0.5) only)."""
