@@ -110,7 +110,7 @@ def main():
     d_bases = torch.empty(n_res * L, dtype=torch.uint8, device=dev)
     torch.cuda.synchronize()
     dm.synth_dev(SEED, L, L, first_read, n_res, d_off.data_ptr(), d_bases.data_ptr())
-    rows_cap = 4 * batch
+    rows_cap = (4 if args.config == "nbd96" else 6) * batch
     d_rows = torch.empty(rows_cap * 48, dtype=torch.uint8, device=dev)
     # per-batch offsets must start at the batch's own base pointer
     d_off_b = d_off[: batch + 1].contiguous()

@@ -28,7 +28,10 @@ for k in acc:
         continue
     f = acc[k]["FETCH_SIZE"] / max(1, calls[k]["FETCH_SIZE"])
     w = acc[k]["WRITE_SIZE"] / max(1, calls[k]["WRITE_SIZE"])
-    per_step = {"k_scan_block": 2, "k_scan_sums": 2, "k_scan_add": 2}.get(k, 1)
+    # launches per step from the data: k_collapse runs exactly once per step (multi-group configs launch the scan kernels per group,
+    # the barcode kernels per (group, strand))
+    steps_seen = max(1, calls.get("k_collapse", {}).get("FETCH_SIZE", 0))
+    per_step = max(1, round(calls[k]["FETCH_SIZE"] / steps_seen)) if "k_collapse" in calls else {"k_scan_block": 2, "k_scan_sums": 2, "k_scan_add": 2}.get(k, 1)
     # kernels of bench.py's filter / trim / ingest legs (outside the timed annotate step) are listed but not part of the step
     in_step = not (k.startswith(("k_filter", "k_rs_", "k_scan32", "k_scan64", "k_scan_sums_t", "k_trim", "k_fq_", "k_nl_", "k_fmt", "k_inspect", "k_iota")))
     res["kernels"][k] = {"launches_seen": calls[k]["FETCH_SIZE"], "launches_per_step": per_step, "FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w,
