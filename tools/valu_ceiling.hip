@@ -25,14 +25,14 @@
 
 enum Op {
     OP_BITOP3, OP_AND, OP_ADD, OP_ADDCO_PAIR, OP_LSHL_OR, OP_ALIGNBIT, OP_ADD3, OP_OR3, OP_MAD24, OP_BCNT, OP_LSHL, OP_LSHL64,
-    OP_CNDMASK, OP_BFREV, OP_MOV, OP_ADD_F64, OP_FMA_F64, OP_DS_READ_B32, OP_DS_READ_B64, OP_LSHL_ADD_U64, OP_XAD, OP_CMP_CND, OP_BFE, OP_AND_SDWA, OP_ADD_SDWA, OP_ADDCO, OP_ADDC, OP_FFBH, OP_CMP, OP_AND_OR, OP_LSHR, OP_NOT, OP_SUB, OP_MIN, OP_OR, OP_XNOR, OP_BFI, OP_PERM, OP_LSHLADD, OP_MYERS2, OP_COUNT
+    OP_CNDMASK, OP_BFREV, OP_MOV, OP_ADD_F64, OP_FMA_F64, OP_DS_READ_B32, OP_DS_READ_B64, OP_LSHL_ADD_U64, OP_XAD, OP_CMP_CND, OP_BFE, OP_AND_SDWA, OP_ADD_SDWA, OP_ADDCO, OP_ADDC, OP_FFBH, OP_CMP, OP_AND_OR, OP_LSHR, OP_NOT, OP_SUB, OP_MIN, OP_OR, OP_XNOR, OP_BFI, OP_PERM, OP_LSHLADD, OP_PK_ADD16, OP_PK_SUB16, OP_PK_LSHL16, OP_PK_LSHR16, OP_LSHL_SDWA, OP_MYERS2, OP_COUNT
 };
 static const char* const kOpName[OP_COUNT] = {
     "v_bitop3_b32", "v_and_b32", "v_add_u32", "v_add_co_u32+v_addc_co_u32", "v_lshl_or_b32", "v_alignbit_b32", "v_add3_u32", "v_or3_b32",
     "v_mad_u32_u24", "v_bcnt_u32_b32", "v_lshlrev_b32", "v_lshlrev_b64", "v_cndmask_b32", "v_bfrev_b32", "v_mov_b32", "v_add_f64",
-    "v_fma_f64", "ds_read_b32", "ds_read_b64", "v_lshl_add_u64", "v_xad_u32", "v_cmp_ne_u32+v_cndmask_b32", "v_bfe_u32", "v_and_b32_sdwa(byte_sel)", "v_add_u32_sdwa(word_sel)", "v_add_co_u32(alone)", "v_addc_co_u32(alone)", "v_ffbh_u32", "v_cmp_lt_i32(vcc)", "v_and_or_b32", "v_lshrrev_b32", "v_not_b32", "v_sub_u32", "v_min_i32", "v_or_b32", "v_xnor_b32", "v_bfi_b32", "v_perm_b32", "v_lshl_add_u32", "myers_step<2> + move_bits (C++, 27 VALU)"};
+    "v_fma_f64", "ds_read_b32", "ds_read_b64", "v_lshl_add_u64", "v_xad_u32", "v_cmp_ne_u32+v_cndmask_b32", "v_bfe_u32", "v_and_b32_sdwa(byte_sel)", "v_add_u32_sdwa(word_sel)", "v_add_co_u32(alone)", "v_addc_co_u32(alone)", "v_ffbh_u32", "v_cmp_lt_i32(vcc)", "v_and_or_b32", "v_lshrrev_b32", "v_not_b32", "v_sub_u32", "v_min_i32", "v_or_b32", "v_xnor_b32", "v_bfi_b32", "v_perm_b32", "v_lshl_add_u32", "v_pk_add_u16", "v_pk_sub_u16", "v_pk_lshlrev_b16", "v_pk_lshrrev_b16", "v_lshlrev_b32_sdwa(byte_sel)", "myers_step<2> + move_bits (C++, 27 VALU)"};
 // instructions per asm instance (the add/addc pair counts two)
-static const int kOpInstr[OP_COUNT] = {1, 1, 1, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1};
+static const int kOpInstr[OP_COUNT] = {1, 1, 1, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1};
 
 #define A1(INS) asm volatile(INS : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h), "+v"(p), "+v"(q), "+v"(r), "+v"(s) : "v"(x), "v"(y) : "vcc")
 
@@ -188,6 +188,21 @@ __global__ void k_issue(uint32_t* __restrict__ out, int iters, unsigned long lon
         } else if constexpr (OP == OP_LSHLADD) {
             if constexpr (DEP) { I_DEP("v_lshl_add_u32 %0, %0, 1, %12") }
             else { I_IND("v_lshl_add_u32 %0, %0, 1, %12", "v_lshl_add_u32 %1, %1, 1, %12", "v_lshl_add_u32 %2, %2, 1, %12", "v_lshl_add_u32 %3, %3, 1, %12", "v_lshl_add_u32 %4, %4, 1, %12", "v_lshl_add_u32 %5, %5, 1, %12", "v_lshl_add_u32 %6, %6, 1, %12", "v_lshl_add_u32 %7, %7, 1, %12") }
+        } else if constexpr (OP == OP_PK_ADD16) {
+            if constexpr (DEP) { I_DEP("v_pk_add_u16 %0, %0, %12") }
+            else { I_IND("v_pk_add_u16 %0, %0, %12", "v_pk_add_u16 %1, %1, %12", "v_pk_add_u16 %2, %2, %12", "v_pk_add_u16 %3, %3, %12", "v_pk_add_u16 %4, %4, %12", "v_pk_add_u16 %5, %5, %12", "v_pk_add_u16 %6, %6, %12", "v_pk_add_u16 %7, %7, %12") }
+        } else if constexpr (OP == OP_PK_SUB16) {
+            if constexpr (DEP) { I_DEP("v_pk_sub_u16 %0, %0, %12") }
+            else { I_IND("v_pk_sub_u16 %0, %0, %12", "v_pk_sub_u16 %1, %1, %12", "v_pk_sub_u16 %2, %2, %12", "v_pk_sub_u16 %3, %3, %12", "v_pk_sub_u16 %4, %4, %12", "v_pk_sub_u16 %5, %5, %12", "v_pk_sub_u16 %6, %6, %12", "v_pk_sub_u16 %7, %7, %12") }
+        } else if constexpr (OP == OP_PK_LSHL16) {
+            if constexpr (DEP) { I_DEP("v_pk_lshlrev_b16 %0, 1, %0 op_sel_hi:[0,1]") }
+            else { I_IND("v_pk_lshlrev_b16 %0, 1, %0 op_sel_hi:[0,1]", "v_pk_lshlrev_b16 %1, 1, %1 op_sel_hi:[0,1]", "v_pk_lshlrev_b16 %2, 1, %2 op_sel_hi:[0,1]", "v_pk_lshlrev_b16 %3, 1, %3 op_sel_hi:[0,1]", "v_pk_lshlrev_b16 %4, 1, %4 op_sel_hi:[0,1]", "v_pk_lshlrev_b16 %5, 1, %5 op_sel_hi:[0,1]", "v_pk_lshlrev_b16 %6, 1, %6 op_sel_hi:[0,1]", "v_pk_lshlrev_b16 %7, 1, %7 op_sel_hi:[0,1]") }
+        } else if constexpr (OP == OP_PK_LSHR16) {
+            if constexpr (DEP) { I_DEP("v_pk_lshrrev_b16 %0, 15, %0 op_sel_hi:[0,1]") }
+            else { I_IND("v_pk_lshrrev_b16 %0, 15, %0 op_sel_hi:[0,1]", "v_pk_lshrrev_b16 %1, 15, %1 op_sel_hi:[0,1]", "v_pk_lshrrev_b16 %2, 15, %2 op_sel_hi:[0,1]", "v_pk_lshrrev_b16 %3, 15, %3 op_sel_hi:[0,1]", "v_pk_lshrrev_b16 %4, 15, %4 op_sel_hi:[0,1]", "v_pk_lshrrev_b16 %5, 15, %5 op_sel_hi:[0,1]", "v_pk_lshrrev_b16 %6, 15, %6 op_sel_hi:[0,1]", "v_pk_lshrrev_b16 %7, 15, %7 op_sel_hi:[0,1]") }
+        } else if constexpr (OP == OP_LSHL_SDWA) {
+            if constexpr (DEP) { I_DEP("v_lshlrev_b32_sdwa %0, %13, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1") }
+            else { I_IND("v_lshlrev_b32_sdwa %0, %13, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1", "v_lshlrev_b32_sdwa %1, %13, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1", "v_lshlrev_b32_sdwa %2, %13, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1", "v_lshlrev_b32_sdwa %3, %13, %3 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1", "v_lshlrev_b32_sdwa %4, %13, %4 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1", "v_lshlrev_b32_sdwa %5, %13, %5 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1", "v_lshlrev_b32_sdwa %6, %13, %6 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1", "v_lshlrev_b32_sdwa %7, %13, %7 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1") }
         } else if constexpr (OP == OP_DS_READ_B32) {
             if constexpr (DEP) { I_DEP("ds_read_b32 %0, %0\n s_waitcnt lgkmcnt(0)") }
             else { A1(R8("ds_read_b32 %0, %0\n ds_read_b32 %1, %1\n ds_read_b32 %2, %2\n ds_read_b32 %3, %3\n ds_read_b32 %4, %4\n ds_read_b32 %5, %5\n"
@@ -371,7 +386,7 @@ int main(int argc, char** argv) {
     }
     ROW(OP_BITOP3) ROW(OP_AND) ROW(OP_ADD) ROW(OP_ADDCO_PAIR) ROW(OP_LSHL_OR) ROW(OP_ALIGNBIT) ROW(OP_ADD3) ROW(OP_OR3) ROW(OP_MAD24) ROW(OP_BCNT)
     ROW(OP_LSHL) ROW(OP_LSHL64) ROW(OP_CNDMASK) ROW(OP_BFREV) ROW(OP_MOV) ROW(OP_ADD_F64) ROW(OP_FMA_F64) ROW(OP_DS_READ_B32) ROW(OP_DS_READ_B64) ROW(OP_LSHL_ADD_U64) ROW(OP_XAD) ROW(OP_CMP_CND)
-    ROW(OP_BFE) ROW(OP_AND_SDWA) ROW(OP_ADD_SDWA) ROW(OP_ADDCO) ROW(OP_ADDC) ROW(OP_FFBH) ROW(OP_CMP) ROW(OP_AND_OR) ROW(OP_LSHR) ROW(OP_NOT) ROW(OP_SUB) ROW(OP_MIN) ROW(OP_OR) ROW(OP_XNOR) ROW(OP_BFI) ROW(OP_PERM) ROW(OP_LSHLADD)
+    ROW(OP_BFE) ROW(OP_AND_SDWA) ROW(OP_ADD_SDWA) ROW(OP_ADDCO) ROW(OP_ADDC) ROW(OP_FFBH) ROW(OP_CMP) ROW(OP_AND_OR) ROW(OP_LSHR) ROW(OP_NOT) ROW(OP_SUB) ROW(OP_MIN) ROW(OP_OR) ROW(OP_XNOR) ROW(OP_BFI) ROW(OP_PERM) ROW(OP_LSHLADD) ROW(OP_PK_ADD16) ROW(OP_PK_SUB16) ROW(OP_PK_LSHL16) ROW(OP_PK_LSHR16) ROW(OP_LSHL_SDWA)
     {
         // C++ Myers column: instruction count per column taken from the disassembly is not needed — report columns/s
         printf("  \"%s\": {", kOpName[OP_MYERS2]);
