@@ -17,7 +17,7 @@ EXPORTS = [
     "bb_synth_offsets", "bb_synth_reads_host", "bb_synth_reads_dev",
     "bb_filter_set", "bb_filter_rows", "bb_filter_rows_dev",
     "bb_inspect_rows", "bb_inspect_rows_dev",
-    "bb_dev_malloc", "bb_dev_free", "bb_dev_download", "bb_dev_upload", "bb_host_malloc", "bb_host_free",
+    "bb_dev_malloc", "bb_dev_free", "bb_dev_download", "bb_dev_upload", "bb_host_malloc", "bb_host_free", "bb_host_malloc_on", "bb_host_free_on",
     "bb_fastq_ingest", "bb_fastq_ingest_dev", "bb_fastq_fetch", "bb_fastq_fetch_lines", "bb_fastq_last_ms",
     "bb_trim_set", "bb_trim_batch", "bb_trim_batch_dev", "bb_trim_plan_dev", "bb_trim_last_ms",
     "bb_format_set_labels", "bb_format_rows_dev",
@@ -91,6 +91,9 @@ def lib():
     L.bb_host_malloc.argtypes = [vp, u64, vp]
     L.bb_host_free.argtypes = [vp, vp]
     L.bb_host_free.restype = None
+    L.bb_host_malloc_on.argtypes = [i32, u64, vp]
+    L.bb_host_free_on.argtypes = [i32, vp]
+    L.bb_host_free_on.restype = None
     L.bb_dev_download.argtypes = [vp, vp, vp, u64]
     L.bb_dev_upload.argtypes = [vp, vp, vp, u64]
     L.bb_fastq_ingest.argtypes = [vp, vp, u64, C.c_int, vp, vp]

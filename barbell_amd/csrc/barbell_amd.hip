@@ -965,6 +965,18 @@ int bb_host_malloc(bb_ctx* c, uint64_t bytes, void** ptr) {
     if (hipHostMalloc(ptr, bytes ? bytes : 16, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); c->last_error = "hipHostMalloc failed"; return BB_E_NOMEM; }
     return BB_OK;
 }
+int bb_host_malloc_on(int device, uint64_t bytes, void** ptr) {
+    if (!ptr) return BB_E_INVALID;
+    *ptr = nullptr;
+    if (hipSetDevice(device) != hipSuccess) { (void)hipGetLastError(); return BB_E_NO_DEVICE; }
+    if (hipHostMalloc(ptr, bytes ? bytes : 16, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return BB_E_NOMEM; }
+    return BB_OK;
+}
+void bb_host_free_on(int device, void* ptr) {
+    if (!ptr) return;
+    (void)hipSetDevice(device);
+    (void)hipHostFree(ptr);
+}
 void bb_host_free(bb_ctx* c, void* ptr) {
     if (!c || !ptr) return;
     (void)hipSetDevice(c->device);

@@ -901,7 +901,12 @@ struct BlockFeeder {
                   // (-1: none recognisable), where the raw bytes came from (to redo the chunk if the guess was wrong), malformed flag
                   size_t raw_nl = 0; int phase0 = 0; uint64_t off = 0; size_t raw_len = 0; bool bad = false; TwoLineSummary sum; };
     size_t HEAD = 16u << 20;  // BARBELL_AMD_HEAD_BYTES overrides it (tests of the over-long-carry path)
-    bb_ctx* ctx;
+    int device;                // the slots are page-locked for uploads to this device; a slot is allocated by the first reader that fills it
+    // Ordinary (pageable, huge-page advised) memory by default: measured on the MI355X box the runtime uploads from it as fast as from
+    // page-locked memory (10.0 M reads/s steady state either way, 2 contexts, 128 MiB blocks) and page-locking 2-6 GB cost 0.4-1.0 s of a
+    // 1.6-2.9 s run, serialised inside the runtime against the contexts being created.  BARBELL_AMD_PINNED_SLOTS=1: hipHostMalloc.
+    bool pageable = getenv("BARBELL_AMD_PINNED_SLOTS") == nullptr;
+    bool keep_slots = false;   // the process is about to exit: the destructor leaves the slots to the OS (unpinning 6 GB costs ~0.5 s)
     std::vector<std::string> paths;
     std::vector<char> is_gz;
     std::vector<int> fds;
@@ -937,7 +942,7 @@ struct BlockFeeder {
     size_t st_part = 0; uint8_t st_part_last = 0; int64_t st_pend = -1, st_last2[2] = {-1, -1};
     void stitch(const Slot& sl, int ph0);
 
-    BlockFeeder(bb_ctx* c, const std::vector<std::string>& files, size_t chunk_bytes, unsigned n_slots, unsigned n_readers, unsigned n_inflate,
+    BlockFeeder(int device_, const std::vector<std::string>& files, size_t chunk_bytes, unsigned n_slots, unsigned n_readers, unsigned n_inflate,
                 bool two_line_mode = false);
     ~BlockFeeder();
     void reader_loop();
@@ -1293,9 +1298,9 @@ static bool sniff_gzip(const std::string& path) {  // magic bytes, not the file 
     return n == 2 && m[0] == 0x1f && m[1] == 0x8b;
 }
 
-BlockFeeder::BlockFeeder(bb_ctx* c, const std::vector<std::string>& files, size_t chunk_bytes, unsigned n_slots, unsigned n_readers, unsigned n_inflate,
+BlockFeeder::BlockFeeder(int device_, const std::vector<std::string>& files, size_t chunk_bytes, unsigned n_slots, unsigned n_readers, unsigned n_inflate,
                          bool two_line_mode)
-    : ctx(c), paths(files), chunk(chunk_bytes), two_line(two_line_mode), lpr(two_line_mode ? 2 : 4) {
+    : device(device_), paths(files), chunk(chunk_bytes), two_line(two_line_mode), lpr(two_line_mode ? 2 : 4) {
     if (const char* e = getenv("BARBELL_AMD_HEAD_BYTES")) HEAD = (size_t)std::max(16L, atol(e));
     is_gz.resize(paths.size()); fds.assign(paths.size(), -1); sizes.assign(paths.size(), 0); size_known.assign(paths.size(), 0);
     maps.assign(paths.size(), nullptr);
@@ -1314,7 +1319,7 @@ BlockFeeder::BlockFeeder(bb_ctx* c, const std::vector<std::string>& files, size_
         struct stat st;
         if (fds[i] < 0 || fstat(fds[i], &st) != 0) throw BarbellError(BB_E_INVALID, "Failed to open FASTQ input: " + paths[i]);
         sizes[i] = (uint64_t)st.st_size; size_known[i] = 1;
-        if (two_line && st.st_size > 0) {  // the readers compact straight out of the page cache: one pass over the text, no copy of the dropped half
+        if (two_line && st.st_size > 0 && !getenv("BARBELL_AMD_NO_MMAP")) {  // the readers compact straight out of the page cache: one pass over the text, no copy of the dropped half
             void* m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fds[i], 0);
             if (m != MAP_FAILED) { maps[i] = (const uint8_t*)m; (void)madvise(m, (size_t)st.st_size, MADV_SEQUENTIAL); }
         }
@@ -1328,12 +1333,11 @@ BlockFeeder::BlockFeeder(bb_ctx* c, const std::vector<std::string>& files, size_
         chunk = (size_t)std::min<uint64_t>(chunk, (mx + 4095) & ~(uint64_t)4095);
         HEAD = std::min(HEAD, (chunk + 15) & ~(size_t)15);
     }
+    // Page-locking is the expensive part of starting up (6 GB took a second, and as long again to undo): a slot is allocated by the reader
+    // that fills it first — in parallel, while the contexts are being created and the first blocks are already on the GPU —, and a short
+    // input never touches most of them.
     slots.resize(std::max(3u, n_slots));
-    for (size_t i = 0; i < slots.size(); ++i) {
-        void* q = nullptr;
-        if (bb_host_malloc(ctx, HEAD + chunk, &q) != BB_OK) throw BarbellError(BB_E_NOMEM, "bb_host_malloc failed");
-        slots[i].p = (uint8_t*)q; slots[i].cap = HEAD + chunk; slots[i].seq = i;
-    }
+    for (size_t i = 0; i < slots.size(); ++i) { slots[i].p = nullptr; slots[i].cap = HEAD + chunk; slots[i].seq = i; }
     for (unsigned i = 0; i < std::max(1u, n_readers); ++i) readers.emplace_back([this]() { reader_loop(); });
 }
 BlockFeeder::~BlockFeeder() {
@@ -1341,8 +1345,10 @@ BlockFeeder::~BlockFeeder() {
     cv.notify_all();
     for (auto& t : readers) if (t.joinable()) t.join();
     inflater.reset();
-    for (auto& sl : slots) if (sl.p) bb_host_free(ctx, sl.p);
-    for (size_t i = 0; i < maps.size(); ++i) if (maps[i]) munmap((void*)maps[i], (size_t)sizes[i]);
+    if (!keep_slots)
+        for (auto& sl : slots) if (sl.p) { if (pageable) free(sl.p); else bb_host_free_on(device, sl.p); }
+    if (!keep_slots)  // (a 32 GB mapping is 8 M page-table entries to take down: left to the exit as well)
+        for (size_t i = 0; i < maps.size(); ++i) if (maps[i]) munmap((void*)maps[i], (size_t)sizes[i]);
     for (int fd : fds) if (fd >= 0) close(fd);
 }
 // next chunk of the stream; gzip files are inflated whole (a few files ahead) and chunked from memory
@@ -1382,6 +1388,14 @@ void BlockFeeder::reader_loop() {
                 cv.wait(lk, [&]() { return stop || (sl.state == 0 && sl.seq == t.seq); });
                 if (stop) return;
                 sl.state = 1;
+            }
+            if (!sl.p) {  // first use of this slot (it is this reader's alone until it is marked full)
+                void* q = nullptr;
+                if (pageable) {
+                    if (posix_memalign(&q, 2u << 20, sl.cap) != 0) throw BarbellError(BB_E_NOMEM, "out of memory (block buffer)");
+                    (void)madvise(q, sl.cap, MADV_HUGEPAGE);
+                } else if (bb_host_malloc_on(device, sl.cap, &q) != BB_OK) throw BarbellError(BB_E_NOMEM, "bb_host_malloc_on failed (page-locked block buffer)");
+                sl.p = (uint8_t*)q;
             }
             uint8_t* dst = sl.p + HEAD;
             const uint8_t* src = nullptr;   // the chunk's raw bytes where they can be read in place (inflated image, mapped file)
@@ -1565,14 +1579,40 @@ AnnotateStats annotate(const std::vector<std::string>& read_files, const std::st
     std::vector<int> devs = config.devices;
     if (devs.empty()) devs.assign(std::max(1u, config.streams_per_device), config.device);
     const size_t G = devs.size();
-    std::vector<std::unique_ptr<Demuxer>> dms;
-    for (size_t w = 0; w < G; ++w) {
-        dms.push_back(std::make_unique<Demuxer>(config.alpha, config.verbose, config.min_score, config.min_score_diff, devs[w]));
-        for (const auto& g : query_groups) dms.back()->add_query_group(g);
-        dms.back()->ctx();  // create now: geometry / device errors surface before any output file exists
-        if (filtering) dms.back()->set_filter(config.filter_patterns);
-        if (trimming) dms.back()->set_trim(*config.trim);
+    const bool prof0 = getenv("BARBELL_AMD_PROFILE") != nullptr;
+    auto now0 = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_enter = now0();
+    // The readers start on the input right away (the feeder needs a device, not a context): by the time the contexts exist — created side
+    // by side, one thread each — the first blocks are staged.  Nothing is written before every context is up: geometry / device errors
+    // surface before any output file exists.
+    const bool two_line = config.compact_upload && !trimming;  // nothing downstream of annotate / filter / inspect reads qualities
+    const bool host_cut = trimming && config.host_cut && !getenv("BARBELL_AMD_GPU_RENDER");
+    const size_t block = config.batch_reads ? std::max<size_t>(config.batch_reads * 4096, 4096) : std::max<size_t>(config.block_bytes, 4096);
+    // two-line mode: a slot is about half full and a chunk costs its reader a pass over the text, so twice the slots and readers
+    // host_cut: a slot also waits for the writer threads (at most 4 blocks there), and the last holder may be one of them
+    auto feeder_p = std::make_shared<BlockFeeder>(devs[0], read_files, block, (unsigned)((two_line ? 2 : 1) * (3 * G + 2) + (host_cut ? 6 : 0)),
+                                                  std::min<unsigned>(std::max(1u, config.n_threads), 32u), config.n_threads, two_line);
+    feeder_p->keep_slots = config.process_exits_after;
+    const double t_feeder_up = now0();
+    std::vector<std::unique_ptr<Demuxer>> dms(G);
+    {
+        std::vector<std::thread> makers;
+        std::vector<std::exception_ptr> errs(G);
+        for (size_t w = 0; w < G; ++w)
+            makers.emplace_back([&, w]() {
+                try {
+                    dms[w] = std::make_unique<Demuxer>(config.alpha, config.verbose, config.min_score, config.min_score_diff, devs[w]);
+                    for (const auto& g : query_groups) dms[w]->add_query_group(g);
+                    dms[w]->ctx();
+                    if (filtering) dms[w]->set_filter(config.filter_patterns);
+                    if (trimming) dms[w]->set_trim(*config.trim);
+                } catch (...) { errs[w] = std::current_exception(); }
+            });
+        for (auto& t : makers) t.join();
+        for (auto& e : errs)
+            if (e) { feeder_p->fail("cancelled"); std::rethrow_exception(e); }
     }
+    const double t_ctx_done = now0();
     FILE* out = fopen(out_file.c_str(), "w");
     if (!out) throw BarbellError(BB_E_INVALID, "Failed to create annotation output file '" + out_file + "'");
     FILE* kept_f = nullptr;
@@ -1590,7 +1630,6 @@ AnnotateStats annotate(const std::vector<std::string>& read_files, const std::st
     }
     AnnotateStats st;
     std::unique_ptr<LabelWriters> writers;
-    const bool host_cut = trimming && config.host_cut && !getenv("BARBELL_AMD_GPU_RENDER");
     FILE* failed_f = nullptr;
     if (trimming) {
         if (mkdir(config.trim_folder.c_str(), 0777) != 0 && errno != EEXIST) {
@@ -1613,16 +1652,21 @@ AnnotateStats annotate(const std::vector<std::string>& read_files, const std::st
         if (ppr_f) fclose(ppr_f);
         writers.reset();
     };
-    const bool two_line = config.compact_upload && !trimming;  // nothing downstream of annotate / filter / inspect reads qualities
-
     const bool prof = getenv("BARBELL_AMD_PROFILE") != nullptr;
     auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const bool want_ids = ppr_f != nullptr || failed_f != nullptr;
+    const bool feed_only = getenv("BARBELL_AMD_FEED_ONLY") != nullptr;   // measurement aid (tools/e2e_rate.py): what one host can feed, whatever the GPUs do
+    std::atomic<uint64_t> fed_bytes{0};
 
     // ---- one block on its context: parsed, annotated, rendered, filtered, inspected and trimmed in HBM -------------
     auto process = [&](Demuxer& dm, const BlockFeeder::Block& blk, const std::shared_ptr<BlockFeeder>& feeder) -> BlockResult {
         BlockResult R;
         double t0 = now();
+        if (feed_only) {  // BARBELL_AMD_FEED_ONLY=1: the host side alone — files -> reader threads -> blocks of whole records —, nothing uploaded
+            fed_bytes += blk.len;
+            feeder->release(blk.slot);
+            return R;
+        }
         const auto ing = dm.ingest(blk.data, blk.len, true, want_ids, two_line);  // blocks hold whole records only
         std::shared_ptr<void> text_hold;   // host_cut: the slot stays until the writer threads have cut the block's records out of it
         if (host_cut) {
@@ -1730,7 +1774,6 @@ AnnotateStats annotate(const std::vector<std::string>& read_files, const std::st
     };
 
     // ---- the pipeline: readers -> sequencer (dispatcher thread) -> G workers -> ordered commit (this thread) -------
-    const size_t block = config.batch_reads ? std::max<size_t>(config.batch_reads * 4096, 4096) : std::max<size_t>(config.block_bytes, 4096);
     std::mutex mu;
     std::condition_variable cv;
     std::vector<std::deque<BlockFeeder::Block>> inq(G);
@@ -1741,12 +1784,9 @@ AnnotateStats annotate(const std::vector<std::string>& read_files, const std::st
     auto set_err = [&](std::exception_ptr e) { { std::lock_guard<std::mutex> lk(mu); if (!first_err) first_err = e; abort = true; } cv.notify_all(); };
     double t_start = 0, t_end = 0;
     try {
-        // two-line mode: a slot is about half full and a chunk costs its reader a pass over the text, so twice the slots and readers
-        // host_cut: a slot also waits for the writer threads (at most 4 blocks there), and the last holder may be one of them
-        auto feeder_p = std::make_shared<BlockFeeder>(dms[0]->ctx(), read_files, block, (unsigned)((two_line ? 2 : 1) * (3 * G + 2) + (host_cut ? 6 : 0)),
-                                                      std::min<unsigned>(std::max(1u, config.n_threads), 32u), config.n_threads, two_line);
         BlockFeeder& feeder = *feeder_p;
         t_start = now();
+        if (prof0) fprintf(stderr, "profile: start-up: feeder (files opened, reader threads started) %.3f s, %zu context(s) side by side %.3f s\n", t_feeder_up - t_enter, G, t_ctx_done - t_feeder_up);
         std::thread dispatcher([&]() {
             try {
                 BlockFeeder::Block b;
@@ -1816,7 +1856,9 @@ AnnotateStats annotate(const std::vector<std::string>& read_files, const std::st
         for (auto& t : workers) t.join();
         t_end = now();
         if (first_err) std::rethrow_exception(first_err);
-        if (writers) writers->wait(0);  // all records on disk (or the writer's error rethrown) before the files are closed
+        if (writers) writers->wait(0);
+        feeder_p.reset();
+        if (prof0) fprintf(stderr, "profile: feeder torn down %.3f s after the last block; %.3f s since annotate() was entered\n", now() - t_end, now() - t_enter);  // all records on disk (or the writer's error rethrown) before the files are closed
     } catch (...) {
         close_all();
         throw;
@@ -1841,6 +1883,8 @@ AnnotateStats annotate(const std::vector<std::string>& read_files, const std::st
             fclose(cf);
         }
     }
+    if (feed_only) fprintf(stderr, "feed-only: %llu bytes of staged text in %.3f s (%.2f GB/s into the block buffers; no GPU work)\n", (unsigned long long)fed_bytes.load(),
+                           st.seconds_pipeline, st.seconds_pipeline > 0 ? (double)fed_bytes.load() / st.seconds_pipeline / 1e9 : 0.0);
     if (prof) fprintf(stderr, "profile: pipeline %.3f s for %zu reads (%.2f M reads/s) on %zu context(s); summed over blocks: upload+parse %.3f s, annotate+render %.3f s, "
                       "filter/inspect/trim %.3f s (%.3f / %.3f / %.3f); commit (file writes) %.3f s, of which waiting for the label writers %.3f s; workers waiting for input %.3f s\n",
                       st.seconds_pipeline, st.total, st.seconds_pipeline > 0 ? st.total / st.seconds_pipeline / 1e6 : 0.0, G, t_ingest, t_gpu, t_rest,
@@ -1885,6 +1929,7 @@ AnnotateStats demux_using_kit(const std::vector<std::string>& fastq_files, const
     c.trim_folder = k.output_folder;
     c.inspect = true;
     c.host_cut = k.host_cut;
+    c.process_exits_after = k.process_exits_after;
     c.read_pattern_out = k.output_folder + "/pattern_per_read.tsv";
     return annotate_with_kit(fastq_files, k.output_folder + "/annotation.tsv", k.kit_name, c);
 }

@@ -2,6 +2,9 @@
 // contexts of a run.  Contexts on DISTINCT devices are all-reduced in place with RCCL over xGMI
 // (ncclAllReduce, ncclUint64, ncclSum on bb_counts_dev, one communicator per device, single process); contexts that
 // share a device are summed on the host first (RCCL cannot put two ranks on one GPU).  No torch, no MPI.
+// librccl.so is bound at the first all-reduce (dlopen), not at program start: it is a 570 MB library, and a run on one device — most
+// runs — never calls it (mapping and relocating it was a fifth of a second of every start-up).
+#include <dlfcn.h>
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
@@ -14,10 +17,39 @@
 
 namespace barbell {
 
+namespace {
+struct Rccl {
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+const Rccl& rccl() {
+    static const Rccl R = []() {
+        Rccl r;
+        void* h = nullptr;
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
+            if ((h = dlopen(name, RTLD_NOW | RTLD_LOCAL))) break;
+        if (!h) throw BarbellError(BB_E_HIP, std::string("librccl.so not found (contexts on several devices need RCCL): ") + dlerror());
+        auto sym = [&](const char* s) { void* p = dlsym(h, s); if (!p) throw BarbellError(BB_E_HIP, std::string("librccl.so lacks ") + s); return p; };
+        r.CommInitAll = (decltype(r.CommInitAll))sym("ncclCommInitAll");
+        r.GroupStart = (decltype(r.GroupStart))sym("ncclGroupStart");
+        r.GroupEnd = (decltype(r.GroupEnd))sym("ncclGroupEnd");
+        r.AllReduce = (decltype(r.AllReduce))sym("ncclAllReduce");
+        r.CommDestroy = (decltype(r.CommDestroy))sym("ncclCommDestroy");
+        r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
+        return r;
+    }();
+    return R;
+}
+}  // namespace
+
 #define RCHK(call)                                                                                             \
     do {                                                                                                       \
         ncclResult_t r_ = (call);                                                                              \
-        if (r_ != ncclSuccess) throw BarbellError(BB_E_HIP, std::string(#call) + ": " + ncclGetErrorString(r_)); \
+        if (r_ != ncclSuccess) throw BarbellError(BB_E_HIP, std::string(#call) + ": " + rccl().GetErrorString(r_)); \
     } while (0)
 #define HCHK(call)                                                                                            \
     do {                                                                                                      \
@@ -50,16 +82,16 @@ std::vector<uint64_t> allreduce_counts(const std::vector<Demuxer*>& dms, std::st
     std::vector<int> devs;
     for (Demuxer* d : leaders) devs.push_back(d->device());
     std::vector<ncclComm_t> comms((size_t)R);
-    RCHK(ncclCommInitAll(comms.data(), R, devs.data()));
-    RCHK(ncclGroupStart());
+    RCHK(rccl().CommInitAll(comms.data(), R, devs.data()));
+    RCHK(rccl().GroupStart());
     for (int i = 0; i < R; ++i) {
         HCHK(hipSetDevice(devs[(size_t)i]));
         uint64_t* p = bb_counts_dev(leaders[(size_t)i]->ctx());
-        RCHK(ncclAllReduce(p, p, n, ncclUint64, ncclSum, comms[(size_t)i], (hipStream_t)0));
+        RCHK(rccl().AllReduce(p, p, n, ncclUint64, ncclSum, comms[(size_t)i], (hipStream_t)0));
     }
-    RCHK(ncclGroupEnd());
+    RCHK(rccl().GroupEnd());
     for (int i = 0; i < R; ++i) { HCHK(hipSetDevice(devs[(size_t)i])); HCHK(hipDeviceSynchronize()); }
-    for (auto& c : comms) (void)ncclCommDestroy(c);
+    for (auto& c : comms) (void)rccl().CommDestroy(c);
     how = "rccl";
     return leaders[0]->counts();
 }

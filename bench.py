@@ -419,9 +419,21 @@ def e2e_leg(d_bases, n, L, dev):
         size = os.path.getsize(fq)
         env = dict(os.environ, BARBELL_AMD_NO_TORCH="1")
         t0 = time.perf_counter()
-        r = subprocess.run([cli, "annotate", "-i", fq, "-o", os.path.join(td, "a.tsv"), "--kit", "SQK-NBD114-96", "--flank-max-errors", "3", "--streams", "3",
-                            "--block-bytes", str(256 << 20), "-t", "32"], capture_output=True, text=True, env=env)
+        cmd = [cli, "annotate", "-i", fq, "-o", os.path.join(td, "a.tsv"), "--kit", "SQK-NBD114-96", "--flank-max-errors", "3", "--streams", "2",
+               "--block-bytes", str(128 << 20), "-t", "32"]
+        r = subprocess.run(cmd, capture_output=True, text=True, env=env)
         wall = time.perf_counter() - t0
+        # the host side alone: files -> reader threads -> blocks of whole records in the upload buffers, no GPU call.  What one host process
+        # can feed: the ceiling of a node's end-to-end rate however many GPUs take the blocks
+        feed = {}
+        try:
+            rf = subprocess.run(cmd[:-6] + ["--streams", "4", "--block-bytes", str(128 << 20), "-t", "64"], capture_output=True, text=True, env=dict(env, BARBELL_AMD_FEED_ONLY="1"))
+            mf = re.search(r"feed-only: (\d+) bytes of staged text in ([\d.]+) s", rf.stderr)
+            if rf.returncode == 0 and mf:
+                feed = {"reads_per_s": n / float(mf.group(2)), "fastq_gb_per_s": size / float(mf.group(2)) / 1e9, "seconds": float(mf.group(2)), "reader_threads": 64,
+                        "note": "BARBELL_AMD_FEED_ONLY=1: no upload, no kernels; one process, page cache"}
+        except Exception as e:  # noqa: BLE001
+            feed = {"error": str(e)[:200]}
         if r.returncode != 0:
             return {"error": r.stderr[-400:]}
         m = re.search(r"Done: (\d+) records, (\d+) with annotations, (\d+) rows .*\(([\d.]+) s in the pipeline", r.stderr)
@@ -451,7 +463,8 @@ def e2e_leg(d_bases, n, L, dev):
         return {"reads": n, "kit": kit, "fastq_bytes": size, "tsv_bytes": os.path.getsize(os.path.join(td, "a.tsv")), "rows": int(m.group(3)),
                 "steady_state_reads_per_s": n / pipe, "steady_state_fastq_gb_per_s": size / pipe / 1e9, "pipeline_s": pipe,
                 "process_wall_s": wall, "process_wall_reads_per_s": n / wall, "fastq_write_s": gen_s,
-                "command": "barbell-amd annotate --kit SQK-NBD114-96 --flank-max-errors 3 --streams 3 --block-bytes 256Mi -t 32",
+                "host_feed_only": feed,
+                "command": "barbell-amd annotate --kit SQK-NBD114-96 --flank-max-errors 3 --streams 2 --block-bytes 128Mi -t 32",
                 "note": "C++ host, FASTQ text from the page cache to annotation.tsv; PCIe-bound (8 KB of text per read); not the headline value"}
 
 

@@ -188,6 +188,10 @@ int  bb_dev_upload(bb_ctx* ctx, void* d_dst, const void* src_host, uint64_t byte
  * records) move over PCIe at full rate when they come from here.                                    */
 int  bb_host_malloc(bb_ctx* ctx, uint64_t bytes, void** ptr);
 void bb_host_free(bb_ctx* ctx, void* ptr);
+/* The same without a context (a host that stages its first FASTQ blocks while its contexts are still being created): page-locked memory
+ * for uploads to `device`.  BB_E_NO_DEVICE without a usable GPU. */
+int  bb_host_malloc_on(int device, uint64_t bytes, void** ptr);
+void bb_host_free_on(int device, void* ptr);
 
 const char* bb_strerror(int code);
 const char* bb_last_error(const bb_ctx* ctx);   /* detail of the last BB_E_HIP / BB_E_UNSUPPORTED; ctx == NULL: of the

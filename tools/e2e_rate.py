@@ -84,10 +84,24 @@ if not a.only_kit:
     for streams in (1, 2, 3):
         for bb in (128 << 20, 256 << 20):
             run(f"annotate_streams{streams}_block{bb >> 20}Mi_t32", base + ["--streams", str(streams), "--block-bytes", str(bb), "-t", "32"])
-    best = max(out["runs"], key=lambda k: out["runs"][k]["steady_state_reads_per_s"] or 0)
-    out["best"] = {"run": best, **{k: out["runs"][best][k] for k in ("steady_state_reads_per_s", "wall_reads_per_s", "fastq_gb_per_s_steady")}}
     out["tsv_bytes"] = os.path.getsize(os.path.join(a.dir, "e2e_a.tsv"))
-if a.kit_run or a.only_kit:
+    # the host side alone (BARBELL_AMD_FEED_ONLY=1: files -> reader threads -> blocks of whole records in the upload buffers, no GPU call):
+    # what ONE host process can feed, i.e. the ceiling of a node's end-to-end rate however many GPUs take the blocks
+    env_run = env
+    for thr in (32, 64):
+        env = dict(env_run, BARBELL_AMD_FEED_ONLY="1")
+        t0 = time.time()
+        r = subprocess.run(base + ["--streams", "4", "--block-bytes", str(128 << 20), "-t", str(thr)], capture_output=True, text=True, env=env)
+        mm = re.search(r"feed-only: (\d+) bytes of staged text in ([\d.]+) s", r.stderr)
+        if r.returncode == 0 and mm:
+            out.setdefault("feed_only", {})[f"t{thr}"] = {"staged_bytes": int(mm.group(1)), "seconds": float(mm.group(2)), "reads_per_s": n / float(mm.group(2)),
+                                                          "fastq_gb_per_s": size / float(mm.group(2)) / 1e9, "wall_s": time.time() - t0}
+    env = env_run
+    best = max(out["runs"], key=lambda k: out["runs"][k]["steady_state_reads_per_s"] or 0)
+    bw = min(out["runs"], key=lambda k: out["runs"][k]["wall_s"])
+    out["best_wall"] = {"run": bw, **{k: out["runs"][bw][k] for k in ("wall_s", "wall_reads_per_s", "steady_state_reads_per_s")}}
+    out["best"] = {"run": best, **{k: out["runs"][best][k] for k in ("steady_state_reads_per_s", "wall_reads_per_s", "fastq_gb_per_s_steady")}}
+if a.kit_run:
     import shutil
 
     for streams in (2, 3, 4):
