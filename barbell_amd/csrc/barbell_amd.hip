@@ -367,6 +367,8 @@ int ensure_hits(bb_ctx* c, uint64_t need) {
     cap = 0;
     if ((r = grow(c, c->d_hits, cap, need))) return r;
     cap = 0;
+    if ((r = grow(c, c->d_hitmeta, cap, need))) return r;
+    cap = 0;
     {
         bool any_split = false;
         for (auto& d : c->gdev) any_split = any_split || d.split[0] || d.split[1];
@@ -487,7 +489,7 @@ void bb_destroy(bb_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     void* ptrs[] = {c->d_groups, c->d_tables, c->d_counts, c->d_cnt, c->d_base, c->d_sums, c->d_nrows, c->d_rowoff, c->d_hitcount,
-                    c->d_lists, c->d_listcnt, c->d_fb_lists, c->d_fbcnt, c->d_flags, c->d_vqueue, c->d_nflag, c->d_raw, c->d_hits, c->d_pfx, c->d_rows, c->d_in_bases, c->d_in_offsets, c->d_out_rows,
+                    c->d_lists, c->d_listcnt, c->d_fb_lists, c->d_fbcnt, c->d_flags, c->d_vqueue, c->d_nflag, c->d_raw, c->d_hits, c->d_hitmeta, c->d_pfx, c->d_rows, c->d_in_bases, c->d_in_offsets, c->d_out_rows,
                     c->d_synth_table, c->d_fpats, c->d_felems, c->d_flabel_ok, c->d_flabel_ids, c->d_frows, c->d_fout, c->d_iout};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -608,7 +610,7 @@ int bb_annotate_batch_dev(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_o
     }
     if (n_hits) {
         HIPCHK(c, hipMemsetAsync(c->d_listcnt, 0, sizeof(uint32_t) * 4 * BB_MAX_GROUPS, c->stream));
-        hipLaunchKernelGGL(k_hit_lists, dim3((n_hits + 255) / 256), dim3(256), 0, c->stream, (const bb_hit*)c->d_hits, n_hits,
+        hipLaunchKernelGGL(k_hit_lists, dim3((n_hits + 255) / 256), dim3(256), 0, c->stream, (const uint32_t*)c->d_hitmeta, n_hits,
                            c->d_rows, c->d_lists, c->cap_hits, c->d_listcnt, G, (const bb_group_dev*)c->d_groups);
     }
     mark(c, K_BARCODE);

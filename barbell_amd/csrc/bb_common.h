@@ -143,6 +143,11 @@ struct __attribute__((aligned(16))) bb_hit {
     uint8_t win[64];                // filled when we - ws <= 64
 };
 static_assert(sizeof(bb_hit) == 96, "bb_hit: 32-byte header + 64 window codes");
+// one word per ordered flank match, written next to the record by k_flank_trace: valid (bits 0-7), list slot 4 g + 2 wide + strand of
+// k_hit_lists (bits 8-15; wide = window of more than 48 columns), window width min(we - ws, 255) (bits 16-23)
+BB_HD uint32_t bb_hit_meta(uint32_t valid, uint32_t group, uint32_t strand, uint32_t wn) {
+    return (valid ? 1u : 0u) | ((4u * group + (wn > 48u ? 2u : 0u) + (strand & 1u)) << 8) | ((wn > 255u ? 255u : wn) << 16);
+}
 
 // ---- row slots of the barcode stage (one per flank hit) ----
 struct __attribute__((aligned(16))) bb_rowtmp {  // one per flank hit: the provisional row; row._pad[0] = 1 when the hit has a row

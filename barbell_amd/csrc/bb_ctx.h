@@ -70,6 +70,7 @@ struct bb_ctx {
     double fast_margin = 1e-9;   // BARBELL_AMD_FAST_MARGIN: slack of the bound test in k_rows (tests: a huge value sends every hit to the fallback)
     bb_hit_raw* d_raw = nullptr;
     bb_hit* d_hits = nullptr;
+    uint32_t* d_hitmeta = nullptr;  // bb_hit_meta per ordered flank match (k_flank_trace -> k_hit_lists, k_barcode_lane)
     bb_hit_pfx* d_pfx = nullptr;  // shared-prefix records of the hits (groups with pfx > 0)
     bb_rowtmp* d_rows = nullptr;
     // staging for the host-pointer variant

@@ -48,7 +48,10 @@ struct hit_buf {
     } while (0)
 
 #ifndef BB_VERIFY_CHUNKS
-#define BB_VERIFY_CHUNKS 2   // 16-byte text loads per lane and round in k_flank_verify (4: 2.60 -> 1.96 GB of HBM traffic per step, but 4.67 -> 4.84 ms: lanes with short intervals idle through the longer rounds)
+#define BB_VERIFY_CHUNKS 5   // 16-byte text loads per lane and round in k_flank_verify.  A verified interval is m + k columns of lead-in plus a flagged piece and
+                             // its margins (~75 columns for SQK-NBD114-96): five chunks take it in ONE round, so its one or two 128-byte lines are fetched once
+                             // (they do not survive in L2 between a lane's rounds: 58 MB of lines are in flight).  Measured, scan stage / kernel's HBM bytes per
+                             // 2 M-read step: 2 chunks 4.75-4.80 ms / 2.40 GB, 3: 4.70-4.79 / 2.0, 4: 4.88-4.96 / 1.95, 5: 4.75-4.76 / 1.5
 #endif
 #define BB_VERIFY_FLW 12u     // flag words per lane cached in LDS by k_flank_verify (reads up to ~5.5 kb; longer ones read theirs from HBM)
 #define BB_VERIFY_STAGE 128u  // hit records per wave in k_flank_verify's LDS staging area (a round with more goes out directly)

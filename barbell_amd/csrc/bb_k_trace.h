@@ -139,12 +139,13 @@ __device__ __forceinline__ uint32_t flank_trace_lane(const uint8_t* __restrict__
             for (int x = 0; x < W; ++x) put(c, x, l[x], hh[x]);
         }
     };
-    if constexpr ((MODE == 2 || MODE == 4) && W <= 2) {
+    constexpr bool KEEP_TEXT = (MODE == 2 || MODE == 4) && W <= 2;  // the first 64 scan positions of the DP's text stay in registers
+    constexpr int NCH = 4;  // 64 columns at once; the rest (m + k > 64: two-word flanks of more than 58 characters) one by one
+    uint32_t buf[KEEP_TEXT ? NCH : 1][4];
+    if constexpr (KEEP_TEXT) {
         // band variants (k <= 6: at most 32 W + 6 columns): every chunk of the window's text requested before the first column. Its
         // 50-70 bytes lie in one or two lines; fetched a chunk at a time as the DP got there, a line was often gone from L2 again by
         // the next request once 24 waves per CU were in flight (1.2 -> 1.7 GB of HBM reads per step with the 8-row band).
-        constexpr int NCH = 4;  // 64 columns at once; the rest (m + k > 64: two-word flanks of more than 58 characters) one by one
-        uint32_t buf[NCH][4];
 #pragma unroll
         for (int q = 0; q < NCH; ++q) {
             buf[q][0] = buf[q][1] = buf[q][2] = buf[q][3] = 0u;
@@ -273,10 +274,36 @@ __device__ __forceinline__ uint32_t flank_trace_lane(const uint8_t* __restrict__
     }
     const int32_t wn = we - ws;
     const uint8_t* lut = tables + G.off_lut;
-    if (wn <= 64) {  // window codes for k_barcode_reg: the window's bytes in four 16-byte loads, then the base-set LUT
+    if (wn <= 64) {  // window codes for the barcode kernels: the window's bytes, then the base-set LUT
         u32x4_t tv[4];
+        // The window lies inside the flank match plus 10 positions either side: almost always inside the 64 scan positions the DP's
+        // text was loaded for.  Those bytes are still in registers: they go through the lane's staging row (LDS) and come back at the
+        // window's byte offset — asking HBM for them again cost as much as the first time (the lines are long gone from L2: 50 MB of
+        // them are in flight), 0.45 GB per 2 M-read step.  Windows that stick out of the buffer take the loads.
+        bool from_regs = false;
+        if constexpr (KEEP_TEXT) {
+            // offset of the window's first forward byte in the buffer, in FORWARD byte order: the forward strand's buffer is in that
+            // order from s0; the rc strand's holds scan position p = n - 1 - f, so reversed (words swapped, bytes swapped) it holds
+            // forward position f = n - 1 - s0 - 63 + x at x
+            const int32_t a = h.strand ? ws - (n - 1 - s0 - 63) : ws - s0;
+            const int32_t ext = min(64, 16 * ((w + 15) / 16));   // scan positions [0, ext) of the buffer were loaded (whole 16-byte chunks up to the hit's end)
+            from_regs = h.strand ? (a >= 64 - ext && a + wn <= 64) : (a >= 0 && a + wn <= ext);
+            if (__any(from_regs)) {
+                uint32_t* st = orec + 8;  // 16 words of the lane's staging row (the record's window area: written with the codes below)
+#pragma unroll
+                for (int x = 0; x < 16; ++x) st[x] = h.strand ? __builtin_bswap32(buf[(15 - x) >> 2][(15 - x) & 3]) : buf[x >> 2][x & 3];
+                const int32_t q = from_regs ? a >> 2 : 0, sh = from_regs ? a & 3 : 0;
+                uint32_t w[17];
+#pragma unroll
+                for (int x = 0; x < 17; ++x) w[x] = st[min(q + x, 15)];
+#pragma unroll
+                for (int x = 0; x < 16; ++x)
+                    if (from_regs) tv[x >> 2][x & 3] = __builtin_amdgcn_alignbyte(w[x + 1], w[x], (uint32_t)sh);
+            }
+        }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
+            if (from_regs) continue;
             const int32_t a = ws + 16 * q;
             if (16 * q < wn && a + 16 <= n) __builtin_memcpy(&tv[q], rb + a, 16);
             else {
@@ -309,7 +336,8 @@ template <int W, int MODE>
 __global__ __launch_bounds__(64) void k_flank_trace(const uint8_t* __restrict__ bases, const uint64_t* __restrict__ offsets,
                                                     const uint8_t* __restrict__ tables, const bb_group_dev* __restrict__ groups,
                                                     uint32_t n_groups, const bb_hit_raw* __restrict__ raw, uint32_t n_hits,
-                                                    const uint32_t* __restrict__ slot_base, bb_hit* __restrict__ hits, uint32_t gmask, int mk_max) {
+                                                    const uint32_t* __restrict__ slot_base, bb_hit* __restrict__ hits, uint32_t* __restrict__ hit_meta,
+                                                    uint32_t gmask, int mk_max) {
     extern __shared__ uint32_t s_dyn[];
     __shared__ uint32_t s_slot[64];
     static_assert(sizeof(bb_hit) == 96, "six 16-byte pieces");
@@ -318,6 +346,13 @@ __global__ __launch_bounds__(64) void k_flank_trace(const uint8_t* __restrict__ 
     uint32_t* s_rec = s_dyn;
     s_slot[threadIdx.x] = flank_trace_lane<W, MODE>(bases, offsets, tables, groups, n_groups, raw, n_hits, slot_base, gmask, mk_max,
                                                     s_rec + threadIdx.x * BB_TRACE_REC_STRIDE, s_dyn);
+    {   // what k_hit_lists and the barcode kernels' lane assignment need of a hit, 4 bytes instead of its 96-byte record (bb_hit_meta)
+        const uint32_t slot = s_slot[threadIdx.x];
+        if (slot != 0xFFFFFFFFu) {
+            const uint32_t* r = s_rec + threadIdx.x * BB_TRACE_REC_STRIDE;
+            hit_meta[slot] = bb_hit_meta(r[6] & 0xFFu, (r[5] >> 16) & 0xFFu, r[5] >> 24, r[4] - r[3]);
+        }
+    }
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < 64u * 6u; i += 64u) {
         const uint32_t hl = i / 6u, pc = i - hl * 6u, slot = s_slot[hl];

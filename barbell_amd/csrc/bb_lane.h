@@ -71,7 +71,7 @@ __device__ __forceinline__ void shared_rows_walk(const uint32_t* s_eqt, const ui
 // PRIO: the class of the policy's traceback order (bb_prio.h): the move planes are one v_bitop3 each with the class's truth tables
 template <int CW, bool TAIL, uint32_t PRIO>
 __global__ __launch_bounds__(256, CW <= 48 ? 3 : 2) void k_barcode_lane(const uint8_t* __restrict__ tables, const bb_group_dev* __restrict__ groups, uint32_t g,
-                                                      uint32_t strand, const bb_hit* __restrict__ hits,
+                                                      uint32_t strand, const bb_hit* __restrict__ hits, const uint32_t* __restrict__ hit_meta,
                                                       const uint32_t* __restrict__ hit_list, const uint32_t* __restrict__ list_cnt,
                                                       uint32_t n_hits_all, bb_rowtmp* __restrict__ rows, double min_score, double min_score_diff,
                                                       double margin, uint32_t* __restrict__ fb_lists, uint32_t list_stride, uint32_t* __restrict__ fb_cnt) {
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256, CW <= 48 ? 3 : 2) void k_barcode_lane(const ui
         const uint32_t li = blockIdx.x * 256u + threadIdx.x;
         const bool ex0 = li < n_list;
         const uint32_t h0i = hit_list ? (ex0 ? hit_list[li] : 0u) : (ex0 ? li : 0u);
-        const bool narrow = ex0 && (hits[h0i].we - hits[h0i].ws) <= (uint32_t)(CW - BB_CG);
+        const bool narrow = ex0 && ((hit_meta[h0i] >> 16) & 0xFFu) <= (uint32_t)(CW - BB_CG);   // the window's width from the hit's meta word, not its record
         const bool wide = ex0 && !narrow;
         const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
         const unsigned long long bn = __ballot(narrow), bw = __ballot(wide);

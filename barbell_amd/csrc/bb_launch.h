@@ -25,7 +25,7 @@ void bb_launch_barcode(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offs
 
 // ---- the per-class units ----
 struct bb_lane_args {
-    const uint8_t* tables; const bb_group_dev* groups; uint32_t g, strand; const bb_hit* hits; const uint32_t* list; const uint32_t* cnt;
+    const uint8_t* tables; const bb_group_dev* groups; uint32_t g, strand; const bb_hit* hits; const uint32_t* hit_meta; const uint32_t* list; const uint32_t* cnt;
     uint32_t n_hits; bb_rowtmp* rows; double min_score, min_score_diff, margin; uint32_t* fb_lists; uint32_t list_stride; uint32_t* fb_cnt;
 };
 struct bb_pfx_args {

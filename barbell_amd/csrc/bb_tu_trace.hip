@@ -40,7 +40,7 @@ void launch_trace(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets, 
         lds = std::max(lds, need);
     }
 #define BB_TRACE_ARGS d_bases, d_offsets, (const uint8_t*)c->d_tables, (const bb_group_dev*)c->d_groups, (uint32_t)c->groups.size(), \
-                      (const bb_hit_raw*)c->d_raw, n_hits, (const uint32_t*)c->d_base, c->d_hits, gmask, mk_max
+                      (const bb_hit_raw*)c->d_raw, n_hits, (const uint32_t*)c->d_base, c->d_hits, c->d_hitmeta, gmask, mk_max
     if (mode == 4) hipLaunchKernelGGL((k_flank_trace<W, 4>), dim3((n_hits + 63) / 64), dim3(64), lds, c->stream, BB_TRACE_ARGS);
     else if (mode == 2) hipLaunchKernelGGL((k_flank_trace<W, 2>), dim3((n_hits + 63) / 64), dim3(64), lds, c->stream, BB_TRACE_ARGS);
     else if (mode == 1) {
