@@ -14,6 +14,9 @@ from barbell_amd import _abi, annotate as A, kits  # noqa: E402
 from tests.common import EX  # noqa: E402
 from tests.test_gpu_parity import run_both  # noqa: E402
 
+import itertools  # noqa: E402
+
+TRACE_ORDERS = ["MISD"] * 6 + ["".join(p) for p in itertools.permutations("MSID")]   # every order, the default a fifth of the time
 first, count = int(sys.argv[1]), int(sys.argv[2])
 bad = 0
 for seed in range(first, first + count):
@@ -38,9 +41,9 @@ for seed in range(first, first + count):
     policy = None
     if rng.random() < 0.35:
         policy = ",".join([f"lm={rng.choice(['right', 'left', 'strict'])}", f"rc={rng.choice(['scan', 'fwd'])}",
-                           f"trace={rng.choice(['MISD', 'MISD', 'MSID', 'MDSI', 'IMSD', 'DMIS', 'SMID'])}",
+                           f"trace={rng.choice(TRACE_ORDERS)}", f"rcpath={rng.choice(['fwd', 'fwd', 'mirror'])}",
                            f"ovh={rng.choice(['floor', 'ceil', 'near', 'floor:f64', 'near:f64'])}", f"tie={rng.choice(['first', 'last'])}",
-                           f"lodhi={rng.choice(['3:0.5:1111', '3:0.5:1111', '3:0.5:2211', '3:0.5:1121', '3:0.5:1110', '2:0.5:1111', '3:0.7:1111', '4:0.5:1212'])}"])
+                           f"lodhi={rng.choice(['3:0.5:1111', '3:0.5:1111', '3:0.5:2211', '3:0.5:1121', '3:0.5:1110', '3:0.5:2131', '3:0.5:1011', '2:0.5:1111', '3:0.7:1111', '4:0.5:1212'])}"])
     os.environ.pop("BARBELL_AMD_ADAPT_FRAC", None)
     if rng.random() < 0.3: os.environ["BARBELL_AMD_ADAPT_FRAC"] = str(rng.choice(["0", "1", "0.01"]))
     noise = float(rng.choice([0.0, 0.0, 0.03, 0.08]))
