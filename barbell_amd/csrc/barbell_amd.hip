@@ -445,6 +445,7 @@ int bb_create_policy(const bb_group_desc* groups, uint32_t n_groups, const bb_pa
     if (getenv("BARBELL_AMD_ADAPT_FRAC")) c->adapt_frac = atof(getenv("BARBELL_AMD_ADAPT_FRAC"));
     if (const char* e = getenv("BARBELL_AMD_LANE_FB_FRAC")) c->lane_fb_frac = atof(e);
     if (const char* e = getenv("BARBELL_AMD_LANE")) c->lane_kernel = std::max(0, std::min(2, atoi(e)));
+    if (const char* e = getenv("BARBELL_AMD_LANE_NM")) c->lane_nm = atoi(e) != 0;
     if (getenv("BARBELL_AMD_PFX_THREADS")) { int t = atoi(getenv("BARBELL_AMD_PFX_THREADS")); if (t >= 64 && t <= 768) c->pfx_threads = (uint32_t)t; }
     if (getenv("BARBELL_AMD_REG_THREADS")) { int t = atoi(getenv("BARBELL_AMD_REG_THREADS")); if (t >= 64 && t <= 512) c->reg_threads = (uint32_t)t; }
     c->groups.resize(n_groups);

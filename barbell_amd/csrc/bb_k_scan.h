@@ -53,6 +53,10 @@ struct hit_buf {
                              // (they do not survive in L2 between a lane's rounds: 58 MB of lines are in flight).  Measured, scan stage / kernel's HBM bytes per
                              // 2 M-read step: 2 chunks 4.75-4.80 ms / 2.40 GB, 3: 4.70-4.79 / 2.0, 4: 4.88-4.96 / 1.95, 5: 4.75-4.76 / 1.5
 #endif
+#ifndef BB_VERIFY_CHUNKS_WIDE
+#define BB_VERIFY_CHUNKS_WIDE 2   // the same for flanks of three words and more (67..256 nt).  Measured on the custom dual-end set (76 / 67 nt, k = 5, 31-row filter
+                                  // windows that flag almost nothing): scan stage 14.1-14.2 ms with 2 chunks, 14.7 with 5, 14.8 with 7 (an interval is ~110 columns)
+#endif
 #define BB_VERIFY_FLW 12u     // flag words per lane cached in LDS by k_flank_verify (reads up to ~5.5 kb; longer ones read theirs from HBM)
 #define BB_VERIFY_STAGE 128u  // hit records per wave in k_flank_verify's LDS staging area (a round with more goes out directly)
 // wave-wide: the staged records go out with one atomic and 16-byte stores of consecutive lanes
@@ -733,15 +737,16 @@ __device__ __forceinline__ void flank_verify_lane(const uint8_t* __restrict__ ba
             // around a flagged piece) comes in one or two rounds, so the lines it lies in are requested once (taken 16 or 32 bytes a
             // round the same sectors were fetched again: they do not survive in L2 between a lane's rounds)
             const bool work = state == WORK && cur < stop;
-            uint32_t wt[BB_VERIFY_CHUNKS][4];
-            const uint32_t cntb = work ? min(16u * BB_VERIFY_CHUNKS, stop - cur) : 0u;
+            constexpr int CH = W <= 2 ? BB_VERIFY_CHUNKS : BB_VERIFY_CHUNKS_WIDE;   // three-word flanks (67..96 nt): an interval is ~110 columns
+            uint32_t wt[CH][4];
+            const uint32_t cntb = work ? min(16u * CH, stop - cur) : 0u;
 #pragma unroll
-            for (int q = 0; q < BB_VERIFY_CHUNKS; ++q) {
+            for (int q = 0; q < CH; ++q) {
                 wt[q][0] = wt[q][1] = wt[q][2] = wt[q][3] = 0u;
                 if (cntb > (uint32_t)(16 * q)) load16(cur + 16u * (uint32_t)q, wt[q]);
             }
 #pragma unroll
-            for (int hb2 = 0; hb2 < BB_VERIFY_CHUNKS; ++hb2) {
+            for (int hb2 = 0; hb2 < CH; ++hb2) {
                 if (__any(cntb > (uint32_t)(16 * hb2))) {
 #pragma unroll
                     for (int b = 0; b < 16; ++b) {

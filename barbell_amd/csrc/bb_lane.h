@@ -74,7 +74,8 @@ __global__ __launch_bounds__(256, CW <= 48 ? 3 : 2) void k_barcode_lane(const ui
                                                       uint32_t strand, const bb_hit* __restrict__ hits, const uint32_t* __restrict__ hit_meta,
                                                       const uint32_t* __restrict__ hit_list, const uint32_t* __restrict__ list_cnt,
                                                       uint32_t n_hits_all, bb_rowtmp* __restrict__ rows, double min_score, double min_score_diff,
-                                                      double margin, uint32_t* __restrict__ fb_lists, uint32_t list_stride, uint32_t* __restrict__ fb_cnt) {
+                                                      double margin, uint32_t* __restrict__ fb_lists, uint32_t list_stride, uint32_t* __restrict__ fb_cnt,
+                                                      uint32_t use_nm) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t n_list = hit_list ? list_cnt[g] : n_hits_all;
     if (blockIdx.x * 256u >= n_list) return;
@@ -90,6 +91,11 @@ __global__ __launch_bounds__(256, CW <= 48 ? 3 : 2) void k_barcode_lane(const ui
     o += 256 * sizeof(bb_lb_entry);
     o = (o + 15) & ~(size_t)15;
     unsigned long long* s_tail = reinterpret_cast<unsigned long long*>(smem + o);  // [t][lo|hi][thread]
+    o += (size_t)T * 2 * 256 * 8;
+    // use_nm (groups with large flank budgets): per entry column, how many Match ops the walk through the shared rows holds — [column][lane]
+    // bytes.  The bound of a barcode then assumes THAT many Match columns ending where its path enters row P instead of all P of them: with
+    // k = 20 the flank hits are mostly chance hits whose pad rows match badly, and the all-P assumption left 8 x as many hits undecided.
+    uint8_t* s_nm = smem + o;
     __shared__ uint32_t s_eqt[16];   // Peq of the leading shared rows per base set; trailing rows matched per base set in bits 16..
     if (threadIdx.x < 16u) {
         const uint32_t e = reinterpret_cast<const uint32_t*>(tables + G.off_peq_pfx[strand])[threadIdx.x];
@@ -164,6 +170,7 @@ __global__ __launch_bounds__(256, CW <= 48 ? 3 : 2) void k_barcode_lane(const ui
     // of the barcode loop): their carry-in masks and the trailing rows' match masks stay in registers, and no prefix record is read.
     {
         uint32_t pv = P ? (P >= 32 ? 0xFFFFFFFFu : (1u << P) - 1u) : 0u, mv = 0u;
+        unsigned long long Mp = 0ull;   // use_nm: Match ops on the walk from (row r, previous column) up to row 0, a nibble per row (saturating at 15)
 #pragma unroll
         for (int c = 0; c < CW; ++c) {
             if (c < wmax) {  // wave-uniform
@@ -178,6 +185,21 @@ __global__ __launch_bounds__(256, CW <= 48 ? 3 : 2) void k_barcode_lane(const ui
                     shared_rows_column<PRIO>(PRIO, e & 0xFFFFu, P, pv, mv, hp, hm, shw);
                     hpw[c >> 5] |= in ? hp << (c & 31) : 0u;
                     hmw[c >> 5] |= in ? hm << (c & 31) : 0u;
+                    if (use_nm) {  // wave-uniform.  M[r][c] = M[r-1][c-1] + 1 (Match), M[r-1][c-1] (Sub), M[r][c-1] (Ins), M[r-1][c] (Del); M[0][.] = M[.][0] = 0
+                        unsigned long long Mc = 0ull;
+                        uint32_t above = 0u;
+                        uint32_t diag = 0u;   // M[r-1][c-1]
+#pragma unroll 1
+                        for (int r = 1; r <= P; ++r) {   // rolled (wave-uniform trip count): unrolled, 16 rows x 48 columns un-unrolled the column loop itself
+                            const uint32_t l = (shw >> (P - r)) & 1u, hh = (shw >> (16 + P - r)) & 1u;   // the cell's move: row r <-> bit P - r of each plane
+                            const uint32_t left = (uint32_t)(Mp >> (4 * (r - 1))) & 15u;
+                            const uint32_t v = hh ? (l ? above : left) : min(15u, diag + (l ? 0u : 1u));
+                            Mc |= (unsigned long long)v << (4 * (r - 1));
+                            above = v; diag = left;
+                        }
+                        s_nm[c * 256 + threadIdx.x] = (uint8_t)((Mc >> (4 * (P - 1))) & 15ull);   // the walk that enters row P in column c + 1
+                        Mp = Mc;
+                    }
                 }
             }
         }
@@ -371,7 +393,13 @@ __global__ __launch_bounds__(256, CW <= 48 ? 3 : 2) void k_barcode_lane(const ui
         // placement is an upper bound of the exact score — and equals the bound of the true path whenever the shared rows match
         // without gaps (the usual case: they are the flank the hit was found with).  Only the winner's walk is ever done (final trip).
         const int32_t ntext1 = cand ? __popc(dg) + __popc(dgt) + __popcll(phi & ~plo) : 0;
-        const int32_t tstart = cand ? max(best_pos - ntext1 - P, 0) : 0;
+        int32_t pmax = P;   // Match columns the bound grants the shared rows: all P, or (use_nm) the Match ops of the walk from the entry column
+        if (use_nm && P > 0) {  // wave-uniform
+            const int32_t cxq = cand ? best_pos - ntext1 : 0;
+            const uint32_t nmv = cxq >= 1 ? (uint32_t)s_nm[(cxq - 1) * 256 + threadIdx.x] : 0u;
+            pmax = nmv >= 15u ? P : (int32_t)nmv;   // 15 = saturated: P is an upper bound of any count
+        }
+        const int32_t tstart = cand ? max(best_pos - ntext1 - pmax, 0) : 0;
         const float ubf = lodhi_bound_tab<CW>(cand ? plo : 0ull, cand ? phi : 0ull, cand ? tstart : 0, cand ? best_pos : 0, CW, s_lb);  // all bytes: no branches between the table reads
         const uint32_t v = __float_as_uint(ubf) + 1u;
         if (cand) {  // first maximum wins: strictly greater replaces

@@ -10,7 +10,8 @@
 #include "bb_ctx.h"
 #include "bb_prio.h"
 
-#define BB_LANE_MAX_FLANK_K 8   // flank edit budget up to which k_barcode_lane's walk-free bound decides as often as the traced one (measured: k = 3, 5 yes; k = 20 no)
+#define BB_LANE_MAX_FLANK_K 8   // flank edit budget up to which k_barcode_lane's walk-free bound (all P shared rows matched) decides as often as the traced one
+                                // (measured: k = 3, 5 yes; k = 20 no); above it the kernel counts the Match ops of the walk per entry column (use_nm)
 
 // timing on: events around one kernel launch on its stream (bb_ctx::lev); bb_launch_timed_end closes the pair opened last
 void bb_launch_timed_begin(bb_ctx* c, hipStream_t st, const char* fmt, ...);
@@ -26,7 +27,7 @@ void bb_launch_barcode(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offs
 // ---- the per-class units ----
 struct bb_lane_args {
     const uint8_t* tables; const bb_group_dev* groups; uint32_t g, strand; const bb_hit* hits; const uint32_t* hit_meta; const uint32_t* list; const uint32_t* cnt;
-    uint32_t n_hits; bb_rowtmp* rows; double min_score, min_score_diff, margin; uint32_t* fb_lists; uint32_t list_stride; uint32_t* fb_cnt;
+    uint32_t n_hits; bb_rowtmp* rows; double min_score, min_score_diff, margin; uint32_t* fb_lists; uint32_t list_stride; uint32_t* fb_cnt; uint32_t use_nm;
 };
 struct bb_pfx_args {
     const uint8_t* tables; const bb_group_dev* groups; uint32_t g, strand; const bb_hit* hits; const bb_hit_pfx* pfxs; const uint32_t* list;

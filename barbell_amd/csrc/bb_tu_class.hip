@@ -18,7 +18,7 @@ template <int CW, bool TAIL>
 void lane_go(uint32_t blocks, size_t smem, hipStream_t st, const bb_lane_args& a) {
     if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_barcode_lane<CW, TAIL, PRIO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     hipLaunchKernelGGL((k_barcode_lane<CW, TAIL, PRIO>), dim3(blocks), dim3(256), smem, st, a.tables, a.groups, a.g, a.strand, a.hits, a.hit_meta, a.list, a.cnt, a.n_hits,
-                       a.rows, a.min_score, a.min_score_diff, a.margin, a.fb_lists, a.list_stride, a.fb_cnt);
+                       a.rows, a.min_score, a.min_score_diff, a.margin, a.fb_lists, a.list_stride, a.fb_cnt, a.use_nm);
 }
 template <bool TAIL, bool DEFPOL>
 void pfx_go(uint32_t blocks, uint32_t threads, size_t smem, hipStream_t st, const bb_pfx_args& a) {
