@@ -410,6 +410,19 @@ def test_cli_drops_quality_lines_that_look_like_headers(tmp_path):
         assert r.returncode == 0, r.stderr
         outs.append(o.read_bytes())
     assert outs[0] == outs[1] == outs[2] == outs[3] and outs[0].count(b"\n") > n // 2
+    # the block buffers page-locked (hipHostMalloc) instead of pageable, plain files read with pread instead of mapped: same bytes out
+    for knob in ("BARBELL_AMD_PINNED_SLOTS", "BARBELL_AMD_NO_MMAP"):
+        o = tmp_path / "knob.tsv"
+        r = subprocess.run([CLI, "annotate", "-i", str(fq), "-o", str(o), "--kit", "SQK-NBD114-96", "--flank-max-errors", "3", "--block-bytes", "30011"],
+                           capture_output=True, text=True, env=dict(env, **{knob: "1"}))
+        assert r.returncode == 0, r.stderr
+        assert o.read_bytes() == outs[0], knob
+    # the host side alone: every staged byte counted, nothing annotated
+    r = subprocess.run([CLI, "annotate", "-i", str(fq), "-o", str(tmp_path / "feed.tsv"), "--kit", "SQK-NBD114-96", "--block-bytes", "30011"],
+                       capture_output=True, text=True, env=dict(env, BARBELL_AMD_FEED_ONLY="1"))
+    assert r.returncode == 0 and "feed-only:" in r.stderr, r.stderr
+    staged = int(r.stderr.split("feed-only: ")[1].split(" bytes")[0])
+    assert 0 < staged < len(fq.read_bytes())   # headers and sequences only (the two-line form)
     py = tmp_path / "py.tsv"
     A.annotate_with_kit([str(fq)], str(py), "SQK-NBD114-96", max_flank_errors=3)
     assert py.read_bytes() == outs[0]

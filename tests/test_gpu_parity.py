@@ -745,3 +745,46 @@ def test_windows_of_exactly_64_columns():
     assert max(int(r["read_end_bar"]) - int(r["read_start_bar"]) for r in want) >= 24
     assert_same(got, want)
     dm.close()
+
+
+def test_dominant_kernel_is_named_and_timed():
+    """bb_last_dominant_kernel: with timing on, the longest launch of the barcode stage carries the name rocprofv3 prints for it and a
+    duration inside the stage's (bench.py's roofline.kernel / avg_launch_ms)."""
+    from barbell_amd import annotate as A
+
+    groups = config_groups("nbd96")
+    bases, offsets = A.synth_reads_host(groups, 3, 2000, 4000, 0, 20000)
+    dm = A.Demuxer()
+    for g in groups:
+        dm.add_query_group(g)
+    dm.set_timing(True)
+    dm.demux_packed(bases, offsets)
+    name, ms = dm.dominant_kernel()
+    stage = dm.kernel_ms()["k_barcode"]
+    assert name.startswith("k_barcode_lane<48, ") and name.endswith(", 216u>") and 0.0 < ms <= stage * 1.05, (name, ms, stage)
+    dm2 = A.Demuxer(policy="trace=MDSI")
+    for g in groups:
+        dm2.add_query_group(g)
+    dm2.set_timing(True)
+    dm2.demux_packed(bases, offsets)
+    assert dm2.dominant_kernel()[0].startswith("k_barcode_lane<48, ") and not dm2.dominant_kernel()[0].endswith(", 216u>")
+    dm.close(); dm2.close()
+
+
+def test_large_flank_budget_lane_kernel_and_its_round3_alternative(monkeypatch):
+    """Groups with flank budgets above 8 (k = 20 on the rapid kits) take k_barcode_lane with the per-entry-column Match counts of the shared
+    rows' walk (use_nm) since round 4; BARBELL_AMD_LANE_NM=0 sends them to k_barcode_pfx as in round 3.  Same rows either way, and the
+    kernel choice shows in bb_last_barcode_stats."""
+    from barbell_amd import annotate as A
+    from tests.common import noisy_reads
+
+    groups, bases, offsets = noisy_reads("rbk96x", 77, 400, 300, 3000, 0.03)
+    kinds = {}
+    for nm in ("1", "0"):
+        monkeypatch.setenv("BARBELL_AMD_LANE_NM", nm)
+        dm, got, want = run_both(groups, bases, offsets)
+        assert len(want) > 100
+        assert_same(got, want)
+        kinds[nm] = dm.barcode_stats(0, 0)["lane_kernel"]
+        dm.close()
+    assert kinds == {"1": True, "0": False}
