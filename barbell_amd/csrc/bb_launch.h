@@ -5,7 +5,7 @@
 //   bb_tu_bar.hip     k_bar_prefix(_list), k_barcode, k_barcode_reg, the run-time-order k_barcode_pfx variants; dispatch of a group's
 //                     barcode stage, incl. the per-class fast kernels below
 //   bb_tu_class.hip   compiled once per class of traceback orders (-DBB_TU_CLASS=0..17, bb_prio.h): k_barcode_lane<48, TAIL, PRIO> and
-//                     the fast k_barcode_pfx<48, TAIL, true, *, PRIO>; class 0 (the default order) also the 64-column k_barcode_lane
+//                     the 48-column k_barcode_pfx<48, TAIL, FAST, *, PRIO> (fast and exact); class 0 (the default order) also the 64-column k_barcode_lane
 #pragma once
 #include "bb_ctx.h"
 #include "bb_prio.h"
@@ -35,7 +35,7 @@ struct bb_pfx_args {
 };
 // false: this unit has no such instantiation (cw = 64 outside class 0) — the caller takes another kernel
 typedef bool (*bb_lane_launch_fn)(int cw, bool tail, uint32_t blocks, size_t smem, hipStream_t st, const bb_lane_args& a);
-typedef bool (*bb_pfx_launch_fn)(bool tail, bool defpol, uint32_t blocks, uint32_t threads, size_t smem, hipStream_t st, const bb_pfx_args& a);
-struct bb_class_unit { bb_lane_launch_fn lane; bb_pfx_launch_fn pfx_fast; };
+typedef bool (*bb_pfx_launch_fn)(bool tail, bool fast, bool defpol, uint32_t blocks, uint32_t threads, size_t smem, hipStream_t st, const bb_pfx_args& a);
+struct bb_class_unit { bb_lane_launch_fn lane; bb_pfx_launch_fn pfx; };   // pfx: the 48-column k_barcode_pfx, fast and exact
 // null members: the class was not built into this library (a development build with fewer classes)
 const bb_class_unit& bb_class_unit_of(int cls);

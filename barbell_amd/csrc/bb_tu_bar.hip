@@ -14,7 +14,7 @@
 // ---- the per-class units: weak references, so that a development build may link fewer classes (make CLASSES="0 5") ----
 #define BB_DECL_CLASS(K)                                                                                                                      \
     extern bool bb_class_lane_##K(int, bool, uint32_t, size_t, hipStream_t, const bb_lane_args&) __attribute__((weak));                        \
-    extern bool bb_class_pfx_##K(bool, bool, uint32_t, uint32_t, size_t, hipStream_t, const bb_pfx_args&) __attribute__((weak));
+    extern bool bb_class_pfx_##K(bool, bool, bool, uint32_t, uint32_t, size_t, hipStream_t, const bb_pfx_args&) __attribute__((weak));
 #define BB_FOR_CLASSES(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17)
 BB_FOR_CLASSES(BB_DECL_CLASS)
 static_assert(BB_PRIO_CLASSES == 18, "BB_FOR_CLASSES lists the classes of bb_prio.h");
@@ -111,15 +111,15 @@ void launch_barcode_pfx(bb_ctx* c, uint32_t n_hits, uint32_t g, uint32_t strand,
     const uint32_t per_cu = std::max(1u, (CW <= 48 ? 768u : 512u) / threads);  // blocks that fit a CU at this kernel's register count
     const uint32_t resident = (uint32_t)c->n_cus * per_cu * c->reg_blocks_mult;
     const uint32_t blocks = n_iter < resident ? n_iter : resident;
-    // the fast 48-column variants come from the class's unit (compile-time traceback order); the exact variants and the 64-column
-    // kernel read the order from the group (BB_PRIO_RT)
-    if (fast && CW == 48 && U.pfx_fast) {
+    // the 48-column variants, fast and exact, come from the class's unit (compile-time traceback order); the 64-column kernel reads the
+    // order from the group (BB_PRIO_RT)
+    if (CW == 48 && U.pfx) {
         const bb_pfx_args a{(const uint8_t*)c->d_tables, (const bb_group_dev*)c->d_groups, g, strand, (const bb_hit*)c->d_hits, (const bb_hit_pfx*)c->d_pfx, list,
                             cnt, n_hits, hpb, c->params.min_score, c->params.min_score_diff, c->d_rows};
-        const bool defpol = c->policy.lm_rule == BB_LM_PLATEAU_RIGHT && c->policy.bar_tie == BB_TIE_FIRST;
-        bb_launch_timed_begin(c, st, "k_barcode_pfx<48, %s, true, %s, %uu>", D.tail[strand] > 0 ? "true" : "false", defpol && c->prio_class == 0 ? "true" : "false",
-                              BB_PRIO_TABLE.cls[c->prio_class]);
-        if (U.pfx_fast(D.tail[strand] > 0, defpol, blocks, threads, smem, st, a)) { bb_launch_timed_end(c, st); return; }
+        const bool defpol = fast && c->policy.lm_rule == BB_LM_PLATEAU_RIGHT && c->policy.bar_tie == BB_TIE_FIRST;
+        bb_launch_timed_begin(c, st, "k_barcode_pfx<48, %s, %s, %s, %uu>", D.tail[strand] > 0 ? "true" : "false", fast ? "true" : "false",
+                              defpol && c->prio_class == 0 ? "true" : "false", BB_PRIO_TABLE.cls[c->prio_class]);
+        if (U.pfx(D.tail[strand] > 0, fast, defpol, blocks, threads, smem, st, a)) { bb_launch_timed_end(c, st); return; }
         --c->n_lev;
     }
 #define BB_PFX_ARGS (const uint8_t*)c->d_tables, (const bb_group_dev*)c->d_groups, g, strand, (const bb_hit*)c->d_hits, (const bb_hit_pfx*)c->d_pfx, list, \

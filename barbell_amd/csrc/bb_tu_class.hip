@@ -20,10 +20,10 @@ void lane_go(uint32_t blocks, size_t smem, hipStream_t st, const bb_lane_args& a
     hipLaunchKernelGGL((k_barcode_lane<CW, TAIL, PRIO>), dim3(blocks), dim3(256), smem, st, a.tables, a.groups, a.g, a.strand, a.hits, a.hit_meta, a.list, a.cnt, a.n_hits,
                        a.rows, a.min_score, a.min_score_diff, a.margin, a.fb_lists, a.list_stride, a.fb_cnt, a.use_nm);
 }
-template <bool TAIL, bool DEFPOL>
+template <bool TAIL, bool FAST, bool DEFPOL>
 void pfx_go(uint32_t blocks, uint32_t threads, size_t smem, hipStream_t st, const bb_pfx_args& a) {
-    if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_barcode_pfx<48, TAIL, true, DEFPOL, PRIO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipLaunchKernelGGL((k_barcode_pfx<48, TAIL, true, DEFPOL, PRIO>), dim3(blocks), dim3(threads), smem, st, a.tables, a.groups, a.g, a.strand, a.hits, a.pfxs,
+    if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_barcode_pfx<48, TAIL, FAST, DEFPOL, PRIO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipLaunchKernelGGL((k_barcode_pfx<48, TAIL, FAST, DEFPOL, PRIO>), dim3(blocks), dim3(threads), smem, st, a.tables, a.groups, a.g, a.strand, a.hits, a.pfxs,
                        a.list, a.cnt, a.n_hits, a.hpb, a.min_score, a.min_score_diff, a.rows);
 }
 }  // namespace
@@ -35,12 +35,15 @@ bool BB_CAT(bb_class_lane_, BB_TU_CLASS)(int cw, bool tail, uint32_t blocks, siz
 #endif
     return false;
 }
-// defpol (the default local-minimum and tie rules as compile-time constants, worth 1 %) exists for the default order only
-bool BB_CAT(bb_class_pfx_, BB_TU_CLASS)(bool tail, bool defpol, uint32_t blocks, uint32_t threads, size_t smem, hipStream_t st, const bb_pfx_args& a) {
+// The 48-column k_barcode_pfx of the class: the fast variant (bounds) and the exact one (every lane scored: the hits the bounds leave
+// undecided — under a non-default order the run-time form of the move planes made that pass 1.3 x slower).  defpol (the default
+// local-minimum and tie rules as compile-time constants, worth 1 %) exists for the default order's fast variant only.
+bool BB_CAT(bb_class_pfx_, BB_TU_CLASS)(bool tail, bool fast, bool defpol, uint32_t blocks, uint32_t threads, size_t smem, hipStream_t st, const bb_pfx_args& a) {
+    if (!fast) { if (tail) pfx_go<true, false, false>(blocks, threads, smem, st, a); else pfx_go<false, false, false>(blocks, threads, smem, st, a); return true; }
 #if BB_TU_CLASS == 0
-    if (defpol) { if (tail) pfx_go<true, true>(blocks, threads, smem, st, a); else pfx_go<false, true>(blocks, threads, smem, st, a); return true; }
+    if (defpol) { if (tail) pfx_go<true, true, true>(blocks, threads, smem, st, a); else pfx_go<false, true, true>(blocks, threads, smem, st, a); return true; }
 #endif
     (void)defpol;
-    if (tail) pfx_go<true, false>(blocks, threads, smem, st, a); else pfx_go<false, false>(blocks, threads, smem, st, a);
+    if (tail) pfx_go<true, true, false>(blocks, threads, smem, st, a); else pfx_go<false, true, false>(blocks, threads, smem, st, a);
     return true;
 }
