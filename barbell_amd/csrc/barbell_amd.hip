@@ -425,7 +425,7 @@ int bb_create(const bb_group_desc* groups, uint32_t n_groups, const bb_params* p
 int bb_create_policy(const bb_group_desc* groups, uint32_t n_groups, const bb_params* params, const bb_policy* policy, bb_ctx** out) {
     g_create_error.clear();
     if (!groups || !params || !out || n_groups == 0) return BB_E_INVALID;
-    if (n_groups > BB_MAX_GROUPS) { g_create_error = "more than 8 query groups"; return BB_E_UNSUPPORTED; }
+    if (n_groups > BB_MAX_GROUPS) { g_create_error = "more than 32 query groups"; return BB_E_UNSUPPORTED; }
     if (!(params->alpha >= 0.0f)) return BB_E_INVALID;
     if (policy && bb_policy_validate(policy) != 0) { g_create_error = "policy: field out of range"; return BB_E_INVALID; }
     bb_ctx* c = new bb_ctx();

@@ -19,7 +19,7 @@
 #define BB_MAX_WB 4        // padded barcode pattern words (m_bar <= 128; <= 64 run the tuned kernels, longer ones the any-geometry kernel)
 #define BB_MAX_WIN 256     // barcode window columns (<= 64 run the tuned kernels)
 #define BB_MAX_FLANK_K 127 // flank error budget
-#define BB_MAX_GROUPS 8
+#define BB_MAX_GROUPS 32   // a group is an index in a byte, a bit of a 32-bit launch mask (k_flank_trace) and four list slots of 128 (bb_hit_meta)
 #define BB_MAX_OPS (32 * BB_MAX_WB + BB_MAX_WIN)  // unit ops of one barcode alignment
 
 // IUPAC base sets A=1 C=2 G=4 T=8 (case-insensitive, U=T, X = empty, non-letters invalid = 0xFF)

@@ -46,7 +46,7 @@ extern "C" {
 #define BB_E_FASTQ        -12  /* malformed FASTQ record (barbell_amd_fastq.h)                         */
 
 /* ---- limits (the reference's BarcodeGroup::new, barcodes.rs:105-197, has none; every shipped kit fits) --------
- *   query groups per context                      <= 8
+ *   query groups per context                      <= 32
  *   sequences per group                           <= 1024
  *   flank = prefix + barcode mask + suffix        <= 256 nt (<= 128 nt run the tuned scan/trace instantiations)
  *   padded barcode pattern (10 + barcode + 10)    <= 128 nt (<= 48 nt and windows <= 64 columns: register-resident kernels;

@@ -69,7 +69,7 @@ def test_create_validates_before_touching_the_gpu(L):
     assert b"flank of 281 nt" in L.bb_last_error(None)
     assert create([([b"ACGTACGTAC" + b"C" * 110 + b"GTGTGTGTGT", b"ACGTACGTAC" + b"T" * 110 + b"GTGTGTGTGT"], 0, None)])[0] == _abi.BB_E_UNSUPPORTED
     assert b"padded barcode pattern of 130 nt" in L.bb_last_error(None)
-    assert create([([b"AAATTTGGG", b"AAACTTGGG"], 0, None)] * 9)[0] == _abi.BB_E_UNSUPPORTED and b"8 query groups" in L.bb_last_error(None)
+    assert create([([b"AAATTTGGG", b"AAACTTGGG"], 0, None)] * 33)[0] == _abi.BB_E_UNSUPPORTED and b"32 query groups" in L.bb_last_error(None)
 
 
 def test_no_cpu_fallback(L):

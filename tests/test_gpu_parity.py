@@ -788,3 +788,32 @@ def test_large_flank_budget_lane_kernel_and_its_round3_alternative(monkeypatch):
         kinds[nm] = dm.barcode_stats(0, 0)["lane_kernel"]
         dm.close()
     assert kinds == {"1": True, "0": False}
+
+
+def test_twelve_query_groups():
+    """More than eight query groups in one context (the limit until round 4; 32 now — the reference's BarcodeGroup::new has none): twelve
+    custom groups of different geometries and types, reads carrying constructs of several of them."""
+    from barbell_amd import annotate as A, kits
+
+    rng = np.random.default_rng(12)
+    rnd = lambda n: bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), n))
+    groups = []
+    for gi in range(12):
+        pre, suf, blen, n = rnd(int(rng.integers(10, 30))), rnd(int(rng.integers(6, 25))), 24, int(rng.integers(13, 40))
+        seqs = [pre + rnd(blen) + suf for _ in range(n)]
+        groups.append(kits.QueryGroup(seqs, [f"g{gi}b{i}" for i in range(n)], _abi.BB_FTAG if gi % 2 == 0 else _abi.BB_RTAG, int(rng.integers(2, 6))))
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    reads = []
+    for _ in range(600):   # one to three constructs of random groups per read, either strand, random spacers
+        r = rnd(int(rng.integers(0, 80)))
+        for _ in range(int(rng.integers(1, 4))):
+            gq = groups[int(rng.integers(0, 12))]
+            s = bytes(gq.seqs[int(rng.integers(0, len(gq.seqs)))])
+            r += (s if rng.random() < 0.6 else s.translate(comp)[::-1]) + rnd(int(rng.integers(100, 700)))
+        reads.append(r)
+    bases = np.frombuffer(b"".join(reads), dtype=np.uint8).copy()
+    offsets = np.concatenate([[0], np.cumsum([len(r) for r in reads])]).astype(np.uint64)
+    dm, got, want = run_both(groups, bases, offsets)
+    assert len(want) > 600 and len(set(want["group_idx"].tolist())) == 12
+    assert_same(got, want)
+    dm.close()
