@@ -105,7 +105,7 @@ struct bb_ctx {
     int lane_kernel = 1;         // BARBELL_AMD_LANE: 1 = the fast barcode stage with one lane per hit (k_barcode_lane) for groups whose flank budget is small
                                  // (its bound assumes the shared rows match, which they do when the flank was found with few edits: at k = 20 eight times
                                  // as many hits go on to the exact kernel), 0 = one lane per (hit, barcode) everywhere (k_barcode_pfx), 2 = one lane per hit everywhere
-    bool lane_nm = true;         // BARBELL_AMD_LANE_NM=0: groups with flank budgets above BB_LANE_MAX_FLANK_K take k_barcode_pfx (round 3) instead of k_barcode_lane with use_nm
+    bool lane_nm = true;         // BARBELL_AMD_LANE_NM=0: groups with flank budgets above BB_LANE_MAX_FLANK_K take k_barcode_pfx (round 3) instead of k_barcode_lane<.., NM = true>
     bool force_generic = false;  // BARBELL_AMD_GENERIC=1: use the generic (any-geometry) kernels, for tests
     hipEvent_t ev[K_COUNT + 1]{};
     float ms[K_COUNT]{};

@@ -69,13 +69,13 @@ __device__ __forceinline__ void shared_rows_walk(const uint32_t* s_eqt, const ui
 
 // waves per SIMD the register budget is set for: the move planes are 2 x CW registers — 48 columns fit three waves (<= 168 VGPRs), 64 two
 // PRIO: the class of the policy's traceback order (bb_prio.h): the move planes are one v_bitop3 each with the class's truth tables
-template <int CW, bool TAIL, uint32_t PRIO>
+template <int CW, bool TAIL, uint32_t PRIO, bool NM>
 __global__ __launch_bounds__(256, CW <= 48 ? 3 : 2) void k_barcode_lane(const uint8_t* __restrict__ tables, const bb_group_dev* __restrict__ groups, uint32_t g,
                                                       uint32_t strand, const bb_hit* __restrict__ hits, const uint32_t* __restrict__ hit_meta,
                                                       const uint32_t* __restrict__ hit_list, const uint32_t* __restrict__ list_cnt,
                                                       uint32_t n_hits_all, bb_rowtmp* __restrict__ rows, double min_score, double min_score_diff,
-                                                      double margin, uint32_t* __restrict__ fb_lists, uint32_t list_stride, uint32_t* __restrict__ fb_cnt,
-                                                      uint32_t use_nm) {
+                                                      double margin, uint32_t* __restrict__ fb_lists, uint32_t list_stride, uint32_t* __restrict__ fb_cnt) {
+    constexpr bool use_nm = NM;   // groups with large flank budgets: the bound by the walk's own Match columns (below)
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t n_list = hit_list ? list_cnt[g] : n_hits_all;
     if (blockIdx.x * 256u >= n_list) return;
@@ -92,10 +92,12 @@ __global__ __launch_bounds__(256, CW <= 48 ? 3 : 2) void k_barcode_lane(const ui
     o = (o + 15) & ~(size_t)15;
     unsigned long long* s_tail = reinterpret_cast<unsigned long long*>(smem + o);  // [t][lo|hi][thread]
     o += (size_t)T * 2 * 256 * 8;
-    // use_nm (groups with large flank budgets): per entry column, how many Match ops the walk through the shared rows holds — [column][lane]
-    // bytes.  The bound of a barcode then assumes THAT many Match columns ending where its path enters row P instead of all P of them: with
-    // k = 20 the flank hits are mostly chance hits whose pad rows match badly, and the all-P assumption left 8 x as many hits undecided.
-    uint8_t* s_nm = smem + o;
+    // use_nm (groups with large flank budgets): per entry column, WHICH of the 16 columns up to it hold a Match op of the walk through the
+    // shared rows — [column][lane] 16-bit masks (bit i <-> column cx - i; 0xFFFF: not representable, grant all P).  The bound of a barcode
+    // then grants the shared rows exactly those Match columns where its path enters row P instead of P contiguous ones: with k = 20 the
+    // flank hits are mostly chance hits whose pad rows match badly, and the all-P assumption left 8 x as many hits undecided (a count of
+    // the walk's Match ops, granted contiguously, still left 5-16 %).
+    uint16_t* s_nm = reinterpret_cast<uint16_t*>(smem + o);
     __shared__ uint32_t s_eqt[16];   // Peq of the leading shared rows per base set; trailing rows matched per base set in bits 16..
     if (threadIdx.x < 16u) {
         const uint32_t e = reinterpret_cast<const uint32_t*>(tables + G.off_peq_pfx[strand])[threadIdx.x];
@@ -170,7 +172,6 @@ __global__ __launch_bounds__(256, CW <= 48 ? 3 : 2) void k_barcode_lane(const ui
     // of the barcode loop): their carry-in masks and the trailing rows' match masks stay in registers, and no prefix record is read.
     {
         uint32_t pv = P ? (P >= 32 ? 0xFFFFFFFFu : (1u << P) - 1u) : 0u, mv = 0u;
-        unsigned long long Mp = 0ull;   // use_nm: Match ops on the walk from (row r, previous column) up to row 0, a nibble per row (saturating at 15)
 #pragma unroll
         for (int c = 0; c < CW; ++c) {
             if (c < wmax) {  // wave-uniform
@@ -185,26 +186,44 @@ __global__ __launch_bounds__(256, CW <= 48 ? 3 : 2) void k_barcode_lane(const ui
                     shared_rows_column<PRIO>(PRIO, e & 0xFFFFu, P, pv, mv, hp, hm, shw);
                     hpw[c >> 5] |= in ? hp << (c & 31) : 0u;
                     hmw[c >> 5] |= in ? hm << (c & 31) : 0u;
-                    if (use_nm) {  // wave-uniform.  M[r][c] = M[r-1][c-1] + 1 (Match), M[r-1][c-1] (Sub), M[r][c-1] (Ins), M[r-1][c] (Del); M[0][.] = M[.][0] = 0
-                        unsigned long long Mc = 0ull;
-                        uint32_t above = 0u;
-                        uint32_t diag = 0u;   // M[r-1][c-1]
-#pragma unroll 1
-                        for (int r = 1; r <= P; ++r) {   // rolled (wave-uniform trip count): unrolled, 16 rows x 48 columns un-unrolled the column loop itself
-                            const uint32_t l = (shw >> (P - r)) & 1u, hh = (shw >> (16 + P - r)) & 1u;   // the cell's move: row r <-> bit P - r of each plane
-                            const uint32_t left = (uint32_t)(Mp >> (4 * (r - 1))) & 15u;
-                            const uint32_t v = hh ? (l ? above : left) : min(15u, diag + (l ? 0u : 1u));
-                            Mc |= (unsigned long long)v << (4 * (r - 1));
-                            above = v; diag = left;
-                        }
-                        s_nm[c * 256 + threadIdx.x] = (uint8_t)((Mc >> (4 * (P - 1))) & 15ull);   // the walk that enters row P in column c + 1
-                        Mp = Mc;
-                    }
                 }
             }
         }
     }
 
+    if (NM && P > 0) {  // wave-uniform
+        // W[r] = Match columns of the walk from (row r, column c) up to row 0, bit i <-> column c - i:
+        //   Match: (W[r-1] of column c-1) << 1 | 1;  Sub: the same without the 1;  Ins: (W[r] of column c-1) << 1;  Del: W[r-1] of column c.
+        // A rolled loop over the columns (the hit's window codes re-read from its record, the shared rows' step again: a dozen instructions),
+        // the rows unrolled with their masks in registers — 32 bits each, so a walk of up to 32 columns is exact; what does not fit 16 bits
+        // when it is stored becomes the sentinel.
+        uint32_t pv = P >= 32 ? 0xFFFFFFFFu : (1u << P) - 1u, mv = 0u;
+        uint32_t Wp[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Wp[r] = 0u;
+        const uint8_t* win = reinterpret_cast<const uint8_t*>(hits + hit_idx) + 32;
+#pragma unroll 1
+        for (int c = 0; c < wmax; ++c) {
+            const uint32_t code = active && c < wn ? (uint32_t)win[c] & 0xFu : 0u;
+            uint32_t hp, hm, shw;
+            shared_rows_column<PRIO>(PRIO, s_eqt[code] & 0xFFFFu, P, pv, mv, hp, hm, shw);
+            uint32_t above = 0u, diag = 0u, out = 0u;
+#pragma unroll
+            for (int r = 1; r <= 16; ++r) {
+                if (r <= P) {  // wave-uniform
+                    const uint32_t l = (shw >> (P - r)) & 1u, hh = (shw >> (16 + P - r)) & 1u;   // the cell's move: row r <-> bit P - r of each plane
+                    const uint32_t left = Wp[r - 1];
+                    const uint32_t src = hh ? left : diag;                  // Ins continues in this row, Match / Sub in the row above, both one column back
+                    const uint32_t v = (hh && l) ? above : ((src << 1) | ((hh | l) ? 0u : 1u) | (src & 0x80000000u ? 0xFFFF0000u : 0u));  // a lost bit poisons the high half
+                    diag = left;          // W[r][c-1] is the next row's diagonal
+                    Wp[r - 1] = v;        // becomes W[r][c]
+                    above = v;
+                    if (r == P) out = v;
+                }
+            }
+            s_nm[c * 256 + threadIdx.x] = (uint16_t)((out >> 16) ? 0xFFFFu : out);   // the walk that enters row P in column c + 1
+        }
+    }
     const uint8_t* s_peq_b = reinterpret_cast<const uint8_t*>(s_peq);
     // running top-2 of the two candidate sets (searcher.rs:303-328): bound bits + 1 (0 = empty), first maximum's barcode
     uint32_t b1A = 0u, b2A = 0u, pA = 0u, b1B = 0u, b2B = 0u, pB = 0u;
@@ -369,6 +388,23 @@ __global__ __launch_bounds__(256, CW <= 48 ? 3 : 2) void k_barcode_lane(const ui
                 W.ub_second = sx ? (double)__uint_as_float(sx - 1u) / G.perfect : -1.0;   // -1: no other candidate
                 W.tstart = (uint8_t)tstart; W.best_pos = (uint8_t)best_pos; W.top = (uint16_t)ptop;
                 W.flags = 0; W.marker = 2; W._pad[0] = W._pad[1] = 0;
+#ifdef BB_LANE_CHECK_NM
+                // debug build only: the stored Match mask of the walk entering at cx against the walk just done; a difference wrecks the
+                // record, so that any parity test fails on it
+                if (use_nm && P > 0 && cand && cx >= 1) {
+                    const uint32_t wm = (uint32_t)s_nm[(cx - 1) * 256 + threadIdx.x];
+                    if (wm != 0xFFFFu) {
+                        uint32_t truth = 0u;
+                        for (int i = 0; i < 16; ++i) {
+                            const int ci = cx - 1 - i;
+                            if (ci >= tstart && ci >= 0 && !(((plo | phi) >> ci) & 1ull)) truth |= 1u << i;
+                        }
+                        bool extra = false;   // a Match further than 16 columns from the entry should have made the sentinel
+                        for (int ci = cx - 17; ci >= tstart && ci >= 0; --ci) extra |= !(((plo | phi) >> ci) & 1ull);
+                        if (truth != wm || extra) W.plo = ~0ull;
+                    } else if (cx - tstart <= 16) W.plo = ~0ull;   // a sentinel for a walk that would have fit
+                }
+#endif
                 int bmax = cand ? best_pos : 0;
 #pragma unroll
                 for (int d = 32; d >= 1; d >>= 1) bmax = max(bmax, __shfl_xor(bmax, d, 64));
@@ -393,14 +429,19 @@ __global__ __launch_bounds__(256, CW <= 48 ? 3 : 2) void k_barcode_lane(const ui
         // placement is an upper bound of the exact score — and equals the bound of the true path whenever the shared rows match
         // without gaps (the usual case: they are the flank the hit was found with).  Only the winner's walk is ever done (final trip).
         const int32_t ntext1 = cand ? __popc(dg) + __popc(dgt) + __popcll(phi & ~plo) : 0;
-        int32_t pmax = P;   // Match columns the bound grants the shared rows: all P, or (use_nm) the Match ops of the walk from the entry column
-        if (use_nm && P > 0) {  // wave-uniform
+        int32_t tstart = cand ? max(best_pos - ntext1 - P, 0) : 0;   // the shared rows granted P Match columns ending at the entry column ...
+        unsigned long long plo_b = cand ? plo : 0ull;
+        if (use_nm && P > 0) {  // wave-uniform: ... or exactly the Match columns of the walk from there (non-Match columns of its 16 marked in the lo plane)
             const int32_t cxq = cand ? best_pos - ntext1 : 0;
-            const uint32_t nmv = cxq >= 1 ? (uint32_t)s_nm[(cxq - 1) * 256 + threadIdx.x] : 0u;
-            pmax = nmv >= 15u ? P : (int32_t)nmv;   // 15 = saturated: P is an upper bound of any count
+            const uint32_t wm = cxq >= 1 ? (uint32_t)s_nm[(cxq - 1) * 256 + threadIdx.x] : 0u;
+            if (wm != 0xFFFFu) {
+                // bit i of wm <-> column cxq - i <-> plane bit cxq - 1 - i: the 16 bits reversed and slid under cxq
+                const unsigned long long nm16 = (unsigned long long)(__brev(~wm) >> 16) & 0xFFFFull;
+                plo_b |= cxq >= 16 ? nm16 << (cxq - 16) : nm16 >> (16 - cxq);
+                tstart = cand ? max(cxq - 16, 0) : 0;
+            }
         }
-        const int32_t tstart = cand ? max(best_pos - ntext1 - pmax, 0) : 0;
-        const float ubf = lodhi_bound_tab<CW>(cand ? plo : 0ull, cand ? phi : 0ull, cand ? tstart : 0, cand ? best_pos : 0, CW, s_lb);  // all bytes: no branches between the table reads
+        const float ubf = lodhi_bound_tab<CW>(plo_b, cand ? phi : 0ull, cand ? tstart : 0, cand ? best_pos : 0, CW, s_lb);  // all bytes: no branches between the table reads
         const uint32_t v = __float_as_uint(ubf) + 1u;
         if (cand) {  // first maximum wins: strictly greater replaces
             if (v > b1B) { b2B = b1B; b1B = v; pB = (uint32_t)it; } else if (v > b2B) b2B = v;

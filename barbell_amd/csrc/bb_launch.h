@@ -4,14 +4,14 @@
 //   bb_tu_trace.hip   k_flank_trace<W, MODE>
 //   bb_tu_bar.hip     k_bar_prefix(_list), k_barcode, k_barcode_reg, the run-time-order k_barcode_pfx variants; dispatch of a group's
 //                     barcode stage, incl. the per-class fast kernels below
-//   bb_tu_class.hip   compiled once per class of traceback orders (-DBB_TU_CLASS=0..17, bb_prio.h): k_barcode_lane<48, TAIL, PRIO> and
+//   bb_tu_class.hip   compiled once per class of traceback orders (-DBB_TU_CLASS=0..17, bb_prio.h): k_barcode_lane<48, TAIL, PRIO, NM> and
 //                     the 48-column k_barcode_pfx<48, TAIL, FAST, *, PRIO> (fast and exact); class 0 (the default order) also the 64-column k_barcode_lane
 #pragma once
 #include "bb_ctx.h"
 #include "bb_prio.h"
 
 #define BB_LANE_MAX_FLANK_K 8   // flank edit budget up to which k_barcode_lane's walk-free bound (all P shared rows matched) decides as often as the traced one
-                                // (measured: k = 3, 5 yes; k = 20 no); above it the kernel counts the Match ops of the walk per entry column (use_nm)
+                                // (measured: k = 3, 5 yes; k = 20 no); above it the NM instantiation follows the walk per entry column (bb_lane.h)
 
 // timing on: events around one kernel launch on its stream (bb_ctx::lev); bb_launch_timed_end closes the pair opened last
 void bb_launch_timed_begin(bb_ctx* c, hipStream_t st, const char* fmt, ...);

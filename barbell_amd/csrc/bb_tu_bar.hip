@@ -45,7 +45,7 @@ void bb_launch_timed_end(bb_ctx* c, hipStream_t st) {
 bool bb_takes_lane(const bb_ctx* c, uint32_t g, uint32_t strand, bool wide) {
     const bb_group_dev& D = c->gdev[g];
     if (!bb_class_unit_of(c->prio_class).lane || (wide && c->prio_class != 0)) return false;
-    // any flank budget since round 4: above BB_LANE_MAX_FLANK_K the kernel's bound counts the Match ops of the shared rows' walk (use_nm);
+    // any flank budget since round 4: above BB_LANE_MAX_FLANK_K the kernel's bound uses the Match columns of the shared rows' walk (the NM instantiation);
     // BARBELL_AMD_LANE_NM=0 restores the round-3 choice (k_barcode_pfx for those groups)
     const bool big_k = c->groups[g].info.flank_k > BB_LANE_MAX_FLANK_K;
     return c->fast_path && D.pfx[strand] <= 16 &&
@@ -83,11 +83,11 @@ void launch_barcode_pfx(bb_ctx* c, uint32_t n_hits, uint32_t g, uint32_t strand,
     if (fast && bb_takes_lane(c, g, strand, CW > 48)) {
         const uint32_t T = (uint32_t)D.tail[strand];
         const uint32_t use_nm = (c->groups[g].info.flank_k > BB_LANE_MAX_FLANK_K && c->lane_nm && D.pfx[strand] > 0) ? 1u : 0u;
-        const size_t smem = (((size_t)N * 64 + 31) & ~(size_t)31) + 256 * 32 + 16 + (size_t)T * 2 * 256 * 8 + (use_nm ? (size_t)CW * 256 : 0);
+        const size_t smem = (((size_t)N * 64 + 31) & ~(size_t)31) + 256 * 32 + 16 + (size_t)T * 2 * 256 * 8 + (use_nm ? (size_t)CW * 256 * 2 : 0);
         const bb_lane_args a{(const uint8_t*)c->d_tables, (const bb_group_dev*)c->d_groups, g, strand, (const bb_hit*)c->d_hits, (const uint32_t*)c->d_hitmeta, list, cnt, n_hits, c->d_rows,
                              c->params.min_score, c->params.min_score_diff, c->fast_margin, c->d_fb_lists, c->cap_hits, c->d_fbcnt, use_nm};
         const uint32_t lev0 = c->n_lev;
-        bb_launch_timed_begin(c, st, "k_barcode_lane<%d, %s, %uu>", CW, T > 0 ? "true" : "false", BB_PRIO_TABLE.cls[c->prio_class]);
+        bb_launch_timed_begin(c, st, "k_barcode_lane<%d, %s, %uu, %s>", CW, T > 0 ? "true" : "false", BB_PRIO_TABLE.cls[c->prio_class], use_nm ? "true" : "false");
         if (U.lane(CW, T > 0, (n_hits + 255) / 256, smem, st, a)) { bb_launch_timed_end(c, st); c->lane_used[g][strand] = 1; return; }
         c->n_lev = lev0;
     }

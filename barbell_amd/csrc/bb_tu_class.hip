@@ -14,11 +14,16 @@
 namespace {
 constexpr uint32_t PRIO = BB_PRIO_TABLE.cls[BB_TU_CLASS];
 
-template <int CW, bool TAIL>
+template <int CW, bool TAIL, bool NM>
 void lane_go(uint32_t blocks, size_t smem, hipStream_t st, const bb_lane_args& a) {
-    if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_barcode_lane<CW, TAIL, PRIO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipLaunchKernelGGL((k_barcode_lane<CW, TAIL, PRIO>), dim3(blocks), dim3(256), smem, st, a.tables, a.groups, a.g, a.strand, a.hits, a.hit_meta, a.list, a.cnt, a.n_hits,
-                       a.rows, a.min_score, a.min_score_diff, a.margin, a.fb_lists, a.list_stride, a.fb_cnt, a.use_nm);
+    if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_barcode_lane<CW, TAIL, PRIO, NM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipLaunchKernelGGL((k_barcode_lane<CW, TAIL, PRIO, NM>), dim3(blocks), dim3(256), smem, st, a.tables, a.groups, a.g, a.strand, a.hits, a.hit_meta, a.list, a.cnt, a.n_hits,
+                       a.rows, a.min_score, a.min_score_diff, a.margin, a.fb_lists, a.list_stride, a.fb_cnt);
+}
+template <int CW>
+void lane_pick(bool tail, bool nm, uint32_t blocks, size_t smem, hipStream_t st, const bb_lane_args& a) {
+    if (nm) { if (tail) lane_go<CW, true, true>(blocks, smem, st, a); else lane_go<CW, false, true>(blocks, smem, st, a); }
+    else { if (tail) lane_go<CW, true, false>(blocks, smem, st, a); else lane_go<CW, false, false>(blocks, smem, st, a); }
 }
 template <bool TAIL, bool FAST, bool DEFPOL>
 void pfx_go(uint32_t blocks, uint32_t threads, size_t smem, hipStream_t st, const bb_pfx_args& a) {
@@ -29,9 +34,9 @@ void pfx_go(uint32_t blocks, uint32_t threads, size_t smem, hipStream_t st, cons
 }  // namespace
 
 bool BB_CAT(bb_class_lane_, BB_TU_CLASS)(int cw, bool tail, uint32_t blocks, size_t smem, hipStream_t st, const bb_lane_args& a) {
-    if (cw == 48) { if (tail) lane_go<48, true>(blocks, smem, st, a); else lane_go<48, false>(blocks, smem, st, a); return true; }
+    if (cw == 48) { lane_pick<48>(tail, a.use_nm != 0u, blocks, smem, st, a); return true; }
 #if BB_TU_CLASS == 0
-    if (cw == 64) { if (tail) lane_go<64, true>(blocks, smem, st, a); else lane_go<64, false>(blocks, smem, st, a); return true; }
+    if (cw == 64) { lane_pick<64>(tail, a.use_nm != 0u, blocks, smem, st, a); return true; }
 #endif
     return false;
 }

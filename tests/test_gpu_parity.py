@@ -761,19 +761,19 @@ def test_dominant_kernel_is_named_and_timed():
     dm.demux_packed(bases, offsets)
     name, ms = dm.dominant_kernel()
     stage = dm.kernel_ms()["k_barcode"]
-    assert name.startswith("k_barcode_lane<48, ") and name.endswith(", 216u>") and 0.0 < ms <= stage * 1.05, (name, ms, stage)
+    assert name.startswith("k_barcode_lane<48, ") and name.endswith(", 216u, false>") and 0.0 < ms <= stage * 1.05, (name, ms, stage)
     dm2 = A.Demuxer(policy="trace=MDSI")
     for g in groups:
         dm2.add_query_group(g)
     dm2.set_timing(True)
     dm2.demux_packed(bases, offsets)
-    assert dm2.dominant_kernel()[0].startswith("k_barcode_lane<48, ") and not dm2.dominant_kernel()[0].endswith(", 216u>")
+    assert dm2.dominant_kernel()[0].startswith("k_barcode_lane<48, ") and ", 216u, " not in dm2.dominant_kernel()[0]
     dm.close(); dm2.close()
 
 
 def test_large_flank_budget_lane_kernel_and_its_round3_alternative(monkeypatch):
-    """Groups with flank budgets above 8 (k = 20 on the rapid kits) take k_barcode_lane with the per-entry-column Match counts of the shared
-    rows' walk (use_nm) since round 4; BARBELL_AMD_LANE_NM=0 sends them to k_barcode_pfx as in round 3.  Same rows either way, and the
+    """Groups with flank budgets above 8 (k = 20 on the rapid kits) take k_barcode_lane with the per-entry-column Match masks of the shared
+    rows' walk (NM) since round 4; BARBELL_AMD_LANE_NM=0 sends them to k_barcode_pfx as in round 3.  Same rows either way, and the
     kernel choice shows in bb_last_barcode_stats."""
     from barbell_amd import annotate as A
     from tests.common import noisy_reads
