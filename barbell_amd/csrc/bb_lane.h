@@ -92,6 +92,8 @@ __global__ __launch_bounds__(256, CW <= 48 ? 3 : 2) void k_barcode_lane(const ui
     o = (o + 15) & ~(size_t)15;
     unsigned long long* s_tail = reinterpret_cast<unsigned long long*>(smem + o);  // [t][lo|hi][thread]
     o += (size_t)T * 2 * 256 * 8;
+    uint4* s_hdr = reinterpret_cast<uint4*>(smem + o);   // [piece][thread]: the hits' 32-byte headers, kept for the final trip (read again from their
+    o += 2 * 256 * sizeof(uint4);                        // records ~100 trips later they came from HBM a second time: ~0.1 KB per hit)
     // use_nm (groups with large flank budgets): per entry column, WHICH of the 16 columns up to it hold a Match op of the walk through the
     // shared rows — [column][lane] 16-bit masks (bit i <-> column cx - i; 0xFFFF: not representable, grant all P).  The bound of a barcode
     // then grants the shared rows exactly those Match columns where its path enters row P instead of P contiguous ones: with k = 20 the
@@ -148,6 +150,7 @@ __global__ __launch_bounds__(256, CW <= 48 ? 3 : 2) void k_barcode_lane(const ui
     {
         const uint4* hp4 = reinterpret_cast<const uint4*>(hits + hit_idx);
         const uint4 h0 = hp4[0], h1 = hp4[1];
+        s_hdr[threadIdx.x] = h0; s_hdr[256u + threadIdx.x] = h1;   // read back by the same lane only: no barrier
         const bool valid = (h1.z & 0xFFu) != 0u;
         active = exists && valid;
         if (exists && !valid) rows[hit_idx].row._pad[0] = 0;
@@ -409,8 +412,7 @@ __global__ __launch_bounds__(256, CW <= 48 ? 3 : 2) void k_barcode_lane(const ui
 #pragma unroll
                 for (int d = 32; d >= 1; d >>= 1) bmax = max(bmax, __shfl_xor(bmax, d, 64));
                 bmax = __builtin_amdgcn_readfirstlane(bmax);
-                const uint4* hp4 = reinterpret_cast<const uint4*>(hits + hit_idx);
-                const uint4 h0 = cand ? hp4[0] : make_uint4(0u, 0u, 0u, 0u), h1 = cand ? hp4[1] : make_uint4(0u, 0u, 0u, 0u);
+                const uint4 h0 = s_hdr[threadIdx.x], h1 = s_hdr[256u + threadIdx.x];   // (lanes without a candidate: ignored by rows_decide)
                 rows_decide(cand, W, h0, h1, hit_idx, bmax, groups, rows, min_score, min_score_diff, margin, fb_lists, list_stride, fb_cnt);
                 if (want && !cand) {  // cannot happen — the winner was a candidate in its own trip; should an edit ever break that, the hit goes to
                                       // the exact kernel instead of keeping whatever an earlier batch left in its slot
@@ -458,8 +460,7 @@ __global__ __launch_bounds__(256, CW <= 48 ? 3 : 2) void k_barcode_lane(const ui
         if (__any(want)) trip(N, true);
     }
     if (active && !want) {  // no candidate at all: flank-only row (searcher.rs:353-362)
-        const uint4* hp4 = reinterpret_cast<const uint4*>(hits + hit_idx);
-        const uint4 h0 = hp4[0], h1 = hp4[1];
+        const uint4 h0 = s_hdr[threadIdx.x], h1 = s_hdr[256u + threadIdx.x];
         bb_rowtmp R;
         bb_row& r = R.row;
         r.read_idx = h0.x; r.read_len = h1.w;
