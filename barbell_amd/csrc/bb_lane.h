@@ -69,6 +69,9 @@ __device__ __forceinline__ void shared_rows_walk(const uint32_t* s_eqt, const ui
 
 // waves per SIMD the register budget is set for: the move planes are 2 x CW registers — 48 columns fit three waves (<= 168 VGPRs), 64 two
 // PRIO: the class of the policy's traceback order (bb_prio.h): the move planes are one v_bitop3 each with the class's truth tables
+#ifndef BB_LANE_LOWSKIP
+#define BB_LANE_LOWSKIP 12   // the column groups from here down are walked only while a lane's cursor needs them
+#endif
 template <int CW, bool TAIL, uint32_t PRIO, bool NM>
 __global__ __launch_bounds__(256, CW <= 48 ? 3 : 2) void k_barcode_lane(const uint8_t* __restrict__ tables, const bb_group_dev* __restrict__ groups, uint32_t g,
                                                       uint32_t strand, const bb_hit* __restrict__ hits, const uint32_t* __restrict__ hit_meta,
@@ -205,8 +208,9 @@ __global__ __launch_bounds__(256, CW <= 48 ? 3 : 2) void k_barcode_lane(const ui
 #pragma unroll
         for (int r = 0; r < 16; ++r) Wp[r] = 0u;
         const uint8_t* win = reinterpret_cast<const uint8_t*>(hits + hit_idx) + 32;
+        const int nmc = min(wmax, BB_LANE_NM_COLS);
 #pragma unroll 1
-        for (int c = 0; c < wmax; ++c) {
+        for (int c = 0; c < nmc; ++c) {
             const uint32_t code = active && c < wn ? (uint32_t)win[c] & 0xFu : 0u;
             uint32_t hp, hm, shw;
             shared_rows_column<PRIO>(PRIO, s_eqt[code] & 0xFFFFu, P, pv, mv, hp, hm, shw);
@@ -341,23 +345,32 @@ __global__ __launch_bounds__(256, CW <= 48 ? 3 : 2) void k_barcode_lane(const ui
         const uint32_t sm_w[2] = {(uint32_t)smask, (uint32_t)(smask >> 32)};
         // ---- phase 1: the lane's own rows, one-hot cursor (see k_barcode_pfx) ----
         uint32_t pl_acc[2] = {0u, 0u}, ph_acc[2] = {0u, 0u};
+        // The lowest column groups only while some lane's cursor is still inside its rows (or yet to enter): the leading shared rows hold the
+        // window's first ~P columns, so the last two or three groups are usually nobody's — a sixth of the walk.
+        int rem = 0;   // columns left out at the low end (wave-uniform)
 #pragma unroll
         for (int c0 = CW; c0 >= BB_CG; c0 -= BB_CG) {
-            if (c0 - (BB_CG - 1) <= wmax) {  // wave-uniform
+            if (c0 - (BB_CG - 1) <= wmax && rem == 0) {  // wave-uniform
+                if (c0 <= BB_LANE_LOWSKIP) {
+                    if (!__any((b | (sm_w[0] & ((2u << (c0 - 1)) - 1u))) != 0u)) rem = c0;
+                }
+                if (rem == 0) {
 #pragma unroll
-                for (int c = c0; c > c0 - BB_CG; --c) {
-                    const uint32_t Lr = L0[c - 1], Hr = H0[c - 1];
-                    const uint32_t Dr = Lr & Hr;
-                    const uint32_t nb = bitop3<0x0C>(Dr, Dr + b + ((sm_w[(c - 1) >> 5] >> ((c - 1) & 31)) & 1u), 0u);  // ~Dr & sum
-                    const uint32_t tl = Lr & nb, th = Hr & nb;
-                    const uint32_t cm = bitop3<0x0C>(Hr, nb, 0u);  // ~Hr & nb
-                    pl_acc[(c - 1) >> 5] = __builtin_amdgcn_alignbit(pl_acc[(c - 1) >> 5], 0u - tl, 31);
-                    ph_acc[(c - 1) >> 5] = __builtin_amdgcn_alignbit(ph_acc[(c - 1) >> 5], 0u - th, 31);
-                    dg |= cm;
-                    b = nb + cm;
+                    for (int c = c0; c > c0 - BB_CG; --c) {
+                        const uint32_t Lr = L0[c - 1], Hr = H0[c - 1];
+                        const uint32_t Dr = Lr & Hr;
+                        const uint32_t nb = bitop3<0x0C>(Dr, Dr + b + ((sm_w[(c - 1) >> 5] >> ((c - 1) & 31)) & 1u), 0u);  // ~Dr & sum
+                        const uint32_t tl = Lr & nb, th = Hr & nb;
+                        const uint32_t cm = bitop3<0x0C>(Hr, nb, 0u);  // ~Hr & nb
+                        pl_acc[(c - 1) >> 5] = __builtin_amdgcn_alignbit(pl_acc[(c - 1) >> 5], 0u - tl, 31);
+                        ph_acc[(c - 1) >> 5] = __builtin_amdgcn_alignbit(ph_acc[(c - 1) >> 5], 0u - th, 31);
+                        dg |= cm;
+                        b = nb + cm;
+                    }
                 }
             }
         }
+        if (rem) { pl_acc[0] <<= rem; ph_acc[0] <<= rem; }   // rem <= BB_LANE_LOWSKIP < 32: the columns left out are all in word 0
         plo |= ((unsigned long long)pl_acc[1] << 32) | pl_acc[0];
         phi |= ((unsigned long long)ph_acc[1] << 32) | ph_acc[0];
         if (last) {
@@ -394,7 +407,7 @@ __global__ __launch_bounds__(256, CW <= 48 ? 3 : 2) void k_barcode_lane(const ui
 #ifdef BB_LANE_CHECK_NM
                 // debug build only: the stored Match mask of the walk entering at cx against the walk just done; a difference wrecks the
                 // record, so that any parity test fails on it
-                if (use_nm && P > 0 && cand && cx >= 1) {
+                if (use_nm && P > 0 && cand && cx >= 1 && cx <= BB_LANE_NM_COLS) {
                     const uint32_t wm = (uint32_t)s_nm[(cx - 1) * 256 + threadIdx.x];
                     if (wm != 0xFFFFu) {
                         uint32_t truth = 0u;
@@ -435,7 +448,7 @@ __global__ __launch_bounds__(256, CW <= 48 ? 3 : 2) void k_barcode_lane(const ui
         unsigned long long plo_b = cand ? plo : 0ull;
         if (use_nm && P > 0) {  // wave-uniform: ... or exactly the Match columns of the walk from there (non-Match columns of its 16 marked in the lo plane)
             const int32_t cxq = cand ? best_pos - ntext1 : 0;
-            const uint32_t wm = cxq >= 1 ? (uint32_t)s_nm[(cxq - 1) * 256 + threadIdx.x] : 0u;
+            const uint32_t wm = cxq >= 1 ? (cxq <= BB_LANE_NM_COLS ? (uint32_t)s_nm[(cxq - 1) * 256 + threadIdx.x] : 0xFFFFu) : 0u;
             if (wm != 0xFFFFu) {
                 // bit i of wm <-> column cxq - i <-> plane bit cxq - 1 - i: the 16 bits reversed and slid under cxq
                 const unsigned long long nm16 = (unsigned long long)(__brev(~wm) >> 16) & 0xFFFFull;

@@ -25,6 +25,8 @@ void bb_launch_bar_prefix(bb_ctx* c, uint32_t n_hits, hipStream_t st);
 void bb_launch_barcode(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n_hits, uint32_t g, int pass);
 
 // ---- the per-class units ----
+#define BB_LANE_NM_COLS 32   // NM: entry columns with a stored walk mask (the lane's 32 rows consume ~32 of the window's columns first: an entry
+                             // further right is rare and gets the sentinel); 16 KB of LDS instead of 2 x CW x 256 keep three blocks per CU
 struct bb_lane_args {
     const uint8_t* tables; const bb_group_dev* groups; uint32_t g, strand; const bb_hit* hits; const uint32_t* hit_meta; const uint32_t* list; const uint32_t* cnt;
     uint32_t n_hits; bb_rowtmp* rows; double min_score, min_score_diff, margin; uint32_t* fb_lists; uint32_t list_stride; uint32_t* fb_cnt; uint32_t use_nm;

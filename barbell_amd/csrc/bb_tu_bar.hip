@@ -83,7 +83,7 @@ void launch_barcode_pfx(bb_ctx* c, uint32_t n_hits, uint32_t g, uint32_t strand,
     if (fast && bb_takes_lane(c, g, strand, CW > 48)) {
         const uint32_t T = (uint32_t)D.tail[strand];
         const uint32_t use_nm = (c->groups[g].info.flank_k > BB_LANE_MAX_FLANK_K && c->lane_nm && D.pfx[strand] > 0) ? 1u : 0u;
-        const size_t smem = (((size_t)N * 64 + 31) & ~(size_t)31) + 256 * 32 + 16 + (size_t)T * 2 * 256 * 8 + 2 * 256 * 16 + (use_nm ? (size_t)CW * 256 * 2 : 0);
+        const size_t smem = (((size_t)N * 64 + 31) & ~(size_t)31) + 256 * 32 + 16 + (size_t)T * 2 * 256 * 8 + 2 * 256 * 16 + (use_nm ? (size_t)BB_LANE_NM_COLS * 256 * 2 : 0);
         const bb_lane_args a{(const uint8_t*)c->d_tables, (const bb_group_dev*)c->d_groups, g, strand, (const bb_hit*)c->d_hits, (const uint32_t*)c->d_hitmeta, list, cnt, n_hits, c->d_rows,
                              c->params.min_score, c->params.min_score_diff, c->fast_margin, c->d_fb_lists, c->cap_hits, c->d_fbcnt, use_nm};
         const uint32_t lev0 = c->n_lev;
