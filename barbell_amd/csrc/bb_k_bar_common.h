@@ -266,9 +266,14 @@ __device__ __forceinline__ void lodhi_bound_table_entry(uint32_t byte, uint32_t 
     e.D = __double2float_ru(P2); e.E = __double2float_ru(P1); e.S = (float)p2(-s); e._p1 = 0.0f;
 }
 template <int CW>
+__device__ __forceinline__ float lodhi_bound_mask(unsigned long long mmask, int wmax, const bb_lb_entry* tab);
+template <int CW>
 __device__ __forceinline__ float lodhi_bound_tab(unsigned long long plo, unsigned long long phi, int32_t tstart, int32_t best_pos, int wmax,
                                                  const bb_lb_entry* tab) {
-    const unsigned long long mmask = low64(best_pos) & ~low64(tstart) & ~(plo | phi);   // Match columns (bit c-1)
+    return lodhi_bound_mask<CW>(low64(best_pos) & ~low64(tstart) & ~(plo | phi), wmax, tab);   // Match columns (bit c-1)
+}
+template <int CW>
+__device__ __forceinline__ float lodhi_bound_mask(unsigned long long mmask, int wmax, const bb_lb_entry* tab) {
     const uint32_t m_w[2] = {(uint32_t)mmask, (uint32_t)(mmask >> 32)};
     float sc = 0.0f, u1 = 0.0f, u2 = 0.0f;
 #pragma unroll

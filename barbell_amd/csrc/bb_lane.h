@@ -30,7 +30,7 @@
 // from column 1: a dozen instructions per column), then one step per column from HI down, for the lanes whose cursor is in that column.
 template <uint32_t PRIO, int LO, int HI, int NW>
 __device__ __forceinline__ void shared_rows_walk(const uint32_t* s_eqt, const uint32_t (&cw)[NW], int P, uint32_t pm, int wmax, uint32_t& bh, int32_t& col,
-                                                 int32_t& ntext, uint32_t& dgh, uint32_t (&pl_w)[2], uint32_t (&ph_w)[2]) {
+                                                 int32_t& ntext, uint32_t& dgh, uint32_t& mth, uint32_t (&pl_w)[2], uint32_t (&ph_w)[2]) {
     uint32_t shw[HI - LO];
     {
         uint32_t pv = P >= 32 ? 0xFFFFFFFFu : (1u << P) - 1u, mv = 0u;
@@ -57,6 +57,7 @@ __device__ __forceinline__ void shared_rows_walk(const uint32_t* s_eqt, const ui
             ph_w[(c - 1) >> 5] |= hi ? 1u << ((c - 1) & 31) : 0u;
             const bool consume = has & !hi;
             dgh |= consume ? nb : 0u;
+            mth |= (has && !lo && !hi) ? nb : 0u;   // rows matched (the debug build's check of the NM masks)
             if (on) {
                 bh = consume ? ((nb << 1) & pm) : nb;
                 ntext += has ? 1 : 0;
@@ -97,11 +98,10 @@ __global__ __launch_bounds__(256, CW <= 48 ? 3 : 2) void k_barcode_lane(const ui
     o += (size_t)T * 2 * 256 * 8;
     uint4* s_hdr = reinterpret_cast<uint4*>(smem + o);   // [piece][thread]: the hits' 32-byte headers, kept for the final trip (read again from their
     o += 2 * 256 * sizeof(uint4);                        // records ~100 trips later they came from HBM a second time: ~0.1 KB per hit)
-    // use_nm (groups with large flank budgets): per entry column, WHICH of the 16 columns up to it hold a Match op of the walk through the
-    // shared rows — [column][lane] 16-bit masks (bit i <-> column cx - i; 0xFFFF: not representable, grant all P).  The bound of a barcode
-    // then grants the shared rows exactly those Match columns where its path enters row P instead of P contiguous ones: with k = 20 the
-    // flank hits are mostly chance hits whose pad rows match badly, and the all-P assumption left 8 x as many hits undecided (a count of
-    // the walk's Match ops, granted contiguously, still left 5-16 %).
+    // NM (groups with large flank budgets): per entry column, WHICH of the P shared rows the walk from there matches — [column][lane] 16-bit
+    // masks (bit q <-> row q + 1).  The bound of a barcode then grants the shared rows exactly those Matches where its path enters row P
+    // instead of all P: with k = 20 the flank hits are mostly chance hits whose pad rows match badly, and the all-P assumption left 8 x as
+    // many hits undecided.
     uint16_t* s_nm = reinterpret_cast<uint16_t*>(smem + o);
     __shared__ uint32_t s_eqt[16];   // Peq of the leading shared rows per base set; trailing rows matched per base set in bits 16..
     if (threadIdx.x < 16u) {
@@ -115,7 +115,9 @@ __global__ __launch_bounds__(256, CW <= 48 ? 3 : 2) void k_barcode_lane(const ui
             const int code = i / N, p = i - code * N;
             s_peq[p * 16 + code] = gp[i];
         }
-        for (uint32_t i = threadIdx.x; i < 256u; i += 256u) lodhi_bound_table_entry(i, (uint32_t)G.pol_lodhi_exp, s_lb[i]);
+        // the bound runs over the pattern's ROWS (below): a row without a Match is a Sub or a Del, so the table's other-op exponent is min(eS, eD)
+        const uint32_t e4 = (uint32_t)G.pol_lodhi_exp, e_rows = (e4 & 0xFFFFu) | ((e4 >> 24) << 16);
+        for (uint32_t i = threadIdx.x; i < 256u; i += 256u) lodhi_bound_table_entry(i, e_rows, s_lb[i]);
     }
     // Which hit a lane takes: the block's 256 hits, those with windows of at most CW - 4 columns first.  A wave walks as many
     // column groups as its widest window needs; 99 % of the windows of SQK-NBD114-96 are 44 columns wide, but one 45-column window
@@ -198,11 +200,10 @@ __global__ __launch_bounds__(256, CW <= 48 ? 3 : 2) void k_barcode_lane(const ui
     }
 
     if (NM && P > 0) {  // wave-uniform
-        // W[r] = Match columns of the walk from (row r, column c) up to row 0, bit i <-> column c - i:
-        //   Match: (W[r-1] of column c-1) << 1 | 1;  Sub: the same without the 1;  Ins: (W[r] of column c-1) << 1;  Del: W[r-1] of column c.
+        // W[r] = the shared rows matched by the walk from (row r, column c) up to row 0 (bit q <-> row q + 1):
+        //   Match: (W[r-1] of column c-1) | bit r-1;  Sub: W[r-1] of column c-1;  Ins: W[r] of column c-1;  Del: W[r-1] of column c.
         // A rolled loop over the columns (the hit's window codes re-read from its record, the shared rows' step again: a dozen instructions),
-        // the rows unrolled with their masks in registers — 32 bits each, so a walk of up to 32 columns is exact; what does not fit 16 bits
-        // when it is stored becomes the sentinel.
+        // the rows unrolled with their masks in registers.
         uint32_t pv = P >= 32 ? 0xFFFFFFFFu : (1u << P) - 1u, mv = 0u;
         uint32_t Wp[16];
 #pragma unroll
@@ -220,15 +221,14 @@ __global__ __launch_bounds__(256, CW <= 48 ? 3 : 2) void k_barcode_lane(const ui
                 if (r <= P) {  // wave-uniform
                     const uint32_t l = (shw >> (P - r)) & 1u, hh = (shw >> (16 + P - r)) & 1u;   // the cell's move: row r <-> bit P - r of each plane
                     const uint32_t left = Wp[r - 1];
-                    const uint32_t src = hh ? left : diag;                  // Ins continues in this row, Match / Sub in the row above, both one column back
-                    const uint32_t v = (hh && l) ? above : ((src << 1) | ((hh | l) ? 0u : 1u) | (src & 0x80000000u ? 0xFFFF0000u : 0u));  // a lost bit poisons the high half
+                    const uint32_t v = hh ? (l ? above : left) : (diag | (l ? 0u : 1u << (r - 1)));
                     diag = left;          // W[r][c-1] is the next row's diagonal
                     Wp[r - 1] = v;        // becomes W[r][c]
                     above = v;
                     if (r == P) out = v;
                 }
             }
-            s_nm[c * 256 + threadIdx.x] = (uint16_t)((out >> 16) ? 0xFFFFu : out);   // the walk that enters row P in column c + 1
+            s_nm[c * 256 + threadIdx.x] = (uint16_t)out;   // the walk that enters row P in column c + 1
         }
     }
     const uint8_t* s_peq_b = reinterpret_cast<const uint8_t*>(s_peq);
@@ -328,7 +328,7 @@ __global__ __launch_bounds__(256, CW <= 48 ? 3 : 2) void k_barcode_lane(const ui
         uint32_t b = 0u, dg = 0u;
         int32_t c_ent = best_pos;
         int32_t tr = cand ? T - 1 : -1;
-        uint32_t dgt = 0u;
+        uint32_t dgt = 0u, mtt = 0u;   // trailing rows left by a diagonal move / matched
         while (TAIL && __any(tr >= 0 && c_ent >= 1)) {
             const bool onn = tr >= 0 && c_ent >= 1;
             const int rr = onn ? tr : 0, sh = onn ? c_ent - 1 : 0;
@@ -338,6 +338,7 @@ __global__ __launch_bounds__(256, CW <= 48 ? 3 : 2) void k_barcode_lane(const ui
             plo |= text ? (unsigned long long)lo << sh : 0ull;
             phi |= text ? (unsigned long long)hi << sh : 0ull;
             dgt |= diag ? 1u << rr : 0u;
+            mtt |= (text && (lo | hi) == 0u) ? 1u << rr : 0u;
             tr -= (del || diag) ? 1 : 0;
             c_ent -= text ? 1 : 0;
         }
@@ -348,6 +349,7 @@ __global__ __launch_bounds__(256, CW <= 48 ? 3 : 2) void k_barcode_lane(const ui
         // The lowest column groups only while some lane's cursor is still inside its rows (or yet to enter): the leading shared rows hold the
         // window's first ~P columns, so the last two or three groups are usually nobody's — a sixth of the walk.
         int rem = 0;   // columns left out at the low end (wave-uniform)
+        uint32_t ncol = 0u, mrow = 0u;
 #pragma unroll
         for (int c0 = CW; c0 >= BB_CG; c0 -= BB_CG) {
             if (c0 - (BB_CG - 1) <= wmax && rem == 0) {  // wave-uniform
@@ -360,24 +362,29 @@ __global__ __launch_bounds__(256, CW <= 48 ? 3 : 2) void k_barcode_lane(const ui
                         const uint32_t Lr = L0[c - 1], Hr = H0[c - 1];
                         const uint32_t Dr = Lr & Hr;
                         const uint32_t nb = bitop3<0x0C>(Dr, Dr + b + ((sm_w[(c - 1) >> 5] >> ((c - 1) & 31)) & 1u), 0u);  // ~Dr & sum
-                        const uint32_t tl = Lr & nb, th = Hr & nb;
                         const uint32_t cm = bitop3<0x0C>(Hr, nb, 0u);  // ~Hr & nb
-                        pl_acc[(c - 1) >> 5] = __builtin_amdgcn_alignbit(pl_acc[(c - 1) >> 5], 0u - tl, 31);
-                        ph_acc[(c - 1) >> 5] = __builtin_amdgcn_alignbit(ph_acc[(c - 1) >> 5], 0u - th, 31);
-                        dg |= cm;
+                        if (last) {   // the winner's walk: both planes of the path and its diagonal rows (rows_decide replays them)
+                            const uint32_t tl = Lr & nb, th = Hr & nb;
+                            pl_acc[(c - 1) >> 5] = __builtin_amdgcn_alignbit(pl_acc[(c - 1) >> 5], 0u - tl, 31);
+                            ph_acc[(c - 1) >> 5] = __builtin_amdgcn_alignbit(ph_acc[(c - 1) >> 5], 0u - th, 31);
+                            dg |= cm;
+                        } else {      // every other walk: the bound wants the matched ROWS only (and, NM, the number of text columns)
+                            mrow |= bitop3<0x10>(nb, Lr, Hr);  // nb & ~Lr & ~Hr: the cursor's cell is a Match
+                            if (NM) asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(ncol) : "v"(nb));   // ncol += popcount(nb): a text op per column the cursor is in
+                        }
                         b = nb + cm;
                     }
                 }
             }
         }
         if (rem) { pl_acc[0] <<= rem; ph_acc[0] <<= rem; }   // rem <= BB_LANE_LOWSKIP < 32: the columns left out are all in word 0
-        plo |= ((unsigned long long)pl_acc[1] << 32) | pl_acc[0];
-        phi |= ((unsigned long long)ph_acc[1] << 32) | ph_acc[0];
         if (last) {
+            plo |= ((unsigned long long)pl_acc[1] << 32) | pl_acc[0];
+            phi |= ((unsigned long long)ph_acc[1] << 32) | ph_acc[0];
             int32_t ntext = cand ? __popc(dg) + __popc(dgt) + __popcll(phi & ~plo) : 0;
             const int32_t cx = cand ? best_pos - ntext : 0;
             // ---- phase 2: the shared rows (row r <-> bit P - r), walked on the lane's own prefix record ----
-            uint32_t dgh = 0u;
+            uint32_t dgh = 0u, mth = 0u;
             if (P > 0) {
                 // the shared rows' move planes again, into registers (the lane rows' planes are dead by now), and the walk column by
                 // column from the top: a lane takes part from the column its cursor entered row P in.  Half the window at a time — 24
@@ -388,8 +395,8 @@ __global__ __launch_bounds__(256, CW <= 48 ? 3 : 2) void k_barcode_lane(const ui
                 int32_t col = cx;
                 uint32_t pl_w[2] = {0u, 0u}, ph_w[2] = {0u, 0u};
                 constexpr int HALF = CW / 2;
-                if (__any(bh != 0u && col > HALF)) shared_rows_walk<PRIO, HALF, CW>(s_eqt, cw, P, pm, wmax, bh, col, ntext, dgh, pl_w, ph_w);
-                shared_rows_walk<PRIO, 0, HALF>(s_eqt, cw, P, pm, wmax, bh, col, ntext, dgh, pl_w, ph_w);
+                if (__any(bh != 0u && col > HALF)) shared_rows_walk<PRIO, HALF, CW>(s_eqt, cw, P, pm, wmax, bh, col, ntext, dgh, mth, pl_w, ph_w);
+                shared_rows_walk<PRIO, 0, HALF>(s_eqt, cw, P, pm, wmax, bh, col, ntext, dgh, mth, pl_w, ph_w);
                 plo |= ((unsigned long long)pl_w[1] << 32) | pl_w[0];
                 phi |= ((unsigned long long)ph_w[1] << 32) | ph_w[0];
             }
@@ -405,20 +412,11 @@ __global__ __launch_bounds__(256, CW <= 48 ? 3 : 2) void k_barcode_lane(const ui
                 W.tstart = (uint8_t)tstart; W.best_pos = (uint8_t)best_pos; W.top = (uint16_t)ptop;
                 W.flags = 0; W.marker = 2; W._pad[0] = W._pad[1] = 0;
 #ifdef BB_LANE_CHECK_NM
-                // debug build only: the stored Match mask of the walk entering at cx against the walk just done; a difference wrecks the
-                // record, so that any parity test fails on it
+                // debug build only: the stored mask of the walk entering at cx against the rows the walk just done matched; a difference wrecks
+                // the record, so that any parity test fails on it
                 if (use_nm && P > 0 && cand && cx >= 1 && cx <= BB_LANE_NM_COLS) {
                     const uint32_t wm = (uint32_t)s_nm[(cx - 1) * 256 + threadIdx.x];
-                    if (wm != 0xFFFFu) {
-                        uint32_t truth = 0u;
-                        for (int i = 0; i < 16; ++i) {
-                            const int ci = cx - 1 - i;
-                            if (ci >= tstart && ci >= 0 && !(((plo | phi) >> ci) & 1ull)) truth |= 1u << i;
-                        }
-                        bool extra = false;   // a Match further than 16 columns from the entry should have made the sentinel
-                        for (int ci = cx - 17; ci >= tstart && ci >= 0; --ci) extra |= !(((plo | phi) >> ci) & 1ull);
-                        if (truth != wm || extra) W.plo = ~0ull;
-                    } else if (cx - tstart <= 16) W.plo = ~0ull;   // a sentinel for a walk that would have fit
+                    if (wm != (__brev(mth) >> (32 - P))) W.plo = ~0ull;
                 }
 #endif
                 int bmax = cand ? best_pos : 0;
@@ -443,20 +441,19 @@ __global__ __launch_bounds__(256, CW <= 48 ? 3 : 2) void k_barcode_lane(const ui
         // columns left of the cursor the contiguous run ending at cx gives every subsequence its shortest span: the bound of THAT
         // placement is an upper bound of the exact score — and equals the bound of the true path whenever the shared rows match
         // without gaps (the usual case: they are the flank the hit was found with).  Only the winner's walk is ever done (final trip).
-        const int32_t ntext1 = cand ? __popc(dg) + __popc(dgt) + __popcll(phi & ~plo) : 0;
-        int32_t tstart = cand ? max(best_pos - ntext1 - P, 0) : 0;   // the shared rows granted P Match columns ending at the entry column ...
-        unsigned long long plo_b = cand ? plo : 0ull;
-        if (use_nm && P > 0) {  // wave-uniform: ... or exactly the Match columns of the walk from there (non-Match columns of its 16 marked in the lo plane)
-            const int32_t cxq = cand ? best_pos - ntext1 : 0;
-            const uint32_t wm = cxq >= 1 ? (cxq <= BB_LANE_NM_COLS ? (uint32_t)s_nm[(cxq - 1) * 256 + threadIdx.x] : 0xFFFFu) : 0u;
-            if (wm != 0xFFFFu) {
-                // bit i of wm <-> column cxq - i <-> plane bit cxq - 1 - i: the 16 bits reversed and slid under cxq
-                const unsigned long long nm16 = (unsigned long long)(__brev(~wm) >> 16) & 0xFFFFull;
-                plo_b |= cxq >= 16 ? nm16 << (cxq - 16) : nm16 >> (16 - cxq);
-                tstart = cand ? max(cxq - 16, 0) : 0;
-            }
+        // The bound, over the pattern's rows.  The exact score runs over the path's op string; dropping ops from it (here: the Ins ops, which
+        // have no row) shortens spans and can only raise it, as can turning ops into Matches.  So: the lane rows' and trailing rows' Match
+        // bits as the walk found them, and the leading shared rows — not walked except by the winner — all P granted as Matches, or (NM)
+        // exactly those the walk from the entry column matches.  [Through round 4 the bound ran over text columns: two planes of the path
+        // collected per column and the entry column computed for every barcode — 12.5 instructions per column of the walk against 8.]
+        unsigned long long rm = (unsigned long long)__brev(mrow) << P;   // row P + 1 <-> bit 31 of the lane's word
+        if (TAIL) rm |= (unsigned long long)mtt << (P + 32);
+        unsigned long long lead = low64(P);
+        if (use_nm && P > 0) {  // wave-uniform
+            const int32_t cxq = cand ? c_ent - (int32_t)ncol : 0;   // the entry column: text columns left of the trailing rows' and the lane rows' ops
+            lead = cxq >= 1 ? (cxq <= BB_LANE_NM_COLS ? (unsigned long long)s_nm[(cxq - 1) * 256 + threadIdx.x] : lead) : 0ull;
         }
-        const float ubf = lodhi_bound_tab<CW>(plo_b, cand ? phi : 0ull, cand ? tstart : 0, cand ? best_pos : 0, CW, s_lb);  // all bytes: no branches between the table reads
+        const float ubf = lodhi_bound_mask<64>(cand ? (rm | lead) : 0ull, m, s_lb);  // all bytes: no branches between the table reads
         const uint32_t v = __float_as_uint(ubf) + 1u;
         if (cand) {  // first maximum wins: strictly greater replaces
             if (v > b1B) { b2B = b1B; b1B = v; pB = (uint32_t)it; } else if (v > b2B) b2B = v;
