@@ -265,6 +265,44 @@ __device__ __forceinline__ void lodhi_bound_table_entry(uint32_t byte, uint32_t 
     e.A = __double2float_ru(A); e.B = __double2float_ru(B); e.C = __double2float_ru(C); e.n = (float)cnt;
     e.D = __double2float_ru(P2); e.E = __double2float_ru(P1); e.S = (float)p2(-s); e._p1 = 0.0f;
 }
+// The table for a bound over the pattern's ROWS when Sub and Del rows decay differently (eS != eD): four rows per entry, two bits per row —
+// index = a | b << 4 with (a, b) of a row = (1, 1) Match, (0, 1) Sub, (0, 0) Del, (1, 0) unknown (a shared row the walk did not match:
+// the smaller of the two exponents).  Same recurrence, same coefficients; only the time a non-Match row takes depends on its class.
+__device__ __forceinline__ void lodhi_bound_table_entry4(uint32_t idx, uint32_t e4, bb_lb_entry& e) {
+    const int eM = (int)(e4 & 0xFFu), eS = (int)((e4 >> 8) & 0xFFu), eD = (int)((e4 >> 24) & 0xFFu), eX = eS < eD ? eS : eD;
+    auto p2 = [](int k) -> double { return __hiloint2double((int)((uint32_t)(1023 + k) << 20), 0); };  // 2^k, |k| < 1023
+    double A = 0.0, B = 0.0, C = 0.0, cnt = 0.0, P1 = 0.0, P2 = 0.0;
+    int s = 0;
+    for (int r = 0; r < 4; ++r) {
+        const uint32_t a = (idx >> r) & 1u, b = (idx >> (4 + r)) & 1u;
+        if (a & b) {
+            s += eM;
+            const double w = p2(-s);
+            A += w; B += w * cnt; C += w * P2;
+            P2 += P1; cnt += 1.0; P1 += p2(s - eM);
+        } else s += a ? eX : (b ? eS : eD);
+    }
+    e.A = __double2float_ru(A); e.B = __double2float_ru(B); e.C = __double2float_ru(C); e.n = (float)cnt;
+    e.D = __double2float_ru(P2); e.E = __double2float_ru(P1); e.S = (float)p2(-s); e._p1 = 0.0f;
+}
+// rows 4q+1 .. 4q+4 <-> bits 4q .. 4q+3 of the two masks
+template <int CW>
+__device__ __forceinline__ float lodhi_bound_mask4(unsigned long long am, unsigned long long bm, int wmax, const bb_lb_entry* tab) {
+    const uint32_t a_w[2] = {(uint32_t)am, (uint32_t)(am >> 32)}, b_w[2] = {(uint32_t)bm, (uint32_t)(bm >> 32)};
+    float sc = 0.0f, u1 = 0.0f, u2 = 0.0f;
+#pragma unroll
+    for (int q = 0; q < CW / 4; ++q) {
+        if (4 * q < wmax) {  // wave-uniform
+            const uint32_t idx = ((a_w[q >> 3] >> (4 * (q & 7))) & 0xFu) | (((b_w[q >> 3] >> (4 * (q & 7))) & 0xFu) << 4);
+            const float4 t0 = *reinterpret_cast<const float4*>(&tab[idx].A);
+            const float4 t1 = *reinterpret_cast<const float4*>(&tab[idx].D);
+            sc = __fmaf_rn(t0.x, u2, __fmaf_rn(t0.y, u1, sc + t0.z));
+            u2 = (__fmaf_rn(t0.w, u1, u2) + t1.x) * t1.z;
+            u1 = (u1 + t1.y) * t1.z;
+        }
+    }
+    return sc * (1.0f + 1.0f / 16384.0f);
+}
 template <int CW>
 __device__ __forceinline__ float lodhi_bound_mask(unsigned long long mmask, int wmax, const bb_lb_entry* tab);
 template <int CW>

@@ -388,6 +388,9 @@ __device__ __forceinline__ uint64_t filt_word_base(uint64_t off, uint64_t off0, 
 
 // WIDE: windows of up to 31 rows, one word per strand (two Myers words per column: ~37 instructions instead of ~20) — for
 // flanks whose 15-row windows say too little at the group's k but whose 31-row windows do (upload_tables decides).
+#ifndef BB_FILT_SCORE5
+#define BB_FILT_SCORE5 1   // the two halves' score updates as one subtraction and one arithmetic shift (18.75 instead of 19.75 instructions per column)
+#endif
 template <bool WIDE>
 __global__ __launch_bounds__(256) void k_flank_filter(const uint8_t* __restrict__ bases, const uint64_t* __restrict__ offsets, uint32_t n_reads,
                                                       const uint8_t* __restrict__ tables, const bb_group_dev* __restrict__ groups, uint32_t g,
@@ -449,6 +452,23 @@ __global__ __launch_bounds__(256) void k_flank_filter(const uint8_t* __restrict_
     uint32_t keep = WIDE ? sc2 | ~0x20u : sc2 | ~0x00100010u;  // column 0 counts for the first piece
     uint32_t keepB = scB | ~0x20u;
     uint32_t bitsA = 0u, bitsB = 0u, nflag = 0u;
+    // one column of the narrow form on the column's Eq word (both blocks)
+    auto step_eq = [&](const uint32_t eq) {
+        const uint32_t x = eq & pv;
+        const uint32_t d0 = bitop3<BB_TT_XOR_OR>(x + pv, pv, eq) | mv;
+        const uint32_t ph = bitop3<BB_TT_OR_NOR>(mv, d0, pv) & BM, mh = pv & d0;
+#if BB_FILT_SCORE5
+        // both halves' +-1 at once: the bottom rows' delta bits (14 and 30) subtracted as whole words — a borrow out of the low half is paid
+        // back by the arithmetic shift, and the biased scores never go below zero — one instruction less than two shifts and two masks
+        sc2 += (uint32_t)((int32_t)((ph & TOPS) - (mh & TOPS)) >> 14);
+#else
+        sc2 = sc2 + ((ph & TOPS) >> 14) - ((mh & TOPS) >> 14);
+#endif
+        keep &= sc2;
+        const uint32_t phs = shl1_32(ph), mhs = shl1_32(mh);
+        pv = bitop3<BB_TT_OR_NOR>(mhs, d0, phs) & BM;
+        mv = phs & d0;
+    };
     auto step = [&](uint32_t chr) {
         if constexpr (WIDE) {
             const uint2 e2 = *reinterpret_cast<const uint2*>(s_fpeq + 2u * chr);
@@ -473,15 +493,7 @@ __global__ __launch_bounds__(256) void k_flank_filter(const uint8_t* __restrict_
                 mvB = phs & d0;
             }
         } else {
-            const uint32_t eq = s_fpeq[chr];
-            const uint32_t x = eq & pv;
-            const uint32_t d0 = bitop3<BB_TT_XOR_OR>(x + pv, pv, eq) | mv;
-            const uint32_t ph = bitop3<BB_TT_OR_NOR>(mv, d0, pv) & BM, mh = pv & d0;
-            sc2 = sc2 + ((ph & TOPS) >> 14) - ((mh & TOPS) >> 14);
-            keep &= sc2;
-            const uint32_t phs = shl1_32(ph), mhs = shl1_32(mh);
-            pv = bitop3<BB_TT_OR_NOR>(mhs, d0, phs) & BM;
-            mv = phs & d0;
+            step_eq(s_fpeq[chr]);
         }
     };
     auto commit = [&](uint32_t bit) {  // end of a piece

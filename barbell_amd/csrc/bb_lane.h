@@ -20,6 +20,7 @@
 //   * that final trip also decides (rows_decide: exact score of the winner's path against the runner-up's bound).
 // Output = k_barcode_pfx<.., FAST = true> + k_rows': the hit's row, or its index on the fallback list of the exact kernel.
 #pragma once
+#include <type_traits>
 #include "bb_k_bar_common.h"
 
 #ifndef BB_LANE_NOHOIST
@@ -66,6 +67,15 @@ __device__ __forceinline__ void shared_rows_walk(const uint32_t* s_eqt, const ui
             }
         }
     }
+}
+
+// The bound runs over the pattern's rows.  With one exponent for every row without a Match — min(eS, eD) — it costs 8 instructions per
+// column of a walk and 8 table steps; where that exponent is 0 but Sub or Del rows do decay (lodhi=3:0.5:1110: the rows without a Match
+// would take no time at all and a third of the hits stayed undecided) the rows go by class (lodhi_bound_table_entry4: 9 instructions per
+// column, 16 table steps — 8 % of the stage, which is why e.g. 2211, whose single exponent decides 98 % of the hits, keeps the cheap form).
+__device__ __forceinline__ bool lane_rows4(uint32_t e4) {
+    const uint32_t eS = (e4 >> 8) & 0xFFu, eD = e4 >> 24;
+    return eS != eD && (eS == 0u || eD == 0u);
 }
 
 // waves per SIMD the register budget is set for: the move planes are 2 x CW registers — 48 columns fit three waves (<= 168 VGPRs), 64 two
@@ -117,8 +127,13 @@ __global__ __launch_bounds__(256, CW <= 48 ? 3 : 2) void k_barcode_lane(const ui
         }
         // the bound runs over the pattern's ROWS (below): a row without a Match is a Sub or a Del, so the table's other-op exponent is min(eS, eD)
         const uint32_t e4 = (uint32_t)G.pol_lodhi_exp, e_rows = (e4 & 0xFFFFu) | ((e4 >> 24) << 16);
-        for (uint32_t i = threadIdx.x; i < 256u; i += 256u) lodhi_bound_table_entry(i, e_rows, s_lb[i]);
+        if (lane_rows4(e4)) {   // the table by row classes (walks collect the rows left diagonally as well)
+            for (uint32_t i = threadIdx.x; i < 256u; i += 256u) lodhi_bound_table_entry4(i, e4, s_lb[i]);
+        } else {
+            for (uint32_t i = threadIdx.x; i < 256u; i += 256u) lodhi_bound_table_entry(i, e_rows, s_lb[i]);
+        }
     }
+    const bool rows4 = lane_rows4((uint32_t)G.pol_lodhi_exp);   // wave-uniform
     // Which hit a lane takes: the block's 256 hits, those with windows of at most CW - 4 columns first.  A wave walks as many
     // column groups as its widest window needs; 99 % of the windows of SQK-NBD114-96 are 44 columns wide, but one 45-column window
     // among a wave's 64 costs all of them a twelfth group, forward and back.  Sorted, three waves in four skip it.
@@ -350,33 +365,38 @@ __global__ __launch_bounds__(256, CW <= 48 ? 3 : 2) void k_barcode_lane(const ui
         // window's first ~P columns, so the last two or three groups are usually nobody's — a sixth of the walk.
         int rem = 0;   // columns left out at the low end (wave-uniform)
         uint32_t ncol = 0u, mrow = 0u;
+        auto walk = [&](auto r4) __attribute__((always_inline)) {   // r4: a non-final walk that also collects the rows left diagonally (eS != eD)
+            constexpr bool R4 = decltype(r4)::value;
 #pragma unroll
-        for (int c0 = CW; c0 >= BB_CG; c0 -= BB_CG) {
-            if (c0 - (BB_CG - 1) <= wmax && rem == 0) {  // wave-uniform
-                if (c0 <= BB_LANE_LOWSKIP) {
-                    if (!__any((b | (sm_w[0] & ((2u << (c0 - 1)) - 1u))) != 0u)) rem = c0;
-                }
-                if (rem == 0) {
+            for (int c0 = CW; c0 >= BB_CG; c0 -= BB_CG) {
+                if (c0 - (BB_CG - 1) <= wmax && rem == 0) {  // wave-uniform
+                    if (c0 <= BB_LANE_LOWSKIP) {
+                        if (!__any((b | (sm_w[0] & ((2u << (c0 - 1)) - 1u))) != 0u)) rem = c0;
+                    }
+                    if (rem == 0) {
 #pragma unroll
-                    for (int c = c0; c > c0 - BB_CG; --c) {
-                        const uint32_t Lr = L0[c - 1], Hr = H0[c - 1];
-                        const uint32_t Dr = Lr & Hr;
-                        const uint32_t nb = bitop3<0x0C>(Dr, Dr + b + ((sm_w[(c - 1) >> 5] >> ((c - 1) & 31)) & 1u), 0u);  // ~Dr & sum
-                        const uint32_t cm = bitop3<0x0C>(Hr, nb, 0u);  // ~Hr & nb
-                        if (last) {   // the winner's walk: both planes of the path and its diagonal rows (rows_decide replays them)
-                            const uint32_t tl = Lr & nb, th = Hr & nb;
-                            pl_acc[(c - 1) >> 5] = __builtin_amdgcn_alignbit(pl_acc[(c - 1) >> 5], 0u - tl, 31);
-                            ph_acc[(c - 1) >> 5] = __builtin_amdgcn_alignbit(ph_acc[(c - 1) >> 5], 0u - th, 31);
-                            dg |= cm;
-                        } else {      // every other walk: the bound wants the matched ROWS only (and, NM, the number of text columns)
-                            mrow |= bitop3<0x10>(nb, Lr, Hr);  // nb & ~Lr & ~Hr: the cursor's cell is a Match
-                            if (NM) asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(ncol) : "v"(nb));   // ncol += popcount(nb): a text op per column the cursor is in
+                        for (int c = c0; c > c0 - BB_CG; --c) {
+                            const uint32_t Lr = L0[c - 1], Hr = H0[c - 1];
+                            const uint32_t Dr = Lr & Hr;
+                            const uint32_t nb = bitop3<0x0C>(Dr, Dr + b + ((sm_w[(c - 1) >> 5] >> ((c - 1) & 31)) & 1u), 0u);  // ~Dr & sum
+                            const uint32_t cm = bitop3<0x0C>(Hr, nb, 0u);  // ~Hr & nb
+                            if (last) {   // the winner's walk: both planes of the path and its diagonal rows (rows_decide replays them)
+                                const uint32_t tl = Lr & nb, th = Hr & nb;
+                                pl_acc[(c - 1) >> 5] = __builtin_amdgcn_alignbit(pl_acc[(c - 1) >> 5], 0u - tl, 31);
+                                ph_acc[(c - 1) >> 5] = __builtin_amdgcn_alignbit(ph_acc[(c - 1) >> 5], 0u - th, 31);
+                                dg |= cm;
+                            } else {      // every other walk: the bound wants the matched ROWS only (and, NM, the number of text columns)
+                                mrow |= bitop3<0x10>(nb, Lr, Hr);  // nb & ~Lr & ~Hr: the cursor's cell is a Match
+                                if (R4) dg |= cm;                  // Match or Sub: what is left of the path's rows are Dels
+                                if (NM) asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(ncol) : "v"(nb));   // ncol += popcount(nb): a text op per column the cursor is in
+                            }
+                            b = nb + cm;
                         }
-                        b = nb + cm;
                     }
                 }
             }
-        }
+        };
+        if (!last && rows4) walk(std::true_type{}); else walk(std::false_type{});
         if (rem) { pl_acc[0] <<= rem; ph_acc[0] <<= rem; }   // rem <= BB_LANE_LOWSKIP < 32: the columns left out are all in word 0
         if (last) {
             plo |= ((unsigned long long)pl_acc[1] << 32) | pl_acc[0];
@@ -448,12 +468,22 @@ __global__ __launch_bounds__(256, CW <= 48 ? 3 : 2) void k_barcode_lane(const ui
         // collected per column and the entry column computed for every barcode — 12.5 instructions per column of the walk against 8.]
         unsigned long long rm = (unsigned long long)__brev(mrow) << P;   // row P + 1 <-> bit 31 of the lane's word
         if (TAIL) rm |= (unsigned long long)mtt << (P + 32);
-        unsigned long long lead = low64(P);
+        unsigned long long lead = low64(P), lead_any = low64(P);   // the shared rows matched / not known to be Dels
         if (use_nm && P > 0) {  // wave-uniform
             const int32_t cxq = cand ? c_ent - (int32_t)ncol : 0;   // the entry column: text columns left of the trailing rows' and the lane rows' ops
             lead = cxq >= 1 ? (cxq <= BB_LANE_NM_COLS ? (unsigned long long)s_nm[(cxq - 1) * 256 + threadIdx.x] : lead) : 0ull;
+            lead_any = cxq >= 1 ? lead_any : 0ull;
         }
-        const float ubf = lodhi_bound_mask<64>(cand ? (rm | lead) : 0ull, m, s_lb);  // all bytes: no branches between the table reads
+        float ubf;
+        if (rows4) {  // wave-uniform: Sub and Del rows decay differently — the rows by class (bb_k_bar_common.h: Match = both masks, Sub = the
+                      // second only, Del = neither; a shared row the walk did not match, or no walk is known for, = the first only: the
+                      // smaller exponent.  With an entry column left of the window the shared rows are Dels: neither)
+            unsigned long long bm = (unsigned long long)__brev(dg) << P;
+            if (TAIL) bm |= (unsigned long long)dgt << (P + 32);
+            const unsigned long long am = rm | lead_any;
+            ubf = lodhi_bound_mask4<64>(cand ? am : 0ull, cand ? (bm | lead) : 0ull, m, s_lb);
+        } else
+            ubf = lodhi_bound_mask<64>(cand ? (rm | lead) : 0ull, m, s_lb);  // all bytes: no branches between the table reads
         const uint32_t v = __float_as_uint(ubf) + 1u;
         if (cand) {  // first maximum wins: strictly greater replaces
             if (v > b1B) { b2B = b1B; b1B = v; pB = (uint32_t)it; } else if (v > b2B) b2B = v;

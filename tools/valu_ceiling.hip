@@ -10,6 +10,7 @@
 // the whole chip and as cycles per instruction per SIMD at the clock measured with s_memrealtime (100 MHz)
 // against the shader clock counter (s_memtime).
 #include <hip/hip_runtime.h>
+#include <cstring>
 
 #include <cstdio>
 #include <cstdlib>
@@ -25,14 +26,14 @@
 
 enum Op {
     OP_BITOP3, OP_AND, OP_ADD, OP_ADDCO_PAIR, OP_LSHL_OR, OP_ALIGNBIT, OP_ADD3, OP_OR3, OP_MAD24, OP_BCNT, OP_LSHL, OP_LSHL64,
-    OP_CNDMASK, OP_BFREV, OP_MOV, OP_ADD_F64, OP_FMA_F64, OP_DS_READ_B32, OP_DS_READ_B64, OP_LSHL_ADD_U64, OP_XAD, OP_CMP_CND, OP_BFE, OP_AND_SDWA, OP_ADD_SDWA, OP_ADDCO, OP_ADDC, OP_FFBH, OP_CMP, OP_AND_OR, OP_LSHR, OP_NOT, OP_SUB, OP_MIN, OP_OR, OP_XNOR, OP_BFI, OP_PERM, OP_LSHLADD, OP_PK_ADD16, OP_PK_SUB16, OP_PK_LSHL16, OP_PK_LSHR16, OP_LSHL_SDWA, OP_MYERS2, OP_COUNT
+    OP_CNDMASK, OP_BFREV, OP_MOV, OP_ADD_F64, OP_FMA_F64, OP_DS_READ_B32, OP_DS_READ_B64, OP_LSHL_ADD_U64, OP_XAD, OP_CMP_CND, OP_BFE, OP_AND_SDWA, OP_ADD_SDWA, OP_ADDCO, OP_ADDC, OP_FFBH, OP_CMP, OP_AND_OR, OP_LSHR, OP_NOT, OP_SUB, OP_MIN, OP_OR, OP_XNOR, OP_BFI, OP_PERM, OP_LSHLADD, OP_PK_ADD16, OP_PK_SUB16, OP_PK_LSHL16, OP_PK_LSHR16, OP_LSHL_SDWA, OP_ASHR, OP_AND_LIT, OP_XOR, OP_SUBREV, OP_MYERS2, OP_COUNT
 };
 static const char* const kOpName[OP_COUNT] = {
     "v_bitop3_b32", "v_and_b32", "v_add_u32", "v_add_co_u32+v_addc_co_u32", "v_lshl_or_b32", "v_alignbit_b32", "v_add3_u32", "v_or3_b32",
     "v_mad_u32_u24", "v_bcnt_u32_b32", "v_lshlrev_b32", "v_lshlrev_b64", "v_cndmask_b32", "v_bfrev_b32", "v_mov_b32", "v_add_f64",
-    "v_fma_f64", "ds_read_b32", "ds_read_b64", "v_lshl_add_u64", "v_xad_u32", "v_cmp_ne_u32+v_cndmask_b32", "v_bfe_u32", "v_and_b32_sdwa(byte_sel)", "v_add_u32_sdwa(word_sel)", "v_add_co_u32(alone)", "v_addc_co_u32(alone)", "v_ffbh_u32", "v_cmp_lt_i32(vcc)", "v_and_or_b32", "v_lshrrev_b32", "v_not_b32", "v_sub_u32", "v_min_i32", "v_or_b32", "v_xnor_b32", "v_bfi_b32", "v_perm_b32", "v_lshl_add_u32", "v_pk_add_u16", "v_pk_sub_u16", "v_pk_lshlrev_b16", "v_pk_lshrrev_b16", "v_lshlrev_b32_sdwa(byte_sel)", "myers_step<2> + move_bits (C++, 27 VALU)"};
+    "v_fma_f64", "ds_read_b32", "ds_read_b64", "v_lshl_add_u64", "v_xad_u32", "v_cmp_ne_u32+v_cndmask_b32", "v_bfe_u32", "v_and_b32_sdwa(byte_sel)", "v_add_u32_sdwa(word_sel)", "v_add_co_u32(alone)", "v_addc_co_u32(alone)", "v_ffbh_u32", "v_cmp_lt_i32(vcc)", "v_and_or_b32", "v_lshrrev_b32", "v_not_b32", "v_sub_u32", "v_min_i32", "v_or_b32", "v_xnor_b32", "v_bfi_b32", "v_perm_b32", "v_lshl_add_u32", "v_pk_add_u16", "v_pk_sub_u16", "v_pk_lshlrev_b16", "v_pk_lshrrev_b16", "v_lshlrev_b32_sdwa(byte_sel)", "v_ashrrev_i32", "v_and_b32(32-bit literal)", "v_xor_b32", "v_subrev_u32", "myers_step<2> + move_bits (C++, 27 VALU)"};
 // instructions per asm instance (the add/addc pair counts two)
-static const int kOpInstr[OP_COUNT] = {1, 1, 1, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1};
+static const int kOpInstr[OP_COUNT] = {1, 1, 1, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1};
 
 #define A1(INS) asm volatile(INS : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h), "+v"(p), "+v"(q), "+v"(r), "+v"(s) : "v"(x), "v"(y) : "vcc")
 
@@ -197,6 +198,18 @@ __global__ void k_issue(uint32_t* __restrict__ out, int iters, unsigned long lon
         } else if constexpr (OP == OP_PK_LSHL16) {
             if constexpr (DEP) { I_DEP("v_pk_lshlrev_b16 %0, 1, %0 op_sel_hi:[0,1]") }
             else { I_IND("v_pk_lshlrev_b16 %0, 1, %0 op_sel_hi:[0,1]", "v_pk_lshlrev_b16 %1, 1, %1 op_sel_hi:[0,1]", "v_pk_lshlrev_b16 %2, 1, %2 op_sel_hi:[0,1]", "v_pk_lshlrev_b16 %3, 1, %3 op_sel_hi:[0,1]", "v_pk_lshlrev_b16 %4, 1, %4 op_sel_hi:[0,1]", "v_pk_lshlrev_b16 %5, 1, %5 op_sel_hi:[0,1]", "v_pk_lshlrev_b16 %6, 1, %6 op_sel_hi:[0,1]", "v_pk_lshlrev_b16 %7, 1, %7 op_sel_hi:[0,1]") }
+        } else if constexpr (OP == OP_ASHR) {
+            if constexpr (DEP) { I_DEP("v_ashrrev_i32 %0, 1, %0") }
+            else { I_IND("v_ashrrev_i32 %0, 1, %0", "v_ashrrev_i32 %1, 1, %1", "v_ashrrev_i32 %2, 1, %2", "v_ashrrev_i32 %3, 1, %3", "v_ashrrev_i32 %4, 1, %4", "v_ashrrev_i32 %5, 1, %5", "v_ashrrev_i32 %6, 1, %6", "v_ashrrev_i32 %7, 1, %7") }
+        } else if constexpr (OP == OP_AND_LIT) {
+            if constexpr (DEP) { I_DEP("v_and_b32 %0, 0x40004000, %0") }
+            else { I_IND("v_and_b32 %0, 0x40004000, %0", "v_and_b32 %1, 0x40004000, %1", "v_and_b32 %2, 0x40004000, %2", "v_and_b32 %3, 0x40004000, %3", "v_and_b32 %4, 0x40004000, %4", "v_and_b32 %5, 0x40004000, %5", "v_and_b32 %6, 0x40004000, %6", "v_and_b32 %7, 0x40004000, %7") }
+        } else if constexpr (OP == OP_XOR) {
+            if constexpr (DEP) { I_DEP("v_xor_b32 %0, %0, %12") }
+            else { I_IND("v_xor_b32 %0, %0, %12", "v_xor_b32 %1, %1, %12", "v_xor_b32 %2, %2, %12", "v_xor_b32 %3, %3, %12", "v_xor_b32 %4, %4, %12", "v_xor_b32 %5, %5, %12", "v_xor_b32 %6, %6, %12", "v_xor_b32 %7, %7, %12") }
+        } else if constexpr (OP == OP_SUBREV) {
+            if constexpr (DEP) { I_DEP("v_subrev_u32 %0, %12, %0") }
+            else { I_IND("v_subrev_u32 %0, %12, %0", "v_subrev_u32 %1, %12, %1", "v_subrev_u32 %2, %12, %2", "v_subrev_u32 %3, %12, %3", "v_subrev_u32 %4, %12, %4", "v_subrev_u32 %5, %12, %5", "v_subrev_u32 %6, %12, %6", "v_subrev_u32 %7, %12, %7") }
         } else if constexpr (OP == OP_PK_LSHR16) {
             if constexpr (DEP) { I_DEP("v_pk_lshrrev_b16 %0, 15, %0 op_sel_hi:[0,1]") }
             else { I_IND("v_pk_lshrrev_b16 %0, 15, %0 op_sel_hi:[0,1]", "v_pk_lshrrev_b16 %1, 15, %1 op_sel_hi:[0,1]", "v_pk_lshrrev_b16 %2, 15, %2 op_sel_hi:[0,1]", "v_pk_lshrrev_b16 %3, 15, %3 op_sel_hi:[0,1]", "v_pk_lshrrev_b16 %4, 15, %4 op_sel_hi:[0,1]", "v_pk_lshrrev_b16 %5, 15, %5 op_sel_hi:[0,1]", "v_pk_lshrrev_b16 %6, 15, %6 op_sel_hi:[0,1]", "v_pk_lshrrev_b16 %7, 15, %7 op_sel_hi:[0,1]") }
@@ -355,6 +368,7 @@ static Result run(K kern, int wps, int instr_per_iter, int iters, int n_cus, uin
 
 int main(int argc, char** argv) {
     int iters = argc > 1 ? atoi(argv[1]) : 16384;
+    const char* only = argc > 2 ? argv[2] : nullptr;   // substring filter on the class names (comma-free); all classes without it
     hipDeviceProp_t prop;
     CHECK(hipGetDeviceProperties(&prop, 0));
     const int n_cus = prop.multiProcessorCount;
@@ -369,7 +383,7 @@ int main(int argc, char** argv) {
            "ind = 8 independent chains per wave\",\n \"classes\": {\n",
            prop.name, prop.gcnArchName, n_cus, prop.clockRate, iters);
 #define ROW(OP)                                                                                                          \
-    {                                                                                                                    \
+    if (!only || strstr(kOpName[OP], only)) {                                                                                                                    \
         printf("  \"%s\": {", kOpName[OP]);                                                                              \
         for (int d = 0; d < 2; ++d) {                                                                                    \
             printf("\"%s\": {", d ? "ind" : "dep");                                                                      \
@@ -386,7 +400,7 @@ int main(int argc, char** argv) {
     }
     ROW(OP_BITOP3) ROW(OP_AND) ROW(OP_ADD) ROW(OP_ADDCO_PAIR) ROW(OP_LSHL_OR) ROW(OP_ALIGNBIT) ROW(OP_ADD3) ROW(OP_OR3) ROW(OP_MAD24) ROW(OP_BCNT)
     ROW(OP_LSHL) ROW(OP_LSHL64) ROW(OP_CNDMASK) ROW(OP_BFREV) ROW(OP_MOV) ROW(OP_ADD_F64) ROW(OP_FMA_F64) ROW(OP_DS_READ_B32) ROW(OP_DS_READ_B64) ROW(OP_LSHL_ADD_U64) ROW(OP_XAD) ROW(OP_CMP_CND)
-    ROW(OP_BFE) ROW(OP_AND_SDWA) ROW(OP_ADD_SDWA) ROW(OP_ADDCO) ROW(OP_ADDC) ROW(OP_FFBH) ROW(OP_CMP) ROW(OP_AND_OR) ROW(OP_LSHR) ROW(OP_NOT) ROW(OP_SUB) ROW(OP_MIN) ROW(OP_OR) ROW(OP_XNOR) ROW(OP_BFI) ROW(OP_PERM) ROW(OP_LSHLADD) ROW(OP_PK_ADD16) ROW(OP_PK_SUB16) ROW(OP_PK_LSHL16) ROW(OP_PK_LSHR16) ROW(OP_LSHL_SDWA)
+    ROW(OP_BFE) ROW(OP_AND_SDWA) ROW(OP_ADD_SDWA) ROW(OP_ADDCO) ROW(OP_ADDC) ROW(OP_FFBH) ROW(OP_CMP) ROW(OP_AND_OR) ROW(OP_LSHR) ROW(OP_NOT) ROW(OP_SUB) ROW(OP_MIN) ROW(OP_OR) ROW(OP_XNOR) ROW(OP_BFI) ROW(OP_PERM) ROW(OP_LSHLADD) ROW(OP_PK_ADD16) ROW(OP_PK_SUB16) ROW(OP_PK_LSHL16) ROW(OP_PK_LSHR16) ROW(OP_LSHL_SDWA) ROW(OP_ASHR) ROW(OP_AND_LIT) ROW(OP_XOR) ROW(OP_SUBREV)
     {
         // C++ Myers column: instruction count per column taken from the disassembly is not needed — report columns/s
         printf("  \"%s\": {", kOpName[OP_MYERS2]);
