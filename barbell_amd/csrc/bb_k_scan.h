@@ -47,6 +47,9 @@ struct hit_buf {
         ST.prev = cur_;                                                                         \
     } while (0)
 
+#ifndef BB_VERIFY_FAST
+#define BB_VERIFY_FAST 1   // groups of four columns without score / local-minimum tracking while every lane's score is out of reach of k (below)
+#endif
 #ifndef BB_VERIFY_CHUNKS
 #define BB_VERIFY_CHUNKS 5   // 16-byte text loads per lane and round in k_flank_verify.  A verified interval is m + k columns of lead-in plus a flagged piece and
                              // its margins (~75 columns for SQK-NBD114-96): five chunks take it in ONE round, so its one or two 128-byte lines are fetched once
@@ -629,6 +632,21 @@ __device__ __forceinline__ void flank_verify_lane(const uint8_t* __restrict__ ba
         ++idx;
         BB_LM_STEP_BUF(st, sc, idx);
     };
+    const uint32_t topmask = TB == 31 ? 0xFFFFFFFFu : ((2u << TB) - 1u);
+    auto score_now = [&]() {   // D[m][idx] from the vertical deltas (the top row is 0)
+        int32_t v = 0;
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+            const uint32_t msk = w == W - 1 ? topmask : 0xFFFFFFFFu;
+            v += __popc(pv[w] & msk) - __popc(mv[w] & msk);
+        }
+        return v;
+    };
+    auto step_fast = [&](uint32_t ch) {
+        uint32_t eq[W], d0[W], ph[W], mh[W];
+        load_eq<W, S>(s_peq, ch, eq);
+        myers_step<W>(pv, mv, eq, d0, ph, mh);
+    };
     // 16 scan positions p0.. as 4 words in scan order (the rc strand reads the text backwards)
     auto load16 = [&](uint32_t p0, uint32_t (&wq)[4]) {
         const int64_t a = STRAND ? (int64_t)n - 16 - (int64_t)p0 : (int64_t)p0;
@@ -760,11 +778,36 @@ __device__ __forceinline__ void flank_verify_lane(const uint8_t* __restrict__ ba
 #pragma unroll
             for (int hb2 = 0; hb2 < CH; ++hb2) {
                 if (__any(cntb > (uint32_t)(16 * hb2))) {
+#if BB_VERIFY_FAST
+                    // The lead-in of an interval starts from the all-insertions column (score m) and the score falls by at most one per column:
+                    // for its first m - k - 4 columns nothing can be reported and neither the score nor the local-minimum state needs tracking
+                    // (k_flank_scan2's fast path: the score re-derived from the vertical deltas afterwards).  Most lanes of a wave start their
+                    // intervals with the round, so the test is wave-uniform often enough: 15 instead of 27 instructions per column there.
+#pragma unroll
+                    for (int b0 = 0; b0 < 16; b0 += 4) {
+                        const bool in4 = (uint32_t)(16 * hb2 + b0 + 3) < cntb;   // all four columns are the lane's
+                        const bool part = !in4 && (uint32_t)(16 * hb2 + b0) < cntb;
+                        if (__any(part || (in4 && sc <= kk + 4))) {
+#pragma unroll
+                            for (int b = b0; b < b0 + 4; ++b) {
+                                const uint32_t w = wt[hb2][b >> 2];
+                                if ((uint32_t)(16 * hb2 + b) < cntb) step((w >> (8 * (b & 3))) & 0xFFu);
+                            }
+                        } else if (in4) {   // (lanes without these columns sit the group out)
+#pragma unroll
+                            for (int b = b0; b < b0 + 4; ++b) step_fast((wt[hb2][b >> 2] >> (8 * (b & 3))) & 0xFFu);
+                            idx += 4;
+                            sc = score_now();
+                            st.prev = sc;  // > k: the lazily evaluated `dec` needs no update (see lm_lane)
+                        }
+                    }
+#else
 #pragma unroll
                     for (int b = 0; b < 16; ++b) {
                         const uint32_t w = wt[hb2][b >> 2];
                         if ((uint32_t)(16 * hb2 + b) < cntb) step((w >> (8 * (b & 3))) & 0xFFu);
                     }
+#endif
                 }
             }
             cur += cntb;
@@ -781,8 +824,10 @@ __device__ __forceinline__ void flank_verify_lane(const uint8_t* __restrict__ ba
     stage_flush(stage, stage_fill, hits, hit_cap, hit_count);
 }
 
+// five waves per SIMD (<= 102 VGPRs) where the step's words leave room: the kernel waits on memory half of its time (4.55 against 4.61 ms
+// scan stage at four waves, nine spilled registers in the W = 2 instantiation notwithstanding)
 template <int W>
-__global__ __launch_bounds__(256) void k_flank_verify(const uint8_t* __restrict__ bases, const uint64_t* __restrict__ offsets, uint32_t n_reads,
+__global__ __launch_bounds__(256, W <= 4 ? 5 : 1) void k_flank_verify(const uint8_t* __restrict__ bases, const uint64_t* __restrict__ offsets, uint32_t n_reads,
                                                       const uint8_t* __restrict__ tables, const bb_group_dev* __restrict__ groups, uint32_t g,
                                                       uint32_t n_groups, const uint32_t* __restrict__ flags, uint64_t words_per_strand,
                                                       uint32_t* __restrict__ cnt, bb_hit_raw* __restrict__ hits, uint32_t hit_cap,

@@ -219,6 +219,32 @@ def test_hip_equals_checker_under_policy(pol):
         dm.close()
 
 
+# k_barcode_lane's bound by row classes (lane_rows4: one of eS, eD is 0), with and without the NM masks of large flank budgets (rbk96x: k = 20)
+@pytest.mark.gpu
+@pytest.mark.parametrize("pol", ["lodhi=3:0.5:1011", "lodhi=3:0.5:2012,trace=DSIM", "lodhi=3:0.5:1110,tie=last,lm=left"])
+def test_hip_equals_checker_row_class_bound(pol):
+    from barbell_amd import annotate as A
+    from tests.test_gpu_parity import assert_same
+
+    from tests.common import noisy_reads
+
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from policy_sensitivity import mutate   # substitutions, insertions and deletions over the whole read: all three row classes occur
+
+    for cfg, n, lmin, lmax, rate in (("nbd96", 1500, 150, 2500, 0.05), ("rbk96x", 600, 300, 2500, 0.04), ("dual", 400, 300, 2000, 0.03)):
+        groups, bases, offsets = noisy_reads(cfg, 4242, n, lmin, lmax, 0.0)
+        bases, offsets = mutate(bases, offsets, rate, 0.03, 0.04, 99)
+        dm = A.Demuxer(policy=pol)
+        for g in groups:
+            dm.add_query_group(g)
+        got = dm.demux_packed(bases, offsets)
+        want = po.Oracle([g.as_tuple() for g in groups], policy=pol).annotate(bases, offsets, n_threads=NT)
+        assert len(want) > n // 4
+        assert_same(got, want)
+        dm.close()
+
+
 # one class of each kind of bb_prio.h (which three bits the planes are functions of: the order's last op) besides the default's
 KIND_CLASSES = ["trace=MSID", "trace=MDSI", "trace=DSIM", "trace=MIDS,rcpath=mirror"]
 VARIANT_KNOBS = [None, ("BARBELL_AMD_LANE", "0"), ("BARBELL_AMD_LANE", "2"), ("BARBELL_AMD_NO_FAST", "1"), ("BARBELL_AMD_FAST_MARGIN", "10"),
