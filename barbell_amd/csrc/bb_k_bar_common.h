@@ -249,6 +249,33 @@ __device__ __forceinline__ float lodhi_bound(unsigned long long plo, unsigned lo
 // byte instead of nine instructions per column; the entries are rounded up, every term is positive, fewer than 60 roundings enter a
 // result: the (1 + 2^-14) scale keeps it a bound.
 struct __attribute__((aligned(32))) bb_lb_entry { float A, B, C, n, D, E, S, _p1; };
+// In LDS the 256 entries sit as two planes of 16 bytes — (A, B, C, n) of every entry, then (D, E, S, -) — not as 32-byte rows: a lane reads
+// both halves at a data-dependent index, and 16-byte rows fall on sixteen bank groups where 32-byte rows fall on eight.
+#ifndef BB_LB_SPLIT
+#define BB_LB_SPLIT 1
+#endif
+__device__ __forceinline__ void lb_put(bb_lb_entry* tab, uint32_t i, const bb_lb_entry& e) {
+#if BB_LB_SPLIT
+    float4* pl = reinterpret_cast<float4*>(tab);
+    pl[i] = make_float4(e.A, e.B, e.C, e.n); pl[256u + i] = make_float4(e.D, e.E, e.S, 0.0f);
+#else
+    tab[i] = e;
+#endif
+}
+__device__ __forceinline__ float4 lb_a(const bb_lb_entry* tab, uint32_t i) {
+#if BB_LB_SPLIT
+    return reinterpret_cast<const float4*>(tab)[i];
+#else
+    return *reinterpret_cast<const float4*>(&tab[i].A);
+#endif
+}
+__device__ __forceinline__ float4 lb_d(const bb_lb_entry* tab, uint32_t i) {
+#if BB_LB_SPLIT
+    return reinterpret_cast<const float4*>(tab)[256u + i];
+#else
+    return *reinterpret_cast<const float4*>(&tab[i].D);
+#endif
+}
 __device__ __forceinline__ void lodhi_bound_table_entry(uint32_t byte, uint32_t expk, bb_lb_entry& e) {
     const int eM = (int)(expk & 0xFFu), eS = (int)((expk >> 8) & 0xFFu), eI = (int)((expk >> 16) & 0xFFu), eX = eS < eI ? eS : eI;
     auto p2 = [](int k) -> double { return __hiloint2double((int)((uint32_t)(1023 + k) << 20), 0); };  // 2^k, |k| < 1023
@@ -294,8 +321,7 @@ __device__ __forceinline__ float lodhi_bound_mask4(unsigned long long am, unsign
     for (int q = 0; q < CW / 4; ++q) {
         if (4 * q < wmax) {  // wave-uniform
             const uint32_t idx = ((a_w[q >> 3] >> (4 * (q & 7))) & 0xFu) | (((b_w[q >> 3] >> (4 * (q & 7))) & 0xFu) << 4);
-            const float4 t0 = *reinterpret_cast<const float4*>(&tab[idx].A);
-            const float4 t1 = *reinterpret_cast<const float4*>(&tab[idx].D);
+            const float4 t0 = lb_a(tab, idx), t1 = lb_d(tab, idx);
             sc = __fmaf_rn(t0.x, u2, __fmaf_rn(t0.y, u1, sc + t0.z));
             u2 = (__fmaf_rn(t0.w, u1, u2) + t1.x) * t1.z;
             u1 = (u1 + t1.y) * t1.z;
@@ -318,8 +344,7 @@ __device__ __forceinline__ float lodhi_bound_mask(unsigned long long mmask, int 
     for (int q = 0; q < CW / 8; ++q) {
         if (8 * q < wmax) {  // wave-uniform
             const uint32_t byte = (m_w[q >> 2] >> (8 * (q & 3))) & 0xFFu;
-            const float4 t0 = *reinterpret_cast<const float4*>(&tab[byte].A);
-            const float4 t1 = *reinterpret_cast<const float4*>(&tab[byte].D);
+            const float4 t0 = lb_a(tab, byte), t1 = lb_d(tab, byte);
             sc = __fmaf_rn(t0.x, u2, __fmaf_rn(t0.y, u1, sc + t0.z));
             u2 = (__fmaf_rn(t0.w, u1, u2) + t1.x) * t1.z;
             u1 = (u1 + t1.y) * t1.z;

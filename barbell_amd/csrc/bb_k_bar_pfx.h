@@ -88,7 +88,7 @@ __global__ __launch_bounds__(CW <= 48 ? 768 : 512) void k_barcode_pfx(const uint
         const int words = 16 * N;
         for (int i = threadIdx.x; i < words; i += blockDim.x) s_peq[i] = gp[i];
         if constexpr (FAST)
-            for (uint32_t i = threadIdx.x; i < 256u; i += blockDim.x) lodhi_bound_table_entry(i, (uint32_t)G.pol_lodhi_exp, s_lb[i]);
+            for (uint32_t i = threadIdx.x; i < 256u; i += blockDim.x) { bb_lb_entry e; lodhi_bound_table_entry(i, (uint32_t)G.pol_lodhi_exp, e); lb_put(s_lb, i, e); }
     }
     const int hl = threadIdx.x / N;
     const int p = threadIdx.x - hl * N;

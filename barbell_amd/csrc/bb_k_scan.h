@@ -824,10 +824,14 @@ __device__ __forceinline__ void flank_verify_lane(const uint8_t* __restrict__ ba
     stage_flush(stage, stage_fill, hits, hit_cap, hit_count);
 }
 
-// five waves per SIMD (<= 102 VGPRs) where the step's words leave room: the kernel waits on memory half of its time (4.55 against 4.61 ms
-// scan stage at four waves, nine spilled registers in the W = 2 instantiation notwithstanding)
+// (106 VGPRs in the W = 2 instantiation: four waves per SIMD.  Held to five — __launch_bounds__(256, 5): 96 VGPRs, 9 spilled — the scan stage
+// was 0.05 ms faster and the kernel fetched 0.2 GB more per step, the lines of its intervals surviving less often between a lane's chunks:
+// BB_VERIFY_MINBLOCKS=5)
+#ifndef BB_VERIFY_MINBLOCKS
+#define BB_VERIFY_MINBLOCKS 1
+#endif
 template <int W>
-__global__ __launch_bounds__(256, W <= 4 ? 5 : 1) void k_flank_verify(const uint8_t* __restrict__ bases, const uint64_t* __restrict__ offsets, uint32_t n_reads,
+__global__ __launch_bounds__(256, W <= 4 ? BB_VERIFY_MINBLOCKS : 1) void k_flank_verify(const uint8_t* __restrict__ bases, const uint64_t* __restrict__ offsets, uint32_t n_reads,
                                                       const uint8_t* __restrict__ tables, const bb_group_dev* __restrict__ groups, uint32_t g,
                                                       uint32_t n_groups, const uint32_t* __restrict__ flags, uint64_t words_per_strand,
                                                       uint32_t* __restrict__ cnt, bb_hit_raw* __restrict__ hits, uint32_t hit_cap,

@@ -128,9 +128,9 @@ __global__ __launch_bounds__(256, CW <= 48 ? 3 : 2) void k_barcode_lane(const ui
         // the bound runs over the pattern's ROWS (below): a row without a Match is a Sub or a Del, so the table's other-op exponent is min(eS, eD)
         const uint32_t e4 = (uint32_t)G.pol_lodhi_exp, e_rows = (e4 & 0xFFFFu) | ((e4 >> 24) << 16);
         if (lane_rows4(e4)) {   // the table by row classes (walks collect the rows left diagonally as well)
-            for (uint32_t i = threadIdx.x; i < 256u; i += 256u) lodhi_bound_table_entry4(i, e4, s_lb[i]);
+            for (uint32_t i = threadIdx.x; i < 256u; i += 256u) { bb_lb_entry e; lodhi_bound_table_entry4(i, e4, e); lb_put(s_lb, i, e); }
         } else {
-            for (uint32_t i = threadIdx.x; i < 256u; i += 256u) lodhi_bound_table_entry(i, e_rows, s_lb[i]);
+            for (uint32_t i = threadIdx.x; i < 256u; i += 256u) { bb_lb_entry e; lodhi_bound_table_entry(i, e_rows, e); lb_put(s_lb, i, e); }
         }
     }
     const bool rows4 = lane_rows4((uint32_t)G.pol_lodhi_exp);   // wave-uniform
