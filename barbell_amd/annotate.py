@@ -206,7 +206,8 @@ class Demuxer:
 
     def scan_stats(self, g=0):
         """how the flank scan of group g ran on the last batch: {flagged_pieces, total_pieces, kind}; kind 0 = full scan, 1 = filter +
-        verification, 2 = the filter flagged too much of the batch and the full scan took over (bb_last_scan_stats)"""
+        verification, 2 = the filter flagged too much of the batch and the full scan took over, 3 = full scan without a filter pass while the group is
+        backed off after a batch of kind 2 (bb_last_scan_stats)"""
         f, t, k = C.c_uint64(), C.c_uint64(), C.c_int()
         self._check(lib().bb_last_scan_stats(self._ctx(), g, C.byref(f), C.byref(t), C.byref(k)))
         return {"flagged_pieces": f.value, "total_pieces": t.value, "kind": k.value}

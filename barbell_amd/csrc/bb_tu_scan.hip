@@ -18,8 +18,15 @@ int bb_scan_u32(bb_ctx* c, const uint32_t* in, uint32_t* out, uint64_t n) {
 namespace {
 template <int W>
 int launch_scan(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n, uint32_t g, uint64_t flag_words, uint64_t batch_bytes) {
+    const uint64_t probed_flagged = c->last_flagged[g], probed_pieces = c->last_pieces[g];
     c->last_scan_kind[g] = 0; c->last_flagged[g] = 0; c->last_pieces[g] = 2 * ((batch_bytes + 15) / 16);
-    if (c->gdev[g].filt_rows > 0) {
+    if (c->gdev[g].filt_rows > 0 && c->scan_off[g] > 0 && c->scan_filter != 1) {
+        // the group's last probed batch flagged above the break-even: data like that comes in runs (a library full of adapter-like decoys), so the
+        // next batches skip the filter pass that would be thrown away and the group is probed again after sixteen of them
+        --c->scan_off[g];
+        c->last_scan_kind[g] = 3;
+        c->last_flagged[g] = probed_flagged; c->last_pieces[g] = probed_pieces;   // the counts stay those of the batch that was probed
+    } else if (c->gdev[g].filt_rows > 0) {
         (void)hipMemsetAsync(c->d_flags, 0, (size_t)2 * flag_words * sizeof(uint32_t), c->stream);  // the filter writes the words that hold a flag
         (void)hipMemsetAsync(c->d_nflag + g, 0, sizeof(unsigned long long), c->stream);
         if (c->gdev[g].filt_mode & BB_FILT_WIDE)
@@ -38,6 +45,7 @@ int launch_scan(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets, ui
         c->last_flagged[g] = nf; c->last_scan_kind[g] = 1;
         if (c->scan_filter != 1 && (double)nf > c->adapt_frac * (double)c->last_pieces[g]) {
             c->last_scan_kind[g] = 2;
+            c->scan_off[g] = 16;
             hipLaunchKernelGGL(k_flank_scan2<W>, dim3((n + 255) / 256, 2), dim3(256), 0, c->stream, d_bases, d_offsets, n,
                                (const uint8_t*)c->d_tables, (const bb_group_dev*)c->d_groups, g, (uint32_t)c->groups.size(), c->d_cnt,
                                c->d_raw, c->cap_hits, c->d_hitcount);

@@ -366,7 +366,8 @@ def stress_leg(mode, dev_idx, dev, L, args, n=1_000_000, steps=3):
     dt = (time.perf_counter() - t0) / steps
     st = dm.scan_stats(0)
     out = {"reads_per_s": n / dt, "ms_per_step": dt * 1e3, "reads": n, "rows_per_step": nr, "flagged_fraction": st["flagged_pieces"] / max(1, st["total_pieces"]),
-           "scan": ("full scan", "filter + verification", "filter, then full scan (flags above break-even)")[st["kind"]], "scan_stage_ms": kms["k_flank_scan"],
+           "scan": ("full scan", "filter + verification", "filter, then full scan (flags above break-even)",
+                    "full scan (the group's last probed batch flagged above break-even: no filter pass for 16 batches)")[st["kind"]], "scan_stage_ms": kms["k_flank_scan"],
            "barcode_stage_ms": kms["k_barcode"]}
     if not args.no_cpu_baseline:
         w = 2048

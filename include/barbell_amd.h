@@ -168,8 +168,10 @@ int         bb_last_dominant_kernel(const bb_ctx* ctx, char* name, size_t name_c
 
 /* How the flank scan (searcher.rs:438) of group `group` ran on the last batch: kind 0 = full-height scan of every column, 1 = 15/31-row
  * filter + full-height verification around the flagged 16-byte pieces, 2 = the filter flagged more than the break-even
- * fraction of the batch's pieces (low-complexity text, adapter-like decoys), so the full scan did the batch.  Results are the
- * same whichever ran; the counts tell a caller how far its data is from the synthetic benchmark's.                       */
+ * fraction of the batch's pieces (low-complexity text, adapter-like decoys), so the full scan did the batch, 3 = the full scan
+ * without a filter pass: the group's last probed batch was of kind 2 (sixteen batches, then the group is probed again;
+ * the counts stay those of the probed batch).  Results are the same whichever ran; the counts tell a caller how far its data is from the
+ * synthetic benchmark's.                                                                                                  */
 int bb_last_scan_stats(const bb_ctx* ctx, uint32_t group, uint64_t* flagged_pieces, uint64_t* total_pieces, int* kind);
 
 /* The barcode stage of the last batch, per (group, strand): flank hits listed for it, how many of them the fast kernel's bounds left

@@ -656,6 +656,32 @@ def test_stress_mixes_and_adaptive_scan(monkeypatch, mode, frac):
         assert st["flagged_pieces"] / st["total_pieces"] > 0.001
 
 
+def test_scan_backs_off_after_an_over_flagged_batch(monkeypatch):
+    """A batch whose flags exceed the break-even sends the group's next sixteen batches straight to the full scan (kind 3: no filter
+    pass to throw away), then the group is probed again; the rows are the same whichever scan ran."""
+    monkeypatch.setenv("BARBELL_AMD_ADAPT_FRAC", "0")   # any flag is too many: the first batch is of kind 2
+    groups = config_groups("nbd96")
+    bases, offsets = A_synth(groups, 977, 300, 2500, 500)
+    dm, got, want = run_both(groups, bases, offsets)
+    assert_same(got, want)
+    assert dm.scan_stats(0)["kind"] == 2
+    probed = dm.scan_stats(0)["flagged_pieces"]
+    kinds = []
+    for _ in range(18):
+        assert_same(dm.demux_packed(bases, offsets), want)
+        st = dm.scan_stats(0)
+        kinds.append(st["kind"])
+        assert st["flagged_pieces"] == probed
+    assert kinds == [3] * 16 + [2, 3]
+    dm.close()
+
+
+def A_synth(groups, seed, lmin, lmax, n):
+    from barbell_amd import annotate as A
+
+    return A.synth_reads_host(groups, seed, lmin, lmax, 0, n)
+
+
 def test_geometry_beyond_the_tuned_kernels():
     """What the reference's BarcodeGroup::new (barcodes.rs:105-197) accepts and only the any-geometry kernels compute: padded barcodes
     longer than 64 nt (three Myers words per lane), a 150-nt flank under its automatic error budget (> 63), windows wider than
