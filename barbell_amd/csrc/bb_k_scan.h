@@ -476,23 +476,25 @@ __global__ __launch_bounds__(256) void k_flank_filter(const uint8_t* __restrict_
         if constexpr (WIDE) {
             const uint2 e2 = *reinterpret_cast<const uint2*>(s_fpeq + 2u * chr);
             {
+                // (a word per strand, rows at bits 0..R-1: what lies above them never flows down — carries and shifts go up — so pv keeps its
+                // upper bits unmasked and only the two horizontal vectors the score reads are cut to the rows: one mask less per column)
                 const uint32_t eq = e2.x, x = eq & pv;
                 const uint32_t d0 = bitop3<BB_TT_XOR_OR>(x + pv, pv, eq) | mv;
-                const uint32_t ph = bitop3<BB_TT_OR_NOR>(mv, d0, pv) & BM, mh = pv & d0;
+                const uint32_t ph = bitop3<BB_TT_OR_NOR>(mv, d0, pv) & BM, mh = bitop3<0x80>(pv, d0, BM);
                 sc2 = sc2 + (ph >> (R - 1)) - (mh >> (R - 1));
                 keep &= sc2;
                 const uint32_t phs = shl1_32(ph), mhs = shl1_32(mh);
-                pv = bitop3<BB_TT_OR_NOR>(mhs, d0, phs) & BM;
+                pv = bitop3<BB_TT_OR_NOR>(mhs, d0, phs);
                 mv = phs & d0;
             }
             {
                 const uint32_t eq = e2.y, x = eq & pvB;
                 const uint32_t d0 = bitop3<BB_TT_XOR_OR>(x + pvB, pvB, eq) | mvB;
-                const uint32_t ph = bitop3<BB_TT_OR_NOR>(mvB, d0, pvB) & BM, mh = pvB & d0;
+                const uint32_t ph = bitop3<BB_TT_OR_NOR>(mvB, d0, pvB) & BM, mh = bitop3<0x80>(pvB, d0, BM);
                 scB = scB + (ph >> (R - 1)) - (mh >> (R - 1));
                 keepB &= scB;
                 const uint32_t phs = shl1_32(ph), mhs = shl1_32(mh);
-                pvB = bitop3<BB_TT_OR_NOR>(mhs, d0, phs) & BM;
+                pvB = bitop3<BB_TT_OR_NOR>(mhs, d0, phs);
                 mvB = phs & d0;
             }
         } else {
