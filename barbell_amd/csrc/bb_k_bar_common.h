@@ -330,19 +330,25 @@ __device__ __forceinline__ float lodhi_bound_mask4(unsigned long long am, unsign
     return sc * (1.0f + 1.0f / 16384.0f);
 }
 template <int CW>
-__device__ __forceinline__ float lodhi_bound_mask(unsigned long long mmask, int wmax, const bb_lb_entry* tab);
+__device__ __forceinline__ float lodhi_bound_mask(unsigned long long mmask, int wmax, const bb_lb_entry* tab, bool skip0, float sc, float u1, float u2);
 template <int CW>
 __device__ __forceinline__ float lodhi_bound_tab(unsigned long long plo, unsigned long long phi, int32_t tstart, int32_t best_pos, int wmax,
                                                  const bb_lb_entry* tab) {
-    return lodhi_bound_mask<CW>(low64(best_pos) & ~low64(tstart) & ~(plo | phi), wmax, tab);   // Match columns (bit c-1)
+    return lodhi_bound_mask<CW>(low64(best_pos) & ~low64(tstart) & ~(plo | phi), wmax, tab, false, 0.0f, 0.0f, 0.0f);   // Match columns (bit c-1)
 }
+// the state after a first byte of eight Matches
+__device__ __forceinline__ void lodhi_bound_first_byte(const bb_lb_entry* tab, float& sc, float& u1, float& u2) {
+    const float4 t0 = lb_a(tab, 0xFFu), t1 = lb_d(tab, 0xFFu);
+    sc = t0.z; u2 = t1.x * t1.z; u1 = t1.y * t1.z;   // from (0, 0, 0): sc = C, u2 = D S, u1 = E S
+}
+// skip0: the mask's first byte is 0xFF in every lane that matters (eight granted shared rows) and (sc, u1, u2) is the state after it —
+// computed once per block (lodhi_bound_first_byte), not once per barcode
 template <int CW>
-__device__ __forceinline__ float lodhi_bound_mask(unsigned long long mmask, int wmax, const bb_lb_entry* tab) {
+__device__ __forceinline__ float lodhi_bound_mask(unsigned long long mmask, int wmax, const bb_lb_entry* tab, bool skip0, float sc, float u1, float u2) {
     const uint32_t m_w[2] = {(uint32_t)mmask, (uint32_t)(mmask >> 32)};
-    float sc = 0.0f, u1 = 0.0f, u2 = 0.0f;
 #pragma unroll
     for (int q = 0; q < CW / 8; ++q) {
-        if (8 * q < wmax) {  // wave-uniform
+        if (8 * q < wmax && !(q == 0 && skip0)) {  // wave-uniform
             const uint32_t byte = (m_w[q >> 2] >> (8 * (q & 3))) & 0xFFu;
             const float4 t0 = lb_a(tab, byte), t1 = lb_d(tab, byte);
             sc = __fmaf_rn(t0.x, u2, __fmaf_rn(t0.y, u1, sc + t0.z));
