@@ -249,7 +249,7 @@ __global__ __launch_bounds__(256, CW <= 48 ? 3 : 2) void k_barcode_lane(const ui
     // eight or more shared rows granted as Matches (no NM masks, one exponent for the rows without a Match): the bound's first table step
     // is the same for every barcode of every hit
     const bool skip0 = !(use_nm && P > 0) && !rows4 && P >= 8;   // wave-uniform
-    float lb_sc0 = 0.0f, lb_u10 = 0.0f, lb_u20 = 0.0f;
+    float lb_sc0 = 0.0f, lb_u10 = 0.0f, lb_u20 = 0.0f;   // (read from the table in every trip instead, the three registers cost more than they hold: 8.96 against 8.88 ms)
     if (skip0) lodhi_bound_first_byte(s_lb, lb_sc0, lb_u10, lb_u20);
     const uint8_t* s_peq_b = reinterpret_cast<const uint8_t*>(s_peq);
     // running top-2 of the two candidate sets (searcher.rs:303-328): bound bits + 1 (0 = empty), first maximum's barcode
@@ -379,24 +379,32 @@ __global__ __launch_bounds__(256, CW <= 48 ? 3 : 2) void k_barcode_lane(const ui
                         if (!__any((b | (sm_w[0] & ((2u << (c0 - 1)) - 1u))) != 0u)) rem = c0;
                     }
                     if (rem == 0) {
+                        // a lane's cursor enters the walk in ONE column (its end position): only the one or two groups that hold some lane's
+                        // entry column extract the entry bit and add it in (two half-rate instructions per column)
+                        auto group = [&](auto inj) __attribute__((always_inline)) {
+                            constexpr bool INJ = decltype(inj)::value;
 #pragma unroll
-                        for (int c = c0; c > c0 - BB_CG; --c) {
-                            const uint32_t Lr = L0[c - 1], Hr = H0[c - 1];
-                            const uint32_t Dr = Lr & Hr;
-                            const uint32_t nb = bitop3<0x0C>(Dr, Dr + b + ((sm_w[(c - 1) >> 5] >> ((c - 1) & 31)) & 1u), 0u);  // ~Dr & sum
-                            const uint32_t cm = bitop3<0x0C>(Hr, nb, 0u);  // ~Hr & nb
-                            if (last) {   // the winner's walk: both planes of the path and its diagonal rows (rows_decide replays them)
-                                const uint32_t tl = Lr & nb, th = Hr & nb;
-                                pl_acc[(c - 1) >> 5] = __builtin_amdgcn_alignbit(pl_acc[(c - 1) >> 5], 0u - tl, 31);
-                                ph_acc[(c - 1) >> 5] = __builtin_amdgcn_alignbit(ph_acc[(c - 1) >> 5], 0u - th, 31);
-                                dg |= cm;
-                            } else {      // every other walk: the bound wants the matched ROWS only (and, NM, the number of text columns)
-                                mrow |= bitop3<0x10>(nb, Lr, Hr);  // nb & ~Lr & ~Hr: the cursor's cell is a Match
-                                if (R4) dg |= cm;                  // Match or Sub: what is left of the path's rows are Dels
-                                if (NM) asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(ncol) : "v"(nb));   // ncol += popcount(nb): a text op per column the cursor is in
+                            for (int c = c0; c > c0 - BB_CG; --c) {
+                                const uint32_t Lr = L0[c - 1], Hr = H0[c - 1];
+                                const uint32_t Dr = Lr & Hr;
+                                const uint32_t sum = INJ ? Dr + b + ((sm_w[(c - 1) >> 5] >> ((c - 1) & 31)) & 1u) : Dr + b;
+                                const uint32_t nb = bitop3<0x0C>(Dr, sum, 0u);  // ~Dr & sum
+                                const uint32_t cm = bitop3<0x0C>(Hr, nb, 0u);  // ~Hr & nb
+                                if (last) {   // the winner's walk: both planes of the path and its diagonal rows (rows_decide replays them)
+                                    const uint32_t tl = Lr & nb, th = Hr & nb;
+                                    pl_acc[(c - 1) >> 5] = __builtin_amdgcn_alignbit(pl_acc[(c - 1) >> 5], 0u - tl, 31);
+                                    ph_acc[(c - 1) >> 5] = __builtin_amdgcn_alignbit(ph_acc[(c - 1) >> 5], 0u - th, 31);
+                                    dg |= cm;
+                                } else {      // every other walk: the bound wants the matched ROWS only (and, NM, the number of text columns)
+                                    mrow |= bitop3<0x10>(nb, Lr, Hr);  // nb & ~Lr & ~Hr: the cursor's cell is a Match
+                                    if (R4) dg |= cm;                  // Match or Sub: what is left of the path's rows are Dels
+                                    if (NM) asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(ncol) : "v"(nb));   // ncol += popcount(nb): a text op per column the cursor is in
+                                }
+                                b = nb + cm;
                             }
-                            b = nb + cm;
-                        }
+                        };
+                        const uint32_t gmask = ((1u << BB_CG) - 1u) << ((c0 - BB_CG) & 31);   // a group's columns lie in one word (BB_CG divides 32)
+                        if (__any((sm_w[(c0 - 1) >> 5] & gmask) != 0u)) group(std::true_type{}); else group(std::false_type{});
                     }
                 }
             }
