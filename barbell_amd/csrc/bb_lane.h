@@ -248,7 +248,7 @@ __global__ __launch_bounds__(256, CW <= 48 ? 3 : 2) void k_barcode_lane(const ui
     }
     // eight or more shared rows granted as Matches (no NM masks, one exponent for the rows without a Match): the bound's first table step
     // is the same for every barcode of every hit
-    const bool skip0 = !(use_nm && P > 0) && !rows4 && P >= 8;   // wave-uniform
+    const bool skip0 = !TAIL && !(use_nm && P > 0) && !rows4 && P >= 8;   // wave-uniform (not with trailing rows: that instantiation has no three registers to spare)
     float lb_sc0 = 0.0f, lb_u10 = 0.0f, lb_u20 = 0.0f;   // (read from the table in every trip instead, the three registers cost more than they hold: 8.96 against 8.88 ms)
     if (skip0) lodhi_bound_first_byte(s_lb, lb_sc0, lb_u10, lb_u20);
     const uint8_t* s_peq_b = reinterpret_cast<const uint8_t*>(s_peq);
