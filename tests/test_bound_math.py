@@ -3,6 +3,8 @@ Ins ops dropped, a row without a Match taking min(eS, eD) (lodhi_bound_table_ent
 Match / Sub / Del / unknown) — and the one k_barcode_pfx computes over the text's COLUMNS (Del ops dropped, min(eS, eI)) are upper bounds
 of cigar-lodhi's score as the checker computes it (oracle/bb_oracle.c lodhi_pol), under every decay-exponent policy the tests use.
 The recurrence below is the kernels' table recurrence (barbell_amd/csrc/bb_k_bar_common.h) written out per row in float64."""
+import zlib
+
 import numpy as np
 import pytest
 
@@ -36,7 +38,7 @@ def exact(ops, pol):
 @pytest.mark.parametrize("pol", ["lodhi=3:0.5:1111", "lodhi=3:0.5:2211", "lodhi=3:0.5:1110", "lodhi=3:0.5:1011", "lodhi=3:0.5:2131", "lodhi=3:0.5:1121", "lodhi=3:0.5:2012"])
 def test_row_and_column_bounds_are_upper_bounds(pol):
     eM, eS, eI, eD = (int(ch) for ch in pol.split(":")[-1])
-    rng = np.random.default_rng(hash(pol) & 0xFFFF)
+    rng = np.random.default_rng(zlib.crc32(pol.encode()))
     for _ in range(400):
         n = int(rng.integers(20, 64))
         ops = rng.choice([M, S, I, D], size=n, p=[0.7, 0.12, 0.08, 0.10]).astype(np.uint8)
