@@ -313,13 +313,24 @@ __device__ __forceinline__ void lodhi_bound_table_entry4(uint32_t idx, uint32_t 
     e.D = __double2float_ru(P2); e.E = __double2float_ru(P1); e.S = (float)p2(-s); e._p1 = 0.0f;
 }
 // rows 4q+1 .. 4q+4 <-> bits 4q .. 4q+3 of the two masks
+// the state after eight Matches, by the class table's own steps (two entries of four Match rows)
+__device__ __forceinline__ void lodhi_bound_first_rows4(const bb_lb_entry* tab, float& sc, float& u1, float& u2) {
+    sc = 0.0f; u1 = 0.0f; u2 = 0.0f;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const float4 t0 = lb_a(tab, 0xFFu), t1 = lb_d(tab, 0xFFu);
+        sc = __fmaf_rn(t0.x, u2, __fmaf_rn(t0.y, u1, sc + t0.z));
+        u2 = (__fmaf_rn(t0.w, u1, u2) + t1.x) * t1.z;
+        u1 = (u1 + t1.y) * t1.z;
+    }
+}
+// skip8: the first eight rows are Matches in every lane that matters and (sc, u1, u2) is the state after them (lodhi_bound_first_rows4)
 template <int CW>
-__device__ __forceinline__ float lodhi_bound_mask4(unsigned long long am, unsigned long long bm, int wmax, const bb_lb_entry* tab) {
+__device__ __forceinline__ float lodhi_bound_mask4(unsigned long long am, unsigned long long bm, int wmax, const bb_lb_entry* tab, bool skip8, float sc, float u1, float u2) {
     const uint32_t a_w[2] = {(uint32_t)am, (uint32_t)(am >> 32)}, b_w[2] = {(uint32_t)bm, (uint32_t)(bm >> 32)};
-    float sc = 0.0f, u1 = 0.0f, u2 = 0.0f;
 #pragma unroll
     for (int q = 0; q < CW / 4; ++q) {
-        if (4 * q < wmax) {  // wave-uniform
+        if (4 * q < wmax && !(q < 2 && skip8)) {  // wave-uniform
             const uint32_t idx = ((a_w[q >> 3] >> (4 * (q & 7))) & 0xFu) | (((b_w[q >> 3] >> (4 * (q & 7))) & 0xFu) << 4);
             const float4 t0 = lb_a(tab, idx), t1 = lb_d(tab, idx);
             sc = __fmaf_rn(t0.x, u2, __fmaf_rn(t0.y, u1, sc + t0.z));

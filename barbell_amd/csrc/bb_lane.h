@@ -248,9 +248,9 @@ __global__ __launch_bounds__(256, CW <= 48 ? 3 : 2) void k_barcode_lane(const ui
     }
     // eight or more shared rows granted as Matches (no NM masks, one exponent for the rows without a Match): the bound's first table step
     // is the same for every barcode of every hit
-    const bool skip0 = !TAIL && !(use_nm && P > 0) && !rows4 && P >= 8;   // wave-uniform (not with trailing rows: that instantiation has no three registers to spare)
+    const bool skip0 = !TAIL && !(use_nm && P > 0) && P >= 8;   // wave-uniform (not with trailing rows: that instantiation has no three registers to spare)
     float lb_sc0 = 0.0f, lb_u10 = 0.0f, lb_u20 = 0.0f;   // (read from the table in every trip instead, the three registers cost more than they hold: 8.96 against 8.88 ms)
-    if (skip0) lodhi_bound_first_byte(s_lb, lb_sc0, lb_u10, lb_u20);
+    if (skip0) { if (rows4) lodhi_bound_first_rows4(s_lb, lb_sc0, lb_u10, lb_u20); else lodhi_bound_first_byte(s_lb, lb_sc0, lb_u10, lb_u20); }
     const uint8_t* s_peq_b = reinterpret_cast<const uint8_t*>(s_peq);
     // running top-2 of the two candidate sets (searcher.rs:303-328): bound bits + 1 (0 = empty), first maximum's barcode
     uint32_t b1A = 0u, b2A = 0u, pA = 0u, b1B = 0u, b2B = 0u, pB = 0u;
@@ -494,7 +494,7 @@ __global__ __launch_bounds__(256, CW <= 48 ? 3 : 2) void k_barcode_lane(const ui
             unsigned long long bm = (unsigned long long)__brev(dg) << P;
             if (TAIL) bm |= (unsigned long long)dgt << (P + 32);
             const unsigned long long am = rm | lead_any;
-            ubf = lodhi_bound_mask4<64>(cand ? am : 0ull, cand ? (bm | lead) : 0ull, m, s_lb);
+            ubf = lodhi_bound_mask4<64>(cand ? am : 0ull, cand ? (bm | lead) : 0ull, m, s_lb, skip0, lb_sc0, lb_u10, lb_u20);
         } else
             ubf = lodhi_bound_mask<64>(cand ? (rm | lead) : 0ull, m, s_lb, skip0, lb_sc0, lb_u10, lb_u20);  // all bytes: no branches between the table reads
         const uint32_t v = __float_as_uint(ubf) + 1u;
