@@ -17,13 +17,15 @@
 using namespace barbell;
 
 // --shard R/W: this process takes the input files whose index is R modulo W (one process per GPU with --device R;
-// reads shard trivially, SURVEY §8e — each process writes its own outputs)
-static bool apply_shard(const std::string& spec, std::vector<std::string>& files) {
+// reads shard trivially, SURVEY §8e — each process writes its own rows; with --rccl-id PATH (the same fresh path for every shard) the
+// per-barcode histograms are all-reduced over the W processes and shard 0 writes --counts)
+static bool apply_shard(const std::string& spec, std::vector<std::string>& files, uint32_t& rank, uint32_t& world) {
     if (spec.empty()) return true;
     const size_t slash = spec.find('/');
     if (slash == std::string::npos) return false;
     const long r = atol(spec.substr(0, slash).c_str()), w = atol(spec.substr(slash + 1).c_str());
     if (w < 1 || r < 0 || r >= w) return false;
+    rank = (uint32_t)r; world = (uint32_t)w;
     std::vector<std::string> mine;
     for (size_t i = 0; i < files.size(); ++i)
         if ((long)(i % (size_t)w) == r) mine.push_back(files[i]);
@@ -64,7 +66,8 @@ static void usage() {
         "Usage: barbell-amd annotate -i <FASTQ>... [-o output.tsv] (--kit <KIT> | -q <FASTA>... [-b Ftag|Rtag ...])\n"
         "                            [--flank-max-errors INT] [--min-score F=0.2] [--min-score-diff F=0.1]\n"
         "                            [--alpha F=0.4] [--use-extended] [-t THREADS=10] [--verbose]\n"
-        "                            [--block-bytes N=128Mi | --batch-reads N (= N*4096 bytes)] [--device D=0] [--shard R/W]\n"
+        "                            [--block-bytes N=128Mi | --batch-reads N (= N*4096 bytes)] [--device D=0]\n"
+        "                            [--shard R/W [--rccl-id PATH (one fresh path for all W processes: their histograms are all-reduced, RCCL ncclCommInitRank; shard 0 writes --counts)]]\n"
         "                            [--devices D0,D1,.. (one FASTQ stream over several contexts, block i -> context i mod G; RCCL all-reduce of the counts)]\n"
         "                            [--streams S=2 (contexts per device when --devices is not given)] [--counts FILE]\n"
         "                            [--policy lm=..,rc=..,trace=..,ovh=..,tie=..,lodhi=.. (include/barbell_amd_policy.h)]\n"
@@ -76,7 +79,7 @@ static void usage() {
         "                            [--inspect [-n TOP=10] [--read-pattern-out FILE] [-s BUCKET=250]]\n"
         "       barbell-amd kit -k <KIT> -i <FASTQ>... -o <OUT_DIR> [--maximize] [--min-score F] [--min-score-diff F]\n"
         "                       [--flank-max-errors INT] [--failed-out FILE] [--use-extended] [--alpha F] [--gzip] [-t N]\n"
-        "                       [--device D=0] [--shard R/W] [--gpu-render]\n"
+        "                       [--device D=0] [--shard R/W [--rccl-id PATH]] [--gpu-render]\n"
         "       barbell-amd kits          list the supported kit names\n"
         "       barbell-amd pattern <STR>...   parse filter pattern strings and print their elements\n",
         stderr);
@@ -142,6 +145,7 @@ int main(int argc, char** argv) {
             else if (a == "--counts") k.counts_file = need("--counts");
             else if (a == "--policy") { if (!set_policy(need("--policy"))) return 2; }
             else if (a == "--shard") shard = need("--shard");
+            else if (a == "--rccl-id") k.rccl_id = need("--rccl-id");
             else if (a == "--maximize") { k.maximize = true; multi_in = false; }
             else if (a == "--verbose") { k.verbose = true; multi_in = false; }
             else if (a == "--use-extended") { k.use_extended = true; multi_in = false; }
@@ -152,8 +156,10 @@ int main(int argc, char** argv) {
         }
         if (k.kit_name.empty() || k.output_folder.empty()) { fputs("error: kit needs --kit and --output\n", stderr); return 2; }
         if (input.empty()) { fputs("error: No FASTQ input files provided\n", stderr); return 2; }
-        if (!apply_shard(shard, input)) { fputs("error: --shard takes R/W with 0 <= R < W\n", stderr); return 2; }
-        if (input.empty()) { puts("Nothing to do for this shard"); return 0; }
+        if (!apply_shard(shard, input, k.shard_rank, k.shard_world)) { fputs("error: --shard takes R/W with 0 <= R < W\n", stderr); return 2; }
+        if (input.empty() && k.rccl_id.empty()) { puts("Nothing to do for this shard"); return 0; }
+        if (input.empty()) { fputs("error: --rccl-id: this shard has no input file, the other shards would wait for it (fewer files than shards)\n", stderr); return 2; }
+        if (!k.rccl_id.empty()) shard_rendezvous_reset(k.rccl_id, k.shard_rank);
         try {
             printf("Kit name: %s\nKit type: %s\n", k.kit_name.c_str(), k.maximize ? "Maximize" : "Safe");
             const AnnotateStats st = demux_using_kit(input, k);
@@ -199,6 +205,7 @@ int main(int argc, char** argv) {
         else if (a == "--gpu-render") { cfg.host_cut = false; multi = nullptr; }
         else if (a == "--policy") { if (!set_policy(need("--policy"))) return 2; multi = nullptr; }
         else if (a == "--shard") { shard = need("--shard"); multi = nullptr; }
+        else if (a == "--rccl-id") { cfg.rccl_id = need("--rccl-id"); multi = nullptr; }
         else if (a == "-f" || a == "--filter-file") { multi = &pattern_files; }
         else if (a == "--filtered") { cfg.filtered_file = need("--filtered"); multi = nullptr; }
         else if (a == "--dropped") { cfg.dropped_file = need("--dropped"); multi = nullptr; }
@@ -230,8 +237,10 @@ int main(int argc, char** argv) {
         else { fprintf(stderr, "error: unexpected argument '%s'\n", a.c_str()); usage(); return 2; }
     }
     if (input.empty()) { fputs("error: No FASTQ input files provided\n", stderr); return 2; }
-    if (!apply_shard(shard, input)) { fputs("error: --shard takes R/W with 0 <= R < W\n", stderr); return 2; }
-    if (input.empty()) { fputs("Nothing to do for this shard\n", stderr); return 0; }
+    if (!apply_shard(shard, input, cfg.shard_rank, cfg.shard_world)) { fputs("error: --shard takes R/W with 0 <= R < W\n", stderr); return 2; }
+    if (input.empty() && cfg.rccl_id.empty()) { fputs("Nothing to do for this shard\n", stderr); return 0; }
+    if (input.empty()) { fputs("error: --rccl-id: this shard has no input file, the other shards would wait for it (fewer files than shards)\n", stderr); return 2; }
+    if (!cfg.rccl_id.empty()) shard_rendezvous_reset(cfg.rccl_id, cfg.shard_rank);
     if (kit.empty() == queries.empty()) { fputs("error: give either --kit or --queries (they conflict, bin/main.rs:85-87)\n", stderr); return 2; }
     if (kit_filter && kit.empty()) { fputs("error: --kit-filter needs --kit\n", stderr); return 2; }
     if (!cfg.trim_folder.empty()) {

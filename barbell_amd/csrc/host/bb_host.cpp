@@ -1568,6 +1568,8 @@ struct BlockResult {
 // bb_rccl.cpp: sums the per-context histograms.  Contexts on distinct devices are all-reduced with RCCL over xGMI
 // (ncclAllReduce, uint64 sum, in place on bb_counts_dev); contexts that share a device are first summed on the host.
 std::vector<uint64_t> allreduce_counts(const std::vector<Demuxer*>& dms, std::string& how);
+std::vector<uint64_t> allreduce_counts_shards(Demuxer* lead, const std::vector<uint64_t>& local, uint32_t rank, uint32_t world,
+                                              const std::string& base, std::string& how);
 
 AnnotateStats annotate(const std::vector<std::string>& read_files, const std::string& out_file,
                        std::vector<BarcodeGroup> query_groups, const AnnotateConfig& config) {
@@ -1869,10 +1871,20 @@ AnnotateStats annotate(const std::vector<std::string>& read_files, const std::st
     {
         std::vector<Demuxer*> ptrs;
         for (auto& d : dms) ptrs.push_back(d.get());
-        const std::vector<uint64_t> total = allreduce_counts(ptrs, st.counts_reduce);
+        std::vector<uint64_t> total = allreduce_counts(ptrs, st.counts_reduce);
+        bool counts_mine = true;   // does this process write counts_file?
+        if (!config.rccl_id.empty()) {
+            std::string how;
+            total = allreduce_counts_shards(ptrs[0], total, config.shard_rank, config.shard_world, config.rccl_id, how);
+            st.counts_reduce += " + " + how;
+            counts_mine = config.shard_rank == 0;
+        } else if (config.shard_world > 1) {
+            fprintf(stderr, "warning: --shard %u/%u without --rccl-id: the counts are this process's own, not the run's (give every shard the same --rccl-id PATH "
+                            "for one all-reduced histogram)\n", config.shard_rank, config.shard_world);
+        }
         const std::vector<std::string> labels = dms[0]->slot_labels();
         for (size_t i = 0; i < total.size(); ++i) st.counts.emplace_back(labels[i], total[i]);
-        if (!config.counts_file.empty()) {
+        if (!config.counts_file.empty() && counts_mine) {
             FILE* cf = fopen(config.counts_file.c_str(), "w");
             if (!cf) throw BarbellError(BB_E_INVALID, "Failed to create counts file '" + config.counts_file + "'");
             size_t gi = 0, left = dms[0]->queries().empty() ? 0 : dms[0]->queries()[0].labels.size() + 1;
@@ -1923,6 +1935,7 @@ AnnotateStats demux_using_kit(const std::vector<std::string>& fastq_files, const
     c.max_flank_errors = k.max_flank_errors; c.alpha = k.alpha; c.n_threads = (unsigned)k.threads; c.verbose = k.verbose;
     c.min_score = k.min_score; c.min_score_diff = k.min_score_diff; c.use_extended = k.use_extended;
     c.batch_reads = k.batch_reads; c.device = k.device; c.devices = k.devices; c.streams_per_device = k.streams_per_device; c.counts_file = k.counts_file;
+    c.shard_rank = k.shard_rank; c.shard_world = k.shard_world; c.rccl_id = k.rccl_id;
     c.filter_patterns = kit_patterns(k.kit_name, k.maximize);
     c.filtered_file = k.output_folder + "/filtered.tsv";
     c.trim = TrimConfig::for_kit(k.failed_out, k.gzip);

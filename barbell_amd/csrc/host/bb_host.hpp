@@ -243,6 +243,11 @@ struct AnnotateConfig {  // config.rs:3-12 with the CLI defaults of bin/main.rs:
     std::vector<int> devices;
     unsigned streams_per_device = 2;
     std::string counts_file;              // label <TAB> count of the all-reduced histogram
+    // one process per GPU (`--shard R/W`): with rccl_id set, the W processes all-reduce their histograms (ncclCommInitRank, the unique id
+    // published through files next to rccl_id; through the files alone where processes share a device) and shard 0 writes counts_file;
+    // without it every process keeps its own counts (a warning says so)
+    uint32_t shard_rank = 0, shard_world = 1;
+    std::string rccl_id;
     // fused filter step: when filter_patterns is non-empty, rows of passing / failing reads go to
     // filtered_file / dropped_file with their cuts column (what `barbell filter -o/--dropped` writes)
     std::vector<Pattern> filter_patterns;
@@ -265,6 +270,7 @@ struct AnnotateStats {
     std::string counts_reduce;                              // "rccl" | "host" | "single": how the histogram was summed
     double seconds_pipeline = 0;                            // first block read .. last block committed (steady state, no start-up)
 };
+void shard_rendezvous_reset(const std::string& rccl_id, uint32_t rank);   // bb_rccl.cpp; call at program start of a --shard R/W --rccl-id run
 std::vector<std::string> inspect_summary(const AnnotateStats& st, size_t top_n);  // the lines of inspect.rs:186-205
 
 struct KitConfig {  // config.rs:34-48, CLI defaults bin/main.rs:208-262
@@ -283,6 +289,8 @@ struct KitConfig {  // config.rs:34-48, CLI defaults bin/main.rs:208-262
     std::vector<int> devices;
     unsigned streams_per_device = 2;
     std::string counts_file;
+    uint32_t shard_rank = 0, shard_world = 1;   // AnnotateConfig::shard_rank / shard_world / rccl_id
+    std::string rccl_id;
     bool process_exits_after = false;   // AnnotateConfig::process_exits_after
 };
 AnnotateStats demux_using_kit(const std::vector<std::string>& fastq_files, const KitConfig& config);  // use_kit.rs:11-109

@@ -2,14 +2,24 @@
 // contexts of a run.  Contexts on DISTINCT devices are all-reduced in place with RCCL over xGMI
 // (ncclAllReduce, ncclUint64, ncclSum on bb_counts_dev, one communicator per device, single process); contexts that
 // share a device are summed on the host first (RCCL cannot put two ranks on one GPU).  No torch, no MPI.
+// One process per GPU (`--shard R/W --rccl-id PATH`, the mode DESIGN §6 recommends past two GPUs): the W processes meet through small files
+// next to PATH, bootstrap one communicator with ncclCommInitRank (rank 0 publishes the ncclUniqueId) and all-reduce the same buffer; processes
+// that share a device (a one-GPU box) are summed through the same files instead — every rank ends with the total (annotator.rs:278-280 is the
+// fan-out this replaces: paraseq's worker threads share ONE process, so the reference never needs this step).
 // librccl.so is bound at the first all-reduce (dlopen), not at program start: it is a 570 MB library, and a run on one device — most
 // runs — never calls it (mapping and relocating it was a fifth of a second of every start-up).
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <unistd.h>
+
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <map>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -20,6 +30,8 @@ namespace barbell {
 namespace {
 struct Rccl {
     decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
     decltype(&ncclGroupStart) GroupStart = nullptr;
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclAllReduce) AllReduce = nullptr;
@@ -35,11 +47,15 @@ const Rccl& rccl() {
         if (!h) throw BarbellError(BB_E_HIP, std::string("librccl.so not found (contexts on several devices need RCCL): ") + dlerror());
         auto sym = [&](const char* s) { void* p = dlsym(h, s); if (!p) throw BarbellError(BB_E_HIP, std::string("librccl.so lacks ") + s); return p; };
         r.CommInitAll = (decltype(r.CommInitAll))sym("ncclCommInitAll");
+        r.CommInitRank = (decltype(r.CommInitRank))sym("ncclCommInitRank");
+        r.GetUniqueId = (decltype(r.GetUniqueId))sym("ncclGetUniqueId");
         r.GroupStart = (decltype(r.GroupStart))sym("ncclGroupStart");
         r.GroupEnd = (decltype(r.GroupEnd))sym("ncclGroupEnd");
         r.AllReduce = (decltype(r.AllReduce))sym("ncclAllReduce");
         r.CommDestroy = (decltype(r.CommDestroy))sym("ncclCommDestroy");
         r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
+        Dl_info di;
+        fprintf(stderr, "librccl.so bound: %s\n", dladdr((void*)r.AllReduce, &di) && di.dli_fname ? di.dli_fname : "?");
         return r;
     }();
     return R;
@@ -94,6 +110,107 @@ std::vector<uint64_t> allreduce_counts(const std::vector<Demuxer*>& dms, std::st
     for (auto& c : comms) (void)rccl().CommDestroy(c);
     how = "rccl";
     return leaders[0]->counts();
+}
+
+
+// ---- one process per GPU: the histogram over the W processes of a `--shard R/W` run --------------------------------------------------
+namespace {
+double rendezvous_timeout_s() { const char* e = getenv("BARBELL_AMD_RCCL_TIMEOUT"); return e && atof(e) > 0 ? atof(e) : 600.0; }
+// whole-file write made visible atomically (tmp + rename): a reader never sees half a file
+void publish(const std::string& path, const void* data, size_t bytes) {
+    const std::string tmp = path + ".tmp" + std::to_string((long)getpid());
+    FILE* f = fopen(tmp.c_str(), "wb");
+    if (!f || fwrite(data, 1, bytes, f) != bytes || fclose(f) != 0) throw BarbellError(BB_E_INVALID, "--rccl-id: cannot write '" + tmp + "'");
+    if (rename(tmp.c_str(), path.c_str()) != 0) throw BarbellError(BB_E_INVALID, "--rccl-id: cannot publish '" + path + "'");
+}
+std::vector<char> await_file(const std::string& path, size_t bytes) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        if (FILE* f = fopen(path.c_str(), "rb")) {
+            std::vector<char> buf(bytes);
+            const size_t got = fread(buf.data(), 1, bytes, f);
+            fclose(f);
+            if (got == bytes) return buf;
+            throw BarbellError(BB_E_INVALID, "--rccl-id: '" + path + "' has " + std::to_string(got) + " bytes, expected " + std::to_string(bytes) +
+                                                 " (a stale file of another run? use a fresh path per run)");
+        }
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > rendezvous_timeout_s())
+            throw BarbellError(BB_E_INVALID, "--rccl-id: timed out waiting for '" + path + "' (is every shard of the run started with the same --rccl-id?)");
+        std::this_thread::sleep_for(std::chrono::milliseconds(2));
+    }
+}
+struct ShardInfo { char bus[64]; uint64_t n_counts; uint32_t world, rank; };
+}  // namespace
+
+// at program start: what an earlier, interrupted run of this rank left behind must not be read as this run's (use a fresh PATH per run anyway)
+void shard_rendezvous_reset(const std::string& base, uint32_t rank) {
+    for (const char* w : {"info", "counts", "done"}) (void)unlink((base + ".r" + std::to_string(rank) + "." + w).c_str());
+    if (rank == 0) (void)unlink((base + ".id").c_str());
+}
+
+std::vector<uint64_t> allreduce_counts_shards(Demuxer* lead, const std::vector<uint64_t>& local, uint32_t rank, uint32_t world,
+                                              const std::string& base, std::string& how) {
+    const size_t n = local.size();
+    auto part = [&](uint32_t r, const char* what) { return base + ".r" + std::to_string(r) + "." + what; };
+    ShardInfo me;
+    memset(&me, 0, sizeof(me));
+    HCHK(hipDeviceGetPCIBusId(me.bus, (int)sizeof(me.bus), lead->device()));
+    char host[40] = "";
+    (void)gethostname(host, sizeof(host) - 1);
+    const size_t bl = strlen(me.bus);
+    snprintf(me.bus + bl, sizeof(me.bus) - bl, "@%s", host);   // RCCL's duplicate-GPU rule is per (host, device)
+    me.n_counts = n; me.world = world; me.rank = rank;
+    publish(part(rank, "info"), &me, sizeof(me));
+    bool shared_device = false;
+    std::vector<ShardInfo> all(world);
+    for (uint32_t r = 0; r < world; ++r) {
+        const std::vector<char> b = await_file(part(r, "info"), sizeof(ShardInfo));
+        memcpy(&all[r], b.data(), sizeof(ShardInfo));
+        if (all[r].n_counts != n || all[r].world != world || all[r].rank != r)
+            throw BarbellError(BB_E_INVALID, "--rccl-id: shard " + std::to_string(r) + " runs other queries or another --shard W (histogram of " +
+                                                 std::to_string(all[r].n_counts) + " slots, W = " + std::to_string(all[r].world) + ")");
+        for (uint32_t q = 0; q < r; ++q) shared_device |= !strcmp(all[q].bus, all[r].bus);
+    }
+    std::vector<uint64_t> total(n, 0);
+    if (shared_device) {
+        // two ranks of one communicator cannot sit on one GPU: sum through the files (every rank reads every rank's counts)
+        publish(part(rank, "counts"), local.data(), n * sizeof(uint64_t));
+        for (uint32_t r = 0; r < world; ++r) {
+            const std::vector<char> b = await_file(part(r, "counts"), n * sizeof(uint64_t));
+            const uint64_t* c = (const uint64_t*)b.data();
+            for (size_t i = 0; i < n; ++i) total[i] += c[i];
+        }
+        how = "files (" + std::to_string(world) + " processes share a device)";
+    } else {
+        ncclUniqueId id;
+        if (rank == 0) {
+            RCHK(rccl().GetUniqueId(&id));
+            publish(base + ".id", &id, sizeof(id));
+        } else {
+            const std::vector<char> b = await_file(base + ".id", sizeof(id));
+            memcpy(&id, b.data(), sizeof(id));
+        }
+        HCHK(hipSetDevice(lead->device()));
+        uint64_t* p = bb_counts_dev(lead->ctx());
+        const int rc = bb_dev_upload(lead->ctx(), p, local.data(), n * sizeof(uint64_t));   // this process's sum over its contexts
+        if (rc != BB_OK) throw BarbellError(rc, "bb_dev_upload (histogram)");
+        ncclComm_t comm;
+        RCHK(rccl().CommInitRank(&comm, (int)world, id, (int)rank));
+        RCHK(rccl().AllReduce(p, p, n, ncclUint64, ncclSum, comm, (hipStream_t)0));
+        HCHK(hipDeviceSynchronize());
+        (void)rccl().CommDestroy(comm);
+        total = lead->counts();
+        how = "rccl (" + std::to_string(world) + " processes, ncclCommInitRank)";
+    }
+    // rank 0 removes the rendezvous files once every rank has read what it needs
+    publish(part(rank, "done"), "1", 1);
+    if (rank == 0) {
+        for (uint32_t r = 0; r < world; ++r) (void)await_file(part(r, "done"), 1);
+        for (uint32_t r = 0; r < world; ++r)
+            for (const char* w : {"info", "counts", "done"}) (void)unlink(part(r, w).c_str());
+        (void)unlink((base + ".id").c_str());
+    }
+    return total;
 }
 
 }  // namespace barbell

@@ -53,6 +53,9 @@ def main():
                     help="torch.distributed backend for N>1 (nccl = RCCL over xGMI; gloo only for single-GPU dry runs)")
     ap.add_argument("--device-mod", type=int, default=0,
                     help="dry-run aid: map LOCAL_RANK onto LOCAL_RANK %% device-mod GPUs (0 = one GPU per rank)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="run the N>1 statements (init_process_group, barrier, all_reduce of the histogram and of the time) at world size 1 too: "
+                         "the RCCL branch executes on a one-GPU box")
     ap.add_argument("--print-histogram", action="store_true", help="carry the all-reduced per-barcode histogram in the JSON line")
     ap.add_argument("--first-read", type=int, default=0,
                     help="index of rank 0's first read in the synthetic stream (tests: a one-rank run of another rank's shard)")
@@ -77,19 +80,28 @@ def main():
                  f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...)")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if world == 1 and "MASTER_PORT" not in os.environ:      # --force-dist started as plain `python bench.py`: a rendezvous of one
+            import socket
+
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
     dev_idx = local_rank % args.device_mod if args.device_mod > 0 else local_rank
     torch.cuda.set_device(dev_idx)
     dev = torch.device("cuda", dev_idx)
     cdev = dev if args.backend == "nccl" else torch.device("cpu")  # where collective tensors live
-    if world > 1:
+    if use_dist:
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group("gloo")
-        assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
+        assert dist.get_world_size() == max(1, args.gpus), (dist.get_world_size(), args.gpus)
 
     from barbell_amd import annotate as A
     from tests.common import config_groups
@@ -125,7 +137,7 @@ def main():
     dm.counts_reset()
     dm.set_timing(True)
     kms, dom_launch = {}, {}
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -138,14 +150,14 @@ def main():
         dk_name, dk_ms = dm.dominant_kernel()
         dom_launch[dk_name] = dom_launch.get(dk_name, 0.0) + dk_ms
     hist = torch.from_numpy(dm.counts().astype(np.int64)).to(cdev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(hist)  # RCCL over xGMI: the only collective of the path
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     t1 = time.perf_counter()
     el = torch.tensor([t1 - t0], dtype=torch.float64, device=cdev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
     reads_done = args.steps * batch * world
@@ -186,6 +198,9 @@ def main():
             "compute": compute_section(args, kavg, cells_flank, batch, L),
             "histogram_total": int(hist.sum().item()),
         }
+        if use_dist:
+            out["dist"] = {"backend": dist.get_backend(), "world": dist.get_world_size(), "forced_at_world_1": bool(args.force_dist and world == 1),
+                           "collectives": ["barrier", "all_reduce(histogram, sum)", "all_reduce(elapsed, max)"]}
         if args.print_histogram:
             out["histogram"] = [int(x) for x in hist.cpu().tolist()]
         if args.config == "nbd96":
@@ -212,7 +227,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = _guarded(cpu_baseline, args, groups, dm, d_bases, L, batch, (args.steps - 1) % n_batches, d_rows, last_rows)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -768,6 +768,23 @@ static void push_flank_only(row_list* rows, uint32_t read_idx, uint32_t read_len
     row_push(rows, &r);
 }
 
+/* Diagnostics for tools/policy_feasible.py: the reference's own invariants on this path, COUNTED instead of aborting — a policy setting
+ * under which real Barbell would panic (searcher.rs:388 expect, the slice at :456) or put the barcode window off the barcode of its own
+ * documented examples cannot be what the real crates do.  Off (NULL) in every other entry point. */
+static __thread bbo_diag* t_diag = NULL;
+static __thread const int32_t* t_truth = NULL;   /* BBO_TRUTH_PER_READ x BBO_TRUTH_FIELDS int32 of the read in hand */
+/* the planted construct (same group and strand) a flank match lies on: at least half of the construct's span is inside the match */
+static const int32_t* diag_on_target(uint32_t gi, const bbo_match* fm) {
+    if (!t_truth) return NULL;
+    for (int t = 0; t < BBO_TRUTH_PER_READ; ++t) {
+        const int32_t* tr = t_truth + t * BBO_TRUTH_FIELDS;   /* group, strand, construct_lo, construct_hi, bar_lo, bar_hi, barcode idx */
+        if (tr[0] != (int32_t)gi || tr[1] != fm->strand) continue;
+        const int lo = fm->text_start > tr[2] ? fm->text_start : tr[2], hi = fm->text_end < tr[3] ? fm->text_end : tr[3];
+        if (2 * (hi - lo) >= tr[3] - tr[2]) return tr;
+    }
+    return NULL;
+}
+
 /* Demuxer::demux (searcher.rs:430-490) for one read; rows appended to `rows` (already collapsed) */
 static void demux_read(const bbo_ctx* c, uint32_t read_idx, const uint8_t* read, uint32_t n, row_list* rows, int fast) {
     int first_row = rows->n;
@@ -778,13 +795,20 @@ static void demux_read(const bbo_ctx* c, uint32_t read_idx, const uint8_t* read,
         bbo_match* fms = NULL;
         int nfm = fast && g->W64 <= BBO_MAXW64 ? search_fast(&c->pol, g, rcode, (int)n, c->p.alpha, &fms)
                                                  : search_pol(&c->pol, g->flank, (int)g->flank_len, read, (int)n, g->flank_k, c->p.alpha, 1, &fms); /* :438 */
+        if (t_diag) t_diag->flank_matches += (uint64_t)nfm;
         for (int f = 0; f < nfm; ++f) {                                               /* :440 */
             const bbo_match* fm = &fms[f];
             int lo, hi;
-            if (!bbo_get_matching_region(fm, (int)g->bar_lo, (int)g->bar_hi, &lo, &hi)) continue; /* :445-449 */
+            const int32_t* on = t_diag ? diag_on_target(gi, fm) : NULL;
+            if (on) t_diag->on_target++;
+            if (!bbo_get_matching_region(fm, (int)g->bar_lo, (int)g->bar_hi, &lo, &hi)) { if (t_diag) t_diag->region_none++; continue; } /* :445-449 */
             uint32_t ws = lo >= PADDING ? (uint32_t)(lo - PADDING) : 0;                /* :453 */
             uint32_t we = (uint32_t)(hi + PADDING) < n ? (uint32_t)(hi + PADDING) : n; /* :454 */
-            if (we < ws) we = ws; /* the reference would panic on the slice; cannot happen for lo <= n */
+            if (we < ws) { we = ws; if (t_diag) t_diag->slice_panic++; } /* the reference would panic on the slice; cannot happen for lo <= n */
+            if (on) {
+                t_diag->window_overlaps += (int32_t)ws < on[5] && (int32_t)we > on[4];
+                t_diag->window_covers += (int32_t)ws <= on[4] && (int32_t)we >= on[5];
+            }
             const uint8_t* wcode = rcode + ws; int wn = (int)(we - ws);
             const uint8_t* pats = fm->strand == BB_FWD ? g->pat_fwd : g->pat_rc;       /* barcodes.rs:97-102 */
             int m = (int)g->m_bar;
@@ -828,11 +852,14 @@ static void demux_read(const bbo_ctx* c, uint32_t read_idx, const uint8_t* read,
                 }
                 int rel_lo = (int)(g->bar_lo - g->pad_lo), rel_hi = (int)(g->bar_hi - g->pad_lo); /* :379-382 */
                 int pl, ph, tl, th, bc;
+                int panicked = 0;
                 if (!bbo_map_pat_to_text_with_cost(&best[top], rel_lo, rel_hi, &pl, &ph, &tl, &th, &bc)) {
-                    fprintf(stderr, "bb_oracle: No barcode match region found; unusual\n"); abort(); /* :388 */
+                    if (!t_diag) { fprintf(stderr, "bb_oracle: No barcode match region found; unusual\n"); abort(); } /* :388 */
+                    t_diag->subpath_none++; panicked = 1;
                 }
-                int valid = top_s >= c->p.min_score;                                   /* :391-396 */
+                int valid = !panicked && top_s >= c->p.min_score;                      /* :391-396 */
                 if (second >= 0) valid = valid && (top_s - second_s) >= c->p.min_score_diff;
+                if (valid && on) { t_diag->tag_rows_on_target++; t_diag->tag_rows_correct += top == on[6]; }
                 if (valid) {                                                           /* :398-416 */
                     bb_row r; memset(&r, 0, sizeof(r));
                     r.read_idx = read_idx; r.read_len = n;
@@ -892,6 +919,41 @@ static int annotate_batch_impl(bbo_ctx* c, const uint8_t* bases, const uint64_t*
     for (uint32_t i = 0; i < n_reads; ++i) free(per[i].v);
     free(per);
     return rcode;
+}
+
+/* the same per-read procedure with the invariants counted (tools/policy_feasible.py); rows are discarded */
+int bbo_annotate_diag(bbo_ctx* c, const uint8_t* bases, const uint64_t* offsets, uint32_t n_reads, const int32_t* truth, int n_threads, int fast,
+                      bbo_diag* out) {
+    if (!c || (!bases && n_reads) || !offsets || !out) return BB_E_INVALID;
+    memset(out, 0, sizeof(*out));
+#ifdef _OPENMP
+    if (n_threads < 1) n_threads = 1;
+#pragma omp parallel num_threads(n_threads)
+#endif
+    {
+        bbo_diag mine; memset(&mine, 0, sizeof(mine));
+        t_diag = &mine;
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 16)
+#endif
+        for (long i = 0; i < (long)n_reads; ++i) {
+            row_list rl; memset(&rl, 0, sizeof(rl));
+            t_truth = truth ? truth + (size_t)i * BBO_TRUTH_PER_READ * BBO_TRUTH_FIELDS : NULL;
+            demux_read(c, (uint32_t)i, bases + offsets[i], (uint32_t)(offsets[i + 1] - offsets[i]), &rl, fast);
+            mine.rows += (uint64_t)rl.n;
+            free(rl.v);
+        }
+        t_diag = NULL; t_truth = NULL;
+#ifdef _OPENMP
+#pragma omp critical
+#endif
+        {
+            const uint64_t* a = (const uint64_t*)&mine; uint64_t* o = (uint64_t*)out;
+            for (size_t k = 0; k < sizeof(bbo_diag) / sizeof(uint64_t); ++k) o[k] += a[k];
+        }
+    }
+    (void)n_threads;
+    return BB_OK;
 }
 
 /* ------------------------------------------------------------------------------------------ */

@@ -87,6 +87,26 @@ int  bbo_annotate_batch(bbo_ctx* ctx, const uint8_t* bases, const uint64_t* offs
  * compare the GPU with bbo_annotate_batch, and tests/test_oracle_fast.py compares this function with it. */
 int  bbo_annotate_batch_fast(bbo_ctx* ctx, const uint8_t* bases, const uint64_t* offsets, uint32_t n_reads,
                              bb_row* rows, uint64_t rows_cap, uint64_t* n_rows, int n_threads);
+
+/* tools/policy_feasible.py: the same per-read procedure with the reference's own invariants COUNTED instead of aborting, and the barcode
+ * windows compared with where the constructs were planted.  truth: per read BBO_TRUTH_PER_READ records of BBO_TRUTH_FIELDS int32 —
+ * group, strand, construct_lo, construct_hi, bar_lo, bar_hi (text coordinates, hi exclusive), barcode idx; group = -1: none. */
+#define BBO_TRUTH_PER_READ 2
+#define BBO_TRUTH_FIELDS   7
+typedef struct {
+    uint64_t flank_matches;       /* matches the flank search returned (searcher.rs:438)                                  */
+    uint64_t region_none;         /* get_matching_region -> None (searcher.rs:445-449: the reference skips the match)      */
+    uint64_t slice_panic;         /* window start beyond its end: `read[ws..we]` would panic (searcher.rs:456)             */
+    uint64_t subpath_none;        /* map_pat_to_text_with_cost -> None: expect("No barcode match region found") (:388)    */
+    uint64_t on_target;           /* flank matches lying on a planted construct of their group and strand                  */
+    uint64_t window_overlaps;     /* ... whose barcode window overlaps the planted barcode                                 */
+    uint64_t window_covers;       /* ... whose barcode window contains it                                                  */
+    uint64_t tag_rows_on_target;  /* ... that became a tag row (before collapse)                                           */
+    uint64_t tag_rows_correct;    /* ... with the planted barcode                                                          */
+    uint64_t rows;                /* rows after collapse                                                                   */
+} bbo_diag;
+int  bbo_annotate_diag(bbo_ctx* ctx, const uint8_t* bases, const uint64_t* offsets, uint32_t n_reads, const int32_t* truth, int n_threads,
+                       int fast, bbo_diag* out);
 /* filter step on a row stream (filter.rs:183-214 check_filter_pass, pattern.rs:96-240 match_pattern);
  * rows grouped by consecutive read_idx like the reference groups by consecutive read_id (filter.rs:54-85) */
 int  bbo_filter_rows(const bbo_ctx* ctx, const bb_pattern* patterns, uint32_t n_patterns, const uint32_t* label_ids,

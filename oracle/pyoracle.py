@@ -35,6 +35,13 @@ class Pos(C.Structure):
     _fields_ = [("i", C.c_int32), ("j", C.c_int32)]
 
 
+class Diag(C.Structure):
+    """bbo_diag (oracle/bb_oracle.h): the reference's invariants on the path, counted (tools/policy_feasible.py)"""
+    _fields_ = [(k, C.c_uint64) for k in ("flank_matches", "region_none", "slice_panic", "subpath_none", "on_target", "window_overlaps",
+                                           "window_covers", "tag_rows_on_target", "tag_rows_correct", "rows")]
+TRUTH_PER_READ, TRUTH_FIELDS = 2, 7
+
+
 _lib = None
 
 
@@ -68,6 +75,7 @@ def lib():
         L.bbo_annotate_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64,
                                          C.POINTER(C.c_uint64), C.c_int]
         L.bbo_annotate_batch_fast.argtypes = L.bbo_annotate_batch.argtypes
+        L.bbo_annotate_diag.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_int, C.c_int, C.POINTER(Diag)]
         L.bbo_set_full_trace.argtypes = [C.c_int]
         L.bbo_filter_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
         L.bbo_trim_batch.argtypes = [C.c_void_p] * 7 + [C.c_uint64] + [C.c_void_p] * 4 + [C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p,
@@ -240,6 +248,21 @@ class Oracle:
                 continue
             assert rc == 0, rc
             return rows[: nr.value]
+
+    def annotate_diag(self, bases, offsets, truth=None, n_threads=1, fast=True):
+        """the per-read procedure with the reference's invariants counted instead of aborting -> dict of bbo_diag's counters;
+        truth: int32[n_reads, TRUTH_PER_READ, TRUTH_FIELDS] (group, strand, construct lo / hi, barcode lo / hi, barcode idx; group -1 = none)"""
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = len(offsets) - 1
+        if truth is not None:
+            truth = np.ascontiguousarray(truth, dtype=np.int32)
+            assert truth.shape == (n, TRUTH_PER_READ, TRUTH_FIELDS), truth.shape
+        d = Diag()
+        rc = lib().bbo_annotate_diag(self.h, bases.ctypes.data, offsets.ctypes.data, n, None if truth is None else truth.ctypes.data,
+                                     n_threads, int(fast), C.byref(d))
+        assert rc == 0, rc
+        return {k: int(getattr(d, k)) for k, _ in Diag._fields_}
 
     def annotate_reads(self, reads, n_threads=1):
         return self.annotate(*_abi.pack_reads(reads), n_threads=n_threads)

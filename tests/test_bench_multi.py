@@ -42,6 +42,18 @@ def test_gpus_2_starts_two_ranks(backend):
     assert abs(two["value"] * two["ms_per_step"] * 1e-3 * two["steps"] - 2 * 2 * 100000) < 1.0
 
 
+@pytest.mark.gpu
+def test_rccl_branch_runs_at_world_size_one():
+    """`--force-dist`: the exact statements of the N>1 branch — init_process_group("nccl", device_id=dev), barrier, all_reduce of the
+    histogram (sum) and of the elapsed time (max), destroy — on the one visible GPU: RCCL (librccl through torch's nccl backend) is
+    initialised and runs a collective; the histogram is the plain single-process one."""
+    forced = _bench(["--gpus", "1", "--force-dist"], {"HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    plain = _bench(["--gpus", "1"])
+    assert forced["dist"]["backend"] == "nccl" and forced["dist"]["world"] == 1 and forced["dist"]["forced_at_world_1"]
+    assert "dist" not in plain
+    assert forced["histogram"] == plain["histogram"] and forced["histogram_total"] > 0
+
+
 def test_gpus_mismatch_is_refused():
     """A launcher that sets WORLD_SIZE but passes another --gpus must not produce a line that says n_gpus: 1."""
     env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")

@@ -370,6 +370,7 @@ def test_one_stream_over_several_contexts(tmp_path):
             files["trim/" + f] = (d / "trim" / f).read_bytes()
         outs[name] = (files, r.stderr)
     assert "histogram summed by single" in outs["one"][1] and "summed by host" in outs["three"][1] and "summed by rccl" in outs["rccl1"][1]
+    assert "librccl.so bound" in outs["rccl1"][1] and "librccl.so bound" not in outs["one"][1]      # the library was really mapped, and only then
     for name in ("three", "default", "rccl1"):
         assert outs[name][0].keys() == outs["one"][0].keys()
         for k in outs["one"][0]:
@@ -381,6 +382,70 @@ def test_one_stream_over_several_contexts(tmp_path):
     got = {l.split("\t")[1]: int(l.split("\t")[2]) for l in outs["one"][0]["c"].decode().splitlines()}
     assert sum(got.values()) == len(rows) and all(got[k] == v for k, v in want.items())
     assert len(outs["one"][0]) > 20  # many per-barcode files
+
+
+@pytest.mark.gpu
+def test_shards_one_process_per_gpu_reduce_their_histograms(tmp_path):
+    """`--shard R/W --rccl-id PATH` (one process per GPU; annotator.rs:278-280 is the fan-out it replaces; north_star: "RCCL ...
+    for the final per-barcode count reduction"): the W processes all-reduce their histograms and shard 0 writes ONE counts file equal to
+    the single-process run's.  On the one-GPU box the two processes share device 0, where one communicator cannot hold both ranks: they are
+    summed through the rendezvous files; `--shard 0/1 --rccl-id` is the same code with W = 1 and goes through ncclGetUniqueId /
+    ncclCommInitRank / ncclAllReduce of librccl.so itself (checked in the process's own map, BARBELL_AMD_PROFILE)."""
+    import subprocess as sp
+
+    from barbell_amd import annotate as A
+
+    groups = kits.groups_from_kit("SQK-NBD114-96", flank_max_errors=3)
+    n = 4000
+    bases, offsets = A.synth_reads_host(groups, 123, 500, 3000, 0, n)
+    ids = [f"r{i}" for i in range(n)]
+    fqs = []
+    for part in range(2):
+        fq = tmp_path / f"reads{part}.fastq"
+        lo, hi = part * n // 2, (part + 1) * n // 2
+        write_fastq(fq, ids[lo:hi], bases[int(offsets[lo]):int(offsets[hi])], offsets[lo:hi + 1] - offsets[lo])
+        fqs.append(str(fq))
+    env = dict(os.environ, BARBELL_AMD_NO_TORCH="1", BARBELL_AMD_RCCL_TIMEOUT="120", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    common = ["--kit", "SQK-NBD114-96", "--flank-max-errors", "3", "--device", "0"]
+
+    def run(name, extra):
+        d = tmp_path / name
+        d.mkdir(exist_ok=True)
+        return sp.Popen([CLI, "annotate", "-i"] + fqs + ["-o", str(d / "a.tsv"), "--counts", str(d / "counts.tsv")] + common + extra,
+                        stdout=sp.PIPE, stderr=sp.PIPE, text=True, env=env), d
+
+    p, d_one = run("one", [])
+    _, err = p.communicate(timeout=600)
+    assert p.returncode == 0, err
+    want = (d_one / "counts.tsv").read_bytes()
+    assert sum(int(l.split(b"\t")[2]) for l in want.splitlines()) > n // 2
+    # two processes, one per shard, both on GPU 0, started together
+    rid = str(tmp_path / "rendezvous")
+    procs = [run(f"shard{r}", ["--shard", f"{r}/2", "--rccl-id", rid]) for r in range(2)]
+    errs = []
+    for p, _ in procs:
+        _, err = p.communicate(timeout=600)
+        assert p.returncode == 0, err
+        errs.append(err)
+    assert (procs[0][1] / "counts.tsv").read_bytes() == want              # ONE counts file, the run's
+    assert not (procs[1][1] / "counts.tsv").exists()
+    assert all("2 processes share a device" in e for e in errs), errs
+    assert (procs[0][1] / "a.tsv").read_bytes() + b"".join((procs[1][1] / "a.tsv").read_bytes().splitlines(keepends=True)[1:]) == (d_one / "a.tsv").read_bytes()
+    assert not [f for f in os.listdir(tmp_path) if f.startswith("rendezvous")]    # shard 0 cleaned the rendezvous files up
+    # without --rccl-id each process keeps its own counts and says so
+    p, d = run("alone", ["--shard", "0/2"])
+    _, err = p.communicate(timeout=600)
+    assert p.returncode == 0 and "without --rccl-id" in err and (d / "counts.tsv").read_bytes() != want
+    # W = 1: the RCCL bootstrap and collective themselves
+    p, d = run("w1", ["--shard", "0/1", "--rccl-id", str(tmp_path / "rv1")])
+    _, err = p.communicate(timeout=600)
+    assert p.returncode == 0, err
+    assert "rccl (1 processes, ncclCommInitRank)" in err and (d / "counts.tsv").read_bytes() == want
+    # a shard whose peers never come gives up with a message instead of hanging
+    env["BARBELL_AMD_RCCL_TIMEOUT"] = "3"
+    p, d = run("lonely", ["--shard", "0/2", "--rccl-id", str(tmp_path / "rv2")])
+    _, err = p.communicate(timeout=600)
+    assert p.returncode == 1 and "timed out waiting" in err
 
 
 @pytest.mark.gpu
