@@ -58,6 +58,12 @@ class DevBuf:
         self.ptr, self.cap = None, 0
 
 
+def build_trace_classes():
+    """indices (barbell_amd/csrc/bb_prio.h order) of the traceback-order classes this build holds fast barcode kernels for"""
+    m = lib().bb_build_trace_classes()
+    return [i for i in range(18) if (m >> i) & 1]
+
+
 class Demuxer:
     """Demuxer::new(alpha, verbose, min_score_frac, min_score_diff_frac) (searcher.rs:202)."""
 
@@ -93,6 +99,10 @@ class Demuxer:
                 raise BarbellError(rc, L.bb_last_error(None).decode())
             self._h = h
         return self._h
+
+    def note(self):
+        """what bb_last_error(ctx) holds: after a successful create, the note that the policy's traceback order has no fast kernels in this build"""
+        return lib().bb_last_error(self._ctx()).decode()
 
     def close(self):
         if self._h is not None:

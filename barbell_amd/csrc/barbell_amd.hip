@@ -280,9 +280,9 @@ int upload_tables(bb_ctx* c) {
         // forward patterns' trailing ones).  P leading rows + 32 rows per lane + T trailing rows = m_bar.
         for (int s = 0; s < 2; ++s) {
             D.split[s] = 0; D.pfx[s] = 0; D.tail[s] = 0;
-            if (!(WB == 2 && mb <= 48 && N >= 13 && N <= 768) || getenv("BARBELL_AMD_NO_PFX") || c->generic_barcode) continue;
-            // windows wider than 48 columns run the 64-column instantiation in 512-lane blocks: a hit's N lanes must fit one
-            if (N > 512 && g.info.mask_len + (uint32_t)g.info.flank_k + 2 * BB_PADDING - 1 > 48) continue;
+            // a hit's N lanes must fit one block of the exact k_barcode_pfx and of the 64-column instantiation: 512 lanes (round 5: the exact
+            // variant is compiled for 512-lane blocks and holds everything in registers; groups of 513..768 sequences take k_barcode)
+            if (!(WB == 2 && mb <= 48 && N >= 13 && N <= 512) || getenv("BARBELL_AMD_NO_PFX") || c->generic_barcode) continue;
             int lcp = mb, lcs = mb;
             for (int p = 1; p < N; ++p) {
                 int j = 0;
@@ -316,6 +316,11 @@ int upload_tables(bb_ctx* c) {
         }
     }
     c->counts_len = count_off;
+    // k_emit keeps one block-local histogram of the whole context in LDS: 4 B per (group, barcode | flank-only) slot.  32 groups x 1024 sequences
+    // are 131 KB — above the 64 KB a launch gets without asking, inside what the CU has
+    if ((size_t)c->counts_len * 4 > BB_LDS_MAX) { c->last_error = "histogram of more than 36 864 (group, barcode) slots"; return BB_E_UNSUPPORTED; }
+    if ((size_t)c->counts_len * 4 > 64 * 1024)
+        HIPCHK(c, hipFuncSetAttribute((const void*)k_emit, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)c->counts_len * 4)));
     HIPCHK(c, hipMalloc((void**)&c->d_tables, blob.b.size()));
     HIPCHK(c, hipMemcpy(c->d_tables, blob.b.data(), blob.b.size(), hipMemcpyHostToDevice));
     HIPCHK(c, hipMalloc((void**)&c->d_groups, sizeof(bb_group_dev) * c->gdev.size()));
@@ -438,6 +443,18 @@ int bb_create_policy(const bb_group_desc* groups, uint32_t n_groups, const bb_pa
     // built from the policy's exponents): an upper bound under every setting of them.
     c->generic_barcode = c->policy.lodhi_p != 3 || c->policy.lodhi_lambda != 0.5;
     c->prio_class = bb_prio_class(BB_PRIO_PACK(c->policy.trace_prio[0], c->policy.trace_prio[1], c->policy.trace_prio[2], c->policy.trace_prio[3]));
+    if (c->prio_class >= 0 && !bb_class_unit_of(c->prio_class).lane) {
+        // the build holds the fast kernels of the classes the reference's own vectors leave open (Makefile CLASSES, tests/golden/policy_feasible.json);
+        // any other order is still computed exactly, by the kernels that read the order at run time
+        const uint8_t* t = c->policy.trace_prio;
+        char note[256];
+        snprintf(note, sizeof note, "note: the fast barcode kernels of traceback order trace=%c%c%c%c are not in this build (make CLASSES=all); its hits run "
+                                    "the kernels that take the order at run time (k_barcode_pfx<.., BB_PRIO_RT>): same rows, slower",
+                 "MSID"[t[0] & 3], "MSID"[t[1] & 3], "MSID"[t[2] & 3], "MSID"[t[3] & 3]);
+        c->last_error = note;
+        static bool said = false;
+        if (!said) { said = true; fprintf(stderr, "barbell_amd: %s\n", note); }
+    }
     c->force_generic = getenv("BARBELL_AMD_GENERIC") && atoi(getenv("BARBELL_AMD_GENERIC")) != 0;
     if (getenv("BARBELL_AMD_SCAN_FILTER")) c->scan_filter = atoi(getenv("BARBELL_AMD_SCAN_FILTER")) != 0 ? 1 : 0;
     if (getenv("BARBELL_AMD_NO_FAST") && atoi(getenv("BARBELL_AMD_NO_FAST")) != 0) c->fast_path = false;

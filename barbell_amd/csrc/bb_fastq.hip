@@ -143,7 +143,7 @@ __device__ __forceinline__ void line_span(const uint8_t* __restrict__ text, cons
 }
 
 // lpr = lines per record: 4, or 2 for the compact form (header and sequence lines only: BB_FASTQ_TWO_LINE)
-__global__ __launch_bounds__(256) void k_fq_records(const uint8_t* __restrict__ text, const uint64_t* __restrict__ nl, uint32_t n_rec, uint32_t lpr,
+__global__ __launch_bounds__(256) void k_fq_records(const uint8_t* __restrict__ text, const uint64_t* __restrict__ nl, uint32_t n_rec, uint32_t lpr, uint32_t packed,
                                                     uint32_t* __restrict__ seq_len, uint32_t* __restrict__ hdr_len,
                                                     uint32_t* __restrict__ id_len, uint32_t* __restrict__ desc_start,
                                                     unsigned long long* __restrict__ bad) {
@@ -156,7 +156,13 @@ __global__ __launch_bounds__(256) void k_fq_records(const uint8_t* __restrict__ 
         line_span(text, nl, 4ull * k + 2, ps, pe);
         line_span(text, nl, 4ull * k + 3, qs, qe);
     }
-    const bool ok = he > hs && text[hs] == '@' && (lpr != 4u || (pe > ps && text[ps] == '+' && (se - ss) == (qe - qs)));
+    bool ok = he > hs && text[hs] == '@' && (lpr != 4u || (pe > ps && text[ps] == '+' && (se - ss) == (qe - qs)));
+    uint32_t sl = (uint32_t)(se - ss);
+    if (packed) {  // BB_FASTQ_PACKED: two bases per byte + one terminator byte that carries the parity of the line's length
+        const uint8_t term = se > ss ? text[se - 1] : 0;
+        ok = ok && (term == 'E' || (term == 'O' && se - ss >= 2));
+        sl = ok ? 2u * (uint32_t)(se - ss - 1) - (term == 'O' ? 1u : 0u) : 0u;
+    }
     if (!ok) atomicMin(bad, (unsigned long long)k);
     const uint32_t hl = he > hs ? (uint32_t)(he - hs - 1) : 0u;  // header without '@'
     uint32_t idl = hl, ds = hl;
@@ -166,13 +172,65 @@ __global__ __launch_bounds__(256) void k_fq_records(const uint8_t* __restrict__ 
         ds = idl;
         for (uint32_t w; ds < hl && (w = ws_len(text + hs + 1 + ds, hl - ds)) != 0u;) ds += w;
     }
-    seq_len[k] = (uint32_t)(se - ss);
+    seq_len[k] = sl;
     hdr_len[k] = hl;
     id_len[k] = idl;
     desc_start[k] = ds;
 }
 
-__global__ __launch_bounds__(256) void k_fq_pack(const uint8_t* __restrict__ text, const uint64_t* __restrict__ nl, uint32_t n_rec, uint32_t lpr,
+// ---- BB_FASTQ_PACKED: two 4-bit base-set codes per byte -> one canonical character per base --------------------------------------
+// four packed bytes -> their eight codes, one per byte, in base order (byte b: code of base 2k = b >> 4, of base 2k+1 = (b & 15) ^ 0xA)
+__device__ __forceinline__ unsigned long long fq_codes8(uint32_t v) {
+    unsigned long long s = (unsigned long long)v;
+    s = (s | (s << 16)) & 0x0000FFFF0000FFFFull;
+    s = (s | (s << 8)) & 0x00FF00FF00FF00FFull;                     // packed byte k in the low byte of 16-bit slot k
+    return (((s >> 4) & 0x000F000F000F000Full) | ((s & 0x000F000F000F000Full) << 8)) ^ 0x0A000A000A000A00ull;
+}
+// four codes (one per byte) -> "-ACMGRSVTWYHKDBN"[code]: two v_perm_b32 over the two halves of the table, selected by bit 3
+__device__ __forceinline__ uint32_t fq_chars4(uint32_t codes) {
+    constexpr uint32_t T0L = '-' | ('A' << 8) | ('C' << 16) | ((uint32_t)'M' << 24), T0H = 'G' | ('R' << 8) | ('S' << 16) | ((uint32_t)'V' << 24);
+    constexpr uint32_t T1L = 'T' | ('W' << 8) | ('Y' << 16) | ((uint32_t)'H' << 24), T1H = 'K' | ('D' << 8) | ('B' << 16) | ((uint32_t)'N' << 24);
+    const uint32_t sel = codes & 0x07070707u;
+    const uint32_t r0 = __builtin_amdgcn_perm(T0H, T0L, sel), r1 = __builtin_amdgcn_perm(T1H, T1L, sel);
+    const uint32_t m = ((codes >> 3) & 0x01010101u) * 0xFFu;
+    return (r0 & ~m) | (r1 & m);
+}
+__device__ __forceinline__ uint8_t fq_char_at(const uint8_t* __restrict__ src, uint32_t j) {   // base j of a packed line
+    const uint8_t b = src[j >> 1];
+    return (uint8_t)"-ACMGRSVTWYHKDBN"[(j & 1u) ? ((b & 15u) ^ 0xAu) : (uint32_t)(b >> 4)];
+}
+// L bases of a packed line -> dst: byte head up to a 16-byte boundary of dst, then 16 bases per lane and step from 8 (or, when the head
+// is odd, 9) packed bytes — the parity is the same for the whole record, a wave-uniform branch —, byte tail
+static __device__ __forceinline__ void wave_unpack(uint8_t* __restrict__ dst, const uint8_t* __restrict__ src, uint32_t L, int lane) {
+    uint32_t head = (uint32_t)((16u - ((uintptr_t)dst & 15u)) & 15u);
+    if (head > L) head = L;
+    if ((uint32_t)lane < head) dst[lane] = fq_char_at(src, (uint32_t)lane);
+    const uint32_t body = (L - head) >> 4;
+    u32x4* d = (u32x4*)(dst + head);
+    const bool odd = (head & 1u) != 0u;
+    for (uint32_t c = (uint32_t)lane; c < body; c += 64u) {
+        const uint32_t j0 = head + (c << 4);              // first base of this lane's 16
+        const uint8_t* s = src + (j0 >> 1);
+        uint32_t w[2];
+        __builtin_memcpy(w, s, 8);
+        const unsigned long long c0 = fq_codes8(w[0]), c1 = fq_codes8(w[1]);
+        uint32_t e[5] = {fq_chars4((uint32_t)c0), fq_chars4((uint32_t)(c0 >> 32)), fq_chars4((uint32_t)c1), fq_chars4((uint32_t)(c1 >> 32)), 0u};
+        u32x4 v;
+        if (odd) {   // bases j0 .. j0+15 start at the SECOND code of packed byte j0 >> 1: the 18 characters of 9 packed bytes without the first and the last
+            e[4] = (uint32_t)"-ACMGRSVTWYHKDBN"[s[8] >> 4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = (e[q] >> 8) | (e[q + 1] << 24);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = e[q];
+        }
+        __builtin_nontemporal_store(v, d + c);
+    }
+    const uint32_t done = head + (body << 4);
+    if (done + (uint32_t)lane < L) dst[done + lane] = fq_char_at(src, done + (uint32_t)lane);
+}
+
+__global__ __launch_bounds__(256) void k_fq_pack(const uint8_t* __restrict__ text, const uint64_t* __restrict__ nl, uint32_t n_rec, uint32_t lpr, uint32_t packed,
                                                  const uint64_t* __restrict__ off, const uint64_t* __restrict__ hoff,
                                                  uint8_t* __restrict__ bases, uint8_t* __restrict__ quals, uint8_t* __restrict__ hdr) {
     const int lane = threadIdx.x & 63;
@@ -182,7 +240,8 @@ __global__ __launch_bounds__(256) void k_fq_pack(const uint8_t* __restrict__ tex
     const uint64_t l0 = (uint64_t)lpr * k;
     const uint64_t hs = (k ? nl[l0 - 1] + 1 : 0) + 1;  // past '@'
     const uint64_t ss = nl[l0] + 1;
-    wave_copy(bases + o, text + ss, (uint32_t)L, lane);
+    if (packed) wave_unpack(bases + o, text + ss, (uint32_t)L, lane);
+    else wave_copy(bases + o, text + ss, (uint32_t)L, lane);
     if (lpr == 4u) wave_copy(quals + o, text + nl[l0 + 2] + 1, (uint32_t)L, lane);
     wave_copy(hdr + ho, text + hs, (uint32_t)HL, lane);
 }
@@ -211,6 +270,8 @@ extern "C" int bb_fastq_ingest_dev(bb_ctx* ctx, const uint8_t* d_text, uint64_t 
                                    bb_fastq_batch_dev* batch) {
     if (!ctx || !info || !batch || (!d_text && text_len) || ((uintptr_t)d_text & 15u)) return BB_E_INVALID;
     const uint32_t lpr = (final_block & BB_FASTQ_TWO_LINE) ? 2u : 4u;  // lines per record
+    const uint32_t packed = (final_block & BB_FASTQ_PACKED) ? 1u : 0u;
+    if (packed && lpr != 2u) return BB_E_INVALID;                      // the packed form is a form of the two-line block
     final_block &= BB_FASTQ_FINAL;
     bb_ctx_view v = bb_ctx_get_view(ctx);
     if (!*v.fastq) *v.fastq = new bb_fastq_state();
@@ -277,7 +338,7 @@ extern "C" int bb_fastq_ingest_dev(bb_ctx* ctx, const uint8_t* d_text, uint64_t 
         }
         const unsigned long long none = ~0ull;
         FCHK(v, hipMemcpyAsync(s->d_misc + 4, &none, 8, hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(k_fq_records, dim3((n + 255) / 256), dim3(256), 0, st, d_text, (const uint64_t*)s->d_nl, n, lpr, s->d_seq_len, s->d_hdr_len,
+        hipLaunchKernelGGL(k_fq_records, dim3((n + 255) / 256), dim3(256), 0, st, d_text, (const uint64_t*)s->d_nl, n, lpr, packed, s->d_seq_len, s->d_hdr_len,
                            s->d_id_len, s->d_desc, (unsigned long long*)(s->d_misc + 4));
         if ((r = scan64(v, s, s->d_seq_len, s->d_off, n, s->d_misc + 2))) return r;
         if ((r = scan64(v, s, s->d_hdr_len, s->d_hoff, n, s->d_misc + 3))) return r;
@@ -294,7 +355,7 @@ extern "C" int bb_fastq_ingest_dev(bb_ctx* ctx, const uint8_t* d_text, uint64_t 
         if ((r = fgrow(v, s->d_bases, s->cap_bases, h[0] + 16))) return r;
         if (lpr == 4u && (r = fgrow(v, s->d_quals, s->cap_quals, h[0] + 16))) return r;
         if ((r = fgrow(v, s->d_hdr, s->cap_hdr, h[1] + 16))) return r;
-        hipLaunchKernelGGL(k_fq_pack, dim3((n + 3) / 4), dim3(256), 0, st, d_text, (const uint64_t*)s->d_nl, n, lpr, (const uint64_t*)s->d_off,
+        hipLaunchKernelGGL(k_fq_pack, dim3((n + 3) / 4), dim3(256), 0, st, d_text, (const uint64_t*)s->d_nl, n, lpr, packed, (const uint64_t*)s->d_off,
                            (const uint64_t*)s->d_hoff, s->d_bases, s->d_quals, s->d_hdr);
         FCHK(v, hipGetLastError());
     }

@@ -224,27 +224,25 @@ __global__ __launch_bounds__(512) void k_barcode_reg(const uint8_t* __restrict__
     const bool in_blk = hl < (int)hpb;
     const int hls = in_blk ? hl : 0;  // lanes past the last hit of the block shadow hit 0, results unused
     constexpr int PIECES = (int)(sizeof(bb_hit) / 16);
-    // prefetch of the next iteration's hit records: the lanes of a hit share its six 16-byte pieces
-    // (piece p, p+N, p+2N: one piece per lane when N >= 6, up to three for the smallest groups)
-    uint4 pre[3] = {make_uint4(0u, 0u, 0u, 0u), make_uint4(0u, 0u, 0u, 0u), make_uint4(0u, 0u, 0u, 0u)};
+    // prefetch of the next iteration's hit records: the lanes of a hit share its six 16-byte pieces: lane p prefetches piece p; groups of fewer
+    // than six sequences fetch pieces p + N, p + 2N at the start of the iteration instead, unprefetched (they have many hits per block
+    // iteration to hide it behind) — one uint4 of prefetch state instead of three: k_barcode_reg<2, 48> held 256 VGPRs + 4 spilled with three
+    uint4 pre = make_uint4(0u, 0u, 0u, 0u);
     auto prefetch = [&](uint32_t it) {
         const uint32_t li = it * hpb + (uint32_t)hl;
-        if (in_blk && p < PIECES && it < n_iter && li < n_list) {
-            const uint32_t idx = hit_list ? hit_list[li] : li;
-            const uint4* src = reinterpret_cast<const uint4*>(hits + idx);
-#pragma unroll
-            for (int q = 0; q < 3; ++q)
-                if (p + q * N < PIECES) pre[q] = src[p + q * N];
-        }
+        if (in_blk && p < PIECES && it < n_iter && li < n_list) pre = reinterpret_cast<const uint4*>(hits + (hit_list ? hit_list[li] : li))[p];
     };
     prefetch(blockIdx.x);
   for (uint32_t it = blockIdx.x; it < n_iter; it += gridDim.x) {
     const uint32_t li = it * hpb + (uint32_t)hl;
     const bool exists = in_blk && li < n_list;
     if (exists && p < PIECES) {
-#pragma unroll
-        for (int q = 0; q < 3; ++q)
-            if (p + q * N < PIECES) s_hit[hl * PIECES + p + q * N] = pre[q];
+        s_hit[hl * PIECES + p] = pre;
+        if (p + N < PIECES) {
+            const uint4* src = reinterpret_cast<const uint4*>(hits + (hit_list ? hit_list[li] : li));
+            s_hit[hl * PIECES + p + N] = src[p + N];
+            if (p + 2 * N < PIECES) s_hit[hl * PIECES + p + 2 * N] = src[p + 2 * N];
+        }
     }
     if (in_blk && p == 0) { s_max[hl] = 0ull; s_sec[hl] = 0ull; s_cnt1[hl] = 0; s_top[hl] = 0x7FFFFFFF; }
     __syncthreads();
@@ -274,9 +272,9 @@ __global__ __launch_bounds__(512) void k_barcode_reg(const uint8_t* __restrict__
     uint32_t L0[CW], H0[CW], X[CW];
     int32_t best_cost = 0x7FFFFFFF, best_pos = -1;
     {
-        uint32_t wc[CW / 4];
-#pragma unroll
-        for (int q = 0; q < CW / 16; ++q) { uint4 v = s_hit[hls * PIECES + 2 + q]; wc[4 * q] = v.x; wc[4 * q + 1] = v.y; wc[4 * q + 2] = v.z; wc[4 * q + 3] = v.w; }
+        // the window's base-set codes, four columns per word, read from the hit's LDS record as the columns come (the lanes of a hit read
+        // the same word: a broadcast) instead of held in CW / 4 registers through the whole pass
+        const uint32_t* wcs = reinterpret_cast<const uint32_t*>(s_hit + hls * PIECES + 2);
         const uint32_t NW = (uint32_t)(N * WB);
         // byte offset into s_peq of this lane's column 0 entry; one v_mad_u32_u24 per column adds code * row bytes
         const uint32_t pb4 = ((uint32_t)((active ? H.strand : 0) * 16) * NW + (uint32_t)p * WB) * 4u, NW4 = NW * 4u;
@@ -291,9 +289,11 @@ __global__ __launch_bounds__(512) void k_barcode_reg(const uint8_t* __restrict__
 #pragma unroll
         for (int c0 = 0; c0 < CW; c0 += BB_CG) {
             if (c0 < wmax) {  // wave-uniform
+                uint32_t wcw = 0u;
 #pragma unroll
                 for (int c = c0; c < c0 + BB_CG; ++c) {
-                    const uint32_t code = (wc[c >> 2] >> (8 * (c & 3))) & 0xFu;
+                    if ((c & 3) == 0) wcw = wcs[c >> 2];
+                    const uint32_t code = (wcw >> (8 * (c & 3))) & 0xFu;
                     uint32_t eq[WB], d0[WB], ph[WB], mh[WB], l[WB], hh[WB];
                     const uint32_t ei = __umul24(code, NW4) + pb4;
                     if constexpr (WB == 2) { uint2 v = *reinterpret_cast<const uint2*>(s_peq_b + ei); eq[0] = v.x; eq[1] = v.y; }

@@ -33,12 +33,16 @@ __device__ __forceinline__ void wave_top2(bool in, uint32_t vbits, unsigned long
          (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)key, l2);
 }
 #define BB_PFX_SYNC() __syncthreads()
+// Block size the kernel is compiled for.  The fast 48-column variants fit 168 VGPRs: 768-lane blocks, 3 waves per SIMD (8 hits x 96 barcodes
+// use every lane).  The exact variants (every lane scored in f64: the hits the bounds leave undecided, 0.5 % on the headline workload) need
+// ~176: compiled for 512-lane blocks they hold everything in registers (8 spilled VGPRs at 768 through round 4).
+#define BB_PFX_MAX_THREADS(CW_, FAST_) (((CW_) <= 48 && (FAST_)) ? 768 : 512)
 // DEFPOL: the default local-minimum and tie rules as compile-time constants (measured: the run-time form costs the 48-column
 // fast variants 1 % — 16.40 against 16.24 ms per 2 M-read step); the host launches it when the context's policy has them
 // PRIO: the class of the policy's traceback order (bb_prio.h) as a compile-time constant — the fast variants of the 48-column kernel,
 // one instantiation per class —, or BB_PRIO_RT: the order is read from the group (the exact variants and the 64-column kernel).
 template <int CW, bool TAIL, bool FAST, bool DEFPOL, uint32_t PRIO>
-__global__ __launch_bounds__(CW <= 48 ? 768 : 512) void k_barcode_pfx(const uint8_t* __restrict__ tables, const bb_group_dev* __restrict__ groups,
+__global__ __launch_bounds__(BB_PFX_MAX_THREADS(CW, FAST)) void k_barcode_pfx(const uint8_t* __restrict__ tables, const bb_group_dev* __restrict__ groups,
                                                      uint32_t g, uint32_t strand, const bb_hit* __restrict__ hits, const bb_hit_pfx* __restrict__ pfxs,
                                                      const uint32_t* __restrict__ hit_list, const uint32_t* __restrict__ list_cnt,
                                                      uint32_t n_hits_all, uint32_t hpb, double min_score, double min_score_diff,

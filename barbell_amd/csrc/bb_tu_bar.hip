@@ -25,6 +25,12 @@ const bb_class_unit& bb_class_unit_of(int cls) {
     return cls >= 0 && cls < BB_PRIO_CLASSES ? units[cls] : none;
 }
 
+extern "C" uint32_t bb_build_trace_classes(void) {
+    uint32_t m = 0;
+    for (int i = 0; i < BB_PRIO_CLASSES; ++i) m |= bb_class_unit_of(i).lane ? 1u << i : 0u;
+    return m;
+}
+
 void bb_launch_timed_begin(bb_ctx* c, hipStream_t st, const char* fmt, ...) {
     if (!c->timing || c->n_lev >= sizeof(c->lev) / sizeof(c->lev[0])) return;
     bb_ctx::LaunchEv& e = c->lev[c->n_lev];
@@ -94,7 +100,7 @@ void launch_barcode_pfx(bb_ctx* c, uint32_t n_hits, uint32_t g, uint32_t strand,
     if (fast) ++c->pfx_fast_launches;  // these leave records for k_rows
     // CW = 48 fits 168 VGPRs -> 3 waves per SIMD: 768-thread blocks (8 hits x 96 barcodes use every lane); measured
     // 22.8 vs 26.8 ms against 512-thread blocks at 2 waves per SIMD
-    uint32_t tmax = CW <= 48 ? 768u : 512u;
+    uint32_t tmax = (uint32_t)BB_PFX_MAX_THREADS(CW, fast);
     if (c->pfx_threads && c->pfx_threads <= tmax) tmax = c->pfx_threads;  // BARBELL_AMD_PFX_THREADS (tuning knob)
     uint32_t hpb = std::max(1u, tmax / N);
     uint32_t threads = ((hpb * N + 63) / 64) * 64;
@@ -108,7 +114,7 @@ void launch_barcode_pfx(bb_ctx* c, uint32_t n_hits, uint32_t g, uint32_t strand,
     while (hpb > 1 && smem_for(hpb, threads) > BB_LDS_MAX) { --hpb; threads = ((hpb * N + 63) / 64) * 64; }
     const size_t smem = smem_for(hpb, threads);
     const uint32_t n_iter = (n_hits + hpb - 1) / hpb;
-    const uint32_t per_cu = std::max(1u, (CW <= 48 ? 768u : 512u) / threads);  // blocks that fit a CU at this kernel's register count
+    const uint32_t per_cu = std::max(1u, (uint32_t)BB_PFX_MAX_THREADS(CW, fast) / threads);  // blocks that fit a CU at this kernel's register count
     const uint32_t resident = (uint32_t)c->n_cus * per_cu * c->reg_blocks_mult;
     const uint32_t blocks = n_iter < resident ? n_iter : resident;
     // the 48-column variants, fast and exact, come from the class's unit (compile-time traceback order); the 64-column kernel reads the
@@ -117,10 +123,11 @@ void launch_barcode_pfx(bb_ctx* c, uint32_t n_hits, uint32_t g, uint32_t strand,
         const bb_pfx_args a{(const uint8_t*)c->d_tables, (const bb_group_dev*)c->d_groups, g, strand, (const bb_hit*)c->d_hits, (const bb_hit_pfx*)c->d_pfx, list,
                             cnt, n_hits, hpb, c->params.min_score, c->params.min_score_diff, c->d_rows};
         const bool defpol = fast && c->policy.lm_rule == BB_LM_PLATEAU_RIGHT && c->policy.bar_tie == BB_TIE_FIRST;
+        const uint32_t lev0 = c->n_lev;   // restored, not decremented: bb_launch_timed_begin may have added nothing (timing off, table full)
         bb_launch_timed_begin(c, st, "k_barcode_pfx<48, %s, %s, %s, %uu>", D.tail[strand] > 0 ? "true" : "false", fast ? "true" : "false",
                               defpol && c->prio_class == 0 ? "true" : "false", BB_PRIO_TABLE.cls[c->prio_class]);
         if (U.pfx(D.tail[strand] > 0, fast, defpol, blocks, threads, smem, st, a)) { bb_launch_timed_end(c, st); return; }
-        --c->n_lev;
+        c->n_lev = lev0;
     }
 #define BB_PFX_ARGS (const uint8_t*)c->d_tables, (const bb_group_dev*)c->d_groups, g, strand, (const bb_hit*)c->d_hits, (const bb_hit_pfx*)c->d_pfx, list, \
                     cnt, n_hits, hpb, c->params.min_score, c->params.min_score_diff, c->d_rows

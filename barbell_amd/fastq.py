@@ -22,6 +22,43 @@ class FastqBatchDev(C.Structure):
     _fields_ = [("d_bases", C.c_void_p), ("d_quals", C.c_void_p), ("d_offsets", C.c_void_p), ("d_headers", HeadersC)]
 
 
+BB_FASTQ_FINAL, BB_FASTQ_TWO_LINE, BB_FASTQ_PACKED = 1, 2, 4   # include/barbell_amd_fastq.h
+CANON = b"-ACMGRSVTWYHKDBN"                                    # what a packed base set unpacks to, by code
+_CODE = np.zeros(256, dtype=np.uint8)
+for _ch, _k in zip(b"ACGTURYSWKMBDHVN", (1, 2, 4, 8, 8, 5, 10, 6, 9, 12, 3, 14, 13, 11, 7, 15)):
+    _CODE[_ch] = _CODE[_ch | 0x20] = _k
+
+
+def base_codes(seq):
+    """4-bit IUPAC base set of every read character (A=1 C=2 G=4 T=8 and unions, case-insensitive, U = T; 0 = not an IUPAC letter)"""
+    return _CODE[np.frombuffer(bytes(seq), dtype=np.uint8)]
+
+
+def pack_sequence_line(seq):
+    """the packed form of one sequence line (BB_FASTQ_PACKED), without the '\n'; None where the form cannot hold it (two adjacent
+    non-IUPAC characters at an even position would pack to the byte '\n')"""
+    c = base_codes(seq).astype(np.uint16)
+    n = len(c)
+    if n & 1:
+        c = np.concatenate([c, np.array([15], dtype=np.uint16)])
+    hi, lo = c[0::2], c[1::2]
+    if np.any((hi == 0) & (lo == 0)):
+        return None
+    return ((hi << 4) | (lo ^ 0xA)).astype(np.uint8).tobytes() + (b"O" if n & 1 else b"E")
+
+
+def pack_two_line(records, nl=b"\n"):
+    """records: (header without '@', sequence) pairs -> the text of a BB_FASTQ_TWO_LINE | BB_FASTQ_PACKED block (what the C++ host's readers
+    stage); None if a sequence cannot be packed"""
+    out = []
+    for h, seq in records:
+        p = pack_sequence_line(seq)
+        if p is None:
+            return None
+        out.append(b"@" + bytes(h) + nl + p + b"\n")
+    return b"".join(out)
+
+
 def ingest(dm, text, final_block=True, device_ptr=None):
     """text: bytes-like block (or `device_ptr` + length given as text=int).  -> (FastqInfo, FastqBatchDev)"""
     from ._lib import lib

@@ -195,6 +195,12 @@ void bb_host_free(bb_ctx* ctx, void* ptr);
 int  bb_host_malloc_on(int device, uint64_t bytes, void** ptr);
 void bb_host_free_on(int device, void* ptr);
 
+/* Which classes of traceback orders (policy field `trace`, barbell_amd_policy.h) this build holds fast barcode kernels for: bit i = class i of
+ * barbell_amd/csrc/bb_prio.h (bit 0 = the default order M,I,S,D).  The default build holds the classes the reference's own known-answer tests
+ * (cigar_parse.rs:163-176) leave open; a context created under another order computes the same rows with the kernels that read the order at run
+ * time and says so in bb_last_error(ctx).  Needs no GPU.                                                                                   */
+uint32_t    bb_build_trace_classes(void);
+
 const char* bb_strerror(int code);
 const char* bb_last_error(const bb_ctx* ctx);   /* detail of the last BB_E_HIP / BB_E_UNSUPPORTED; ctx == NULL: of the
                                                    last failed bb_create on this thread                          */

@@ -42,6 +42,16 @@ typedef struct {
                                  over PCIe; the host side drops the '+' and quality lines while it stages the text (bb_host.cpp).
                                  batch->d_quals is NULL for such a block.                                                       */
 
+#define BB_FASTQ_PACKED   4   /* with BB_FASTQ_TWO_LINE: the sequence line holds two bases per byte — what crosses PCIe for annotate is then ~2 KB
+                                 per 4-kb read instead of 4.  The kernels only ever look at a read character's IUPAC base set (a 4-bit code:
+                                 A=1 C=2 G=4 T=8, their unions, 0 = not an IUPAC letter: matches nothing), so the host keeps exactly that.
+                                 Line format: bases 2i, 2i+1 of the line -> byte (code[2i] << 4) | (code[2i+1] ^ 0xA); an odd last base is
+                                 paired with code 15; then ONE terminator byte 'E' / 'O' (even / odd number of bases), then '\n'.  No packed
+                                 byte is '\n' unless both codes are 0 (two adjacent non-IUPAC characters): the host must not pack such input
+                                 (bb_host.cpp falls back to the plain two-line form).  The ingest unpacks into batch->d_bases as one canonical
+                                 character per base set ("-ACMGRSVTWYHKDBN"[code]): rows are those of the original text, the read's own
+                                 spelling (case, U for T) is not recoverable — the annotate path never reports it.                          */
+
 /* Parses text[0, text_len).  final_block & BB_FASTQ_FINAL: the text is the end of the stream — a last line without
  * '\n' counts, trailing blank lines are ignored, and a trailing partial record is an error; otherwise
  * the partial tail is left to the caller (info->consumed).  "\r\n" line ends are accepted.

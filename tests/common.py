@@ -54,5 +54,32 @@ ALTERNATIVES = {   # hazard -> the non-default settings (the default is the firs
 }
 GPU_POLICIES = [a for alts in ALTERNATIVES.values() for a in alts] + [
     "lm=left,rc=fwd,trace=MSID,ovh=ceil,tie=last,lodhi=3:0.5:2211,rcpath=mirror",      # everything at once, register-resident Lodhi family
+    "lm=left,rc=fwd,trace=MSID,ovh=ceil,tie=last,lodhi=3:0.5:2211",                    # the same without the refuted rcpath=mirror
     "lm=strict,tie=last,lodhi=3:0.5:1121",
 ]
+
+
+# ---- what the reference's own vectors and invariants still allow (tools/policy_feasible.py -> tests/golden/policy_feasible.json) ----
+def policy_feasible():
+    import json
+
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "policy_feasible.json")) as f:
+        return json.load(f)
+
+
+def is_feasible(policy_text):
+    """every field the (possibly partial) policy text names holds a value the reference's KATs (cigar_parse.rs:104-176) and no-panic /
+    windowing invariants (searcher.rs:388, :445-456) leave open; `lodhi` is unconstrained by them"""
+    f = policy_feasible()
+    full = dict(tok.split("=", 1) for tok in _abi.policy_to_str(_abi.policy_from_str(policy_text)).split(","))
+    full["trace"] = full["trace"].replace("SM", "MS")
+    keys = [k for k in f["space"]]
+    if not f["feasible_is_product_of_fields"]:
+        return ",".join(f"{k}={full[k]}" for k in keys) in f["feasible_joint"]
+    return all(full[k] in f["feasible"][k] for k in keys)
+
+
+def split_feasible(policies):
+    """(feasible, refuted) halves of a list of policy texts, order kept"""
+    ok = [p for p in policies if is_feasible(p)]
+    return ok, [p for p in policies if p not in ok]

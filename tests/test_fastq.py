@@ -265,3 +265,73 @@ def test_gpu_two_line_form():
         nr = dm.demux_dev(batch.d_bases, batch.d_offsets, n, d_rows.data_ptr(), 4 * n)
         outs.append(d_rows[: nr * 48].cpu().numpy().tobytes())
     assert outs[0] == outs[1] and len(outs[0]) > 48 * n // 2
+
+
+# ---- the packed two-line form (BB_FASTQ_PACKED: two 4-bit base sets per byte, what `barbell-amd annotate` uploads) ---------------------
+def test_packed_line_format_cpu():
+    from barbell_amd import fastq as Q
+
+    assert Q.pack_sequence_line(b"") == b"E"
+    assert Q.pack_sequence_line(b"A") == bytes([(1 << 4) | (15 ^ 0xA)]) + b"O"
+    assert Q.pack_sequence_line(b"ACGT") == bytes([(1 << 4) | (2 ^ 0xA), (4 << 4) | (8 ^ 0xA)]) + b"E"
+    assert Q.pack_sequence_line(b"acgu") == Q.pack_sequence_line(b"ACGT")                 # case and U: the same base sets
+    assert Q.pack_sequence_line(b"A**A") is not None and Q.pack_sequence_line(b"**AA") is None and Q.pack_sequence_line(b"A*") is not None
+    rng = np.random.default_rng(1)
+    for _ in range(200):   # no packable line holds a newline; every base set survives
+        seq = bytes(rng.choice(np.frombuffer(b"ACGTNacgtnRYKMSWBDHVU*-.x", dtype=np.uint8), int(rng.integers(0, 70))))
+        p = Q.pack_sequence_line(seq)
+        if p is None:
+            continue
+        assert b"\n" not in p and p[-1:] in (b"E", b"O")
+        body = np.frombuffer(p[:-1], dtype=np.uint8)
+        codes = np.stack([body >> 4, (body & 15) ^ 0xA], axis=1).reshape(-1)[: len(seq)]
+        assert codes.tolist() == Q.base_codes(seq).tolist()
+        assert all(po.lib().bbo_iupac_code(Q.CANON[k]) % 255 == k for k in range(16))    # the canonical characters carry their code (0xFF = invalid = 0)
+
+
+@pytest.mark.gpu
+def test_gpu_ingest_packed_form_equals_the_text_form():
+    """The same records as 4-line text, as two-line text and as packed two-line text: offsets, headers, ids identical; the unpacked bases are
+    the canonical character of each original character's base set; annotate rows identical — on reads with lower case, N, IUPAC codes, U and
+    single non-IUPAC characters, of every length parity, with record starts at every alignment."""
+    from barbell_amd import annotate as A, fastq as Q
+    from tests.common import config_groups
+
+    groups = config_groups("nbd96")
+    n = 3000
+    bases, offsets = A.synth_reads_host(groups, 321, 1, 3000, 0, n)
+    rng = np.random.default_rng(8)
+    b = bases.copy()
+    for alphabet, rate in ((b"acgtn", 0.05), (b"NRYKMSWBDHVU", 0.01), (b"*-.1x", 0.002)):
+        pos = np.nonzero(rng.random(len(b)) < rate)[0]
+        b[pos] = rng.choice(np.frombuffer(alphabet, dtype=np.uint8), len(pos))
+    recs = [((b"read%d" % i) + (b" ch=%d  x" % (i % 9) if i % 3 else b""), b[int(offsets[i]):int(offsets[i + 1])].tobytes()) for i in range(n)]
+    recs = [(h, s) for h, s in recs if Q.pack_sequence_line(s) is not None] + [(b"empty", b""), (b"one", b"G"), (b"two", b"gN")]
+    n = len(recs)
+    assert n > 2900
+    text4 = b"".join(b"@" + h + b"\n" + s + b"\n+\n" + b"I" * len(s) + b"\n" for h, s in recs)
+    text2 = b"".join(b"@" + h + b"\n" + s + b"\n" for h, s in recs)
+    textp = Q.pack_two_line(recs)
+    assert len(textp) < 0.55 * len(text2)
+    dm = A.Demuxer()
+    for g in groups:
+        dm.add_query_group(g)
+    res = {}
+    for name, text, flags in (("4", text4, Q.BB_FASTQ_FINAL), ("2", text2, Q.BB_FASTQ_FINAL | Q.BB_FASTQ_TWO_LINE),
+                              ("p", textp, Q.BB_FASTQ_FINAL | Q.BB_FASTQ_TWO_LINE | Q.BB_FASTQ_PACKED)):
+        info, batch = Q.ingest(dm, text, flags)
+        arr = Q.fetch(dm, info, bases=True)
+        nr = dm.demux_dev(batch.d_bases, batch.d_offsets, int(info.n_records), dm.buf("rows").ensure(6 * n * 48), 6 * n)
+        rows = dm.buf("rows").download(nr * 48).view(_abi.ROW_DTYPE) if hasattr(dm.buf("rows"), "download") else None
+        res[name] = (info, arr, rows)
+        assert int(info.n_records) == n and int(info.consumed) == len(text)
+    for k in ("offsets", "hdr", "hdr_offsets", "id_len", "desc_start"):
+        assert res["p"][1][k].tobytes() == res["4"][1][k].tobytes() == res["2"][1][k].tobytes(), k
+    want = np.frombuffer(Q.CANON, dtype=np.uint8)[Q.base_codes(res["4"][1]["bases"].tobytes())]
+    assert res["p"][1]["bases"].tobytes() == want.tobytes()
+    assert res["2"][1]["bases"].tobytes() == res["4"][1]["bases"].tobytes()
+    if res["p"][2] is not None:
+        assert res["p"][2].tobytes() == res["4"][2].tobytes() == res["2"][2].tobytes() and len(res["p"][2]) > n // 2
+    # a malformed packed line (no terminator) is a FASTQ error, not garbage
+    with pytest.raises(A.BarbellError):
+        Q.ingest(dm, b"@r\n\x1f\x2e\n", Q.BB_FASTQ_FINAL | Q.BB_FASTQ_TWO_LINE | Q.BB_FASTQ_PACKED)

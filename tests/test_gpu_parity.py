@@ -376,18 +376,21 @@ def test_large_batch_properties_without_oracle():
     assert len(tags) > 0.7 * n and set(np.unique(tags["strand"]).tolist()) == {0, 1}
 
 
-def test_offsets_beyond_4gib_against_oracle():
-    """One full BASELINE batch (2 M x 4000 nt = 8 GB: byte offsets pass 2^32 half-way) through the device-pointer
-    entry point; the rows of three windows of reads — head, middle and the LAST reads of the batch, whose offsets lie
-    beyond 4 GiB — are compared bit-exact with the oracle run on those reads alone (reads are independent, so the
-    full batch restricted to a window must equal the window annotated by itself)."""
+@pytest.mark.parametrize("cfg,w,fast", [("nbd96", 6000, False), ("dual", 4000, True), ("rbk96x", 2000, True)])
+def test_offsets_beyond_4gib_against_oracle(cfg, w, fast):
+    """One full BASELINE batch (2 M x 4000 nt = 8 GB: byte offsets pass 2^32 half-way) of configs[1] / configs[3] / configs[4]'s query sets
+    through the device-pointer entry point; the rows of four windows of reads — head, middle, the window straddling the 4 GiB line and the
+    LAST reads of the batch — are compared bit-exact with the oracle run on those reads alone (reads are independent, so the full batch
+    restricted to a window must equal the window annotated by itself).  dual: two groups, k = 5; rbk96x: two groups, k = 20 (chance hits,
+    four lane launches per group, the checkpointed flank traceback) — there the oracle's bit-parallel path does the windows (itself checked
+    against the scalar one in tests/test_oracle_fast.py, and here on the first 300 reads)."""
     import torch
 
     from barbell_amd import annotate as A
     from oracle import pyoracle as po
 
-    groups = config_groups("nbd96")
-    n, L, w = 2_000_000, 4000, 6000
+    groups = config_groups(cfg)
+    n, L = 2_000_000, 4000
     assert (n - w) * L > 2 ** 32
     dm = A.Demuxer()
     for g in groups:
@@ -396,19 +399,57 @@ def test_offsets_beyond_4gib_against_oracle():
     d_bases = torch.empty(n * L, dtype=torch.uint8, device="cuda")
     torch.cuda.synchronize()
     dm.synth_dev(0xBA7BE11 ^ 2, L, L, 0, n, d_off.data_ptr(), d_bases.data_ptr())
-    d_rows = torch.empty(4 * n * 48, dtype=torch.uint8, device="cuda")
-    nr = dm.demux_dev(d_bases.data_ptr(), d_off.data_ptr(), n, d_rows.data_ptr(), 4 * n)
+    cap = (4 if cfg == "nbd96" else 6) * n
+    d_rows = torch.empty(cap * 48, dtype=torch.uint8, device="cuda")
+    nr = dm.demux_dev(d_bases.data_ptr(), d_off.data_ptr(), n, d_rows.data_ptr(), cap)
     full = np.frombuffer(d_rows[: nr * 48].cpu().numpy().tobytes(), dtype=_abi.ROW_DTYPE)
-    assert nr > n and int(full["read_idx"].max()) > n - 100
+    assert nr > n // 2 and int(full["read_idx"].max()) > n - 100
+    assert set(np.unique(full["group_idx"]).tolist()) == set(range(len(groups)))
     orc = po.Oracle([g.as_tuple() for g in groups])
     offs = np.arange(w + 1, dtype=np.uint64) * np.uint64(L)
     for first in (0, n // 2 - w // 2, (2 ** 32) // L - w // 2, n - w):   # incl. the window straddling the 4 GiB line
         host = d_bases[first * L: (first + w) * L].cpu().numpy()
-        want = orc.annotate(host, offs, n_threads=NT)
+        want = orc.annotate(host, offs, n_threads=NT, fast=fast)
         got = full[(full["read_idx"] >= first) & (full["read_idx"] < first + w)].copy()
         got["read_idx"] -= first
         assert len(want) > w // 2
         assert_same(got, want)
+        if fast and first == 0:
+            ws = 300
+            assert_same(got[got["read_idx"] < ws], orc.annotate(host[: ws * L], offs[: ws + 1], n_threads=NT))
+
+
+def test_hit_buffer_grows_with_two_groups():
+    """The flank-hit buffers start at 3 hits per read (+ 1024) and grow when a batch has more (the scan is redone once with the larger
+    buffers): reads that each carry six constructs of the custom dual-end set's two groups — both strands, well apart — give more than
+    three hits per read; rows against the oracle, and a second, ordinary batch through the same (grown) context."""
+    from barbell_amd import annotate as A
+
+    groups = config_groups("dual")
+    rng = np.random.default_rng(31)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    reads = []
+    n = 3000
+    for i in range(n):
+        parts = [acgt[rng.integers(0, 4, int(rng.integers(0, 40)))].tobytes()]
+        for j in range(6):
+            g = groups[(i + j) % 2]
+            s = bytes(g.seqs[int(rng.integers(len(g.seqs)))])
+            parts.append(s if rng.random() < 0.5 else s.translate(comp)[::-1])
+            parts.append(acgt[rng.integers(0, 4, int(rng.integers(120, 260)))].tobytes())
+        reads.append(b"".join(parts))
+    bases, offsets = _abi.pack_reads(reads)
+    dm, got, want = run_both(groups, bases, offsets)
+    assert len(want) > 3 * n + 1024                      # more rows than the initial hit capacity: the buffers grew
+    assert_same(got, want)
+    b2, o2 = A.synth_reads_host(groups, 5, 300, 2500, 0, 2000)
+    got2 = dm.demux_packed(b2, o2)
+    from oracle import pyoracle as po
+
+    want2 = po.Oracle([g.as_tuple() for g in groups]).annotate(b2, o2, n_threads=NT)
+    assert_same(got2, want2)
+    dm.close()
 
 
 def test_wide_barcode_windows_take_the_64_column_kernels():
@@ -788,13 +829,21 @@ def test_dominant_kernel_is_named_and_timed():
     name, ms = dm.dominant_kernel()
     stage = dm.kernel_ms()["k_barcode"]
     assert name.startswith("k_barcode_lane<48, ") and name.endswith(", 216u, false>") and 0.0 < ms <= stage * 1.05, (name, ms, stage)
-    dm2 = A.Demuxer(policy="trace=MDSI")
-    for g in groups:
-        dm2.add_query_group(g)
-    dm2.set_timing(True)
-    dm2.demux_packed(bases, offsets)
-    assert dm2.dominant_kernel()[0].startswith("k_barcode_lane<48, ") and ", 216u, " not in dm2.dominant_kernel()[0]
-    dm.close(); dm2.close()
+    # another traceback order: a class of this build runs its own k_barcode_lane instantiation (MSID is in every build: one of the five the
+    # reference's vectors leave open); a class outside the build (MDSI, unless `make CLASSES=all`) the kernels that read the order at run time
+    for pol, in_build in (("trace=MSID", True), ("trace=MDSI", len(A.build_trace_classes()) == 18)):
+        dm2 = A.Demuxer(policy=pol)
+        for g in groups:
+            dm2.add_query_group(g)
+        dm2.set_timing(True)
+        dm2.demux_packed(bases, offsets)
+        nm2 = dm2.dominant_kernel()[0]
+        if in_build:
+            assert nm2.startswith("k_barcode_lane<48, ") and ", 216u, " not in nm2, nm2
+        else:
+            assert nm2.startswith("k_barcode_pfx<48, ") and nm2.endswith("4294967295u>"), nm2
+        dm2.close()
+    dm.close()
 
 
 def test_large_flank_budget_lane_kernel_and_its_round3_alternative(monkeypatch):
@@ -842,4 +891,44 @@ def test_twelve_query_groups():
     dm, got, want = run_both(groups, bases, offsets)
     assert len(want) > 600 and len(set(want["group_idx"].tolist())) == 12
     assert_same(got, want)
+    dm.close()
+
+
+def test_histogram_beyond_64_kib_of_lds():
+    """k_emit's block-local histogram is 4 B per (group, barcode | flank-only) slot of the whole context; 18 groups x 1000 sequences
+    are 72 KB, more than a launch gets without hipFuncSetAttribute (bb_create raises the kernel's limit; up to 32 x 1024 fits the CU).  Rows
+    against the oracle, the histogram against the rows."""
+    from barbell_amd import annotate as A, kits
+
+    rng = np.random.default_rng(77)
+    rnd = lambda n: bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), n))
+    groups = []
+    for gi in range(18):
+        pre, suf = rnd(int(rng.integers(12, 24))), rnd(int(rng.integers(8, 20)))
+        seqs = list({pre + rnd(24) + suf for _ in range(1000)})
+        groups.append(kits.QueryGroup(seqs, [f"g{gi}b{i}" for i in range(len(seqs))], _abi.BB_FTAG if gi % 2 == 0 else _abi.BB_RTAG, 3))
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    reads = []
+    for _ in range(250):
+        r = rnd(int(rng.integers(0, 60)))
+        for _ in range(int(rng.integers(1, 3))):
+            gq = groups[int(rng.integers(0, len(groups)))]
+            s = bytes(gq.seqs[int(rng.integers(0, len(gq.seqs)))])
+            r += (s if rng.random() < 0.6 else s.translate(comp)[::-1]) + rnd(int(rng.integers(100, 500)))
+        reads.append(r)
+    bases = np.frombuffer(b"".join(reads), dtype=np.uint8).copy()
+    offsets = np.concatenate([[0], np.cumsum([len(r) for r in reads])]).astype(np.uint64)
+    dm, got, want = run_both(groups, bases, offsets)
+    assert sum(len(g.seqs) + 1 for g in groups) * 4 > 64 * 1024
+    assert len(want) > 250
+    assert_same(got, want)
+    cnt = dm.counts()
+    assert int(cnt.sum()) == len(got)
+    off = 0
+    for gi, g in enumerate(groups):
+        rows = got[got["group_idx"] == gi]
+        assert int(cnt[off + len(g.seqs)]) == int((rows["barcode_idx"] < 0).sum())
+        for b in np.unique(rows["barcode_idx"][rows["barcode_idx"] >= 0]):
+            assert int(cnt[off + int(b)]) == int((rows["barcode_idx"] == b).sum())
+        off += len(g.seqs) + 1
     dm.close()

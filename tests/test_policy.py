@@ -299,20 +299,37 @@ def test_fast_path_with_zero_and_unequal_decay_exponents(pol):
 
 
 @pytest.mark.gpu
-def test_no_trace_order_leaves_the_fast_kernels():
-    """bb_last_barcode_stats: under every one of the 18 classes the SQK-NBD114-96 hits are decided by k_barcode_lane (the any-policy
-    kernel k_barcode is for Lodhi p / lambda other than (3, 0.5) only)."""
-    from barbell_amd import annotate as A
+def test_trace_orders_in_and_out_of_the_build():
+    """bb_last_barcode_stats: under every traceback class THIS BUILD holds (bb_build_trace_classes: by default the five classes the
+    reference's own KATs leave open, tests/golden/policy_feasible.json; all 18 with `make CLASSES=all`) the SQK-NBD114-96 hits are decided
+    by k_barcode_lane.  A class outside the build gives the same rows as the checker through the kernels that read the order at run time,
+    and the context says so (bb_last_error(ctx))."""
+    import sys
 
+    from barbell_amd import annotate as A
+    from tests.common import policy_feasible
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import policy_feasible as pf
+
+    order = pf.build_class_order()
+    built = [order[i] for i in A.build_trace_classes()]
+    assert "MISD" in built and set(policy_feasible()["feasible"]["trace"]) <= set(built)    # every feasible class is fast in every build
     groups = config_groups("nbd96")
     bases, offsets = A.synth_reads_host(groups, 17, 1000, 3000, 0, 2000)
     for cls in TRACE_CLASSES:
         dm = A.Demuxer(policy="trace=" + cls)
         for g in groups:
             dm.add_query_group(g)
-        dm.demux_packed(bases, offsets)
+        got = dm.demux_packed(bases, offsets)
         st = [dm.barcode_stats(0, s) for s in (0, 1)]
-        assert all(s["lane_kernel"] for s in st) and sum(s["hits"] for s in st) > 1000, (cls, st)
+        if cls in built:
+            assert all(s["lane_kernel"] for s in st) and sum(s["hits"] for s in st) > 1000, (cls, st)
+            assert dm.note() == ""
+        else:
+            assert "not in this build" in dm.note() and "trace=" + cls in dm.note()
+            want = po.Oracle([g.as_tuple() for g in groups], policy="trace=" + cls).annotate(bases, offsets, n_threads=NT, fast=True)
+            assert got.tobytes() == want.tobytes(), cls
         dm.close()
 
 

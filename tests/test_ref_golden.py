@@ -177,11 +177,13 @@ def test_kat_inputs_discriminate_every_alternative():
                            else a["bits"] if a["kind"] == "lodhi" else a["matches"])
         return json.dumps(out)
 
-    for field, kinds in (("lm", ("search", "search_set")), ("rc", ("search",)), ("ovh", ("search",)), ("tie", ("search_set",)), ("lodhi", ("lodhi",))):
-        sigs = {sig(dict(d, **{field: v}), kinds) for v in ref_fit.SPACE[field]}
-        assert len(sigs) == len(ref_fit.SPACE[field]), field
+    # over the FULL space, refuted values included (tests/golden/policy_feasible.json cuts ref_fit.SPACE to what the reference's own vectors allow)
+    for field, kinds in (("lm", ("search", "search_set")), ("rc", ("search",)), ("ovh", ("search",)), ("tie", ("search_set",)), ("lodhi", ("lodhi",)),
+                         ("rcpath", ("search",))):
+        sigs = {sig(dict(d, **{field: v}), kinds) for v in ref_fit.FULL_SPACE[field]}
+        assert len(sigs) == len(ref_fit.FULL_SPACE[field]), field
     groups = {}
-    for v in ref_fit.SPACE["trace"]:
+    for v in ref_fit.FULL_SPACE["trace"]:
         groups.setdefault(sig(dict(d, trace=v), ("search", "search_set")), []).append(v)
     for g in groups.values():
         assert len(g) == 1 or (len(g) == 2 and g[0].replace("MS", "SM") == g[1].replace("MS", "SM")), g
@@ -194,7 +196,7 @@ def test_fit_recovers_a_planted_policy_from_kat_vectors(tmp_path):
     import gen_kat_inputs as G
     import ref_fit
 
-    planted = "lm=left,rc=fwd,trace=MDSI,ovh=near:f64,tie=last,lodhi=3:0.5:2211"
+    planted = "lm=left,rc=fwd,trace=MSDI,ovh=near:f64,rcpath=fwd,tie=last,lodhi=3:0.5:2211"   # a feasible one (tests/golden/policy_feasible.json)
     vectors = [ref_fit.checker_answer(inp, planted) for inp in G.load()]
     for v in vectors:  # tie=last models a crate whose Vec comes in descending position order (Barbell keeps its first strictly lowest)
         if v["kind"] == "search_set":
@@ -207,7 +209,26 @@ def test_fit_recovers_a_planted_policy_from_kat_vectors(tmp_path):
     pol, rep = ref_fit.fit_kat(vectors)
     assert all(r["explained"] == r["vectors"] for r in rep.values()), rep
     assert ref_fit.to_text(pol) == planted
-    assert not any(r["not_told_apart"] for r in rep.values()), rep
+    # nothing else explains them as well, except the other spelling of the planted order's class (adjacent M / S swapped: never distinguishable)
+    for r in rep.values():
+        assert all(f == "trace" and all(v.replace("SM", "MS") == "MSDI" for v in vals) for f, vals in r["not_told_apart"].items()), rep
+
+
+def test_fit_searches_refuted_values_only_on_request(monkeypatch):
+    """a planted policy the reference's own vectors refute (trace=MDSI breaks cigar_parse.rs:163-176, rcpath=mirror mis-windows the rapid kits:
+    tests/golden/policy_feasible.json) is outside the default search space and found with the full one (ref_fit.py --all)"""
+    import gen_kat_inputs as G
+    import ref_fit
+
+    planted = "lm=right,rc=scan,trace=MDSI,ovh=floor,rcpath=mirror,tie=first,lodhi=3:0.5:1111"
+    vectors = [ref_fit.checker_answer(inp, planted) for inp in G.load() if inp[0] == "search"]
+    assert "MDSI" in ref_fit.REFUTED["trace"] and "MDSI" not in ref_fit.SPACE["trace"] and ref_fit.SPACE["rcpath"] == ["fwd"]
+    pol, rep = ref_fit.fit_kat(vectors)
+    assert rep["search"]["explained"] < rep["search"]["vectors"]
+    for k, v in ref_fit.FULL_SPACE.items():
+        monkeypatch.setitem(ref_fit.SPACE, k, list(v))
+    pol, rep = ref_fit.fit_kat(vectors)
+    assert rep["search"]["explained"] == rep["search"]["vectors"] and pol["trace"] == "MDSI" and pol["rcpath"] == "mirror"
 
 
 def test_fit_recovers_a_planted_policy_from_a_tsv(tmp_path):

@@ -26,16 +26,37 @@ sys.path.insert(0, os.path.join(ROOT, "tools", "ref_golden"))
 
 OPS = {"=": 0, "X": 1, "I": 2, "D": 3}
 
-# the space searched, per field of the text form (first value = default)
-SPACE = {
+# the space per field of the text form (first value = default) ...
+FULL_SPACE = {
     "lm": ["right", "left", "strict"],
     "rc": ["scan", "fwd"],
     "trace": ["MISD"] + ["".join(p) for p in itertools.permutations("MSID") if "".join(p) != "MISD"],
     "ovh": ["floor", "ceil", "near", "floor:f64", "ceil:f64", "near:f64"],
+    "rcpath": ["fwd", "mirror"],
     "tie": ["first", "last"],
     "lodhi": ["3:0.5:1111"] + [f"{p}:0.5:{a}{b}{c}{d}" for p in (3, 2, 4) for a in (1, 2, 0) for b in (1, 2, 0) for c in (1, 2, 0) for d in (1, 2, 0)
                                if (p, a, b, c, d) != (3, 1, 1, 1, 1)],
 }
+
+
+def _feasible_space():
+    """... cut to what the reference's own vectors and invariants leave open (tests/golden/policy_feasible.json, tools/policy_feasible.py:
+    cigar_parse.rs:163-176 refutes 13 of the 18 traceback classes, the documented dual-end example refutes rcpath=mirror): there is no point
+    in asking whether the real crates do what the reference's own tests say they do not.  `--all` searches the refuted values too."""
+    with open(os.path.join(ROOT, "tests", "golden", "policy_feasible.json")) as f:
+        feas = json.load(f)["feasible"]
+    space, refuted = {}, {}
+    for k, vals in FULL_SPACE.items():
+        if k not in feas:
+            space[k] = list(vals)
+            continue
+        ok = lambda v: (v.replace("SM", "MS") if k == "trace" else v) in feas[k]
+        space[k] = [v for v in vals if ok(v)]
+        refuted[k] = [v for v in vals if not ok(v)]
+    return space, refuted
+
+
+SPACE, REFUTED = _feasible_space()
 KEYS = list(SPACE)
 
 
@@ -118,7 +139,7 @@ def kat_score(vectors, pol, kinds=None):
 
 # which fields can influence which kind of vector: the three kinds are fitted independently, each exhaustively where that
 # is cheap (lodhi: 242 settings) and by coordinate descent over its fields otherwise
-FIELDS_OF = {"lodhi": ["lodhi"], "search": ["lm", "rc", "trace", "ovh"], "search_set": ["lm", "trace", "tie"]}
+FIELDS_OF = {"lodhi": ["lodhi"], "search": ["lm", "rc", "trace", "ovh", "rcpath"], "search_set": ["lm", "trace", "tie"]}
 
 
 def descend(score_fn, pol, fields, log=None):
@@ -198,7 +219,10 @@ def main():
     ap.add_argument("mode", choices=["kat", "tsv"])
     ap.add_argument("path")
     ap.add_argument("--reads", type=int, default=2000)
+    ap.add_argument("--all", action="store_true", help="search the values the reference's own vectors refute as well (tests/golden/policy_feasible.json)")
     a = ap.parse_args()
+    if a.all:
+        SPACE.update({k: list(v) for k, v in FULL_SPACE.items()})
     log = lambda s: print(s, file=sys.stderr)
     if a.mode == "kat":
         pol, rep = fit_kat([json.loads(l) for l in open(a.path) if l.strip()], log)
@@ -206,7 +230,8 @@ def main():
     else:
         pol, rep = fit_tsv(a.path, a.reads, log)
         done = rep["reads_identical"] == rep["reads"]
-    print(json.dumps({"policy": to_text(pol), "explains_everything": done, "report": rep}, indent=1))
+    print(json.dumps({"policy": to_text(pol), "explains_everything": done, "report": rep, "searched": {k: len(v) for k, v in SPACE.items()},
+                      "not_searched_refuted_by_the_reference": {} if a.all else {k: v for k, v in REFUTED.items() if v}}, indent=1))
     return 0 if done else 1
 
 
