@@ -289,6 +289,8 @@ extern "C" int bb_fastq_ingest_dev(bb_ctx* ctx, const uint8_t* d_text, uint64_t 
     int r;
     uint64_t n_lines = 0;
     uint8_t last_byte = '\n';
+    uint8_t tail[16];                                            // the text's last bytes (trailing blank lines, below)
+    const uint64_t tn = std::min<uint64_t>(text_len, sizeof tail);
     if (text_len) {
         const uint32_t nb = (uint32_t)((text_len + 4095) / 4096);
         if ((r = fgrow(v, s->d_cnt, s->cap_cnt, nb))) return r;
@@ -296,37 +298,57 @@ extern "C" int bb_fastq_ingest_dev(bb_ctx* ctx, const uint8_t* d_text, uint64_t 
         if ((r = fgrow(v, s->d_masks, s->cap_masks, (uint64_t)nb * 256))) return r;
         hipLaunchKernelGGL(k_nl_count, dim3(nb), dim3(256), 0, st, d_text, text_len, s->d_cnt, s->d_masks);
         if ((r = scan64(v, s, s->d_cnt, s->d_cbase, nb, s->d_misc))) return r;
+        // one round trip for everything the host decides on: the line count and the text's last bytes
         FCHK(v, hipMemcpyAsync(&n_lines, s->d_misc, 8, hipMemcpyDeviceToHost, st));
-        FCHK(v, hipMemcpyAsync(&last_byte, d_text + text_len - 1, 1, hipMemcpyDeviceToHost, st));
+        FCHK(v, hipMemcpyAsync(tail, d_text + text_len - tn, tn, hipMemcpyDeviceToHost, st));
         FCHK(v, hipStreamSynchronize(st));
+        last_byte = tail[tn - 1];
         if ((r = fgrow(v, s->d_nl, s->cap_nl, n_lines + 2))) return r;
         hipLaunchKernelGGL(k_nl_write, dim3(nb), dim3(256), 0, st, (const uint16_t*)s->d_masks, (const uint64_t*)s->d_cbase, s->d_nl);
         FCHK(v, hipGetLastError());
-        if (final_block && last_byte != '\n') {  // last line without a newline: a virtual one at text_len
+        if (final_block && last_byte != '\n') {  // last line without a newline: a virtual one at text_len (stream order puts it after k_nl_write)
             FCHK(v, hipMemcpyAsync(s->d_nl + n_lines, &text_len, 8, hipMemcpyHostToDevice, st));
             FCHK(v, hipStreamSynchronize(st));
             ++n_lines;
         }
     }
+    if (final_block && n_lines && last_byte == '\n') {
+        // blank lines after the last record are not lines of a record.  In the 4-line form up to three of them fall out of n_lines / 4 by
+        // themselves; in the two-line forms two of them would make a record of their own: take the trailing blank lines off first.
+        uint64_t p = tn, nls = 0;
+        while (p > 0) {                                    // the maximal suffix of line ends ("\n" or "\r\n")
+            if (tail[p - 1] != '\n') break;
+            ++nls; --p;
+            if (p > 0 && tail[p - 1] == '\r') --p;
+        }
+        uint64_t blank = (p == 0 && tn == text_len) ? nls : (nls ? nls - 1 : 0);   // the first of them ends the last real line
+        blank = std::min(blank, n_lines);
+        // a record's last line may be empty (an empty sequence or quality line): only blank lines that cannot belong to a record go —
+        // those beyond the last whole record, then whole records of nothing but blank lines (a record starts with '@')
+        const uint64_t r2 = n_lines % lpr;
+        if (blank >= r2) { n_lines -= r2; blank -= r2; }
+        while (blank >= lpr) { n_lines -= lpr; blank -= lpr; }
+    }
     if (n_lines / lpr > 0xFFFFFFF0ull) { *v.last_error = "more than 2^32 records in one block"; return BB_E_UNSUPPORTED; }
     const uint32_t n = (uint32_t)(n_lines / lpr);
-    uint64_t consumed = 0;
-    if (n) FCHK(v, hipMemcpy(&consumed, s->d_nl + ((uint64_t)lpr * n - 1), 8, hipMemcpyDeviceToHost));
-    consumed = n ? std::min<uint64_t>(consumed + 1, text_len) : 0;
-    if (final_block && consumed < text_len) {  // what is left may only be blank lines
-        std::vector<uint8_t> tail((size_t)std::min<uint64_t>(text_len - consumed, 1 << 20));
-        FCHK(v, hipMemcpy(tail.data(), d_text + consumed, tail.size(), hipMemcpyDeviceToHost));
-        bool blank = text_len - consumed <= tail.size();
-        for (uint8_t ch : tail) if (ch != '\n' && ch != '\r') blank = false;
-        if (!blank) {
-            info->n_records = n; info->consumed = consumed; info->bad_record = (int64_t)n;
-            *v.last_error = "Input FASTQ parsing failed: the stream ends inside record " + std::to_string(n);
-            return BB_E_FASTQ;
-        }
-        consumed = text_len;
-    }
     info->n_records = n;
-    info->consumed = consumed;
+    // `consumed` (the end of the last record's last line) comes back with the record totals below: one round trip less per block
+    uint64_t consumed = 0;
+    if (n == 0) {
+        if (final_block && text_len) {  // what is left may only be blank lines
+            std::vector<uint8_t> rest((size_t)std::min<uint64_t>(text_len, 1 << 20));
+            FCHK(v, hipMemcpy(rest.data(), d_text, rest.size(), hipMemcpyDeviceToHost));
+            bool blank = text_len <= rest.size();
+            for (uint8_t ch : rest) if (ch != '\n' && ch != '\r') blank = false;
+            if (!blank) {
+                info->n_records = 0; info->consumed = 0; info->bad_record = 0;
+                *v.last_error = "Input FASTQ parsing failed: the stream ends inside record 0";
+                return BB_E_FASTQ;
+            }
+            consumed = text_len;
+        }
+        info->consumed = consumed;
+    }
     if (n) {
         if (n > s->cap_rec || !s->d_seq_len) {
             for (void** p : {(void**)&s->d_seq_len, (void**)&s->d_hdr_len, (void**)&s->d_id_len, (void**)&s->d_desc, (void**)&s->d_off, (void**)&s->d_hoff})
@@ -344,7 +366,22 @@ extern "C" int bb_fastq_ingest_dev(bb_ctx* ctx, const uint8_t* d_text, uint64_t 
         if ((r = scan64(v, s, s->d_hdr_len, s->d_hoff, n, s->d_misc + 3))) return r;
         uint64_t h[3];
         FCHK(v, hipMemcpyAsync(h, s->d_misc + 2, sizeof(h), hipMemcpyDeviceToHost, st));
+        FCHK(v, hipMemcpyAsync(&consumed, s->d_nl + ((uint64_t)lpr * n - 1), 8, hipMemcpyDeviceToHost, st));
         FCHK(v, hipStreamSynchronize(st));
+        consumed = std::min<uint64_t>(consumed + 1, text_len);
+        if (final_block && consumed < text_len) {  // what is left may only be blank lines
+            std::vector<uint8_t> rest((size_t)std::min<uint64_t>(text_len - consumed, 1 << 20));
+            FCHK(v, hipMemcpy(rest.data(), d_text + consumed, rest.size(), hipMemcpyDeviceToHost));
+            bool blank = text_len - consumed <= rest.size();
+            for (uint8_t ch : rest) if (ch != '\n' && ch != '\r') blank = false;
+            if (!blank) {
+                info->n_records = n; info->consumed = consumed; info->bad_record = (int64_t)n;
+                *v.last_error = "Input FASTQ parsing failed: the stream ends inside record " + std::to_string(n);
+                return BB_E_FASTQ;
+            }
+            consumed = text_len;
+        }
+        info->consumed = consumed;
         if (h[2] != none) {
             info->bad_record = (int64_t)h[2];
             *v.last_error = "Input FASTQ parsing failed: record " + std::to_string(h[2]) + " of the block is not a " + std::to_string(lpr) + "-line FASTQ record";

@@ -66,12 +66,13 @@ static void usage() {
         "Usage: barbell-amd annotate -i <FASTQ>... [-o output.tsv] (--kit <KIT> | -q <FASTA>... [-b Ftag|Rtag ...])\n"
         "                            [--flank-max-errors INT] [--min-score F=0.2] [--min-score-diff F=0.1]\n"
         "                            [--alpha F=0.4] [--use-extended] [-t THREADS=10] [--verbose]\n"
-        "                            [--block-bytes N=128Mi | --batch-reads N (= N*4096 bytes)] [--device D=0]\n"
+        "                            [--block-bytes N=256Mi | --batch-reads N (= N*4096 bytes)] [--device D=0]\n"
         "                            [--shard R/W [--rccl-id PATH (one fresh path for all W processes: their histograms are all-reduced, RCCL ncclCommInitRank; shard 0 writes --counts)]]\n"
         "                            [--devices D0,D1,.. (one FASTQ stream over several contexts, block i -> context i mod G; RCCL all-reduce of the counts)]\n"
         "                            [--streams S=2 (contexts per device when --devices is not given)] [--counts FILE]\n"
         "                            [--policy lm=..,rc=..,trace=..,ovh=..,tie=..,lodhi=.. (include/barbell_amd_policy.h)]\n"
         "                            [--no-compact (upload the quality lines too; without --trim-output they are dropped on the host)]\n"
+        "                            [--no-pack (upload the sequence lines as text; by default two bases per byte: the kernels only look at IUPAC base sets)]\n"
         "                            [(-f <PATTERN_FILE>... | --kit-filter [--maximize]) [--filtered FILE] [--dropped FILE]]\n"
         "                            [--trim-output DIR [--no-label] [--no-orientation] [--no-flanks] [--sort-labels]\n"
         "                             [--only-side left|right] [--failed-out FILE] [--skip-trim] [--flip] [--gzip]\n"
@@ -116,6 +117,31 @@ int main(int argc, char** argv) {
                 }
                 puts("--");
             }
+        } catch (const BarbellError& e) { fprintf(stderr, "error: %s\n", e.what()); return 1; }
+        return 0;
+    }
+    if (cmd == "stage") {   // test aid, no GPU: the staged upload text of the annotate path -> a file
+        std::vector<std::string> in;
+        std::string out;
+        size_t block = 128u << 20;
+        unsigned threads = 4;
+        bool two_line = true, pack = true, multi_in = false;
+        for (int i = 2; i < argc; ++i) {
+            const std::string a = argv[i];
+            if (a == "-i") multi_in = true;
+            else if (a == "-o" && i + 1 < argc) { out = argv[++i]; multi_in = false; }
+            else if (a == "--block-bytes" && i + 1 < argc) { block = (size_t)atoll(argv[++i]); multi_in = false; }
+            else if (a == "-t" && i + 1 < argc) { threads = (unsigned)atoi(argv[++i]); multi_in = false; }
+            else if (a == "--no-pack") { pack = false; multi_in = false; }
+            else if (a == "--no-compact") { two_line = false; pack = false; multi_in = false; }
+            else if (multi_in && !a.empty() && a[0] != '-') in.push_back(a);
+            else { fprintf(stderr, "error: unexpected argument '%s'\n", a.c_str()); return 2; }
+        }
+        if (in.empty() || out.empty()) { fputs("usage: barbell-amd stage -i FASTQ... -o FILE [--block-bytes N] [-t N] [--no-pack] [--no-compact]\n", stderr); return 2; }
+        try {
+            size_t nb = 0;
+            const int form = stage_blocks(in, block, threads, two_line, pack, out, nb);
+            printf("form %d blocks %zu\n", form, nb);
         } catch (const BarbellError& e) { fprintf(stderr, "error: %s\n", e.what()); return 1; }
         return 0;
     }
@@ -167,7 +193,7 @@ int main(int argc, char** argv) {
             for (const auto& l : inspect_summary(st, 10)) puts(l.c_str());
             printf("Annotated %zu of %zu reads; filter kept %zu, dropped %zu; trimmed %zu (%zu split, %zu failed)\nDone!\n", st.found, st.total,
                    st.kept, st.dropped, st.trimmed, st.trimmed_split, st.trim_failed);
-            fprintf(stderr, "Done: %zu records (%.2f s in the pipeline, %.2f M reads/s; histogram summed by %s)\n", st.total, st.seconds_pipeline,
+            fprintf(stderr, "Done: %zu records (%.3f s in the pipeline, %.2f M reads/s; histogram summed by %s)\n", st.total, st.seconds_pipeline,
                     st.seconds_pipeline > 0 ? st.total / st.seconds_pipeline / 1e6 : 0.0, st.counts_reduce.c_str());
         } catch (const BarbellError& e) { fprintf(stderr, "error: %s\n", e.what()); return 1; }
         return done_ok();
@@ -202,6 +228,7 @@ int main(int argc, char** argv) {
         else if (a == "--streams") { cfg.streams_per_device = (unsigned)atoi(need("--streams")); multi = nullptr; }
         else if (a == "--counts") { cfg.counts_file = need("--counts"); multi = nullptr; }
         else if (a == "--no-compact") { cfg.compact_upload = false; multi = nullptr; }
+        else if (a == "--no-pack") { cfg.pack_upload = false; multi = nullptr; }
         else if (a == "--gpu-render") { cfg.host_cut = false; multi = nullptr; }
         else if (a == "--policy") { if (!set_policy(need("--policy"))) return 2; multi = nullptr; }
         else if (a == "--shard") { shard = need("--shard"); multi = nullptr; }
@@ -266,7 +293,7 @@ int main(int argc, char** argv) {
             }
             st = annotate_with_files(input, queries, types, output, cfg);
         }
-        fprintf(stderr, "Done: %zu records, %zu with annotations, %zu rows -> %s (%.2f s in the pipeline, %.2f M reads/s; histogram summed by %s)\n", st.total, st.found,
+        fprintf(stderr, "Done: %zu records, %zu with annotations, %zu rows -> %s (%.3f s in the pipeline, %.2f M reads/s; histogram summed by %s)\n", st.total, st.found,
                 st.rows, output.c_str(), st.seconds_pipeline, st.seconds_pipeline > 0 ? st.total / st.seconds_pipeline / 1e6 : 0.0, st.counts_reduce.c_str());
         if (!cfg.filter_patterns.empty()) fprintf(stderr, "Filter: %zu kept, %zu dropped\n", st.kept, st.dropped);
         if (cfg.trim) fprintf(stderr, "Trim: %zu trimmed, %zu split, %zu failed\n", st.trimmed, st.trimmed_split, st.trim_failed);

@@ -3,8 +3,10 @@
 #include "bb_host.hpp"
 
 #include <zlib.h>
+#include <immintrin.h>
 
 #include <algorithm>
+#include <array>
 #include <atomic>
 #include <unordered_map>
 #include <cctype>
@@ -588,11 +590,12 @@ void DevBuf::release() {
 
 #define BB_THROW(rc, what) throw BarbellError((rc), std::string(what ": ") + bb_strerror(rc) + " " + bb_last_error(ctx_))
 
-Demuxer::Ingested Demuxer::ingest(const uint8_t* text, uint64_t len, bool final_block, bool want_ids, bool two_line) {
+Demuxer::Ingested Demuxer::ingest(const uint8_t* text, uint64_t len, bool final_block, bool want_ids, bool two_line, bool packed) {
     ensure_ctx();
     ing_ = Ingested{};
     n_rows_ = 0;
-    int rc = bb_fastq_ingest(ctx_, text, len, (final_block ? BB_FASTQ_FINAL : 0) | (two_line ? BB_FASTQ_TWO_LINE : 0), &ing_.info, &batch_);
+    int rc = bb_fastq_ingest(ctx_, text, len, (final_block ? BB_FASTQ_FINAL : 0) | (two_line ? BB_FASTQ_TWO_LINE : 0) | (two_line && packed ? BB_FASTQ_PACKED : 0),
+                             &ing_.info, &batch_);
     if (rc != BB_OK) BB_THROW(rc, "bb_fastq_ingest");
     if (!want_ids) return ing_;  // the TSV renderer reads the ids where they are
     const uint64_t n = ing_.info.n_records;
@@ -893,13 +896,18 @@ struct TwoLineSummary {
     int64_t last2[2] = {-1, -1};                  // lengths of the last two lines that end in the chunk (-2: that line is the chunk's first)
 };
 
+// thrown by the sequencer when a chunk cannot be staged in the packed form (two adjacent non-IUPAC characters in a read, a gzip chunk whose
+// line layout the reader could not tell): annotate() starts over with the plain two-line form
+struct PackFallback {};
+
 struct BlockFeeder {
     struct Block { uint64_t index = 0; const uint8_t* data = nullptr; size_t len = 0; int slot = -1; std::shared_ptr<std::vector<uint8_t>> big; };
     struct Task { size_t file = 0; uint64_t off = 0; size_t len = 0; uint64_t seq = 0; bool last = false; const uint8_t* mem = nullptr; };
     struct Slot { uint8_t* p = nullptr; size_t cap = 0, got = 0, nl = 0; bool last = false; int state = 0; uint64_t seq = 0; int refs = 0; size_t file = 0;
                   // two-line mode: raw newlines of the chunk, the phase (line index mod 4) the reader took its first byte to be in
                   // (-1: none recognisable), where the raw bytes came from (to redo the chunk if the guess was wrong), malformed flag
-                  size_t raw_nl = 0; int phase0 = 0; uint64_t off = 0; size_t raw_len = 0; bool bad = false; TwoLineSummary sum; };
+                  size_t raw_nl = 0; int phase0 = 0; uint64_t off = 0; size_t raw_len = 0; bool bad = false; TwoLineSummary sum;
+                  bool unpackable = false; };   // packed staging: this chunk cannot be packed (PackCtx::unpackable, or no look-back possible)
     size_t HEAD = 16u << 20;  // BARBELL_AMD_HEAD_BYTES overrides it (tests of the over-long-carry path)
     int device;                // the slots are page-locked for uploads to this device; a slot is allocated by the first reader that fills it
     // Ordinary (pageable, huge-page advised) memory by default: measured on the MI355X box the runtime uploads from it as fast as from
@@ -936,6 +944,7 @@ struct BlockFeeder {
     // text ("@..." two lines above "+..."; a sequence line cannot start with '+', so the test is unambiguous for FASTQ) and the
     // sequencer, which knows the true phase from the running line count, checks every guess and redoes a chunk that was wrong.
     bool two_line = false;
+    bool pack = false;                    // two-line mode with the sequence lines packed two bases per byte (PackCtx); needs the raw text in memory
     size_t lpr = 4;                       // lines per record in the staged text
     size_t seq_file = (size_t)-1; uint64_t seq_raw_lines = 0;   // sequencer: file in hand, its raw lines so far
     // stitch(): a line in progress across chunk ends, the sequence length waiting for its quality line, the last two lines' lengths
@@ -943,8 +952,13 @@ struct BlockFeeder {
     void stitch(const Slot& sl, int ph0);
 
     BlockFeeder(int device_, const std::vector<std::string>& files, size_t chunk_bytes, unsigned n_slots, unsigned n_readers, unsigned n_inflate,
-                bool two_line_mode = false);
+                bool two_line_mode = false, bool pack_mode = false);
     ~BlockFeeder();
+    // where in its line byte `off` of a file lies: the readers look back for the line's start (mapped file / inflated image)
+    static size_t line_pos(const uint8_t* file_base, uint64_t off) {
+        const void* q = off ? memrchr(file_base, '\n', (size_t)off) : nullptr;
+        return q ? (size_t)(file_base + off - ((const uint8_t*)q + 1)) : (size_t)off;
+    }
     void reader_loop();
     bool claim(Task& t);
     bool next(Block& b);
@@ -1183,11 +1197,79 @@ struct LabelWriters {  // the per-label writers of trim_matches (trim.rs:356-446
     }
 };
 
+// Packed staging (BB_FASTQ_PACKED, include/barbell_amd_fastq.h): the kernels only ever look at a read character's IUPAC base set, so the
+// readers keep exactly that — two 4-bit codes per byte — and the sequence lines cross PCIe at half their size again (~2 KB per 4-kb read;
+// annotator.rs:125-127 hands `demux` the bytes, nothing downstream of it reports them).  Pairs are aligned to the START of a line, so that
+// the packed chunks still concatenate to the packed stream: a reader knows where in its line the chunk's first byte lies (it looks back in
+// the mapped file / inflated image for the line's start), leaves a first byte at an odd position to the chunk before, and pairs a last
+// unpaired base with the first byte of the chunk after (two bytes of look-ahead tell a base from a line end).
+struct PackCtx {
+    size_t line_pos0 = 0;      // index within its line of the chunk's first byte (used when that byte lies in a sequence line)
+    size_t after = 0;          // bytes readable beyond the chunk's end (0: the chunk ends the file)
+    bool prev_is_cr = false;   // the byte before the chunk is '\r' (a chunk that starts with the '\n' of a "\r\n": the '\r' is not a base of the line)
+    bool unpackable = false;   // out: two adjacent non-IUPAC characters would pack to '\n'; the run falls back to the plain two-line form
+};
+static const uint8_t* base_code_table() {
+    static const std::array<uint8_t, 256> T = []() {
+        std::array<uint8_t, 256> t{};
+        const char* letters = "ACGTURYSWKMBDHVN";
+        const uint8_t codes[16] = {1, 2, 4, 8, 8, 5, 10, 6, 9, 12, 3, 14, 13, 11, 7, 15};   // bb_text_code (bb_common.h): A=1 C=2 G=4 T=8 and unions; X and non-letters 0
+        for (int i = 0; i < 16; ++i) { t[(uint8_t)letters[i]] = codes[i]; t[(uint8_t)(letters[i] | 0x20)] = codes[i]; }
+        return t;
+    }();
+    return T.data();
+}
+// 32 characters -> 16 packed bytes with AVX2 (the readers pack ~50 GB/s of sequence text at 12 M reads/s: a byte-wise table walk was the slowest
+// stage of the whole FASTQ -> TSV pipeline).  Letters fold to upper case (c & 0xDF), 'A'..'Z' index two 16-entry vpshufb tables, anything
+// else is 0; vpmaddubsw forms (c0 << 4) + (c1 ^ 0xA) per pair.  Returns false if some pair was (0, 0) (no packed form).
+__attribute__((target("avx2"))) static bool pack32_avx2(uint8_t* out, const uint8_t* in) {
+    const __m256i T0 = _mm256_setr_epi8(0, 1, 14, 2, 13, 0, 0, 4, 11, 0, 0, 12, 0, 3, 15, 0, 0, 1, 14, 2, 13, 0, 0, 4, 11, 0, 0, 12, 0, 3, 15, 0);   // @ A B C D E F G H I J K L M N O
+    const __m256i T1 = _mm256_setr_epi8(0, 0, 5, 6, 8, 8, 7, 9, 0, 10, 0, 0, 0, 0, 0, 0, 0, 0, 5, 6, 8, 8, 7, 9, 0, 10, 0, 0, 0, 0, 0, 0);          // P Q R S T U V W X Y Z
+    const __m256i x = _mm256_loadu_si256((const __m256i*)in);
+    const __m256i v = _mm256_xor_si256(_mm256_and_si256(x, _mm256_set1_epi8((char)0xDF)), _mm256_set1_epi8(0x40));   // letters: 1..26
+    const __m256i vm1 = _mm256_sub_epi8(v, _mm256_set1_epi8(1));
+    const __m256i valid = _mm256_cmpeq_epi8(_mm256_min_epu8(vm1, _mm256_set1_epi8(25)), vm1);
+    const __m256i r = _mm256_blendv_epi8(_mm256_shuffle_epi8(T0, v), _mm256_shuffle_epi8(T1, v), _mm256_slli_epi16(v, 3));
+    const __m256i c = _mm256_and_si256(r, valid);
+    const bool ok = _mm256_movemask_epi8(_mm256_cmpeq_epi16(c, _mm256_setzero_si256())) == 0;
+    const __m256i m = _mm256_maddubs_epi16(_mm256_xor_si256(c, _mm256_set1_epi16(0x0A00)), _mm256_set1_epi16(0x0110));   // c0 * 16 + (c1 ^ 0xA) * 1
+    const __m256i pk = _mm256_permute4x64_epi64(_mm256_packus_epi16(m, m), 0x08);
+    _mm_storeu_si128((__m128i*)out, _mm256_castsi256_si128(pk));
+    return ok;
+}
+static const bool g_have_avx2 = __builtin_cpu_supports("avx2") && !getenv("BARBELL_AMD_NO_AVX2");
+// the bases [b, e) of a sequence line, b at an even position of the line, as packed bytes; `next` pairs with a last unpaired base (15 = none)
+static inline size_t pack_bases(uint8_t* out, const uint8_t* b, const uint8_t* e, uint8_t next, bool& unpackable) {
+    const uint8_t* C = base_code_table();
+    size_t d = 0;
+    uint8_t z = 0xFF;   // AND of (c0 | c1) != 0 over the pairs, folded: becomes 0 if some pair was (0, 0)
+    if (g_have_avx2) {
+        bool ok = true;
+        for (; b + 32 <= e; b += 32, d += 16) ok &= pack32_avx2(out + d, b);
+        if (!ok) z = 0;
+    }
+    for (; b + 1 < e; b += 2) {
+        const uint8_t c0 = C[b[0]], c1 = C[b[1]];
+        z &= (uint8_t)((c0 | c1) ? 0xFF : 0);
+        out[d++] = (uint8_t)((c0 << 4) | (c1 ^ 0xA));
+    }
+    if (b < e) {
+        const uint8_t c0 = C[b[0]];
+        z &= (uint8_t)((c0 | next) ? 0xFF : 0);
+        out[d++] = (uint8_t)((c0 << 4) | (next ^ 0xA));
+    }
+    if (!z) unpackable = true;
+    return d;
+}
+
 // keeps the bytes of the lines in phase 0 and 1 (header, sequence) of a chunk whose first byte lies in a line of phase ph0; in
 // place when out == buf (the write position never passes the read position), or straight from a mapping of the file.  nl_kept / nl_all: newlines kept / seen; bad: a line that starts
 // inside the chunk in phase 0 / 2 does not start with '@' / '+'.
-static size_t compact_two_line(uint8_t* out, const uint8_t* buf, size_t n, int ph0, size_t& nl_kept, size_t& nl_all, bool& bad, TwoLineSummary& S) {
+// pk != nullptr: sequence lines packed (never in place: out and buf must not overlap; buf[n .. n + pk->after) must be readable).
+static size_t compact_two_line(uint8_t* out, const uint8_t* buf, size_t n, int ph0, size_t& nl_kept, size_t& nl_all, bool& bad, TwoLineSummary& S,
+                               PackCtx* pk = nullptr) {
     size_t d = 0, p = 0;
+    bool hdr_blank = false;   // the header line of the record in hand was empty (blank lines after the last record stay blank lines)
     int ph = ph0 & 3;
     bool line_start = false;  // the first line may be the tail of one that began in the previous chunk
     nl_kept = nl_all = 0; bad = false;
@@ -1213,7 +1295,33 @@ static size_t compact_two_line(uint8_t* out, const uint8_t* buf, size_t n, int p
                 S.last2[0] = S.last2[1]; S.last2[1] = len;
             }
         } else { S.tail_raw = n - p; S.tail_last = buf[n - 1]; if (nl_all == 0) { S.head_raw = n - p; S.head_last = buf[n - 1]; } }
-        if (ph < 2) {
+        if (ph == 1 && pk) {
+            // the line's bases inside the chunk: [p, se); a '\r' belongs to the line end if a '\n' (or the end of the file) follows it
+            size_t se = q ? (size_t)(q - buf) : n;
+            if (se > p && buf[se - 1] == '\r' && (q || pk->after == 0 || buf[n] == '\n')) --se;
+            const size_t i0 = nl_all == 0 ? pk->line_pos0 : 0;    // where in its line the segment starts
+            size_t b = p;
+            if ((i0 & 1u) && se > b) ++b;                          // an odd first base went into the last pair of the chunk before
+            uint8_t next = 15;                                     // pairs with a last unpaired base: nothing, unless the line goes on in the next chunk
+            if (!q && ((se - b) & 1u) && se == n && pk->after > 0) {
+                const bool eol = buf[n] == '\n' || (buf[n] == '\r' && (pk->after == 1 || buf[n + 1] == '\n'));
+                if (!eol) next = base_code_table()[buf[n]];
+            }
+            if (i0 == 0 && se == p && q && hdr_blank) {            // blank line after a blank header line: not a record, stays as it is
+                out[d++] = '\n'; ++nl_kept;
+            } else {
+                d += pack_bases(out + d, buf + b, buf + se, next, pk->unpackable);
+                if (q || pk->after == 0) {                          // the line ends here (its '\n', or the end of a file without one): parity terminator
+                    const size_t cr_before = (nl_all == 0 && i0 > 0 && q == buf + p && pk->prev_is_cr) ? 1 : 0;   // "\r" | "\n" split over two chunks
+                    out[d++] = ((i0 - cr_before + (se - p)) & 1u) ? 'O' : 'E';
+                    if (q) { out[d++] = '\n'; ++nl_kept; }
+                }
+            }
+        } else if (ph < 2) {
+            if (ph == 0 && pk) {   // a whole header line (not the tail of one that began in the chunk before) without a character
+                const size_t raw = q ? (size_t)(q - buf) - p : 1;
+                hdr_blank = q && raw - ((raw && buf[p + raw - 1] == '\r') ? 1 : 0) == 0 && (nl_all > 0 || pk->line_pos0 == 0);
+            }
             if (out + d != buf + p) memmove(out + d, buf + p, e - p);
             d += e - p;
             if (q) ++nl_kept;
@@ -1299,8 +1407,8 @@ static bool sniff_gzip(const std::string& path) {  // magic bytes, not the file 
 }
 
 BlockFeeder::BlockFeeder(int device_, const std::vector<std::string>& files, size_t chunk_bytes, unsigned n_slots, unsigned n_readers, unsigned n_inflate,
-                         bool two_line_mode)
-    : device(device_), paths(files), chunk(chunk_bytes), two_line(two_line_mode), lpr(two_line_mode ? 2 : 4) {
+                         bool two_line_mode, bool pack_mode)
+    : device(device_), paths(files), chunk(chunk_bytes), two_line(two_line_mode), pack(two_line_mode && pack_mode), lpr(two_line_mode ? 2 : 4) {
     if (const char* e = getenv("BARBELL_AMD_HEAD_BYTES")) HEAD = (size_t)std::max(16L, atol(e));
     is_gz.resize(paths.size()); fds.assign(paths.size(), -1); sizes.assign(paths.size(), 0); size_known.assign(paths.size(), 0);
     maps.assign(paths.size(), nullptr);
@@ -1324,6 +1432,8 @@ BlockFeeder::BlockFeeder(int device_, const std::vector<std::string>& files, siz
             if (m != MAP_FAILED) { maps[i] = (const uint8_t*)m; (void)madvise(m, (size_t)st.st_size, MADV_SEQUENTIAL); }
         }
     }
+    for (size_t i = 0; i < paths.size(); ++i)
+        if (!is_gz[i] && !maps[i] && sizes[i] > 0) pack = false;   // a plain file that could not be mapped is read with pread: no look-back, no packing
     bool any_gz = false;
     for (char g : is_gz) any_gz = any_gz || g;
     if (any_gz) inflater = std::make_unique<ParallelInflater>(paths, is_gz, n_inflate);
@@ -1347,8 +1457,27 @@ BlockFeeder::~BlockFeeder() {
     inflater.reset();
     if (!keep_slots)
         for (auto& sl : slots) if (sl.p) { if (pageable) free(sl.p); else bb_host_free_on(device, sl.p); }
-    if (!keep_slots)  // (a 32 GB mapping is 8 M page-table entries to take down: left to the exit as well)
+    if (!keep_slots) {
         for (size_t i = 0; i < maps.size(); ++i) if (maps[i]) munmap((void*)maps[i], (size_t)sizes[i]);
+    } else {
+        // The process is about to exit and would take the mappings down by itself — on ONE thread: 128 GB of FASTQ are 32 M page-table
+        // entries, 1.0 s of a 2.6 s run on 16 M reads.  Thirty-two threads drop them side by side in a few tens of milliseconds (the page cache
+        // keeps the data).
+        std::vector<std::thread> zap;
+        const uintptr_t pg = (uintptr_t)sysconf(_SC_PAGESIZE);
+        for (size_t i = 0; i < maps.size(); ++i) {
+            if (!maps[i] || sizes[i] < (64u << 20)) continue;
+            const unsigned parts = 32;
+            const uint64_t part = ((sizes[i] / parts) + pg - 1) & ~(uint64_t)(pg - 1);
+            for (unsigned k = 0; k < parts; ++k) {
+                const uint64_t a = (uint64_t)k * part, b = std::min<uint64_t>(sizes[i], a + part);
+                if (a >= b) break;
+                const uint8_t* base = maps[i];
+                zap.emplace_back([base, a, b]() { (void)madvise((void*)(base + a), (size_t)(b - a), MADV_DONTNEED); });
+            }
+        }
+        for (auto& t : zap) t.join();
+    }
     for (int fd : fds) if (fd >= 0) close(fd);
 }
 // next chunk of the stream; gzip files are inflated whole (a few files ahead) and chunked from memory
@@ -1408,14 +1537,33 @@ void BlockFeeder::reader_loop() {
                     throw BarbellError(BB_E_INVALID, "FASTQ file '" + paths[t.file] + "' shrank while it was read");
                 src = maps[t.file] + t.off;
             }
+            static const bool map_populate = getenv("BARBELL_AMD_MAP_POPULATE") != nullptr;
+            if (map_populate && src && maps[t.file] && t.len) {   // experiment: the chunk's pages mapped by one call instead of one fault per 64 KB
+                const uintptr_t pg = (uintptr_t)sysconf(_SC_PAGESIZE);
+                const uintptr_t a0 = (uintptr_t)src & ~(pg - 1), a1 = ((uintptr_t)src + t.len + pg - 1) & ~(pg - 1);
+                (void)madvise((void*)a0, (size_t)(a1 - a0), 22 /* MADV_POPULATE_READ */);
+            }
             size_t got_len = t.len, nl = 0, raw_nl = 0;
             int ph0 = 0;
             bool bad = false;
             TwoLineSummary sum;
+            bool unpackable = false;
             if (two_line && src) {
-                ph0 = guess_phase(src, t.len, t.off == 0);
-                if (ph0 >= 0) got_len = compact_two_line(dst, src, t.len, ph0, nl, raw_nl, bad, sum);
-                else { if (t.len) memcpy(dst, src, t.len); raw_nl = count_nl(dst, t.len); }   // left raw: the sequencer compacts it with the true phase
+                // the phase is read off the first lines from the chunk's start; they may lie beyond its end (a chunk shorter than three lines):
+                // the mapped file / inflated image can be read ahead
+                ph0 = guess_phase(src, t.len + (size_t)std::min<uint64_t>(sizes[t.file] - (t.off + t.len), 1u << 20), t.off == 0);
+                if (ph0 < 0 && t.off > 0) {   // too few lines from here to the end of the file: read the phase off the text BEFORE the chunk and count on
+                    const uint64_t back = std::min<uint64_t>(t.off, 4u << 20);
+                    const uint8_t* w = src - back;
+                    const int pw = guess_phase(w, (size_t)(sizes[t.file] - (t.off - back)), t.off == back);
+                    if (pw >= 0) ph0 = (int)((pw + count_nl(w, (size_t)back)) & 3u);
+                }
+                if (ph0 >= 0) {
+                    PackCtx pk;
+                    if (pack) { pk.line_pos0 = line_pos(src - t.off, t.off); pk.after = (size_t)(sizes[t.file] - (t.off + t.len)); pk.prev_is_cr = t.off > 0 && src[-1] == '\r'; }
+                    got_len = compact_two_line(dst, src, t.len, ph0, nl, raw_nl, bad, sum, pack ? &pk : nullptr);
+                    unpackable = pk.unpackable;
+                } else { if (t.len) memcpy(dst, src, t.len); raw_nl = count_nl(dst, t.len); }   // left raw: the sequencer compacts it with the true phase
             } else {
                 if (src) { if (t.len) memcpy(dst, src, t.len); }
                 else {
@@ -1433,6 +1581,15 @@ void BlockFeeder::reader_loop() {
                     else raw_nl = count_nl(dst, t.len);
                 } else nl = count_nl(dst, t.len);
             }
+            static const bool map_drop = getenv("BARBELL_AMD_MAP_DROP") != nullptr;
+            if (src && maps[t.file] && t.len && map_drop) {
+                // BARBELL_AMD_MAP_DROP=1: this chunk's pages of the mapping dropped as soon as it is staged (a process that must not hold page-table
+                // entries for the whole input).  Measured on 8 M reads: steady state 12.5 -> 11.3 M reads/s (the shoot-downs disturb the upload
+                // threads); by default the mapping is taken down at the end instead, by all readers at once (~BlockFeeder)
+                const uintptr_t pg = (uintptr_t)sysconf(_SC_PAGESIZE);
+                const uintptr_t a0 = ((uintptr_t)src + pg - 1) & ~(pg - 1), a1 = ((uintptr_t)src + t.len) & ~(pg - 1);
+                if (a1 > a0) (void)madvise((void*)a0, (size_t)(a1 - a0), MADV_DONTNEED);
+            }
             if (is_gz[t.file]) {
                 bool last_copy;
                 { std::lock_guard<std::mutex> lk(mu); last_copy = --chunks_left[t.file] == 0; }
@@ -1441,7 +1598,7 @@ void BlockFeeder::reader_loop() {
             {
                 std::lock_guard<std::mutex> lk(mu);
                 sl.got = got_len; sl.nl = nl; sl.last = t.last; sl.file = t.file; sl.raw_nl = raw_nl; sl.phase0 = ph0; sl.off = t.off; sl.raw_len = t.len;
-                sl.bad = bad; sl.sum = sum; sl.state = 2;
+                sl.bad = bad; sl.sum = sum; sl.unpackable = unpackable; sl.state = 2;
             }
             cv.notify_all();
         }
@@ -1476,7 +1633,18 @@ bool BlockFeeder::next(Block& b) {
         if (two_line) {   // the reader's guess of the chunk's first phase against the running line count of the file
             if (sl->file != seq_file) { seq_file = sl->file; seq_raw_lines = 0; }
             const int truth = (int)(seq_raw_lines & 3u);
-            if (sl->phase0 != truth) {
+            if (sl->phase0 != truth && pack) {
+                // packed staging: the chunk is redone from the mapped file under the true phase (look-back and look-ahead need the file); a
+                // gzip image may be gone by now: the run then falls back to the plain two-line form
+                if (is_gz[sl->file] || !maps[sl->file]) sl->unpackable = true;
+                else {
+                    PackCtx pk;
+                    pk.line_pos0 = line_pos(maps[sl->file], sl->off); pk.after = (size_t)(sizes[sl->file] - (sl->off + sl->raw_len));
+                    pk.prev_is_cr = sl->off > 0 && maps[sl->file][sl->off - 1] == '\r';
+                    sl->got = compact_two_line(body, maps[sl->file] + sl->off, sl->raw_len, truth, sl->nl, sl->raw_nl, sl->bad, sl->sum, &pk);
+                    sl->unpackable = pk.unpackable;
+                }
+            } else if (sl->phase0 != truth) {
                 if (sl->phase0 >= 0) {  // compacted under a wrong phase: the raw bytes are needed again
                     if (is_gz[sl->file]) throw BarbellError(BB_E_FASTQ, "'" + paths[sl->file] + "': line layout not recognised while dropping quality lines; rerun with --no-compact");
                     if (maps[sl->file]) memcpy(body, maps[sl->file] + sl->off, sl->raw_len);
@@ -1490,6 +1658,11 @@ bool BlockFeeder::next(Block& b) {
                     }
                 }
                 sl->got = compact_two_line(body, body, sl->raw_len, truth, sl->nl, sl->raw_nl, sl->bad, sl->sum);
+            }
+            if (sl->unpackable) {
+                if (getenv("BARBELL_AMD_PROFILE")) fprintf(stderr, "profile: chunk at %llu of '%s' (%zu bytes, phase guessed %d, true %d) has no packed form\n",
+                                                           (unsigned long long)sl->off, paths[sl->file].c_str(), sl->raw_len, sl->phase0, truth);
+                throw PackFallback();
             }
             if (sl->bad) throw BarbellError(BB_E_FASTQ, "Input FASTQ parsing failed: '" + paths[sl->file] + "' holds a record that is not a 4-line FASTQ record");
             stitch(*sl, truth);
@@ -1571,8 +1744,51 @@ std::vector<uint64_t> allreduce_counts(const std::vector<Demuxer*>& dms, std::st
 std::vector<uint64_t> allreduce_counts_shards(Demuxer* lead, const std::vector<uint64_t>& local, uint32_t rank, uint32_t world,
                                               const std::string& base, std::string& how);
 
+// `barbell-amd stage` (tests, no GPU): the text the reader threads and the sequencer stage for upload — the blocks of whole records, one after
+// the other — written to a file.  Returns the form that was staged: 4 (4-line text), 2 (two-line), 1 (two-line, sequence lines packed); a
+// packed run that meets input without a packed form falls back to the two-line form like annotate() does.
+int stage_blocks(const std::vector<std::string>& read_files, size_t block_bytes, unsigned n_threads, bool two_line, bool pack, const std::string& out_path,
+                 size_t& n_blocks) {
+    for (int attempt = 0;; ++attempt) {
+        FILE* f = fopen(out_path.c_str(), "wb");
+        if (!f) throw BarbellError(BB_E_INVALID, "Failed to create '" + out_path + "'");
+        n_blocks = 0;
+        try {
+            BlockFeeder feeder(-1, read_files, std::max<size_t>(block_bytes, 16), 8, std::max(1u, n_threads), std::max(1u, n_threads), two_line, pack);
+            const bool packed = feeder.pack;
+            BlockFeeder::Block b;
+            while (feeder.next(b)) {
+                if (b.len && fwrite(b.data, 1, b.len, f) != b.len) { fclose(f); throw BarbellError(BB_E_INVALID, "write failed"); }
+                ++n_blocks;
+                feeder.release(b.slot);
+            }
+            fclose(f);
+            return packed ? 1 : (two_line ? 2 : 4);
+        } catch (const PackFallback&) {
+            fclose(f);
+            if (attempt) throw BarbellError(BB_E_INVALID, "staging failed twice");
+            pack = false;
+        } catch (...) { fclose(f); throw; }
+    }
+}
+
+static AnnotateStats annotate_once(const std::vector<std::string>& read_files, const std::string& out_file,
+                                   std::vector<BarcodeGroup> query_groups, const AnnotateConfig& config);
 AnnotateStats annotate(const std::vector<std::string>& read_files, const std::string& out_file,
                        std::vector<BarcodeGroup> query_groups, const AnnotateConfig& config) {
+    try {
+        return annotate_once(read_files, out_file, query_groups, config);
+    } catch (const PackFallback&) {
+        // a read with two adjacent characters that are not IUPAC letters (or a gzip chunk whose line layout could not be told) has no packed
+        // form: the same run again with the sequence lines as text — every output file is created anew
+        if (config.verbose || getenv("BARBELL_AMD_PROFILE")) fputs("note: input not representable in the packed upload form; staging the sequence lines as text\n", stderr);
+        AnnotateConfig plain = config;
+        plain.pack_upload = false;
+        return annotate_once(read_files, out_file, std::move(query_groups), plain);
+    }
+}
+static AnnotateStats annotate_once(const std::vector<std::string>& read_files, const std::string& out_file,
+                                   std::vector<BarcodeGroup> query_groups, const AnnotateConfig& config) {
     if (read_files.empty()) throw BarbellError(BB_E_INVALID, "No FASTQ input files provided");  // io.rs:20-26
     const bool filtering = !config.filter_patterns.empty();
     const bool trimming = config.trim.has_value();
@@ -1593,7 +1809,9 @@ AnnotateStats annotate(const std::vector<std::string>& read_files, const std::st
     // two-line mode: a slot is about half full and a chunk costs its reader a pass over the text, so twice the slots and readers
     // host_cut: a slot also waits for the writer threads (at most 4 blocks there), and the last holder may be one of them
     auto feeder_p = std::make_shared<BlockFeeder>(devs[0], read_files, block, (unsigned)((two_line ? 2 : 1) * (3 * G + 2) + (host_cut ? 6 : 0)),
-                                                  std::min<unsigned>(std::max(1u, config.n_threads), 32u), config.n_threads, two_line);
+                                                  std::min<unsigned>(std::max(1u, config.n_threads), 32u), config.n_threads, two_line,
+                                                  config.pack_upload && !getenv("BARBELL_AMD_NO_PACK"));
+    const bool packed = feeder_p->pack;   // two bases per byte in the sequence lines (needs the raw text in memory: mapped or inflated)
     feeder_p->keep_slots = config.process_exits_after;
     const double t_feeder_up = now0();
     std::vector<std::unique_ptr<Demuxer>> dms(G);
@@ -1669,7 +1887,7 @@ AnnotateStats annotate(const std::vector<std::string>& read_files, const std::st
             feeder->release(blk.slot);
             return R;
         }
-        const auto ing = dm.ingest(blk.data, blk.len, true, want_ids, two_line);  // blocks hold whole records only
+        const auto ing = dm.ingest(blk.data, blk.len, true, want_ids, two_line, packed);  // blocks hold whole records only
         std::shared_ptr<void> text_hold;   // host_cut: the slot stays until the writer threads have cut the block's records out of it
         if (host_cut) {
             const int slot = blk.slot;

@@ -165,7 +165,7 @@ public:
     // ingest() parses the block on the GPU (bb_fastq_ingest) and fetches only the headers; the *_ingested
     // calls run on the batch it left in HBM and download rows / verdicts / rendered text.
     struct Ingested { bb_fastq_info info{}; std::vector<std::string> ids; };
-    Ingested ingest(const uint8_t* text, uint64_t len, bool final_block, bool want_ids = true, bool two_line = false);
+    Ingested ingest(const uint8_t* text, uint64_t len, bool final_block, bool want_ids = true, bool two_line = false, bool packed = false);
     // annotate the ingested batch; rows stay in HBM, their POD copy is rows() (no strings are built)
     uint64_t annotate_ingested();
     const bb_row* rows() const { return rows_.data(); }
@@ -227,11 +227,14 @@ struct AnnotateConfig {  // config.rs:3-12 with the CLI defaults of bin/main.rs:
     double min_score = 0.2, min_score_diff = 0.1;
     bool use_extended = false;
     size_t batch_reads = 0;               // if set: block_bytes = batch_reads * 4096 (kept for CLI compatibility)
-    size_t block_bytes = 128u << 20;      // raw FASTQ text handed to the GPU per ingest call.  Page-locked memory: 3 slots per context + 2 (twice
+    size_t block_bytes = 256u << 20;      // raw FASTQ text handed to the GPU per ingest call (round 5: 256 MiB — a block costs ~2.5 ms of fixed work on its
+                                          // context whatever its size; 128 MiB blocks held the pipeline at 11.1 M reads/s, 256 MiB at 11.8 M).  Page-locked memory: 3 slots per context + 2 (twice
                                           // that when the quality lines are dropped on the host), each block_bytes + 16 MiB or the largest input
                                           // file if that is smaller — 1.2 GiB at the defaults (2 contexts), 6 GiB at --streams 3 --block-bytes 256Mi;
                                           // with the trim step and host_cut six slots more (blocks wait in them for the file writers)
     bool compact_upload = true;           // without the trim step: drop the '+' and quality lines on the host (half the PCIe bytes); --no-compact
+    bool pack_upload = true;              // ... and stage the sequence lines two bases per byte (BB_FASTQ_PACKED: a quarter of the PCIe bytes; the kernels
+                                          // only look at a character's IUPAC base set); --no-pack.  Falls back by itself where the form cannot hold the input
     bool host_cut = true;                 // trim step: the GPU plans (slices, labels, offsets), the threads that write the per-label files cut the
                                           // records out of the block's own page-locked text — the rendered records (as many bytes as went up) do
                                           // not come back over PCIe.  false (--gpu-render): bb_trim_batch_dev renders them in HBM and they are downloaded
@@ -270,6 +273,8 @@ struct AnnotateStats {
     std::string counts_reduce;                              // "rccl" | "host" | "single": how the histogram was summed
     double seconds_pipeline = 0;                            // first block read .. last block committed (steady state, no start-up)
 };
+int stage_blocks(const std::vector<std::string>& read_files, size_t block_bytes, unsigned n_threads, bool two_line, bool pack, const std::string& out_path,
+                 size_t& n_blocks);   // `barbell-amd stage`: what the host stages for upload, to a file (no GPU); returns 4 / 2 / 1 (packed)
 void shard_rendezvous_reset(const std::string& rccl_id, uint32_t rank);   // bb_rccl.cpp; call at program start of a --shard R/W --rccl-id run
 std::vector<std::string> inspect_summary(const AnnotateStats& st, size_t top_n);  // the lines of inspect.rs:186-205
 

@@ -1306,6 +1306,12 @@ int bbo_fastq_parse(const uint8_t* text, uint64_t len, int final_block, bb_fastq
             break;
         }
         for (int i = 0; i < lpr; ++i) if (le[i] > ls[i] && text[le[i] - 1] == '\r') --le[i];
+        if (final_block) {   /* blank lines after the last record: nothing from here to the end of the stream but line ends (in the two-line form
+                                two of them would otherwise be taken for a record) */
+            int blank = 1;
+            for (uint64_t q = pos; q < len && blank; ++q) if (text[q] != '\n' && text[q] != '\r') blank = 0;
+            if (blank) { pos = len; break; }
+        }
         if (!(le[0] > ls[0] && text[ls[0]] == '@' && (lpr == 2 || (le[2] > ls[2] && text[ls[2]] == '+' && le[1] - ls[1] == le[3] - ls[3])))) {
             if (info->bad_record < 0) info->bad_record = (int64_t)n;
         }

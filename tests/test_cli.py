@@ -165,6 +165,68 @@ def test_cli_tsv_matches_python_and_oracle(tmp_path, gz):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("crlf", [False, True])
+def test_cli_packed_upload_on_odd_characters(tmp_path, crlf):
+    """By default `annotate` uploads the sequence lines two bases per byte (BB_FASTQ_PACKED: the kernels only look at a character's IUPAC base
+    set).  Reads with lower case, N, IUPAC codes, U and single non-IUPAC characters, plain and gzip, LF and CRLF, tiny and ordinary blocks:
+    annotation.tsv is byte-identical to --no-pack (sequence lines as text), --no-compact (whole records) and the oracle's rows.  A read with
+    two adjacent non-IUPAC characters has no packed form: the run falls back by itself, same bytes."""
+    from barbell_amd import annotate as A
+    from oracle import pyoracle as po
+
+    groups = kits.groups_from_kit("SQK-NBD114-96", flank_max_errors=3)
+    n = 1200
+    bases, offsets = A.synth_reads_host(groups, 4711, 1, 2500, 0, n)
+    rng = np.random.default_rng(3)
+    b = bases.copy()
+    for alphabet, rate in ((b"acgtn", 0.06), (b"NRYKMSWBDHVUu", 0.01), (b"*-.1x", 0.003)):
+        pos = np.nonzero(rng.random(len(b)) < rate)[0]
+        b[pos] = rng.choice(np.frombuffer(alphabet, dtype=np.uint8), len(pos))
+    # no two adjacent non-IUPAC characters in the first input (the packed form holds it) ...
+    junk = np.isin(b, np.frombuffer(b"*-.1x", dtype=np.uint8))
+    b[1:][junk[1:] & junk[:-1]] = ord("A")
+    ids = [f"r{i}" for i in range(n)]
+    nl = b"\r\n" if crlf else b"\n"
+
+    def write(path, bb, gz=False):
+        op = gzip.open if gz else open
+        with op(path, "wb") as f:
+            for i, rid in enumerate(ids):
+                s_ = bytes(bb[int(offsets[i]):int(offsets[i + 1])])
+                f.write(b"@" + rid.encode() + b" ch=2" + nl + s_ + nl + b"+" + nl + b"I" * len(s_) + nl)
+
+    env = dict(os.environ, BARBELL_AMD_NO_TORCH="1", BARBELL_AMD_PROFILE="1")
+    rows = po.Oracle([g.as_tuple() for g in groups]).annotate(b, offsets, n_threads=os.cpu_count() or 1)
+    want = (A.TSV_HEADER + "\n" + "\n".join(A.format_rows(rows, ids, groups)) + "\n").encode()
+    assert len(rows) > n // 2
+    outs = {}
+    for gz in (False, True):
+        fq = tmp_path / ("r.fastq.gz" if gz else "r.fastq")
+        write(fq, b, gz)
+        for name, extra in (("packed", []), ("packed_small", ["--block-bytes", "3000"]), ("text", ["--no-pack"]), ("whole", ["--no-compact"])):
+            out = tmp_path / f"{name}{int(gz)}.tsv"
+            r = subprocess.run([CLI, "annotate", "-i", str(fq), "-o", str(out), "--kit", "SQK-NBD114-96", "--flank-max-errors", "3"] + extra,
+                               capture_output=True, text=True, env=env)
+            assert r.returncode == 0, r.stderr
+            assert "not representable" not in r.stderr
+            assert out.read_bytes() == want, (name, gz)
+    # ... and two adjacent ones in the second: packed staging gives up, the run starts over with text lines, same rows as the oracle's
+    b2 = b.copy()
+    k = int(offsets[n // 2]) + 10
+    b2[k:k + 2] = np.frombuffer(b"**", dtype=np.uint8)
+    if (k - int(offsets[n // 2])) % 2:
+        b2[k + 2] = ord("*")            # whatever the alignment, one pair of the line is (junk, junk)
+    fq2 = tmp_path / "r2.fastq"
+    write(fq2, b2)
+    out = tmp_path / "fallback.tsv"
+    r = subprocess.run([CLI, "annotate", "-i", str(fq2), "-o", str(out), "--kit", "SQK-NBD114-96", "--flank-max-errors", "3", "--block-bytes", "200000"],
+                       capture_output=True, text=True, env=env)
+    assert r.returncode == 0 and "not representable in the packed upload form" in r.stderr, r.stderr
+    rows2 = po.Oracle([g.as_tuple() for g in groups]).annotate(b2, offsets, n_threads=os.cpu_count() or 1)
+    assert out.read_bytes() == (A.TSV_HEADER + "\n" + "\n".join(A.format_rows(rows2, ids, groups)) + "\n").encode()
+
+
+@pytest.mark.gpu
 def test_cli_custom_dual_end_queries(tmp_path):
     from barbell_amd import annotate as A
     from tests.common import EX, config_groups

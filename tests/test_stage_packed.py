@@ -1,0 +1,106 @@
+"""The C++ host's staging of FASTQ text for upload (bb_host.cpp: reader threads + sequencer), without a GPU: `barbell-amd stage` writes the
+blocks it would upload.  The packed form (BB_FASTQ_PACKED: two 4-bit IUPAC base sets per byte in the sequence lines) must equal the Python
+packer's text of the same records whatever the chunk size, reader count, line ends and file layout — the pairs are aligned to line starts, so
+chunk boundaries inside a sequence line (odd and even positions, the byte before a line end, inside "\\r\\n") must not show."""
+import gzip
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from barbell_amd import fastq as Q
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "barbell_amd", "bin", "barbell-amd")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _built():
+    if not os.path.exists(CLI):
+        import __graft_entry__ as g
+
+        g.build()
+
+
+def stage(files, out, *args, env=None):
+    r = subprocess.run([CLI, "stage", "-i"] + [str(f) for f in files] + ["-o", str(out)] + list(args), capture_output=True, text=True,
+                       env=dict(os.environ, **(env or {})))
+    assert r.returncode == 0, r.stderr
+    if os.environ.get("STAGE_DEBUG"):
+        print(r.args, r.stdout, r.stderr)
+    form, blocks = int(r.stdout.split()[1]), int(r.stdout.split()[3])
+    return form, blocks, open(out, "rb").read()
+
+
+def records(rng, n, lmin, lmax, alphabet=b"ACGT", junk=0.0):
+    recs = []
+    for i in range(n):
+        L = int(rng.integers(lmin, lmax + 1))
+        s = rng.choice(np.frombuffer(alphabet, dtype=np.uint8), L)
+        if junk:
+            pos = np.nonzero(rng.random(L) < junk)[0]
+            pos = pos[np.concatenate([[True], np.diff(pos) > 1])] if len(pos) else pos      # never two adjacent: those have no packed form
+            s[pos] = rng.choice(np.frombuffer(b"*-.1", dtype=np.uint8), len(pos))
+        recs.append(((b"r%d" % i) + (b" ch=%d" % (i % 7) if i % 2 else b""), s.tobytes()))
+    return recs
+
+
+def fastq(recs, nl=b"\n", final_nl=True):
+    t = b"".join(b"@" + h + nl + s + nl + b"+" + nl + b"I" * len(s) + nl for h, s in recs)
+    return t if final_nl else t[: -len(nl)]
+
+
+@pytest.mark.parametrize("nl", [b"\n", b"\r\n"])
+def test_packed_staging_equals_the_python_packer(tmp_path, nl):
+    rng = np.random.default_rng(5)
+    recs = records(rng, 400, 0, 300, b"ACGTNacgtRYKMSWBDHVU", junk=0.01) + records(rng, 3, 5000, 9000)
+    want = Q.pack_two_line(recs, nl)
+    assert want is not None
+    want2 = b"".join(b"@" + h + nl + s + nl for h, s in recs)
+    for final_nl in (True, False):
+        fq = tmp_path / "a.fastq"
+        fq.write_bytes(fastq(recs, nl, final_nl))
+        for block, threads in ((1 << 20, 1), (4096, 3), (1000, 4), (257, 2), (64, 5), (17, 3)):
+            form, blocks, got = stage([fq], tmp_path / "o.bin", "--block-bytes", str(block), "-t", str(threads))
+            assert form == 1, (block, threads)
+            # (without a final newline it is the QUALITY line that lacks it: the staged header and sequence lines are whole either way)
+            assert got == want, (block, threads, final_nl, len(got), len(want))
+            form, blocks, got = stage([fq], tmp_path / "o.bin", "--block-bytes", str(block), "-t", str(threads), "--no-pack")
+            assert form == 2 and got == want2
+    assert len(want) < 0.56 * len(want2)
+
+
+def test_several_files_gzip_and_blank_tails(tmp_path):
+    rng = np.random.default_rng(9)
+    parts = [records(rng, 150, 1, 400), records(rng, 1, 0, 0) + records(rng, 80, 30, 90), records(rng, 60, 200, 900)]
+    files = []
+    for i, recs in enumerate(parts):
+        text = fastq(recs) + (b"\n" if i == 0 else b"\n\n" if i == 2 else b"")      # blank lines after the last record of a file
+        p = tmp_path / f"f{i}.fastq{'.gz' if i == 1 else ''}"
+        with (gzip.open(p, "wb") if i == 1 else open(p, "wb")) as f:
+            f.write(text)
+        files.append(p)
+    for block in (1 << 20, 3000, 100):
+        form, blocks, got = stage(files, tmp_path / "o.bin", "--block-bytes", str(block), "-t", "3")
+        assert form == 1
+        want = b"".join(Q.pack_two_line(recs) + (b"\n" if i == 0 else b"\n\n" if i == 2 else b"") for i, recs in enumerate(parts))
+        assert got == want, block
+
+
+def test_input_without_a_packed_form_falls_back(tmp_path):
+    """two adjacent non-IUPAC characters at an even position of a line would pack to the byte '\\n': the run is staged as two-line text"""
+    rng = np.random.default_rng(2)
+    recs = records(rng, 50, 10, 200)
+    recs[17] = (recs[17][0], b"ACGT**ACGT")
+    fq = tmp_path / "a.fastq"
+    fq.write_bytes(fastq(recs))
+    form, blocks, got = stage([fq], tmp_path / "o.bin", "--block-bytes", "512", "-t", "2")
+    assert form == 2 and got == b"".join(b"@" + h + b"\n" + s + b"\n" for h, s in recs)
+    recs[17] = (recs[17][0], b"ACG**TACGT")      # at an odd position the pair is split over two bytes: packable
+    fq.write_bytes(fastq(recs))
+    form, blocks, got = stage([fq], tmp_path / "o.bin", "--block-bytes", "512", "-t", "2")
+    assert form == 1 and got == Q.pack_two_line(recs)
+    # files read with pread (no mapping) cannot be packed: no look-back
+    form, blocks, got = stage([fq], tmp_path / "o.bin", "--block-bytes", "512", env={"BARBELL_AMD_NO_MMAP": "1"})
+    assert form == 2

@@ -29,6 +29,7 @@ ap.add_argument("read_len", nargs="?", type=int, default=4000)
 ap.add_argument("--kit-run", action="store_true", help="also time `barbell-amd kit` (annotate + inspect + filter + trim)")
 ap.add_argument("--only-kit", action="store_true", help="skip the annotate runs")
 ap.add_argument("--kit-env", action="append", default=[], help="NAME=VALUE[,NAME=VALUE..]: one more kit run (3 streams) under this environment")
+ap.add_argument("--quick", action="store_true", help="only the default operating point (2 streams, 256 MiB blocks), three times, and its text-lines form")
 ap.add_argument("--json")
 ap.add_argument("--dir", default=os.environ.get("TMPDIR", "/tmp"))
 a = ap.parse_args()
@@ -80,10 +81,24 @@ def run(name, cmd):
 
 
 base = [cli, "annotate", "-i", fq, "-o", os.path.join(a.dir, "e2e_a.tsv"), "--kit", "SQK-NBD114-96", "--flank-max-errors", "3"]
-if not a.only_kit:
-    for streams in (1, 2, 3):
-        for bb in (128 << 20, 256 << 20):
+if a.quick:
+    for rep in range(3):
+        run(f"annotate_streams2_block256Mi_t32_rep{rep}", base + ["--streams", "2", "--block-bytes", str(256 << 20), "-t", "32"])
+    run("annotate_text_lines_streams2_block256Mi_t32", base + ["--streams", "2", "--block-bytes", str(256 << 20), "-t", "32", "--no-pack"])
+    best = max(out["runs"], key=lambda k: out["runs"][k]["steady_state_reads_per_s"] or 0)
+    out["best"] = {"run": best, **{k: out["runs"][best][k] for k in ("steady_state_reads_per_s", "wall_reads_per_s", "wall_s")}}
+elif not a.only_kit:
+    for streams in (1, 2, 3, 4):
+        for bb in (128 << 20, 256 << 20, 512 << 20):
             run(f"annotate_streams{streams}_block{bb >> 20}Mi_t32", base + ["--streams", str(streams), "--block-bytes", str(bb), "-t", "32"])
+    # the upload forms side by side (default: header lines + two bases per byte; --no-pack: sequence lines as text; --no-compact: whole records)
+    for name, extra in (("text_lines", ["--no-pack"]), ("whole_records", ["--no-compact"])):
+        run(f"annotate_{name}_streams2_block256Mi_t32", base + ["--streams", "2", "--block-bytes", str(256 << 20), "-t", "32"] + extra)
+    run("annotate_streams2_block256Mi_t64", base + ["--streams", "2", "--block-bytes", str(256 << 20), "-t", "64"])
+    env_keep = env
+    env = dict(env_keep, BARBELL_AMD_PINNED_SLOTS="1")
+    run("annotate_streams2_block256Mi_t32_pinned_slots", base + ["--streams", "2", "--block-bytes", str(256 << 20), "-t", "32"])
+    env = env_keep
     out["tsv_bytes"] = os.path.getsize(os.path.join(a.dir, "e2e_a.tsv"))
     # the host side alone (BARBELL_AMD_FEED_ONLY=1: files -> reader threads -> blocks of whole records in the upload buffers, no GPU call):
     # what ONE host process can feed, i.e. the ceiling of a node's end-to-end rate however many GPUs take the blocks
