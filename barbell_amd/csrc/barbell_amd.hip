@@ -572,16 +572,16 @@ int bb_annotate_batch_dev(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_o
             if (ends[1] < ends[0]) { c->last_error = "offsets are not ascending"; return BB_E_INVALID; }
             flag_words = ((ends[1] - ends[0]) >> 9) + 3ull * n + 3;
             batch_bytes = ends[1] - ends[0];
-            if ((r = grow(c, c->d_flags, c->cap_flags, 2 * flag_words))) return r;
+            uint64_t n_filt = 0;   // one region of flag words per filtered group (their filter passes run as one launch)
+            for (uint32_t g = 0; g < G; ++g) n_filt += c->gdev[g].filt_rows > 0 ? 1 : 0;
+            if ((r = grow(c, c->d_flags, c->cap_flags, 2 * flag_words * n_filt))) return r;
         }
     }
     for (int attempt = 0;; ++attempt) {
         mark(c, K_SCAN);
         HIPCHK(c, hipMemsetAsync(c->d_hitcount, 0, 16, c->stream));
         HIPCHK(c, hipMemsetAsync(c->d_cnt + (M - 1), 0, 4, c->stream));
-        for (uint32_t g = 0; g < G; ++g) {
-            if ((r = bb_launch_scan(c, d_bases, d_offsets, n, g, flag_words, batch_bytes))) return r;
-        }
+        if ((r = bb_launch_scans(c, d_bases, d_offsets, n, flag_words, batch_bytes))) return r;   // every group's flank scan (bb_tu_scan.hip)
         HIPCHK(c, hipGetLastError());
         mark(c, K_PREFIX);
         HIPCHK(c, hipMemcpyAsync(&n_hits, c->d_hitcount, 4, hipMemcpyDeviceToHost, c->stream));

@@ -171,10 +171,10 @@ __device__ __forceinline__ void flank_scan_lane(const uint8_t* __restrict__ base
                                                 uint32_t off_pv0, uint32_t off_ovh, int ovh_steps, int pol_lm,
                                                 uint32_t g, uint32_t n_groups, uint32_t* __restrict__ cnt,
                                                 bb_hit_raw* __restrict__ hits, uint32_t hit_cap, uint32_t* __restrict__ hit_count,
-                                                const uint32_t* s_peq, uint4* s_line /* this wave's [BB_SCAN_LQ][64] */) {
+                                                const uint32_t* s_peq, uint4* s_line /* this wave's [BB_SCAN_LQ][64] */, uint32_t chunk /* which 256 reads */) {
     constexpr int S = (W <= 2 ? 2 : (W <= 4 ? 4 : 8));
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t read = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t read = chunk * 256u + threadIdx.x;
     const bool live = read < n_reads;
     const uint64_t off = live ? offsets[read] : 0ull;
     const uint32_t n = live ? (uint32_t)(offsets[read + 1] - off) : 0u;
@@ -337,17 +337,36 @@ __device__ __forceinline__ void flank_scan_lane(const uint8_t* __restrict__ base
     scan_finish<W, STRAND>(live, n, m, kk, sc, pv, mv, idx, st, hb, ovh, read, g, n_groups, cnt, hits, hit_cap, hit_count, pol_lm, true, ovh_steps);
 }
 
+// The groups of one launch (round 5).  Every group of a context scans the same reads; launched one after the other each pass streamed the
+// batch from HBM again (custom dual-end 3.1 x, SQK-RBK114-96 extended 4.8 x the algorithmic bytes).  One launch now carries all groups of
+// a kind, and the block index is laid out so that the blocks that stream the SAME 256 reads in the SAME direction — one per group — are
+// dispatched back to back onto the SAME XCD (block b is observed to run on XCD b % 8: a speed assumption, never a correctness one): they
+// run side by side and the second to ask for a line finds it in that XCD's L2.
+struct bb_glist { uint32_t n; uint8_t g[28]; };
+// block -> (group index, strand or pass, chunk of 256 reads): blocks lin and lin + 8 sit on one XCD, so `gi` varies fastest there
+__device__ __forceinline__ bool bb_coscheduled(uint32_t lin, uint32_t n_g, uint32_t n_pass, uint32_t n_chunks, uint32_t& gi, uint32_t& pass, uint32_t& chunk) {
+    const uint32_t xcd = lin & 7u, slot = lin >> 3;
+    gi = slot % n_g;
+    const uint32_t rest = slot / n_g;
+    pass = rest % n_pass;
+    chunk = (rest / n_pass) * 8u + xcd;
+    return chunk < n_chunks;
+}
+static inline uint32_t bb_coscheduled_blocks(uint32_t n_g, uint32_t n_pass, uint32_t n_chunks) { return ((n_chunks + 7u) / 8u) * 8u * n_g * n_pass; }
+
 template <int W>
 __global__ __launch_bounds__(256) void k_flank_scan2(const uint8_t* __restrict__ bases, const uint64_t* __restrict__ offsets,
                                                      uint32_t n_reads, const uint8_t* __restrict__ tables,
-                                                     const bb_group_dev* __restrict__ groups, uint32_t g, uint32_t n_groups,
+                                                     const bb_group_dev* __restrict__ groups, bb_glist gl, uint32_t n_groups,
                                                      uint32_t* __restrict__ cnt, bb_hit_raw* __restrict__ hits,
                                                      uint32_t hit_cap, uint32_t* __restrict__ hit_count) {
     constexpr int S = (W <= 2 ? 2 : (W <= 4 ? 4 : 8));
     __shared__ __attribute__((aligned(16))) uint32_t s_peq[256 * S];
     __shared__ __attribute__((aligned(16))) uint4 s_lines[4][BB_SCAN_LQ * 64];
+    uint32_t gi, strand, chunk;
+    if (!bb_coscheduled(blockIdx.x, gl.n, 2u, (n_reads + 255u) / 256u, gi, strand, chunk)) return;
+    const uint32_t g = gl.g[gi];
     const bb_group_dev* G = groups + g;
-    const uint32_t strand = blockIdx.y;
     {
         const uint32_t* src = reinterpret_cast<const uint32_t*>(tables + G->off_peq_flank[strand]);
         for (int i = threadIdx.x; i < 256 * S; i += 256) s_peq[i] = src[i];
@@ -358,9 +377,9 @@ __global__ __launch_bounds__(256) void k_flank_scan2(const uint8_t* __restrict__
     const int m = G->m;
     const uint32_t o_pv0 = G->off_pv0, o_ovh = G->off_ovh;
     if (strand == 0)
-        flank_scan_lane<W, 0>(bases, offsets, n_reads, tables, kk, m, score0, o_pv0, o_ovh, G->ovh_steps, G->pol_lm, g, n_groups, cnt, hits, hit_cap, hit_count, s_peq, line);
+        flank_scan_lane<W, 0>(bases, offsets, n_reads, tables, kk, m, score0, o_pv0, o_ovh, G->ovh_steps, G->pol_lm, g, n_groups, cnt, hits, hit_cap, hit_count, s_peq, line, chunk);
     else
-        flank_scan_lane<W, 1>(bases, offsets, n_reads, tables, kk, m, score0, o_pv0, o_ovh, G->ovh_steps, G->pol_lm, g, n_groups, cnt, hits, hit_cap, hit_count, s_peq, line);
+        flank_scan_lane<W, 1>(bases, offsets, n_reads, tables, kk, m, score0, o_pv0, o_ovh, G->ovh_steps, G->pol_lm, g, n_groups, cnt, hits, hit_cap, hit_count, s_peq, line, chunk);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -396,11 +415,18 @@ __device__ __forceinline__ uint64_t filt_word_base(uint64_t off, uint64_t off0, 
 #endif
 template <bool WIDE>
 __global__ __launch_bounds__(256) void k_flank_filter(const uint8_t* __restrict__ bases, const uint64_t* __restrict__ offsets, uint32_t n_reads,
-                                                      const uint8_t* __restrict__ tables, const bb_group_dev* __restrict__ groups, uint32_t g,
-                                                      uint32_t* __restrict__ flags, uint64_t words_per_strand, unsigned long long* __restrict__ n_flagged) {
+                                                      const uint8_t* __restrict__ tables, const bb_group_dev* __restrict__ groups, bb_glist gl,
+                                                      uint32_t* __restrict__ flags_all, uint64_t words_per_strand, unsigned long long* __restrict__ n_flagged_all) {
     __shared__ uint32_t s_fpeq[WIDE ? 512 : 256];
     __shared__ __attribute__((aligned(16))) uint4 s_lines[4][BB_SCAN_LQ * 64];
     static_assert(BB_SCAN_LQ == 8u, "piece bits assume 128-byte lines");
+    // one block per (group of the launch, 256 reads); the groups' blocks for the same reads co-scheduled on one XCD (bb_coscheduled).
+    // Group gi of the launch writes its flag words into region gi of the array (2 * words_per_strand words each) and counts into its own cell.
+    uint32_t gi, pass_, chunk;
+    if (!bb_coscheduled(blockIdx.x, gl.n, 1u, (n_reads + 255u) / 256u, gi, pass_, chunk)) return;
+    const uint32_t g = gl.g[gi];
+    uint32_t* flags = flags_all + (uint64_t)gi * 2ull * words_per_strand;
+    unsigned long long* n_flagged = n_flagged_all + g;
     const bb_group_dev* G = groups + g;
     const int R = G->filt_rows;
     const int32_t kk = min(G->flank_k, R);  // k >= R: every column qualifies
@@ -422,7 +448,7 @@ __global__ __launch_bounds__(256) void k_flank_filter(const uint8_t* __restrict_
     __syncthreads();
     uint4* s_line = s_lines[threadIdx.x >> 6];
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t read = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t read = chunk * 256u + threadIdx.x;
     const bool live = read < n_reads;
     const uint64_t off0 = offsets[0];
     const uint64_t off = live ? offsets[read] : off0;

@@ -17,7 +17,7 @@
 void bb_launch_timed_begin(bb_ctx* c, hipStream_t st, const char* fmt, ...);
 void bb_launch_timed_end(bb_ctx* c, hipStream_t st);
 int bb_scan_u32(bb_ctx* c, const uint32_t* in, uint32_t* out, uint64_t n);
-int bb_launch_scan(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n, uint32_t g, uint64_t flag_words, uint64_t batch_bytes);
+int bb_launch_scans(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n, uint64_t flag_words, uint64_t batch_bytes);   // the flank scan of every group
 int bb_trace_mode(const bb_ctx* c, uint32_t g);
 void bb_launch_trace(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n_hits, uint32_t gmask, int mode, int W);
 bool bb_takes_lane(const bb_ctx* c, uint32_t g, uint32_t strand, bool wide);

@@ -1,6 +1,7 @@
 // bb_tu_scan.hip — the flank scan's kernels (bb_k_scan.h) and their launches: one translation unit of libbarbell_amd.so (bb_launch.h).
 #include <algorithm>
 #include <cstdlib>
+#include <vector>
 
 #include "bb_launch.h"
 #include "bb_k_scan.h"
@@ -16,64 +17,118 @@ int bb_scan_u32(bb_ctx* c, const uint32_t* in, uint32_t* out, uint64_t n) {
 
 
 namespace {
+// one launch of k_flank_scan2<W> for a list of groups (all of width W), in pieces of at most 28 groups
 template <int W>
-int launch_scan(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n, uint32_t g, uint64_t flag_words, uint64_t batch_bytes) {
-    const uint64_t probed_flagged = c->last_flagged[g], probed_pieces = c->last_pieces[g];
-    c->last_scan_kind[g] = 0; c->last_flagged[g] = 0; c->last_pieces[g] = 2 * ((batch_bytes + 15) / 16);
-    if (c->gdev[g].filt_rows > 0 && c->scan_off[g] > 0 && c->scan_filter != 1) {
-        // the group's last probed batch flagged above the break-even: data like that comes in runs (a library full of adapter-like decoys), so the
-        // next batches skip the filter pass that would be thrown away and the group is probed again after sixteen of them
-        --c->scan_off[g];
-        c->last_scan_kind[g] = 3;
-        c->last_flagged[g] = probed_flagged; c->last_pieces[g] = probed_pieces;   // the counts stay those of the batch that was probed
-    } else if (c->gdev[g].filt_rows > 0) {
-        (void)hipMemsetAsync(c->d_flags, 0, (size_t)2 * flag_words * sizeof(uint32_t), c->stream);  // the filter writes the words that hold a flag
-        (void)hipMemsetAsync(c->d_nflag + g, 0, sizeof(unsigned long long), c->stream);
-        if (c->gdev[g].filt_mode & BB_FILT_WIDE)
-            hipLaunchKernelGGL(k_flank_filter<true>, dim3((n + 255) / 256), dim3(256), 0, c->stream, d_bases, d_offsets, n, (const uint8_t*)c->d_tables,
-                               (const bb_group_dev*)c->d_groups, g, c->d_flags, flag_words, c->d_nflag + g);
-        else
-            hipLaunchKernelGGL(k_flank_filter<false>, dim3((n + 255) / 256), dim3(256), 0, c->stream, d_bases, d_offsets, n, (const uint8_t*)c->d_tables,
-                               (const bb_group_dev*)c->d_groups, g, c->d_flags, flag_words, c->d_nflag + g);
-        // The choice made at bb_create on pseudo-random text is re-made on the batch in hand: the verification's cost grows with
-        // the number of flagged pieces (each costs its columns plus m + k of lead-in; low-complexity text, adapter-like decoys
-        // and chimeric reads flag many), the full scan's does not.  Above the break-even (measured: DESIGN.md §4) the flags are
-        // dropped and the full-height streaming scan does the batch.
-        unsigned long long nf = 0;
-        HIPCHK(c, hipMemcpyAsync(&nf, c->d_nflag + g, sizeof(nf), hipMemcpyDeviceToHost, c->stream));  // a failure must not be read as "no flags"
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        c->last_flagged[g] = nf; c->last_scan_kind[g] = 1;
-        if (c->scan_filter != 1 && (double)nf > c->adapt_frac * (double)c->last_pieces[g]) {
-            c->last_scan_kind[g] = 2;
-            c->scan_off[g] = 16;
-            hipLaunchKernelGGL(k_flank_scan2<W>, dim3((n + 255) / 256, 2), dim3(256), 0, c->stream, d_bases, d_offsets, n,
-                               (const uint8_t*)c->d_tables, (const bb_group_dev*)c->d_groups, g, (uint32_t)c->groups.size(), c->d_cnt,
-                               c->d_raw, c->cap_hits, c->d_hitcount);
-            return BB_OK;
-        }
-        (void)hipMemsetAsync(c->d_vqueue, 0, 2 * sizeof(uint32_t), c->stream);
-        const uint32_t vblocks = std::min((n + 255u) / 256u, (uint32_t)c->n_cus * 3u);  // persistent: lanes draw (read, strand) items from a queue
-        hipLaunchKernelGGL(k_flank_verify<W>, dim3(vblocks, 2), dim3(256), 0, c->stream, d_bases, d_offsets, n,
-                           (const uint8_t*)c->d_tables, (const bb_group_dev*)c->d_groups, g, (uint32_t)c->groups.size(),
-                           (const uint32_t*)c->d_flags, flag_words, c->d_cnt, c->d_raw, c->cap_hits, c->d_hitcount, c->d_vqueue);
-        return BB_OK;
+void launch_scan2(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n, const std::vector<uint32_t>& gs) {
+    for (size_t at = 0; at < gs.size(); at += sizeof(bb_glist::g)) {
+        bb_glist gl{};
+        gl.n = (uint32_t)std::min(gs.size() - at, sizeof(bb_glist::g));
+        for (uint32_t i = 0; i < gl.n; ++i) gl.g[i] = (uint8_t)gs[at + i];
+        hipLaunchKernelGGL(k_flank_scan2<W>, dim3(bb_coscheduled_blocks(gl.n, 2u, (n + 255u) / 256u)), dim3(256), 0, c->stream, d_bases, d_offsets, n,
+                           (const uint8_t*)c->d_tables, (const bb_group_dev*)c->d_groups, gl, (uint32_t)c->groups.size(), c->d_cnt,
+                           c->d_raw, c->cap_hits, c->d_hitcount);
     }
-    hipLaunchKernelGGL(k_flank_scan2<W>, dim3((n + 255) / 256, 2), dim3(256), 0, c->stream, d_bases, d_offsets, n,
-                       (const uint8_t*)c->d_tables, (const bb_group_dev*)c->d_groups, g, (uint32_t)c->groups.size(), c->d_cnt,
-                       c->d_raw, c->cap_hits, c->d_hitcount);
-    return BB_OK;
+}
+void launch_scan2_w(bb_ctx* c, int W, const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n, const std::vector<uint32_t>& gs) {
+    if (gs.empty()) return;
+    switch (W) {
+        case 1: launch_scan2<1>(c, d_bases, d_offsets, n, gs); break;
+        case 2: launch_scan2<2>(c, d_bases, d_offsets, n, gs); break;
+        case 3: launch_scan2<3>(c, d_bases, d_offsets, n, gs); break;
+        case 4: launch_scan2<4>(c, d_bases, d_offsets, n, gs); break;
+        case 5: launch_scan2<5>(c, d_bases, d_offsets, n, gs); break;
+        case 6: launch_scan2<6>(c, d_bases, d_offsets, n, gs); break;
+        case 7: launch_scan2<7>(c, d_bases, d_offsets, n, gs); break;
+        default: launch_scan2<8>(c, d_bases, d_offsets, n, gs); break;
+    }
+}
+template <int W>
+void launch_verify(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n, uint32_t g, const uint32_t* flags, uint64_t flag_words) {
+    (void)hipMemsetAsync(c->d_vqueue, 0, 2 * sizeof(uint32_t), c->stream);
+    const uint32_t vblocks = std::min((n + 255u) / 256u, (uint32_t)c->n_cus * 3u);  // persistent: lanes draw (read, strand) items from a queue
+    hipLaunchKernelGGL(k_flank_verify<W>, dim3(vblocks, 2), dim3(256), 0, c->stream, d_bases, d_offsets, n,
+                       (const uint8_t*)c->d_tables, (const bb_group_dev*)c->d_groups, g, (uint32_t)c->groups.size(),
+                       flags, flag_words, c->d_cnt, c->d_raw, c->cap_hits, c->d_hitcount, c->d_vqueue);
 }
 }  // namespace
 
-int bb_launch_scan(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n, uint32_t g, uint64_t flag_words, uint64_t batch_bytes) {
-    switch (c->gdev[g].W) {
-        case 1: return launch_scan<1>(c, d_bases, d_offsets, n, g, flag_words, batch_bytes);
-        case 2: return launch_scan<2>(c, d_bases, d_offsets, n, g, flag_words, batch_bytes);
-        case 3: return launch_scan<3>(c, d_bases, d_offsets, n, g, flag_words, batch_bytes);
-        case 4: return launch_scan<4>(c, d_bases, d_offsets, n, g, flag_words, batch_bytes);
-        case 5: return launch_scan<5>(c, d_bases, d_offsets, n, g, flag_words, batch_bytes);
-        case 6: return launch_scan<6>(c, d_bases, d_offsets, n, g, flag_words, batch_bytes);
-        case 7: return launch_scan<7>(c, d_bases, d_offsets, n, g, flag_words, batch_bytes);
-        default: return launch_scan<8>(c, d_bases, d_offsets, n, g, flag_words, batch_bytes);
+// The flank scan of EVERY group of the context on one batch (searcher.rs:433-438: `for group in groups { search(flank, read) }`).
+// Groups are sorted by what their scan is — the full-height streaming scan (no filter window says enough, or the group's last probed batch
+// flagged above the break-even), or filter + verification — and each kind goes out as ONE launch whose blocks for the same reads sit on the
+// same XCD (bb_coscheduled): the batch is streamed from HBM once per kind and direction instead of once per group.  The decisions per
+// group (filter or not, back-off, verification or full scan after the filter) are the ones bb_launch_scan made group by group until round 4.
+int bb_launch_scans(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n, uint64_t flag_words, uint64_t batch_bytes) {
+    const uint32_t G = (uint32_t)c->groups.size();
+    std::vector<uint32_t> plain[9], plain2[9], filt[2];   // by width; filt[wide]
+    for (uint32_t g = 0; g < G; ++g) {
+        const uint64_t probed_flagged = c->last_flagged[g], probed_pieces = c->last_pieces[g];
+        c->last_scan_kind[g] = 0; c->last_flagged[g] = 0; c->last_pieces[g] = 2 * ((batch_bytes + 15) / 16);
+        const int W = std::min(8, std::max(1, (int)c->gdev[g].W));
+        if (c->gdev[g].filt_rows > 0 && c->scan_off[g] > 0 && c->scan_filter != 1) {
+            // the group's last probed batch flagged above the break-even: data like that comes in runs (a library full of adapter-like decoys), so the
+            // next batches skip the filter pass that would be thrown away and the group is probed again after sixteen of them
+            --c->scan_off[g];
+            c->last_scan_kind[g] = 3;
+            c->last_flagged[g] = probed_flagged; c->last_pieces[g] = probed_pieces;   // the counts stay those of the batch that was probed
+            plain[W].push_back(g);
+        } else if (c->gdev[g].filt_rows > 0) filt[(c->gdev[g].filt_mode & BB_FILT_WIDE) ? 1 : 0].push_back(g);
+        else plain[W].push_back(g);
     }
+    // flag regions: one per filtered group, in launch order (narrow windows first)
+    std::vector<uint32_t> region(G, 0);
+    const uint32_t n_filt = (uint32_t)(filt[0].size() + filt[1].size());
+    if (n_filt) {
+        (void)hipMemsetAsync(c->d_flags, 0, (size_t)2 * flag_words * n_filt * sizeof(uint32_t), c->stream);  // the filter writes the words that hold a flag
+        (void)hipMemsetAsync(c->d_nflag, 0, sizeof(unsigned long long) * BB_MAX_GROUPS, c->stream);
+        uint32_t reg = 0;
+        for (int wide = 0; wide < 2; ++wide)
+            for (size_t at = 0; at < filt[wide].size(); at += sizeof(bb_glist::g)) {
+                bb_glist gl{};
+                gl.n = (uint32_t)std::min(filt[wide].size() - at, sizeof(bb_glist::g));
+                for (uint32_t i = 0; i < gl.n; ++i) { gl.g[i] = (uint8_t)filt[wide][at + i]; region[filt[wide][at + i]] = reg + i; }
+                uint32_t* fl = c->d_flags + (uint64_t)reg * 2ull * flag_words;
+                const dim3 grid(bb_coscheduled_blocks(gl.n, 1u, (n + 255u) / 256u));
+                if (wide)
+                    hipLaunchKernelGGL(k_flank_filter<true>, grid, dim3(256), 0, c->stream, d_bases, d_offsets, n, (const uint8_t*)c->d_tables,
+                                       (const bb_group_dev*)c->d_groups, gl, fl, flag_words, c->d_nflag);
+                else
+                    hipLaunchKernelGGL(k_flank_filter<false>, grid, dim3(256), 0, c->stream, d_bases, d_offsets, n, (const uint8_t*)c->d_tables,
+                                       (const bb_group_dev*)c->d_groups, gl, fl, flag_words, c->d_nflag);
+                reg += gl.n;
+            }
+    }
+    for (int W = 1; W <= 8; ++W) launch_scan2_w(c, W, d_bases, d_offsets, n, plain[W]);
+    if (n_filt) {
+        // The choice made at bb_create on pseudo-random text is re-made on the batch in hand: the verification's cost grows with
+        // the number of flagged pieces (each costs its columns plus m + k of lead-in; low-complexity text, adapter-like decoys
+        // and chimeric reads flag many), the full scan's does not.  Above the break-even (measured: DESIGN.md §4) the flags are
+        // dropped and the full-height streaming scan does the batch.  One round trip for all groups' counts.
+        unsigned long long nf[BB_MAX_GROUPS];
+        HIPCHK(c, hipMemcpyAsync(nf, c->d_nflag, sizeof(nf), hipMemcpyDeviceToHost, c->stream));  // a failure must not be read as "no flags"
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        for (int wide = 0; wide < 2; ++wide)
+            for (uint32_t g : filt[wide]) {
+                const int W = std::min(8, std::max(1, (int)c->gdev[g].W));
+                c->last_flagged[g] = nf[g]; c->last_scan_kind[g] = 1;
+                if (c->scan_filter != 1 && (double)nf[g] > c->adapt_frac * (double)c->last_pieces[g]) {
+                    c->last_scan_kind[g] = 2;
+                    c->scan_off[g] = 16;
+                    plain2[W].push_back(g);
+                    continue;
+                }
+                const uint32_t* fl = c->d_flags + (uint64_t)region[g] * 2ull * flag_words;
+                switch (W) {
+                    case 1: launch_verify<1>(c, d_bases, d_offsets, n, g, fl, flag_words); break;
+                    case 2: launch_verify<2>(c, d_bases, d_offsets, n, g, fl, flag_words); break;
+                    case 3: launch_verify<3>(c, d_bases, d_offsets, n, g, fl, flag_words); break;
+                    case 4: launch_verify<4>(c, d_bases, d_offsets, n, g, fl, flag_words); break;
+                    case 5: launch_verify<5>(c, d_bases, d_offsets, n, g, fl, flag_words); break;
+                    case 6: launch_verify<6>(c, d_bases, d_offsets, n, g, fl, flag_words); break;
+                    case 7: launch_verify<7>(c, d_bases, d_offsets, n, g, fl, flag_words); break;
+                    default: launch_verify<8>(c, d_bases, d_offsets, n, g, fl, flag_words); break;
+                }
+            }
+        for (int W = 1; W <= 8; ++W) launch_scan2_w(c, W, d_bases, d_offsets, n, plain2[W]);
+    }
+    return BB_OK;
 }
