@@ -1465,16 +1465,24 @@ BlockFeeder::~BlockFeeder() {
         // keeps the data).
         std::vector<std::thread> zap;
         const uintptr_t pg = (uintptr_t)sysconf(_SC_PAGESIZE);
-        for (size_t i = 0; i < maps.size(); ++i) {
-            if (!maps[i] || sizes[i] < (64u << 20)) continue;
-            const unsigned parts = 32;
-            const uint64_t part = ((sizes[i] / parts) + pg - 1) & ~(uint64_t)(pg - 1);
-            for (unsigned k = 0; k < parts; ++k) {
-                const uint64_t a = (uint64_t)k * part, b = std::min<uint64_t>(sizes[i], a + part);
-                if (a >= b) break;
-                const uint8_t* base = maps[i];
-                zap.emplace_back([base, a, b]() { (void)madvise((void*)(base + a), (size_t)(b - a), MADV_DONTNEED); });
+        uint64_t total = 0;
+        for (size_t i = 0; i < maps.size(); ++i) if (maps[i]) total += sizes[i];
+        if (total >= (256u << 20)) {
+            // ranges of at least 64 MiB, at most ~32 of them per run of threads, whatever the number of files
+            const uint64_t part = std::max<uint64_t>(64u << 20, ((total / 32) + pg - 1) & ~(uint64_t)(pg - 1));
+            std::vector<std::pair<const uint8_t*, uint64_t>> ranges;
+            for (size_t i = 0; i < maps.size(); ++i) {
+                if (!maps[i]) continue;
+                for (uint64_t a0 = 0; a0 < sizes[i]; a0 += part) ranges.emplace_back(maps[i] + a0, std::min<uint64_t>(part, sizes[i] - a0));
             }
+            std::atomic<size_t> next_range{0};
+            const unsigned nt = (unsigned)std::min<size_t>(32, ranges.size());
+            for (unsigned k = 0; k < nt; ++k)
+                zap.emplace_back([&ranges, &next_range]() {
+                    for (size_t r; (r = next_range.fetch_add(1)) < ranges.size();) (void)madvise((void*)ranges[r].first, (size_t)ranges[r].second, MADV_DONTNEED);
+                });
+            for (auto& t : zap) t.join();
+            zap.clear();
         }
         for (auto& t : zap) t.join();
     }

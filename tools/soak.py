@@ -21,11 +21,17 @@ first, count = int(sys.argv[1]), int(sys.argv[2])
 bad = 0
 for seed in range(first, first + count):
     rng = np.random.default_rng(seed)
-    cfg = rng.choice(["nbd96", "nbd24", "dual", "rbk24", "left"])
+    cfg = rng.choice(["nbd96", "nbd24", "dual", "rbk24", "left", "rbk96x", "mixed", "mixed"])   # round 5: contexts of several groups of different widths and scan kinds (one launch per kind: bb_launch_scans)
     k = None if rng.random() < 0.2 else int(rng.integers(0, 9))
     if cfg == "nbd96": groups = kits.groups_from_kit("SQK-NBD114-96", flank_max_errors=k)
     elif cfg == "nbd24": groups = kits.groups_from_kit("SQK-NBD114-24", flank_max_errors=k)
     elif cfg == "rbk24": groups = kits.groups_from_kit("SQK-RBK114-24", flank_max_errors=k if k is None or rng.random() < 0.7 else None)
+    elif cfg == "rbk96x": groups = kits.groups_from_kit("SQK-RBK114-96", use_extended=True, flank_max_errors=k if rng.random() < 0.5 else None)
+    elif cfg == "mixed":   # two to five groups drawn from different kits and the examples: widths 2 and 3, filtered and full scans, narrow and wide windows side by side
+        pool = [lambda: kits.groups_from_kit("SQK-NBD114-24", flank_max_errors=k)[0], lambda: kits.groups_from_kit("SQK-RBK114-24", flank_max_errors=None if rng.random() < 0.5 else k)[0],
+                lambda: kits.group_from_fasta(os.path.join(EX, "native_left.fasta"), _abi.BB_FTAG, k), lambda: kits.group_from_fasta(os.path.join(EX, "native_right.fasta"), _abi.BB_RTAG, k),
+                lambda: kits.groups_from_kit("SQK-PCB114-24", flank_max_errors=k)[0], lambda: kits.groups_from_kit("SQK-16S114-24", flank_max_errors=k)[-1]]
+        groups = [pool[int(j)]() for j in rng.permutation(len(pool))[: int(rng.integers(2, 6))]]
     elif cfg == "left": groups = [kits.group_from_fasta(os.path.join(EX, "native_left.fasta"), _abi.BB_FTAG, k)]
     else: groups = [kits.group_from_fasta(os.path.join(EX, "native_left.fasta"), _abi.BB_FTAG, k),
                     kits.group_from_fasta(os.path.join(EX, "native_right.fasta"), _abi.BB_RTAG, k)]
