@@ -1237,7 +1237,7 @@ __attribute__((target("avx2"))) static bool pack32_avx2(uint8_t* out, const uint
     _mm_storeu_si128((__m128i*)out, _mm256_castsi256_si128(pk));
     return ok;
 }
-static const bool g_have_avx2 = __builtin_cpu_supports("avx2") && !getenv("BARBELL_AMD_NO_AVX2");
+static const bool g_have_avx2 = (__builtin_cpu_init(), __builtin_cpu_supports("avx2")) && !getenv("BARBELL_AMD_NO_AVX2");
 // the bases [b, e) of a sequence line, b at an even position of the line, as packed bytes; `next` pairs with a last unpaired base (15 = none)
 static inline size_t pack_bases(uint8_t* out, const uint8_t* b, const uint8_t* e, uint8_t next, bool& unpackable) {
     const uint8_t* C = base_code_table();
