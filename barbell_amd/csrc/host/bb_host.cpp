@@ -1429,7 +1429,11 @@ BlockFeeder::BlockFeeder(int device_, const std::vector<std::string>& files, siz
         sizes[i] = (uint64_t)st.st_size; size_known[i] = 1;
         if (two_line && st.st_size > 0 && !getenv("BARBELL_AMD_NO_MMAP")) {  // the readers compact straight out of the page cache: one pass over the text, no copy of the dropped half
             void* m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fds[i], 0);
-            if (m != MAP_FAILED) { maps[i] = (const uint8_t*)m; (void)madvise(m, (size_t)st.st_size, MADV_SEQUENTIAL); }
+            if (m != MAP_FAILED) {
+                maps[i] = (const uint8_t*)m;
+                (void)madvise(m, (size_t)st.st_size, MADV_SEQUENTIAL);
+            }
+            }
         }
     }
     for (size_t i = 0; i < paths.size(); ++i)
