@@ -1433,7 +1433,6 @@ BlockFeeder::BlockFeeder(int device_, const std::vector<std::string>& files, siz
                 maps[i] = (const uint8_t*)m;
                 (void)madvise(m, (size_t)st.st_size, MADV_SEQUENTIAL);
             }
-            }
         }
     }
     for (size_t i = 0; i < paths.size(); ++i)
