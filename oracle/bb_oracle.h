@@ -85,6 +85,7 @@ int  bbo_annotate_batch(bbo_ctx* ctx, const uint8_t* bases, const uint64_t* offs
 /* The same rows from bit-parallel scans (64-bit Myers / Hyyro words instead of scalar DP cells).  TIMING ONLY: bench.py's
  * cpu_baseline reports it so the CPU figure is not a scalar loop against a reference that runs AVX2 sassy; the parity tests
  * compare the GPU with bbo_annotate_batch, and tests/test_oracle_fast.py compares this function with it. */
+void bbo_set_pin_threads(int on);   /* default 1: the batch entry points run one pinned OpenMP worker per allowed CPU */
 int  bbo_annotate_batch_fast(bbo_ctx* ctx, const uint8_t* bases, const uint64_t* offsets, uint32_t n_reads,
                              bb_row* rows, uint64_t rows_cap, uint64_t* n_rows, int n_threads);
 
