@@ -20,6 +20,7 @@
 #include <mutex>
 #include <thread>
 
+#include <sched.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <fcntl.h>
@@ -1755,6 +1756,28 @@ std::vector<uint64_t> allreduce_counts(const std::vector<Demuxer*>& dms, std::st
 std::vector<uint64_t> allreduce_counts_shards(Demuxer* lead, const std::vector<uint64_t>& local, uint32_t rank, uint32_t world,
                                               const std::string& base, std::string& how);
 
+// CPUs this process can keep busy: the affinity mask cut by the cgroup's CPU quota.  A container may see every CPU of its host and still be
+// throttled to a few (round 5's MI355X box: 256 visible, cpu.max = "1600000 100000" = 16): more runnable threads than that only buy
+// throttling.  BARBELL_AMD_CPUS overrides.
+unsigned effective_cpus() {
+    if (const char* e = getenv("BARBELL_AMD_CPUS")) { const long v = atol(e); if (v > 0) return (unsigned)v; }
+    unsigned n = std::max(1u, std::thread::hardware_concurrency());
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) n = std::max(1, CPU_COUNT(&set));
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {            // cgroup v2: "<quota|max> <period>"
+        char q[32] = ""; long per = 0;
+        if (fscanf(f, "%31s %ld", q, &per) == 2 && strcmp(q, "max") != 0 && per > 0) n = std::min<unsigned>(n, (unsigned)std::max(1L, (atol(q) + per / 2) / per));
+        fclose(f);
+    } else if (FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {   // cgroup v1
+        long q = -1, per = 100000;
+        if (fscanf(g, "%ld", &q) != 1) q = -1;
+        fclose(g);
+        if (FILE* h = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(h, "%ld", &per) != 1) per = 100000; fclose(h); }
+        if (q > 0 && per > 0) n = std::min<unsigned>(n, (unsigned)std::max(1L, (q + per / 2) / per));
+    }
+    return std::max(1u, n);
+}
+
 // `barbell-amd stage` (tests, no GPU): the text the reader threads and the sequencer stage for upload — the blocks of whole records, one after
 // the other — written to a file.  Returns the form that was staged: 4 (4-line text), 2 (two-line), 1 (two-line, sequence lines packed); a
 // packed run that meets input without a packed form falls back to the two-line form like annotate() does.
@@ -1820,7 +1843,7 @@ static AnnotateStats annotate_once(const std::vector<std::string>& read_files, c
     // two-line mode: a slot is about half full and a chunk costs its reader a pass over the text, so twice the slots and readers
     // host_cut: a slot also waits for the writer threads (at most 4 blocks there), and the last holder may be one of them
     auto feeder_p = std::make_shared<BlockFeeder>(devs[0], read_files, block, (unsigned)((two_line ? 2 : 1) * (3 * G + 2) + (host_cut ? 6 : 0)),
-                                                  std::min<unsigned>(std::max(1u, config.n_threads), 32u), config.n_threads, two_line,
+                                                  std::min<unsigned>(std::min<unsigned>(std::max(1u, config.n_threads), 32u), std::max(4u, effective_cpus())), config.n_threads, two_line,
                                                   config.pack_upload && !getenv("BARBELL_AMD_NO_PACK"));
     const bool packed = feeder_p->pack;   // two bases per byte in the sequence lines (needs the raw text in memory: mapped or inflated)
     feeder_p->keep_slots = config.process_exits_after;

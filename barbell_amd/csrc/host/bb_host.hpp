@@ -273,6 +273,7 @@ struct AnnotateStats {
     std::string counts_reduce;                              // "rccl" | "host" | "single": how the histogram was summed
     double seconds_pipeline = 0;                            // first block read .. last block committed (steady state, no start-up)
 };
+unsigned effective_cpus();   // CPUs the process can keep busy: affinity mask cut by the cgroup's CPU quota (BARBELL_AMD_CPUS overrides)
 int stage_blocks(const std::vector<std::string>& read_files, size_t block_bytes, unsigned n_threads, bool two_line, bool pack, const std::string& out_path,
                  size_t& n_blocks);   // `barbell-amd stage`: what the host stages for upload, to a file (no GPU); returns 4 / 2 / 1 (packed)
 void shard_rendezvous_reset(const std::string& rccl_id, uint32_t rank);   // bb_rccl.cpp; call at program start of a --shard R/W --rccl-id run

@@ -3,7 +3,34 @@ read — searcher.rs:430), so rank r of W owns a contiguous block of the read st
 data-path collective.  The only exchange is one all-reduce (sum) of the per-(group, barcode)
 histogram at the end — RCCL over xGMI on the GPUs (`nccl` backend), `gloo` in the
 CPU tests."""
+import os
+
 import numpy as np
+
+
+def effective_cpus():
+    """CPUs this process can actually keep busy: the affinity mask cut by the cgroup's CPU quota.  A container may SEE every CPU of its host
+    and still be throttled to a few of them (the MI355X box of round 5: 256 visible, `cpu.max` = 1600000 100000 = 16 CPUs) — a thread pool
+    sized by os.cpu_count() then runs slower than one sized by the quota (the CPU checker: 112 k reads/s on 16 threads, 51-74 k on 256)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    for path, parse in (("/sys/fs/cgroup/cpu.max", lambda t: (t.split()[0], t.split()[1])),):
+        try:
+            q, per = parse(open(path).read())
+            if q != "max" and int(per) > 0:
+                n = min(n, max(1, int(int(q) / int(per) + 0.5)))
+        except (OSError, ValueError, IndexError):
+            pass
+    try:   # cgroup v1
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0 and per > 0:
+            n = min(n, max(1, int(q / per + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
 
 
 def shard_range(rank, world, reads_per_rank):

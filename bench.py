@@ -26,6 +26,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
+from barbell_amd.parallel import effective_cpus  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
@@ -275,7 +276,7 @@ def other_config_leg(cfg, dev_idx, dev, L, args, n=1_000_000, steps=3):
     out = {"reads_per_s": n / dt, "ms_per_step": dt * 1e3, "reads": n, "read_len": L, "steps": steps, "rows_per_step": nr, "groups": len(groups),
            "dominant_kernel": dom, "dominant_kernel_ms": kms[dom], "kernel_ms_per_step": kms}
     if not args.no_cpu_baseline:
-        cores = os.cpu_count() or 1
+        cores = effective_cpus()
         w = 4096 if cfg == "dual" else 2048
         full = np.frombuffer(d_rows[: nr * 48].cpu().numpy().tobytes(), dtype=_abi.ROW_DTYPE)
         orc = po.Oracle([g.as_tuple() for g in groups])
@@ -346,7 +347,7 @@ def policy_variants_leg(dev_idx, dev, L, args, n=1_000_000, steps=3):
         if not args.no_cpu_baseline:
             full = np.frombuffer(d_rows[: nr * 48].cpu().numpy().tobytes(), dtype=_abi.ROW_DTYPE)
             want = po.Oracle([g.as_tuple() for g in groups], policy=ptxt or None).annotate(sample, np.arange(w + 1, dtype=np.uint64) * np.uint64(L),
-                                                                                    n_threads=os.cpu_count() or 1, fast=True)
+                                                                                    n_threads=effective_cpus(), fast=True)
             e["parity_on_sample"] = bool(full[full["read_idx"] < w].tobytes() == want.tobytes())
         dm.close()
         if pol == "default":
@@ -400,7 +401,7 @@ def stress_leg(mode, dev_idx, dev, L, args, n=1_000_000, steps=3):
         w = 2048
         full = np.frombuffer(d_rows[: nr * 48].cpu().numpy().tobytes(), dtype=_abi.ROW_DTYPE)
         want = po.Oracle([g.as_tuple() for g in groups]).annotate(d_bases[: w * L].cpu().numpy(), np.arange(w + 1, dtype=np.uint64) * np.uint64(L),
-                                                                  n_threads=os.cpu_count() or 1, fast=True)
+                                                                  n_threads=effective_cpus(), fast=True)
         out["parity_on_sample"] = bool(full[full["read_idx"] < w].tobytes() == want.tobytes())
     dm.close()
     return out
@@ -752,7 +753,7 @@ def cpu_baseline(args, groups, dm, d_bases, L, batch, last_batch, d_rows, last_r
     from oracle import pyoracle as po
 
     po.build()
-    cores = os.cpu_count() or 1
+    cores = effective_cpus()
     orc = po.Oracle([g.as_tuple() for g in groups])
     probe = min(max(64, 8 * cores), 4096, batch)
     base0 = last_batch * batch  # first resident read of the last timed batch
@@ -792,7 +793,10 @@ def cpu_baseline(args, groups, dm, d_bases, L, batch, last_batch, d_rows, last_r
     fwant = orc.annotate(b, o, n_threads=cores, fast=True)
     fdt = time.perf_counter() - t
     fgot = full[full["read_idx"] < nf]
-    out = {"value": nf / fdt, "unit": "reads/s", "cores": cores, "kind": "port-bitparallel",
+    visible = os.cpu_count() or 1
+    out = {"value": nf / fdt, "unit": "reads/s", "cores": cores, "kind": "port-bitparallel", "cpus_visible": visible,
+           "cores_note": (f"{cores} = this container's CPU quota (cgroup cpu.max) of the {visible} CPUs it sees; one pinned OpenMP worker per quota CPU "
+                          f"(a pool of {visible} floating threads ran slower: throttled)" if cores < visible else f"all {cores} CPUs, one pinned OpenMP worker each"),
            "sample": f"first {nf} reads of the last timed {batch}-read batch of the same synthetic stream, CPU checker's bit-parallel path (64-bit "
                      f"Myers words, OpenMP over reads, {cores} threads), {fdt:.1f} s wall; parity windows: 3 x {w} reads (head, middle, tail) with "
                      f"the scalar restatement, {total_dt:.1f} s wall",

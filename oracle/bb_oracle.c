@@ -26,6 +26,7 @@
 #define _GNU_SOURCE   /* sched_setaffinity: the batch entry points pin their OpenMP workers */
 #include "bb_oracle.h"
 
+#include <malloc.h>
 #include <math.h>
 #include <sched.h>
 #include <stdio.h>
@@ -909,6 +910,12 @@ static int annotate_batch_impl(bbo_ctx* c, const uint8_t* bases, const uint64_t*
     /* One worker per CPU, pinned for the region (round 5): left to the scheduler the workers of this loop migrate, and with them the
      * per-read working set — measured on the 8-CPU build box 3.8 k reads/s on 8 floating threads against 30 k pinned (4.4 k on one thread),
      * i.e. the "CPU baseline" of rounds 1-4 was an eighth of what the same code does.  The calling thread's mask is restored afterwards. */
+    {   /* the per-read scratch (a few KB to tens of KB, malloc'd and freed per read and per hit) makes every thread's arena grow and trim
+         * all the time: mprotect / madvise under the process's mapping lock — the loop stopped scaling at 16 threads on the 256-thread
+         * GPU box (112 k reads/s at 16, 51 k at 256).  Arenas that keep what they have freed do not go to the kernel. */
+        static int tuned = 0;
+        if (!tuned) { tuned = 1; mallopt(M_TRIM_THRESHOLD, 1 << 30); mallopt(M_TOP_PAD, 16 << 20); mallopt(M_MMAP_THRESHOLD, 1 << 30); }
+    }
     cpu_set_t allowed, caller;
     const int have_mask = n_threads > 1 && g_pin_threads && sched_getaffinity(0, sizeof(allowed), &allowed) == 0;
     int cpus[1024], n_cpus = 0;

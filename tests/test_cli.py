@@ -10,6 +10,7 @@ import numpy as np
 import pytest
 
 from barbell_amd import kits
+from barbell_amd.parallel import effective_cpus  # noqa: E402
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CLI = os.path.join(ROOT, "barbell_amd", "bin", "barbell-amd")
@@ -150,7 +151,7 @@ def test_cli_tsv_matches_python_and_oracle(tmp_path, gz):
     th.join()
     assert r.returncode == 0, r.stderr
     assert out4.read_bytes() == cli
-    rows = po.Oracle([g.as_tuple() for g in groups]).annotate(bases, offsets, n_threads=os.cpu_count() or 1)
+    rows = po.Oracle([g.as_tuple() for g in groups]).annotate(bases, offsets, n_threads=effective_cpus())
     want = (A.TSV_HEADER + "\n" + "\n".join(A.format_rows(rows, ids, groups)) + "\n").encode()
     assert cli == want
     assert cli.split(b"\n")[0].decode() == A.TSV_HEADER and cli.count(b"\n") == len(rows) + 1
@@ -160,7 +161,7 @@ def test_cli_tsv_matches_python_and_oracle(tmp_path, gz):
     r = subprocess.run([CLI, "annotate", "-i", str(fq), "-o", str(out5), "--kit", "SQK-NBD114-96", "--flank-max-errors", "3", "--policy", pol],
                        capture_output=True, text=True, env=env)
     assert r.returncode == 0, r.stderr
-    rows = po.Oracle([g.as_tuple() for g in groups], policy=pol).annotate(bases, offsets, n_threads=os.cpu_count() or 1)
+    rows = po.Oracle([g.as_tuple() for g in groups], policy=pol).annotate(bases, offsets, n_threads=effective_cpus())
     assert out5.read_bytes() == (A.TSV_HEADER + "\n" + "\n".join(A.format_rows(rows, ids, groups)) + "\n").encode() != cli
 
 
@@ -196,7 +197,7 @@ def test_cli_packed_upload_on_odd_characters(tmp_path, crlf):
                 f.write(b"@" + rid.encode() + b" ch=2" + nl + s_ + nl + b"+" + nl + b"I" * len(s_) + nl)
 
     env = dict(os.environ, BARBELL_AMD_NO_TORCH="1", BARBELL_AMD_PROFILE="1")
-    rows = po.Oracle([g.as_tuple() for g in groups]).annotate(b, offsets, n_threads=os.cpu_count() or 1)
+    rows = po.Oracle([g.as_tuple() for g in groups]).annotate(b, offsets, n_threads=effective_cpus())
     want = (A.TSV_HEADER + "\n" + "\n".join(A.format_rows(rows, ids, groups)) + "\n").encode()
     assert len(rows) > n // 2
     outs = {}
@@ -222,7 +223,7 @@ def test_cli_packed_upload_on_odd_characters(tmp_path, crlf):
     r = subprocess.run([CLI, "annotate", "-i", str(fq2), "-o", str(out), "--kit", "SQK-NBD114-96", "--flank-max-errors", "3", "--block-bytes", "200000"],
                        capture_output=True, text=True, env=env)
     assert r.returncode == 0 and "not representable in the packed upload form" in r.stderr, r.stderr
-    rows2 = po.Oracle([g.as_tuple() for g in groups]).annotate(b2, offsets, n_threads=os.cpu_count() or 1)
+    rows2 = po.Oracle([g.as_tuple() for g in groups]).annotate(b2, offsets, n_threads=effective_cpus())
     assert out.read_bytes() == (A.TSV_HEADER + "\n" + "\n".join(A.format_rows(rows2, ids, groups)) + "\n").encode()
 
 

@@ -6,10 +6,11 @@ import numpy as np
 import pytest
 
 from barbell_amd import _abi
+from barbell_amd.parallel import effective_cpus  # noqa: E402
 from tests.common import config_groups
 
 pytestmark = pytest.mark.gpu
-NT = os.cpu_count() or 1
+NT = effective_cpus()
 
 
 def run_both(groups, bases, offsets, **kw):

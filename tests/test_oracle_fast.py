@@ -8,9 +8,10 @@ import numpy as np
 import pytest
 
 from oracle import pyoracle as po
+from barbell_amd.parallel import effective_cpus  # noqa: E402
 from tests.common import config_groups, noisy_reads
 
-NT = os.cpu_count() or 1
+NT = effective_cpus()
 
 
 @pytest.mark.parametrize("cfg,n,lmin,lmax,rate", [("nbd96", 500, 1, 1200, 0.0), ("nbd96", 400, 200, 900, 0.08), ("dual", 300, 50, 1500, 0.05),

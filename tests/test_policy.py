@@ -11,10 +11,11 @@ import numpy as np
 import pytest
 
 from barbell_amd import _abi
+from barbell_amd.parallel import effective_cpus  # noqa: E402
 from oracle import pyoracle as po
 from tests.common import ALTERNATIVES, GPU_POLICIES, TRACE_CLASSES, config_groups
 
-NT = os.cpu_count() or 1
+NT = effective_cpus()
 
 def test_text_form_round_trips_and_rejects_nonsense():
     for alts in ALTERNATIVES.values():

@@ -18,6 +18,7 @@ import ref_diff  # noqa: E402
 import ref_export  # noqa: E402
 
 from barbell_amd import annotate as A  # noqa: E402
+from barbell_amd.parallel import effective_cpus  # noqa: E402
 from oracle import pyoracle as po  # noqa: E402
 
 GOLD = os.path.join(ROOT, "tests", "golden")
@@ -38,7 +39,7 @@ def oracle_tsv(export_dir, cfg, path, policy=None):
     for rid, s in A.read_fastq(os.path.join(export_dir, "reads.fastq")):
         ids.append(rid)
         seqs.append(s)
-    rows = po.Oracle([g.as_tuple() for g in groups], policy=policy).annotate_reads(seqs, n_threads=os.cpu_count() or 1)
+    rows = po.Oracle([g.as_tuple() for g in groups], policy=policy).annotate_reads(seqs, n_threads=effective_cpus())
     lines = A.format_rows(rows, ids, groups)
     with open(path, "w") as f:
         if lines:

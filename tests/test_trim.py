@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 
 from barbell_amd import _abi, filter as F, trim as T
+from barbell_amd.parallel import effective_cpus  # noqa: E402
 from barbell_amd.kits import QueryGroup
 from oracle import pyoracle as po
 
@@ -353,7 +354,7 @@ def test_fused_annotate_filter_trim_files(tmp_path, gz):
     assert total == n
     # expectation: oracle, one batch
     o = po.Oracle([g.as_tuple() for g in groups])
-    rows = o.annotate(bases, offsets, n_threads=os.cpu_count() or 1)
+    rows = o.annotate(bases, offsets, n_threads=effective_cpus())
     ver = o.filter_rows(F.kit_patterns(kit, True), groups, rows)
     want = o.trim_batch(groups, cfg, rows, ver, bases, quals, offsets, hdr)
     tb = T.LabelTables(groups, cfg)

@@ -8,6 +8,7 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from barbell_amd import annotate as A, kits  # noqa: E402
+from barbell_amd.parallel import effective_cpus  # noqa: E402
 from oracle import pyoracle as po  # noqa: E402
 from tests.common import config_groups  # noqa: E402
 
@@ -38,7 +39,7 @@ for s in range(n_seeds):
     for g in groups:
         dm.add_query_group(g)
     got = dm.demux_packed(b, offsets)
-    want = po.Oracle([g.as_tuple() for g in groups]).annotate(b, offsets, n_threads=os.cpu_count() or 1)
+    want = po.Oracle([g.as_tuple() for g in groups]).annotate(b, offsets, n_threads=effective_cpus())
     ok = got.tobytes() == want.tobytes()
     total += len(got)
     print(f"seed {s} kind {kind} reads {per} len {lo}..{hi}: rows {len(got)} {'ok' if ok else 'MISMATCH'}", flush=True)

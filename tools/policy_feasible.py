@@ -39,6 +39,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 from barbell_amd import _abi, kits  # noqa: E402
+from barbell_amd.parallel import effective_cpus  # noqa: E402
 
 OUT = os.path.join(ROOT, "tests", "golden", "policy_feasible.json")
 EX = os.path.join(ROOT, "tests", "golden", "examples")
@@ -369,7 +370,7 @@ def main():
         print(" ".join(str(i) for i in feasible_class_indices(args.out)))
         return
     which = [g for g in args.geometries.split(",") if g] or None
-    res = compute(args.reads, which, args.seed, os.cpu_count() or 1)
+    res = compute(args.reads, which, args.seed, effective_cpus())
     if args.check:
         old = load(args.out)
         bad = [k for k in ("inputs_digest", "space", "n_joint_total", "default", "default_feasible") if old[k] != res[k]]

@@ -26,6 +26,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 from barbell_amd import _abi  # noqa: E402
+from barbell_amd.parallel import effective_cpus  # noqa: E402
 from tests.common import ALTERNATIVES, config_groups, is_feasible  # noqa: E402
 
 HAZARD_TEXT = {
@@ -99,7 +100,7 @@ def main():
     ap.add_argument("--len-max", type=int, default=4000)
     ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "policy_sensitivity.json"))
     args = ap.parse_args()
-    nt = os.cpu_count() or 1
+    nt = effective_cpus()
     from barbell_amd import annotate as A
     from oracle import pyoracle as po
 

@@ -35,6 +35,9 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+from barbell_amd.parallel import effective_cpus  # noqa: E402
 
 COLS = ["read_id", "read_len", "rel_dist_to_end", "read_start_bar", "read_end_bar", "read_start_flank", "read_end_flank", "bar_start",
         "bar_end", "match_type", "flank_cost", "barcode_cost", "label", "strand", "cuts"]
@@ -141,7 +144,7 @@ def reference_check(export_dir, barbell=None, ours_tsv=None, ours_bin=None, thre
     string 'unpinned beyond KATs' (no binary, no cached ref.tsv) or 'identical' / 'differs'."""
     man = json.load(open(os.path.join(export_dir, "manifest.json")))
     fastq = os.path.join(export_dir, "reads.fastq")
-    threads = threads or os.cpu_count() or 1
+    threads = threads or effective_cpus()
     ref_tsv = os.path.join(export_dir, "ref.tsv")
     secs = None
     bin_ = find_barbell(barbell)
@@ -183,7 +186,7 @@ def main():
 
         if find_barbell(a.barbell) and (a.rerun or not os.path.exists(os.path.join(a.export_dir, "ref.tsv"))):
             man = json.load(open(os.path.join(a.export_dir, "manifest.json")))
-            run_annotate(find_barbell(a.barbell), man["barbell_args"], "reads.fastq", "ref.tsv", a.threads or os.cpu_count() or 1, a.export_dir)
+            run_annotate(find_barbell(a.barbell), man["barbell_args"], "reads.fastq", "ref.tsv", a.threads or effective_cpus(), a.export_dir)
         if not os.path.exists(os.path.join(a.export_dir, "ref.tsv")):
             print("no `barbell` binary (BARBELL_BIN / PATH) and no cached ref.tsv: reference parity " + UNPINNED, file=sys.stderr)
             return 2

@@ -23,6 +23,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools", "ref_golden"))
+from barbell_amd.parallel import effective_cpus  # noqa: E402
 
 OPS = {"=": 0, "X": 1, "I": 2, "D": 3}
 
@@ -196,7 +197,7 @@ def fit_tsv(export_dir, n_reads=2000, log=None, threads=None):
             break
     keep = set(ids)
     ref_rows = [r for r in ref_diff.parse_tsv(os.path.join(export_dir, "ref.tsv")) if r["read_id"] in keep]
-    threads = threads or os.cpu_count() or 1
+    threads = threads or effective_cpus()
 
     def rows_under(pol):
         rows = po.Oracle([g.as_tuple() for g in groups], policy=to_text(pol)).annotate_reads(seqs, n_threads=threads)
