@@ -569,10 +569,19 @@ def e2e_leg(d_bases, n, L, dev):
                 big = {"skipped": "/dev/shm cannot hold 129 GB"}
         except Exception as e:  # noqa: BLE001
             big = {"error": str(e)[:300]}
-        return {"reads": n, "kit": kit, "fastq_bytes": size, "wall_16m_reads": big, "tsv_bytes": os.path.getsize(os.path.join(td, "a.tsv")), "rows": int(m.group(3)),
-                "steady_state_reads_per_s": n / pipe, "steady_state_fastq_gb_per_s": size / pipe / 1e9, "pipeline_s": pipe,
-                "process_wall_s": wall, "process_wall_reads_per_s": n / wall, "fastq_write_s": gen_s,
-                "runs": [{"pipeline_s": p_, "process_wall_s": w_} for p_, w_ in zip(pipes, walls)], "reported": "median of the runs",
+        short = {"reads": n, "fastq_bytes": size, "steady_state_reads_per_s": n / pipe, "steady_state_fastq_gb_per_s": size / pipe / 1e9, "pipeline_s": pipe,
+                 "process_wall_s": wall, "process_wall_reads_per_s": n / wall, "runs": [{"pipeline_s": p_, "process_wall_s": w_} for p_, w_ in zip(pipes, walls)],
+                 "reported": "median of the runs"}
+        # The figures at the top of this object come from the LONG input where it could be run (16 M reads: 1.1-1.4 s of pipeline; the 4 M-read
+        # runs last a third of a second — one 0.05 s hiccup is 15 % — and are kept under `short_input`); medians of three runs either way.
+        top = short
+        if big.get("runs"):
+            med = lambda key: sorted(x[key] for x in big["runs"])[len(big["runs"]) // 2]
+            top = {"reads": big["reads"], "fastq_bytes": big["fastq_bytes"], "pipeline_s": med("pipeline_s"), "steady_state_reads_per_s": big["reads"] / med("pipeline_s"),
+                   "steady_state_fastq_gb_per_s": big["fastq_bytes"] / med("pipeline_s") / 1e9, "process_wall_s": med("process_wall_s"),
+                   "process_wall_reads_per_s": big["reads"] / med("process_wall_s"), "runs": big["runs"], "reported": "median of the runs on the 16 M-read input"}
+        return {**top, "short_input": short, "kit": kit, "wall_16m_reads": big, "tsv_bytes": os.path.getsize(os.path.join(td, "a.tsv")), "rows": int(m.group(3)),
+                "fastq_write_s": gen_s,
                 "host_feed_only": feed, "upload_form": "packed: header lines + two bases per byte (BB_FASTQ_PACKED), ~2 KB per read over PCIe",
                 "text_lines_form": text_form,
                 "command": "barbell-amd annotate --kit SQK-NBD114-96 --flank-max-errors 3 --streams 2 --block-bytes 256Mi -t 32",
