@@ -1208,6 +1208,18 @@ struct PackCtx {
     size_t line_pos0 = 0;      // index within its line of the chunk's first byte (used when that byte lies in a sequence line)
     size_t after = 0;          // bytes readable beyond the chunk's end (0: the chunk ends the file)
     bool prev_is_cr = false;   // the byte before the chunk is '\r' (a chunk that starts with the '\n' of a "\r\n": the '\r' is not a base of the line)
+    bool prev_line_blank = false;   // the line before the one the chunk starts in is empty (blank lines after a file's last record that straddle a chunk start)
+    // from the raw text around a chunk that starts at file_base + off
+    void look_back(const uint8_t* file_base, uint64_t off) {    // line_pos0 is set
+        prev_is_cr = off > 0 && file_base[off - 1] == '\r';
+        prev_line_blank = false;
+        const uint64_t ls = off - line_pos0;                       // start of the line the chunk begins in
+        if (ls > 0 && file_base[ls - 1] == '\n') {
+            uint64_t e = ls - 1;                                    // the '\n' that ends the line before
+            if (e > 0 && file_base[e - 1] == '\r') --e;
+            prev_line_blank = e == 0 || file_base[e - 1] == '\n';
+        }
+    }
     bool unpackable = false;   // out: two adjacent non-IUPAC characters would pack to '\n'; the run falls back to the plain two-line form
 };
 static const uint8_t* base_code_table() {
@@ -1270,7 +1282,9 @@ static inline size_t pack_bases(uint8_t* out, const uint8_t* b, const uint8_t* e
 static size_t compact_two_line(uint8_t* out, const uint8_t* buf, size_t n, int ph0, size_t& nl_kept, size_t& nl_all, bool& bad, TwoLineSummary& S,
                                PackCtx* pk = nullptr) {
     size_t d = 0, p = 0;
-    bool hdr_blank = false;   // the header line of the record in hand was empty (blank lines after the last record stay blank lines)
+    // the header line of the record in hand was empty (blank lines after the last record stay blank lines); for a chunk that starts with a
+    // sequence-phase line the reader has looked at the line before
+    bool hdr_blank = pk && (ph0 & 3) == 1 && pk->prev_line_blank;
     int ph = ph0 & 3;
     bool line_start = false;  // the first line may be the tail of one that began in the previous chunk
     nl_kept = nl_all = 0; bad = false;
@@ -1308,8 +1322,10 @@ static size_t compact_two_line(uint8_t* out, const uint8_t* buf, size_t n, int p
                 const bool eol = buf[n] == '\n' || (buf[n] == '\r' && (pk->after == 1 || buf[n + 1] == '\n'));
                 if (!eol) next = base_code_table()[buf[n]];
             }
-            if (i0 == 0 && se == p && q && hdr_blank) {            // blank line after a blank header line: not a record, stays as it is
-                out[d++] = '\n'; ++nl_kept;
+            const size_t cr_split = (nl_all == 0 && i0 > 0 && q == buf + p && pk->prev_is_cr) ? 1 : 0;   // "\r" | "\n" split over two chunks
+            if (i0 - cr_split == 0 && se == p && q && hdr_blank) {  // blank line after a blank header line: not a record, stays as it is ("\n" or "\r\n")
+                if (cr_split) out[d++] = '\r';                      // (its '\r' ended the chunk before, which left it to this one)
+                memcpy(out + d, buf + p, e - p); d += e - p; ++nl_kept;
             } else {
                 d += pack_bases(out + d, buf + b, buf + se, next, pk->unpackable);
                 if (q || pk->after == 0) {                          // the line ends here (its '\n', or the end of a file without one): parity terminator
@@ -1319,9 +1335,11 @@ static size_t compact_two_line(uint8_t* out, const uint8_t* buf, size_t n, int p
                 }
             }
         } else if (ph < 2) {
-            if (ph == 0 && pk) {   // a whole header line (not the tail of one that began in the chunk before) without a character
+            if (ph == 0 && pk) {   // a header line without a character — counting what the chunk before holds of it (at most the '\r' of its "\r\n")
                 const size_t raw = q ? (size_t)(q - buf) - p : 1;
-                hdr_blank = q && raw - ((raw && buf[p + raw - 1] == '\r') ? 1 : 0) == 0 && (nl_all > 0 || pk->line_pos0 == 0);
+                const size_t len = raw - ((raw && buf[p + raw - 1] == '\r') ? 1 : 0);
+                const size_t before = nl_all == 0 ? pk->line_pos0 - ((pk->line_pos0 == 1 && raw == 0 && pk->prev_is_cr) ? 1 : 0) : 0;
+                hdr_blank = q && len == 0 && before == 0;
             }
             if (out + d != buf + p) memmove(out + d, buf + p, e - p);
             d += e - p;
@@ -1572,7 +1590,7 @@ void BlockFeeder::reader_loop() {
                 }
                 if (ph0 >= 0) {
                     PackCtx pk;
-                    if (pack) { pk.line_pos0 = line_pos(src - t.off, t.off); pk.after = (size_t)(sizes[t.file] - (t.off + t.len)); pk.prev_is_cr = t.off > 0 && src[-1] == '\r'; }
+                    if (pack) { pk.line_pos0 = line_pos(src - t.off, t.off); pk.after = (size_t)(sizes[t.file] - (t.off + t.len)); pk.look_back(src - t.off, t.off); }
                     got_len = compact_two_line(dst, src, t.len, ph0, nl, raw_nl, bad, sum, pack ? &pk : nullptr);
                     unpackable = pk.unpackable;
                 } else { if (t.len) memcpy(dst, src, t.len); raw_nl = count_nl(dst, t.len); }   // left raw: the sequencer compacts it with the true phase
@@ -1652,7 +1670,7 @@ bool BlockFeeder::next(Block& b) {
                 else {
                     PackCtx pk;
                     pk.line_pos0 = line_pos(maps[sl->file], sl->off); pk.after = (size_t)(sizes[sl->file] - (sl->off + sl->raw_len));
-                    pk.prev_is_cr = sl->off > 0 && maps[sl->file][sl->off - 1] == '\r';
+                    pk.look_back(maps[sl->file], sl->off);
                     sl->got = compact_two_line(body, maps[sl->file] + sl->off, sl->raw_len, truth, sl->nl, sl->raw_nl, sl->bad, sl->sum, &pk);
                     sl->unpackable = pk.unpackable;
                 }

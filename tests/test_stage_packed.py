@@ -104,3 +104,11 @@ def test_input_without_a_packed_form_falls_back(tmp_path):
     # files read with pread (no mapping) cannot be packed: no look-back
     form, blocks, got = stage([fq], tmp_path / "o.bin", "--block-bytes", "512", env={"BARBELL_AMD_NO_MMAP": "1"})
     assert form == 2
+
+
+def test_randomised_staging_slice():
+    """a slice of tools/stage_fuzz.py (the full tool runs thousands of seeds): random layouts, line ends, blank tails, tiny chunks"""
+    import sys
+
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "stage_fuzz.py"), "100", "120"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and r.stdout.strip().endswith("120 seeds 0 bad"), r.stdout[-1500:] + r.stderr[-500:]
