@@ -1251,11 +1251,31 @@ __attribute__((target("avx2"))) static bool pack32_avx2(uint8_t* out, const uint
     return ok;
 }
 static const bool g_have_avx2 = (__builtin_cpu_init(), __builtin_cpu_supports("avx2")) && !getenv("BARBELL_AMD_NO_AVX2");
+// 64 characters -> 32 packed bytes with AVX-512 VBMI (Zen 4 / 5, Ice Lake and later): the character's low six bits index ONE 64-entry vpermb
+// table (upper case 1..26, lower case 33..58), the mask keeps bytes 0x40..0x7F only; vpmaddubsw pairs, vpmovwb narrows.
+__attribute__((target("avx512f,avx512bw,avx512vbmi"))) static bool pack64_avx512(uint8_t* out, const uint8_t* in) {
+    alignas(64) static const uint8_t T[64] = {0, 1, 14, 2, 13, 0, 0, 4, 11, 0, 0, 12, 0, 3, 15, 0, 0, 0, 5, 6, 8, 8, 7, 9, 0, 10, 0, 0, 0, 0, 0, 0,
+                                              0, 1, 14, 2, 13, 0, 0, 4, 11, 0, 0, 12, 0, 3, 15, 0, 0, 0, 5, 6, 8, 8, 7, 9, 0, 10, 0, 0, 0, 0, 0, 0};
+    const __m512i x = _mm512_loadu_si512((const void*)in);
+    const __mmask64 letter = _mm512_cmpeq_epi8_mask(_mm512_and_si512(x, _mm512_set1_epi8((char)0xC0)), _mm512_set1_epi8(0x40));
+    const __m512i c = _mm512_maskz_permutexvar_epi8(letter, x, _mm512_load_si512((const void*)T));   // vpermb uses the low six bits of each index byte
+    const bool ok = _mm512_cmpeq_epi16_mask(c, _mm512_setzero_si512()) == 0;
+    const __m512i m = _mm512_maddubs_epi16(_mm512_xor_si512(c, _mm512_set1_epi16(0x0A00)), _mm512_set1_epi16(0x0110));
+    _mm256_storeu_si256((__m256i*)out, _mm512_cvtepi16_epi8(m));
+    return ok;
+}
+static const bool g_have_avx512 = (__builtin_cpu_init(), __builtin_cpu_supports("avx512vbmi") && __builtin_cpu_supports("avx512bw")) &&
+                                  !getenv("BARBELL_AMD_NO_AVX512") && !getenv("BARBELL_AMD_NO_AVX2");
 // the bases [b, e) of a sequence line, b at an even position of the line, as packed bytes; `next` pairs with a last unpaired base (15 = none)
 static inline size_t pack_bases(uint8_t* out, const uint8_t* b, const uint8_t* e, uint8_t next, bool& unpackable) {
     const uint8_t* C = base_code_table();
     size_t d = 0;
     uint8_t z = 0xFF;   // AND of (c0 | c1) != 0 over the pairs, folded: becomes 0 if some pair was (0, 0)
+    if (g_have_avx512) {
+        bool ok = true;
+        for (; b + 64 <= e; b += 64, d += 32) ok &= pack64_avx512(out + d, b);
+        if (!ok) z = 0;
+    }
     if (g_have_avx2) {
         bool ok = true;
         for (; b + 32 <= e; b += 32, d += 16) ok &= pack32_avx2(out + d, b);
