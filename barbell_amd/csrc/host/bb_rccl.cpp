@@ -115,7 +115,9 @@ std::vector<uint64_t> allreduce_counts(const std::vector<Demuxer*>& dms, std::st
 
 // ---- one process per GPU: the histogram over the W processes of a `--shard R/W` run --------------------------------------------------
 namespace {
-double rendezvous_timeout_s() { const char* e = getenv("BARBELL_AMD_RCCL_TIMEOUT"); return e && atof(e) > 0 ? atof(e) : 600.0; }
+// how long a shard that has finished its own files waits for the others to finish theirs (they meet at the END of their runs: unequal
+// shards make the fast ones wait); BARBELL_AMD_RCCL_TIMEOUT, in seconds
+double rendezvous_timeout_s() { const char* e = getenv("BARBELL_AMD_RCCL_TIMEOUT"); return e && atof(e) > 0 ? atof(e) : 3600.0; }
 // whole-file write made visible atomically (tmp + rename): a reader never sees half a file
 void publish(const std::string& path, const void* data, size_t bytes) {
     const std::string tmp = path + ".tmp" + std::to_string((long)getpid());
