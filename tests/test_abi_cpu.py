@@ -38,6 +38,17 @@ def test_row_layout():
     assert C.sizeof(_abi.GroupInfo) == 56
 
 
+def test_build_holds_the_feasible_trace_classes(L):
+    """bb_build_trace_classes (no GPU needed): the default build holds fast barcode kernels for the traceback classes the reference's own
+    known-answer tests leave open (tests/golden/policy_feasible.json), the default order (class 0) among them; `make CLASSES=all` holds all 18."""
+    from tests.common import policy_feasible
+
+    m = L.bb_build_trace_classes()
+    held = [i for i in range(18) if (m >> i) & 1]
+    assert 0 in held and m < (1 << 18)
+    assert set(policy_feasible()["feasible_trace_class_indices"]) <= set(held)
+
+
 def test_strerror(L):
     assert L.bb_strerror(0) == b"ok"
     assert b"IUPAC" in L.bb_strerror(_abi.BB_E_NOT_IUPAC)
