@@ -14,7 +14,8 @@
 use crate::annotate::barcodes::{BarcodeGroup, BarcodeType};
 use crate::annotate::searcher::BarbellMatch;
 use anyhow::{anyhow, Result};
-use sassy::{Cost, Strand};
+use pa_types::Cost; // as searcher.rs:7 imports it
+use sassy::Strand;
 use std::ffi::CStr;
 use std::os::raw::c_char;
 
