@@ -19,18 +19,42 @@ using namespace barbell;
 // --shard R/W: this process takes the input files whose index is R modulo W (one process per GPU with --device R;
 // reads shard trivially, SURVEY §8e — each process writes its own rows; with --rccl-id PATH (the same fresh path for every shard) the
 // per-barcode histograms are all-reduced over the W processes and shard 0 writes --counts)
-static bool apply_shard(const std::string& spec, std::vector<std::string>& files, uint32_t& rank, uint32_t& world) {
+// --shard-by bytes: every process keeps the whole file list and takes the records that start in its R-th of W equal byte ranges of each file
+// (one big FASTQ over W GPUs; plain files only — a gzip stream has no entry points)
+static bool apply_shard(const std::string& spec, std::vector<std::string>& files, uint32_t& rank, uint32_t& world, bool by_bytes = false) {
     if (spec.empty()) return true;
     const size_t slash = spec.find('/');
     if (slash == std::string::npos) return false;
     const long r = atol(spec.substr(0, slash).c_str()), w = atol(spec.substr(slash + 1).c_str());
     if (w < 1 || r < 0 || r >= w) return false;
     rank = (uint32_t)r; world = (uint32_t)w;
+    if (by_bytes) return true;
     std::vector<std::string> mine;
     for (size_t i = 0; i < files.size(); ++i)
         if ((long)(i % (size_t)w) == r) mine.push_back(files[i]);
     files.swap(mine);
     return true;
+}
+
+// sizes: a byte count with an optional binary suffix (4096, 64Ki, 256Mi, 1Gi; K / M / G mean the same)
+static size_t parse_size(const char* v, const char* flag) {
+    char* end = nullptr;
+    const unsigned long long x = strtoull(v, &end, 10);
+    unsigned shift = 0;
+    if (end == v) { fprintf(stderr, "error: %s takes a byte count (e.g. 4096, 256Mi)\n", flag); exit(2); }
+    if (*end == 'K' || *end == 'k') shift = 10; else if (*end == 'M' || *end == 'm') shift = 20; else if (*end == 'G' || *end == 'g') shift = 30;
+    if (shift) ++end;
+    if (shift && (*end == 'i' || *end == 'I')) ++end;
+    if (shift && (*end == 'B' || *end == 'b')) ++end;
+    if (*end) { fprintf(stderr, "error: %s takes a byte count (e.g. 4096, 256Mi), got '%s'\n", flag, v); exit(2); }
+    return (size_t)(x << shift);
+}
+
+static bool parse_shard_by(const std::string& v, bool& by_bytes) {
+    if (v == "bytes") { by_bytes = true; return true; }
+    if (v == "files") { by_bytes = false; return true; }
+    fputs("error: --shard-by takes files or bytes\n", stderr);
+    return false;
 }
 
 // --devices 0,1,2 (a device may repeat: 0,0 = two contexts on GPU 0)
@@ -67,7 +91,8 @@ static void usage() {
         "                            [--flank-max-errors INT] [--min-score F=0.2] [--min-score-diff F=0.1]\n"
         "                            [--alpha F=0.4] [--use-extended] [-t THREADS=10] [--verbose]\n"
         "                            [--block-bytes N=256Mi | --batch-reads N (= N*4096 bytes)] [--device D=0]\n"
-        "                            [--shard R/W [--rccl-id PATH (one fresh path for all W processes: their histograms are all-reduced, RCCL ncclCommInitRank; shard 0 writes --counts)]]\n"
+        "                            [--shard R/W [--shard-by files|bytes (files: the inputs with index R mod W; bytes: the records that start in the R-th of W byte ranges of each plain file)]\n"
+        "                             [--rccl-id PATH (one fresh path for all W processes: their histograms are all-reduced, RCCL ncclCommInitRank; shard 0 writes --counts)]]\n"
         "                            [--devices D0,D1,.. (one FASTQ stream over several contexts, block i -> context i mod G; RCCL all-reduce of the counts)]\n"
         "                            [--streams S=2 (contexts per device when --devices is not given)] [--counts FILE]\n"
         "                            [--policy lm=..,rc=..,trace=..,ovh=..,tie=..,lodhi=.. (include/barbell_amd_policy.h)]\n"
@@ -80,7 +105,7 @@ static void usage() {
         "                            [--inspect [-n TOP=10] [--read-pattern-out FILE] [-s BUCKET=250]]\n"
         "       barbell-amd kit -k <KIT> -i <FASTQ>... -o <OUT_DIR> [--maximize] [--min-score F] [--min-score-diff F]\n"
         "                       [--flank-max-errors INT] [--failed-out FILE] [--use-extended] [--alpha F] [--gzip] [-t N]\n"
-        "                       [--device D=0] [--shard R/W [--rccl-id PATH]] [--gpu-render]\n"
+        "                       [--device D=0] [--shard R/W [--shard-by files|bytes] [--rccl-id PATH]] [--gpu-render]\n"
         "       barbell-amd kits          list the supported kit names\n"
         "       barbell-amd pattern <STR>...   parse filter pattern strings and print their elements\n",
         stderr);
@@ -125,22 +150,28 @@ int main(int argc, char** argv) {
         std::string out;
         size_t block = 128u << 20;
         unsigned threads = 4;
-        bool two_line = true, pack = true, multi_in = false;
+        bool two_line = true, pack = true, multi_in = false, by_bytes = false;
+        std::string shard;
+        uint32_t srank = 0, sworld = 1;
         for (int i = 2; i < argc; ++i) {
             const std::string a = argv[i];
             if (a == "-i") multi_in = true;
             else if (a == "-o" && i + 1 < argc) { out = argv[++i]; multi_in = false; }
-            else if (a == "--block-bytes" && i + 1 < argc) { block = (size_t)atoll(argv[++i]); multi_in = false; }
+            else if (a == "--block-bytes" && i + 1 < argc) { block = parse_size(argv[++i], "--block-bytes"); multi_in = false; }
             else if (a == "-t" && i + 1 < argc) { threads = (unsigned)atoi(argv[++i]); multi_in = false; }
             else if (a == "--no-pack") { pack = false; multi_in = false; }
             else if (a == "--no-compact") { two_line = false; pack = false; multi_in = false; }
+            else if (a == "--shard" && i + 1 < argc) { shard = argv[++i]; multi_in = false; }
+            else if (a == "--shard-by" && i + 1 < argc) { if (!parse_shard_by(argv[++i], by_bytes)) return 2; multi_in = false; }
             else if (multi_in && !a.empty() && a[0] != '-') in.push_back(a);
             else { fprintf(stderr, "error: unexpected argument '%s'\n", a.c_str()); return 2; }
         }
-        if (in.empty() || out.empty()) { fputs("usage: barbell-amd stage -i FASTQ... -o FILE [--block-bytes N] [-t N] [--no-pack] [--no-compact]\n", stderr); return 2; }
+        if (!apply_shard(shard, in, srank, sworld, by_bytes)) { fputs("error: --shard takes R/W with 0 <= R < W\n", stderr); return 2; }
+        if (!by_bytes) { srank = 0; sworld = 1; }
+        if (in.empty() || out.empty()) { fputs("usage: barbell-amd stage -i FASTQ... -o FILE [--block-bytes N] [-t N] [--no-pack] [--no-compact] [--shard R/W [--shard-by files|bytes]]\n", stderr); return 2; }
         try {
             size_t nb = 0;
-            const int form = stage_blocks(in, block, threads, two_line, pack, out, nb);
+            const int form = stage_blocks(in, block, threads, two_line, pack, out, nb, srank, sworld);
             printf("form %d blocks %zu\n", form, nb);
         } catch (const BarbellError& e) { fprintf(stderr, "error: %s\n", e.what()); return 1; }
         return 0;
@@ -172,6 +203,7 @@ int main(int argc, char** argv) {
             else if (a == "--policy") { if (!set_policy(need("--policy"))) return 2; }
             else if (a == "--shard") shard = need("--shard");
             else if (a == "--rccl-id") k.rccl_id = need("--rccl-id");
+            else if (a == "--shard-by") { if (!parse_shard_by(need("--shard-by"), k.shard_by_bytes)) return 2; }
             else if (a == "--maximize") { k.maximize = true; multi_in = false; }
             else if (a == "--verbose") { k.verbose = true; multi_in = false; }
             else if (a == "--use-extended") { k.use_extended = true; multi_in = false; }
@@ -182,7 +214,7 @@ int main(int argc, char** argv) {
         }
         if (k.kit_name.empty() || k.output_folder.empty()) { fputs("error: kit needs --kit and --output\n", stderr); return 2; }
         if (input.empty()) { fputs("error: No FASTQ input files provided\n", stderr); return 2; }
-        if (!apply_shard(shard, input, k.shard_rank, k.shard_world)) { fputs("error: --shard takes R/W with 0 <= R < W\n", stderr); return 2; }
+        if (!apply_shard(shard, input, k.shard_rank, k.shard_world, k.shard_by_bytes)) { fputs("error: --shard takes R/W with 0 <= R < W\n", stderr); return 2; }
         if (input.empty() && k.rccl_id.empty()) { puts("Nothing to do for this shard"); return 0; }
         if (input.empty()) { fputs("error: --rccl-id: this shard has no input file, the other shards would wait for it (fewer files than shards)\n", stderr); return 2; }
         if (!k.rccl_id.empty()) shard_rendezvous_reset(k.rccl_id, k.shard_rank);
@@ -222,7 +254,7 @@ int main(int argc, char** argv) {
         else if (a == "--min-score-diff") { cfg.min_score_diff = atof(need("--min-score-diff")); multi = nullptr; }
         else if (a == "--alpha") { cfg.alpha = (float)atof(need("--alpha")); multi = nullptr; }
         else if (a == "--batch-reads") { cfg.batch_reads = (size_t)atol(need("--batch-reads")); multi = nullptr; }
-        else if (a == "--block-bytes") { cfg.block_bytes = (size_t)atoll(need("--block-bytes")); multi = nullptr; }
+        else if (a == "--block-bytes") { cfg.block_bytes = parse_size(need("--block-bytes"), "--block-bytes"); multi = nullptr; }
         else if (a == "--device") { cfg.device = atoi(need("--device")); multi = nullptr; }
         else if (a == "--devices") { cfg.devices = parse_devices(need("--devices")); multi = nullptr; }
         else if (a == "--streams") { cfg.streams_per_device = (unsigned)atoi(need("--streams")); multi = nullptr; }
@@ -233,6 +265,7 @@ int main(int argc, char** argv) {
         else if (a == "--policy") { if (!set_policy(need("--policy"))) return 2; multi = nullptr; }
         else if (a == "--shard") { shard = need("--shard"); multi = nullptr; }
         else if (a == "--rccl-id") { cfg.rccl_id = need("--rccl-id"); multi = nullptr; }
+        else if (a == "--shard-by") { if (!parse_shard_by(need("--shard-by"), cfg.shard_by_bytes)) return 2; multi = nullptr; }
         else if (a == "-f" || a == "--filter-file") { multi = &pattern_files; }
         else if (a == "--filtered") { cfg.filtered_file = need("--filtered"); multi = nullptr; }
         else if (a == "--dropped") { cfg.dropped_file = need("--dropped"); multi = nullptr; }
@@ -264,7 +297,7 @@ int main(int argc, char** argv) {
         else { fprintf(stderr, "error: unexpected argument '%s'\n", a.c_str()); usage(); return 2; }
     }
     if (input.empty()) { fputs("error: No FASTQ input files provided\n", stderr); return 2; }
-    if (!apply_shard(shard, input, cfg.shard_rank, cfg.shard_world)) { fputs("error: --shard takes R/W with 0 <= R < W\n", stderr); return 2; }
+    if (!apply_shard(shard, input, cfg.shard_rank, cfg.shard_world, cfg.shard_by_bytes)) { fputs("error: --shard takes R/W with 0 <= R < W\n", stderr); return 2; }
     if (input.empty() && cfg.rccl_id.empty()) { fputs("Nothing to do for this shard\n", stderr); return 0; }
     if (input.empty()) { fputs("error: --rccl-id: this shard has no input file, the other shards would wait for it (fewer files than shards)\n", stderr); return 2; }
     if (!cfg.rccl_id.empty()) shard_rendezvous_reset(cfg.rccl_id, cfg.shard_rank);

@@ -894,7 +894,7 @@ struct TwoLineSummary {
     int64_t len1 = -1, len2 = -1;                 // lengths of the second and third line that END in the chunk
     int64_t pend = -1;                            // length of the last sequence line, not the chunk's first line, whose quality line does not end in the chunk
     bool pend_cleared = false;                    // some quality line other than the chunk's first two lines ends in the chunk: nothing older is pending after it
-    int64_t last2[2] = {-1, -1};                  // lengths of the last two lines that end in the chunk (-2: that line is the chunk's first)
+    int64_t last3[3] = {-1, -1, -1};              // lengths of the last three lines that end in the chunk (-2: that line is the chunk's first)
 };
 
 // thrown by the sequencer when a chunk cannot be staged in the packed form (two adjacent non-IUPAC characters in a read, a gzip chunk whose
@@ -921,6 +921,10 @@ struct BlockFeeder {
     std::vector<int> fds;
     std::vector<const uint8_t*> maps; // two-line mode, plain files: the file mapped (the readers compact out of the page cache)
     std::vector<uint64_t> sizes;      // plain: st_size; gzip: inflated size once known
+    // the part of each file this process stages: [begins, ends) — the whole file, or (--shard R/W --shard-by bytes) the records that START in
+    // the R-th of W equal byte ranges of a plain file: both ends are record starts, found by the same rule from either side (record_start)
+    std::vector<uint64_t> begins, ends;
+    uint32_t shard_rank = 0, shard_world = 1;   // byte-range sharding (1: off)
     std::vector<char> size_known;
     size_t chunk;
     std::vector<Slot> slots;
@@ -949,12 +953,13 @@ struct BlockFeeder {
     size_t lpr = 4;                       // lines per record in the staged text
     size_t seq_file = (size_t)-1; uint64_t seq_raw_lines = 0;   // sequencer: file in hand, its raw lines so far
     // stitch(): a line in progress across chunk ends, the sequence length waiting for its quality line, the last two lines' lengths
-    size_t st_part = 0; uint8_t st_part_last = 0; int64_t st_pend = -1, st_last2[2] = {-1, -1};
+    size_t st_part = 0; uint8_t st_part_last = 0; int64_t st_pend = -1, st_last3[3] = {-1, -1, -1};
     void stitch(const Slot& sl, int ph0);
 
     BlockFeeder(int device_, const std::vector<std::string>& files, size_t chunk_bytes, unsigned n_slots, unsigned n_readers, unsigned n_inflate,
-                bool two_line_mode = false, bool pack_mode = false);
+                bool two_line_mode = false, bool pack_mode = false, uint32_t byte_shard_rank = 0, uint32_t byte_shard_world = 1);
     ~BlockFeeder();
+    static uint64_t record_start(int fd, uint64_t size, uint64_t pos, const std::string& path);
     // where in its line byte `off` of a file lies: the readers look back for the line's start (mapped file / inflated image)
     static size_t line_pos(const uint8_t* file_base, uint64_t off) {
         const void* q = off ? memrchr(file_base, '\n', (size_t)off) : nullptr;
@@ -1305,18 +1310,21 @@ static size_t compact_two_line(uint8_t* out, const uint8_t* buf, size_t n, int p
     // the header line of the record in hand was empty (blank lines after the last record stay blank lines); for a chunk that starts with a
     // sequence-phase line the reader has looked at the line before
     bool hdr_blank = pk && (ph0 & 3) == 1 && pk->prev_line_blank;
+    int hdr_state = pk && (ph0 & 3) == 1 ? (pk->prev_line_blank ? 1 : 0) : -1;   // the same for the '+' line's check, in every mode: -1 = began before the chunk, not known
     int ph = ph0 & 3;
     bool line_start = false;  // the first line may be the tail of one that began in the previous chunk
     nl_kept = nl_all = 0; bad = false;
     S = TwoLineSummary();
     int64_t seq_len = -1;     // the sequence line of the record in hand, if it began in this chunk after the first line
     while (p < n) {
-        if (line_start && ((ph == 0 && buf[p] != '@' && buf[p] != '\n' && buf[p] != '\r') || (ph == 2 && buf[p] != '+'))) bad = true;
+        if (line_start && ph == 0) hdr_state = (buf[p] == '\n' || (buf[p] == '\r' && p + 1 < n && buf[p + 1] == '\n')) ? 1 : 0;
+        if (line_start && ((ph == 0 && buf[p] != '@' && buf[p] != '\n' && buf[p] != '\r') ||
+                           (ph == 2 && buf[p] != '+' && !(hdr_state != 0 && (buf[p] == '\n' || buf[p] == '\r'))))) bad = true;   // a blank '+' line: only below a blank header (blank lines after the last record)
         const uint8_t* q = (const uint8_t*)memchr(buf + p, '\n', n - p);
         const size_t e = q ? (size_t)(q - buf) + 1 : n;
         if (q) {
             const size_t raw = (size_t)(q - buf) - p;   // without the '\n'
-            if (nl_all == 0) { S.head_raw = raw; S.head_last = raw ? buf[p + raw - 1] : 0; S.last2[1] = -2; }
+            if (nl_all == 0) { S.head_raw = raw; S.head_last = raw ? buf[p + raw - 1] : 0; S.last3[2] = -2; }
             else {
                 const int64_t len = (int64_t)raw - (raw && buf[p + raw - 1] == '\r' ? 1 : 0);
                 if (nl_all == 1) S.len1 = len;
@@ -1327,7 +1335,7 @@ static size_t compact_two_line(uint8_t* out, const uint8_t* buf, size_t n, int p
                     if (nl_all >= 3 || seq_len >= 0) S.pend_cleared = true;
                     seq_len = -1;
                 }
-                S.last2[0] = S.last2[1]; S.last2[1] = len;
+                S.last3[0] = S.last3[1]; S.last3[1] = S.last3[2]; S.last3[2] = len;
             }
         } else { S.tail_raw = n - p; S.tail_last = buf[n - 1]; if (nl_all == 0) { S.head_raw = n - p; S.head_last = buf[n - 1]; } }
         if (ph == 1 && pk) {
@@ -1390,11 +1398,13 @@ void BlockFeeder::stitch(const Slot& sl, int ph0) {
         if (S.pend_cleared) st_pend = -1;
         if (S.pend >= 0) st_pend = S.pend;
         // the last two lines that have ended, for the check at the end of the file
-        const int64_t a = S.last2[0] == -2 ? L0 : S.last2[0], b = S.last2[1] == -2 ? L0 : S.last2[1];
-        if (sl.raw_nl >= 2) { st_last2[0] = a; st_last2[1] = b; } else { st_last2[0] = st_last2[1]; st_last2[1] = b; }
+        const int64_t a = S.last3[0] == -2 ? L0 : S.last3[0], b = S.last3[1] == -2 ? L0 : S.last3[1], c = S.last3[2] == -2 ? L0 : S.last3[2];
+        if (sl.raw_nl >= 3) { st_last3[0] = a; st_last3[1] = b; st_last3[2] = c; }
+        else if (sl.raw_nl == 2) { st_last3[0] = st_last3[2]; st_last3[1] = b; st_last3[2] = c; }
+        else { st_last3[0] = st_last3[1]; st_last3[1] = st_last3[2]; st_last3[2] = c; }
         st_part = S.tail_raw; st_part_last = S.tail_last;
     }
-    if (sl.last) {  // the file's end: a last line without '\n' counts; at most two blank lines may follow the last record (the GPU parser ignores them)
+    if (sl.last) {  // the file's end: a last line without '\n' counts; blank lines may follow the last record (the GPU parser ignores them: whole blank records, then the surplus lines)
         uint64_t lines = seq_raw_lines + sl.raw_nl;
         int64_t tail_len = -1;
         if (st_part) { tail_len = (int64_t)st_part - (st_part_last == '\r' ? 1 : 0); ++lines; }
@@ -1403,11 +1413,11 @@ void BlockFeeder::stitch(const Slot& sl, int ph0) {
             if (tail_len >= 0 && st_pend >= 0 && st_pend != tail_len) fail("holds a record whose quality line is not as long as its sequence");
         } else {
             // r surplus lines: they must all be blank
-            const int64_t l1 = tail_len >= 0 ? tail_len : st_last2[1], l2 = tail_len >= 0 ? st_last2[1] : st_last2[0];
-            const bool blank = r == 1 ? l1 == 0 : (r == 2 ? l1 == 0 && l2 == 0 : false);
+            const int64_t l1 = tail_len >= 0 ? tail_len : st_last3[2], l2 = tail_len >= 0 ? st_last3[2] : st_last3[1], l3 = tail_len >= 0 ? st_last3[1] : st_last3[0];
+            const bool blank = l1 == 0 && (r < 2 || l2 == 0) && (r < 3 || l3 == 0);
             if (!blank) fail("ends inside a record (truncated file?)");
         }
-        st_part = 0; st_part_last = 0; st_pend = -1; st_last2[0] = st_last2[1] = -1;
+        st_part = 0; st_part_last = 0; st_pend = -1; st_last3[0] = st_last3[1] = st_last3[2] = -1;
     }
 }
 // phase of a chunk's first byte, read off the text: the first line that starts with '@' and has a line starting with '+' two
@@ -1445,9 +1455,47 @@ static bool sniff_gzip(const std::string& path) {  // magic bytes, not the file 
     return n == 2 && m[0] == 0x1f && m[1] == 0x8b;
 }
 
+// First record start at or after byte `pos` of a plain FASTQ file (--shard-by bytes): the phase of the line `pos` lies in is read off the text
+// as the readers do (guess_phase: a line that starts with '@' two lines above one that starts with '+'), then as many line ends are skipped
+// as it takes to stand at the start of a header line.  Shard R ends where shard R + 1 begins: both call this with the same `pos`.
+uint64_t BlockFeeder::record_start(int fd, uint64_t size, uint64_t pos, const std::string& path) {
+    if (pos == 0) return 0;
+    if (pos >= size) return size;
+    const size_t want = (size_t)std::min<uint64_t>(size - (pos - 1), (32u << 20) + 1);   // from the byte before `pos` on
+    std::vector<uint8_t> buf(want);
+    size_t got = 0;
+    while (got < want) {
+        const ssize_t r = pread(fd, buf.data() + got, want - got, (off_t)(pos - 1 + got));
+        if (r < 0) { if (errno == EINTR) continue; throw BarbellError(BB_E_INVALID, "Error reading FASTQ file '" + path + "'"); }
+        if (r == 0) break;
+        got += (size_t)r;
+    }
+    if (got < 2) return size;
+    const bool at_line_start = buf[0] == '\n';
+    const uint8_t* w = buf.data() + 1;
+    const size_t n = got - 1;
+    const int ph = guess_phase(w, n, false);
+    if (ph < 0) {
+        if (pos - 1 + got >= size) return size;   // fewer than three line ends from here to the end of the file: the last record started earlier
+        throw BarbellError(BB_E_FASTQ, "--shard-by bytes: no record boundary found in '" + path + "' within 32 MiB of byte " + std::to_string(pos));
+    }
+    if (at_line_start && ph == 0) return pos;
+    size_t skip = (size_t)((4 - ph) & 3);
+    if (skip == 0) skip = 4;          // inside a header line: the next record
+    size_t p = 0;
+    for (size_t k = 0; k < skip; ++k) {
+        const void* q = memchr(w + p, '\n', n - p);
+        if (!q) return size;          // the file ends first
+        p = (size_t)((const uint8_t*)q - w) + 1;
+    }
+    return pos + p;
+}
+
 BlockFeeder::BlockFeeder(int device_, const std::vector<std::string>& files, size_t chunk_bytes, unsigned n_slots, unsigned n_readers, unsigned n_inflate,
-                         bool two_line_mode, bool pack_mode)
+                         bool two_line_mode, bool pack_mode, uint32_t byte_shard_rank, uint32_t byte_shard_world)
     : device(device_), paths(files), chunk(chunk_bytes), two_line(two_line_mode), pack(two_line_mode && pack_mode), lpr(two_line_mode ? 2 : 4) {
+    shard_rank = byte_shard_rank; shard_world = std::max(1u, byte_shard_world);
+    begins.assign(paths.size(), 0); ends.assign(paths.size(), 0);
     if (const char* e = getenv("BARBELL_AMD_HEAD_BYTES")) HEAD = (size_t)std::max(16L, atol(e));
     is_gz.resize(paths.size()); fds.assign(paths.size(), -1); sizes.assign(paths.size(), 0); size_known.assign(paths.size(), 0);
     maps.assign(paths.size(), nullptr);
@@ -1459,13 +1507,21 @@ BlockFeeder::BlockFeeder(int device_, const std::vector<std::string>& files, siz
         // and inflates gzip, whichever arrives (the reference's paraseq reader streams both as well, io.rs:29-33).
         struct stat pst;
         if (stat(paths[i].c_str(), &pst) != 0) throw BarbellError(BB_E_INVALID, "Failed to open FASTQ input: " + paths[i]);
-        if (!S_ISREG(pst.st_mode)) { is_gz[i] = 1; continue; }
-        is_gz[i] = sniff_gzip(paths[i]) ? 1 : 0;
-        if (is_gz[i]) continue;
+        if (!S_ISREG(pst.st_mode)) { is_gz[i] = 1; }
+        else is_gz[i] = sniff_gzip(paths[i]) ? 1 : 0;
+        if (is_gz[i]) {
+            if (shard_world > 1) throw BarbellError(BB_E_INVALID, "--shard-by bytes: '" + paths[i] + "' is gzip (or a pipe): only plain files can be cut by byte ranges; shard those by file");
+            continue;
+        }
         fds[i] = open(paths[i].c_str(), O_RDONLY);
         struct stat st;
         if (fds[i] < 0 || fstat(fds[i], &st) != 0) throw BarbellError(BB_E_INVALID, "Failed to open FASTQ input: " + paths[i]);
         sizes[i] = (uint64_t)st.st_size; size_known[i] = 1;
+        ends[i] = sizes[i];
+        if (shard_world > 1) {   // this process's byte range of the file, widened to record starts
+            begins[i] = record_start(fds[i], sizes[i], sizes[i] / shard_world * shard_rank, paths[i]);
+            ends[i] = shard_rank + 1 == shard_world ? sizes[i] : record_start(fds[i], sizes[i], sizes[i] / shard_world * (shard_rank + 1), paths[i]);
+        }
         if (two_line && st.st_size > 0 && !getenv("BARBELL_AMD_NO_MMAP")) {  // the readers compact straight out of the page cache: one pass over the text, no copy of the dropped half
             void* m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fds[i], 0);
             if (m != MAP_FAILED) {
@@ -1540,13 +1596,14 @@ bool BlockFeeder::claim(Task& t) {
             if (cur_file >= paths.size()) { if (!claims_done) { claims_done = true; cv.notify_all(); } return false; }
             f = cur_file;
             if (size_known[f]) {
-                if (sizes[f] == 0 && cur_off == 0) {  // empty file: an empty last chunk keeps the sequence simple
-                    t = Task{f, 0, 0, next_seq++, true, nullptr};
-                    ++cur_file;
+                if (cur_off < begins[f]) cur_off = begins[f];
+                if (ends[f] == begins[f]) {  // empty file (or an empty byte range of one): an empty last chunk keeps the sequence simple
+                    t = Task{f, begins[f], 0, next_seq++, true, nullptr};
+                    ++cur_file; cur_off = 0;
                     return true;
                 }
-                const size_t len = (size_t)std::min<uint64_t>(chunk, sizes[f] - cur_off);
-                t = Task{f, cur_off, len, next_seq++, cur_off + len == sizes[f], nullptr};
+                const size_t len = (size_t)std::min<uint64_t>(chunk, ends[f] - cur_off);
+                t = Task{f, cur_off, len, next_seq++, cur_off + len == ends[f], nullptr};
                 cur_off += len;
                 if (t.last) { ++cur_file; cur_off = 0; }
                 return true;
@@ -1554,7 +1611,7 @@ bool BlockFeeder::claim(Task& t) {
         }
         const uint64_t isz = inflater->size_of(f);  // blocks until inflated (thread-safe, several readers may wait)
         std::lock_guard<std::mutex> lk(mu);
-        if (!size_known[f]) { sizes[f] = isz; size_known[f] = 1; chunks_left[f] = std::max<uint64_t>(1, (isz + chunk - 1) / chunk); }
+        if (!size_known[f]) { sizes[f] = isz; ends[f] = isz; size_known[f] = 1; chunks_left[f] = std::max<uint64_t>(1, (isz + chunk - 1) / chunk); }
     }
 }
 void BlockFeeder::reader_loop() {
@@ -1601,16 +1658,16 @@ void BlockFeeder::reader_loop() {
             if (two_line && src) {
                 // the phase is read off the first lines from the chunk's start; they may lie beyond its end (a chunk shorter than three lines):
                 // the mapped file / inflated image can be read ahead
-                ph0 = guess_phase(src, t.len + (size_t)std::min<uint64_t>(sizes[t.file] - (t.off + t.len), 1u << 20), t.off == 0);
-                if (ph0 < 0 && t.off > 0) {   // too few lines from here to the end of the file: read the phase off the text BEFORE the chunk and count on
-                    const uint64_t back = std::min<uint64_t>(t.off, 4u << 20);
+                ph0 = guess_phase(src, t.len + (size_t)std::min<uint64_t>(sizes[t.file] - (t.off + t.len), 1u << 20), t.off == begins[t.file]);   // (a shard's range begins at a record start)
+                if (ph0 < 0 && t.off > begins[t.file]) {   // too few lines from here to the end of the file: read the phase off the text BEFORE the chunk and count on
+                    const uint64_t back = std::min<uint64_t>(t.off - begins[t.file], 4u << 20);
                     const uint8_t* w = src - back;
-                    const int pw = guess_phase(w, (size_t)(sizes[t.file] - (t.off - back)), t.off == back);
+                    const int pw = guess_phase(w, (size_t)(sizes[t.file] - (t.off - back)), t.off - back == begins[t.file]);
                     if (pw >= 0) ph0 = (int)((pw + count_nl(w, (size_t)back)) & 3u);
                 }
                 if (ph0 >= 0) {
                     PackCtx pk;
-                    if (pack) { pk.line_pos0 = line_pos(src - t.off, t.off); pk.after = (size_t)(sizes[t.file] - (t.off + t.len)); pk.look_back(src - t.off, t.off); }
+                    if (pack) { pk.line_pos0 = line_pos(src - t.off, t.off); pk.after = (size_t)(ends[t.file] - (t.off + t.len)); pk.look_back(src - t.off, t.off); }
                     got_len = compact_two_line(dst, src, t.len, ph0, nl, raw_nl, bad, sum, pack ? &pk : nullptr);
                     unpackable = pk.unpackable;
                 } else { if (t.len) memcpy(dst, src, t.len); raw_nl = count_nl(dst, t.len); }   // left raw: the sequencer compacts it with the true phase
@@ -1626,7 +1683,7 @@ void BlockFeeder::reader_loop() {
                     }
                 }
                 if (two_line) {
-                    ph0 = guess_phase(dst, t.len, t.off == 0);
+                    ph0 = guess_phase(dst, t.len, t.off == begins[t.file]);
                     if (ph0 >= 0) got_len = compact_two_line(dst, dst, t.len, ph0, nl, raw_nl, bad, sum);
                     else raw_nl = count_nl(dst, t.len);
                 } else nl = count_nl(dst, t.len);
@@ -1689,7 +1746,7 @@ bool BlockFeeder::next(Block& b) {
                 if (is_gz[sl->file] || !maps[sl->file]) sl->unpackable = true;
                 else {
                     PackCtx pk;
-                    pk.line_pos0 = line_pos(maps[sl->file], sl->off); pk.after = (size_t)(sizes[sl->file] - (sl->off + sl->raw_len));
+                    pk.line_pos0 = line_pos(maps[sl->file], sl->off); pk.after = (size_t)(ends[sl->file] - (sl->off + sl->raw_len));
                     pk.look_back(maps[sl->file], sl->off);
                     sl->got = compact_two_line(body, maps[sl->file] + sl->off, sl->raw_len, truth, sl->nl, sl->raw_nl, sl->bad, sl->sum, &pk);
                     sl->unpackable = pk.unpackable;
@@ -1820,13 +1877,14 @@ unsigned effective_cpus() {
 // the other — written to a file.  Returns the form that was staged: 4 (4-line text), 2 (two-line), 1 (two-line, sequence lines packed); a
 // packed run that meets input without a packed form falls back to the two-line form like annotate() does.
 int stage_blocks(const std::vector<std::string>& read_files, size_t block_bytes, unsigned n_threads, bool two_line, bool pack, const std::string& out_path,
-                 size_t& n_blocks) {
+                 size_t& n_blocks, uint32_t byte_shard_rank, uint32_t byte_shard_world) {
     for (int attempt = 0;; ++attempt) {
         FILE* f = fopen(out_path.c_str(), "wb");
         if (!f) throw BarbellError(BB_E_INVALID, "Failed to create '" + out_path + "'");
         n_blocks = 0;
         try {
-            BlockFeeder feeder(-1, read_files, std::max<size_t>(block_bytes, 16), 8, std::max(1u, n_threads), std::max(1u, n_threads), two_line, pack);
+            BlockFeeder feeder(-1, read_files, std::max<size_t>(block_bytes, 16), 8, std::max(1u, n_threads), std::max(1u, n_threads), two_line, pack,
+                               byte_shard_rank, byte_shard_world);
             const bool packed = feeder.pack;
             BlockFeeder::Block b;
             while (feeder.next(b)) {
@@ -1882,7 +1940,8 @@ static AnnotateStats annotate_once(const std::vector<std::string>& read_files, c
     // host_cut: a slot also waits for the writer threads (at most 4 blocks there), and the last holder may be one of them
     auto feeder_p = std::make_shared<BlockFeeder>(devs[0], read_files, block, (unsigned)((two_line ? 2 : 1) * (3 * G + 2) + (host_cut ? 6 : 0)),
                                                   std::min<unsigned>(std::min<unsigned>(std::max(1u, config.n_threads), 32u), std::max(4u, effective_cpus())), config.n_threads, two_line,
-                                                  config.pack_upload && !getenv("BARBELL_AMD_NO_PACK"));
+                                                  config.pack_upload && !getenv("BARBELL_AMD_NO_PACK"),
+                                                  config.shard_by_bytes ? config.shard_rank : 0u, config.shard_by_bytes ? config.shard_world : 1u);
     const bool packed = feeder_p->pack;   // two bases per byte in the sequence lines (needs the raw text in memory: mapped or inflated)
     feeder_p->keep_slots = config.process_exits_after;
     const double t_feeder_up = now0();
@@ -2225,7 +2284,7 @@ AnnotateStats demux_using_kit(const std::vector<std::string>& fastq_files, const
     c.max_flank_errors = k.max_flank_errors; c.alpha = k.alpha; c.n_threads = (unsigned)k.threads; c.verbose = k.verbose;
     c.min_score = k.min_score; c.min_score_diff = k.min_score_diff; c.use_extended = k.use_extended;
     c.batch_reads = k.batch_reads; c.device = k.device; c.devices = k.devices; c.streams_per_device = k.streams_per_device; c.counts_file = k.counts_file;
-    c.shard_rank = k.shard_rank; c.shard_world = k.shard_world; c.rccl_id = k.rccl_id;
+    c.shard_rank = k.shard_rank; c.shard_world = k.shard_world; c.rccl_id = k.rccl_id; c.shard_by_bytes = k.shard_by_bytes;
     c.filter_patterns = kit_patterns(k.kit_name, k.maximize);
     c.filtered_file = k.output_folder + "/filtered.tsv";
     c.trim = TrimConfig::for_kit(k.failed_out, k.gzip);

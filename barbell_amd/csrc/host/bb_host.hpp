@@ -251,6 +251,8 @@ struct AnnotateConfig {  // config.rs:3-12 with the CLI defaults of bin/main.rs:
     // without it every process keeps its own counts (a warning says so)
     uint32_t shard_rank = 0, shard_world = 1;
     std::string rccl_id;
+    bool shard_by_bytes = false;          // --shard-by bytes: shard R of W takes the records that start in the R-th of W equal byte ranges of EVERY (plain)
+                                          // input file — one big FASTQ over W processes; false: the files with index R modulo W
     // fused filter step: when filter_patterns is non-empty, rows of passing / failing reads go to
     // filtered_file / dropped_file with their cuts column (what `barbell filter -o/--dropped` writes)
     std::vector<Pattern> filter_patterns;
@@ -275,7 +277,7 @@ struct AnnotateStats {
 };
 unsigned effective_cpus();   // CPUs the process can keep busy: affinity mask cut by the cgroup's CPU quota (BARBELL_AMD_CPUS overrides)
 int stage_blocks(const std::vector<std::string>& read_files, size_t block_bytes, unsigned n_threads, bool two_line, bool pack, const std::string& out_path,
-                 size_t& n_blocks);   // `barbell-amd stage`: what the host stages for upload, to a file (no GPU); returns 4 / 2 / 1 (packed)
+                 size_t& n_blocks, uint32_t byte_shard_rank = 0, uint32_t byte_shard_world = 1);   // `barbell-amd stage`: what the host stages for upload, to a file (no GPU); returns 4 / 2 / 1 (packed)
 void shard_rendezvous_reset(const std::string& rccl_id, uint32_t rank);   // bb_rccl.cpp; call at program start of a --shard R/W --rccl-id run
 std::vector<std::string> inspect_summary(const AnnotateStats& st, size_t top_n);  // the lines of inspect.rs:186-205
 
@@ -295,8 +297,9 @@ struct KitConfig {  // config.rs:34-48, CLI defaults bin/main.rs:208-262
     std::vector<int> devices;
     unsigned streams_per_device = 2;
     std::string counts_file;
-    uint32_t shard_rank = 0, shard_world = 1;   // AnnotateConfig::shard_rank / shard_world / rccl_id
+    uint32_t shard_rank = 0, shard_world = 1;   // AnnotateConfig::shard_rank / shard_world / rccl_id / shard_by_bytes
     std::string rccl_id;
+    bool shard_by_bytes = false;
     bool process_exits_after = false;   // AnnotateConfig::process_exits_after
 };
 AnnotateStats demux_using_kit(const std::vector<std::string>& fastq_files, const KitConfig& config);  // use_kit.rs:11-109

@@ -45,6 +45,14 @@ def test_argument_errors(tmp_path):
     assert r.returncode == 2
     r = subprocess.run([CLI, "annotate", "-i", str(fq), "-o", str(tmp_path / "o.tsv"), "--kit", "NOPE"], capture_output=True, text=True)
     assert r.returncode == 1 and "Unknown or unsupported kit" in r.stderr
+    # byte counts take binary suffixes (the documented default is "256Mi")
+    base = [CLI, "stage", "-i", str(fq), "-o", str(tmp_path / "s.bin")]
+    assert subprocess.run(base + ["--block-bytes", "1Ki"], capture_output=True).returncode == 0
+    assert subprocess.run(base + ["--block-bytes", "256MiB"], capture_output=True).returncode == 0
+    r = subprocess.run(base + ["--block-bytes", "12x"], capture_output=True, text=True)
+    assert r.returncode == 2 and "byte count" in r.stderr
+    r = subprocess.run(base + ["--shard", "0/2", "--shard-by", "lines"], capture_output=True, text=True)
+    assert r.returncode == 2 and "files or bytes" in r.stderr
 
 
 def test_shard_argument(tmp_path):
@@ -509,6 +517,48 @@ def test_shards_one_process_per_gpu_reduce_their_histograms(tmp_path):
     p, d = run("lonely", ["--shard", "0/2", "--rccl-id", str(tmp_path / "rv2")])
     _, err = p.communicate(timeout=600)
     assert p.returncode == 1 and "timed out waiting" in err
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pack", [True, False])
+def test_byte_range_shards_of_one_file(tmp_path, pack):
+    """`--shard R/W --shard-by bytes`: ONE plain FASTQ over W processes (one per GPU in production, all on GPU 0 here) — shard R takes the
+    records that start in the R-th of W byte ranges; the shards' TSVs, one after the other, are the single-process TSV and the reduced
+    counts file is the single-process one.  Five blank lines after the last record (CRLF) ride along: every upload form ignores them."""
+    import subprocess as sp
+
+    from barbell_amd import annotate as A
+
+    groups = kits.groups_from_kit("SQK-NBD114-96", flank_max_errors=3)
+    n = 3001
+    bases, offsets = A.synth_reads_host(groups, 77, 200, 4000, 0, n)
+    fq = tmp_path / "reads.fastq"
+    write_fastq(fq, [f"r{i} ch={i % 7}" for i in range(n)], bases, offsets)
+    fq.write_bytes(fq.read_bytes().replace(b"\n", b"\r\n") + b"\r\n" * 5)
+    env = dict(os.environ, BARBELL_AMD_NO_TORCH="1", BARBELL_AMD_RCCL_TIMEOUT="120", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    common = ["--kit", "SQK-NBD114-96", "--flank-max-errors", "3", "--device", "0", "--block-bytes", "1Mi"] + ([] if pack else ["--no-pack"])
+
+    def run(name, extra):
+        d = tmp_path / name
+        d.mkdir(exist_ok=True)
+        return sp.Popen([CLI, "annotate", "-i", str(fq), "-o", str(d / "a.tsv"), "--counts", str(d / "counts.tsv")] + common + extra,
+                        stdout=sp.PIPE, stderr=sp.PIPE, text=True, env=env), d
+
+    p, d_one = run("one", [])
+    _, err = p.communicate(timeout=600)
+    assert p.returncode == 0, err
+    whole = (d_one / "a.tsv").read_bytes().splitlines(keepends=True)
+    assert len({l.split(b"\t")[0] for l in whole[1:]}) > n // 2
+    W = 3
+    rid = str(tmp_path / "rendezvous")
+    procs = [run(f"shard{r}", ["--shard", f"{r}/{W}", "--shard-by", "bytes", "--rccl-id", rid]) for r in range(W)]
+    for p, _ in procs:
+        _, err = p.communicate(timeout=600)
+        assert p.returncode == 0, err
+    parts = [(d / "a.tsv").read_bytes().splitlines(keepends=True) for _, d in procs]
+    assert all(len(x) > len(whole) // 6 for x in parts)                      # every shard had its share
+    assert parts[0] + parts[1][1:] + parts[2][1:] == whole
+    assert (procs[0][1] / "counts.tsv").read_bytes() == (d_one / "counts.tsv").read_bytes()
 
 
 @pytest.mark.gpu

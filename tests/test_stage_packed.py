@@ -106,9 +106,39 @@ def test_input_without_a_packed_form_falls_back(tmp_path):
     assert form == 2
 
 
+@pytest.mark.parametrize("nl", [b"\n", b"\r\n"])
+def test_byte_range_shards_partition_the_records(tmp_path, nl):
+    """--shard R/W --shard-by bytes: shard R stages the records that START in the R-th of W equal byte ranges of the file (the boundary is
+    found in the text: BlockFeeder::record_start) — every record in exactly one shard, in file order, in every upload form; more shards
+    than records leaves some empty; a gzip stream has no entry points and is refused"""
+    rng = np.random.default_rng(31)
+    recs = records(rng, 90, 1, 700)
+    # quality lines that start with '@' and '+' must not be taken for headers / separators
+    text = b"".join(b"@" + h + nl + s + nl + b"+" + nl + (b"@+" * len(s))[: len(s)] + nl for h, s in recs) + nl * 3
+    fq = tmp_path / "a.fastq"
+    fq.write_bytes(text)
+    for flags in ([], ["--no-pack"], ["--no-compact"]):
+        form, _, whole = stage([fq], tmp_path / "o.bin", "--block-bytes", "4096", *flags)
+        for W in (2, 3, 16, 200):
+            parts = [stage([fq], tmp_path / "s.bin", "--block-bytes", "4096", "--shard", f"{R}/{W}", "--shard-by", "bytes", *flags)[2] for R in range(W)]
+            assert b"".join(parts) == whole, (flags, W)
+            if W == 200:
+                assert sum(1 for x in parts if not x) > 100      # more shards than records: most stage nothing
+            if W == 2:
+                assert all(len(x) > len(whole) // 4 for x in parts)
+        env = {"BARBELL_AMD_NO_MMAP": "1"}
+        parts = [stage([fq], tmp_path / "s.bin", "--block-bytes", "4096", "--shard", f"{R}/3", "--shard-by", "bytes", *flags, env=env)[2] for R in range(3)]
+        assert b"".join(parts) == stage([fq], tmp_path / "o.bin", "--block-bytes", "4096", *flags, env=env)[2]
+    gz = tmp_path / "a.fastq.gz"
+    with gzip.open(gz, "wb") as f:
+        f.write(text)
+    r = subprocess.run([CLI, "stage", "-i", str(gz), "-o", str(tmp_path / "s.bin"), "--shard", "0/2", "--shard-by", "bytes"], capture_output=True, text=True)
+    assert r.returncode != 0 and "--shard-by bytes" in r.stderr
+
+
 def test_randomised_staging_slice():
     """a slice of tools/stage_fuzz.py (the full tool runs thousands of seeds): random layouts, line ends, blank tails, tiny chunks"""
     import sys
 
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "stage_fuzz.py"), "100", "120"], capture_output=True, text=True, timeout=900)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "stage_fuzz.py"), "100", "120"], capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0 and r.stdout.strip().endswith("120 seeds 0 bad"), r.stdout[-1500:] + r.stderr[-500:]
