@@ -1521,6 +1521,7 @@ BlockFeeder::BlockFeeder(int device_, const std::vector<std::string>& files, siz
         if (shard_world > 1) {   // this process's byte range of the file, widened to record starts
             begins[i] = record_start(fds[i], sizes[i], sizes[i] / shard_world * shard_rank, paths[i]);
             ends[i] = shard_rank + 1 == shard_world ? sizes[i] : record_start(fds[i], sizes[i], sizes[i] / shard_world * (shard_rank + 1), paths[i]);
+            if (ends[i] < begins[i]) ends[i] = begins[i];   // (not for FASTQ text: record_start is monotone there)
         }
         if (two_line && st.st_size > 0 && !getenv("BARBELL_AMD_NO_MMAP")) {  // the readers compact straight out of the page cache: one pass over the text, no copy of the dropped half
             void* m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fds[i], 0);
