@@ -83,3 +83,25 @@ def split_feasible(policies):
     """(feasible, refuted) halves of a list of policy texts, order kept"""
     ok = [p for p in policies if is_feasible(p)]
     return ok, [p for p in policies if p not in ok]
+
+
+def long_batch(groups, seed, long_lens=(300_000, 1_000_000, 2_500_000), n_short=400):
+    """a batch with megabase reads (glued from synthetic constructs: flank hits all along them) first, in the middle and last among ordinary reads"""
+    import numpy as np
+
+    from barbell_amd import annotate as A
+
+    bases, offsets = A.synth_reads_host(groups, seed, 200, 4000, 0, n_short + sum(long_lens) // 2000 + 8)
+    reads = [bases[int(offsets[i]):int(offsets[i + 1])] for i in range(len(offsets) - 1)]
+    out, k = [], 0
+    for L in long_lens:
+        parts, tot = [], 0
+        while tot < L:
+            parts.append(reads[k]); tot += len(reads[k]); k += 1
+        out.append(np.concatenate(parts)[:L])
+    short = reads[k:k + n_short]
+    # long reads first, in the middle and last
+    seq = [out[0]] + short[: n_short // 2] + [out[1]] + short[n_short // 2:] + [out[2]]
+    offs = np.zeros(len(seq) + 1, dtype=np.uint64)
+    offs[1:] = np.cumsum([len(r) for r in seq])
+    return np.concatenate(seq), offs

@@ -174,6 +174,32 @@ def test_cli_tsv_matches_python_and_oracle(tmp_path, gz):
 
 
 @pytest.mark.gpu
+def test_cli_megabase_reads(tmp_path):
+    """FASTQ records far larger than a block (reads of 0.3 / 1 / 2.5 M nt among ordinary ones, 64 KiB blocks: a record is carried over dozens
+    of chunks), in every upload form and through a gzip stream: the TSV equals the oracle's rows rendered"""
+    from barbell_amd import annotate as A
+    from oracle import pyoracle as po
+    from tests.common import long_batch
+
+    groups = kits.groups_from_kit("SQK-NBD114-96", flank_max_errors=3)
+    bases, offsets = long_batch(groups, 5, n_short=200)
+    ids = [f"r{i}" for i in range(len(offsets) - 1)]
+    rows = po.Oracle([g.as_tuple() for g in groups]).annotate(bases, offsets, n_threads=effective_cpus())
+    want = (A.TSV_HEADER + "\n" + "\n".join(A.format_rows(rows, ids, groups)) + "\n").encode()
+    env = dict(os.environ, BARBELL_AMD_NO_TORCH="1")
+    for gz in (False, True):
+        fq = tmp_path / ("reads.fastq.gz" if gz else "reads.fastq")
+        write_fastq(fq, ids, bases, offsets, gz)
+        for name, extra in (("packed", ["--block-bytes", "64Ki"]), ("text", ["--no-pack", "--block-bytes", "64Ki"]), ("whole", ["--no-compact", "--block-bytes", "1Mi"]),
+                            ("default", [])):
+            out = tmp_path / f"{name}.tsv"
+            r = subprocess.run([CLI, "annotate", "-i", str(fq), "-o", str(out), "--kit", "SQK-NBD114-96", "--flank-max-errors", "3"] + extra,
+                               capture_output=True, text=True, env=env, timeout=600)
+            assert r.returncode == 0, (name, gz, r.stderr)
+            assert out.read_bytes() == want, (name, gz)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("crlf", [False, True])
 def test_cli_packed_upload_on_odd_characters(tmp_path, crlf):
     """By default `annotate` uploads the sequence lines two bases per byte (BB_FASTQ_PACKED: the kernels only look at a character's IUPAC base

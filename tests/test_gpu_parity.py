@@ -261,6 +261,20 @@ def A_rc(b):
     return bytes(b.translate(bytes.maketrans(b"ACGT", b"TGCA"))[::-1])
 
 
+@pytest.mark.parametrize("cfg", ["nbd96", "rbk96x"])
+def test_megabase_reads_among_ordinary_ones(cfg):
+    """nanopore reads reach megabases: reads of 0.3 / 1 / 2.5 M nt (glued from synthetic constructs, so flank hits lie all along them) first,
+    in the middle and last in a batch of ordinary reads — the filtered scan (nbd96) and the full k = 20 scan of two groups (rbk96x): one
+    lane's (read, strand) item is 600 x the others'; rows equal the oracle's"""
+    from tests.common import long_batch
+
+    groups = config_groups(cfg)
+    bases, offsets = long_batch(groups, 11)
+    dm, got, want = run_both(groups, bases, offsets)
+    assert len(want) > 2000
+    assert_same(got, want)
+
+
 def test_empty_and_tiny_reads():
     groups = config_groups("nbd96")
     reads = [b"", b"A", b"ACGT", b"", bytes(groups[0].seqs[5]), bytes(groups[0].seqs[5])[:20], b"N" * 50, b""]
