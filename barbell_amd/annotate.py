@@ -222,6 +222,13 @@ class Demuxer:
         self._check(lib().bb_last_scan_stats(self._ctx(), g, C.byref(f), C.byref(t), C.byref(k)))
         return {"flagged_pieces": f.value, "total_pieces": t.value, "kind": k.value}
 
+    def length_stats(self):
+        """the last batch's read lengths as the scans saw them: {min_lines, max_lines, work_items} (128-byte lines; work items = reads, or
+        segments where the lengths differ: bb_last_length_stats)"""
+        a, b, w = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        self._check(lib().bb_last_length_stats(self._ctx(), C.byref(a), C.byref(b), C.byref(w)))
+        return {"min_lines": a.value, "max_lines": b.value, "work_items": w.value}
+
     def barcode_stats(self, g=0, strand=0):
         """the barcode stage of the last batch for (group, strand): {hits, undecided, lane_kernel} — flank hits listed, how many the fast
         kernel's bounds left to the exact pass, and whether the pair's next batch takes the one-lane-per-hit kernel (bb_last_barcode_stats)"""

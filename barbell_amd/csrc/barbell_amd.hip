@@ -460,6 +460,11 @@ int bb_create_policy(const bb_group_desc* groups, uint32_t n_groups, const bb_pa
     if (getenv("BARBELL_AMD_NO_FAST") && atoi(getenv("BARBELL_AMD_NO_FAST")) != 0) c->fast_path = false;
     if (getenv("BARBELL_AMD_FAST_MARGIN")) c->fast_margin = atof(getenv("BARBELL_AMD_FAST_MARGIN"));
     if (getenv("BARBELL_AMD_ADAPT_FRAC")) c->adapt_frac = atof(getenv("BARBELL_AMD_ADAPT_FRAC"));
+    if (getenv("BARBELL_AMD_SEG_LINES")) {   // lines (128 bytes) per segment of a cut read: a multiple of 4 up to 64; reads above twice that are cut; 0: lanes take whole reads in file order
+        const int v = atoi(getenv("BARBELL_AMD_SEG_LINES"));
+        c->seg_lines = v <= 0 ? 0u : (uint32_t)std::min(64, std::max(4, v & ~3));
+        c->split_above = 2u * c->seg_lines;
+    }
     if (const char* e = getenv("BARBELL_AMD_LANE_FB_FRAC")) c->lane_fb_frac = atof(e);
     if (const char* e = getenv("BARBELL_AMD_LANE")) c->lane_kernel = std::max(0, std::min(2, atoi(e)));
     if (const char* e = getenv("BARBELL_AMD_LANE_NM")) c->lane_nm = atoi(e) != 0;
@@ -507,7 +512,7 @@ void bb_destroy(bb_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     void* ptrs[] = {c->d_groups, c->d_tables, c->d_counts, c->d_cnt, c->d_base, c->d_sums, c->d_nrows, c->d_rowoff, c->d_hitcount,
-                    c->d_lists, c->d_listcnt, c->d_fb_lists, c->d_fbcnt, c->d_flags, c->d_vqueue, c->d_nflag, c->d_raw, c->d_hits, c->d_hitmeta, c->d_pfx, c->d_rows, c->d_in_bases, c->d_in_offsets, c->d_out_rows,
+                    c->d_lists, c->d_listcnt, c->d_fb_lists, c->d_fbcnt, c->d_flags, c->d_vqueue, c->d_nflag, c->d_lenstat, c->d_lencur, c->d_vtab, c->d_perm, c->d_raw, c->d_hits, c->d_hitmeta, c->d_pfx, c->d_rows, c->d_in_bases, c->d_in_offsets, c->d_out_rows,
                     c->d_synth_table, c->d_fpats, c->d_felems, c->d_flabel_ok, c->d_flabel_ids, c->d_frows, c->d_fout, c->d_iout};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -560,18 +565,16 @@ int bb_annotate_batch_dev(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_o
     if ((r = ensure_hits(c, (uint64_t)n * 3 + 1024))) return r;
     const uint64_t M = (uint64_t)n * G * 2 + 1;
     uint32_t n_hits = 0;
-    uint64_t flag_words = 0, batch_bytes = (uint64_t)n * 4000;  // per strand; the byte span is read below where the filter needs it
+    uint64_t flag_words = 0, batch_bytes = 0;  // per strand
     {
+        // the batch's byte span and read lengths (bb_len.h: segments / reads sorted by length where they differ), one round trip
+        uint64_t ends[2] = {0, 0};
+        if ((r = bb_prepare_lengths(c, d_bases, d_offsets, n, &ends[0], &ends[1]))) return r;
+        batch_bytes = ends[1] - ends[0];
         bool any_filt = false;
         for (uint32_t g = 0; g < G; ++g) any_filt = any_filt || c->gdev[g].filt_rows > 0;
         if (any_filt) {  // the flag words of a read sit at (offset >> 9) + 3 * read: the batch's byte span sizes the array
-            uint64_t ends[2] = {0, 0};
-            HIPCHK(c, hipMemcpyAsync(&ends[0], d_offsets, 8, hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipMemcpyAsync(&ends[1], d_offsets + n, 8, hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipStreamSynchronize(c->stream));
-            if (ends[1] < ends[0]) { c->last_error = "offsets are not ascending"; return BB_E_INVALID; }
             flag_words = ((ends[1] - ends[0]) >> 9) + 3ull * n + 3;
-            batch_bytes = ends[1] - ends[0];
             uint64_t n_filt = 0;   // one region of flag words per filtered group (their filter passes run as one launch)
             for (uint32_t g = 0; g < G; ++g) n_filt += c->gdev[g].filt_rows > 0 ? 1 : 0;
             if ((r = grow(c, c->d_flags, c->cap_flags, 2 * flag_words * n_filt))) return r;
@@ -867,6 +870,13 @@ int bb_last_scan_stats(const bb_ctx* c, uint32_t g, uint64_t* flagged_pieces, ui
     if (flagged_pieces) *flagged_pieces = c->last_flagged[g];
     if (total_pieces) *total_pieces = c->last_pieces[g];
     if (kind) *kind = c->last_scan_kind[g];
+    return BB_OK;
+}
+int bb_last_length_stats(const bb_ctx* c, uint32_t* min_lines, uint32_t* max_lines, uint32_t* work_items) {
+    if (!c) return BB_E_INVALID;
+    if (min_lines) *min_lines = c->last_min_lines;
+    if (max_lines) *max_lines = c->last_max_lines;
+    if (work_items) *work_items = c->last_segments;
     return BB_OK;
 }
 int bb_n_kernels(void) { return K_COUNT; }

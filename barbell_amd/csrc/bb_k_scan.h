@@ -171,11 +171,13 @@ __device__ __forceinline__ void flank_scan_lane(const uint8_t* __restrict__ base
                                                 uint32_t off_pv0, uint32_t off_ovh, int ovh_steps, int pol_lm,
                                                 uint32_t g, uint32_t n_groups, uint32_t* __restrict__ cnt,
                                                 bb_hit_raw* __restrict__ hits, uint32_t hit_cap, uint32_t* __restrict__ hit_count,
-                                                const uint32_t* s_peq, uint4* s_line /* this wave's [BB_SCAN_LQ][64] */, uint32_t chunk /* which 256 reads */) {
+                                                const uint32_t* s_peq, uint4* s_line /* this wave's [BB_SCAN_LQ][64] */, uint32_t chunk /* which 256 reads */,
+                                                const uint32_t* __restrict__ perm /* reads by falling length (bb_len.h), or null: lane i takes read i */) {
     constexpr int S = (W <= 2 ? 2 : (W <= 4 ? 4 : 8));
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t read = chunk * 256u + threadIdx.x;
-    const bool live = read < n_reads;
+    const uint32_t slot = chunk * 256u + threadIdx.x;
+    const bool live = slot < n_reads;
+    const uint32_t read = live && perm ? perm[slot] : slot;
     const uint64_t off = live ? offsets[read] : 0ull;
     const uint32_t n = live ? (uint32_t)(offsets[read + 1] - off) : 0u;
     const uint8_t* rb = bases + off;
@@ -359,7 +361,7 @@ __global__ __launch_bounds__(256) void k_flank_scan2(const uint8_t* __restrict__
                                                      uint32_t n_reads, const uint8_t* __restrict__ tables,
                                                      const bb_group_dev* __restrict__ groups, bb_glist gl, uint32_t n_groups,
                                                      uint32_t* __restrict__ cnt, bb_hit_raw* __restrict__ hits,
-                                                     uint32_t hit_cap, uint32_t* __restrict__ hit_count) {
+                                                     uint32_t hit_cap, uint32_t* __restrict__ hit_count, const uint32_t* __restrict__ perm) {
     constexpr int S = (W <= 2 ? 2 : (W <= 4 ? 4 : 8));
     __shared__ __attribute__((aligned(16))) uint32_t s_peq[256 * S];
     __shared__ __attribute__((aligned(16))) uint4 s_lines[4][BB_SCAN_LQ * 64];
@@ -377,9 +379,9 @@ __global__ __launch_bounds__(256) void k_flank_scan2(const uint8_t* __restrict__
     const int m = G->m;
     const uint32_t o_pv0 = G->off_pv0, o_ovh = G->off_ovh;
     if (strand == 0)
-        flank_scan_lane<W, 0>(bases, offsets, n_reads, tables, kk, m, score0, o_pv0, o_ovh, G->ovh_steps, G->pol_lm, g, n_groups, cnt, hits, hit_cap, hit_count, s_peq, line, chunk);
+        flank_scan_lane<W, 0>(bases, offsets, n_reads, tables, kk, m, score0, o_pv0, o_ovh, G->ovh_steps, G->pol_lm, g, n_groups, cnt, hits, hit_cap, hit_count, s_peq, line, chunk, perm);
     else
-        flank_scan_lane<W, 1>(bases, offsets, n_reads, tables, kk, m, score0, o_pv0, o_ovh, G->ovh_steps, G->pol_lm, g, n_groups, cnt, hits, hit_cap, hit_count, s_peq, line, chunk);
+        flank_scan_lane<W, 1>(bases, offsets, n_reads, tables, kk, m, score0, o_pv0, o_ovh, G->ovh_steps, G->pol_lm, g, n_groups, cnt, hits, hit_cap, hit_count, s_peq, line, chunk, perm);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -416,14 +418,15 @@ __device__ __forceinline__ uint64_t filt_word_base(uint64_t off, uint64_t off0, 
 template <bool WIDE>
 __global__ __launch_bounds__(256) void k_flank_filter(const uint8_t* __restrict__ bases, const uint64_t* __restrict__ offsets, uint32_t n_reads,
                                                       const uint8_t* __restrict__ tables, const bb_group_dev* __restrict__ groups, bb_glist gl,
-                                                      uint32_t* __restrict__ flags_all, uint64_t words_per_strand, unsigned long long* __restrict__ n_flagged_all) {
+                                                      uint32_t* __restrict__ flags_all, uint64_t words_per_strand, unsigned long long* __restrict__ n_flagged_all,
+                                                      const uint2* __restrict__ vtab, uint32_t n_virtual, uint32_t seg_lines, uint32_t split_above) {
     __shared__ uint32_t s_fpeq[WIDE ? 512 : 256];
     __shared__ __attribute__((aligned(16))) uint4 s_lines[4][BB_SCAN_LQ * 64];
     static_assert(BB_SCAN_LQ == 8u, "piece bits assume 128-byte lines");
     // one block per (group of the launch, 256 reads); the groups' blocks for the same reads co-scheduled on one XCD (bb_coscheduled).
     // Group gi of the launch writes its flag words into region gi of the array (2 * words_per_strand words each) and counts into its own cell.
     uint32_t gi, pass_, chunk;
-    if (!bb_coscheduled(blockIdx.x, gl.n, 1u, (n_reads + 255u) / 256u, gi, pass_, chunk)) return;
+    if (!bb_coscheduled(blockIdx.x, gl.n, 1u, ((vtab ? n_virtual : n_reads) + 255u) / 256u, gi, pass_, chunk)) return;
     const uint32_t g = gl.g[gi];
     uint32_t* flags = flags_all + (uint64_t)gi * 2ull * words_per_strand;
     unsigned long long* n_flagged = n_flagged_all + g;
@@ -448,15 +451,28 @@ __global__ __launch_bounds__(256) void k_flank_filter(const uint8_t* __restrict_
     __syncthreads();
     uint4* s_line = s_lines[threadIdx.x >> 6];
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t read = chunk * 256u + threadIdx.x;
-    const bool live = read < n_reads;
+    // A lane takes a read, or — where the batch's reads differ in length (bb_len.h: vtab, sorted by falling length so that a wave's lanes
+    // finish together) — ONE SEGMENT of a read: reads of more than split_above lines are cut into segments of seg_lines lines (a multiple
+    // of 4: a flag word holds 4 lines, so no two segments share one).  A segment other than the read's first starts from the all-insertions
+    // column `lead` lines early: a window score <= k depends on the last R + k columns only, so after them the values <= k are exact and
+    // the larger ones stay larger (the argument of k_flank_verify's lead-in); what the lead-in lines flag belongs to the segment before.
+    const uint32_t vslot = chunk * 256u + threadIdx.x;
+    const bool live = vslot < (vtab ? n_virtual : n_reads);
+    const uint2 vt = live && vtab ? vtab[vslot] : make_uint2(vslot, 0u);
+    const uint32_t read = vt.x, seg = vt.y;
     const uint64_t off0 = offsets[0];
     const uint64_t off = live ? offsets[read] : off0;
     const uint32_t n = live ? (uint32_t)(offsets[read + 1] - off) : 0u;
     const uint8_t* rb = bases + off;
     constexpr uint32_t LB = 128u, LSH = 7u;
     const uint32_t mis = (uint32_t)((uint64_t)(uintptr_t)rb & (LB - 1u));
-    const uint32_t nlines = n ? (mis + n + LB - 1u) >> LSH : 0u;
+    const uint32_t nlines_read = n ? (mis + n + LB - 1u) >> LSH : 0u;
+    const bool cut = vtab && nlines_read > split_above;
+    const uint32_t l_first = cut ? seg * seg_lines : 0u;
+    const uint32_t nlines = cut ? min(nlines_read, l_first + seg_lines) : nlines_read;   // one past the segment's last line
+    const bool last_seg = nlines == nlines_read;
+    const uint32_t lead = l_first ? min(l_first, ((uint32_t)R + (uint32_t)min(G->flank_k, 127) + LB) >> LSH) : 0u;
+    const uint32_t l_begin = l_first - lead;
     const uint8_t* line0 = rb - mis;
     uint32_t* fl0 = flags + filt_word_base(off, off0, read);
     uint32_t* fl1 = fl0 + words_per_strand;
@@ -468,7 +484,7 @@ __global__ __launch_bounds__(256) void k_flank_filter(const uint8_t* __restrict_
     const int32_t* ovh = reinterpret_cast<const int32_t*>(tables + G->off_ovh);
     const uint32_t pvA0 = own_rows ? reinterpret_cast<const uint32_t*>(tables + G->off_pv0)[0] & maskR : maskR;
     const int scA0 = own_rows ? (int)__popc(pvA0) : R;
-    uint32_t pv = WIDE ? pvA0 : (pvA0 << SA) | (maskR << (SA + 16u)), mv = 0u;
+    uint32_t pv = WIDE ? (l_first ? maskR : pvA0) : ((l_first ? maskR : pvA0) << SA) | (maskR << (SA + 16u)), mv = 0u;
     uint32_t pvB = maskR, mvB = 0u;  // WIDE: the rc strand's word
     // Both blocks' D[R][i], biased by 15 - k, in the two halves of one register (the bottom rows' delta bits sit at bits 14
     // and 30: one mask, one shift): a half's bit 4 is clear exactly while its score is <= k, so AND-ing the register over
@@ -476,9 +492,10 @@ __global__ __launch_bounds__(256) void k_flank_filter(const uint8_t* __restrict_
     // bias 31 - k, bit 5.)
     const uint32_t TOPS = 0x40004000u;
     const int bias = (WIDE ? 31 : 15) - kk;
-    uint32_t sc2 = WIDE ? (uint32_t)(scA0 + bias) : ((uint32_t)(R + bias) << 16) | (uint32_t)(scA0 + bias);
+    const int scA_init = l_first ? R : scA0;
+    uint32_t sc2 = WIDE ? (uint32_t)(scA_init + bias) : ((uint32_t)(R + bias) << 16) | (uint32_t)(scA_init + bias);
     uint32_t scB = (uint32_t)(R + bias);
-    uint32_t keep = WIDE ? sc2 | ~0x20u : sc2 | ~0x00100010u;  // column 0 counts for the first piece
+    uint32_t keep = l_first ? 0xFFFFFFFFu : (WIDE ? sc2 | ~0x20u : sc2 | ~0x00100010u);  // column 0 (of the read) counts for the first piece
     uint32_t keepB = scB | ~0x20u;
     uint32_t bitsA = 0u, bitsB = 0u, nflag = 0u;
     // one column of the narrow form on the column's Eq word (both blocks)
@@ -536,14 +553,15 @@ __global__ __launch_bounds__(256) void k_flank_filter(const uint8_t* __restrict_
         }
         keep = 0xFFFFFFFFu;
     };
-    uint32_t lmax = nlines;
+    uint32_t lmax = nlines - l_begin;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) lmax = max(lmax, (uint32_t)__shfl_xor((int)lmax, d, 64));
     lmax = __builtin_amdgcn_readfirstlane(lmax);
-    for (uint32_t l = 0; l < lmax; ++l) {
+    for (uint32_t lj = 0; lj < lmax; ++lj) {
+        const uint32_t l = l_begin + lj;   // line of the read
         const bool on = l < nlines;
         if (on) {
-            const uint8_t* src = line0 + (l << LSH);
+            const uint8_t* src = line0 + ((uint64_t)l << LSH);
 #pragma unroll
             for (int q = 0; q < 8; ++q)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 16 * q),
@@ -579,6 +597,7 @@ __global__ __launch_bounds__(256) void k_flank_filter(const uint8_t* __restrict_
                 if (16u * (uint32_t)q + 16u > lo && 16u * (uint32_t)q < hi) commit(qb + (uint32_t)q);
             }
         }
+        if (on && l < l_first) { bitsA = 0u; bitsB = 0u; }   // a lead-in line: its flags are the previous segment's
         if (on && ((l & 3u) == 3u || l + 1u == nlines)) {
             if (bitsA) fl0[l >> 2] = bitsA;  // the array is zeroed before the launch: only words with a flag are written
             if (bitsB) fl1[l >> 2] = bitsB;
@@ -596,14 +615,14 @@ __global__ __launch_bounds__(256) void k_flank_filter(const uint8_t* __restrict_
     // end at the read's end, i.e. the rc block's first R-o rows do in its last column: D[R-o][n] + floor(alpha * o) <= k is
     // necessary.  One bit in the word after the rc strand's piece words tells k_flank_verify to scan the rc strand's
     // first columns (groups with BB_FILT_RC_BEGIN_HINT; windows that start deeper never hang, see upload_tables).
-    if (live && n && (G->filt_mode & BB_FILT_RC_BEGIN_HINT)) {
+    if (live && n && last_seg && (G->filt_mode & BB_FILT_RC_BEGIN_HINT)) {
         const uint32_t pb = WIDE ? pvB & maskR : (pv >> (SA + 16u)) & maskR, mb = WIDE ? mvB & maskR : (mv >> (SA + 16u)) & maskR;
         uint32_t hint = 0u;
         for (int o = 1; o < R; ++o) {
             const uint32_t low = (1u << (R - o)) - 1u;
             if ((int32_t)__popc(pb & low) - (int32_t)__popc(mb & low) + ovh[o] <= G->flank_k) hint = 1u;
         }
-        if (hint) fl1[(nlines + 3u) >> 2] = hint;
+        if (hint) fl1[(nlines_read + 3u) >> 2] = hint;
     }
 }
 

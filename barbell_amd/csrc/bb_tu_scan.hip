@@ -5,6 +5,7 @@
 
 #include "bb_launch.h"
 #include "bb_k_scan.h"
+#include "bb_len.h"
 
 int bb_scan_u32(bb_ctx* c, const uint32_t* in, uint32_t* out, uint64_t n) {
     const uint32_t nb = (uint32_t)((n + 2047) / 2048);
@@ -26,7 +27,7 @@ void launch_scan2(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets, 
         for (uint32_t i = 0; i < gl.n; ++i) gl.g[i] = (uint8_t)gs[at + i];
         hipLaunchKernelGGL(k_flank_scan2<W>, dim3(bb_coscheduled_blocks(gl.n, 2u, (n + 255u) / 256u)), dim3(256), 0, c->stream, d_bases, d_offsets, n,
                            (const uint8_t*)c->d_tables, (const bb_group_dev*)c->d_groups, gl, (uint32_t)c->groups.size(), c->d_cnt,
-                           c->d_raw, c->cap_hits, c->d_hitcount);
+                           c->d_raw, c->cap_hits, c->d_hitcount, c->perm);
     }
 }
 void launch_scan2_w(bb_ctx* c, int W, const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n, const std::vector<uint32_t>& gs) {
@@ -51,6 +52,43 @@ void launch_verify(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets,
                        flags, flag_words, c->d_cnt, c->d_raw, c->cap_hits, c->d_hitcount, c->d_vqueue);
 }
 }  // namespace
+
+// The batch's read lengths, once per batch and before its scans (bb_len.h).  Batches of (nearly) equal reads — the benchmark's — pay one small
+// kernel in a round trip the filtered scan made already; others get their segments / reads sorted by falling length.
+int bb_prepare_lengths(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n, uint64_t* off0, uint64_t* off1) {
+    c->vtab = nullptr; c->perm = nullptr; c->n_virtual = 0;
+    if (!c->d_lenstat) {
+        HIPCHK(c, hipMalloc((void**)&c->d_lenstat, sizeof(bb_lenstat)));
+        HIPCHK(c, hipMalloc((void**)&c->d_lencur, sizeof(bb_lencur)));
+    }
+    const uint32_t seg_lines = c->seg_lines ? c->seg_lines : 32u, split_above = c->seg_lines ? c->split_above : 0xFFFFFFFFu;
+    bb_lenstat st;
+    memset(&st, 0, sizeof(st));
+    st.min_nl = 0xFFFFFFFFu;
+    HIPCHK(c, hipMemcpyAsync(c->d_lenstat, &st, sizeof(st), hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_len_hist, dim3((n + 255u) / 256u), dim3(256), 0, c->stream, d_bases, d_offsets, n, seg_lines, split_above, c->d_lenstat);
+    HIPCHK(c, hipMemcpyAsync(&st, c->d_lenstat, sizeof(st), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    *off0 = st.off0; *off1 = st.off1;
+    c->last_min_lines = st.min_nl; c->last_max_lines = st.max_nl; c->last_segments = n;
+    if (st.off1 < st.off0) { c->last_error = "offsets are not ascending"; return BB_E_INVALID; }
+    if (!c->seg_lines || (st.max_nl <= c->split_above && st.max_nl - st.min_nl <= 2u)) return BB_OK;   // lanes of a wave finish together as they are
+    bb_lencur cur;
+    uint64_t at = 0;
+    for (int b = (int)BB_LEN_SEG_BINS - 1; b >= 0; --b) { cur.seg[b] = (uint32_t)at; at += st.seg[b]; }
+    const uint64_t n_virtual = at;
+    at = 0;
+    for (int b = (int)BB_LEN_RD_BINS - 1; b >= 0; --b) { cur.rd[b] = (uint32_t)at; at += st.rd[b]; }
+    if (n_virtual >= 0xFFFFFFFFull) { c->last_error = "more than 2^32 read segments in a batch"; return BB_E_UNSUPPORTED; }
+    int r;
+    if ((r = grow(c, c->d_vtab, c->cap_vtab, n_virtual + 1))) return r;
+    if ((r = grow(c, c->d_perm, c->cap_perm, (uint64_t)n + 1))) return r;
+    HIPCHK(c, hipMemcpyAsync(c->d_lencur, &cur, sizeof(cur), hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_len_scatter, dim3((n + 255u) / 256u), dim3(256), 0, c->stream, d_bases, d_offsets, n, seg_lines, split_above, c->d_lencur, c->d_vtab, c->d_perm);
+    HIPCHK(c, hipGetLastError());
+    c->vtab = c->d_vtab; c->perm = c->d_perm; c->n_virtual = (uint32_t)n_virtual; c->last_segments = (uint32_t)n_virtual;
+    return BB_OK;
+}
 
 // The flank scan of EVERY group of the context on one batch (searcher.rs:433-438: `for group in groups { search(flank, read) }`).
 // Groups are sorted by what their scan is — the full-height streaming scan (no filter window says enough, or the group's last probed batch
@@ -87,13 +125,13 @@ int bb_launch_scans(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets
                 gl.n = (uint32_t)std::min(filt[wide].size() - at, sizeof(bb_glist::g));
                 for (uint32_t i = 0; i < gl.n; ++i) { gl.g[i] = (uint8_t)filt[wide][at + i]; region[filt[wide][at + i]] = reg + i; }
                 uint32_t* fl = c->d_flags + (uint64_t)reg * 2ull * flag_words;
-                const dim3 grid(bb_coscheduled_blocks(gl.n, 1u, (n + 255u) / 256u));
+                const dim3 grid(bb_coscheduled_blocks(gl.n, 1u, ((c->vtab ? c->n_virtual : n) + 255u) / 256u));   // a lane per read, or per segment (bb_len.h)
                 if (wide)
                     hipLaunchKernelGGL(k_flank_filter<true>, grid, dim3(256), 0, c->stream, d_bases, d_offsets, n, (const uint8_t*)c->d_tables,
-                                       (const bb_group_dev*)c->d_groups, gl, fl, flag_words, c->d_nflag);
+                                       (const bb_group_dev*)c->d_groups, gl, fl, flag_words, c->d_nflag, c->vtab, c->n_virtual, c->seg_lines, c->split_above);
                 else
                     hipLaunchKernelGGL(k_flank_filter<false>, grid, dim3(256), 0, c->stream, d_bases, d_offsets, n, (const uint8_t*)c->d_tables,
-                                       (const bb_group_dev*)c->d_groups, gl, fl, flag_words, c->d_nflag);
+                                       (const bb_group_dev*)c->d_groups, gl, fl, flag_words, c->d_nflag, c->vtab, c->n_virtual, c->seg_lines, c->split_above);
                 reg += gl.n;
             }
     }

@@ -174,6 +174,13 @@ int         bb_last_dominant_kernel(const bb_ctx* ctx, char* name, size_t name_c
  * synthetic benchmark's.                                                                                                  */
 int bb_last_scan_stats(const bb_ctx* ctx, uint32_t group, uint64_t* flagged_pieces, uint64_t* total_pieces, int* kind);
 
+/* The read lengths of the last batch as the scans saw them: the shortest and the longest read in 128-byte lines, and the number of work
+ * items the scans' lanes drew — the number of reads for a batch of (nearly) equal reads (lanes take reads in file order), otherwise the
+ * number of SEGMENTS: reads of more than 64 lines are cut into segments of 32 for the filter pass and lanes take segments / reads by
+ * falling length, so that a wave's lanes finish together and a 100 kb read is not one lane's work (real runs are heavy-tailed; the
+ * reference's threads take reads one by one, annotator.rs:123-135, and never meet the problem).  Results do not depend on it.     */
+int bb_last_length_stats(const bb_ctx* ctx, uint32_t* min_lines, uint32_t* max_lines, uint32_t* work_items);
+
 /* The barcode stage of the last batch, per (group, strand): flank hits listed for it, how many of them the fast kernel's bounds left
  * undecided (those are scored exactly by the second pass), and whether the pair's NEXT batch takes the one-lane-per-hit kernel
  * (k_barcode_lane: its bound assumes the shared pad rows match; above 20 % undecided the pair goes back to k_barcode_pfx for 32
