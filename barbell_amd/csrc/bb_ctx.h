@@ -70,6 +70,11 @@ struct bb_ctx {
     struct bb_lenstat* d_lenstat = nullptr; struct bb_lencur* d_lencur = nullptr;
     uint2* d_vtab = nullptr; uint64_t cap_vtab = 0;
     uint32_t* d_perm = nullptr; uint64_t cap_perm = 0;
+    uint32_t* d_vcut = nullptr; uint64_t cap_vcut = 0;         // per vtab entry: its cell among the cut reads' segments
+    uint32_t* d_cutread = nullptr; uint64_t cap_cutread = 0;   // per cell: the read
+    uint4* d_cutlist = nullptr; uint64_t cap_cutlist = 0;      // per cut read: read, first cell, segments
+    uint32_t* d_vcnt = nullptr; uint64_t cap_vcnt = 0;         // hit counts per (cell, group, strand) of the segmented full scan
+    uint32_t n_cut_reads = 0, n_cut_segs = 0;
     const uint2* vtab = nullptr; const uint32_t* perm = nullptr;   // of the batch in hand (d_vtab / d_perm or null)
     uint32_t n_virtual = 0;        // entries of vtab
     uint32_t seg_lines = 32, split_above = 64;   // BARBELL_AMD_SEG_LINES (a multiple of 4; split_above = twice that; 0 = never cut, never sort)

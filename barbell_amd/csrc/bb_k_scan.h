@@ -82,10 +82,15 @@ __device__ __forceinline__ void scan_finish(bool live, uint32_t n, int m, int32_
                                             uint32_t idx, lm_lane& st, hit_buf& hb, const int32_t* __restrict__ ovh, uint32_t read,
                                             uint32_t g, uint32_t n_groups, uint32_t* __restrict__ cnt, bb_hit_raw* __restrict__ hits,
                                             uint32_t hit_cap, uint32_t* __restrict__ hit_count, int pol_lm, bool at_end = true, int ovh_steps = 0x7FFFFFFF,
-                                            bb_hit_raw* stage = nullptr, uint32_t* stage_fill = nullptr) {
+                                            bb_hit_raw* stage = nullptr, uint32_t* stage_fill = nullptr,
+                                            // a SEGMENT of a read (flank_scan_lane<.., SEG>): where the count goes, whether the lane reports yet (armed) and
+                                            // whether the overhang positions are its own (the read's last segment) or only the valley it is in
+                                            uint32_t* cnt_cell = nullptr, bool seg = false, bool armed = true, bool last_seg = true) {
     const uint32_t lane = threadIdx.x & 63u;
     const int TB = (m - 1) & 31;
     const bool lm_left = pol_lm == BB_LM_PLATEAU_LEFT, lm_strict = pol_lm == BB_LM_STRICT;
+    const int32_t kk_true = kk;
+    int32_t kkl = (seg && !armed) ? -1 : kk;   // the budget the local-minimum machine sees: -1 while the lane must not report
     // right overhang (oracle [H4]): C[n+o] = D[m-o][n] + floor(alpha*o), o = 1..m
     if (live) {
         int32_t d = sc;
@@ -99,8 +104,12 @@ __device__ __forceinline__ void scan_finish(bool live, uint32_t n, int m, int32_
                 mv[w] = (mv[w] << 1) | (w ? (mv[w - 1] >> 31) : 0u);
             }
             ++idx;
-            BB_LM_STEP_BUF(st, d + ovh[o], idx);
+            { const int32_t kk = kkl; BB_LM_STEP_BUF(st, d + ovh[o], idx); }
+            if (seg && d + ovh[o] > kk_true) {   // between valleys: the last segment starts to report, an earlier one that followed its valley here is done
+                if (last_seg) kkl = kk_true; else kkl = -1;
+            }
         }
+        const int32_t kk = kkl;
         if (at_end && st.dec && st.prev <= kk) {
             const uint32_t e_ = lm_left ? st.cand : n + (uint32_t)m, k_ = st.nrep;
             if (k_ < 4u) {
@@ -112,7 +121,7 @@ __device__ __forceinline__ void scan_finish(bool live, uint32_t n, int m, int32_
             }
             st.nrep = k_ + 1u;
         }
-        cnt[((uint64_t)read * n_groups + g) * 2 + STRAND] = st.nrep;
+        if (cnt_cell) *cnt_cell = st.nrep; else cnt[((uint64_t)read * n_groups + g) * 2 + STRAND] = st.nrep;
     }
     // flush the buffered hits: one atomic per wave
     {
@@ -165,25 +174,59 @@ __device__ __forceinline__ void scan_finish(bool live, uint32_t n, int m, int32_
 #ifndef BB_SCAN_LQ
 #define BB_SCAN_LQ 8u  // 16-byte pieces per streamed line: 8 = 128-byte lines (8 KB of LDS per wave), 4 = 64-byte lines
 #endif
-template <int W, int STRAND>
+// SEG: the lane takes ONE SEGMENT of a read (bb_len.h: vtab; reads of more than split_above lines are cut into segments of seg_lines lines) —
+// for batches whose reads differ in length, where a lane per read makes a wave wait for its longest read and the batch for its longest lane.
+// The hits must be the whole read's scan's, so the segments divide them by VALLEY (a maximal run of columns with cost <= k: the local-minimum
+// machine acts inside valleys and on the steps into / out of them only): a valley belongs to the segment that holds its first column.
+//   * a segment other than the first starts m + k columns early from the all-insertions column (values <= k are exact after that, larger ones
+//     stay larger: k_flank_verify's lead-in) and does not report (the machine sees a budget of -1) until it has seen a column > k at or after
+//     the last column before its own first — a valley in progress there began earlier and is the previous segment's;
+//   * a segment follows a valley it owns past its last line, until the first column > k (then it is done), to the read's end and over the
+//     overhang positions if need be; valleys that begin in the overhang positions are the last segment's.
+// Counts go to a cell per (cut segment, group, strand), hits carry the segment (bit 31 set): k_seg_fold / k_seg_hits turn both into the
+// read's (ordinals run on from segment to segment in scan order).
+template <int W, int STRAND, bool SEG = false>
 __device__ __forceinline__ void flank_scan_lane(const uint8_t* __restrict__ bases, const uint64_t* __restrict__ offsets,
                                                 uint32_t n_reads, const uint8_t* __restrict__ tables, int32_t kk, int m, int32_t score0,
                                                 uint32_t off_pv0, uint32_t off_ovh, int ovh_steps, int pol_lm,
                                                 uint32_t g, uint32_t n_groups, uint32_t* __restrict__ cnt,
                                                 bb_hit_raw* __restrict__ hits, uint32_t hit_cap, uint32_t* __restrict__ hit_count,
                                                 const uint32_t* s_peq, uint4* s_line /* this wave's [BB_SCAN_LQ][64] */, uint32_t chunk /* which 256 reads */,
-                                                const uint32_t* __restrict__ perm /* reads by falling length (bb_len.h), or null: lane i takes read i */) {
+                                                const uint32_t* __restrict__ perm /* reads by falling length (bb_len.h), or null: lane i takes read i */,
+                                                const uint2* __restrict__ vtab = nullptr, uint32_t n_virtual = 0, uint32_t seg_lines = 0, uint32_t split_above = 0,
+                                                const uint32_t* __restrict__ vcut = nullptr, uint32_t* __restrict__ vcnt = nullptr) {
     constexpr int S = (W <= 2 ? 2 : (W <= 4 ? 4 : 8));
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t slot = chunk * 256u + threadIdx.x;
-    const bool live = slot < n_reads;
-    const uint32_t read = live && perm ? perm[slot] : slot;
-    const uint64_t off = live ? offsets[read] : 0ull;
-    const uint32_t n = live ? (uint32_t)(offsets[read + 1] - off) : 0u;
+    const bool live = slot < (SEG ? n_virtual : n_reads);
+    const uint2 vt = SEG && live ? vtab[slot] : make_uint2(0u, 0u);
+    const uint32_t rd = SEG ? vt.x : (live && perm ? perm[slot] : slot);   // the read
+    const uint64_t off = live ? offsets[rd] : 0ull;
+    const uint32_t n = live ? (uint32_t)(offsets[rd + 1] - off) : 0u;
     const uint8_t* rb = bases + off;
     const int TB = (m - 1) & 31;
     const uint32_t* pv0 = reinterpret_cast<const uint32_t*>(tables + off_pv0);
     const int32_t* ovh = reinterpret_cast<const int32_t*>(tables + off_ovh);
+
+    // geometry of the walk in forward byte coordinates [0, n): the lane's lines are the LB-byte-aligned lines of HBM that hold its read, in scan order
+    const uint64_t a0 = (uint64_t)(uintptr_t)rb;
+    constexpr uint32_t LB = BB_SCAN_LQ * 16u, LSH = BB_SCAN_LQ == 16 ? 8u : BB_SCAN_LQ == 8 ? 7u : 6u;  // line bytes (256, 128 or 64)
+    static_assert(!SEG || BB_SCAN_LQ == 8u, "segments are counted in 128-byte lines");
+    const uint32_t mis = STRAND == 0 ? (uint32_t)(a0 & (LB - 1u)) : (uint32_t)((LB - (uint32_t)((a0 + n) & (LB - 1u))) & (LB - 1u));
+    const uint32_t nlines_read = n ? (mis + n + LB - 1u) >> LSH : 0u;
+    // SEG: lines [l_first, l_end) of the read are the lane's own, scanning starts at l_begin (lead-in) and may go on past l_end (a valley it owns)
+    const bool cut = SEG && nlines_read > split_above;
+    const uint32_t l_first = cut ? vt.y * seg_lines : 0u;
+    const uint32_t l_end = cut ? min(nlines_read, l_first + seg_lines) : nlines_read;
+    const bool last_seg = l_end == nlines_read;
+    const uint32_t l_begin = l_first - min(l_first, ((uint32_t)m + (uint32_t)kk + LB) >> LSH);
+    const uint32_t s_pos = l_first ? (l_first << LSH) - mis : 0u;            // first own scan position
+    const uint32_t e_pos = last_seg ? 0xFFFFFFFFu : (l_end << LSH) - mis;    // one past the last own one (the last segment owns the overhang positions too)
+    const uint32_t cs = cut ? vcut[slot] : 0u;                               // the segment's cell (cut reads)
+    const uint32_t read = cut ? (cs | 0x80000000u) : rd;                     // what the hits carry
+    uint32_t* const cnt_cell = live ? (cut ? vcnt + ((uint64_t)cs * n_groups + g) * 2 + STRAND : cnt + ((uint64_t)rd * n_groups + g) * 2 + STRAND) : nullptr;
+    bool armed = l_first == 0u, fin = false;
+    int32_t kkl = armed ? kk : -1;   // the budget the local-minimum machine sees
 
     uint32_t pv[W], mv[W];
 #pragma unroll
@@ -192,7 +235,20 @@ __device__ __forceinline__ void flank_scan_lane(const uint8_t* __restrict__ base
     lm_lane st = {score0, 1u, 0u, 0u};
     hit_buf hb = {0u, 0u, 0u, 0u, 0u};
     uint32_t idx = 0;  // scan position (characters consumed)
+    if (SEG && l_begin) {   // from the all-insertions column, m + k columns (whole lines of them) ahead of the segment
+#pragma unroll
+        for (int x = 0; x < W; ++x) { const int bt = m - 32 * x; pv[x] = bt >= 32 ? 0xFFFFFFFFu : (bt > 0 ? ((1u << bt) - 1u) : 0u); }
+        sc = m; st.prev = m;
+        idx = (l_begin << LSH) - mis;
+    }
     const bool lm_left = pol_lm == BB_LM_PLATEAU_LEFT, lm_strict = pol_lm == BB_LM_STRICT;
+    // SEG, after a column (or four) that left the score at sc: the steps between valleys
+    auto seg_after = [&]() {
+        if (!armed) {
+            if (idx >= e_pos) fin = true;                                   // a valley of an earlier segment covers this one
+            else if (sc > kk && idx >= s_pos) { armed = true; kkl = kk; }
+        } else if (sc > kk && idx >= e_pos) { kkl = -1; fin = true; }
+    };
 
     auto step = [&](uint32_t ch) {
         uint32_t eq[W], d0[W], ph[W], mh[W];
@@ -200,7 +256,12 @@ __device__ __forceinline__ void flank_scan_lane(const uint8_t* __restrict__ base
         myers_step<W>(pv, mv, eq, d0, ph, mh);
         sc += (int32_t)((ph[W - 1] >> TB) & 1u) - (int32_t)((mh[W - 1] >> TB) & 1u);
         ++idx;
-        BB_LM_STEP_BUF(st, sc, idx);
+        if constexpr (SEG) {
+            { const int32_t kk = kkl; BB_LM_STEP_BUF(st, sc, idx); }
+            seg_after();
+        } else {
+            BB_LM_STEP_BUF(st, sc, idx);
+        }
     };
     // Fast path: the bottom-row score moves by at most 1 per column, so while it is more than 4 above
     // k no position of the next 4 columns can be reported and neither the score nor the local-minimum
@@ -222,9 +283,6 @@ __device__ __forceinline__ void flank_scan_lane(const uint8_t* __restrict__ base
         myers_step<W>(pv, mv, eq, d0, ph, mh);
     };
 
-    // geometry of the walk in forward byte coordinates [0, n)
-    const uint64_t a0 = (uint64_t)(uintptr_t)rb;
-    constexpr uint32_t LB = BB_SCAN_LQ * 16u, LSH = BB_SCAN_LQ == 16 ? 8u : BB_SCAN_LQ == 8 ? 7u : 6u;  // line bytes (256, 128 or 64)
     // one group of 4 columns of the 16-byte piece v, starting at byte b0 (scan order): wave-uniform choice of path;
     // sc is exact on entry (either stepped or re-derived)
     auto group4 = [&](const uint4& v, int b0) {
@@ -245,6 +303,7 @@ __device__ __forceinline__ void flank_scan_lane(const uint8_t* __restrict__ base
             idx += 4;
             sc = score_now();
             st.prev = sc;  // > k: the lazily evaluated `dec` needs no update (see lm_lane)
+            if constexpr (SEG) seg_after();
         }
     };
 #if BB_SCAN_UNALIGNED == 2
@@ -253,17 +312,19 @@ __device__ __forceinline__ void flank_scan_lane(const uint8_t* __restrict__ base
     // early.  Those two partial lines go through the same LDS path with the bytes outside the read predicated off, so
     // every line of the batch is requested once per strand and no lane runs a byte loop of its own.  (A line that
     // holds one byte of the read lies in that byte's page: the bytes outside the read are fetched, never used.)
-    const uint32_t mis = STRAND == 0 ? (uint32_t)(a0 & (LB - 1u)) : (uint32_t)((LB - (uint32_t)((a0 + n) & (LB - 1u))) & (LB - 1u));
-    const uint32_t nlines = n ? (mis + n + LB - 1u) >> LSH : 0u;
+    const uint32_t nlines = nlines_read;
     const uint8_t* line0 = STRAND == 0 ? rb - mis : rb + n + mis - LB;  // first line in scan order
     uint32_t lmax = nlines;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) lmax = max(lmax, (uint32_t)__shfl_xor((int)lmax, d, 64));
     lmax = __builtin_amdgcn_readfirstlane(lmax);
-    for (uint32_t l = 0; l < lmax; ++l) {
-        const bool on = l < nlines;
+    for (uint32_t lj = 0; SEG || lj < lmax; ++lj) {
+        const uint32_t l = l_begin + lj;   // line of the read, in scan order
+        // SEG: the lane's own lines, then on while a valley it owns is open
+        const bool on = SEG ? (live && !fin && l < nlines && (l < l_end || armed)) : l < nlines;
+        if (SEG && !__any(on)) break;
         if (on) {
-            const uint8_t* src = STRAND == 0 ? line0 + (l << LSH) : line0 - (l << LSH);
+            const uint8_t* src = STRAND == 0 ? line0 + ((uint64_t)l << LSH) : line0 - ((uint64_t)l << LSH);
 #pragma unroll
             for (int q = 0; q < (int)BB_SCAN_LQ; ++q)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 16 * q),
@@ -336,7 +397,11 @@ __device__ __forceinline__ void flank_scan_lane(const uint8_t* __restrict__ base
     for (uint32_t t = 0; t < tail; ++t) step(STRAND == 0 ? rb[head + (nlines << LSH) + t] : rb[tail - 1 - t]);
 #endif
 
-    scan_finish<W, STRAND>(live, n, m, kk, sc, pv, mv, idx, st, hb, ovh, read, g, n_groups, cnt, hits, hit_cap, hit_count, pol_lm, true, ovh_steps);
+    if constexpr (SEG)   // the overhang positions and the pending minimum: the lane that got to the read's end with the right to report, or to earn it there
+        scan_finish<W, STRAND>(live, n, m, kk, sc, pv, mv, idx, st, hb, ovh, read, g, n_groups, cnt, hits, hit_cap, hit_count, pol_lm, !fin && idx == n, ovh_steps,
+                               nullptr, nullptr, cnt_cell, true, armed, last_seg);
+    else
+        scan_finish<W, STRAND>(live, n, m, kk, sc, pv, mv, idx, st, hb, ovh, read, g, n_groups, cnt, hits, hit_cap, hit_count, pol_lm, true, ovh_steps);
 }
 
 // The groups of one launch (round 5).  Every group of a context scans the same reads; launched one after the other each pass streamed the
@@ -382,6 +447,70 @@ __global__ __launch_bounds__(256) void k_flank_scan2(const uint8_t* __restrict__
         flank_scan_lane<W, 0>(bases, offsets, n_reads, tables, kk, m, score0, o_pv0, o_ovh, G->ovh_steps, G->pol_lm, g, n_groups, cnt, hits, hit_cap, hit_count, s_peq, line, chunk, perm);
     else
         flank_scan_lane<W, 1>(bases, offsets, n_reads, tables, kk, m, score0, o_pv0, o_ovh, G->ovh_steps, G->pol_lm, g, n_groups, cnt, hits, hit_cap, hit_count, s_peq, line, chunk, perm);
+}
+
+// The full scan of a batch whose reads differ in length: a lane per SEGMENT (flank_scan_lane<.., SEG>)
+template <int W>
+__global__ __launch_bounds__(256) void k_flank_scan_seg(const uint8_t* __restrict__ bases, const uint64_t* __restrict__ offsets,
+                                                        uint32_t n_reads, const uint8_t* __restrict__ tables,
+                                                        const bb_group_dev* __restrict__ groups, bb_glist gl, uint32_t n_groups,
+                                                        uint32_t* __restrict__ cnt, bb_hit_raw* __restrict__ hits,
+                                                        uint32_t hit_cap, uint32_t* __restrict__ hit_count,
+                                                        const uint2* __restrict__ vtab, uint32_t n_virtual, uint32_t seg_lines, uint32_t split_above,
+                                                        const uint32_t* __restrict__ vcut, uint32_t* __restrict__ vcnt) {
+    constexpr int S = (W <= 2 ? 2 : (W <= 4 ? 4 : 8));
+    __shared__ __attribute__((aligned(16))) uint32_t s_peq[256 * S];
+    __shared__ __attribute__((aligned(16))) uint4 s_lines[4][BB_SCAN_LQ * 64];
+    uint32_t gi, strand, chunk;
+    if (!bb_coscheduled(blockIdx.x, gl.n, 2u, (n_virtual + 255u) / 256u, gi, strand, chunk)) return;
+    const uint32_t g = gl.g[gi];
+    const bb_group_dev* G = groups + g;
+    {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(tables + G->off_peq_flank[strand]);
+        for (int i = threadIdx.x; i < 256 * S; i += 256) s_peq[i] = src[i];
+    }
+    __syncthreads();
+    uint4* line = s_lines[threadIdx.x >> 6];
+    const int32_t kk = G->flank_k, score0 = G->score0;
+    const int m = G->m;
+    const uint32_t o_pv0 = G->off_pv0, o_ovh = G->off_ovh;
+    if (strand == 0)
+        flank_scan_lane<W, 0, true>(bases, offsets, n_reads, tables, kk, m, score0, o_pv0, o_ovh, G->ovh_steps, G->pol_lm, g, n_groups, cnt, hits, hit_cap, hit_count, s_peq, line, chunk,
+                                    nullptr, vtab, n_virtual, seg_lines, split_above, vcut, vcnt);
+    else
+        flank_scan_lane<W, 1, true>(bases, offsets, n_reads, tables, kk, m, score0, o_pv0, o_ovh, G->ovh_steps, G->pol_lm, g, n_groups, cnt, hits, hit_cap, hit_count, s_peq, line, chunk,
+                                    nullptr, vtab, n_virtual, seg_lines, split_above, vcut, vcnt);
+}
+// After it: the counts of a cut read's segments folded into the read's (each cell left holding the hits of the segments before it) ...
+__global__ __launch_bounds__(256) void k_seg_fold(const uint4* __restrict__ cutlist /* read, first cell, segments, - */, uint32_t n_cut, uint32_t n_groups, uint32_t gmask,
+                                                  uint32_t* __restrict__ vcnt, uint32_t* __restrict__ cnt) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t per = n_groups * 2u;
+    if (i >= n_cut * per) return;
+    const uint4 c = cutlist[i / per];
+    const uint32_t gs = i % per;
+    if (!((gmask >> (gs >> 1)) & 1u)) return;   // a group whose scan went by reads (filter + verification) wrote the read's count itself
+    uint32_t run = 0u;
+    for (uint32_t t = 0; t < c.z; ++t) {
+        uint32_t* cell = vcnt + (uint64_t)(c.y + t) * per + gs;
+        const uint32_t v = *cell;
+        *cell = run;
+        run += v;
+    }
+    cnt[(uint64_t)c.x * per + gs] = run;
+}
+// ... and the hits of segments made hits of their reads: ordinals run on from segment to segment
+__global__ __launch_bounds__(256) void k_seg_hits(bb_hit_raw* __restrict__ hits, const uint32_t* __restrict__ hit_count, uint32_t hit_cap, uint32_t n_groups,
+                                                  const uint32_t* __restrict__ vcnt, const uint32_t* __restrict__ cutread) {
+    const uint32_t n = min(*hit_count, hit_cap);
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+        bb_hit_raw h = hits[i];
+        if (!(h.read_idx & 0x80000000u)) continue;
+        const uint32_t cs = h.read_idx & 0x7FFFFFFFu;
+        h.ordinal += vcnt[((uint64_t)cs * n_groups + h.group) * 2u + h.strand];
+        h.read_idx = cutread[cs];
+        hits[i] = h;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -17,10 +17,11 @@
 struct bb_lenstat {
     unsigned long long off0, off1;   // offsets[0], offsets[n]
     uint32_t min_nl, max_nl;
+    uint32_t n_cut_reads, n_cut_segs;   // reads cut into segments, and their segments
     uint32_t seg[BB_LEN_SEG_BINS];
     uint32_t rd[BB_LEN_RD_BINS];
 };
-struct bb_lencur { uint32_t seg[BB_LEN_SEG_BINS]; uint32_t rd[BB_LEN_RD_BINS]; };   // next free position of every bin
+struct bb_lencur { uint32_t seg[BB_LEN_SEG_BINS]; uint32_t rd[BB_LEN_RD_BINS]; uint32_t cut_reads, cut_segs; };   // next free position of every bin / list
 
 __device__ __forceinline__ uint32_t bb_len_lines(const uint8_t* bases, uint64_t off, uint32_t n) {
     return n ? (uint32_t)((((uint64_t)(uintptr_t)(bases + off) & 127u) + n + 127u) >> 7) : 0u;
@@ -44,7 +45,8 @@ __global__ __launch_bounds__(256) void k_len_hist(const uint8_t* __restrict__ ba
             const uint32_t nseg = (nl + seg_lines - 1u) / seg_lines;
             atomicAdd(&s_seg[seg_lines], nseg - 1u);
             atomicAdd(&s_seg[nl - (nseg - 1u) * seg_lines], 1u);
-        } else if (nl) atomicAdd(&s_seg[nl], 1u);
+            atomicAdd(&st->n_cut_reads, 1u); atomicAdd(&st->n_cut_segs, nseg);   // (few)
+        } else atomicAdd(&s_seg[nl], 1u);   // empty reads too: the full scan closes them (overhang positions, count)
     }
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < BB_LEN_SEG_BINS; i += 256u) if (s_seg[i]) atomicAdd(&st->seg[i], s_seg[i]);
@@ -57,7 +59,9 @@ __global__ __launch_bounds__(256) void k_len_hist(const uint8_t* __restrict__ ba
 
 __global__ __launch_bounds__(256) void k_len_scatter(const uint8_t* __restrict__ bases, const uint64_t* __restrict__ offsets, uint32_t n_reads,
                                                      uint32_t seg_lines, uint32_t split_above, bb_lencur* __restrict__ cur,
-                                                     uint2* __restrict__ vtab, uint32_t* __restrict__ perm) {
+                                                     uint2* __restrict__ vtab, uint32_t* __restrict__ perm,
+                                                     uint32_t* __restrict__ vcut /* per vtab entry: its cell among the cut reads' segments */,
+                                                     uint32_t* __restrict__ cutread /* per cell: the read */, uint4* __restrict__ cutlist /* per cut read: read, first cell, segments */) {
     __shared__ uint32_t s_seg[BB_LEN_SEG_BINS], s_rd[BB_LEN_RD_BINS];
     for (uint32_t i = threadIdx.x; i < BB_LEN_SEG_BINS; i += 256u) s_seg[i] = 0u;
     s_rd[threadIdx.x] = 0u;
@@ -72,8 +76,8 @@ __global__ __launch_bounds__(256) void k_len_scatter(const uint8_t* __restrict__
             nseg = (nl + seg_lines - 1u) / seg_lines;
             last_lines = nl - (nseg - 1u) * seg_lines;
             slot_full = atomicAdd(&s_seg[seg_lines], nseg - 1u);
-        } else if (nl) { nseg = 1u; last_lines = nl; }
-        if (nseg) slot_last = atomicAdd(&s_seg[last_lines], 1u);
+        } else { nseg = 1u; last_lines = nl; }
+        slot_last = atomicAdd(&s_seg[last_lines], 1u);
     }
     __syncthreads();
     // the block's share of every bin, reserved with one atomic per bin in use; the LDS cell then holds where the share begins
@@ -82,10 +86,18 @@ __global__ __launch_bounds__(256) void k_len_scatter(const uint8_t* __restrict__
     __syncthreads();
     if (read < n_reads) {
         perm[s_rd[bb_len_rd_bin(nl)] + slot_rd] = read;
-        if (nseg) {
-            // (a cut read's last segment may have seg_lines lines as well: its slot and the full segments' slots are distinct draws of one cell)
-            for (uint32_t t = 0; t + 1u < nseg; ++t) vtab[s_seg[seg_lines] + slot_full + t] = make_uint2(read, t);
-            vtab[s_seg[last_lines] + slot_last] = make_uint2(read, nseg - 1u);
+        // (a cut read's last segment may have seg_lines lines as well: its slot and the full segments' slots are distinct draws of one cell)
+        uint32_t cell0 = 0xFFFFFFFFu;
+        if (nseg > 1u) {
+            cell0 = atomicAdd(&cur->cut_segs, nseg);
+            cutlist[atomicAdd(&cur->cut_reads, 1u)] = make_uint4(read, cell0, nseg, 0u);
+            for (uint32_t t = 0; t < nseg; ++t) cutread[cell0 + t] = read;
         }
+        for (uint32_t t = 0; t + 1u < nseg; ++t) {
+            const uint32_t v = s_seg[seg_lines] + slot_full + t;
+            vtab[v] = make_uint2(read, t); vcut[v] = cell0 + t;
+        }
+        const uint32_t v = s_seg[last_lines] + slot_last;
+        vtab[v] = make_uint2(read, nseg - 1u); vcut[v] = nseg > 1u ? cell0 + nseg - 1u : 0xFFFFFFFFu;
     }
 }

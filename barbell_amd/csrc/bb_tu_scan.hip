@@ -25,6 +25,12 @@ void launch_scan2(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets, 
         bb_glist gl{};
         gl.n = (uint32_t)std::min(gs.size() - at, sizeof(bb_glist::g));
         for (uint32_t i = 0; i < gl.n; ++i) gl.g[i] = (uint8_t)gs[at + i];
+        if (c->vtab) {   // reads of differing lengths: a lane per segment (bb_len.h), counts and hits folded back by seg_fixup
+            hipLaunchKernelGGL(k_flank_scan_seg<W>, dim3(bb_coscheduled_blocks(gl.n, 2u, (c->n_virtual + 255u) / 256u)), dim3(256), 0, c->stream, d_bases, d_offsets, n,
+                               (const uint8_t*)c->d_tables, (const bb_group_dev*)c->d_groups, gl, (uint32_t)c->groups.size(), c->d_cnt,
+                               c->d_raw, c->cap_hits, c->d_hitcount, c->vtab, c->n_virtual, c->seg_lines, c->split_above, (const uint32_t*)c->d_vcut, c->d_vcnt);
+            continue;
+        }
         hipLaunchKernelGGL(k_flank_scan2<W>, dim3(bb_coscheduled_blocks(gl.n, 2u, (n + 255u) / 256u)), dim3(256), 0, c->stream, d_bases, d_offsets, n,
                            (const uint8_t*)c->d_tables, (const bb_group_dev*)c->d_groups, gl, (uint32_t)c->groups.size(), c->d_cnt,
                            c->d_raw, c->cap_hits, c->d_hitcount, c->perm);
@@ -56,7 +62,7 @@ void launch_verify(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets,
 // The batch's read lengths, once per batch and before its scans (bb_len.h).  Batches of (nearly) equal reads — the benchmark's — pay one small
 // kernel in a round trip the filtered scan made already; others get their segments / reads sorted by falling length.
 int bb_prepare_lengths(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n, uint64_t* off0, uint64_t* off1) {
-    c->vtab = nullptr; c->perm = nullptr; c->n_virtual = 0;
+    c->vtab = nullptr; c->perm = nullptr; c->n_virtual = 0; c->n_cut_reads = 0; c->n_cut_segs = 0;
     if (!c->d_lenstat) {
         HIPCHK(c, hipMalloc((void**)&c->d_lenstat, sizeof(bb_lenstat)));
         HIPCHK(c, hipMalloc((void**)&c->d_lencur, sizeof(bb_lencur)));
@@ -83,9 +89,16 @@ int bb_prepare_lengths(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offs
     int r;
     if ((r = grow(c, c->d_vtab, c->cap_vtab, n_virtual + 1))) return r;
     if ((r = grow(c, c->d_perm, c->cap_perm, (uint64_t)n + 1))) return r;
+    if ((r = grow(c, c->d_vcut, c->cap_vcut, n_virtual + 1))) return r;
+    if ((r = grow(c, c->d_cutread, c->cap_cutread, (uint64_t)st.n_cut_segs + 1))) return r;
+    if ((r = grow(c, c->d_cutlist, c->cap_cutlist, (uint64_t)st.n_cut_reads + 1))) return r;
+    if ((r = grow(c, c->d_vcnt, c->cap_vcnt, (uint64_t)st.n_cut_segs * c->groups.size() * 2 + 1))) return r;
+    cur.cut_reads = 0; cur.cut_segs = 0;
     HIPCHK(c, hipMemcpyAsync(c->d_lencur, &cur, sizeof(cur), hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(k_len_scatter, dim3((n + 255u) / 256u), dim3(256), 0, c->stream, d_bases, d_offsets, n, seg_lines, split_above, c->d_lencur, c->d_vtab, c->d_perm);
+    hipLaunchKernelGGL(k_len_scatter, dim3((n + 255u) / 256u), dim3(256), 0, c->stream, d_bases, d_offsets, n, seg_lines, split_above, c->d_lencur, c->d_vtab, c->d_perm,
+                       c->d_vcut, c->d_cutread, c->d_cutlist);
     HIPCHK(c, hipGetLastError());
+    c->n_cut_reads = st.n_cut_reads; c->n_cut_segs = st.n_cut_segs;
     c->vtab = c->d_vtab; c->perm = c->d_perm; c->n_virtual = (uint32_t)n_virtual; c->last_segments = (uint32_t)n_virtual;
     return BB_OK;
 }
@@ -167,6 +180,16 @@ int bb_launch_scans(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets
                 }
             }
         for (int W = 1; W <= 8; ++W) launch_scan2_w(c, W, d_bases, d_offsets, n, plain2[W]);
+    }
+    if (c->vtab && c->n_cut_reads) {   // the segmented full scans' counts and hits made the reads' (k_seg_fold, k_seg_hits)
+        uint32_t gmask = 0;
+        for (int W = 1; W <= 8; ++W) { for (uint32_t g : plain[W]) gmask |= 1u << g; for (uint32_t g : plain2[W]) gmask |= 1u << g; }
+        if (gmask) {
+            const uint32_t items = c->n_cut_reads * G * 2u;
+            hipLaunchKernelGGL(k_seg_fold, dim3((items + 255u) / 256u), dim3(256), 0, c->stream, (const uint4*)c->d_cutlist, c->n_cut_reads, G, gmask, c->d_vcnt, c->d_cnt);
+            hipLaunchKernelGGL(k_seg_hits, dim3(1024), dim3(256), 0, c->stream, c->d_raw, (const uint32_t*)c->d_hitcount, c->cap_hits, G, (const uint32_t*)c->d_vcnt,
+                               (const uint32_t*)c->d_cutread);
+        }
     }
     return BB_OK;
 }
