@@ -226,6 +226,9 @@ def main():
             # the same pipeline where the filtered scan's assumption (unrelated text rarely comes within k edits of a flank window)
             # is strained; outside `value`
             out["stress"] = {name: _guarded(stress_leg, mode, dev_idx, dev, L, args) for name, mode in (("low_complexity_30pct", 1), ("prefix_decoys_every_200nt", 2), ("artefacts_50pct", 3), ("prefix_decoys_every_60nt", 4))}
+        if world == 1 and args.config == "nbd96" and not args.no_stress:
+            # read lengths as a real run's (heavy-tailed) against equal reads of the same mean: what the benchmark's fixed 4 kb does not show
+            out["length_mix"] = {c: _guarded(length_mix_leg, c, dev_idx, dev, args) for c in ("nbd96", "rbk96x")}
         if world == 1 and args.config == "nbd96" and not args.no_policy_variants:
             # the same workload under every setting of the assumptions about sassy / cigar-lodhi-rs that Barbell's own code does not pin
             # (include/barbell_amd_policy.h): what the headline becomes if the real crates turn out to differ from the default; outside `value`
@@ -404,6 +407,55 @@ def stress_leg(mode, dev_idx, dev, L, args, n=1_000_000, steps=3):
                                                                   n_threads=effective_cpus(), fast=True)
         out["parity_on_sample"] = bool(full[full["read_idx"] < w].tobytes() == want.tobytes())
     dm.close()
+    return out
+
+
+def length_mix_leg(cfg, dev_idx, dev, args, n=100_000, steps=3):
+    """Reads whose lengths differ as a run's do (tests/common.py::heavy_tailed_batch: 200 nt .. 120 kb, 70 % under 3 kb) against the same number of
+    bases in equal reads: bases/s of the whole step and the scan stage's time for both.  The scans give a lane one read; where the lengths
+    differ the lanes take segments of reads by falling length instead (bb_len.h) — without that the heavy-tailed batch ran the scan stage at
+    13 x (SQK-NBD114-96) the time of the equal reads (round 5, tools/ragged_probe.py).  Host-generated reads, uploaded once; outside `value`."""
+    from barbell_amd import _abi
+    from barbell_amd import annotate as A
+    from oracle import pyoracle as po
+    from tests.common import config_groups, heavy_tailed_batch
+
+    groups = config_groups(cfg)
+    hb, ho = heavy_tailed_batch(groups, n)
+    mean = int(len(hb) / (len(ho) - 1))
+    fb, fo = A.synth_reads_host(groups, 9, mean, mean, 0, len(ho) - 1)
+    out = {"reads": len(ho) - 1, "mean_len": mean, "max_len": int((ho[1:] - ho[:-1]).max())}
+    for name, (b, o) in (("equal_reads", (fb, fo)), ("heavy_tailed", (hb, ho))):
+        dm = A.Demuxer(device=dev_idx)
+        for g in groups:
+            dm.add_query_group(g)
+        nr_ = len(o) - 1
+        d_b = torch.from_numpy(b).to(dev)
+        d_o = torch.from_numpy(o.astype(np.int64)).to(dev)
+        cap = 8 * nr_
+        d_rows = torch.empty(cap * 48, dtype=torch.uint8, device=dev)
+        nr = dm.demux_dev(d_b.data_ptr(), d_o.data_ptr(), nr_, d_rows.data_ptr(), cap)
+        dm.set_timing(True)
+        kms = {}
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            nr = dm.demux_dev(d_b.data_ptr(), d_o.data_ptr(), nr_, d_rows.data_ptr(), cap)
+            for k, v in dm.kernel_ms().items():
+                kms[k] = kms.get(k, 0.0) + v / steps
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        ls = dm.length_stats()
+        out[name] = {"gbases_per_s": len(b) / dt / 1e9, "reads_per_s": nr_ / dt, "ms_per_step": dt * 1e3, "scan_stage_ms": kms["k_flank_scan"],
+                     "barcode_stage_ms": kms["k_barcode"], "rows_per_step": nr, "work_items": ls["work_items"], "lines_min_max": [ls["min_lines"], ls["max_lines"]]}
+        if name == "heavy_tailed" and not args.no_cpu_baseline:
+            w = 1024
+            full = np.frombuffer(d_rows[: nr * 48].cpu().numpy().tobytes(), dtype=_abi.ROW_DTYPE)
+            want = po.Oracle([g.as_tuple() for g in groups]).annotate(b[: int(o[w])], o[: w + 1], n_threads=effective_cpus(), fast=True)
+            out[name]["parity_on_sample"] = bool(full[full["read_idx"] < w].tobytes() == want.tobytes())
+        dm.close()
+        del d_b, d_o, d_rows
+    out["heavy_tailed_vs_equal"] = out["heavy_tailed"]["gbases_per_s"] / out["equal_reads"]["gbases_per_s"]
     return out
 
 

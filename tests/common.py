@@ -105,3 +105,26 @@ def long_batch(groups, seed, long_lens=(300_000, 1_000_000, 2_500_000), n_short=
     offs = np.zeros(len(seq) + 1, dtype=np.uint64)
     offs[1:] = np.cumsum([len(r) for r in seq])
     return np.concatenate(seq), offs
+
+
+def heavy_tailed_batch(groups, n, seed=3, scale=1.0):
+    """reads whose lengths differ as a nanopore run's do — 70 % 200..3000 nt, 25 % 3..12 kb, 4.5 % 12..40 kb, 0.5 % 40..120 kb (x scale) —
+    in random order; synthetic constructs at the ends of every read as in the benchmark's reads"""
+    import numpy as np
+
+    from barbell_amd import annotate as A
+
+    parts = []
+    for frac, lo, hi in ((0.70, 200, 3000), (0.25, 3000, 12000), (0.045, 12000, 40000), (0.005, 40000, 120000)):
+        k = max(1, int(n * frac))
+        parts.append(A.synth_reads_host(groups, seed + len(parts), max(1, int(lo * scale)), max(2, int(hi * scale)), 0, k))
+    reads = [(p, i) for p, (b, o) in enumerate(parts) for i in range(len(o) - 1)]
+    np.random.default_rng(seed).shuffle(reads)
+    lens = np.array([int(parts[p][1][i + 1] - parts[p][1][i]) for p, i in reads], dtype=np.uint64)
+    offs = np.zeros(len(reads) + 1, dtype=np.uint64)
+    offs[1:] = np.cumsum(lens)
+    out = np.empty(int(offs[-1]), dtype=np.uint8)
+    for j, (p, i) in enumerate(reads):
+        b, o = parts[p]
+        out[int(offs[j]):int(offs[j + 1])] = b[int(o[i]):int(o[i + 1])]
+    return out, offs

@@ -275,6 +275,37 @@ def test_megabase_reads_among_ordinary_ones(cfg):
     assert_same(got, want)
 
 
+@pytest.mark.parametrize("cfg,seg,policy", [
+    ("nbd96", None, None), ("nbd96", "4", None), ("dual", "4", None), ("rbk96x", None, None), ("rbk96x", "4", None), ("rbk96x", "8", "lm=left"),
+    ("rbk24", "4", "lm=strict"), ("nbd96", "0", None)])
+def test_reads_of_differing_lengths(monkeypatch, cfg, seg, policy):
+    """A run's reads differ in length by three orders of magnitude; the scans then give their lanes SEGMENTS of reads, sorted by falling
+    length (bb_len.h), instead of reads in file order.  The filter pass cuts a read where it likes (flags are addressed by position); the
+    full scan's segments divide the hits by valley (flank_scan_lane<.., SEG>): same rows as the oracle's, with the default segments
+    (4 KB, reads above 8 KB cut), with 512-byte / 1 KB segments that cut nearly every read many times (BARBELL_AMD_SEG_LINES), under the
+    other local-minimum rules, and with the whole thing off (=0)."""
+    from tests.common import heavy_tailed_batch
+
+    if seg is not None:
+        monkeypatch.setenv("BARBELL_AMD_SEG_LINES", seg)
+    groups = config_groups(cfg)
+    bases, offsets = heavy_tailed_batch(groups, 1500, seed=5, scale=0.5)
+    kw = {"policy": policy} if policy else {}
+    dm, got, want = run_both(groups, bases, offsets, **kw)
+    assert len(want) > 1000
+    assert_same(got, want)
+    ls = dm.length_stats()
+    n = len(offsets) - 1
+    assert ls["max_lines"] > 300 and ls["min_lines"] < 4
+    assert ls["work_items"] == n if seg == "0" else ls["work_items"] > n + 100
+    # a batch of equal reads is scanned as it always was: a lane per read, file order
+    from barbell_amd import annotate as A
+
+    b2, o2 = A.synth_reads_host(groups, 21, 2000, 2000, 0, 300)
+    dm.demux_packed(b2, o2)
+    assert dm.length_stats()["work_items"] == 300 or seg not in (None, "0")   # (with 512-byte segments forced these are cut as well)
+
+
 def test_empty_and_tiny_reads():
     groups = config_groups("nbd96")
     reads = [b"", b"A", b"ACGT", b"", bytes(groups[0].seqs[5]), bytes(groups[0].seqs[5])[:20], b"N" * 50, b""]

@@ -12,26 +12,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from barbell_amd import annotate as A  # noqa: E402
-from tests.common import config_groups  # noqa: E402
-
-
-def mixed(groups, n, seed=3):
-    parts = []
-    for frac, lo, hi in ((0.70, 200, 3000), (0.25, 3000, 12000), (0.045, 12000, 40000), (0.005, 40000, 120000)):
-        k = max(1, int(n * frac))
-        b, o = A.synth_reads_host(groups, seed + len(parts), lo, hi, 0, k)
-        parts.append((b, o))
-    reads = [(p, i) for p, (b, o) in enumerate(parts) for i in range(len(o) - 1)]
-    rng = np.random.default_rng(seed)
-    rng.shuffle(reads)
-    lens = np.array([int(parts[p][1][i + 1] - parts[p][1][i]) for p, i in reads], dtype=np.uint64)
-    offs = np.zeros(len(reads) + 1, dtype=np.uint64)
-    offs[1:] = np.cumsum(lens)
-    out = np.empty(int(offs[-1]), dtype=np.uint8)
-    for j, (p, i) in enumerate(reads):
-        b, o = parts[p]
-        out[int(offs[j]):int(offs[j + 1])] = b[int(o[i]):int(o[i + 1])]
-    return out, offs
+from tests.common import config_groups, heavy_tailed_batch as mixed  # noqa: E402
 
 
 def run(groups, bases, offs, label, order=None):
