@@ -512,7 +512,7 @@ void bb_destroy(bb_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     void* ptrs[] = {c->d_groups, c->d_tables, c->d_counts, c->d_cnt, c->d_base, c->d_sums, c->d_nrows, c->d_rowoff, c->d_hitcount,
-                    c->d_lists, c->d_listcnt, c->d_fb_lists, c->d_fbcnt, c->d_flags, c->d_vqueue, c->d_nflag, c->d_lenstat, c->d_lencur, c->d_vtab, c->d_perm, c->d_vcut, c->d_cutread, c->d_cutlist, c->d_vcnt, c->d_raw, c->d_hits, c->d_hitmeta, c->d_pfx, c->d_rows, c->d_in_bases, c->d_in_offsets, c->d_out_rows,
+                    c->d_lists, c->d_listcnt, c->d_fb_lists, c->d_fbcnt, c->d_flags, c->d_vqueue, c->d_nflag, c->d_lenstat, c->d_lencur, c->d_vtab, c->d_vcut, c->d_cutread, c->d_cutlist, c->d_vcnt, c->d_raw, c->d_hits, c->d_hitmeta, c->d_pfx, c->d_rows, c->d_in_bases, c->d_in_offsets, c->d_out_rows,
                     c->d_synth_table, c->d_fpats, c->d_felems, c->d_flabel_ok, c->d_flabel_ids, c->d_frows, c->d_fout, c->d_iout};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);

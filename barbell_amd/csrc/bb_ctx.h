@@ -66,16 +66,15 @@ struct bb_ctx {
     uint8_t last_scan_kind[BB_MAX_GROUPS]{};  // 0 full scan, 1 filter + verification, 2 filter, then the full scan (too many flags), 3 full scan while backed off
     uint8_t scan_off[BB_MAX_GROUPS]{};        // batches for which the group goes straight to the full scan (set to 16 by a batch of kind 2: its filter pass was wasted)
     uint32_t* d_flags = nullptr; uint64_t cap_flags = 0;  // filtered scan: one bit per 32 text bytes and strand (k_flank_filter)
-    // reads of differing lengths (bb_len.h): the batch's segments / reads by falling length, or null for a batch of (nearly) equal reads
+    // reads of differing lengths (bb_len.h): the batch's segments by falling length, or null for a batch of (nearly) equal reads
     struct bb_lenstat* d_lenstat = nullptr; struct bb_lencur* d_lencur = nullptr;
     uint2* d_vtab = nullptr; uint64_t cap_vtab = 0;
-    uint32_t* d_perm = nullptr; uint64_t cap_perm = 0;
     uint32_t* d_vcut = nullptr; uint64_t cap_vcut = 0;         // per vtab entry: its cell among the cut reads' segments
     uint32_t* d_cutread = nullptr; uint64_t cap_cutread = 0;   // per cell: the read
     uint4* d_cutlist = nullptr; uint64_t cap_cutlist = 0;      // per cut read: read, first cell, segments
     uint32_t* d_vcnt = nullptr; uint64_t cap_vcnt = 0;         // hit counts per (cell, group, strand) of the segmented full scan
     uint32_t n_cut_reads = 0, n_cut_segs = 0;
-    const uint2* vtab = nullptr; const uint32_t* perm = nullptr;   // of the batch in hand (d_vtab / d_perm or null)
+    const uint2* vtab = nullptr;   // of the batch in hand (d_vtab or null)
     uint32_t n_virtual = 0;        // entries of vtab
     uint32_t seg_lines = 32, split_above = 64;   // BARBELL_AMD_SEG_LINES (a multiple of 4; split_above = twice that; 0 = never cut, never sort)
     uint32_t last_min_lines = 0, last_max_lines = 0, last_segments = 0;   // of the last batch (bb_last_length_stats)

@@ -191,8 +191,7 @@ __device__ __forceinline__ void flank_scan_lane(const uint8_t* __restrict__ base
                                                 uint32_t off_pv0, uint32_t off_ovh, int ovh_steps, int pol_lm,
                                                 uint32_t g, uint32_t n_groups, uint32_t* __restrict__ cnt,
                                                 bb_hit_raw* __restrict__ hits, uint32_t hit_cap, uint32_t* __restrict__ hit_count,
-                                                const uint32_t* s_peq, uint4* s_line /* this wave's [BB_SCAN_LQ][64] */, uint32_t chunk /* which 256 reads */,
-                                                const uint32_t* __restrict__ perm /* reads by falling length (bb_len.h), or null: lane i takes read i */,
+                                                const uint32_t* s_peq, uint4* s_line /* this wave's [BB_SCAN_LQ][64] */, uint32_t chunk /* which 256 reads (SEG: segments) */,
                                                 const uint2* __restrict__ vtab = nullptr, uint32_t n_virtual = 0, uint32_t seg_lines = 0, uint32_t split_above = 0,
                                                 const uint32_t* __restrict__ vcut = nullptr, uint32_t* __restrict__ vcnt = nullptr) {
     constexpr int S = (W <= 2 ? 2 : (W <= 4 ? 4 : 8));
@@ -200,7 +199,7 @@ __device__ __forceinline__ void flank_scan_lane(const uint8_t* __restrict__ base
     const uint32_t slot = chunk * 256u + threadIdx.x;
     const bool live = slot < (SEG ? n_virtual : n_reads);
     const uint2 vt = SEG && live ? vtab[slot] : make_uint2(0u, 0u);
-    const uint32_t rd = SEG ? vt.x : (live && perm ? perm[slot] : slot);   // the read
+    const uint32_t rd = SEG ? vt.x : slot;   // the read
     const uint64_t off = live ? offsets[rd] : 0ull;
     const uint32_t n = live ? (uint32_t)(offsets[rd + 1] - off) : 0u;
     const uint8_t* rb = bases + off;
@@ -426,7 +425,7 @@ __global__ __launch_bounds__(256) void k_flank_scan2(const uint8_t* __restrict__
                                                      uint32_t n_reads, const uint8_t* __restrict__ tables,
                                                      const bb_group_dev* __restrict__ groups, bb_glist gl, uint32_t n_groups,
                                                      uint32_t* __restrict__ cnt, bb_hit_raw* __restrict__ hits,
-                                                     uint32_t hit_cap, uint32_t* __restrict__ hit_count, const uint32_t* __restrict__ perm) {
+                                                     uint32_t hit_cap, uint32_t* __restrict__ hit_count) {
     constexpr int S = (W <= 2 ? 2 : (W <= 4 ? 4 : 8));
     __shared__ __attribute__((aligned(16))) uint32_t s_peq[256 * S];
     __shared__ __attribute__((aligned(16))) uint4 s_lines[4][BB_SCAN_LQ * 64];
@@ -444,9 +443,9 @@ __global__ __launch_bounds__(256) void k_flank_scan2(const uint8_t* __restrict__
     const int m = G->m;
     const uint32_t o_pv0 = G->off_pv0, o_ovh = G->off_ovh;
     if (strand == 0)
-        flank_scan_lane<W, 0>(bases, offsets, n_reads, tables, kk, m, score0, o_pv0, o_ovh, G->ovh_steps, G->pol_lm, g, n_groups, cnt, hits, hit_cap, hit_count, s_peq, line, chunk, perm);
+        flank_scan_lane<W, 0>(bases, offsets, n_reads, tables, kk, m, score0, o_pv0, o_ovh, G->ovh_steps, G->pol_lm, g, n_groups, cnt, hits, hit_cap, hit_count, s_peq, line, chunk);
     else
-        flank_scan_lane<W, 1>(bases, offsets, n_reads, tables, kk, m, score0, o_pv0, o_ovh, G->ovh_steps, G->pol_lm, g, n_groups, cnt, hits, hit_cap, hit_count, s_peq, line, chunk, perm);
+        flank_scan_lane<W, 1>(bases, offsets, n_reads, tables, kk, m, score0, o_pv0, o_ovh, G->ovh_steps, G->pol_lm, g, n_groups, cnt, hits, hit_cap, hit_count, s_peq, line, chunk);
 }
 
 // The full scan of a batch whose reads differ in length: a lane per SEGMENT (flank_scan_lane<.., SEG>)
@@ -476,10 +475,10 @@ __global__ __launch_bounds__(256) void k_flank_scan_seg(const uint8_t* __restric
     const uint32_t o_pv0 = G->off_pv0, o_ovh = G->off_ovh;
     if (strand == 0)
         flank_scan_lane<W, 0, true>(bases, offsets, n_reads, tables, kk, m, score0, o_pv0, o_ovh, G->ovh_steps, G->pol_lm, g, n_groups, cnt, hits, hit_cap, hit_count, s_peq, line, chunk,
-                                    nullptr, vtab, n_virtual, seg_lines, split_above, vcut, vcnt);
+                                    vtab, n_virtual, seg_lines, split_above, vcut, vcnt);
     else
         flank_scan_lane<W, 1, true>(bases, offsets, n_reads, tables, kk, m, score0, o_pv0, o_ovh, G->ovh_steps, G->pol_lm, g, n_groups, cnt, hits, hit_cap, hit_count, s_peq, line, chunk,
-                                    nullptr, vtab, n_virtual, seg_lines, split_above, vcut, vcnt);
+                                    vtab, n_virtual, seg_lines, split_above, vcut, vcnt);
 }
 // After it: the counts of a cut read's segments folded into the read's (each cell left holding the hits of the segments before it) ...
 __global__ __launch_bounds__(256) void k_seg_fold(const uint4* __restrict__ cutlist /* read, first cell, segments, - */, uint32_t n_cut, uint32_t n_groups, uint32_t gmask,

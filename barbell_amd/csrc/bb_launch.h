@@ -17,7 +17,7 @@
 void bb_launch_timed_begin(bb_ctx* c, hipStream_t st, const char* fmt, ...);
 void bb_launch_timed_end(bb_ctx* c, hipStream_t st);
 int bb_scan_u32(bb_ctx* c, const uint32_t* in, uint32_t* out, uint64_t n);
-// the batch's read lengths (bb_len.h): sets c->vtab / c->perm / c->n_virtual for the scans of this batch, *off0 / *off1 = offsets[0] / offsets[n]; one round trip
+// the batch's read lengths (bb_len.h): sets c->vtab / c->n_virtual for the scans of this batch, *off0 / *off1 = offsets[0] / offsets[n]; one round trip
 int bb_prepare_lengths(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n, uint64_t* off0, uint64_t* off1);
 int bb_launch_scans(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n, uint64_t flag_words, uint64_t batch_bytes);   // the flank scan of every group
 int bb_trace_mode(const bb_ctx* c, uint32_t g);

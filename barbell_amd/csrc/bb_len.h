@@ -2,37 +2,34 @@
 // benchmark's reads all have 4000).  The scans give a lane one read, so a wave runs at the pace of its longest lane and a batch at the pace
 // of its longest read: measured on a heavy-tailed mix, the scan stage took 13 x (SQK-NBD114-96) the time of the same bases in equal reads.
 //   k_len_hist     one pass over the offsets: line counts of the reads (128-byte lines as the scans stream them), their minimum / maximum,
-//                  a histogram of SEGMENT line counts — a read of more than split_above lines is cut into segments of seg_lines lines —
-//                  and one of read line counts.  The host reads it in the round trip it makes for the batch's byte span anyway; batches
+//                  and a histogram of SEGMENT line counts — a read of more than split_above lines is cut into segments of seg_lines lines.
+//                  The host reads it in the round trip it makes for the batch's byte span anyway; batches
 //                  of (nearly) equal reads stop here and the scans run as they always did.
-//   k_len_scatter  otherwise: the segments (read, index) into `vtab` and the reads into `perm`, both by FALLING length (counting sort;
-//                  the bins' start positions come from the host) — k_flank_filter takes its lanes' work from vtab, k_flank_scan2 from perm.
+//   k_len_scatter  otherwise: the segments (read, index) into `vtab` by FALLING length (counting sort; the bins' start positions come from
+//                  the host) — k_flank_filter and the full scan (k_flank_scan_seg) take their lanes' work from it; the segments of cut
+//                  reads also get a cell each (contiguous per read) for the full scan's hit counts.
 // Which lane scans what never shows in the results: flags are addressed by text position, hits by (read, ordinal).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #define BB_LEN_SEG_BINS 130u   // segment line counts 0 .. 129 (split_above <= 128)
-#define BB_LEN_RD_BINS 256u    // read line counts, two lines to a bin, the last bin open-ended
 struct bb_lenstat {
     unsigned long long off0, off1;   // offsets[0], offsets[n]
     uint32_t min_nl, max_nl;
     uint32_t n_cut_reads, n_cut_segs;   // reads cut into segments, and their segments
     uint32_t seg[BB_LEN_SEG_BINS];
-    uint32_t rd[BB_LEN_RD_BINS];
 };
-struct bb_lencur { uint32_t seg[BB_LEN_SEG_BINS]; uint32_t rd[BB_LEN_RD_BINS]; uint32_t cut_reads, cut_segs; };   // next free position of every bin / list
+struct bb_lencur { uint32_t seg[BB_LEN_SEG_BINS]; uint32_t cut_reads, cut_segs; };   // next free position of every bin / list
 
 __device__ __forceinline__ uint32_t bb_len_lines(const uint8_t* bases, uint64_t off, uint32_t n) {
     return n ? (uint32_t)((((uint64_t)(uintptr_t)(bases + off) & 127u) + n + 127u) >> 7) : 0u;
 }
-__device__ __forceinline__ uint32_t bb_len_rd_bin(uint32_t nl) { return min(nl >> 1, BB_LEN_RD_BINS - 1u); }
 
 __global__ __launch_bounds__(256) void k_len_hist(const uint8_t* __restrict__ bases, const uint64_t* __restrict__ offsets, uint32_t n_reads,
                                                   uint32_t seg_lines, uint32_t split_above, bb_lenstat* __restrict__ st) {
-    __shared__ uint32_t s_seg[BB_LEN_SEG_BINS], s_rd[BB_LEN_RD_BINS], s_mm[2];
+    __shared__ uint32_t s_seg[BB_LEN_SEG_BINS], s_mm[2];
     for (uint32_t i = threadIdx.x; i < BB_LEN_SEG_BINS; i += 256u) s_seg[i] = 0u;
-    s_rd[threadIdx.x] = 0u;
     if (threadIdx.x == 0) { s_mm[0] = 0xFFFFFFFFu; s_mm[1] = 0u; }
     __syncthreads();
     const uint32_t read = blockIdx.x * 256u + threadIdx.x;
@@ -40,7 +37,6 @@ __global__ __launch_bounds__(256) void k_len_hist(const uint8_t* __restrict__ ba
         const uint64_t off = offsets[read];
         const uint32_t nl = bb_len_lines(bases, off, (uint32_t)(offsets[read + 1] - off));
         atomicMin(&s_mm[0], nl); atomicMax(&s_mm[1], nl);
-        atomicAdd(&s_rd[bb_len_rd_bin(nl)], 1u);
         if (nl > split_above) {
             const uint32_t nseg = (nl + seg_lines - 1u) / seg_lines;
             atomicAdd(&s_seg[seg_lines], nseg - 1u);
@@ -50,7 +46,6 @@ __global__ __launch_bounds__(256) void k_len_hist(const uint8_t* __restrict__ ba
     }
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < BB_LEN_SEG_BINS; i += 256u) if (s_seg[i]) atomicAdd(&st->seg[i], s_seg[i]);
-    if (s_rd[threadIdx.x]) atomicAdd(&st->rd[threadIdx.x], s_rd[threadIdx.x]);
     if (threadIdx.x == 0) {
         atomicMin(&st->min_nl, s_mm[0]); atomicMax(&st->max_nl, s_mm[1]);
         if (blockIdx.x == 0) { st->off0 = offsets[0]; st->off1 = offsets[n_reads]; }
@@ -59,19 +54,17 @@ __global__ __launch_bounds__(256) void k_len_hist(const uint8_t* __restrict__ ba
 
 __global__ __launch_bounds__(256) void k_len_scatter(const uint8_t* __restrict__ bases, const uint64_t* __restrict__ offsets, uint32_t n_reads,
                                                      uint32_t seg_lines, uint32_t split_above, bb_lencur* __restrict__ cur,
-                                                     uint2* __restrict__ vtab, uint32_t* __restrict__ perm,
+                                                     uint2* __restrict__ vtab,
                                                      uint32_t* __restrict__ vcut /* per vtab entry: its cell among the cut reads' segments */,
                                                      uint32_t* __restrict__ cutread /* per cell: the read */, uint4* __restrict__ cutlist /* per cut read: read, first cell, segments */) {
-    __shared__ uint32_t s_seg[BB_LEN_SEG_BINS], s_rd[BB_LEN_RD_BINS];
+    __shared__ uint32_t s_seg[BB_LEN_SEG_BINS];
     for (uint32_t i = threadIdx.x; i < BB_LEN_SEG_BINS; i += 256u) s_seg[i] = 0u;
-    s_rd[threadIdx.x] = 0u;
     __syncthreads();
     const uint32_t read = blockIdx.x * 256u + threadIdx.x;
-    uint32_t nl = 0u, nseg = 0u, last_lines = 0u, slot_rd = 0u, slot_full = 0u, slot_last = 0u;
+    uint32_t nl = 0u, nseg = 0u, last_lines = 0u, slot_full = 0u, slot_last = 0u;
     if (read < n_reads) {
         const uint64_t off = offsets[read];
         nl = bb_len_lines(bases, off, (uint32_t)(offsets[read + 1] - off));
-        slot_rd = atomicAdd(&s_rd[bb_len_rd_bin(nl)], 1u);
         if (nl > split_above) {
             nseg = (nl + seg_lines - 1u) / seg_lines;
             last_lines = nl - (nseg - 1u) * seg_lines;
@@ -82,10 +75,8 @@ __global__ __launch_bounds__(256) void k_len_scatter(const uint8_t* __restrict__
     __syncthreads();
     // the block's share of every bin, reserved with one atomic per bin in use; the LDS cell then holds where the share begins
     for (uint32_t i = threadIdx.x; i < BB_LEN_SEG_BINS; i += 256u) if (s_seg[i]) s_seg[i] = atomicAdd(&cur->seg[i], s_seg[i]);
-    if (s_rd[threadIdx.x]) s_rd[threadIdx.x] = atomicAdd(&cur->rd[threadIdx.x], s_rd[threadIdx.x]);
     __syncthreads();
     if (read < n_reads) {
-        perm[s_rd[bb_len_rd_bin(nl)] + slot_rd] = read;
         // (a cut read's last segment may have seg_lines lines as well: its slot and the full segments' slots are distinct draws of one cell)
         uint32_t cell0 = 0xFFFFFFFFu;
         if (nseg > 1u) {

@@ -33,7 +33,7 @@ void launch_scan2(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets, 
         }
         hipLaunchKernelGGL(k_flank_scan2<W>, dim3(bb_coscheduled_blocks(gl.n, 2u, (n + 255u) / 256u)), dim3(256), 0, c->stream, d_bases, d_offsets, n,
                            (const uint8_t*)c->d_tables, (const bb_group_dev*)c->d_groups, gl, (uint32_t)c->groups.size(), c->d_cnt,
-                           c->d_raw, c->cap_hits, c->d_hitcount, c->perm);
+                           c->d_raw, c->cap_hits, c->d_hitcount);
     }
 }
 void launch_scan2_w(bb_ctx* c, int W, const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n, const std::vector<uint32_t>& gs) {
@@ -62,7 +62,7 @@ void launch_verify(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets,
 // The batch's read lengths, once per batch and before its scans (bb_len.h).  Batches of (nearly) equal reads — the benchmark's — pay one small
 // kernel in a round trip the filtered scan made already; others get their segments / reads sorted by falling length.
 int bb_prepare_lengths(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n, uint64_t* off0, uint64_t* off1) {
-    c->vtab = nullptr; c->perm = nullptr; c->n_virtual = 0; c->n_cut_reads = 0; c->n_cut_segs = 0;
+    c->vtab = nullptr; c->n_virtual = 0; c->n_cut_reads = 0; c->n_cut_segs = 0;
     if (!c->d_lenstat) {
         HIPCHK(c, hipMalloc((void**)&c->d_lenstat, sizeof(bb_lenstat)));
         HIPCHK(c, hipMalloc((void**)&c->d_lencur, sizeof(bb_lencur)));
@@ -83,23 +83,20 @@ int bb_prepare_lengths(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offs
     uint64_t at = 0;
     for (int b = (int)BB_LEN_SEG_BINS - 1; b >= 0; --b) { cur.seg[b] = (uint32_t)at; at += st.seg[b]; }
     const uint64_t n_virtual = at;
-    at = 0;
-    for (int b = (int)BB_LEN_RD_BINS - 1; b >= 0; --b) { cur.rd[b] = (uint32_t)at; at += st.rd[b]; }
     if (n_virtual >= 0xFFFFFFFFull) { c->last_error = "more than 2^32 read segments in a batch"; return BB_E_UNSUPPORTED; }
     int r;
     if ((r = grow(c, c->d_vtab, c->cap_vtab, n_virtual + 1))) return r;
-    if ((r = grow(c, c->d_perm, c->cap_perm, (uint64_t)n + 1))) return r;
     if ((r = grow(c, c->d_vcut, c->cap_vcut, n_virtual + 1))) return r;
     if ((r = grow(c, c->d_cutread, c->cap_cutread, (uint64_t)st.n_cut_segs + 1))) return r;
     if ((r = grow(c, c->d_cutlist, c->cap_cutlist, (uint64_t)st.n_cut_reads + 1))) return r;
     if ((r = grow(c, c->d_vcnt, c->cap_vcnt, (uint64_t)st.n_cut_segs * c->groups.size() * 2 + 1))) return r;
     cur.cut_reads = 0; cur.cut_segs = 0;
     HIPCHK(c, hipMemcpyAsync(c->d_lencur, &cur, sizeof(cur), hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(k_len_scatter, dim3((n + 255u) / 256u), dim3(256), 0, c->stream, d_bases, d_offsets, n, seg_lines, split_above, c->d_lencur, c->d_vtab, c->d_perm,
+    hipLaunchKernelGGL(k_len_scatter, dim3((n + 255u) / 256u), dim3(256), 0, c->stream, d_bases, d_offsets, n, seg_lines, split_above, c->d_lencur, c->d_vtab,
                        c->d_vcut, c->d_cutread, c->d_cutlist);
     HIPCHK(c, hipGetLastError());
     c->n_cut_reads = st.n_cut_reads; c->n_cut_segs = st.n_cut_segs;
-    c->vtab = c->d_vtab; c->perm = c->d_perm; c->n_virtual = (uint32_t)n_virtual; c->last_segments = (uint32_t)n_virtual;
+    c->vtab = c->d_vtab; c->n_virtual = (uint32_t)n_virtual; c->last_segments = (uint32_t)n_virtual;
     return BB_OK;
 }
 
