@@ -72,7 +72,7 @@ int bb_prepare_lengths(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offs
     memset(&st, 0, sizeof(st));
     st.min_nl = 0xFFFFFFFFu;
     HIPCHK(c, hipMemcpyAsync(c->d_lenstat, &st, sizeof(st), hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(k_len_hist, dim3((n + 255u) / 256u), dim3(256), 0, c->stream, d_bases, d_offsets, n, seg_lines, split_above, c->d_lenstat);
+    hipLaunchKernelGGL(k_len_hist, dim3(std::min((n + 255u) / 256u, 1024u)), dim3(256), 0, c->stream, d_bases, d_offsets, n, seg_lines, split_above, c->d_lenstat);
     HIPCHK(c, hipMemcpyAsync(&st, c->d_lenstat, sizeof(st), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     *off0 = st.off0; *off1 = st.off1;
