@@ -51,6 +51,14 @@ def run(groups, bases, offs, label, order=None):
 if __name__ == "__main__":
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     n = int(sys.argv[sys.argv.index("--reads") + 1]) if "--reads" in sys.argv else 300000
+    if "--short" in sys.argv:   # many short reads (amplicons): what a read costs apart from its bases
+        for cfg in (args or ["nbd96"]):
+            groups = config_groups(cfg)
+            print(cfg, flush=True)
+            for lo, hi, k in ((4000, 4000, 300000), (300, 600, 2000000), (150, 250, 4000000)):
+                b, o = A.synth_reads_host(groups, 13, lo, hi, 0, k)
+                run(groups, b, o, f"{k} reads of {lo}..{hi} nt")
+        sys.exit(0)
     for cfg in (args or ["nbd96", "dual", "rbk96x"]):
         groups = config_groups(cfg)
         print(cfg, flush=True)
