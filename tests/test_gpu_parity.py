@@ -527,6 +527,51 @@ def test_wide_barcode_windows_take_the_64_column_kernels():
     assert len(want) > 300 and int(wide.sum()) > 20   # tag rows that span an inserted barcode
 
 
+@pytest.mark.parametrize("seg,policy", [("4", None), ("4", "lm=left"), ("8", "lm=strict"), (None, None)])
+def test_valleys_that_span_segments(monkeypatch, seg, policy):
+    """The segmented full scan divides a read's hits by valley (flank_scan_lane<.., SEG>).  A low-complexity flank — (AC)15 N24 (AC)10 — on
+    reads with (AC)n runs of 100 .. 3000 nt, a few of them mutated: the bottom-row cost stays within k over thousands of columns (valleys far
+    longer than a 512-byte segment: the owner follows them through several segments, the lanes in between never report), with a local
+    minimum every other column (hundreds of hits per (read, strand): the ordinals run on from segment to segment and past the four a lane
+    buffers), plateaus under every rule.  Full scan and filtered scan, rows equal the oracle's."""
+    from barbell_amd.kits import QueryGroup
+
+    if seg is not None:
+        monkeypatch.setenv("BARBELL_AMD_SEG_LINES", seg)
+    rng = np.random.default_rng(77)
+    rnd = lambda n: bytes(rng.choice(list(b"ACGT"), n).tolist())
+    g = [QueryGroup([b"AC" * 15 + rnd(24) + b"AC" * 10 for _ in range(12)], [f"v{i}" for i in range(12)], _abi.BB_FTAG, 6)]
+    reads = []
+    for i in range(60):
+        parts = []
+        for _ in range(int(rng.integers(1, 4))):
+            parts.append(rnd(int(rng.integers(50, 1500))))
+            run = bytearray(b"AC" * int(rng.integers(50, 1500)))
+            for _ in range(int(rng.integers(0, 4))):                      # a few substitutions / deletions inside the run
+                q = int(rng.integers(0, len(run)))
+                if rng.random() < 0.5: run[q:q + 1] = b"G"
+                else: del run[q:q + 1]
+            if rng.random() < 0.3: run[len(run) // 2:len(run) // 2] = bytes(g[0].seqs[int(rng.integers(0, 12))])   # a whole construct inside
+            parts.append(bytes(run))
+        if i % 7 == 0: parts = parts[1:]                                  # the run at the read's very start: left overhang inside a valley
+        if i % 5 == 0: parts.append(rnd(40))
+        reads.append(b"".join(parts))
+    reads += [b"AC" * 4000, b"CA" * 2500 + b"T"]                          # one valley from end to end, over the overhang positions too
+    bases, offsets = _abi.pack_reads(reads)
+    kw = {"policy": policy} if policy else {}
+    for env in ({}, {"BARBELL_AMD_SCAN_FILTER": "0"}):
+        for k, v in env.items(): monkeypatch.setenv(k, v)
+        dm, got, want = run_both(g, bases, offsets, **kw)
+        assert len(want) > 60
+        assert_same(got, want)
+        # most of the hits collapse into few rows (interval.rs:4-79): the number of flank matches themselves, against the oracle's count
+        from oracle import pyoracle as po
+
+        d = po.Oracle([x.as_tuple() for x in g], **kw).annotate_diag(bases, offsets, n_threads=NT, fast=False)
+        hits = sum(dm.barcode_stats(0, sd)["hits"] for sd in (0, 1))
+        assert d["flank_matches"] > 20000 and hits == d["flank_matches"] - d["region_none"], (hits, d)
+
+
 def test_wide_flanks_up_to_256():
     """custom adapters longer than any kit's: flanks of 150 and 230 nt (W = 5 and 8 words in the scan / trace)"""
     from barbell_amd import annotate as A
