@@ -50,4 +50,16 @@ if __name__ == "__main__":
         for l in r.stderr.splitlines():
             if "profile:" in l:
                 print("   ", l[:200])
+        # the whole kit pipeline (annotate -> filter -> trim, per-barcode FASTQ files written): the trim kernels on long records
+        import shutil
+        outd = f"{d}/ragged_kit_{name}"
+        t0 = time.time()
+        r = subprocess.run([CLI, "kit", "-k", "SQK-NBD114-96", "-i", fq, "-o", outd, "--maximize", "--flank-max-errors", "3", "-t", "32"],
+                           capture_output=True, text=True, env=dict(os.environ, BARBELL_AMD_PROFILE="1", BARBELL_AMD_NO_TORCH="1"))
+        m = re.search(r"pipeline ([0-9.]+) s", r.stderr)
+        print(name, "kit rc", r.returncode, "wall %.2f s" % (time.time() - t0), "pipeline", m.group(1) if m else "?", flush=True)
+        for l in r.stderr.splitlines():
+            if "profile: pipeline" in l:
+                print("   ", l[:260])
+        shutil.rmtree(outd, ignore_errors=True)
         os.remove(fq)
