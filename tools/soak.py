@@ -2,7 +2,7 @@
 """dev aid (GPU box): randomised soak of the annotate path against the oracle — kit / custom query sets with random flank
 error budgets and overhang factors, read mixtures (synthetic constructs, constructs cut at either end, homopolymers,
 repeats of flank pieces, tiny reads), random scan variants (BARBELL_AMD_SCAN_FILTER / _WIDE / _ENDS).
-usage: soak.py FIRST_SEED N_SEEDS"""
+usage: soak.py FIRST_SEED N_SEEDS   (BARBELL_AMD_SEG_LINES_FIXED=1: keep the caller's BARBELL_AMD_SEG_LINES instead of drawing one per seed)"""
 import os
 import sys
 
@@ -50,6 +50,12 @@ for seed in range(first, first + count):
                            f"trace={rng.choice(TRACE_ORDERS)}", f"rcpath={rng.choice(['fwd', 'fwd', 'mirror'])}",
                            f"ovh={rng.choice(['floor', 'ceil', 'near', 'floor:f64', 'near:f64'])}", f"tie={rng.choice(['first', 'last'])}",
                            f"lodhi={rng.choice(['3:0.5:1111', '3:0.5:1111', '3:0.5:2211', '3:0.5:1121', '3:0.5:1110', '3:0.5:2131', '3:0.5:1011', '2:0.5:1111', '3:0.7:1111', '4:0.5:1212'])}"])
+    # round 5: the scans' work items — segments of 512 bytes .. 2 KB (nearly every read cut, the full scan's valley rule at every cut), the
+    # default (reads above 8 KB cut), or whole reads in file order; a setting given from outside (a forced soak) stays
+    if "BARBELL_AMD_SEG_LINES_FIXED" not in os.environ:
+        os.environ.pop("BARBELL_AMD_SEG_LINES", None)
+        sl = rng.choice(["", "", "4", "8", "16", "0"])
+        if sl: os.environ["BARBELL_AMD_SEG_LINES"] = str(sl)
     os.environ.pop("BARBELL_AMD_ADAPT_FRAC", None)
     if rng.random() < 0.3: os.environ["BARBELL_AMD_ADAPT_FRAC"] = str(rng.choice(["0", "1", "0.01"]))
     noise = float(rng.choice([0.0, 0.0, 0.03, 0.08]))
@@ -88,6 +94,6 @@ for seed in range(first, first + count):
     ok = got.tobytes() == want.tobytes()
     if not ok:
         bad += 1
-        print(f"MISMATCH seed {seed} {cfg} k={k} alpha={alpha} mode='{mode}' policy={policy} adapt={os.environ.get('BARBELL_AMD_ADAPT_FRAC')} noise={noise} rows {len(got)} vs {len(want)}")
+        print(f"MISMATCH seed {seed} {cfg} k={k} alpha={alpha} mode='{mode}' policy={policy} adapt={os.environ.get('BARBELL_AMD_ADAPT_FRAC')} seg={os.environ.get('BARBELL_AMD_SEG_LINES')} noise={noise} rows {len(got)} vs {len(want)}")
 print(f"{count} seeds, {bad} bad")
 sys.exit(1 if bad else 0)
