@@ -516,6 +516,7 @@ void bb_destroy(bb_ctx* c) {
                     c->d_synth_table, c->d_fpats, c->d_felems, c->d_flabel_ok, c->d_flabel_ids, c->d_frows, c->d_fout, c->d_iout};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
+    if (c->h_lencur) (void)hipHostFree(c->h_lencur);
     bb_trim_state_free(c->trim);
     bb_fastq_state_free(c->fastq);
     bb_format_state_free(c->format);

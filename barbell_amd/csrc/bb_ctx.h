@@ -67,7 +67,7 @@ struct bb_ctx {
     uint8_t scan_off[BB_MAX_GROUPS]{};        // batches for which the group goes straight to the full scan (set to 16 by a batch of kind 2: its filter pass was wasted)
     uint32_t* d_flags = nullptr; uint64_t cap_flags = 0;  // filtered scan: one bit per 32 text bytes and strand (k_flank_filter)
     // reads of differing lengths (bb_len.h): the batch's segments by falling length, or null for a batch of (nearly) equal reads
-    struct bb_lenstat* d_lenstat = nullptr; struct bb_lencur* d_lencur = nullptr;
+    struct bb_lenstat* d_lenstat = nullptr; struct bb_lencur* d_lencur = nullptr; struct bb_lencur* h_lencur = nullptr;   // h_: page-locked host copy
     uint2* d_vtab = nullptr; uint64_t cap_vtab = 0;
     uint32_t* d_vcut = nullptr; uint64_t cap_vcut = 0;         // per vtab entry: its cell among the cut reads' segments
     uint32_t* d_cutread = nullptr; uint64_t cap_cutread = 0;   // per cell: the read

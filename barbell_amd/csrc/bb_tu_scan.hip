@@ -66,12 +66,12 @@ int bb_prepare_lengths(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offs
     if (!c->d_lenstat) {
         HIPCHK(c, hipMalloc((void**)&c->d_lenstat, sizeof(bb_lenstat)));
         HIPCHK(c, hipMalloc((void**)&c->d_lencur, sizeof(bb_lencur)));
+        HIPCHK(c, hipHostMalloc((void**)&c->h_lencur, sizeof(bb_lencur), hipHostMallocDefault));   // (uploaded asynchronously: not from the stack)
     }
     const uint32_t seg_lines = c->seg_lines ? c->seg_lines : 32u, split_above = c->seg_lines ? c->split_above : 0xFFFFFFFFu;
     bb_lenstat st;
-    memset(&st, 0, sizeof(st));
-    st.min_nl = 0xFFFFFFFFu;
-    HIPCHK(c, hipMemcpyAsync(c->d_lenstat, &st, sizeof(st), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_lenstat, 0, sizeof(bb_lenstat), c->stream));
+    HIPCHK(c, hipMemsetAsync(&c->d_lenstat->min_nl, 0xFF, sizeof(uint32_t), c->stream));
     hipLaunchKernelGGL(k_len_hist, dim3(std::min((n + 255u) / 256u, 1024u)), dim3(256), 0, c->stream, d_bases, d_offsets, n, seg_lines, split_above, c->d_lenstat);
     HIPCHK(c, hipMemcpyAsync(&st, c->d_lenstat, sizeof(st), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -79,7 +79,7 @@ int bb_prepare_lengths(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offs
     c->last_min_lines = st.min_nl; c->last_max_lines = st.max_nl; c->last_segments = n;
     if (st.off1 < st.off0) { c->last_error = "offsets are not ascending"; return BB_E_INVALID; }
     if (!c->seg_lines || (st.max_nl <= c->split_above && st.max_nl - st.min_nl <= 2u)) return BB_OK;   // lanes of a wave finish together as they are
-    bb_lencur cur;
+    bb_lencur& cur = *c->h_lencur;   // (the last batch's upload of it has long been consumed: every batch ends with a round trip)
     uint64_t at = 0;
     for (int b = (int)BB_LEN_SEG_BINS - 1; b >= 0; --b) { cur.seg[b] = (uint32_t)at; at += st.seg[b]; }
     const uint64_t n_virtual = at;
@@ -91,7 +91,7 @@ int bb_prepare_lengths(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offs
     if ((r = grow(c, c->d_cutlist, c->cap_cutlist, (uint64_t)st.n_cut_reads + 1))) return r;
     if ((r = grow(c, c->d_vcnt, c->cap_vcnt, (uint64_t)st.n_cut_segs * c->groups.size() * 2 + 1))) return r;
     cur.cut_reads = 0; cur.cut_segs = 0;
-    HIPCHK(c, hipMemcpyAsync(c->d_lencur, &cur, sizeof(cur), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_lencur, c->h_lencur, sizeof(bb_lencur), hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(k_len_scatter, dim3((n + 255u) / 256u), dim3(256), 0, c->stream, d_bases, d_offsets, n, seg_lines, split_above, c->d_lencur, c->d_vtab,
                        c->d_vcut, c->d_cutread, c->d_cutlist);
     HIPCHK(c, hipGetLastError());
