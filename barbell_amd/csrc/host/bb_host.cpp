@@ -903,7 +903,7 @@ struct PackFallback {};
 
 struct BlockFeeder {
     struct Block { uint64_t index = 0; const uint8_t* data = nullptr; size_t len = 0; int slot = -1; std::shared_ptr<std::vector<uint8_t>> big; };
-    struct Task { size_t file = 0; uint64_t off = 0; size_t len = 0; uint64_t seq = 0; bool last = false; const uint8_t* mem = nullptr; };
+    struct Task { size_t file = 0; uint64_t off = 0; size_t len = 0; uint64_t seq = 0; bool last = false; std::shared_ptr<struct GzPiece> piece; };   // piece: gzip input, off within it
     struct Slot { uint8_t* p = nullptr; size_t cap = 0, got = 0, nl = 0; bool last = false; int state = 0; uint64_t seq = 0; int refs = 0; size_t file = 0;
                   // two-line mode: raw newlines of the chunk, the phase (line index mod 4) the reader took its first byte to be in
                   // (-1: none recognisable), where the raw bytes came from (to redo the chunk if the guess was wrong), malformed flag
@@ -934,7 +934,8 @@ struct BlockFeeder {
     std::condition_variable cv;
     // claim cursor
     size_t cur_file = 0; uint64_t cur_off = 0, next_seq = 0;
-    std::vector<uint64_t> chunks_left;  // per gzip file: chunks not yet copied out of the inflated image
+    std::shared_ptr<struct GzPiece> cur_piece;   // gzip input: the piece being chunked (claim)
+    bool piece_fetching = false;                 // a reader is waiting for the inflater's next piece; the others wait for that reader
     bool stop = false, claims_done = false;
     std::string err;
     // sequencer state
@@ -973,96 +974,147 @@ struct BlockFeeder {
     void fail(const std::string& e) { { std::lock_guard<std::mutex> lk(mu); if (err.empty() && !e.empty()) err = e; stop = true; } cv.notify_all(); }
 };
 
-// Several gzip files: zlib inflates one stream on one core (~0.3 GB/s), far below what the GPU takes, so the
-// files are inflated whole by a pool of threads, a few files ahead of the consumer, and handed over in input
-// order (the TSV keeps the reads' order).  n_threads comes from -t/--threads like the reference's worker count.
+// gzip files (and pipes): zlib inflates one stream on one core (~0.3 GB/s), far below what the GPU takes, so a pool of threads inflates
+// several files at once, a few files ahead of the consumer, and hands them over in input order (the TSV keeps the reads' order).  A file
+// comes as PIECES of at most `piece_bytes` of text, each cut after a whole record (the file starts with one, so the cut is after line
+// 4 * floor(lines / 4) of what has been read): the feeder treats a piece like a small file of its own.  Round 5: before, a file was inflated
+// whole — a 50 GB fastq.gz meant 200 GB of text in memory (and its buffer's last doubling as much again); now a file holds at most
+// `pieces_ahead` pieces whatever its size.  n_threads comes from -t/--threads like the reference's worker count.
+static size_t count_nl(const uint8_t* p, size_t n);
+struct GzPiece { std::vector<uint8_t> data; size_t size = 0; uint64_t chunks_left = 0; };
 struct ParallelInflater {
     std::vector<std::string> paths;
     std::vector<char> gz;    // files that are not gzip are skipped (the feeder reads them directly)
-    std::vector<std::vector<uint8_t>> data;
-    std::vector<int> state;  // 0 = not started, 1 = in progress, 2 = ready, 3 = consumed
-    std::vector<uint64_t> inflated_size;
+    struct FileState { std::deque<std::shared_ptr<GzPiece>> ready; int state = 0; /* 0 not started, 1 being inflated, 2 all pieces made */ size_t out = 0; /* pieces made, not yet consumed */ };
+    std::vector<FileState> fs;
     std::vector<std::thread> pool;
     std::mutex mu;
     std::condition_variable cv;
     size_t next_file = 0, consumed_upto = 0, ahead;
+    size_t piece_bytes = 256u << 20, pieces_ahead = 3;
     std::string err;
+    bool cancelled = false;
+    uint64_t n_pieces = 0, held = 0, max_held = 0;   // pieces made; bytes of inflated text made and not yet consumed, and the most there ever was (BARBELL_AMD_PROFILE)
     ParallelInflater(std::vector<std::string> p, std::vector<char> is_gz, unsigned n_threads)
-        : paths(std::move(p)), gz(std::move(is_gz)), data(paths.size()), state(paths.size(), 0), inflated_size(paths.size(), 0) {
+        : paths(std::move(p)), gz(std::move(is_gz)), fs(paths.size()) {
+        if (const char* e = getenv("BARBELL_AMD_GZ_PIECE")) piece_bytes = (size_t)std::max(64L, atol(e));   // tests: pieces of a few hundred bytes
         const unsigned nt = std::max(1u, std::min<unsigned>(n_threads, (unsigned)paths.size()));
-        ahead = nt + 2;  // files inflated but not yet consumed: bounds the memory
+        ahead = nt + 2;  // files being inflated or inflated and not yet consumed: bounds the memory
         for (unsigned i = 0; i < nt; ++i) pool.emplace_back([this]() { work(); });
+    }
+    // hands a piece over; waits while the file has pieces_ahead of them unconsumed.  false: cancelled
+    bool publish(size_t i, std::shared_ptr<GzPiece> pc) {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&]() { return cancelled || !err.empty() || fs[i].out < pieces_ahead; });
+        if (cancelled || !err.empty()) return false;
+        ++n_pieces; held += pc->size; max_held = std::max(max_held, held);
+        fs[i].ready.push_back(std::move(pc)); ++fs[i].out;
+        lk.unlock();
+        cv.notify_all();
+        return true;
     }
     void work() {
         for (;;) {
             size_t i;
             {
                 std::unique_lock<std::mutex> lk(mu);
-                cv.wait(lk, [this]() { return next_file >= paths.size() || next_file < consumed_upto + ahead || !err.empty(); });
-                if (next_file >= paths.size() || !err.empty()) return;
+                cv.wait(lk, [this]() { return cancelled || next_file >= paths.size() || next_file < consumed_upto + ahead || !err.empty(); });
+                if (cancelled || next_file >= paths.size() || !err.empty()) return;
                 i = next_file++;
-                if (!gz[i]) { state[i] = 3; continue; }
-                state[i] = 1;
+                if (!gz[i]) { fs[i].state = 2; continue; }
+                fs[i].state = 1;
             }
-            std::vector<uint8_t> buf;
             std::string e;
             gzFile f = gzopen(paths[i].c_str(), "rb");
             if (!f) e = "Failed to open FASTQ input: " + paths[i];
             else {
                 gzbuffer(f, 1 << 20);
-                size_t cap = 64u << 20, n = 0;
-                buf.resize(cap);
-                for (;;) {
-                    if (n == cap) { cap *= 2; buf.resize(cap); }
-                    const int r = gzread(f, buf.data() + n, (unsigned)std::min<size_t>(cap - n, 1u << 30));
-                    if (r < 0) { e = "Error reading FASTQ file '" + paths[i] + "'"; break; }
-                    if (r == 0) break;
-                    n += (size_t)r;
+                std::vector<uint8_t> buf, carry;
+                bool eof = false, any = false;
+                while (!eof && e.empty()) {
+                    size_t cap = std::max<size_t>(std::min<size_t>(piece_bytes, 64u << 20), carry.size() + 64), n = carry.size();
+                    buf.resize(cap);
+                    if (n) memcpy(buf.data(), carry.data(), n);
+                    carry.clear();
+                    size_t cut = 0;
+                    for (;;) {   // fill up to piece_bytes; a piece without a whole record in it (a record larger than the piece) grows until it holds one
+                        while (n < cap && !eof) {
+                            const int r = gzread(f, buf.data() + n, (unsigned)std::min<size_t>(cap - n, 1u << 30));
+                            if (r < 0) { e = "Error reading FASTQ file '" + paths[i] + "'"; eof = true; break; }
+                            if (r == 0) eof = true; else n += (size_t)r;
+                        }
+                        if (eof) { cut = n; break; }
+                        if (cap < piece_bytes) { cap = std::min(piece_bytes, cap * 2); buf.resize(cap); continue; }
+                        // the piece ends after the last whole record: after line 4 * floor(lines / 4)
+                        const size_t lines = count_nl(buf.data(), n);
+                        if (lines >= 4) {
+                            const uint8_t* end = buf.data() + n;
+                            for (size_t k = 0; k <= lines % 4; ++k) {   // back over the partial last line and the lines % 4 whole ones after the record
+                                const void* q = memrchr(buf.data(), '\n', (size_t)(end - buf.data()));
+                                end = (const uint8_t*)q;             // not null: lines >= 4
+                                if (k == lines % 4) ++end;           // ... up to and including the record's last line end
+                            }
+                            cut = (size_t)(end - buf.data());
+                            break;
+                        }
+                        cap *= 2; buf.resize(cap);
+                    }
+                    if (!e.empty()) break;
+                    if (cut < n) carry.assign(buf.data() + cut, buf.data() + n);
+                    if (cut == 0 && !eof) continue;   // (cannot happen: lines >= 4 puts the cut after a line end)
+                    if (cut == 0 && any) break;       // nothing after the last piece: the file ended on a record
+                    auto pc = std::make_shared<GzPiece>();
+                    buf.resize(cut);
+                    pc->size = cut;
+                    pc->data.swap(buf);
+                    any = true;
+                    if (!publish(i, std::move(pc))) { gzclose(f); return; }
                 }
                 gzclose(f);
-                buf.resize(n);
             }
             {
                 std::lock_guard<std::mutex> lk(mu);
                 if (!e.empty() && err.empty()) err = e;
-                inflated_size[i] = buf.size();
-                data[i] = std::move(buf);
-                state[i] = 2;
+                fs[i].state = 2;
             }
             cv.notify_all();
         }
     }
-    // blocks until file i is inflated; the caller owns the bytes until release(i)
-    const std::vector<uint8_t>& get(size_t i) {
+    // the file's next piece, in order; blocks until it is there.  nullptr: the file has no more (an empty file gives one empty piece first)
+    std::shared_ptr<GzPiece> next_piece(size_t i) {
         std::unique_lock<std::mutex> lk(mu);
-        cv.wait(lk, [&]() { return state[i] == 2 || !err.empty(); });
+        cv.wait(lk, [&]() { return cancelled || !err.empty() || !fs[i].ready.empty() || fs[i].state == 2; });
         if (!err.empty()) throw BarbellError(BB_E_INVALID, err);
-        return data[i];
+        if (cancelled) throw BarbellError(BB_E_INVALID, "cancelled");
+        if (fs[i].ready.empty()) {   // every piece has been handed out: the next file may start (its pieces already made stay until consumed)
+            consumed_upto = std::max(consumed_upto, i + 1);
+            lk.unlock();
+            cv.notify_all();
+            return nullptr;
+        }
+        auto pc = fs[i].ready.front();
+        fs[i].ready.pop_front();
+        return pc;
     }
-    // size of the inflated file, once known; stays valid after release(i) (another reader may have consumed the file
-    // while this one was still waiting to learn its size)
-    uint64_t size_of(size_t i) {
-        std::unique_lock<std::mutex> lk(mu);
-        cv.wait(lk, [&]() { return state[i] >= 2 || !err.empty(); });
-        if (state[i] < 2) throw BarbellError(BB_E_INVALID, err);
-        return inflated_size[i];
+    // every chunk of a piece has been copied out: its memory goes with the last reference, the file may make another
+    void piece_consumed(size_t i, size_t bytes) {
+        { std::lock_guard<std::mutex> lk(mu); --fs[i].out; held -= bytes; }
+        cv.notify_all();
     }
-    void release(size_t i) {
+    // wakes everything that waits here (workers, and readers inside next_piece): called before the feeder joins its readers
+    void cancel() {
         {
             std::lock_guard<std::mutex> lk(mu);
-            std::vector<uint8_t>().swap(data[i]);
-            state[i] = 3;
-            consumed_upto = std::max(consumed_upto, i + 1);
+            next_file = paths.size();
+            cancelled = true;
         }
         cv.notify_all();
     }
     ~ParallelInflater() {
-        {
-            std::lock_guard<std::mutex> lk(mu);
-            next_file = paths.size();
-            if (err.empty()) err = "cancelled";
-        }
-        cv.notify_all();
+        if (getenv("BARBELL_AMD_PROFILE"))
+            fprintf(stderr, "profile: gzip / pipe input inflated in %llu piece(s) of at most %zu bytes; at most %llu bytes of inflated text held at once\n",
+                    (unsigned long long)n_pieces, piece_bytes, (unsigned long long)max_held);
+        cancel();
         for (auto& t : pool) if (t.joinable()) t.join();
     }
 };
@@ -1499,7 +1551,6 @@ BlockFeeder::BlockFeeder(int device_, const std::vector<std::string>& files, siz
     if (const char* e = getenv("BARBELL_AMD_HEAD_BYTES")) HEAD = (size_t)std::max(16L, atol(e));
     is_gz.resize(paths.size()); fds.assign(paths.size(), -1); sizes.assign(paths.size(), 0); size_known.assign(paths.size(), 0);
     maps.assign(paths.size(), nullptr);
-    chunks_left.assign(paths.size(), 0);
     std::vector<std::string> gz_paths;
     for (size_t i = 0; i < paths.size(); ++i) {
         // Pipes, process substitutions and /dev/stdin have no size and cannot be read at offsets (and a sniff would eat their
@@ -1552,6 +1603,7 @@ BlockFeeder::BlockFeeder(int device_, const std::vector<std::string>& files, siz
 BlockFeeder::~BlockFeeder() {
     { std::lock_guard<std::mutex> lk(mu); stop = true; }
     cv.notify_all();
+    if (inflater) inflater->cancel();   // a reader may be waiting for a piece of inflated text
     for (auto& t : readers) if (t.joinable()) t.join();
     inflater.reset();
     if (!keep_slots)
@@ -1587,16 +1639,16 @@ BlockFeeder::~BlockFeeder() {
     }
     for (int fd : fds) if (fd >= 0) close(fd);
 }
-// next chunk of the stream; gzip files are inflated whole (a few files ahead) and chunked from memory
+// next chunk of the stream; gzip files come as record-aligned pieces of inflated text (ParallelInflater), each chunked like a small file
 bool BlockFeeder::claim(Task& t) {
     for (;;) {
         size_t f;
         {
-            std::lock_guard<std::mutex> lk(mu);
+            std::unique_lock<std::mutex> lk(mu);
             if (stop) return false;
             if (cur_file >= paths.size()) { if (!claims_done) { claims_done = true; cv.notify_all(); } return false; }
             f = cur_file;
-            if (size_known[f]) {
+            if (!is_gz[f]) {
                 if (cur_off < begins[f]) cur_off = begins[f];
                 if (ends[f] == begins[f]) {  // empty file (or an empty byte range of one): an empty last chunk keeps the sequence simple
                     t = Task{f, begins[f], 0, next_seq++, true, nullptr};
@@ -1609,10 +1661,29 @@ bool BlockFeeder::claim(Task& t) {
                 if (t.last) { ++cur_file; cur_off = 0; }
                 return true;
             }
+            if (cur_piece) {
+                const size_t len = (size_t)std::min<uint64_t>(chunk, cur_piece->size - cur_off);
+                t = Task{f, cur_off, len, next_seq++, cur_off + len == cur_piece->size, cur_piece};
+                cur_off += len;
+                if (t.last) { cur_piece.reset(); cur_off = 0; }
+                return true;
+            }
+            if (piece_fetching) { cv.wait(lk, [&]() { return stop || !piece_fetching; }); continue; }
+            piece_fetching = true;
         }
-        const uint64_t isz = inflater->size_of(f);  // blocks until inflated (thread-safe, several readers may wait)
-        std::lock_guard<std::mutex> lk(mu);
-        if (!size_known[f]) { sizes[f] = isz; ends[f] = isz; size_known[f] = 1; chunks_left[f] = std::max<uint64_t>(1, (isz + chunk - 1) / chunk); }
+        std::shared_ptr<GzPiece> pc;
+        std::string e;
+        try { pc = inflater->next_piece(f); } catch (const std::exception& ex) { e = ex.what(); }   // blocks until inflated
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            piece_fetching = false;
+            if (e.empty()) {
+                if (!pc) { ++cur_file; cur_off = 0; }
+                else { cur_piece = pc; cur_off = 0; pc->chunks_left = std::max<uint64_t>(1, (pc->size + chunk - 1) / chunk); }
+            }
+        }
+        cv.notify_all();
+        if (!e.empty()) throw BarbellError(BB_E_INVALID, e);
     }
 }
 void BlockFeeder::reader_loop() {
@@ -1636,7 +1707,9 @@ void BlockFeeder::reader_loop() {
             }
             uint8_t* dst = sl.p + HEAD;
             const uint8_t* src = nullptr;   // the chunk's raw bytes where they can be read in place (inflated image, mapped file)
-            if (is_gz[t.file]) src = inflater->get(t.file).data() + t.off;
+            // the file the chunk lies in, for the look-ahead / look-back below: a plain file's range, or the piece of inflated text
+            const uint64_t f_begin = t.piece ? 0 : begins[t.file], f_end = t.piece ? t.piece->size : ends[t.file], f_size = t.piece ? t.piece->size : sizes[t.file];
+            if (t.piece) src = t.piece->data.data() + t.off;
             else if (maps[t.file]) {
                 // a mapped file that has been truncated since it was opened would fault (SIGBUS) when its lost pages are touched: look at its
                 // size again before every chunk and fail like the pread path does (a file cut while a chunk is being read is still a race)
@@ -1659,16 +1732,16 @@ void BlockFeeder::reader_loop() {
             if (two_line && src) {
                 // the phase is read off the first lines from the chunk's start; they may lie beyond its end (a chunk shorter than three lines):
                 // the mapped file / inflated image can be read ahead
-                ph0 = guess_phase(src, t.len + (size_t)std::min<uint64_t>(sizes[t.file] - (t.off + t.len), 1u << 20), t.off == begins[t.file]);   // (a shard's range begins at a record start)
-                if (ph0 < 0 && t.off > begins[t.file]) {   // too few lines from here to the end of the file: read the phase off the text BEFORE the chunk and count on
-                    const uint64_t back = std::min<uint64_t>(t.off - begins[t.file], 4u << 20);
+                ph0 = guess_phase(src, t.len + (size_t)std::min<uint64_t>(f_size - (t.off + t.len), 1u << 20), t.off == f_begin);   // (a shard's range, and a piece, begin at a record start)
+                if (ph0 < 0 && t.off > f_begin) {   // too few lines from here to the end of the file: read the phase off the text BEFORE the chunk and count on
+                    const uint64_t back = std::min<uint64_t>(t.off - f_begin, 4u << 20);
                     const uint8_t* w = src - back;
-                    const int pw = guess_phase(w, (size_t)(sizes[t.file] - (t.off - back)), t.off - back == begins[t.file]);
+                    const int pw = guess_phase(w, (size_t)(f_size - (t.off - back)), t.off - back == f_begin);
                     if (pw >= 0) ph0 = (int)((pw + count_nl(w, (size_t)back)) & 3u);
                 }
                 if (ph0 >= 0) {
                     PackCtx pk;
-                    if (pack) { pk.line_pos0 = line_pos(src - t.off, t.off); pk.after = (size_t)(ends[t.file] - (t.off + t.len)); pk.look_back(src - t.off, t.off); }
+                    if (pack) { pk.line_pos0 = line_pos(src - t.off, t.off); pk.after = (size_t)(f_end - (t.off + t.len)); pk.look_back(src - t.off, t.off); }
                     got_len = compact_two_line(dst, src, t.len, ph0, nl, raw_nl, bad, sum, pack ? &pk : nullptr);
                     unpackable = pk.unpackable;
                 } else { if (t.len) memcpy(dst, src, t.len); raw_nl = count_nl(dst, t.len); }   // left raw: the sequencer compacts it with the true phase
@@ -1684,7 +1757,7 @@ void BlockFeeder::reader_loop() {
                     }
                 }
                 if (two_line) {
-                    ph0 = guess_phase(dst, t.len, t.off == begins[t.file]);
+                    ph0 = guess_phase(dst, t.len, t.off == f_begin);
                     if (ph0 >= 0) got_len = compact_two_line(dst, dst, t.len, ph0, nl, raw_nl, bad, sum);
                     else raw_nl = count_nl(dst, t.len);
                 } else nl = count_nl(dst, t.len);
@@ -1698,10 +1771,11 @@ void BlockFeeder::reader_loop() {
                 const uintptr_t a0 = ((uintptr_t)src + pg - 1) & ~(pg - 1), a1 = ((uintptr_t)src + t.len) & ~(pg - 1);
                 if (a1 > a0) (void)madvise((void*)a0, (size_t)(a1 - a0), MADV_DONTNEED);
             }
-            if (is_gz[t.file]) {
+            if (t.piece) {
                 bool last_copy;
-                { std::lock_guard<std::mutex> lk(mu); last_copy = --chunks_left[t.file] == 0; }
-                if (last_copy) inflater->release(t.file);  // every chunk of the image has been copied out
+                { std::lock_guard<std::mutex> lk(mu); last_copy = --t.piece->chunks_left == 0; }
+                if (last_copy) inflater->piece_consumed(t.file, t.piece->size);  // every chunk of the piece has been copied out
+                t.piece.reset();
             }
             {
                 std::lock_guard<std::mutex> lk(mu);

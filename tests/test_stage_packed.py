@@ -136,6 +136,34 @@ def test_byte_range_shards_partition_the_records(tmp_path, nl):
     assert r.returncode != 0 and "--shard-by bytes" in r.stderr
 
 
+def test_gzip_input_streams_in_bounded_pieces(tmp_path):
+    """A gzip file (or a pipe) is inflated in record-aligned PIECES that the feeder chunks like small files (ParallelInflater; round 5: it used
+    to be inflated whole — a 50 GB fastq.gz meant 200 GB of text in memory).  The staged text equals the plain file's whatever the piece size
+    (64 bytes: every record its own piece; records larger than a piece), in every upload form, and what is held at once is bounded by the
+    pieces in flight, not by the file."""
+    import re
+
+    rng = np.random.default_rng(41)
+    recs = records(rng, 3000, 1, 900) + [(b"big", bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), 300_000)))] + records(rng, 200, 50, 400)
+    text = fastq(recs) + b"\n\n"
+    plain, gz = tmp_path / "a.fastq", tmp_path / "a.fastq.gz"
+    plain.write_bytes(text)
+    with gzip.open(gz, "wb", compresslevel=1) as f:
+        f.write(text)
+    for flags in ([], ["--no-pack"], ["--no-compact"]):
+        form, _, want = stage([plain], tmp_path / "p.bin", "--block-bytes", "65536", *flags)
+        for piece in ("64", "5000", "100000", None):
+            env = {"BARBELL_AMD_GZ_PIECE": piece} if piece else {}
+            f2, _, got = stage([gz], tmp_path / "g.bin", "--block-bytes", "65536", *flags, env=env)
+            assert got == want and f2 == form, (flags, piece)
+    # the bound: 3 MB of text in pieces of 100 kB — never more than a few pieces held (three published per file + the one a reader is copying)
+    r = subprocess.run([CLI, "stage", "-i", str(gz), "-o", str(tmp_path / "g.bin"), "--block-bytes", "65536", "-t", "3"], capture_output=True, text=True,
+                       env=dict(os.environ, BARBELL_AMD_GZ_PIECE="100000", BARBELL_AMD_PROFILE="1"))
+    m = re.search(r"inflated in (\d+) piece\(s\) of at most (\d+) bytes; at most (\d+) bytes", r.stderr)
+    assert r.returncode == 0 and m, r.stderr
+    assert int(m.group(1)) >= len(text) // 400_000 and int(m.group(3)) <= 4 * 100_000 + 700_000 < len(text)   # (one piece grew to hold the 300 kb record: 600 KB of text)
+
+
 def test_randomised_staging_slice():
     """a slice of tools/stage_fuzz.py (the full tool runs thousands of seeds): random layouts, line ends, blank tails, tiny chunks"""
     import sys

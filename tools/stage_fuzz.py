@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """dev aid (no GPU): randomised check of the C++ host's packed staging (`barbell-amd stage`, bb_host.cpp compact_two_line + PackCtx) against the
 Python packer (barbell_amd/fastq.py): random record lengths around the 32-base vector width, LF / CRLF, IUPAC and non-IUPAC characters, files
-with and without a final newline, blank lines after the last record, gzip, several files, chunk sizes from 17 bytes up, 1-5 reader threads.
+with and without a final newline, blank lines after the last record, gzip (inflated in pieces of 64 bytes up), several files, chunk sizes from 17 bytes up, 1-5 reader threads.
 Every other seed also checks --shard R/W --shard-by bytes (the shards' texts concatenated = the unsharded text).
 Round 5 found three chunk-boundary bugs with it (a "\r" | "\n" split over two chunks, blank tail lines straddling a chunk start).
 usage: stage_fuzz.py FIRST_SEED N_SEEDS"""
@@ -42,7 +42,9 @@ for seed in range(int(sys.argv[1]), int(sys.argv[1])+int(sys.argv[2])):
         else: want+=pk+tail
     block=int(rng.choice([17,64,100,257,1000,4096,1<<20]))
     t=int(rng.integers(1,6))
-    r=subprocess.run([CLI,'stage','-i']+files+['-o','/tmp/barbell_stage_fuzz/o.bin','--block-bytes',str(block),'-t',str(t)],capture_output=True,text=True)
+    env=dict(os.environ)
+    if rng.random()<0.7: env['BARBELL_AMD_GZ_PIECE']=str(int(rng.choice([64,100,333,1000,5000,70000])))   # gzip input comes in record-aligned pieces (ParallelInflater): tiny ones
+    r=subprocess.run([CLI,'stage','-i']+files+['-o','/tmp/barbell_stage_fuzz/o.bin','--block-bytes',str(block),'-t',str(t)],capture_output=True,text=True,env=env,timeout=120)   # (a hang is a failure: the traceback names the seed)
     if r.returncode!=0:
         print('seed',seed,'rc',r.returncode,r.stderr[-200:]); bad+=1; continue
     form=int(r.stdout.split()[1]); got=open('/tmp/barbell_stage_fuzz/o.bin','rb').read()
