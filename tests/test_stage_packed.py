@@ -164,6 +164,51 @@ def test_gzip_input_streams_in_bounded_pieces(tmp_path):
     assert int(m.group(1)) >= len(text) // 400_000 and int(m.group(3)) <= 4 * 100_000 + 700_000 < len(text)   # (one piece grew to hold the 300 kb record: 600 KB of text)
 
 
+def test_gzip_members_inflated_side_by_side(tmp_path):
+    """`cat run/*.fastq.gz > all.fastq.gz` makes one gzip file of many members; zlib inflates 0.3 GB/s on one core.  The members are inflated
+    on several (ParallelInflater::inflate_regular): the compressed bytes cut into ranges, a range's first member found by the gzip magic and
+    its chain accepted only if it starts exactly where the text accepted so far ended — so a false start (stored members whose TEXT holds the
+    magic bytes) costs time, never bytes.  Same staged text as from the plain file: members cut at arbitrary points of the text, ranges of
+    200 bytes to 30 KB; a single member falls back to the serial path; trailing garbage is ignored and a truncated file is an error, as with gzread."""
+    import re
+    import zlib
+
+    def member(t, level):
+        c = zlib.compressobj(level, zlib.DEFLATED, 31)
+        return c.compress(t) + c.flush()
+
+    rng = np.random.default_rng(43)
+    recs = records(rng, 700, 1, 700)
+    recs = [(h + (b" \x1f\x8b\x08\x00\x00\x00\x00\x00\x00\x03" if i % 5 == 0 else b""), s) for i, (h, s) in enumerate(recs)]   # the magic in header lines
+    text = fastq(recs)
+    cuts = [0] + sorted(int(x) for x in rng.integers(0, len(text), 40)) + [len(text)]
+    blob = b"".join(member(text[a:b], int(rng.choice([0, 1, 6]))) for a, b in zip(cuts[:-1], cuts[1:]))
+    plain, gz = tmp_path / "a.fastq", tmp_path / "a.fastq.gz"
+    plain.write_bytes(text)
+    want = stage([plain], tmp_path / "p.bin", "--block-bytes", "65536", "--no-compact")[2]
+    assert want == text
+
+    def run(blob_, env):
+        gz.write_bytes(blob_)
+        r = subprocess.run([CLI, "stage", "-i", str(gz), "-o", str(tmp_path / "g.bin"), "--block-bytes", "65536", "--no-compact", "-t", "6"], capture_output=True,
+                           text=True, env=dict(os.environ, BARBELL_AMD_PROFILE="1", **env), timeout=120)
+        m = re.search(r"(\d+) range\(s\) of members", r.stderr)
+        return r.returncode, (tmp_path / "g.bin").read_bytes() if r.returncode == 0 else b"", int(m.group(1)) if m else -1, r.stderr
+
+    for rb, least in (("200", 1), ("8000", 8), ("30000", 5)):   # (with the range size fixed, members beyond 4 ranges of compressed bytes go to the serial path: 200-byte ranges give up early)
+        rc, got, n_ranges, err = run(blob, {"BARBELL_AMD_GZ_RANGE": rb, "BARBELL_AMD_GZ_PIECE": "5000"})
+        assert rc == 0 and got == text and n_ranges >= least, (rb, n_ranges, err[-300:])
+    rc, got, n_ranges, _ = run(blob, {"BARBELL_AMD_GZ_SERIAL": "1"})
+    assert rc == 0 and got == text and n_ranges == 0
+    rc, got, n_ranges, _ = run(member(text, 6), {"BARBELL_AMD_GZ_RANGE": "200"})            # one member: nothing to do side by side
+    assert rc == 0 and got == text and n_ranges <= 1
+    rc, got, n_ranges, _ = run(blob + b"\x00" * 700, {"BARBELL_AMD_GZ_RANGE": "200"})       # trailing bytes that are no member: ignored
+    assert rc == 0 and got == text
+    for env in ({"BARBELL_AMD_GZ_RANGE": "200"}, {"BARBELL_AMD_GZ_SERIAL": "1"}):           # cut inside the last member: an error, not a short file
+        rc, got, _, err = run(blob[:-40], env)
+        assert rc != 0 and "Error reading FASTQ file" in err, err[-300:]
+
+
 def test_randomised_staging_slice():
     """a slice of tools/stage_fuzz.py (the full tool runs thousands of seeds): random layouts, line ends, blank tails, tiny chunks"""
     import sys
