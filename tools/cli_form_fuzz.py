@@ -38,14 +38,25 @@ for seed in range(int(sys.argv[1]), int(sys.argv[1]) + int(sys.argv[2])):
         if final_nl and recs:
             text += [b"", b"", nl, nl + nl][int(rng.integers(0, 4))]
         p = f"{D}/f{f}.fq" + (".gz" if rng.random() < 0.25 else "")
-        with (gzip.open(p, "wb") if p.endswith(".gz") else open(p, "wb")) as fh:
-            fh.write(text)
+        if p.endswith(".gz") and rng.random() < 0.5 and len(text) > 10:   # several gzip members, cut anywhere in the text (`cat a.gz b.gz`)
+            cuts = [0] + sorted(int(x) for x in rng.integers(0, len(text), int(rng.integers(1, 12)))) + [len(text)]
+            with open(p, "wb") as fh:
+                for a, b in zip(cuts[:-1], cuts[1:]):
+                    fh.write(gzip.compress(text[a:b], compresslevel=int(rng.choice([0, 1, 6]))))
+        else:
+            with (gzip.open(p, "wb") if p.endswith(".gz") else open(p, "wb")) as fh:
+                fh.write(text)
         files.append(p)
     block = int(rng.choice([257, 1000, 4096, 70000, 1 << 20]))
+    env = dict(os.environ, BARBELL_AMD_NO_TORCH="1")
+    # round 5: gzip input inflated in pieces and by ranges of members (tiny ones), the scans' segments (nearly every read cut)
+    if rng.random() < 0.6: env["BARBELL_AMD_GZ_PIECE"] = str(int(rng.choice([64, 500, 4000, 100000])))
+    if rng.random() < 0.6: env["BARBELL_AMD_GZ_RANGE"] = str(int(rng.choice([64, 300, 2000, 20000])))
+    if rng.random() < 0.4: env["BARBELL_AMD_SEG_LINES"] = str(int(rng.choice([4, 8, 16])))
     outs = {}
     for name, extra in (("packed", []), ("text", ["--no-pack"]), ("whole", ["--no-compact"])):
         r = subprocess.run([CLI, "annotate", "-i"] + files + ["-o", f"{D}/{name}.tsv", "--kit", "SQK-NBD114-96", "--flank-max-errors", "3", "--block-bytes", str(block),
-                            "-t", str(int(rng.integers(1, 6)))] + extra, capture_output=True, text=True, env=dict(os.environ, BARBELL_AMD_NO_TORCH="1"))
+                            "-t", str(int(rng.integers(1, 6)))] + extra, capture_output=True, text=True, env=env, timeout=300)
         outs[name] = (r.returncode, open(f"{D}/{name}.tsv", "rb").read() if r.returncode == 0 else r.stderr[-200:])
     if not (outs["packed"] == outs["text"] == outs["whole"]) or outs["whole"][0] != 0:
         bad += 1
