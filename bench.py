@@ -585,6 +585,51 @@ def e2e_leg(d_bases, n, L, dev):
                 kit = {"error": rk.stderr[-300:]}
         except Exception as e:  # the kit run is an extra, never a reason to lose the line
             kit = {"error": str(e)[:200]}
+        # gzip input as a run's files concatenated (`cat run/*.fastq.gz`): the first 200 k reads as 64 gzip members in one file — bound by zlib
+        # (0.3 GB/s of text per core; the reference's reader has the same limit), the members inflated side by side against one after the other
+        gzm = {}
+        try:
+            import zlib
+            from multiprocessing.pool import ThreadPool
+
+            n_gz, n_mem = min(n, 200_000), 64
+            rec = 2 * L + 64                 # upper bound of a record's bytes; the text is cut at record starts found in the file itself
+            with open(fq, "rb") as f:
+                head = f.read(n_gz * rec)
+            ends_, pos_ = [0], 0
+            per = n_gz // n_mem
+            for _ in range(n_mem):
+                for _ in range(per * 4):
+                    pos_ = head.index(b"\n", pos_) + 1
+                ends_.append(pos_)
+            def _member(ab):
+                c = zlib.compressobj(1, zlib.DEFLATED, 31)
+                return c.compress(head[ab[0]:ab[1]]) + c.flush()
+            t0 = time.perf_counter()
+            with ThreadPool(effective_cpus()) as tp:    # (zlib releases the GIL)
+                blobs = tp.map(_member, list(zip(ends_[:-1], ends_[1:])))
+            gzp = os.path.join(td, "members.fastq.gz")
+            with open(gzp, "wb") as f:
+                for b_ in blobs:
+                    f.write(b_)
+            gzm = {"reads": per * n_mem, "members": n_mem, "text_bytes": ends_[-1], "compressed_bytes": os.path.getsize(gzp), "compress_s": time.perf_counter() - t0}
+            del head, blobs
+            tsvs = []
+            for key, extra_env in (("members_side_by_side", {}), ("one_after_the_other", {"BARBELL_AMD_GZ_SERIAL": "1"})):
+                t0 = time.perf_counter()
+                rg = subprocess.run([cli, "annotate", "-i", gzp, "-o", os.path.join(td, key + ".tsv"), "--kit", "SQK-NBD114-96", "--flank-max-errors", "3", "-t", "32"],
+                                    capture_output=True, text=True, env=dict(env, **extra_env))
+                w_ = time.perf_counter() - t0
+                if rg.returncode != 0:
+                    gzm[key] = {"error": rg.stderr[-300:]}
+                    continue
+                gzm[key] = {"process_wall_s": w_, "reads_per_s": per * n_mem / w_, "text_gb_per_s": ends_[-1] / w_ / 1e9}
+                tsvs.append(open(os.path.join(td, key + ".tsv"), "rb").read())
+            gzm["tsv_identical"] = len(tsvs) == 2 and tsvs[0] == tsvs[1]
+            gzm["note"] = "process wall incl. ~0.3 s of start-up; -t 32 on the container's CPU quota"
+            os.remove(gzp)
+        except Exception as e:  # noqa: BLE001
+            gzm = {"error": f"{type(e).__name__}: {e}"[:300]}
         # the process wall on an input long enough for start-up (~0.35 s: loader, HIP, two contexts) not to dominate: 16 M reads = 129 GB of FASTQ,
         # in /dev/shm (the scratch directory's file system is smaller than that); skipped where /dev/shm cannot hold it
         big = {}
@@ -632,7 +677,7 @@ def e2e_leg(d_bases, n, L, dev):
             top = {"reads": big["reads"], "fastq_bytes": big["fastq_bytes"], "pipeline_s": med("pipeline_s"), "steady_state_reads_per_s": big["reads"] / med("pipeline_s"),
                    "steady_state_fastq_gb_per_s": big["fastq_bytes"] / med("pipeline_s") / 1e9, "process_wall_s": med("process_wall_s"),
                    "process_wall_reads_per_s": big["reads"] / med("process_wall_s"), "runs": big["runs"], "reported": "median of the runs on the 16 M-read input"}
-        return {**top, "short_input": short, "kit": kit, "wall_16m_reads": big, "tsv_bytes": os.path.getsize(os.path.join(td, "a.tsv")), "rows": int(m.group(3)),
+        return {**top, "short_input": short, "kit": kit, "gzip_members": gzm, "wall_16m_reads": big, "tsv_bytes": os.path.getsize(os.path.join(td, "a.tsv")), "rows": int(m.group(3)),
                 "fastq_write_s": gen_s,
                 "host_feed_only": feed, "upload_form": "packed: header lines + two bases per byte (BB_FASTQ_PACKED), ~2 KB per read over PCIe",
                 "text_lines_form": text_form,
