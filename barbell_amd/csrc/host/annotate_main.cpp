@@ -89,7 +89,7 @@ static void usage() {
     fputs(
         "Usage: barbell-amd annotate -i <FASTQ>... [-o output.tsv] (--kit <KIT> | -q <FASTA>... [-b Ftag|Rtag ...])\n"
         "                            [--flank-max-errors INT] [--min-score F=0.2] [--min-score-diff F=0.1]\n"
-        "                            [--alpha F=0.4] [--use-extended] [-t THREADS=10] [--verbose]\n"
+        "                            [--alpha F=0.4] [--use-extended] [-t THREADS=auto (reader / inflater threads: the CPUs the process may use, at most 32; the reference's default is 10)] [--verbose]\n"
         "                            [--block-bytes N=256Mi | --batch-reads N (= N*4096 bytes)] [--device D=0]\n"
         "                            [--shard R/W [--shard-by files|bytes (files: the inputs with index R mod W; bytes: the records that start in the R-th of W byte ranges of each plain file)]\n"
         "                             [--rccl-id PATH (one fresh path for all W processes: their histograms are all-reduced, RCCL ncclCommInitRank; shard 0 writes --counts)]]\n"
@@ -104,7 +104,7 @@ static void usage() {
         "                             [--gpu-render (records rendered in HBM and downloaded; default: the GPU plans, the file writers cut them out of the staged text)]]\n"
         "                            [--inspect [-n TOP=10] [--read-pattern-out FILE] [-s BUCKET=250]]\n"
         "       barbell-amd kit -k <KIT> -i <FASTQ>... -o <OUT_DIR> [--maximize] [--min-score F] [--min-score-diff F]\n"
-        "                       [--flank-max-errors INT] [--failed-out FILE] [--use-extended] [--alpha F] [--gzip] [-t N]\n"
+        "                       [--flank-max-errors INT] [--failed-out FILE] [--use-extended] [--alpha F] [--gzip] [-t N=auto]\n"
         "                       [--device D=0] [--shard R/W [--shard-by files|bytes] [--rccl-id PATH]] [--gpu-render]\n"
         "       barbell-amd kits          list the supported kit names\n"
         "       barbell-amd pattern <STR>...   parse filter pattern strings and print their elements\n",

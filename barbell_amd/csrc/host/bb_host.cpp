@@ -2228,8 +2228,9 @@ static AnnotateStats annotate_once(const std::vector<std::string>& read_files, c
     const size_t block = config.batch_reads ? std::max<size_t>(config.batch_reads * 4096, 4096) : std::max<size_t>(config.block_bytes, 4096);
     // two-line mode: a slot is about half full and a chunk costs its reader a pass over the text, so twice the slots and readers
     // host_cut: a slot also waits for the writer threads (at most 4 blocks there), and the last holder may be one of them
+    const unsigned n_threads = config.n_threads ? config.n_threads : std::min(32u, std::max(4u, effective_cpus()));
     auto feeder_p = std::make_shared<BlockFeeder>(devs[0], read_files, block, (unsigned)((two_line ? 2 : 1) * (3 * G + 2) + (host_cut ? 6 : 0)),
-                                                  std::min<unsigned>(std::min<unsigned>(std::max(1u, config.n_threads), 32u), std::max(4u, effective_cpus())), config.n_threads, two_line,
+                                                  std::min<unsigned>(std::min<unsigned>(std::max(1u, n_threads), 32u), std::max(4u, effective_cpus())), n_threads, two_line,
                                                   config.pack_upload && !getenv("BARBELL_AMD_NO_PACK"),
                                                   config.shard_by_bytes ? config.shard_rank : 0u, config.shard_by_bytes ? config.shard_world : 1u);
     const bool packed = feeder_p->pack;   // two bases per byte in the sequence lines (needs the raw text in memory: mapped or inflated)

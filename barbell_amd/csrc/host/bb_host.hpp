@@ -222,7 +222,8 @@ private:
 struct AnnotateConfig {  // config.rs:3-12 with the CLI defaults of bin/main.rs:64-112
     std::optional<size_t> max_flank_errors;
     float alpha = 0.4f;
-    unsigned n_threads = 10;  // accepted for CLI compatibility; the GPU path uses one host thread per context
+    unsigned n_threads = 0;   // -t: reader / inflater threads of the input feeder (the reference's worker threads, default 10 there); 0 = as many as the
+                              // process may use, at most 32 (measured on the 16-CPU box, 4 M reads: -t 4 7.7, 10 11–12, 16 14.6, 32 13.5 M reads/s)
     bool verbose = false;
     double min_score = 0.2, min_score_diff = 0.1;
     bool use_extended = false;
@@ -283,7 +284,7 @@ std::vector<std::string> inspect_summary(const AnnotateStats& st, size_t top_n);
 
 struct KitConfig {  // config.rs:34-48, CLI defaults bin/main.rs:208-262
     std::string kit_name, output_folder;
-    size_t threads = 10;
+    size_t threads = 0;   // AnnotateConfig::n_threads
     bool maximize = false, verbose = false;
     double min_score = 0.2, min_score_diff = 0.1;
     std::optional<size_t> max_flank_errors;

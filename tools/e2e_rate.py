@@ -85,6 +85,9 @@ if a.quick:
     for rep in range(3):
         run(f"annotate_streams2_block256Mi_t32_rep{rep}", base + ["--streams", "2", "--block-bytes", str(256 << 20), "-t", "32"])
     run("annotate_text_lines_streams2_block256Mi_t32", base + ["--streams", "2", "--block-bytes", str(256 << 20), "-t", "32", "--no-pack"])
+    for thr in ("4", "10", "16"):   # -t: the reference's default is 10 (worker threads there, reader threads here)
+        run(f"annotate_defaults_t{thr}", base + ["-t", thr])
+    run("annotate_defaults", base)
     best = max(out["runs"], key=lambda k: out["runs"][k]["steady_state_reads_per_s"] or 0)
     out["best"] = {"run": best, **{k: out["runs"][best][k] for k in ("steady_state_reads_per_s", "wall_reads_per_s", "wall_s")}}
 elif not a.only_kit:
