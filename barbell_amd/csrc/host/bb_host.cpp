@@ -20,6 +20,7 @@
 #include <mutex>
 #include <thread>
 
+#include <dlfcn.h>
 #include <sched.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -981,6 +982,35 @@ struct BlockFeeder {
 // whole — a 50 GB fastq.gz meant 200 GB of text in memory (and its buffer's last doubling as much again); now a file holds at most
 // `pieces_ahead` pieces whatever its size.  n_threads comes from -t/--threads like the reference's worker count.
 static size_t count_nl(const uint8_t* p, size_t n);
+// libdeflate, where the system has it (dlopen: no build dependency; BARBELL_AMD_NO_LIBDEFLATE=1 switches it off): inflates a gzip member
+// whose text fits a buffer 4-5 x as fast as zlib (320 MB of FASTQ text in 32 members: 0.41 against 1.84 s on one core).  It has no
+// streaming form, so members too large to buffer — and systems without the library — take zlib as before.
+struct LibDeflate {
+    void* (*alloc)() = nullptr;
+    void (*release)(void*) = nullptr;
+    int (*gzip_ex)(void*, const void*, size_t, void*, size_t, size_t*, size_t*) = nullptr;   // 0 ok, 1 bad data, 3 insufficient space
+    static const LibDeflate& get() {
+        static const LibDeflate L = []() {
+            LibDeflate l;
+            if (getenv("BARBELL_AMD_NO_LIBDEFLATE")) return l;
+            void* h = nullptr;
+            for (const char* name : {"libdeflate.so.0", "libdeflate.so"}) if ((h = dlopen(name, RTLD_NOW | RTLD_LOCAL))) break;
+            if (!h) return l;
+            l.alloc = (void* (*)())dlsym(h, "libdeflate_alloc_decompressor");
+            l.release = (void (*)(void*))dlsym(h, "libdeflate_free_decompressor");
+            l.gzip_ex = (int (*)(void*, const void*, size_t, void*, size_t, size_t*, size_t*))dlsym(h, "libdeflate_gzip_decompress_ex");
+            if (!l.alloc || !l.release || !l.gzip_ex) l.gzip_ex = nullptr;
+            return l;
+        }();
+        return L;
+    }
+    struct Dec { void* d = nullptr; ~Dec() { if (d) LibDeflate::get().release(d); } };
+    static void* decompressor() {   // one per thread
+        static thread_local Dec t;
+        if (!t.d && get().gzip_ex) t.d = get().alloc();
+        return t.d;
+    }
+};
 // bytes without the zero-fill a std::vector pays on every growth (the inflaters write every byte they count; at GB/s the fill was a third of the time)
 struct RawBuf {
     uint8_t* p = nullptr; size_t cap = 0;
@@ -1101,6 +1131,26 @@ struct ParallelInflater {
     // one member at map[pos ..]: its text appended to `out` (or handed to `sink` as it comes); returns the compressed bytes it took, 0 on error
     // or when it grows beyond the limits (max_in compressed bytes / max_out bytes of text in `out`)
     static uint64_t inflate_member(const uint8_t* map, uint64_t size, uint64_t pos, RawBuf* out, size_t* out_n, PieceSink* sink, uint64_t max_in, uint64_t max_out) {
+        // libdeflate first: the member's text into a buffer of guessed size (doubled while it says the space does not suffice)
+        if (void* dec = LibDeflate::decompressor()) {
+            const uint64_t left = size - pos;
+            const size_t in_n = (size_t)std::min<uint64_t>(left, out ? std::min<uint64_t>(max_in, 1ull << 40) + 65536 : (512ull << 20));
+            const uint64_t cap_out = out ? max_out + (16ull << 20) : (2048ull << 20);
+            static thread_local RawBuf tmp;   // (serial path)
+            const size_t have = out ? *out_n : 0;
+            RawBuf& dst = out ? *out : tmp;
+            const bool whole = out || left <= (512ull << 20);   // a member that may not fit the input window is zlib's (the serial path of a huge single-member file)
+            for (uint64_t space = std::min<uint64_t>(cap_out, std::max<uint64_t>(16ull << 20, 6ull * std::min<uint64_t>(in_n, 64ull << 20))); whole; space *= 2) {
+                dst.reserve(have + (size_t)space);
+                size_t a_in = 0, a_out = 0;
+                const int r = LibDeflate::get().gzip_ex(dec, map + pos, in_n, dst.data() + have, (size_t)space, &a_in, &a_out);
+                if (r == 0) {
+                    if (out) { *out_n = have + a_out; return a_in; }
+                    return sink->append(tmp.data(), a_out) ? a_in : 0;
+                }
+                if (r != 3 || space >= cap_out) break;   // bad data (or cut off by the window), or larger than what may be buffered: zlib decides
+            }
+        }
         z_stream zs;
         memset(&zs, 0, sizeof(zs));
         if (inflateInit2(&zs, 15 + 16) != Z_OK) return 0;
@@ -1252,6 +1302,9 @@ struct ParallelInflater {
         if (pos < size) e = inflate_serial(map, size, pos, sink, paths[i]);
         munmap(m, (size_t)size); close(fd);
         if (e.empty()) sink.finish();
+        if (getenv("BARBELL_AMD_PROFILE"))
+            fprintf(stderr, "profile: '%s' inflated in %.3f s (its thread's time, waits for the consumer included)\n", paths[i].c_str(),
+                    std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count());
         return e;
     }
     std::string inflate_stream(size_t i) {   // pipes, process substitutions, /dev/stdin: sequentially through gzread (plain text passes through)
@@ -1329,6 +1382,7 @@ struct ParallelInflater {
         if (getenv("BARBELL_AMD_PROFILE"))
             fprintf(stderr, "profile: gzip / pipe input inflated in %llu piece(s) of at most %zu bytes; at most %llu bytes of inflated text held at once; %llu range(s) of members inflated side by side\n",
                     (unsigned long long)n_pieces, piece_bytes, (unsigned long long)max_held, (unsigned long long)n_ranges_parallel.load());
+        if (getenv("BARBELL_AMD_PROFILE")) fprintf(stderr, "profile: gzip members inflated with %s\n", LibDeflate::get().gzip_ex ? "libdeflate (zlib for members too large to buffer)" : "zlib");
         cancel();
         for (auto& t : pool) if (t.joinable()) t.join();
     }
