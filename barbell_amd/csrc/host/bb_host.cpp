@@ -1028,7 +1028,29 @@ struct RawBuf {
     const uint8_t* data() const { return p; }
     void swap(RawBuf& o) { std::swap(p, o.p); std::swap(cap, o.cap); }
 };
-struct GzPiece { RawBuf data; size_t size = 0; uint64_t chunks_left = 0; };
+// piece buffers go round: a fresh 256 MiB buffer costs 65 K page faults on first touch (a third of the coordinator's time per piece), a used one none
+struct BufPool {
+    std::mutex mu;
+    std::vector<std::unique_ptr<RawBuf>> spare;
+    void give(RawBuf& b) {
+        if (b.cap < (16u << 20)) return;
+        std::lock_guard<std::mutex> lk(mu);
+        if (spare.size() >= 8) return;
+        spare.emplace_back(new RawBuf());
+        spare.back()->swap(b);
+    }
+    bool take(RawBuf& into, size_t want) {   // a spare buffer of at least `want` bytes, if there is one
+        std::lock_guard<std::mutex> lk(mu);
+        for (size_t i = 0; i < spare.size(); ++i)
+            if (spare[i]->cap >= want) { into.swap(*spare[i]); spare.erase(spare.begin() + (long)i); return true; }
+        return false;
+    }
+};
+struct GzPiece {
+    RawBuf data; size_t size = 0; uint64_t chunks_left = 0;
+    std::shared_ptr<BufPool> pool;
+    ~GzPiece() { if (pool) pool->give(data); }
+};
 struct ParallelInflater {
     std::vector<std::string> paths;
     std::vector<char> gz;    // files that are not gzip are skipped (the feeder reads them directly)
@@ -1041,6 +1063,7 @@ struct ParallelInflater {
     size_t piece_bytes = 256u << 20, pieces_ahead = 3;
     std::string err;
     bool cancelled = false;
+    std::shared_ptr<BufPool> bufs = std::make_shared<BufPool>();
     unsigned n_threads_total = 1; size_t n_gz_files = 0;
     uint64_t range_bytes = 32u << 20;   // compressed bytes per range of the member-parallel inflate; BARBELL_AMD_GZ_RANGE (tests) fixes it and scales the limits with it
     bool range_cap = false;
@@ -1076,9 +1099,10 @@ struct ParallelInflater {
         size_t first_cap() const { return std::max<size_t>(64, std::min<size_t>(P.piece_bytes, 4u << 20)); }   // (small files do not pay for a piece-sized buffer)
         bool emit(size_t cut) {   // buf[0, cut) goes out as a piece, the rest starts the next
             auto pc = std::make_shared<GzPiece>();
+            pc->pool = P.bufs;
             RawBuf next;
             const size_t rest = n - cut;
-            next.reserve(std::max(first_cap(), rest + 64));
+            if (!P.bufs->take(next, std::max<size_t>(P.piece_bytes, rest + 64))) next.reserve(std::max(first_cap(), rest + 64));
             if (rest) memcpy(next.data(), buf.data() + cut, rest);
             pc->size = cut; pc->data.swap(buf);
             buf.swap(next);
@@ -1108,6 +1132,7 @@ struct ParallelInflater {
         bool finish() {   // the end of the file: whatever is left (a last line without a line end, blank lines); an empty file gives one empty piece
             if (n == 0 && any) return true;
             auto pc = std::make_shared<GzPiece>();
+            pc->pool = P.bufs;
             pc->size = n; pc->data.swap(buf);
             any = true; n = 0;
             return P.publish(file, std::move(pc));
