@@ -1095,6 +1095,7 @@ struct ParallelInflater {
     struct PieceSink {
         ParallelInflater& P; size_t file;
         RawBuf buf; size_t n = 0; bool any = false;
+        bool no_fast = false;   // a member of this file did not fit libdeflate's buffers: zlib for the rest (inflate_member)
         PieceSink(ParallelInflater& p, size_t f) : P(p), file(f) {}
         size_t first_cap() const { return std::max<size_t>(64, std::min<size_t>(P.piece_bytes, 4u << 20)); }   // (small files do not pay for a piece-sized buffer)
         bool emit(size_t cut) {   // buf[0, cut) goes out as a piece, the rest starts the next
@@ -1157,15 +1158,18 @@ struct ParallelInflater {
     // or when it grows beyond the limits (max_in compressed bytes / max_out bytes of text in `out`)
     static uint64_t inflate_member(const uint8_t* map, uint64_t size, uint64_t pos, RawBuf* out, size_t* out_n, PieceSink* sink, uint64_t max_in, uint64_t max_out) {
         // libdeflate first: the member's text into a buffer of guessed size (doubled while it says the space does not suffice)
-        if (void* dec = LibDeflate::decompressor()) {
+        if (void* dec = (sink && sink->no_fast) ? nullptr : LibDeflate::decompressor()) {
             const uint64_t left = size - pos;
             const size_t in_n = (size_t)std::min<uint64_t>(left, out ? std::min<uint64_t>(max_in, 1ull << 40) + 65536 : (512ull << 20));
-            const uint64_t cap_out = out ? max_out + (16ull << 20) : (2048ull << 20);
+            static const uint64_t serial_cap = getenv("BARBELL_AMD_LIBDEFLATE_MAX") ? (uint64_t)atoll(getenv("BARBELL_AMD_LIBDEFLATE_MAX")) : (1024ull << 20);   // (tests: a small one)
+            const uint64_t cap_out = out ? max_out + (16ull << 20) : serial_cap;
             static thread_local RawBuf tmp;   // (serial path)
             const size_t have = out ? *out_n : 0;
             RawBuf& dst = out ? *out : tmp;
-            const bool whole = out || left <= (512ull << 20);   // a member that may not fit the input window is zlib's (the serial path of a huge single-member file)
-            for (uint64_t space = std::min<uint64_t>(cap_out, std::max<uint64_t>(16ull << 20, 6ull * std::min<uint64_t>(in_n, 64ull << 20))); whole; space *= 2) {
+            // (serial path: a member that does not fit 512 MB of input or 1 GiB of text is zlib's, and so is the rest of its file: a huge single-member
+            // file pays for one failed attempt, ~2 s, not for one per member)
+            const bool whole = true;
+            for (uint64_t space = std::min<uint64_t>(cap_out, std::max<uint64_t>(16ull << 20, 6ull * std::min<uint64_t>(in_n, 64ull << 20))); whole; space = std::min(cap_out, space * 2)) {
                 dst.reserve(have + (size_t)space);
                 size_t a_in = 0, a_out = 0;
                 const int r = LibDeflate::get().gzip_ex(dec, map + pos, in_n, dst.data() + have, (size_t)space, &a_in, &a_out);
@@ -1175,6 +1179,7 @@ struct ParallelInflater {
                 }
                 if (r != 3 || space >= cap_out) break;   // bad data (or cut off by the window), or larger than what may be buffered: zlib decides
             }
+            if (sink) sink->no_fast = true;
         }
         z_stream zs;
         memset(&zs, 0, sizeof(zs));
