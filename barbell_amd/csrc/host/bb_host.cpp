@@ -989,6 +989,11 @@ struct LibDeflate {
     void* (*alloc)() = nullptr;
     void (*release)(void*) = nullptr;
     int (*gzip_ex)(void*, const void*, size_t, void*, size_t, size_t*, size_t*) = nullptr;   // 0 ok, 1 bad data, 3 insufficient space
+    // the other direction (the per-label files of --gzip): a span of records -> one gzip member
+    void* (*calloc_)(int) = nullptr;
+    void (*cfree)(void*) = nullptr;
+    size_t (*gzip_bound)(void*, size_t) = nullptr;
+    size_t (*gzip_compress)(void*, const void*, size_t, void*, size_t) = nullptr;
     static const LibDeflate& get() {
         static const LibDeflate L = []() {
             LibDeflate l;
@@ -1000,9 +1005,20 @@ struct LibDeflate {
             l.release = (void (*)(void*))dlsym(h, "libdeflate_free_decompressor");
             l.gzip_ex = (int (*)(void*, const void*, size_t, void*, size_t, size_t*, size_t*))dlsym(h, "libdeflate_gzip_decompress_ex");
             if (!l.alloc || !l.release || !l.gzip_ex) l.gzip_ex = nullptr;
+            l.calloc_ = (void* (*)(int))dlsym(h, "libdeflate_alloc_compressor");
+            l.cfree = (void (*)(void*))dlsym(h, "libdeflate_free_compressor");
+            l.gzip_bound = (size_t (*)(void*, size_t))dlsym(h, "libdeflate_gzip_compress_bound");
+            l.gzip_compress = (size_t (*)(void*, const void*, size_t, void*, size_t))dlsym(h, "libdeflate_gzip_compress");
+            if (!l.calloc_ || !l.cfree || !l.gzip_bound || !l.gzip_compress) l.gzip_compress = nullptr;
             return l;
         }();
         return L;
+    }
+    struct Comp { void* c = nullptr; ~Comp() { if (c) LibDeflate::get().cfree(c); } };
+    static void* compressor() {   // one per thread, level 6 (zlib's default, what gzopen("wb") writes with)
+        static thread_local Comp t;
+        if (!t.c && get().gzip_compress) t.c = get().calloc_(6);
+        return t.c;
     }
     struct Dec { void* d = nullptr; ~Dec() { if (d) LibDeflate::get().release(d); } };
     static void* decompressor() {   // one per thread
@@ -1521,7 +1537,25 @@ struct LabelWriters {  // the per-label writers of trim_matches (trim.rs:356-446
     }
     void write(LabelQ& L, const std::string& label, const uint8_t* p, size_t n) {
         const std::string path = folder + "/" + label + (gz ? ".trimmed.fastq.gz" : ".trimmed.fastq");
-        if (gz) {
+        if (gz && LibDeflate::compressor()) {
+            // a span = one gzip member appended to the label's file (concatenated members are one gzip file): libdeflate compresses 2-3 x as fast
+            // as zlib at the same level, and the writer threads are what `kit --gzip` waits for
+            if (!L.plain) {
+                L.plain = fopen(path.c_str(), "wb");
+                if (!L.plain) throw BarbellError(BB_E_INVALID, "Failed to create output file '" + path + "'\nTry setting ulimit higher: \"ulimit -n 65000\"");
+                setvbuf(L.plain, nullptr, _IONBF, 0);
+            }
+            static thread_local RawBuf zb;
+            void* c = LibDeflate::compressor();
+            size_t o = 0;
+            do {   // (an empty span still leaves a member: the file is a gzip file from its first write on, as with gzopen)
+                const size_t chunk = std::min<size_t>(n - o, 256u << 20);
+                zb.reserve(LibDeflate::get().gzip_bound(c, chunk) + 64);
+                const size_t z = LibDeflate::get().gzip_compress(c, p + o, chunk, zb.data(), zb.cap);
+                if (!z || fwrite(zb.data(), 1, z, L.plain) != z) throw BarbellError(BB_E_INVALID, "Failed to write sequence to '" + path + "'");
+                o += chunk;
+            } while (o < n);
+        } else if (gz) {
             if (!L.gzf) {
                 L.gzf = gzopen(path.c_str(), "wb");
                 if (!L.gzf) throw BarbellError(BB_E_INVALID, "Failed to create output file '" + path + "'\nTry setting ulimit higher: \"ulimit -n 65000\"");

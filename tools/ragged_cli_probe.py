@@ -62,4 +62,12 @@ if __name__ == "__main__":
             if "profile: pipeline" in l:
                 print("   ", l[:260])
         shutil.rmtree(outd, ignore_errors=True)
+        if "--gzip-out" in sys.argv:   # the per-label files gzip-compressed: libdeflate members against zlib's gzwrite
+            for lib, e2 in (("libdeflate", {}), ("zlib", {"BARBELL_AMD_NO_LIBDEFLATE": "1"})):
+                t0 = time.time()
+                r = subprocess.run([CLI, "kit", "-k", "SQK-NBD114-96", "-i", fq, "-o", outd, "--maximize", "--flank-max-errors", "3", "--gzip"],
+                                   capture_output=True, text=True, env=dict(os.environ, BARBELL_AMD_PROFILE="1", BARBELL_AMD_NO_TORCH="1", **e2))
+                sz = sum(os.path.getsize(os.path.join(outd, x)) for x in os.listdir(outd)) if os.path.isdir(outd) else 0
+                print(name, "kit --gzip", lib, "rc", r.returncode, "wall %.2f s" % (time.time() - t0), "output bytes", sz, flush=True)
+                shutil.rmtree(outd, ignore_errors=True)
         os.remove(fq)
