@@ -354,6 +354,13 @@ def test_cli_kit_matches_python_kit_driver(tmp_path, gz, render):
             a, b = gzmod.decompress(a), gzmod.decompress(b)
         assert a == b, x
     assert (tmp_path / "failed_cli.txt").read_bytes() == (tmp_path / "failed_py.txt").read_bytes()
+    if gz:   # the .gz files are written by libdeflate (one member per span) where the system has it: zlib's gzwrite holds the same records
+        oz = tmp_path / "cli_zlib"
+        r2 = subprocess.run([CLI, "kit", "-k", kit, "-i", str(fq), "-o", str(oz)] + flags, capture_output=True, text=True, env=dict(env, BARBELL_AMD_NO_LIBDEFLATE="1"))
+        assert r2.returncode == 0, r2.stderr
+        for x in names:
+            if x.endswith(".gz"):
+                assert gzmod.decompress((oz / x).read_bytes()) == gzmod.decompress((oc / x).read_bytes()), x
     # the summary lines printed by the CLI are the inspector's
     want = insp.summary(10)
     got = [l for l in r.stdout.splitlines() if l.startswith(("Found", "\tPattern", "\t\t", "Showed"))]
