@@ -34,7 +34,10 @@ def effective_cpus():
 
 
 def shard_range(rank, world, reads_per_rank):
-    """(first_read, n_reads) of rank's contiguous shard of the synthetic/real read stream."""
+    """(first_read, n_reads) of rank's contiguous shard of the synthetic/real read stream (weak scaling: every rank of the
+    `world` holds `reads_per_rank` reads; a rank outside the world is a launch error, not an empty shard)."""
+    if not 0 <= rank < max(1, world):
+        raise ValueError(f"shard_range: rank {rank} outside a world of {world}")
     return rank * reads_per_rank, reads_per_rank
 
 
