@@ -1,0 +1,394 @@
+"""The reference's stand-alone steps on FILES: `barbell filter`, `barbell inspect`, `barbell trim` take an annotation.tsv (and the
+FASTQ) written earlier — by the reference or by this package — instead of rows that are still in HBM.
+
+The fused path (annotate.annotate with filter / trim / inspector, `barbell-amd kit`) stays the fast one: every batch goes to
+the GPU once.  These entry points exist so that the reference's documented four-command workflow (README: annotate -> inspect
+-> filter -> trim, with files in between; bin/main.rs:274-470) keeps working on the same files: the TSV is parsed back into
+the C-ABI's `bb_row`s (searcher.rs:31-142 is the schema), the same HIP kernels decide (k_filter, k_inspect, k_trim_plan /
+k_trim_render through bb_filter_rows, bb_inspect_rows, bb_trim_batch) and the same writers write.
+
+Labels: a row's `label` column is mapped to a (group, barcode) slot.  With the run's query groups at hand (`groups=`: the kit or
+the FASTA files of the annotate run) the slots are the run's own; without them (the reference's filter / trim / inspect need
+no queries either) `LabelSpace.from_labels` builds stand-in groups that only carry the file's label strings — the kernels of
+these steps read a row's slot and its label id, never the query sequences."""
+import csv
+import io
+import os
+
+import numpy as np
+
+from . import _abi
+from .annotate import TSV_HEADER, Demuxer, _csv_field, read_fastq_records, split_fastq_header
+from .filter import MAX_CUTS, VERDICT_DTYPE, Filter, format_cuts, patterns_from_files
+from .inspect_rows import Inspector
+from .kits import QueryGroup
+from .trim import LabelWriters, TrimConfig, Trimmer
+
+COLUMNS = TSV_HEADER.split("\t")
+_TAG_OF = {"Ftag": _abi.BB_FTAG, "Rtag": _abi.BB_RTAG, "Fflank": _abi.BB_FTAG, "Rflank": _abi.BB_RTAG}
+_MT = {s: i for i, s in enumerate(_abi.MATCH_TYPE_STR)}
+_STRAND = {s: i for i, s in enumerate(_abi.STRAND_STR)}
+GROUP_MAX_LABELS = 1022   # 1024 sequences per group (include/barbell_amd.h) minus the two stand-ins that pin the barcode region
+_DUMMY = ("\x00barbell-amd stand-in A", "\x00barbell-amd stand-in T")
+
+
+class TsvError(ValueError):
+    pass
+
+
+# ---- the `cuts` column (searcher.rs:91-140, pattern.rs:40-95) -----------------------------------------------------------
+def parse_cuts(s):
+    """"After(0):1,Before(2):1" -> ([(direction 1 = After, group_id), ...], position).  The position is the row's index among
+    its read's rows (filter.rs:183-214 writes the element index); the verdict record holds one per row."""
+    if not s:
+        return [], None
+    cuts, pos = [], None
+    for part in s.split(","):
+        cut, sep, p = part.partition(":")
+        if not sep:
+            raise TsvError("Invalid cut format: missing position part")
+        if cut.startswith("Before(") and cut.endswith(")"):
+            d, gid = 0, cut[7:-1]
+        elif cut.startswith("After(") and cut.endswith(")"):
+            d, gid = 1, cut[6:-1]
+        else:
+            raise TsvError(f"Invalid cut string: {cut}")
+        if not gid.isdigit() or not p.isdigit():
+            raise TsvError(f"Invalid cut string: {part}")
+        if pos is not None and int(p) != pos:
+            raise TsvError(f"cuts of one row with different positions ({s}): not what the filter step writes")
+        pos = int(p)
+        cuts.append((d, int(gid)))
+    if len(cuts) > MAX_CUTS:
+        raise TsvError(f"more than {MAX_CUTS} cuts on one row (kernel limit, include/barbell_amd_filter.h)")
+    return cuts, pos
+
+
+# ---- labels <-> slots ----------------------------------------------------------------------------------------------------
+def _standin_seq(i):
+    """A 46-nt sequence of SQK-NBD114-96's shape (14 / 24 / 8) whose 24-nt barcode encodes i: never searched, only there so
+    that bb_create has a well-formed group to hang the labels on."""
+    digits = "".join("ACGT"[(i >> (2 * j)) & 3] for j in range(22))
+    return b"AAGGTTAACACAAA" + ("G" + digits + "C").encode() + b"CAGCACCT"
+
+
+class LabelSpace:
+    """(tag kind, label) -> (group_idx, barcode_idx) and back, over real query groups or stand-in ones"""
+
+    def __init__(self, groups, standin=False):
+        self.groups, self.standin = list(groups), standin
+        self.slot, self.flank_group = {}, {}
+        for gi, g in enumerate(self.groups):
+            kind = _abi.BB_RTAG if g.match_type == _abi.BB_RTAG else _abi.BB_FTAG
+            self.flank_group.setdefault(kind, gi)
+            for bi, lab in enumerate(g.labels):
+                self.slot.setdefault((kind, lab), (gi, bi))
+
+    @staticmethod
+    def from_labels(pairs):
+        """pairs: iterable of (match_type string, label) as they stand in the file"""
+        by_kind = {_abi.BB_FTAG: [], _abi.BB_RTAG: []}
+        seen = set()
+        for mt, lab in pairs:
+            kind = _TAG_OF[mt]
+            if mt in ("Fflank", "Rflank"):
+                seen.add((kind, None))
+            elif (kind, lab) not in seen:
+                seen.add((kind, lab))
+                by_kind[kind].append(lab)
+        groups = []
+        for kind in (_abi.BB_FTAG, _abi.BB_RTAG):
+            labs = by_kind[kind]
+            if not labs and (kind, None) not in seen:
+                continue
+            for a in range(0, max(1, len(labs)), GROUP_MAX_LABELS):
+                part = labs[a:a + GROUP_MAX_LABELS]
+                seqs = [_standin_seq(i) for i in range(len(part))] + [b"AAGGTTAACACAAA" + b"A" * 24 + b"CAGCACCT", b"AAGGTTAACACAAA" + b"T" * 24 + b"CAGCACCT"]
+                groups.append(QueryGroup(seqs, part + list(_DUMMY), kind, flank_k=0))
+        if len(groups) > 32:
+            raise TsvError(f"{sum(len(v) for v in by_kind.values())} distinct labels need {len(groups)} stand-in groups; a context holds 32 "
+                           "(include/barbell_amd.h) — pass the run's query groups instead")
+        return LabelSpace(groups, standin=True)
+
+    def lookup(self, match_type, label):
+        kind = _TAG_OF[match_type]
+        if match_type in ("Fflank", "Rflank"):
+            gi = self.flank_group.get(kind)
+            if gi is None:
+                raise TsvError(f"a {match_type} row, but no query group of that tag type")
+            return gi, -1
+        s = self.slot.get((kind, label))
+        if s is None:
+            raise TsvError(f"label {label!r} ({match_type}) is not among the query groups' labels")
+        return s
+
+
+# ---- annotation.tsv -> rows -----------------------------------------------------------------------------------------------
+class TsvBatch:
+    """rows of some consecutive reads of the file: `rows` (ROW_DTYPE, read_idx = index into read_ids), `verdicts` from the
+    cuts column (pass = 1: a filtered file holds passing reads only), the raw fields for writing a row back out unchanged"""
+
+    def __init__(self, rows, verdicts, read_ids, has_cuts):
+        self.rows, self.verdicts, self.read_ids, self.has_cuts = rows, verdicts, read_ids, has_cuts
+
+
+def _open_tsv(path):
+    f = open(path, newline="", encoding="utf-8")
+    rd = csv.reader(f, delimiter="\t", quotechar='"', doublequote=True, strict=True)
+    try:
+        header = next(rd)
+    except StopIteration:
+        f.close()
+        return None, None, None   # an empty file: the csv writer emits the header with the first record only
+    missing = [c for c in COLUMNS if c not in header]
+    if missing:
+        f.close()
+        raise TsvError(f"{path}: columns missing from the header: {missing}")
+    return f, rd, [header.index(c) for c in COLUMNS]
+
+
+def scan_labels(path):
+    """the distinct (match_type, label) pairs of a file, in order of first appearance"""
+    f, rd, col = _open_tsv(path)
+    if f is None:
+        return []
+    out, seen = [], set()
+    i_mt, i_lab = col[COLUMNS.index("match_type")], col[COLUMNS.index("label")]
+    with f:
+        for rec in rd:
+            k = (rec[i_mt], rec[i_lab])
+            if k not in seen:
+                if k[0] not in _MT:
+                    raise TsvError(f"{path}: match_type {k[0]!r}")
+                seen.add(k)
+                out.append(k)
+    return out
+
+
+_INT_FIELDS = ("read_len", "rel_dist_to_end", "read_start_bar", "read_end_bar", "read_start_flank", "read_end_flank", "bar_start", "bar_end",
+               "flank_cost", "barcode_cost")
+
+
+def read_annotation_tsv(path, space, batch_rows=1 << 18, group_consecutive=True):
+    """Yields TsvBatch objects.  Rows of one read (consecutive lines with the same read_id: filter.rs:52-85) are never split
+    over two batches.  With group_consecutive=False every distinct read_id of the whole file is one read however its lines lie
+    (trim.rs:337-358 collects them in a map) — the caller then gets ONE batch."""
+    f, rd, col = _open_tsv(path)
+    if f is None:
+        return
+    c = {name: col[i] for i, name in enumerate(COLUMNS)}
+    pend, ids, id_of = [], [], {}
+
+    def flush():
+        n = len(pend)
+        rows = np.zeros(n, dtype=_abi.ROW_DTYPE)
+        ver = np.zeros(n, dtype=VERDICT_DTYPE)
+        has_cuts = False
+        try:
+            for name in _INT_FIELDS:
+                rows[name] = np.array([int(r[1][c[name]]) for r in pend], dtype=np.int64).astype(rows.dtype[name])
+        except ValueError as e:
+            raise TsvError(f"{path}: {e}") from None
+        for i, (ridx, rec) in enumerate(pend):
+            mt = rec[c["match_type"]]
+            if mt not in _MT or rec[c["strand"]] not in _STRAND:
+                raise TsvError(f"{path}: match_type {mt!r} / strand {rec[c['strand']]!r}")
+            gi, bi = space.lookup(mt, rec[c["label"]])
+            r = rows[i]
+            r["read_idx"], r["group_idx"], r["barcode_idx"], r["match_type"], r["strand"] = ridx, gi, bi, _MT[mt], _STRAND[rec[c["strand"]]]
+            cuts, pos = parse_cuts(rec[c["cuts"]])
+            v = ver[i]
+            v["pass"] = 1
+            if cuts:
+                has_cuts = True
+                v["n_cuts"], v["match_idx"] = len(cuts), pos
+                for q, (d, gid) in enumerate(cuts):
+                    if gid > 0xFFFF:
+                        raise TsvError("cut group id above 65535 (kernel limit, include/barbell_amd_filter.h)")
+                    v["cuts"][q]["direction"], v["cuts"][q]["group_id"] = d, gid
+        if not group_consecutive:   # rows of a read together, reads in order of first appearance, a read's rows in file order
+            order = np.argsort(rows["read_idx"], kind="stable")
+            rows, ver = rows[order], ver[order]
+        # the position of a row without cuts: its index among its read's rows (what k_filter writes for every row)
+        first = np.r_[True, rows["read_idx"][1:] != rows["read_idx"][:-1]] if n else np.zeros(0, dtype=bool)
+        start = np.maximum.accumulate(np.where(first, np.arange(n), 0)) if n else np.zeros(0, dtype=np.int64)
+        idx_in_read = (np.arange(n) - start).astype(np.uint16)
+        nocut = ver["n_cuts"] == 0
+        ver["match_idx"][nocut] = idx_in_read[nocut]
+        return TsvBatch(rows, ver, list(ids), has_cuts)
+
+    with f:
+        cur = None
+        for rec in rd:
+            rid = rec[c["read_id"]]
+            if group_consecutive:
+                if rid != cur:
+                    if len(pend) >= batch_rows:
+                        yield flush()
+                        pend, ids = [], []
+                    cur = rid
+                    ids.append(rid)
+                pend.append((len(ids) - 1, rec))
+            else:
+                k = id_of.get(rid)
+                if k is None:
+                    k = id_of[rid] = len(ids)
+                    ids.append(rid)
+                pend.append((k, rec))
+        if pend:
+            yield flush()
+
+
+def _context(space, device, patterns=()):
+    """a library context that carries the label space (and a filter: the trim step takes its label ids from it)"""
+    dm = Demuxer(device=device)
+    for g in space.groups:
+        dm.add_query_group(g)
+    return dm, Filter(dm, list(patterns))
+
+
+def _space_for(path, groups):
+    return LabelSpace(groups) if groups is not None else LabelSpace.from_labels(scan_labels(path))
+
+
+def _format(rows, read_ids, space, verdicts):
+    """annotate.format_rows, with the file's own label strings"""
+    out = []
+    for i, r in enumerate(rows):
+        g = space.groups[int(r["group_idx"])]
+        label = "flank" if r["barcode_idx"] < 0 else g.labels[int(r["barcode_idx"])]
+        out.append("\t".join((
+            _csv_field(read_ids[int(r["read_idx"])]), str(int(r["read_len"])), str(int(r["rel_dist_to_end"])),
+            str(int(r["read_start_bar"])), str(int(r["read_end_bar"])), str(int(r["read_start_flank"])), str(int(r["read_end_flank"])),
+            str(int(r["bar_start"])), str(int(r["bar_end"])), _abi.MATCH_TYPE_STR[int(r["match_type"])], str(int(r["flank_cost"])),
+            str(int(r["barcode_cost"])), _csv_field(label), _abi.STRAND_STR[int(r["strand"])], format_cuts(verdicts[i]))))
+    return out
+
+
+# ---- barbell filter (filter.rs:10-119) -----------------------------------------------------------------------------------
+def filter_file(annotated_file, output_file, patterns, dropped_out_file=None, groups=None, device=0, batch_rows=1 << 18, log=print):
+    """Reads of annotation.tsv (consecutive lines of one read_id) against the patterns on the GPU (k_filter); passing reads' rows
+    go to `output_file` with their cuts, the others to `dropped_out_file`.  Returns (reads, kept, dropped)."""
+    space = _space_for(annotated_file, groups)
+    outs = {True: open(output_file, "w", encoding="utf-8", newline=""),
+            False: open(dropped_out_file, "w", encoding="utf-8", newline="") if dropped_out_file else None}
+    wrote = {True: False, False: False}
+    total = kept = 0
+    try:
+        if space.groups:
+            dm, flt = _context(space, device, patterns)
+            for b in read_annotation_tsv(annotated_file, space, batch_rows):
+                ver = flt.verdicts(b.rows)
+                lines = _format(b.rows, b.read_ids, space, ver)
+                first = np.r_[True, b.rows["read_idx"][1:] != b.rows["read_idx"][:-1]]
+                total += int(first.sum())
+                kept += int((first & (ver["pass"] != 0)).sum())
+                for ok in (True, False):
+                    f = outs[ok]
+                    sel = [l for l, p in zip(lines, ver["pass"]) if bool(p) == ok]
+                    if f is None or not sel:
+                        continue
+                    if not wrote[ok]:   # the csv writer emits the header with the first record only
+                        f.write(TSV_HEADER + "\n")
+                        wrote[ok] = True
+                    f.write("\n".join(sel) + "\n")
+            dm.close()
+    finally:
+        for f in outs.values():
+            if f is not None:
+                f.close()
+    log(f"filter: {total} reads, {kept} kept, {total - kept} dropped")
+    return total, kept, total - kept
+
+
+# ---- barbell inspect (inspect.rs:119-208) --------------------------------------------------------------------------------
+def inspect_file(annotated_file, top_n=10, read_pattern_out=None, bucket_size=250, groups=None, device=0, batch_rows=1 << 18, log=print):
+    """-> the Inspector (counts, summary lines already logged)"""
+    space = _space_for(annotated_file, groups)
+    if not space.groups:
+        insp = Inspector(None, read_pattern_out, bucket_size)
+    else:
+        dm, _ = _context(space, device)
+        insp = Inspector(dm, read_pattern_out, bucket_size)
+        for b in read_annotation_tsv(annotated_file, space, batch_rows):
+            insp.add(b.rows, b.read_ids, b.verdicts if b.has_cuts else None)
+        dm.close()
+    insp.close()
+    for line in insp.summary(top_n):
+        log(line)
+    return insp
+
+
+# ---- barbell trim (trim.rs:317-480) ---------------------------------------------------------------------------------------
+def trim_file(filtered_match_file, read_fastq_files, output_folder, config=None, groups=None, device=0, batch_reads=20000, log=print):
+    """Annotations by read id (the whole filtered file in memory, as the reference holds it), the FASTQ streamed; every batch of
+    annotated reads is cut and rendered on the GPU (bb_trim_batch) and appended to '{output_folder}/{label}.trimmed.fastq[.gz]'.
+    Returns (total reads, trimmed, failed, split)."""
+    cfg = config or TrimConfig()
+    if cfg.sort_labels and cfg.only_side is not None:
+        raise ValueError("Cannot enable only keeping left/right label and sorting; this is ambiguous")   # trim.rs:331-335
+    os.makedirs(output_folder, exist_ok=True)
+    space = _space_for(filtered_match_file, groups)
+    total = 0
+    if not space.groups:   # no annotations: every read is counted, none is written
+        for path in read_fastq_files:
+            total += sum(1 for _ in read_fastq_records(str(path)))
+        log(f"trim: {total} reads, 0 trimmed, 0 failed")
+        return total, 0, 0, 0
+    batches = list(read_annotation_tsv(filtered_match_file, space, group_consecutive=False))
+    anno = batches[0]
+    bounds = np.searchsorted(anno.rows["read_idx"], np.arange(len(anno.read_ids) + 1))
+    by_id = {rid: k for k, rid in enumerate(anno.read_ids)}
+    dm, _ = _context(space, device)
+    trimmer = Trimmer(dm, cfg)
+    writers = LabelWriters(output_folder, cfg, trimmer.tables)
+
+    pend = []   # (annotation index, header line, seq, qual)
+
+    def flush():
+        if not pend:
+            return
+        rows = np.concatenate([anno.rows[bounds[k]:bounds[k + 1]] for k, *_ in pend])
+        ver = np.concatenate([anno.verdicts[bounds[k]:bounds[k + 1]] for k, *_ in pend])
+        rows["read_idx"] = np.repeat(np.arange(len(pend), dtype=np.uint32), [bounds[k + 1] - bounds[k] for k, *_ in pend])
+        offsets = np.zeros(len(pend) + 1, dtype=np.uint64)
+        np.cumsum([len(s) for _, _, s, _ in pend], out=offsets[1:])
+        bases = np.frombuffer(b"".join(s for _, _, s, _ in pend), dtype=np.uint8)
+        quals = np.frombuffer(b"".join(q for _, _, _, q in pend), dtype=np.uint8)
+        res = trimmer.trim_batch(rows, ver, bases, quals, offsets, [h for _, h, _, _ in pend])
+        writers.write(res, [anno.read_ids[k] for k, *_ in pend])
+        pend.clear()
+
+    try:
+        for path in read_fastq_files:
+            for h, s, q in read_fastq_records(str(path)):
+                total += 1
+                rid = split_fastq_header(h.decode("utf-8"))[0]
+                k = by_id.get(rid)
+                if k is None:
+                    continue
+                if len(q) != len(s):
+                    raise ValueError(f"FASTQ record '{rid}' has no quality scores" if not q else f"FASTQ record '{rid}': {len(s)} bases, {len(q)} qualities")
+                pend.append((k, h, s, q))
+                if len(pend) >= batch_reads:
+                    flush()
+        flush()
+    finally:
+        writers.close()
+        dm.close()
+    log(f"trim: {total} reads, {writers.n_trimmed} trimmed, {writers.n_failed} failed, {writers.n_split} split")
+    return total, writers.n_trimmed, writers.n_failed, writers.n_split
+
+
+def rows_to_tsv_text(rows, read_ids, space, verdicts=None):
+    """header + lines, for tests and tools"""
+    v = verdicts if verdicts is not None else np.zeros(len(rows), dtype=VERDICT_DTYPE)
+    buf = io.StringIO()
+    buf.write(TSV_HEADER + "\n")
+    for line in _format(rows, read_ids, space, v):
+        buf.write(line + "\n")
+    return buf.getvalue()
+
+
+__all__ = ["LabelSpace", "TsvError", "filter_file", "inspect_file", "trim_file", "read_annotation_tsv", "scan_labels", "parse_cuts",
+           "patterns_from_files", "rows_to_tsv_text"]

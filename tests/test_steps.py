@@ -1,0 +1,241 @@
+"""The reference's stand-alone steps on files (barbell_amd/steps.py, `python -m barbell_amd filter|inspect|trim`): bin/main.rs:340-420,
+filter.rs:10-119, inspect.rs:119-208, trim.rs:317-480.  CPU: the TSV comes back as the rows it was written from, the stand-in label
+groups are well-formed, the command line takes the reference's flags.  GPU: the steps run one by one on the files of a fused run give
+the fused run's files, byte for byte."""
+import os
+
+import numpy as np
+import pytest
+
+from barbell_amd import _abi, kits
+from barbell_amd import annotate as A
+from barbell_amd import filter as F
+
+KIT = "SQK-NBD114-96"
+
+
+def _oracle_rows(groups, n=300, seed=5):
+    """rows of noisy reads (tag rows and flank-only rows) from the CPU checker"""
+    from barbell_amd.parallel import effective_cpus
+    from oracle import pyoracle
+    from tests.common import noisy_reads
+
+    _, bases, offsets = noisy_reads("nbd96", seed, n, 300, 1500, rate=0.10)
+    rows = pyoracle.Oracle([g.as_tuple() for g in groups]).annotate(bases, offsets, n_threads=effective_cpus(), fast=True)
+    return bases, offsets, rows
+
+
+def test_cuts_column_round_trip():
+    from barbell_amd import steps
+
+    v = np.zeros(1, dtype=F.VERDICT_DTYPE)[0]
+    v["n_cuts"], v["match_idx"] = 2, 3
+    v["cuts"][0]["direction"], v["cuts"][0]["group_id"] = 1, 0
+    v["cuts"][1]["direction"], v["cuts"][1]["group_id"] = 0, 12
+    s = F.format_cuts(v)
+    assert s == "After(0):3,Before(12):3"
+    assert steps.parse_cuts(s) == ([(1, 0), (0, 12)], 3)
+    assert steps.parse_cuts("") == ([], None)
+    for bad in ("After(0)", "Around(0):1", "After(x):1", "After(0):1,Before(0):2", "After(0):1,After(1):1,After(2):1,After(3):1"):
+        with pytest.raises(steps.TsvError):
+            steps.parse_cuts(bad)
+
+
+def test_tsv_comes_back_as_the_rows_it_was_written_from(tmp_path):
+    from barbell_amd import steps
+
+    groups = kits.groups_from_kit(KIT, flank_max_errors=3)
+    _, _, rows = _oracle_rows(groups)
+    assert len(rows) > 200 and (rows["barcode_idx"] < 0).any() and (rows["barcode_idx"] >= 0).any()
+    n_reads = int(rows["read_idx"].max()) + 1
+    ids = ["r%d" % i for i in range(n_reads)]
+    ids[int(rows["read_idx"][3])] = 'odd\t"id"'   # quoted by the csv writer (annotator.rs:246-251), unquoted by the reader
+    text = A.TSV_HEADER + "\n" + "\n".join(A.format_rows(rows, ids, groups)) + "\n"
+    p = tmp_path / "a.tsv"
+    p.write_text(text)
+    # (a) with the run's groups: the very rows (read_idx renumbered over the reads that have rows)
+    space = steps.LabelSpace(groups)
+    for batch_rows in (1 << 18, 7):
+        got, got_ids = [], []
+        for b in steps.read_annotation_tsv(str(p), space, batch_rows):
+            first = np.r_[True, b.rows["read_idx"][1:] != b.rows["read_idx"][:-1]]
+            assert first.sum() == len(b.read_ids)          # a read never straddles two batches
+            r = b.rows.copy()
+            r["read_idx"] += len(got_ids)
+            got.append(r)
+            got_ids += b.read_ids
+            assert not b.has_cuts and (b.verdicts["n_cuts"] == 0).all()
+        got = np.concatenate(got)
+        assert batch_rows > 7 or len(got_ids) > 20
+        want = rows.copy()
+        _, want["read_idx"] = np.unique(rows["read_idx"], return_inverse=True)
+        assert got.tobytes() == want.tobytes()
+        assert got_ids == [ids[i] for i in np.unique(rows["read_idx"])]
+    # (b) without them: stand-in groups that carry the file's labels; the text written back is the file
+    space2 = steps.LabelSpace.from_labels(steps.scan_labels(str(p)))
+    assert space2.standin and 1 <= len(space2.groups) <= 2
+    bs = list(steps.read_annotation_tsv(str(p), space2))
+    assert len(bs) == 1
+    assert steps.rows_to_tsv_text(bs[0].rows, bs[0].read_ids, space2) == text
+    # an unknown label under explicit groups is an error, not a silent slot
+    with pytest.raises(steps.TsvError):
+        list(steps.read_annotation_tsv(str(p), steps.LabelSpace(kits.groups_from_kit("SQK-RBK114-24"))))
+    # trim's view: one read per distinct id wherever its lines lie
+    lines = text.splitlines()
+    (tmp_path / "shuffled.tsv").write_text("\n".join([lines[0]] + lines[1:][::2] + lines[1:][1::2]) + "\n")
+    b = list(steps.read_annotation_tsv(str(tmp_path / "shuffled.tsv"), space, group_consecutive=False))[0]
+    assert len(b.read_ids) == len(np.unique(rows["read_idx"])) and (np.diff(b.rows["read_idx"].astype(np.int64)) >= 0).all()
+
+
+def test_stand_in_groups_are_well_formed_query_groups():
+    """bb_create must take them: the checker builds the same geometry from them (barcodes.rs:105-197) — 14 / 24 / 8 like SQK-NBD114-96"""
+    from barbell_amd import steps
+    from oracle import pyoracle
+
+    pairs = [("Ftag", "NB%02d" % i) for i in range(1, 30)] + [("Fflank", "flank"), ("Rflank", "flank"), ("Rtag", "x y"), ("Ftag", "NB01")]
+    space = steps.LabelSpace.from_labels(pairs)
+    assert [g.match_type for g in space.groups] == [_abi.BB_FTAG, _abi.BB_RTAG]
+    assert space.lookup("Ftag", "NB07") == (0, 6) and space.lookup("Rtag", "x y") == (1, 0)
+    assert space.lookup("Fflank", "flank") == (0, -1) and space.lookup("Rflank", "flank") == (1, -1)
+    orc = pyoracle.Oracle([g.as_tuple() for g in space.groups])
+    geo = orc.geometry() if hasattr(orc, "geometry") else None
+    if geo is not None:
+        assert all(int(g["bar_hi"]) - int(g["bar_lo"]) == 23 for g in geo)
+    for g in space.groups:
+        assert len(set(g.seqs)) == len(g.seqs) and len({len(s) for s in g.seqs}) == 1
+    many = steps.LabelSpace.from_labels(("Ftag", "L%d" % i) for i in range(2500))
+    assert len(many.groups) == 3 and many.lookup("Ftag", "L2499") == (2, 2499 - 2 * steps.GROUP_MAX_LABELS)
+    assert steps.LabelSpace.from_labels([]).groups == []
+
+
+def test_command_line_takes_the_reference_flags():
+    from barbell_amd.__main__ import parser
+
+    ap = parser()
+    a = ap.parse_args("filter -i a.tsv -o f.tsv -f p1.txt p2.txt --dropped d.tsv --verbose".split())
+    assert (a.command, a.file, a.dropped) == ("filter", ["p1.txt", "p2.txt"], "d.tsv")
+    a = ap.parse_args("trim -i f.tsv -r a.fastq b.fastq -o out --no-label --no-orientation --no-flanks --only-side left --failed-out x --skip-trim --flip --gzip".split())
+    assert a.reads == ["a.fastq", "b.fastq"] and a.only_side == "left" and a.skip_trim and a.flip and a.gzip and not a.sort_labels
+    a = ap.parse_args("inspect -i a.tsv".split())
+    assert (a.top_n, a.bucket_size, a.read_pattern_out) == (10, 250, None)
+    a = ap.parse_args("annotate -i r.fastq --kit SQK-RBK114-24".split())
+    assert (a.output, a.threads, a.min_score, a.min_score_diff, a.alpha, a.barcode_types) == ("output.tsv", 10, 0.2, 0.1, 0.4, ["Ftag"])
+    a = ap.parse_args("kit -k SQK-NBD114-96 -i r.fastq -o out --maximize".split())
+    assert a.maximize and a.failed_out is None
+    with pytest.raises(SystemExit):
+        ap.parse_args("trim -i f.tsv -o out".split())   # -r is required (bin/main.rs:143)
+
+
+def test_empty_annotation_files_need_no_device(tmp_path):
+    """the csv writer emits the header with the first record only: a run without rows leaves an EMPTY file, and the steps take it"""
+    from barbell_amd import steps
+
+    (tmp_path / "a.tsv").write_bytes(b"")
+    logs = []
+    assert steps.filter_file(str(tmp_path / "a.tsv"), str(tmp_path / "f.tsv"), [F.pattern_from_str("Ftag[fw, *, @left(0..250), >>]")],
+                             str(tmp_path / "d.tsv"), log=logs.append) == (0, 0, 0)
+    assert (tmp_path / "f.tsv").read_bytes() == b"" and (tmp_path / "d.tsv").read_bytes() == b""
+    insp = steps.inspect_file(str(tmp_path / "a.tsv"), log=logs.append)
+    assert insp.summary(10)[0] == "Found 0 unique patterns"
+    (tmp_path / "r.fastq").write_bytes(b"@a\nACGT\n+\nIIII\n@b x\nAC\n+\nII\n")
+    assert steps.trim_file(str(tmp_path / "f.tsv"), [str(tmp_path / "r.fastq")], str(tmp_path / "t"), log=logs.append) == (2, 0, 0, 0)
+    assert list((tmp_path / "t").iterdir()) == []
+    (tmp_path / "bad.tsv").write_text("read_id\tread_len\n")
+    with pytest.raises(steps.TsvError):
+        steps.scan_labels(str(tmp_path / "bad.tsv"))
+
+
+def _write_fastq(path, groups, n, seed):
+    bases, offsets = A.synth_reads_host(groups, seed, 300, 2500, 0, n)
+    with open(path, "wb") as f:
+        for i in range(n):
+            s = bases[int(offsets[i]):int(offsets[i + 1])].tobytes()
+            f.write(b"@q%d ch=%d\n" % (i, i % 7) + s + b"\n+\n" + bytes(33 + (j * 7 + i) % 40 for j in range(len(s))) + b"\n")
+
+
+def _dir_bytes(d, suffix):
+    return {p.name: p.read_bytes() for p in d.iterdir() if p.name.endswith(suffix)}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("with_groups", [False, True])
+def test_steps_on_files_give_the_fused_runs_files(tmp_path, with_groups):
+    from barbell_amd import steps, trim as T
+    from barbell_amd.inspect_rows import Inspector
+
+    groups = kits.groups_from_kit(KIT)
+    fq = tmp_path / "r.fastq"
+    _write_fastq(fq, groups, 1500, 11)
+    pats = F.kit_patterns(KIT, True)
+    fused = tmp_path / "fused"
+    fused.mkdir()
+    holder = {}
+
+    def make_inspector(dm):
+        holder["i"] = Inspector(dm, str(fused / "pattern_per_read.tsv"), 250)
+        return holder["i"]
+
+    cfg = T.TrimConfig.for_kit(str(fused / "failed.txt"))
+    total, found = A.annotate([str(fq)], str(fused / "annotation.tsv"), kits.groups_from_kit(KIT), batch_reads=400, filter_patterns=pats,
+                              filtered_file=str(fused / "filtered.tsv"), dropped_file=str(fused / "dropped.tsv"), trim_folder=str(fused),
+                              trim_config=cfg, inspector=make_inspector)
+    holder["i"].close()
+    assert total == 1500 and found > 900
+    g = kits.groups_from_kit(KIT) if with_groups else None
+    alone = tmp_path / "alone"
+    alone.mkdir()
+    logs = []
+    # filter: small batches, so that reads sit at batch borders
+    t, kept, dropped = steps.filter_file(str(fused / "annotation.tsv"), str(alone / "filtered.tsv"), pats, str(alone / "dropped.tsv"), groups=g,
+                                         batch_rows=333, log=logs.append)
+    assert t == found and kept > 500 and dropped > 20
+    assert (alone / "filtered.tsv").read_bytes() == (fused / "filtered.tsv").read_bytes()
+    assert (alone / "dropped.tsv").read_bytes() == (fused / "dropped.tsv").read_bytes()
+    # inspect
+    insp = steps.inspect_file(str(fused / "annotation.tsv"), 10, str(alone / "pattern_per_read.tsv"), 250, groups=g, batch_rows=500, log=logs.append)
+    assert (alone / "pattern_per_read.tsv").read_bytes() == (fused / "pattern_per_read.tsv").read_bytes()
+    assert insp.summary(10) == holder["i"].summary(10)
+    # trim, from the filtered file the stand-alone filter wrote
+    cfg2 = T.TrimConfig.for_kit(str(alone / "failed.txt"))
+    tt, n_trim, n_fail, _ = steps.trim_file(str(alone / "filtered.tsv"), [str(fq)], str(alone), cfg2, groups=g, batch_reads=257, log=logs.append)
+    assert tt == 1500 and n_trim + n_fail == kept
+    a, b = _dir_bytes(alone, ".trimmed.fastq"), _dir_bytes(fused, ".trimmed.fastq")
+    assert len(b) > 20 and a.keys() == b.keys()
+    for k in b:
+        assert a[k] == b[k], k
+    assert (alone / "failed.txt").read_bytes() == (fused / "failed.txt").read_bytes()
+    assert any(l.startswith("filter:") for l in logs) and any(l.startswith("trim:") for l in logs)
+
+
+@pytest.mark.gpu
+def test_command_line_steps_with_other_label_flags(tmp_path):
+    """the four commands one after the other through `python -m barbell_amd`'s main(), custom patterns from a file, label flags other than
+    the kit preset's; checked against the in-HBM pipeline with the same configuration"""
+    from barbell_amd import trim as T
+    from barbell_amd.__main__ import main
+
+    groups = kits.groups_from_kit("SQK-RBK114-24")
+    fq = tmp_path / "r.fastq"
+    _write_fastq(fq, groups, 600, 23)
+    pat_file = tmp_path / "pats.txt"
+    pat_file.write_text("Ftag[fw, *, @left(0..250), >>]\nFtag[fw, *, @left(0..250), >>]__Ftag[<<, rc, *, @right(0..250)]\n")
+    out = tmp_path / "cli"
+    out.mkdir()
+    assert main(["annotate", "-i", str(fq), "-o", str(out / "a.tsv"), "--kit", "SQK-RBK114-24"]) == 0
+    assert main(["filter", "-i", str(out / "a.tsv"), "-o", str(out / "f.tsv"), "-f", str(pat_file), "--dropped", str(out / "d.tsv")]) == 0
+    assert main(["inspect", "-i", str(out / "f.tsv"), "-n", "5", "-o", str(out / "ppr.tsv")]) == 0
+    assert main(["trim", "-i", str(out / "f.tsv"), "-r", str(fq), "-o", str(out / "t"), "--sort-labels", "--no-flanks", "--gzip"]) == 0
+    ref = tmp_path / "ref"
+    ref.mkdir()
+    cfg = T.TrimConfig(True, True, False, True, None, None, True, False, False, False, True)
+    A.annotate([str(fq)], str(ref / "a.tsv"), kits.groups_from_kit("SQK-RBK114-24"), filter_patterns=F.patterns_from_files([str(pat_file)]),
+               filtered_file=str(ref / "f.tsv"), dropped_file=str(ref / "d.tsv"), trim_folder=str(ref / "t"), trim_config=cfg)
+    for name in ("a.tsv", "f.tsv", "d.tsv"):
+        assert (out / name).read_bytes() == (ref / name).read_bytes(), name
+    import gzip
+
+    a = {p.name: gzip.open(p).read() for p in (out / "t").iterdir()}
+    b = {p.name: gzip.open(p).read() for p in (ref / "t").iterdir()}
+    assert len(b) >= 10 and a == b
+    # the filtered file carries cuts: inspect shows the cut markers
+    assert ">>" in (out / "ppr.tsv").read_text()
