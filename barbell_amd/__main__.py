@@ -32,6 +32,10 @@ def _groups(a, required=False):
     if getattr(a, "kit", None):
         return kits.groups_from_kit(a.kit, getattr(a, "use_extended", False))
     if getattr(a, "queries", None):
+        # the reference's README writes `-q left.fasta,right.fasta -b Ftag,Rtag`, its clap definition takes the values space-separated
+        # (bin/main.rs:77-83): both spellings are taken here
+        a.queries = [x for v in a.queries for x in v.split(",") if x]
+        a.barcode_types = [x for v in a.barcode_types for x in v.split(",") if x]
         types = _barcode_types(a.barcode_types)
         if len(types) != len(a.queries):
             raise SystemExit("--barcode-types must match --queries in number and order")

@@ -239,3 +239,35 @@ def test_command_line_steps_with_other_label_flags(tmp_path):
     assert len(b) >= 10 and a == b
     # the filtered file carries cuts: inspect shows the cut markers
     assert ">>" in (out / "ppr.tsv").read_text()
+
+
+@pytest.mark.gpu
+def test_dual_end_experiment_as_the_reference_readme_runs_it(tmp_path):
+    """README "Custom experiment": annotate -q left.fasta,right.fasta -b Ftag,Rtag, then two filters on the same annotation file (exact label,
+    `~substring` label, Ftag + Rtag elements) and a trim per filtered file — against the one-pass pipeline run once per filter"""
+    from barbell_amd import trim as T
+    from barbell_amd.__main__ import main
+    from tests.common import EX, config_groups
+
+    fq = tmp_path / "r.fastq"
+    _write_fastq(fq, config_groups("dual"), 800, 31)
+    q = os.path.join(EX, "native_left.fasta") + "," + os.path.join(EX, "native_right.fasta")
+    out = tmp_path / "cli"
+    out.mkdir()
+    assert main(["annotate", "-i", str(fq), "-q", q, "-b", "Ftag,Rtag", "--flank-max-errors", "5", "-o", str(out / "anno.tsv")]) == 0
+    labels = sorted({l.split("\t")[12] for l in (out / "anno.tsv").read_text().splitlines()[1:]} - {"flank"})
+    assert len(labels) > 20
+    filters = {"g1": "Ftag[fw, *, @left(0..250), >>]__Rtag[<<, fw, *, @right(0..250)]\nFtag[fw, *, @left(0..250), >>]\n",
+               "g2": "Ftag[fw, ~%s, @left(0..250), >>]\nRtag[<<, fw, %s, @right(0..250)]\n" % (labels[0][-2:], labels[-1])}
+    for name, text in filters.items():
+        (tmp_path / (name + ".txt")).write_text(text)
+        assert main(["filter", "-i", str(out / "anno.tsv"), "-f", str(tmp_path / (name + ".txt")), "-o", str(out / (name + ".tsv"))]) == 0
+        assert main(["trim", "-i", str(out / (name + ".tsv")), "-r", str(fq), "-o", str(out / name), "--no-orientation"]) == 0
+        ref = tmp_path / ("ref_" + name)
+        ref.mkdir()
+        A.annotate([str(fq)], str(ref / "anno.tsv"), config_groups("dual"), filter_patterns=F.patterns_from_files([str(tmp_path / (name + ".txt"))]),
+                   filtered_file=str(ref / "f.tsv"), trim_folder=str(ref / "t"), trim_config=T.TrimConfig(True, False, True, False, None, None, True, False, False, False, False))
+        assert (out / "anno.tsv").read_bytes() == (ref / "anno.tsv").read_bytes()
+        assert (out / (name + ".tsv")).read_bytes() == (ref / "f.tsv").read_bytes() and len((ref / "f.tsv").read_bytes()) > 1000, name
+        a, b = _dir_bytes(out / name, ".trimmed.fastq"), _dir_bytes(ref / "t", ".trimmed.fastq")
+        assert len(b) >= 1 and a == b, name
