@@ -128,115 +128,171 @@ class TsvBatch:
     """rows of some consecutive reads of the file: `rows` (ROW_DTYPE, read_idx = index into read_ids), `verdicts` from the
     cuts column (pass = 1: a filtered file holds passing reads only), the raw fields for writing a row back out unchanged"""
 
-    def __init__(self, rows, verdicts, read_ids, has_cuts):
-        self.rows, self.verdicts, self.read_ids, self.has_cuts = rows, verdicts, read_ids, has_cuts
+    def __init__(self, rows, verdicts, read_ids, has_cuts, fields=None, columns=None):
+        self.rows, self.verdicts, self.read_ids, self.has_cuts, self.fields, self.columns = rows, verdicts, read_ids, has_cuts, fields, columns
+
+    def lines(self, verdicts):
+        """the records as TSV lines in the schema's column order with the cuts of `verdicts` — the fields as they stand in the file (the
+        csv writer's own output is canonical: re-serialising it gives it back), a field that needs quoting quoted again"""
+        order = [self.columns[name] for name in COLUMNS[:-1]]
+        cut_rows = np.nonzero(verdicts["n_cuts"])[0]
+        cuts = dict(zip(cut_rows.tolist(), (format_cuts(verdicts[i]) for i in cut_rows)))
+        out = []
+        for i, rec in enumerate(self.fields):
+            f = [rec[j] for j in order]
+            if any(ch in f[0] for ch in '\t"\n\r') or any(ch in f[12] for ch in '\t"\n\r'):
+                f[0], f[12] = _csv_field(f[0]), _csv_field(f[12])
+            f.append(cuts.get(i, ""))
+            out.append("\t".join(f))
+        return out
 
 
-def _open_tsv(path):
+def _records(path):
+    """-> (column index of every schema field, iterator over the records' field lists).  Lines without a quote character are split at
+    the tabs (what the csv crate wrote for every ordinary read id); the others — a field holding a tab, a quote, CR or LF is quoted,
+    quotes doubled, annotator.rs:246-251 — go through the csv module, together with the lines a quoted line break continues on."""
     f = open(path, newline="", encoding="utf-8")
-    rd = csv.reader(f, delimiter="\t", quotechar='"', doublequote=True, strict=True)
-    try:
-        header = next(rd)
-    except StopIteration:
+    head = f.readline()
+    if not head:
         f.close()
-        return None, None, None   # an empty file: the csv writer emits the header with the first record only
+        return None, iter(())   # an empty file: the csv writer emits the header with the first record only
+    header = next(csv.reader([head], delimiter="\t"))
     missing = [c for c in COLUMNS if c not in header]
     if missing:
         f.close()
         raise TsvError(f"{path}: columns missing from the header: {missing}")
-    return f, rd, [header.index(c) for c in COLUMNS]
+    ncol = len(header)
+
+    def it():
+        with f:
+            for line in f:
+                if '"' not in line:
+                    rec = line.rstrip("\r\n").split("\t")
+                else:
+                    while line.count('"') % 2:   # a quoted field with a line break in it
+                        more = f.readline()
+                        if not more:
+                            raise TsvError(f"{path}: unterminated quoted field")
+                        line += more
+                    rec = next(csv.reader(io.StringIO(line, newline=""), delimiter="\t", quotechar='"', doublequote=True, strict=True))
+                if len(rec) != ncol:
+                    if rec in ([], [""]):
+                        continue
+                    raise TsvError(f"{path}: a record of {len(rec)} fields under a header of {ncol}")
+                yield rec
+
+    return [header.index(c) for c in COLUMNS], it()
 
 
 def scan_labels(path):
     """the distinct (match_type, label) pairs of a file, in order of first appearance"""
-    f, rd, col = _open_tsv(path)
-    if f is None:
+    col, recs = _records(path)
+    if col is None:
         return []
-    out, seen = [], set()
     i_mt, i_lab = col[COLUMNS.index("match_type")], col[COLUMNS.index("label")]
-    with f:
-        for rec in rd:
-            k = (rec[i_mt], rec[i_lab])
-            if k not in seen:
-                if k[0] not in _MT:
-                    raise TsvError(f"{path}: match_type {k[0]!r}")
-                seen.add(k)
-                out.append(k)
-    return out
+    seen = dict.fromkeys((rec[i_mt], rec[i_lab]) for rec in recs)
+    for mt, _ in seen:
+        if mt not in _MT:
+            raise TsvError(f"{path}: match_type {mt!r}")
+    return list(seen)
 
 
 _INT_FIELDS = ("read_len", "rel_dist_to_end", "read_start_bar", "read_end_bar", "read_start_flank", "read_end_flank", "bar_start", "bar_end",
                "flank_cost", "barcode_cost")
 
 
+def _ints(strings, what, path):
+    """decimal fields of many records in one C call"""
+    a = np.fromstring(" ".join(strings), dtype=np.int64, sep=" ") if strings else np.zeros(0, dtype=np.int64)
+    if len(a) != len(strings) or not all(s.lstrip("-").isdigit() for s in strings[:: max(1, len(strings) // 64)]):
+        bad = next((s for s in strings if not s.lstrip("-").isdigit()), "?")
+        raise TsvError(f"{path}: {what}: {bad!r} is not an integer")
+    return a
+
+
 def read_annotation_tsv(path, space, batch_rows=1 << 18, group_consecutive=True):
     """Yields TsvBatch objects.  Rows of one read (consecutive lines with the same read_id: filter.rs:52-85) are never split
     over two batches.  With group_consecutive=False every distinct read_id of the whole file is one read however its lines lie
     (trim.rs:337-358 collects them in a map) — the caller then gets ONE batch."""
-    f, rd, col = _open_tsv(path)
-    if f is None:
+    col, recs = _records(path)
+    if col is None:
         return
     c = {name: col[i] for i, name in enumerate(COLUMNS)}
-    pend, ids, id_of = [], [], {}
+    c_id, c_mt, c_lab, c_strand, c_cuts = c["read_id"], c["match_type"], c["label"], c["strand"], c["cuts"]
+    slot_cache = {}
 
-    def flush():
+    def slot_of(key):
+        s = slot_cache.get(key)
+        if s is None:
+            if key[0] not in _MT:
+                raise TsvError(f"{path}: match_type {key[0]!r}")
+            s = slot_cache[key] = space.lookup(*key) + (_MT[key[0]],)
+        return s
+
+    def build(pend, id_col, ridx, read_ids):
         n = len(pend)
         rows = np.zeros(n, dtype=_abi.ROW_DTYPE)
         ver = np.zeros(n, dtype=VERDICT_DTYPE)
-        has_cuts = False
+        for name in _INT_FIELDS:
+            ci = c[name]
+            v = _ints([r[ci] for r in pend], name, path)
+            info = np.iinfo(rows.dtype[name])
+            if len(v) and (v.min() < info.min or v.max() > info.max):
+                raise TsvError(f"{path}: {name} outside the range of the row record")
+            rows[name] = v
+        slots = np.array([slot_of((r[c_mt], r[c_lab])) for r in pend], dtype=np.int64).reshape(n, 3)
+        rows["group_idx"], rows["barcode_idx"], rows["match_type"] = slots[:, 0], slots[:, 1], slots[:, 2]
         try:
-            for name in _INT_FIELDS:
-                rows[name] = np.array([int(r[1][c[name]]) for r in pend], dtype=np.int64).astype(rows.dtype[name])
-        except ValueError as e:
-            raise TsvError(f"{path}: {e}") from None
-        for i, (ridx, rec) in enumerate(pend):
-            mt = rec[c["match_type"]]
-            if mt not in _MT or rec[c["strand"]] not in _STRAND:
-                raise TsvError(f"{path}: match_type {mt!r} / strand {rec[c['strand']]!r}")
-            gi, bi = space.lookup(mt, rec[c["label"]])
-            r = rows[i]
-            r["read_idx"], r["group_idx"], r["barcode_idx"], r["match_type"], r["strand"] = ridx, gi, bi, _MT[mt], _STRAND[rec[c["strand"]]]
-            cuts, pos = parse_cuts(rec[c["cuts"]])
+            rows["strand"] = [_STRAND[r[c_strand]] for r in pend]
+        except KeyError as e:
+            raise TsvError(f"{path}: Invalid strand: {e.args[0]}") from None
+        rows["read_idx"] = ridx
+        ver["pass"] = 1
+        with_cuts = [i for i, r in enumerate(pend) if r[c_cuts]]
+        for i in with_cuts:
+            cuts, pos = parse_cuts(pend[i][c_cuts])
             v = ver[i]
-            v["pass"] = 1
-            if cuts:
-                has_cuts = True
-                v["n_cuts"], v["match_idx"] = len(cuts), pos
-                for q, (d, gid) in enumerate(cuts):
-                    if gid > 0xFFFF:
-                        raise TsvError("cut group id above 65535 (kernel limit, include/barbell_amd_filter.h)")
-                    v["cuts"][q]["direction"], v["cuts"][q]["group_id"] = d, gid
+            v["n_cuts"], v["match_idx"] = len(cuts), pos
+            for q, (d, gid) in enumerate(cuts):
+                if gid > 0xFFFF:
+                    raise TsvError("cut group id above 65535 (kernel limit, include/barbell_amd_filter.h)")
+                v["cuts"][q]["direction"], v["cuts"][q]["group_id"] = d, gid
+        fields = pend
         if not group_consecutive:   # rows of a read together, reads in order of first appearance, a read's rows in file order
             order = np.argsort(rows["read_idx"], kind="stable")
             rows, ver = rows[order], ver[order]
+            fields = [pend[i] for i in order]
         # the position of a row without cuts: its index among its read's rows (what k_filter writes for every row)
-        first = np.r_[True, rows["read_idx"][1:] != rows["read_idx"][:-1]] if n else np.zeros(0, dtype=bool)
-        start = np.maximum.accumulate(np.where(first, np.arange(n), 0)) if n else np.zeros(0, dtype=np.int64)
-        idx_in_read = (np.arange(n) - start).astype(np.uint16)
-        nocut = ver["n_cuts"] == 0
-        ver["match_idx"][nocut] = idx_in_read[nocut]
-        return TsvBatch(rows, ver, list(ids), has_cuts)
+        if n:
+            first = np.r_[True, rows["read_idx"][1:] != rows["read_idx"][:-1]]
+            start = np.maximum.accumulate(np.where(first, np.arange(n), 0))
+            nocut = ver["n_cuts"] == 0
+            ver["match_idx"][nocut] = (np.arange(n) - start).astype(np.uint16)[nocut]
+        return TsvBatch(rows, ver, read_ids, bool(with_cuts), fields, c)
 
-    with f:
-        cur = None
-        for rec in rd:
-            rid = rec[c["read_id"]]
-            if group_consecutive:
-                if rid != cur:
-                    if len(pend) >= batch_rows:
-                        yield flush()
-                        pend, ids = [], []
-                    cur = rid
-                    ids.append(rid)
-                pend.append((len(ids) - 1, rec))
-            else:
-                k = id_of.get(rid)
-                if k is None:
-                    k = id_of[rid] = len(ids)
-                    ids.append(rid)
-                pend.append((k, rec))
+    if not group_consecutive:
+        pend = list(recs)
         if pend:
-            yield flush()
+            id_of = {}
+            ridx = np.array([id_of.setdefault(r[c_id], len(id_of)) for r in pend], dtype=np.uint32)
+            yield build(pend, None, ridx, list(id_of))
+        return
+    pend, last = [], None
+    for rec in recs:
+        if len(pend) >= batch_rows and rec[c_id] != last:
+            yield _consecutive(build, pend, c_id)
+            pend = []
+        pend.append(rec)
+        last = rec[c_id]
+    if pend:
+        yield _consecutive(build, pend, c_id)
+
+
+def _consecutive(build, pend, c_id):
+    ids = [r[c_id] for r in pend]
+    first = np.array([True] + [a != b for a, b in zip(ids[1:], ids[:-1])])
+    ridx = (np.cumsum(first) - 1).astype(np.uint32)
+    return build(pend, ids, ridx, [ids[i] for i in np.nonzero(first)[0]])
 
 
 def _context(space, device, patterns=()):
@@ -279,7 +335,7 @@ def filter_file(annotated_file, output_file, patterns, dropped_out_file=None, gr
             dm, flt = _context(space, device, patterns)
             for b in read_annotation_tsv(annotated_file, space, batch_rows):
                 ver = flt.verdicts(b.rows)
-                lines = _format(b.rows, b.read_ids, space, ver)
+                lines = b.lines(ver)
                 first = np.r_[True, b.rows["read_idx"][1:] != b.rows["read_idx"][:-1]]
                 total += int(first.sum())
                 kept += int((first & (ver["pass"] != 0)).sum())
