@@ -106,6 +106,11 @@ static void usage() {
         "       barbell-amd kit -k <KIT> -i <FASTQ>... -o <OUT_DIR> [--maximize] [--min-score F] [--min-score-diff F]\n"
         "                       [--flank-max-errors INT] [--failed-out FILE] [--use-extended] [--alpha F] [--gzip] [-t N=auto]\n"
         "                       [--device D=0] [--shard R/W [--shard-by files|bytes] [--rccl-id PATH]] [--gpu-render]\n"
+        "       barbell-amd filter -i <annotation.tsv> -o <filtered.tsv> -f <PATTERN_FILE>... [--dropped FILE] [--device D=0]\n"
+        "       barbell-amd inspect -i <annotation.tsv> [-n TOP=10] [-o pattern_per_read.tsv] [-s BUCKET=250] [--device D=0]\n"
+        "       barbell-amd trim -i <filtered.tsv> -r <FASTQ>... -o <OUT_DIR> [--no-label] [--no-orientation] [--no-flanks] [--sort-labels]\n"
+        "                        [--only-side left|right] [--failed-out FILE] [--skip-trim] [--flip] [--gzip] [--device D=0]\n"
+        "                        (the reference's stand-alone steps on files written earlier; annotate / kit do all of it in one pass)\n"
         "       barbell-amd kits          list the supported kit names\n"
         "       barbell-amd pattern <STR>...   parse filter pattern strings and print their elements\n",
         stderr);
@@ -144,6 +149,65 @@ int main(int argc, char** argv) {
             }
         } catch (const BarbellError& e) { fprintf(stderr, "error: %s\n", e.what()); return 1; }
         return 0;
+    }
+    if (cmd == "filter" || cmd == "inspect" || cmd == "trim") {   // the stand-alone steps on files (bb_steps.cpp); flags as bin/main.rs:114-206
+        std::string input, output, dropped, failed_out, read_pattern_out;
+        std::vector<std::string> files, reads;
+        std::vector<std::string>* multi = nullptr;
+        TrimConfig tcfg;
+        size_t top_n = 10;
+        uint32_t bucket = 250;
+        int device = 0;
+        for (int i = 2; i < argc; ++i) {
+            const std::string a = argv[i];
+            auto need = [&](const char* what) -> const char* { if (i + 1 >= argc) { fprintf(stderr, "error: %s needs a value\n", what); exit(2); } multi = nullptr; return argv[++i]; };
+            if (a == "-i" || a == "--input") input = need("--input");
+            else if (a == "-o" || a == "--output" || (cmd == "inspect" && a == "--read-pattern-out")) output = need("--output");
+            else if ((a == "-f" || a == "--file") && cmd == "filter") multi = &files;
+            else if ((a == "-r" || a == "--reads") && cmd == "trim") multi = &reads;
+            else if (a == "--dropped" && cmd == "filter") dropped = need("--dropped");
+            else if ((a == "-n" || a == "--top-n") && cmd == "inspect") top_n = (size_t)atol(need("--top-n"));
+            else if ((a == "-s" || a == "--bucket-size") && cmd == "inspect") bucket = (uint32_t)atol(need("--bucket-size"));
+            else if (a == "--device") device = atoi(need("--device"));
+            else if (a == "--verbose") { tcfg.verbose = true; multi = nullptr; }
+            else if (cmd == "trim" && a == "--no-label") { tcfg.add_labels = false; multi = nullptr; }
+            else if (cmd == "trim" && a == "--no-orientation") { tcfg.add_orientation = false; multi = nullptr; }
+            else if (cmd == "trim" && a == "--no-flanks") { tcfg.add_flank = false; multi = nullptr; }
+            else if (cmd == "trim" && a == "--sort-labels") { tcfg.sort_labels = true; multi = nullptr; }
+            else if (cmd == "trim" && a == "--skip-trim") { tcfg.skip_trim = true; multi = nullptr; }
+            else if (cmd == "trim" && a == "--flip") { tcfg.flip = true; multi = nullptr; }
+            else if (cmd == "trim" && a == "--gzip") { tcfg.gzip = true; multi = nullptr; }
+            else if (cmd == "trim" && a == "--failed-out") tcfg.failed_trimmed_writer = std::string(need("--failed-out"));
+            else if (cmd == "trim" && a == "--only-side") {
+                const std::string v = need("--only-side");
+                if (v == "left") tcfg.only_side = LabelSide::Left;
+                else if (v == "right") tcfg.only_side = LabelSide::Right;
+                else { fprintf(stderr, "error: --only-side takes left or right\n"); return 2; }
+            }
+            else if (!a.empty() && a[0] != '-' && multi) multi->push_back(a);
+            else { fprintf(stderr, "error: unexpected argument '%s'\n", a.c_str()); usage(); return 2; }
+        }
+        if (input.empty()) { fprintf(stderr, "error: %s needs --input\n", cmd.c_str()); return 2; }
+        try {
+            if (cmd == "filter") {
+                if (output.empty() || files.empty()) { fputs("error: filter needs --output and --file\n", stderr); return 2; }
+                puts("Starting filtering...");
+                const StepStats st = filter_file(input, output, dropped.empty() ? std::nullopt : std::optional<std::string>(dropped), patterns_from_files(files), device);
+                printf("Filtering complete! %zu reads, %zu kept, %zu dropped\n", st.total, st.kept, st.dropped);
+            } else if (cmd == "inspect") {
+                puts("Inspecting...");
+                AnnotateStats pats;
+                inspect_file(input, output.empty() ? std::nullopt : std::optional<std::string>(output), bucket, pats, device);
+                for (const auto& l : inspect_summary(pats, top_n)) puts(l.c_str());
+            } else {
+                if (output.empty() || reads.empty()) { fputs("error: trim needs --output and --reads\n", stderr); return 2; }
+                if (tcfg.sort_labels && tcfg.only_side) { fputs("error: --only-side conflicts with --sort-labels (bin/main.rs:160-161)\n", stderr); return 2; }
+                puts("Starting trimming...");
+                const StepStats st = trim_file(input, reads, output, tcfg, device);
+                printf("Trimming complete! %zu reads, %zu trimmed (%zu split), %zu failed\n", st.total, st.kept, st.split, st.dropped);
+            }
+        } catch (const std::exception& e) { fprintf(stderr, "error: %s\n", e.what()); return 1; }
+        return done_ok();
     }
     if (cmd == "stage") {   // test aid, no GPU: the staged upload text of the annotate path -> a file
         std::vector<std::string> in;

@@ -158,6 +158,8 @@ public:
     // trim step (trim.rs:127-300 on the GPU) on the rows + verdicts of the LAST batch; needs set_filter
     void set_trim(const TrimConfig& cfg);
     TrimBatch trim_last_batch(const std::vector<bb_row_verdict>& verdicts, const FastqBatch& batch);
+    // rows parsed back from an annotation file take the place of the last batch's (bb_steps.cpp: the steps on files)
+    void load_rows(const std::vector<bb_row>& rows);
     std::string label_of_key(uint32_t key) const;  // LabelConfig::create_label's string for a bb_slice.label_key
     // inspect step (inspect.rs:15-117) on the rows of the LAST batch: one pattern string per read with rows
     std::vector<std::pair<uint32_t, std::string>> inspect_last_batch(const std::vector<bb_row_verdict>* verdicts, uint32_t bucket_size);
@@ -314,5 +316,14 @@ AnnotateStats annotate_with_kit(const std::vector<std::string>& read_files, cons
 AnnotateStats annotate_with_files(const std::vector<std::string>& read_files, const std::vector<std::string>& query_files,
                                   const std::vector<BarcodeType>& query_types, const std::string& out_file,
                                   const AnnotateConfig& config);                                            // :155-193
+
+// ---- the stand-alone steps on files (bb_steps.cpp): an annotation.tsv written earlier back through the same kernels ----
+struct StepStats { size_t total = 0, kept = 0, dropped = 0, split = 0; };   // reads; trim: kept = trimmed, dropped = failed
+StepStats filter_file(const std::string& annotated_file, const std::string& output_file, const std::optional<std::string>& dropped_out_file,
+                      const std::vector<Pattern>& filters, int device = 0, size_t batch_rows = 1u << 18);                       // filter.rs:10-119
+StepStats inspect_file(const std::string& annotated_file, const std::optional<std::string>& read_pattern_out, uint32_t bucket_size,
+                       AnnotateStats& patterns, int device = 0, size_t batch_rows = 1u << 18);                                   // inspect.rs:119-208
+StepStats trim_file(const std::string& filtered_match_file, const std::vector<std::string>& read_fastq_files, const std::string& output_folder,
+                    const TrimConfig& config, int device = 0, size_t batch_reads = 20000);                                       // trim.rs:317-480
 
 }  // namespace barbell

@@ -271,3 +271,83 @@ def test_dual_end_experiment_as_the_reference_readme_runs_it(tmp_path):
         assert (out / (name + ".tsv")).read_bytes() == (ref / "f.tsv").read_bytes() and len((ref / "f.tsv").read_bytes()) > 1000, name
         a, b = _dir_bytes(out / name, ".trimmed.fastq"), _dir_bytes(ref / "t", ".trimmed.fastq")
         assert len(b) >= 1 and a == b, name
+
+
+CLI = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "barbell_amd", "bin", "barbell-amd")
+
+
+def _cli(*args):
+    import subprocess
+
+    return subprocess.run([CLI, *map(str, args)], capture_output=True, text=True, timeout=600)
+
+
+def test_cpp_host_steps_without_rows_need_no_device(tmp_path):
+    """barbell-amd filter / inspect / trim (host/bb_steps.cpp) on the EMPTY annotation file a run without rows leaves; malformed files fail loudly"""
+    (tmp_path / "a.tsv").write_bytes(b"")
+    (tmp_path / "p.txt").write_text("Ftag[fw, *, @left(0..250), >>]\n")
+    r = _cli("filter", "-i", tmp_path / "a.tsv", "-o", tmp_path / "f.tsv", "-f", tmp_path / "p.txt", "--dropped", tmp_path / "d.tsv")
+    assert r.returncode == 0 and "0 reads, 0 kept, 0 dropped" in r.stdout, r.stderr
+    assert (tmp_path / "f.tsv").read_bytes() == b"" and (tmp_path / "d.tsv").read_bytes() == b""
+    r = _cli("inspect", "-i", tmp_path / "a.tsv")
+    assert r.returncode == 0 and "Found 0 unique patterns" in r.stdout
+    (tmp_path / "r.fastq").write_bytes(b"@a\nACGT\n+\nIIII\n@b x\nAC\n+\nII\n")
+    r = _cli("trim", "-i", tmp_path / "f.tsv", "-r", tmp_path / "r.fastq", "-o", tmp_path / "t")
+    assert r.returncode == 0 and "2 reads, 0 trimmed" in r.stdout, r.stderr
+    assert list((tmp_path / "t").iterdir()) == []
+    (tmp_path / "bad.tsv").write_text("read_id\tread_len\nx\t5\n")
+    r = _cli("filter", "-i", tmp_path / "bad.tsv", "-o", tmp_path / "f2.tsv", "-f", tmp_path / "p.txt")
+    assert r.returncode == 1 and "column missing" in r.stderr
+    assert _cli("trim", "-i", tmp_path / "f.tsv", "-o", tmp_path / "t").returncode == 2      # -r is required
+    assert _cli("trim", "-i", tmp_path / "f.tsv", "-r", tmp_path / "r.fastq", "-o", tmp_path / "t", "--sort-labels", "--only-side", "left").returncode == 2
+
+
+@pytest.mark.gpu
+def test_cpp_host_steps_on_files_give_the_fused_runs_files(tmp_path):
+    """the C++ host's filter / inspect / trim on the files of a one-pass `barbell-amd kit` run: the same filtered.tsv, pattern_per_read.tsv,
+    trimmed FASTQ files and failed ids, byte for byte; and a read id that needs quoting survives the round trip"""
+    from barbell_amd import kits as K
+
+    groups = K.groups_from_kit(KIT)
+    fq = tmp_path / "r.fastq"
+    _write_fastq(fq, groups, 1500, 17)
+    fused = tmp_path / "fused"
+    r = _cli("kit", "-k", KIT, "-i", fq, "-o", fused, "--maximize", "--failed-out", fused / "failed.txt", "--batch-reads", 400)
+    assert r.returncode == 0, r.stderr
+    d = K._data()
+    pats = tmp_path / "pats.txt"
+    pats.write_text("\n".join(d["pattern_sets"][d["kit_filter"][KIT]["maximize"]]) + "\n")
+    alone = tmp_path / "alone"
+    alone.mkdir()
+    r = _cli("filter", "-i", fused / "annotation.tsv", "-o", alone / "filtered.tsv", "-f", pats, "--dropped", alone / "dropped.tsv")
+    assert r.returncode == 0, r.stderr
+    assert (alone / "filtered.tsv").read_bytes() == (fused / "filtered.tsv").read_bytes() and len((fused / "filtered.tsv").read_bytes()) > 10000
+    kept = {l.split("\t")[0] for l in (alone / "filtered.tsv").read_text().splitlines()[1:]}
+    drop = {l.split("\t")[0] for l in (alone / "dropped.tsv").read_text().splitlines()[1:]}
+    every = {l.split("\t")[0] for l in (fused / "annotation.tsv").read_text().splitlines()[1:]}
+    assert kept and drop and not (kept & drop) and (kept | drop) == every
+    r = _cli("inspect", "-i", fused / "annotation.tsv", "-o", alone / "pattern_per_read.tsv")
+    assert r.returncode == 0, r.stderr
+    assert (alone / "pattern_per_read.tsv").read_bytes() == (fused / "pattern_per_read.tsv").read_bytes()
+    assert "Found " in r.stdout and "Pattern 1:" in r.stdout
+    r = _cli("trim", "-i", alone / "filtered.tsv", "-r", fq, "-o", alone, "--no-orientation", "--no-flanks", "--only-side", "left", "--failed-out", alone / "failed.txt")
+    assert r.returncode == 0, r.stderr   # the label flags of the kit preset (use_kit.rs:87-99)
+    a, b = _dir_bytes(alone, ".trimmed.fastq"), _dir_bytes(fused, ".trimmed.fastq")
+    assert len(b) > 20 and a.keys() == b.keys()
+    for k in b:
+        assert a[k] == b[k], k
+    assert (alone / "failed.txt").read_bytes() == (fused / "failed.txt").read_bytes()
+    # the Python twin on the same files
+    from barbell_amd import filter as FF, steps
+
+    steps.filter_file(str(fused / "annotation.tsv"), str(alone / "py_filtered.tsv"), FF.patterns_from_files([str(pats)]), log=lambda s: None)
+    assert (alone / "py_filtered.tsv").read_bytes() == (alone / "filtered.tsv").read_bytes()
+    # a read id that the csv writer quotes
+    lines = (fused / "annotation.tsv").read_text().splitlines()
+    first_id = lines[1].split("\t")[0]
+    odd = [lines[0]] + [l.replace(first_id + "\t", '"odd ""id""\tx"\t', 1) if l.startswith(first_id + "\t") else l for l in lines[1:]]
+    (alone / "odd.tsv").write_text("\n".join(odd) + "\n")
+    r = _cli("filter", "-i", alone / "odd.tsv", "-o", alone / "odd_f.tsv", "-f", pats, "--dropped", alone / "odd_d.tsv")
+    assert r.returncode == 0, r.stderr
+    both = (alone / "odd_f.tsv").read_text() + (alone / "odd_d.tsv").read_text()
+    assert '"odd ""id""\tx"\t' in both
