@@ -387,6 +387,8 @@ def trim_file(filtered_match_file, read_fastq_files, output_folder, config=None,
     space = _space_for(filtered_match_file, groups)
     total = 0
     if not space.groups:   # no annotations: every read is counted, none is written
+        if cfg.failed_trimmed_writer:
+            open(cfg.failed_trimmed_writer, "w").close()   # the reference creates it before the first read (trim.rs:364-370)
         for path in read_fastq_files:
             total += sum(1 for _ in read_fastq_records(str(path)))
         log(f"trim: {total} reads, 0 trimmed, 0 failed")
