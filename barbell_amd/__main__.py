@@ -124,11 +124,17 @@ def main(argv=None):
         total, found = A.annotate(a.input, a.output, _groups(a, required=True), alpha=a.alpha, min_score=a.min_score, min_score_diff=a.min_score_diff,
                                   max_flank_errors=a.flank_max_errors, device=a.device)
         print(f"Annotation complete! {total} reads, {found} with annotations")
+        if a.verbose:   # annotator.rs:259-266, :110-112
+            import os
+
+            from .steps import write_progress_log
+
+            write_progress_log("annotate", os.path.dirname(a.output), [("Total:", total), ("Kept:", found), ("Dropped:", total - found)])
     elif a.command == "filter":
         from . import steps
 
         print("Starting filtering...")
-        steps.filter_file(a.input, a.output, steps.patterns_from_files(a.file), a.dropped, groups=_groups(a), device=a.device)
+        steps.filter_file(a.input, a.output, steps.patterns_from_files(a.file), a.dropped, groups=_groups(a), device=a.device, verbose=a.verbose)
         print("Filtering complete!")
     elif a.command == "trim":
         from . import steps

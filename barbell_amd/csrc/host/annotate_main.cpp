@@ -194,6 +194,7 @@ int main(int argc, char** argv) {
                 puts("Starting filtering...");
                 const StepStats st = filter_file(input, output, dropped.empty() ? std::nullopt : std::optional<std::string>(dropped), patterns_from_files(files), device);
                 printf("Filtering complete! %zu reads, %zu kept, %zu dropped\n", st.total, st.kept, st.dropped);
+                if (tcfg.verbose) write_progress_log("filter", parent_dir(output), {{"Total:", st.total}, {"Kept:", st.kept}, {"Dropped:", st.dropped}});   // filter.rs:18-25
             } else if (cmd == "inspect") {
                 puts("Inspecting...");
                 AnnotateStats pats;
@@ -205,6 +206,7 @@ int main(int argc, char** argv) {
                 puts("Starting trimming...");
                 const StepStats st = trim_file(input, reads, output, tcfg, device);
                 printf("Trimming complete! %zu reads, %zu trimmed (%zu split), %zu failed\n", st.total, st.kept, st.split, st.dropped);
+                if (tcfg.verbose) write_progress_log("trim", output, {{"Total:", st.total}, {"Kept:", st.kept}, {"Kept split:", st.split}, {"Failed:", st.dropped}});   // trim.rs:341-345
             }
         } catch (const std::exception& e) { fprintf(stderr, "error: %s\n", e.what()); return 1; }
         return done_ok();
@@ -289,6 +291,11 @@ int main(int argc, char** argv) {
             for (const auto& l : inspect_summary(st, 10)) puts(l.c_str());
             printf("Annotated %zu of %zu reads; filter kept %zu, dropped %zu; trimmed %zu (%zu split, %zu failed)\nDone!\n", st.found, st.total,
                    st.kept, st.dropped, st.trimmed, st.trimmed_split, st.trim_failed);
+            if (k.verbose) {   // use_kit.rs:38,73,97 hands --verbose to its three steps: each leaves its log in the output folder
+                write_progress_log("annotate", k.output_folder, {{"Total:", st.total}, {"Kept:", st.found}, {"Dropped:", st.total - st.found}});
+                write_progress_log("filter", k.output_folder, {{"Total:", st.kept + st.dropped}, {"Kept:", st.kept}, {"Dropped:", st.dropped}});
+                write_progress_log("trim", k.output_folder, {{"Total:", st.total}, {"Kept:", st.trimmed}, {"Kept split:", st.trimmed_split}, {"Failed:", st.trim_failed}});
+            }
             fprintf(stderr, "Done: %zu records (%.3f s in the pipeline, %.2f M reads/s; histogram summed by %s)\n", st.total, st.seconds_pipeline,
                     st.seconds_pipeline > 0 ? st.total / st.seconds_pipeline / 1e6 : 0.0, st.counts_reduce.c_str());
         } catch (const BarbellError& e) { fprintf(stderr, "error: %s\n", e.what()); return 1; }
@@ -392,6 +399,7 @@ int main(int argc, char** argv) {
         }
         fprintf(stderr, "Done: %zu records, %zu with annotations, %zu rows -> %s (%.3f s in the pipeline, %.2f M reads/s; histogram summed by %s)\n", st.total, st.found,
                 st.rows, output.c_str(), st.seconds_pipeline, st.seconds_pipeline > 0 ? st.total / st.seconds_pipeline / 1e6 : 0.0, st.counts_reduce.c_str());
+        if (cfg.verbose) write_progress_log("annotate", parent_dir(output), {{"Total:", st.total}, {"Kept:", st.found}, {"Dropped:", st.total - st.found}});   // annotator.rs:259-266, :110-112
         if (!cfg.filter_patterns.empty()) fprintf(stderr, "Filter: %zu kept, %zu dropped\n", st.kept, st.dropped);
         if (cfg.trim) fprintf(stderr, "Trim: %zu trimmed, %zu split, %zu failed\n", st.trimmed, st.trimmed_split, st.trim_failed);
         if (cfg.inspect) for (const auto& l : inspect_summary(st, top_n)) puts(l.c_str());

@@ -326,4 +326,8 @@ StepStats inspect_file(const std::string& annotated_file, const std::optional<st
 StepStats trim_file(const std::string& filtered_match_file, const std::vector<std::string>& read_fastq_files, const std::string& output_folder,
                     const TrimConfig& config, int device = 0, size_t batch_reads = 20000);                                       // trim.rs:317-480
 
+// what --verbose leaves behind (progress.rs:96-144): '{log_dir}/{step}.{unix ms}.log', "step\tmetric\tcount" + a line per counter; returns the path
+std::string write_progress_log(const std::string& step, const std::string& log_dir, const std::vector<std::pair<std::string, size_t>>& counts);
+std::string parent_dir(const std::string& file);
+
 }  // namespace barbell

@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <ctime>
 #include <filesystem>
 #include <fstream>
 #include <unordered_map>
@@ -337,6 +338,25 @@ struct OutFile {   // '{folder}/{label}.trimmed.fastq[.gz]' (trim.rs:428-446)
 };
 
 }  // namespace
+
+// ProgressTracker::new_with_logging + ProgressLog::write (progress.rs:96-144, 188-195): '{log_dir}/{step}.{unix ms}.log' holding
+// "step\tmetric\tcount" and one line per counter — what --verbose leaves behind besides the progress bars (which stay out of scope)
+std::string write_progress_log(const std::string& step, const std::string& log_dir, const std::vector<std::pair<std::string, size_t>>& counts) {
+    struct timespec ts;
+    clock_gettime(CLOCK_REALTIME, &ts);
+    const unsigned long long ms = (unsigned long long)ts.tv_sec * 1000ull + (unsigned long long)(ts.tv_nsec / 1000000);
+    const std::string path = (log_dir.empty() ? std::string(".") : log_dir) + "/" + step + "." + std::to_string(ms) + ".log";
+    FILE* f = fopen(path.c_str(), "wb");
+    if (!f) { fprintf(stderr, "Failed to create log file '%s'\n", path.c_str()); return ""; }
+    fputs("step\tmetric\tcount\n", f);
+    for (const auto& c : counts) fprintf(f, "%s\t%s\t%zu\n", step.c_str(), c.first.c_str(), c.second);
+    fclose(f);
+    return path;
+}
+std::string parent_dir(const std::string& file) {   // Path::parent() of an output file, "." where it has none
+    const size_t q = file.find_last_of('/');
+    return q == std::string::npos ? std::string(".") : (q == 0 ? std::string("/") : file.substr(0, q));
+}
 
 void Demuxer::load_rows(const std::vector<bb_row>& rows) {
     ensure_ctx();

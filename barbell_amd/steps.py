@@ -321,8 +321,21 @@ def _format(rows, read_ids, space, verdicts):
     return out
 
 
+def write_progress_log(step, log_dir, counts):
+    """ProgressTracker::new_with_logging + ProgressLog::write (progress.rs:96-144, 188-195): '{log_dir}/{step}.{unix ms}.log' holding
+    "step\\tmetric\\tcount" and a line per counter — what --verbose leaves behind besides the progress bars (those stay out of scope)"""
+    import time
+
+    path = os.path.join(log_dir or ".", f"{step}.{int(time.time() * 1000)}.log")
+    with open(path, "w") as f:
+        f.write("step\tmetric\tcount\n")
+        for metric, n in counts:
+            f.write(f"{step}\t{metric}\t{n}\n")
+    return path
+
+
 # ---- barbell filter (filter.rs:10-119) -----------------------------------------------------------------------------------
-def filter_file(annotated_file, output_file, patterns, dropped_out_file=None, groups=None, device=0, batch_rows=1 << 18, log=print):
+def filter_file(annotated_file, output_file, patterns, dropped_out_file=None, groups=None, device=0, batch_rows=1 << 18, log=print, verbose=False):
     """Reads of annotation.tsv (consecutive lines of one read_id) against the patterns on the GPU (k_filter); passing reads' rows
     go to `output_file` with their cuts, the others to `dropped_out_file`.  Returns (reads, kept, dropped)."""
     space = _space_for(annotated_file, groups)
@@ -354,6 +367,8 @@ def filter_file(annotated_file, output_file, patterns, dropped_out_file=None, gr
             if f is not None:
                 f.close()
     log(f"filter: {total} reads, {kept} kept, {total - kept} dropped")
+    if verbose:   # filter.rs:18-25: next to the output file
+        write_progress_log("filter", os.path.dirname(output_file), [("Total:", total), ("Kept:", kept), ("Dropped:", total - kept)])
     return total, kept, total - kept
 
 
@@ -392,6 +407,8 @@ def trim_file(filtered_match_file, read_fastq_files, output_folder, config=None,
         for path in read_fastq_files:
             total += sum(1 for _ in read_fastq_records(str(path)))
         log(f"trim: {total} reads, 0 trimmed, 0 failed")
+        if cfg.verbose:
+            write_progress_log("trim", output_folder, [("Total:", total), ("Kept:", 0), ("Kept split:", 0), ("Failed:", 0)])
         return total, 0, 0, 0
     batches = list(read_annotation_tsv(filtered_match_file, space, group_consecutive=False))
     anno = batches[0]
@@ -435,6 +452,8 @@ def trim_file(filtered_match_file, read_fastq_files, output_folder, config=None,
         writers.close()
         dm.close()
     log(f"trim: {total} reads, {writers.n_trimmed} trimmed, {writers.n_failed} failed, {writers.n_split} split")
+    if cfg.verbose:   # trim.rs:341-345: in the output folder
+        write_progress_log("trim", output_folder, [("Total:", total), ("Kept:", writers.n_trimmed), ("Kept split:", writers.n_split), ("Failed:", writers.n_failed)])
     return total, writers.n_trimmed, writers.n_failed, writers.n_split
 
 

@@ -143,6 +143,11 @@ def test_empty_annotation_files_need_no_device(tmp_path):
     (tmp_path / "bad.tsv").write_text("read_id\tread_len\n")
     with pytest.raises(steps.TsvError):
         steps.scan_labels(str(tmp_path / "bad.tsv"))
+    # --verbose leaves '{step}.{unix ms}.log' next to the output (progress.rs:96-144)
+    steps.filter_file(str(tmp_path / "a.tsv"), str(tmp_path / "f.tsv"), [], verbose=True, log=logs.append)
+    (log,) = [p for p in tmp_path.iterdir() if p.name.startswith("filter.") and p.name.endswith(".log")]
+    assert log.read_text() == "step\tmetric\tcount\nfilter\tTotal:\t0\nfilter\tKept:\t0\nfilter\tDropped:\t0\n"
+    assert log.name.split(".")[1].isdigit() and len(log.name.split(".")[1]) == 13
 
 
 def _write_fastq(path, groups, n, seed):
@@ -295,6 +300,10 @@ def test_cpp_host_steps_without_rows_need_no_device(tmp_path):
     r = _cli("trim", "-i", tmp_path / "f.tsv", "-r", tmp_path / "r.fastq", "-o", tmp_path / "t")
     assert r.returncode == 0 and "2 reads, 0 trimmed" in r.stdout, r.stderr
     assert list((tmp_path / "t").iterdir()) == []
+    r = _cli("trim", "-i", tmp_path / "f.tsv", "-r", tmp_path / "r.fastq", "-o", tmp_path / "t", "--verbose")
+    (log,) = [p for p in (tmp_path / "t").iterdir() if p.name.startswith("trim.") and p.name.endswith(".log")]
+    assert log.read_text() == "step\tmetric\tcount\ntrim\tTotal:\t2\ntrim\tKept:\t0\ntrim\tKept split:\t0\ntrim\tFailed:\t0\n"   # progress.rs:96-127, :51-70
+    log.unlink()
     (tmp_path / "bad.tsv").write_text("read_id\tread_len\nx\t5\n")
     r = _cli("filter", "-i", tmp_path / "bad.tsv", "-o", tmp_path / "f2.tsv", "-f", tmp_path / "p.txt")
     assert r.returncode == 1 and "column missing" in r.stderr
@@ -312,15 +321,22 @@ def test_cpp_host_steps_on_files_give_the_fused_runs_files(tmp_path):
     fq = tmp_path / "r.fastq"
     _write_fastq(fq, groups, 1500, 17)
     fused = tmp_path / "fused"
-    r = _cli("kit", "-k", KIT, "-i", fq, "-o", fused, "--maximize", "--failed-out", fused / "failed.txt", "--batch-reads", 400)
+    r = _cli("kit", "-k", KIT, "-i", fq, "-o", fused, "--maximize", "--failed-out", fused / "failed.txt", "--batch-reads", 400, "--verbose")
     assert r.returncode == 0, r.stderr
+
+    def log_of(folder, step):   # what --verbose leaves behind (progress.rs:96-144)
+        (p,) = [p for p in folder.iterdir() if p.name.startswith(step + ".") and p.name.endswith(".log")]
+        return p.read_text()
+
+    assert log_of(fused, "annotate").startswith("step\tmetric\tcount\nannotate\tTotal:\t1500\nannotate\tKept:\t")
     d = K._data()
     pats = tmp_path / "pats.txt"
     pats.write_text("\n".join(d["pattern_sets"][d["kit_filter"][KIT]["maximize"]]) + "\n")
     alone = tmp_path / "alone"
     alone.mkdir()
-    r = _cli("filter", "-i", fused / "annotation.tsv", "-o", alone / "filtered.tsv", "-f", pats, "--dropped", alone / "dropped.tsv")
+    r = _cli("filter", "-i", fused / "annotation.tsv", "-o", alone / "filtered.tsv", "-f", pats, "--dropped", alone / "dropped.tsv", "--verbose")
     assert r.returncode == 0, r.stderr
+    assert log_of(alone, "filter") == log_of(fused, "filter") and "filter\tKept:\t" in log_of(alone, "filter")
     assert (alone / "filtered.tsv").read_bytes() == (fused / "filtered.tsv").read_bytes() and len((fused / "filtered.tsv").read_bytes()) > 10000
     kept = {l.split("\t")[0] for l in (alone / "filtered.tsv").read_text().splitlines()[1:]}
     drop = {l.split("\t")[0] for l in (alone / "dropped.tsv").read_text().splitlines()[1:]}
@@ -330,8 +346,10 @@ def test_cpp_host_steps_on_files_give_the_fused_runs_files(tmp_path):
     assert r.returncode == 0, r.stderr
     assert (alone / "pattern_per_read.tsv").read_bytes() == (fused / "pattern_per_read.tsv").read_bytes()
     assert "Found " in r.stdout and "Pattern 1:" in r.stdout
-    r = _cli("trim", "-i", alone / "filtered.tsv", "-r", fq, "-o", alone, "--no-orientation", "--no-flanks", "--only-side", "left", "--failed-out", alone / "failed.txt")
+    r = _cli("trim", "-i", alone / "filtered.tsv", "-r", fq, "-o", alone, "--no-orientation", "--no-flanks", "--only-side", "left", "--failed-out", alone / "failed.txt",
+             "--verbose")
     assert r.returncode == 0, r.stderr   # the label flags of the kit preset (use_kit.rs:87-99)
+    assert log_of(alone, "trim") == log_of(fused, "trim") and "trim\tKept split:\t" in log_of(alone, "trim")
     a, b = _dir_bytes(alone, ".trimmed.fastq"), _dir_bytes(fused, ".trimmed.fastq")
     assert len(b) > 20 and a.keys() == b.keys()
     for k in b:
