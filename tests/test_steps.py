@@ -244,6 +244,11 @@ def test_command_line_steps_with_other_label_flags(tmp_path):
     assert len(b) >= 10 and a == b
     # the filtered file carries cuts: inspect shows the cut markers
     assert ">>" in (out / "ppr.tsv").read_text()
+    # `kit` through the same front end: the annotate step's file is the one written above
+    assert main(["kit", "-k", "SQK-RBK114-24", "-i", str(fq), "-o", str(out / "kit"), "--maximize"]) == 0
+    assert (out / "kit" / "annotation.tsv").read_bytes() == (out / "a.tsv").read_bytes()
+    assert (out / "kit" / "filtered.tsv").exists() and (out / "kit" / "pattern_per_read.tsv").exists()
+    assert any(p.name.endswith(".trimmed.fastq") for p in (out / "kit").iterdir())
 
 
 @pytest.mark.gpu
