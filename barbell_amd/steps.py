@@ -203,7 +203,14 @@ _INT_FIELDS = ("read_len", "rel_dist_to_end", "read_start_bar", "read_end_bar", 
 
 def _ints(strings, what, path):
     """decimal fields of many records in one C call"""
-    a = np.fromstring(" ".join(strings), dtype=np.int64, sep=" ") if strings else np.zeros(0, dtype=np.int64)
+    import warnings
+
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", DeprecationWarning)   # text that does not parse to its end: caught by the length check below
+            a = np.fromstring(" ".join(strings), dtype=np.int64, sep=" ") if strings else np.zeros(0, dtype=np.int64)
+    except ValueError:
+        a = np.zeros(0, dtype=np.int64)
     if len(a) != len(strings) or not all(s.lstrip("-").isdigit() for s in strings[:: max(1, len(strings) // 64)]):
         bad = next((s for s in strings if not s.lstrip("-").isdigit()), "?")
         raise TsvError(f"{path}: {what}: {bad!r} is not an integer")

@@ -80,6 +80,13 @@ def test_tsv_comes_back_as_the_rows_it_was_written_from(tmp_path):
     # an unknown label under explicit groups is an error, not a silent slot
     with pytest.raises(steps.TsvError):
         list(steps.read_annotation_tsv(str(p), steps.LabelSpace(kits.groups_from_kit("SQK-RBK114-24"))))
+    # a field that is not an integer, a strand that is none
+    for col, val in ((1, "12x"), (3, ""), (13, "Forward"), (9, "Xtag")):
+        f = text.splitlines()[5].split("\t")
+        f[col] = val
+        (tmp_path / "broken.tsv").write_text("\n".join(text.splitlines()[:5] + ["\t".join(f)]) + "\n")
+        with pytest.raises(steps.TsvError):
+            list(steps.read_annotation_tsv(str(tmp_path / "broken.tsv"), space))
     # trim's view: one read per distinct id wherever its lines lie
     lines = text.splitlines()
     (tmp_path / "shuffled.tsv").write_text("\n".join([lines[0]] + lines[1:][::2] + lines[1:][1::2]) + "\n")
