@@ -326,7 +326,7 @@ def read_fastq(path):
 
 def annotate(read_files, out_file, query_groups, alpha=0.4, min_score=0.2, min_score_diff=0.1, max_flank_errors=None,
              batch_reads=0, block_bytes=512 << 20, device=0, filter_patterns=None, filtered_file=None, dropped_file=None, trim_folder=None,
-             trim_config=None, inspector=None, policy=None):
+             trim_config=None, inspector=None, policy=None, stats=None):
     """annotate_with_groups + annotate (annotator.rs:207-285): sets the flank threshold of each group
     (explicit --flank-max-errors or the automatic cutoff), hands the FASTQ text to the GPU block by block
     (`block_bytes`, or `batch_reads` * 4096; records are parsed there, barbell_amd/fastq.py) and writes annotation.tsv.  With `filter_patterns` the filter step (filter.rs:10-119) runs on
@@ -336,7 +336,8 @@ def annotate(read_files, out_file, query_groups, alpha=0.4, min_score=0.2, min_s
     batch as well: the GPU cuts the passing reads and renders the FASTQ records grouped by output label, the
     host appends each group to '{trim_folder}/{label}.trimmed.fastq[.gz]'.  `inspector(dm)` may build an
     inspect_rows.Inspector that is fed the rows of every batch (inspect.rs:119-208 without re-reading the TSV).
-    Returns (total_reads, reads_with_rows)."""
+    Returns (total_reads, reads_with_rows); a dict passed as `stats` also gets the counters of the fused steps (reads kept / dropped by the
+    filter, trimmed / split / failed: what the reference's progress logs hold, progress.rs:15-88)."""
     for g in query_groups:
         if max_flank_errors is not None:
             g.set_flank_threshold(max_flank_errors)
@@ -392,7 +393,11 @@ def annotate(read_files, out_file, query_groups, alpha=0.4, min_score=0.2, min_s
         if insp is not None:
             insp.add(rows, ids, d_rows=d_rows)
         if flt is not None:
-            flt.verdicts_ingested(d_rows, len(rows), download=trimmer is not None)
+            ver = flt.verdicts_ingested(d_rows, len(rows), download=trimmer is not None or stats is not None)
+            if stats is not None and len(rows):
+                first = np.r_[True, rows["read_idx"][1:] != rows["read_idx"][:-1]]
+                stats["kept"] = stats.get("kept", 0) + int((first & (ver["pass"] != 0)).sum())
+                stats["dropped"] = stats.get("dropped", 0) + int((first & (ver["pass"] == 0)).sum())
             d_v = dm.buf("verdicts").ptr
             emit_bytes("kept", fmt.render(d_rows, len(rows), batch, FMT_KEPT, d_v)[0])
             emit_bytes("dropped", fmt.render(d_rows, len(rows), batch, FMT_DROPPED, d_v)[0])
@@ -408,6 +413,10 @@ def annotate(read_files, out_file, query_groups, alpha=0.4, min_score=0.2, min_s
                 f.close()
         if writers is not None:
             writers.close()
+        if stats is not None:
+            stats.update(total=total, found=found)
+            if writers is not None:
+                stats.update(trimmed=writers.n_trimmed, split=writers.n_split, failed=writers.n_failed)
         if insp is not None:
             insp.close()
     dm.close()

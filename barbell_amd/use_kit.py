@@ -28,11 +28,20 @@ def demux_using_kit(fastq_files, kit_name, output_folder, maximize=False, verbos
         holder["i"] = Inspector(dm, os.path.join(output_folder, "pattern_per_read.tsv"), 250)
         return holder["i"]
 
+    stats = {}
     total, found = A.annotate(
         fastq_files, os.path.join(output_folder, "annotation.tsv"), kits.groups_from_kit(kit_name, use_extended), alpha=alpha,
         min_score=min_score, min_score_diff=min_score_diff, max_flank_errors=max_flank_errors, batch_reads=batch_reads, device=device,
         filter_patterns=F.kit_patterns(kit_name, maximize), filtered_file=os.path.join(output_folder, "filtered.tsv"),
-        trim_folder=output_folder, trim_config=TrimConfig.for_kit(failed_out, gzip), inspector=make_inspector)
+        trim_folder=output_folder, trim_config=TrimConfig.for_kit(failed_out, gzip), inspector=make_inspector, stats=stats)
+    if verbose:   # use_kit.rs:38,73,97 hands --verbose to its three steps: each leaves its log in the output folder (progress.rs:96-144)
+        from .steps import write_progress_log
+
+        write_progress_log("annotate", output_folder, [("Total:", total), ("Kept:", found), ("Dropped:", total - found)])
+        write_progress_log("filter", output_folder, [("Total:", stats.get("kept", 0) + stats.get("dropped", 0)), ("Kept:", stats.get("kept", 0)),
+                                                     ("Dropped:", stats.get("dropped", 0))])
+        write_progress_log("trim", output_folder, [("Total:", total), ("Kept:", stats.get("trimmed", 0)), ("Kept split:", stats.get("split", 0)),
+                                                   ("Failed:", stats.get("failed", 0))])
     log("Top 10 most common patterns")
     for line in holder["i"].summary(10):
         log(line)

@@ -252,7 +252,15 @@ def test_command_line_steps_with_other_label_flags(tmp_path):
     # the filtered file carries cuts: inspect shows the cut markers
     assert ">>" in (out / "ppr.tsv").read_text()
     # `kit` through the same front end: the annotate step's file is the one written above
-    assert main(["kit", "-k", "SQK-RBK114-24", "-i", str(fq), "-o", str(out / "kit"), "--maximize"]) == 0
+    assert main(["kit", "-k", "SQK-RBK114-24", "-i", str(fq), "-o", str(out / "kit"), "--maximize", "--verbose"]) == 0
+    logs = {p.name.split(".")[0]: p.read_text().splitlines() for p in (out / "kit").iterdir() if p.name.endswith(".log")}
+    assert set(logs) == {"annotate", "filter", "trim"} and logs["annotate"][1] == "annotate\tTotal:\t600" and logs["trim"][1] == "trim\tTotal:\t600"
+    n = {k: [int(l.split("\t")[2]) for l in v[1:]] for k, v in logs.items()}
+    assert n["filter"][0] == n["filter"][1] + n["filter"][2] == n["annotate"][1] and n["trim"][1] + n["trim"][3] == n["filter"][1] > 100
+    r = _cli("kit", "-k", "SQK-RBK114-24", "-i", fq, "-o", out / "ckit", "--maximize", "--verbose")   # the C++ host counts the same
+    assert r.returncode == 0, r.stderr
+    clogs = {p.name.split(".")[0]: p.read_text().splitlines() for p in (out / "ckit").iterdir() if p.name.endswith(".log")}
+    assert clogs == logs
     assert (out / "kit" / "annotation.tsv").read_bytes() == (out / "a.tsv").read_bytes()
     assert (out / "kit" / "filtered.tsv").exists() and (out / "kit" / "pattern_per_read.tsv").exists()
     assert any(p.name.endswith(".trimmed.fastq") for p in (out / "kit").iterdir())
