@@ -114,7 +114,16 @@ def parser():
 
 
 def main(argv=None):
+    """0 when the step ran; 1 with 'Error during processing: …' where the reference prints its error and returns (bin/main.rs:300-420)"""
     a = parser().parse_args(argv)
+    try:
+        return _run(a)
+    except (ValueError, OSError, RuntimeError) as e:   # TsvError / pattern errors / BarbellError / unreadable files
+        print(f"Error during processing: {e}", file=sys.stderr)
+        return 1
+
+
+def _run(a):
     if a.command == "annotate":
         from . import annotate as A
 

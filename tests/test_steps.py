@@ -133,6 +133,21 @@ def test_command_line_takes_the_reference_flags():
         ap.parse_args("trim -i f.tsv -o out".split())   # -r is required (bin/main.rs:143)
 
 
+def test_command_line_reports_errors_like_the_reference(tmp_path, capsys):
+    from barbell_amd.__main__ import main
+
+    (tmp_path / "f.tsv").write_bytes(b"")
+    (tmp_path / "r.fastq").write_bytes(b"@a\nACGT\n+\nIIII\n")
+    base = ["trim", "-i", str(tmp_path / "f.tsv"), "-r", str(tmp_path / "r.fastq"), "-o", str(tmp_path / "t")]
+    assert main(base) == 0
+    assert main(base + ["--sort-labels", "--only-side", "left"]) == 1          # trim.rs:331-335
+    assert "ambiguous" in capsys.readouterr().err
+    (tmp_path / "p.txt").write_text("Xtag[fw, *, @left(0..250)]\n")
+    assert main(["filter", "-i", str(tmp_path / "f.tsv"), "-o", str(tmp_path / "o.tsv"), "-f", str(tmp_path / "p.txt")]) == 1
+    assert main(["inspect", "-i", str(tmp_path / "missing.tsv")]) == 1
+    assert capsys.readouterr().err.count("Error during processing:") == 2
+
+
 def test_empty_annotation_files_need_no_device(tmp_path):
     """the csv writer emits the header with the first record only: a run without rows leaves an EMPTY file, and the steps take it"""
     from barbell_amd import steps
