@@ -161,6 +161,32 @@ class Demuxer:
             self._check(rc)
             return rows[: nr.value]
 
+    def demux_nibbles(self, bases, offsets):
+        """bb_annotate_batch_packed: the same batch with every read packed two bases per byte by bb_pack_bases (half the PCIe bytes; the
+        kernels only look at a character's IUPAC base set, so the rows are demux_packed's)"""
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = len(offsets) - 1
+        lens = (offsets[1:] - offsets[:-1]).astype(np.uint64)
+        poff = np.zeros(n + 1, dtype=np.uint64)
+        poff[1:] = np.cumsum((lens + np.uint64(1)) // np.uint64(2), dtype=np.uint64)
+        packed = np.zeros(int(poff[n]) + 16, dtype=np.uint8)
+        L = lib()
+        for i in range(n):
+            wrote = L.bb_pack_bases(bases.ctypes.data + int(offsets[i]), int(lens[i]), packed.ctypes.data + int(poff[i]))
+            assert wrote == (int(lens[i]) + 1) // 2
+        rel = offsets - offsets[0]
+        cap = 4 * n + 64
+        while True:
+            rows = np.zeros(cap, dtype=_abi.ROW_DTYPE)
+            got = C.c_uint64(0)
+            rc = L.bb_annotate_batch_packed(self._ctx(), packed.ctypes.data, poff.ctypes.data, rel.ctypes.data, n, rows.ctypes.data, cap, C.byref(got))
+            if rc == _abi.BB_E_CAPACITY:
+                cap = int(got.value)
+                continue
+            self._check(rc)
+            return rows[: got.value].copy()
+
     def demux_batch(self, reads):
         return self.demux_packed(*_abi.pack_reads(reads))
 
@@ -221,6 +247,10 @@ class Demuxer:
         f, t, k = C.c_uint64(), C.c_uint64(), C.c_int()
         self._check(lib().bb_last_scan_stats(self._ctx(), g, C.byref(f), C.byref(t), C.byref(k)))
         return {"flagged_pieces": f.value, "total_pieces": t.value, "kind": k.value}
+
+    def host_syncs(self):
+        """how often the host waited for the device inside the last batch call (bb_last_host_syncs)"""
+        return int(lib().bb_last_host_syncs(self._ctx()))
 
     def length_stats(self):
         """the last batch's read lengths as the scans saw them: {min_lines, max_lines, work_items} (128-byte lines; work items = reads, or

@@ -3,6 +3,7 @@
 // No CPU fallback: every entry point that computes needs the GPU and fails loudly without it.
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -21,6 +22,7 @@
 #include "bb_common.h"
 #include "bb_ctx.h"
 #include "bb_launch.h"
+#include "bb_lenstat.h"
 #include "bb_k_rows.h"
 #include "bb_k_misc.h"
 #include "bb_synth.h"
@@ -135,6 +137,7 @@ void build_synth_tables(const std::vector<std::vector<std::string>>& seqs, bb_sy
     }
 }
 
+int ensure_ctl(bb_ctx* c, uint64_t flag_words);
 int upload_tables(bb_ctx* c) {
     Blob blob;
     c->gdev.resize(c->groups.size());
@@ -327,11 +330,8 @@ int upload_tables(bb_ctx* c) {
     HIPCHK(c, hipMemcpy(c->d_groups, c->gdev.data(), sizeof(bb_group_dev) * c->gdev.size(), hipMemcpyHostToDevice));
     HIPCHK(c, hipMalloc((void**)&c->d_counts, sizeof(unsigned long long) * c->counts_len));
     HIPCHK(c, hipMemset(c->d_counts, 0, sizeof(unsigned long long) * c->counts_len));
-    HIPCHK(c, hipMalloc((void**)&c->d_hitcount, 16));
-    HIPCHK(c, hipMalloc((void**)&c->d_listcnt, sizeof(uint32_t) * 4 * BB_MAX_GROUPS));
-    HIPCHK(c, hipMalloc((void**)&c->d_fbcnt, sizeof(uint32_t) * 4 * BB_MAX_GROUPS));
-    HIPCHK(c, hipMalloc((void**)&c->d_vqueue, sizeof(uint32_t) * 4));
-    HIPCHK(c, hipMalloc((void**)&c->d_nflag, sizeof(unsigned long long) * BB_MAX_GROUPS));
+    { int r = ensure_ctl(c, 0); if (r != BB_OK) return r; }
+    HIPCHK(c, hipHostMalloc((void**)&c->h_ctl, sizeof(bb_ctl), hipHostMallocDefault));
     // synth tables
     std::vector<std::vector<std::string>> seqs;
     for (auto& g : c->groups) seqs.push_back(g.seqs);
@@ -342,6 +342,20 @@ int upload_tables(bb_ctx* c) {
     return BB_OK;
 }
 
+// the control block and, behind it, `flag_words` words for the filtered groups' flags: one allocation, one memset per batch (bb_ctl)
+int ensure_ctl(bb_ctx* c, uint64_t flag_words) {
+    if (c->d_ctl && flag_words <= c->cap_flags) return BB_OK;
+    if (c->d_ctl) HIPCHK(c, hipFree(c->d_ctl));
+    c->d_ctl = nullptr;
+    const uint64_t cap = flag_words + flag_words / 4 + 64;
+    uint8_t* p = nullptr;
+    HIPCHK(c, hipMalloc((void**)&p, BB_CTL_BYTES + cap * sizeof(uint32_t)));
+    c->d_ctl = reinterpret_cast<bb_ctl*>(p);
+    c->d_flags = reinterpret_cast<uint32_t*>(p + BB_CTL_BYTES); c->cap_flags = cap;
+    c->d_hitcount = c->d_ctl->hitcount; c->d_vqueue = c->d_ctl->vqueue; c->d_nflag = c->d_ctl->nflag;
+    c->d_listcnt = c->d_ctl->listcnt; c->d_fbcnt = c->d_ctl->fbcnt;
+    return BB_OK;
+}
 int ensure_reads(bb_ctx* c, uint32_t n) {
     const uint64_t M = (uint64_t)n * c->groups.size() * 2 + 1;
     if (M > c->cap_m) {
@@ -393,6 +407,36 @@ void mark(bb_ctx* c, int i) {
 }
 
 }  // namespace
+
+// What k_len_hist (bb_len.h) computes, from offsets the host holds: the staging buffer is 128-byte aligned, so a read's first line begins
+// (offset mod 128) bytes before it.  Same record, same decisions downstream (bb_prepare_lengths).
+static void bb_host_lenstat(const uint64_t* offsets, uint32_t n, uint32_t seg_lines, uint32_t split_above, bb_lenstat* st) {
+    memset(st, 0, sizeof *st);
+    st->off0 = offsets[0]; st->off1 = offsets[n];
+    uint32_t lo = 0xFFFFFFFFu, hi = 0u;
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint64_t off = offsets[i];
+        const uint32_t len = (uint32_t)(offsets[i + 1] - off);
+        const uint32_t nl = len ? (uint32_t)(((off & 127u) + len + 127u) >> 7) : 0u;
+        lo = std::min(lo, nl); hi = std::max(hi, nl);
+        if (nl <= split_above) { if (nl < BB_LEN_SEG_BINS) ++st->seg[nl]; }
+        else {
+            const uint32_t nseg = (nl + seg_lines - 1u) / seg_lines;
+            st->seg[seg_lines] += nseg - 1u;
+            ++st->seg[nl - (nseg - 1u) * seg_lines];
+            ++st->n_cut_reads; st->n_cut_segs += nseg;
+        }
+    }
+    st->min_nl = lo; st->max_nl = hi;
+}
+
+static inline double bb_now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// A binding's worker threads hold a context each (annotator.rs:88-101 keeps one Demuxer per thread) and every context owns two streams; HIP spreads a
+// process's streams over FOUR hardware queues unless told otherwise, and streams that share a queue run one after the other.  Measured (round 6,
+// ten threads, 8 192-read calls): 9.1 M reads/s on four queues, 13.1 M on sixteen.  The runtime reads the variable when it initialises, so
+// it is set when this library is loaded, and only if the process has not chosen a value itself.
+__attribute__((constructor)) static void bb_more_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
 
 static thread_local std::string g_create_error;  // why the last bb_create on this thread failed (bb_last_error(NULL))
 
@@ -465,6 +509,10 @@ int bb_create_policy(const bb_group_desc* groups, uint32_t n_groups, const bb_pa
         c->seg_lines = v <= 0 ? 0u : (uint32_t)std::min(64, std::max(4, v & ~3));
         c->split_above = 2u * c->seg_lines;
     }
+    if (const char* e = getenv("BARBELL_AMD_DEFER_MAX")) c->defer_max = (uint32_t)strtoul(e, nullptr, 10);
+    if (const char* e = getenv("BARBELL_AMD_SMALL_PFX_MAX")) c->small_pfx_max = (uint32_t)strtoul(e, nullptr, 10);
+    if (const char* e = getenv("BARBELL_AMD_HOST_LEN_MAX")) c->host_len_max = (uint32_t)strtoul(e, nullptr, 10);
+    c->phases = getenv("BARBELL_AMD_PHASES") && atoi(getenv("BARBELL_AMD_PHASES")) != 0;
     if (const char* e = getenv("BARBELL_AMD_LANE_FB_FRAC")) c->lane_fb_frac = atof(e);
     if (const char* e = getenv("BARBELL_AMD_LANE")) c->lane_kernel = std::max(0, std::min(2, atoi(e)));
     if (const char* e = getenv("BARBELL_AMD_LANE_NM")) c->lane_nm = atoi(e) != 0;
@@ -511,12 +559,14 @@ int bb_create_policy(const bb_group_desc* groups, uint32_t n_groups, const bb_pa
 void bb_destroy(bb_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    void* ptrs[] = {c->d_groups, c->d_tables, c->d_counts, c->d_cnt, c->d_base, c->d_sums, c->d_nrows, c->d_rowoff, c->d_hitcount,
-                    c->d_lists, c->d_listcnt, c->d_fb_lists, c->d_fbcnt, c->d_flags, c->d_vqueue, c->d_nflag, c->d_lenstat, c->d_lencur, c->d_vtab, c->d_vcut, c->d_cutread, c->d_cutlist, c->d_vcnt, c->d_raw, c->d_hits, c->d_hitmeta, c->d_pfx, c->d_rows, c->d_in_bases, c->d_in_offsets, c->d_out_rows,
+    void* ptrs[] = {c->d_groups, c->d_tables, c->d_counts, c->d_cnt, c->d_base, c->d_sums, c->d_nrows, c->d_rowoff, c->d_ctl,
+                    c->d_lists, c->d_fb_lists, c->d_lenstat, c->d_lencur, c->d_vtab, c->d_vcut, c->d_cutread, c->d_cutlist, c->d_vcnt, c->d_raw, c->d_hits, c->d_hitmeta, c->d_pfx, c->d_rows, c->d_in_bases, c->d_in_offsets, c->d_out_rows, c->d_in_packed, c->d_in_poffs,
                     c->d_synth_table, c->d_fpats, c->d_felems, c->d_flabel_ok, c->d_flabel_ids, c->d_frows, c->d_fout, c->d_iout};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (c->h_lencur) (void)hipHostFree(c->h_lencur);
+    if (c->h_ctl) (void)hipHostFree(c->h_ctl);
+    delete c->host_len;
     bb_trim_state_free(c->trim);
     bb_fastq_state_free(c->fastq);
     bb_format_state_free(c->format);
@@ -558,145 +608,180 @@ int bb_annotate_batch_dev(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_o
                           uint64_t rows_cap, uint64_t* n_rows) {
     if (!c || !d_offsets || !n_rows || (!d_bases && n)) return BB_E_INVALID;
     *n_rows = 0;
+    bb_row* const spec_dst = c->spec_dst;   // (set by the host-pointer form for this call only)
+    const uint64_t spec_cap = c->spec_cap;
+    c->spec_dst = nullptr; c->spec_cap = 0; c->spec_done = 0;
     if (n == 0) return BB_OK;
     HIPCHK(c, hipSetDevice(c->device));
+    bb_call_scope scope(c);
     const uint32_t G = (uint32_t)c->groups.size();
     int r;
     if ((r = ensure_reads(c, n))) return r;
     if ((r = ensure_hits(c, (uint64_t)n * 3 + 1024))) return r;
     const uint64_t M = (uint64_t)n * G * 2 + 1;
+    // DEFERRED (bb_ctx::defer_max): a small batch's kernels take tens of microseconds each and its host thread's waits and launches the rest; nothing
+    // between here and the rows waits for the device
+    const bool deferred = n <= c->defer_max;
+    c->batch_no_lane = n <= c->small_pfx_max;
     uint32_t n_hits = 0;
-    uint64_t flag_words = 0, batch_bytes = 0;  // per strand
+    uint64_t flag_words = 0, batch_bytes = 0, flag_total = 0;  // per strand; of all filtered groups
+    double pt[5] = {c->phases ? bb_now() : 0.0, 0, 0, 0, 0};
     {
-        // the batch's byte span and read lengths (bb_len.h: segments / reads sorted by length where they differ), one round trip
+        // the batch's byte span and read lengths (bb_len.h: segments / reads sorted by length where they differ): one round trip, or none where the
+        // host-pointer form took them from the offsets it holds
         uint64_t ends[2] = {0, 0};
         if ((r = bb_prepare_lengths(c, d_bases, d_offsets, n, &ends[0], &ends[1]))) return r;
         batch_bytes = ends[1] - ends[0];
-        bool any_filt = false;
-        for (uint32_t g = 0; g < G; ++g) any_filt = any_filt || c->gdev[g].filt_rows > 0;
-        if (any_filt) {  // the flag words of a read sit at (offset >> 9) + 3 * read: the batch's byte span sizes the array
+        if (c->phases) pt[1] = bb_now();
+        uint64_t n_filt = 0;   // one region of flag words per filtered group (their filter passes run as one launch)
+        for (uint32_t g = 0; g < G; ++g) n_filt += c->gdev[g].filt_rows > 0 ? 1 : 0;
+        if (n_filt) {  // the flag words of a read sit at (offset >> 9) + 3 * read: the batch's byte span sizes the array
             flag_words = ((ends[1] - ends[0]) >> 9) + 3ull * n + 3;
-            uint64_t n_filt = 0;   // one region of flag words per filtered group (their filter passes run as one launch)
-            for (uint32_t g = 0; g < G; ++g) n_filt += c->gdev[g].filt_rows > 0 ? 1 : 0;
-            if ((r = grow(c, c->d_flags, c->cap_flags, 2 * flag_words * n_filt))) return r;
+            flag_total = 2 * flag_words * n_filt;
+            if ((r = ensure_ctl(c, flag_total))) return r;
         }
     }
-    for (int attempt = 0;; ++attempt) {
-        mark(c, K_SCAN);
-        HIPCHK(c, hipMemsetAsync(c->d_hitcount, 0, 16, c->stream));
-        HIPCHK(c, hipMemsetAsync(c->d_cnt + (M - 1), 0, 4, c->stream));
-        if ((r = bb_launch_scans(c, d_bases, d_offsets, n, flag_words, batch_bytes))) return r;   // every group's flank scan (bb_tu_scan.hip)
-        HIPCHK(c, hipGetLastError());
-        mark(c, K_PREFIX);
-        HIPCHK(c, hipMemcpyAsync(&n_hits, c->d_hitcount, 4, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        if (n_hits <= c->cap_hits) break;
-        if (attempt > 2) { c->last_error = "flank hit buffer overflow"; return BB_E_HIP; }
-        if ((r = ensure_hits(c, (uint64_t)n_hits + 1024))) return r;
-    }
-    if ((r = bb_scan_u32(c, c->d_cnt, c->d_base, M))) return r;
-    mark(c, K_TRACE);
-    if (n_hits) {
-        uint32_t done = 0;
-        for (uint32_t g = 0; g < G; ++g) {
-            if ((done >> g) & 1u) continue;
-            const int W = c->gdev[g].W, mode = bb_trace_mode(c, g);
-            uint32_t gmask = 0;
-            for (uint32_t g2 = g; g2 < G; ++g2)
-                if (c->gdev[g2].W == W && bb_trace_mode(c, g2) == mode) gmask |= 1u << g2;
-            done |= gmask;
-            bb_launch_trace(c, d_bases, d_offsets, n_hits, gmask, mode, W);
-        }
-        HIPCHK(c, hipGetLastError());
-    }
-    mark(c, K_LISTS);
     bool any_split = false;
     for (uint32_t g = 0; g < G; ++g) any_split = any_split || c->gdev[g].split[0] || c->gdev[g].split[1];
-    bool any_split_prefix = any_split;  // k_bar_prefix over every hit
-    c->use_lists = true;  // one list per (group, strand)
-    bool all_lane = any_split;
-    for (uint32_t g = 0; g < G; ++g)
-        for (uint32_t sd = 0; sd < 2; ++sd)
-            if (c->gdev[g].split[sd]) {
-                const uint32_t win_max = c->groups[g].info.mask_len + (uint32_t)c->groups[g].info.flank_k + 2 * BB_PADDING - 1;
-                if (!(c->gdev[g].WB == 2 && !c->force_generic && !c->generic_barcode && bb_takes_lane(c, g, sd, false) && win_max <= 63 &&
-                      (win_max <= 48 || bb_takes_lane(c, g, sd, true)))) all_lane = false;
-            }
-    c->lazy_prefix = all_lane && !getenv("BARBELL_AMD_FULL_PREFIX");
-    if (c->lazy_prefix) any_split_prefix = false;
-    const bool prefix_aside = n_hits && any_split_prefix && c->side != nullptr;  // k_bar_prefix needs the hits, not their lists: alongside k_hit_lists
-    if (prefix_aside) {
-        HIPCHK(c, hipEventRecord(c->ev_fork, c->stream)); HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_fork, 0));
-        bb_launch_bar_prefix(c, n_hits, c->side);
-        HIPCHK(c, hipEventRecord(c->ev_join, c->side));
-    }
-    if (n_hits) {
-        HIPCHK(c, hipMemsetAsync(c->d_listcnt, 0, sizeof(uint32_t) * 4 * BB_MAX_GROUPS, c->stream));
-        hipLaunchKernelGGL(k_hit_lists, dim3((n_hits + 255) / 256), dim3(256), 0, c->stream, (const uint32_t*)c->d_hitmeta, n_hits,
-                           c->d_rows, c->d_lists, c->cap_hits, c->d_listcnt, G, (const bb_group_dev*)c->d_groups);
-    }
-    mark(c, K_BARCODE);
-    c->n_lev = 0;
-    if (prefix_aside) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
-    if (n_hits) {
-        if (any_split_prefix && !prefix_aside)  // shared rows of the padded barcodes, once per hit
-            bb_launch_bar_prefix(c, n_hits, c->stream);
-        for (int pass = 0; pass < 2; ++pass) {
-            if (pass == 1) {
-                if (!(any_split && c->fast_path)) break;
-                // the exact score of every hit's best-bounded barcode; rows of the hits the bounds decide (k_barcode_lane has done that itself)
-                if (c->pfx_fast_launches)
-                    hipLaunchKernelGGL(k_rows, dim3((n_hits + 255) / 256), dim3(256), 0, c->stream, (const bb_group_dev*)c->d_groups, (const bb_hit*)c->d_hits,
-                                       n_hits, c->d_rows, c->params.min_score, c->params.min_score_diff, c->fast_margin, c->d_fb_lists, c->cap_hits, c->d_fbcnt);
-            } else {
-                c->pfx_fast_launches = 0;
-                if (any_split && c->fast_path) HIPCHK(c, hipMemsetAsync(c->d_fbcnt, 0, sizeof(uint32_t) * 4 * BB_MAX_GROUPS, c->stream));  // before the fork
-            }
-            const bool fork = c->side != nullptr;  // pass 1: the two strands' exact launches are small (the undecided hits) and overlap entirely
-            if (fork) { HIPCHK(c, hipEventRecord(c->ev_fork, c->stream)); HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_fork, 0)); }
-            c->use_side = fork;
-            for (uint32_t g = 0; g < G; ++g) {
-                bb_launch_barcode(c, d_bases, d_offsets, n_hits, g, pass);
-            }
-            c->use_side = false;
-            if (fork) { HIPCHK(c, hipEventRecord(c->ev_join, c->side)); HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0)); }
-        }
-        HIPCHK(c, hipGetLastError());
-    }
-    mark(c, K_COLLAPSE);
-    hipLaunchKernelGGL(k_collapse, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->d_rows, (const uint32_t*)c->d_base, n, G,
-                       c->d_nrows);
-    HIPCHK(c, hipMemsetAsync(c->d_nrows + n, 0, 4, c->stream));
-    if ((r = bb_scan_u32(c, c->d_nrows, c->d_rowoff, (uint64_t)n + 1))) return r;
+    const uint32_t* const hits_dev = deferred ? c->d_hitcount : nullptr;   // BB_HITS_ON_DEVICE
     uint32_t total = 0;
-    uint32_t h_listed[4 * BB_MAX_GROUPS], h_undecided[4 * BB_MAX_GROUPS];
-    const bool fb_stats = n_hits && c->fast_path && c->lane_kernel == 1;
-    if (fb_stats) {
-        HIPCHK(c, hipMemcpyAsync(h_listed, c->d_listcnt, sizeof(uint32_t) * 4 * G, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipMemcpyAsync(h_undecided, c->d_fbcnt, sizeof(uint32_t) * 4 * G, hipMemcpyDeviceToHost, c->stream));
+    for (int attempt = 0;; ++attempt) {
+        mark(c, K_SCAN);
+        // every counter of the batch and the filter's flag words: one memset (bb_ctl)
+        HIPCHK(c, hipMemsetAsync(c->d_ctl, 0, BB_CTL_BYTES + flag_total * sizeof(uint32_t), c->stream));
+        if ((r = bb_launch_scans(c, d_bases, d_offsets, n, flag_words, batch_bytes, deferred))) return r;   // every group's flank scan (bb_tu_scan.hip)
+        HIPCHK(c, hipGetLastError());
+        mark(c, K_PREFIX);
+        if (!deferred) {
+            HIPCHK(c, hipMemcpyAsync(&n_hits, c->d_hitcount, 4, hipMemcpyDeviceToHost, c->stream));
+            BB_SYNC(c, c->stream);
+            if (n_hits > c->cap_hits) {
+                if (attempt > 2) { c->last_error = "flank hit buffer overflow"; return BB_E_HIP; }
+                if ((r = ensure_hits(c, (uint64_t)n_hits + 1024))) return r;
+                continue;
+            }
+        } else n_hits = c->cap_hits;   // an upper bound: the kernels read the count (hits_dev)
+        if (c->phases) pt[2] = bb_now();
+        if ((r = bb_scan_u32(c, c->d_cnt, c->d_base, M))) return r;
+        mark(c, K_TRACE);
+        if (n_hits) {
+            uint32_t done = 0;
+            for (uint32_t g = 0; g < G; ++g) {
+                if ((done >> g) & 1u) continue;
+                const int W = c->gdev[g].W, mode = bb_trace_mode(c, g);
+                uint32_t gmask = 0;
+                for (uint32_t g2 = g; g2 < G; ++g2)
+                    if (c->gdev[g2].W == W && bb_trace_mode(c, g2) == mode) gmask |= 1u << g2;
+                done |= gmask;
+                bb_launch_trace(c, d_bases, d_offsets, n_hits, gmask, mode, W, hits_dev);
+            }
+            HIPCHK(c, hipGetLastError());
+        }
+        mark(c, K_LISTS);
+        bool any_split_prefix = any_split;  // k_bar_prefix over every hit
+        c->use_lists = true;  // one list per (group, strand)
+        bool all_lane = any_split;
+        for (uint32_t g = 0; g < G; ++g)
+            for (uint32_t sd = 0; sd < 2; ++sd)
+                if (c->gdev[g].split[sd]) {
+                    const uint32_t win_max = c->groups[g].info.mask_len + (uint32_t)c->groups[g].info.flank_k + 2 * BB_PADDING - 1;
+                    if (!(c->gdev[g].WB == 2 && !c->force_generic && !c->generic_barcode && bb_takes_lane(c, g, sd, false) && win_max <= 63 &&
+                          (win_max <= 48 || bb_takes_lane(c, g, sd, true)))) all_lane = false;
+                }
+        c->lazy_prefix = all_lane && !getenv("BARBELL_AMD_FULL_PREFIX");
+        if (c->lazy_prefix) any_split_prefix = false;
+        // the second stream pays where launches are long enough to have a tail worth filling; in a small batch every fork and join is two more calls of a
+        // host thread that has nothing else to spend
+        hipStream_t const side = c->batch_no_lane ? nullptr : c->side;
+        const bool prefix_aside = n_hits && any_split_prefix && side != nullptr;  // k_bar_prefix needs the hits, not their lists: alongside k_hit_lists
+        if (prefix_aside) {
+            HIPCHK(c, hipEventRecord(c->ev_fork, c->stream)); HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_fork, 0));
+            bb_launch_bar_prefix(c, n_hits, c->side, hits_dev);
+            HIPCHK(c, hipEventRecord(c->ev_join, c->side));
+        }
+        if (n_hits)
+            hipLaunchKernelGGL(k_hit_lists, dim3((n_hits + 255) / 256), dim3(256), 0, c->stream, (const uint32_t*)c->d_hitmeta, n_hits,
+                               c->d_rows, c->d_lists, c->cap_hits, c->d_listcnt, G, (const bb_group_dev*)c->d_groups, hits_dev);
+        mark(c, K_BARCODE);
+        c->n_lev = 0;
+        if (prefix_aside) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
+        if (n_hits) {
+            if (any_split_prefix && !prefix_aside)  // shared rows of the padded barcodes, once per hit
+                bb_launch_bar_prefix(c, n_hits, c->stream, hits_dev);
+            for (int pass = 0; pass < 2; ++pass) {
+                if (pass == 1) {
+                    if (!(any_split && c->fast_path)) break;
+                    // the exact score of every hit's best-bounded barcode; rows of the hits the bounds decide (k_barcode_lane has done that itself)
+                    if (c->pfx_fast_launches)
+                        hipLaunchKernelGGL(k_rows, dim3((n_hits + 255) / 256), dim3(256), 0, c->stream, (const bb_group_dev*)c->d_groups, (const bb_hit*)c->d_hits,
+                                           n_hits, c->d_rows, c->params.min_score, c->params.min_score_diff, c->fast_margin, c->d_fb_lists, c->cap_hits, c->d_fbcnt, hits_dev);
+                } else c->pfx_fast_launches = 0;
+                const bool fork = side != nullptr;  // pass 1: the two strands' exact launches are small (the undecided hits) and overlap entirely
+                if (fork) { HIPCHK(c, hipEventRecord(c->ev_fork, c->stream)); HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_fork, 0)); }
+                c->use_side = fork;
+                for (uint32_t g = 0; g < G; ++g) {
+                    bb_launch_barcode(c, d_bases, d_offsets, n_hits, g, pass);
+                }
+                c->use_side = false;
+                if (fork) { HIPCHK(c, hipEventRecord(c->ev_join, c->side)); HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0)); }
+            }
+            HIPCHK(c, hipGetLastError());
+        }
+        mark(c, K_COLLAPSE);
+        hipLaunchKernelGGL(k_collapse, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->d_rows, (const uint32_t*)c->d_base, n, G,
+                           c->d_nrows, hits_dev, c->cap_hits);
+        if ((r = bb_scan_u32(c, c->d_nrows, c->d_rowoff, (uint64_t)n + 1, &c->d_ctl->total_rows))) return r;
+        if (deferred) {
+            // rows out and counted on the device's own say-so (k_emit checks what the host is about to read), the batch's numbers into the page-locked
+            // twin, the first rows to a host caller's buffer: then the batch's one wait
+            mark(c, K_EMIT);
+            if (d_rows)
+                hipLaunchKernelGGL(k_emit, dim3((n + 255) / 256), dim3(256), (size_t)c->counts_len * 4, c->stream, (const bb_rowtmp*)c->d_rows,
+                                   (const uint32_t*)c->d_base, (const uint32_t*)c->d_rowoff, n, G, (const bb_group_dev*)c->d_groups, d_rows,
+                                   c->d_counts, c->counts_len, hits_dev, c->cap_hits, rows_cap);
+            mark(c, K_COUNT);
+            HIPCHK(c, hipGetLastError());
+        }
+        HIPCHK(c, hipMemcpyAsync(c->h_ctl, c->d_ctl, sizeof(bb_ctl), hipMemcpyDeviceToHost, c->stream));
+        const uint64_t spec = deferred && spec_dst && d_rows ? std::min<uint64_t>(std::min(spec_cap, rows_cap), 2ull * n + 64) : 0;
+        if (spec) HIPCHK(c, hipMemcpyAsync(spec_dst, d_rows, spec * sizeof(bb_row), hipMemcpyDeviceToHost, c->stream));
+        BB_SYNC(c, c->stream);
+        if (deferred && c->h_ctl->hitcount[0] > c->cap_hits) {   // the kernels after the scans left at once; again, with room
+            if (attempt > 2) { c->last_error = "flank hit buffer overflow"; return BB_E_HIP; }
+            if ((r = ensure_hits(c, (uint64_t)c->h_ctl->hitcount[0] + 1024))) return r;
+            continue;
+        }
+        total = c->h_ctl->total_rows;
+        c->spec_done = spec;
+        break;
     }
-    HIPCHK(c, hipMemcpyAsync(&total, c->d_rowoff + n, 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
     *n_rows = total;
+    if (c->phases) pt[3] = bb_now();
+    if (deferred) bb_note_flag_counts(c, c->h_ctl->nflag);
+    const bool fb_stats = c->fast_path && c->lane_kernel == 1;
     for (uint32_t g = 0; g < G; ++g)
         for (uint32_t sd = 0; sd < 2; ++sd) {
             if (c->lane_off[g][sd]) --c->lane_off[g][sd];
             if (fb_stats) {
+                const uint32_t *h_listed = c->h_ctl->listcnt, *h_undecided = c->h_ctl->fbcnt;
                 const uint64_t listed = (uint64_t)h_listed[4 * g + sd] + h_listed[4 * g + 2 + sd], und = (uint64_t)h_undecided[4 * g + sd] + h_undecided[4 * g + 2 + sd];
                 c->last_listed[g][sd] = listed; c->last_undecided[g][sd] = und;
                 if (c->lane_used[g][sd] && listed >= 1024 && (double)und > c->lane_fb_frac * (double)listed) c->lane_off[g][sd] = 32;
             }
             c->lane_used[g][sd] = 0;
         }
-    mark(c, K_EMIT);
     if (total > rows_cap || (total && !d_rows)) return BB_E_CAPACITY;
-    if (total)
-        hipLaunchKernelGGL(k_emit, dim3((n + 255) / 256), dim3(256), (size_t)c->counts_len * 4, c->stream, (const bb_rowtmp*)c->d_rows,
-                           (const uint32_t*)c->d_base, (const uint32_t*)c->d_rowoff, n, G, (const bb_group_dev*)c->d_groups, d_rows,
-                           c->d_counts, c->counts_len);
-    mark(c, K_COUNT);
-    HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (!deferred) {
+        mark(c, K_EMIT);
+        if (total)
+            hipLaunchKernelGGL(k_emit, dim3((n + 255) / 256), dim3(256), (size_t)c->counts_len * 4, c->stream, (const bb_rowtmp*)c->d_rows,
+                               (const uint32_t*)c->d_base, (const uint32_t*)c->d_rowoff, n, G, (const bb_group_dev*)c->d_groups, d_rows,
+                               c->d_counts, c->counts_len, (const uint32_t*)nullptr, 0u, (uint64_t)0);
+        mark(c, K_COUNT);
+        HIPCHK(c, hipGetLastError());
+        BB_SYNC(c, c->stream);
+    }
+    if (c->phases) { pt[4] = bb_now(); for (int i = 0; i < 4; ++i) c->ph[3 + i] += pt[i + 1] - pt[i]; }
     if (c->timing) {
         for (int i = 0; i < K_COUNT; ++i) (void)hipEventElapsedTime(&c->ms[i], c->ev[i], c->ev[i + 1]);
         c->dom_ms = 0.f; c->dom_name[0] = 0;
@@ -708,25 +793,60 @@ int bb_annotate_batch_dev(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_o
     return BB_OK;
 }
 
-// One chunk of a host batch, synchronous: H2D, pipeline, rows D2H.
+// One chunk of a host batch, synchronous: H2D, pipeline, rows D2H.  Everything goes over the context's own stream: a copy on the null stream
+// waits for every other context's stream on the device, and a binding's worker threads (one context each) would run one after the other.
+// (Measured, round 6: HIP's own path for pageable memory moves a 4 MB batch in 0.29 ms; copying it through page-locked slots of the context
+// first took 1.3 ms — not kept.)
+// packed != nullptr: the reads come two bases per byte (bb_pack.h; read i at packed + packed_offsets[i], offsets zero-based in BASES) and are
+// spread to one byte per base in HBM before anything looks at them — half the bytes over PCIe.
 static int annotate_host_chunk(bb_ctx* c, const uint8_t* bases, const uint64_t* offsets, uint32_t n, bb_row* rows, uint64_t rows_cap,
-                               uint64_t* n_rows) {
+                               uint64_t* n_rows, const uint8_t* packed = nullptr, const uint64_t* packed_offsets = nullptr) {
     const uint64_t nb = offsets[n];
     int r;
+    const double t0 = c->phases ? bb_now() : 0.0;
     if ((r = grow(c, c->d_in_bases, c->cap_in_bases, nb + 16))) return r;
     if ((r = grow(c, c->d_in_offsets, c->cap_in_offsets, (uint64_t)n + 1))) return r;
     uint64_t want = rows_cap < (uint64_t)n * 4 + 64 ? rows_cap : (uint64_t)n * 4 + 64;
     if ((r = grow(c, c->d_out_rows, c->cap_out_rows, want ? want : 1))) return r;
-    HIPCHK(c, hipMemcpyAsync(c->d_in_bases, bases, nb, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->d_in_offsets, offsets, ((uint64_t)n + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    if (packed) {
+        const uint64_t pb = packed_offsets[n] - packed_offsets[0];
+        if ((r = grow(c, c->d_in_packed, c->cap_in_packed, pb + 16))) return r;
+        if ((r = grow(c, c->d_in_poffs, c->cap_in_poffs, (uint64_t)n + 1))) return r;
+        HIPCHK(c, hipMemcpyAsync(c->d_in_packed, packed + packed_offsets[0], pb, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->d_in_poffs, packed_offsets, ((uint64_t)n + 1) * 8, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->d_in_offsets, offsets, ((uint64_t)n + 1) * 8, hipMemcpyHostToDevice, c->stream));
+        // (the kernel subtracts nothing: the device copy of the packed bytes starts at the batch's first read)
+        bb_launch_unpack_reads(c->stream, c->d_in_packed - packed_offsets[0], c->d_in_poffs, c->d_in_offsets, n, c->d_in_bases);
+        HIPCHK(c, hipGetLastError());
+    } else {
+        HIPCHK(c, hipMemcpyAsync(c->d_in_bases, bases, nb, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->d_in_offsets, offsets, ((uint64_t)n + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    }
+    if (n <= c->host_len_max && ((uintptr_t)c->d_in_bases & 127u) == 0) {
+        // the batch's length statistics from the offsets in hand (bb_host_lenstat) instead of a kernel and a round trip
+        if (!c->host_len) c->host_len = new bb_lenstat;
+        const uint32_t seg_lines = c->seg_lines ? c->seg_lines : 32u, split_above = c->seg_lines ? c->split_above : 0xFFFFFFFFu;
+        bb_host_lenstat(offsets, n, seg_lines, split_above, c->host_len);
+        c->host_len_valid = true;
+    }
+    const double t1 = c->phases ? bb_now() : 0.0;
     uint64_t dev_cap = c->cap_out_rows < rows_cap ? c->cap_out_rows : rows_cap;
+    c->spec_dst = rows; c->spec_cap = rows_cap;   // a deferred batch copies its first rows before its one wait
     r = bb_annotate_batch_dev(c, c->d_in_bases, c->d_in_offsets, n, c->d_out_rows, dev_cap, n_rows);
+    c->host_len_valid = false;
+    uint64_t have = c->spec_done;
     if (r == BB_E_CAPACITY && *n_rows <= rows_cap) {  // staging buffer was the limit, not the caller's
         if ((r = grow(c, c->d_out_rows, c->cap_out_rows, *n_rows))) return r;
         r = bb_annotate_batch_dev(c, c->d_in_bases, c->d_in_offsets, n, c->d_out_rows, c->cap_out_rows, n_rows);
+        have = 0;
     }
     if (r != BB_OK) return r;
-    if (*n_rows) HIPCHK(c, hipMemcpy(rows, c->d_out_rows, *n_rows * sizeof(bb_row), hipMemcpyDeviceToHost));
+    const double t2 = c->phases ? bb_now() : 0.0;
+    if (*n_rows > have) {
+        HIPCHK(c, hipMemcpyAsync(rows + have, c->d_out_rows + have, (*n_rows - have) * sizeof(bb_row), hipMemcpyDeviceToHost, c->stream));
+        BB_SYNC(c, c->stream);
+    }
+    if (c->phases) { const double t3 = bb_now(); c->ph[0] += t1 - t0; c->ph[1] += t2 - t1; c->ph[2] += t3 - t2; ++c->ph_calls; }
     return BB_OK;
 }
 
@@ -739,6 +859,7 @@ int bb_annotate_batch(bb_ctx* c, const uint8_t* bases, const uint64_t* offsets, 
     *n_rows = 0;
     if (n == 0) return BB_OK;
     HIPCHK(c, hipSetDevice(c->device));
+    bb_call_scope scope(c);
     const uint64_t total_bytes = offsets[n] - offsets[0];
     const uint64_t chunk_bytes = 256ull << 20;
     if (total_bytes <= 2 * chunk_bytes || n < 8192) {
@@ -842,6 +963,64 @@ int bb_annotate_batch(bb_ctx* c, const uint8_t* bases, const uint64_t* offsets, 
     return r;
 }
 
+// The host-pointer boundary with the sequences two bases per byte (bb_pack_bases): pieces of at most ~256 MB of bases, one after the other.
+int bb_annotate_batch_packed(bb_ctx* c, const uint8_t* packed, const uint64_t* packed_offsets, const uint64_t* offsets, uint32_t n, bb_row* rows,
+                             uint64_t rows_cap, uint64_t* n_rows) {
+    if (!c || !offsets || !packed_offsets || !n_rows || (!packed && n)) return BB_E_INVALID;
+    *n_rows = 0;
+    if (n == 0) return BB_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    bb_call_scope scope(c);
+    for (uint32_t i = 0; i < n; ++i)   // a read begins at a byte of its own and takes (length + 1) / 2 of them
+        if (offsets[i + 1] < offsets[i] || packed_offsets[i + 1] - packed_offsets[i] < (offsets[i + 1] - offsets[i] + 1) / 2) {
+            c->last_error = "bb_annotate_batch_packed: read " + std::to_string(i) + " has fewer packed bytes than (length + 1) / 2";
+            return BB_E_INVALID;
+        }
+    const uint64_t chunk_bytes = 256ull << 20;
+    std::vector<uint64_t> rel;
+    std::vector<unsigned long long> counts_backup;
+    uint64_t total = 0;
+    bool overflow = false;
+    int r = BB_OK;
+    for (uint32_t f = 0; f < n && r == BB_OK;) {
+        uint32_t e = f + 1;
+        while (e < n && offsets[e + 1] - offsets[f] <= chunk_bytes) ++e;
+        const uint32_t cn = e - f;
+        const bool whole = f == 0 && e == n && offsets[0] == 0;
+        if (!whole) {
+            if (counts_backup.empty()) {   // nothing of a failed call may stay in the histogram
+                counts_backup.resize(c->counts_len);
+                if (hipMemcpy(counts_backup.data(), c->d_counts, sizeof(uint64_t) * c->counts_len, hipMemcpyDeviceToHost) != hipSuccess) { r = BB_E_HIP; break; }
+            }
+            rel.resize((size_t)cn + 1);
+            for (uint32_t i = 0; i <= cn; ++i) rel[i] = offsets[f + i] - offsets[f];
+        }
+        uint64_t got = 0;
+        const uint64_t room = overflow || !rows ? 0 : rows_cap - total;
+        r = annotate_host_chunk(c, nullptr, whole ? offsets : rel.data(), cn, rows ? rows + total : nullptr, room, &got, packed, packed_offsets + f);
+        if (r == BB_E_CAPACITY) { overflow = true; r = BB_OK; }   // keep going to learn the required capacity
+        else if (r == BB_OK && f) for (uint64_t i = 0; i < got; ++i) rows[total + i].read_idx += f;   // piece-local -> batch-local read index
+        total += got;
+        f = e;
+    }
+    *n_rows = total;
+    if (r == BB_OK && overflow) r = BB_E_CAPACITY;
+    if (r != BB_OK && r != BB_E_NOMEM && !counts_backup.empty())
+        (void)hipMemcpy(c->d_counts, counts_backup.data(), sizeof(uint64_t) * c->counts_len, hipMemcpyHostToDevice);
+    return r;
+}
+
+int bb_last_host_syncs(const bb_ctx* c) { return c ? (int)c->last_syncs : BB_E_INVALID; }
+int bb_host_phases(bb_ctx* c, int enable, double* ms, uint64_t* calls) {
+    if (!c) return BB_E_INVALID;
+    if (ms) for (int i = 0; i < BB_N_HOST_PHASES; ++i) ms[i] = 1e3 * c->ph[i];
+    if (calls) *calls = c->ph_calls;
+    for (double& x : c->ph) x = 0.0;
+    c->ph_calls = 0;
+    c->phases = enable != 0;
+    return BB_OK;
+}
+
 uint32_t bb_counts_len(const bb_ctx* c) { return c ? c->counts_len : 0; }
 int bb_counts(bb_ctx* c, uint64_t* out) {
     if (!c || !out) return BB_E_INVALID;
@@ -862,7 +1041,7 @@ int bb_last_barcode_stats(const bb_ctx* c, uint32_t g, uint32_t strand, uint64_t
     if (hits) *hits = c->last_listed[g][strand];
     if (undecided) *undecided = c->last_undecided[g][strand];
     // what the pair's next batch runs: the one-lane-per-hit kernel of the policy's traceback class, where the group is split and the class was built
-    if (lane_kernel) *lane_kernel = c->gdev[g].split[strand] && c->gdev[g].WB == 2 && !c->force_generic && !c->generic_barcode && bb_takes_lane(c, g, strand, false);
+    if (lane_kernel) *lane_kernel = c->gdev[g].split[strand] && c->gdev[g].WB == 2 && !c->force_generic && !c->generic_barcode && bb_lane_eligible(c, g, strand, false);
     return BB_OK;
 }
 

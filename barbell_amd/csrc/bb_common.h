@@ -178,3 +178,16 @@ struct bb_pat_elem_dev {
     bb_cut cuts[BB_MAX_CUTS];
 };
 struct bb_pat_dev { uint32_t first, n; };
+
+// Kernels over the batch's flank hits take the hit count from the host — or, in a DEFERRED batch (no round trip between the scans and the
+// kernels after them: barbell_amd.hip), an upper bound from the host and the count from device memory: blocks beyond the count leave, and so
+// does every block if the count exceeds the bound (= the hit buffers' capacity: slots lie beyond them; the host grows them and runs the batch again).
+#define BB_HITS_ON_DEVICE(n_hits, n_hits_dev, block_items)                                \
+    do {                                                                                  \
+        if (n_hits_dev) {                                                                 \
+            const uint32_t nd_ = *(n_hits_dev);                                           \
+            if (nd_ > (n_hits)) return;                                                   \
+            (n_hits) = nd_;                                                               \
+        }                                                                                 \
+        if ((uint64_t)blockIdx.x * (block_items) >= (n_hits)) return;                     \
+    } while (0)

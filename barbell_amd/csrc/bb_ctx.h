@@ -26,6 +26,20 @@ struct HostGroup {
     uint8_t type;
 };
 
+// The batch's counters, one allocation with the filter's flag words behind them: ONE memset per batch (eight until round 6 — a small batch's
+// host thread spent more time enqueueing them than the device spent on its kernels), and ONE copy back into the page-locked twin when the
+// batch ends (hit count, row count, flag counts, list counts came back in four round trips).
+struct bb_ctl {
+    uint32_t hitcount[4];
+    uint32_t total_rows, pad_[3];
+    uint32_t vqueue[2 * BB_MAX_GROUPS];            // k_flank_verify's item counters, one pair (strands) per group
+    unsigned long long nflag[BB_MAX_GROUPS];       // flagged 16-byte pieces per group (k_flank_filter)
+    uint32_t listcnt[4 * BB_MAX_GROUPS];           // hit lists per (group, window class, strand) (k_hit_lists)
+    uint32_t fbcnt[4 * BB_MAX_GROUPS];             // ... of the hits the fast barcode kernels' bounds left undecided
+};
+#define BB_CTL_BYTES 2048u
+static_assert(sizeof(bb_ctl) <= BB_CTL_BYTES, "the flag words begin BB_CTL_BYTES behind the control block");
+
 struct bb_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -57,6 +71,16 @@ struct bb_ctx {
     uint64_t cap_m = 0;  // entries of cnt/base (n*G*2+1)
     uint32_t cap_reads = 0, cap_hits = 0;
     uint32_t *d_cnt = nullptr, *d_base = nullptr, *d_sums = nullptr, *d_nrows = nullptr, *d_rowoff = nullptr;
+    bb_ctl* d_ctl = nullptr;     // d_hitcount, d_vqueue, d_nflag, d_listcnt, d_fbcnt and d_flags point into this allocation (ensure_ctl)
+    bb_ctl* h_ctl = nullptr;     // page-locked: where the batch's numbers come back to
+    // A batch of up to defer_max reads runs DEFERRED: nothing between the upload and the rows waits for the device — the hit count stays on the
+    // device (launches are sized by the hit buffers' capacity, BB_HITS_ON_DEVICE), every filtered group is verified and its flag count decides for
+    // the NEXT batches, and the batch's numbers come back in one copy at the end.  A batch of up to small_pfx_max reads also takes one lane per
+    // (hit, barcode) in the barcode stage.  BARBELL_AMD_DEFER_MAX / BARBELL_AMD_SMALL_PFX_MAX (0 = never).
+    uint32_t defer_max = 1u << 16, small_pfx_max = 1u << 12;
+    bool batch_no_lane = false;  // the batch in hand: bb_takes_lane says no
+    // host-pointer form of a deferred batch: the first rows are copied to the caller's buffer before the batch's only wait
+    bb_row* spec_dst = nullptr; uint64_t spec_cap = 0, spec_done = 0;
     uint32_t *d_hitcount = nullptr, *d_lists = nullptr, *d_listcnt = nullptr;
     uint32_t *d_fb_lists = nullptr, *d_fbcnt = nullptr;  // hits the fast barcode kernel's bounds left undecided, per (group, strand)
     uint32_t* d_vqueue = nullptr;  // k_flank_verify's item counters (one per strand)
@@ -90,6 +114,14 @@ struct bb_ctx {
     uint8_t* d_in_bases = nullptr; uint64_t cap_in_bases = 0;
     uint64_t* d_in_offsets = nullptr; uint64_t cap_in_offsets = 0;
     bb_row* d_out_rows = nullptr; uint64_t cap_out_rows = 0;
+    uint8_t* d_in_packed = nullptr; uint64_t cap_in_packed = 0;      // bb_annotate_batch_packed: the batch two bases per byte, and where its reads begin
+    uint64_t* d_in_poffs = nullptr; uint64_t cap_in_poffs = 0;
+    // host-pointer form of a batch of up to host_len_max reads: the batch's length statistics (bb_len.h) are taken on the host from the offsets it has
+    // in hand instead of in a kernel and a round trip (BARBELL_AMD_HOST_LEN_MAX; 0 = never)
+    uint32_t host_len_max = 1u << 17;
+    struct bb_lenstat* host_len = nullptr; bool host_len_valid = false;
+    // bb_host_phases: wall time of the phases of the host-pointer form, summed over calls (tools/boundary_rate.py)
+    bool phases = false; double ph[BB_N_HOST_PHASES]{}; uint64_t ph_calls = 0;
     // filter step
     bb_pat_dev* d_fpats = nullptr;
     bb_pat_elem_dev* d_felems = nullptr;
@@ -129,6 +161,17 @@ struct bb_ctx {
     uint32_t n_lev = 0;
     float dom_ms = 0.f; char dom_name[72] = "";
     std::string last_error;
+    // blocking waits of the host on the device inside the batch call in hand (stream synchronisations and blocking copies): what a call costs
+    // whatever its size (bb_last_host_syncs; tools/boundary_rate.py)
+    uint32_t n_syncs = 0, last_syncs = 0;
+    int call_depth = 0;
+};
+
+// counts the host's blocking waits of one outermost batch call (the host-pointer form calls the device form)
+struct bb_call_scope {
+    bb_ctx* c;
+    explicit bb_call_scope(bb_ctx* ctx) : c(ctx) { if (c->call_depth++ == 0) c->n_syncs = 0; }
+    ~bb_call_scope() { if (--c->call_depth == 0) c->last_syncs = c->n_syncs; }
 };
 
 #define HIPCHK(ctx, call)                                                                        \
@@ -139,6 +182,8 @@ struct bb_ctx {
             return BB_E_HIP;                                                                     \
         }                                                                                        \
     } while (0)
+
+#define BB_SYNC(ctx, stream) do { ++(ctx)->n_syncs; HIPCHK(ctx, hipStreamSynchronize(stream)); } while (0)
 
 #define BB_LDS_MAX (144 * 1024)  // dynamic LDS a block may ask for (160 KB per CU on gfx950, some of it static)
 

@@ -246,6 +246,16 @@ __global__ __launch_bounds__(256) void k_fq_pack(const uint8_t* __restrict__ tex
     wave_copy(hdr + ho, text + hs, (uint32_t)HL, lane);
 }
 
+// bb_annotate_batch_packed: read k of a batch whose sequences came two bases per byte (each read from a byte of its own), a wave per read
+__global__ __launch_bounds__(256) void k_unpack_reads(const uint8_t* __restrict__ packed, const uint64_t* __restrict__ poff, const uint64_t* __restrict__ off,
+                                                      uint32_t n_reads, uint8_t* __restrict__ bases) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t k = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (k >= n_reads) return;
+    const uint64_t o = off[k];
+    wave_unpack(bases + o, packed + poff[k], (uint32_t)(off[k + 1] - o), lane);
+}
+
 int scan64(bb_ctx_view& v, bb_fastq_state* s, const uint32_t* in, uint64_t* out, uint32_t n, uint64_t* d_total) {
     const uint32_t nb = (n + 1023) / 1024;
     int r;
@@ -456,6 +466,10 @@ extern "C" int bb_fastq_fetch_lines(bb_ctx* ctx, uint64_t* line_ends) {
     FCHK(v, hipMemcpyAsync(line_ends, s->d_nl, n * 8, hipMemcpyDeviceToHost, v.stream));
     FCHK(v, hipStreamSynchronize(v.stream));
     return BB_OK;
+}
+
+void bb_launch_unpack_reads(hipStream_t st, const uint8_t* d_packed, const uint64_t* d_poff, const uint64_t* d_off, uint32_t n, uint8_t* d_bases) {
+    hipLaunchKernelGGL(k_unpack_reads, dim3((n + 3u) / 4u), dim3(256), 0, st, d_packed, d_poff, d_off, n, d_bases);
 }
 
 extern "C" float bb_fastq_last_ms(bb_ctx* ctx) {

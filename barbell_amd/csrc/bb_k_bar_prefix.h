@@ -16,7 +16,9 @@
 // 128 hits per block; records enter and leave through LDS so that global traffic is whole lines (a lane-per-
 // record access pattern with 96-byte / 272-byte strides moved 4 GB per 2.6 M hits instead of ~1 GB).
 __global__ __launch_bounds__(128) void k_bar_prefix(const uint8_t* __restrict__ tables, const bb_group_dev* __restrict__ groups,
-                                                    const bb_hit* __restrict__ hits, uint32_t n_hits, bb_hit_pfx* __restrict__ out, uint32_t n_groups) {
+                                                    const bb_hit* __restrict__ hits, uint32_t n_hits, bb_hit_pfx* __restrict__ out, uint32_t n_groups,
+                                                    const uint32_t* __restrict__ n_hits_dev) {
+    BB_HITS_ON_DEVICE(n_hits, n_hits_dev, 128u);
     constexpr int HW = (int)(sizeof(bb_hit) / 4), OW = (int)(sizeof(bb_hit_pfx) / 4), OS = OW + 1;  // odd row stride: no bank conflicts
     __shared__ uint32_t s_in[128 * (HW + 1)];
     __shared__ uint32_t s_out[128 * OS];

@@ -5,7 +5,9 @@
 
 __global__ __launch_bounds__(256) void k_rows(const bb_group_dev* __restrict__ groups, const bb_hit* __restrict__ hits, uint32_t n_hits,
                                               bb_rowtmp* __restrict__ rows, double min_score, double min_score_diff, double margin,
-                                              uint32_t* __restrict__ fb_lists, uint32_t list_stride, uint32_t* __restrict__ fb_cnt) {
+                                              uint32_t* __restrict__ fb_lists, uint32_t list_stride, uint32_t* __restrict__ fb_cnt,
+                                              const uint32_t* __restrict__ n_hits_dev) {
+    BB_HITS_ON_DEVICE(n_hits, n_hits_dev, 256u);
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
     const bool in = t < n_hits;
     bb_winrec W;
@@ -30,7 +32,8 @@ __global__ __launch_bounds__(256) void k_rows(const bb_group_dev* __restrict__ g
 // (block, slot): ballots + LDS.
 __global__ __launch_bounds__(256) void k_hit_lists(const uint32_t* __restrict__ hit_meta, uint32_t n_hits, bb_rowtmp* __restrict__ rows,
                                                    uint32_t* __restrict__ lists, uint32_t list_stride, uint32_t* __restrict__ list_cnt,
-                                                   uint32_t n_groups, const bb_group_dev* __restrict__ groups) {
+                                                   uint32_t n_groups, const bb_group_dev* __restrict__ groups, const uint32_t* __restrict__ n_hits_dev) {
+    BB_HITS_ON_DEVICE(n_hits, n_hits_dev, 256u);
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
     const bool in = t < n_hits;
     const uint32_t meta = in ? hit_meta[t] : 0u;   // bb_hit_meta: 4 bytes per hit instead of its 96-byte record (0.26 GB per 2 M-read step)
@@ -86,7 +89,9 @@ __device__ __forceinline__ int rows_cmp(const bb_row& a, const bb_row& b) {  // 
     return 0;
 }
 __global__ __launch_bounds__(256) void k_collapse(bb_rowtmp* __restrict__ rows, const uint32_t* __restrict__ slot_base,
-                                                  uint32_t n_reads, uint32_t n_groups, uint32_t* __restrict__ nrows) {
+                                                  uint32_t n_reads, uint32_t n_groups, uint32_t* __restrict__ nrows,
+                                                  const uint32_t* __restrict__ n_hits_dev, uint32_t cap_hits) {
+    if (n_hits_dev && *n_hits_dev > cap_hits) return;   // deferred batch whose hits overflowed their buffers: the host runs it again (slots beyond the buffers)
     const uint32_t read = blockIdx.x * 256u + threadIdx.x;
     if (read >= n_reads) return;
     const uint32_t b0 = slot_base[(uint64_t)read * n_groups * 2], b1 = slot_base[(uint64_t)(read + 1) * n_groups * 2];
@@ -123,7 +128,11 @@ __global__ __launch_bounds__(256) void k_collapse(bb_rowtmp* __restrict__ rows, 
 __global__ __launch_bounds__(256) void k_emit(const bb_rowtmp* __restrict__ rows, const uint32_t* __restrict__ slot_base,
                                               const uint32_t* __restrict__ row_off, uint32_t n_reads, uint32_t n_groups,
                                               const bb_group_dev* __restrict__ groups, bb_row* __restrict__ out,
-                                              unsigned long long* __restrict__ counts, uint32_t counts_len) {
+                                              unsigned long long* __restrict__ counts, uint32_t counts_len,
+                                              const uint32_t* __restrict__ n_hits_dev, uint32_t cap_hits, uint64_t rows_cap) {
+    // a deferred batch (no round trip between the scans and here): nothing is emitted or counted if the host is going to run the batch again
+    // (hits overflowed) or to hand it back (rows beyond the caller's capacity) — it reads the same two numbers after this launch
+    if (n_hits_dev && (*n_hits_dev > cap_hits || (uint64_t)row_off[n_reads] > rows_cap)) return;
     extern __shared__ uint32_t s_hist[];  // per-block histogram, flushed with one global atomic per non-empty bin
     for (uint32_t i = threadIdx.x; i < counts_len; i += 256u) s_hist[i] = 0u;
     __syncthreads();

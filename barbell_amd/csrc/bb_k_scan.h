@@ -1032,13 +1032,14 @@ __global__ __launch_bounds__(256, W <= 4 ? BB_VERIFY_MINBLOCKS : 1) void k_flank
 // ------------------------------------------------------------------------------------------------
 // exclusive scan of uint32 (3 small kernels): 2048 elements per block
 // ------------------------------------------------------------------------------------------------
+// (the scans' last input is a place holder whose output is the total: read as 0 whatever it holds, so that nobody has to zero it)
 __global__ __launch_bounds__(256) void k_scan_block(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint64_t n,
                                                     uint32_t* __restrict__ sums) {
     __shared__ uint32_t s_w[4];
     const uint64_t base = (uint64_t)blockIdx.x * 2048u + (uint64_t)threadIdx.x * 8u;
     uint32_t v[8], t = 0;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { v[i] = base + i < n ? in[base + i] : 0u; }
+    for (int i = 0; i < 8; ++i) { v[i] = base + i + 1 < n ? in[base + i] : 0u; }
 #pragma unroll
     for (int i = 0; i < 8; ++i) { uint32_t x = v[i]; v[i] = t; t += x; }
     // wave inclusive scan of t
@@ -1068,10 +1069,39 @@ __global__ __launch_bounds__(64) void k_scan_sums(uint32_t* __restrict__ sums, u
         carry += __shfl(inc, 63, 64);
     }
 }
-__global__ __launch_bounds__(256) void k_scan_add(uint32_t* __restrict__ out, uint64_t n, const uint32_t* __restrict__ sums) {
+__global__ __launch_bounds__(256) void k_scan_add(uint32_t* __restrict__ out, uint64_t n, const uint32_t* __restrict__ sums, uint32_t* __restrict__ total) {
     const uint64_t base = (uint64_t)blockIdx.x * 2048u + (uint64_t)threadIdx.x * 8u;
     const uint32_t a = sums[blockIdx.x];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) if (base + i < n) out[base + i] += a;
+    for (int i = 0; i < 8; ++i) if (base + i < n) { const uint32_t v = out[base + i] + a; out[base + i] = v; if (total && base + i + 1 == n) *total = v; }
 }
+// The same scan in ONE launch for inputs one block walks in a few rounds (a small batch: three launches cost its host thread more than the
+// scan costs the device): 1024 lanes, 8 values each per round, the carry in a register of every lane.
+__global__ __launch_bounds__(1024) void k_scan_one(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint32_t n, uint32_t* __restrict__ total) {
+    __shared__ uint32_t s_w[16];
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    uint32_t carry = 0u;
+    for (uint32_t r0 = 0; r0 < n; r0 += 8192u) {   // (block-uniform trip count)
+        const uint32_t base = r0 + threadIdx.x * 8u;
+        uint32_t v[8], t = 0u;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = base + i + 1 < n ? in[base + i] : 0u;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { const uint32_t x = v[i]; v[i] = t; t += x; }
+        uint32_t inc = t;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(inc, d, 64); if (lane >= d) inc += y; }
+        __syncthreads();   // the last round's s_w has been read by everyone
+        if (lane == 63u) s_w[wv] = inc;
+        __syncthreads();
+        uint32_t wbase = 0u, all = 0u;
+#pragma unroll
+        for (uint32_t i = 0; i < 16u; ++i) { const uint32_t x = s_w[i]; if (i < wv) wbase += x; all += x; }
+        const uint32_t excl = carry + wbase + inc - t;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) if (base + i < n) { out[base + i] = v[i] + excl; if (total && base + i + 1 == n) *total = v[i] + excl; }
+        carry += all;
+    }
+}
+#define BB_SCAN_ONE_MAX (1u << 16)   // inputs up to this many values (+ the place holder) take k_scan_one
 

@@ -337,9 +337,10 @@ __global__ __launch_bounds__(64) void k_flank_trace(const uint8_t* __restrict__ 
                                                     const uint8_t* __restrict__ tables, const bb_group_dev* __restrict__ groups,
                                                     uint32_t n_groups, const bb_hit_raw* __restrict__ raw, uint32_t n_hits,
                                                     const uint32_t* __restrict__ slot_base, bb_hit* __restrict__ hits, uint32_t* __restrict__ hit_meta,
-                                                    uint32_t gmask, int mk_max) {
+                                                    uint32_t gmask, int mk_max, const uint32_t* __restrict__ n_hits_dev) {
     extern __shared__ uint32_t s_dyn[];
     __shared__ uint32_t s_slot[64];
+    BB_HITS_ON_DEVICE(n_hits, n_hits_dev, 64u);
     static_assert(sizeof(bb_hit) == 96, "six 16-byte pieces");
     // the staged records reuse the move bits' LDS (>= 64 * BB_TRACE_REC_STRIDE words, launch_trace): the block is one wave,
     // a lane writes its record after every lane's walk is over, and LDS operations of a wave execute in order

@@ -16,14 +16,18 @@
 // timing on: events around one kernel launch on its stream (bb_ctx::lev); bb_launch_timed_end closes the pair opened last
 void bb_launch_timed_begin(bb_ctx* c, hipStream_t st, const char* fmt, ...);
 void bb_launch_timed_end(bb_ctx* c, hipStream_t st);
-int bb_scan_u32(bb_ctx* c, const uint32_t* in, uint32_t* out, uint64_t n);
+int bb_scan_u32(bb_ctx* c, const uint32_t* in, uint32_t* out, uint64_t n, uint32_t* total = nullptr);   // in[n - 1]: place holder; out[n - 1] (and *total) = the sum
 // the batch's read lengths (bb_len.h): sets c->vtab / c->n_virtual for the scans of this batch, *off0 / *off1 = offsets[0] / offsets[n]; one round trip
 int bb_prepare_lengths(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n, uint64_t* off0, uint64_t* off1);
-int bb_launch_scans(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n, uint64_t flag_words, uint64_t batch_bytes);   // the flank scan of every group
+int bb_launch_scans(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n, uint64_t flag_words, uint64_t batch_bytes, bool deferred);   // the flank scan of every group
+void bb_note_flag_counts(bb_ctx* c, const unsigned long long* nflag);
 int bb_trace_mode(const bb_ctx* c, uint32_t g);
-void bb_launch_trace(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n_hits, uint32_t gmask, int mode, int W);
-bool bb_takes_lane(const bb_ctx* c, uint32_t g, uint32_t strand, bool wide);
-void bb_launch_bar_prefix(bb_ctx* c, uint32_t n_hits, hipStream_t st);
+void bb_launch_trace(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n_hits, uint32_t gmask, int mode, int W, const uint32_t* n_hits_dev);
+// bb_fastq.hip: reads that came two bases per byte (bb_pack.h) into the one-byte-per-base batch every kernel takes
+void bb_launch_unpack_reads(hipStream_t st, const uint8_t* d_packed, const uint64_t* d_poff, const uint64_t* d_off, uint32_t n, uint8_t* d_bases);
+bool bb_takes_lane(const bb_ctx* c, uint32_t g, uint32_t strand, bool wide);      // the batch in hand
+bool bb_lane_eligible(const bb_ctx* c, uint32_t g, uint32_t strand, bool wide);   // ... any batch large enough for one lane per hit to pay
+void bb_launch_bar_prefix(bb_ctx* c, uint32_t n_hits, hipStream_t st, const uint32_t* n_hits_dev);
 void bb_launch_barcode(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n_hits, uint32_t g, int pass);
 
 // ---- the per-class units ----

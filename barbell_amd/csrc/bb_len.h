@@ -13,14 +13,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#define BB_LEN_SEG_BINS 130u   // segment line counts 0 .. 129 (split_above <= 128)
-struct bb_lenstat {
-    unsigned long long off0, off1;   // offsets[0], offsets[n]
-    uint32_t min_nl, max_nl;
-    uint32_t n_cut_reads, n_cut_segs;   // reads cut into segments, and their segments
-    uint32_t seg[BB_LEN_SEG_BINS];
-};
-struct bb_lencur { uint32_t seg[BB_LEN_SEG_BINS]; uint32_t cut_reads, cut_segs; };   // next free position of every bin / list
+#include "bb_lenstat.h"
 
 __device__ __forceinline__ uint32_t bb_len_lines(const uint8_t* bases, uint64_t off, uint32_t n) {
     return n ? (uint32_t)((((uint64_t)(uintptr_t)(bases + off) & 127u) + n + 127u) >> 7) : 0u;
@@ -50,7 +43,7 @@ __global__ __launch_bounds__(256) void k_len_hist(const uint8_t* __restrict__ ba
         while (rest) {
             const uint32_t v = (uint32_t)__shfl((int)nl, __ffsll((long long)rest) - 1, 64);
             const unsigned long long same = __ballot(nl == v) & rest;
-            if (lane == 0u) atomicAdd(&s_seg[v], (uint32_t)__popcll(same));
+            if (lane == 0u && v < BB_LEN_SEG_BINS) atomicAdd(&s_seg[v], (uint32_t)__popcll(same));   // (seg_lines = 0: no bins are read)
             rest &= ~same;
         }
         if (live && nl > split_above) {   // cut reads (few)

@@ -49,6 +49,10 @@ void bb_launch_timed_end(bb_ctx* c, hipStream_t st) {
 // pass 0 of a split (group, strand): k_barcode_lane (which computes the shared rows itself) or k_barcode_pfx (which reads k_bar_prefix's
 // records).  wide: the hits whose window exceeds 48 columns — their 64-column k_barcode_lane exists for the default order only.
 bool bb_takes_lane(const bb_ctx* c, uint32_t g, uint32_t strand, bool wide) {
+    // a small batch: one lane per (hit, barcode) finishes in a fraction of the time one lane per hit takes to walk the group's barcodes
+    return !c->batch_no_lane && bb_lane_eligible(c, g, strand, wide);
+}
+bool bb_lane_eligible(const bb_ctx* c, uint32_t g, uint32_t strand, bool wide) {
     const bb_group_dev& D = c->gdev[g];
     if (!bb_class_unit_of(c->prio_class).lane || (wide && c->prio_class != 0)) return false;
     // any flank budget since round 4: above BB_LANE_MAX_FLANK_K the kernel's bound uses the Match columns of the shared rows' walk (the NM instantiation);
@@ -57,9 +61,9 @@ bool bb_takes_lane(const bb_ctx* c, uint32_t g, uint32_t strand, bool wide) {
     return c->fast_path && D.pfx[strand] <= 16 &&
            (c->lane_kernel == 2 || (c->lane_kernel == 1 && (!big_k || c->lane_nm) && c->lane_off[g][strand] == 0));
 }
-void bb_launch_bar_prefix(bb_ctx* c, uint32_t n_hits, hipStream_t st) {
+void bb_launch_bar_prefix(bb_ctx* c, uint32_t n_hits, hipStream_t st, const uint32_t* n_hits_dev) {
     hipLaunchKernelGGL(k_bar_prefix, dim3((n_hits + 127) / 128), dim3(128), 0, st, (const uint8_t*)c->d_tables, (const bb_group_dev*)c->d_groups,
-                       (const bb_hit*)c->d_hits, n_hits, c->d_pfx, (uint32_t)c->groups.size());
+                       (const bb_hit*)c->d_hits, n_hits, c->d_pfx, (uint32_t)c->groups.size(), n_hits_dev);
 }
 
 namespace {

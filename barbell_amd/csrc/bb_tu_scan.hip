@@ -7,11 +7,17 @@
 #include "bb_k_scan.h"
 #include "bb_len.h"
 
-int bb_scan_u32(bb_ctx* c, const uint32_t* in, uint32_t* out, uint64_t n) {
+// exclusive scan of in[0 .. n - 2]; in[n - 1] is a place holder (read as 0), out[n - 1] the total, also left in *total where that is given
+int bb_scan_u32(bb_ctx* c, const uint32_t* in, uint32_t* out, uint64_t n, uint32_t* total) {
+    if (n <= (uint64_t)BB_SCAN_ONE_MAX + 1u) {
+        hipLaunchKernelGGL(k_scan_one, dim3(1), dim3(1024), 0, c->stream, in, out, (uint32_t)n, total);
+        HIPCHK(c, hipGetLastError());
+        return BB_OK;
+    }
     const uint32_t nb = (uint32_t)((n + 2047) / 2048);
     hipLaunchKernelGGL(k_scan_block, dim3(nb), dim3(256), 0, c->stream, in, out, n, c->d_sums);
     hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(64), 0, c->stream, c->d_sums, nb);
-    hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(256), 0, c->stream, out, n, (const uint32_t*)c->d_sums);
+    hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(256), 0, c->stream, out, n, (const uint32_t*)c->d_sums, total);
     HIPCHK(c, hipGetLastError());
     return BB_OK;
 }
@@ -51,11 +57,10 @@ void launch_scan2_w(bb_ctx* c, int W, const uint8_t* d_bases, const uint64_t* d_
 }
 template <int W>
 void launch_verify(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n, uint32_t g, const uint32_t* flags, uint64_t flag_words) {
-    (void)hipMemsetAsync(c->d_vqueue, 0, 2 * sizeof(uint32_t), c->stream);
     const uint32_t vblocks = std::min((n + 255u) / 256u, (uint32_t)c->n_cus * 3u);  // persistent: lanes draw (read, strand) items from a queue
     hipLaunchKernelGGL(k_flank_verify<W>, dim3(vblocks, 2), dim3(256), 0, c->stream, d_bases, d_offsets, n,
                        (const uint8_t*)c->d_tables, (const bb_group_dev*)c->d_groups, g, (uint32_t)c->groups.size(),
-                       flags, flag_words, c->d_cnt, c->d_raw, c->cap_hits, c->d_hitcount, c->d_vqueue);
+                       flags, flag_words, c->d_cnt, c->d_raw, c->cap_hits, c->d_hitcount, c->d_vqueue + 2u * g);   // (the queue counters of every group were zeroed with the batch's control block)
 }
 }  // namespace
 
@@ -70,11 +75,16 @@ int bb_prepare_lengths(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offs
     }
     const uint32_t seg_lines = c->seg_lines ? c->seg_lines : 32u, split_above = c->seg_lines ? c->split_above : 0xFFFFFFFFu;
     bb_lenstat st;
-    HIPCHK(c, hipMemsetAsync(c->d_lenstat, 0, sizeof(bb_lenstat), c->stream));
-    HIPCHK(c, hipMemsetAsync(&c->d_lenstat->min_nl, 0xFF, sizeof(uint32_t), c->stream));
-    hipLaunchKernelGGL(k_len_hist, dim3(std::min((n + 255u) / 256u, 1024u)), dim3(256), 0, c->stream, d_bases, d_offsets, n, seg_lines, split_above, c->d_lenstat);
-    HIPCHK(c, hipMemcpyAsync(&st, c->d_lenstat, sizeof(st), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->host_len_valid) {   // the host-pointer form of a small batch took them from the offsets it holds (bb_host_lenstat): no kernel, no round trip
+        st = *c->host_len;
+        c->host_len_valid = false;
+    } else {
+        HIPCHK(c, hipMemsetAsync(c->d_lenstat, 0, sizeof(bb_lenstat), c->stream));
+        HIPCHK(c, hipMemsetAsync(&c->d_lenstat->min_nl, 0xFF, sizeof(uint32_t), c->stream));
+        hipLaunchKernelGGL(k_len_hist, dim3(std::min((n + 255u) / 256u, 1024u)), dim3(256), 0, c->stream, d_bases, d_offsets, n, seg_lines, split_above, c->d_lenstat);
+        HIPCHK(c, hipMemcpyAsync(&st, c->d_lenstat, sizeof(st), hipMemcpyDeviceToHost, c->stream));
+        BB_SYNC(c, c->stream);
+    }
     *off0 = st.off0; *off1 = st.off1;
     c->last_min_lines = st.min_nl; c->last_max_lines = st.max_nl; c->last_segments = n;
     if (st.off1 < st.off0) { c->last_error = "offsets are not ascending"; return BB_E_INVALID; }
@@ -105,7 +115,9 @@ int bb_prepare_lengths(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offs
 // flagged above the break-even), or filter + verification — and each kind goes out as ONE launch whose blocks for the same reads sit on the
 // same XCD (bb_coscheduled): the batch is streamed from HBM once per kind and direction instead of once per group.  The decisions per
 // group (filter or not, back-off, verification or full scan after the filter) are the ones bb_launch_scan made group by group until round 4.
-int bb_launch_scans(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n, uint64_t flag_words, uint64_t batch_bytes) {
+// deferred: no round trip for the filter's flag counts — every filtered group is verified, and the counts (read with the batch's other
+// numbers when it ends: bb_note_flag_counts) decide for the NEXT batches whether the group skips its filter pass.
+int bb_launch_scans(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n, uint64_t flag_words, uint64_t batch_bytes, bool deferred) {
     const uint32_t G = (uint32_t)c->groups.size();
     std::vector<uint32_t> plain[9], plain2[9], filt[2];   // by width; filt[wide]
     for (uint32_t g = 0; g < G; ++g) {
@@ -126,8 +138,7 @@ int bb_launch_scans(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets
     std::vector<uint32_t> region(G, 0);
     const uint32_t n_filt = (uint32_t)(filt[0].size() + filt[1].size());
     if (n_filt) {
-        (void)hipMemsetAsync(c->d_flags, 0, (size_t)2 * flag_words * n_filt * sizeof(uint32_t), c->stream);  // the filter writes the words that hold a flag
-        (void)hipMemsetAsync(c->d_nflag, 0, sizeof(unsigned long long) * BB_MAX_GROUPS, c->stream);
+        // (the flag words — the filter writes the ones that hold a flag — and the flag counters were zeroed with the batch's control block: bb_zero_ctl)
         uint32_t reg = 0;
         for (int wide = 0; wide < 2; ++wide)
             for (size_t at = 0; at < filt[wide].size(); at += sizeof(bb_glist::g)) {
@@ -151,14 +162,16 @@ int bb_launch_scans(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets
         // the number of flagged pieces (each costs its columns plus m + k of lead-in; low-complexity text, adapter-like decoys
         // and chimeric reads flag many), the full scan's does not.  Above the break-even (measured: DESIGN.md §4) the flags are
         // dropped and the full-height streaming scan does the batch.  One round trip for all groups' counts.
-        unsigned long long nf[BB_MAX_GROUPS];
-        HIPCHK(c, hipMemcpyAsync(nf, c->d_nflag, sizeof(nf), hipMemcpyDeviceToHost, c->stream));  // a failure must not be read as "no flags"
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        unsigned long long nf[BB_MAX_GROUPS] = {};
+        if (!deferred) {
+            HIPCHK(c, hipMemcpyAsync(nf, c->d_nflag, sizeof(nf), hipMemcpyDeviceToHost, c->stream));  // a failure must not be read as "no flags"
+            BB_SYNC(c, c->stream);
+        }
         for (int wide = 0; wide < 2; ++wide)
             for (uint32_t g : filt[wide]) {
                 const int W = std::min(8, std::max(1, (int)c->gdev[g].W));
                 c->last_flagged[g] = nf[g]; c->last_scan_kind[g] = 1;
-                if (c->scan_filter != 1 && (double)nf[g] > c->adapt_frac * (double)c->last_pieces[g]) {
+                if (!deferred && c->scan_filter != 1 && (double)nf[g] > c->adapt_frac * (double)c->last_pieces[g]) {
                     c->last_scan_kind[g] = 2;
                     c->scan_off[g] = 16;
                     plain2[W].push_back(g);
@@ -189,4 +202,14 @@ int bb_launch_scans(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets
         }
     }
     return BB_OK;
+}
+
+// A deferred batch's flag counts, read when the batch has ended: a group whose filter flagged more than the break-even fraction was verified all the
+// same (correct, slower than the full scan would have been); its next sixteen batches go straight to the full scan, as after a batch of kind 2.
+void bb_note_flag_counts(bb_ctx* c, const unsigned long long* nf) {
+    for (uint32_t g = 0; g < c->groups.size(); ++g) {
+        if (c->last_scan_kind[g] != 1) continue;
+        c->last_flagged[g] = nf[g];
+        if (c->scan_filter != 1 && (double)nf[g] > c->adapt_frac * (double)c->last_pieces[g]) c->scan_off[g] = 16;
+    }
 }

@@ -23,7 +23,7 @@ namespace {
 // One launch for every group of the same width and variant (the raw hits of all groups share one array: a launch per
 // group walks it once per group with the other groups' lanes idle).
 template <int W>
-void launch_trace(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n_hits, uint32_t gmask, int mode) {
+void launch_trace(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n_hits, uint32_t gmask, int mode, const uint32_t* n_hits_dev) {
     const size_t lds_rec = (size_t)64 * BB_TRACE_REC_STRIDE * 4;  // the staged hit records share the move bits' LDS
     size_t lds = lds_rec;
     int mk_max = 0;
@@ -40,7 +40,7 @@ void launch_trace(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets, 
         lds = std::max(lds, need);
     }
 #define BB_TRACE_ARGS d_bases, d_offsets, (const uint8_t*)c->d_tables, (const bb_group_dev*)c->d_groups, (uint32_t)c->groups.size(), \
-                      (const bb_hit_raw*)c->d_raw, n_hits, (const uint32_t*)c->d_base, c->d_hits, c->d_hitmeta, gmask, mk_max
+                      (const bb_hit_raw*)c->d_raw, n_hits, (const uint32_t*)c->d_base, c->d_hits, c->d_hitmeta, gmask, mk_max, n_hits_dev
     if (mode == 4) hipLaunchKernelGGL((k_flank_trace<W, 4>), dim3((n_hits + 63) / 64), dim3(64), lds, c->stream, BB_TRACE_ARGS);
     else if (mode == 2) hipLaunchKernelGGL((k_flank_trace<W, 2>), dim3((n_hits + 63) / 64), dim3(64), lds, c->stream, BB_TRACE_ARGS);
     else if (mode == 1) {
@@ -52,15 +52,15 @@ void launch_trace(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets, 
 }
 }  // namespace
 
-void bb_launch_trace(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n_hits, uint32_t gmask, int mode, int W) {
+void bb_launch_trace(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n_hits, uint32_t gmask, int mode, int W, const uint32_t* n_hits_dev) {
     switch (W) {
-        case 1: launch_trace<1>(c, d_bases, d_offsets, n_hits, gmask, mode); break;
-        case 2: launch_trace<2>(c, d_bases, d_offsets, n_hits, gmask, mode); break;
-        case 3: launch_trace<3>(c, d_bases, d_offsets, n_hits, gmask, mode); break;
-        case 4: launch_trace<4>(c, d_bases, d_offsets, n_hits, gmask, mode); break;
-        case 5: launch_trace<5>(c, d_bases, d_offsets, n_hits, gmask, mode); break;
-        case 6: launch_trace<6>(c, d_bases, d_offsets, n_hits, gmask, mode); break;
-        case 7: launch_trace<7>(c, d_bases, d_offsets, n_hits, gmask, mode); break;
-        default: launch_trace<8>(c, d_bases, d_offsets, n_hits, gmask, mode); break;
+        case 1: launch_trace<1>(c, d_bases, d_offsets, n_hits, gmask, mode, n_hits_dev); break;
+        case 2: launch_trace<2>(c, d_bases, d_offsets, n_hits, gmask, mode, n_hits_dev); break;
+        case 3: launch_trace<3>(c, d_bases, d_offsets, n_hits, gmask, mode, n_hits_dev); break;
+        case 4: launch_trace<4>(c, d_bases, d_offsets, n_hits, gmask, mode, n_hits_dev); break;
+        case 5: launch_trace<5>(c, d_bases, d_offsets, n_hits, gmask, mode, n_hits_dev); break;
+        case 6: launch_trace<6>(c, d_bases, d_offsets, n_hits, gmask, mode, n_hits_dev); break;
+        case 7: launch_trace<7>(c, d_bases, d_offsets, n_hits, gmask, mode, n_hits_dev); break;
+        default: launch_trace<8>(c, d_bases, d_offsets, n_hits, gmask, mode, n_hits_dev); break;
     }
 }

@@ -140,6 +140,17 @@ int bb_group_get_pattern(const bb_ctx* ctx, uint32_t group, uint32_t idx, int rc
 int bb_annotate_batch(bb_ctx* ctx, const uint8_t* bases, const uint64_t* offsets, uint32_t n_reads,
                       bb_row* rows, uint64_t rows_cap, uint64_t* n_rows);
 
+/* The same with the sequences TWO BASES PER BYTE: what crosses PCIe is ~2 KB per 4-kb read instead of 4 (the host-pointer form is PCIe-bound from a
+ * few thousand reads per call on: INTEGRATION.md, "Batch size").  Every kernel looks at a read character only through its IUPAC base set — a 4-bit
+ * code: A=1 C=2 G=4 T/U=8, their unions, 0 = not an IUPAC letter (matches nothing) — so rows are those of the original text.  Read i's bases
+ * 2j, 2j+1 are byte packed[packed_offsets[i] + j] = (code << 4) | (code' ^ 0xA), an odd last base paired with anything; every read begins at a byte of
+ * its own; `offsets` are the reads' offsets in BASES (n_reads + 1, as for bb_annotate_batch), `packed_offsets` in bytes of `packed`.
+ * bb_pack_bases writes the packed form of `n` characters (AVX2 / AVX-512 where the CPU has them; a binding calls it per record as it collects
+ * a batch, annotator.rs:123-135) and returns the bytes written, (n + 1) / 2.  `out` must not overlap `bases`.                                    */
+uint64_t bb_pack_bases(const uint8_t* bases, uint64_t n, uint8_t* out);
+int bb_annotate_batch_packed(bb_ctx* ctx, const uint8_t* packed, const uint64_t* packed_offsets, const uint64_t* offsets, uint32_t n_reads,
+                             bb_row* rows, uint64_t rows_cap, uint64_t* n_rows);
+
 /* Device-pointer variant: `d_bases`, `d_offsets` and `d_rows` are HIP device pointers on the
  * context's device.  The call enqueues on the context's stream and returns after the row count is
  * known (one small D2H of 8 bytes); rows stay in HBM.                                          */
@@ -181,10 +192,23 @@ int bb_last_scan_stats(const bb_ctx* ctx, uint32_t group, uint64_t* flagged_piec
  * reference's threads take reads one by one, annotator.rs:123-135, and never meet the problem).  Results do not depend on it.     */
 int bb_last_length_stats(const bb_ctx* ctx, uint32_t* min_lines, uint32_t* max_lines, uint32_t* work_items);
 
+/* How often the host WAITED for the device inside the last bb_annotate_batch / bb_annotate_batch_dev call (stream synchronisations and blocking
+ * copies): the part of a call's cost that does not shrink with the batch.  A caller that hands over small batches (paraseq's ~1 k records,
+ * annotator.rs:278-280) pays it per call — INTEGRATION.md, "Batch size".                                                                   */
+int bb_last_host_syncs(const bb_ctx* ctx);
+/* Where the host-pointer form spends its wall time (diagnostics; off by default).  `enable` switches the clock on or off for the calls that follow;
+ * ms[0..BB_N_HOST_PHASES) and *calls (either may be NULL) receive what was summed since the last call of this function, then the sums start over:
+ * 0 upload enqueued (incl. HIP's copy of pageable memory), 1 the whole device pipeline, 2 rows back; inside 1: 3 read lengths, 4 flank scans up to
+ * the hit count's round trip, 5 traceback .. barcode stage .. collapse up to the row count's round trip, 6 rows emitted and the stream drained.   */
+#define BB_N_HOST_PHASES 7
+int bb_host_phases(bb_ctx* ctx, int enable, double* ms, uint64_t* calls);
+
 /* The barcode stage of the last batch, per (group, strand): flank hits listed for it, how many of them the fast kernel's bounds left
  * undecided (those are scored exactly by the second pass), and whether the pair's NEXT batch takes the one-lane-per-hit kernel
  * (k_barcode_lane: its bound assumes the shared pad rows match; above 20 % undecided the pair goes back to k_barcode_pfx for 32
- * batches).  Counts are only collected in the default kernel choice (BARBELL_AMD_LANE=1).  Rows do not depend on any of this.   */
+ * batches; a batch of up to 4 096 reads takes one lane per (hit, barcode) whatever this says: one lane per hit is a long walk that only pays
+ * when there are hits enough to fill the GPU with it).  Counts are only collected in the default kernel choice (BARBELL_AMD_LANE=1).
+ * Rows do not depend on any of this.                                                                                                */
 int bb_last_barcode_stats(const bb_ctx* ctx, uint32_t group, uint32_t strand, uint64_t* hits, uint64_t* undecided, int* lane_kernel);
 
 /* Device buffers for callers of the *_dev entry points that have no HIP binding of their own (the Rust

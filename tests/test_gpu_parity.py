@@ -12,6 +12,25 @@ from tests.common import config_groups
 pytestmark = pytest.mark.gpu
 NT = effective_cpus()
 
+# Tests whose batches are far above the small-batch thresholds (same path under both settings) or that set the thresholds themselves
+ONE_BATCHING = {"test_large_batch_properties_without_oracle": "small-batch", "test_offsets_beyond_4gib_against_oracle": "small-batch",
+                "test_small_batches_run_deferred": "small-batch", "test_deferred_batch_grows_its_hit_buffers": "small-batch",
+                "test_lane_kernel_backs_off_when_its_bound_decides_too_little": "classic"}   # (batches of 3 000 reads: one lane per hit only there)
+
+
+@pytest.fixture(autouse=True, params=["small-batch", "classic"])
+def batching(request, monkeypatch):
+    """Every test of this module under both treatments of a batch (round 6): as the library runs a small batch by default — DEFERRED (no round
+    trip between upload and rows, the hit count stays on the device, flag counts decide for the next batch: bb_ctx::defer_max) and, up to
+    4 096 reads, with one lane per (hit, barcode) in the barcode stage — and `classic`: both thresholds 0, the path every 2 M-read step of
+    the benchmark takes (a round trip per decision, k_barcode_lane), on the same small inputs."""
+    if ONE_BATCHING.get(request.node.originalname, request.param) != request.param:
+        pytest.skip("one treatment only")
+    if request.param == "classic":
+        monkeypatch.setenv("BARBELL_AMD_DEFER_MAX", "0")
+        monkeypatch.setenv("BARBELL_AMD_SMALL_PFX_MAX", "0")
+    return request.param
+
 
 def run_both(groups, bases, offsets, **kw):
     from barbell_amd import annotate as A
@@ -769,7 +788,7 @@ def test_geometry_matches_oracle_on_device_ctx():
 
 @pytest.mark.parametrize("mode", [1, 2, 3])
 @pytest.mark.parametrize("frac", [None, "0", "1"])
-def test_stress_mixes_and_adaptive_scan(monkeypatch, mode, frac):
+def test_stress_mixes_and_adaptive_scan(monkeypatch, mode, frac, batching):
     """The read mixes bench.py's `stress` object measures (bb_synth.h: low-complexity bodies, near-copies of the constructs' shared
     prefix every ~200 nt, half the reads chimeric) against the checker, with the per-batch choice between verification and the full
     scan left alone, forced to the full scan (BARBELL_AMD_ADAPT_FRAC=0: any flag is too many) and switched off (=1)."""
@@ -783,28 +802,76 @@ def test_stress_mixes_and_adaptive_scan(monkeypatch, mode, frac):
     assert len(want) > 300
     assert_same(got, want)
     st = dm.scan_stats(0)
-    assert st["total_pieces"] > 0 and st["kind"] == (2 if frac == "0" and st["flagged_pieces"] else 1 if frac in ("0", "1") else st["kind"])
+    if batching == "classic":
+        assert st["total_pieces"] > 0 and st["kind"] == (2 if frac == "0" and st["flagged_pieces"] else 1 if frac in ("0", "1") else st["kind"])
+    else:   # a deferred batch is verified whatever its filter flagged; the count decides for the batches after it
+        assert st["total_pieces"] > 0 and st["kind"] == 1
     if mode == 1:
         assert st["flagged_pieces"] / st["total_pieces"] > 0.001
 
 
-def test_scan_backs_off_after_an_over_flagged_batch(monkeypatch):
+def test_scan_backs_off_after_an_over_flagged_batch(monkeypatch, batching):
     """A batch whose flags exceed the break-even sends the group's next sixteen batches straight to the full scan (kind 3: no filter
-    pass to throw away), then the group is probed again; the rows are the same whichever scan ran."""
+    pass to throw away), then the group is probed again; the rows are the same whichever scan ran.  A deferred batch (the default for
+    a batch this small) learns its flag count when it has ended: it is verified (kind 1) and the sixteen batches after it skip the filter."""
     monkeypatch.setenv("BARBELL_AMD_ADAPT_FRAC", "0")   # any flag is too many: the first batch is of kind 2
     groups = config_groups("nbd96")
     bases, offsets = A_synth(groups, 977, 300, 2500, 500)
     dm, got, want = run_both(groups, bases, offsets)
     assert_same(got, want)
-    assert dm.scan_stats(0)["kind"] == 2
+    probe_kind = 2 if batching == "classic" else 1
+    assert dm.scan_stats(0)["kind"] == probe_kind
     probed = dm.scan_stats(0)["flagged_pieces"]
+    assert probed > 0
     kinds = []
     for _ in range(18):
         assert_same(dm.demux_packed(bases, offsets), want)
         st = dm.scan_stats(0)
         kinds.append(st["kind"])
         assert st["flagged_pieces"] == probed
-    assert kinds == [3] * 16 + [2, 3]
+    assert kinds == [3] * 16 + [probe_kind, 3]
+    dm.close()
+
+
+def test_small_batches_run_deferred(monkeypatch):
+    """What the boundary's small-batch treatment promises (include/barbell_amd.h, bb_last_host_syncs): one wait of the host per call up to
+    bb_ctx::defer_max reads, the classic number of round trips beyond it, the same rows either way and whatever the thresholds."""
+    groups = config_groups("nbd96")
+    bases, offsets = A_synth(groups, 4242, 200, 3000, 3000)
+    dm, got, want = run_both(groups, bases, offsets)
+    assert_same(got, want)
+    assert dm.host_syncs() == 1
+    dm.close()
+    # classic: the filter's flag counts, the hit count, the row count, the drained stream, the rows' copy (the read lengths come from the offsets in hand)
+    for defer, pfx, syncs in (("0", "0", 5), ("100000", "0", 1), ("100000", "100000", 1), ("0", "100000", 5)):
+        monkeypatch.setenv("BARBELL_AMD_DEFER_MAX", defer)
+        monkeypatch.setenv("BARBELL_AMD_SMALL_PFX_MAX", pfx)
+        dm, got, _ = run_both(groups, bases, offsets)
+        assert_same(got, want)
+        assert dm.host_syncs() == syncs, (defer, pfx, dm.host_syncs())
+        dm.close()
+
+
+def test_deferred_batch_grows_its_hit_buffers():
+    """A deferred batch sizes its launches by the hit buffers' capacity and learns the hit count when it has ended: more hits than room (a read
+    full of constructs: the buffers are sized for three hits a read) and every kernel after the scans leaves at once, nothing is emitted or
+    counted, the host grows the buffers and runs the batch again."""
+    from barbell_amd import annotate as A
+
+    groups = config_groups("nbd96")
+    construct = groups[0].seqs[5]
+    construct = construct.encode() if isinstance(construct, str) else bytes(construct)
+    body = np.random.default_rng(5).choice(np.frombuffer(b"ACGT", dtype=np.uint8), 60).tobytes()
+    read = (construct + body) * 120    # ~120 constructs in one read
+    reads = [read] * 40
+    bases, offsets = _abi.pack_reads(reads)
+    dm, got, want = run_both(groups, bases, offsets)
+    assert len(want) > 40 * 100
+    assert_same(got, want)
+    cnt = dm.counts()
+    assert int(cnt.sum()) == len(got)     # counted once, not once per attempt
+    assert_same(dm.demux_packed(bases, offsets), want)
+    assert int(dm.counts().sum()) == 2 * len(got)
     dm.close()
 
 
@@ -937,7 +1004,7 @@ def test_dominant_kernel_is_named_and_timed():
     dm.close()
 
 
-def test_large_flank_budget_lane_kernel_and_its_round3_alternative(monkeypatch):
+def test_large_flank_budget_lane_kernel_and_its_round3_alternative(monkeypatch, batching):
     """Groups with flank budgets above 8 (k = 20 on the rapid kits) take k_barcode_lane with the per-entry-column Match masks of the shared
     rows' walk (NM) since round 4; BARBELL_AMD_LANE_NM=0 sends them to k_barcode_pfx as in round 3.  Same rows either way, and the
     kernel choice shows in bb_last_barcode_stats."""
@@ -953,7 +1020,7 @@ def test_large_flank_budget_lane_kernel_and_its_round3_alternative(monkeypatch):
         assert_same(got, want)
         kinds[nm] = dm.barcode_stats(0, 0)["lane_kernel"]
         dm.close()
-    assert kinds == {"1": True, "0": False}
+    assert kinds == {"1": True, "0": False}   # (what the pair's NEXT batch takes if it is large enough for one lane per hit to pay: bb_ctx::small_pfx_max)
 
 
 def test_twelve_query_groups():
@@ -1022,4 +1089,36 @@ def test_histogram_beyond_64_kib_of_lds():
         for b in np.unique(rows["barcode_idx"][rows["barcode_idx"] >= 0]):
             assert int(cnt[off + int(b)]) == int((rows["barcode_idx"] == b).sum())
         off += len(g.seqs) + 1
+    dm.close()
+
+
+def test_two_bases_per_byte_at_the_boundary():
+    """bb_annotate_batch_packed: every read packed by bb_pack_bases (4-bit IUPAC base sets, a read from a byte of its own) gives the rows of
+    the one-byte-per-base call — on synthetic reads, on reads of odd and tiny lengths, on lower case, U, IUPAC codes, N runs and junk, and in
+    pieces (a batch beyond 256 MB of bases is cut)."""
+    from barbell_amd import annotate as A
+
+    for cfg, n, lmin, lmax in (("nbd96", 1500, 1, 900), ("dual", 500, 3999, 4000), ("rbk96x", 200, 500, 3000)):
+        groups = config_groups(cfg)
+        bases, offsets = A.synth_reads_host(groups, 99, lmin, lmax, 0, n)
+        b = bases.copy()
+        rng = np.random.default_rng(7)
+        for frac, alphabet in ((0.02, b"acgtu"), (0.01, b"NRYSWKMBDHVnrys"), (0.005, b"X-*.@ \t1")):
+            pos = rng.random(len(b)) < frac
+            b[pos] = rng.choice(np.frombuffer(alphabet, dtype=np.uint8), int(pos.sum()))
+        dm, got, want = run_both(groups, b, offsets)
+        assert_same(got, want)
+        assert_same(dm.demux_nibbles(b, offsets), want)
+        dm.close()
+    groups = config_groups("nbd96")
+    n, L = 80_000, 4000    # 320 MB of bases: two pieces
+    bases, offsets = A.synth_reads_host(groups, 5, L, L, 0, n)
+    dm = A.Demuxer()
+    for g in groups:
+        dm.add_query_group(g)
+    a = dm.demux_packed(bases, offsets)
+    b2 = dm.demux_nibbles(bases, offsets)
+    assert len(a) > n // 2 and int(a["read_idx"].max()) > n - 50
+    assert_same(b2, a)
+    assert int(dm.counts().sum()) == 2 * len(a)
     dm.close()
