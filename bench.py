@@ -47,6 +47,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
+    ap.add_argument("--no-boundary", action="store_true")
     ap.add_argument("--no-stress", action="store_true")
     ap.add_argument("--no-policy-variants", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
@@ -235,6 +236,10 @@ def main():
             out["policy_variants"] = _guarded(policy_variants_leg, dev_idx, dev, L, args)
         if world == 1 and args.config == "nbd96" and not args.no_e2e:
             out["e2e_step"] = _guarded(e2e_leg, d_bases, min(n_res, args.e2e_reads), L, dev)
+        if world == 1 and args.config == "nbd96" and not args.no_boundary:
+            # the C ABI as the reference-side binding drives it: worker threads x own context x bb_annotate_batch on pageable host memory
+            # (tools/boundary_rate.py, csrc/host/boundary_bench.cpp); the resident reads are released first: the harness is a process of its own
+            out["boundary_step"] = _guarded(boundary_leg)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = _guarded(cpu_baseline, args, groups, dm, d_bases, L, batch, (args.steps - 1) % n_batches, d_rows, last_rows)
         print(json.dumps(out), flush=True)
@@ -457,6 +462,13 @@ def length_mix_leg(cfg, dev_idx, dev, args, n=100_000, steps=3):
         del d_b, d_o, d_rows
     out["heavy_tailed_vs_equal"] = out["heavy_tailed"]["gbases_per_s"] / out["equal_reads"]["gbases_per_s"]
     return out
+
+
+def boundary_leg():
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import boundary_rate
+
+    return boundary_rate.measure()
 
 
 def _guarded(leg, *a):

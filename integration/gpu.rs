@@ -143,6 +143,17 @@ extern "C" {
         rows_cap: u64,
         n_rows: *mut u64,
     ) -> i32;
+    fn bb_pack_bases(bases: *const u8, n: u64, out: *mut u8) -> u64;
+    fn bb_annotate_batch_packed(
+        ctx: *mut BbCtx,
+        packed: *const u8,
+        packed_offsets: *const u64,
+        offsets: *const u64,
+        n_reads: u32,
+        rows: *mut BbRow,
+        rows_cap: u64,
+        n_rows: *mut u64,
+    ) -> i32;
     fn bb_counts_len(ctx: *const BbCtx) -> u32;
     fn bb_counts(ctx: *mut BbCtx, out: *mut u64) -> i32;
     fn bb_strerror(code: i32) -> *const c_char;
@@ -203,6 +214,22 @@ fn match_type_of(code: u8) -> Result<BarcodeType> {
         BB_RFLANK => Ok(BarcodeType::Rflank),
         other => Err(anyhow!("barbell_amd: row with match_type {other}")),
     }
+}
+
+/// Reads per GPU call.  paraseq hands a worker ~1 k records at a time (`process_parallel(.., None)`, `annotator.rs:278-280`); a call into the
+/// library costs ~0.4 ms of its thread whatever it carries, so `DemuxProcessor` collects batches until it holds this many reads (32 MB of
+/// bases, 16 MB packed, per worker).  Measured on one MI355X with the reference's ten worker threads (`bench.py` -> `boundary_step`):
+/// calls of 1 024 reads 7.7 M reads/s, of 8 192 reads 12.7 M (PCIe-bound at 4 KB per read), of 8 192 packed reads 15-21 M.
+pub const GPU_BATCH_READS: usize = 8192;
+
+/// Appends `seq` two bases per byte (`bb_pack_bases`: 4-bit IUPAC base sets; AVX2 / AVX-512 inside the library) — the form
+/// `GpuDemuxer::annotate_batch_packed` takes.  Every read begins at a byte of its own.
+pub fn pack_bases_into(seq: &[u8], out: &mut Vec<u8>) {
+    let at = out.len();
+    let n = (seq.len() + 1) / 2;
+    out.resize(at + n, 0);
+    let wrote = unsafe { bb_pack_bases(seq.as_ptr(), seq.len() as u64, out.as_mut_ptr().add(at)) };
+    debug_assert_eq!(wrote as usize, n);
 }
 
 /// One annotate context on one GPU: the stand-in for `Demuxer` (`searcher.rs:202-226`).  Not `Sync`, like `Demuxer` (`&mut self`);
@@ -298,6 +325,44 @@ impl GpuDemuxer {
                     &mut n_rows,
                 )
             };
+        }
+        if rc != BB_OK {
+            return Err(error_text(rc, self.ctx));
+        }
+        Ok(&self.rows[..n_rows as usize])
+    }
+
+    /// The same for reads packed with `pack_bases_into`: read i is `packed[packed_offsets[i]..packed_offsets[i + 1]]`, its bases
+    /// `offsets[i]..offsets[i + 1]` (all three vectors as `DemuxProcessor` grows them record by record).  Rows are those of
+    /// `annotate_batch` on the original bytes; half the bytes cross PCIe.
+    pub fn annotate_batch_packed(&mut self, packed: &[u8], packed_offsets: &[u64], offsets: &[u64]) -> Result<&[BbRow]> {
+        let n_reads = (offsets.len().max(1) - 1) as u32;
+        if packed_offsets.len() != offsets.len() {
+            return Err(anyhow!("barbell_amd: {} packed offsets for {} offsets", packed_offsets.len(), offsets.len()));
+        }
+        if self.rows.len() < 4 * n_reads as usize + 64 {
+            self.rows.resize(4 * n_reads as usize + 64, BbRow::default());
+        }
+        let mut n_rows = 0u64;
+        let mut rc = BB_E_CAPACITY;
+        for _attempt in 0..2 {
+            rc = unsafe {
+                bb_annotate_batch_packed(
+                    self.ctx,
+                    packed.as_ptr(),
+                    packed_offsets.as_ptr(),
+                    offsets.as_ptr(),
+                    n_reads,
+                    self.rows.as_mut_ptr(),
+                    self.rows.len() as u64,
+                    &mut n_rows,
+                )
+            };
+            if rc != BB_E_CAPACITY {
+                break;
+            }
+            // n_rows holds the number of rows the batch has: grow once and run it again
+            self.rows.resize(n_rows as usize, BbRow::default());
         }
         if rc != BB_OK {
             return Err(error_text(rc, self.ctx));
