@@ -211,6 +211,36 @@ int main(int argc, char** argv) {
         } catch (const std::exception& e) { fprintf(stderr, "error: %s\n", e.what()); return 1; }
         return done_ok();
     }
+    if (cmd == "rendezvous") {   // test aid, no GPU: one rank of the --shard R/W --rccl-id meeting, summing the given counts through the files
+        std::string base, shard, bus = "cpu", counts;
+        double delay = 0;
+        bool say_hello = true;
+        for (int i = 2; i < argc; ++i) {
+            const std::string a = argv[i];
+            if (a == "--rccl-id" && i + 1 < argc) base = argv[++i];
+            else if (a == "--shard" && i + 1 < argc) shard = argv[++i];
+            else if (a == "--bus" && i + 1 < argc) bus = argv[++i];
+            else if (a == "--counts" && i + 1 < argc) counts = argv[++i];
+            else if (a == "--start-delay" && i + 1 < argc) delay = atof(argv[++i]);   // seconds before this rank "starts" (says hello)
+            else if (a == "--no-hello") say_hello = false;
+            else { fprintf(stderr, "error: unexpected argument '%s'\n", a.c_str()); return 2; }
+        }
+        std::vector<std::string> none;
+        uint32_t rank = 0, world = 1;
+        if (base.empty() || shard.empty() || !apply_shard(shard, none, rank, world, true)) { fputs("usage: barbell-amd rendezvous --rccl-id PATH --shard R/W --counts a,b,c [--bus NAME] [--start-delay S]\n", stderr); return 2; }
+        std::vector<uint64_t> local;
+        for (size_t pos = 0; pos < counts.size();) { const size_t c = counts.find(',', pos); local.push_back(strtoull(counts.substr(pos, c - pos).c_str(), nullptr, 10)); if (c == std::string::npos) break; pos = c + 1; }
+        try {
+            if (delay > 0) usleep((useconds_t)(delay * 1e6));
+            if (say_hello) shard_rendezvous_reset(base, rank);
+            bool shared = false;
+            const std::vector<uint64_t> total = rendezvous_sum_counts(base, rank, world, bus, local, &shared);
+            printf("total");
+            for (uint64_t v : total) printf(" %llu", (unsigned long long)v);
+            printf("\nshared_device %d\n", shared ? 1 : 0);
+        } catch (const BarbellError& e) { fprintf(stderr, "error: %s\n", e.what()); return 1; }
+        return 0;
+    }
     if (cmd == "stage") {   // test aid, no GPU: the staged upload text of the annotate path -> a file
         std::vector<std::string> in;
         std::string out;

@@ -281,7 +281,10 @@ struct AnnotateStats {
 unsigned effective_cpus();   // CPUs the process can keep busy: affinity mask cut by the cgroup's CPU quota (BARBELL_AMD_CPUS overrides)
 int stage_blocks(const std::vector<std::string>& read_files, size_t block_bytes, unsigned n_threads, bool two_line, bool pack, const std::string& out_path,
                  size_t& n_blocks, uint32_t byte_shard_rank = 0, uint32_t byte_shard_world = 1);   // `barbell-amd stage`: what the host stages for upload, to a file (no GPU); returns 4 / 2 / 1 (packed)
-void shard_rendezvous_reset(const std::string& rccl_id, uint32_t rank);   // bb_rccl.cpp; call at program start of a --shard R/W --rccl-id run
+void shard_rendezvous_reset(const std::string& rccl_id, uint32_t rank);   // bb_rendezvous.cpp (Rendezvous::hello); call at program start of a --shard R/W --rccl-id run
+// the histogram summed over the W processes through the rendezvous files alone, no GPU (`barbell-amd rendezvous`: tests/test_rendezvous.py)
+std::vector<uint64_t> rendezvous_sum_counts(const std::string& rccl_id, uint32_t rank, uint32_t world, const std::string& bus, const std::vector<uint64_t>& local,
+                                            bool* shared_device = nullptr);
 std::vector<std::string> inspect_summary(const AnnotateStats& st, size_t top_n);  // the lines of inspect.rs:186-205
 
 struct KitConfig {  // config.rs:34-48, CLI defaults bin/main.rs:208-262

@@ -14,16 +14,15 @@
 
 #include <unistd.h>
 
-#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
-#include <thread>
 #include <string>
 #include <vector>
 
 #include "bb_host.hpp"
+#include "bb_rendezvous.hpp"
 
 namespace barbell {
 
@@ -114,46 +113,11 @@ std::vector<uint64_t> allreduce_counts(const std::vector<Demuxer*>& dms, std::st
 
 
 // ---- one process per GPU: the histogram over the W processes of a `--shard R/W` run --------------------------------------------------
-namespace {
-// how long a shard that has finished its own files waits for the others to finish theirs (they meet at the END of their runs: unequal
-// shards make the fast ones wait); BARBELL_AMD_RCCL_TIMEOUT, in seconds
-double rendezvous_timeout_s() { const char* e = getenv("BARBELL_AMD_RCCL_TIMEOUT"); return e && atof(e) > 0 ? atof(e) : 3600.0; }
-// whole-file write made visible atomically (tmp + rename): a reader never sees half a file
-void publish(const std::string& path, const void* data, size_t bytes) {
-    const std::string tmp = path + ".tmp" + std::to_string((long)getpid());
-    FILE* f = fopen(tmp.c_str(), "wb");
-    if (!f || fwrite(data, 1, bytes, f) != bytes || fclose(f) != 0) throw BarbellError(BB_E_INVALID, "--rccl-id: cannot write '" + tmp + "'");
-    if (rename(tmp.c_str(), path.c_str()) != 0) throw BarbellError(BB_E_INVALID, "--rccl-id: cannot publish '" + path + "'");
-}
-std::vector<char> await_file(const std::string& path, size_t bytes) {
-    const auto t0 = std::chrono::steady_clock::now();
-    for (;;) {
-        if (FILE* f = fopen(path.c_str(), "rb")) {
-            std::vector<char> buf(bytes);
-            const size_t got = fread(buf.data(), 1, bytes, f);
-            fclose(f);
-            if (got == bytes) return buf;
-            throw BarbellError(BB_E_INVALID, "--rccl-id: '" + path + "' has " + std::to_string(got) + " bytes, expected " + std::to_string(bytes) +
-                                                 " (a stale file of another run? use a fresh path per run)");
-        }
-        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > rendezvous_timeout_s())
-            throw BarbellError(BB_E_INVALID, "--rccl-id: timed out waiting for '" + path + "' (is every shard of the run started with the same --rccl-id?)");
-        std::this_thread::sleep_for(std::chrono::milliseconds(2));
-    }
-}
-struct ShardInfo { char bus[64]; uint64_t n_counts; uint32_t world, rank; };
-}  // namespace
-
-// at program start: what an earlier, interrupted run of this rank left behind must not be read as this run's (use a fresh PATH per run anyway)
-void shard_rendezvous_reset(const std::string& base, uint32_t rank) {
-    for (const char* w : {"info", "counts", "done"}) (void)unlink((base + ".r" + std::to_string(rank) + "." + w).c_str());
-    if (rank == 0) (void)unlink((base + ".id").c_str());
-}
-
+// The processes meet through bb_rendezvous.cpp (identity-stamped files: a stale file of an interrupted run is never read as this run's).
 std::vector<uint64_t> allreduce_counts_shards(Demuxer* lead, const std::vector<uint64_t>& local, uint32_t rank, uint32_t world,
                                               const std::string& base, std::string& how) {
     const size_t n = local.size();
-    auto part = [&](uint32_t r, const char* what) { return base + ".r" + std::to_string(r) + "." + what; };
+    Rendezvous rv(base, rank, world);
     ShardInfo me;
     memset(&me, 0, sizeof(me));
     HCHK(hipDeviceGetPCIBusId(me.bus, (int)sizeof(me.bus), lead->device()));
@@ -162,23 +126,16 @@ std::vector<uint64_t> allreduce_counts_shards(Demuxer* lead, const std::vector<u
     const size_t bl = strlen(me.bus);
     snprintf(me.bus + bl, sizeof(me.bus) - bl, "@%s", host);   // RCCL's duplicate-GPU rule is per (host, device)
     me.n_counts = n; me.world = world; me.rank = rank;
-    publish(part(rank, "info"), &me, sizeof(me));
+    const std::vector<ShardInfo> all = rv.meet(me);
     bool shared_device = false;
-    std::vector<ShardInfo> all(world);
-    for (uint32_t r = 0; r < world; ++r) {
-        const std::vector<char> b = await_file(part(r, "info"), sizeof(ShardInfo));
-        memcpy(&all[r], b.data(), sizeof(ShardInfo));
-        if (all[r].n_counts != n || all[r].world != world || all[r].rank != r)
-            throw BarbellError(BB_E_INVALID, "--rccl-id: shard " + std::to_string(r) + " runs other queries or another --shard W (histogram of " +
-                                                 std::to_string(all[r].n_counts) + " slots, W = " + std::to_string(all[r].world) + ")");
+    for (uint32_t r = 0; r < world; ++r)
         for (uint32_t q = 0; q < r; ++q) shared_device |= !strcmp(all[q].bus, all[r].bus);
-    }
     std::vector<uint64_t> total(n, 0);
     if (shared_device) {
         // two ranks of one communicator cannot sit on one GPU: sum through the files (every rank reads every rank's counts)
-        publish(part(rank, "counts"), local.data(), n * sizeof(uint64_t));
+        rv.publish("counts", local.data(), n * sizeof(uint64_t), (int)rank);
         for (uint32_t r = 0; r < world; ++r) {
-            const std::vector<char> b = await_file(part(r, "counts"), n * sizeof(uint64_t));
+            const std::vector<char> b = rv.await("counts", n * sizeof(uint64_t), (int)r);
             const uint64_t* c = (const uint64_t*)b.data();
             for (size_t i = 0; i < n; ++i) total[i] += c[i];
         }
@@ -187,9 +144,9 @@ std::vector<uint64_t> allreduce_counts_shards(Demuxer* lead, const std::vector<u
         ncclUniqueId id;
         if (rank == 0) {
             RCHK(rccl().GetUniqueId(&id));
-            publish(base + ".id", &id, sizeof(id));
+            rv.publish("id", &id, sizeof(id), -1);
         } else {
-            const std::vector<char> b = await_file(base + ".id", sizeof(id));
+            const std::vector<char> b = rv.await("id", sizeof(id), -1);
             memcpy(&id, b.data(), sizeof(id));
         }
         HCHK(hipSetDevice(lead->device()));
@@ -204,14 +161,7 @@ std::vector<uint64_t> allreduce_counts_shards(Demuxer* lead, const std::vector<u
         total = lead->counts();
         how = "rccl (" + std::to_string(world) + " processes, ncclCommInitRank)";
     }
-    // rank 0 removes the rendezvous files once every rank has read what it needs
-    publish(part(rank, "done"), "1", 1);
-    if (rank == 0) {
-        for (uint32_t r = 0; r < world; ++r) (void)await_file(part(r, "done"), 1);
-        for (uint32_t r = 0; r < world; ++r)
-            for (const char* w : {"info", "counts", "done"}) (void)unlink(part(r, w).c_str());
-        (void)unlink((base + ".id").c_str());
-    }
+    rv.finish();   // rank 0 removes the run's files once every rank has read what it needs
     return total;
 }
 

@@ -155,6 +155,7 @@ def main():
         dl[0] += dk_ms
         dl[1] += 1
     hist = torch.from_numpy(dm.counts().astype(np.int64)).to(cdev)
+    rank_devices = None
     if use_dist:
         dist.all_reduce(hist)  # RCCL over xGMI: the only collective of the path
     torch.cuda.synchronize()
@@ -165,6 +166,12 @@ def main():
     if use_dist:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
+    if use_dist:
+        # which device every rank ran on (outside the timed region): a SCALE record can be checked for "the backend saw N ranks on N devices"
+        mine = {"rank": rank, "local_rank": local_rank, "device": dev_idx, "pci_bus_id": _pci_bus_id(dev_idx), "reads": args.steps * batch}
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
+        rank_devices = gathered
     reads_done = args.steps * batch * world
     value = reads_done / elapsed
 
@@ -209,7 +216,8 @@ def main():
         }
         if use_dist:
             out["dist"] = {"backend": dist.get_backend(), "world": dist.get_world_size(), "forced_at_world_1": bool(args.force_dist and world == 1),
-                           "collectives": ["barrier", "all_reduce(histogram, sum)", "all_reduce(elapsed, max)"]}
+                           "collectives": ["barrier", "all_reduce(histogram, sum)", "all_reduce(elapsed, max)"],
+                           "ranks": rank_devices, "distinct_devices": len({(r or {}).get("pci_bus_id") for r in rank_devices or []})}
         if args.print_histogram:
             out["histogram"] = [int(x) for x in hist.cpu().tolist()]
         if args.config == "nbd96":
@@ -246,6 +254,14 @@ def main():
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def _pci_bus_id(dev_idx):
+    try:
+        p = torch.cuda.get_device_properties(dev_idx)
+        return f"{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}" if hasattr(p, "pci_bus_id") else str(dev_idx)
+    except Exception:  # noqa: BLE001
+        return str(dev_idx)
 
 
 def other_config_leg(cfg, dev_idx, dev, L, args, n=1_000_000, steps=3):

@@ -11,7 +11,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 COMMON = ["--reads", "200000", "--batch", "100000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-other-configs", "--no-e2e", "--no-policy-variants",
-          "--print-histogram"]
+          "--no-stress", "--no-boundary", "--print-histogram"]
 
 
 def _bench(extra, env_extra=None):
@@ -40,6 +40,21 @@ def test_gpus_2_starts_two_ranks(backend):
     assert two["histogram"] == want and two["histogram_total"] == a["histogram_total"] + b["histogram_total"] > 0
     # two ranks x 2 steps x 100000 reads
     assert abs(two["value"] * two["ms_per_step"] * 1e-3 * two["steps"] - 2 * 2 * 100000) < 1.0
+
+
+@pytest.mark.gpu
+def test_eight_ranks_as_the_scaling_run_starts_them():
+    """The size SCALE runs at: `python bench.py --gpus 8` -> eight ranks (launcher, port choice, --gpus / WORLD_SIZE checks, shards, the
+    histogram reduce, the line's `dist` object with every rank's device), here on the one GPU (gloo, --device-mod 1) with the reads cut
+    to fit: the all-reduced histogram is the one-rank histogram of the same 8 x 40 000 reads, and the line says eight ranks on one device."""
+    small = ["--reads", "40000", "--batch", "20000"]
+    eight = _bench(["--gpus", "8", "--backend", "gloo", "--device-mod", "1"] + small)
+    assert eight["n_gpus"] == 8 and eight["dist"]["world"] == 8 and eight["dist"]["backend"] == "gloo"
+    assert [r["rank"] for r in eight["dist"]["ranks"]] == list(range(8)) and eight["dist"]["distinct_devices"] == 1
+    assert all(r["reads"] == 2 * 20000 for r in eight["dist"]["ranks"])
+    one = _bench(["--gpus", "1", "--reads", "320000", "--batch", "20000", "--steps", "16"])
+    assert eight["histogram"] == one["histogram"] and eight["histogram_total"] > 100000
+    assert abs(eight["value"] * eight["ms_per_step"] * 1e-3 * eight["steps"] - 8 * 2 * 20000) < 1.0
 
 
 @pytest.mark.gpu
