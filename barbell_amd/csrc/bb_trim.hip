@@ -114,6 +114,8 @@ __global__ __launch_bounds__(128) void k_trim_plan(const bb_row* __restrict__ ro
         for (uint32_t q = 0; q < v.n_cuts && q < BB_MAX_CUTS; ++q) {
             if (n_e == BB_TRIM_MAX_E) { overflow = true; break; }
             e_gid[n_e] = v.cuts[q].group_id; e_start[n_e] = rows[t + r].read_start_flank; e_end[n_e] = rows[t + r].read_end_flank;
+            // rows that do not belong to this read (an annotation file of other reads with the same ids: the reference panics on seq[start..end])
+            if (e_end[n_e] > seq_len || e_start[n_e] > e_end[n_e]) { atomicOr(err, 4u); atomicMin(err + 1, read); return; }
             e_row[n_e] = (uint16_t)r;
             if (v.cuts[q].direction == BB_CUT_AFTER) after_mask |= 1u << n_e;
             ++n_e;
@@ -409,6 +411,7 @@ static int trim_impl(bb_ctx* ctx, const bb_row* d_rows, const bb_row_verdict* d_
         const uint32_t nb = (uint32_t)((n_rows + 2047) / 2048);
         if ((r = tgrow(v, s->d_sums, s->cap_sums, (uint64_t)nb + 1))) return r;
         TCHK(v, hipMemsetAsync(s->d_err, 0, 4 * sizeof(uint32_t), st));
+        TCHK(v, hipMemsetAsync(s->d_err + 1, 0xFF, sizeof(uint32_t), st));   // the first read whose rows lie beyond its end (atomicMin)
         const dim3 pg((unsigned)((n_rows + 127) / 128));
         hipLaunchKernelGGL(k_trim_plan<false>, pg, dim3(128), 0, st, d_rows, d_ver, n_rows, v.d_groups, v.d_label_ids,
                            (const uint8_t*)s->d_is_flank, (const uint32_t*)s->d_part_rank, s->cfg, d_offsets, h->hdr_offsets, h->id_len,
@@ -419,6 +422,7 @@ static int trim_impl(bb_ctx* ctx, const bb_row* d_rows, const bb_row_verdict* d_
         TCHK(v, hipStreamSynchronize(st));
         if (herr[0] & 1u) { *v.last_error = "row with read_idx >= n_reads"; return BB_E_INVALID; }
         if (herr[0] & 2u) { *v.last_error = "more than 32 cuts on one read"; return BB_E_UNSUPPORTED; }
+        if (herr[0] & 4u) { *v.last_error = "read " + std::to_string(herr[1]) + ": a row with a cut lies beyond the read's end (rows of other reads?)"; return BB_E_INVALID; }
         ns = herr[2];
     }
     if (ns) {

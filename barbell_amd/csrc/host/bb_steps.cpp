@@ -12,6 +12,7 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <cerrno>
 #include <cstdio>
 #include <cstring>
 #include <ctime>
@@ -99,8 +100,9 @@ inline int kind_of(int mt) { return mt == (int)BarcodeType::Rtag || mt == (int)B
 long long to_int(const std::string& s, const char* what, const std::string& path) {
     if (s.empty()) fail(path + ": " + what + ": empty");
     char* end = nullptr;
+    errno = 0;
     const long long v = strtoll(s.c_str(), &end, 10);
-    if (*end) fail(path + ": " + what + ": '" + s + "' is not an integer");
+    if (*end || errno == ERANGE) fail(path + ": " + what + ": '" + s + "' is not an integer");
     return v;
 }
 
@@ -123,6 +125,7 @@ void parse_cuts(const std::string& s, bb_row_verdict& v) {
         else fail("Invalid cut string: " + cut);
         if (gid.empty() || p.empty() || gid.find_first_not_of("0123456789") != std::string::npos || p.find_first_not_of("0123456789") != std::string::npos)
             fail("Invalid cut string: " + part);
+        if (p.size() > 5 || atol(p.c_str()) > 0xFFFF) fail("cut position above 65535: " + part);
         const long q = atol(p.c_str());
         if (pos >= 0 && q != pos) fail("cuts of one row with different positions (" + s + "): not what the filter step writes");
         pos = q;
@@ -203,15 +206,22 @@ struct LabelSpace {
     }
 };
 
+// a column's value inside its field of the row record (the Python twin raises TsvError "outside the range of the row record")
+long long in_range(const std::string& text, const char* what, const std::string& path, long long lo, long long hi) {
+    const long long v = to_int(text, what, path);
+    if (v < lo || v > hi) fail(path + ": " + what + ": " + text + " is outside the range of the row record");
+    return v;
+}
 bb_row make_row(const std::vector<std::string>& f, uint32_t read_idx, const LabelSpace& sp, const std::string& path) {
     bb_row r{};
+    const long long U32 = 0xFFFFFFFFll;
     r.read_idx = read_idx;
-    r.read_len = (uint32_t)to_int(f[C_LEN], "read_len", path);
-    r.rel_dist_to_end = (int32_t)to_int(f[C_REL], "rel_dist_to_end", path);
-    r.read_start_bar = (uint32_t)to_int(f[C_SB], "read_start_bar", path); r.read_end_bar = (uint32_t)to_int(f[C_EB], "read_end_bar", path);
-    r.read_start_flank = (uint32_t)to_int(f[C_SF], "read_start_flank", path); r.read_end_flank = (uint32_t)to_int(f[C_EF], "read_end_flank", path);
-    r.bar_start = (uint32_t)to_int(f[C_BS], "bar_start", path); r.bar_end = (uint32_t)to_int(f[C_BE], "bar_end", path);
-    r.flank_cost = (int16_t)to_int(f[C_FC], "flank_cost", path); r.barcode_cost = (int16_t)to_int(f[C_BC], "barcode_cost", path);
+    r.read_len = (uint32_t)in_range(f[C_LEN], "read_len", path, 0, U32);
+    r.rel_dist_to_end = (int32_t)in_range(f[C_REL], "rel_dist_to_end", path, -0x80000000ll, 0x7FFFFFFFll);
+    r.read_start_bar = (uint32_t)in_range(f[C_SB], "read_start_bar", path, 0, U32); r.read_end_bar = (uint32_t)in_range(f[C_EB], "read_end_bar", path, 0, U32);
+    r.read_start_flank = (uint32_t)in_range(f[C_SF], "read_start_flank", path, 0, U32); r.read_end_flank = (uint32_t)in_range(f[C_EF], "read_end_flank", path, 0, U32);
+    r.bar_start = (uint32_t)in_range(f[C_BS], "bar_start", path, 0, U32); r.bar_end = (uint32_t)in_range(f[C_BE], "bar_end", path, 0, U32);
+    r.flank_cost = (int16_t)in_range(f[C_FC], "flank_cost", path, -32768, 32767); r.barcode_cost = (int16_t)in_range(f[C_BC], "barcode_cost", path, -32768, 32767);
     const int mt = match_type_of(f[C_MT], path);
     const auto s = sp.lookup(mt, f[C_LAB], path);
     r.group_idx = (decltype(r.group_idx))s.first; r.barcode_idx = (int16_t)s.second; r.match_type = (uint8_t)mt;
@@ -387,7 +397,13 @@ StepStats filter_file(const std::string& annotated_file, const std::string& outp
                 if (!i || rows[i].read_idx != rows[i - 1].read_idx) { ++st.total; ++(w ? st.dropped : st.kept); }
                 if (!out[w]) continue;
                 if (!wrote[w]) { fprintf(out[w], "%s\n", TSV_HEADER); wrote[w] = true; }   // the csv writer emits the header with the first record only
-                const std::string l = line_of(fields[i], format_cuts(v[i]));
+                // the cuts the row came with stay, the new ones follow (filter.rs:204-209: existing_cuts.push) — a filtered.tsv filtered again,
+                // e.g. with a sub-selecting pattern without cut markers, keeps what `trim` needs
+                if ((size_t)ver[i].n_cuts + v[i].n_cuts > BB_MAX_CUTS)
+                    fail(annotated_file + ": read '" + ids[rows[i].read_idx] + "': more than 3 cuts on one row after this filter (kernel limit, include/barbell_amd_filter.h)");
+                std::string cuts = ver[i].n_cuts ? fields[i][C_CUTS] : std::string();
+                if (v[i].n_cuts) { if (!cuts.empty()) cuts += ','; cuts += format_cuts(v[i]); }
+                const std::string l = line_of(fields[i], cuts);
                 fwrite(l.data(), 1, l.size(), out[w]);
             }
         }
@@ -461,6 +477,7 @@ StepStats trim_file(const std::string& filtered_match_file, const std::vector<st
     if (!sp.groups.empty()) { dm = context_for(sp, device, {}); dm->set_trim(cfg); }
     std::map<std::string, OutFile> writers;
     FILE* failed = cfg.failed_trimmed_writer ? fopen(cfg.failed_trimmed_writer->c_str(), "wb") : nullptr;
+    if (cfg.failed_trimmed_writer && !failed) fail("Failed to create " + *cfg.failed_trimmed_writer);   // (the reference unwraps the open: trim.rs:364-370)
     FastqBatch b;
     std::vector<bb_row> rows;
     std::vector<bb_row_verdict> ver;
@@ -500,7 +517,16 @@ StepStats trim_file(const std::string& filtered_match_file, const std::vector<st
             if (it == by_id.end()) continue;
             if (qual.size() != seq.size()) fail("FASTQ record '" + h.substr(0, id_len) + "': " + std::to_string(seq.size()) + " bases, " + std::to_string(qual.size()) + " qualities");
             const uint32_t ridx = (uint32_t)b.ids.size();
-            for (const auto& rv : anno[it->second]) { rows.push_back(rv.first); rows.back().read_idx = ridx; ver.push_back(rv.second); }
+            for (const auto& rv : anno[it->second]) {
+                // the annotation must be THIS record's (another FASTQ with the same ids, re-basecalled reads, edited rows): the reference panics on
+                // seq[start..end]; unchecked, the kernels would copy a neighbour's bases
+                const bb_row& a = rv.first;
+                if (a.read_len != seq.size() || a.read_start_flank > seq.size() || a.read_end_flank > seq.size() || a.read_start_flank > a.read_end_flank)
+                    fail(filtered_match_file + ": read '" + h.substr(0, id_len) + "': the annotation says read_len " + std::to_string(a.read_len) + ", flank " +
+                         std::to_string(a.read_start_flank) + ".." + std::to_string(a.read_end_flank) + ", the FASTQ record has " + std::to_string(seq.size()) +
+                         " bases (an annotation file of other reads?)");
+                rows.push_back(a); rows.back().read_idx = ridx; ver.push_back(rv.second);
+            }
             b.ids.push_back(h.substr(0, id_len));
             b.bases.insert(b.bases.end(), seq.begin(), seq.end());
             b.quals.insert(b.quals.end(), qual.begin(), qual.end());

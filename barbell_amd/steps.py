@@ -14,6 +14,7 @@ these steps read a row's slot and its label id, never the query sequences."""
 import csv
 import io
 import os
+import re
 
 import numpy as np
 
@@ -132,17 +133,24 @@ class TsvBatch:
         self.rows, self.verdicts, self.read_ids, self.has_cuts, self.fields, self.columns = rows, verdicts, read_ids, has_cuts, fields, columns
 
     def lines(self, verdicts):
-        """the records as TSV lines in the schema's column order with the cuts of `verdicts` — the fields as they stand in the file (the
-        csv writer's own output is canonical: re-serialising it gives it back), a field that needs quoting quoted again"""
+        """the records as TSV lines in the schema's column order — the fields as they stand in the file (the csv writer's own output is
+        canonical: re-serialising it gives it back), a field that needs quoting quoted again — with the cuts the rows CAME with followed by
+        the cuts of `verdicts` (filter.rs:204-209: `existing_cuts.push`; a filtered.tsv filtered again keeps what `trim` needs)"""
         order = [self.columns[name] for name in COLUMNS[:-1]]
+        cut_col = self.columns[COLUMNS[-1]]
         cut_rows = np.nonzero(verdicts["n_cuts"])[0]
         cuts = dict(zip(cut_rows.tolist(), (format_cuts(verdicts[i]) for i in cut_rows)))
+        too_many = np.nonzero(self.verdicts["n_cuts"].astype(np.int64) + verdicts["n_cuts"] > 3)[0]
+        if len(too_many):
+            raise TsvError(f"read {self.read_ids[int(self.rows['read_idx'][too_many[0]])]!r}: more than 3 cuts on one row after this filter "
+                           "(kernel limit, include/barbell_amd_filter.h)")
         out = []
         for i, rec in enumerate(self.fields):
             f = [rec[j] for j in order]
             if any(ch in f[0] for ch in '\t"\n\r') or any(ch in f[12] for ch in '\t"\n\r'):
                 f[0], f[12] = _csv_field(f[0]), _csv_field(f[12])
-            f.append(cuts.get(i, ""))
+            old, new = (rec[cut_col] if self.verdicts["n_cuts"][i] else ""), cuts.get(i, "")
+            f.append(old + "," + new if old and new else old or new)
             out.append("\t".join(f))
         return out
 
@@ -201,6 +209,9 @@ _INT_FIELDS = ("read_len", "rel_dist_to_end", "read_start_bar", "read_end_bar", 
                "flank_cost", "barcode_cost")
 
 
+_INTS_RE = re.compile(r"(?:-?[0-9]+)?(?:\n-?[0-9]+)*")
+
+
 def _ints(strings, what, path):
     """decimal fields of many records in one C call"""
     import warnings
@@ -211,8 +222,9 @@ def _ints(strings, what, path):
             a = np.fromstring(" ".join(strings), dtype=np.int64, sep=" ") if strings else np.zeros(0, dtype=np.int64)
     except ValueError:
         a = np.zeros(0, dtype=np.int64)
-    if len(a) != len(strings) or not all(s.lstrip("-").isdigit() for s in strings[:: max(1, len(strings) // 64)]):
-        bad = next((s for s in strings if not s.lstrip("-").isdigit()), "?")
+    # every field is checked, not a sample: "1 2" in one record and "" in another would parse to the right COUNT and shift values onto other rows
+    if len(a) != len(strings) or not _INTS_RE.fullmatch("\n".join(strings)):
+        bad = next((s for s in strings if not re.fullmatch(r"-?[0-9]+", s)), "?")
         raise TsvError(f"{path}: {what}: {bad!r} is not an integer")
     return a
 
@@ -451,6 +463,12 @@ def trim_file(filtered_match_file, read_fastq_files, output_folder, config=None,
                     continue
                 if len(q) != len(s):
                     raise ValueError(f"FASTQ record '{rid}' has no quality scores" if not q else f"FASTQ record '{rid}': {len(s)} bases, {len(q)} qualities")
+                # the annotation must be THIS record's (another FASTQ with the same ids, re-basecalled reads, edited rows): the reference panics
+                # on seq[start..end]; unchecked, the kernels would copy a neighbour's bases
+                a = anno.rows[bounds[k]:bounds[k + 1]]
+                if np.any(a["read_len"] != len(s)) or np.any(a["read_end_flank"] > len(s)) or np.any(a["read_start_flank"] > a["read_end_flank"]):
+                    raise TsvError(f"{filtered_match_file}: read {rid!r}: the annotation says read_len {int(a['read_len'][0])}, flank ends up to "
+                                   f"{int(a['read_end_flank'].max())}; the FASTQ record has {len(s)} bases (an annotation file of other reads?)")
                 pend.append((k, h, s, q))
                 if len(pend) >= batch_reads:
                     flush()

@@ -404,3 +404,79 @@ def test_cpp_host_steps_on_files_give_the_fused_runs_files(tmp_path):
     assert r.returncode == 0, r.stderr
     both = (alone / "odd_f.tsv").read_text() + (alone / "odd_d.tsv").read_text()
     assert '"odd ""id""\tx"\t' in both
+
+
+@pytest.mark.gpu
+def test_filtering_a_filtered_file_keeps_its_cuts_and_trim_refuses_rows_of_other_reads(tmp_path):
+    """ADVICE r5.  (a) `filter` on a filtered.tsv with a second, sub-selecting pattern WITHOUT cut markers: the rows keep the cuts they came
+    with (filter.rs:204-209 pushes onto the existing cuts), so `trim` on the result still cuts every read — both hosts, same bytes.
+    (b) `trim` with a FASTQ whose records are not the annotated ones (same ids, shorter sequences): an error naming the read, in both
+    hosts, instead of neighbours' bases in the output (the reference panics on seq[start..end])."""
+    from barbell_amd import steps, trim as T
+
+    groups = kits.groups_from_kit(KIT)
+    fq = tmp_path / "r.fastq"
+    _write_fastq(fq, groups, 600, 23)
+    pats = F.kit_patterns(KIT, True)
+    one = tmp_path / "one"
+    one.mkdir()
+    A.annotate([str(fq)], str(one / "annotation.tsv"), kits.groups_from_kit(KIT), batch_reads=300, filter_patterns=pats, filtered_file=str(one / "filtered.tsv"),
+               dropped_file=str(one / "dropped.tsv"))
+    first = (one / "filtered.tsv").read_text().splitlines()
+    assert sum(1 for l in first[1:] if l.split("\t")[-1]) > 200
+    # (a) a pattern set that matches every read the first filter kept, and marks no cut
+    plain = tmp_path / "plain.txt"
+    import re
+
+    plain.write_text("\n".join(re.sub(r"(, )?(>>|<<)[0-9]*(, )?", lambda m: ", " if m.group(1) and m.group(3) else "", p)
+                               for p in kits._data()["pattern_sets"][kits._data()["kit_filter"][KIT]["maximize"]]) + "\n")
+    assert ">>" not in plain.read_text() and "<<" not in plain.read_text()
+    two_py, two_cc = tmp_path / "two_py.tsv", tmp_path / "two_cc.tsv"
+    t, kept, dropped = steps.filter_file(str(one / "filtered.tsv"), str(two_py), F.patterns_from_files([str(plain)]), log=lambda s: None)
+    assert kept == t > 300 and dropped == 0
+    r = _cli("filter", "-i", one / "filtered.tsv", "-o", two_cc, "-f", plain)
+    assert r.returncode == 0, r.stderr
+    assert two_py.read_bytes() == two_cc.read_bytes() == (one / "filtered.tsv").read_bytes()      # nothing new to add: the file as it was, cuts included
+    # ... and with cut markers again: old cuts first, the new ones behind them
+    again = tmp_path / "again.tsv"
+    steps.filter_file(str(one / "filtered.tsv"), str(again), pats, log=lambda s: None)
+    both = [(a.split("\t")[-1], b.split("\t")[-1]) for a, b in zip(first[1:], again.read_text().splitlines()[1:])]
+    assert all(b == (a + "," + a if a else "") for a, b in both) and any(a for a, _ in both)
+    kit_pats = tmp_path / "kit_pats.txt"
+    kit_pats.write_text("\n".join(kits._data()["pattern_sets"][kits._data()["kit_filter"][KIT]["maximize"]]) + "\n")
+    r = _cli("filter", "-i", one / "filtered.tsv", "-o", tmp_path / "again_cc.tsv", "-f", kit_pats)
+    assert r.returncode == 0 and (tmp_path / "again_cc.tsv").read_bytes() == again.read_bytes(), r.stderr
+    cfg = T.TrimConfig.for_kit(None)
+    out_a, out_b = tmp_path / "ta", tmp_path / "tb"
+    n_a = steps.trim_file(str(one / "filtered.tsv"), [str(fq)], str(out_a), cfg, log=lambda s: None)
+    n_b = steps.trim_file(str(two_py), [str(fq)], str(out_b), cfg, log=lambda s: None)
+    assert n_a == n_b and n_a[1] > 300 and _dir_bytes(out_a, ".trimmed.fastq") == _dir_bytes(out_b, ".trimmed.fastq")
+    # (b) the same ids, every sequence cut to its first 120 bases
+    short = tmp_path / "short.fastq"
+    recs = fq.read_bytes().split(b"\n")
+    with open(short, "wb") as f:
+        for i in range(0, len(recs) - 1, 4):
+            f.write(recs[i] + b"\n" + recs[i + 1][:120] + b"\n+\n" + recs[i + 3][:120] + b"\n")
+    with pytest.raises(steps.TsvError, match="FASTQ record has 120 bases"):
+        steps.trim_file(str(one / "filtered.tsv"), [str(short)], str(tmp_path / "tc"), cfg, log=lambda s: None)
+    r = _cli("trim", "-i", one / "filtered.tsv", "-r", short, "-o", tmp_path / "td")
+    assert r.returncode == 1 and "FASTQ record has 120 bases" in r.stderr and "read 'q" in r.stderr, r.stderr
+    assert not any(p.stat().st_size for p in (tmp_path / "td").glob("*.trimmed.fastq"))
+    # the kernel's own guard, for callers of the C ABI that skip the hosts' check: rows beyond the read's end are BB_E_INVALID, not a copy
+    dm = A.Demuxer()
+    for g in kits.groups_from_kit(KIT):
+        dm.add_query_group(g)
+    space = steps.LabelSpace(kits.groups_from_kit(KIT))
+    b = next(steps.read_annotation_tsv(str(one / "filtered.tsv"), space, group_consecutive=False))
+    k = int(np.nonzero(b.verdicts["n_cuts"])[0][0])
+    rd = int(b.rows["read_idx"][k])
+    sel = b.rows["read_idx"] == rd
+    rows, ver = b.rows[sel].copy(), b.verdicts[sel].copy()
+    rows["read_idx"] = 0
+    L = 10                                      # a record far shorter than the rows say
+    assert int(rows["read_end_flank"].max()) > L
+    F.Filter(dm, pats)                          # (installs the label ids the trim step keys its labels by)
+    tr = T.Trimmer(dm, cfg)
+    with pytest.raises(A.BarbellError, match="beyond the read's end"):
+        tr.trim_batch(rows, ver, np.full(L, ord("A"), dtype=np.uint8), np.full(L, ord("I"), dtype=np.uint8), np.array([0, L], dtype=np.uint64), [b"x"])
+    dm.close()
