@@ -877,9 +877,11 @@ def cpu_baseline(args, groups, dm, d_bases, L, batch, last_batch, d_rows, last_r
     * The CPU checker is always run on three windows of the LAST timed batch — its first reads, its middle and its last
       reads, whose byte offsets lie beyond 4 GiB — with its scalar restatement (what every parity test compares the GPU with),
       and each window's rows are compared bit-exact with the full-batch device rows restricted to it.
-    * The reported CPU rate (kind "port-bitparallel") is the checker's bit-parallel path — 64-bit Myers / Hyyro words for the flank
-      scan and the barcode set, OpenMP over reads, the same rows (tests/test_oracle_fast.py) — on a larger window of the same
-      batch; the scalar restatement's rate is carried as `scalar_value`.  Real Barbell runs AVX2 sassy: a scalar O(m n)
+    * The reported CPU rate is the checker's timing path on a larger window of the same batch, OpenMP over reads, the same rows
+      (tests/test_oracle_fast.py): kind "port-simd" where the host has AVX-512 (round 6: the flank scan text-parallel as sassy's `search` is
+      — chunks of the read in the lanes of a vector with an m + k overlap —, the barcode pass pattern-parallel as its
+      `search_encoded_patterns`, Lodhi scores eight candidates per vector: oracle/bb_oracle_simd.h), "port-bitparallel" (64-bit Myers /
+      Hyyro words) elsewhere; the scalar restatement's rate is carried as `scalar_value`.  Real Barbell runs SIMD sassy: a scalar O(m n)
       loop would understate what a CPU does by an order of magnitude."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import ref_diff
@@ -928,11 +930,16 @@ def cpu_baseline(args, groups, dm, d_bases, L, batch, last_batch, d_rows, last_r
     fdt = time.perf_counter() - t
     fgot = full[full["read_idx"] < nf]
     visible = os.cpu_count() or 1
-    out = {"value": nf / fdt, "unit": "reads/s", "cores": cores, "kind": "port-bitparallel", "cpus_visible": visible,
+    simd = po.Oracle.fast_is_simd()
+    out = {"value": nf / fdt, "unit": "reads/s", "cores": cores, "kind": "port-simd" if simd else "port-bitparallel", "cpus_visible": visible,
+           "per_core": nf / fdt / cores,
+           "simd": ("AVX-512: flank scan text-parallel (8 chunks of the read in the 64-bit lanes of a vector, m + k columns of overlap, valleys replayed by the "
+                    "local-minimum machine), barcode pass pattern-parallel (8 padded barcodes per vector), Lodhi scores 8 candidates per vector; "
+                    "round 5's 64-bit words on the same box: 6.8 k reads/s per core" if simd else "none (no AVX-512 on this host): 64-bit Myers words"),
            "cores_note": (f"{cores} = this container's CPU quota (cgroup cpu.max) of the {visible} CPUs it sees; one pinned OpenMP worker per quota CPU "
                           f"(a pool of {visible} floating threads ran slower: throttled)" if cores < visible else f"all {cores} CPUs, one pinned OpenMP worker each"),
-           "sample": f"first {nf} reads of the last timed {batch}-read batch of the same synthetic stream, CPU checker's bit-parallel path (64-bit "
-                     f"Myers words, OpenMP over reads, {cores} threads), {fdt:.1f} s wall; parity windows: 3 x {w} reads (head, middle, tail) with "
+           "sample": f"first {nf} reads of the last timed {batch}-read batch of the same synthetic stream, CPU checker's timing path "
+                     f"(bbo_annotate_batch_fast, OpenMP over reads, {cores} threads), {fdt:.1f} s wall; parity windows: 3 x {w} reads (head, middle, tail) with "
                      f"the scalar restatement, {total_dt:.1f} s wall",
            "scalar_value": 3 * w / total_dt, "bitparallel_rows_equal_gpu": bool(fgot.tobytes() == fwant.tobytes()),
            "parity_on_sample": all(v["parity"] for v in windows.values()), "parity_windows": windows, "rows_on_sample": int(total_rows),

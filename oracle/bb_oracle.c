@@ -88,6 +88,16 @@ static inline uint8_t text_code(uint8_t c) {
     uint8_t k = bbo_iupac_code(c);
     return k == 0xFF ? 0 : k;
 }
+/* the same as a table (the timing path converts every base of every read) */
+static const uint8_t* text_code_table(void) {
+    static uint8_t T[256];
+    static int made = 0;
+    if (!made) {
+#pragma omp critical(bbo_text_code_table)
+        { if (!made) { for (int c = 0; c < 256; ++c) T[c] = text_code((uint8_t)c); __atomic_store_n(&made, 1, __ATOMIC_RELEASE); } }
+    }
+    return T;
+}
 /* complement of a base set: A<->T, C<->G */
 static inline uint8_t comp_code(uint8_t k) {
     return (uint8_t)(((k & 1) << 3) | ((k & 8) >> 3) | ((k & 2) << 1) | ((k & 4) >> 1));
@@ -479,6 +489,7 @@ typedef struct {
     int W64;               /* 64-bit words of the flank */
     uint64_t* fpeq[2];     /* [strand][16 text codes][W64]; strand 1 = complement(flank) */
     uint64_t* bpeq[2];     /* [strand][n_seqs][16 text codes], padded barcodes (<= 64 characters) */
+    void* bartab[2];       /* bbo_bartab (bb_oracle_simd.h): the same masks, 8 patterns per vector; NULL without AVX-512 */
 } ogroup;
 
 struct bbo_ctx { uint32_t n_groups; ogroup* g; bb_params p; bb_policy pol; };
@@ -557,7 +568,9 @@ static int prep_group(const bb_policy* P, const bb_group_desc* d, ogroup* g) {
     }
     return BB_OK;
 }
-static void free_group(ogroup* g) { free(g->flank); free(g->pat_fwd); free(g->pat_rc); for (int st = 0; st < 2; ++st) { free(g->fpeq[st]); free(g->bpeq[st]); } }
+static void free_bartab(void* t);   /* bb_oracle_simd.h */
+static void group_build_bartab(ogroup* g);
+static void free_group(ogroup* g) { free(g->flank); free(g->pat_fwd); free(g->pat_rc); for (int st = 0; st < 2; ++st) { free(g->fpeq[st]); free(g->bpeq[st]); free_bartab(g->bartab[st]); } }
 
 int bbo_create(const bb_group_desc* groups, uint32_t n_groups, const bb_params* params, bbo_ctx** out) {
     return bbo_create_policy(groups, n_groups, params, cur_pol(), out);
@@ -572,6 +585,7 @@ int bbo_create_policy(const bb_group_desc* groups, uint32_t n_groups, const bb_p
     for (uint32_t i = 0; i < n_groups; ++i) {
         int rcode = prep_group(&c->pol, &groups[i], &c->g[i]);
         if (rcode != BB_OK) { for (uint32_t k = 0; k <= i; ++k) free_group(&c->g[k]); free(c->g); free(c); return rcode; }
+        group_build_bartab(&c->g[i]);
     }
     *out = c;
     return BB_OK;
@@ -629,6 +643,23 @@ static int best_match_for_pattern(const bb_policy* P, const uint8_t* pcode, int 
 /* the scalar functions above (tests/test_oracle_fast.py) and are never what a parity test compares the GPU with.        */
 /* ------------------------------------------------------------------------------------------ */
 #define BBO_MAXW64 4
+#define BB_FAST_MAXWIN 160
+#include "bb_oracle_simd.h"
+/* per-thread scratch of the vector forms (flags of a scan, move planes of a window) */
+static __thread uint8_t* t_scan_scratch = NULL; static __thread size_t t_scan_cap = 0;
+static __thread __m512i* t_planes = NULL; static __thread size_t t_planes_cap = 0;
+
+static void free_bartab(void* t) { if (t) { free(((bbo_bartab*)t)->eq); free(t); } }
+/* the vector tables of a group's barcodes, built when the context is made (bbo_create_policy) */
+static void group_build_bartab(ogroup* g) {
+    for (int st = 0; st < 2; ++st) {
+        g->bartab[st] = NULL;
+        if (!bbo_have_avx512() || !g->bpeq[st]) continue;
+        bbo_bartab* t = (bbo_bartab*)calloc(1, sizeof(bbo_bartab));
+        bbo_bartab_build(t, g->bpeq[st], g->n_seqs);
+        g->bartab[st] = t;
+    }
+}
 /* one strand of the flank scan: end positions by the policy's local-minimum rule, exactly scan_strand's */
 static int scan_strand_fast(const bb_policy* P, const uint64_t* peq, int W, int m, const uint8_t* tcode, int n, int reverse, int k, float alpha,
                             end_list* out) {
@@ -678,12 +709,20 @@ static int scan_strand_fast(const bb_policy* P, const uint64_t* peq, int W, int 
 static int search_fast(const bb_policy* P, const ogroup* g, const uint8_t* tc, int n, float alpha, bbo_match** out) {
     const int m = (int)g->flank_len, k = g->flank_k;
     uint8_t* pc = (uint8_t*)malloc((size_t)m); uint8_t* pcc = (uint8_t*)malloc((size_t)m);
-    uint8_t* trv = (uint8_t*)malloc((size_t)(n ? n : 1));
+    /* the reversed text, readable BBO_SIMD_PAD bytes either side like the caller's tc (the vector scan's lanes start before the text and run past it) */
+    uint8_t* trv_alloc = (uint8_t*)calloc((size_t)n + 2 * BBO_SIMD_PAD, 1);
+    uint8_t* trv = trv_alloc + BBO_SIMD_PAD;
     for (int j = 0; j < m; ++j) { pc[j] = text_code(g->flank[j]); pcc[j] = comp_code(pc[j]); }
     for (int i = 0; i < n; ++i) trv[i] = tc[n - 1 - i];
     end_list ef = {0, 0, 0}, er = {0, 0, 0};
-    if (!scan_strand_fast(P, g->fpeq[0], g->W64, m, tc, n, 0, k, alpha, &ef)) { ef.n = 0; scan_strand(P, pc, m, tc, n, k, alpha, &ef); }
-    if (!scan_strand_fast(P, g->fpeq[1], g->W64, m, tc, n, 1, k, alpha, &er)) { er.n = 0; scan_strand(P, pcc, m, trv, n, k, alpha, &er); }
+    if (!scan_strand_simd(P, g->fpeq[0], g->W64, m, tc, n, k, alpha, &ef, &t_scan_scratch, &t_scan_cap)) {
+        ef.n = 0;
+        if (!scan_strand_fast(P, g->fpeq[0], g->W64, m, tc, n, 0, k, alpha, &ef)) { ef.n = 0; scan_strand(P, pc, m, tc, n, k, alpha, &ef); }
+    }
+    if (!scan_strand_simd(P, g->fpeq[1], g->W64, m, trv, n, k, alpha, &er, &t_scan_scratch, &t_scan_cap)) {
+        er.n = 0;
+        if (!scan_strand_fast(P, g->fpeq[1], g->W64, m, tc, n, 1, k, alpha, &er)) { er.n = 0; scan_strand(P, pcc, m, trv, n, k, alpha, &er); }
+    }
     const int total = ef.n + er.n;
     bbo_match* ms = (bbo_match*)calloc((size_t)(total ? total : 1), sizeof(bbo_match));
     for (int t = 0; t < ef.n; ++t) {
@@ -698,14 +737,13 @@ static int search_fast(const bb_policy* P, const ogroup* g, const uint8_t* tc, i
         mm->strand = BB_RC; mm->rc_text_len = n;
         mm->rc_mirror_len = P->rc_path == BB_RCPATH_MIRROR ? m : 0;
     }
-    free(ef.v); free(er.v); free(pc); free(pcc); free(trv);
+    free(ef.v); free(er.v); free(pc); free(pcc); free(trv_alloc);
     *out = ms;
     return total;
 }
 /* best_match_for_pattern on one 64-bit word (m <= 64, window <= BB_FAST_MAXWIN columns): the forward pass keeps the preferred
  * move of every cell as two bit planes (by default Match: d0 & eq; else Ins: ph; else Sub: ~d0; else Del — trace_match's
  * order, any policy order alike), the walk back reads them */
-#define BB_FAST_MAXWIN 160
 static int best_match_for_pattern_fast(const bb_policy* P, const uint64_t* peq16, int m, const uint8_t* wcode, int wn, int k, bbo_match* best,
                                        uint8_t* ops_store /* m + wn + 2 bytes of the caller's: no allocation per pattern */) {
     uint64_t lo[BB_FAST_MAXWIN + 1], hi[BB_FAST_MAXWIN + 1];
@@ -793,8 +831,9 @@ static const int32_t* diag_on_target(uint32_t gi, const bbo_match* fm) {
 /* Demuxer::demux (searcher.rs:430-490) for one read; rows appended to `rows` (already collapsed) */
 static void demux_read(const bbo_ctx* c, uint32_t read_idx, const uint8_t* read, uint32_t n, row_list* rows, int fast) {
     int first_row = rows->n;
-    uint8_t* rcode = (uint8_t*)malloc(n ? n : 1);
-    for (uint32_t i = 0; i < n; ++i) rcode[i] = text_code(read[i]);
+    uint8_t* rcode_alloc = (uint8_t*)calloc((size_t)n + 2 * BBO_SIMD_PAD, 1);   /* (padded: scan_strand_simd) */
+    uint8_t* rcode = rcode_alloc + BBO_SIMD_PAD;
+    { const uint8_t* T = text_code_table(); for (uint32_t i = 0; i < n; ++i) rcode[i] = T[read[i]]; }
     for (uint32_t gi = 0; gi < c->n_groups; ++gi) {                                   /* :433 */
         const ogroup* g = &c->g[gi];
         bbo_match* fms = NULL;
@@ -824,8 +863,18 @@ static void demux_read(const bbo_ctx* c, uint32_t read_idx, const uint8_t* read,
             const size_t ops_stride = (size_t)(m + wn + 2);
             uint8_t* ops_arena = fast_bar ? (uint8_t*)malloc(ops_stride * g->n_seqs) : NULL;   /* the candidates' op strings, one block */
             int k = g->k1, matched = 0;
+            const bbo_bartab* bt = fast_bar ? (const bbo_bartab*)g->bartab[fm->strand] : NULL;
+            if (bt) {
+                const size_t need = (size_t)bt->n_vec * 2 * (BB_FAST_MAXWIN + 1);
+                if (t_planes_cap < need) { free(t_planes); t_planes = (__m512i*)aligned_alloc(64, need * sizeof(__m512i)); t_planes_cap = need; }
+            }
             for (int pass = 0; pass < 2; ++pass) {                                    /* :282-328 */
                 matched = 0;
+                if (bt) {   /* every pattern of the group at once, 8 per vector (bb_oracle_simd.h) */
+                    matched = best_matches_simd(&c->pol, bt, g->n_seqs, m, wcode, wn, k, best, has, ops_arena, ops_stride, t_planes);
+                    if (matched <= 1 && g->k1 < g->k2 && pass == 0) { k = g->k2; continue; }
+                    break;
+                }
                 for (uint32_t p = 0; p < g->n_seqs; ++p) {
                     for (int j = 0; j < m; ++j) pcode[j] = text_code(pats[(size_t)p * m + j]);
                     if (has[p]) { if (!fast_bar) free(best[p].ops); best[p].ops = NULL; has[p] = 0; }
@@ -845,10 +894,24 @@ static void demux_read(const bbo_ctx* c, uint32_t read_idx, const uint8_t* read,
                  * maximum in ascending idx order, second = best of the rest */
                 int top = -1, second = -1; double top_s = 0, second_s = 0;
                 double* sc = (double*)malloc(sizeof(double) * g->n_seqs);
+                if (bt && c->pol.lodhi_p <= 5) {   /* eight candidates' scores at a time, the same f64 operations each (lodhi_pol8) */
+                    const uint8_t* oq[8]; int on_[8]; uint32_t who[8]; double sv[8];
+                    int nq = 0;
+                    for (uint32_t p = 0; p <= g->n_seqs; ++p) {
+                        if (p < g->n_seqs && has[p]) { oq[nq] = best[p].ops; on_[nq] = best[p].n_ops; who[nq] = p; ++nq; }
+                        if (nq == 8 || (p == g->n_seqs && nq)) {
+                            lodhi_pol8(&c->pol, oq, on_, nq, sv);
+                            for (int t = 0; t < nq; ++t) sc[who[t]] = g->perfect > 0.0 ? sv[t] / g->perfect : 0.0;
+                            nq = 0;
+                        }
+                    }
+                }
                 for (uint32_t p = 0; p < g->n_seqs; ++p) {
                     if (!has[p]) continue;
-                    double s = lodhi_pol(&c->pol, best[p].ops, best[p].n_ops);
-                    sc[p] = g->perfect > 0.0 ? s / g->perfect : 0.0;                   /* :368-372 */
+                    if (!(bt && c->pol.lodhi_p <= 5)) {
+                        double s = lodhi_pol(&c->pol, best[p].ops, best[p].n_ops);
+                        sc[p] = g->perfect > 0.0 ? s / g->perfect : 0.0;               /* :368-372 */
+                    }
                     if (top < 0 || sc[p] > top_s) { top = (int)p; top_s = sc[p]; }
                 }
                 for (uint32_t p = 0; p < g->n_seqs; ++p) {
@@ -887,7 +950,7 @@ static void demux_read(const bbo_ctx* c, uint32_t read_idx, const uint8_t* read,
         }
         bbo_free_matches(fms, nfm);
     }
-    free(rcode);
+    free(rcode_alloc);
     rows->n = first_row + bbo_collapse(rows->v + first_row, rows->n - first_row, 0.8f); /* :489 */
 }
 
@@ -897,6 +960,8 @@ int bbo_annotate_batch(bbo_ctx* c, const uint8_t* bases, const uint64_t* offsets
                        bb_row* rows, uint64_t rows_cap, uint64_t* n_rows, int n_threads) {
     return annotate_batch_impl(c, bases, offsets, n_reads, rows, rows_cap, n_rows, n_threads, 0);
 }
+/* 1: bbo_annotate_batch_fast runs the AVX-512 forms of the flank scan and the barcode pass (bb_oracle_simd.h) on this CPU; 0: 64-bit words */
+int bbo_fast_is_simd(void) { return bbo_have_avx512(); }
 int bbo_annotate_batch_fast(bbo_ctx* c, const uint8_t* bases, const uint64_t* offsets, uint32_t n_reads,
                             bb_row* rows, uint64_t rows_cap, uint64_t* n_rows, int n_threads) {
     return annotate_batch_impl(c, bases, offsets, n_reads, rows, rows_cap, n_rows, n_threads, 1);

@@ -86,6 +86,7 @@ int  bbo_annotate_batch(bbo_ctx* ctx, const uint8_t* bases, const uint64_t* offs
  * cpu_baseline reports it so the CPU figure is not a scalar loop against a reference that runs AVX2 sassy; the parity tests
  * compare the GPU with bbo_annotate_batch, and tests/test_oracle_fast.py compares this function with it. */
 void bbo_set_pin_threads(int on);   /* default 1: the batch entry points run one pinned OpenMP worker per allowed CPU */
+int  bbo_fast_is_simd(void);   /* the timing path runs its AVX-512 forms (bb_oracle_simd.h) on this CPU; BBO_NO_SIMD=1 switches them off */
 int  bbo_annotate_batch_fast(bbo_ctx* ctx, const uint8_t* bases, const uint64_t* offsets, uint32_t n_reads,
                              bb_row* rows, uint64_t rows_cap, uint64_t* n_rows, int n_threads);
 

@@ -232,6 +232,11 @@ class Oracle:
         assert lib().bbo_group_get_pattern(self.h, g, idx, int(rc), buf) == 0
         return buf.raw
 
+    @staticmethod
+    def fast_is_simd():
+        """the timing path (fast=True) runs its AVX-512 forms on this CPU (oracle/bb_oracle_simd.h)"""
+        return bool(lib().bbo_fast_is_simd())
+
     def annotate(self, bases, offsets, n_threads=1, fast=False):
         """fast=True: the bit-parallel timing path (bench.py's cpu_baseline); same rows"""
         bases = np.ascontiguousarray(bases, dtype=np.uint8)
