@@ -21,10 +21,13 @@
 // two thirds of its time (one lane per hit: the raw hit, the read's offset, four text chunks, the Peq rows), and its LDS decides how many
 // waves share a CU in the meantime (13 KB per 64-lane block: 12; 6.5 KB: 24).
 // MODE 3 (k > 6 where the full height does not fit): no move bits during the forward pass, only the column state (Pv, Mv)
-// every 8 columns in LDS; the walk then goes back block by block — the wave recomputes the 8 columns of a block from its
-// checkpoint with their move bits into a small LDS window and every lane walks through its part of the block — so the DP
-// is computed twice, and nothing lives in private memory (the k = 20 tracebacks of the rapid kits: 3.9 -> ms below).
-#define BB_TRACE_CKB 8
+// every 16 columns in LDS; the walk then goes back block by block — the lane recomputes the 16 columns of a block from its
+// checkpoint with their move bits and walks through its part of the block — so the DP is computed twice, and nothing lives
+// in private memory.  Round 6: the block's move bits stay in REGISTERS (2 x W words per column, the walk's column loop unrolled so
+// that every index is static) instead of an LDS window, and checkpoints are 16 columns apart instead of 8: 10.7 KB of LDS per
+// 64-lane block for the rapid kits' 90-nt flank at k = 20 instead of 33.8 KB — twelve waves share a CU instead of four, and
+// the kernel, which waits on memory most of its time (one lane per hit), had 52 % of its wave time parked at one wave per SIMD.
+#define BB_TRACE_CKB 16
 #define BB_TRACE_REC_STRIDE 25  // words per staged bb_hit (24) + 1: lanes land in different banks
 template <int W, int MODE>
 __device__ __forceinline__ uint32_t flank_trace_lane(const uint8_t* __restrict__ bases, const uint64_t* __restrict__ offsets,
@@ -200,39 +203,40 @@ __device__ __forceinline__ uint32_t flank_trace_lane(const uint8_t* __restrict__
         }
     };
     if constexpr (MODE == 3) {
-        const int NB = (m + k) / BB_TRACE_CKB + 1;          // checkpoints 0 .. NB-1 of this lane's group (the LDS is sized for the launch's largest)
-        uint32_t* win = s_moves + NB * 2 * W * 64;           // [column of the block][lo | hi][word][64 lanes]
+        static_assert(BB_TRACE_CKB == 16, "a block's text is one 16-byte chunk");
         uint32_t tq[4], tn[4] = {0u, 0u, 0u, 0u};            // the block's text; the next (lower) block's, requested a block ahead
         {
             const int32_t cl = ((w - 1) / BB_TRACE_CKB) * BB_TRACE_CKB;  // this lane's last block
             if (w > 0) load16(s0 + cl, tn);
         }
         for (int blk = (mk_max - 1) / BB_TRACE_CKB; blk >= 0; --blk) {  // wave-uniform: the largest m + k of the launch's groups
-            const int32_t c0 = blk * BB_TRACE_CKB;           // the block holds columns c0+1 .. c0+8
+            const int32_t c0 = blk * BB_TRACE_CKB;           // the block holds columns c0+1 .. c0+16
             if (c0 < w) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) tq[q] = tn[q];
                 if (c0 >= BB_TRACE_CKB) load16(s0 + c0 - BB_TRACE_CKB, tn);
             }
             if (c0 < w && j > 0 && i > c0) {
+                uint32_t wl[BB_TRACE_CKB][W], wh[BB_TRACE_CKB][W];   // the block's move bits: registers (every index below is a compile-time constant)
 #pragma unroll
                 for (int x = 0; x < W; ++x) { pv[x] = s_moves[((blk * 2 * W) + x) * 64 + threadIdx.x]; mv[x] = s_moves[((blk * 2 * W) + W + x) * 64 + threadIdx.x]; }
 #pragma unroll
                 for (int b = 0; b < BB_TRACE_CKB; ++b) {
-                    if (c0 + b + 1 <= w) {
-                        const uint32_t ch = (tq[b >> 2] >> (8 * (b & 3))) & 0xFFu;
-                        uint32_t eq[W], d0[W], ph[W], mh[W], l[W], hh[W];
-                        load_eq<W, S>(peq, ch, eq);
-                        myers_step<W>(pv, mv, eq, d0, ph, mh);
-                        move_bits_prio<W>(prio, eq, d0, ph, pv, l, hh);
-#pragma unroll
-                        for (int x = 0; x < W; ++x) { win[((b * 2 + 0) * W + x) * 64 + threadIdx.x] = l[x]; win[((b * 2 + 1) * W + x) * 64 + threadIdx.x] = hh[x]; }
-                    }
+                    const uint32_t ch = (tq[b >> 2] >> (8 * (b & 3))) & 0xFFu;
+                    uint32_t eq[W], d0[W], ph[W], mh[W];
+                    load_eq<W, S>(peq, ch, eq);
+                    myers_step<W>(pv, mv, eq, d0, ph, mh);       // (columns beyond w: computed on whatever the chunk holds, never walked)
+                    move_bits_prio<W>(prio, eq, d0, ph, pv, wl[b], wh[b]);
                 }
-                while (j > 0 && i > c0) {
-                    const int cc = i - c0 - 1, bit = j - 1;
-                    const uint32_t lw = win[((cc * 2 + 0) * W + (bit >> 5)) * 64 + threadIdx.x], hw = win[((cc * 2 + 1) * W + (bit >> 5)) * 64 + threadIdx.x];
-                    take(((lw >> (bit & 31)) & 1u) | (((hw >> (bit & 31)) & 1u) << 1));
+#pragma unroll
+                for (int cc = BB_TRACE_CKB - 1; cc >= 0; --cc) {
+                    while (j > 0 && i == c0 + cc + 1) {          // ops that stay in the column (rows deleted) repeat here; the others leave it
+                        const int bit = j - 1, q = bit >> 5;
+                        uint32_t lw = wl[cc][0], hw = wh[cc][0];
+#pragma unroll
+                        for (int x = 1; x < W; ++x) { lw = q == x ? wl[cc][x] : lw; hw = q == x ? wh[cc][x] : hw; }
+                        take(((lw >> (bit & 31)) & 1u) | (((hw >> (bit & 31)) & 1u) << 1));
+                    }
                 }
             }
         }

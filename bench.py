@@ -431,11 +431,12 @@ def stress_leg(mode, dev_idx, dev, L, args, n=1_000_000, steps=3):
     return out
 
 
-def length_mix_leg(cfg, dev_idx, dev, args, n=100_000, steps=3):
+def length_mix_leg(cfg, dev_idx, dev, args, n=1_000_000, steps=3):
     """Reads whose lengths differ as a run's do (tests/common.py::heavy_tailed_batch: 200 nt .. 120 kb, 70 % under 3 kb) against the same number of
     bases in equal reads: bases/s of the whole step and the scan stage's time for both.  The scans give a lane one read; where the lengths
     differ the lanes take segments of reads by falling length instead (bb_len.h) — without that the heavy-tailed batch ran the scan stage at
-    13 x (SQK-NBD114-96) the time of the equal reads (round 5, tools/ragged_probe.py).  Host-generated reads, uploaded once; outside `value`."""
+    13 x (SQK-NBD114-96) the time of the equal reads (round 5, tools/ragged_probe.py).  Host-generated reads, uploaded once; outside `value`.
+    1 M reads since round 6 (100 k until then: a batch that small is half fixed costs, and DESIGN quoted a larger mix the driver never ran)."""
     from barbell_amd import _abi
     from barbell_amd import annotate as A
     from oracle import pyoracle as po
