@@ -549,7 +549,7 @@ def test_shards_one_process_per_gpu_reduce_their_histograms(tmp_path):
     env["BARBELL_AMD_RCCL_TIMEOUT"] = "3"
     p, d = run("lonely", ["--shard", "0/2", "--rccl-id", str(tmp_path / "rv2")])
     _, err = p.communicate(timeout=600)
-    assert p.returncode == 1 and "timed out waiting" in err
+    assert p.returncode == 1 and "timed out after 3 s waiting for" in err and "rv2.r1.hello" in err, err   # (names the peer that never said hello)
 
 
 @pytest.mark.gpu

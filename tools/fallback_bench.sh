@@ -3,7 +3,7 @@
 # kernel's back-off): reads/s and stage times of bench.py with each forced.  -> stdout, one line per variant
 cd "$(dirname "$0")/.."
 run() {
-  env "$@" python bench.py --steps 3 --warmup 1 --reads 4000000 --no-cpu-baseline --no-other-configs --no-e2e --no-stress --no-policy-variants 2>/dev/null | python -c "
+  env "$@" python bench.py --steps 3 --warmup 1 --reads 4000000 --no-cpu-baseline --no-other-configs --no-e2e --no-stress --no-policy-variants --no-boundary 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); k=d['kernel_ms_per_step']
 print('%-34s %6.1f M reads/s  scan %5.2f trace %5.2f barcode %6.2f  dominant %s' % ('$*', d['value']/1e6, k['k_flank_scan'], k['k_flank_trace'], k['k_barcode'], d['roofline']['kernel']))"

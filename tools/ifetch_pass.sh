@@ -8,7 +8,7 @@ REPO=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$REPO/gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-BENCH="python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-other-configs --no-e2e --no-stress --no-policy-variants $*"
+BENCH="python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-other-configs --no-e2e --no-stress --no-policy-variants --no-boundary $*"
 cd /tmp
 for mode in overlap serial; do
   if [ $mode = serial ]; then export BARBELL_AMD_NO_SIDE_STREAM=1; else unset BARBELL_AMD_NO_SIDE_STREAM; fi

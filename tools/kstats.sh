@@ -2,7 +2,7 @@
 # per-kernel device time of one bench configuration (runs on the GPU box): tools/kstats.sh TAG [bench args]
 TAG=${1:-ks}; shift
 REPO=$(cd "$(dirname "$0")/.." && pwd); OUT=$REPO/gpurun_out/$TAG; mkdir -p "$OUT"; export TMPDIR=/tmp; cd /tmp
-rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o t --output-format csv -- python $REPO/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-other-configs --no-policy-variants "$@" > "$OUT/bench.json" 2> "$OUT/trace.log"
+rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o t --output-format csv -- python $REPO/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-other-configs --no-policy-variants --no-boundary "$@" > "$OUT/bench.json" 2> "$OUT/trace.log"
 f=$(find "$OUT/trace" -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" "$OUT/kernel_stats.csv"
 python - "$OUT/kernel_stats.csv" <<'PY'
 import csv,sys

@@ -8,9 +8,9 @@ REPO=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$REPO/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd /tmp
-python $REPO/bench.py --config $CONFIG --steps 20 --warmup 2 --no-cpu-baseline --no-other-configs --no-e2e --no-stress --no-policy-variants > "$OUT/bench_20.json" 2> "$OUT/bench_20.err"
+python $REPO/bench.py --config $CONFIG --steps 20 --warmup 2 --no-cpu-baseline --no-other-configs --no-e2e --no-stress --no-policy-variants --no-boundary > "$OUT/bench_20.json" 2> "$OUT/bench_20.err"
 bash $REPO/tools/profile_round.sh $TAG --config $CONFIG > "$OUT/profile_round.log" 2>&1
-CMD="python bench.py --config $CONFIG --steps 4 --warmup 1 --no-cpu-baseline --no-other-configs --no-e2e --no-stress --no-policy-variants"
+CMD="python bench.py --config $CONFIG --steps 4 --warmup 1 --no-cpu-baseline --no-other-configs --no-e2e --no-stress --no-policy-variants --no-boundary"
 python $REPO/tools/collect_traffic.py "$OUT" "$OUT/traffic_$CONFIG.json" 2000000 4000 "$CMD" > "$OUT/collect.log" 2>&1
 python $REPO/tools/collect_valu.py "$OUT/pmc1" "$OUT/pmc2" "$OUT/pmc3" "$OUT/valu_$CONFIG.json" 2000000 4000 >> "$OUT/collect.log" 2>&1
 find "$OUT" -name "*.csv" -size +8M -delete

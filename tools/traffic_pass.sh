@@ -6,7 +6,7 @@ REPO=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$REPO/gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-BENCH="python $REPO/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-other-configs --no-e2e --no-stress --no-policy-variants $*"
+BENCH="python $REPO/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-other-configs --no-e2e --no-stress --no-policy-variants --no-boundary $*"
 cd /tmp
 i=3
 for set in "FETCH_SIZE" "WRITE_SIZE"; do
