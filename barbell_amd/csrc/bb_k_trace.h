@@ -26,7 +26,10 @@
 // in private memory.  Round 6: the block's move bits stay in REGISTERS (2 x W words per column, the walk's column loop unrolled so
 // that every index is static) instead of an LDS window, and checkpoints are 16 columns apart instead of 8: 10.7 KB of LDS per
 // 64-lane block for the rapid kits' 90-nt flank at k = 20 instead of 33.8 KB — twelve waves share a CU instead of four, and
-// the kernel, which waits on memory most of its time (one lane per hit), had 52 % of its wave time parked at one wave per SIMD.
+// the kernel, which waits on memory most of its time (one lane per hit), had 52 % of its wave time parked at one wave per SIMD:
+// 6.8 -> 2.9 ms per 2 M-read step.  The price: with three times the lanes in flight the text lines of the first pass are often gone
+// from L2 when the walk asks for them again (1.95 -> 3.65 GB of HBM traffic per step).  Keeping the text in LDS as well (7 KB more per
+// block: nine waves per CU) brought the traffic back to 1.87 GB and the time to 3.8 ms — measured, not kept: the path is not HBM-bound.
 #define BB_TRACE_CKB 16
 #define BB_TRACE_REC_STRIDE 25  // words per staged bb_hit (24) + 1: lanes land in different banks
 template <int W, int MODE>

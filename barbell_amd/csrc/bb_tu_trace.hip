@@ -14,10 +14,9 @@ int bb_trace_mode(const bb_ctx* c, uint32_t g) {
     const size_t lds_ck = (size_t)(((D.m + D.flank_k) / BB_TRACE_CKB + 1) * 2 * W) * 64 * 4;   // checkpoints only: a block's move bits live in registers
     const size_t lds_band = (size_t)(D.m + D.flank_k + 2) * 64 * 4;
     if (D.flank_k <= 3 && lds_band <= 64 * 1024 && !c->force_generic && !getenv("BARBELL_AMD_TRACE_FULL") && !getenv("BARBELL_AMD_TRACE_BAND16")) return 4;  // 2(k+1) <= 8 rows in 8 bits
-    // (three-word flanks, e.g. the custom dual-end set's: the checkpointed variant's 10.7 KB per block let twelve waves share a CU where the band's
-    // 24.8 KB let six, and its window's text comes from registers — 2.10 -> 1.94 ms per 2 M-read step although it computes the DP twice)
-    const bool ck_pays = W >= 3 && 2 * lds_ck <= lds_band && lds_ck <= 64 * 1024 && !getenv("BARBELL_AMD_TRACE_NOCKPT") && !getenv("BARBELL_AMD_TRACE_BAND16");
-    if (D.flank_k <= 6 && lds_band <= 64 * 1024 && !c->force_generic && !getenv("BARBELL_AMD_TRACE_FULL") && !ck_pays) return 2;  // band of 2(k+1)+1 <= 15 rows in 16 bits
+    // (measured, round 6: three-word flanks at k <= 6 — the custom dual-end set's — through the checkpointed variant instead: 2.10 -> 1.94 ms per 2 M-read
+    // step, but 2.4 -> 4.0 GB of HBM traffic: twelve waves per CU instead of six evict each other's text lines from L2 between the two passes.  Not taken.)
+    if (D.flank_k <= 6 && lds_band <= 64 * 1024 && !c->force_generic && !getenv("BARBELL_AMD_TRACE_FULL")) return 2;  // band of 2(k+1)+1 <= 15 rows in 16 bits
     if (W <= 4 && lds <= 64 * 1024 && !c->force_generic) return 1;
     if (lds_ck <= 64 * 1024 && !c->force_generic && !getenv("BARBELL_AMD_TRACE_NOCKPT")) return 3;
     return 0;
