@@ -648,6 +648,7 @@ static int best_match_for_pattern(const bb_policy* P, const uint8_t* pcode, int 
 /* per-thread scratch of the vector forms (flags of a scan, move planes of a window) */
 static __thread uint8_t* t_scan_scratch = NULL; static __thread size_t t_scan_cap = 0;
 static __thread __m512i* t_planes = NULL; static __thread size_t t_planes_cap = 0;
+static __thread __m512i* t_opsT = NULL; static __thread size_t t_opsT_cap = 0;   /* the lockstep walks' op matrix + one vector of lengths per vector of patterns */
 
 static void free_bartab(void* t) { if (t) { free(((bbo_bartab*)t)->eq); free(t); } }
 /* the vector tables of a group's barcodes, built when the context is made (bbo_create_policy) */
@@ -861,17 +862,22 @@ static void demux_read(const bbo_ctx* c, uint32_t read_idx, const uint8_t* read,
             uint8_t* pcode = (uint8_t*)malloc((size_t)m);
             const int fast_bar = fast && g->bpeq[fm->strand] && wn <= BB_FAST_MAXWIN;
             const size_t ops_stride = (size_t)(m + wn + 2);
-            uint8_t* ops_arena = fast_bar ? (uint8_t*)malloc(ops_stride * g->n_seqs) : NULL;   /* the candidates' op strings, one block */
+            /* the candidates' op strings, one block (the vector form keeps its walks as a matrix instead: bt below) */
+            uint8_t* ops_arena = fast_bar && !g->bartab[fm->strand] ? (uint8_t*)malloc(ops_stride * g->n_seqs) : NULL;
             int k = g->k1, matched = 0;
             const bbo_bartab* bt = fast_bar ? (const bbo_bartab*)g->bartab[fm->strand] : NULL;
+            const size_t ops_cap = 64 + BB_FAST_MAXWIN + 2;
             if (bt) {
                 const size_t need = (size_t)bt->n_vec * 2 * (BB_FAST_MAXWIN + 1);
                 if (t_planes_cap < need) { free(t_planes); t_planes = (__m512i*)aligned_alloc(64, need * sizeof(__m512i)); t_planes_cap = need; }
+                const size_t need2 = (size_t)bt->n_vec * (ops_cap + 1);
+                if (t_opsT_cap < need2) { free(t_opsT); t_opsT = (__m512i*)aligned_alloc(64, need2 * sizeof(__m512i)); t_opsT_cap = need2; }
             }
+            __m512i* const nopsT = bt ? t_opsT + (size_t)bt->n_vec * ops_cap : NULL;
             for (int pass = 0; pass < 2; ++pass) {                                    /* :282-328 */
                 matched = 0;
                 if (bt) {   /* every pattern of the group at once, 8 per vector (bb_oracle_simd.h) */
-                    matched = best_matches_simd(&c->pol, bt, g->n_seqs, m, wcode, wn, k, best, has, ops_arena, ops_stride, t_planes);
+                    matched = best_matches_simd(&c->pol, bt, g->n_seqs, m, wcode, wn, k, best, has, ops_arena, ops_stride, t_planes, t_opsT, ops_cap, nopsT);
                     if (matched <= 1 && g->k1 < g->k2 && pass == 0) { k = g->k2; continue; }
                     break;
                 }
@@ -894,22 +900,20 @@ static void demux_read(const bbo_ctx* c, uint32_t read_idx, const uint8_t* read,
                  * maximum in ascending idx order, second = best of the rest */
                 int top = -1, second = -1; double top_s = 0, second_s = 0;
                 double* sc = (double*)malloc(sizeof(double) * g->n_seqs);
-                if (bt && c->pol.lodhi_p <= 5) {   /* eight candidates' scores at a time, the same f64 operations each (lodhi_pol8) */
-                    const uint8_t* oq[8]; int on_[8]; uint32_t who[8]; double sv[8];
-                    int nq = 0;
-                    for (uint32_t p = 0; p <= g->n_seqs; ++p) {
-                        if (p < g->n_seqs && has[p]) { oq[nq] = best[p].ops; on_[nq] = best[p].n_ops; who[nq] = p; ++nq; }
-                        if (nq == 8 || (p == g->n_seqs && nq)) {
-                            lodhi_pol8(&c->pol, oq, on_, nq, sv);
-                            for (int t = 0; t < nq; ++t) sc[who[t]] = g->perfect > 0.0 ? sv[t] / g->perfect : 0.0;
-                            nq = 0;
-                        }
+                if (bt && c->pol.lodhi_p <= 5) {   /* the scores of a vector's eight candidates at a time, the same f64 operations each (lodhi_polT) */
+                    for (int v = 0; v < bt->n_vec; ++v) {
+                        double sv[8];
+                        lodhi_polT(&c->pol, t_opsT + (size_t)v * ops_cap, &nopsT[v], sv);
+                        for (int l = 0; l < 8 && (uint32_t)(8 * v + l) < g->n_seqs; ++l)
+                            if (has[8 * v + l]) sc[8 * v + l] = g->perfect > 0.0 ? sv[l] / g->perfect : 0.0;
                     }
                 }
                 for (uint32_t p = 0; p < g->n_seqs; ++p) {
                     if (!has[p]) continue;
-                    if (!(bt && c->pol.lodhi_p <= 5)) {
-                        double s = lodhi_pol(&c->pol, best[p].ops, best[p].n_ops);
+                    if (!bt || c->pol.lodhi_p > 5) {
+                        uint8_t tmp_ops[64 + BB_FAST_MAXWIN + 2];
+                        if (bt) bbo_ops_from_T(t_opsT, ops_cap, p, best[p].n_ops, tmp_ops);
+                        double s = lodhi_pol(&c->pol, bt ? tmp_ops : best[p].ops, best[p].n_ops);
                         sc[p] = g->perfect > 0.0 ? s / g->perfect : 0.0;               /* :368-372 */
                     }
                     if (top < 0 || sc[p] > top_s) { top = (int)p; top_s = sc[p]; }
@@ -918,6 +922,8 @@ static void demux_read(const bbo_ctx* c, uint32_t read_idx, const uint8_t* read,
                     if (!has[p] || (int)p == top) continue;
                     if (second < 0 || sc[p] > second_s) { second = (int)p; second_s = sc[p]; }
                 }
+                uint8_t top_ops[64 + BB_FAST_MAXWIN + 2];
+                if (bt) { bbo_ops_from_T(t_opsT, ops_cap, (uint32_t)top, best[top].n_ops, top_ops); best[top].ops = top_ops; }
                 int rel_lo = (int)(g->bar_lo - g->pad_lo), rel_hi = (int)(g->bar_hi - g->pad_lo); /* :379-382 */
                 int pl, ph, tl, th, bc;
                 int panicked = 0;

@@ -75,18 +75,14 @@ static inline void bbo_win_step(const uint64_t* peq, int W, int TW, int TB, uint
         mv[w] = _mm512_loadu_si512((const void*)a);                                                                                         \
     }                                                                                                                                       \
     __m512i score = _mm512_set_epi64(zi->score, zi->score, zi->score, zi->score, zi->score, zi->score, zi->score, z0->score);              \
-    const __m512i one = _mm512_set1_epi64(1), kv = _mm512_set1_epi64(k), nib = _mm512_set1_epi64(15);                                       \
-    const uint8_t* stream[8];                                                                                                               \
-    for (int l = 0; l < 8; ++l) stream[l] = sc + (long)l * C - mk;                                                                          \
+    const __m512i one = _mm512_set1_epi64(1), kv = _mm512_set1_epi64(k), nib = _mm512_set1_epi64(15), topbit = _mm512_set1_epi64((long long)(1ull << TB)); \
+    /* lane l's stream begins at sc + l C - mk: eight bytes of every stream per gather, a byte of them per step */                         \
+    const __m512i stream = _mm512_sub_epi64(_mm512_mullo_epi64(_mm512_set_epi64(7, 6, 5, 4, 3, 2, 1, 0), _mm512_set1_epi64(C)), _mm512_set1_epi64(mk)); \
     const int T = C + mk;                                                                                                                   \
     __m512i text = _mm512_setzero_si512();                                                                                                  \
     for (int t = 1; t <= T; ++t) {                                                                                                          \
         const int tb = (t - 1) & 7;                                                                                                         \
-        if (!tb) {                                                                                                                          \
-            uint64_t q[8];                                                                                                                  \
-            for (int l = 0; l < 8; ++l) memcpy(&q[l], stream[l] + (t - 1), 8);                                                              \
-            text = _mm512_loadu_si512((const void*)q);                                                                                      \
-        }                                                                                                                                   \
+        if (!tb) text = _mm512_i64gather_epi64(_mm512_add_epi64(stream, _mm512_set1_epi64(t - 1)), (const void*)sc, 1);                     \
         const __m512i code = _mm512_and_si512(_mm512_srli_epi64(text, 8 * tb), nib);                                                        \
         __m512i carry = _mm512_setzero_si512(), pin = carry, min_ = carry, npv[W], nmv[W], nscore = score;                                  \
         for (int w = 0; w < W; ++w) {                                                                                                       \
@@ -98,15 +94,15 @@ static inline void bbo_win_step(const uint64_t* peq, int W, int TW, int TB, uint
                 const __mmask8 c1 = _mm512_cmplt_epu64_mask(s1, x), c2 = _mm512_cmplt_epu64_mask(sum, s1);                                  \
                 carry = _mm512_maskz_mov_epi64((__mmask8)(c1 | c2), one);                                                                   \
             }                                                                                                                               \
-            const __m512i d0 = _mm512_or_si512(_mm512_or_si512(_mm512_xor_si512(sum, pv[w]), eq), mv[w]);                                   \
-            const __m512i ph = _mm512_or_si512(mv[w], _mm512_andnot_si512(_mm512_or_si512(d0, pv[w]), _mm512_set1_epi64(-1)));              \
+            const __m512i d0 = _mm512_ternarylogic_epi64(_mm512_xor_si512(sum, pv[w]), eq, mv[w], 0xFE);          /* a | b | c */           \
+            const __m512i ph = _mm512_ternarylogic_epi64(mv[w], d0, pv[w], 0xF1);                                 /* a | ~(b | c) */        \
             const __m512i mh = _mm512_and_si512(pv[w], d0);                                                                                 \
             if (w == TW)                                                                                                                    \
-                nscore = _mm512_sub_epi64(_mm512_add_epi64(score, _mm512_and_si512(_mm512_srli_epi64(ph, TB), one)),                        \
-                                          _mm512_and_si512(_mm512_srli_epi64(mh, TB), one));                                                \
+                nscore = _mm512_mask_sub_epi64(_mm512_mask_add_epi64(score, _mm512_test_epi64_mask(ph, topbit), score, one),                \
+                                               _mm512_test_epi64_mask(mh, topbit), _mm512_mask_add_epi64(score, _mm512_test_epi64_mask(ph, topbit), score, one), one); \
             const __m512i phs = _mm512_or_si512(_mm512_slli_epi64(ph, 1), pin), mhs = _mm512_or_si512(_mm512_slli_epi64(mh, 1), min_);      \
             pin = _mm512_srli_epi64(ph, 63); min_ = _mm512_srli_epi64(mh, 63);                                                              \
-            npv[w] = _mm512_or_si512(mhs, _mm512_andnot_si512(_mm512_or_si512(d0, phs), _mm512_set1_epi64(-1)));                            \
+            npv[w] = _mm512_ternarylogic_epi64(mhs, d0, phs, 0xF1);                                                                         \
             nmv[w] = _mm512_and_si512(phs, d0);                                                                                             \
         }                                                                                                                                   \
         if (t <= mk) { /* lane 0 starts at column 0 with the scan's own start: it waits while the others run their lead-in */             \
@@ -222,10 +218,12 @@ BBO_SIMD_TARGET static void bbo_bartab_build(bbo_bartab* t, const uint64_t* bpeq
 }
 
 /* best_match_for_pattern_fast for all patterns: has[p], best[p] (ops in ops_arena + p * ops_stride); planes: 2 * n_vec * (wn + 1) vectors of scratch */
+/* opsT (may be NULL: scalar walks into ops_arena): n_vec x ops_cap vectors, ops_cap >= m + wn + 2; nopsT: n_vec vectors */
 BBO_SIMD_TARGET static int best_matches_simd(const bb_policy* P, const bbo_bartab* bt, uint32_t n_seqs, int m, const uint8_t* wcode, int wn, int k,
-                                             bbo_match* best, uint8_t* has, uint8_t* ops_arena, size_t ops_stride, __m512i* planes) {
+                                             bbo_match* best, uint8_t* has, uint8_t* ops_arena, size_t ops_stride, __m512i* planes,
+                                             __m512i* opsT, size_t ops_cap, __m512i* nopsT) {
     const int NV = bt->n_vec, TB = m - 1;
-    const __m512i one = _mm512_set1_epi64(1), kv = _mm512_set1_epi64(k), ones = _mm512_set1_epi64(-1);
+    const __m512i one = _mm512_set1_epi64(1), kv = _mm512_set1_epi64(k), ones = _mm512_set1_epi64(-1), topbit = _mm512_set1_epi64((long long)(1ull << TB));
     const int left = P->lm_rule == BB_LM_PLATEAU_LEFT, strict = P->lm_rule == BB_LM_STRICT, tie_last = P->bar_tie == BB_TIE_LAST;
     int matched = 0;
     for (int v = 0; v < NV; ++v) {
@@ -237,11 +235,12 @@ BBO_SIMD_TARGET static int best_matches_simd(const bb_policy* P, const bbo_barta
         for (int c = 1; c <= wn; ++c) {
             const __m512i eq = bt->eq[v * 16 + wcode[c - 1]];
             const __m512i x = _mm512_and_si512(eq, pv);
-            const __m512i d0 = _mm512_or_si512(_mm512_or_si512(_mm512_xor_si512(_mm512_add_epi64(x, pv), pv), eq), mv);
-            const __m512i ph = _mm512_or_si512(mv, _mm512_andnot_si512(_mm512_or_si512(d0, pv), ones)), mh = _mm512_and_si512(pv, d0);
-            score = _mm512_sub_epi64(_mm512_add_epi64(score, _mm512_and_si512(_mm512_srli_epi64(ph, TB), one)), _mm512_and_si512(_mm512_srli_epi64(mh, TB), one));
+            const __m512i d0 = _mm512_ternarylogic_epi64(_mm512_xor_si512(_mm512_add_epi64(x, pv), pv), eq, mv, 0xFE);
+            const __m512i ph = _mm512_ternarylogic_epi64(mv, d0, pv, 0xF1), mh = _mm512_and_si512(pv, d0);
+            score = _mm512_mask_add_epi64(score, _mm512_test_epi64_mask(ph, topbit), score, one);
+            score = _mm512_mask_sub_epi64(score, _mm512_test_epi64_mask(mh, topbit), score, one);
             const __m512i phs = _mm512_slli_epi64(ph, 1), mhs = _mm512_slli_epi64(mh, 1);
-            pv = _mm512_or_si512(mhs, _mm512_andnot_si512(_mm512_or_si512(d0, phs), ones)); mv = _mm512_and_si512(phs, d0);
+            pv = _mm512_ternarylogic_epi64(mhs, d0, phs, 0xF1); mv = _mm512_and_si512(phs, d0);
             {   /* policy [H3]: per cell the first applicable op of the order (best_match_for_pattern_fast) */
                 __m512i vv[4], s[4], taken = _mm512_setzero_si512();
                 vv[BBO_MATCH] = _mm512_and_si512(d0, eq); vv[BBO_SUB] = _mm512_andnot_si512(d0, ones); vv[BBO_INS] = ph; vv[BBO_DEL] = pv;
@@ -267,6 +266,45 @@ BBO_SIMD_TARGET static int best_matches_simd(const bb_policy* P, const bbo_barta
         }
         long long bc[8], bp[8];
         _mm512_storeu_si512((void*)bc, best_cost); _mm512_storeu_si512((void*)bp, best_pos);
+        if (opsT) {
+            /* the eight walks back in lockstep: a lane's cell (row j, column i) -> its two move bits by gather from the planes; step t of every lane in
+             * opsT[v][t] (a walk's ops in REVERSE order; lodhi_polT and bbo_ops_from_T read them back to front) */
+            __m512i* oT = opsT + (size_t)v * ops_cap;
+            __mmask8 active = (__mmask8)(_mm512_cmpge_epi64_mask(best_pos, _mm512_setzero_si512()) & (8 * v + 8 <= (int)n_seqs ? 0xFF : (0xFF >> (8 * v + 8 - (int)n_seqs))));
+            const __mmask8 todo = active;
+            const __m512i lanes = _mm512_set_epi64(7, 6, 5, 4, 3, 2, 1, 0), three = _mm512_set1_epi64(BBO_DEL), two = _mm512_set1_epi64(BBO_INS);
+            __m512i i = best_pos, j = _mm512_set1_epi64(m), nops = _mm512_setzero_si512();
+            int t = 0;
+            while (active) {
+                const __m512i idx = _mm512_add_epi64(_mm512_slli_epi64(i, 3), lanes);
+                const __m512i lw = _mm512_mask_i64gather_epi64(_mm512_setzero_si512(), active, idx, (const void*)lo, 8);
+                const __m512i hw = _mm512_mask_i64gather_epi64(_mm512_setzero_si512(), active, idx, (const void*)hi, 8);
+                const __m512i sh = _mm512_sub_epi64(j, one);
+                __m512i op = _mm512_or_si512(_mm512_and_si512(_mm512_srlv_epi64(lw, sh), one), _mm512_slli_epi64(_mm512_and_si512(_mm512_srlv_epi64(hw, sh), one), 1));
+                op = _mm512_mask_mov_epi64(op, _mm512_cmpeq_epi64_mask(i, _mm512_setzero_si512()), three);   /* column 0: the rows left are deleted */
+                oT[t++] = op;
+                nops = _mm512_mask_add_epi64(nops, active, nops, one);
+                j = _mm512_mask_sub_epi64(j, (__mmask8)(active & _mm512_cmpneq_epi64_mask(op, two)), j, one);
+                i = _mm512_mask_sub_epi64(i, (__mmask8)(active & _mm512_cmpneq_epi64_mask(op, three)), i, one);
+                active = (__mmask8)(active & _mm512_cmpgt_epi64_mask(j, _mm512_setzero_si512()));
+            }
+            long long ts[8], no[8];
+            _mm512_storeu_si512((void*)ts, i); _mm512_storeu_si512((void*)no, nops);
+            nopsT[v] = nops;
+            for (int l = 0; l < 8; ++l) {
+                const uint32_t p = (uint32_t)(8 * v + l);
+                if (p >= n_seqs) break;
+                has[p] = (uint8_t)((todo >> l) & 1);
+                if (!has[p]) continue;
+                bbo_match* b = &best[p];
+                memset(b, 0, sizeof(*b));
+                b->pattern_start = 0; b->pattern_end = m; b->text_start = (int)ts[l]; b->text_end = (int)bp[l];
+                b->cost = (int)bc[l]; b->n_ops = (int)no[l]; b->strand = BB_FWD; b->rc_text_len = wn;
+                b->ops = NULL;   /* bbo_ops_from_T for the one candidate that needs its string */
+                ++matched;
+            }
+            continue;
+        }
         for (int l = 0; l < 8; ++l) {
             const uint32_t p = (uint32_t)(8 * v + l);
             if (p >= n_seqs) break;
@@ -296,9 +334,17 @@ BBO_SIMD_TARGET static int best_matches_simd(const bb_policy* P, const bbo_barta
     return matched;
 }
 
-/* ---- lodhi_pol for 8 candidates at once: the SAME sequence of f64 multiplications and additions per candidate (no FMA: -ffp-contract=off), one
- * candidate per lane, lanes past their op string's end left alone — bit-identical scores (tests/test_oracle_fast.py) ------------------------ */
-BBO_SIMD_TARGET static void lodhi_pol8(const bb_policy* P, const uint8_t* const* ops, const int* n_ops, int n_cand, double* out) {
+/* ---- Lodhi scores of a vector's eight candidates at once: the SAME sequence of f64 multiplications and additions per candidate as lodhi_pol (no FMA:
+ * -ffp-contract=off), one candidate per lane, lanes past their op string's end left alone — bit-identical scores (tests/test_oracle_fast.py) ---------- */
+/* the op string of pattern p (lane p & 7 of vector p >> 3) in forward order, from the lockstep walks' matrix */
+static void bbo_ops_from_T(const __m512i* opsT, size_t ops_cap, uint32_t p, int n_ops, uint8_t* out) {
+    const long long* col = (const long long*)(opsT + (size_t)(p >> 3) * ops_cap) + (p & 7);
+    for (int c = 0; c < n_ops; ++c) out[c] = (uint8_t)col[(size_t)(n_ops - 1 - c) * 8];
+}
+
+/* lodhi_pol8 on the eight walks of one vector: lane l's column c is row n_ops[l] - 1 - c of the matrix (one gather per column) */
+BBO_SIMD_TARGET static void lodhi_polT(const bb_policy* P, const __m512i* oT, const __m512i* nops_p, double* out) {
+    const __m512i nops = *nops_p;
     const int p = P->lodhi_p;
     double dk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int o = 0; o < 4; ++o) {
@@ -308,19 +354,18 @@ BBO_SIMD_TARGET static void lodhi_pol8(const bb_policy* P, const uint8_t* const*
     }
     const __m512d dkv = _mm512_loadu_pd(dk), onev = _mm512_set1_pd(1.0);
     __m512d A[4] = {_mm512_setzero_pd(), _mm512_setzero_pd(), _mm512_setzero_pd(), _mm512_setzero_pd()}, score = _mm512_setzero_pd();
+    long long no[8];
+    _mm512_storeu_si512((void*)no, nops);
     int maxn = 0;
-    for (int l = 0; l < n_cand; ++l) if (n_ops[l] > maxn) maxn = n_ops[l];
-    static const uint8_t none[1] = {0};
-    const uint8_t* q[8]; int len[8];
-    for (int l = 0; l < 8; ++l) { q[l] = l < n_cand ? ops[l] : none; len[l] = l < n_cand ? n_ops[l] : 0; }
+    for (int l = 0; l < 8; ++l) if (no[l] > maxn) maxn = (int)no[l];
+    const __m512i lanes = _mm512_set_epi64(7, 6, 5, 4, 3, 2, 1, 0), one = _mm512_set1_epi64(1);
+    __m512i row = _mm512_sub_epi64(nops, one);                     /* the matrix row of every lane's column 0 */
     for (int c = 0; c < maxn; ++c) {
-        long long op[8];
-        __mmask8 live = 0;
-        for (int l = 0; l < 8; ++l) { const int in = c < len[l]; op[l] = in ? (q[l][c] & 3) : 0; live |= (__mmask8)(in << l); }
-        const __m512i opv = _mm512_loadu_si512((const void*)op);
+        const __mmask8 live = _mm512_cmpge_epi64_mask(row, _mm512_setzero_si512());
+        const __m512i opv = _mm512_mask_i64gather_epi64(_mm512_setzero_si512(), live, _mm512_add_epi64(_mm512_slli_epi64(row, 3), lanes), (const void*)oT, 8);
+        row = _mm512_sub_epi64(row, one);
         const __m512d d = _mm512_permutexvar_pd(opv, dkv);
         const __mmask8 isM = (__mmask8)(_mm512_cmpeq_epi64_mask(opv, _mm512_set1_epi64(BBO_MATCH)) & live), notM = (__mmask8)(live & ~isM);
-        /* match column: score = score + d * A[p - 2] (1.0 for p < 2); A[q] = d * (A[q] + A[q - 1]), q = p - 2 .. 1; A[0] = d * (A[0] + 1.0) */
         const __m512d prod = _mm512_mul_pd(d, p >= 2 ? A[p - 2] : onev);
         score = _mm512_mask_add_pd(score, isM, score, prod);
         for (int qq = p - 2; qq >= 1; --qq) {
@@ -332,7 +377,5 @@ BBO_SIMD_TARGET static void lodhi_pol8(const bb_policy* P, const uint8_t* const*
             A[0] = _mm512_mask_mov_pd(_mm512_mask_mov_pd(A[0], isM, m_), notM, o_);
         }
     }
-    double sc[8];
-    _mm512_storeu_pd(sc, score);
-    for (int l = 0; l < n_cand; ++l) out[l] = sc[l];
+    _mm512_storeu_pd(out, score);
 }
