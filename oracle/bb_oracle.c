@@ -706,6 +706,60 @@ static int scan_strand_fast(const bb_policy* P, const uint64_t* peq, int W, int 
     lm_finish(&st, last, k, out);
     return 1;
 }
+/* trace_match with the window's DP as 64-bit words and the preferred move of every cell as two bit planes (what best_match_for_pattern_fast does for
+ * a barcode): at cell (j, i) Match applies iff the characters match (then the diagonal is free), Sub iff the diagonal costs 1, Ins iff the horizontal
+ * step into the cell costs 1, Del iff the vertical one does — trace_match's four cost comparisons, read off the column step's vectors.  0: not
+ * applicable (overhang costs that are no 0/1 deltas, full-matrix mode): the caller takes trace_match. */
+#define BBO_TRACE_FAST_MAXW (64 * BBO_MAXW64 + 128)
+static int trace_match_fast(const bb_policy* P, const uint64_t* peq, int W, int m, const uint8_t* tcode, int n, int k, float alpha,
+                            int e, int cost, bbo_match* out) {
+    if (g_full_trace || W > BBO_MAXW64) return 0;
+    const int o = e > n ? e - n : 0;
+    const int j0 = m - o, i0 = e > n ? n : e;
+    int s0 = i0 - (m + k);
+    if (s0 < 0) s0 = 0;
+    const int w = i0 - s0;
+    if (w > BBO_TRACE_FAST_MAXW) return 0;
+    bbo_colstate cs;
+    if (!bbo_win_init(P, W, m, alpha, s0 == 0, &cs)) return 0;
+    static __thread uint64_t lo[BBO_TRACE_FAST_MAXW + 1][BBO_MAXW64], hi[BBO_TRACE_FAST_MAXW + 1][BBO_MAXW64];
+    for (int c = 1; c <= w; ++c) {
+        const uint64_t* eqv = peq + (size_t)tcode[s0 + c - 1] * W;
+        uint64_t carry = 0, pin = 0, min_ = 0;
+        for (int x = 0; x < W; ++x) {
+            const uint64_t eq = eqv[x], pv = cs.pv[x], mv = cs.mv[x], xx = eq & pv;
+            const unsigned __int128 sum = (unsigned __int128)xx + pv + carry;
+            carry = (uint64_t)(sum >> 64);
+            const uint64_t d0 = (((uint64_t)sum ^ pv) | eq | mv);
+            const uint64_t ph = mv | ~(d0 | pv), mh = pv & d0;
+            const uint64_t phs = (ph << 1) | pin, mhs = (mh << 1) | min_;
+            pin = ph >> 63; min_ = mh >> 63;
+            const uint64_t npv = mhs | ~(d0 | phs);
+            cs.pv[x] = npv; cs.mv[x] = phs & d0;
+            uint64_t v[4], sp[4] = {0, 0, 0, 0}, taken = 0;
+            v[BBO_MATCH] = d0 & eq; v[BBO_SUB] = ~d0; v[BBO_INS] = ph; v[BBO_DEL] = npv;
+            for (int q = 0; q < 4; ++q) { const int op = P->trace_prio[q]; const uint64_t y = v[op] & ~taken; taken |= y; sp[op] |= y; }
+            lo[c][x] = sp[BBO_SUB] | sp[BBO_DEL]; hi[c][x] = sp[BBO_INS] | sp[BBO_DEL];
+        }
+    }
+    uint8_t rev[64 * BBO_MAXW64 + BBO_TRACE_FAST_MAXW + 2];
+    int nops = 0, j = j0, i = w;
+    while (j > 0) {
+        if (i == 0 && s0 == 0 && alpha >= 0.f) break;            /* left overhang: rest of pattern is outside */
+        uint8_t op = BBO_DEL;
+        if (i > 0) { const int b = j - 1; op = (uint8_t)(((lo[i][b >> 6] >> (b & 63)) & 1u) | (((hi[i][b >> 6] >> (b & 63)) & 1u) << 1)); }
+        rev[nops++] = op;
+        if (op != BBO_INS) --j;
+        if (op != BBO_DEL) --i;
+    }
+    out->pattern_start = j; out->pattern_end = j0;
+    out->text_start = s0 + i; out->text_end = i0;
+    out->cost = cost; out->n_ops = nops;
+    out->ops = (uint8_t*)malloc((size_t)(nops ? nops : 1));
+    for (int t = 0; t < nops; ++t) out->ops[t] = rev[nops - 1 - t];
+    return 1;
+}
+
 /* the flank search with bit-parallel scans; matches traced by trace_match like search_pol's */
 static int search_fast(const bb_policy* P, const ogroup* g, const uint8_t* tc, int n, float alpha, bbo_match** out) {
     const int m = (int)g->flank_len, k = g->flank_k;
@@ -727,12 +781,14 @@ static int search_fast(const bb_policy* P, const ogroup* g, const uint8_t* tc, i
     const int total = ef.n + er.n;
     bbo_match* ms = (bbo_match*)calloc((size_t)(total ? total : 1), sizeof(bbo_match));
     for (int t = 0; t < ef.n; ++t) {
-        trace_match(P, pc, m, tc, n, k, alpha, ef.v[t].e, ef.v[t].cost, &ms[t]);
+        if (!trace_match_fast(P, g->fpeq[0], g->W64, m, tc, n, k, alpha, ef.v[t].e, ef.v[t].cost, &ms[t]))
+            trace_match(P, pc, m, tc, n, k, alpha, ef.v[t].e, ef.v[t].cost, &ms[t]);
         ms[t].strand = BB_FWD; ms[t].rc_text_len = n;
     }
     for (int t = 0; t < er.n; ++t) {
         bbo_match* mm = &ms[ef.n + (P->rc_order == BB_RC_FWD_ORDER ? er.n - 1 - t : t)];
-        trace_match(P, pcc, m, trv, n, k, alpha, er.v[t].e, er.v[t].cost, mm);
+        if (!trace_match_fast(P, g->fpeq[1], g->W64, m, trv, n, k, alpha, er.v[t].e, er.v[t].cost, mm))
+            trace_match(P, pcc, m, trv, n, k, alpha, er.v[t].e, er.v[t].cost, mm);
         const int ts = mm->text_start, te = mm->text_end;
         mm->text_start = n - te; mm->text_end = n - ts;
         mm->strand = BB_RC; mm->rc_text_len = n;
@@ -857,9 +913,17 @@ static void demux_read(const bbo_ctx* c, uint32_t read_idx, const uint8_t* read,
             const uint8_t* wcode = rcode + ws; int wn = (int)(we - ws);
             const uint8_t* pats = fm->strand == BB_FWD ? g->pat_fwd : g->pat_rc;       /* barcodes.rs:97-102 */
             int m = (int)g->m_bar;
-            bbo_match* best = (bbo_match*)calloc(g->n_seqs, sizeof(bbo_match));
-            uint8_t* has = (uint8_t*)calloc(g->n_seqs, 1);
-            uint8_t* pcode = (uint8_t*)malloc((size_t)m);
+            /* per-thread buffers, grown once (a hit of a 96-barcode kit used to cost four allocations and 7 KB of zeroing) */
+            static __thread bbo_match* t_best = NULL; static __thread uint8_t* t_has = NULL; static __thread double* t_sc = NULL; static __thread uint32_t t_cand_cap = 0;
+            static __thread uint8_t* t_pcode = NULL; static __thread int t_pcode_cap = 0;
+            if (t_cand_cap < g->n_seqs) {
+                free(t_best); free(t_has); free(t_sc);
+                t_cand_cap = g->n_seqs + 8;
+                t_best = (bbo_match*)calloc(t_cand_cap, sizeof(bbo_match)); t_has = (uint8_t*)malloc(t_cand_cap); t_sc = (double*)malloc(sizeof(double) * t_cand_cap);
+            }
+            if (t_pcode_cap < m) { free(t_pcode); t_pcode_cap = m + 16; t_pcode = (uint8_t*)malloc((size_t)t_pcode_cap); }
+            bbo_match* best = t_best; uint8_t* has = t_has; uint8_t* pcode = t_pcode;
+            memset(has, 0, g->n_seqs);
             const int fast_bar = fast && g->bpeq[fm->strand] && wn <= BB_FAST_MAXWIN;
             const size_t ops_stride = (size_t)(m + wn + 2);
             /* the candidates' op strings, one block (the vector form keeps its walks as a matrix instead: bt below) */
@@ -899,7 +963,7 @@ static void demux_read(const bbo_ctx* c, uint32_t read_idx, const uint8_t* read,
                 /* :364-377 score every candidate, stable sort descending by s_norm: top = first
                  * maximum in ascending idx order, second = best of the rest */
                 int top = -1, second = -1; double top_s = 0, second_s = 0;
-                double* sc = (double*)malloc(sizeof(double) * g->n_seqs);
+                double* sc = t_sc;
                 if (bt && c->pol.lodhi_p <= 5) {   /* the scores of a vector's eight candidates at a time, the same f64 operations each (lodhi_polT) */
                     for (int v = 0; v < bt->n_vec; ++v) {
                         double sv[8];
@@ -948,11 +1012,9 @@ static void demux_read(const bbo_ctx* c, uint32_t read_idx, const uint8_t* read,
                 } else {
                     push_flank_only(rows, read_idx, n, gi, g, fm);                     /* :417-425 */
                 }
-                free(sc);
             }
             if (!fast_bar) for (uint32_t p = 0; p < g->n_seqs; ++p) if (has[p]) free(best[p].ops);
             free(ops_arena);
-            free(best); free(has); free(pcode);
         }
         bbo_free_matches(fms, nfm);
     }
