@@ -935,7 +935,7 @@ def cpu_baseline(args, groups, dm, d_bases, L, batch, last_batch, d_rows, last_r
     out = {"value": nf / fdt, "unit": "reads/s", "cores": cores, "kind": "port-simd" if simd else "port-bitparallel", "cpus_visible": visible,
            "per_core": nf / fdt / cores,
            "simd": ("AVX-512: flank scan text-parallel (8 chunks of the read in the 64-bit lanes of a vector, m + k columns of overlap, valleys replayed by the "
-                    "local-minimum machine), barcode pass pattern-parallel (8 padded barcodes per vector), Lodhi scores 8 candidates per vector; "
+                    "local-minimum machine), barcode pass pattern-parallel (8 padded barcodes per vector), 8 walks back in lockstep, Lodhi scores 8 candidates per vector; "
                     "round 5's 64-bit words on the same box: 6.8 k reads/s per core" if simd else "none (no AVX-512 on this host): 64-bit Myers words"),
            "cores_note": (f"{cores} = this container's CPU quota (cgroup cpu.max) of the {visible} CPUs it sees; one pinned OpenMP worker per quota CPU "
                           f"(a pool of {visible} floating threads ran slower: throttled)" if cores < visible else f"all {cores} CPUs, one pinned OpenMP worker each"),

@@ -765,8 +765,9 @@ static int search_fast(const bb_policy* P, const ogroup* g, const uint8_t* tc, i
     const int m = (int)g->flank_len, k = g->flank_k;
     uint8_t* pc = (uint8_t*)malloc((size_t)m); uint8_t* pcc = (uint8_t*)malloc((size_t)m);
     /* the reversed text, readable BBO_SIMD_PAD bytes either side like the caller's tc (the vector scan's lanes start before the text and run past it) */
-    uint8_t* trv_alloc = (uint8_t*)calloc((size_t)n + 2 * BBO_SIMD_PAD, 1);
+    uint8_t* trv_alloc = (uint8_t*)malloc((size_t)n + 2 * BBO_SIMD_PAD);
     uint8_t* trv = trv_alloc + BBO_SIMD_PAD;
+    memset(trv_alloc, 0, BBO_SIMD_PAD); memset(trv + n, 0, BBO_SIMD_PAD);
     for (int j = 0; j < m; ++j) { pc[j] = text_code(g->flank[j]); pcc[j] = comp_code(pc[j]); }
     for (int i = 0; i < n; ++i) trv[i] = tc[n - 1 - i];
     end_list ef = {0, 0, 0}, er = {0, 0, 0};
@@ -888,8 +889,9 @@ static const int32_t* diag_on_target(uint32_t gi, const bbo_match* fm) {
 /* Demuxer::demux (searcher.rs:430-490) for one read; rows appended to `rows` (already collapsed) */
 static void demux_read(const bbo_ctx* c, uint32_t read_idx, const uint8_t* read, uint32_t n, row_list* rows, int fast) {
     int first_row = rows->n;
-    uint8_t* rcode_alloc = (uint8_t*)calloc((size_t)n + 2 * BBO_SIMD_PAD, 1);   /* (padded: scan_strand_simd) */
+    uint8_t* rcode_alloc = (uint8_t*)malloc((size_t)n + 2 * BBO_SIMD_PAD);   /* (padded: scan_strand_simd) */
     uint8_t* rcode = rcode_alloc + BBO_SIMD_PAD;
+    memset(rcode_alloc, 0, BBO_SIMD_PAD); memset(rcode + n, 0, BBO_SIMD_PAD);
     { const uint8_t* T = text_code_table(); for (uint32_t i = 0; i < n; ++i) rcode[i] = T[read[i]]; }
     for (uint32_t gi = 0; gi < c->n_groups; ++gi) {                                   /* :433 */
         const ogroup* g = &c->g[gi];
