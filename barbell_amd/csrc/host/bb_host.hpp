@@ -14,6 +14,8 @@
 // The per-read call `Demuxer::demux(read_id, read)` (searcher.rs:430) becomes `demux_batch`: one
 // bb_annotate_batch per batch.  All arithmetic of the path runs in the HIP kernels of
 // libbarbell_amd.so; nothing here computes alignments.
+// Units (round 6): bb_host.cpp (kits, patterns, Demuxer), bb_feed.{hpp,cpp} (FASTQ files -> blocks), bb_inflate.{hpp,cpp} (gzip), bb_writers.{hpp,cpp}
+// (per-label FASTQ files), bb_annotate.cpp (the block pipeline, annotate*, demux_using_kit), bb_rccl.cpp + bb_rendezvous.{hpp,cpp}, bb_steps.cpp.
 #pragma once
 #include <cstdint>
 #include <map>

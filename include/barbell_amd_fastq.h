@@ -39,7 +39,7 @@ typedef struct {
 #define BB_FASTQ_FINAL    1   /* the text is the end of the stream                                                              */
 #define BB_FASTQ_TWO_LINE 2   /* compact form: records are their header and sequence lines only ("@id ..\nACGT..\n") — what the
                                  annotate path needs (annotator.rs:125-127 never looks at the quality line), half the bytes to move
-                                 over PCIe; the host side drops the '+' and quality lines while it stages the text (bb_host.cpp).
+                                 over PCIe; the host side drops the '+' and quality lines while it stages the text (host/bb_feed.cpp).
                                  batch->d_quals is NULL for such a block.                                                       */
 
 #define BB_FASTQ_PACKED   4   /* with BB_FASTQ_TWO_LINE: the sequence line holds two bases per byte — what crosses PCIe for annotate is then ~2 KB
@@ -48,7 +48,7 @@ typedef struct {
                                  Line format: bases 2i, 2i+1 of the line -> byte (code[2i] << 4) | (code[2i+1] ^ 0xA); an odd last base is
                                  paired with code 15; then ONE terminator byte 'E' / 'O' (even / odd number of bases), then '\n'.  No packed
                                  byte is '\n' unless both codes are 0 (two adjacent non-IUPAC characters): the host must not pack such input
-                                 (bb_host.cpp falls back to the plain two-line form).  The ingest unpacks into batch->d_bases as one canonical
+                                 (host/bb_annotate.cpp falls back to the plain two-line form).  The ingest unpacks into batch->d_bases as one canonical
                                  character per base set ("-ACMGRSVTWYHKDBN"[code]): rows are those of the original text, the read's own
                                  spelling (case, U for T) is not recoverable — the annotate path never reports it.                          */
 

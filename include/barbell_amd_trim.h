@@ -97,7 +97,7 @@ int bb_trim_batch_dev(bb_ctx* ctx, const bb_row* d_rows, const bb_row_verdict* d
 /* The plan without the text: slices (text order: grouped by label_key ascending, read order inside a label; out_off / rec_len as
  * bb_trim_batch_dev would lay the records out), spans, statuses and *text_len — everything `trim_matches` (trim.rs:317-480) decides,
  * nothing it copies.  For callers whose reads are in host memory anyway (a FASTQ file staged for upload): the records are then cut
- * out of that text by the threads that write the per-label files (bb_host.cpp), and neither the qualities nor the rendered records
+ * out of that text by the threads that write the per-label files (host/bb_writers.cpp), and neither the qualities nor the rendered records
  * cross PCIe.  Needs no bases or qualities on the device: works on a BB_FASTQ_TWO_LINE block.                                    */
 int bb_trim_plan_dev(bb_ctx* ctx, const bb_row* d_rows, const bb_row_verdict* d_verdicts, uint64_t n_rows, const uint64_t* d_offsets,
                      const bb_headers* d_headers, uint32_t n_reads, uint64_t* text_len, bb_slice* d_slices, uint64_t slices_cap,

@@ -1,4 +1,4 @@
-"""The C++ host's staging of FASTQ text for upload (bb_host.cpp: reader threads + sequencer), without a GPU: `barbell-amd stage` writes the
+"""The C++ host's staging of FASTQ text for upload (host/bb_feed.cpp: reader threads + sequencer), without a GPU: `barbell-amd stage` writes the
 blocks it would upload.  The packed form (BB_FASTQ_PACKED: two 4-bit IUPAC base sets per byte in the sequence lines) must equal the Python
 packer's text of the same records whatever the chunk size, reader count, line ends and file layout — the pairs are aligned to line starts, so
 chunk boundaries inside a sequence line (odd and even positions, the byte before a line end, inside "\\r\\n") must not show."""

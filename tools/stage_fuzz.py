@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""dev aid (no GPU): randomised check of the C++ host's packed staging (`barbell-amd stage`, bb_host.cpp compact_two_line + PackCtx) against the
+"""dev aid (no GPU): randomised check of the C++ host's packed staging (`barbell-amd stage`, host/bb_feed.cpp compact_two_line + PackCtx) against the
 Python packer (barbell_amd/fastq.py): random record lengths around the 32-base vector width, LF / CRLF, IUPAC and non-IUPAC characters, files
 with and without a final newline, blank lines after the last record, gzip (inflated in pieces of 64 bytes up), several files, chunk sizes from 17 bytes up, 1-5 reader threads.
 Every other seed also checks --shard R/W --shard-by bytes (the shards' texts concatenated = the unsharded text).
