@@ -1122,3 +1122,29 @@ def test_two_bases_per_byte_at_the_boundary():
     assert_same(b2, a)
     assert int(dm.counts().sum()) == 2 * len(a)
     dm.close()
+
+
+def test_a_row_buffer_that_is_too_small_leaves_nothing_behind():
+    """BB_E_CAPACITY from every host form of a small (deferred) batch: *n_rows says how many rows the batch has, nothing of the failed call
+    stays in the histogram (k_emit checks the count the host is about to read before it emits or counts), and the call again with room
+    gives the rows."""
+    import ctypes as C
+
+    from barbell_amd import annotate as A
+    from barbell_amd._lib import lib
+
+    groups = config_groups("nbd96")
+    bases, offsets = A.synth_reads_host(groups, 21, 500, 3000, 0, 2000)
+    dm, want, _ = run_both(groups, bases, offsets)
+    dm.counts_reset()
+    small = np.zeros(100, dtype=_abi.ROW_DTYPE)
+    need = C.c_uint64()
+    for _ in range(2):
+        rc = lib().bb_annotate_batch(dm._ctx(), bases.ctypes.data, offsets.ctypes.data, 2000, small.ctypes.data, len(small), C.byref(need))
+        assert rc == _abi.BB_E_CAPACITY and need.value == len(want) > 1000
+        assert int(dm.counts().sum()) == 0
+    assert_same(dm.demux_packed(bases, offsets), want)
+    assert int(dm.counts().sum()) == len(want)
+    assert_same(dm.demux_nibbles(bases, offsets), want)
+    assert int(dm.counts().sum()) == 2 * len(want)
+    dm.close()
