@@ -508,9 +508,11 @@ int bb_create_policy(const bb_group_desc* groups, uint32_t n_groups, const bb_pa
         const int v = atoi(getenv("BARBELL_AMD_SEG_LINES"));
         c->seg_lines = v <= 0 ? 0u : (uint32_t)std::min(64, std::max(4, v & ~3));
         c->split_above = 2u * c->seg_lines;
+        c->seg_from_env = true;
     }
     if (const char* e = getenv("BARBELL_AMD_DEFER_MAX")) c->defer_max = (uint32_t)strtoul(e, nullptr, 10);
     if (const char* e = getenv("BARBELL_AMD_SMALL_PFX_MAX")) c->small_pfx_max = (uint32_t)strtoul(e, nullptr, 10);
+    if (const char* e = getenv("BARBELL_AMD_SMALL_SEG_MAX")) c->small_seg_max = (uint32_t)strtoul(e, nullptr, 10);
     if (const char* e = getenv("BARBELL_AMD_HOST_LEN_MAX")) c->host_len_max = (uint32_t)strtoul(e, nullptr, 10);
     c->phases = getenv("BARBELL_AMD_PHASES") && atoi(getenv("BARBELL_AMD_PHASES")) != 0;
     if (const char* e = getenv("BARBELL_AMD_LANE_FB_FRAC")) c->lane_fb_frac = atof(e);
@@ -566,6 +568,7 @@ void bb_destroy(bb_ctx* c) {
         if (p) (void)hipFree(p);
     if (c->h_lencur) (void)hipHostFree(c->h_lencur);
     if (c->h_ctl) (void)hipHostFree(c->h_ctl);
+    if (c->h_offs) (void)hipHostFree(c->h_offs);
     delete c->host_len;
     bb_trim_state_free(c->trim);
     bb_fastq_state_free(c->fastq);
@@ -797,6 +800,59 @@ int bb_annotate_batch_dev(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_o
 // waits for every other context's stream on the device, and a binding's worker threads (one context each) would run one after the other.
 // (Measured, round 6: HIP's own path for pageable memory moves a 4 MB batch in 0.29 ms; copying it through page-locked slots of the context
 // first took 1.3 ms — not kept.)
+// A small host batch, every group on the filter pass: the reads cut into 512-byte segments by the host (bb_ctx::small_seg_max).  The table — one
+// (read, segment) pair per lane of k_flank_filter, longest segments first, what k_len_scatter builds on the device for batches of differing
+// lengths — is written behind the offsets in a page-locked buffer and goes up with them in ONE copy.  1: done (offsets uploaded too), 0: not
+// applicable (the caller uploads the offsets), < 0: error.
+static int bb_small_segments(bb_ctx* c, const uint64_t* offsets, uint32_t n) {
+    c->host_vtab_valid = false;
+    if (!c->small_seg_max || n > c->small_seg_max || n > c->defer_max || !c->seg_lines || c->seg_from_env || c->scan_filter == 0) return 0;
+    for (size_t g = 0; g < c->groups.size(); ++g)   // the full scan's segments need more than a table (cells per cut read, k_seg_fold): filtered groups only
+        if (!(c->gdev[g].filt_rows > 0) || (c->scan_off[g] > 0 && c->scan_filter != 1)) return 0;
+    constexpr uint32_t SL = 4u, SA = 8u;
+    uint64_t n_virtual = 0;
+    uint32_t max_nl = 0, bins[SA + 1] = {};
+    auto lines_of = [&](uint32_t i) { const uint64_t off = offsets[i]; const uint32_t len = (uint32_t)(offsets[i + 1] - off); return len ? (uint32_t)(((off & 127u) + len + 127u) >> 7) : 0u; };
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint32_t nl = lines_of(i);
+        max_nl = std::max(max_nl, nl);
+        if (nl > SA) { const uint32_t ns = (nl + SL - 1u) / SL; bins[SL] += ns - 1u; ++bins[nl - (ns - 1u) * SL]; n_virtual += ns; }
+        else { ++bins[nl]; ++n_virtual; }
+    }
+    if (max_nl <= SA || n_virtual > 32ull * n || ((uintptr_t)c->d_in_bases & 127u)) return 0;   // nothing to cut / reads so long that the table would outweigh the gain
+    int r;
+    if ((r = grow(c, c->d_in_offsets, c->cap_in_offsets, (uint64_t)n + 1 + n_virtual))) return r;
+    if (c->cap_h_offs < (uint64_t)n + 1 + n_virtual) {
+        if (c->h_offs) HIPCHK(c, hipHostFree(c->h_offs));
+        c->h_offs = nullptr; c->cap_h_offs = 0;
+        const uint64_t cap = ((uint64_t)n + 1 + n_virtual) * 5 / 4 + 64;
+        HIPCHK(c, hipHostMalloc((void**)&c->h_offs, cap * 8, hipHostMallocDefault));
+        c->cap_h_offs = cap;
+    }
+    memcpy(c->h_offs, offsets, ((uint64_t)n + 1) * 8);
+    uint2* vt = reinterpret_cast<uint2*>(c->h_offs + n + 1);
+    uint32_t at[SA + 1], pos = 0;
+    for (int b = (int)SA; b >= 0; --b) { at[b] = pos; pos += bins[b]; }   // falling length: a wave's lanes finish together
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint32_t nl = lines_of(i);
+        if (nl > SA) {
+            const uint32_t ns = (nl + SL - 1u) / SL;
+            for (uint32_t t = 0; t + 1u < ns; ++t) vt[at[SL]++] = make_uint2(i, t);
+            vt[at[nl - (ns - 1u) * SL]++] = make_uint2(i, ns - 1u);
+        } else vt[at[nl]++] = make_uint2(i, 0u);
+    }
+    HIPCHK(c, hipMemcpyAsync(c->d_in_offsets, c->h_offs, ((uint64_t)n + 1 + n_virtual) * 8, hipMemcpyHostToDevice, c->stream));
+    c->host_vtab = reinterpret_cast<const uint2*>(c->d_in_offsets + n + 1); c->host_n_virtual = (uint32_t)n_virtual; c->host_vtab_valid = true;
+    return 1;
+}
+
+static int bb_upload_offsets(bb_ctx* c, const uint64_t* offsets, uint32_t n) {
+    const int r = bb_small_segments(c, offsets, n);
+    if (r < 0) return r;
+    if (r == 0) HIPCHK(c, hipMemcpyAsync(c->d_in_offsets, offsets, ((uint64_t)n + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    return BB_OK;   // (r == 1: they went up with the segment table behind them)
+}
+
 // packed != nullptr: the reads come two bases per byte (bb_pack.h; read i at packed + packed_offsets[i], offsets zero-based in BASES) and are
 // spread to one byte per base in HBM before anything looks at them — half the bytes over PCIe.
 static int annotate_host_chunk(bb_ctx* c, const uint8_t* bases, const uint64_t* offsets, uint32_t n, bb_row* rows, uint64_t rows_cap,
@@ -814,13 +870,13 @@ static int annotate_host_chunk(bb_ctx* c, const uint8_t* bases, const uint64_t* 
         if ((r = grow(c, c->d_in_poffs, c->cap_in_poffs, (uint64_t)n + 1))) return r;
         HIPCHK(c, hipMemcpyAsync(c->d_in_packed, packed + packed_offsets[0], pb, hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemcpyAsync(c->d_in_poffs, packed_offsets, ((uint64_t)n + 1) * 8, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipMemcpyAsync(c->d_in_offsets, offsets, ((uint64_t)n + 1) * 8, hipMemcpyHostToDevice, c->stream));
+        if ((r = bb_upload_offsets(c, offsets, n))) return r;
         // (the kernel subtracts nothing: the device copy of the packed bytes starts at the batch's first read)
         bb_launch_unpack_reads(c->stream, c->d_in_packed - packed_offsets[0], c->d_in_poffs, c->d_in_offsets, n, c->d_in_bases);
         HIPCHK(c, hipGetLastError());
     } else {
         HIPCHK(c, hipMemcpyAsync(c->d_in_bases, bases, nb, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipMemcpyAsync(c->d_in_offsets, offsets, ((uint64_t)n + 1) * 8, hipMemcpyHostToDevice, c->stream));
+        if ((r = bb_upload_offsets(c, offsets, n))) return r;
     }
     if (n <= c->host_len_max && ((uintptr_t)c->d_in_bases & 127u) == 0) {
         // the batch's length statistics from the offsets in hand (bb_host_lenstat) instead of a kernel and a round trip
@@ -832,8 +888,9 @@ static int annotate_host_chunk(bb_ctx* c, const uint8_t* bases, const uint64_t* 
     const double t1 = c->phases ? bb_now() : 0.0;
     uint64_t dev_cap = c->cap_out_rows < rows_cap ? c->cap_out_rows : rows_cap;
     c->spec_dst = rows; c->spec_cap = rows_cap;   // a deferred batch copies its first rows before its one wait
+    if (!c->host_len_valid) c->host_vtab_valid = false;   // (the table rides on the host's length statistics)
     r = bb_annotate_batch_dev(c, c->d_in_bases, c->d_in_offsets, n, c->d_out_rows, dev_cap, n_rows);
-    c->host_len_valid = false;
+    c->host_len_valid = false; c->host_vtab_valid = false;
     uint64_t have = c->spec_done;
     if (r == BB_E_CAPACITY && *n_rows <= rows_cap) {  // staging buffer was the limit, not the caller's
         if ((r = grow(c, c->d_out_rows, c->cap_out_rows, *n_rows))) return r;

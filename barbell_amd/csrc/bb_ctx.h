@@ -101,6 +101,14 @@ struct bb_ctx {
     const uint2* vtab = nullptr;   // of the batch in hand (d_vtab or null)
     uint32_t n_virtual = 0;        // entries of vtab
     uint32_t seg_lines = 32, split_above = 64;   // BARBELL_AMD_SEG_LINES (a multiple of 4; split_above = twice that; 0 = never cut, never sort)
+    bool seg_from_env = false;                   // ... given explicitly: no per-batch choice below
+    uint32_t batch_seg_lines = 32, batch_split_above = 64;   // of the batch in hand (what the scans' launches pass)
+    // A SMALL host batch whose groups all take the filter pass (round 6): a 4 kb read is one lane's 210 us — most of a lone caller's call.  The host
+    // form cuts the reads into 512-byte segments itself (it holds the offsets): the segment table rides behind the offsets in the same upload (no
+    // kernel, no extra submission), the filter's lanes take 4 lines + 1 of lead-in each.  BARBELL_AMD_SMALL_SEG_MAX reads (0 = never).
+    uint32_t small_seg_max = 8192;
+    uint64_t* h_offs = nullptr; uint64_t cap_h_offs = 0;    // page-locked: offsets + segment table of such a batch
+    const uint2* host_vtab = nullptr; uint32_t host_n_virtual = 0; bool host_vtab_valid = false;
     uint32_t last_min_lines = 0, last_max_lines = 0, last_segments = 0;   // of the last batch (bb_last_length_stats)
     int scan_filter = -1;        // BARBELL_AMD_SCAN_FILTER: 0 never, 1 wherever it is valid (tests), unset: where the prefix says enough
     bool fast_path = true;       // BARBELL_AMD_NO_FAST=1: score every barcode of every hit exactly (the fallback kernel only)

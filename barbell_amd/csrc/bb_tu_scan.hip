@@ -34,7 +34,7 @@ void launch_scan2(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets, 
         if (c->vtab) {   // reads of differing lengths: a lane per segment (bb_len.h), counts and hits folded back by seg_fixup
             hipLaunchKernelGGL(k_flank_scan_seg<W>, dim3(bb_coscheduled_blocks(gl.n, 2u, (c->n_virtual + 255u) / 256u)), dim3(256), 0, c->stream, d_bases, d_offsets, n,
                                (const uint8_t*)c->d_tables, (const bb_group_dev*)c->d_groups, gl, (uint32_t)c->groups.size(), c->d_cnt,
-                               c->d_raw, c->cap_hits, c->d_hitcount, c->vtab, c->n_virtual, c->seg_lines, c->split_above, (const uint32_t*)c->d_vcut, c->d_vcnt);
+                               c->d_raw, c->cap_hits, c->d_hitcount, c->vtab, c->n_virtual, c->batch_seg_lines, c->batch_split_above, (const uint32_t*)c->d_vcut, c->d_vcnt);
             continue;
         }
         hipLaunchKernelGGL(k_flank_scan2<W>, dim3(bb_coscheduled_blocks(gl.n, 2u, (n + 255u) / 256u)), dim3(256), 0, c->stream, d_bases, d_offsets, n,
@@ -68,6 +68,7 @@ void launch_verify(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets,
 // kernel in a round trip the filtered scan made already; others get their segments / reads sorted by falling length.
 int bb_prepare_lengths(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n, uint64_t* off0, uint64_t* off1) {
     c->vtab = nullptr; c->n_virtual = 0; c->n_cut_reads = 0; c->n_cut_segs = 0;
+    c->batch_seg_lines = c->seg_lines; c->batch_split_above = c->split_above;
     if (!c->d_lenstat) {
         HIPCHK(c, hipMalloc((void**)&c->d_lenstat, sizeof(bb_lenstat)));
         HIPCHK(c, hipMalloc((void**)&c->d_lencur, sizeof(bb_lencur)));
@@ -88,6 +89,12 @@ int bb_prepare_lengths(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offs
     *off0 = st.off0; *off1 = st.off1;
     c->last_min_lines = st.min_nl; c->last_max_lines = st.max_nl; c->last_segments = n;
     if (st.off1 < st.off0) { c->last_error = "offsets are not ascending"; return BB_E_INVALID; }
+    if (c->host_vtab_valid) {   // a small host batch whose segment table came up with its offsets (annotate_host_chunk): 512-byte segments for the filter pass
+        c->host_vtab_valid = false;
+        c->vtab = c->host_vtab; c->n_virtual = c->host_n_virtual; c->last_segments = c->host_n_virtual;
+        c->batch_seg_lines = 4u; c->batch_split_above = 8u;
+        return BB_OK;
+    }
     if (!c->seg_lines || (st.max_nl <= c->split_above && st.max_nl - st.min_nl <= 2u)) return BB_OK;   // lanes of a wave finish together as they are
     bb_lencur& cur = *c->h_lencur;   // (the last batch's upload of it has long been consumed: every batch ends with a round trip)
     uint64_t at = 0;
@@ -149,10 +156,10 @@ int bb_launch_scans(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets
                 const dim3 grid(bb_coscheduled_blocks(gl.n, 1u, ((c->vtab ? c->n_virtual : n) + 255u) / 256u));   // a lane per read, or per segment (bb_len.h)
                 if (wide)
                     hipLaunchKernelGGL(k_flank_filter<true>, grid, dim3(256), 0, c->stream, d_bases, d_offsets, n, (const uint8_t*)c->d_tables,
-                                       (const bb_group_dev*)c->d_groups, gl, fl, flag_words, c->d_nflag, c->vtab, c->n_virtual, c->seg_lines, c->split_above);
+                                       (const bb_group_dev*)c->d_groups, gl, fl, flag_words, c->d_nflag, c->vtab, c->n_virtual, c->batch_seg_lines, c->batch_split_above);
                 else
                     hipLaunchKernelGGL(k_flank_filter<false>, grid, dim3(256), 0, c->stream, d_bases, d_offsets, n, (const uint8_t*)c->d_tables,
-                                       (const bb_group_dev*)c->d_groups, gl, fl, flag_words, c->d_nflag, c->vtab, c->n_virtual, c->seg_lines, c->split_above);
+                                       (const bb_group_dev*)c->d_groups, gl, fl, flag_words, c->d_nflag, c->vtab, c->n_virtual, c->batch_seg_lines, c->batch_split_above);
                 reg += gl.n;
             }
     }

@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 NT = effective_cpus()
 
 # Tests whose batches are far above the small-batch thresholds (same path under both settings) or that set the thresholds themselves
-ONE_BATCHING = {"test_large_batch_properties_without_oracle": "small-batch", "test_offsets_beyond_4gib_against_oracle": "small-batch",
+ONE_BATCHING = {"test_large_batch_properties_without_oracle": "small-batch", "test_small_filtered_batches_are_cut_by_the_host": "small-batch", "test_offsets_beyond_4gib_against_oracle": "small-batch",
                 "test_small_batches_run_deferred": "small-batch", "test_deferred_batch_grows_its_hit_buffers": "small-batch",
                 "test_lane_kernel_backs_off_when_its_bound_decides_too_little": "classic"}   # (batches of 3 000 reads: one lane per hit only there)
 
@@ -297,7 +297,7 @@ def test_megabase_reads_among_ordinary_ones(cfg):
 @pytest.mark.parametrize("cfg,seg,policy", [
     ("nbd96", None, None), ("nbd96", "4", None), ("dual", "4", None), ("rbk96x", None, None), ("rbk96x", "4", None), ("rbk96x", "8", "lm=left"),
     ("rbk24", "4", "lm=strict"), ("nbd96", "0", None)])
-def test_reads_of_differing_lengths(monkeypatch, cfg, seg, policy):
+def test_reads_of_differing_lengths(monkeypatch, batching, cfg, seg, policy):
     """A run's reads differ in length by three orders of magnitude; the scans then give their lanes SEGMENTS of reads, sorted by falling
     length (bb_len.h), instead of reads in file order.  The filter pass cuts a read where it likes (flags are addressed by position); the
     full scan's segments divide the hits by valley (flank_scan_lane<.., SEG>): same rows as the oracle's, with the default segments
@@ -322,7 +322,11 @@ def test_reads_of_differing_lengths(monkeypatch, cfg, seg, policy):
 
     b2, o2 = A.synth_reads_host(groups, 21, 2000, 2000, 0, 300)
     dm.demux_packed(b2, o2)
-    assert dm.length_stats()["work_items"] == 300 or seg not in (None, "0")   # (with 512-byte segments forced these are cut as well)
+    # (with 512-byte segments forced these are cut as well — and in a SMALL batch whose groups all take the filter pass: the host form cuts such
+    # reads into 512-byte segments itself, bb_ctx::small_seg_max)
+    host_cut = batching == "small-batch" and cfg == "nbd96" and seg is None
+    items = dm.length_stats()["work_items"]
+    assert (300 * 4 <= items <= 300 * 5 if host_cut else items == 300) or seg not in (None, "0")   # (2000 nt: 16 or 17 lines)
 
 
 def test_empty_and_tiny_reads():
@@ -850,6 +854,44 @@ def test_small_batches_run_deferred(monkeypatch):
         assert_same(got, want)
         assert dm.host_syncs() == syncs, (defer, pfx, dm.host_syncs())
         dm.close()
+
+
+@pytest.mark.parametrize("cfg,cut", [("nbd96", True), ("dual", True), ("rbk96x", False)])
+def test_small_filtered_batches_are_cut_by_the_host(monkeypatch, cfg, cut):
+    """A small host-form batch whose groups all take the filter pass (bb_ctx::small_seg_max): the host cuts the reads into 512-byte segments
+    from the offsets in hand and the table goes up behind them in the same copy — 8 lanes of the filter pass per 4 kb read instead of one
+    (0.57 -> 0.40 ms for a lone caller's 1 024-read call).  Same rows with the table, without it (BARBELL_AMD_SMALL_SEG_MAX=0), in the
+    two-bases-per-byte form, on ragged reads and with empty ones; a context with a full-scan group (k = 20: rbk96x) is left alone (its
+    segments need cells per cut read: bb_len.h)."""
+    from tests.common import heavy_tailed_batch
+
+    groups = config_groups(cfg)
+    bases, offsets = A_synth(groups, 77, 3000, 4000, 1200)
+    dm, got, want = run_both(groups, bases, offsets)
+    assert_same(got, want)
+    n = len(offsets) - 1
+    items = dm.length_stats()["work_items"]
+    assert items >= 6 * n if cut else items == n, items
+    assert dm.host_syncs() == 1
+    assert_same(dm.demux_nibbles(bases, offsets), want)
+    assert (dm.length_stats()["work_items"] >= 6 * n) == cut
+    # ragged: short reads whole (up to 8 lines), long ones cut, empty reads in between
+    hb, ho = heavy_tailed_batch(groups, 900, seed=9, scale=0.3)
+    reads = [hb[int(ho[i]):int(ho[i + 1])].tobytes() for i in range(len(ho) - 1)]
+    for at in (0, 17, 400, len(reads)): reads.insert(at, b"")
+    rb, ro = _abi.pack_reads(reads)
+    from oracle import pyoracle as po
+
+    want2 = po.Oracle([g.as_tuple() for g in groups]).annotate(rb, ro, n_threads=NT)
+    assert_same(dm.demux_packed(rb, ro), want2)
+    assert dm.length_stats()["work_items"] > len(reads) + (100 if cut else 20)   # (512-byte segments / the device's 4 KB ones)
+    dm.close()
+    monkeypatch.setenv("BARBELL_AMD_SMALL_SEG_MAX", "0")
+    dm, got, _ = run_both(groups, bases, offsets)
+    assert_same(got, want)
+    assert dm.length_stats()["work_items"] == n
+    assert_same(dm.demux_packed(rb, ro), want2)
+    dm.close()
 
 
 def test_deferred_batch_grows_its_hit_buffers():
