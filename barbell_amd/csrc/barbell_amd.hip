@@ -732,7 +732,7 @@ int bb_annotate_batch_dev(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_o
         }
         mark(c, K_COLLAPSE);
         hipLaunchKernelGGL(k_collapse, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->d_rows, (const uint32_t*)c->d_base, n, G,
-                           c->d_nrows, hits_dev, c->cap_hits);
+                           c->d_nrows, hits_dev, c->cap_hits, (const uint32_t*)c->d_hitmeta);
         if ((r = bb_scan_u32(c, c->d_nrows, c->d_rowoff, (uint64_t)n + 1, &c->d_ctl->total_rows))) return r;
         if (deferred) {
             // rows out and counted on the device's own say-so (k_emit checks what the host is about to read), the batch's numbers into the page-locked

@@ -90,12 +90,15 @@ __device__ __forceinline__ int rows_cmp(const bb_row& a, const bb_row& b) {  // 
 }
 __global__ __launch_bounds__(256) void k_collapse(bb_rowtmp* __restrict__ rows, const uint32_t* __restrict__ slot_base,
                                                   uint32_t n_reads, uint32_t n_groups, uint32_t* __restrict__ nrows,
-                                                  const uint32_t* __restrict__ n_hits_dev, uint32_t cap_hits) {
+                                                  const uint32_t* __restrict__ n_hits_dev, uint32_t cap_hits, const uint32_t* __restrict__ hit_meta) {
     if (n_hits_dev && *n_hits_dev > cap_hits) return;   // deferred batch whose hits overflowed their buffers: the host runs it again (slots beyond the buffers)
     const uint32_t read = blockIdx.x * 256u + threadIdx.x;
     if (read >= n_reads) return;
     const uint32_t b0 = slot_base[(uint64_t)read * n_groups * 2], b1 = slot_base[(uint64_t)(read + 1) * n_groups * 2];
     if (b0 == b1) { nrows[read] = 0; return; }
+    // one hit (the common case): nothing to sort or to collapse, and whether it has a row is its meta word's say (a hit has a row — a barcode's
+    // or the flank's alone — unless get_matching_region gave None: k_hit_lists) — 4 bytes instead of the row's line
+    if (b1 - b0 == 1u) { nrows[read] = (hit_meta[b0] & 0xFFu) ? 1u : 0u; return; }
     bb_rowtmp* R = rows + b0;
     int n = 0;
     for (uint32_t i = 0; i < b1 - b0; ++i)  // drop hits without a row, keep order
