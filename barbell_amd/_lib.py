@@ -13,7 +13,7 @@ SO_PATH = os.environ.get("BARBELL_AMD_SO") or os.path.join(_HERE, "libbarbell_am
 EXPORTS = [
     "bb_create", "bb_create_policy", "bb_get_policy", "bb_destroy", "bb_n_groups", "bb_group_get_info", "bb_group_get_flank", "bb_group_get_pattern",
     "bb_annotate_batch", "bb_annotate_batch_dev", "bb_counts_len", "bb_counts", "bb_counts_dev", "bb_counts_reset",
-    "bb_last_scan_stats", "bb_last_length_stats", "bb_pack_bases", "bb_annotate_batch_packed", "bb_last_host_syncs", "bb_host_phases", "bb_last_barcode_stats", "bb_n_kernels", "bb_kernel_name", "bb_last_kernel_ms", "bb_set_timing", "bb_last_dominant_kernel", "bb_strerror", "bb_last_error", "bb_build_trace_classes",
+    "bb_last_scan_stats", "bb_filter_twin", "bb_last_length_stats", "bb_pack_bases", "bb_annotate_batch_packed", "bb_last_host_syncs", "bb_host_phases", "bb_last_barcode_stats", "bb_n_kernels", "bb_kernel_name", "bb_last_kernel_ms", "bb_set_timing", "bb_last_dominant_kernel", "bb_strerror", "bb_last_error", "bb_build_trace_classes",
     "bb_synth_offsets", "bb_synth_reads_host", "bb_synth_reads_dev",
     "bb_filter_set", "bb_filter_rows", "bb_filter_rows_dev",
     "bb_inspect_rows", "bb_inspect_rows_dev",
@@ -67,6 +67,7 @@ def lib():
     L.bb_counts_dev.restype = vp
     L.bb_counts_reset.argtypes = [vp]
     L.bb_last_scan_stats.argtypes = [vp, u32, C.POINTER(u64), C.POINTER(u64), C.POINTER(i32)]
+    L.bb_filter_twin.argtypes = [vp, u32, C.POINTER(i32), C.POINTER(i32)]
     L.bb_last_length_stats.argtypes = [vp, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)]
     L.bb_last_host_syncs.argtypes = [vp]
     L.bb_host_phases.argtypes = [vp, i32, vp, vp]

@@ -138,9 +138,54 @@ void build_synth_tables(const std::vector<std::vector<std::string>>& seqs, bb_sy
 }
 
 int ensure_ctl(bb_ctx* c, uint64_t flag_words);
+// What a filter window (rows u .. u+R-1 of a flank whose forward Peq table is t) costs on L pseudo-random bases, run with the filter's own
+// recurrence: every flagged column, plus per_run for the lead-in, piece granularity and margins of every flagged run (given up beyond `limit`).
+static long filt_window_cost(const uint32_t* t, int S, int W, int k, int R, int u, int L, long per_run, long limit) {
+    const uint32_t maskR = R >= 32 ? 0xFFFFFFFFu : (1u << R) - 1u;
+    uint32_t eqs[4];
+    for (int b = 0; b < 4; ++b) {
+        const uint32_t* e = t + (size_t)"ACGT"[b] * S;
+        uint64_t two = e[u >> 5];
+        if ((u >> 5) + 1 < W) two |= (uint64_t)e[(u >> 5) + 1] << 32;
+        eqs[b] = (uint32_t)(two >> (u & 31)) & maskR;
+    }
+    uint32_t pv = maskR, mv = 0, x = 0x9E3779B9u;
+    int sc = R;
+    long cost = 0;
+    bool in = false;
+    for (int i = 0; i < L && cost < limit; ++i) {
+        x = x * 1664525u + 1013904223u;
+        const uint32_t eq = eqs[x >> 30];
+        const uint32_t xx = eq & pv, d0 = (((xx + pv) ^ pv) | eq | mv) & maskR;
+        const uint32_t ph = (mv | ~(d0 | pv)) & maskR, mh = pv & d0;
+        sc += (int)((ph >> (R - 1)) & 1u) - (int)((mh >> (R - 1)) & 1u);
+        const uint32_t phs = ph << 1, mhs = mh << 1;
+        pv = (mhs | ~(d0 | phs)) & maskR; mv = phs & d0 & maskR;
+        const bool f = sc <= k;
+        cost += f ? (in ? 1 : per_run) : 0;
+        in = f;
+    }
+    return cost;
+}
+// bb_group_dev::filt_mode of a window at row u (what k_flank_verify scans whatever the flags say, and how the filter's forward block starts)
+static uint32_t filt_mode_of(const bb_policy& pol, float alpha, int m, int k, int R, int u, bool wide) {
+    int o_max = 0;  // most rows that can hang over a read end within the budget (edit_model: floor(alpha * o))
+    for (int o = 1; o <= m; ++o)
+        if (overhang_cost(pol, alpha, o) <= k) o_max = o;
+    uint32_t mode = wide ? BB_FILT_WIDE : 0u;
+    if (u == 0) mode |= BB_FILT_TRUE_INIT;
+    if (!(u == 0 || u >= o_max)) mode |= BB_FILT_FWD_BEGIN_ALWAYS;
+    if (u == 0 && o_max < R) mode |= BB_FILT_RC_BEGIN_HINT;
+    else if (u < o_max) mode |= BB_FILT_RC_BEGIN_ALWAYS;
+    if (o_max > m - u - R) mode |= BB_FILT_END_ALWAYS;
+    if (getenv("BARBELL_AMD_FILTER_ENDS")) mode = (mode & (BB_FILT_TRUE_INIT | BB_FILT_WIDE)) | BB_FILT_FWD_BEGIN_ALWAYS | BB_FILT_RC_BEGIN_ALWAYS | BB_FILT_END_ALWAYS;  // test knob: both ends of every read
+    return mode;
+}
+
 int upload_tables(bb_ctx* c) {
     Blob blob;
     c->gdev.resize(c->groups.size());
+    memset(c->filt_twin, -1, sizeof(c->filt_twin)); memset(c->last_twin, -1, sizeof(c->last_twin));
     uint32_t count_off = 0;
     const float alpha = c->params.alpha;
     const bb_policy& pol = c->policy;
@@ -191,33 +236,10 @@ int upload_tables(bb_ctx* c) {
                 // piece granularity and margins of every flagged run
                 const long per_run = m + 3 * k + 24;
                 auto best_window = [&](int R, int& best_u) -> double {
-                    const uint32_t maskR = R >= 32 ? 0xFFFFFFFFu : (1u << R) - 1u;
                     long best_cost = (long)L * per_run;
                     best_u = 0;
                     for (int u = 0; u + R <= m; ++u) {
-                        uint32_t eqs[4];
-                        for (int b = 0; b < 4; ++b) {
-                            const uint32_t* e = t + (size_t)"ACGT"[b] * S;
-                            uint64_t two = e[u >> 5];
-                            if ((u >> 5) + 1 < W) two |= (uint64_t)e[(u >> 5) + 1] << 32;
-                            eqs[b] = (uint32_t)(two >> (u & 31)) & maskR;
-                        }
-                        uint32_t pv = maskR, mv = 0, x = 0x9E3779B9u;
-                        int sc = R;
-                        long cost = 0;
-                        bool in = false;
-                        for (int i = 0; i < L && cost < best_cost; ++i) {
-                            x = x * 1664525u + 1013904223u;
-                            const uint32_t eq = eqs[x >> 30];
-                            const uint32_t xx = eq & pv, d0 = (((xx + pv) ^ pv) | eq | mv) & maskR;
-                            const uint32_t ph = (mv | ~(d0 | pv)) & maskR, mh = pv & d0;
-                            sc += (int)((ph >> (R - 1)) & 1u) - (int)((mh >> (R - 1)) & 1u);
-                            const uint32_t phs = ph << 1, mhs = mh << 1;
-                            pv = (mhs | ~(d0 | phs)) & maskR; mv = phs & d0 & maskR;
-                            const bool f = sc <= k;
-                            cost += f ? (in ? 1 : per_run) : 0;
-                            in = f;
-                        }
+                        const long cost = filt_window_cost(t, S, W, k, R, u, L, per_run, best_cost);
                         if (cost < best_cost) { best_cost = cost; best_u = u; }
                     }
                     return (double)best_cost / L;
@@ -242,17 +264,7 @@ int upload_tables(bb_ctx* c) {
                 if (pick) {
                     const int R = pick == 1 ? R15 : R31, u = pick == 1 ? u15 : u31;
                     D.filt_rows = R; D.filt_off = u;
-                    int o_max = 0;  // most rows that can hang over a read end within the budget (edit_model: floor(alpha * o))
-                    for (int o = 1; o <= m; ++o)
-                        if (overhang_cost(pol, alpha, o) <= k) o_max = o;
-                    uint32_t mode = pick == 2 ? BB_FILT_WIDE : 0u;
-                    if (u == 0) mode |= BB_FILT_TRUE_INIT;
-                    if (!(u == 0 || u >= o_max)) mode |= BB_FILT_FWD_BEGIN_ALWAYS;
-                    if (u == 0 && o_max < R) mode |= BB_FILT_RC_BEGIN_HINT;
-                    else if (u < o_max) mode |= BB_FILT_RC_BEGIN_ALWAYS;
-                    if (o_max > m - u - R) mode |= BB_FILT_END_ALWAYS;
-                    if (getenv("BARBELL_AMD_FILTER_ENDS")) mode = (mode & (BB_FILT_TRUE_INIT | BB_FILT_WIDE)) | BB_FILT_FWD_BEGIN_ALWAYS | BB_FILT_RC_BEGIN_ALWAYS | BB_FILT_END_ALWAYS;  // test knob: both ends of every read
-                    D.filt_mode = (int32_t)mode;
+                    D.filt_mode = (int32_t)filt_mode_of(pol, alpha, m, k, R, u, pick == 2);
                 }
             }
         }
@@ -316,6 +328,57 @@ int upload_tables(bb_ctx* c) {
                 for (int t = 0; t < T; ++t)
                     if (bb_text_code((uint8_t)g.pat[s][0][P + 32 + t]) & code) tl[code] |= (uint8_t)(1u << t);
             }
+        }
+    }
+    // TWIN filter windows (bb_ctx::filt_twin).  The right-hand pattern of a dual-end kit is the left-hand one's reverse complement, give or take a
+    // few bases at the ends: R rows of group B's flank are then R rows of group A's read backwards and complemented, B's forward block in
+    // k_flank_filter is A's rc block row for row (and the other way round), and ONE pass flags for both (k_flank_verify: swap_strands).  Each
+    // group above chose its window alone; here pairs of groups with the same kind of pass get the quietest pair of MIRRORED windows — both
+    // their own semi-global problem on both strands (no BB_FILT_TRUE_INIT, no rc-begin hint: neither at row 0) — if that beats two passes.
+    for (size_t b = 1; b < c->groups.size() && !getenv("BARBELL_AMD_NO_TWIN_WINDOWS"); ++b) {
+        bb_group_dev& B = c->gdev[b];
+        for (size_t a = 0; a < b && B.filt_rows > 0 && c->filt_twin[b] < 0; ++a) {
+            bb_group_dev& A = c->gdev[a];
+            const int R = A.filt_rows;
+            const bool wide = ((uint32_t)A.filt_mode & BB_FILT_WIDE) != 0;
+            if (R <= 0 || R != B.filt_rows || wide != (((uint32_t)B.filt_mode & BB_FILT_WIDE) != 0) || c->filt_twin[a] >= 0) continue;
+            if (std::min(A.flank_k, R) != std::min(B.flank_k, R)) continue;
+            bool a_fixed = false;   // already another group's twin: its window stays
+            for (size_t t = 0; t < c->groups.size(); ++t) a_fixed = a_fixed || c->filt_twin[t] == (int8_t)a;
+            const std::string &fa = c->groups[a].flank, &fb = c->groups[b].flank;
+            const int L = 1 << 15;
+            struct Side { const uint32_t* t; int S, W, m, k; long per_run; double full; };
+            auto side = [&](const bb_group_dev& D) {
+                const int W = D.W;
+                return Side{reinterpret_cast<const uint32_t*>(blob.b.data() + D.off_peq_flank[0]), bb_peq_stride_words(W), W, D.m, D.flank_k, (long)D.m + 3 * D.flank_k + 24,
+                            W == 1 ? 0.6 : 0.5 * W};
+            };
+            const Side sa = side(A), sb = side(B);
+            auto cost = [&](const Side& s, int u) { return (double)filt_window_cost(s.t, s.S, s.W, s.k, R, u, L, s.per_run, (long)L * s.per_run) / L; };
+            auto ends = [&](const Side& s, uint32_t mode) {   // what the verification scans whatever the flags say: ~ (m + k) columns per read end and strand
+                return 0.05 * s.full * (double)__builtin_popcount(mode & (BB_FILT_FWD_BEGIN_ALWAYS | BB_FILT_RC_BEGIN_ALWAYS | BB_FILT_END_ALWAYS));
+            };
+            const double pass = wide ? 0.80 : 0.43;
+            const double t_sep = 2.0 * pass + 1.3 * (cost(sa, A.filt_off) * sa.full + cost(sb, B.filt_off) * sb.full) + ends(sa, (uint32_t)A.filt_mode) + ends(sb, (uint32_t)B.filt_mode);
+            double best = t_sep;
+            int best_ua = -1, best_ub = -1;
+            for (int ua = a_fixed ? A.filt_off : 1; ua + R <= sa.m && (!a_fixed || ua == A.filt_off); ++ua)
+                for (int ub = 1; ub + R <= sb.m; ++ub) {
+                    bool same = true;
+                    for (int i = 0; i < R && same; ++i) same = bb_text_code((uint8_t)fb[ub + i]) == bb_comp_code(bb_text_code((uint8_t)fa[ua + R - 1 - i]));
+                    if (!same) continue;
+                    const uint32_t ma = filt_mode_of(pol, alpha, sa.m, sa.k, R, ua, wide), mb = filt_mode_of(pol, alpha, sb.m, sb.k, R, ub, wide);
+                    if ((ma | mb) & (BB_FILT_TRUE_INIT | BB_FILT_RC_BEGIN_HINT)) continue;
+                    const double tt = pass + 1.3 * (cost(sa, ua) * sa.full + cost(sb, ub) * sb.full) + ends(sa, ma) + ends(sb, mb);
+                    if (tt < best) { best = tt; best_ua = ua; best_ub = ub; }
+                }
+            if (best_ua < 0) continue;
+            if (getenv("BARBELL_AMD_VERBOSE"))
+                fprintf(stderr, "barbell_amd: groups %zu and %zu: windows at rows %d and %d (their own choices: %d and %d) are each other's reverse complement: one filter pass "
+                        "for both (cost %.2f against %.2f)\n", a, b, best_ua, best_ub, A.filt_off, B.filt_off, best, t_sep);
+            A.filt_off = best_ua; A.filt_mode = (int32_t)filt_mode_of(pol, alpha, sa.m, sa.k, R, best_ua, wide);
+            B.filt_off = best_ub; B.filt_mode = (int32_t)filt_mode_of(pol, alpha, sb.m, sb.k, R, best_ub, wide);
+            c->filt_twin[b] = (int8_t)a;
         }
     }
     c->counts_len = count_off;
@@ -512,6 +575,8 @@ int bb_create_policy(const bb_group_desc* groups, uint32_t n_groups, const bb_pa
     }
     if (const char* e = getenv("BARBELL_AMD_DEFER_MAX")) c->defer_max = (uint32_t)strtoul(e, nullptr, 10);
     if (const char* e = getenv("BARBELL_AMD_SMALL_PFX_MAX")) c->small_pfx_max = (uint32_t)strtoul(e, nullptr, 10);
+    memset(c->filt_twin, -1, sizeof(c->filt_twin)); memset(c->last_twin, -1, sizeof(c->last_twin));
+    if (const char* e = getenv("BARBELL_AMD_FILTER_TWINS")) c->use_twins = atoi(e) != 0;
     if (const char* e = getenv("BARBELL_AMD_SMALL_SEG_MAX")) c->small_seg_max = (uint32_t)strtoul(e, nullptr, 10);
     if (const char* e = getenv("BARBELL_AMD_HOST_LEN_MAX")) c->host_len_max = (uint32_t)strtoul(e, nullptr, 10);
     c->phases = getenv("BARBELL_AMD_PHASES") && atoi(getenv("BARBELL_AMD_PHASES")) != 0;
@@ -1107,6 +1172,12 @@ int bb_last_scan_stats(const bb_ctx* c, uint32_t g, uint64_t* flagged_pieces, ui
     if (flagged_pieces) *flagged_pieces = c->last_flagged[g];
     if (total_pieces) *total_pieces = c->last_pieces[g];
     if (kind) *kind = c->last_scan_kind[g];
+    return BB_OK;
+}
+int bb_filter_twin(const bb_ctx* c, uint32_t g, int* twin_of, int* shared) {
+    if (!c || g >= c->groups.size()) return BB_E_INVALID;
+    if (twin_of) *twin_of = c->filt_twin[g];
+    if (shared) *shared = c->last_twin[g] >= 0 ? 1 : 0;
     return BB_OK;
 }
 int bb_last_length_stats(const bb_ctx* c, uint32_t* min_lines, uint32_t* max_lines, uint32_t* work_items) {

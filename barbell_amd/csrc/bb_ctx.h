@@ -88,6 +88,12 @@ struct bb_ctx {
     double adapt_frac = 0.13;    // BARBELL_AMD_ADAPT_FRAC: flagged fraction of a batch's pieces above which the full scan takes over
     uint64_t last_flagged[BB_MAX_GROUPS]{}, last_pieces[BB_MAX_GROUPS]{};
     uint8_t last_scan_kind[BB_MAX_GROUPS]{};  // 0 full scan, 1 filter + verification, 2 filter, then the full scan (too many flags), 3 full scan while backed off
+    // TWIN filter windows (round 6): the right-hand pattern of a dual-end kit is (nearly) the reverse complement of the left-hand one — its filter
+    // window on the forward strand is then, row for row, the left-hand window's rc block and vice versa, and its flags are the other group's with the
+    // strands swapped.  filt_twin[g] = the group whose filter pass says it all for g (upload_tables: g's window is laid where it mirrors that
+    // group's), -1 otherwise; last_twin[g] = the group whose pass g's verification read in the batch in hand (both filtered there), -1: its own.
+    int8_t filt_twin[BB_MAX_GROUPS], last_twin[BB_MAX_GROUPS];
+    bool use_twins = true;   // BARBELL_AMD_FILTER_TWINS=0: every filtered group runs its own pass (tests; the windows stay where they are)
     uint8_t scan_off[BB_MAX_GROUPS]{};        // batches for which the group goes straight to the full scan (set to 16 by a batch of kind 2: its filter pass was wasted)
     uint32_t* d_flags = nullptr; uint64_t cap_flags = 0;  // filtered scan: one bit per 32 text bytes and strand (k_flank_filter)
     // reads of differing lengths (bb_len.h): the batch's segments by falling length, or null for a batch of (nearly) equal reads

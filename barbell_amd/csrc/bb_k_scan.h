@@ -1010,7 +1010,7 @@ __global__ __launch_bounds__(256, W <= 4 ? BB_VERIFY_MINBLOCKS : 1) void k_flank
                                                       const uint8_t* __restrict__ tables, const bb_group_dev* __restrict__ groups, uint32_t g,
                                                       uint32_t n_groups, const uint32_t* __restrict__ flags, uint64_t words_per_strand,
                                                       uint32_t* __restrict__ cnt, bb_hit_raw* __restrict__ hits, uint32_t hit_cap,
-                                                      uint32_t* __restrict__ hit_count, uint32_t* __restrict__ queues) {
+                                                      uint32_t* __restrict__ hit_count, uint32_t* __restrict__ queues, uint32_t swap_strands) {
     constexpr int S = (W <= 2 ? 2 : (W <= 4 ? 4 : 8));
     __shared__ __attribute__((aligned(16))) uint32_t s_peq[256 * S];
     __shared__ __attribute__((aligned(16))) bb_hit_raw s_stage[4][BB_VERIFY_STAGE];
@@ -1023,10 +1023,12 @@ __global__ __launch_bounds__(256, W <= 4 ? BB_VERIFY_MINBLOCKS : 1) void k_flank
     }
     __syncthreads();
     bb_hit_raw* stage = s_stage[threadIdx.x >> 6];
+    // swap_strands: the flags are a TWIN group's (bb_ctx::filt_twin) — its rc block is this group's forward window and the other way round
+    const uint32_t* fls = flags + ((strand ^ swap_strands) ? words_per_strand : 0ull);
     if (strand == 0)
-        flank_verify_lane<W, 0>(bases, offsets, n_reads, tables, G, g, n_groups, flags, cnt, hits, hit_cap, hit_count, queues, s_peq, stage, s_flws[threadIdx.x >> 6]);
+        flank_verify_lane<W, 0>(bases, offsets, n_reads, tables, G, g, n_groups, fls, cnt, hits, hit_cap, hit_count, queues, s_peq, stage, s_flws[threadIdx.x >> 6]);
     else
-        flank_verify_lane<W, 1>(bases, offsets, n_reads, tables, G, g, n_groups, flags + words_per_strand, cnt, hits, hit_cap, hit_count, queues + 1, s_peq, stage, s_flws[threadIdx.x >> 6]);
+        flank_verify_lane<W, 1>(bases, offsets, n_reads, tables, G, g, n_groups, fls, cnt, hits, hit_cap, hit_count, queues + 1, s_peq, stage, s_flws[threadIdx.x >> 6]);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -56,11 +56,11 @@ void launch_scan2_w(bb_ctx* c, int W, const uint8_t* d_bases, const uint64_t* d_
     }
 }
 template <int W>
-void launch_verify(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n, uint32_t g, const uint32_t* flags, uint64_t flag_words) {
+void launch_verify(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n, uint32_t g, const uint32_t* flags, uint64_t flag_words, bool swap) {
     const uint32_t vblocks = std::min((n + 255u) / 256u, (uint32_t)c->n_cus * 3u);  // persistent: lanes draw (read, strand) items from a queue
     hipLaunchKernelGGL(k_flank_verify<W>, dim3(vblocks, 2), dim3(256), 0, c->stream, d_bases, d_offsets, n,
                        (const uint8_t*)c->d_tables, (const bb_group_dev*)c->d_groups, g, (uint32_t)c->groups.size(),
-                       flags, flag_words, c->d_cnt, c->d_raw, c->cap_hits, c->d_hitcount, c->d_vqueue + 2u * g);   // (the queue counters of every group were zeroed with the batch's control block)
+                       flags, flag_words, c->d_cnt, c->d_raw, c->cap_hits, c->d_hitcount, c->d_vqueue + 2u * g, swap ? 1u : 0u);   // (the queue counters of every group were zeroed with the batch's control block)
 }
 }  // namespace
 
@@ -141,17 +141,26 @@ int bb_launch_scans(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets
         } else if (c->gdev[g].filt_rows > 0) filt[(c->gdev[g].filt_mode & BB_FILT_WIDE) ? 1 : 0].push_back(g);
         else plain[W].push_back(g);
     }
-    // flag regions: one per filtered group, in launch order (narrow windows first)
+    // flag regions: one per filter pass, in launch order (narrow windows first).  A group whose window mirrors another filtered group's
+    // (bb_ctx::filt_twin) has no pass of its own: its verification reads the other group's flags with the strands swapped.
     std::vector<uint32_t> region(G, 0);
     const uint32_t n_filt = (uint32_t)(filt[0].size() + filt[1].size());
+    std::vector<uint32_t> pass[2];
+    for (uint32_t g = 0; g < G; ++g) c->last_twin[g] = -1;
+    for (int wide = 0; wide < 2; ++wide)
+        for (uint32_t g : filt[wide]) {
+            const int a = c->filt_twin[g];
+            if (a >= 0 && c->use_twins && std::find(filt[wide].begin(), filt[wide].end(), (uint32_t)a) != filt[wide].end()) c->last_twin[g] = (int8_t)a;
+            else pass[wide].push_back(g);
+        }
     if (n_filt) {
         // (the flag words — the filter writes the ones that hold a flag — and the flag counters were zeroed with the batch's control block: bb_zero_ctl)
         uint32_t reg = 0;
         for (int wide = 0; wide < 2; ++wide)
-            for (size_t at = 0; at < filt[wide].size(); at += sizeof(bb_glist::g)) {
+            for (size_t at = 0; at < pass[wide].size(); at += sizeof(bb_glist::g)) {
                 bb_glist gl{};
-                gl.n = (uint32_t)std::min(filt[wide].size() - at, sizeof(bb_glist::g));
-                for (uint32_t i = 0; i < gl.n; ++i) { gl.g[i] = (uint8_t)filt[wide][at + i]; region[filt[wide][at + i]] = reg + i; }
+                gl.n = (uint32_t)std::min(pass[wide].size() - at, sizeof(bb_glist::g));
+                for (uint32_t i = 0; i < gl.n; ++i) { gl.g[i] = (uint8_t)pass[wide][at + i]; region[pass[wide][at + i]] = reg + i; }
                 uint32_t* fl = c->d_flags + (uint64_t)reg * 2ull * flag_words;
                 const dim3 grid(bb_coscheduled_blocks(gl.n, 1u, ((c->vtab ? c->n_virtual : n) + 255u) / 256u));   // a lane per read, or per segment (bb_len.h)
                 if (wide)
@@ -162,6 +171,7 @@ int bb_launch_scans(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets
                                        (const bb_group_dev*)c->d_groups, gl, fl, flag_words, c->d_nflag, c->vtab, c->n_virtual, c->batch_seg_lines, c->batch_split_above);
                 reg += gl.n;
             }
+        for (uint32_t g = 0; g < G; ++g) if (c->last_twin[g] >= 0) region[g] = region[(uint32_t)c->last_twin[g]];
     }
     for (int W = 1; W <= 8; ++W) launch_scan2_w(c, W, d_bases, d_offsets, n, plain[W]);
     if (n_filt) {
@@ -173,10 +183,12 @@ int bb_launch_scans(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets
         if (!deferred) {
             HIPCHK(c, hipMemcpyAsync(nf, c->d_nflag, sizeof(nf), hipMemcpyDeviceToHost, c->stream));  // a failure must not be read as "no flags"
             BB_SYNC(c, c->stream);
+            for (uint32_t g = 0; g < G; ++g) if (c->last_twin[g] >= 0) nf[g] = nf[(uint32_t)c->last_twin[g]];   // (the same pieces, the strands swapped)
         }
         for (int wide = 0; wide < 2; ++wide)
             for (uint32_t g : filt[wide]) {
                 const int W = std::min(8, std::max(1, (int)c->gdev[g].W));
+                const bool swap = c->last_twin[g] >= 0;
                 c->last_flagged[g] = nf[g]; c->last_scan_kind[g] = 1;
                 if (!deferred && c->scan_filter != 1 && (double)nf[g] > c->adapt_frac * (double)c->last_pieces[g]) {
                     c->last_scan_kind[g] = 2;
@@ -186,14 +198,14 @@ int bb_launch_scans(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets
                 }
                 const uint32_t* fl = c->d_flags + (uint64_t)region[g] * 2ull * flag_words;
                 switch (W) {
-                    case 1: launch_verify<1>(c, d_bases, d_offsets, n, g, fl, flag_words); break;
-                    case 2: launch_verify<2>(c, d_bases, d_offsets, n, g, fl, flag_words); break;
-                    case 3: launch_verify<3>(c, d_bases, d_offsets, n, g, fl, flag_words); break;
-                    case 4: launch_verify<4>(c, d_bases, d_offsets, n, g, fl, flag_words); break;
-                    case 5: launch_verify<5>(c, d_bases, d_offsets, n, g, fl, flag_words); break;
-                    case 6: launch_verify<6>(c, d_bases, d_offsets, n, g, fl, flag_words); break;
-                    case 7: launch_verify<7>(c, d_bases, d_offsets, n, g, fl, flag_words); break;
-                    default: launch_verify<8>(c, d_bases, d_offsets, n, g, fl, flag_words); break;
+                    case 1: launch_verify<1>(c, d_bases, d_offsets, n, g, fl, flag_words, swap); break;
+                    case 2: launch_verify<2>(c, d_bases, d_offsets, n, g, fl, flag_words, swap); break;
+                    case 3: launch_verify<3>(c, d_bases, d_offsets, n, g, fl, flag_words, swap); break;
+                    case 4: launch_verify<4>(c, d_bases, d_offsets, n, g, fl, flag_words, swap); break;
+                    case 5: launch_verify<5>(c, d_bases, d_offsets, n, g, fl, flag_words, swap); break;
+                    case 6: launch_verify<6>(c, d_bases, d_offsets, n, g, fl, flag_words, swap); break;
+                    case 7: launch_verify<7>(c, d_bases, d_offsets, n, g, fl, flag_words, swap); break;
+                    default: launch_verify<8>(c, d_bases, d_offsets, n, g, fl, flag_words, swap); break;
                 }
             }
         for (int W = 1; W <= 8; ++W) launch_scan2_w(c, W, d_bases, d_offsets, n, plain2[W]);
@@ -216,7 +228,8 @@ int bb_launch_scans(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets
 void bb_note_flag_counts(bb_ctx* c, const unsigned long long* nf) {
     for (uint32_t g = 0; g < c->groups.size(); ++g) {
         if (c->last_scan_kind[g] != 1) continue;
-        c->last_flagged[g] = nf[g];
-        if (c->scan_filter != 1 && (double)nf[g] > c->adapt_frac * (double)c->last_pieces[g]) c->scan_off[g] = 16;
+        const unsigned long long f = nf[c->last_twin[g] >= 0 ? (uint32_t)c->last_twin[g] : g];   // (a twin's flags are the other group's)
+        c->last_flagged[g] = f;
+        if (c->scan_filter != 1 && (double)f > c->adapt_frac * (double)c->last_pieces[g]) c->scan_off[g] = 16;
     }
 }

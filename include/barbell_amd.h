@@ -185,6 +185,13 @@ int         bb_last_dominant_kernel(const bb_ctx* ctx, char* name, size_t name_c
  * synthetic benchmark's.                                                                                                  */
 int bb_last_scan_stats(const bb_ctx* ctx, uint32_t group, uint64_t* flagged_pieces, uint64_t* total_pieces, int* kind);
 
+/* Twin filter windows.  The right-hand query group of a dual-end kit is (give or take a few bases at the ends) the reverse complement of
+ * the left-hand one: searching group B on the forward strand and group A on the reverse-complement strand look at the same text for the
+ * same rows.  Where bb_finalize finds R rows of B's flank that are A's filter window reverse-complemented, it lays B's window there, and a
+ * batch in which both groups take the filter pass runs ONE pass for the two (B's verification reads A's flags with the strands swapped).
+ * *twin_of = that group A or -1; *shared = 1 if the last batch's scan of `group` read its twin's flags.  Results do not depend on it.   */
+int bb_filter_twin(const bb_ctx* ctx, uint32_t group, int* twin_of, int* shared);
+
 /* The read lengths of the last batch as the scans saw them: the shortest and the longest read in 128-byte lines, and the number of work
  * items the scans' lanes drew — the number of reads for a batch of (nearly) equal reads (lanes take reads in file order), otherwise the
  * number of SEGMENTS: reads of more than 64 lines are cut into segments of 32 for the filter pass and lanes take segments / reads by

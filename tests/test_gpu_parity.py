@@ -837,6 +837,78 @@ def test_scan_backs_off_after_an_over_flagged_batch(monkeypatch, batching):
     dm.close()
 
 
+def _dual_ragged(groups, seed):
+    """reads of 30..4000 nt plus reads that begin / end inside a construct (matches hanging over a read end by a few rows: the windows of a
+    twinned pair sit in the middle of their flanks and no read end is verified unless a flag lies near it) and bare pieces of constructs"""
+    b1, o1 = A_synth(groups, seed, 30, 4000, 700)
+    reads = [b1[int(o1[i]):int(o1[i + 1])].tobytes() for i in range(len(o1) - 1)]
+    rng = np.random.default_rng(seed)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    for i in range(400):
+        g = groups[i & 1]
+        q = g.seqs[int(rng.integers(0, len(g.seqs)))]
+        q = q.encode() if isinstance(q, str) else bytes(q)
+        if i & 2: q = q.translate(comp)[::-1]
+        body = bytes(rng.choice(acgt, int(rng.integers(0, 500))))
+        cut = int(rng.integers(1, 14))
+        reads.append([q[cut:] + body, body + q[:len(q) - cut], q[cut:len(q) - cut], body[:40] + q + body[40:] + q[cut:]][(i >> 2) & 3])
+    order = rng.permutation(len(reads))
+    return _abi.pack_reads([reads[int(i)] for i in order])
+
+
+def test_twin_filter_windows(monkeypatch, batching):
+    """The custom dual-end set (BASELINE configs[3]): the right-hand flank is the left-hand one's reverse complement minus a few bases, so
+    bb_finalize lays the two groups' filter windows where they mirror each other and a batch runs ONE filter pass for both — the right-hand
+    group's verification reads the left-hand group's flags with the strands swapped (include/barbell_amd.h: bb_filter_twin).  Same rows as
+    the checker's and as with a pass per group (BARBELL_AMD_FILTER_TWINS=0: the mirrored windows, two passes) and with each group's own
+    window (BARBELL_AMD_NO_TWIN_WINDOWS=1); the flag counts of the two groups are one number; after an over-flagged batch both groups back
+    off together and come back together; a kit whose groups are not each other's reverse complement has no twins."""
+    from oracle import pyoracle as po
+
+    groups = config_groups("dual")
+    bases, offsets = _dual_ragged(groups, 31)
+    dm, got, want = run_both(groups, bases, offsets)
+    assert len(want) > 1200
+    assert_same(got, want)
+    assert dm.filter_twin(0) == (-1, False) and dm.filter_twin(1) == (0, True)
+    s0, s1 = dm.scan_stats(0), dm.scan_stats(1)
+    assert s0["kind"] == 1 and s1["kind"] == 1 and s0["flagged_pieces"] == s1["flagged_pieces"] > 0
+    hb, ho = A_synth(groups, 5, 4000, 4000, 1500)
+    want_h = po.Oracle([g.as_tuple() for g in groups]).annotate(hb, ho, n_threads=NT)
+    assert_same(dm.demux_packed(hb, ho), want_h)
+    assert_same(dm.demux_nibbles(bases, offsets), want)
+    dm.close()
+    for var in ("BARBELL_AMD_FILTER_TWINS", "BARBELL_AMD_NO_TWIN_WINDOWS"):
+        monkeypatch.setenv(var, "0" if var.endswith("TWINS") else "1")
+        dm, got, _ = run_both(groups, bases, offsets)
+        assert_same(got, want)
+        assert dm.filter_twin(1) == ((0, False) if var.endswith("TWINS") else (-1, False))
+        if var.endswith("TWINS"):
+            assert dm.scan_stats(0)["flagged_pieces"] == dm.scan_stats(1)["flagged_pieces"] == s0["flagged_pieces"]   # (the same pieces, the strands swapped)
+        dm.close()
+        monkeypatch.delenv(var)
+    # both groups back off together (any flag is too many) and are probed again together
+    monkeypatch.setenv("BARBELL_AMD_ADAPT_FRAC", "0")
+    dm, got, _ = run_both(groups, bases, offsets)
+    assert_same(got, want)
+    probe_kind = 2 if batching == "classic" else 1
+    assert [dm.scan_stats(g)["kind"] for g in (0, 1)] == [probe_kind] * 2
+    kinds = []
+    for _ in range(17):
+        assert_same(dm.demux_packed(bases, offsets), want)
+        kinds.append((dm.scan_stats(0)["kind"], dm.scan_stats(1)["kind"], dm.filter_twin(1)[1]))
+    assert kinds == [(3, 3, False)] * 16 + [(probe_kind, probe_kind, True)]
+    dm.close()
+    monkeypatch.delenv("BARBELL_AMD_ADAPT_FRAC")
+    # other kits: no twins
+    for cfg in ("nbd96", "rbk96x", "rbk24"):
+        g2 = config_groups(cfg)
+        dm = A_demuxer(g2)
+        assert all(dm.filter_twin(g) == (-1, False) for g in range(len(g2)))
+        dm.close()
+
+
 def test_small_batches_run_deferred(monkeypatch):
     """What the boundary's small-batch treatment promises (include/barbell_amd.h, bb_last_host_syncs): one wait of the host per call up to
     bb_ctx::defer_max reads, the classic number of round trips beyond it, the same rows either way and whatever the thresholds."""
@@ -915,6 +987,15 @@ def test_deferred_batch_grows_its_hit_buffers():
     assert_same(dm.demux_packed(bases, offsets), want)
     assert int(dm.counts().sum()) == 2 * len(got)
     dm.close()
+
+
+def A_demuxer(groups, **kw):
+    from barbell_amd import annotate as A
+
+    dm = A.Demuxer(**kw)
+    for g in groups:
+        dm.add_query_group(g)
+    return dm
 
 
 def A_synth(groups, seed, lmin, lmax, n):
