@@ -249,11 +249,11 @@ class Demuxer:
         return {"flagged_pieces": f.value, "total_pieces": t.value, "kind": k.value}
 
     def filter_twin(self, g=0):
-        """(the group whose filter pass says it all for group g — its window reverse-complemented is g's — or -1, whether g's scan of the last batch
-        read that group's flags): bb_filter_twin"""
+        """(the group whose filter pass says it all for group g — its window is g's, reverse-complemented or as it is — or -1; how g's scan of the
+        last batch used it: 0 not, 1 that group's flags with the strands swapped, 2 as they are): bb_filter_twin"""
         a, sh = C.c_int(), C.c_int()
         self._check(lib().bb_filter_twin(self._ctx(), g, C.byref(a), C.byref(sh)))
-        return a.value, bool(sh.value)
+        return a.value, sh.value
 
     def host_syncs(self):
         """how often the host waited for the device inside the last batch call (bb_last_host_syncs)"""

@@ -362,20 +362,28 @@ int upload_tables(bb_ctx* c) {
             const double t_sep = 2.0 * pass + 1.3 * (cost(sa, A.filt_off) * sa.full + cost(sb, B.filt_off) * sb.full) + ends(sa, (uint32_t)A.filt_mode) + ends(sb, (uint32_t)B.filt_mode);
             double best = t_sep;
             int best_ua = -1, best_ub = -1;
+            bool best_swap = false;
+            // (two relations: B's rows are A's read backwards and complemented — the two ends of a dual-end kit: strands swapped — or the very same rows:
+            // groups of one kit that share most of their flank, e.g. the two of SQK-RBK114-96 --use-extended, which differ in their first 16 nt)
             for (int ua = a_fixed ? A.filt_off : 1; ua + R <= sa.m && (!a_fixed || ua == A.filt_off); ++ua)
                 for (int ub = 1; ub + R <= sb.m; ++ub) {
-                    bool same = true;
-                    for (int i = 0; i < R && same; ++i) same = bb_text_code((uint8_t)fb[ub + i]) == bb_comp_code(bb_text_code((uint8_t)fa[ua + R - 1 - i]));
-                    if (!same) continue;
+                    bool mirror = true, same = true;
+                    for (int i = 0; i < R && (mirror || same); ++i) {
+                        const uint8_t cb = bb_text_code((uint8_t)fb[ub + i]);
+                        mirror = mirror && cb == bb_comp_code(bb_text_code((uint8_t)fa[ua + R - 1 - i]));
+                        same = same && cb == bb_text_code((uint8_t)fa[ua + i]);
+                    }
+                    if (!mirror && !same) continue;
                     const uint32_t ma = filt_mode_of(pol, alpha, sa.m, sa.k, R, ua, wide), mb = filt_mode_of(pol, alpha, sb.m, sb.k, R, ub, wide);
                     if ((ma | mb) & (BB_FILT_TRUE_INIT | BB_FILT_RC_BEGIN_HINT)) continue;
                     const double tt = pass + 1.3 * (cost(sa, ua) * sa.full + cost(sb, ub) * sb.full) + ends(sa, ma) + ends(sb, mb);
-                    if (tt < best) { best = tt; best_ua = ua; best_ub = ub; }
+                    if (tt < best) { best = tt; best_ua = ua; best_ub = ub; best_swap = !same; }
                 }
             if (best_ua < 0) continue;
+            c->filt_twin_swap[b] = best_swap;
             if (getenv("BARBELL_AMD_VERBOSE"))
-                fprintf(stderr, "barbell_amd: groups %zu and %zu: windows at rows %d and %d (their own choices: %d and %d) are each other's reverse complement: one filter pass "
-                        "for both (cost %.2f against %.2f)\n", a, b, best_ua, best_ub, A.filt_off, B.filt_off, best, t_sep);
+                fprintf(stderr, "barbell_amd: groups %zu and %zu: windows at rows %d and %d (their own choices: %d and %d) are %s: one filter pass "
+                        "for both (cost %.2f against %.2f)\n", a, b, best_ua, best_ub, A.filt_off, B.filt_off, best_swap ? "each other's reverse complement" : "the same rows", best, t_sep);
             A.filt_off = best_ua; A.filt_mode = (int32_t)filt_mode_of(pol, alpha, sa.m, sa.k, R, best_ua, wide);
             B.filt_off = best_ub; B.filt_mode = (int32_t)filt_mode_of(pol, alpha, sb.m, sb.k, R, best_ub, wide);
             c->filt_twin[b] = (int8_t)a;
@@ -1177,7 +1185,7 @@ int bb_last_scan_stats(const bb_ctx* c, uint32_t g, uint64_t* flagged_pieces, ui
 int bb_filter_twin(const bb_ctx* c, uint32_t g, int* twin_of, int* shared) {
     if (!c || g >= c->groups.size()) return BB_E_INVALID;
     if (twin_of) *twin_of = c->filt_twin[g];
-    if (shared) *shared = c->last_twin[g] >= 0 ? 1 : 0;
+    if (shared) *shared = c->last_twin[g] >= 0 ? (c->filt_twin_swap[g] ? 1 : 2) : 0;
     return BB_OK;
 }
 int bb_last_length_stats(const bb_ctx* c, uint32_t* min_lines, uint32_t* max_lines, uint32_t* work_items) {

@@ -93,6 +93,7 @@ struct bb_ctx {
     // strands swapped.  filt_twin[g] = the group whose filter pass says it all for g (upload_tables: g's window is laid where it mirrors that
     // group's), -1 otherwise; last_twin[g] = the group whose pass g's verification read in the batch in hand (both filtered there), -1: its own.
     int8_t filt_twin[BB_MAX_GROUPS], last_twin[BB_MAX_GROUPS];
+    bool filt_twin_swap[BB_MAX_GROUPS]{};   // the twin's window is g's reverse-complemented (strands swapped) / the very same rows (two groups of a kit that share most of their flank)
     bool use_twins = true;   // BARBELL_AMD_FILTER_TWINS=0: every filtered group runs its own pass (tests; the windows stay where they are)
     uint8_t scan_off[BB_MAX_GROUPS]{};        // batches for which the group goes straight to the full scan (set to 16 by a batch of kind 2: its filter pass was wasted)
     uint32_t* d_flags = nullptr; uint64_t cap_flags = 0;  // filtered scan: one bit per 32 text bytes and strand (k_flank_filter)

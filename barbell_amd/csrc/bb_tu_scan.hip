@@ -188,7 +188,7 @@ int bb_launch_scans(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets
         for (int wide = 0; wide < 2; ++wide)
             for (uint32_t g : filt[wide]) {
                 const int W = std::min(8, std::max(1, (int)c->gdev[g].W));
-                const bool swap = c->last_twin[g] >= 0;
+                const bool swap = c->last_twin[g] >= 0 && c->filt_twin_swap[g];
                 c->last_flagged[g] = nf[g]; c->last_scan_kind[g] = 1;
                 if (!deferred && c->scan_filter != 1 && (double)nf[g] > c->adapt_frac * (double)c->last_pieces[g]) {
                     c->last_scan_kind[g] = 2;

@@ -189,7 +189,10 @@ int bb_last_scan_stats(const bb_ctx* ctx, uint32_t group, uint64_t* flagged_piec
  * the left-hand one: searching group B on the forward strand and group A on the reverse-complement strand look at the same text for the
  * same rows.  Where bb_finalize finds R rows of B's flank that are A's filter window reverse-complemented, it lays B's window there, and a
  * batch in which both groups take the filter pass runs ONE pass for the two (B's verification reads A's flags with the strands swapped).
- * *twin_of = that group A or -1; *shared = 1 if the last batch's scan of `group` read its twin's flags.  Results do not depend on it.   */
+ * The same holds, without the swap, for groups of one kit that share most of their flank (SQK-RBK114-96 --use-extended: two groups that
+ * differ in their first 16 nt) when their windows can lie on the same rows.
+ * *twin_of = that group A or -1; *shared = 1 if the last batch's scan of `group` read its twin's flags with the strands swapped, 2 if as
+ * they are, 0 if the group ran its own pass (or none).  Results do not depend on it.                                                  */
 int bb_filter_twin(const bb_ctx* ctx, uint32_t group, int* twin_of, int* shared);
 
 /* The read lengths of the last batch as the scans saw them: the shortest and the longest read in 128-byte lines, and the number of work

@@ -871,7 +871,7 @@ def test_twin_filter_windows(monkeypatch, batching):
     dm, got, want = run_both(groups, bases, offsets)
     assert len(want) > 1200
     assert_same(got, want)
-    assert dm.filter_twin(0) == (-1, False) and dm.filter_twin(1) == (0, True)
+    assert dm.filter_twin(0) == (-1, 0) and dm.filter_twin(1) == (0, 1)
     s0, s1 = dm.scan_stats(0), dm.scan_stats(1)
     assert s0["kind"] == 1 and s1["kind"] == 1 and s0["flagged_pieces"] == s1["flagged_pieces"] > 0
     hb, ho = A_synth(groups, 5, 4000, 4000, 1500)
@@ -883,7 +883,7 @@ def test_twin_filter_windows(monkeypatch, batching):
         monkeypatch.setenv(var, "0" if var.endswith("TWINS") else "1")
         dm, got, _ = run_both(groups, bases, offsets)
         assert_same(got, want)
-        assert dm.filter_twin(1) == ((0, False) if var.endswith("TWINS") else (-1, False))
+        assert dm.filter_twin(1) == ((0, 0) if var.endswith("TWINS") else (-1, 0))
         if var.endswith("TWINS"):
             assert dm.scan_stats(0)["flagged_pieces"] == dm.scan_stats(1)["flagged_pieces"] == s0["flagged_pieces"]   # (the same pieces, the strands swapped)
         dm.close()
@@ -898,14 +898,31 @@ def test_twin_filter_windows(monkeypatch, batching):
     for _ in range(17):
         assert_same(dm.demux_packed(bases, offsets), want)
         kinds.append((dm.scan_stats(0)["kind"], dm.scan_stats(1)["kind"], dm.filter_twin(1)[1]))
-    assert kinds == [(3, 3, False)] * 16 + [(probe_kind, probe_kind, True)]
+    assert kinds == [(3, 3, 0)] * 16 + [(probe_kind, probe_kind, 1)]
     dm.close()
     monkeypatch.delenv("BARBELL_AMD_ADAPT_FRAC")
+    # two groups of one kit that share most of their flank (SQK-RBK114-96 --use-extended: they differ in their first 16 nt), filtered at k = 5:
+    # windows on the same rows, one pass, no swap
+    from barbell_amd import kits
+
+    g3 = kits.groups_from_kit("SQK-RBK114-96", use_extended=True, flank_max_errors=5)
+    b3, o3 = A_synth(g3, 8, 100, 3000, 800)
+    dm, got, want3 = run_both(g3, b3, o3)
+    assert len(want3) > 500
+    assert_same(got, want3)
+    assert dm.filter_twin(1) == (0, 2) and dm.scan_stats(0)["kind"] == 1
+    dm.close()
+    monkeypatch.setenv("BARBELL_AMD_FILTER_TWINS", "0")
+    dm, got, _ = run_both(g3, b3, o3)
+    assert_same(got, want3)
+    assert dm.filter_twin(1) == (0, 0)
+    dm.close()
+    monkeypatch.delenv("BARBELL_AMD_FILTER_TWINS")
     # other kits: no twins
     for cfg in ("nbd96", "rbk96x", "rbk24"):
         g2 = config_groups(cfg)
         dm = A_demuxer(g2)
-        assert all(dm.filter_twin(g) == (-1, False) for g in range(len(g2)))
+        assert all(dm.filter_twin(g) == (-1, 0) for g in range(len(g2)))
         dm.close()
 
 
