@@ -589,6 +589,7 @@ int bb_create_policy(const bb_group_desc* groups, uint32_t n_groups, const bb_pa
     if (const char* e = getenv("BARBELL_AMD_HOST_LEN_MAX")) c->host_len_max = (uint32_t)strtoul(e, nullptr, 10);
     c->phases = getenv("BARBELL_AMD_PHASES") && atoi(getenv("BARBELL_AMD_PHASES")) != 0;
     if (const char* e = getenv("BARBELL_AMD_LANE_FB_FRAC")) c->lane_fb_frac = atof(e);
+    if (const char* e = getenv("BARBELL_AMD_LANE_PFX_GAIN")) c->lane_pfx_gain = atof(e);
     if (const char* e = getenv("BARBELL_AMD_LANE")) c->lane_kernel = std::max(0, std::min(2, atoi(e)));
     if (const char* e = getenv("BARBELL_AMD_LANE_NM")) c->lane_nm = atoi(e) != 0;
     if (getenv("BARBELL_AMD_PFX_THREADS")) { int t = atoi(getenv("BARBELL_AMD_PFX_THREADS")); if (t >= 64 && t <= 768) c->pfx_threads = (uint32_t)t; }
@@ -837,12 +838,21 @@ int bb_annotate_batch_dev(bb_ctx* c, const uint8_t* d_bases, const uint64_t* d_o
     const bool fb_stats = c->fast_path && c->lane_kernel == 1;
     for (uint32_t g = 0; g < G; ++g)
         for (uint32_t sd = 0; sd < 2; ++sd) {
+            const bool probing = c->lane_off[g][sd] != 0;   // this batch ran k_barcode_pfx because the lane kernel had left too much undecided
             if (c->lane_off[g][sd]) --c->lane_off[g][sd];
+            if (c->lane_noback[g][sd]) --c->lane_noback[g][sd];
             if (fb_stats) {
                 const uint32_t *h_listed = c->h_ctl->listcnt, *h_undecided = c->h_ctl->fbcnt;
                 const uint64_t listed = (uint64_t)h_listed[4 * g + sd] + h_listed[4 * g + 2 + sd], und = (uint64_t)h_undecided[4 * g + sd] + h_undecided[4 * g + 2 + sd];
                 c->last_listed[g][sd] = listed; c->last_undecided[g][sd] = und;
-                if (c->lane_used[g][sd] && listed >= 1024 && (double)und > c->lane_fb_frac * (double)listed) c->lane_off[g][sd] = 32;
+                if (c->lane_used[g][sd] && listed >= 1024 && (double)und > c->lane_fb_frac * (double)listed && !c->lane_noback[g][sd]) {
+                    c->lane_off[g][sd] = 32;
+                    c->lane_und_frac[g][sd] = (float)((double)und / (double)listed);
+                } else if (probing && !c->lane_used[g][sd] && listed >= 1024 &&
+                           (double)c->lane_und_frac[g][sd] - (double)und / (double)listed < c->lane_pfx_gain) {
+                    c->lane_off[g][sd] = 0;      // k_barcode_pfx decided hardly more (bb_ctx::lane_pfx_gain): back to the lane kernel ...
+                    c->lane_noback[g][sd] = 64;  // ... for the next 64 batches whatever it leaves undecided
+                }
             }
             c->lane_used[g][sd] = 0;
         }

@@ -52,6 +52,13 @@ struct bb_ctx {
     // flank the hit was found with) — on text where they do not, more hits go on to the exact kernel.  Each batch's undecided fraction
     // is read back with the row count; above BARBELL_AMD_LANE_FB_FRAC (0.2) the pair takes k_barcode_pfx for the next 32 batches.
     uint8_t lane_off[BB_MAX_GROUPS][2]{};   // batches left on k_barcode_pfx
+    // ... which pays only if that kernel's bounds (the shared rows walked) decide MUCH more: per hit the lane kernel costs ~3.4 ns, k_barcode_pfx ~6.3 ns,
+    // the exact pass ~10.3 ns (profiles/r05_fallback_bench.txt) — 3.4 + 10.3 u_lane against 6.3 + 10.3 u_pfx.  The first backed-off batch is a probe:
+    // unless it leaves lane_pfx_gain (0.28) of the hits fewer undecided, the pair returns to the lane kernel and stays for 64 batches (round 6: reads
+    // full of near-copies of the flank leave both kernels 39 % undecided, and the back-off cost 19.8 -> 27.5 ms per 1 M reads).
+    float lane_und_frac[BB_MAX_GROUPS][2]{};
+    uint8_t lane_noback[BB_MAX_GROUPS][2]{};
+    double lane_pfx_gain = 0.28;            // BARBELL_AMD_LANE_PFX_GAIN
     uint8_t lane_used[BB_MAX_GROUPS][2]{};  // this batch: the pair ran k_barcode_lane
     double lane_fb_frac = 0.2;
     uint64_t last_listed[BB_MAX_GROUPS][2]{}, last_undecided[BB_MAX_GROUPS][2]{};  // of the last batch (bb_last_barcode_stats)

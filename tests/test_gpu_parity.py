@@ -1067,23 +1067,32 @@ def test_lane_kernel_backs_off_when_its_bound_decides_too_little(monkeypatch):
 
     monkeypatch.setenv("BARBELL_AMD_LANE_FB_FRAC", "0")
     groups = config_groups("nbd96")
-    dm = A.Demuxer()
-    for g in groups:
-        dm.add_query_group(g)
     orc = po.Oracle([g.as_tuple() for g in groups])
-    flipped = False
-    for batch in range(3):
-        _, bases, offsets = noisy_reads("nbd96", 77 + batch, 3000, 300, 1500, rate=0.1)
-        got = dm.demux_packed(bases, offsets)
-        want = orc.annotate(bases, offsets, n_threads=NT)
-        assert_same(got, want)
-        st = [dm.barcode_stats(0, s) for s in (0, 1)]
-        assert all(x["hits"] > 500 for x in st)
-        if batch == 0:
-            assert any(x["undecided"] > 0 for x in st)  # noisy reads: some hits always go on to the exact pass
-        flipped = flipped or any(not x["lane_kernel"] for x in st)
-    assert flipped
-    dm.close()
+    # the first backed-off batch is a probe (round 6): k_barcode_pfx costs a hit twice the lane kernel's time, so the pair stays with it only if it
+    # leaves bb_ctx::lane_pfx_gain of the hits fewer undecided — here it does not (a few per cent either way): back to the lane kernel, and no
+    # back-off for the next 64 batches.  With the gain asked for at -1 the pair stays away for its 32 batches, as through round 5.
+    for gain, expect in ((None, [False, True, True, True]), ("-1", [False, False, False, False])):
+        if gain is not None:
+            monkeypatch.setenv("BARBELL_AMD_LANE_PFX_GAIN", gain)
+        dm = A.Demuxer()
+        for g in groups:
+            dm.add_query_group(g)
+        seen = []
+        for batch in range(4):
+            _, bases, offsets = noisy_reads("nbd96", 77 + batch, 3000, 300, 1500, rate=0.1)
+            got = dm.demux_packed(bases, offsets)
+            want = orc.annotate(bases, offsets, n_threads=NT)
+            assert_same(got, want)
+            st = [dm.barcode_stats(0, s) for s in (0, 1)]
+            assert all(x["hits"] > 500 for x in st)
+            if batch == 0:
+                assert all(x["undecided"] > 0 for x in st)  # noisy reads: some hits always go on to the exact pass
+            seen.append([x["lane_kernel"] for x in st])
+            big = [x["hits"] >= 1024 for x in st]   # (a pair with fewer hits in a batch decides nothing)
+        assert any(big)
+        for sd in (0, 1):
+            assert [b[sd] for b in seen] == (expect if big[sd] else [True] * 4), seen
+        dm.close()
 
 
 def test_windows_of_exactly_64_columns():
