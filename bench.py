@@ -264,7 +264,7 @@ def _pci_bus_id(dev_idx):
         return str(dev_idx)
 
 
-def other_config_leg(cfg, dev_idx, dev, L, args, n=1_000_000, steps=3):
+def other_config_leg(cfg, dev_idx, dev, L, args, n=2_000_000, steps=3):   # (n = BASELINE's step size since round 6: 1 M-read steps ran the same kernels 10-15 % below it)
     """One of the other BASELINE query sets on its own resident reads: `dual` = configs[3] (native_left/right.fasta,
     --flank-max-errors 5, two groups), `rbk96x` = configs[4] made meaningful (SQK-RBK114-96 --use-extended: two groups,
     90-nt flanks, automatic cutoff; --use-extended is a no-op for SQK-NBD114-96).  n reads x L resident, one batch,
