@@ -231,6 +231,10 @@ def main():
         if world == 1 and args.config == "nbd96" and not args.no_other_configs:
             # BASELINE configs[3] / configs[4] (driver-run numbers for the other query geometries; `value` stays configs[1])
             out["other_configs"] = {c: _guarded(other_config_leg, c, dev_idx, dev, L, args) for c in ("dual", "rbk96x")}
+        if world == 1 and not args.no_other_configs:
+            # the same steps with the batch halved between TWO contexts of this GPU (two host threads, a stream pair each, as the product host's --streams 2):
+            # one half's scan runs into the other half's barcode stage and the launches' tails fill each other; outside `value`, whose step is one context's
+            out["two_contexts"] = _guarded(two_contexts_leg, args, groups, dev_idx, d_bases, batch, n_batches, L, dev, rows_per_launch)
         if world == 1 and args.config == "nbd96" and not args.no_stress:
             # the same pipeline where the filtered scan's assumption (unrelated text rarely comes within k edits of a flank window)
             # is strained; outside `value`
@@ -262,6 +266,50 @@ def _pci_bus_id(dev_idx):
         return f"{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}" if hasattr(p, "pci_bus_id") else str(dev_idx)
     except Exception:  # noqa: BLE001
         return str(dev_idx)
+
+
+def two_contexts_leg(args, groups, dev_idx, d_bases, batch, n_batches, L, dev, rows_per_launch, parts=2):
+    """The timed loop of `value` again, every step's batch split between `parts` contexts that run side by side (a host thread each: the C ABI's calls
+    block, as the reference's worker threads do — one Demuxer each, annotator.rs:88-101).  Nothing else differs: same resident reads, same steps."""
+    import threading
+
+    from barbell_amd import annotate as A
+
+    n = batch // parts
+    dms = []
+    for _ in range(parts):
+        dm = A.Demuxer(device=dev_idx)
+        for g in groups:
+            dm.add_query_group(g)
+        dms.append(dm)
+    d_off = torch.arange(0, n + 1, dtype=torch.int64, device=dev) * L
+    cap = 4 * n if args.config == "nbd96" else 6 * n
+    rows = [torch.empty(cap * 48, dtype=torch.uint8, device=dev) for _ in range(parts)]
+    got = [0] * parts
+
+    def work(i, first, k):
+        for s in range(first, first + k):
+            b = s % n_batches
+            got[i] = dms[i].demux_dev(d_bases.data_ptr() + (b * batch + i * n) * L, d_off.data_ptr(), n, rows[i].data_ptr(), cap)
+
+    def run(first, k):
+        th = [threading.Thread(target=work, args=(i, first, k)) for i in range(parts)]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
+    run(0, max(1, args.warmup))
+    dt = run(0, args.steps)
+    out = {"contexts": parts, "reads_per_s": args.steps * n * parts / dt, "ms_per_step": dt / args.steps * 1e3, "steps": args.steps, "batch_reads": n * parts,
+           "rows_last_step": int(sum(got)), "note": "each step's batch halved between two contexts on one GPU, a host thread each; `value` is one context's"}
+    for dm in dms:
+        dm.close()
+    return out
 
 
 def other_config_leg(cfg, dev_idx, dev, L, args, n=2_000_000, steps=3):   # (n = BASELINE's step size since round 6: 1 M-read steps ran the same kernels 10-15 % below it)
